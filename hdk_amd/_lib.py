@@ -1,0 +1,103 @@
+"""Loader for the product library hdk_amd/libhdk_hip.so (C ABI of include/hdk_hip.h).
+
+The library is the ONLY compute path: there is no CPU or PyTorch fallback.  If it is missing (or
+a GPU call fails) the caller gets a loud error, never a silent eager path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhdk_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class HdkHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hdk_hip status {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/hdk_hip.h declares
+v, i32, u32, i64, sz, i8 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_size_t, C.c_int8
+SIGNATURES = {
+    "hdk_hip_last_error": (C.c_char_p, []),
+    "hdk_hip_version": (i32, []),
+    "hdk_hip_mgr_get_device_count": (i32, [C.POINTER(i32)]),
+    "hdk_hip_mgr_set_context": (i32, [i32]),
+    "hdk_hip_mgr_allocate_device_mem": (i32, [sz, i32, C.POINTER(v)]),
+    "hdk_hip_mgr_free_device_mem": (i32, [v]),
+    "hdk_hip_mgr_allocate_pinned_host_mem": (i32, [sz, C.POINTER(v)]),
+    "hdk_hip_mgr_free_pinned_host_mem": (i32, [v]),
+    "hdk_hip_mgr_copy_host_to_device": (i32, [v, v, sz, i32]),
+    "hdk_hip_mgr_copy_host_to_device_async": (i32, [v, v, sz, i32]),
+    "hdk_hip_mgr_synchronize_stream": (i32, [i32]),
+    "hdk_hip_mgr_copy_device_to_host": (i32, [v, v, sz, i32]),
+    "hdk_hip_mgr_copy_device_to_device": (i32, [v, v, sz, i32, i32]),
+    "hdk_hip_mgr_zero_device_mem": (i32, [v, sz, i32]),
+    "hdk_hip_mgr_set_device_mem": (i32, [v, C.c_ubyte, sz, i32]),
+    "hdk_hip_mgr_synchronize_devices": (i32, []),
+    "hdk_hip_mgr_get_stream": (i32, [i32, C.POINTER(v)]),
+    "hdk_hip_mgr_get_device_properties": (i32, [i32, C.POINTER(A.DeviceProperties)]),
+    "hdk_hip_init_group_by_buffer": (i32, [v, v, u32, u32, u32, u32, i32, i8, sz, sz, i32, v]),
+    "hdk_hip_init_columnar_group_by_buffer": (i32, [v, v, u32, u32, u32, v, i32, i32, i8, sz, sz, i32, v]),
+    "hdk_hip_workspace_size": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.POINTER(sz)]),
+    "hdk_hip_launch": (i32, [C.POINTER(A.Plan), C.POINTER(v), C.POINTER(A.KernelOptions), i32, v, v, sz]),
+    "hdk_hip_describe_launch": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.c_char_p, sz]),
+    "hdk_hip_reduce_buffers": (i32, [C.POINTER(A.Plan), v, u32, C.POINTER(v), C.POINTER(u32), i32, v, v,
+                                     i32, v]),
+    "hdk_hip_init_hash_join_buff": (i32, [v, i64, i32, i32, v]),
+    "hdk_hip_fill_hash_join_buff": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i32, v]),
+    "hdk_hip_fill_hash_join_buff_bucketized": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo,
+                                                     i64, i32, v]),
+    "hdk_hip_fill_one_to_many_hash_table": (i32, [v, A.HashEntryInfo, i32, A.JoinColumn,
+                                                  A.JoinColumnTypeInfo, i32, v]),
+    "hdk_hip_fill_one_to_many_hash_table_bucketized": (i32, [v, A.HashEntryInfo, i32, A.JoinColumn,
+                                                             A.JoinColumnTypeInfo, i32, v]),
+}
+# introspection helpers (not part of the drop-in surface)
+EXTRA_SIGNATURES = {
+    "hdk_hip_sizeof_plan": (sz, []),
+    "hdk_hip_sizeof_expr": (sz, []),
+    "hdk_hip_sizeof_target": (sz, []),
+    "hdk_hip_sizeof_qual": (sz, []),
+    "hdk_hip_sizeof_join": (sz, []),
+    "hdk_hip_sizeof_device_properties": (sz, []),
+}
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HdkHipError(A.ERR_RUNTIME,
+                          f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C hdk_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in {**SIGNATURES, **EXTRA_SIGNATURES}.items():
+        f = getattr(L, name)  # AttributeError here == the library does not export its header
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != A.OK:
+        msg = lib().hdk_hip_last_error()
+        raise HdkHipError(status, msg.decode() if msg else "")
+    return status

@@ -1,0 +1,429 @@
+// device_common.h -- per-row primitives shared by the gfx950 kernels.
+//
+// Device restatement of the reference's per-row runtime (the functions HDK's JIT inlines into its
+// row function): decoders (QE/DecodersImpl.h:30-150), nullable arithmetic / comparisons
+// (QE/RuntimeFunctions.cpp:49-230), scalar helpers (:240-280, omniscidb/Utils/ExtractFromTime.cpp),
+// join probes (QE/GroupByRuntime.cpp:274-366) and MurmurHash3 (QE/MurmurHash3Inl.h:11-76).
+// The plan lives in device memory and is wave-uniform: every branch on it is a scalar branch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hdk_hip.h"
+
+#define HDK_DEV __device__ __forceinline__
+
+namespace hdk {
+
+constexpr int kWave = 64;
+
+HDK_DEV double bits_to_double(int64_t b) { return __longlong_as_double(b); }
+HDK_DEV int64_t double_to_bits(double d) { return __double_as_longlong(d); }
+
+// ---------------------------------------------------------------------------------------------
+// kernel parameters: the reference's 12 device pointers (QE/QueryExecutionContext.h:111-125)
+// ---------------------------------------------------------------------------------------------
+struct KernParams {
+  const int8_t* const* const* col_buffers;  // COL_BUFFERS
+  const uint64_t* num_fragments;            // NUM_FRAGMENTS
+  const int8_t* literals;                   // LITERALS (unused)
+  const int64_t* num_rows;                  // NUM_ROWS
+  const uint64_t* frag_row_offsets;         // FRAG_ROW_OFFSETS
+  const int32_t* max_matched;               // MAX_MATCHED
+  int32_t* total_matched;                   // TOTAL_MATCHED
+  const int64_t* init_agg_vals;             // INIT_AGG_VALS
+  int64_t** groupby_buf;                    // GROUPBY_BUF
+  int32_t* error_code;                      // ERROR_CODE
+  const uint32_t* num_tables;               // NUM_TABLES
+  const int64_t* join_hash_tables;          // JOIN_HASH_TABLES
+};
+
+// record_error_code (QE/RuntimeFunctions.cpp:1123-1135): positive codes are sticky.
+HDK_DEV void record_error(int32_t* error_code, int32_t err) {
+  if (err > 0) {
+    atomicMax(error_code, err);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoders
+// ---------------------------------------------------------------------------------------------
+HDK_DEV int64_t decode_col(const int8_t* __restrict__ buf, int32_t width, int32_t kind, int64_t row) {
+  switch (kind) {
+    case HDK_COL_DOUBLE:
+      return reinterpret_cast<const int64_t*>(buf)[row];
+    case HDK_COL_FLOAT:
+      return double_to_bits(static_cast<double>(reinterpret_cast<const float*>(buf)[row]));
+    case HDK_COL_UNSIGNED:
+      switch (width) {
+        case 1:
+          return reinterpret_cast<const uint8_t*>(buf)[row];
+        case 2:
+          return reinterpret_cast<const uint16_t*>(buf)[row];
+        case 4:
+          return reinterpret_cast<const uint32_t*>(buf)[row];
+        default:
+          return reinterpret_cast<const int64_t*>(buf)[row];
+      }
+    default:
+      switch (width) {
+        case 1:
+          return reinterpret_cast<const int8_t*>(buf)[row];
+        case 2:
+          return reinterpret_cast<const int16_t*>(buf)[row];
+        case 4:
+          return reinterpret_cast<const int32_t*>(buf)[row];
+        default:
+          return reinterpret_cast<const int64_t*>(buf)[row];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------------
+HDK_DEV int64_t floor_div_lhs(int64_t dividend, int64_t divisor) {
+  return (dividend < 0 ? dividend - (divisor - 1) : dividend) / divisor;
+}
+
+HDK_DEV int64_t scale_decimal_down(int64_t operand, int64_t scale) {
+  int64_t tmp = scale >> 1;
+  tmp = operand >= 0 ? operand + tmp : operand - tmp;
+  return tmp / scale;
+}
+
+HDK_DEV int64_t extract_year(int64_t timeval) {
+  constexpr uint32_t kEpochOffsetYear1900 = 2208988800u;
+  constexpr uint32_t kSecsJanToMar1900 = 5097600u;
+  constexpr uint32_t kSecondsPer4YearCycle = 126230400u;
+  constexpr uint32_t kUSecsPerDay = 86400u;
+  constexpr uint32_t kSecondsPerNonLeapYear = 31536000u;
+  if (timeval >= 0LL && timeval <= static_cast<int64_t>(UINT32_MAX - kEpochOffsetYear1900)) {
+    const uint32_t seconds_1900 = static_cast<uint32_t>(timeval) + kEpochOffsetYear1900;
+    const uint32_t leap_years = (seconds_1900 - kSecsJanToMar1900) / kSecondsPer4YearCycle;
+    const uint32_t year = (seconds_1900 - leap_years * kUSecsPerDay) / kSecondsPerNonLeapYear + 1900;
+    return static_cast<int32_t>(year);
+  }
+  constexpr int64_t kSecsPerDay = 86400;
+  constexpr int64_t kEpochAdjustedDays = 11017;
+  constexpr int64_t kDaysPer400Years = 146097;
+  constexpr unsigned MARJAN = 31 + 30 + 31 + 30 + 31 + 31 + 30 + 31 + 30 + 31;
+  const int64_t day = floor_div_lhs(timeval, kSecsPerDay);
+  const int64_t era = floor_div_lhs(day - kEpochAdjustedDays, kDaysPer400Years);
+  const unsigned doe = static_cast<unsigned>(day - kEpochAdjustedDays - era * kDaysPer400Years);
+  const unsigned yoe = (doe - doe / 1460 + doe / 36524 - (doe == 146096)) / 365;
+  const unsigned doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  return 2000 + era * 400 + yoe + (MARJAN <= doy);
+}
+
+HDK_DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+// MurmurHash3_x86_32 over `nwords` 32-bit words (key bytes are always a multiple of 4 here).
+HDK_DEV uint32_t murmur_hash3_words(const uint32_t* k, int nwords, uint32_t seed) {
+  uint32_t h1 = seed;
+  const uint32_t c1 = 0xcc9e2d51;
+  const uint32_t c2 = 0x1b873593;
+  for (int i = 0; i < nwords; ++i) {
+    uint32_t k1 = k[i];
+    k1 *= c1;
+    k1 = rotl32(k1, 15);
+    k1 *= c2;
+    h1 ^= k1;
+    h1 = rotl32(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64;
+  }
+  h1 ^= static_cast<uint32_t>(nwords * 4);
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6b;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan interpretation
+// ---------------------------------------------------------------------------------------------
+struct RowCtx {
+  const hdk_hip_plan* plan;        // device copy, uniform
+  const int8_t* const* cols;       // col_buffers[frag], uniform
+  int64_t pos;                     // outer row of this lane
+  int64_t join_row[HDK_HIP_MAX_JOINS];
+};
+
+HDK_DEV bool col_is_fp(const hdk_hip_plan* p, int32_t col) {
+  const int32_t k = p->cols[col].kind;
+  return k == HDK_COL_FLOAT || k == HDK_COL_DOUBLE;
+}
+
+HDK_DEV int64_t load_leaf(const RowCtx& c, const hdk_hip_leaf& l) {
+  if (l.kind == HDK_LEAF_COL) {
+    const hdk_hip_col& col = c.plan->cols[l.col];
+    int64_t row = c.pos;
+    if (col.table == 1) {
+      row = c.join_row[0];
+    } else if (col.table == 2) {
+      row = c.join_row[1];
+    }
+    return decode_col(c.cols[col.buf_idx], col.width, col.kind, row);
+  }
+  return l.ival;
+}
+
+HDK_DEV bool leaf_is_fp(const hdk_hip_plan* p, const hdk_hip_leaf& l) {
+  return l.kind == HDK_LEAF_FP || (l.kind == HDK_LEAF_COL && col_is_fp(p, l.col));
+}
+
+HDK_DEV bool is_null_val(int64_t v, int64_t null_val, int32_t nullable, bool fp) {
+  if (!nullable) {
+    return false;
+  }
+  return fp ? (bits_to_double(v) == bits_to_double(null_val)) : (v == null_val);
+}
+
+// expression chain; err receives ERR_DIV_BY_ZERO like the reference's division guard.
+HDK_DEV int64_t eval_expr(const RowCtx& c, const hdk_hip_expr& e, int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  int64_t acc = load_leaf(c, e.leaf0);
+  bool acc_fp = leaf_is_fp(p, e.leaf0);
+  int64_t acc_null = e.leaf0.null_val;
+  int32_t acc_nullable = e.leaf0.nullable;
+  const int nsteps = e.nsteps;
+  for (int s = 0; s < nsteps; ++s) {
+    const hdk_hip_step& st = e.steps[s];
+    const bool lhs_null = is_null_val(acc, acc_null, acc_nullable, acc_fp);
+    int64_t r = 0;
+    bool r_null = false;
+    const int op = st.op;
+    if (op <= HDK_OP_MOD) {
+      const int64_t rhs = load_leaf(c, st.rhs);
+      const bool rhs_fp = leaf_is_fp(p, st.rhs);
+      const bool rhs_null = is_null_val(rhs, st.rhs.null_val, st.rhs.nullable, rhs_fp);
+      if (lhs_null || rhs_null) {
+        r_null = true;
+      } else if (st.out_class == HDK_VC_FP) {
+        const double a = acc_fp ? bits_to_double(acc) : static_cast<double>(acc);
+        const double b = rhs_fp ? bits_to_double(rhs) : static_cast<double>(rhs);
+        double d = 0;
+        switch (op) {
+          case HDK_OP_ADD: d = a + b; break;
+          case HDK_OP_SUB: d = a - b; break;
+          case HDK_OP_MUL: d = a * b; break;
+          case HDK_OP_DIV:
+            if (b == 0.0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; } else { d = a / b; }
+            break;
+          default: r_null = true; break;
+        }
+        r = double_to_bits(d);
+      } else {
+        const int64_t a = acc, b = rhs;
+        switch (op) {
+          case HDK_OP_ADD: r = static_cast<int64_t>(static_cast<uint64_t>(a) + static_cast<uint64_t>(b)); break;
+          case HDK_OP_SUB: r = static_cast<int64_t>(static_cast<uint64_t>(a) - static_cast<uint64_t>(b)); break;
+          case HDK_OP_MUL: r = static_cast<int64_t>(static_cast<uint64_t>(a) * static_cast<uint64_t>(b)); break;
+          case HDK_OP_DIV:
+            if (b == 0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; }
+            else if (a == INT64_MIN && b == -1) { r = INT64_MIN; }
+            else { r = a / b; }
+            break;
+          default:  // MOD
+            if (b == 0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; }
+            else if (b == -1) { r = 0; }
+            else { r = a % b; }
+            break;
+        }
+      }
+    } else {
+      if (lhs_null) {
+        r_null = true;
+      } else {
+        switch (op) {
+          case HDK_OP_EXTRACT_YEAR: r = extract_year(acc); break;
+          case HDK_OP_SCALE_DOWN: r = scale_decimal_down(acc, st.rhs.ival); break;
+          case HDK_OP_FLOOR_DIV: r = floor_div_lhs(acc, st.rhs.ival); break;
+          case HDK_OP_CAST_INT_TO_FP: r = double_to_bits(static_cast<double>(acc)); break;
+          case HDK_OP_CAST_FP_TO_INT: {
+            const double d = bits_to_double(acc);
+            r = static_cast<int64_t>(d + (d < 0.0 ? -0.5 : 0.5));
+            break;
+          }
+          default: r_null = true; break;
+        }
+      }
+    }
+    acc = r_null ? st.null_out : r;
+    acc_fp = st.out_class == HDK_VC_FP;
+    acc_null = st.null_out;
+    acc_nullable = 1;
+  }
+  return acc;
+}
+
+// one filter conjunct: true iff the three-valued comparison is TRUE
+HDK_DEV bool eval_qual(const RowCtx& c, const hdk_hip_qual& q, int32_t& err) {
+  const int64_t lhs = eval_expr(c, q.lhs, err);
+  const int64_t rhs = load_leaf(c, q.rhs);
+  const bool lhs_fp = q.lhs.vclass == HDK_VC_FP;
+  const bool rhs_fp = leaf_is_fp(c.plan, q.rhs);
+  if (is_null_val(lhs, q.lhs.null_val, q.lhs.nullable, lhs_fp) ||
+      is_null_val(rhs, q.rhs.null_val, q.rhs.nullable, rhs_fp)) {
+    return false;
+  }
+  if (lhs_fp || rhs_fp) {
+    const double a = lhs_fp ? bits_to_double(lhs) : static_cast<double>(lhs);
+    const double b = rhs_fp ? bits_to_double(rhs) : static_cast<double>(rhs);
+    switch (q.cmp) {
+      case HDK_CMP_EQ: return a == b;
+      case HDK_CMP_NE: return a != b;
+      case HDK_CMP_LT: return a < b;
+      case HDK_CMP_GT: return a > b;
+      case HDK_CMP_LE: return a <= b;
+      default: return a >= b;
+    }
+  }
+  switch (q.cmp) {
+    case HDK_CMP_EQ: return lhs == rhs;
+    case HDK_CMP_NE: return lhs != rhs;
+    case HDK_CMP_LT: return lhs < rhs;
+    case HDK_CMP_GT: return lhs > rhs;
+    case HDK_CMP_LE: return lhs <= rhs;
+    default: return lhs >= rhs;
+  }
+}
+
+// join probe: hash_join_idx[_nullable/_bitwise] and the bucketized forms
+HDK_DEV int64_t probe_join(const hdk_hip_join& jn, const int32_t* __restrict__ table, int64_t key) {
+  int64_t k = key;
+  int64_t maxk = jn.max_key;
+  if (jn.null_mode != HDK_JOIN_NULL_NONE && key == jn.null_val) {
+    if (jn.null_mode == HDK_JOIN_NULL_NULLABLE) {
+      return -1;
+    }
+    k = jn.translated_null;
+    maxk = jn.translated_null;
+  }
+  if (k >= jn.min_key && k <= maxk) {
+    int64_t off = k - jn.min_key;
+    if (jn.bucket > 1) {
+      off /= jn.bucket;
+    }
+    return table[off];
+  }
+  return -1;
+}
+
+// filter + join probes; returns false when the row is dropped
+HDK_DEV bool row_passes(RowCtx& c, const int64_t* join_hash_tables, int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  const int nq = p->num_quals;
+  for (int q = 0; q < nq; ++q) {
+    if (!eval_qual(c, p->quals[q], err)) {
+      return false;
+    }
+  }
+  const int nj = p->num_joins;
+  for (int j = 0; j < nj; ++j) {
+    const hdk_hip_join& jn = p->joins[j];
+    const int64_t key = eval_expr(c, jn.outer_key, err);
+    const int32_t* table = (nj == 1 && jn.table_idx == 0)
+                               ? reinterpret_cast<const int32_t*>(join_hash_tables)
+                               : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
+    const int64_t idx = probe_join(jn, table, key);
+    if (idx < 0 && jn.type == HDK_JOIN_INNER) {
+      return false;
+    }
+    if (j == 0) {
+      c.join_row[0] = idx;
+    } else {
+      c.join_row[1] = idx;
+    }
+  }
+  return true;
+}
+
+// group key #k with the perfect-hash NULL translation (translate_null_key_*)
+HDK_DEV int64_t eval_key(const RowCtx& c, int k, int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  int64_t kv = eval_expr(c, p->keys[k], err);
+  if (p->query_kind == HDK_Q_PERFECT_HASH && p->key_has_nulls[k] && p->keys[k].nullable &&
+      kv == p->keys[k].null_val) {
+    kv = p->key_null_translated[k];
+  }
+  return kv;
+}
+
+// perfect-hash entry index: single column (get_group_value_fast) or perfect_key_hash
+// (QE/RowFuncBuilder.cpp:748-801).
+HDK_DEV int64_t perfect_hash_entry(const RowCtx& c, int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  const int nk = p->key_count;
+  int64_t h = 0;
+  int64_t stride = 1;
+  for (int k = 0; k < nk; ++k) {
+    const int64_t kv = eval_key(c, k, err);
+    int64_t term = kv - p->key_min[k];
+    if (p->key_bucket[k]) {
+      term /= p->key_bucket[k];
+    }
+    h += term * stride;
+    stride *= p->key_card[k];
+  }
+  return h;
+}
+
+// target argument with the arg-type NULL rewritten to the slot-type NULL (convertNullIfAny) and
+// int->fp promotion (Executor::castToFP).  *is_null tells whether the value is the skip value.
+HDK_DEV int64_t eval_target_arg(const RowCtx& c, const hdk_hip_target& tg, bool& is_null, int32_t& err) {
+  is_null = false;
+  if (!tg.has_arg) {
+    return 0;
+  }
+  int64_t v = eval_expr(c, tg.arg, err);
+  if (tg.agg == HDK_AGG_ID) {
+    return v;
+  }
+  const bool arg_fp = tg.arg.vclass == HDK_VC_FP;
+  if (tg.skip_null && is_null_val(v, tg.arg.null_val, tg.arg.nullable, arg_fp)) {
+    is_null = true;
+    return tg.null_val;
+  }
+  if (tg.arg_is_fp && !arg_fp) {
+    v = double_to_bits(static_cast<double>(v));
+  }
+  if (tg.skip_null) {
+    // a computed value that collides with the skip value is skipped, exactly as `val != skip_val`
+    is_null = tg.arg_is_fp ? (bits_to_double(v) == bits_to_double(tg.null_val)) : (v == tg.null_val);
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// columnar layout helpers (RS/QueryMemoryDescriptor.cpp getColOffInBytes)
+// ---------------------------------------------------------------------------------------------
+HDK_DEV size_t align8(size_t x) { return (x + 7) & ~static_cast<size_t>(7); }
+
+HDK_DEV size_t columnar_slot_off(const hdk_hip_plan* p, uint32_t entry_count, int slot) {
+  size_t off = p->keyless ? 0 : static_cast<size_t>(p->key_count) * align8(static_cast<size_t>(entry_count) * 8);
+  int s = 0;
+  const int nt = p->num_targets;
+  for (int t = 0; t < nt; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    off = align8(off);
+    if (s == slot) {
+      return off;
+    }
+    off += static_cast<size_t>(entry_count) * tg.slot_width;
+    ++s;
+    if (tg.agg == HDK_AGG_AVG) {
+      off = align8(off);
+      if (s == slot) {
+        return off;
+      }
+      off += static_cast<size_t>(entry_count) * tg.slot2_width;
+      ++s;
+    }
+  }
+  return off;
+}
+
+}  // namespace hdk

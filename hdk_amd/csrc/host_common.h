@@ -1,0 +1,35 @@
+// host_common.h -- host-side plumbing shared by the API translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/hdk_hip.h"
+
+namespace hdk {
+
+// thread-local message for hdk_hip_last_error(); no exception ever crosses the ABI
+void set_error(const char* fmt, ...);
+void clear_error();
+// per-device state (lazy): sets the device and returns the stream to use (`stream` or the manager's)
+int32_t device_enter(int32_t device_id, void* stream, hipStream_t* out);
+const hdk_hip_device_properties* device_props(int32_t device_id);
+
+#define HDK_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      hdk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? HDK_HIP_ERR_OUT_OF_GPU_MEM : HDK_HIP_ERR_RUNTIME;   \
+    }                                                                                        \
+  } while (0)
+
+#define HDK_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      hdk::set_error(__VA_ARGS__);      \
+      return HDK_HIP_ERR_INVALID_ARG;   \
+    }                                   \
+  } while (0)
+
+}  // namespace hdk

@@ -1,0 +1,384 @@
+// join_build.hip -- perfect-hash join table build on the device.
+//
+// New kernels for the contract of the reference's *_on_device build functions
+// (QE/JoinHashTable/Runtime/HashJoinRuntime.h:66-68,158-200; CUDA bodies
+// QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:32-190 wrapping HashJoinRuntime.cpp:127-293,
+// 589-853):
+//   one-to-one : buff[(key-min)/bucket] = CAS(invalid -> row index); a taken slot reports -1 so the
+//                caller falls back to one-to-many (Builders/PerfectHashTableBuilder.h:134-141)
+//   one-to-many: [pos | count | row ids]: histogram -> inclusive scan -> scatter
+// The reference walks the column with a per-thread strided iterator over JoinChunks
+// (JoinColumnIterator.h:30-100); here each chunk is swept by the whole grid with coalesced loads,
+// and the scan is a hand-written 3-kernel block scan instead of thrust::inclusive_scan.
+#include "device_common.h"
+#include "host_common.h"
+
+namespace hdk {
+
+constexpr int kJoinBlock = 256;
+
+__global__ __launch_bounds__(kJoinBlock) void k_fill_i32(int32_t* __restrict__ buff, int64_t n, int32_t val) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kJoinBlock;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kJoinBlock + threadIdx.x;
+  // 16-B stores over the aligned body, scalar stores for head/tail
+  const int64_t head = min<int64_t>(n, ((16 - (reinterpret_cast<uintptr_t>(buff) & 15)) & 15) / 4);
+  if (i < head) {
+    buff[i] = val;
+  }
+  int4* body = reinterpret_cast<int4*>(buff + head);
+  const int64_t nvec = (n - head) / 4;
+  const int4 v4 = make_int4(val, val, val, val);
+  for (int64_t j = i; j < nvec; j += stride) {
+    body[j] = v4;
+  }
+  const int64_t tail0 = head + nvec * 4;
+  if (tail0 + i < n && i < 4) {
+    buff[tail0 + i] = val;
+  }
+}
+
+// JoinColumnIterator::getElementSwitch (JoinColumnIterator.h:36-62)
+HDK_DEV int64_t join_elem(const int8_t* __restrict__ chunk, size_t i, int elem_sz, int column_type) {
+  switch (column_type) {
+    case HDK_JC_SMALL_DATE: {
+      const int64_t v = decode_col(chunk, elem_sz, HDK_COL_INT, static_cast<int64_t>(i));
+      const int64_t nullv = elem_sz == 4 ? static_cast<int64_t>(HDK_NULL_INT) : static_cast<int64_t>(HDK_NULL_SMALLINT);
+      return v == nullv ? nullv : v * 86400;  // fixed_width_small_date_decode
+    }
+    case HDK_JC_UNSIGNED:
+      return decode_col(chunk, elem_sz, HDK_COL_UNSIGNED, static_cast<int64_t>(i));
+    case HDK_JC_DOUBLE:
+      return static_cast<int64_t>(bits_to_double(decode_col(chunk, 8, HDK_COL_DOUBLE, static_cast<int64_t>(i))));
+    default:
+      return decode_col(chunk, elem_sz, HDK_COL_INT, static_cast<int64_t>(i));
+  }
+}
+
+enum BuildMode { BUILD_ONE_TO_ONE = 0, BUILD_COUNT = 1, BUILD_FILL_IDS = 2 };
+
+struct BuildArgs {
+  int32_t* buff;           // one-to-one: the table; count: count_buff; fill: pos_buff (start of table)
+  int64_t hash_entry_count;
+  int32_t invalid_slot_val;
+  int32_t for_semi_join;
+  int32_t* dev_err;
+  const hdk_hip_join_chunk* chunks;
+  size_t num_chunks;
+  hdk_hip_join_column_type_info ti;
+  int64_t bucket;  // <= 1: plain
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kJoinBlock) void k_join_build(BuildArgs a) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinBlock;
+  const size_t start = static_cast<size_t>(blockIdx.x) * kJoinBlock + threadIdx.x;
+  const int elem_sz = static_cast<int>(a.ti.elem_sz);
+  size_t index_base = 0;
+  for (size_t c = 0; c < a.num_chunks; ++c) {
+    const hdk_hip_join_chunk ch = a.chunks[c];
+    for (size_t i = start; i < ch.num_elems; i += stride) {
+      int64_t elem = join_elem(ch.col_buff, i, elem_sz, a.ti.column_type);
+      if (elem == a.ti.null_val) {
+        if (a.ti.uses_bw_eq) {
+          elem = a.ti.translated_null_val;
+        } else {
+          continue;
+        }
+      }
+      int64_t slot = elem - a.ti.min_val;
+      if (a.bucket > 1) {
+        slot /= a.bucket;
+      }
+      if (static_cast<uint64_t>(slot) >= static_cast<uint64_t>(a.hash_entry_count)) {
+        if (a.dev_err) {
+          atomicMin(a.dev_err, -2);  // key outside [min,max]: the metadata the table was sized from is stale
+        }
+        continue;
+      }
+      const int32_t index = static_cast<int32_t>(index_base + i);
+      if (MODE == BUILD_ONE_TO_ONE) {
+        // fill_one_to_one_hashtable / fill_hashtable_for_semi_join (JoinHashImpl.h:55-80)
+        const int32_t old = atomicCAS(a.buff + slot, a.invalid_slot_val, index);
+        if (old != a.invalid_slot_val && !a.for_semi_join) {
+          atomicMin(a.dev_err, -1);
+        }
+      } else if (MODE == BUILD_COUNT) {
+        atomicAdd(a.buff + slot, 1);  // count_matches (HashJoinRuntime.cpp:589-636)
+      } else {
+        // fill_row_ids (HashJoinRuntime.cpp:770-822)
+        int32_t* pos_buff = a.buff;
+        int32_t* count_buff = a.buff + a.hash_entry_count;
+        int32_t* id_buff = count_buff + a.hash_entry_count;
+        const int32_t id_idx = atomicAdd(count_buff + slot, 1) + pos_buff[slot];
+        id_buff[id_idx] = index;
+      }
+    }
+    index_base += ch.num_elems;
+  }
+}
+
+// ---- in-place inclusive scan of int32 (3 kernels) -------------------------------------------
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kJoinBlock * kScanItems;
+
+HDK_DEV int32_t block_exclusive_scan(int32_t v, int32_t* total) {
+  __shared__ int32_t wave_sums[kJoinBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  int32_t incl = v;
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int32_t n = __shfl_up(incl, d, kWave);
+    if (lane >= d) {
+      incl += n;
+    }
+  }
+  if (lane == kWave - 1) {
+    wave_sums[wave] = incl;
+  }
+  __syncthreads();
+  int32_t wave_off = 0;
+  int32_t tot = 0;
+  for (int w = 0; w < kJoinBlock / kWave; ++w) {
+    if (w < wave) {
+      wave_off += wave_sums[w];
+    }
+    tot += wave_sums[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(kJoinBlock) void k_scan_block_sums(const int32_t* __restrict__ data, int64_t n,
+                                                                int32_t* __restrict__ block_sums) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanChunk + static_cast<int64_t>(threadIdx.x) * kScanItems;
+  int32_t s = 0;
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    if (i < n) {
+      s += data[i];
+    }
+  }
+  int32_t total;
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = total;
+  }
+}
+
+__global__ __launch_bounds__(kJoinBlock) void k_scan_sums_inplace(int32_t* __restrict__ sums, int64_t nb) {
+  // single block: exclusive scan of the block sums, chunk by chunk with a running carry
+  int32_t carry = 0;
+  for (int64_t base = 0; base < nb; base += kJoinBlock) {
+    const int64_t i = base + threadIdx.x;
+    const int32_t v = i < nb ? sums[i] : 0;
+    int32_t total;
+    const int32_t ex = block_exclusive_scan(v, &total);
+    if (i < nb) {
+      sums[i] = carry + ex;
+    }
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(kJoinBlock) void k_scan_apply(int32_t* __restrict__ data, int64_t n,
+                                                           const int32_t* __restrict__ block_offs) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanChunk + static_cast<int64_t>(threadIdx.x) * kScanItems;
+  int32_t vals[kScanItems];
+  int32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    vals[k] = i < n ? data[i] : 0;
+    s += vals[k];
+  }
+  int32_t total;
+  int32_t run = block_exclusive_scan(s, &total) + block_offs[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    run += vals[k];
+    if (i < n) {
+      data[i] = run;  // inclusive
+    }
+  }
+}
+
+// set_valid_pos_flag / set_valid_pos (HashJoinRuntimeGpu.cu:110-133) fused: runs before the scan for
+// the flag and after it for the value, so it takes both forms through `after_scan`.
+__global__ __launch_bounds__(kJoinBlock) void k_set_valid_pos(int32_t* __restrict__ pos_buff,
+                                                              const int32_t* __restrict__ count_buff,
+                                                              int64_t entry_count, int after_scan) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kJoinBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJoinBlock + threadIdx.x; i < entry_count; i += stride) {
+    if (!after_scan) {
+      if (count_buff[i]) {
+        pos_buff[i] = 0;  // VALID_POS_FLAG
+      }
+    } else if (pos_buff[i] == 0) {
+      pos_buff[i] = i ? count_buff[i - 1] : 0;
+    }
+  }
+}
+
+static unsigned grid_for(size_t n, int32_t device_id) {
+  const hdk_hip_device_properties* props = device_props(device_id);
+  size_t blocks = (n + kJoinBlock - 1) / kJoinBlock;
+  const size_t cap = static_cast<size_t>(props->num_cu) * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+static int32_t inclusive_scan_inplace(int32_t* data, int64_t n, hipStream_t s) {
+  if (n <= 0) {
+    return HDK_HIP_OK;
+  }
+  const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
+  int32_t* sums = nullptr;
+  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sums), static_cast<size_t>(nb) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(static_cast<unsigned>(nb)), dim3(kJoinBlock), 0, s, data, n, sums);
+  hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(kJoinBlock), 0, s, sums, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<unsigned>(nb)), dim3(kJoinBlock), 0, s, data, n, sums);
+  HDK_HIP_CHECK(hipGetLastError());
+  HDK_HIP_CHECK(hipFreeAsync(sums, s));
+  return HDK_HIP_OK;
+}
+
+static int32_t check_join_args(const hdk_hip_join_column& jc, const hdk_hip_join_column_type_info& ti) {
+  HDK_REQUIRE(jc.num_chunks == 0 || jc.col_chunks_buff, "JoinColumn.col_chunks_buff is NULL");
+  HDK_REQUIRE(ti.elem_sz == 1 || ti.elem_sz == 2 || ti.elem_sz == 4 || ti.elem_sz == 8,
+              "join column element size must be 1/2/4/8");
+  return HDK_HIP_OK;
+}
+
+static int32_t one_to_one(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join, int32_t* dev_err_buff,
+                          const hdk_hip_join_column& jc, const hdk_hip_join_column_type_info& ti,
+                          int64_t bucket, int32_t device_id, void* stream) {
+  HDK_REQUIRE(buff && dev_err_buff, "NULL buffer");
+  int32_t st = check_join_args(jc, ti);
+  if (st) return st;
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  if (jc.num_elems == 0) {
+    return HDK_HIP_OK;
+  }
+  BuildArgs a;
+  a.buff = buff;
+  const int64_t range = ti.max_val - ti.min_val + 1 + (ti.uses_bw_eq ? 1 : 0);
+  a.hash_entry_count = bucket > 1 ? (range + bucket - 1) / bucket + 1 : range;
+  a.invalid_slot_val = invalid_slot_val;
+  a.for_semi_join = for_semi_join;
+  a.dev_err = dev_err_buff;
+  a.chunks = reinterpret_cast<const hdk_hip_join_chunk*>(jc.col_chunks_buff);
+  a.num_chunks = jc.num_chunks;
+  a.ti = ti;
+  a.bucket = bucket;
+  hipLaunchKernelGGL(k_join_build<BUILD_ONE_TO_ONE>, dim3(grid_for(jc.num_elems, device_id)), dim3(kJoinBlock),
+                     0, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+static int32_t one_to_many(int32_t* buff, int64_t hash_entry_count, int32_t invalid_slot_val,
+                           const hdk_hip_join_column& jc, const hdk_hip_join_column_type_info& ti,
+                           int64_t bucket, int32_t device_id, void* stream) {
+  HDK_REQUIRE(buff, "NULL buffer");
+  HDK_REQUIRE(hash_entry_count > 0, "hash_entry_count must be positive");
+  int32_t st = check_join_args(jc, ti);
+  if (st) return st;
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  int32_t* pos_buff = buff;
+  int32_t* count_buff = buff + hash_entry_count;
+  HDK_HIP_CHECK(hipMemsetAsync(count_buff, 0, static_cast<size_t>(hash_entry_count) * sizeof(int32_t), s));
+  BuildArgs a;
+  a.hash_entry_count = hash_entry_count;
+  a.invalid_slot_val = invalid_slot_val;
+  a.for_semi_join = 0;
+  a.dev_err = nullptr;
+  a.chunks = reinterpret_cast<const hdk_hip_join_chunk*>(jc.col_chunks_buff);
+  a.num_chunks = jc.num_chunks;
+  a.ti = ti;
+  a.bucket = bucket;
+  const unsigned g = grid_for(jc.num_elems, device_id);
+  const unsigned ge = grid_for(static_cast<size_t>(hash_entry_count), device_id);
+  if (jc.num_elems) {
+    a.buff = count_buff;
+    hipLaunchKernelGGL(k_join_build<BUILD_COUNT>, dim3(g), dim3(kJoinBlock), 0, s, a);
+  }
+  hipLaunchKernelGGL(k_set_valid_pos, dim3(ge), dim3(kJoinBlock), 0, s, pos_buff, count_buff, hash_entry_count, 0);
+  st = inclusive_scan_inplace(count_buff, hash_entry_count, s);
+  if (st) return st;
+  hipLaunchKernelGGL(k_set_valid_pos, dim3(ge), dim3(kJoinBlock), 0, s, pos_buff, count_buff, hash_entry_count, 1);
+  HDK_HIP_CHECK(hipMemsetAsync(count_buff, 0, static_cast<size_t>(hash_entry_count) * sizeof(int32_t), s));
+  if (jc.num_elems) {
+    a.buff = pos_buff;
+    hipLaunchKernelGGL(k_join_build<BUILD_FILL_IDS>, dim3(g), dim3(kJoinBlock), 0, s, a);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+}  // namespace hdk
+
+using namespace hdk;
+
+extern "C" int32_t hdk_hip_init_hash_join_buff(int32_t* buff, int64_t entry_count, int32_t invalid_slot_val,
+                                               int32_t device_id, void* stream) {
+  HDK_REQUIRE(buff || entry_count == 0, "NULL buffer");
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  if (entry_count <= 0) {
+    return HDK_HIP_OK;
+  }
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(static_cast<size_t>(entry_count) / 4 + 1, device_id)),
+                     dim3(kJoinBlock), 0, s, buff, entry_count, invalid_slot_val);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_fill_hash_join_buff(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join,
+                                               int32_t* dev_err_buff, hdk_hip_join_column join_column,
+                                               hdk_hip_join_column_type_info type_info, int32_t device_id,
+                                               void* stream) {
+  return one_to_one(buff, invalid_slot_val, for_semi_join, dev_err_buff, join_column, type_info, 1, device_id,
+                    stream);
+}
+
+extern "C" int32_t hdk_hip_fill_hash_join_buff_bucketized(int32_t* buff, int32_t invalid_slot_val,
+                                                          int32_t for_semi_join, int32_t* dev_err_buff,
+                                                          hdk_hip_join_column join_column,
+                                                          hdk_hip_join_column_type_info type_info,
+                                                          int64_t bucket_normalization, int32_t device_id,
+                                                          void* stream) {
+  HDK_REQUIRE(bucket_normalization > 0, "bucket_normalization must be positive");
+  return one_to_one(buff, invalid_slot_val, for_semi_join, dev_err_buff, join_column, type_info,
+                    bucket_normalization, device_id, stream);
+}
+
+extern "C" int32_t hdk_hip_fill_one_to_many_hash_table(int32_t* buff, hdk_hip_hash_entry_info hash_entry_info,
+                                                       int32_t invalid_slot_val,
+                                                       hdk_hip_join_column join_column,
+                                                       hdk_hip_join_column_type_info type_info,
+                                                       int32_t device_id, void* stream) {
+  return one_to_many(buff, static_cast<int64_t>(hash_entry_info.hash_entry_count), invalid_slot_val,
+                     join_column, type_info, 1, device_id, stream);
+}
+
+extern "C" int32_t hdk_hip_fill_one_to_many_hash_table_bucketized(int32_t* buff,
+                                                                  hdk_hip_hash_entry_info hash_entry_info,
+                                                                  int32_t invalid_slot_val,
+                                                                  hdk_hip_join_column join_column,
+                                                                  hdk_hip_join_column_type_info type_info,
+                                                                  int32_t device_id, void* stream) {
+  HDK_REQUIRE(hash_entry_info.bucket_normalization > 0, "bucket_normalization must be positive");
+  // HashEntryInfo::getNormalizedHashEntryCount (HashJoinRuntime.h:47-55)
+  const size_t b = static_cast<size_t>(hash_entry_info.bucket_normalization);
+  const size_t n = hash_entry_info.hash_entry_count / b + (hash_entry_info.hash_entry_count % b ? 1 : 0);
+  return one_to_many(buff, static_cast<int64_t>(n), invalid_slot_val, join_column, type_info,
+                     hash_entry_info.bucket_normalization, device_id, stream);
+}

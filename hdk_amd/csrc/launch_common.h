@@ -1,0 +1,26 @@
+// launch_common.h -- launch-shape decisions shared by the scan kernels' translation unit.
+#pragma once
+#include "agg_common.h"
+#include "host_common.h"
+
+namespace hdk {
+
+enum Strategy { STRAT_LDS = 0, STRAT_GLOBAL = 1 };
+
+// LDS budget for the privatised table: 32 KiB per 256-thread block keeps 4-5 blocks (16-20 waves)
+// resident per CU out of the 160 KiB LDS.
+constexpr uint64_t kLdsWordBudget = 4096;
+constexpr size_t kPlanRegionBytes = (sizeof(hdk_hip_plan) + 255) & ~static_cast<size_t>(255);
+
+struct LaunchShape {
+  Strategy strategy;
+  uint32_t grid;
+  uint32_t block;
+  uint32_t rep;
+  uint32_t lds_bytes;
+  uint32_t wpe;
+  uint32_t entry_count;
+  uint64_t slab_words;  // words per block slab (STRAT_LDS)
+};
+
+}  // namespace hdk

@@ -1,0 +1,423 @@
+// reduce.hip -- merge partial result buffers on the device.
+//
+// New kernels for what the reference does on the host with tbb (ResultSetReduction::reduce,
+// QE/ResultSetReduction.cpp:174-330, driven by Executor::reduceMultiDeviceResultSets,
+// QE/Execute.cpp:1224-1336): per-GPU / per-launch partial buffers that already sit in HBM (e.g.
+// after an RCCL all-gather or all-to-all) are folded into `this_buf` without a D->H round trip.
+//   perfect hash / non-grouped: entry-wise, slot-wise reduceOneSlot (:1234-1330) -- one thread per
+//       entry walks the partials in argument order, so the result does not depend on scheduling;
+//   baseline hash: every non-empty entry of each partial is re-inserted (reduceOneEntryBaseline,
+//       :694-731): CAS-claim of the key in `this_buf`, fill_slots for a fresh entry, reduceOneSlot
+//       otherwise.  Partials are merged one launch after another; inside one partial keys are
+//       unique, so an entry of `this_buf` has a single writer per launch.
+#include "device_common.h"
+#include "host_common.h"
+
+namespace hdk {
+
+constexpr int kRedBlock = 256;
+constexpr int kMaxSlots = 2 * HDK_HIP_MAX_TARGETS;
+
+struct SlotInit {
+  int64_t v[kMaxSlots];
+};
+
+// reduceOneSlot with AGGREGATE_ONE_[NULLABLE_]VALUE / AGGREGATE_ONE_COUNT
+// (QE/ResultSetReduction.cpp:1026-1107,1234-1385)
+HDK_DEV void reduce_slot(const hdk_hip_target& tg, int8_t* this1, int8_t* this2, const int8_t* that1,
+                         const int8_t* that2, int64_t init_val) {
+  const int agg = tg.agg;
+  if (agg == HDK_AGG_ID) {
+    if (tg.slot_width == 4) {
+      const int32_t rhs = *reinterpret_cast<const int32_t*>(that1);
+      if (rhs != init_val) *reinterpret_cast<int32_t*>(this1) = rhs;
+    } else {
+      const int64_t rhs = *reinterpret_cast<const int64_t*>(that1);
+      if (rhs != init_val) *reinterpret_cast<int64_t*>(this1) = rhs;
+    }
+    return;
+  }
+  if (agg == HDK_AGG_COUNT || agg == HDK_AGG_AVG) {
+    int8_t* cs = agg == HDK_AGG_COUNT ? this1 : this2;
+    const int8_t* co = agg == HDK_AGG_COUNT ? that1 : that2;
+    const int cw = agg == HDK_AGG_COUNT ? tg.slot_width : tg.slot2_width;
+    if (cw == 4) {
+      *reinterpret_cast<uint32_t*>(cs) += *reinterpret_cast<const uint32_t*>(co);
+    } else {
+      *reinterpret_cast<uint64_t*>(cs) += *reinterpret_cast<const uint64_t*>(co);
+    }
+    if (agg == HDK_AGG_COUNT) {
+      return;
+    }
+  }
+  const bool skip = tg.skip_null;
+  if (tg.slot_width == 4) {  // integer only (float32 slots are rejected by validate_plan)
+    int32_t* s = reinterpret_cast<int32_t*>(this1);
+    const int32_t o = *reinterpret_cast<const int32_t*>(that1);
+    const int32_t nv = static_cast<int32_t>(init_val);
+    if (skip && o == nv) return;
+    const int32_t old = *s;
+    if (skip && old == nv) {
+      *s = o;
+    } else if (agg == HDK_AGG_MIN) {
+      *s = old < o ? old : o;
+    } else if (agg == HDK_AGG_MAX) {
+      *s = old > o ? old : o;
+    } else {
+      *s = static_cast<int32_t>(static_cast<uint32_t>(old) + static_cast<uint32_t>(o));
+    }
+    return;
+  }
+  int64_t* s = reinterpret_cast<int64_t*>(this1);
+  const int64_t o = *reinterpret_cast<const int64_t*>(that1);
+  const int64_t old = *s;
+  if (tg.arg_is_fp) {
+    const double od = bits_to_double(o);
+    if (skip && od == bits_to_double(init_val)) return;  // `val != skip_val` is a value compare
+    if (skip && old == init_val) {                        // the accumulator is compared bit-wise
+      *s = o;
+      return;
+    }
+    const double a = bits_to_double(old);
+    double r;
+    if (agg == HDK_AGG_MIN) {
+      r = (od < a) ? od : a;
+    } else if (agg == HDK_AGG_MAX) {
+      r = (a < od) ? od : a;
+    } else {
+      r = a + od;
+    }
+    *s = double_to_bits(r);
+    return;
+  }
+  if (skip && o == init_val) return;
+  if (skip && old == init_val) {
+    *s = o;
+  } else if (agg == HDK_AGG_MIN) {
+    *s = old < o ? old : o;
+  } else if (agg == HDK_AGG_MAX) {
+    *s = old > o ? old : o;
+  } else {
+    *s = static_cast<int64_t>(static_cast<uint64_t>(old) + static_cast<uint64_t>(o));
+  }
+}
+
+HDK_DEV int64_t read_slot(const int8_t* p, int w) {
+  return w == 4 ? static_cast<int64_t>(*reinterpret_cast<const int32_t*>(p)) : *reinterpret_cast<const int64_t*>(p);
+}
+
+HDK_DEV void slot_ptrs(const hdk_hip_plan* p, int64_t* buf, uint32_t entry_count, uint32_t entry, int t,
+                       int first_slot, int8_t** s1, int8_t** s2) {
+  const hdk_hip_target& tg = p->targets[t];
+  if (p->query_kind == HDK_Q_NON_GROUPED) {
+    *s1 = reinterpret_cast<int8_t*>(buf + first_slot);
+    *s2 = reinterpret_cast<int8_t*>(buf + first_slot + 1);
+  } else if (p->output_columnar) {
+    *s1 = reinterpret_cast<int8_t*>(buf) + columnar_slot_off(p, entry_count, first_slot) +
+          static_cast<size_t>(entry) * tg.slot_width;
+    *s2 = tg.agg == HDK_AGG_AVG ? reinterpret_cast<int8_t*>(buf) + columnar_slot_off(p, entry_count, first_slot + 1) +
+                                      static_cast<size_t>(entry) * tg.slot2_width
+                                : nullptr;
+  } else {
+    int8_t* row = reinterpret_cast<int8_t*>(buf + static_cast<size_t>(entry) * p->row_size_quad);
+    *s1 = row + tg.slot_off;
+    *s2 = row + tg.slot2_off;
+  }
+}
+
+// ResultSetStorage::isEmptyEntry[Columnar] (RS/ResultSetStorage.cpp:439-521)
+HDK_DEV bool is_empty_entry(const hdk_hip_plan* p, const int64_t* buf, uint32_t entry_count, uint32_t e,
+                            const SlotInit& init) {
+  if (p->query_kind == HDK_Q_NON_GROUPED) {
+    return false;
+  }
+  if (p->keyless) {
+    const int ks = p->idx_target_as_key;
+    int s = 0;
+    const int nt = p->num_targets;
+    for (int t = 0; t < nt; ++t) {
+      const hdk_hip_target& tg = p->targets[t];
+      const int n = tg.agg == HDK_AGG_AVG ? 2 : 1;
+      if (ks < s + n) {
+        int8_t *s1, *s2;
+        slot_ptrs(p, const_cast<int64_t*>(buf), entry_count, e, t, s, &s1, &s2);
+        const bool second = ks != s;
+        const int w = second ? tg.slot2_width : tg.slot_width;
+        int64_t iv = init.v[0];
+#pragma unroll
+        for (int k = 1; k < kMaxSlots; ++k) {
+          if (k == ks) iv = init.v[k];
+        }
+        if (w == 4) iv = static_cast<int32_t>(iv);
+        return read_slot(second ? s2 : s1, w) == iv;
+      }
+      s += n;
+    }
+    return true;
+  }
+  if (p->output_columnar) {
+    return buf[e] == HDK_EMPTY_KEY_64;
+  }
+  const int64_t* keys = buf + static_cast<size_t>(e) * p->row_size_quad;
+  return p->key_width == 4 ? *reinterpret_cast<const int32_t*>(keys) == HDK_EMPTY_KEY_32
+                           : *keys == HDK_EMPTY_KEY_64;
+}
+
+HDK_DEV int64_t slot_init(const SlotInit& init, int idx) {
+  int64_t iv = init.v[0];
+#pragma unroll
+  for (int k = 1; k < kMaxSlots; ++k) {
+    if (k == idx) iv = init.v[k];
+  }
+  return iv;
+}
+
+constexpr int kMaxThat = 16;
+struct ThatList {
+  const int64_t* buf[kMaxThat];
+  int32_t n;
+};
+
+// perfect hash / non-grouped: one thread per entry, partials in argument order
+__global__ __launch_bounds__(kRedBlock) void k_reduce_entrywise(const hdk_hip_plan* __restrict__ p, int64_t* this_buf,
+                                                                uint32_t entry_count, ThatList that, SlotInit init) {
+  const uint32_t e = blockIdx.x * kRedBlock + threadIdx.x;
+  if (e >= entry_count) {
+    return;
+  }
+  const int nt = p->num_targets;
+  const int nk = p->key_count;
+  for (int b = 0; b < that.n; ++b) {
+    const int64_t* tb = that.buf[0];
+#pragma unroll
+    for (int k = 1; k < kMaxThat; ++k) {
+      if (k == b) tb = that.buf[k];
+    }
+    if (is_empty_entry(p, tb, entry_count, e, init)) {
+      continue;
+    }
+    if (p->query_kind == HDK_Q_PERFECT_HASH && !p->keyless) {  // copyKeyColWise / rowwise key copy
+      if (p->output_columnar) {
+        for (int k = 0; k < nk; ++k) {
+          this_buf[static_cast<size_t>(k) * entry_count + e] = tb[static_cast<size_t>(k) * entry_count + e];
+        }
+      } else {
+        for (int k = 0; k < nk; ++k) {
+          this_buf[static_cast<size_t>(e) * p->row_size_quad + k] = tb[static_cast<size_t>(e) * p->row_size_quad + k];
+        }
+      }
+    }
+    int s = 0;
+    for (int t = 0; t < nt; ++t) {
+      int8_t *a1, *a2, *b1, *b2;
+      slot_ptrs(p, this_buf, entry_count, e, t, s, &a1, &a2);
+      slot_ptrs(p, const_cast<int64_t*>(tb), entry_count, e, t, s, &b1, &b2);
+      reduce_slot(p->targets[t], a1, a2, b1, b2, slot_init(init, s));
+      s += p->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
+    }
+  }
+}
+
+// ---- baseline re-insert ---------------------------------------------------------------------
+HDK_DEV uint32_t key_hash_dev(const int64_t* key, int key_count, int key_width) {
+  // key_hash = MurmurHash3(key, width*count, 0) (QE/GroupByRuntime.cpp:24-29)
+  return murmur_hash3_words(reinterpret_cast<const uint32_t*>(key), key_count * key_width / 4, 0);
+}
+
+template <typename K>
+HDK_DEV K empty_key();
+template <>
+HDK_DEV int64_t empty_key<int64_t>() { return HDK_EMPTY_KEY_64; }
+template <>
+HDK_DEV int32_t empty_key<int32_t>() { return HDK_EMPTY_KEY_32; }
+
+HDK_DEV int64_t atomic_load_i64(const int64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+HDK_DEV int32_t atomic_load_i32(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Find or claim the entry of `key` (packed components of width K) in a baseline table.
+// Returns the entry index or -1 (table full); *fresh tells whether this call created it.
+// Row-wise (get_matching_group_value, QE/cuda_mapd_rt.cu:167-203): CAS the first component, write
+// the rest, readers spin until the last component is published.  Columnar
+// (get_matching_group_value_columnar_slot, :229-261) likewise per key column.
+template <typename K>
+HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entry_count, const K* key,
+                              bool* fresh) {
+  const int nk = p->key_count;
+  const bool columnar = p->output_columnar;
+  const uint32_t h = key_hash_dev(reinterpret_cast<const int64_t*>(key), nk, sizeof(K)) % entry_count;
+  uint32_t probe = h;
+  const K ek = empty_key<K>();
+  do {
+    K* k0 = columnar ? reinterpret_cast<K*>(buf) + probe
+                     : reinterpret_cast<K*>(buf + static_cast<size_t>(probe) * p->row_size_quad);
+    const size_t kstride = columnar ? entry_count : 1;
+    K old;
+    if constexpr (sizeof(K) == 8) {
+      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(k0), static_cast<unsigned long long>(ek),
+                                     static_cast<unsigned long long>(key[0])));
+    } else {
+      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(k0), static_cast<unsigned int>(ek),
+                                     static_cast<unsigned int>(key[0])));
+    }
+    if (old == ek) {
+      for (int i = 1; i < nk; ++i) {
+        __hip_atomic_store(k0 + i * kstride, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *fresh = true;
+      return probe;
+    }
+    if (old == key[0]) {
+      bool match = true;
+      for (int i = 1; i < nk && match; ++i) {
+        K v;
+        do {  // the winner may still be publishing the remaining components
+          if constexpr (sizeof(K) == 8) {
+            v = atomic_load_i64(reinterpret_cast<const int64_t*>(k0 + i * kstride));
+          } else {
+            v = atomic_load_i32(reinterpret_cast<const int32_t*>(k0 + i * kstride));
+          }
+        } while (v == ek);
+        match = v == key[i];
+      }
+      if (match) {
+        *fresh = false;
+        return probe;
+      }
+    }
+    probe = (probe + 1) % entry_count;
+  } while (probe != h);
+  return -1;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kRedBlock) void k_reduce_baseline(const hdk_hip_plan* __restrict__ p, int64_t* this_buf,
+                                                               uint32_t this_entry_count, const int64_t* that_buf,
+                                                               uint32_t that_entry_count, SlotInit init,
+                                                               int32_t* dev_error) {
+  const uint32_t stride = gridDim.x * kRedBlock;
+  const int nk = p->key_count;
+  const int nt = p->num_targets;
+  for (uint32_t e = blockIdx.x * kRedBlock + threadIdx.x; e < that_entry_count; e += stride) {
+    if (is_empty_entry(p, that_buf, that_entry_count, e, init)) {
+      continue;
+    }
+    K key[HDK_HIP_MAX_KEYS];
+#pragma unroll
+    for (int k = 0; k < HDK_HIP_MAX_KEYS; ++k) {
+      if (k < nk) {
+        key[k] = p->output_columnar
+                     ? reinterpret_cast<const K*>(that_buf)[static_cast<size_t>(k) * that_entry_count + e]
+                     : reinterpret_cast<const K*>(that_buf + static_cast<size_t>(e) * p->row_size_quad)[k];
+      } else {
+        key[k] = 0;
+      }
+    }
+    bool fresh = false;
+    const int64_t dst = find_or_claim<K>(p, this_buf, this_entry_count, key, &fresh);
+    if (dst < 0) {
+      record_error(dev_error, HDK_HIP_ERR_OUT_OF_SLOTS);
+      continue;
+    }
+    int s = 0;
+    for (int t = 0; t < nt; ++t) {
+      const hdk_hip_target& tg = p->targets[t];
+      int8_t *a1, *a2, *b1, *b2;
+      slot_ptrs(p, this_buf, this_entry_count, static_cast<uint32_t>(dst), t, s, &a1, &a2);
+      slot_ptrs(p, const_cast<int64_t*>(that_buf), that_entry_count, e, t, s, &b1, &b2);
+      if (fresh) {  // fill_slots (ResultSetReduction.cpp:560-600): plain copy into the new entry
+        if (tg.slot_width == 4) {
+          *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
+        } else {
+          *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);
+        }
+        if (tg.agg == HDK_AGG_AVG) {
+          if (tg.slot2_width == 4) {
+            *reinterpret_cast<int32_t*>(a2) = *reinterpret_cast<const int32_t*>(b2);
+          } else {
+            *reinterpret_cast<int64_t*>(a2) = *reinterpret_cast<const int64_t*>(b2);
+          }
+        }
+      } else {
+        reduce_slot(tg, a1, a2, b1, b2, slot_init(init, s));
+      }
+      s += tg.agg == HDK_AGG_AVG ? 2 : 1;
+    }
+  }
+}
+
+int32_t validate_plan(const hdk_hip_plan* p);  // scan_agg.hip
+
+}  // namespace hdk
+
+using namespace hdk;
+
+extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* this_buf, uint32_t this_entry_count,
+                                          const int64_t* const* that_bufs, const uint32_t* that_entry_counts,
+                                          int32_t num_that, const int64_t* init_vals, int32_t* dev_error,
+                                          int32_t device_id, void* stream) {
+  int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(this_buf && (num_that == 0 || (that_bufs && that_entry_counts)) && init_vals, "NULL argument");
+  HDK_REQUIRE(num_that >= 0, "num_that must be >= 0");
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  if (num_that == 0) {
+    return HDK_HIP_OK;
+  }
+  int nslots = 0;
+  for (int t = 0; t < plan->num_targets; ++t) {
+    nslots += plan->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
+  }
+  SlotInit init;
+  for (int i = 0; i < kMaxSlots; ++i) {
+    init.v[i] = i < nslots ? init_vals[i] : 0;  // init_vals is a HOST array (ResultSetStorage::target_init_vals_)
+  }
+  // device copy of the plan (stream-ordered scratch)
+  hdk_hip_plan* d_plan = nullptr;
+  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_plan), sizeof(hdk_hip_plan), s));
+  HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  const hdk_hip_device_properties* props = device_props(device_id);
+  if (plan->query_kind != HDK_Q_BASELINE_HASH) {
+    const uint32_t n = plan->query_kind == HDK_Q_NON_GROUPED ? 1u : this_entry_count;
+    for (int i = 0; i < num_that; ++i) {
+      if (plan->query_kind != HDK_Q_NON_GROUPED && that_entry_counts[i] != this_entry_count) {
+        set_error("perfect-hash partials must have the same entry count (%u != %u)", that_entry_counts[i],
+                  this_entry_count);
+        (void)hipFreeAsync(d_plan, s);
+        return HDK_HIP_ERR_INVALID_ARG;
+      }
+    }
+    for (int base = 0; base < num_that; base += kMaxThat) {
+      ThatList tl;
+      tl.n = num_that - base < kMaxThat ? num_that - base : kMaxThat;
+      for (int i = 0; i < kMaxThat; ++i) {
+        tl.buf[i] = i < tl.n ? that_bufs[base + i] : nullptr;
+      }
+      hipLaunchKernelGGL(k_reduce_entrywise, dim3((n + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, d_plan,
+                         this_buf, n, tl, init);
+    }
+  } else {
+    HDK_REQUIRE(dev_error, "dev_error is NULL");
+    for (int i = 0; i < num_that; ++i) {
+      if (that_entry_counts[i] == 0) continue;
+      size_t blocks = (static_cast<size_t>(that_entry_counts[i]) + kRedBlock - 1) / kRedBlock;
+      const size_t cap = static_cast<size_t>(props->num_cu) * 8;
+      if (blocks > cap) blocks = cap;
+      if (plan->key_width == 4) {
+        hipLaunchKernelGGL(k_reduce_baseline<int32_t>, dim3(static_cast<unsigned>(blocks)), dim3(kRedBlock), 0, s,
+                           d_plan, this_buf, this_entry_count, that_bufs[i], that_entry_counts[i], init, dev_error);
+      } else {
+        hipLaunchKernelGGL(k_reduce_baseline<int64_t>, dim3(static_cast<unsigned>(blocks)), dim3(kRedBlock), 0, s,
+                           d_plan, this_buf, this_entry_count, that_bufs[i], that_entry_counts[i], init, dev_error);
+      }
+    }
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  HDK_HIP_CHECK(hipFreeAsync(d_plan, s));
+  return HDK_HIP_OK;
+}

@@ -1,0 +1,253 @@
+// runtime.hip -- HipMgr: the device manager that sits under HDK's BufferProvider.
+//
+// New code for the `GpuMgr` contract (reference omniscidb/DataMgr/GpuMgr.h:29-79); the reference's
+// two implementations are CudaMgr (omniscidb/CudaMgr/CudaMgr.h:83-260, CUDA driver API) and
+// L0Manager.  One HIP-runtime function per virtual, exported through the C ABI so that a
+// `class HipMgr : public GpuMgr` in HDK is a list of one-line forwards.
+#include <mutex>
+#include <string.h>
+
+#include "host_common.h"
+
+namespace hdk {
+
+static thread_local char tl_error[1024] = {0};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tl_error, sizeof(tl_error), fmt, ap);
+  va_end(ap);
+}
+void clear_error() { tl_error[0] = 0; }
+
+constexpr int kMaxDevices = 16;  // Executor::max_gpu_count (reference QE/Execute.h:959-960)
+
+struct DeviceState {
+  std::once_flag once;
+  hipStream_t stream = nullptr;
+  hdk_hip_device_properties props;
+  int32_t status = HDK_HIP_OK;
+};
+static DeviceState g_dev[kMaxDevices];
+
+static void init_device(int32_t d) {
+  DeviceState& s = g_dev[d];
+  hipDeviceProp_t hp;
+  if (hipSetDevice(d) != hipSuccess || hipGetDeviceProperties(&hp, d) != hipSuccess ||
+      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+    s.status = HDK_HIP_ERR_RUNTIME;
+    return;
+  }
+  memset(&s.props, 0, sizeof(s.props));
+  s.props.global_mem = hp.totalGlobalMem;
+  s.props.num_cu = hp.multiProcessorCount;
+  s.props.max_threads_per_block = hp.maxThreadsPerBlock;
+  s.props.wavefront_size = hp.warpSize;
+  // CudaMgr::getGridSize is 2 x #SM (CudaMgr.h:176); the persistent kernels here want 4 blocks of
+  // 256 threads per CU (16 waves/CU) -- measured choice, see DESIGN.md.
+  s.props.grid_size = 4 * hp.multiProcessorCount;
+  s.props.shared_mem_per_block = hp.sharedMemPerBlock;
+  s.props.has_shared_memory_atomics = 1;
+  s.props.can_load_async = 1;
+  s.props.has_fp64 = 1;
+  s.props.clock_khz = hp.clockRate;
+  s.props.memory_clock_khz = hp.memoryClockRate;
+  s.props.memory_bus_width = hp.memoryBusWidth;
+  strncpy(s.props.arch_name, hp.gcnArchName, sizeof(s.props.arch_name) - 1);
+}
+
+static int32_t ensure_device(int32_t d) {
+  if (d < 0 || d >= kMaxDevices) {
+    set_error("device %d out of range", d);
+    return HDK_HIP_ERR_INVALID_ARG;
+  }
+  int n = 0;
+  HDK_HIP_CHECK(hipGetDeviceCount(&n));
+  if (d >= n) {
+    set_error("device %d out of range: %d device(s) visible", d, n);
+    return HDK_HIP_ERR_INVALID_ARG;
+  }
+  std::call_once(g_dev[d].once, init_device, d);
+  if (g_dev[d].status != HDK_HIP_OK) {
+    set_error("failed to initialise device %d", d);
+  }
+  return g_dev[d].status;
+}
+
+int32_t device_enter(int32_t device_id, void* stream, hipStream_t* out) {
+  const int32_t st = ensure_device(device_id);
+  if (st != HDK_HIP_OK) {
+    return st;
+  }
+  HDK_HIP_CHECK(hipSetDevice(device_id));
+  *out = stream ? static_cast<hipStream_t>(stream) : g_dev[device_id].stream;
+  return HDK_HIP_OK;
+}
+
+const hdk_hip_device_properties* device_props(int32_t device_id) {
+  return ensure_device(device_id) == HDK_HIP_OK ? &g_dev[device_id].props : nullptr;
+}
+
+}  // namespace hdk
+
+using namespace hdk;
+
+extern "C" {
+
+const char* hdk_hip_last_error(void) { return tl_error; }
+int32_t hdk_hip_version(void) { return 1000; }
+
+int32_t hdk_hip_mgr_get_device_count(int32_t* count) {
+  HDK_REQUIRE(count, "count is NULL");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;  // like CudaMgr on a CPU-only box: no devices rather than a hard failure
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return HDK_HIP_ERR_RUNTIME;
+  }
+  *count = n;
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_set_context(int32_t device_num) {
+  hipStream_t s;
+  return device_enter(device_num, nullptr, &s);
+}
+
+int32_t hdk_hip_mgr_allocate_device_mem(size_t num_bytes, int32_t device_num, int8_t** device_ptr) {
+  HDK_REQUIRE(device_ptr, "device_ptr is NULL");
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  void* p = nullptr;
+  HDK_HIP_CHECK(hipMalloc(&p, num_bytes ? num_bytes : 1));
+  *device_ptr = static_cast<int8_t*>(p);
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_free_device_mem(int8_t* device_ptr) {
+  if (device_ptr) {
+    HDK_HIP_CHECK(hipFree(device_ptr));
+  }
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_allocate_pinned_host_mem(size_t num_bytes, int8_t** host_ptr) {
+  HDK_REQUIRE(host_ptr, "host_ptr is NULL");
+  void* p = nullptr;
+  HDK_HIP_CHECK(hipHostMalloc(&p, num_bytes ? num_bytes : 1, hipHostMallocDefault));
+  *host_ptr = static_cast<int8_t*>(p);
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_free_pinned_host_mem(int8_t* host_ptr) {
+  if (host_ptr) {
+    HDK_HIP_CHECK(hipHostFree(host_ptr));
+  }
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_copy_host_to_device(int8_t* device_ptr, const int8_t* host_ptr, size_t num_bytes,
+                                        int32_t device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipMemcpy(device_ptr, host_ptr, num_bytes, hipMemcpyHostToDevice));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_copy_host_to_device_async(int8_t* device_ptr, const int8_t* host_ptr,
+                                              size_t num_bytes, int32_t device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipMemcpyAsync(device_ptr, host_ptr, num_bytes, hipMemcpyHostToDevice, s));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_synchronize_stream(int32_t device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipStreamSynchronize(s));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_copy_device_to_host(int8_t* host_ptr, const int8_t* device_ptr, size_t num_bytes,
+                                        int32_t device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  // results of kernels enqueued on the manager's stream must be complete (CudaMgr copies are
+  // synchronous on the context that ran the kernel)
+  HDK_HIP_CHECK(hipStreamSynchronize(s));
+  HDK_HIP_CHECK(hipMemcpy(host_ptr, device_ptr, num_bytes, hipMemcpyDeviceToHost));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_copy_device_to_device(int8_t* dest_ptr, int8_t* src_ptr, size_t num_bytes,
+                                          int32_t dest_device_num, int32_t src_device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(src_device_num, nullptr, &s);
+  if (st) return st;
+  if (dest_device_num == src_device_num) {
+    HDK_HIP_CHECK(hipMemcpy(dest_ptr, src_ptr, num_bytes, hipMemcpyDeviceToDevice));
+  } else {
+    HDK_HIP_CHECK(hipMemcpyPeer(dest_ptr, dest_device_num, src_ptr, src_device_num, num_bytes));
+  }
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_zero_device_mem(int8_t* device_ptr, size_t num_bytes, int32_t device_num) {
+  return hdk_hip_mgr_set_device_mem(device_ptr, 0, num_bytes, device_num);
+}
+
+int32_t hdk_hip_mgr_set_device_mem(int8_t* device_ptr, unsigned char uc, size_t num_bytes,
+                                   int32_t device_num) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipMemset(device_ptr, uc, num_bytes));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_synchronize_devices(void) {
+  int n = 0;
+  HDK_HIP_CHECK(hipGetDeviceCount(&n));
+  for (int d = 0; d < n; ++d) {
+    HDK_HIP_CHECK(hipSetDevice(d));
+    HDK_HIP_CHECK(hipDeviceSynchronize());
+  }
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_get_stream(int32_t device_num, void** stream) {
+  HDK_REQUIRE(stream, "stream is NULL");
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  *stream = s;
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_mgr_get_device_properties(int32_t device_num, hdk_hip_device_properties* out) {
+  HDK_REQUIRE(out, "out is NULL");
+  const hdk_hip_device_properties* p = device_props(device_num);
+  if (!p) {
+    return HDK_HIP_ERR_RUNTIME;
+  }
+  *out = *p;
+  return HDK_HIP_OK;
+}
+
+// sizes of the ABI PODs, for the ctypes mirror's self-check (tests/test_abi.py)
+size_t hdk_hip_sizeof_plan(void) { return sizeof(hdk_hip_plan); }
+size_t hdk_hip_sizeof_expr(void) { return sizeof(hdk_hip_expr); }
+size_t hdk_hip_sizeof_target(void) { return sizeof(hdk_hip_target); }
+size_t hdk_hip_sizeof_qual(void) { return sizeof(hdk_hip_qual); }
+size_t hdk_hip_sizeof_join(void) { return sizeof(hdk_hip_join); }
+size_t hdk_hip_sizeof_device_properties(void) { return sizeof(hdk_hip_device_properties); }
+
+}  // extern "C"

@@ -1,0 +1,585 @@
+// scan_agg.hip -- the hot pass: scan -> filter -> join probe -> group -> aggregate, LDS-privatised.
+//
+// Replaces what HDK JITs per query (multifrag_query_hoisted_literals -> query_group_by_template ->
+// row_func, reference QE/RuntimeFunctions.cpp:1692-1768, QE/QueryTemplateGenerator.cpp:488-785)
+// with fixed kernels for NonGroupedAggregate and GroupByPerfectHash plans whose partial table fits
+// in LDS.  Reference GPU behaviour being replaced: one global atomic per row and target
+// (agg_*_shared, QE/cuda_mapd_rt.cu:424-478,886-957) onto <= entry_count contended addresses.
+//
+// MI355X design:
+//   * persistent grid (blocks = CUs x k), static tile walk over ALL fragments (tile -> fragment by a
+//     scalar walk of NUM_ROWS), so there is no per-fragment tail;
+//   * every lane reads its rows with the widest naturally aligned load the column allows; the
+//     specialised kernels (scan_agg_fast.hip) read 16 B per lane per column;
+//   * aggregation in LDS with ds_add_u64 / ds_add_f64 / ds_min/max_i64 into a table replicated REP
+//     times (lane & (REP-1) picks the replica) so that 64 lanes hitting one key do not serialise;
+//   * one slab store per block, then `k_finalize` folds the slabs into the output buffer with the
+//     reference's exact agg_*[_skip_val] semantics -- no global atomics, deterministic slab order.
+#include "agg_common.h"
+
+namespace hdk {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// LDS atomics on 64-bit words
+// ---------------------------------------------------------------------------------------------
+HDK_DEV void lds_add_u64(int64_t* p, int64_t v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
+}
+HDK_DEV void lds_add_f64(int64_t* p, double v) {
+  atomicAdd(reinterpret_cast<double*>(p), v);  // ds_add_f64 (-munsafe-fp-atomics)
+}
+HDK_DEV void lds_min_i64(int64_t* p, int64_t v) { atomicMin(reinterpret_cast<long long*>(p), static_cast<long long>(v)); }
+HDK_DEV void lds_max_i64(int64_t* p, int64_t v) { atomicMax(reinterpret_cast<long long*>(p), static_cast<long long>(v)); }
+HDK_DEV void lds_min_f64(int64_t* p, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long old = *a;
+  while (v < bits_to_double(static_cast<int64_t>(old))) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(a, assumed, static_cast<unsigned long long>(double_to_bits(v)));
+    if (old == assumed) {
+      break;
+    }
+  }
+}
+HDK_DEV void lds_max_f64(int64_t* p, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long old = *a;
+  while (bits_to_double(static_cast<int64_t>(old)) < v) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(a, assumed, static_cast<unsigned long long>(double_to_bits(v)));
+    if (old == assumed) {
+      break;
+    }
+  }
+}
+
+struct ScanArgs {
+  const hdk_hip_plan* plan;  // device copy (workspace head)
+  KernParams kp;
+  int64_t* slabs;            // [gridDim.x][entry_count * wpe]
+  uint32_t entry_count;      // 1 for non-grouped
+  uint32_t rep;              // power of two, <= 32
+  uint32_t rows_per_tile;    // kBlock * rows per thread
+};
+
+// ---------------------------------------------------------------------------------------------
+// K1 (generic): any plan the library accepts, evaluated by the plan interpreter.
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  __shared__ WordLayout wl;
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    make_word_layout(p, &wl);
+  }
+  __syncthreads();
+  const int wpe = wl.wpe;
+  const uint32_t rep = a.rep;
+  const uint32_t ew = a.entry_count * wpe;
+  const uint32_t total_words = ew * rep;
+  for (uint32_t i = tid; i < total_words; i += kBlock) {
+    lds[i] = word_identity(wl.wop[(i / rep) % wpe]);
+  }
+  __syncthreads();
+
+  const uint32_t my_rep = tid & (rep - 1);
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const int64_t tile_rows = a.rows_per_tile;
+  const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
+  const int nt = p->num_targets;
+
+  RowCtx c;
+  c.plan = p;
+  c.join_row[0] = 0;
+  c.join_row[1] = 0;
+  int32_t err = 0;
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
+    c.cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * tile_rows;
+      const int64_t row_end = min(row0 + tile_rows, nrows);
+      for (int64_t row = row0 + tid; row < row_end; row += kBlock) {
+        c.pos = row;
+        if (!row_passes(c, a.kp.join_hash_tables, err)) {
+          continue;
+        }
+        int64_t entry = 0;
+        if (grouped) {
+          entry = perfect_hash_entry(c, err);
+          if (static_cast<uint64_t>(entry) >= a.entry_count) {
+            err = HDK_HIP_ERR_OUT_OF_SLOTS;  // key outside the range the layout was sized for
+            continue;
+          }
+        }
+        int64_t* base = lds + (static_cast<uint32_t>(entry) * wpe) * rep + my_rep;
+        lds_add_u64(base, 1);
+        for (int t = 0; t < nt; ++t) {
+          const hdk_hip_target& tg = p->targets[t];
+          const int vw = wl.vword[t];
+          const int nw = wl.nword[t];
+          if (vw < 0 && nw < 0) {
+            continue;
+          }
+          bool is_null;
+          const int64_t v = eval_target_arg(c, tg, is_null, err);
+          if (is_null) {
+            continue;
+          }
+          if (nw >= 0) {
+            lds_add_u64(base + nw * rep, 1);
+          }
+          if (vw >= 0) {
+            int64_t* wp = base + vw * rep;
+            switch (wl.wop[vw]) {
+              case WOP_ADD_U64: lds_add_u64(wp, v); break;
+              case WOP_ADD_F64: lds_add_f64(wp, bits_to_double(v)); break;
+              case WOP_MIN_I64: lds_min_i64(wp, v); break;
+              case WOP_MAX_I64: lds_max_i64(wp, v); break;
+              case WOP_MIN_F64: lds_min_f64(wp, bits_to_double(v)); break;
+              default: lds_max_f64(wp, bits_to_double(v)); break;
+            }
+          }
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+  __syncthreads();
+  // flush: fold the REP replicas, one slab per block
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += kBlock) {
+    const int32_t op = wl.wop[i % wpe];
+    int64_t acc = lds[i * rep];
+    for (uint32_t r = 1; r < rep; ++r) {
+      acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    slab[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: fold the per-block slabs into the output buffer.  One wave per entry.
+// ---------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+  const hdk_hip_plan* plan;
+  const int64_t* slabs;
+  int64_t** groupby_buf;  // GROUPBY_BUF
+  uint32_t num_slabs;
+  uint32_t entry_count;
+};
+
+HDK_DEV int64_t shfl_down_i64(int64_t v, int delta) {
+  int lo = static_cast<int>(v & 0xffffffff);
+  int hi = static_cast<int>(v >> 32);
+  lo = __shfl_down(lo, delta, kWave);
+  hi = __shfl_down(hi, delta, kWave);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+HDK_DEV void apply_count(int8_t* slot, int width, int64_t cnt) {
+  if (width == 4) {
+    *reinterpret_cast<int32_t*>(slot) =
+        static_cast<int32_t>(static_cast<uint32_t>(*reinterpret_cast<int32_t*>(slot)) + static_cast<uint32_t>(cnt));
+  } else {
+    *reinterpret_cast<int64_t*>(slot) =
+        static_cast<int64_t>(static_cast<uint64_t>(*reinterpret_cast<int64_t*>(slot)) + static_cast<uint64_t>(cnt));
+  }
+}
+
+// agg_{sum,min,max}[_double][_skip_val] applied once with the block-folded partial
+HDK_DEV void apply_value(const hdk_hip_target& tg, int8_t* slot, int64_t partial, int64_t nn, int64_t rowcount) {
+  const bool skip = tg.skip_null;
+  if ((skip && nn == 0) || rowcount == 0) {
+    return;  // nothing but NULLs (or no rows): the slot keeps its value
+  }
+  const int agg = tg.agg;
+  if (tg.slot_width == 4) {  // int32 slots (only integer arguments reach here)
+    int32_t* s = reinterpret_cast<int32_t*>(slot);
+    const int32_t v = static_cast<int32_t>(partial);
+    const int32_t nullv = static_cast<int32_t>(tg.null_val);
+    const int32_t old = *s;
+    if (skip && old == nullv) {
+      *s = v;
+    } else if (agg == HDK_AGG_MIN) {
+      *s = old < v ? old : v;
+    } else if (agg == HDK_AGG_MAX) {
+      *s = old > v ? old : v;
+    } else {
+      *s = static_cast<int32_t>(static_cast<uint32_t>(old) + static_cast<uint32_t>(v));
+    }
+    return;
+  }
+  int64_t* s = reinterpret_cast<int64_t*>(slot);
+  const int64_t old = *s;
+  if (skip && old == tg.null_val) {  // first non-NULL value replaces the sentinel (bit compare)
+    *s = partial;
+    return;
+  }
+  if (tg.arg_is_fp) {
+    const double o = bits_to_double(old);
+    const double v = bits_to_double(partial);
+    double r;
+    if (agg == HDK_AGG_MIN) {
+      r = (v < o) ? v : o;
+    } else if (agg == HDK_AGG_MAX) {
+      r = (o < v) ? v : o;
+    } else {
+      r = o + v;
+    }
+    *s = double_to_bits(r);
+  } else if (agg == HDK_AGG_MIN) {
+    *s = old < partial ? old : partial;
+  } else if (agg == HDK_AGG_MAX) {
+    *s = old > partial ? old : partial;
+  } else {
+    *s = static_cast<int64_t>(static_cast<uint64_t>(old) + static_cast<uint64_t>(partial));
+  }
+}
+
+extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a) {
+  __shared__ WordLayout wl;
+  __shared__ int64_t s_words[kBlock / kWave][kMaxWordsPerEntry];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  if (threadIdx.x == 0) {
+    make_word_layout(p, &wl);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t entry = blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+  if (entry >= a.entry_count) {
+    return;
+  }
+  const int wpe = wl.wpe;
+  const size_t ew = static_cast<size_t>(a.entry_count) * wpe;
+  // fold slabs: lane l takes slabs l, l+64, ...; then a fixed shuffle tree (deterministic order)
+  int64_t* words = s_words[threadIdx.x / kWave];  // written and read by lane 0 only
+  for (int w = 0; w < wpe; ++w) {
+    const int32_t op = wl.wop[w];
+    int64_t acc = word_identity(op);
+    for (uint32_t b = lane; b < a.num_slabs; b += kWave) {
+      acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      acc = word_combine(op, acc, shfl_down_i64(acc, d));
+    }
+    if (lane == 0) {
+      words[w] = acc;
+    }
+  }
+  if (lane != 0) {
+    return;
+  }
+  const int64_t rowcount = words[0];
+  if (rowcount == 0) {
+    return;
+  }
+  int64_t* buf = a.groupby_buf[0];
+  const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
+  const bool columnar = p->output_columnar;
+  const int nk = p->key_count;
+  // reconstruct the (translated) key components from the entry index
+  int64_t keys[HDK_HIP_MAX_KEYS];
+  if (grouped) {
+    uint64_t rem = entry;
+#pragma unroll
+    for (int k = 0; k < HDK_HIP_MAX_KEYS; ++k) {
+      if (k < nk) {
+        uint64_t comp = rem;
+        if (nk > 1) {
+          comp = rem % static_cast<uint64_t>(p->key_card[k]);
+          rem /= static_cast<uint64_t>(p->key_card[k]);
+        }
+        const int64_t bucket = p->key_bucket[k] ? p->key_bucket[k] : 1;
+        keys[k] = p->key_min[k] + static_cast<int64_t>(comp) * bucket;
+      }
+    }
+    if (!p->keyless) {
+      if (columnar) {
+        // set_matching_group_value_perfect_hash_columnar / get_columnar_group_bin_offset
+        if (buf[entry] == HDK_EMPTY_KEY_64) {
+#pragma unroll
+          for (int k = 0; k < HDK_HIP_MAX_KEYS; ++k) {
+            if (k < nk) {
+              buf[static_cast<size_t>(k) * a.entry_count + entry] = keys[k];
+            }
+          }
+        }
+      } else {
+        int64_t* row = buf + static_cast<size_t>(entry) * p->row_size_quad;
+        if (row[0] == HDK_EMPTY_KEY_64) {  // get_group_value_fast / get_matching_group_value_perfect_hash
+#pragma unroll
+          for (int k = 0; k < HDK_HIP_MAX_KEYS; ++k) {
+            if (k < nk) {
+              row[k] = keys[k];
+            }
+          }
+        }
+      }
+    }
+  }
+  const int nt = p->num_targets;
+  int slot_idx = 0;
+  for (int t = 0; t < nt; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    int8_t* s1;
+    int8_t* s2 = nullptr;
+    if (!grouped) {
+      s1 = reinterpret_cast<int8_t*>(a.groupby_buf[slot_idx]);
+      if (tg.agg == HDK_AGG_AVG) {
+        s2 = reinterpret_cast<int8_t*>(a.groupby_buf[slot_idx + 1]);
+      }
+    } else if (columnar) {
+      s1 = reinterpret_cast<int8_t*>(buf) + columnar_slot_off(p, a.entry_count, slot_idx) +
+           static_cast<size_t>(entry) * tg.slot_width;
+      if (tg.agg == HDK_AGG_AVG) {
+        s2 = reinterpret_cast<int8_t*>(buf) + columnar_slot_off(p, a.entry_count, slot_idx + 1) +
+             static_cast<size_t>(entry) * tg.slot2_width;
+      }
+    } else {
+      int8_t* row = reinterpret_cast<int8_t*>(buf + static_cast<size_t>(entry) * p->row_size_quad);
+      s1 = row + tg.slot_off;
+      s2 = row + tg.slot2_off;
+    }
+    const int vw = wl.vword[t];
+    const int nw = wl.nword[t];
+    const int64_t nn = nw >= 0 ? words[nw] : rowcount;
+    switch (tg.agg) {
+      case HDK_AGG_COUNT:
+        apply_count(s1, tg.slot_width, nn);
+        break;
+      case HDK_AGG_ID: {
+        int64_t kv = keys[0];
+#pragma unroll
+        for (int k = 1; k < HDK_HIP_MAX_KEYS; ++k) {
+          if (k == tg.key_idx) {
+            kv = keys[k];
+          }
+        }
+        const int ki = tg.key_idx;
+        if (p->key_has_nulls[ki] && kv == p->key_null_translated[ki]) {
+          kv = p->keys[ki].null_val;  // the target re-evaluates the key expression: untranslated NULL
+        }
+        if (tg.slot_width == 4) {
+          *reinterpret_cast<int32_t*>(s1) = static_cast<int32_t>(kv);
+        } else {
+          *reinterpret_cast<int64_t*>(s1) = kv;
+        }
+        break;
+      }
+      case HDK_AGG_AVG:
+        apply_count(s2, tg.slot2_width, nn);
+        apply_value(tg, s1, words[vw], nn, rowcount);
+        break;
+      default:
+        apply_value(tg, s1, words[vw], nn, rowcount);
+        break;
+    }
+    slot_idx += tg.agg == HDK_AGG_AVG ? 2 : 1;
+  }
+}
+
+}  // namespace hdk
+
+// =============================================================================================
+// host side: strategy choice + launch
+// =============================================================================================
+#include "host_common.h"
+#include "launch_common.h"
+
+using namespace hdk;
+
+namespace hdk {
+
+int32_t validate_plan(const hdk_hip_plan* p) {
+  HDK_REQUIRE(p, "plan is NULL");
+  HDK_REQUIRE(p->abi_version == HDK_HIP_PLAN_ABI, "plan ABI %u != library ABI %u", p->abi_version,
+              HDK_HIP_PLAN_ABI);
+  HDK_REQUIRE(p->num_cols >= 0 && p->num_cols <= HDK_HIP_MAX_COLS, "bad num_cols");
+  HDK_REQUIRE(p->num_quals >= 0 && p->num_quals <= HDK_HIP_MAX_QUALS, "bad num_quals");
+  HDK_REQUIRE(p->num_joins >= 0 && p->num_joins <= HDK_HIP_MAX_JOINS, "bad num_joins");
+  HDK_REQUIRE(p->key_count >= 0 && p->key_count <= HDK_HIP_MAX_KEYS, "bad key_count");
+  HDK_REQUIRE(p->num_targets > 0 && p->num_targets <= HDK_HIP_MAX_TARGETS, "bad num_targets");
+  HDK_REQUIRE(p->query_kind >= HDK_Q_NON_GROUPED && p->query_kind <= HDK_Q_BASELINE_HASH,
+              "bad query_kind");
+  if (p->query_kind != HDK_Q_NON_GROUPED) {
+    HDK_REQUIRE(p->entry_count > 0, "entry_count must be positive");
+    HDK_REQUIRE(p->key_count > 0, "group-by plan without keys");
+    HDK_REQUIRE(p->output_columnar || p->row_size_quad > 0, "row_size_quad must be positive");
+  }
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "slot width must be 4 or 8");
+    if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
+      set_error("float32 aggregate slots are outside the fixed kernel library");
+      return HDK_HIP_ERR_UNSUPPORTED;
+    }
+  }
+  if (p->query_kind == HDK_Q_PERFECT_HASH) {
+    HDK_REQUIRE(p->key_width == 8, "perfect hash uses 8-byte keys");
+  }
+  if (p->output_columnar) {
+    HDK_REQUIRE(p->key_width == 8, "columnar output uses 8-byte keys");
+  }
+  return HDK_HIP_OK;
+}
+
+LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko,
+                         const hdk_hip_device_properties* props) {
+  LaunchShape s;
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  s.wpe = wl.wpe;
+  s.entry_count = p->query_kind == HDK_Q_NON_GROUPED ? 1u : p->entry_count;
+  s.grid = (ko && ko->grid_dim_x) ? ko->grid_dim_x : static_cast<uint32_t>(props->grid_size);
+  s.block = kBlock;
+  const bool force_global = ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS);
+  const uint64_t words = static_cast<uint64_t>(s.entry_count) * s.wpe;
+  if (p->query_kind != HDK_Q_BASELINE_HASH && words <= kLdsWordBudget && !force_global) {
+    s.strategy = STRAT_LDS;
+    uint32_t rep = 32;
+    while (rep > 1 && words * rep > kLdsWordBudget) {
+      rep >>= 1;
+    }
+    s.rep = rep;
+    s.lds_bytes = static_cast<uint32_t>(words * rep * 8);
+    s.slab_words = words;
+  } else {
+    s.strategy = STRAT_GLOBAL;
+    s.rep = 1;
+    s.lds_bytes = 0;
+    s.slab_words = 0;
+  }
+  return s;
+}
+
+size_t workspace_bytes_for(const LaunchShape& s) {
+  return kPlanRegionBytes + static_cast<size_t>(s.grid) * s.slab_words * 8;
+}
+
+static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
+  (void)p;
+  (void)s;
+  return "hdk_scan_agg_generic";
+}
+
+static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                               const LaunchShape& shape, int64_t* slabs, hipStream_t s) {
+  (void)plan;
+  ScanArgs a;
+  a.plan = d_plan;
+  a.kp = kp;
+  a.slabs = slabs;
+  a.entry_count = shape.entry_count;
+  a.rep = shape.rep;
+  a.rows_per_tile = kBlock * 4;
+  hipLaunchKernelGGL(hdk_scan_agg_generic, dim3(shape.grid), dim3(kBlock), shape.lds_bytes, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
+                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s) {
+  (void)plan;
+  (void)d_plan;
+  (void)kp;
+  (void)shape;
+  (void)s;
+  set_error("baseline-hash / large perfect-hash plans are not implemented yet");
+  return HDK_HIP_ERR_UNSUPPORTED;
+}
+
+}  // namespace hdk
+
+extern "C" int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
+                                          int32_t device_id, size_t* bytes) {
+  HDK_REQUIRE(bytes, "bytes is NULL");
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  const hdk_hip_device_properties* props = device_props(device_id);
+  if (!props) return HDK_HIP_ERR_RUNTIME;
+  *bytes = workspace_bytes_for(choose_shape(plan, ko, props));
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
+                                           int32_t device_id, char* out, size_t out_len) {
+  HDK_REQUIRE(out && out_len, "out is NULL");
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  const hdk_hip_device_properties* props = device_props(device_id);
+  if (!props) return HDK_HIP_ERR_RUNTIME;
+  const LaunchShape s = choose_shape(plan, ko, props);
+  if (s.strategy == STRAT_LDS) {
+    snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
+  } else {
+    snprintf(out, out_len, "hdk_scan_agg_global");
+  }
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                                  const hdk_hip_kernel_options* ko, int32_t device_id, void* stream,
+                                  void* workspace, size_t workspace_bytes) {
+  int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(params, "params is NULL");
+  HDK_REQUIRE(params[HDK_KP_NUM_FRAGMENTS] && params[HDK_KP_NUM_ROWS] && params[HDK_KP_NUM_TABLES] &&
+                  params[HDK_KP_GROUPBY_BUF] && params[HDK_KP_ERROR_CODE],
+              "a required kernel parameter is NULL");
+  HDK_REQUIRE(plan->num_joins == 0 || params[HDK_KP_JOIN_HASH_TABLES], "JOIN_HASH_TABLES is NULL");
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  const hdk_hip_device_properties* props = device_props(device_id);
+  const LaunchShape shape = choose_shape(plan, ko, props);
+  HDK_REQUIRE(workspace && workspace_bytes >= workspace_bytes_for(shape),
+              "workspace too small: %zu < %zu", workspace_bytes, workspace_bytes_for(shape));
+  HDK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "workspace must be 16-byte aligned");
+
+  // the plan is read by the kernels from device memory (wave-uniform scalar loads)
+  hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
+  HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+
+  KernParams kp;
+  kp.col_buffers = reinterpret_cast<const int8_t* const* const*>(params[HDK_KP_COL_BUFFERS]);
+  kp.num_fragments = reinterpret_cast<const uint64_t*>(params[HDK_KP_NUM_FRAGMENTS]);
+  kp.literals = params[HDK_KP_LITERALS];
+  kp.num_rows = reinterpret_cast<const int64_t*>(params[HDK_KP_NUM_ROWS]);
+  kp.frag_row_offsets = reinterpret_cast<const uint64_t*>(params[HDK_KP_FRAG_ROW_OFFSETS]);
+  kp.max_matched = reinterpret_cast<const int32_t*>(params[HDK_KP_MAX_MATCHED]);
+  kp.total_matched = reinterpret_cast<int32_t*>(params[HDK_KP_TOTAL_MATCHED]);
+  kp.init_agg_vals = reinterpret_cast<const int64_t*>(params[HDK_KP_INIT_AGG_VALS]);
+  kp.groupby_buf = reinterpret_cast<int64_t**>(params[HDK_KP_GROUPBY_BUF]);
+  kp.error_code = reinterpret_cast<int32_t*>(params[HDK_KP_ERROR_CODE]);
+  kp.num_tables = reinterpret_cast<const uint32_t*>(params[HDK_KP_NUM_TABLES]);
+  kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
+
+  if (shape.strategy == STRAT_LDS) {
+    int64_t* slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(workspace) + kPlanRegionBytes);
+    st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s);
+    if (st) return st;
+    FinalizeArgs fa;
+    fa.plan = d_plan;
+    fa.slabs = slabs;
+    fa.groupby_buf = kp.groupby_buf;
+    fa.num_slabs = shape.grid;
+    fa.entry_count = shape.entry_count;
+    const unsigned fblocks = (shape.entry_count + (kBlock / kWave) - 1) / (kBlock / kWave);
+    hipLaunchKernelGGL(hdk_finalize, dim3(fblocks), dim3(kBlock), 0, s, fa);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
+  }
+  return launch_scan_global(plan, d_plan, kp, shape, s);
+}

@@ -1,0 +1,306 @@
+"""Host side of the hot path: fragments -> device buffers -> kernel params -> launch -> result set.
+
+Mirrors the reference's call chain for one execution step:
+  Executor::fetchChunks            (QE/Execute.cpp:2965-3068)   -> `BufferCache.chunk`
+  buildHashTableForQualifier       (QE/Execute.cpp:3692) + PerfectJoinHashTableBuilder::
+      initHashTableOnGpu           (QE/JoinHashTable/Builders/PerfectHashTableBuilder.h:53-137)
+                                                                -> `Executor._build_join_table`
+  prepareKernelParams              (QE/QueryExecutionContext.cpp:788-964) -> `PreparedStep._params`
+  createAndInitializeGroupByBufferGpu (QE/QueryMemoryInitializer.cpp:1054-1156) -> `init_output`
+  DeviceKernel::launch             (QE/QueryExecutionContext.cpp:355)     -> `hdk_hip_launch`
+  copyGroupByBuffersFromGpu        (:404-426) + aggregate_error_codes (:221-234) -> `fetch`
+All compute goes through the C ABI; there is no CPU execution path in this package
+(`device_type="CPU"` raises).
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _abi as A
+from . import result_set
+from ._lib import HdkHipError, check, lib
+from .hip_mgr import DeviceBuffer, HipMgr
+from .ir import QueryMustRunOnCpu, QueryUnit
+from .plan import CompiledPlan, compact_init_vals, compile_query
+from .storage import ArrowStorage
+
+
+class BufferCache:
+    """Device-resident chunks, keyed like DataMgr's GPU_LEVEL chunk cache (table, column, fragment)."""
+
+    def __init__(self, mgr: HipMgr, device_id: int):
+        self.mgr, self.device_id = mgr, device_id
+        self._chunks: Dict[tuple, DeviceBuffer] = {}
+
+    def chunk(self, table, col_name, frag_idx) -> DeviceBuffer:
+        key = (table.name, col_name, frag_idx)
+        b = self._chunks.get(key)
+        if b is None:
+            b = self.mgr.to_device(table.columns[col_name].fragments[frag_idx], self.device_id)
+            self._chunks[key] = b
+        return b
+
+    def linearized(self, table, col_name) -> DeviceBuffer:
+        """All fragments of an inner-join column as one buffer (ColumnFetcher::linearizeColumnFragments)."""
+        key = (table.name, col_name, "all")
+        b = self._chunks.get(key)
+        if b is None:
+            frags = table.columns[col_name].fragments
+            arr = frags[0] if len(frags) == 1 else np.concatenate(frags)
+            b = self.mgr.to_device(arr, self.device_id)
+            self._chunks[key] = b
+        return b
+
+    def put(self, key, buf: DeviceBuffer):
+        self._chunks[key] = buf
+
+    def clear(self):
+        for b in self._chunks.values():
+            b.free()
+        self._chunks.clear()
+
+    def nbytes(self):
+        return sum(b.nbytes for b in self._chunks.values())
+
+
+class ExecutionResult:
+    """Host ResultSet + its layout; `to_arrow()` like pyhdk's ExecutionResult (_sql.pyx:76-83)."""
+
+    def __init__(self, cp: CompiledPlan, buf: np.ndarray, entry_count: int, error_code: int = 0):
+        self.compiled = cp
+        self.buffer = buf
+        self.entry_count = entry_count
+        self.error_code = error_code
+
+    def to_arrow(self):
+        return result_set.to_arrow(self.compiled, self.buffer, self.entry_count)
+
+    def to_columns(self):
+        return result_set.to_columns(self.compiled, self.buffer, self.entry_count)
+
+    def row_count(self):
+        return int(result_set.non_empty_mask(self.compiled, self.buffer, self.entry_count).sum())
+
+
+class PreparedStep:
+    """Everything one (multi-fragment) kernel launch needs, resident on the device."""
+
+    def __init__(self, ex: "Executor", cp: CompiledPlan, frag_ids: List[int], grid=0, flags=0,
+                 out_ptr: Optional[int] = None):
+        self.ex, self.cp, self.frag_ids = ex, cp, list(frag_ids)
+        self.mgr, self.dev = ex.mgr, ex.device_id
+        self.L = lib()
+        self.keep: List[DeviceBuffer] = []
+        p = cp.plan
+        self.ko = A.KernelOptions(grid, 0, 0, flags)
+        storage = ex.storage
+        outer = storage.get(cp.query.table)
+        nfrag = len(self.frag_ids)
+        ntab = 1 + len(cp.inner_tables)
+
+        # ---- join hash tables (built once per device, cached) ----------------------------
+        self.join_tables = [ex._build_join_table(cp, ji) for ji in range(len(cp.inner_tables))]
+
+        # ---- col_buffers[frag][buf_idx] ---------------------------------------------------
+        ncols = len(cp.input_cols)
+        flat = np.zeros(max(nfrag * ncols, 1), dtype=np.uint64)
+        for fi, f in enumerate(self.frag_ids):
+            for ci, (tn, cn, slot) in enumerate(cp.input_cols):
+                if slot == 0:
+                    flat[fi * ncols + ci] = ex.cache.chunk(outer, cn, f).ptr
+                else:
+                    flat[fi * ncols + ci] = ex.cache.linearized(storage.get(tn), cn).ptr
+        d_flat = self._dev(flat)
+        frag_ptrs = np.array([d_flat.ptr + fi * ncols * 8 for fi in range(nfrag)] or [0], dtype=np.uint64)
+        d_frag_ptrs = self._dev(frag_ptrs)
+        num_rows = np.zeros(max(nfrag * ntab, 1), dtype=np.int64)
+        frag_offs = np.zeros(max(nfrag * ntab, 1), dtype=np.uint64)
+        row_off = 0
+        starts = np.concatenate([[0], np.cumsum(outer.frag_rows)]) if outer.frag_rows else [0]
+        for fi, f in enumerate(self.frag_ids):
+            num_rows[fi * ntab] = outer.frag_rows[f]
+            frag_offs[fi * ntab] = starts[f]
+            for ti, tn in enumerate(cp.inner_tables):
+                num_rows[fi * ntab + 1 + ti] = storage.get(tn).num_rows
+        self.rows_in_step = int(sum(outer.frag_rows[f] for f in self.frag_ids))
+        d_num_rows = self._dev(num_rows)
+        d_frag_offs = self._dev(frag_offs)
+        d_nfrag = self._dev(np.array([nfrag], dtype=np.uint64))
+        d_ntab = self._dev(np.array([ntab], dtype=np.uint32))
+        self.init_vals_host = compact_init_vals(cp)
+        d_init = self._dev(self.init_vals_host)
+        self.d_init = d_init
+        self.d_err = self._dev(np.zeros(1, dtype=np.int32))
+        d_max_matched = self._dev(np.array([p.entry_count], dtype=np.int32))
+        d_total_matched = self._dev(np.zeros(1, dtype=np.int32))
+        if len(self.join_tables) == 1:
+            jt_param = self.join_tables[0].ptr
+        elif self.join_tables:
+            jt_param = self._dev(np.array([t.ptr for t in self.join_tables], dtype=np.int64)).ptr
+        else:
+            jt_param = 0
+
+        # ---- output buffer + GROUPBY_BUF ---------------------------------------------------
+        self.buffer_bytes = cp.buffer_bytes
+        if out_ptr is None:
+            self.out = self.mgr.alloc(max(self.buffer_bytes, 8), self.dev)
+            self.keep.append(self.out)
+            self.out_ptr = self.out.ptr
+        else:
+            self.out_ptr = out_ptr
+        if p.query_kind == A.Q_NON_GROUPED:
+            nslots = len(cp.slot_widths)
+            ptrs = np.array([self.out_ptr + 8 * i for i in range(nslots)], dtype=np.uint64)
+        else:
+            ptrs = np.array([self.out_ptr], dtype=np.uint64)
+        d_gb = self._dev(ptrs)
+        if p.output_columnar:
+            self.d_col_sizes = self._dev(np.array(cp.slot_widths, dtype=np.int8))
+            self.d_init_raw = self._dev(cp.init_vals)
+
+        params = (C.c_void_p * A.KP_COUNT)()
+        params[A.KP_COL_BUFFERS] = d_frag_ptrs.ptr
+        params[A.KP_NUM_FRAGMENTS] = d_nfrag.ptr
+        params[A.KP_LITERALS] = None
+        params[A.KP_NUM_ROWS] = d_num_rows.ptr
+        params[A.KP_FRAG_ROW_OFFSETS] = d_frag_offs.ptr
+        params[A.KP_MAX_MATCHED] = d_max_matched.ptr
+        params[A.KP_TOTAL_MATCHED] = d_total_matched.ptr
+        params[A.KP_INIT_AGG_VALS] = d_init.ptr
+        params[A.KP_GROUPBY_BUF] = d_gb.ptr
+        params[A.KP_ERROR_CODE] = self.d_err.ptr
+        params[A.KP_NUM_TABLES] = d_ntab.ptr
+        params[A.KP_JOIN_HASH_TABLES] = jt_param or None
+        self._params = params
+
+        ws = C.c_size_t(0)
+        check(self.L.hdk_hip_workspace_size(C.byref(p), C.byref(self.ko), self.dev, C.byref(ws)))
+        self.workspace = self.mgr.alloc(max(ws.value, 16), self.dev)
+        self.keep.append(self.workspace)
+        self.workspace_bytes = ws.value
+
+    def _dev(self, arr) -> DeviceBuffer:
+        b = self.mgr.to_device(arr, self.dev)
+        self.keep.append(b)
+        return b
+
+    def kernel_names(self) -> str:
+        out = C.create_string_buffer(256)
+        check(self.L.hdk_hip_describe_launch(C.byref(self.cp.plan), C.byref(self.ko), self.dev, out, 256))
+        return out.value.decode()
+
+    # ---- the three steps of launchGpuCode ------------------------------------------------------
+    def init_output(self, stream=None):
+        p = self.cp.plan
+        props = self.mgr.getDeviceProperties(self.dev)
+        if p.query_kind == A.Q_NON_GROUPED:
+            # out_vec slots start at init_agg_vals (QueryExecutionContext.cpp:452-458); the keyless
+            # row-wise fill with one "entry" of nslots quads is exactly that copy, on the stream
+            check(self.L.hdk_hip_init_group_by_buffer(
+                self.out_ptr, self.d_init.ptr, 1, 0, 8, len(self.cp.slot_widths), 1, 1,
+                props.max_threads_per_block, props.grid_size, self.dev, stream))
+        elif p.output_columnar:
+            check(self.L.hdk_hip_init_columnar_group_by_buffer(
+                self.out_ptr, self.d_init_raw.ptr, p.entry_count, p.key_count, len(self.cp.slot_widths),
+                self.d_col_sizes.ptr, 1, p.keyless, 8, props.max_threads_per_block, props.grid_size,
+                self.dev, stream))
+        else:
+            check(self.L.hdk_hip_init_group_by_buffer(
+                self.out_ptr, self.d_init.ptr, p.entry_count, p.key_count, p.key_width, p.row_size_quad,
+                p.keyless, 1, props.max_threads_per_block, props.grid_size, self.dev, stream))
+
+    def launch(self, stream=None):
+        check(self.L.hdk_hip_launch(C.byref(self.cp.plan), self._params, C.byref(self.ko), self.dev, stream,
+                                    self.workspace.ptr, self.workspace.nbytes))
+
+    def fetch(self, stream_synced=False) -> ExecutionResult:
+        if not stream_synced:
+            self.mgr.synchronizeStream(self.dev)
+        err = int(self.mgr.to_host(self.d_err.ptr, 4, self.dev, np.int32)[0])
+        if err > 0:
+            raise HdkHipError(err, f"device error code {err} (QE/Execute.h:1019-1031)")
+        buf = self.mgr.to_host(self.out_ptr, max(self.buffer_bytes, 8), self.dev, np.int64)
+        return ExecutionResult(self.cp, buf[:self.buffer_bytes // 8], self.cp.entry_count, err)
+
+    def run(self, stream=None) -> ExecutionResult:
+        self.init_output(stream)
+        self.launch(stream)
+        return self.fetch()
+
+    def free(self):
+        for b in self.keep:
+            b.free()
+        self.keep.clear()
+
+
+class Executor:
+    """One device's executor (cf. Executor + QueryExecutionContext for a MultifragmentKernel,
+    QE/Execute.cpp:2084-2090: one kernel over all fragments assigned to the device)."""
+
+    def __init__(self, storage: ArrowStorage, device_id: int = 0, mgr: Optional[HipMgr] = None):
+        self.storage = storage
+        self.mgr = mgr or HipMgr()
+        self.device_id = device_id
+        self.cache = BufferCache(self.mgr, device_id)
+        self._join_cache: Dict[tuple, DeviceBuffer] = {}
+
+    def compile(self, q: QueryUnit) -> CompiledPlan:
+        return compile_query(self.storage, q)
+
+    def _build_join_table(self, cp: CompiledPlan, ji: int) -> DeviceBuffer:
+        """PerfectJoinHashTable::reify for one device: init + one-to-one fill; a duplicate key
+        (NeedsOneToManyHash) is outside the probe kernels this round -> QueryMustRunOnCpu."""
+        info = cp.join_infos[ji]
+        key = (info["inner_table"], info["inner_col"])
+        if key in self._join_cache:
+            return self._join_cache[key]
+        L = lib()
+        inner = self.storage.get(info["inner_table"])
+        entries = info["max"] - info["min"] + 1
+        if entries <= 0 or entries > 2**31 - 1:
+            raise QueryMustRunOnCpu("join key range too large for a perfect hash table (TooManyHashEntries)")
+        table = self.mgr.alloc(entries * 4, self.device_id)
+        check(L.hdk_hip_init_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, self.device_id, None))
+        # JoinColumn: one JoinChunk per inner fragment
+        chunks = (A.JoinChunk * inner.num_fragments)()
+        rid = 0
+        for f in range(inner.num_fragments):
+            chunks[f].col_buff = self.cache.chunk(inner, info["inner_col"], f).ptr
+            chunks[f].num_elems = inner.frag_rows[f]
+            chunks[f].row_id = rid
+            rid += inner.frag_rows[f]
+        raw = np.frombuffer(bytes(chunks), dtype=np.uint8)
+        d_chunks = self.mgr.to_device(raw, self.device_id)
+        jc = A.JoinColumn(d_chunks.ptr, raw.nbytes, inner.num_fragments, inner.num_rows, info["elem_sz"])
+        ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], 0, A.JC_SIGNED, 0)
+        d_err = self.mgr.to_device(np.zeros(1, dtype=np.int32), self.device_id)
+        check(L.hdk_hip_fill_hash_join_buff(table.ptr, A.JOIN_INVALID_SLOT, 0, d_err.ptr, jc, ti,
+                                            self.device_id, None))
+        self.mgr.synchronizeStream(self.device_id)
+        err = int(self.mgr.to_host(d_err.ptr, 4, self.device_id, np.int32)[0])
+        d_err.free()
+        d_chunks.free()
+        if err != 0:
+            table.free()
+            raise QueryMustRunOnCpu("join keys are not unique: one-to-many probe is outside the fixed kernel "
+                                    "library this round (PerfectHashTableBuilder.h:134-141 NeedsOneToManyHash)")
+        self._join_cache[key] = table
+        return table
+
+    def prepare(self, q, frag_ids: Optional[List[int]] = None, grid=0, flags=0,
+                out_ptr: Optional[int] = None) -> PreparedStep:
+        cp = q if isinstance(q, CompiledPlan) else self.compile(q)
+        outer = self.storage.get(cp.query.table)
+        if frag_ids is None:
+            frag_ids = list(range(outer.num_fragments))
+        return PreparedStep(self, cp, frag_ids, grid=grid, flags=flags, out_ptr=out_ptr)
+
+    def execute(self, q: QueryUnit, device_type: str = "GPU", frag_ids=None, **kw) -> ExecutionResult:
+        if device_type != "GPU":
+            raise QueryMustRunOnCpu("hdk_amd ships the GPU path only; run device_type='CPU' on HDK itself")
+        step = self.prepare(q, frag_ids, **kw)
+        try:
+            return step.run()
+        finally:
+            step.free()

@@ -1,0 +1,704 @@
+"""QueryUnit -> (memory layout, init values, POD plan).
+
+Host-side mirror of what the reference does between `RelAlgExecutionUnit` and the JIT:
+  * expression ranges           QueryEngine/ExpressionRange.cpp:380-420,796-830
+  * perfect vs baseline hash    QueryEngine/MemoryLayoutBuilder.cpp:91-237, ColRangeInfo.cpp:24-66
+  * keyless hash                QueryEngine/MemoryLayoutBuilder.cpp:249-413
+  * slot widths / compaction    QueryEngine/MemoryLayoutBuilder.cpp:559-652, ResultSet/ColSlotContext.cpp
+  * row / column offsets        ResultSet/QueryMemoryDescriptor.cpp:240-258,301-372,457-478
+  * init values                 QueryEngine/OutputBufferInitialization.cpp:24-77,112-258
+Instead of emitting LLVM IR the work unit is pattern-matched into `hdk_hip_plan`; shapes outside the
+fixed kernel library raise QueryMustRunOnCpu (reference RelAlgExecutor.cpp:183-192 retry).
+"""
+import math
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi as A
+from .ir import (Agg, BinOp, Cast, Cmp, ColRef, Expr, ExtractYear, KeyRef, Lit, QueryMustRunOnCpu,
+                 QueryUnit, Type)
+from .storage import ArrowStorage, Table
+
+BASELINE_THRESHOLD = 1_000_000  # Config.exec.group_by.baseline_threshold (Shared/Config.h:51)
+DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS = 16384  # Shared/Config.h:42
+MAX_BUFFER_SIZE = 1 << 30  # MemoryLayoutBuilder.cpp:176
+
+
+def _dbits(x: float) -> int:
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+def align8(x: int) -> int:
+    return (x + 7) & ~7
+
+
+# ---------------------------------------------------------------------------------------------
+# expression ranges (ExpressionRange.cpp)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Range:
+    kind: str  # 'int' | 'fp' | 'invalid'
+    lo: float = 0
+    hi: float = 0
+    bucket: int = 0
+    has_nulls: bool = False
+
+
+def _extract_year(ts: int) -> int:
+    # host restatement of omniscidb/Utils/ExtractFromTime.cpp:260-272 (general path)
+    day = ts // 86400
+    era = (day - 11017) // 146097
+    doe = day - 11017 - era * 146097
+    yoe = (doe - doe // 1460 + doe // 36524 - (1 if doe == 146096 else 0)) // 365
+    doy = doe - (365 * yoe + yoe // 4 - yoe // 100)
+    return 2000 + era * 400 + yoe + (1 if 306 <= doy else 0)
+
+
+def _scale_down(v: int, scale: int) -> int:
+    tmp = scale >> 1
+    tmp = v + tmp if v >= 0 else v - tmp
+    return int(tmp / scale) if scale else v  # C truncation
+
+
+class _Binder:
+    """Resolves columns and types for one QueryUnit."""
+
+    def __init__(self, storage: ArrowStorage, q: QueryUnit):
+        self.storage = storage
+        self.q = q
+        self.outer: Table = storage.get(q.table)
+        self.inner: List[Table] = [storage.get(j.inner_table) for j in q.joins]
+        self.cols: List[Tuple[str, str, int]] = []  # (table_name, col_name, table_slot)
+
+    def resolve(self, c: ColRef):
+        if c.table in (None, self.q.table):
+            if c.name in self.outer.columns:
+                return 0, self.outer, self.outer.columns[c.name]
+            if c.table is not None:
+                raise KeyError(f"column {c.name} not in table {c.table}")
+        for ji, t in enumerate(self.inner):
+            if (c.table in (None, t.name)) and c.name in t.columns:
+                return ji + 1, t, t.columns[c.name]
+        raise KeyError(f"cannot resolve column {c}")
+
+    def col_index(self, c: ColRef) -> int:
+        slot, t, _ = self.resolve(c)
+        key = (t.name, c.name, slot)
+        if key not in self.cols:
+            if len(self.cols) >= A.MAX_COLS:
+                raise QueryMustRunOnCpu("too many input columns for the fixed kernel library")
+            self.cols.append(key)
+        return self.cols.index(key)
+
+    # ----- types -------------------------------------------------------------------------
+    def type_of(self, e: Expr) -> Type:
+        if isinstance(e, ColRef):
+            return self.resolve(e)[2].type
+        if isinstance(e, Lit):
+            return Type("fp", 8, False) if isinstance(e.value, float) else Type("int", 8, False)
+        if isinstance(e, BinOp):
+            lt, rt = self.type_of(e.lhs), self.type_of(e.rhs)
+            nullable = lt.nullable or rt.nullable
+            if lt.kind == "decimal" or rt.kind == "decimal":
+                raise QueryMustRunOnCpu("decimal arithmetic is outside the fixed kernel library")
+            if lt.is_fp or rt.is_fp:
+                if e.op == "%":
+                    raise QueryMustRunOnCpu("fp modulo")
+                return Type("fp", 8, nullable)
+            return Type("int", 8, nullable)
+        if isinstance(e, ExtractYear):
+            return Type("int", 8, self.type_of(e.arg).nullable)
+        if isinstance(e, Cast):
+            return e.to.with_nullable(self.type_of(e.arg).nullable)
+        raise QueryMustRunOnCpu(f"unsupported expression {e!r}")
+
+    # ----- ranges ------------------------------------------------------------------------
+    def range_of(self, e: Expr) -> Range:
+        if isinstance(e, ColRef):
+            col = self.resolve(e)[2]
+            st = col.table_stats()
+            if st.min is None:
+                return Range("invalid", has_nulls=st.has_nulls)
+            if col.type.is_fp:
+                return Range("fp", st.min, st.max, 0, st.has_nulls)
+            return Range("int", st.min, st.max, 0, st.has_nulls)
+        if isinstance(e, Lit):
+            if isinstance(e.value, float):
+                return Range("fp", e.value, e.value)
+            return Range("int", int(e.value), int(e.value))
+        if isinstance(e, BinOp):
+            a, b = self.range_of(e.lhs), self.range_of(e.rhs)
+            if a.kind == "invalid" or b.kind == "invalid":
+                return Range("invalid")
+            hn = a.has_nulls or b.has_nulls
+            kind = "fp" if "fp" in (a.kind, b.kind) else "int"
+            if e.op == "+":
+                return Range(kind, a.lo + b.lo, a.hi + b.hi, 0, hn)
+            if e.op == "-":
+                return Range(kind, a.lo - b.hi, a.hi - b.lo, 0, hn)
+            if e.op == "*":
+                c = [a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi]
+                return Range(kind, min(c), max(c), 0, hn)
+            if e.op == "/" and kind == "int" and b.lo == b.hi and b.lo > 0:
+                return Range("int", int(a.lo / b.lo), int(a.hi / b.lo), 0, hn)
+            return Range("invalid")  # modulo etc.: ExpressionRange.cpp:416-419
+        if isinstance(e, ExtractYear):
+            a = self.range_of(e.arg)
+            if a.kind != "int":
+                return Range("invalid")
+            return Range("int", _extract_year(int(a.lo)), _extract_year(int(a.hi)), 0, a.has_nulls)
+        if isinstance(e, Cast):
+            a = self.range_of(e.arg)
+            st = self.type_of(e.arg)
+            if a.kind == "invalid":
+                return a
+            if st.kind == "decimal" and e.to.kind == "int":
+                s = 10 ** st.scale
+                return Range("int", _scale_down(int(a.lo), s), _scale_down(int(a.hi), s), 0, a.has_nulls)
+            if e.to.is_fp:
+                return Range("fp", float(a.lo), float(a.hi), 0, a.has_nulls)
+            if st.is_fp:
+                return Range("int", math.floor(a.lo), math.ceil(a.hi), 0, a.has_nulls)
+            return a
+        return Range("invalid")
+
+
+# ---------------------------------------------------------------------------------------------
+# expression flattening into hdk_hip_expr chains
+# ---------------------------------------------------------------------------------------------
+_OPS = {"+": A.OP_ADD, "-": A.OP_SUB, "*": A.OP_MUL, "/": A.OP_DIV, "%": A.OP_MOD}
+
+
+def _result_null(t: Type) -> int:
+    """Null sentinel of an expression RESULT: computed values are carried as int64 / double."""
+    return A.NULL_DOUBLE_BITS if t.is_fp else A.NULL_BIGINT
+
+
+def _make_leaf(b: _Binder, e: Expr) -> A.Leaf:
+    leaf = A.Leaf()
+    if isinstance(e, ColRef):
+        t = b.type_of(e)
+        leaf.kind = A.LEAF_COL
+        leaf.col = b.col_index(e)
+        leaf.null_val = A.to_i64(t.null_as_int64_or_double_bits())
+        leaf.nullable = 1 if t.nullable else 0
+    elif isinstance(e, Lit):
+        if isinstance(e.value, float):
+            leaf.kind = A.LEAF_FP
+            leaf.ival = _dbits(e.value)
+        else:
+            leaf.kind = A.LEAF_INT
+            leaf.ival = A.to_i64(int(e.value))
+        leaf.nullable = 0
+    else:
+        raise QueryMustRunOnCpu("expression too deep for the fixed kernel library (right operand must "
+                                "be a column or literal)")
+    return leaf
+
+
+def _flatten(b: _Binder, e: Expr):
+    """-> (leaf0_expr, [(op, rhs_expr_or_None, literal_param, out_type)])."""
+    if isinstance(e, (ColRef, Lit)):
+        return e, []
+    if isinstance(e, BinOp):
+        l0, steps = _flatten(b, e.lhs)
+        if not isinstance(e.rhs, (ColRef, Lit)):
+            raise QueryMustRunOnCpu("right operand must be a column or literal")
+        return l0, steps + [(_OPS[e.op], e.rhs, b.type_of(e))]
+    if isinstance(e, ExtractYear):
+        l0, steps = _flatten(b, e.arg)
+        at = b.type_of(e.arg)
+        if at.kind != "timestamp" or at.unit != "s":
+            raise QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) argument")
+        return l0, steps + [(A.OP_EXTRACT_YEAR, None, b.type_of(e))]
+    if isinstance(e, Cast):
+        l0, steps = _flatten(b, e.arg)
+        at = b.type_of(e.arg)
+        if at.kind == "decimal" and e.to.kind == "int":
+            return l0, steps + [(A.OP_SCALE_DOWN, Lit(10 ** at.scale), b.type_of(e))]
+        if at.is_integer_like and e.to.is_fp:
+            return l0, steps + [(A.OP_CAST_INT_TO_FP, None, b.type_of(e))]
+        if at.is_fp and e.to.is_integer_like:
+            return l0, steps + [(A.OP_CAST_FP_TO_INT, None, b.type_of(e))]
+        if at.is_integer_like and e.to.is_integer_like and at.kind != "decimal":
+            return l0, steps  # widening int cast: values are carried as int64 already
+        raise QueryMustRunOnCpu(f"unsupported cast {at} -> {e.to}")
+    raise QueryMustRunOnCpu(f"unsupported expression {e!r}")
+
+
+def make_expr(b: _Binder, e: Expr) -> A.Expr:
+    l0, steps = _flatten(b, e)
+    if len(steps) > A.MAX_EXPR_STEPS:
+        raise QueryMustRunOnCpu("expression chain too long for the fixed kernel library")
+    x = A.Expr()
+    x.leaf0 = _make_leaf(b, l0)
+    x.nsteps = len(steps)
+    for i, (op, rhs, out_t) in enumerate(steps):
+        st = x.steps[i]
+        st.op = op
+        st.out_class = A.VC_FP if out_t.is_fp else A.VC_INT
+        if rhs is not None:
+            st.rhs = _make_leaf(b, rhs)
+        st.null_out = A.to_i64(_result_null(out_t))
+    t = b.type_of(e)
+    x.vclass = A.VC_FP if t.is_fp else A.VC_INT
+    if steps:
+        x.null_val = A.to_i64(_result_null(t))
+        x.nullable = 1  # every step may produce NULL (eval tracks it in-band)
+        # a chain over non-nullable inputs can still never be NULL; keep `nullable` precise
+        x.nullable = 1 if t.nullable else 0
+    else:
+        x.null_val = x.leaf0.null_val
+        x.nullable = x.leaf0.nullable
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# layout + plan
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class OutCol:
+    name: str
+    kind: str  # 'key' | 'agg'
+    type: Type
+    target_idx: int = -1
+    key_idx: int = -1
+    agg: str = ""
+    dictionary: Optional[list] = None
+    scale: int = 0  # decimal scale of the aggregate's argument (values are scaled int64)
+
+
+@dataclass
+class CompiledPlan:
+    plan: A.Plan
+    query: QueryUnit
+    init_vals: np.ndarray  # int64 per slot (init_agg_val_vec)
+    slot_widths: List[int]
+    input_cols: List[Tuple[str, str, int]]  # (table, column, table_slot) per buf_idx
+    inner_tables: List[str]
+    join_infos: list
+    out_cols: List[OutCol]
+    key_types: List[Type]
+    buffer_bytes: int
+    key_ranges: List[Range] = field(default_factory=list)
+
+    @property
+    def entry_count(self):
+        return int(self.plan.entry_count)
+
+    @property
+    def buffer_quads(self):
+        return self.buffer_bytes // 8
+
+
+_CMP = {"=": A.CMP_EQ, "==": A.CMP_EQ, "<>": A.CMP_NE, "!=": A.CMP_NE, "<": A.CMP_LT, ">": A.CMP_GT,
+        "<=": A.CMP_LE, ">=": A.CMP_GE}
+_AGG = {"count": A.AGG_COUNT, "sum": A.AGG_SUM, "min": A.AGG_MIN, "max": A.AGG_MAX, "avg": A.AGG_AVG}
+
+
+def _agg_init_val(kind: str, arg_t: Optional[Type], nullable: bool, width: int) -> int:
+    """get_agg_initial_val (OutputBufferInitialization.cpp:112-258) for an 8/4-byte slot."""
+    is_fp = arg_t is not None and arg_t.is_fp
+    if kind in ("count", "avg_count"):
+        return 0
+    if kind in ("sum", "avg"):
+        if nullable:
+            if is_fp:
+                return A.NULL_DOUBLE_BITS if width == 8 else A.NULL_FLOAT_BITS
+            return A.NULL_BIGINT if width == 8 else A.NULL_INT
+        return 0  # 0 / 0.0 share the all-zero pattern
+    if kind == "min":
+        if nullable:
+            return (A.NULL_DOUBLE_BITS if is_fp else A.NULL_BIGINT) if width == 8 else (
+                A.NULL_FLOAT_BITS if is_fp else A.NULL_INT)
+        if is_fp:
+            return _dbits(np.finfo(np.float64).max) if width == 8 else int(
+                np.array([np.finfo(np.float32).max], dtype=np.float32).view(np.int32)[0])
+        return (2**63 - 1) if width == 8 else (2**31 - 1)
+    if kind == "max":
+        if nullable:
+            return (A.NULL_DOUBLE_BITS if is_fp else A.NULL_BIGINT) if width == 8 else (
+                A.NULL_FLOAT_BITS if is_fp else A.NULL_INT)
+        if is_fp:
+            return _dbits(-np.finfo(np.float64).max) if width == 8 else int(
+                np.array([-np.finfo(np.float32).max], dtype=np.float32).view(np.int32)[0])
+        return -(2**63) if width == 8 else -(2**31)
+    raise ValueError(kind)
+
+
+def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
+    b = _Binder(storage, q)
+    p = A.Plan()
+    p.abi_version = A.PLAN_ABI
+    if len(q.quals) > A.MAX_QUALS or len(q.joins) > A.MAX_JOINS or len(q.groupby) > A.MAX_KEYS or \
+            len(q.targets) > A.MAX_TARGETS:
+        raise QueryMustRunOnCpu("query exceeds the fixed kernel library's limits")
+
+    # ---- joins first: inner-table columns need their table slot -------------------------
+    join_infos = []
+    p.num_joins = len(q.joins)
+    for ji, j in enumerate(q.joins):
+        inner = b.inner[ji]
+        icol = inner.columns[j.inner_col]
+        if not icol.type.is_integer_like:
+            raise QueryMustRunOnCpu("join keys must be integers")
+        st = icol.table_stats()
+        if st.min is None:
+            raise QueryMustRunOnCpu("empty join inner table")
+        jn = p.joins[ji]
+        jn.outer_key = make_expr(b, j.outer_key)
+        jn.min_key = int(st.min)
+        jn.max_key = int(st.max)
+        okt = b.type_of(j.outer_key)
+        jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits()) if not okt.is_fp else 0
+        jn.null_mode = A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE
+        jn.bucket = 0
+        jn.kind = A.JOIN_ONE_TO_ONE
+        jn.type = A.JOIN_INNER if j.type == "inner" else A.JOIN_LEFT
+        if jn.type == A.JOIN_LEFT:
+            raise QueryMustRunOnCpu("LEFT joins are outside the fixed kernel library")
+        jn.table_idx = ji
+        join_infos.append({"inner_table": inner.name, "inner_col": j.inner_col, "min": int(st.min),
+                           "max": int(st.max), "null_val": icol.type.null_value(),
+                           "elem_sz": icol.type.size})
+
+    # ---- quals ----------------------------------------------------------------------------
+    p.num_quals = len(q.quals)
+    for qi, c in enumerate(q.quals):
+        ql = p.quals[qi]
+        ql.lhs = make_expr(b, c.lhs)
+        ql.rhs = _make_leaf(b, c.rhs)
+        ql.cmp = _CMP[c.op]
+
+    # ---- group-by keys + hash type (get_col_range_info) ---------------------------------
+    nkeys = len(q.groupby)
+    key_types = [b.type_of(k) for k in q.groupby]
+    key_ranges = [b.range_of(k) for k in q.groupby]
+    p.key_count = nkeys
+    for ki, k in enumerate(q.groupby):
+        if key_types[ki].is_fp:
+            raise QueryMustRunOnCpu("floating-point group-by keys are outside the fixed kernel library")
+        p.keys[ki] = make_expr(b, k)
+
+    def card(r: Range) -> int:  # ColRangeInfo::getBucketedCardinality
+        c = int(r.hi) - int(r.lo)
+        if r.bucket:
+            c //= r.bucket
+        return c + 1 + (1 if r.has_nulls else 0)
+
+    if nkeys == 0:
+        kind = A.Q_NON_GROUPED
+        entry_count = 1
+    else:
+        perfect = all(r.kind == "int" for r in key_ranges) and not q.force_baseline
+        entry_count = 0
+        if perfect and nkeys == 1:
+            col_count = nkeys + len(q.targets)
+            max_entry_count = MAX_BUFFER_SIZE // (col_count * 8)
+            r = key_ranges[0]
+            if int(r.hi) - int(r.lo) >= max_entry_count and not r.bucket:
+                perfect = False
+            else:
+                entry_count = max(card(r), 1)
+        elif perfect:
+            total = 1
+            for r in key_ranges:
+                total *= card(r)
+            if total == 0 or total > BASELINE_THRESHOLD:
+                perfect = False
+            else:
+                entry_count = total
+        kind = A.Q_PERFECT_HASH if perfect else A.Q_BASELINE_HASH
+        if not perfect:
+            if q.baseline_entry_count:
+                entry_count = int(q.baseline_entry_count)
+            else:
+                # RelAlgExecutor.cpp:1553-1557: 2 x the cardinality estimate; the estimate here is
+                # min(row count, product of key ranges)
+                est = b.outer.num_rows
+                prod = 1
+                for r in key_ranges:
+                    if r.kind != "int":
+                        prod = None
+                        break
+                    prod *= card(r)
+                if prod is not None:
+                    est = min(est, prod)
+                entry_count = max(2 * est, DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS)
+        if entry_count >= 2**31:
+            raise QueryMustRunOnCpu("group-by buffer entry count does not fit int32")
+    p.query_kind = kind
+    p.entry_count = entry_count
+
+    for ki, r in enumerate(key_ranges):
+        if kind == A.Q_PERFECT_HASH:
+            p.key_min[ki] = int(r.lo)
+            p.key_bucket[ki] = int(r.bucket)
+            p.key_card[ki] = card(r)
+            p.key_has_nulls[ki] = 1 if r.has_nulls else 0
+            p.key_null_translated[ki] = int(r.hi) + (r.bucket if r.bucket else 1)
+
+    # ---- slots: widths (pick_target_compact_width) ----------------------------------------
+    all_small = nkeys == 1 and all(
+        (isinstance(t, Agg) and t.kind == "count" and t.arg is None) or
+        (isinstance(t, KeyRef) and key_types[t.idx].size <= 4)
+        for t in q.targets)
+    total_tuples = b.outer.num_rows + sum(t.num_rows for t in b.inner)
+    W = 4 if (all_small and not q.bigint_count and total_tuples <= 0xFFFFFFFF) else 8
+    if kind == A.Q_NON_GROUPED:
+        W = 8
+
+    # ---- keyless (get_keyless_info), single-column perfect hash only ----------------------
+    keyless, idx_target_as_key = False, -1
+    if kind == A.Q_PERFECT_HASH and nkeys == 1 and not key_ranges[0].bucket:
+        found, index, ok = False, 0, True
+        for t in q.targets:
+            if isinstance(t, Agg) and not found:
+                at = b.type_of(t.arg) if t.arg is not None else None
+                ar = b.range_of(t.arg) if t.arg is not None else None
+                if t.kind == "avg":
+                    index += 1
+                    if not (at.nullable and (ar.kind == "invalid" or ar.has_nulls)):
+                        found = True
+                elif t.kind == "count":
+                    if not (at is not None and at.nullable and (ar.kind == "invalid" or ar.has_nulls)):
+                        found = True
+                elif t.kind == "sum":
+                    if at.nullable:
+                        if ar.kind != "invalid" and not ar.has_nulls:
+                            found = True
+                    elif ar.kind != "invalid" and (ar.hi < 0 or ar.lo > 0):
+                        found = True
+                elif t.kind == "min":
+                    init_max = np.finfo(np.float64).max if at.is_fp else 2**63 - 1
+                    if ar.kind != "invalid" and ar.hi < init_max:
+                        found = True
+                elif t.kind == "max":
+                    init_min = -np.finfo(np.float64).max if at.is_fp else -(2**63)
+                    if ar.kind != "invalid" and not ar.has_nulls and ar.lo > init_min:
+                        found = True
+                else:
+                    ok = False
+            if not ok:
+                break
+            if not found:
+                index += 1
+        keyless = ok and found
+        idx_target_as_key = index
+    p.keyless = 1 if keyless else 0
+    p.idx_target_as_key = idx_target_as_key if keyless else -1
+
+    # ---- key width / columnar ---------------------------------------------------------------
+    columnar = bool(q.output_columnar) and kind != A.Q_NON_GROUPED
+    if kind == A.Q_BASELINE_HASH and not columnar:
+        # pick_baseline_key_width (MemoryLayoutBuilder.cpp:654-690)
+        kw = 4
+        for r, t in zip(key_ranges, key_types):
+            if r.kind != "int" or (t.size == 8 and r.has_nulls) or not (
+                    r.lo > -(2**31) and r.hi < A.EMPTY_KEY_32 - 1):
+                kw = 8
+        key_width = kw
+    else:
+        key_width = 8
+    p.key_width = key_width
+    p.output_columnar = 1 if columnar else 0
+
+    # ---- targets ------------------------------------------------------------------------------
+    p.num_targets = len(q.targets)
+    init_vals: List[int] = []
+    slot_widths: List[int] = []
+    out_cols: List[OutCol] = []
+    keys_bytes = 0 if (keyless or kind == A.Q_NON_GROUPED) else align8(nkeys * key_width)
+    row_off = keys_bytes
+    for ti, t in enumerate(q.targets):
+        tg = p.targets[ti]
+        tg.slot_width = W
+        tg.slot2_width = W
+        if isinstance(t, KeyRef):
+            if kind == A.Q_NON_GROUPED:
+                raise QueryMustRunOnCpu("key projection without GROUP BY")
+            tg.agg = A.AGG_ID
+            tg.has_arg = 1
+            tg.key_idx = t.idx
+            tg.arg = make_expr(b, q.groupby[t.idx])
+            tg.skip_null = 0
+            tg.arg_is_fp = 0
+            tg.null_val = 0
+            init_vals.append(0)  # non-agg targets init to 0 (OutputBufferInitialization.cpp:45-47)
+            slot_widths.append(W)
+            src = q.groupby[t.idx]
+            dic = b.resolve(src)[2].dictionary if isinstance(src, ColRef) else None
+            out_cols.append(OutCol(t.name or (src.name if isinstance(src, ColRef) else f"key{t.idx}"),
+                                   "key", key_types[t.idx], ti, t.idx, dictionary=dic))
+        else:
+            tg.agg = _AGG[t.kind]
+            tg.has_arg = 0 if t.arg is None else 1
+            at = None
+            if t.arg is not None:
+                tg.arg = make_expr(b, t.arg)
+                at = b.type_of(t.arg)
+                if at.kind in ("dict", "bool") and t.kind != "count":
+                    raise QueryMustRunOnCpu(f"{t.kind} over {at.kind}")
+            elif t.kind != "count":
+                raise ValueError(f"{t.kind} needs an argument")
+            if at is not None and at.is_fp and at.size == 4 and t.kind != "count":
+                # HDK accumulates float32 arguments in 4-byte float slots (takes_float_argument);
+                # that path is not in the fixed library
+                raise QueryMustRunOnCpu("aggregates over float32 are outside the fixed kernel library")
+            arg_nullable = at.nullable if at is not None else False
+            # group-by: the declared nullability decides; non-grouped: always nullable and always
+            # *_skip_val (OutputBufferInitialization.cpp:57-60, TargetExprBuilder.cpp:546-551)
+            eff_nullable = True if kind == A.Q_NON_GROUPED else arg_nullable
+            tg.skip_null = 1 if (t.arg is not None and eff_nullable) else 0
+            tg.arg_is_fp = 1 if (at is not None and at.is_fp) else 0
+            if t.kind == "count":
+                # agg_count[_skip_val]: skip value = the argument type's NULL (widened)
+                tg.null_val = A.to_i64(at.null_as_int64_or_double_bits()) if at is not None else 0
+                init_vals.append(0)
+                slot_widths.append(W)
+            else:
+                if t.kind in ("min", "max"):
+                    # domain-range-equivalent aggregates keep the ARGUMENT type's NULL
+                    # (get_agg_initial_val on the arg type: inline_int_null_value(type) in an 8-byte slot)
+                    nullv = at.null_as_int64_or_double_bits()
+                else:
+                    # SUM / AVG: integer sums are BIGINT (TargetInfo.h:121-135), fp sums DOUBLE
+                    nullv = A.NULL_DOUBLE_BITS if at.is_fp else A.NULL_BIGINT
+                tg.null_val = A.to_i64(nullv)
+                if eff_nullable:
+                    iv = nullv
+                else:
+                    iv = _agg_init_val("sum" if t.kind == "avg" else t.kind, at, False, 8)
+                init_vals.append(A.to_i64(iv))
+                slot_widths.append(W)
+                if t.kind == "avg":
+                    init_vals.append(0)
+                    slot_widths.append(W)
+            if t.kind == "count":
+                rt = Type("int", 4 if W == 4 else (8 if q.bigint_count else 4), False)
+            elif t.kind == "avg":
+                rt = Type("fp", 8, True)
+            elif t.kind == "sum":
+                rt = Type("fp", 8, True) if at.is_fp else Type("int", 8, True)
+            else:
+                rt = at
+            out_cols.append(OutCol(t.name or f"{t.kind}_{ti}", "agg", rt, ti, agg=t.kind,
+                                   scale=(at.scale if (at is not None and at.kind == "decimal") else 0)))
+        # row-wise offsets (ColSlotContext::getColOnlyOffInBytes)
+        if W == 8:
+            row_off = align8(row_off)
+        tg.slot_off = row_off
+        row_off += W
+        if tg.agg == A.AGG_AVG:
+            if W == 8:
+                row_off = align8(row_off)
+            tg.slot2_off = row_off
+            row_off += W
+    row_bytes = align8(row_off)
+    p.row_size_quad = row_bytes // 8 if not columnar else 0
+
+    if kind == A.Q_NON_GROUPED:
+        buffer_bytes = 8 * len(init_vals)
+        for ti in range(p.num_targets):  # out_vec: one int64 slot per agg column
+            pass
+    elif columnar:
+        if key_width != 8:
+            raise QueryMustRunOnCpu("columnar output needs 8-byte keys")
+        total = 0 if keyless else nkeys * align8(entry_count * 8)
+        for w in slot_widths:
+            total = align8(total) + entry_count * w
+        buffer_bytes = align8(total)
+    else:
+        buffer_bytes = row_bytes * entry_count
+
+    # ---- input columns (buf_idx order == order of first use) ----------------------------------
+    p.num_cols = len(b.cols)
+    for i, (tn, cn, slot) in enumerate(b.cols):
+        ct = storage.get(tn).columns[cn].type
+        c = p.cols[i]
+        c.buf_idx = i
+        c.table = slot
+        c.width = ct.size
+        if ct.is_fp:
+            c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
+        else:
+            c.kind = A.COL_INT
+    return CompiledPlan(plan=p, query=q, init_vals=np.array(init_vals, dtype=np.int64),
+                        slot_widths=slot_widths, input_cols=list(b.cols),
+                        inner_tables=[t.name for t in b.inner], join_infos=join_infos,
+                        out_cols=out_cols, key_types=key_types, buffer_bytes=buffer_bytes,
+                        key_ranges=key_ranges)
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side helpers shared by the executor and the tests
+# ---------------------------------------------------------------------------------------------
+def columnar_slot_offsets(cp: CompiledPlan, entry_count: Optional[int] = None) -> List[int]:
+    """Byte offset of every slot column (QueryMemoryDescriptor::getColOffInBytes, columnar)."""
+    p = cp.plan
+    n = int(entry_count if entry_count is not None else p.entry_count)
+    off = 0 if p.keyless else p.key_count * align8(n * 8)
+    offs = []
+    for w in cp.slot_widths:
+        off = align8(off)
+        offs.append(off)
+        off += n * w
+    return offs
+
+
+def compact_init_vals(cp: CompiledPlan) -> np.ndarray:
+    """Row-wise init values as the kernel's INIT_AGG_VALS param: one int64 word per quad of the
+    row's slot region (QueryExecutionContext.cpp:829-836 compact_init_vals)."""
+    p = cp.plan
+    if p.query_kind == A.Q_NON_GROUPED or p.output_columnar:
+        return cp.init_vals.copy()
+    keys_bytes = 0 if p.keyless else align8(p.key_count * p.key_width)
+    nbytes = p.row_size_quad * 8 - keys_bytes
+    raw = np.zeros(nbytes, dtype=np.uint8)
+    s = 0
+    for ti in range(p.num_targets):
+        tg = p.targets[ti]
+        n = 2 if tg.agg == A.AGG_AVG else 1
+        for k in range(n):
+            off = (tg.slot_off if k == 0 else tg.slot2_off) - keys_bytes
+            w = cp.slot_widths[s]
+            v = int(cp.init_vals[s])
+            raw[off:off + w] = np.frombuffer(
+                (v & ((1 << (8 * w)) - 1)).to_bytes(w, "little"), dtype=np.uint8)
+            s += 1
+    return raw.view(np.int64).copy()
+
+
+def init_buffer_host(cp: CompiledPlan, entry_count: Optional[int] = None) -> np.ndarray:
+    """Host copy of a freshly initialised output buffer (what hdk_hip_init_*_group_by_buffer
+    writes on the device) -- numpy restatement used by tests and by CPU-side reduction."""
+    p = cp.plan
+    n = int(entry_count if entry_count is not None else p.entry_count)
+    if p.query_kind == A.Q_NON_GROUPED:
+        return cp.init_vals.copy()
+    if p.output_columnar:
+        offs = columnar_slot_offsets(cp, n)
+        total = offs[-1] + n * cp.slot_widths[-1] if offs else p.key_count * align8(n * 8)
+        buf = np.zeros(align8(total), dtype=np.uint8)
+        if not p.keyless:
+            buf[:p.key_count * align8(n * 8)].view(np.int64)[:] = A.EMPTY_KEY_64
+        for off, w, v in zip(offs, cp.slot_widths, cp.init_vals):
+            dt = np.int64 if w == 8 else np.int32
+            buf[off:off + n * w].view(dt)[:] = dt(int(v) if w == 8 else np.int64(v).astype(np.int32))
+        return buf.view(np.int64).copy()
+    rq = int(p.row_size_quad)
+    buf = np.zeros((n, rq), dtype=np.int64)
+    keys_quads = 0
+    if not p.keyless:
+        keys_quads = align8(p.key_count * p.key_width) // 8
+        kb = np.zeros((n, keys_quads * 8), dtype=np.uint8)
+        if p.key_width == 8:
+            kb.view(np.int64)[:, :p.key_count] = A.EMPTY_KEY_64
+        else:
+            kb.view(np.int32)[:, :p.key_count] = A.EMPTY_KEY_32
+        buf[:, :keys_quads] = kb.view(np.int64)
+    buf[:, keys_quads:] = compact_init_vals(cp)[None, :]
+    return buf.reshape(-1).copy()

@@ -1,0 +1,407 @@
+/*
+ * hdk_hip.h -- C ABI of the MI355X (gfx950) operator library for HDK's per-fragment hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / PODs, returns an int32 status
+ * (0 = ok; 1..16 = HDK's own Executor error codes, reference omniscidb/QueryEngine/Execute.h:1019-1031;
+ * <0 = out of slots, as in RuntimeFunctions.cpp:1123-1135) and never lets an exception cross the
+ * boundary.  `hdk_hip_last_error()` returns a thread-local message for the last non-zero status.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * root, `QE/` = omniscidb/QueryEngine/).  INTEGRATION.md shows the HDK-side bindings
+ * (HipMgr : GpuMgr, HipKernel : DeviceKernel, the *_on_device free functions).
+ *
+ * The JIT'ed row function that HDK generates per query (QE/RowFuncBuilder.cpp,
+ * QE/QueryTemplateGenerator.cpp) is replaced by a POD *plan* (`hdk_hip_plan`) interpreted by a
+ * fixed library of hand-written kernels; shapes the library does not cover are rejected with
+ * HDK_HIP_ERR_UNSUPPORTED so the caller can take HDK's existing QueryMustRunOnCpu retry
+ * (QE/RelAlgExecutor.cpp:183-192).
+ */
+#ifndef HDK_HIP_H
+#define HDK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Constants shared with the reference
+ * ---------------------------------------------------------------------------------------- */
+#define HDK_EMPTY_KEY_64 INT64_MAX /* QE/GpuRtConstants.h:29 */
+#define HDK_EMPTY_KEY_32 INT32_MAX /* :30 */
+#define HDK_EMPTY_KEY_16 INT16_MAX /* :31 */
+#define HDK_EMPTY_KEY_8 INT8_MAX   /* :32 */
+#define HDK_NULL_BIGINT INT64_MIN  /* Shared/InlineNullValues.h:37 */
+#define HDK_NULL_INT INT32_MIN
+#define HDK_NULL_SMALLINT INT16_MIN
+#define HDK_NULL_TINYINT INT8_MIN
+/* NULL_DOUBLE = DBL_MIN, NULL_FLOAT = FLT_MIN (smallest positive normal), compared bit-wise. */
+#define HDK_NULL_DOUBLE_BITS INT64_C(0x0010000000000000)
+#define HDK_NULL_FLOAT_BITS INT32_C(0x00800000)
+#define HDK_JOIN_INVALID_SLOT (-1) /* QE/JoinHashTable/Runtime/JoinHashTableQueryRuntime.cpp:38 */
+
+/* status / error codes: QE/Execute.h:1019-1031 */
+#define HDK_HIP_OK 0
+#define HDK_HIP_ERR_DIV_BY_ZERO 1
+#define HDK_HIP_ERR_OUT_OF_GPU_MEM 2
+#define HDK_HIP_ERR_OUT_OF_SLOTS 3
+#define HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW 7
+#define HDK_HIP_ERR_OUT_OF_TIME 9
+#define HDK_HIP_ERR_INTERRUPTED 10
+#define HDK_HIP_ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES 15
+/* library-level failures (not produced by HDK's runtime): */
+#define HDK_HIP_ERR_UNSUPPORTED 100 /* plan shape outside the fixed library -> QueryMustRunOnCpu */
+#define HDK_HIP_ERR_INVALID_ARG 101
+#define HDK_HIP_ERR_RUNTIME 102 /* a HIP runtime call failed; see hdk_hip_last_error() */
+#define HDK_HIP_ERR_JOIN_SLOT_TAKEN (-1) /* one-to-one build hit a duplicate key (JoinHashImpl.h:55-66) */
+
+const char* hdk_hip_last_error(void);
+/* Library/ABI version (major*1000+minor). */
+int32_t hdk_hip_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * HipMgr -- device manager under BufferProvider.
+ * Replaces CudaMgr/L0Manager behind `struct GpuMgr` (omniscidb/DataMgr/GpuMgr.h:29-79,
+ * omniscidb/CudaMgr/CudaMgr.h:83-260); one function per virtual.  There is no handle: state is a
+ * per-device table (stream, properties) initialised lazily and thread-safe.
+ * ---------------------------------------------------------------------------------------- */
+int32_t hdk_hip_mgr_get_device_count(int32_t* count);               /* GpuMgr::getDeviceCount */
+int32_t hdk_hip_mgr_set_context(int32_t device_num);                /* GpuMgr::setContext */
+int32_t hdk_hip_mgr_allocate_device_mem(size_t num_bytes, int32_t device_num,
+                                        int8_t** device_ptr);       /* GpuMgr::allocateDeviceMem;
+                                                                       OOM -> ERR_OUT_OF_GPU_MEM */
+int32_t hdk_hip_mgr_free_device_mem(int8_t* device_ptr);            /* GpuMgr::freeDeviceMem */
+int32_t hdk_hip_mgr_allocate_pinned_host_mem(size_t num_bytes, int8_t** host_ptr); /* CudaMgr.h:120 */
+int32_t hdk_hip_mgr_free_pinned_host_mem(int8_t* host_ptr);
+int32_t hdk_hip_mgr_copy_host_to_device(int8_t* device_ptr, const int8_t* host_ptr, size_t num_bytes,
+                                        int32_t device_num);        /* GpuMgr::copyHostToDevice */
+int32_t hdk_hip_mgr_copy_host_to_device_async(int8_t* device_ptr, const int8_t* host_ptr,
+                                              size_t num_bytes, int32_t device_num);
+int32_t hdk_hip_mgr_synchronize_stream(int32_t device_num);         /* GpuMgr::synchronizeStream */
+int32_t hdk_hip_mgr_copy_device_to_host(int8_t* host_ptr, const int8_t* device_ptr, size_t num_bytes,
+                                        int32_t device_num);        /* GpuMgr::copyDeviceToHost */
+int32_t hdk_hip_mgr_copy_device_to_device(int8_t* dest_ptr, int8_t* src_ptr, size_t num_bytes,
+                                          int32_t dest_device_num, int32_t src_device_num);
+int32_t hdk_hip_mgr_zero_device_mem(int8_t* device_ptr, size_t num_bytes, int32_t device_num);
+int32_t hdk_hip_mgr_set_device_mem(int8_t* device_ptr, unsigned char uc, size_t num_bytes,
+                                   int32_t device_num);
+int32_t hdk_hip_mgr_synchronize_devices(void);                      /* GpuMgr::synchronizeDevices */
+/* The per-device stream the manager's async copies and (when `stream`==NULL) the kernels use. */
+int32_t hdk_hip_mgr_get_stream(int32_t device_num, void** stream);
+
+typedef struct hdk_hip_device_properties { /* CudaMgr.h:43-66 `DeviceProperties` */
+  size_t global_mem;                /* GpuMgr::getTotalMem */
+  int32_t num_cu;                   /* GpuMgr::getMinEUNumForAllDevices (256 on MI355X) */
+  int32_t max_threads_per_block;    /* GpuMgr::getMaxBlockSize */
+  int32_t wavefront_size;           /* GpuMgr::getSubGroupSize -> 64 on CDNA4 */
+  int32_t grid_size;                /* GpuMgr::getGridSize: blocks a persistent launch uses */
+  size_t shared_mem_per_block;      /* GpuMgr::getMinSharedMemoryPerBlockForAllDevices */
+  int32_t has_shared_memory_atomics;/* GpuMgr::hasSharedMemoryAtomicsSupport -> 1 */
+  int32_t can_load_async;           /* GpuMgr::canLoadAsync -> 1 */
+  int32_t has_fp64;                 /* GpuMgr::hasFP64Support -> 1 */
+  int32_t clock_khz;
+  int32_t memory_clock_khz;
+  int32_t memory_bus_width;
+  char arch_name[64];               /* "gfx950..." */
+} hdk_hip_device_properties;
+int32_t hdk_hip_mgr_get_device_properties(int32_t device_num, hdk_hip_device_properties* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Output-buffer initialisation (kernel #1 of every group-by launch).
+ * Replaces init_group_by_buffer_on_device / init_columnar_group_by_buffer_on_device
+ * (QE/GpuInitGroups.h:23-48, kernels QE/GpuInitGroups.cu:17-232).  Same arguments minus the
+ * platform enum, plus device + stream.  block/grid sizes are accepted for signature parity and
+ * only used as hints.
+ * ---------------------------------------------------------------------------------------- */
+int32_t hdk_hip_init_group_by_buffer(int64_t* groups_buffer, const int64_t* init_vals,
+                                     uint32_t groups_buffer_entry_count, uint32_t key_count,
+                                     uint32_t key_width, uint32_t row_size_quad, int32_t keyless,
+                                     int8_t warp_size, size_t block_size_x, size_t grid_size_x,
+                                     int32_t device_id, void* stream);
+int32_t hdk_hip_init_columnar_group_by_buffer(int64_t* groups_buffer, const int64_t* init_vals,
+                                              uint32_t groups_buffer_entry_count, uint32_t key_count,
+                                              uint32_t agg_col_count, const int8_t* col_sizes,
+                                              int32_t need_padding, int32_t keyless, int8_t key_size,
+                                              size_t block_size_x, size_t grid_size_x,
+                                              int32_t device_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The plan: POD replacement for the JIT'ed row function.
+ * ---------------------------------------------------------------------------------------- */
+#define HDK_HIP_MAX_COLS 24
+#define HDK_HIP_MAX_KEYS 4
+#define HDK_HIP_MAX_TARGETS 8
+#define HDK_HIP_MAX_QUALS 6
+#define HDK_HIP_MAX_JOINS 2
+#define HDK_HIP_MAX_EXPR_STEPS 3
+
+enum hdk_hip_value_class { HDK_VC_INT = 0, HDK_VC_FP = 1 };
+
+/* How a fixed-width column element is decoded (QE/DecodersImpl.h:30-150). */
+enum hdk_hip_col_kind {
+  HDK_COL_INT = 0,      /* fixed_width_int_decode: sign-extend 1/2/4/8 bytes */
+  HDK_COL_UNSIGNED = 1, /* fixed_width_unsigned_decode (dictionary ids of 1/2 bytes) */
+  HDK_COL_FLOAT = 2,    /* fixed_width_float_decode, widened to double */
+  HDK_COL_DOUBLE = 3    /* fixed_width_double_decode */
+};
+
+typedef struct hdk_hip_col {
+  int32_t buf_idx;   /* index into col_buffers[frag][...] (the COL_BUFFERS kernel param) */
+  int32_t table;     /* 0 = outer table (row = pos); j>0 = inner table of join j-1 (row = matched id) */
+  int32_t width;     /* bytes per element */
+  int32_t kind;      /* hdk_hip_col_kind */
+} hdk_hip_col;
+
+/* Expression: a short left-to-right chain  acc = leaf0; acc = op_i(acc, leaf_i)  i < nsteps.
+ * Integer values are carried as int64, fp as double.  NULLs stay in-band exactly like the
+ * reference's *_nullable runtime functions (QE/RuntimeFunctions.cpp:49-230): each step names the
+ * sentinel of its inputs and of its result. */
+enum hdk_hip_leaf_kind { HDK_LEAF_NONE = 0, HDK_LEAF_COL = 1, HDK_LEAF_INT = 2, HDK_LEAF_FP = 3 };
+typedef struct hdk_hip_leaf {
+  int32_t kind;     /* hdk_hip_leaf_kind */
+  int32_t col;      /* index into plan->cols when kind == HDK_LEAF_COL */
+  int64_t ival;     /* literal (int), or bit pattern of the double literal */
+  int64_t null_val; /* in-band NULL of this leaf, widened (int) or double bits (fp); */
+  int32_t nullable; /* 0 => the leaf can never be NULL (null_val ignored) */
+  int32_t pad_;
+} hdk_hip_leaf;
+
+enum hdk_hip_op {
+  HDK_OP_ADD = 1, HDK_OP_SUB, HDK_OP_MUL, HDK_OP_DIV, HDK_OP_MOD, /* DEF_ARITH_NULLABLE */
+  HDK_OP_EXTRACT_YEAR,     /* omniscidb/Utils/ExtractFromTime.cpp: extract_year on epoch seconds */
+  HDK_OP_SCALE_DOWN,       /* scale_decimal_down_[not_]nullable (RuntimeFunctions.cpp:245-262) */
+  HDK_OP_FLOOR_DIV,        /* floor_div_[nullable_]lhs (:266-279) */
+  HDK_OP_CAST_INT_TO_FP,   /* cast_int64_t_to_double_nullable (:311-345) */
+  HDK_OP_CAST_FP_TO_INT    /* DEF_ROUND_NULLABLE(double,int64_t) */
+};
+typedef struct hdk_hip_step {
+  int32_t op;        /* hdk_hip_op */
+  int32_t out_class; /* hdk_hip_value_class of the result */
+  hdk_hip_leaf rhs;  /* second operand (unused by unary ops) */
+  int64_t null_out;  /* in-band NULL of the result */
+} hdk_hip_step;
+typedef struct hdk_hip_expr {
+  int32_t vclass;    /* value class of the final result */
+  int32_t nsteps;
+  hdk_hip_leaf leaf0;
+  hdk_hip_step steps[HDK_HIP_MAX_EXPR_STEPS];
+  int64_t null_val;  /* in-band NULL of the final result */
+  int32_t nullable;  /* whether the result may be NULL */
+  int32_t pad_;
+} hdk_hip_expr;
+
+/* Filter conjunct `lhs cmp rhs`, three-valued (DEF_CMP_NULLABLE, RuntimeFunctions.cpp:83-117);
+ * a row passes when every conjunct is TRUE (logical_and, :357-372; NULL does not pass). */
+enum hdk_hip_cmp { HDK_CMP_EQ = 1, HDK_CMP_NE, HDK_CMP_LT, HDK_CMP_GT, HDK_CMP_LE, HDK_CMP_GE };
+typedef struct hdk_hip_qual {
+  hdk_hip_expr lhs;
+  hdk_hip_leaf rhs;
+  int32_t cmp;
+  int32_t pad_;
+} hdk_hip_qual;
+
+/* Perfect-hash equi-join probe (hash_join_idx family, QE/GroupByRuntime.cpp:274-366). */
+enum hdk_hip_join_kind { HDK_JOIN_ONE_TO_ONE = 0, HDK_JOIN_ONE_TO_MANY = 1 };
+enum hdk_hip_join_type { HDK_JOIN_INNER = 0, HDK_JOIN_LEFT = 1 };
+enum hdk_hip_join_null { HDK_JOIN_NULL_NONE = 0, HDK_JOIN_NULL_NULLABLE = 1, HDK_JOIN_NULL_BITWISE = 2 };
+typedef struct hdk_hip_join {
+  hdk_hip_expr outer_key;
+  int64_t min_key;
+  int64_t max_key;
+  int64_t null_val;
+  int64_t translated_null; /* hash_join_idx_bitwise */
+  int64_t bucket;          /* bucket_normalization; 0/1 => plain */
+  int32_t kind;            /* hdk_hip_join_kind */
+  int32_t type;            /* hdk_hip_join_type */
+  int32_t null_mode;       /* hdk_hip_join_null */
+  int32_t table_idx;       /* which entry of JOIN_HASH_TABLES */
+} hdk_hip_join;
+
+/* Query shape: RS/QueryMemoryDescriptor.h `QueryDescriptionType`. */
+enum hdk_hip_query_kind {
+  HDK_Q_NON_GROUPED = 0,        /* NonGroupedAggregate */
+  HDK_Q_PERFECT_HASH = 1,       /* GroupByPerfectHash */
+  HDK_Q_BASELINE_HASH = 2       /* GroupByBaselineHash */
+};
+
+enum hdk_hip_agg {
+  HDK_AGG_COUNT = 0, HDK_AGG_SUM = 1, HDK_AGG_MIN = 2, HDK_AGG_MAX = 3, HDK_AGG_AVG = 4,
+  HDK_AGG_ID = 5 /* non-aggregate target = a projected group-by key, written with agg_id
+                    (QE/RuntimeFunctions.cpp:473-476); `key_idx` names the key, `arg` repeats its
+                    expression */
+};
+typedef struct hdk_hip_target {
+  int32_t agg;        /* hdk_hip_agg */
+  int32_t has_arg;    /* 0 => COUNT(*) */
+  hdk_hip_expr arg;
+  int32_t skip_null;  /* TargetInfo::skip_null_val -> *_skip_val runtime (RuntimeFunctions.cpp:612-875) */
+  int32_t slot_width; /* 4 or 8: padded slot width of the first slot (RS/ColSlotContext) */
+  int32_t slot_off;   /* row-wise: byte offset of the first slot inside the row (after keys);
+                         columnar: byte offset of the slot column from the buffer start */
+  int32_t slot2_width;/* AVG: width of the count slot */
+  int32_t slot2_off;  /* AVG: offset of the count slot */
+  int32_t arg_is_fp;  /* the slot holds a double/float bit pattern */
+  int32_t key_idx;    /* HDK_AGG_ID: index of the projected group-by key */
+  int32_t pad_;
+  int64_t null_val;   /* skip value == init value of the slot for nullable args (slot-typed bits) */
+} hdk_hip_target;
+
+typedef struct hdk_hip_plan {
+  uint32_t abi_version;     /* must be HDK_HIP_PLAN_ABI */
+  int32_t query_kind;       /* hdk_hip_query_kind */
+  /* inputs */
+  int32_t num_cols;
+  hdk_hip_col cols[HDK_HIP_MAX_COLS];
+  int32_t num_quals;
+  hdk_hip_qual quals[HDK_HIP_MAX_QUALS];
+  int32_t num_joins;
+  hdk_hip_join joins[HDK_HIP_MAX_JOINS];
+  /* group-by keys */
+  int32_t key_count;
+  hdk_hip_expr keys[HDK_HIP_MAX_KEYS];
+  int64_t key_min[HDK_HIP_MAX_KEYS];       /* perfect hash: ColRangeInfo.min */
+  int64_t key_bucket[HDK_HIP_MAX_KEYS];    /* ColRangeInfo.bucket (0 => none) */
+  int64_t key_card[HDK_HIP_MAX_KEYS];      /* getBucketedCardinality (multi-col stride factors) */
+  int64_t key_null_translated[HDK_HIP_MAX_KEYS]; /* max + (bucket?bucket:1) (RowFuncBuilder.cpp:456-461) */
+  int32_t key_has_nulls[HDK_HIP_MAX_KEYS]; /* translate NULL keys (perfect hash only) */
+  /* output layout (subset of RS/QueryMemoryDescriptor) */
+  uint32_t entry_count;
+  int32_t key_width;        /* effective key width in the buffer: 4 or 8 (perfect hash: 8) */
+  int32_t keyless;          /* hasKeylessHash */
+  int32_t idx_target_as_key;/* keyless: SLOT index whose init value marks an empty entry
+                               (QueryMemoryDescriptor::getTargetIdxForKey; AVG counts as 2 slots) */
+  int32_t output_columnar;  /* didOutputColumnar */
+  uint32_t row_size_quad;   /* row-wise: row bytes / 8 (keys + slots) */
+  int32_t num_targets;
+  hdk_hip_target targets[HDK_HIP_MAX_TARGETS];
+} hdk_hip_plan;
+#define HDK_HIP_PLAN_ABI 1u
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel launch.
+ * Replaces DeviceKernel::launch(const KernelOptions&, std::vector<int8_t*>& kernelParams)
+ * (QE/DeviceKernel.h:33-61) for the JIT'ed `multifrag_query[_hoisted_literals]`
+ * (QE/RuntimeFunctions.cpp:1692-1768).  `params` holds exactly the reference's 12 *device*
+ * pointers in the order of QE/QueryExecutionContext.h:111-125, laid out as
+ * QueryExecutionContext::prepareKernelParams builds them (QE/QueryExecutionContext.cpp:788-964).
+ * ---------------------------------------------------------------------------------------- */
+enum hdk_hip_kern_param {
+  HDK_KP_COL_BUFFERS = 0,   /* const int8_t***  [num_fragments][num_cols] */
+  HDK_KP_NUM_FRAGMENTS,     /* const uint64_t*  */
+  HDK_KP_LITERALS,          /* const int8_t*    (unused: literals live in the plan) */
+  HDK_KP_NUM_ROWS,          /* const int64_t*   [num_fragments * num_tables] */
+  HDK_KP_FRAG_ROW_OFFSETS,  /* const uint64_t*  [num_fragments * num_tables] */
+  HDK_KP_MAX_MATCHED,       /* const int32_t*   */
+  HDK_KP_TOTAL_MATCHED,     /* int32_t*         */
+  HDK_KP_INIT_AGG_VALS,     /* const int64_t*   */
+  HDK_KP_GROUPBY_BUF,       /* int64_t**        group-by: [0] = the shared output buffer;
+                                                non-grouped: out_vec, [i] = slot of target i */
+  HDK_KP_ERROR_CODE,        /* int32_t*         [grid*block]; entry 0 is written */
+  HDK_KP_NUM_TABLES,        /* const uint32_t*  */
+  HDK_KP_JOIN_HASH_TABLES,  /* 1 table: the table itself; >1: const int64_t* array of tables */
+  HDK_KP_COUNT
+};
+
+typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-43 */
+  uint32_t grid_dim_x;  /* 0 => library default (persistent grid sized from the CU count) */
+  uint32_t block_dim_x; /* 0 => library default */
+  uint32_t shared_mem_bytes; /* ignored: LDS use is decided by the kernel choice */
+  uint32_t flags;       /* HDK_HIP_LAUNCH_* */
+} hdk_hip_kernel_options;
+#define HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS 1u /* skip the LDS-privatised strategy (testing) */
+
+/* Bytes of device scratch `hdk_hip_launch` needs for this plan (per-block partial tables). */
+int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
+                               int32_t device_id, size_t* bytes);
+/* Enqueue the scan -> filter -> join-probe -> group/aggregate pass over all fragments described by
+ * `params` on `stream` (NULL = the manager's stream for `device_id`).  Asynchronous: results and
+ * error codes are complete when the stream is.  The output buffer must already be initialised
+ * (hdk_hip_init_*_group_by_buffer, or INIT_AGG_VALS copies for non-grouped out slots). */
+int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                       const hdk_hip_kernel_options* ko, int32_t device_id, void* stream,
+                       void* workspace, size_t workspace_bytes);
+/* Names of the device kernels a launch of `plan` dispatches (for profiling), comma separated. */
+int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
+                                int32_t device_id, char* out, size_t out_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Partial-result reduction on device.
+ * Replaces the host-side ResultSetReduction::reduce (QE/ResultSetReduction.cpp:174-330:
+ * perfect hash = slot-wise reduceOneSlot :1234-1330; baseline = reduceOneEntryBaseline :694-731)
+ * for per-GPU / per-launch partial buffers that already sit in HBM (e.g. after an RCCL
+ * all-gather).  `that_bufs[i]` are merged into `this_buf`; layouts come from `plan`.
+ * For HDK_Q_BASELINE_HASH `this_entry_count` may exceed `plan->entry_count` (Execute.cpp:1241-1253).
+ * ---------------------------------------------------------------------------------------- */
+int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* this_buf, uint32_t this_entry_count,
+                               const int64_t* const* that_bufs, const uint32_t* that_entry_counts,
+                               int32_t num_that, const int64_t* init_vals, int32_t* dev_error,
+                               int32_t device_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hash-join table build (perfect hash).
+ * Replaces the *_on_device free functions of QE/JoinHashTable/Runtime/HashJoinRuntime.h:66-68,
+ * 158-200 (GPU bodies QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:32-190).  Structs are the
+ * reference's PODs (HashJoinRuntime.h:43-57,100-124) with fixed-width members.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hdk_hip_join_chunk {  /* JoinChunk */
+  const int8_t* col_buff;
+  size_t num_elems;
+  size_t row_id;
+} hdk_hip_join_chunk;
+typedef struct hdk_hip_join_column { /* JoinColumn */
+  const int8_t* col_chunks_buff;     /* device array of hdk_hip_join_chunk */
+  size_t col_chunks_buff_sz;
+  size_t num_chunks;
+  size_t num_elems;
+  size_t elem_sz;
+} hdk_hip_join_column;
+enum hdk_hip_column_type { HDK_JC_SMALL_DATE = 0, HDK_JC_SIGNED = 1, HDK_JC_UNSIGNED = 2, HDK_JC_DOUBLE = 3 };
+typedef struct hdk_hip_join_column_type_info { /* JoinColumnTypeInfo */
+  size_t elem_sz;
+  int64_t min_val;
+  int64_t max_val;
+  int64_t null_val;
+  int32_t uses_bw_eq;
+  int32_t column_type; /* hdk_hip_column_type */
+  int64_t translated_null_val;
+} hdk_hip_join_column_type_info;
+typedef struct hdk_hip_hash_entry_info { /* HashEntryInfo */
+  size_t hash_entry_count;
+  int64_t bucket_normalization;
+} hdk_hip_hash_entry_info;
+
+/* init_hash_join_buff_on_device (HashJoinRuntime.h:66-68) */
+int32_t hdk_hip_init_hash_join_buff(int32_t* buff, int64_t entry_count, int32_t invalid_slot_val,
+                                    int32_t device_id, void* stream);
+/* fill_hash_join_buff_on_device[_bucketized] (HashJoinRuntime.h:158-171): one-to-one; on a duplicate
+ * key `*dev_err_buff` becomes -1 (the caller then rebuilds one-to-many, PerfectHashTableBuilder.h:134-141). */
+int32_t hdk_hip_fill_hash_join_buff(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join,
+                                    int32_t* dev_err_buff, hdk_hip_join_column join_column,
+                                    hdk_hip_join_column_type_info type_info, int32_t device_id,
+                                    void* stream);
+int32_t hdk_hip_fill_hash_join_buff_bucketized(int32_t* buff, int32_t invalid_slot_val,
+                                               int32_t for_semi_join, int32_t* dev_err_buff,
+                                               hdk_hip_join_column join_column,
+                                               hdk_hip_join_column_type_info type_info,
+                                               int64_t bucket_normalization, int32_t device_id,
+                                               void* stream);
+/* fill_one_to_many_hash_table_on_device[_bucketized] (HashJoinRuntime.h:188-200): layout
+ * [pos | count | row ids] of int32 (Builders/PerfectHashTableBuilder.h:35-38). `buff` must have been
+ * initialised with hdk_hip_init_hash_join_buff over 2*entries + num_elems slots' first 2*entries. */
+int32_t hdk_hip_fill_one_to_many_hash_table(int32_t* buff, hdk_hip_hash_entry_info hash_entry_info,
+                                            int32_t invalid_slot_val, hdk_hip_join_column join_column,
+                                            hdk_hip_join_column_type_info type_info, int32_t device_id,
+                                            void* stream);
+int32_t hdk_hip_fill_one_to_many_hash_table_bucketized(int32_t* buff,
+                                                       hdk_hip_hash_entry_info hash_entry_info,
+                                                       int32_t invalid_slot_val,
+                                                       hdk_hip_join_column join_column,
+                                                       hdk_hip_join_column_type_info type_info,
+                                                       int32_t device_id, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDK_HIP_H */
