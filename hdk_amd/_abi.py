@@ -55,6 +55,7 @@ JC_SMALL_DATE, JC_SIGNED, JC_UNSIGNED, JC_DOUBLE = 0, 1, 2, 3
  KP_TOTAL_MATCHED, KP_INIT_AGG_VALS, KP_GROUPBY_BUF, KP_ERROR_CODE, KP_NUM_TABLES,
  KP_JOIN_HASH_TABLES, KP_COUNT) = range(13)
 LAUNCH_FORCE_GLOBAL_ATOMICS = 1
+LAUNCH_RECORD_EVENTS = 2
 
 
 class Col(C.Structure):

@@ -55,6 +55,7 @@ SIGNATURES = {
     "hdk_hip_init_columnar_group_by_buffer": (i32, [v, v, u32, u32, u32, v, i32, i32, i8, sz, sz, i32, v]),
     "hdk_hip_workspace_size": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.POINTER(sz)]),
     "hdk_hip_launch": (i32, [C.POINTER(A.Plan), C.POINTER(v), C.POINTER(A.KernelOptions), i32, v, v, sz]),
+    "hdk_hip_collect_scan_times": (i32, [i32, C.POINTER(C.c_float), i32, C.POINTER(i32)]),
     "hdk_hip_describe_launch": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.c_char_p, sz]),
     "hdk_hip_reduce_buffers": (i32, [C.POINTER(A.Plan), v, u32, C.POINTER(v), C.POINTER(u32), i32, v, v,
                                      i32, v]),

@@ -395,6 +395,10 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 // =============================================================================================
 // host side: strategy choice + launch
 // =============================================================================================
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "host_common.h"
 #include "launch_common.h"
 
@@ -466,6 +470,24 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
 
 size_t workspace_bytes_for(const LaunchShape& s) {
   return kPlanRegionBytes + static_cast<size_t>(s.grid) * s.slab_words * 8;
+}
+
+// ---- optional per-launch timing of the scan kernel (HDK_HIP_LAUNCH_RECORD_EVENTS) -----------------
+// HIP events recorded on the launch stream right around the dominant kernel; bench.py collects
+// them after its final synchronize (the roofline's `achieved` is algorithmic bytes / this).
+struct ScanEventLog {
+  std::mutex mu;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static ScanEventLog g_scan_events[16];
+
+static int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+  HDK_HIP_CHECK(hipEventCreate(e0));
+  HDK_HIP_CHECK(hipEventCreate(e1));
+  HDK_HIP_CHECK(hipEventRecord(*e0, s));
+  std::lock_guard<std::mutex> lk(g_scan_events[device_id].mu);
+  g_scan_events[device_id].pending.emplace_back(*e0, *e1);
+  return HDK_HIP_OK;
 }
 
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
@@ -566,10 +588,19 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   kp.num_tables = reinterpret_cast<const uint32_t*>(params[HDK_KP_NUM_TABLES]);
   kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
 
+  const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
   if (shape.strategy == STRAT_LDS) {
     int64_t* slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(workspace) + kPlanRegionBytes);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+      st = scan_events_begin(device_id, s, &e0, &e1);
+      if (st) return st;
+    }
     st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s);
     if (st) return st;
+    if (timed) {
+      HDK_HIP_CHECK(hipEventRecord(e1, s));
+    }
     FinalizeArgs fa;
     fa.plan = d_plan;
     fa.slabs = slabs;
@@ -582,4 +613,26 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     return HDK_HIP_OK;
   }
   return launch_scan_global(plan, d_plan, kp, shape, s);
+}
+
+extern "C" int32_t hdk_hip_collect_scan_times(int32_t device_id, float* ms_out, int32_t capacity, int32_t* count) {
+  HDK_REQUIRE(count, "count is NULL");
+  HDK_REQUIRE(device_id >= 0 && device_id < 16, "bad device");
+  std::lock_guard<std::mutex> lk(g_scan_events[device_id].mu);
+  auto& v = g_scan_events[device_id].pending;
+  int32_t n = 0;
+  for (auto& pr : v) {
+    HDK_HIP_CHECK(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    HDK_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    if (ms_out && n < capacity) {
+      ms_out[n] = ms;
+    }
+    ++n;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  v.clear();
+  *count = n;
+  return HDK_HIP_OK;
 }

@@ -311,6 +311,8 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
   uint32_t flags;       /* HDK_HIP_LAUNCH_* */
 } hdk_hip_kernel_options;
 #define HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS 1u /* skip the LDS-privatised strategy (testing) */
+#define HDK_HIP_LAUNCH_RECORD_EVENTS 2u        /* bracket the scan kernel with HIP events on the launch
+                                                  stream (DeviceClock, QE/DeviceKernel.cpp:25-43) */
 
 /* Bytes of device scratch `hdk_hip_launch` needs for this plan (per-block partial tables). */
 int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
@@ -322,6 +324,10 @@ int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_op
 int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
                        const hdk_hip_kernel_options* ko, int32_t device_id, void* stream,
                        void* workspace, size_t workspace_bytes);
+/* Elapsed milliseconds of every scan kernel launched with HDK_HIP_LAUNCH_RECORD_EVENTS on
+ * `device_id` since the last call (waits for them); at most `capacity` values are written, `*count`
+ * receives how many there were. */
+int32_t hdk_hip_collect_scan_times(int32_t device_id, float* ms_out, int32_t capacity, int32_t* count);
 /* Names of the device kernels a launch of `plan` dispatches (for profiling), comma separated. */
 int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                 int32_t device_id, char* out, size_t out_len);
