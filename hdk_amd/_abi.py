@@ -56,6 +56,7 @@ JC_SMALL_DATE, JC_SIGNED, JC_UNSIGNED, JC_DOUBLE = 0, 1, 2, 3
  KP_JOIN_HASH_TABLES, KP_COUNT) = range(13)
 LAUNCH_FORCE_GLOBAL_ATOMICS = 1
 LAUNCH_RECORD_EVENTS = 2
+LAUNCH_FORCE_GENERIC = 4
 
 
 class Col(C.Structure):

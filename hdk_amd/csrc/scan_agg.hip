@@ -399,8 +399,11 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include <utility>
 #include <vector>
 
+#include <string.h>
+
 #include "host_common.h"
 #include "launch_common.h"
+#include "scan_agg_fast.h"
 
 using namespace hdk;
 
@@ -490,15 +493,158 @@ static int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e
   return HDK_HIP_OK;
 }
 
+// ---- fast-path matcher: plan -> FastArgs (scan_agg_fast.h) -----------------------------------------
+static bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* col) {
+  if (e.nsteps != 0 || e.leaf0.kind != HDK_LEAF_COL) return false;
+  const hdk_hip_col& c = p->cols[e.leaf0.col];
+  if (c.table != 0) return false;
+  *col = e.leaf0.col;
+  return true;
+}
+
+static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out) {
+  if (shape.strategy != STRAT_LDS || p->num_quals || p->num_joins || p->key_count > 1) return false;
+  if (p->query_kind == HDK_Q_BASELINE_HASH) return false;
+  int kw = 0;
+  memset(fa, 0, sizeof(*fa));
+  if (p->key_count == 1) {
+    int kc;
+    if (!plain_outer_col(p, p->keys[0], &kc)) return false;
+    const hdk_hip_col& c = p->cols[kc];
+    if (c.kind != HDK_COL_INT || p->key_bucket[0] > 1) return false;
+    kw = c.width;
+    fa->key_buf_idx = c.buf_idx;
+    fa->key_min = p->key_min[0];
+    fa->key_null = p->keys[0].null_val;
+    fa->key_null_translated = p->key_null_translated[0];
+    fa->key_translate_null = p->key_has_nulls[0] && p->keys[0].nullable;
+  }
+  int vcol = -1;
+  int vw = 0;
+  bool need_real_rowcount = false, need_real_nn = false;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_ID) {
+      if (tg.key_idx != 0) return false;
+      continue;
+    }
+    if (!tg.has_arg) {
+      if (tg.agg != HDK_AGG_COUNT) return false;
+      need_real_rowcount = true;
+      continue;
+    }
+    int c;
+    if (!plain_outer_col(p, tg.arg, &c)) return false;
+    if (vcol >= 0 && c != vcol) return false;
+    vcol = c;
+    const hdk_hip_col& col = p->cols[c];
+    const bool fp = col.kind == HDK_COL_DOUBLE;
+    if (col.kind != HDK_COL_INT && !fp) return false;
+    if (tg.agg != HDK_AGG_COUNT && (tg.arg_is_fp != 0) != fp) return false;  // no int->fp promotion here
+    if (col.width != 4 && col.width != 8) return false;
+    const int nullable = tg.skip_null && tg.arg.nullable;
+    if (vw && fa->val_nullable != nullable) return false;
+    vw = col.width;
+    fa->val_buf_idx = col.buf_idx;
+    fa->val_null = tg.arg.null_val;
+    fa->val_nullable = nullable;
+    fa->val_is_fp = fp;
+    const bool counts_rows = tg.agg == HDK_AGG_COUNT || tg.agg == HDK_AGG_AVG;
+    if (counts_rows && target_has_nn_word(tg)) need_real_nn = true;
+    if (counts_rows && !target_has_nn_word(tg)) need_real_rowcount = true;
+  }
+  if (kw == 0 && vw == 0) return false;
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  fa->wpe = wl.wpe;
+  for (int w = 0; w < wl.wpe; ++w) fa->wop[w] = wl.wop[w];
+  fa->entry_count = shape.entry_count;
+  fa->rep = shape.rep;
+  fa->mask_mode = shape.entry_count <= 64 && !need_real_rowcount && !need_real_nn;
+  int nops = 0;
+  auto push = [&](int kind, int word) {
+    if (nops < kFastMaxOps) {
+      fa->op_kind[nops] = kind;
+      fa->op_word[nops] = word;
+    }
+    ++nops;
+  };
+  if (!fa->mask_mode) push(FOP_ADD_ONE, 0);
+  for (int t = 0; t < p->num_targets; ++t) {
+    if (wl.vword[t] >= 0) {
+      int kind;
+      switch (wl.wop[wl.vword[t]]) {
+        case WOP_ADD_U64: kind = FOP_ADD_U64; break;
+        case WOP_ADD_F64: kind = FOP_ADD_F64; break;
+        case WOP_MIN_I64: kind = FOP_MIN_I64; break;
+        case WOP_MAX_I64: kind = FOP_MAX_I64; break;
+        case WOP_MIN_F64: kind = FOP_MIN_F64; break;
+        default: kind = FOP_MAX_F64; break;
+      }
+      push(kind, wl.vword[t]);
+    }
+    if (wl.nword[t] >= 0) {
+      if (fa->mask_mode) {
+        fa->nn_words[fa->n_nn_words++] = wl.nword[t];
+      } else {
+        push(FOP_ADD_ONE_NOT_NULL, wl.nword[t]);
+      }
+    }
+  }
+  if (nops > kFastMaxOps) return false;
+  fa->nops = nops;
+  *kw_out = kw;
+  *vw_out = vw;
+  return true;
+}
+
+template <int KW, int VW, int FIXED>
+static int32_t launch_direct(const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
+  constexpr int U = (KW != 0 && VW != 0) ? 4 : 8;
+  hipLaunchKernelGGL((hdk_scan_agg_direct<KW, VW, U, FIXED>), dim3(shape.grid), dim3(kFastBlock), shape.lds_bytes,
+                     s, fa);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+// compile-time op list for the single-op shapes (C2: one ds_add_u64 per row; Q1: one +1 per row)
+template <int KW>
+static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
+  const int only = fa.nops == 1 ? fa.op_kind[0] : -1;
+  switch (vw) {
+    case 0:
+      if (KW != 0 && only == FOP_ADD_ONE) return launch_direct<KW, 0, FOP_ADD_ONE>(fa, shape, s);
+      return launch_direct<KW, 0, -1>(fa, shape, s);
+    case 4:
+      return launch_direct<KW, 4, -1>(fa, shape, s);
+    default:
+      if (only == FOP_ADD_U64) return launch_direct<KW, 8, FOP_ADD_U64>(fa, shape, s);
+      if (only == FOP_ADD_F64) return launch_direct<KW, 8, FOP_ADD_F64>(fa, shape, s);
+      return launch_direct<KW, 8, -1>(fa, shape, s);
+  }
+}
+
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
-  (void)p;
-  (void)s;
-  return "hdk_scan_agg_generic";
+  FastArgs fa;
+  int kw, vw;
+  return match_fast(p, s, &fa, &kw, &vw) ? "hdk_scan_agg_direct" : "hdk_scan_agg_generic";
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
-                               const LaunchShape& shape, int64_t* slabs, hipStream_t s) {
-  (void)plan;
+                               const LaunchShape& shape, int64_t* slabs, hipStream_t s, bool force_generic) {
+  FastArgs fa;
+  int kw, vw;
+  if (!force_generic && match_fast(plan, shape, &fa, &kw, &vw)) {
+    fa.kp = kp;
+    fa.slabs = slabs;
+    switch (kw) {
+      case 0: return launch_direct_kw<0>(vw, fa, shape, s);
+      case 1: return launch_direct_kw<1>(vw, fa, shape, s);
+      case 2: return launch_direct_kw<2>(vw, fa, shape, s);
+      case 4: return launch_direct_kw<4>(vw, fa, shape, s);
+      default: return launch_direct_kw<8>(vw, fa, shape, s);
+    }
+  }
   ScanArgs a;
   a.plan = d_plan;
   a.kp = kp;
@@ -596,7 +742,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       st = scan_events_begin(device_id, s, &e0, &e1);
       if (st) return st;
     }
-    st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s);
+    st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s, ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GENERIC));
     if (st) return st;
     if (timed) {
       HDK_HIP_CHECK(hipEventRecord(e1, s));

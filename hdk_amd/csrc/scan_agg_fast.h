@@ -1,0 +1,312 @@
+// scan_agg_fast.h -- specialised scan/aggregate kernels for the shapes the headline configs use.
+//
+// Shape ("direct columns"): no filter, no join; zero or one group-by key that is a plain integer
+// column (perfect hash, with or without NULL translation); every aggregate argument is the same
+// plain column (or COUNT(*) / the projected key).  That is BASELINE C1 (SELECT SUM(a)), C2
+// (GROUP BY key, SUM(val)), taxi Q1 (GROUP BY cab_type, COUNT(*)) and Q2 (GROUP BY passenger_count,
+// AVG(total_amount)).  Everything data-dependent per row is template/SGPR resident:
+//   * column widths are template parameters, so each lane reads 16 B (R rows) of the widest column
+//     per load instruction, fully coalesced (lane i -> bytes [16 i, 16 i + 16) of the step), U steps
+//     issued back to back before the first use (8 x 16 B in flight per lane for two int64 columns);
+//   * the per-row LDS update list (which words get +1 / +val / min / max) is a handful of SGPRs;
+//   * for <= 64 entries the "entry touched" / "saw a non-NULL" facts are two 64-bit register masks
+//     per lane instead of LDS counters, leaving ONE ds_add_u64 per row for C2;
+//   * non-grouped plans accumulate in registers and touch LDS once per lane.
+// The slab format written at the end is the generic one (agg_common.h), so hdk_finalize is shared.
+#pragma once
+#include "agg_common.h"
+
+namespace hdk {
+
+constexpr int kFastBlock = 256;
+constexpr int kFastMaxOps = 8;
+
+enum FastOpKind : int32_t {
+  FOP_ADD_ONE = 0,        // rowcount: +1 for every row
+  FOP_ADD_ONE_NOT_NULL,   // non-null count: +1 when the value is not NULL
+  FOP_ADD_U64,            // += value (non-NULL rows)
+  FOP_ADD_F64,
+  FOP_MIN_I64,
+  FOP_MAX_I64,
+  FOP_MIN_F64,
+  FOP_MAX_F64
+};
+
+struct FastArgs {
+  KernParams kp;
+  int64_t* slabs;
+  int64_t key_min;
+  int64_t key_null;             // in-band NULL of the key column (widened)
+  int64_t key_null_translated;
+  int64_t val_null;             // in-band NULL of the value column (widened / double bits)
+  uint32_t entry_count;
+  uint32_t rep;
+  int32_t wpe;
+  int32_t key_buf_idx;
+  int32_t val_buf_idx;
+  int32_t key_translate_null;   // perfect hash with NULL keys
+  int32_t val_nullable;         // skip NULL values
+  int32_t val_is_fp;            // value column is double
+  int32_t mask_mode;            // entry_count <= 64 and no real counts needed
+  int32_t rowcount_word_is_flag;  // (mask mode) word 0 receives 0/1
+  int32_t nops;
+  int32_t op_kind[kFastMaxOps];
+  int32_t op_word[kFastMaxOps];
+  int32_t wop[kMaxWordsPerEntry];  // combine op per word (flush)
+  int32_t nn_words[HDK_HIP_MAX_TARGETS];  // (mask mode) words that receive the non-null flag
+  int32_t n_nn_words;
+};
+
+// column buffers are plain hipMalloc'ed global memory: say so, or the pointers loaded from
+// COL_BUFFERS are generic and every access becomes a flat_load
+typedef const __attribute__((address_space(1))) int8_t* gcol_t;
+
+// sign-extending element extraction from a 16-B (or narrower) register image
+template <int W>
+HDK_DEV int64_t extract_elem(const uint32_t* regs, int i) {
+  if (W == 8) {
+    return static_cast<int64_t>((static_cast<uint64_t>(regs[2 * i + 1]) << 32) | regs[2 * i]);
+  } else if (W == 4) {
+    return static_cast<int32_t>(regs[i]);
+  } else if (W == 2) {
+    return static_cast<int16_t>((regs[i / 2] >> (16 * (i & 1))) & 0xffff);
+  } else {
+    return static_cast<int8_t>((regs[i / 4] >> (8 * (i & 3))) & 0xff);
+  }
+}
+
+// load NB bytes (4, 8 or 16; or 2/1 for the narrowest cases) for this lane
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NB>
+HDK_DEV void load_bytes(gcol_t p, uint32_t* regs) {
+  if (NB == 16) {
+    const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(p);
+    regs[0] = v.x; regs[1] = v.y; regs[2] = v.z; regs[3] = v.w;
+  } else if (NB == 8) {
+    const u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2*>(p);
+    regs[0] = v.x; regs[1] = v.y;
+  } else if (NB == 4) {
+    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(p);
+  } else if (NB == 2) {
+    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint16_t*>(p);
+  } else {
+    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(p);
+  }
+}
+
+template <int W>
+HDK_DEV int64_t load_elem(gcol_t p, int64_t row) {
+  if (W == 8) return reinterpret_cast<const __attribute__((address_space(1))) int64_t*>(p)[row];
+  if (W == 4) return reinterpret_cast<const __attribute__((address_space(1))) int32_t*>(p)[row];
+  if (W == 2) return reinterpret_cast<const __attribute__((address_space(1))) int16_t*>(p)[row];
+  return reinterpret_cast<const __attribute__((address_space(1))) int8_t*>(p)[row];
+}
+
+HDK_DEV void fast_lds_op(int32_t kind, int64_t* wp, int64_t v) {
+  switch (kind) {
+    case FOP_ADD_ONE:
+    case FOP_ADD_ONE_NOT_NULL:
+      atomicAdd(reinterpret_cast<unsigned long long*>(wp), 1ull);
+      break;
+    case FOP_ADD_U64:
+      atomicAdd(reinterpret_cast<unsigned long long*>(wp), static_cast<unsigned long long>(v));
+      break;
+    case FOP_ADD_F64:
+      atomicAdd(reinterpret_cast<double*>(wp), bits_to_double(v));
+      break;
+    case FOP_MIN_I64:
+      atomicMin(reinterpret_cast<long long*>(wp), static_cast<long long>(v));
+      break;
+    case FOP_MAX_I64:
+      atomicMax(reinterpret_cast<long long*>(wp), static_cast<long long>(v));
+      break;
+    case FOP_MIN_F64: {
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(wp);
+      unsigned long long old = *a;
+      const double d = bits_to_double(v);
+      while (d < bits_to_double(static_cast<int64_t>(old))) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, static_cast<unsigned long long>(v));
+        if (old == assumed) break;
+      }
+      break;
+    }
+    default: {
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(wp);
+      unsigned long long old = *a;
+      const double d = bits_to_double(v);
+      while (bits_to_double(static_cast<int64_t>(old)) < d) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, static_cast<unsigned long long>(v));
+        if (old == assumed) break;
+      }
+      break;
+    }
+  }
+}
+
+struct OpList {  // the per-row LDS update list, hoisted into scalar registers
+  int32_t kind[kFastMaxOps];
+  int32_t word[kFastMaxOps];
+  int32_t n;
+};
+
+// One row: entry lookup + the LDS update list.  KW == 0 => non-grouped (entry 0).
+// FIXED >= 0: the list is exactly one op of that kind (compile-time), at word ops.word[0].
+template <int KW, int FIXED>
+HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32_t my_rep, int64_t key,
+                      int64_t val, bool has_val, uint64_t& touched, uint64_t& nonnull, int32_t& err) {
+  uint32_t entry = 0;
+  if (KW != 0) {
+    if (a.key_translate_null && key == a.key_null) {
+      key = a.key_null_translated;
+    }
+    const uint64_t e = static_cast<uint64_t>(key - a.key_min);
+    if (e >= a.entry_count) {
+      err = HDK_HIP_ERR_OUT_OF_SLOTS;
+      return;
+    }
+    entry = static_cast<uint32_t>(e);
+  }
+  bool is_null = false;
+  if (has_val && a.val_nullable) {
+    is_null = a.val_is_fp ? (bits_to_double(val) == bits_to_double(a.val_null)) : (val == a.val_null);
+  }
+  if (a.mask_mode) {
+    const uint64_t bit = 1ull << entry;
+    touched |= bit;
+    if (!is_null) {
+      nonnull |= bit;
+    }
+  }
+  int64_t* base = lds + (entry * a.wpe) * a.rep + my_rep;
+  if (FIXED >= 0) {
+    if (FIXED == FOP_ADD_ONE || !is_null) {
+      fast_lds_op(FIXED, base + ops.word[0] * a.rep, val);
+    }
+    return;
+  }
+#pragma unroll
+  for (int o = 0; o < kFastMaxOps; ++o) {
+    if (o < ops.n) {
+      const int32_t kind = ops.kind[o];
+      if (kind == FOP_ADD_ONE || !is_null) {
+        fast_lds_op(kind, base + ops.word[o] * a.rep, val);
+      }
+    }
+  }
+}
+
+// R = rows per lane per step (16 B of the widest column); U = steps per tile.
+template <int KW, int VW, int U, int FIXED>
+__global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  __shared__ unsigned long long s_masks[2];
+  constexpr int WMAX = (KW > VW ? KW : VW) == 0 ? 8 : (KW > VW ? KW : VW);
+  constexpr int R = 16 / WMAX;
+  constexpr int KB = KW * R;  // bytes per lane per step, key column
+  constexpr int VB = VW * R;
+  constexpr int KREGS = KB >= 4 ? KB / 4 : 1;
+  constexpr int VREGS = VB >= 4 ? VB / 4 : 1;
+  const int tid = threadIdx.x;
+  const uint32_t rep = a.rep;
+  const int wpe = a.wpe;
+  const uint32_t ew = a.entry_count * wpe;
+  const uint32_t total_words = ew * rep;
+  for (uint32_t i = tid; i < total_words; i += kFastBlock) {
+    lds[i] = word_identity(a.wop[(i / rep) % wpe]);
+  }
+  if (tid < 2) {
+    s_masks[tid] = 0;
+  }
+  __syncthreads();
+
+  OpList ops;
+  ops.n = a.nops;
+#pragma unroll
+  for (int o = 0; o < kFastMaxOps; ++o) {
+    ops.kind[o] = a.op_kind[o];
+    ops.word[o] = a.op_word[o];
+  }
+  const uint32_t my_rep = tid & (rep - 1);
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  constexpr int64_t kTileRows = static_cast<int64_t>(kFastBlock) * R * U;
+  uint64_t touched = 0, nonnull = 0;
+  int32_t err = 0;
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    const int8_t* const* cols = a.kp.col_buffers[f];
+    const gcol_t kcol = KW ? (gcol_t)cols[a.key_buf_idx] : nullptr;
+    const gcol_t vcol = VW ? (gcol_t)cols[a.val_buf_idx] : nullptr;
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
+      if (row0 + kTileRows <= nrows) {
+        // full tile: U coalesced 16-B steps per column, all issued before the first use
+        uint32_t kr[U][KREGS];
+        uint32_t vr[U][VREGS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t r = row0 + (static_cast<int64_t>(u) * kFastBlock + tid) * R;
+          if (KW) load_bytes<(KB > 0 ? KB : 4)>(kcol + r * KW, kr[u]);
+          if (VW) load_bytes<(VB > 0 ? VB : 4)>(vcol + r * VW, vr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const int64_t key = KW ? extract_elem<(KW ? KW : 8)>(kr[u], i) : 0;
+            const int64_t val = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
+            fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+          }
+        }
+      } else {
+        // ragged tail of a fragment: one row per lane per pass
+        for (int64_t r = row0 + tid; r < nrows; r += kFastBlock) {
+          const int64_t key = KW ? load_elem<(KW ? KW : 8)>(kcol, r) : 0;
+          const int64_t val = VW ? load_elem<(VW ? VW : 8)>(vcol, r) : 0;
+          fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+  if (a.mask_mode) {
+    if (touched) atomicOr(&s_masks[0], static_cast<unsigned long long>(touched));
+    if (nonnull) atomicOr(&s_masks[1], static_cast<unsigned long long>(nonnull));
+  }
+  __syncthreads();
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += kFastBlock) {
+    const uint32_t w = i % wpe;
+    const uint32_t e = i / wpe;
+    const int32_t op = a.wop[w];
+    int64_t acc = lds[i * rep];
+    for (uint32_t r = 1; r < rep; ++r) {
+      acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    if (a.mask_mode) {
+      if (w == 0) {
+        acc = (s_masks[0] >> e) & 1;  // "row count" degenerates to touched/not touched
+      } else {
+        for (int k = 0; k < a.n_nn_words; ++k) {
+          if (static_cast<uint32_t>(a.nn_words[k]) == w) {
+            acc = (s_masks[1] >> e) & 1;
+          }
+        }
+      }
+    }
+    slab[i] = acc;
+  }
+}
+
+}  // namespace hdk

@@ -19,6 +19,9 @@ def _check(O, make, st, q, grid=0, flags=0):
     ex = make(st)
     res = ex.execute(cp, grid=grid, flags=flags)
     assert_buffers_equal(cp, res.buffer, want)
+    # the plan-interpreter kernel must agree too (it is the fallback for every other shape)
+    res_g = ex.execute(cp, grid=grid, flags=flags | A.LAUNCH_FORCE_GENERIC)
+    assert_buffers_equal(cp, res_g.buffer, want)
     return cp, res
 
 
