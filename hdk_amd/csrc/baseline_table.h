@@ -1,0 +1,87 @@
+// baseline_table.h -- open-addressing (baseline hash) group lookup on the device.
+//
+// Device restatement of get_group_value / get_group_value_columnar_slot with the CUDA twin's claim
+// protocol (reference QE/GroupByRuntime.cpp:31-113; QE/cuda_mapd_rt.cu:167-261): MurmurHash3 of the
+// packed key, linear probe, CAS on the first key component, remaining components published by the
+// winner and awaited by readers.
+#pragma once
+#include "device_common.h"
+
+namespace hdk {
+
+HDK_DEV uint32_t key_hash_dev(const int64_t* key, int key_count, int key_width) {
+  // key_hash = MurmurHash3(key, width*count, 0) (QE/GroupByRuntime.cpp:24-29)
+  return murmur_hash3_words(reinterpret_cast<const uint32_t*>(key), key_count * key_width / 4, 0);
+}
+
+template <typename K>
+HDK_DEV K empty_key();
+template <>
+HDK_DEV int64_t empty_key<int64_t>() { return HDK_EMPTY_KEY_64; }
+template <>
+HDK_DEV int32_t empty_key<int32_t>() { return HDK_EMPTY_KEY_32; }
+
+HDK_DEV int64_t atomic_load_i64(const int64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+HDK_DEV int32_t atomic_load_i32(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Find or claim the entry of `key` (packed components of width K) in a baseline table.
+// Returns the entry index or -1 (table full); *fresh tells whether this call created it.
+// Row-wise (get_matching_group_value, QE/cuda_mapd_rt.cu:167-203): CAS the first component, write
+// the rest, readers spin until the last component is published.  Columnar
+// (get_matching_group_value_columnar_slot, :229-261) likewise per key column.
+template <typename K>
+HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entry_count, const K* key,
+                              bool* fresh) {
+  const int nk = p->key_count;
+  const bool columnar = p->output_columnar;
+  const uint32_t h = key_hash_dev(reinterpret_cast<const int64_t*>(key), nk, sizeof(K)) % entry_count;
+  uint32_t probe = h;
+  const K ek = empty_key<K>();
+  do {
+    K* k0 = columnar ? reinterpret_cast<K*>(buf) + probe
+                     : reinterpret_cast<K*>(buf + static_cast<size_t>(probe) * p->row_size_quad);
+    const size_t kstride = columnar ? entry_count : 1;
+    K old;
+    if constexpr (sizeof(K) == 8) {
+      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(k0), static_cast<unsigned long long>(ek),
+                                     static_cast<unsigned long long>(key[0])));
+    } else {
+      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(k0), static_cast<unsigned int>(ek),
+                                     static_cast<unsigned int>(key[0])));
+    }
+    if (old == ek) {
+      for (int i = 1; i < nk; ++i) {
+        __hip_atomic_store(k0 + i * kstride, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *fresh = true;
+      return probe;
+    }
+    if (old == key[0]) {
+      bool match = true;
+      for (int i = 1; i < nk && match; ++i) {
+        K v;
+        do {  // the winner may still be publishing the remaining components
+          if constexpr (sizeof(K) == 8) {
+            v = atomic_load_i64(reinterpret_cast<const int64_t*>(k0 + i * kstride));
+          } else {
+            v = atomic_load_i32(reinterpret_cast<const int32_t*>(k0 + i * kstride));
+          }
+        } while (v == ek);
+        match = v == key[i];
+      }
+      if (match) {
+        *fresh = false;
+        return probe;
+      }
+    }
+    probe = (probe + 1) % entry_count;
+  } while (probe != h);
+  return -1;
+}
+
+
+}  // namespace hdk

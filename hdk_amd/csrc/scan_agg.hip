@@ -404,6 +404,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "host_common.h"
 #include "launch_common.h"
 #include "scan_agg_fast.h"
+#include "scan_agg_global.h"
 
 using namespace hdk;
 
@@ -660,12 +661,14 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
 static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
                                   const KernParams& kp, const LaunchShape& shape, hipStream_t s) {
   (void)plan;
-  (void)d_plan;
-  (void)kp;
-  (void)shape;
-  (void)s;
-  set_error("baseline-hash / large perfect-hash plans are not implemented yet");
-  return HDK_HIP_ERR_UNSUPPORTED;
+  GlobalArgs a;
+  a.plan = d_plan;
+  a.kp = kp;
+  a.entry_count = shape.entry_count;
+  a.rows_per_tile = kGlobalBlock * 4;
+  hipLaunchKernelGGL(hdk_scan_agg_global, dim3(shape.grid), dim3(kGlobalBlock), 0, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
 }
 
 }  // namespace hdk

@@ -1,0 +1,106 @@
+"""GPU parity for the global-atomics strategy: GroupByBaselineHash (open addressing, config C5's
+shape) and perfect-hash tables forced off LDS.  Slot positions of a baseline table depend on
+insertion order, so buffers are compared as {key -> slots} after decoding; keys/ints bit-exact."""
+import numpy as np
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd import result_set as rs
+from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+from util import assert_buffers_equal, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(cp, buf):
+    cols = rs.to_columns(cp, buf)
+    names = list(cols)
+    return sorted(zip(*[cols[n] for n in names]), key=lambda r: tuple((x is None, x) for x in r[:cp.plan.key_count]))
+
+
+def _check_rows(cp, got_buf, want_buf, rtol=1e-6):
+    g, w = _rows(cp, got_buf), _rows(cp, want_buf)
+    assert len(g) == len(w)
+    for a, b in zip(g, w):
+        for x, y in zip(a, b):
+            if isinstance(y, float) and y is not None:
+                assert x is not None and abs(x - y) <= rtol * max(1e-300, abs(y)), (a, b)
+            else:
+                assert x == y, (a, b)
+
+
+@pytest.mark.parametrize("columnar", [False, True])
+def test_baseline_single_key(oracle, gpu_executor_factory, columnar):
+    rng = np.random.default_rng(99)
+    n = 400_000
+    key = rng.integers(0, 50_000, n, dtype=np.int64) * 1_000_003  # sparse range -> baseline hash
+    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    val[rng.random(n) < 0.02] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": key, "val": val}, fragment_size=120_000)
+    q = QueryUnit("t", groupby=[ColRef("key")], output_columnar=columnar, force_baseline=True,
+                  baseline_entry_count=131_071,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s"), Agg("count", None, "c"),
+                           Agg("min", ColRef("val"), "mn"), Agg("max", ColRef("val"), "mx")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.query_kind == A.Q_BASELINE_HASH
+    res = gpu_executor_factory(st).execute(cp)
+    _check_rows(cp, res.buffer, want)
+    assert res.row_count() == len(np.unique(key))
+
+
+def test_baseline_multi_key_int32_and_fp(oracle, gpu_executor_factory):
+    rng = np.random.default_rng(100)
+    n = 200_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": rng.integers(0, 300, n).astype(np.int32), "b": rng.integers(-40, 40, n).astype(np.int32),
+                          "f": rng.normal(size=n)}, fragment_size=64_000)
+    q = QueryUnit("t", groupby=[ColRef("a"), ColRef("b")], force_baseline=True, baseline_entry_count=60_013,
+                  targets=[KeyRef(0, "a"), KeyRef(1, "b"), Agg("avg", ColRef("f"), "af"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.key_width == 4
+    res = gpu_executor_factory(st).execute(cp)
+    _check_rows(cp, res.buffer, want)
+
+
+def test_baseline_table_full_reports_out_of_slots(oracle, gpu_executor_factory):
+    from hdk_amd._lib import HdkHipError
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": np.arange(1000, dtype=np.int64) * 7919, "v": np.ones(1000, dtype=np.int64)})
+    q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=100,
+                  targets=[KeyRef(0), Agg("sum", ColRef("v"))])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == A.ERR_OUT_OF_SLOTS  # reference: get_group_value -> NULL -> ERR_OUT_OF_SLOTS
+    with pytest.raises(HdkHipError) as ei:
+        gpu_executor_factory(st).execute(cp)
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS
+
+
+def test_perfect_hash_via_global_atomics(oracle, gpu_executor_factory):
+    """Same plans as the LDS strategy, forced onto the global-atomics kernel: buffers must be identical."""
+    rng = np.random.default_rng(101)
+    n = 250_000
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    v[rng.random(n) < 0.1] = A.NULL_BIGINT
+    k = rng.integers(0, 5000, n).astype(np.int64)
+    k[rng.random(n) < 0.01] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": k, "v": v, "d": rng.normal(size=n)}, fragment_size=70_000)
+    for columnar in (False, True):
+        q = QueryUnit("t", groupby=[ColRef("k")], output_columnar=columnar,
+                      targets=[KeyRef(0), Agg("sum", ColRef("v")), Agg("count", ColRef("v")), Agg("min", ColRef("v")),
+                               Agg("max", ColRef("d")), Agg("avg", ColRef("d"))])
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        res = gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS)
+        assert_buffers_equal(cp, res.buffer, want)
+    # large perfect-hash table (does not fit LDS): default strategy must pick global atomics by itself
+    k2 = rng.integers(0, 200_000, n).astype(np.int64)
+    st.import_numpy("u", {"k": k2, "v": v}, fragment_size=70_000)
+    q = QueryUnit("u", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v")), Agg("count")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert cp.plan.query_kind == A.Q_PERFECT_HASH and cp.entry_count >= 199_000
+    res = gpu_executor_factory(st).execute(cp)
+    assert_buffers_equal(cp, res.buffer, want)

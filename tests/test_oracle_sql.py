@@ -1,0 +1,115 @@
+"""SQL-level pins of the oracle: the reference's taxi Q1-Q4 known answers and SQLite as an independent
+second opinion (the reference's own test method, Tests/ArrowSQLRunner/SQLiteComparator.cpp:68-120)."""
+import sqlite3
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd import result_set as rs
+from hdk_amd.ir import Agg, Cmp, ColRef, JoinSpec, KeyRef, Lit, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+from taxi import check_taxi_results, load_taxi, taxi_queries
+from util import run_oracle
+
+
+def test_taxi_q1_q4_known_answers(oracle):
+    for frag in (None, 7):
+        st = ArrowStorage()
+        load_taxi(st, frag)
+        cols = []
+        for q in taxi_queries():
+            cp, buf, err = run_oracle(oracle, st, q)
+            assert err == 0
+            cols.append(rs.to_columns(cp, buf))
+        check_taxi_results(*cols)
+
+
+def _sqlite(tables, sql):
+    con = sqlite3.connect(":memory:")
+    for name, cols in tables.items():
+        names = list(cols)
+        con.execute(f"create table {name} ({', '.join(names)})")
+        rows = list(zip(*[cols[n] for n in names]))
+        con.executemany(f"insert into {name} values ({', '.join('?' * len(names))})", rows)
+    return con.execute(sql).fetchall()
+
+
+def _rows(cols, order):
+    names = list(cols)
+    rows = list(zip(*[cols[n] for n in names]))
+    return sorted(rows, key=lambda r: tuple((x is None, x) for x in (r[i] for i in order)))
+
+
+def test_groupby_vs_sqlite(oracle):
+    rng = np.random.default_rng(42)
+    n = 5000
+    k = rng.integers(-3, 20, n).tolist()
+    v = [None if rng.random() < 0.1 else int(x) for x in rng.integers(-1000, 1000, n)]
+    f = [None if rng.random() < 0.1 else float(x) for x in rng.normal(size=n)]
+    kk = [None if rng.random() < 0.05 else x for x in k]
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array(kk, pa.int32()), "v": pa.array(v, pa.int64()), "f": pa.array(f, pa.float64())}),
+                    "t", fragment_size=1300)
+    q = QueryUnit("t", groupby=[ColRef("k")],
+                  targets=[KeyRef(0, "k"), Agg("count", None, "c"), Agg("count", ColRef("v"), "cv"),
+                           Agg("sum", ColRef("v"), "s"), Agg("min", ColRef("v"), "mn"), Agg("max", ColRef("v"), "mx"),
+                           Agg("avg", ColRef("f"), "af")])
+    cp, buf, err = run_oracle(oracle, st, q)
+    assert err == 0
+    got = _rows(rs.to_columns(cp, buf), [0])
+    want = _sqlite({"t": {"k": kk, "v": v, "f": f}},
+                   "select k, count(*), count(v), sum(v), min(v), max(v), avg(f) from t group by k")
+    want = sorted(want, key=lambda r: (r[0] is None, r[0]))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[:6] == w[:6]
+        assert (g[6] is None and w[6] is None) or abs(g[6] - w[6]) <= 1e-9 * max(1, abs(w[6]))
+
+
+def test_filter_nongrouped_vs_sqlite(oracle):
+    rng = np.random.default_rng(43)
+    n = 4000
+    a = rng.integers(0, 100, n).tolist()
+    b = [None if rng.random() < 0.2 else int(x) for x in rng.integers(-50, 50, n)]
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"a": pa.array(a, pa.int64()), "b": pa.array(b, pa.int32())}), "t", fragment_size=999)
+    q = QueryUnit("t", quals=[Cmp(ColRef("a"), ">", Lit(30)), Cmp(ColRef("b"), "<=", Lit(10))],
+                  targets=[Agg("count", None, "c"), Agg("sum", ColRef("b") + ColRef("a"), "s"), Agg("min", ColRef("b"), "m")])
+    cp, buf, err = run_oracle(oracle, st, q)
+    assert err == 0
+    got = rs.to_columns(cp, buf)
+    want = _sqlite({"t": {"a": a, "b": b}}, "select count(*), sum(b + a), min(b) from t where a > 30 and b <= 10")[0]
+    assert (got["c"][0], got["s"][0], got["m"][0]) == want
+
+
+def test_join_vs_sqlite(oracle):
+    rng = np.random.default_rng(44)
+    nd, nf = 200, 6000
+    dkey = rng.permutation(nd).astype(np.int64) + 1000
+    dval = rng.integers(0, 1000, nd).astype(np.int64)
+    fk = rng.integers(990, 1000 + nd + 10, nf).astype(np.int64)  # some keys miss the dim table
+    val = rng.integers(-100, 100, nf).astype(np.int64)
+    st = ArrowStorage()
+    st.import_numpy("dim", {"key": dkey, "dval": dval}, fragment_size=64)
+    st.import_numpy("fact", {"fk": fk, "val": val}, fragment_size=1700)
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")],
+                  targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"), "s"), Agg("count", None, "c")])
+    cp, buf, err = run_oracle(oracle, st, q)
+    assert err == 0
+    got = rs.to_columns(cp, buf)
+    want = _sqlite({"dim": {"key": dkey.tolist(), "dval": dval.tolist()}, "fact": {"fk": fk.tolist(), "val": val.tolist()}},
+                   "select sum(val + dval), count(*) from fact join dim on fact.fk = dim.key")[0]
+    assert (got["s"][0], got["c"][0]) == want
+    # grouped by a dim column
+    q2 = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") / 100],
+                   targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s")])
+    cp, buf, err = run_oracle(oracle, st, q2)
+    assert err == 0
+    got = _rows(rs.to_columns(cp, buf), [0])
+    want = sorted(_sqlite({"dim": {"key": dkey.tolist(), "dval": dval.tolist()},
+                           "fact": {"fk": fk.tolist(), "val": val.tolist()}},
+                          "select dval / 100, sum(val) from fact join dim on fact.fk = dim.key group by dval / 100"))
+    assert got == want

@@ -1,0 +1,127 @@
+"""Randomised symbol-by-symbol comparison of the oracle with the REFERENCE's own compiled runtime
+(oracle/_ref/libhdk_ref_runtime.so).  Skipped where that library was not built (no /root/reference);
+tests/test_oracle_golden.py pins the same functions through committed vectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+NULL64 = -(2**63)
+EMPTY64 = 2**63 - 1
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built on this machine")
+    return R
+
+
+def test_hash_and_decode(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        n = int(rng.integers(1, 6))
+        a = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+        assert L.orc_key_hash(a.ctypes.data, n, 8) == ref.key_hash(a.ctypes.data, n, 8)
+        assert L.orc_murmur_hash1(a.ctypes.data, 8 * n, 0) == ref.MurmurHash1(a.ctypes.data, 8 * n, 0)
+        assert L.orc_murmur_hash64a(a.ctypes.data, 8 * n, 0) == ref.MurmurHash64A(a.ctypes.data, 8 * n, 0)
+    raw = rng.integers(-128, 127, 64, dtype=np.int8)
+    for w in (1, 2, 4, 8):
+        for pos in range(64 // w):
+            assert L.orc_fixed_width_int_decode(raw.ctypes.data, w, pos) == ref.fixed_width_int_decode(raw.ctypes.data, w, pos)
+            assert L.orc_fixed_width_unsigned_decode(raw.ctypes.data, w, pos) == \
+                ref.fixed_width_unsigned_decode(raw.ctypes.data, w, pos)
+
+
+@pytest.mark.parametrize("nkeys,kw", [(1, 8), (2, 8), (1, 4), (3, 4)])
+def test_baseline_group_lookup_random(oracle, ref, nkeys, kw):
+    L = oracle.lib()
+    rng = np.random.default_rng(nkeys * 10 + kw)
+    n = 37
+    rsq = (nkeys * kw + 7) // 8 + 1
+    def fresh():
+        b = np.zeros(n * rsq, dtype=np.int64)
+        if kw == 8:
+            b.reshape(n, rsq)[:, :nkeys] = EMPTY64
+        else:
+            b.view(np.int32).reshape(n, rsq * 2)[:, :nkeys] = 2**31 - 1
+        return b
+    a, b = fresh(), fresh()
+    for _ in range(300):
+        key = rng.integers(0, 7, nkeys).astype(np.int64 if kw == 8 else np.int32)
+        pa = L.orc_get_group_value(a.ctypes.data, n, key.ctypes.data, nkeys, kw, rsq)
+        pb = ref.get_group_value(b.ctypes.data, n, key.ctypes.data, nkeys, kw, rsq)
+        oa = -1 if not pa else (pa - a.ctypes.data) // 8
+        ob = -1 if not pb else (pb - b.ctypes.data) // 8
+        assert oa == ob
+        if pa:
+            a[oa] += 1
+            b[ob] += 1
+    assert np.array_equal(a, b)
+
+
+def test_columnar_group_lookup_random(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    n, nk = 29, 2
+    a = np.zeros(n * (nk + 1), dtype=np.int64)
+    a[:n * nk] = EMPTY64
+    b = a.copy()
+    for _ in range(200):
+        key = rng.integers(0, 6, nk).astype(np.int64)
+        sa = L.orc_get_group_value_columnar_slot(a.ctypes.data, n, key.ctypes.data, nk, 8)
+        sb = ref.get_group_value_columnar_slot(b.ctypes.data, n, key.ctypes.data, nk, 8)
+        assert sa == sb
+    assert np.array_equal(a, b)
+
+
+def test_aggregates_random(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(9)
+    for name in ("sum", "min", "max"):
+        a = np.array([NULL64], dtype=np.int64)
+        b = a.copy()
+        a32 = np.array([-(2**31)], dtype=np.int32)
+        b32 = a32.copy()
+        for _ in range(500):
+            v = int(rng.integers(-2**40, 2**40)) if rng.random() > 0.1 else NULL64
+            getattr(L, f"orc_agg_{name}_skip_val")(a.ctypes.data, v, NULL64)
+            getattr(ref, f"agg_{name}_skip_val")(b.ctypes.data, v, NULL64)
+            v32 = int(rng.integers(-1000, 1000)) if rng.random() > 0.1 else -(2**31)
+            getattr(L, f"orc_agg_{name}_int32_skip_val")(a32.ctypes.data, v32, -(2**31))
+            getattr(ref, f"agg_{name}_int32_skip_val")(b32.ctypes.data, v32, -(2**31))
+        assert a[0] == b[0] and a32[0] == b32[0]
+    nulld = float(np.array([0x0010000000000000], dtype=np.int64).view(np.float64)[0])
+    for name in ("sum", "min", "max"):
+        a = np.array([0x0010000000000000], dtype=np.int64)
+        b = a.copy()
+        for _ in range(300):
+            v = float(rng.normal()) if rng.random() > 0.1 else nulld
+            getattr(L, f"orc_agg_{name}_double_skip_val")(a.ctypes.data, v, nulld)
+            getattr(ref, f"agg_{name}_double_skip_val")(b.ctypes.data, v, nulld)
+        assert a[0] == b[0]
+
+
+def test_scalar_random(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(13)
+    for _ in range(3000):
+        t = int(rng.integers(-10**11, 10**11))
+        assert L.orc_extract_year(t) == ref.extract_year(t), t
+        x = int(rng.integers(-10**12, 10**12))
+        s = int(10 ** rng.integers(1, 6))
+        assert L.orc_scale_decimal_down_nullable(x, s, NULL64) == ref.scale_decimal_down_nullable(x, s, NULL64)
+        assert L.orc_floor_div_lhs(x, s) == ref.floor_div_lhs(x, s)
+
+
+def test_join_probe_random(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(17)
+    table = rng.integers(-1, 50, 40).astype(np.int32)
+    for _ in range(500):
+        k = int(rng.integers(-5, 60))
+        assert L.orc_hash_join_idx(table.ctypes.data, k, 3, 42) == ref.hash_join_idx(table.ctypes.data, k, 3, 42)
+        assert L.orc_hash_join_idx_nullable(table.ctypes.data, k, 3, 42, 7) == \
+            ref.hash_join_idx_nullable(table.ctypes.data, k, 3, 42, 7)
