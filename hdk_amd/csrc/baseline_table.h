@@ -41,7 +41,14 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
   const uint32_t h = key_hash_dev(reinterpret_cast<const int64_t*>(key), nk, sizeof(K)) % entry_count;
   uint32_t probe = h;
   const K ek = empty_key<K>();
-  do {
+  uint32_t steps = 0;
+  int64_t result = -2;  // -2: still probing
+  *fresh = false;
+  // Wave-safe form of the reference's "winner publishes, readers spin" protocol: a reader that finds
+  // a half-published key does NOT spin inside the iteration (the publisher may be a lane of the same
+  // wave, masked off until the branches reconverge) -- it re-examines the same slot on the next trip
+  // of this loop, by which time every lane of the wave has passed the publishing block.
+  while (result == -2) {
     K* k0 = columnar ? reinterpret_cast<K*>(buf) + probe
                      : reinterpret_cast<K*>(buf + static_cast<size_t>(probe) * p->row_size_quad);
     const size_t kstride = columnar ? entry_count : 1;
@@ -53,35 +60,48 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
       old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(k0), static_cast<unsigned int>(ek),
                                      static_cast<unsigned int>(key[0])));
     }
-    if (old == ek) {
+    const bool won = old == ek;
+    if (won) {
       for (int i = 1; i < nk; ++i) {
         __hip_atomic_store(k0 + i * kstride, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       *fresh = true;
-      return probe;
+      result = probe;
     }
-    if (old == key[0]) {
+    bool advance = !won;
+    if (!won && old == key[0]) {
       bool match = true;
-      for (int i = 1; i < nk && match; ++i) {
+      bool pending = false;
+      for (int i = 1; i < nk; ++i) {
         K v;
-        do {  // the winner may still be publishing the remaining components
-          if constexpr (sizeof(K) == 8) {
-            v = atomic_load_i64(reinterpret_cast<const int64_t*>(k0 + i * kstride));
-          } else {
-            v = atomic_load_i32(reinterpret_cast<const int32_t*>(k0 + i * kstride));
-          }
-        } while (v == ek);
-        match = v == key[i];
+        if constexpr (sizeof(K) == 8) {
+          v = atomic_load_i64(reinterpret_cast<const int64_t*>(k0 + i * kstride));
+        } else {
+          v = atomic_load_i32(reinterpret_cast<const int32_t*>(k0 + i * kstride));
+        }
+        if (v == ek && key[i] != ek) {
+          pending = true;  // the winner has not published this component yet
+        } else if (v != key[i]) {
+          match = false;
+        }
       }
-      if (match) {
-        *fresh = false;
-        return probe;
+      if (!match) {
+        advance = true;
+      } else if (pending) {
+        advance = false;  // look at this slot again
+      } else {
+        result = probe;
+        advance = false;
       }
     }
-    probe = (probe + 1) % entry_count;
-  } while (probe != h);
-  return -1;
+    if (result == -2 && advance) {
+      probe = (probe + 1) % entry_count;
+      if (++steps >= entry_count) {
+        result = -1;  // wrapped around: table full
+      }
+    }
+  }
+  return result;
 }
-
 
 }  // namespace hdk

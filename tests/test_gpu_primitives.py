@@ -89,9 +89,10 @@ def test_join_build_kats_and_random(mgr, oracle):
     L = lib()
     O = oracle
     rng = np.random.default_rng(3)
+    perm = rng.permutation(100_000).astype(np.int64) + 17
     cases = [([np.arange(10, dtype=np.int32)], True), ([np.array([0, 1, 2, 4, 5, 6, 7, 9], dtype=np.int32)], True),
              ([np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4], dtype=np.int32)], False),
-             ([rng.permutation(100_000).astype(np.int64)[i::3] + 17 for i in range(3)], True),
+             ([np.ascontiguousarray(perm[i::3]) for i in range(3)], True),
              ([rng.integers(5, 5000, 20_000).astype(np.int32), rng.integers(5, 5000, 7_001).astype(np.int32)], False)]
     for arrays, unique in cases:
         allk = np.concatenate(arrays)
