@@ -1,0 +1,141 @@
+"""Host logic: layout decisions mirror the reference's MemoryLayoutBuilder / QueryMemoryDescriptor rules
+(file:line cited per case).  CPU only."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd.ir import Agg, BinOp, Cast, ColRef, ExtractYear, INT32, KeyRef, Lit, QueryMustRunOnCpu, QueryUnit
+from hdk_amd.plan import (compact_init_vals, columnar_slot_offsets, compile_query, init_buffer_host)
+from hdk_amd.storage import ArrowStorage
+
+
+def _st(n=1000, nulls=False, keys=64):
+    rng = np.random.default_rng(1)
+    val = rng.integers(-2**31, 2**31, n).astype(np.int64)
+    if nulls:
+        val[::17] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": rng.integers(0, keys, n).astype(np.int64), "val": val}, fragment_size=300)
+    return st
+
+
+def test_c2_layout_keyless_when_sum_arg_has_no_nulls():
+    # get_keyless_info (MemoryLayoutBuilder.cpp:296-325): SUM over a nullable-typed column whose range
+    # has no NULLs can never equal its init value -> keyless, slot index 1 marks empty entries
+    cp = compile_query(_st(), QueryUnit("t", groupby=[ColRef("key")],
+                                        targets=[KeyRef(0), Agg("sum", ColRef("val"))]))
+    p = cp.plan
+    assert p.query_kind == A.Q_PERFECT_HASH and p.entry_count == 64
+    assert p.keyless == 1 and p.idx_target_as_key == 1
+    assert p.row_size_quad == 2 and cp.buffer_bytes == 64 * 16
+    assert cp.init_vals.tolist() == [0, A.NULL_BIGINT]
+    assert p.targets[0].slot_off == 0 and p.targets[1].slot_off == 8
+
+
+def test_c2_layout_keyed_when_nulls_present():
+    cp = compile_query(_st(nulls=True), QueryUnit("t", groupby=[ColRef("key")],
+                                                  targets=[KeyRef(0), Agg("sum", ColRef("val"))]))
+    p = cp.plan
+    assert p.keyless == 0 and p.row_size_quad == 3  # [key][key target][sum]
+    assert p.targets[0].slot_off == 8 and p.targets[1].slot_off == 16
+    buf = init_buffer_host(cp).reshape(64, 3)
+    assert (buf[:, 0] == A.EMPTY_KEY_64).all() and (buf[:, 1] == 0).all() and (buf[:, 2] == A.NULL_BIGINT).all()
+
+
+def test_null_keys_add_an_entry_and_translate():
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array([5, None, 7, 9], pa.int32()), "v": pa.array([1, 2, 3, 4], pa.int64())}), "t")
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("count")]))
+    p = cp.plan
+    # getBucketedCardinality: max-min+1 (+1 with nulls) (ColRangeInfo.cpp:24-27); NULL -> max+1 (RowFuncBuilder.cpp:456-461)
+    assert p.entry_count == 6 and p.key_has_nulls[0] == 1 and p.key_null_translated[0] == 10 and p.key_min[0] == 5
+
+
+def test_compact_count_slots():
+    # pick_target_compact_width (MemoryLayoutBuilder.cpp:559-652): single key, COUNT(*) only -> 4-byte slots
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"c": pa.array(["green", "yellow", "green"])}), "t")
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("c")], targets=[KeyRef(0), Agg("count")]))
+    assert cp.slot_widths == [4, 4] and cp.plan.row_size_quad == 1 and cp.plan.keyless == 1
+    cp8 = compile_query(st, QueryUnit("t", groupby=[ColRef("c")], targets=[KeyRef(0), Agg("count")], bigint_count=True))
+    assert cp8.slot_widths == [8, 8]
+    assert compact_init_vals(cp).tolist() == [0]
+
+
+def test_perfect_vs_baseline_switch():
+    st = ArrowStorage()
+    n = 100
+    st.import_numpy("t", {"a": np.arange(n, dtype=np.int64) * 10_000_000, "b": np.arange(n, dtype=np.int64) % 7,
+                          "c": np.arange(n, dtype=np.int64) % 5})
+    # single column: range >= 2^30 / ((keys+targets)*8) -> baseline (MemoryLayoutBuilder.cpp:176-179,228-236)
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("a")], targets=[KeyRef(0), Agg("count")]))
+    assert cp.plan.query_kind == A.Q_BASELINE_HASH
+    # multi column: product of cardinalities <= baseline_threshold -> perfect, entry_count = product (:121-162)
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("b"), ColRef("c")], targets=[KeyRef(0), KeyRef(1), Agg("count")]))
+    assert cp.plan.query_kind == A.Q_PERFECT_HASH and cp.plan.entry_count == 35 and cp.plan.keyless == 0
+    assert [cp.plan.key_card[i] for i in range(2)] == [7, 5]
+    # modulo has no expression range -> baseline (ExpressionRange.cpp:416-419)
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("b") % 3], targets=[KeyRef(0), Agg("count")]))
+    assert cp.plan.query_kind == A.Q_BASELINE_HASH and cp.plan.key_width == 8  # Invalid range -> 8-byte component
+
+
+def test_baseline_key_width_and_columnar_offsets():
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": np.arange(50, dtype=np.int32), "b": np.arange(50, dtype=np.int32) % 3, "v": np.ones(50)})
+    q = QueryUnit("t", groupby=[ColRef("a"), ColRef("b")], force_baseline=True, baseline_entry_count=101,
+                  targets=[KeyRef(0), KeyRef(1), Agg("avg", ColRef("v"))])
+    cp = compile_query(st, q)
+    assert cp.plan.key_width == 4  # pick_baseline_key_width: both ranges fit int32
+    assert cp.plan.row_size_quad == 1 + 4  # align8(2*4) + 4 slots of 8
+    q.output_columnar = True
+    cpc = compile_query(st, q)
+    assert cpc.plan.key_width == 8  # columnar group keys are 64-bit (QueryMemoryDescriptor.cpp:344-372)
+    offs = columnar_slot_offsets(cpc)
+    assert offs == [2 * 101 * 8 + i * 101 * 8 for i in range(4)]
+    assert cpc.buffer_bytes == 6 * 101 * 8
+
+
+def test_non_grouped_init_is_null_sentinel_and_skip():
+    # OutputBufferInitialization.cpp:57-60 + TargetExprBuilder.cpp:546-551
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": np.arange(10, dtype=np.int64)})
+    cp = compile_query(st, QueryUnit("t", targets=[Agg("sum", ColRef("a")), Agg("count"), Agg("min", ColRef("a")),
+                                                   Agg("avg", ColRef("a"))]))
+    assert cp.plan.query_kind == A.Q_NON_GROUPED
+    assert cp.init_vals.tolist() == [A.NULL_BIGINT, 0, A.NULL_BIGINT, A.NULL_BIGINT, 0]
+    assert [cp.plan.targets[i].skip_null for i in range(4)] == [1, 0, 1, 1]
+
+
+def test_min_max_keep_argument_null():
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array([1, 1, 2], pa.int8()), "v": pa.array([3, None, 4], pa.int32())}), "t")
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("k")],
+                                     targets=[KeyRef(0), Agg("min", ColRef("v")), Agg("sum", ColRef("v"))]))
+    # MIN/MAX: init = the ARGUMENT type's NULL widened (get_agg_initial_val on int32 in an 8-byte slot); SUM: BIGINT NULL
+    assert cp.plan.targets[1].null_val == A.NULL_INT and cp.plan.targets[2].null_val == A.NULL_BIGINT
+    assert cp.init_vals.tolist() == [0, A.NULL_INT, A.NULL_BIGINT]
+
+
+def test_unsupported_shapes_raise_query_must_run_on_cpu():
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": np.arange(10, dtype=np.int64), "f": np.ones(10, dtype=np.float32), "d": np.ones(10)})
+    with pytest.raises(QueryMustRunOnCpu):
+        compile_query(st, QueryUnit("t", targets=[Agg("sum", ColRef("f"))]))  # float32 accumulators
+    with pytest.raises(QueryMustRunOnCpu):
+        compile_query(st, QueryUnit("t", groupby=[ColRef("d")], targets=[Agg("count")]))  # fp group key
+    deep = BinOp("+", ColRef("a"), BinOp("*", ColRef("a"), Lit(2)))
+    with pytest.raises(QueryMustRunOnCpu):
+        compile_query(st, QueryUnit("t", targets=[Agg("sum", deep)]))  # right operand must be a leaf
+
+
+def test_taxi_q4_plan_shape():
+    import sys, os
+    from taxi import load_taxi, taxi_queries
+    st = ArrowStorage()
+    load_taxi(st)
+    cp = compile_query(st, taxi_queries()[3])
+    p = cp.plan
+    assert p.query_kind == A.Q_PERFECT_HASH and p.key_count == 3
+    assert p.keys[1].steps[0].op == A.OP_EXTRACT_YEAR and p.keys[2].steps[0].op == A.OP_SCALE_DOWN
+    assert p.keys[2].steps[0].rhs.ival == 100
