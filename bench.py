@@ -104,6 +104,7 @@ def main():
         return f, gen_fragment(rank * nfrag + f, frag_rows[f], args.keys, args.null_frac)
 
     host_frags = {}
+    t_upload = 0.0
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
         for f, (key, val) in pool.map(produce, range(nfrag)):
             has_null = bool(args.null_frac > 0 and (val == -(2**63)).any())
@@ -111,8 +112,10 @@ def main():
             kcol.stats[f] = ChunkStats(int(key.min()), int(key.max()), False)
             vcol.stats[f] = ChunkStats(int(vv.min()), int(vv.max()), has_null)
             # device-resident chunk (DataMgr GPU_LEVEL cache); the host copy is dropped unless sampled
+            tu = time.perf_counter()
             ex.cache.put(("t", "key", f), mgr.to_device(key, dev))
             ex.cache.put(("t", "val", f), mgr.to_device(val, dev))
+            t_upload += time.perf_counter() - tu
             if f < keep_host:
                 host_frags[f] = (key, val)
                 kcol.fragments[f], vcol.fragments[f] = key, val
@@ -220,6 +223,13 @@ def main():
         total_rows = args.rows * world
         value = total_rows * args.steps / elapsed
         achieved = args.rows * ALG_BYTES_PER_ROW / (avg_scan_ms * 1e-3) / 1e9 if scan_ms else None
+        # HBM traffic per launch from the committed PMC passes of this same workload (profiles/), taken
+        # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs and corrected as the guide says
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
+        if os.path.exists(pmc_path) and args.rows == 1_000_000_000 and args.keys == 64 and args.null_frac == 0:
+            with open(pmc_path) as fpmc:
+                traffic = json.load(fpmc).get("traffic_bytes_per_launch")
         out = {
             "metric": "rows/sec, 1B-row int64 GROUP BY SUM",
             "value": value,
@@ -240,12 +250,15 @@ def main():
                                                                    cp.entry_count),
                        "parallelism": f"fragments sharded over {world} GPU(s), all-gather + device reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "kernel": step.kernel_names().split(",")[0], "avg_kernel_ms": avg_scan_ms,
                          "alg_bytes_per_row": ALG_BYTES_PER_ROW},
             "cpu_baseline": cpu,
             "checks": checks,
-            "setup_s": {"generate_and_upload": t_gen},
+            "setup_s": {"generate_and_upload": t_gen, "upload_h2d": t_upload},
+            "pcie_inclusive": {"note": "informational: one cold pass incl. pageable-host -> HBM upload of the 16 B/row inputs",
+                               "h2d_GBps": args.rows * ALG_BYTES_PER_ROW / t_upload / 1e9 if t_upload else None,
+                               "rows_per_s": args.rows / (t_upload + elapsed / args.steps) if t_upload else None},
         }
         print(json.dumps(out))
     if world > 1:

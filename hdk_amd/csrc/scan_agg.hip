@@ -761,7 +761,17 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }
-  return launch_scan_global(plan, d_plan, kp, shape, s);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    st = scan_events_begin(device_id, s, &e0, &e1);
+    if (st) return st;
+  }
+  st = launch_scan_global(plan, d_plan, kp, shape, s);
+  if (st) return st;
+  if (timed) {
+    HDK_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  return HDK_HIP_OK;
 }
 
 extern "C" int32_t hdk_hip_collect_scan_times(int32_t device_id, float* ms_out, int32_t capacity, int32_t* count) {

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench line): the other BASELINE.json configs on one GPU,
+at sizes that fit comfortably, reported as rows/s and algorithmic GB/s (SURVEY.md 8d byte counts).
+
+    python scripts/bench_configs.py [--rows N] [--only c1,c2n,c3,c4,c5]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(step, reps=5, warm=2):
+    from hdk_amd._lib import check, lib
+    L = lib()
+    for _ in range(warm):
+        step.init_output()
+        step.launch()
+    step.mgr.synchronizeStream(step.dev)
+    n = C.c_int32(0)
+    check(L.hdk_hip_collect_scan_times(step.dev, None, 0, C.byref(n)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step.init_output()
+        step.launch()
+    step.mgr.synchronizeStream(step.dev)
+    wall = (time.perf_counter() - t0) / reps
+    buf = (C.c_float * reps)()
+    check(L.hdk_hip_collect_scan_times(step.dev, buf, reps, C.byref(n)))
+    k = [buf[i] for i in range(min(n.value, reps))]
+    return wall, (float(np.mean(k)) * 1e-3 if k else None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=256_000_000)
+    ap.add_argument("--only", default="c1,c2,c2n,c3,c3g,q1,q2,q3,q4,c5")
+    ap.add_argument("--grid", type=int, default=0)
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+
+    from hdk_amd import _abi as A
+    from hdk_amd.executor import Executor
+    from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
+    from hdk_amd.storage import ArrowStorage
+
+    n = args.rows
+    rng = np.random.default_rng(20261002)
+    st = ArrowStorage()
+    frag = 32_000_000
+    print(f"# generating {n} rows ...", file=sys.stderr)
+    key = rng.integers(0, 64, n, dtype=np.int64)
+    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    valn = val.copy()
+    valn[rng.random(n) < 0.01] = A.NULL_BIGINT
+    nd = 10_000_000
+    st.import_numpy("t", {"key": key, "val": val, "valn": valn, "fk": rng.integers(0, nd, n, dtype=np.int64),
+                          "hk": rng.integers(0, max(n // 10, 1000), n, dtype=np.int64)}, fragment_size=frag)
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64)},
+                    fragment_size=frag)
+    # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types)
+    st.import_numpy("trips", {"cab_type": rng.integers(0, 2, n).astype(np.int32),
+                              "passenger_count": rng.integers(0, 7, n).astype(np.int16),
+                              "pickup_datetime": rng.integers(1230768000, 1451606400, n, dtype=np.int64),
+                              "trip_distance": rng.integers(0, 5000, n, dtype=np.int64),
+                              "total_amount": rng.integers(0, 20000, n, dtype=np.int64)}, fragment_size=frag,
+                    types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
+                           "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
+    ex = Executor(st, 0)
+    Q = {
+        "c1": (QueryUnit("t", targets=[Agg("sum", ColRef("val"))]), 8),
+        "c2": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
+        "c2n": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("valn"))]), 16),
+        "c3": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")],
+                         targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"))]), 16),
+        "c3g": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") / 15625],
+                          targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
+        "q1": (QueryUnit("trips", groupby=[ColRef("cab_type")], targets=[KeyRef(0), Agg("count")]), 4),
+        "q2": (QueryUnit("trips", groupby=[ColRef("passenger_count")],
+                         targets=[KeyRef(0), Agg("avg", ColRef("total_amount"))]), 10),
+        "q3": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime"))],
+                         targets=[KeyRef(0), KeyRef(1), Agg("count")]), 10),
+        "q4": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime")),
+                                           Cast(ColRef("trip_distance"), INT32)],
+                         targets=[KeyRef(0), KeyRef(1), KeyRef(2), Agg("count")]), 18),
+        "c5": (QueryUnit("t", groupby=[ColRef("hk")], force_baseline=True,
+                         targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
+    }
+    for name, (q, bpr) in Q.items():
+        if name not in only:
+            continue
+        try:
+            cp = ex.compile(q)
+            step = ex.prepare(cp, grid=args.grid, flags=A.LAUNCH_RECORD_EVENTS)
+            wall, kern = timed(step)
+            res = step.fetch()
+            t = kern or wall
+            print(json.dumps({"config": name, "kernel": step.kernel_names(), "rows": n, "entries": cp.entry_count,
+                              "rows_per_s": n / wall, "kernel_ms": None if kern is None else kern * 1e3,
+                              "step_ms": wall * 1e3, "alg_bytes_per_row": bpr, "alg_GBps": n * bpr / t / 1e9,
+                              "frac_of_8TBps": n * bpr / t / 8e12, "groups": res.row_count()}))
+            step.free()
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"config": name, "error": repr(e)}))
+
+
+if __name__ == "__main__":
+    main()
