@@ -57,6 +57,7 @@ JC_SMALL_DATE, JC_SIGNED, JC_UNSIGNED, JC_DOUBLE = 0, 1, 2, 3
 LAUNCH_FORCE_GLOBAL_ATOMICS = 1
 LAUNCH_RECORD_EVENTS = 2
 LAUNCH_FORCE_GENERIC = 4
+LAUNCH_FORCE_SCALAR = 8
 
 
 class Col(C.Structure):

@@ -405,6 +405,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "launch_common.h"
 #include "scan_agg_fast.h"
 #include "scan_agg_global.h"
+#include "scan_agg_vec.h"
 
 using namespace hdk;
 
@@ -628,11 +629,12 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
   FastArgs fa;
   int kw, vw;
-  return match_fast(p, s, &fa, &kw, &vw) ? "hdk_scan_agg_direct" : "hdk_scan_agg_generic";
+  return match_fast(p, s, &fa, &kw, &vw) ? "hdk_scan_agg_direct" : "hdk_scan_agg_vec";
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
-                               const LaunchShape& shape, int64_t* slabs, hipStream_t s, bool force_generic) {
+                               const LaunchShape& shape, int64_t* slabs, hipStream_t s, bool force_generic,
+                               bool force_scalar) {
   FastArgs fa;
   int kw, vw;
   if (!force_generic && match_fast(plan, shape, &fa, &kw, &vw)) {
@@ -645,6 +647,17 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
       case 4: return launch_direct_kw<4>(vw, fa, shape, s);
       default: return launch_direct_kw<8>(vw, fa, shape, s);
     }
+  }
+  if (!force_scalar) {
+    VecArgs v;
+    v.plan = d_plan;
+    v.kp = kp;
+    v.slabs = slabs;
+    v.entry_count = shape.entry_count;
+    v.rep = shape.rep;
+    hipLaunchKernelGGL(hdk_scan_agg_vec, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
   }
   ScanArgs a;
   a.plan = d_plan;
@@ -745,7 +758,8 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       st = scan_events_begin(device_id, s, &e0, &e1);
       if (st) return st;
     }
-    st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s, ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GENERIC));
+    st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
+                         ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR));
     if (st) return st;
     if (timed) {
       HDK_HIP_CHECK(hipEventRecord(e1, s));

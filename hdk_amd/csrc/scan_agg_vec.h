@@ -1,0 +1,168 @@
+// scan_agg_vec.h -- the general LDS-privatised scan/aggregate kernel: the plan interpreter run on
+// batches of VR rows per lane (vec_eval.h).  Handles every NonGroupedAggregate / GroupByPerfectHash
+// plan the library accepts: filters, perfect-hash join probes, expression keys and arguments,
+// multi-column perfect hash (taxi Q3/Q4, BASELINE C3).  Same LDS table, slab and finalize protocol as
+// the other scan kernels (agg_common.h).
+#pragma once
+#include "agg_common.h"
+#include "vec_eval.h"
+
+namespace hdk {
+
+constexpr int kVecBlock = 256;
+
+struct VecArgs {
+  const hdk_hip_plan* plan;
+  KernParams kp;
+  int64_t* slabs;
+  uint32_t entry_count;
+  uint32_t rep;
+};
+
+HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
+  switch (wop) {
+    case WOP_ADD_U64: atomicAdd(reinterpret_cast<unsigned long long*>(wp), static_cast<unsigned long long>(v)); break;
+    case WOP_ADD_F64: atomicAdd(reinterpret_cast<double*>(wp), bits_to_double(v)); break;
+    case WOP_MIN_I64: atomicMin(reinterpret_cast<long long*>(wp), static_cast<long long>(v)); break;
+    case WOP_MAX_I64: atomicMax(reinterpret_cast<long long*>(wp), static_cast<long long>(v)); break;
+    case WOP_MIN_F64: {
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(wp);
+      unsigned long long old = *a;
+      const double d = bits_to_double(v);
+      while (d < bits_to_double(static_cast<int64_t>(old))) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, static_cast<unsigned long long>(v));
+        if (old == assumed) break;
+      }
+      break;
+    }
+    default: {
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(wp);
+      unsigned long long old = *a;
+      const double d = bits_to_double(v);
+      while (bits_to_double(static_cast<int64_t>(old)) < d) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, static_cast<unsigned long long>(v));
+        if (old == assumed) break;
+      }
+      break;
+    }
+  }
+}
+
+extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  __shared__ WordLayout wl;
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    make_word_layout(p, &wl);
+  }
+  __syncthreads();
+  const int wpe = wl.wpe;
+  const uint32_t rep = a.rep;
+  const uint32_t ew = a.entry_count * wpe;
+  const uint32_t total_words = ew * rep;
+  for (uint32_t i = tid; i < total_words; i += kVecBlock) {
+    lds[i] = word_identity(wl.wop[(i / rep) % wpe]);
+  }
+  __syncthreads();
+
+  const uint32_t my_rep = tid & (rep - 1);
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  constexpr int64_t kTileRows = static_cast<int64_t>(kVecBlock) * VR;
+  const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
+  const int nt = p->num_targets;
+
+  VecCtx c;
+  c.plan = p;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    c.jrow0[r] = 0;
+    c.jrow1[r] = 0;
+  }
+  int32_t err = 0;
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    c.cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
+      bool pass[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const int64_t row = row0 + static_cast<int64_t>(r) * kVecBlock + tid;
+        pass[r] = row < nrows;
+        c.row[r] = pass[r] ? row : row0;  // dead slots re-read a valid row; their results are dropped
+      }
+      rows_pass_v(c, a.kp.join_hash_tables, pass, err);
+      int64_t entry[VR];
+      if (grouped) {
+        perfect_hash_entry_v(c, entry, pass, err);
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r] && static_cast<uint64_t>(entry[r]) >= a.entry_count) {
+            err = HDK_HIP_ERR_OUT_OF_SLOTS;
+            pass[r] = false;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          entry[r] = 0;
+        }
+      }
+      uint32_t base[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        base[r] = (pass[r] ? static_cast<uint32_t>(entry[r]) * wpe : 0u) * rep + my_rep;
+        if (pass[r]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[r]), 1ull);  // row count
+        }
+      }
+      for (int t = 0; t < nt; ++t) {
+        const int vw = wl.vword[t];
+        const int nw = wl.nword[t];
+        if (vw < 0 && nw < 0) {
+          continue;
+        }
+        const hdk_hip_target& tg = p->targets[t];
+        int64_t v[VR];
+        bool is_null[VR];
+        eval_target_arg_v(c, tg, v, is_null, pass, err);
+        const int32_t wop = vw >= 0 ? wl.wop[vw] : 0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r] && !is_null[r]) {
+            if (nw >= 0) {
+              atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[r] + nw * rep), 1ull);
+            }
+            if (vw >= 0) {
+              vec_lds_op(wop, lds + base[r] + vw * rep, v[r]);
+            }
+          }
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+  __syncthreads();
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += kVecBlock) {
+    const int32_t op = wl.wop[i % wpe];
+    int64_t acc = lds[i * rep];
+    for (uint32_t r = 1; r < rep; ++r) {
+      acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    slab[i] = acc;
+  }
+}
+
+}  // namespace hdk

@@ -1,0 +1,303 @@
+// vec_eval.h -- the plan interpreter, VR rows per lane at a time.
+//
+// Same semantics as device_common.h (decoders, *_nullable arithmetic, three-valued filters, join
+// probes: reference QE/DecodersImpl.h:30-150, QE/RuntimeFunctions.cpp:49-384,
+// QE/GroupByRuntime.cpp:274-366), but every interpreter step is executed once per BATCH of VR rows
+// per lane: the wave-uniform work (scalar loads of plan fields, branches on op codes) is amortised
+// over VR x 64 rows, per-row differences are handled by selects, and the VR column loads of a leaf
+// are issued back to back (lane i of step r reads row base + r*blockDim + i: coalesced).
+// All row loops are fully unrolled so the per-row values live in registers.
+#pragma once
+#include "device_common.h"
+
+namespace hdk {
+
+constexpr int VR = 8;
+
+struct VecCtx {
+  const hdk_hip_plan* plan;
+  const int8_t* const* cols;  // col_buffers[frag]
+  int64_t row[VR];            // outer row per slot (clamped into the fragment for dead slots)
+  int32_t jrow0[VR];          // matched inner row of join 0 / 1
+  int32_t jrow1[VR];
+};
+
+template <typename F>
+HDK_DEV void for_rows(F&& f) {
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    f(r);
+  }
+}
+
+HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[VR]) {
+  if (l.kind == HDK_LEAF_COL) {
+    const hdk_hip_col col = c.plan->cols[l.col];
+    const int8_t* __restrict__ buf = c.cols[col.buf_idx];
+    const int width = col.width;
+    const int kind = col.kind;
+    const int table = col.table;
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      int64_t row = c.row[r];
+      if (table == 1) {
+        row = c.jrow0[r];
+      } else if (table == 2) {
+        row = c.jrow1[r];
+      }
+      out[r] = decode_col(buf, width, kind, row);
+    }
+  } else {
+    const int64_t v = l.ival;
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      out[r] = v;
+    }
+  }
+}
+
+// `live[r]`: only live rows may raise ERR_DIV_BY_ZERO (dead rows are evaluated speculatively)
+HDK_DEV void eval_expr_v(const VecCtx& c, const hdk_hip_expr& e, int64_t (&acc)[VR], const bool (&live)[VR],
+                         int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  load_leaf_v(c, e.leaf0, acc);
+  bool acc_fp = leaf_is_fp(p, e.leaf0);
+  int64_t acc_null = e.leaf0.null_val;
+  int32_t acc_nullable = e.leaf0.nullable;
+  const int nsteps = e.nsteps;
+  for (int s = 0; s < nsteps; ++s) {
+    const hdk_hip_step& st = e.steps[s];
+    const int op = st.op;
+    const bool out_fp = st.out_class == HDK_VC_FP;
+    const int64_t null_out = st.null_out;
+    if (op <= HDK_OP_MOD) {
+      int64_t rhs[VR];
+      load_leaf_v(c, st.rhs, rhs);
+      const bool rhs_fp = leaf_is_fp(p, st.rhs);
+      const int64_t rhs_null = st.rhs.null_val;
+      const int32_t rhs_nullable = st.rhs.nullable;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const bool isnull = is_null_val(acc[r], acc_null, acc_nullable, acc_fp) ||
+                            is_null_val(rhs[r], rhs_null, rhs_nullable, rhs_fp);
+        int64_t res;
+        bool bad = false;
+        if (out_fp) {
+          const double a = acc_fp ? bits_to_double(acc[r]) : static_cast<double>(acc[r]);
+          const double b = rhs_fp ? bits_to_double(rhs[r]) : static_cast<double>(rhs[r]);
+          double d;
+          switch (op) {
+            case HDK_OP_ADD: d = a + b; break;
+            case HDK_OP_SUB: d = a - b; break;
+            case HDK_OP_MUL: d = a * b; break;
+            default:
+              bad = b == 0.0;
+              d = bad ? 0.0 : a / b;
+              break;
+          }
+          res = double_to_bits(d);
+        } else {
+          const int64_t a = acc[r], b = rhs[r];
+          switch (op) {
+            case HDK_OP_ADD: res = static_cast<int64_t>(static_cast<uint64_t>(a) + static_cast<uint64_t>(b)); break;
+            case HDK_OP_SUB: res = static_cast<int64_t>(static_cast<uint64_t>(a) - static_cast<uint64_t>(b)); break;
+            case HDK_OP_MUL: res = static_cast<int64_t>(static_cast<uint64_t>(a) * static_cast<uint64_t>(b)); break;
+            case HDK_OP_DIV: {
+              bad = b == 0;
+              const int64_t bb = (bad || isnull) ? 1 : b;
+              res = (a == INT64_MIN && bb == -1) ? INT64_MIN : a / bb;
+              break;
+            }
+            default: {
+              bad = b == 0;
+              const int64_t bb = (bad || isnull) ? 1 : b;
+              res = bb == -1 ? 0 : a % bb;
+              break;
+            }
+          }
+        }
+        if (bad && !isnull && live[r]) {
+          err = HDK_HIP_ERR_DIV_BY_ZERO;
+        }
+        acc[r] = (isnull || bad) ? null_out : res;
+      }
+    } else {
+      const int64_t param = st.rhs.ival;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const bool isnull = is_null_val(acc[r], acc_null, acc_nullable, acc_fp);
+        int64_t res;
+        switch (op) {
+          case HDK_OP_EXTRACT_YEAR: res = extract_year(acc[r]); break;
+          case HDK_OP_SCALE_DOWN: res = scale_decimal_down(acc[r], param); break;
+          case HDK_OP_FLOOR_DIV: res = floor_div_lhs(acc[r], param); break;
+          case HDK_OP_CAST_INT_TO_FP: res = double_to_bits(static_cast<double>(acc[r])); break;
+          case HDK_OP_CAST_FP_TO_INT: {
+            const double d = bits_to_double(acc[r]);
+            res = static_cast<int64_t>(d + (d < 0.0 ? -0.5 : 0.5));
+            break;
+          }
+          default: res = null_out; break;
+        }
+        acc[r] = isnull ? null_out : res;
+      }
+    }
+    acc_fp = out_fp;
+    acc_null = null_out;
+    acc_nullable = 1;
+  }
+}
+
+// pass[r] &= (conjunct is TRUE)
+HDK_DEV void eval_qual_v(const VecCtx& c, const hdk_hip_qual& q, bool (&pass)[VR], int32_t& err) {
+  int64_t lhs[VR];
+  int64_t rhs[VR];
+  eval_expr_v(c, q.lhs, lhs, pass, err);
+  load_leaf_v(c, q.rhs, rhs);
+  const bool lhs_fp = q.lhs.vclass == HDK_VC_FP;
+  const bool rhs_fp = leaf_is_fp(c.plan, q.rhs);
+  const int cmp = q.cmp;
+  const int64_t lnull = q.lhs.null_val, rnull = q.rhs.null_val;
+  const int32_t lnullable = q.lhs.nullable, rnullable = q.rhs.nullable;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    const bool isnull = is_null_val(lhs[r], lnull, lnullable, lhs_fp) || is_null_val(rhs[r], rnull, rnullable, rhs_fp);
+    bool t;
+    if (lhs_fp || rhs_fp) {
+      const double a = lhs_fp ? bits_to_double(lhs[r]) : static_cast<double>(lhs[r]);
+      const double b = rhs_fp ? bits_to_double(rhs[r]) : static_cast<double>(rhs[r]);
+      switch (cmp) {
+        case HDK_CMP_EQ: t = a == b; break;
+        case HDK_CMP_NE: t = a != b; break;
+        case HDK_CMP_LT: t = a < b; break;
+        case HDK_CMP_GT: t = a > b; break;
+        case HDK_CMP_LE: t = a <= b; break;
+        default: t = a >= b; break;
+      }
+    } else {
+      const int64_t a = lhs[r], b = rhs[r];
+      switch (cmp) {
+        case HDK_CMP_EQ: t = a == b; break;
+        case HDK_CMP_NE: t = a != b; break;
+        case HDK_CMP_LT: t = a < b; break;
+        case HDK_CMP_GT: t = a > b; break;
+        case HDK_CMP_LE: t = a <= b; break;
+        default: t = a >= b; break;
+      }
+    }
+    pass[r] = pass[r] && !isnull && t;
+  }
+}
+
+// filter + join probes for the batch; dead slots stay dead
+HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass)[VR], int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  const int nq = p->num_quals;
+  for (int q = 0; q < nq; ++q) {
+    eval_qual_v(c, p->quals[q], pass, err);
+  }
+  const int nj = p->num_joins;
+  for (int j = 0; j < nj; ++j) {
+    const hdk_hip_join& jn = p->joins[j];
+    int64_t key[VR];
+    eval_expr_v(c, jn.outer_key, key, pass, err);
+    const int32_t* __restrict__ table = (nj == 1 && jn.table_idx == 0)
+                                            ? reinterpret_cast<const int32_t*>(join_hash_tables)
+                                            : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
+    const bool inner = jn.type == HDK_JOIN_INNER;
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      // dead slots probe with their (clamped, valid) row too: harmless, keeps the loads unconditional
+      const int64_t idx = probe_join(jn, table, key[r]);
+      if (inner) {
+        pass[r] = pass[r] && idx >= 0;
+      }
+      const int32_t safe = idx < 0 ? 0 : static_cast<int32_t>(idx);
+      if (j == 0) {
+        c.jrow0[r] = safe;
+      } else {
+        c.jrow1[r] = safe;
+      }
+    }
+  }
+}
+
+// group key #k for the batch (perfect hash: NULL translated)
+HDK_DEV void eval_key_v(const VecCtx& c, int k, int64_t (&out)[VR], const bool (&live)[VR], int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  eval_expr_v(c, p->keys[k], out, live, err);
+  if (p->query_kind == HDK_Q_PERFECT_HASH && p->key_has_nulls[k] && p->keys[k].nullable) {
+    const int64_t nullv = p->keys[k].null_val;
+    const int64_t tr = p->key_null_translated[k];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      out[r] = out[r] == nullv ? tr : out[r];
+    }
+  }
+}
+
+HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const bool (&live)[VR], int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  const int nk = p->key_count;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    entry[r] = 0;
+  }
+  int64_t stride = 1;
+  for (int k = 0; k < nk; ++k) {
+    int64_t kv[VR];
+    eval_key_v(c, k, kv, live, err);
+    const int64_t kmin = p->key_min[k];
+    const int64_t bucket = p->key_bucket[k];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      int64_t term = kv[r] - kmin;
+      if (bucket) {
+        term /= bucket;
+      }
+      entry[r] += term * stride;
+    }
+    stride *= p->key_card[k];
+  }
+}
+
+// target argument for the batch; is_null[r] = the value is the skip value
+HDK_DEV void eval_target_arg_v(const VecCtx& c, const hdk_hip_target& tg, int64_t (&v)[VR], bool (&is_null)[VR],
+                               const bool (&live)[VR], int32_t& err) {
+  if (!tg.has_arg) {
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      v[r] = 0;
+      is_null[r] = false;
+    }
+    return;
+  }
+  eval_expr_v(c, tg.arg, v, live, err);
+  const bool arg_fp = tg.arg.vclass == HDK_VC_FP;
+  const bool skip = tg.skip_null && tg.agg != HDK_AGG_ID;
+  const bool promote = tg.arg_is_fp && !arg_fp && tg.agg != HDK_AGG_ID;
+  const int64_t anull = tg.arg.null_val;
+  const int32_t anullable = tg.arg.nullable;
+  const int64_t tnull = tg.null_val;
+  const bool slot_fp = tg.arg_is_fp;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    bool n = false;
+    int64_t x = v[r];
+    if (skip && is_null_val(x, anull, anullable, arg_fp)) {
+      n = true;
+      x = tnull;
+    } else {
+      if (promote) {
+        x = double_to_bits(static_cast<double>(x));
+      }
+      if (skip) {
+        n = slot_fp ? (bits_to_double(x) == bits_to_double(tnull)) : (x == tnull);
+      }
+    }
+    v[r] = x;
+    is_null[r] = n;
+  }
+}
+
+}  // namespace hdk

@@ -311,8 +311,9 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
   uint32_t flags;       /* HDK_HIP_LAUNCH_* */
 } hdk_hip_kernel_options;
 #define HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS 1u /* skip the LDS-privatised strategy (testing) */
-#define HDK_HIP_LAUNCH_FORCE_GENERIC 4u        /* use the plan-interpreter kernel even when a specialised
-                                                  kernel matches (testing) */
+#define HDK_HIP_LAUNCH_FORCE_GENERIC 4u        /* use the (batched) plan-interpreter kernel even when a
+                                                  specialised kernel matches (testing) */
+#define HDK_HIP_LAUNCH_FORCE_SCALAR 8u         /* use the row-at-a-time interpreter kernel (testing) */
 #define HDK_HIP_LAUNCH_RECORD_EVENTS 2u        /* bracket the scan kernel with HIP events on the launch
                                                   stream (DeviceClock, QE/DeviceKernel.cpp:25-43) */
 

@@ -22,6 +22,8 @@ def _check(O, make, st, q, grid=0, flags=0):
     # the plan-interpreter kernel must agree too (it is the fallback for every other shape)
     res_g = ex.execute(cp, grid=grid, flags=flags | A.LAUNCH_FORCE_GENERIC)
     assert_buffers_equal(cp, res_g.buffer, want)
+    res_s = ex.execute(cp, grid=grid, flags=flags | A.LAUNCH_FORCE_SCALAR)
+    assert_buffers_equal(cp, res_s.buffer, want)
     return cp, res
 
 
