@@ -48,7 +48,7 @@ CMP_EQ, CMP_NE, CMP_LT, CMP_GT, CMP_LE, CMP_GE = range(1, 7)
 JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY = 0, 1
 JOIN_INNER, JOIN_LEFT = 0, 1
 JOIN_NULL_NONE, JOIN_NULL_NULLABLE, JOIN_NULL_BITWISE = 0, 1, 2
-Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH = 0, 1, 2
+Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH, Q_PROJECTION = 0, 1, 2, 3
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX, AGG_AVG, AGG_ID = 0, 1, 2, 3, 4, 5
 JC_SMALL_DATE, JC_SIGNED, JC_UNSIGNED, JC_DOUBLE = 0, 1, 2, 3
 (KP_COL_BUFFERS, KP_NUM_FRAGMENTS, KP_LITERALS, KP_NUM_ROWS, KP_FRAG_ROW_OFFSETS, KP_MAX_MATCHED,

@@ -404,6 +404,9 @@ HDK_DEV size_t align8(size_t x) { return (x + 7) & ~static_cast<size_t>(7); }
 
 HDK_DEV size_t columnar_slot_off(const hdk_hip_plan* p, uint32_t entry_count, int slot) {
   size_t off = p->keyless ? 0 : static_cast<size_t>(p->key_count) * align8(static_cast<size_t>(entry_count) * 8);
+  if (p->query_kind == HDK_Q_PROJECTION) {
+    off = align8(static_cast<size_t>(entry_count) * 8);  // the row-position column
+  }
   int s = 0;
   const int nt = p->num_targets;
   for (int t = 0; t < nt; ++t) {

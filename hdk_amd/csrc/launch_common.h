@@ -5,7 +5,7 @@
 
 namespace hdk {
 
-enum Strategy { STRAT_LDS = 0, STRAT_GLOBAL = 1 };
+enum Strategy { STRAT_LDS = 0, STRAT_GLOBAL = 1, STRAT_PROJECT = 2 };
 
 // LDS budget for the privatised table: 32 KiB per 256-thread block keeps 4-5 blocks (16-20 waves)
 // resident per CU out of the 160 KiB LDS.

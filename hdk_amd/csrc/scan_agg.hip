@@ -406,6 +406,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_agg_fast.h"
 #include "scan_agg_global.h"
 #include "scan_agg_vec.h"
+#include "scan_project.h"
 
 using namespace hdk;
 
@@ -420,8 +421,21 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   HDK_REQUIRE(p->num_joins >= 0 && p->num_joins <= HDK_HIP_MAX_JOINS, "bad num_joins");
   HDK_REQUIRE(p->key_count >= 0 && p->key_count <= HDK_HIP_MAX_KEYS, "bad key_count");
   HDK_REQUIRE(p->num_targets > 0 && p->num_targets <= HDK_HIP_MAX_TARGETS, "bad num_targets");
-  HDK_REQUIRE(p->query_kind >= HDK_Q_NON_GROUPED && p->query_kind <= HDK_Q_BASELINE_HASH,
+  HDK_REQUIRE(p->query_kind >= HDK_Q_NON_GROUPED && p->query_kind <= HDK_Q_PROJECTION,
               "bad query_kind");
+  if (p->query_kind == HDK_Q_PROJECTION) {
+    HDK_REQUIRE(p->entry_count > 0, "entry_count must be positive");
+    HDK_REQUIRE(p->key_count == 0 && !p->keyless, "projection plans have no group-by keys");
+    HDK_REQUIRE(p->output_columnar || p->row_size_quad > 0, "row_size_quad must be positive");
+    for (int t = 0; t < p->num_targets; ++t) {
+      const hdk_hip_target& tg = p->targets[t];
+      HDK_REQUIRE(tg.agg == HDK_AGG_ID && tg.has_arg, "projection targets are plain expressions");
+      HDK_REQUIRE(tg.slot_width == 1 || tg.slot_width == 2 || tg.slot_width == 4 || tg.slot_width == 8,
+                  "slot width must be 1/2/4/8");
+      HDK_REQUIRE(p->output_columnar || tg.slot_width == 8, "row-wise projection slots are 8 bytes");
+    }
+    return HDK_HIP_OK;
+  }
   if (p->query_kind != HDK_Q_NON_GROUPED) {
     HDK_REQUIRE(p->entry_count > 0, "entry_count must be positive");
     HDK_REQUIRE(p->key_count > 0, "group-by plan without keys");
@@ -444,6 +458,10 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   return HDK_HIP_OK;
 }
 
+struct FastArgs;
+static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
+static bool plan_matches_direct(const hdk_hip_plan* p, const LaunchShape& shape);
+
 LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko,
                          const hdk_hip_device_properties* props) {
   LaunchShape s;
@@ -455,7 +473,12 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
   s.block = kBlock;
   const bool force_global = ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS);
   const uint64_t words = static_cast<uint64_t>(s.entry_count) * s.wpe;
-  if (p->query_kind != HDK_Q_BASELINE_HASH && words <= kLdsWordBudget && !force_global) {
+  if (p->query_kind == HDK_Q_PROJECTION) {
+    s.strategy = STRAT_PROJECT;
+    s.rep = 1;
+    s.lds_bytes = 0;
+    s.slab_words = 0;
+  } else if (p->query_kind != HDK_Q_BASELINE_HASH && words <= kLdsWordBudget && !force_global) {
     s.strategy = STRAT_LDS;
     uint32_t rep = 32;
     while (rep > 1 && words * rep > kLdsWordBudget) {
@@ -469,6 +492,11 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     s.rep = 1;
     s.lds_bytes = 0;
     s.slab_words = 0;
+  }
+  if (!(ko && ko->grid_dim_x) && plan_matches_direct(p, s)) {
+    // measured on C2 (1e9 rows): 512 blocks 2.60 ms, 1024 blocks 2.71 ms -- the streaming kernel wants
+    // 2 blocks per CU (fewer slabs to fold, same bytes in flight: 8 x 16 B per lane)
+    s.grid = 2u * static_cast<uint32_t>(props->num_cu);
   }
   return s;
 }
@@ -600,6 +628,12 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   return true;
 }
 
+static bool plan_matches_direct(const hdk_hip_plan* p, const LaunchShape& shape) {
+  FastArgs fa;
+  int kw, vw;
+  return match_fast(p, shape, &fa, &kw, &vw);
+}
+
 template <int KW, int VW, int FIXED>
 static int32_t launch_direct(const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
   constexpr int U = (KW != 0 && VW != 0) ? 4 : 8;
@@ -707,6 +741,8 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   const LaunchShape s = choose_shape(plan, ko, props);
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
+  } else if (s.strategy == STRAT_PROJECT) {
+    snprintf(out, out_len, "hdk_scan_project");
   } else {
     snprintf(out, out_len, "hdk_scan_agg_global");
   }
@@ -780,7 +816,18 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     st = scan_events_begin(device_id, s, &e0, &e1);
     if (st) return st;
   }
-  st = launch_scan_global(plan, d_plan, kp, shape, s);
+  if (shape.strategy == STRAT_PROJECT) {
+    HDK_REQUIRE(params[HDK_KP_MAX_MATCHED] && params[HDK_KP_TOTAL_MATCHED], "MAX_MATCHED / TOTAL_MATCHED is NULL");
+    ProjArgs pa;
+    pa.plan = d_plan;
+    pa.kp = kp;
+    pa.entry_count = plan->entry_count;
+    hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+    HDK_HIP_CHECK(hipGetLastError());
+    st = HDK_HIP_OK;
+  } else {
+    st = launch_scan_global(plan, d_plan, kp, shape, s);
+  }
   if (st) return st;
   if (timed) {
     HDK_HIP_CHECK(hipEventRecord(e1, s));

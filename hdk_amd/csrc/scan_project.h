@@ -1,0 +1,143 @@
+// scan_project.h -- filter/project: one output row per input row that passes the filter (and the
+// inner-join probes), compacted through a selection vector.
+//
+// Reference behaviour (QE/RowFuncBuilder.cpp:162-215, QE/GroupByRuntime.cpp:248-272): every passing
+// row does `old = atomicAdd(total_matched, 1)` and writes its position + targets at output row `old`
+// (get_scan_output_slot / get_columnar_scan_output_offset); rows past max_matched report -pos.
+//
+// MI355X form: the batch interpreter (vec_eval.h) produces pass[VR] per lane; a wave-level exclusive
+// prefix sum over the lanes' pass counts (DPP-free shuffle scan, 64 lanes) turns the wave's selection
+// vector into dense output positions with ONE global atomic per wave per batch instead of one per row.
+// Output row order is therefore a permutation of the reference's (which is itself scheduling-dependent
+// on a GPU); the set of rows is identical.
+#pragma once
+#include "vec_eval.h"
+
+namespace hdk {
+
+constexpr int kProjBlock = 256;
+
+struct ProjArgs {
+  const hdk_hip_plan* plan;
+  KernParams kp;
+  uint32_t entry_count;  // == *MAX_MATCHED
+};
+
+HDK_DEV void store_slot(int8_t* p, int width, int64_t v) {
+  switch (width) {
+    case 1: *reinterpret_cast<int8_t*>(p) = static_cast<int8_t>(v); break;
+    case 2: *reinterpret_cast<int16_t*>(p) = static_cast<int16_t>(v); break;
+    case 4: *reinterpret_cast<int32_t*>(p) = static_cast<int32_t>(v); break;
+    default: *reinterpret_cast<int64_t*>(p) = v; break;
+  }
+}
+
+extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjArgs a) {
+  __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const bool columnar = p->output_columnar;
+  const int nt = p->num_targets;
+  if (columnar && tid < HDK_HIP_MAX_TARGETS) {
+    s_col_off[tid] = columnar_slot_off(p, a.entry_count, tid);
+  }
+  __syncthreads();
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const uint32_t max_matched = static_cast<uint32_t>(*a.kp.max_matched);
+  constexpr int64_t kTileRows = static_cast<int64_t>(kProjBlock) * VR;
+  int64_t* buf = a.kp.groupby_buf[0];
+
+  VecCtx c;
+  c.plan = p;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    c.jrow0[r] = 0;
+    c.jrow1[r] = 0;
+  }
+  int32_t err = 0;
+  int32_t slots_err = 0;
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    c.cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
+      bool pass[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const int64_t row = row0 + static_cast<int64_t>(r) * kProjBlock + tid;
+        pass[r] = row < nrows;
+        c.row[r] = pass[r] ? row : row0;
+      }
+      rows_pass_v(c, a.kp.join_hash_tables, pass, err);
+      // ---- selection vector -> dense output positions ------------------------------------------
+      uint32_t mine = 0;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        mine += pass[r] ? 1u : 0u;
+      }
+      uint32_t incl = mine;  // inclusive scan over the wave's 64 lanes
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t n = __shfl_up(incl, d, kWave);
+        if (lane >= d) {
+          incl += n;
+        }
+      }
+      const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+      uint32_t wave_base = 0;
+      if (wave_total) {
+        if (lane == 0) {
+          wave_base = static_cast<uint32_t>(atomicAdd(a.kp.total_matched, static_cast<int32_t>(wave_total)));
+        }
+        wave_base = __shfl(wave_base, 0, kWave);
+      }
+      uint32_t out_pos = wave_base + incl - mine;
+      // ---- project ------------------------------------------------------------------------------
+      uint32_t pos_r[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        pos_r[r] = out_pos;
+        if (pass[r]) {
+          ++out_pos;
+          if (pos_r[r] >= max_matched) {
+            slots_err = -1 - static_cast<int32_t>(c.row[r] & 0x3fffffff);  // out of slots: negative
+            pass[r] = false;
+          } else if (columnar) {
+            buf[pos_r[r]] = c.row[r];  // get_columnar_scan_output_offset
+          } else {
+            buf[static_cast<size_t>(pos_r[r]) * p->row_size_quad] = c.row[r];  // get_scan_output_slot
+          }
+        }
+      }
+      for (int t = 0; t < nt; ++t) {
+        const hdk_hip_target& tg = p->targets[t];
+        int64_t v[VR];
+        eval_expr_v(c, tg.arg, v, pass, err);
+        const int w = tg.slot_width;
+        const int off = tg.slot_off;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r]) {
+            int8_t* dst = columnar ? reinterpret_cast<int8_t*>(buf) + s_col_off[t] + static_cast<size_t>(pos_r[r]) * w
+                                   : reinterpret_cast<int8_t*>(buf + static_cast<size_t>(pos_r[r]) * p->row_size_quad) + off;
+            store_slot(dst, w, v[r]);
+          }
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  } else if (slots_err) {
+    atomicCAS(a.kp.error_code, 0, slots_err);  // negative = ran out of slots (benign under a LIMIT)
+  }
+}
+
+}  // namespace hdk

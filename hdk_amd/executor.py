@@ -22,7 +22,7 @@ from . import result_set
 from ._lib import HdkHipError, check, lib
 from .hip_mgr import DeviceBuffer, HipMgr
 from .ir import QueryMustRunOnCpu, QueryUnit
-from .plan import CompiledPlan, compact_init_vals, compile_query
+from .plan import CompiledPlan, compact_init_vals, compile_query, eff_key_count
 from .storage import ArrowStorage
 
 
@@ -67,19 +67,23 @@ class BufferCache:
 class ExecutionResult:
     """Host ResultSet + its layout; `to_arrow()` like pyhdk's ExecutionResult (_sql.pyx:76-83)."""
 
-    def __init__(self, cp: CompiledPlan, buf: np.ndarray, entry_count: int, error_code: int = 0):
+    def __init__(self, cp: CompiledPlan, buf: np.ndarray, entry_count: int, error_code: int = 0,
+                 total_matched: Optional[int] = None):
         self.compiled = cp
         self.buffer = buf
         self.entry_count = entry_count
         self.error_code = error_code
+        self.total_matched = total_matched  # projection: rows claimed (TOTAL_MATCHED)
 
     def to_arrow(self):
-        return result_set.to_arrow(self.compiled, self.buffer, self.entry_count)
+        return result_set.to_arrow(self.compiled, self.buffer, self.entry_count, self.total_matched)
 
     def to_columns(self):
-        return result_set.to_columns(self.compiled, self.buffer, self.entry_count)
+        return result_set.to_columns(self.compiled, self.buffer, self.entry_count, self.total_matched)
 
     def row_count(self):
+        if self.compiled.plan.query_kind == A.Q_PROJECTION:
+            return min(int(self.total_matched or 0), self.entry_count)
         return int(result_set.non_empty_mask(self.compiled, self.buffer, self.entry_count).sum())
 
 
@@ -133,7 +137,9 @@ class PreparedStep:
         self.d_init = d_init
         self.d_err = self._dev(np.zeros(1, dtype=np.int32))
         d_max_matched = self._dev(np.array([p.entry_count], dtype=np.int32))
-        d_total_matched = self._dev(np.zeros(1, dtype=np.int32))
+        d_total_matched = self._dev(np.zeros(2, dtype=np.int32))  # int32 counter in an 8-byte cell
+        self.d_total_matched = d_total_matched
+        self.d_zero = self._dev(np.zeros(1, dtype=np.int64))
         if len(self.join_tables) == 1:
             jt_param = self.join_tables[0].ptr
         elif self.join_tables:
@@ -202,13 +208,19 @@ class PreparedStep:
                 props.max_threads_per_block, props.grid_size, self.dev, stream))
         elif p.output_columnar:
             check(self.L.hdk_hip_init_columnar_group_by_buffer(
-                self.out_ptr, self.d_init_raw.ptr, p.entry_count, p.key_count, len(self.cp.slot_widths),
+                self.out_ptr, self.d_init_raw.ptr, p.entry_count, eff_key_count(p), len(self.cp.slot_widths),
                 self.d_col_sizes.ptr, 1, p.keyless, 8, props.max_threads_per_block, props.grid_size,
                 self.dev, stream))
         else:
             check(self.L.hdk_hip_init_group_by_buffer(
-                self.out_ptr, self.d_init.ptr, p.entry_count, p.key_count, p.key_width, p.row_size_quad,
+                self.out_ptr, self.d_init.ptr, p.entry_count, eff_key_count(p), p.key_width, p.row_size_quad,
                 p.keyless, 1, props.max_threads_per_block, props.grid_size, self.dev, stream))
+        if p.query_kind == A.Q_PROJECTION:
+            # TOTAL_MATCHED restarts at 0 for every launch (prepareKernelParams,
+            # QueryExecutionContext.cpp:941-950); reset on the launch stream with the fill kernel
+            check(self.L.hdk_hip_init_group_by_buffer(
+                self.d_total_matched.ptr, self.d_zero.ptr, 1, 0, 8, 1, 1, 1,
+                props.max_threads_per_block, props.grid_size, self.dev, stream))
 
     def launch(self, stream=None):
         check(self.L.hdk_hip_launch(C.byref(self.cp.plan), self._params, C.byref(self.ko), self.dev, stream,
@@ -221,7 +233,12 @@ class PreparedStep:
         if err > 0:
             raise HdkHipError(err, f"device error code {err} (QE/Execute.h:1019-1031)")
         buf = self.mgr.to_host(self.out_ptr, max(self.buffer_bytes, 8), self.dev, np.int64)
-        return ExecutionResult(self.cp, buf[:self.buffer_bytes // 8], self.cp.entry_count, err)
+        total = None
+        if self.cp.plan.query_kind == A.Q_PROJECTION:
+            total = int(self.mgr.to_host(self.d_total_matched.ptr, 4, self.dev, np.int32)[0])
+        # err < 0: a projection ran out of output rows (benign under a LIMIT; aggregate_error_codes,
+        # QueryExecutionContext.cpp:221-234, surfaces it only when nothing positive happened)
+        return ExecutionResult(self.cp, buf[:self.buffer_bytes // 8], self.cp.entry_count, err, total)
 
     def run(self, stream=None) -> ExecutionResult:
         self.init_output(stream)

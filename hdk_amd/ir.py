@@ -150,6 +150,13 @@ class KeyRef:
 
 
 @dataclass(frozen=True)
+class Proj:
+    """Projected expression of a filter/project step (no GROUP BY, no aggregates)."""
+    expr: Expr
+    name: Optional[str] = None
+
+
+@dataclass(frozen=True)
 class JoinSpec:
     """Equi-join of the outer table with `inner_table` on outer_key == inner_col (perfect hash)."""
     inner_table: str
@@ -165,7 +172,8 @@ class QueryUnit:
     quals: List[Cmp] = field(default_factory=list)
     joins: List[JoinSpec] = field(default_factory=list)
     groupby: List[Expr] = field(default_factory=list)
-    targets: List[Union[Agg, KeyRef]] = field(default_factory=list)
+    targets: List[Union[Agg, KeyRef, Proj]] = field(default_factory=list)
+    scan_limit: Optional[int] = None  # projection: max output rows (RelAlgExecutionUnit::scan_limit)
     # hints (ExecutionOptions / Config.exec.group_by)
     output_columnar: bool = False
     bigint_count: bool = False  # Config.exec.group_by.bigint_count (omniscidb/Shared/Config.h:44)

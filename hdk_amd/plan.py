@@ -329,7 +329,132 @@ def _agg_init_val(kind: str, arg_t: Optional[Type], nullable: bool, width: int) 
     raise ValueError(kind)
 
 
+def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
+    join_infos = []
+    p.num_joins = len(q.joins)
+    for ji, j in enumerate(q.joins):
+        inner = b.inner[ji]
+        icol = inner.columns[j.inner_col]
+        if not icol.type.is_integer_like:
+            raise QueryMustRunOnCpu("join keys must be integers")
+        st = icol.table_stats()
+        if st.min is None:
+            raise QueryMustRunOnCpu("empty join inner table")
+        jn = p.joins[ji]
+        jn.outer_key = make_expr(b, j.outer_key)
+        jn.min_key = int(st.min)
+        jn.max_key = int(st.max)
+        okt = b.type_of(j.outer_key)
+        jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits()) if not okt.is_fp else 0
+        jn.null_mode = A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE
+        jn.bucket = 0
+        jn.kind = A.JOIN_ONE_TO_ONE
+        jn.type = A.JOIN_INNER if j.type == "inner" else A.JOIN_LEFT
+        if jn.type == A.JOIN_LEFT:
+            raise QueryMustRunOnCpu("LEFT joins are outside the fixed kernel library")
+        jn.table_idx = ji
+        join_infos.append({"inner_table": inner.name, "inner_col": j.inner_col, "min": int(st.min),
+                           "max": int(st.max), "null_val": icol.type.null_value(),
+                           "elem_sz": icol.type.size})
+    p.num_quals = len(q.quals)
+    for qi, c in enumerate(q.quals):
+        ql = p.quals[qi]
+        ql.lhs = make_expr(b, c.lhs)
+        ql.rhs = _make_leaf(b, c.rhs)
+        ql.cmp = _CMP[c.op]
+    return join_infos
+
+
+def _fill_cols(storage: ArrowStorage, b: "_Binder", p: A.Plan):
+    p.num_cols = len(b.cols)
+    for i, (tn, cn, slot) in enumerate(b.cols):
+        ct = storage.get(tn).columns[cn].type
+        c = p.cols[i]
+        c.buf_idx = i
+        c.table = slot
+        c.width = ct.size
+        if ct.is_fp:
+            c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
+        else:
+            c.kind = A.COL_INT
+
+
+def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
+    """Filter/project step: QueryDescriptionType::Projection.  Layout (QueryMemoryDescriptor.cpp:314-342,
+    457-478): row-wise [int64 row position | 8-byte slots]; columnar [positions | columns at their
+    logical widths] (isLogicalSizedColumnsAllowed, :496-500).  entry_count = scan_limit, else the number
+    of input rows (the reference guesses max_groups_buffer_entry_count and retries on -pos)."""
+    from .ir import Proj
+    b = _Binder(storage, q)
+    p = A.Plan()
+    p.abi_version = A.PLAN_ABI
+    if len(q.targets) > A.MAX_TARGETS or len(q.quals) > A.MAX_QUALS or len(q.joins) > A.MAX_JOINS:
+        raise QueryMustRunOnCpu("query exceeds the fixed kernel library's limits")
+    join_infos = _compile_joins_and_quals(b, q, p)
+    p.query_kind = A.Q_PROJECTION
+    p.key_count = 0
+    p.keyless = 0
+    p.idx_target_as_key = -1
+    p.key_width = 8
+    columnar = bool(q.output_columnar)
+    p.output_columnar = 1 if columnar else 0
+    entry_count = int(q.scan_limit) if q.scan_limit else max(b.outer.num_rows, 1)
+    if entry_count >= 2**31:
+        raise QueryMustRunOnCpu("projection of more than 2^31-1 rows")
+    p.entry_count = entry_count
+    p.num_targets = len(q.targets)
+    out_cols, slot_widths, init_vals = [], [], []
+    row_off = 8
+    for ti, t in enumerate(q.targets):
+        assert isinstance(t, Proj)
+        tt = b.type_of(t.expr)
+        if tt.is_fp and tt.size == 4:
+            raise QueryMustRunOnCpu("float32 projections are outside the fixed kernel library")
+        tg = p.targets[ti]
+        tg.agg = A.AGG_ID
+        tg.has_arg = 1
+        tg.key_idx = -1
+        tg.arg = make_expr(b, t.expr)
+        tg.arg_is_fp = 1 if tt.is_fp else 0
+        w = tt.size if (columnar and not (tg.arg.nsteps and not tt.is_fp)) else 8
+        if columnar and tg.arg.nsteps and not tt.is_fp:
+            w = 8  # computed integer expressions are carried as int64
+        tg.slot_width = w
+        tg.slot2_width = w
+        tg.slot_off = row_off
+        row_off += 8
+        slot_widths.append(w)
+        init_vals.append(0)
+        src = t.expr
+        dic = b.resolve(src)[2].dictionary if isinstance(src, ColRef) else None
+        name = t.name or (src.name if isinstance(src, ColRef) else f"expr_{ti}")
+        rt = tt if w == tt.size else Type("fp" if tt.is_fp else "int", 8, tt.nullable)
+        if isinstance(src, ColRef) and tt.kind in ("decimal", "timestamp", "dict", "bool") and w == tt.size:
+            rt = tt
+        out_cols.append(OutCol(name, "proj", rt, ti, dictionary=dic,
+                               scale=(tt.scale if tt.kind == "decimal" else 0)))
+    p.row_size_quad = 0 if columnar else row_off // 8
+    if columnar:
+        total = align8(entry_count * 8)
+        for w in slot_widths:
+            total = align8(total) + entry_count * w
+        buffer_bytes = align8(total)
+    else:
+        buffer_bytes = row_off * entry_count
+    _fill_cols(storage, b, p)
+    return CompiledPlan(plan=p, query=q, init_vals=np.array(init_vals, dtype=np.int64), slot_widths=slot_widths,
+                        input_cols=list(b.cols), inner_tables=[t.name for t in b.inner], join_infos=join_infos,
+                        out_cols=out_cols, key_types=[], buffer_bytes=buffer_bytes, key_ranges=[])
+
+
 def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
+    from .ir import Proj
+    if q.targets and all(isinstance(t, Proj) for t in q.targets):
+        if q.groupby:
+            raise QueryMustRunOnCpu("projection targets with GROUP BY")
+        return compile_projection(storage, q)
+    if any(isinstance(t, Proj) for t in q.targets):
+        raise QueryMustRunOnCpu("mixing projections and aggregates")
     b = _Binder(storage, q)
     p = A.Plan()
     p.abi_version = A.PLAN_ABI
@@ -636,11 +761,18 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
 # ---------------------------------------------------------------------------------------------
 # host-side helpers shared by the executor and the tests
 # ---------------------------------------------------------------------------------------------
+def eff_key_count(p) -> int:
+    """Key columns in front of the slots: the group-by keys, or the row-position column of a projection."""
+    return 1 if p.query_kind == A.Q_PROJECTION else int(p.key_count)
+
+
 def columnar_slot_offsets(cp: CompiledPlan, entry_count: Optional[int] = None) -> List[int]:
     """Byte offset of every slot column (QueryMemoryDescriptor::getColOffInBytes, columnar)."""
     p = cp.plan
     n = int(entry_count if entry_count is not None else p.entry_count)
     off = 0 if p.keyless else p.key_count * align8(n * 8)
+    if p.query_kind == A.Q_PROJECTION:
+        off = align8(n * 8)  # the row-position column
     offs = []
     for w in cp.slot_widths:
         off = align8(off)
@@ -655,7 +787,7 @@ def compact_init_vals(cp: CompiledPlan) -> np.ndarray:
     p = cp.plan
     if p.query_kind == A.Q_NON_GROUPED or p.output_columnar:
         return cp.init_vals.copy()
-    keys_bytes = 0 if p.keyless else align8(p.key_count * p.key_width)
+    keys_bytes = 0 if p.keyless else align8(eff_key_count(p) * p.key_width)
     nbytes = p.row_size_quad * 8 - keys_bytes
     raw = np.zeros(nbytes, dtype=np.uint8)
     s = 0
@@ -681,24 +813,26 @@ def init_buffer_host(cp: CompiledPlan, entry_count: Optional[int] = None) -> np.
         return cp.init_vals.copy()
     if p.output_columnar:
         offs = columnar_slot_offsets(cp, n)
-        total = offs[-1] + n * cp.slot_widths[-1] if offs else p.key_count * align8(n * 8)
+        nk = eff_key_count(p)
+        total = offs[-1] + n * cp.slot_widths[-1] if offs else nk * align8(n * 8)
         buf = np.zeros(align8(total), dtype=np.uint8)
         if not p.keyless:
-            buf[:p.key_count * align8(n * 8)].view(np.int64)[:] = A.EMPTY_KEY_64
+            buf[:nk * align8(n * 8)].view(np.int64)[:] = A.EMPTY_KEY_64
         for off, w, v in zip(offs, cp.slot_widths, cp.init_vals):
-            dt = np.int64 if w == 8 else np.int32
-            buf[off:off + n * w].view(dt)[:] = dt(int(v) if w == 8 else np.int64(v).astype(np.int32))
+            dt = {8: np.int64, 4: np.int32, 2: np.int16, 1: np.int8}[w]
+            buf[off:off + n * w].view(dt)[:] = np.int64(v).astype(dt)
         return buf.view(np.int64).copy()
     rq = int(p.row_size_quad)
     buf = np.zeros((n, rq), dtype=np.int64)
     keys_quads = 0
     if not p.keyless:
-        keys_quads = align8(p.key_count * p.key_width) // 8
+        nk = eff_key_count(p)
+        keys_quads = align8(nk * p.key_width) // 8
         kb = np.zeros((n, keys_quads * 8), dtype=np.uint8)
         if p.key_width == 8:
-            kb.view(np.int64)[:, :p.key_count] = A.EMPTY_KEY_64
+            kb.view(np.int64)[:, :nk] = A.EMPTY_KEY_64
         else:
-            kb.view(np.int32)[:, :p.key_count] = A.EMPTY_KEY_32
+            kb.view(np.int32)[:, :nk] = A.EMPTY_KEY_32
         buf[:, :keys_quads] = kb.view(np.int64)
     buf[:, keys_quads:] = compact_init_vals(cp)[None, :]
     return buf.reshape(-1).copy()

@@ -78,11 +78,61 @@ def non_empty_mask(cp: CompiledPlan, buf: np.ndarray, entry_count: int) -> np.nd
     return k0 != empty
 
 
-def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None) -> Dict[str, list]:
+def projection_arrays(cp: CompiledPlan, buf: np.ndarray, nrows: int, capacity=None):
+    """(row positions, [one int64/float64 numpy array per projected column]) of a Projection buffer
+    holding `nrows` rows (TOTAL_MATCHED)."""
+    p = cp.plan
+    n = int(capacity if capacity is not None else p.entry_count)
+    raw = np.ascontiguousarray(buf).view(np.uint8)
+    nrows = min(int(nrows), n)
+    cols = []
+    if p.output_columnar:
+        pos = raw[:n * 8].view(np.int64)[:nrows].copy()
+        for off, w in zip(columnar_slot_offsets(cp, n), cp.slot_widths):
+            dt = {8: np.int64, 4: np.int32, 2: np.int16, 1: np.int8}[w]
+            cols.append(raw[off:off + n * w].view(dt)[:nrows].astype(np.int64))
+    else:
+        rb = int(p.row_size_quad) * 8
+        rows = raw[:n * rb].reshape(n, rb)[:nrows]
+        pos = np.ascontiguousarray(rows[:, :8]).view(np.int64).reshape(-1)
+        for ti in range(p.num_targets):
+            off = p.targets[ti].slot_off
+            cols.append(np.ascontiguousarray(rows[:, off:off + 8]).view(np.int64).reshape(-1))
+    return pos, cols
+
+
+def _projection_columns(cp: CompiledPlan, buf: np.ndarray, nrows: int, capacity=None) -> Dict[str, list]:
+    p = cp.plan
+    _, cols = projection_arrays(cp, buf, nrows, capacity)
+    res: Dict[str, list] = {}
+    for oc, arr in zip(cp.out_cols, cols):
+        tg = p.targets[oc.target_idx]
+        if tg.arg_is_fp:
+            nullv = tg.arg.null_val
+            vals = [None if (tg.arg.nullable and v == nullv) else float(np.int64(v).view(np.float64))
+                    for v in arr.tolist()]
+        else:
+            # a narrow columnar slot holds the value truncated to its width: compare with the truncated NULL
+            w = cp.slot_widths[oc.target_idx]
+            nullv = int(tg.arg.null_val)
+            if w < 8:
+                nullv = int(np.int64(nullv).astype({4: np.int32, 2: np.int16, 1: np.int8}[w]))
+            vals = [None if (tg.arg.nullable and v == nullv) else v for v in arr.tolist()]
+            if oc.dictionary is not None:
+                vals = [None if v is None else oc.dictionary[v] for v in vals]
+            elif oc.scale:
+                vals = [None if v is None else v / 10 ** oc.scale for v in vals]
+        res[oc.name] = vals
+    return res
+
+
+def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) -> Dict[str, list]:
     """Materialise result rows as {column name: python list} in entry order (None = NULL)."""
     p = cp.plan
     n = int(entry_count if entry_count is not None else p.entry_count)
     buf = np.ascontiguousarray(buf)
+    if p.query_kind == A.Q_PROJECTION:
+        return _projection_columns(cp, buf, n if nrows is None else nrows, n)
     mask = non_empty_mask(cp, buf, n)
     slots = _slot_arrays(cp, buf, n)
     keys = _key_arrays(cp, buf, n)
@@ -146,13 +196,13 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None) -> Dict[str,
     return res
 
 
-def to_arrow(cp: CompiledPlan, buf: np.ndarray, entry_count=None):
+def to_arrow(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None):
     import pyarrow as pa
-    cols = to_columns(cp, buf, entry_count)
+    cols = to_columns(cp, buf, entry_count, nrows)
     arrays, names = [], []
     for oc in cp.out_cols:
         v = cols[oc.name]
-        if oc.kind == "key" and oc.dictionary is not None:
+        if oc.kind in ("key", "proj") and oc.dictionary is not None:
             arr = pa.array(v, type=pa.string())
         elif oc.agg == "count":
             arr = pa.array(v, type=pa.int32() if oc.type.size == 4 else pa.int64())

@@ -223,14 +223,19 @@ typedef struct hdk_hip_join {
 enum hdk_hip_query_kind {
   HDK_Q_NON_GROUPED = 0,        /* NonGroupedAggregate */
   HDK_Q_PERFECT_HASH = 1,       /* GroupByPerfectHash */
-  HDK_Q_BASELINE_HASH = 2       /* GroupByBaselineHash */
+  HDK_Q_BASELINE_HASH = 2,      /* GroupByBaselineHash */
+  HDK_Q_PROJECTION = 3          /* Projection: filter/project, one output row per passing input row.
+                                   Layout (RS/QueryMemoryDescriptor.cpp:314-342): row-wise
+                                   [int64 row position | slots], columnar [int64 positions | slot
+                                   columns at their logical widths]; rows land at atomically claimed
+                                   positions (TOTAL_MATCHED), `entry_count` = MAX_MATCHED rows. */
 };
 
 enum hdk_hip_agg {
   HDK_AGG_COUNT = 0, HDK_AGG_SUM = 1, HDK_AGG_MIN = 2, HDK_AGG_MAX = 3, HDK_AGG_AVG = 4,
-  HDK_AGG_ID = 5 /* non-aggregate target = a projected group-by key, written with agg_id
-                    (QE/RuntimeFunctions.cpp:473-476); `key_idx` names the key, `arg` repeats its
-                    expression */
+  HDK_AGG_ID = 5 /* non-aggregate target, written with agg_id (QE/RuntimeFunctions.cpp:473-476).
+                    Group-by plans: a projected group-by key, `key_idx` names it and `arg` repeats its
+                    expression.  Projection plans: any expression `arg`, key_idx = -1. */
 };
 typedef struct hdk_hip_target {
   int32_t agg;        /* hdk_hip_agg */

@@ -1163,6 +1163,9 @@ static int8_t eval_qual(const orc_row_ctx* c, const hdk_hip_qual* q, int32_t* er
 }
 
 static inline size_t columnar_keys_bytes(const hdk_hip_plan* p, uint32_t entry_count) {
+  if (p->query_kind == HDK_Q_PROJECTION) { /* row-position column (QueryMemoryDescriptor.cpp:457-478) */
+    return align_to_int64_sz((size_t)entry_count * 8);
+  }
   if (p->keyless) {
     return 0;
   }
@@ -1209,6 +1212,8 @@ static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2,
   const int64_t nullv = tg->null_val;
   if (tg->agg == HDK_AGG_ID) { /* agg_id / agg_id_int32: RuntimeFunctions.cpp:473-476, 562-571 */
     if (tg->slot_width == 4) *(int32_t*)slot1 = (int32_t)val;
+    else if (tg->slot_width == 2) *(int16_t*)slot1 = (int16_t)val;
+    else if (tg->slot_width == 1) *(int8_t*)slot1 = (int8_t)val;
     else *(int64_t*)slot1 = val;
     return;
   }
@@ -1492,6 +1497,75 @@ int32_t orc_run_plan(const hdk_hip_plan* plan, const int8_t* const* const* col_b
                      const int64_t* join_hash_tables, int64_t* out) {
   return orc_run_plan_range(plan, col_buffers, 0, num_fragments, num_rows, num_tables,
                             join_hash_tables, out);
+}
+
+/* ============================================================================================
+ * Projection (filter/project): QE/RowFuncBuilder.cpp:162-215 claims an output row with
+ * old = (*total_matched)++ and get_scan_output_slot / get_columnar_scan_output_offset
+ * (QE/GroupByRuntime.cpp:248-272) writes the row position and returns the slot base; targets are
+ * stored with agg_id.  Rows beyond max_matched report "out of slots" as -pos.
+ * ========================================================================================== */
+int32_t orc_run_projection(const hdk_hip_plan* plan, const int8_t* const* const* col_buffers,
+                           uint64_t num_fragments, const int64_t* num_rows, uint32_t num_tables,
+                           const int64_t* join_hash_tables, int64_t* out, int32_t max_matched,
+                           int32_t* total_matched) {
+  int32_t first_err = 0;
+  orc_row_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.plan = plan;
+  const hdk_hip_plan* p = plan;
+  for (uint64_t f = 0; f < num_fragments; ++f) {
+    c.cols = col_buffers[f];
+    const int64_t n = num_rows[f * num_tables];
+    for (int64_t pos = 0; pos < n; ++pos) {
+      c.pos = pos;
+      int32_t err = 0;
+      int passes = 1;
+      for (int q = 0; q < p->num_quals && passes; ++q) {
+        if (eval_qual(&c, &p->quals[q], &err) != 1) passes = 0;
+      }
+      for (int j = 0; j < p->num_joins && passes; ++j) {
+        const hdk_hip_join* jn = &p->joins[j];
+        const int64_t key = eval_expr(&c, &jn->outer_key, &err);
+        const int32_t* table = (const int32_t*)(intptr_t)(p->num_joins == 1 && jn->table_idx == 0
+                                                              ? (int64_t)(intptr_t)join_hash_tables
+                                                              : join_hash_tables[jn->table_idx]);
+        int64_t idx;
+        if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) idx = orc_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val);
+        else if (jn->null_mode == HDK_JOIN_NULL_BITWISE) idx = orc_hash_join_idx_bitwise(table, key, jn->min_key, jn->max_key, jn->null_val, jn->translated_null);
+        else idx = orc_hash_join_idx(table, key, jn->min_key, jn->max_key);
+        if (idx < 0 && jn->type == HDK_JOIN_INNER) passes = 0;
+        c.join_row[j] = idx;
+      }
+      if (!passes) {
+        if (err && !first_err) first_err = err;
+        continue;
+      }
+      const uint32_t slot = (uint32_t)(*total_matched)++;
+      if (slot >= (uint32_t)max_matched) {
+        if (!first_err) first_err = -(int32_t)pos; /* out of slots: -pos (RowFuncBuilder.cpp:268-273) */
+        continue;
+      }
+      int8_t* row_base = NULL;
+      if (p->output_columnar) {
+        out[slot] = pos; /* get_columnar_scan_output_offset */
+      } else {
+        int64_t* rp = out + (size_t)slot * p->row_size_quad; /* get_scan_output_slot */
+        rp[0] = pos;
+        row_base = (int8_t*)rp;
+      }
+      for (int t = 0; t < p->num_targets; ++t) {
+        const hdk_hip_target* tg = &p->targets[t];
+        int64_t v = eval_expr(&c, &tg->arg, &err);
+        int8_t* s1 = p->output_columnar
+                         ? (int8_t*)out + columnar_slot_off(p, p->entry_count, t) + (size_t)slot * tg->slot_width
+                         : row_base + tg->slot_off;
+        apply_target(tg, s1, NULL, v);
+      }
+      if (err && !first_err) first_err = err;
+    }
+  }
+  return first_err;
 }
 
 /* ============================================================================================

@@ -153,6 +153,13 @@ int32_t orc_run_plan_range(const hdk_hip_plan* plan, const int8_t* const* const*
                            uint64_t frag_begin, uint64_t frag_end, const int64_t* num_rows,
                            uint32_t num_tables, const int64_t* join_hash_tables, int64_t* out);
 
+/* Projection (filter/project) plans: rows are claimed in scan order through *total_matched
+ * (QE/RowFuncBuilder.cpp:162-215, QE/GroupByRuntime.cpp:248-272). */
+int32_t orc_run_projection(const hdk_hip_plan* plan, const int8_t* const* const* col_buffers,
+                           uint64_t num_fragments, const int64_t* num_rows, uint32_t num_tables,
+                           const int64_t* join_hash_tables, int64_t* out, int32_t max_matched,
+                           int32_t* total_matched);
+
 /* Partial-result reduction: QE/ResultSetReduction.cpp:174-330 (perfect hash / non-grouped:
  * entry-wise reduceOneSlot :1234-1330; baseline: reduceOneEntryBaseline :694-731 re-insert).
  * `that` is merged into `this_`.  Non-grouped buffers are the per-target slot vectors. */

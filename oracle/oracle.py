@@ -97,6 +97,7 @@ def lib():
     _sig(L, "orc_run_plan", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, v, C.c_uint32, v, v)
     _sig(L, "orc_run_plan_range", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, C.c_uint64, v,
          C.c_uint32, v, v)
+    _sig(L, "orc_run_projection", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, v, C.c_uint32, v, v, C.c_int32, v)
     _sig(L, "orc_reduce", C.c_int32, C.POINTER(A.Plan), v, C.c_uint32, v, C.c_uint32, v)
     _sig(L, "orc_is_empty_entry", C.c_int32, C.POINTER(A.Plan), v, C.c_uint32, C.c_uint32, v)
     _sig(L, "orc_run_plan_parallel", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, v, C.c_uint32, v,
@@ -217,6 +218,22 @@ def run_plan(plan, frags: HostFragments, out: np.ndarray, join_tables=None):
     err = lib().orc_run_plan(C.byref(plan), C.cast(frags.outer, C.c_void_p), frags.num_fragments,
                              _ptr(frags.num_rows), frags.num_tables, jt, _ptr(out))
     return err
+
+
+def run_projection(plan, frags: HostFragments, out: np.ndarray, max_matched: int, join_tables=None):
+    """Filter/project plan; returns (err, number of rows claimed)."""
+    jt = None
+    keep = None
+    if join_tables:
+        if len(join_tables) == 1:
+            jt = C.c_void_p(join_tables[0].ctypes.data)
+        else:
+            keep = np.array([t.ctypes.data for t in join_tables], dtype=np.int64)
+            jt = _ptr(keep)
+    total = np.zeros(1, dtype=np.int32)
+    err = lib().orc_run_projection(C.byref(plan), C.cast(frags.outer, C.c_void_p), frags.num_fragments,
+                                   _ptr(frags.num_rows), frags.num_tables, jt, _ptr(out), max_matched, _ptr(total))
+    return err, int(total[0])
 
 
 def run_plan_parallel(plan, frags: HostFragments, init_buffer: np.ndarray, init_vals: np.ndarray,
