@@ -45,7 +45,7 @@ LEAF_NONE, LEAF_COL, LEAF_INT, LEAF_FP = 0, 1, 2, 3
 (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_EXTRACT_YEAR, OP_SCALE_DOWN, OP_FLOOR_DIV,
  OP_CAST_INT_TO_FP, OP_CAST_FP_TO_INT) = range(1, 11)
 CMP_EQ, CMP_NE, CMP_LT, CMP_GT, CMP_LE, CMP_GE = range(1, 7)
-JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY = 0, 1
+JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY, JOIN_ONE_TO_ONE_FUSED = 0, 1, 2
 JOIN_INNER, JOIN_LEFT = 0, 1
 JOIN_NULL_NONE, JOIN_NULL_NULLABLE, JOIN_NULL_BITWISE = 0, 1, 2
 Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH, Q_PROJECTION = 0, 1, 2, 3
@@ -89,7 +89,7 @@ class Join(C.Structure):
     _fields_ = [("outer_key", Expr), ("min_key", C.c_int64), ("max_key", C.c_int64),
                 ("null_val", C.c_int64), ("translated_null", C.c_int64), ("bucket", C.c_int64),
                 ("kind", C.c_int32), ("type", C.c_int32), ("null_mode", C.c_int32),
-                ("table_idx", C.c_int32)]
+                ("table_idx", C.c_int32), ("fused_stride", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Target(C.Structure):

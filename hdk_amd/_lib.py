@@ -59,6 +59,7 @@ SIGNATURES = {
     "hdk_hip_describe_launch": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.c_char_p, sz]),
     "hdk_hip_reduce_buffers": (i32, [C.POINTER(A.Plan), v, u32, C.POINTER(v), C.POINTER(u32), i32, v, v,
                                      i32, v]),
+    "hdk_hip_build_fused_join_table": (i32, [v, i64, C.POINTER(v), C.POINTER(i32), C.POINTER(i32), i32, v, i32, v]),
     "hdk_hip_init_hash_join_buff": (i32, [v, i64, i32, i32, v]),
     "hdk_hip_fill_hash_join_buff": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i32, v]),
     "hdk_hip_fill_hash_join_buff_bucketized": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo,

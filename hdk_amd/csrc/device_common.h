@@ -79,6 +79,40 @@ HDK_DEV int64_t decode_col(const int8_t* __restrict__ buf, int32_t width, int32_
   }
 }
 
+// Same decode through an explicit GLOBAL address-space pointer (column buffers are hipMalloc'ed:
+// a pointer loaded from COL_BUFFERS is otherwise generic and compiles to flat_load), optionally
+// non-temporal: streamed outer-table columns should not evict the join tables from the
+// Infinity Cache.
+template <typename T>
+HDK_DEV T gload(const int8_t* buf, int64_t row, bool nt) {
+  const __attribute__((address_space(1))) T* p =
+      reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(buf)) + row;
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
+HDK_DEV int64_t decode_col_g(const int8_t* buf, int32_t width, int32_t kind, int64_t row, bool nt) {
+  switch (kind) {
+    case HDK_COL_DOUBLE:
+      return gload<int64_t>(buf, row, nt);
+    case HDK_COL_FLOAT:
+      return double_to_bits(static_cast<double>(gload<float>(buf, row, nt)));
+    case HDK_COL_UNSIGNED:
+      switch (width) {
+        case 1: return gload<uint8_t>(buf, row, nt);
+        case 2: return gload<uint16_t>(buf, row, nt);
+        case 4: return gload<uint32_t>(buf, row, nt);
+        default: return gload<int64_t>(buf, row, nt);
+      }
+    default:
+      switch (width) {
+        case 1: return gload<int8_t>(buf, row, nt);
+        case 2: return gload<int16_t>(buf, row, nt);
+        case 4: return gload<int32_t>(buf, row, nt);
+        default: return gload<int64_t>(buf, row, nt);
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------------
@@ -308,6 +342,29 @@ HDK_DEV int64_t probe_join(const hdk_hip_join& jn, const int32_t* __restrict__ t
       off /= jn.bucket;
     }
     return table[off];
+  }
+  return -1;
+}
+
+// same probe, table read through a global-address-space pointer; *slot_out = the slot index
+HDK_DEV int64_t probe_join_g(const hdk_hip_join& jn, const int32_t* table, int64_t key, int64_t* slot_out) {
+  int64_t k = key;
+  int64_t maxk = jn.max_key;
+  *slot_out = 0;
+  if (jn.null_mode != HDK_JOIN_NULL_NONE && key == jn.null_val) {
+    if (jn.null_mode == HDK_JOIN_NULL_NULLABLE) {
+      return -1;
+    }
+    k = jn.translated_null;
+    maxk = jn.translated_null;
+  }
+  if (k >= jn.min_key && k <= maxk) {
+    int64_t off = k - jn.min_key;
+    if (jn.bucket > 1) {
+      off /= jn.bucket;
+    }
+    *slot_out = off;
+    return gload<int32_t>(reinterpret_cast<const int8_t*>(table), off, false);
   }
   return -1;
 }

@@ -322,9 +322,62 @@ static int32_t one_to_many(int32_t* buff, int64_t hash_entry_count, int32_t inva
   return HDK_HIP_OK;
 }
 
+// ---- fused one-to-one table: [row id | payload words] per slot (HDK_JOIN_ONE_TO_ONE_FUSED) ------------
+constexpr int kMaxFusedCols = 7;
+struct FusedArgs {
+  const int32_t* table;
+  int64_t entry_count;
+  const int8_t* cols[kMaxFusedCols];
+  int32_t widths[kMaxFusedCols];
+  int32_t kinds[kMaxFusedCols];
+  int32_t ncols;
+  int64_t* out;
+};
+
+__global__ __launch_bounds__(kJoinBlock) void k_build_fused(FusedArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kJoinBlock;
+  const int64_t es = 1 + a.ncols;
+  for (int64_t slot = static_cast<int64_t>(blockIdx.x) * kJoinBlock + threadIdx.x; slot < a.entry_count; slot += stride) {
+    const int32_t rid = a.table[slot];
+    int64_t* o = a.out + slot * es;
+    o[0] = rid;
+    for (int c = 0; c < a.ncols; ++c) {
+      o[1 + c] = rid >= 0 ? decode_col(a.cols[c], a.widths[c], a.kinds[c], rid) : 0;
+    }
+  }
+}
+
 }  // namespace hdk
 
 using namespace hdk;
+
+extern "C" int32_t hdk_hip_build_fused_join_table(const int32_t* table, int64_t entry_count,
+                                                  const int8_t* const* inner_cols, const int32_t* widths,
+                                                  const int32_t* kinds, int32_t ncols, int64_t* out,
+                                                  int32_t device_id, void* stream) {
+  HDK_REQUIRE(table && out, "NULL buffer");
+  HDK_REQUIRE(ncols >= 0 && ncols <= kMaxFusedCols, "0..%d payload columns", kMaxFusedCols);
+  HDK_REQUIRE(ncols == 0 || (inner_cols && widths && kinds), "NULL column description");
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  if (entry_count <= 0) {
+    return HDK_HIP_OK;
+  }
+  FusedArgs a;
+  a.table = table;
+  a.entry_count = entry_count;
+  a.ncols = ncols;
+  a.out = out;
+  for (int c = 0; c < kMaxFusedCols; ++c) {
+    a.cols[c] = c < ncols ? inner_cols[c] : nullptr;
+    a.widths[c] = c < ncols ? widths[c] : 0;
+    a.kinds[c] = c < ncols ? kinds[c] : 0;
+  }
+  hipLaunchKernelGGL(k_build_fused, dim3(grid_for(static_cast<size_t>(entry_count), device_id)), dim3(kJoinBlock), 0, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
 
 extern "C" int32_t hdk_hip_init_hash_join_buff(int32_t* buff, int64_t entry_count, int32_t invalid_slot_val,
                                                int32_t device_id, void* stream) {

@@ -764,6 +764,18 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   if (st) return st;
   const hdk_hip_device_properties* props = device_props(device_id);
   const LaunchShape shape = choose_shape(plan, ko, props);
+  for (int j = 0; j < plan->num_joins; ++j) {
+    if (plan->joins[j].kind == HDK_JOIN_ONE_TO_ONE_FUSED) {
+      HDK_REQUIRE(plan->joins[j].fused_stride >= 1, "fused join table needs fused_stride >= 1");
+      if (shape.strategy == STRAT_GLOBAL || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
+        set_error("fused join tables are only read by the batched interpreter kernels");
+        return HDK_HIP_ERR_UNSUPPORTED;
+      }
+    } else if (plan->joins[j].kind != HDK_JOIN_ONE_TO_ONE) {
+      set_error("one-to-many join probes are outside the fixed kernel library");
+      return HDK_HIP_ERR_UNSUPPORTED;
+    }
+  }
   HDK_REQUIRE(workspace && workspace_bytes >= workspace_bytes_for(shape),
               "workspace too small: %zu < %zu", workspace_bytes, workspace_bytes_for(shape));
   HDK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "workspace must be 16-byte aligned");

@@ -81,7 +81,13 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs
   for (int r = 0; r < VR; ++r) {
     c.jrow0[r] = 0;
     c.jrow1[r] = 0;
+    c.jslot0[r] = 0;
+    c.jslot1[r] = 0;
   }
+  c.fused0 = nullptr;
+  c.fused1 = nullptr;
+  c.fstride0 = 0;
+  c.fstride1 = 0;
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;

@@ -55,7 +55,13 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjAr
   for (int r = 0; r < VR; ++r) {
     c.jrow0[r] = 0;
     c.jrow1[r] = 0;
+    c.jslot0[r] = 0;
+    c.jslot1[r] = 0;
   }
+  c.fused0 = nullptr;
+  c.fused1 = nullptr;
+  c.fstride0 = 0;
+  c.fstride1 = 0;
   int32_t err = 0;
   int32_t slots_err = 0;
 

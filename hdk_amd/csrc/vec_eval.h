@@ -20,6 +20,12 @@ struct VecCtx {
   int64_t row[VR];            // outer row per slot (clamped into the fragment for dead slots)
   int32_t jrow0[VR];          // matched inner row of join 0 / 1
   int32_t jrow1[VR];
+  int32_t jslot0[VR];         // probed slot of join 0 / 1 (payload words of a fused table)
+  int32_t jslot1[VR];
+  const int64_t* fused0;      // fused tables (HDK_JOIN_ONE_TO_ONE_FUSED) or nullptr
+  const int64_t* fused1;
+  int32_t fstride0;
+  int32_t fstride1;
 };
 
 template <typename F>
@@ -33,10 +39,21 @@ HDK_DEV void for_rows(F&& f) {
 HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[VR]) {
   if (l.kind == HDK_LEAF_COL) {
     const hdk_hip_col col = c.plan->cols[l.col];
-    const int8_t* __restrict__ buf = c.cols[col.buf_idx];
     const int width = col.width;
     const int kind = col.kind;
     const int table = col.table;
+    const int8_t* __restrict__ buf = table >= 0 ? c.cols[col.buf_idx] : nullptr;
+    if (table < 0) {  // payload word of a fused join table: same cache line as the probed row id
+      const int64_t* __restrict__ ft = table == -1 ? c.fused0 : c.fused1;
+      const int64_t stride = table == -1 ? c.fstride0 : c.fstride1;
+      const int word = col.buf_idx;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const int64_t slot = table == -1 ? c.jslot0[r] : c.jslot1[r];
+        out[r] = gload<int64_t>(reinterpret_cast<const int8_t*>(ft), slot * stride + word, false);
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       int64_t row = c.row[r];
@@ -45,7 +62,9 @@ HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[
       } else if (table == 2) {
         row = c.jrow1[r];
       }
-      out[r] = decode_col(buf, width, kind, row);
+      // outer-table columns are streamed exactly once: non-temporal; inner (joined) columns are
+      // gathered repeatedly and should stay cached
+      out[r] = decode_col_g(buf, width, kind, row, table == 0);
     }
   } else {
     const int64_t v = l.ival;
@@ -205,10 +224,46 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
                                             ? reinterpret_cast<const int32_t*>(join_hash_tables)
                                             : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
     const bool inner = jn.type == HDK_JOIN_INNER;
+    const bool fused = jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED;
+    if (fused) {
+      if (j == 0) {
+        c.fused0 = reinterpret_cast<const int64_t*>(table);
+        c.fstride0 = jn.fused_stride;
+      } else {
+        c.fused1 = reinterpret_cast<const int64_t*>(table);
+        c.fstride1 = jn.fused_stride;
+      }
+    }
+    const int64_t fstride = jn.fused_stride;
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       // dead slots probe with their (clamped, valid) row too: harmless, keeps the loads unconditional
-      const int64_t idx = probe_join(jn, table, key[r]);
+      int64_t slot;
+      int64_t idx;
+      if (fused) {
+        // the slot computation of probe_join_g, but the row id is word 0 of the 8*(1+k)-byte entry
+        int64_t k = key[r];
+        int64_t maxk = jn.max_key;
+        bool in_range = true;
+        if (jn.null_mode != HDK_JOIN_NULL_NONE && k == jn.null_val) {
+          if (jn.null_mode == HDK_JOIN_NULL_NULLABLE) {
+            in_range = false;
+          }
+          k = jn.translated_null;
+          maxk = jn.translated_null;
+        }
+        in_range = in_range && k >= jn.min_key && k <= maxk;
+        slot = in_range ? (jn.bucket > 1 ? (k - jn.min_key) / jn.bucket : (k - jn.min_key)) : 0;
+        const int64_t rid = gload<int64_t>(reinterpret_cast<const int8_t*>(table), slot * fstride, false);
+        idx = in_range ? rid : -1;
+      } else {
+        idx = probe_join_g(jn, table, key[r], &slot);
+      }
+      if (j == 0) {
+        c.jslot0[r] = static_cast<int32_t>(slot);
+      } else {
+        c.jslot1[r] = static_cast<int32_t>(slot);
+      }
       if (inner) {
         pass[r] = pass[r] && idx >= 0;
       }

@@ -105,6 +105,12 @@ class PreparedStep:
 
         # ---- join hash tables (built once per device, cached) ----------------------------
         self.join_tables = [ex._build_join_table(cp, ji) for ji in range(len(cp.inner_tables))]
+        # the launch uses a private copy of the plan: fusing join tables rewrites column descriptors
+        self.plan = A.Plan.from_buffer_copy(cp.plan)
+        if self.join_tables and ex.fuse_join_tables and not (flags & (A.LAUNCH_FORCE_SCALAR |
+                                                                        A.LAUNCH_FORCE_GLOBAL_ATOMICS)):
+            self._fuse_join_tables()
+        p = self.plan
 
         # ---- col_buffers[frag][buf_idx] ---------------------------------------------------
         ncols = len(cp.input_cols)
@@ -193,8 +199,48 @@ class PreparedStep:
 
     def kernel_names(self) -> str:
         out = C.create_string_buffer(256)
-        check(self.L.hdk_hip_describe_launch(C.byref(self.cp.plan), C.byref(self.ko), self.dev, out, 256))
+        check(self.L.hdk_hip_describe_launch(C.byref(self.plan), C.byref(self.ko), self.dev, out, 256))
         return out.value.decode()
+
+    def _fuse_join_tables(self, max_bytes=2 << 30):
+        """Replace each one-to-one join table by the fused [row id | payload ...] form when the batched
+        interpreter (or the projection kernel) will run the plan: one gather per probing row instead of
+        slot -> row id -> inner column (HDK_JOIN_ONE_TO_ONE_FUSED, include/hdk_hip.h)."""
+        names = self.kernel_names()
+        if not (names.startswith("hdk_scan_agg_vec") or names.startswith("hdk_scan_project")):
+            return
+        cp, p, storage = self.cp, self.plan, self.ex.storage
+        for ji, info in enumerate(cp.join_infos):
+            cols = [ci for ci, (tn, cn, slot) in enumerate(cp.input_cols) if slot == ji + 1]
+            entries = info["max"] - info["min"] + 1
+            stride = 1 + len(cols)
+            if len(cols) > 7 or entries * stride * 8 > max_bytes:
+                continue
+            key = (info["inner_table"], info["inner_col"], tuple(cp.input_cols[ci][1] for ci in cols))
+            fused = self.ex._fused_cache.get(key)
+            if fused is None:
+                inner = storage.get(info["inner_table"])
+                ptrs = (C.c_void_p * max(len(cols), 1))()
+                widths = (C.c_int32 * max(len(cols), 1))()
+                kinds = (C.c_int32 * max(len(cols), 1))()
+                for k, ci in enumerate(cols):
+                    ptrs[k] = self.ex.cache.linearized(inner, cp.input_cols[ci][1]).ptr
+                    widths[k] = p.cols[ci].width
+                    kinds[k] = p.cols[ci].kind
+                fused = self.mgr.alloc(entries * stride * 8, self.dev)
+                check(self.L.hdk_hip_build_fused_join_table(self.join_tables[ji].ptr, entries, ptrs, widths, kinds,
+                                                            len(cols), fused.ptr, self.dev, None))
+                self.mgr.synchronizeStream(self.dev)
+                self.ex._fused_cache[key] = fused
+            for k, ci in enumerate(cols):
+                # payload words are int64 (ints sign-extended, float widened to double by the decoder)
+                p.cols[ci].kind = A.COL_DOUBLE if p.cols[ci].kind in (A.COL_FLOAT, A.COL_DOUBLE) else A.COL_INT
+                p.cols[ci].width = 8
+                p.cols[ci].table = -(ji + 1)
+                p.cols[ci].buf_idx = 1 + k
+            p.joins[ji].kind = A.JOIN_ONE_TO_ONE_FUSED
+            p.joins[ji].fused_stride = stride
+            self.join_tables[ji] = fused
 
     # ---- the three steps of launchGpuCode ------------------------------------------------------
     def init_output(self, stream=None):
@@ -223,7 +269,7 @@ class PreparedStep:
                 props.max_threads_per_block, props.grid_size, self.dev, stream))
 
     def launch(self, stream=None):
-        check(self.L.hdk_hip_launch(C.byref(self.cp.plan), self._params, C.byref(self.ko), self.dev, stream,
+        check(self.L.hdk_hip_launch(C.byref(self.plan), self._params, C.byref(self.ko), self.dev, stream,
                                     self.workspace.ptr, self.workspace.nbytes))
 
     def fetch(self, stream_synced=False) -> ExecutionResult:
@@ -261,6 +307,8 @@ class Executor:
         self.device_id = device_id
         self.cache = BufferCache(self.mgr, device_id)
         self._join_cache: Dict[tuple, DeviceBuffer] = {}
+        self._fused_cache: Dict[tuple, DeviceBuffer] = {}
+        self.fuse_join_tables = True  # HDK_JOIN_ONE_TO_ONE_FUSED for the batched kernels
 
     def compile(self, q: QueryUnit) -> CompiledPlan:
         return compile_query(self.storage, q)

@@ -149,7 +149,9 @@ enum hdk_hip_col_kind {
 
 typedef struct hdk_hip_col {
   int32_t buf_idx;   /* index into col_buffers[frag][...] (the COL_BUFFERS kernel param) */
-  int32_t table;     /* 0 = outer table (row = pos); j>0 = inner table of join j-1 (row = matched id) */
+  int32_t table;     /* 0 = outer table (row = pos); j>0 = inner table of join j-1 (row = matched id);
+                        -j (j>0) = PAYLOAD word `buf_idx` of join j-1's fused table (see
+                        HDK_JOIN_ONE_TO_ONE_FUSED): no column buffer is read */
   int32_t width;     /* bytes per element */
   int32_t kind;      /* hdk_hip_col_kind */
 } hdk_hip_col;
@@ -203,7 +205,15 @@ typedef struct hdk_hip_qual {
 } hdk_hip_qual;
 
 /* Perfect-hash equi-join probe (hash_join_idx family, QE/GroupByRuntime.cpp:274-366). */
-enum hdk_hip_join_kind { HDK_JOIN_ONE_TO_ONE = 0, HDK_JOIN_ONE_TO_MANY = 1 };
+enum hdk_hip_join_kind {
+  HDK_JOIN_ONE_TO_ONE = 0,  /* the reference's table: int32 row id per slot (PerfectHashTableBuilder.h:35-38) */
+  HDK_JOIN_ONE_TO_MANY = 1,
+  /* MI355X addition (no reference counterpart): int64 entries [row id | payload 1 | ... ] per slot,
+   * `fused_stride` quads apart, built by hdk_hip_build_fused_join_table from the reference table and
+   * the referenced inner columns.  One 16..32-B gather per probing row replaces the dependent
+   * slot -> row id -> inner column chain (two cache lines) of the reference layout. */
+  HDK_JOIN_ONE_TO_ONE_FUSED = 2
+};
 enum hdk_hip_join_type { HDK_JOIN_INNER = 0, HDK_JOIN_LEFT = 1 };
 enum hdk_hip_join_null { HDK_JOIN_NULL_NONE = 0, HDK_JOIN_NULL_NULLABLE = 1, HDK_JOIN_NULL_BITWISE = 2 };
 typedef struct hdk_hip_join {
@@ -217,6 +227,8 @@ typedef struct hdk_hip_join {
   int32_t type;            /* hdk_hip_join_type */
   int32_t null_mode;       /* hdk_hip_join_null */
   int32_t table_idx;       /* which entry of JOIN_HASH_TABLES */
+  int32_t fused_stride;    /* HDK_JOIN_ONE_TO_ONE_FUSED: int64 words per slot (1 + payload columns) */
+  int32_t pad_;
 } hdk_hip_join;
 
 /* Query shape: RS/QueryMemoryDescriptor.h `QueryDescriptionType`. */
@@ -414,6 +426,15 @@ int32_t hdk_hip_fill_one_to_many_hash_table_bucketized(int32_t* buff,
                                                        hdk_hip_join_column join_column,
                                                        hdk_hip_join_column_type_info type_info,
                                                        int32_t device_id, void* stream);
+
+/* Build a fused join table (HDK_JOIN_ONE_TO_ONE_FUSED) from a one-to-one table:
+ *   out[slot * (1 + ncols) + 0]     = table[slot]                      (row id or invalid)
+ *   out[slot * (1 + ncols) + 1 + c] = decode(inner_cols[c][row id])     (0 when the slot is empty)
+ * `inner_cols` / `widths` / `kinds` are HOST arrays of ncols device pointers / element widths /
+ * hdk_hip_col_kind; inner columns must be linearised (one buffer per column). */
+int32_t hdk_hip_build_fused_join_table(const int32_t* table, int64_t entry_count, const int8_t* const* inner_cols,
+                                       const int32_t* widths, const int32_t* kinds, int32_t ncols, int64_t* out,
+                                       int32_t device_id, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1858,6 +1858,10 @@ int32_t orc_reduce(const hdk_hip_plan* p, int64_t* this_buf, uint32_t this_entry
  * (QE/Execute.cpp:2776-2788, :1290-1317).  Used only for the timed cpu_baseline in bench.py.
  * ========================================================================================== */
 
+size_t orc_sizeof_plan(void) { /* guards against a stale build after include/hdk_hip.h changed */
+  return sizeof(hdk_hip_plan);
+}
+
 int32_t orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -25,8 +25,10 @@ u32p = C.POINTER(C.c_uint32)
 
 def build(force=False):
     """(Re)build the oracle library (and _ref when /root/reference exists)."""
-    if force or not os.path.exists(_LIB):
-        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"])
+    # always go through make: it is a no-op when up to date and rebuilds when include/hdk_hip.h (the
+    # plan POD the oracle's row function reads) changed
+    subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", "libhdk_oracle.so"],
+                          stdout=subprocess.DEVNULL)
 
 
 def _sig(lib, name, restype, *argtypes):
@@ -103,6 +105,10 @@ def lib():
     _sig(L, "orc_run_plan_parallel", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, v, C.c_uint32, v,
          v, C.c_size_t, v, C.c_int32, v)
     _sig(L, "orc_max_threads", C.c_int32)
+    _sig(L, "orc_sizeof_plan", C.c_size_t)
+    if L.orc_sizeof_plan() != C.sizeof(A.Plan):
+        raise RuntimeError("oracle/libhdk_oracle.so was built against a different include/hdk_hip.h "
+                           f"(plan is {L.orc_sizeof_plan()} B there, {C.sizeof(A.Plan)} B here): make -C oracle")
     _lib = L
     return L
 

@@ -19,6 +19,11 @@ def _run(O, make, st, q, **kw):
     ex = make(st)
     res = ex.execute(cp, **kw)
     assert_buffers_equal(cp, res.buffer, want)
+    if cp.join_infos:  # the reference-layout join table (no fused payload) and the scalar interpreter
+        ex2 = make(st)
+        ex2.fuse_join_tables = False
+        assert_buffers_equal(cp, ex2.execute(cp, **kw).buffer, want)
+        assert_buffers_equal(cp, ex2.execute(cp, flags=A.LAUNCH_FORCE_SCALAR).buffer, want)
     return cp, res
 
 
