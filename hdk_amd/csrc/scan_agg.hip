@@ -663,7 +663,8 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
   FastArgs fa;
   int kw, vw;
-  return match_fast(p, s, &fa, &kw, &vw) ? "hdk_scan_agg_direct" : "hdk_scan_agg_vec";
+  if (match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
@@ -689,7 +690,11 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     v.slabs = slabs;
     v.entry_count = shape.entry_count;
     v.rep = shape.rep;
-    hipLaunchKernelGGL(hdk_scan_agg_vec, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+    if (plan->num_joins) {
+      hipLaunchKernelGGL(hdk_scan_agg_vec_join, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_agg_vec, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+    }
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }
@@ -742,7 +747,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
   } else if (s.strategy == STRAT_PROJECT) {
-    snprintf(out, out_len, "hdk_scan_project");
+    snprintf(out, out_len, plan->num_joins ? "hdk_scan_project_join" : "hdk_scan_project");
   } else {
     snprintf(out, out_len, "hdk_scan_agg_global");
   }
@@ -834,7 +839,11 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     pa.plan = d_plan;
     pa.kp = kp;
     pa.entry_count = plan->entry_count;
-    hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+    if (plan->num_joins) {
+      hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+    }
     HDK_HIP_CHECK(hipGetLastError());
     st = HDK_HIP_OK;
   } else {

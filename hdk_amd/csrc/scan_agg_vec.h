@@ -50,7 +50,8 @@ HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
   }
 }
 
-extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs a) {
+template <bool J>
+HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
   const hdk_hip_plan* __restrict__ p = a.plan;
@@ -75,19 +76,8 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs
   const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
   const int nt = p->num_targets;
 
-  VecCtx c;
-  c.plan = p;
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    c.jrow0[r] = 0;
-    c.jrow1[r] = 0;
-    c.jslot0[r] = 0;
-    c.jslot1[r] = 0;
-  }
-  c.fused0 = nullptr;
-  c.fused1 = nullptr;
-  c.fstride0 = 0;
-  c.fstride1 = 0;
+  VecCtxT<J> c;
+  vec_ctx_init(c, p, tid, kVecBlock);
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
@@ -99,12 +89,7 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       bool pass[VR];
-#pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        const int64_t row = row0 + static_cast<int64_t>(r) * kVecBlock + tid;
-        pass[r] = row < nrows;
-        c.row[r] = pass[r] ? row : row0;  // dead slots re-read a valid row; their results are dropped
-      }
+      vec_ctx_tile(c, row0, nrows, pass);  // dead slots re-read a valid row; their results are dropped
       rows_pass_v(c, a.kp.join_hash_tables, pass, err);
       int64_t entry[VR];
       if (grouped) {
@@ -169,6 +154,16 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs
     }
     slab[i] = acc;
   }
+}
+
+// Two instantiations: plans without joins carry no probe state (fewer VGPRs, more waves for the
+// compute-bound taxi Q3/Q4 shapes); plans with joins trade occupancy for 16-byte probe gathers --
+// a random gather is bound by line fetches from HBM, not by occupancy (scripts/microbench/gather.hip).
+extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs a) {
+  scan_agg_vec_body<false>(a);
+}
+extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_join(VecArgs a) {
+  scan_agg_vec_body<true>(a);
 }
 
 }  // namespace hdk

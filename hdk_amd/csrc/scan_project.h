@@ -32,7 +32,8 @@ HDK_DEV void store_slot(int8_t* p, int width, int64_t v) {
   }
 }
 
-extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjArgs a) {
+template <bool J>
+HDK_DEV void scan_project_body(const ProjArgs& a) {
   __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
@@ -49,19 +50,8 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjAr
   constexpr int64_t kTileRows = static_cast<int64_t>(kProjBlock) * VR;
   int64_t* buf = a.kp.groupby_buf[0];
 
-  VecCtx c;
-  c.plan = p;
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    c.jrow0[r] = 0;
-    c.jrow1[r] = 0;
-    c.jslot0[r] = 0;
-    c.jslot1[r] = 0;
-  }
-  c.fused0 = nullptr;
-  c.fused1 = nullptr;
-  c.fstride0 = 0;
-  c.fstride1 = 0;
+  VecCtxT<J> c;
+  vec_ctx_init(c, p, tid, kProjBlock);
   int32_t err = 0;
   int32_t slots_err = 0;
 
@@ -74,12 +64,7 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjAr
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       bool pass[VR];
-#pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        const int64_t row = row0 + static_cast<int64_t>(r) * kProjBlock + tid;
-        pass[r] = row < nrows;
-        c.row[r] = pass[r] ? row : row0;
-      }
+      vec_ctx_tile(c, row0, nrows, pass);
       rows_pass_v(c, a.kp.join_hash_tables, pass, err);
       // ---- selection vector -> dense output positions ------------------------------------------
       uint32_t mine = 0;
@@ -112,12 +97,12 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjAr
         if (pass[r]) {
           ++out_pos;
           if (pos_r[r] >= max_matched) {
-            slots_err = -1 - static_cast<int32_t>(c.row[r] & 0x3fffffff);  // out of slots: negative
+            slots_err = -1 - static_cast<int32_t>(vrow(c, r) & 0x3fffffff);  // out of slots: negative
             pass[r] = false;
           } else if (columnar) {
-            buf[pos_r[r]] = c.row[r];  // get_columnar_scan_output_offset
+            buf[pos_r[r]] = vrow(c, r);  // get_columnar_scan_output_offset
           } else {
-            buf[static_cast<size_t>(pos_r[r]) * p->row_size_quad] = c.row[r];  // get_scan_output_slot
+            buf[static_cast<size_t>(pos_r[r]) * p->row_size_quad] = vrow(c, r);  // get_scan_output_slot
           }
         }
       }
@@ -144,6 +129,13 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjAr
   } else if (slots_err) {
     atomicCAS(a.kp.error_code, 0, slots_err);  // negative = ran out of slots (benign under a LIMIT)
   }
+}
+
+extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjArgs a) {
+  scan_project_body<false>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_join(ProjArgs a) {
+  scan_project_body<true>(a);
 }
 
 }  // namespace hdk

@@ -13,20 +13,65 @@
 namespace hdk {
 
 constexpr int VR = 8;
+typedef long long __attribute__((ext_vector_type(2))) i64x2;
 
-struct VecCtx {
+template <bool J>
+struct VecCtxT {
+  static constexpr bool kJoins = J;  // false: the plan has no joins; all probe state compiles away
   const hdk_hip_plan* plan;
   const int8_t* const* cols;  // col_buffers[frag]
-  int64_t row[VR];            // outer row per slot (clamped into the fragment for dead slots)
-  int32_t jrow0[VR];          // matched inner row of join 0 / 1
-  int32_t jrow1[VR];
-  int32_t jslot0[VR];         // probed slot of join 0 / 1 (payload words of a fused table)
-  int32_t jslot1[VR];
+  int64_t row0;               // first row of the tile; slot r of lane `tid` is row0 + r*blk + tid
+  int32_t nlive;              // rows of the tile inside the fragment (dead slots re-read row0)
+  int32_t tid;
+  int32_t blk;
+  int32_t jref0[VR];          // join 0 / 1: matched inner row (reference table) or probed slot (fused table)
+  int32_t jref1[VR];
+  int64_t jpay0[VR];          // payload word 1 of a fused entry: arrives with the row id in one 16-B gather
+  int64_t jpay1[VR];
   const int64_t* fused0;      // fused tables (HDK_JOIN_ONE_TO_ONE_FUSED) or nullptr
   const int64_t* fused1;
   int32_t fstride0;
   int32_t fstride1;
 };
+
+// outer row of batch slot r (kept as three scalars + the lane id instead of VR 64-bit registers)
+template <class VecCtx>
+HDK_DEV int64_t vrow(const VecCtx& c, int r) {
+  const int32_t o = r * c.blk + c.tid;
+  return c.row0 + (o < c.nlive ? o : 0);
+}
+
+template <class VecCtx>
+HDK_DEV void vec_ctx_init(VecCtx& c, const hdk_hip_plan* p, int tid, int blk) {
+  c.plan = p;
+  c.tid = tid;
+  c.blk = blk;
+  c.row0 = 0;
+  c.nlive = 0;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    c.jref0[r] = 0;
+    c.jref1[r] = 0;
+    c.jpay0[r] = 0;
+    c.jpay1[r] = 0;
+  }
+  c.fused0 = nullptr;
+  c.fused1 = nullptr;
+  c.fstride0 = 0;
+  c.fstride1 = 0;
+}
+
+// start a tile: sets pass[r] = "slot r is a real row"
+template <class VecCtx>
+HDK_DEV void vec_ctx_tile(VecCtx& c, int64_t row0, int64_t nrows, bool (&pass)[VR]) {
+  const int64_t left = nrows - row0;
+  c.row0 = row0;
+  c.nlive = left > static_cast<int64_t>(VR) * c.blk ? VR * c.blk : static_cast<int32_t>(left);
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    pass[r] = r * c.blk + c.tid < c.nlive;
+  }
+}
 
 template <typename F>
 HDK_DEV void for_rows(F&& f) {
@@ -36,6 +81,7 @@ HDK_DEV void for_rows(F&& f) {
   }
 }
 
+template <class VecCtx>
 HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[VR]) {
   if (l.kind == HDK_LEAF_COL) {
     const hdk_hip_col col = c.plan->cols[l.col];
@@ -43,24 +89,33 @@ HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[
     const int kind = col.kind;
     const int table = col.table;
     const int8_t* __restrict__ buf = table >= 0 ? c.cols[col.buf_idx] : nullptr;
-    if (table < 0) {  // payload word of a fused join table: same cache line as the probed row id
+    if (VecCtx::kJoins && table < 0) {  // payload word of a fused join table: same cache line as the probed row id
       const int64_t* __restrict__ ft = table == -1 ? c.fused0 : c.fused1;
       const int64_t stride = table == -1 ? c.fstride0 : c.fstride1;
       const int word = col.buf_idx;
+      if (word == 1) {  // already in registers (rows_pass_v)
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          out[r] = table == -1 ? c.jpay0[r] : c.jpay1[r];
+        }
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const int64_t slot = table == -1 ? c.jslot0[r] : c.jslot1[r];
+        const int64_t slot = table == -1 ? c.jref0[r] : c.jref1[r];
         out[r] = gload<int64_t>(reinterpret_cast<const int8_t*>(ft), slot * stride + word, false);
       }
       return;
     }
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
-      int64_t row = c.row[r];
-      if (table == 1) {
-        row = c.jrow0[r];
-      } else if (table == 2) {
-        row = c.jrow1[r];
+      int64_t row;
+      if (VecCtx::kJoins && table == 1) {
+        row = c.jref0[r];
+      } else if (VecCtx::kJoins && table == 2) {
+        row = c.jref1[r];
+      } else {
+        row = vrow(c, r);
       }
       // outer-table columns are streamed exactly once: non-temporal; inner (joined) columns are
       // gathered repeatedly and should stay cached
@@ -76,6 +131,7 @@ HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[
 }
 
 // `live[r]`: only live rows may raise ERR_DIV_BY_ZERO (dead rows are evaluated speculatively)
+template <class VecCtx>
 HDK_DEV void eval_expr_v(const VecCtx& c, const hdk_hip_expr& e, int64_t (&acc)[VR], const bool (&live)[VR],
                          int32_t& err) {
   const hdk_hip_plan* p = c.plan;
@@ -168,6 +224,7 @@ HDK_DEV void eval_expr_v(const VecCtx& c, const hdk_hip_expr& e, int64_t (&acc)[
 }
 
 // pass[r] &= (conjunct is TRUE)
+template <class VecCtx>
 HDK_DEV void eval_qual_v(const VecCtx& c, const hdk_hip_qual& q, bool (&pass)[VR], int32_t& err) {
   int64_t lhs[VR];
   int64_t rhs[VR];
@@ -209,13 +266,14 @@ HDK_DEV void eval_qual_v(const VecCtx& c, const hdk_hip_qual& q, bool (&pass)[VR
 }
 
 // filter + join probes for the batch; dead slots stay dead
+template <class VecCtx>
 HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass)[VR], int32_t& err) {
   const hdk_hip_plan* p = c.plan;
   const int nq = p->num_quals;
   for (int q = 0; q < nq; ++q) {
     eval_qual_v(c, p->quals[q], pass, err);
   }
-  const int nj = p->num_joins;
+  const int nj = VecCtx::kJoins ? p->num_joins : 0;
   for (int j = 0; j < nj; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     int64_t key[VR];
@@ -254,30 +312,45 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
         }
         in_range = in_range && k >= jn.min_key && k <= maxk;
         slot = in_range ? (jn.bucket > 1 ? (k - jn.min_key) / jn.bucket : (k - jn.min_key)) : 0;
-        const int64_t rid = gload<int64_t>(reinterpret_cast<const int8_t*>(table), slot * fstride, false);
+        // one line fetch per probe: the row id and the first payload word come in together (a later,
+        // separate payload gather would find the line evicted again -- 16 waves x 512 probes in flight
+        // per CU dwarf the L1)
+        int64_t rid;
+        int64_t pay = 0;
+        if ((fstride & 1) == 0) {
+          const i64x2 e = gload<i64x2>(reinterpret_cast<const int8_t*>(table), slot * (fstride >> 1), false);
+          rid = e.x;
+          pay = e.y;
+        } else {
+          rid = gload<int64_t>(reinterpret_cast<const int8_t*>(table), slot * fstride, false);
+          if (fstride > 1) {
+            pay = gload<int64_t>(reinterpret_cast<const int8_t*>(table), slot * fstride + 1, false);
+          }
+        }
+        if (j == 0) {
+          c.jpay0[r] = pay;
+        } else {
+          c.jpay1[r] = pay;
+        }
         idx = in_range ? rid : -1;
       } else {
         idx = probe_join_g(jn, table, key[r], &slot);
       }
-      if (j == 0) {
-        c.jslot0[r] = static_cast<int32_t>(slot);
-      } else {
-        c.jslot1[r] = static_cast<int32_t>(slot);
-      }
       if (inner) {
         pass[r] = pass[r] && idx >= 0;
       }
-      const int32_t safe = idx < 0 ? 0 : static_cast<int32_t>(idx);
+      const int32_t ref = fused ? static_cast<int32_t>(slot) : (idx < 0 ? 0 : static_cast<int32_t>(idx));
       if (j == 0) {
-        c.jrow0[r] = safe;
+        c.jref0[r] = ref;
       } else {
-        c.jrow1[r] = safe;
+        c.jref1[r] = ref;
       }
     }
   }
 }
 
 // group key #k for the batch (perfect hash: NULL translated)
+template <class VecCtx>
 HDK_DEV void eval_key_v(const VecCtx& c, int k, int64_t (&out)[VR], const bool (&live)[VR], int32_t& err) {
   const hdk_hip_plan* p = c.plan;
   eval_expr_v(c, p->keys[k], out, live, err);
@@ -291,6 +364,7 @@ HDK_DEV void eval_key_v(const VecCtx& c, int k, int64_t (&out)[VR], const bool (
   }
 }
 
+template <class VecCtx>
 HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const bool (&live)[VR], int32_t& err) {
   const hdk_hip_plan* p = c.plan;
   const int nk = p->key_count;
@@ -317,6 +391,7 @@ HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const b
 }
 
 // target argument for the batch; is_null[r] = the value is the skip value
+template <class VecCtx>
 HDK_DEV void eval_target_arg_v(const VecCtx& c, const hdk_hip_target& tg, int64_t (&v)[VR], bool (&is_null)[VR],
                                const bool (&live)[VR], int32_t& err) {
   if (!tg.has_arg) {

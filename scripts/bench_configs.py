@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--rows", type=int, default=256_000_000)
     ap.add_argument("--only", default="c1,c2,c2n,c3,c3g,q1,q2,q3,q4,c5")
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--dim-rows", type=int, default=10_000_000)
+    ap.add_argument("--no-fuse", action="store_true")
     args = ap.parse_args()
     only = set(args.only.split(","))
 
@@ -60,7 +62,7 @@ def main():
     val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n) < 0.01] = A.NULL_BIGINT
-    nd = 10_000_000
+    nd = args.dim_rows
     st.import_numpy("t", {"key": key, "val": val, "valn": valn, "fk": rng.integers(0, nd, n, dtype=np.int64),
                           "hk": rng.integers(0, max(n // 10, 1000), n, dtype=np.int64)}, fragment_size=frag)
     st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64)},
@@ -74,6 +76,7 @@ def main():
                     types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
                            "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
     ex = Executor(st, 0)
+    ex.fuse_join_tables = not args.no_fuse
     Q = {
         "c1": (QueryUnit("t", targets=[Agg("sum", ColRef("val"))]), 8),
         "c2": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
@@ -105,7 +108,8 @@ def main():
             print(json.dumps({"config": name, "kernel": step.kernel_names(), "rows": n, "entries": cp.entry_count,
                               "rows_per_s": n / wall, "kernel_ms": None if kern is None else kern * 1e3,
                               "step_ms": wall * 1e3, "alg_bytes_per_row": bpr, "alg_GBps": n * bpr / t / 1e9,
-                              "frac_of_8TBps": n * bpr / t / 8e12, "groups": res.row_count()}))
+                              "frac_of_8TBps": n * bpr / t / 8e12, "groups": res.row_count(),
+                              "join_kinds": [int(step.plan.joins[i].kind) for i in range(step.plan.num_joins)]}))
             step.free()
         except Exception as e:  # noqa: BLE001
             print(json.dumps({"config": name, "error": repr(e)}))
