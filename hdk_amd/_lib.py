@@ -59,6 +59,9 @@ SIGNATURES = {
     "hdk_hip_describe_launch": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.c_char_p, sz]),
     "hdk_hip_reduce_buffers": (i32, [C.POINTER(A.Plan), v, u32, C.POINTER(v), C.POINTER(u32), i32, v, v,
                                      i32, v]),
+    "hdk_hip_baseline_table_quads": (i32, [C.POINTER(A.Plan), u32, C.POINTER(i64)]),
+    "hdk_hip_partition_baseline_count": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), i32, v]),
+    "hdk_hip_partition_baseline": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), C.POINTER(v), i32, v]),
     "hdk_hip_build_fused_join_table": (i32, [v, i64, C.POINTER(v), C.POINTER(i32), C.POINTER(i32), i32, v, i32, v]),
     "hdk_hip_init_hash_join_buff": (i32, [v, i64, i32, i32, v]),
     "hdk_hip_fill_hash_join_buff": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i32, v]),
@@ -82,6 +85,35 @@ EXTRA_SIGNATURES = {
 
 def lib():
     """The loaded library; raises if it has not been built (no fallback)."""
+    return _load()
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so (soname
+    libamdhip64.so.7) that libtorch_hip.so asks for by the unversioned name: if libhdk_hip.so pulled in
+    /opt/rocm's copy first, a later `import torch` would load a SECOND runtime that finds no devices.
+    Loading the wheel's copy first makes both sides resolve to it (the dynamic loader matches our
+    NEEDED libamdhip64.so.7 by soname).  Only relevant to Python processes that use torch.distributed
+    next to this library; set HDK_HIP_SYSTEM_RUNTIME=1 to skip."""
+    import importlib.util
+    import sys
+    if os.environ.get("HDK_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def _load():
     global _lib
     if _lib is not None:
         return _lib
@@ -89,6 +121,7 @@ def lib():
         raise HdkHipError(A.ERR_RUNTIME,
                           f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C hdk_amd/csrc).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in {**SIGNATURES, **EXTRA_SIGNATURES}.items():
         f = getattr(L, name)  # AttributeError here == the library does not export its header

@@ -9,9 +9,38 @@
 
 namespace hdk {
 
-HDK_DEV uint32_t key_hash_dev(const int64_t* key, int key_count, int key_width) {
-  // key_hash = MurmurHash3(key, width*count, 0) (QE/GroupByRuntime.cpp:24-29)
-  return murmur_hash3_words(reinterpret_cast<const uint32_t*>(key), key_count * key_width / 4, 0);
+// key_hash = MurmurHash3(key, width*count, 0) (QE/GroupByRuntime.cpp:24-29) over the packed key
+// components.  The 32-bit words are taken from the typed values (no pointer punning: reading an
+// int64 key array through a uint32 pointer lets the optimiser drop the stores that filled it).
+template <typename K>
+HDK_DEV uint32_t key_hash_dev(const K* key, int key_count) {
+  uint32_t h1 = 0;
+  const uint32_t c1 = 0xcc9e2d51;
+  const uint32_t c2 = 0x1b873593;
+  auto mix = [&](uint32_t k1) {
+    k1 *= c1;
+    k1 = rotl32(k1, 15);
+    k1 *= c2;
+    h1 ^= k1;
+    h1 = rotl32(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64;
+  };
+  for (int i = 0; i < key_count; ++i) {
+    if constexpr (sizeof(K) == 8) {
+      const uint64_t v = static_cast<uint64_t>(key[i]);
+      mix(static_cast<uint32_t>(v));
+      mix(static_cast<uint32_t>(v >> 32));
+    } else {
+      mix(static_cast<uint32_t>(key[i]));
+    }
+  }
+  h1 ^= static_cast<uint32_t>(key_count * sizeof(K));
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6b;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35;
+  h1 ^= h1 >> 16;
+  return h1;
 }
 
 template <typename K>
@@ -38,7 +67,7 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
                               bool* fresh) {
   const int nk = p->key_count;
   const bool columnar = p->output_columnar;
-  const uint32_t h = key_hash_dev(reinterpret_cast<const int64_t*>(key), nk, sizeof(K)) % entry_count;
+  const uint32_t h = key_hash_dev<K>(key, nk) % entry_count;
   uint32_t probe = h;
   const K ek = empty_key<K>();
   uint32_t steps = 0;

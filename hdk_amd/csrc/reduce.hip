@@ -276,6 +276,182 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_baseline(const hdk_hip_pla
   }
 }
 
+
+// ---- owner partition of a baseline table (multi-GPU exchange step, include/hdk_hip.h) ---------------
+constexpr int kMaxOwners = 64;
+
+struct OwnerSegs {
+  int64_t* buf[kMaxOwners];
+  uint32_t count[kMaxOwners];
+};
+
+// owner of a key: the high part of hash * G, so an owner's keys still spread over every home slot
+// h % entry_count of its table (h % G would leave it only the slots congruent to the owner id)
+HDK_DEV uint32_t owner_of(uint32_t h, uint32_t num_owners) {
+  return static_cast<uint32_t>((static_cast<uint64_t>(h) * num_owners) >> 32);
+}
+
+template <typename K>
+HDK_DEV uint32_t entry_owner(const hdk_hip_plan* p, const int64_t* buf, uint32_t entry_count, uint32_t e,
+                             uint32_t num_owners, K (&key)[HDK_HIP_MAX_KEYS]) {
+  const int nk = p->key_count;
+#pragma unroll
+  for (int k = 0; k < HDK_HIP_MAX_KEYS; ++k) {
+    if (k < nk) {
+      key[k] = p->output_columnar ? reinterpret_cast<const K*>(buf)[static_cast<size_t>(k) * entry_count + e]
+                                  : reinterpret_cast<const K*>(buf + static_cast<size_t>(e) * p->row_size_quad)[k];
+    } else {
+      key[k] = 0;
+    }
+  }
+  return owner_of(key_hash_dev<K>(key, nk), num_owners);
+}
+
+// MODE 0: count entries per owner; MODE 1: scatter them into the owners' segments.
+// One atomic per wave and owner: lanes holding the same owner are ranked with a ballot.
+template <typename K, int MODE>
+__global__ __launch_bounds__(kRedBlock) void k_partition_baseline(const hdk_hip_plan* __restrict__ p,
+                                                                  const int64_t* buf, uint32_t entry_count,
+                                                                  uint32_t num_owners, SlotInit init,
+                                                                  uint32_t* cursors, OwnerSegs segs) {
+  const uint32_t stride = gridDim.x * kRedBlock;
+  const uint32_t lane = threadIdx.x & 63;
+  const int nk = p->key_count;
+  const int nt = p->num_targets;
+  const uint32_t rounds = (entry_count + stride - 1) / stride;
+  for (uint32_t it = 0; it < rounds; ++it) {
+    const uint32_t e = it * stride + blockIdx.x * kRedBlock + threadIdx.x;
+    K key[HDK_HIP_MAX_KEYS];
+    uint32_t owner = 0xffffffffu;
+    if (e < entry_count && !is_empty_entry(p, buf, entry_count, e, init)) {
+      owner = entry_owner<K>(p, buf, entry_count, e, num_owners, key);
+    }
+    uint32_t dst = 0;
+    for (uint32_t o = 0; o < num_owners; ++o) {
+      const uint64_t mask = __ballot(owner == o);
+      if (mask == 0) {
+        continue;
+      }
+      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1;
+      uint32_t base = 0;
+      if (lane == leader) {
+        base = atomicAdd(cursors + o, static_cast<uint32_t>(__popcll(mask)));
+      }
+      base = __shfl(base, leader, 64);
+      if (owner == o) {
+        dst = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1)));
+      }
+    }
+    if (MODE == 0 || owner == 0xffffffffu) {
+      continue;
+    }
+    int64_t* seg = segs.buf[0];
+    uint32_t seg_n = segs.count[0];
+#pragma unroll
+    for (int k = 1; k < kMaxOwners; ++k) {
+      if (static_cast<uint32_t>(k) == owner) {
+        seg = segs.buf[k];
+        seg_n = segs.count[k];
+      }
+    }
+    for (int k = 0; k < nk; ++k) {
+      if (p->output_columnar) {
+        reinterpret_cast<K*>(seg)[static_cast<size_t>(k) * seg_n + dst] = key[k];
+      } else {
+        reinterpret_cast<K*>(seg + static_cast<size_t>(dst) * p->row_size_quad)[k] = key[k];
+      }
+    }
+    int s = 0;
+    for (int t = 0; t < nt; ++t) {
+      const hdk_hip_target& tg = p->targets[t];
+      int8_t *a1, *a2, *b1, *b2;
+      slot_ptrs(p, seg, seg_n, dst, t, s, &a1, &a2);
+      slot_ptrs(p, const_cast<int64_t*>(buf), entry_count, e, t, s, &b1, &b2);
+      if (tg.slot_width == 4) {
+        *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
+      } else {
+        *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);
+      }
+      if (tg.agg == HDK_AGG_AVG) {
+        if (tg.slot2_width == 4) {
+          *reinterpret_cast<int32_t*>(a2) = *reinterpret_cast<const int32_t*>(b2);
+        } else {
+          *reinterpret_cast<int64_t*>(a2) = *reinterpret_cast<const int64_t*>(b2);
+        }
+      }
+      s += tg.agg == HDK_AGG_AVG ? 2 : 1;
+    }
+  }
+}
+
+static size_t table_quads(const hdk_hip_plan* p, uint32_t entry_count) {
+  if (!p->output_columnar) {
+    return static_cast<size_t>(entry_count) * p->row_size_quad;
+  }
+  int nslots = 0;
+  for (int t = 0; t < p->num_targets; ++t) {
+    nslots += p->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
+  }
+  size_t off = p->keyless ? 0 : static_cast<size_t>(p->key_count) * ((static_cast<size_t>(entry_count) * 8 + 7) & ~size_t(7));
+  int s = 0;
+  for (int t = 0; t < p->num_targets && s < nslots; ++t) {
+    off = (off + 7) & ~size_t(7);
+    off += static_cast<size_t>(entry_count) * p->targets[t].slot_width;
+    ++s;
+    if (p->targets[t].agg == HDK_AGG_AVG) {
+      off = (off + 7) & ~size_t(7);
+      off += static_cast<size_t>(entry_count) * p->targets[t].slot2_width;
+      ++s;
+    }
+  }
+  return ((off + 7) & ~size_t(7)) / 8;
+}
+
+static void fill_slot_init(const hdk_hip_plan* plan, const int64_t* init_vals, SlotInit* init) {
+  int nslots = 0;
+  for (int t = 0; t < plan->num_targets; ++t) {
+    nslots += plan->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
+  }
+  for (int i = 0; i < kMaxSlots; ++i) {
+    init->v[i] = i < nslots ? init_vals[i] : 0;
+  }
+}
+
+template <int MODE>
+static int32_t run_partition(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count, const int64_t* init_vals,
+                             int32_t num_owners, uint32_t* counts_out, const OwnerSegs& segs, int32_t device_id,
+                             hipStream_t s) {
+  SlotInit init;
+  fill_slot_init(plan, init_vals, &init);
+  int8_t* scratch = nullptr;  // [plan | cursors]
+  constexpr size_t kPlanBytes = (sizeof(hdk_hip_plan) + 255) & ~size_t(255);
+  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), kPlanBytes + kMaxOwners * sizeof(uint32_t), s));
+  hdk_hip_plan* d_plan = reinterpret_cast<hdk_hip_plan*>(scratch);
+  uint32_t* cursors = reinterpret_cast<uint32_t*>(scratch + kPlanBytes);
+  HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  HDK_HIP_CHECK(hipMemsetAsync(cursors, 0, kMaxOwners * sizeof(uint32_t), s));
+  const hdk_hip_device_properties* props = device_props(device_id);
+  size_t blocks = (static_cast<size_t>(entry_count) + kRedBlock - 1) / kRedBlock;
+  const size_t cap = static_cast<size_t>(props->num_cu) * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  const bool k32 = !plan->output_columnar && plan->key_width == 4;
+  if (k32) {
+    hipLaunchKernelGGL((k_partition_baseline<int32_t, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(kRedBlock), 0, s,
+                       d_plan, buf, entry_count, static_cast<uint32_t>(num_owners), init, cursors, segs);
+  } else {
+    hipLaunchKernelGGL((k_partition_baseline<int64_t, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(kRedBlock), 0, s,
+                       d_plan, buf, entry_count, static_cast<uint32_t>(num_owners), init, cursors, segs);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  if (counts_out) {
+    HDK_HIP_CHECK(hipMemcpyAsync(counts_out, cursors, num_owners * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HDK_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  HDK_HIP_CHECK(hipFreeAsync(scratch, s));
+  return HDK_HIP_OK;
+}
+
 int32_t validate_plan(const hdk_hip_plan* p);  // scan_agg.hip
 
 }  // namespace hdk
@@ -347,4 +523,54 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
   HDK_HIP_CHECK(hipGetLastError());
   HDK_HIP_CHECK(hipFreeAsync(d_plan, s));
   return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_baseline_table_quads(const hdk_hip_plan* plan, uint32_t entry_count, int64_t* quads) {
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(quads, "quads is NULL");
+  HDK_REQUIRE(plan->query_kind == HDK_Q_BASELINE_HASH, "not a baseline-hash plan");
+  *quads = static_cast<int64_t>(table_quads(plan, entry_count));
+  return HDK_HIP_OK;
+}
+
+static int32_t check_partition_args(const hdk_hip_plan* plan, const int64_t* buf, const int64_t* init_vals,
+                                    int32_t num_owners) {
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(plan->query_kind == HDK_Q_BASELINE_HASH, "not a baseline-hash plan");
+  HDK_REQUIRE(buf && init_vals, "NULL argument");
+  HDK_REQUIRE(num_owners >= 1 && num_owners <= kMaxOwners, "num_owners must be in [1, 64]");
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_partition_baseline_count(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count,
+                                                    const int64_t* init_vals, int32_t num_owners, uint32_t* counts,
+                                                    int32_t device_id, void* stream) {
+  int32_t st = check_partition_args(plan, buf, init_vals, num_owners);
+  if (st) return st;
+  HDK_REQUIRE(counts, "counts is NULL");
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  OwnerSegs segs = {};
+  return run_partition<0>(plan, buf, entry_count, init_vals, num_owners, counts, segs, device_id, s);
+}
+
+extern "C" int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count,
+                                              const int64_t* init_vals, int32_t num_owners, const uint32_t* counts,
+                                              int64_t* const* seg_bufs, int32_t device_id, void* stream) {
+  int32_t st = check_partition_args(plan, buf, init_vals, num_owners);
+  if (st) return st;
+  HDK_REQUIRE(counts && seg_bufs, "NULL argument");
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  OwnerSegs segs = {};
+  for (int o = 0; o < num_owners; ++o) {
+    HDK_REQUIRE(counts[o] == 0 || seg_bufs[o], "segment buffer is NULL");
+    segs.buf[o] = seg_bufs[o];
+    segs.count[o] = counts[o];
+  }
+  return run_partition<1>(plan, buf, entry_count, init_vals, num_owners, nullptr, segs, device_id, s);
 }

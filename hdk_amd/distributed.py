@@ -10,8 +10,10 @@ the devices:
     the (small) tables, then `hdk_hip_reduce_buffers` folds partials 1..G-1 into partial 0 in rank
     order on every rank (deterministic, every rank ends with the full result, like an all-reduce
     but with the exact agg_*_skip_val semantics a plain ncclSum cannot express);
-  * baseline-hash plans: slot positions differ per rank -> all-gather the tables and re-insert
-    (reduceOneEntryBaseline) into a table sized for the union.
+  * baseline-hash plans: slot positions differ per rank -> every rank splits its non-empty entries
+    by owner = mulhi(key_hash, G), one all-to-all moves each entry to its owner, the owner re-inserts
+    what it received (reduceOneEntryBaseline); the result is the concatenation of the owners'
+    disjoint tables (reduce_baseline_multi_gpu).
 The collective calls are backend-agnostic (gloo on CPU in the tests); the merge itself is the HIP
 kernel and needs a device.
 """
@@ -58,7 +60,7 @@ def merge_gathered_on_device(cp, gathered, world_size: int, device_id: int, stre
     if world_size == 1:
         return gathered[:quads]
     if cp.plan.query_kind == A.Q_BASELINE_HASH:
-        raise NotImplementedError("baseline-hash merge goes through merge_baseline_on_device")
+        raise NotImplementedError("baseline-hash partials go through reduce_baseline_multi_gpu")
     that = (C.c_void_p * (world_size - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world_size)])
     counts = (C.c_uint32 * (world_size - 1))(*([cp.entry_count] * (world_size - 1)))
     if d_err is None:
@@ -80,3 +82,110 @@ def merge_gathered(cp, gathered_host: np.ndarray, world_size: int, reducer: Call
         if rc:
             raise RuntimeError(f"reduction failed with code {rc}")
     return this
+
+
+# ---- baseline hash: owner-partitioned all-to-all ----------------------------------------
+def baseline_table_quads(cp, entry_count: int) -> int:
+    """int64 words of a baseline table of `entry_count` entries in cp's layout (host-only call)."""
+    from ._lib import check, lib
+    q = C.c_int64(0)
+    check(lib().hdk_hip_baseline_table_quads(C.byref(cp.plan), int(entry_count), C.byref(q)))
+    return int(q.value)
+
+
+def partition_baseline_on_device(cp, table, num_owners: int, device_id: int, stream=None):
+    """Split the non-empty entries of the local table (device int64 tensor) by owner.
+    Returns (send, counts): `send` holds the owners' compact tables back to back in owner order
+    (owner o: baseline_table_quads(cp, counts[o]) words), `counts` is a numpy uint32 array."""
+    from ._lib import check, lib
+    import torch
+    L = lib()
+    iv = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
+    counts = (C.c_uint32 * num_owners)()
+    check(L.hdk_hip_partition_baseline_count(C.byref(cp.plan), table.data_ptr(), cp.entry_count, iv.ctypes.data,
+                                             num_owners, counts, device_id, stream))
+    quads = [baseline_table_quads(cp, counts[o]) for o in range(num_owners)]
+    send = torch.empty(max(sum(quads), 1), dtype=torch.int64, device=table.device)
+    offs = np.concatenate([[0], np.cumsum(quads)])
+    segs = (C.c_void_p * num_owners)(*[send.data_ptr() + int(offs[o]) * 8 for o in range(num_owners)])
+    check(L.hdk_hip_partition_baseline(C.byref(cp.plan), table.data_ptr(), cp.entry_count, iv.ctypes.data, num_owners,
+                                       counts, segs, device_id, stream))
+    return send, np.array(list(counts), dtype=np.uint32)
+
+
+def exchange_owner_segments(cp, send, counts: np.ndarray, world_size: int, rank: int, group=None):
+    """The one exchange step of the baseline merge: rank r sends its owner-o segment to rank o.
+    Backend-agnostic (RCCL all-to-all over xGMI in production, gloo in the CPU tests).
+    Returns (recv, recv_counts): segments received from ranks 0..G-1 back to back, and their entry counts."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return send, counts.copy()
+    mine = torch.from_numpy(counts.astype(np.int64)).to(send.device)
+    allc = torch.empty(world_size * world_size, dtype=torch.int64, device=send.device)
+    try:
+        dist.all_gather_into_tensor(allc, mine, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(mine) for _ in range(world_size)]
+        dist.all_gather(parts, mine, group=group)
+        allc = torch.cat(parts)
+    allc = allc.cpu().numpy().reshape(world_size, world_size)  # allc[r][o]: entries rank r holds for owner o
+    in_split = [baseline_table_quads(cp, int(c)) for c in counts]
+    recv_counts = allc[:, rank].astype(np.uint32)
+    out_split = [baseline_table_quads(cp, int(c)) for c in recv_counts]
+    recv = torch.empty(max(sum(out_split), 1), dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(recv[:sum(out_split)], send[:sum(in_split)], out_split, in_split, group=group)
+    return recv, recv_counts
+
+
+def merge_baseline_on_device(cp, recv, recv_counts: np.ndarray, device_id: int, owner_entry_count: Optional[int] = None,
+                             stream=None):
+    """Owner side: initialise a fresh table and re-insert every received segment in rank order
+    (reduceOneEntryBaseline semantics, QE/ResultSetReduction.cpp:694-731).  Returns (table, entry_count)."""
+    from ._lib import check, lib
+    from .plan import compact_init_vals, eff_key_count
+    import torch
+    L = lib()
+    p = cp.plan
+    n = int(owner_entry_count or p.entry_count)
+    table = torch.empty(baseline_table_quads(cp, n), dtype=torch.int64, device=recv.device)
+    block, grid = 1024, 1024  # launch shape of the fill kernel only
+    if p.output_columnar:
+        d_init = torch.from_numpy(np.ascontiguousarray(cp.init_vals, dtype=np.int64)).to(recv.device)
+        d_sizes = torch.from_numpy(np.array(cp.slot_widths, dtype=np.int8)).to(recv.device)
+        check(L.hdk_hip_init_columnar_group_by_buffer(table.data_ptr(), d_init.data_ptr(), n, eff_key_count(p),
+                                                      len(cp.slot_widths), d_sizes.data_ptr(), 1, p.keyless, 8, block,
+                                                      grid, device_id, stream))
+    else:
+        d_init = torch.from_numpy(compact_init_vals(cp)).to(recv.device)
+        check(L.hdk_hip_init_group_by_buffer(table.data_ptr(), d_init.data_ptr(), n, eff_key_count(p), p.key_width,
+                                             p.row_size_quad, p.keyless, 1, block, grid, device_id, stream))
+    offs, segs, cnts = 0, [], []
+    for c in recv_counts:
+        if c:
+            segs.append(recv.data_ptr() + offs * 8)
+            cnts.append(int(c))
+        offs += baseline_table_quads(cp, int(c))
+    d_err = torch.zeros(1, dtype=torch.int32, device=recv.device)
+    if segs:
+        that = (C.c_void_p * len(segs))(*segs)
+        tc = (C.c_uint32 * len(segs))(*cnts)
+        iv = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
+        check(L.hdk_hip_reduce_buffers(C.byref(p), table.data_ptr(), n, that, tc, len(segs), iv.ctypes.data,
+                                       d_err.data_ptr(), device_id, stream))
+    err = int(d_err.item())
+    if err:
+        raise RuntimeError(f"baseline merge failed with error code {err}")
+    return table, n
+
+
+def reduce_baseline_multi_gpu(cp, table, world_size: int, rank: int, device_id: int, group=None, stream=None):
+    """partition -> all-to-all -> owner merge.  Every rank returns its owner table: the query result
+    is the concatenation of the ranks' non-empty entries (keys are disjoint across owners)."""
+    import torch
+    if stream is None and table.is_cuda:
+        # everything -- library kernels, torch copies, the RCCL all-to-all -- is ordered on torch's current stream
+        stream = torch.cuda.current_stream(table.device).cuda_stream
+    send, counts = partition_baseline_on_device(cp, table, world_size, device_id, stream)
+    recv, recv_counts = exchange_owner_segments(cp, send, counts, world_size, rank, group)
+    return merge_baseline_on_device(cp, recv, recv_counts, device_id, None, stream)

@@ -366,6 +366,31 @@ int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* this_buf, uint
                                int32_t device_id, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-GPU exchange step of a baseline-hash group-by.  No reference counterpart:
+ * the reference copies every device's partial ResultSet to the host and re-inserts the entries
+ * there (Executor::reduceMultiDeviceResultSets, QE/Execute.cpp:1224-1336, with
+ * reduceOneEntryBaseline, QE/ResultSetReduction.cpp:694-731).  Here the non-empty entries of a
+ * rank's table are split by owner = mulhi32(key_hash(key), num_owners) into `num_owners` compact
+ * tables that keep the plan's layout (row-wise or columnar) with entry_count = counts[o]; after an
+ * all-to-all each owner folds what it received with hdk_hip_reduce_buffers, and the result is the
+ * concatenation of the owners' disjoint tables.
+ *   hdk_hip_baseline_table_quads     size (int64 words) of a table of `entry_count` entries
+ *   hdk_hip_partition_baseline_count entries per owner -> HOST array counts[num_owners] (synchronises)
+ *   hdk_hip_partition_baseline       scatter into seg_bufs[o] (HOST array of device pointers, each
+ *                                    hdk_hip_baseline_table_quads(counts[o]) words); `counts` is the
+ *                                    HOST array the count step returned
+ * `init_vals` is the HOST array of hdk_hip_reduce_buffers (keyless tables cannot be baseline, but the
+ * emptiness rule is shared).
+ * ---------------------------------------------------------------------------------------- */
+int32_t hdk_hip_baseline_table_quads(const hdk_hip_plan* plan, uint32_t entry_count, int64_t* quads);
+int32_t hdk_hip_partition_baseline_count(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count,
+                                         const int64_t* init_vals, int32_t num_owners, uint32_t* counts,
+                                         int32_t device_id, void* stream);
+int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count,
+                                   const int64_t* init_vals, int32_t num_owners, const uint32_t* counts,
+                                   int64_t* const* seg_bufs, int32_t device_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hash-join table build (perfect hash).
  * Replaces the *_on_device free functions of QE/JoinHashTable/Runtime/HashJoinRuntime.h:66-68,
  * 158-200 (GPU bodies QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:32-190).  Structs are the

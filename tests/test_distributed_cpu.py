@@ -84,3 +84,88 @@ def test_two_rank_gather_and_merge_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _baseline_worker(rank, world, port, result_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hdk_amd import result_set as rs
+        from hdk_amd.distributed import baseline_table_quads, exchange_owner_segments, shard_fragments
+        from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
+        from hdk_amd.plan import compile_query, init_buffer_host
+        from hdk_amd.storage import ArrowStorage
+        from oracle import oracle as O
+        from util import host_fragments, run_oracle
+        rng = np.random.default_rng(78)
+        n = 50_000
+        st = ArrowStorage()
+        st.import_numpy("t", {"k": rng.integers(0, 3000, n).astype(np.int64) * 1_000_003,
+                              "v": rng.integers(-1000, 1000, n).astype(np.int64)}, fragment_size=6_000)
+        q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=8_191,
+                      targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+        cp = compile_query(st, q)
+        p = cp.plan
+        assert not p.output_columnar and p.key_width == 8
+        rq = p.row_size_quad
+        assert baseline_table_quads(cp, 10) == 10 * rq  # host-only ABI call: works without a GPU
+        mine = shard_fragments(st.get("t").num_fragments, world, rank)
+        local = init_buffer_host(cp)
+        assert O.run_plan(p, host_fragments(O, st, cp, mine), local) == 0
+        # host stand-in for hdk_hip_partition_baseline (the HIP kernel is covered by the GPU test):
+        # non-empty rows, owner = mulhi32(key_hash, G), compact row-wise segments in owner order
+        rows = local.view(np.int64).reshape(p.entry_count, rq)
+        rows = rows[rows[:, 0] != np.iinfo(np.int64).max]
+        L = O.lib()
+        owners = np.array([(L.orc_key_hash(np.array([k], dtype=np.int64).ctypes.data, 1, 8) * world) >> 32
+                           for k in rows[:, 0]], dtype=np.int64)
+        counts = np.array([(owners == o).sum() for o in range(world)], dtype=np.uint32)
+        send = torch.from_numpy(np.concatenate([rows[owners == o].reshape(-1) for o in range(world)] +
+                                               [np.zeros(1, dtype=np.int64)]))
+        recv, recv_counts = exchange_owner_segments(cp, send, counts, world, rank)
+        recv = recv.numpy()
+        owner_table = init_buffer_host(cp)
+        off = 0
+        for c in recv_counts:
+            seg = np.ascontiguousarray(recv[off:off + int(c) * rq])
+            if c:
+                assert O.reduce(p, owner_table, p.entry_count, seg, int(c), cp.init_vals) == 0
+            off += int(c) * rq
+        got = rs.to_columns(cp, owner_table)
+        # the whole query on one process, restricted to the keys this rank owns
+        _, full, err = run_oracle(O, st, cp)
+        want = rs.to_columns(cp, full)
+        want_mine = {}
+        for k, s, c in zip(want["k"], want["s"], want["c"]):
+            if (L.orc_key_hash(np.array([k], dtype=np.int64).ctypes.data, 1, 8) * world) >> 32 == rank:
+                want_mine[k] = (s, c)
+        assert {k: (s, c) for k, s, c in zip(got["k"], got["s"], got["c"])} == want_mine
+        tot = torch.tensor([len(got["k"])])
+        dist.all_reduce(tot)
+        assert int(tot.item()) == len(want["k"])
+        result_q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        result_q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_baseline_owner_exchange_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_baseline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

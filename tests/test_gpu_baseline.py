@@ -104,3 +104,63 @@ def test_perfect_hash_via_global_atomics(oracle, gpu_executor_factory):
     assert cp.plan.query_kind == A.Q_PERFECT_HASH and cp.entry_count >= 199_000
     res = gpu_executor_factory(st).execute(cp)
     assert_buffers_equal(cp, res.buffer, want)
+
+
+@pytest.mark.parametrize("columnar,world", [(False, 2), (True, 4), (False, 3)])
+def test_multi_gpu_baseline_merge_emulated(oracle, gpu_executor_factory, columnar, world):
+    """The N-GPU baseline merge (partition by owner -> all-to-all -> owner re-insert), with the ranks
+    emulated one after another on one device: the union of the owners' tables must equal the oracle's
+    result of the whole query, and owners must be disjoint."""
+    import torch
+    from hdk_amd import distributed as D
+    rng = np.random.default_rng(5)
+    n = 300_000
+    key = rng.integers(0, 30_000, n, dtype=np.int64) * 1_000_003
+    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    val[rng.random(n) < 0.02] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": key, "val": val, "f": rng.normal(size=n)}, fragment_size=40_000)
+    q = QueryUnit("t", groupby=[ColRef("key")], output_columnar=columnar, force_baseline=True,
+                  baseline_entry_count=65_537,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s"), Agg("count", None, "c"),
+                           Agg("min", ColRef("val"), "mn"), Agg("avg", ColRef("f"), "af")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    nfrag = len(st.get("t").frag_rows)
+    dev = torch.device("cuda", 0)
+    sends, counts = [], []
+    for r in range(world):
+        part = ex.execute(cp, frag_ids=D.shard_fragments(nfrag, world, r))
+        table = torch.from_numpy(part.buffer.view(np.int64).copy()).to(dev)
+        s, c = D.partition_baseline_on_device(cp, table, world, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(c.sum()) == part.row_count()
+        sends.append(s.cpu().numpy())
+        counts.append(c)
+    all_rows = []
+    for o in range(world):  # what the all-to-all delivers to owner o, in rank order
+        segs = []
+        for r in range(world):
+            offs = np.concatenate([[0], np.cumsum([D.baseline_table_quads(cp, int(x)) for x in counts[r]])])
+            segs.append(sends[r][offs[o]:offs[o + 1]])
+        recv = torch.from_numpy(np.concatenate(segs + [np.zeros(1, dtype=np.int64)])).to(dev)
+        rc = np.array([counts[r][o] for r in range(world)], dtype=np.uint32)
+        table, ne = D.merge_baseline_on_device(cp, recv, rc, 0, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rows = _rows(cp, table.cpu().numpy())
+        all_rows.extend(rows)
+    keys = [r[0] for r in all_rows]
+    assert len(keys) == len(set(keys))  # owners are disjoint
+    w = _rows(cp, want)
+    g = sorted(all_rows, key=lambda r: r[0])
+    assert len(g) == len(w)
+    for a, b in zip(g, w):
+        for x, y in zip(a, b):
+            if isinstance(y, float):
+                assert abs(x - y) <= 1e-6 * max(1e-300, abs(y)), (a, b)
+            else:
+                assert x == y, (a, b)
+    # balance: mulhi(hash, G) spreads the keys evenly
+    per_owner = np.sum(np.array(counts, dtype=np.int64), axis=0)
+    assert per_owner.min() > 0.8 * per_owner.mean()
