@@ -12,8 +12,9 @@ MAX_KEYS = 4
 MAX_TARGETS = 8
 MAX_QUALS = 6
 MAX_JOINS = 2
+MAX_JOIN_KEYS = 3
 MAX_EXPR_STEPS = 3
-PLAN_ABI = 1
+PLAN_ABI = 2
 
 # --- sentinels: reference omniscidb/Shared/InlineNullValues.h:33-39, QueryEngine/GpuRtConstants.h:29-32
 EMPTY_KEY_64 = 2**63 - 1
@@ -45,7 +46,7 @@ LEAF_NONE, LEAF_COL, LEAF_INT, LEAF_FP = 0, 1, 2, 3
 (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_EXTRACT_YEAR, OP_SCALE_DOWN, OP_FLOOR_DIV,
  OP_CAST_INT_TO_FP, OP_CAST_FP_TO_INT) = range(1, 11)
 CMP_EQ, CMP_NE, CMP_LT, CMP_GT, CMP_LE, CMP_GE = range(1, 7)
-JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY, JOIN_ONE_TO_ONE_FUSED = 0, 1, 2
+JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY, JOIN_ONE_TO_ONE_FUSED, JOIN_KEYED_ONE_TO_ONE, JOIN_KEYED_ONE_TO_MANY = 0, 1, 2, 3, 4
 JOIN_INNER, JOIN_LEFT = 0, 1
 JOIN_NULL_NONE, JOIN_NULL_NULLABLE, JOIN_NULL_BITWISE = 0, 1, 2
 Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH, Q_PROJECTION = 0, 1, 2, 3
@@ -82,14 +83,16 @@ class Expr(C.Structure):
 
 
 class Qual(C.Structure):
-    _fields_ = [("lhs", Expr), ("rhs", Leaf), ("cmp", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("lhs", Expr), ("rhs", Leaf), ("cmp", C.c_int32), ("after_joins", C.c_int32)]
 
 
 class Join(C.Structure):
     _fields_ = [("outer_key", Expr), ("min_key", C.c_int64), ("max_key", C.c_int64),
                 ("null_val", C.c_int64), ("translated_null", C.c_int64), ("bucket", C.c_int64),
                 ("kind", C.c_int32), ("type", C.c_int32), ("null_mode", C.c_int32),
-                ("table_idx", C.c_int32), ("fused_stride", C.c_int32), ("pad_", C.c_int32)]
+                ("table_idx", C.c_int32), ("fused_stride", C.c_int32), ("key_component_count", C.c_int32),
+                ("entry_count", C.c_int64), ("key_component_width", C.c_int32), ("pad_", C.c_int32),
+                ("extra_keys", Expr * (MAX_JOIN_KEYS - 1))]
 
 
 class Target(C.Structure):

@@ -62,6 +62,11 @@ SIGNATURES = {
     "hdk_hip_baseline_table_quads": (i32, [C.POINTER(A.Plan), u32, C.POINTER(i64)]),
     "hdk_hip_partition_baseline_count": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), i32, v]),
     "hdk_hip_partition_baseline": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), C.POINTER(v), i32, v]),
+    "hdk_hip_init_baseline_hash_join_buff": (i32, [v, i64, sz, i32, i32, i32, i32, v]),
+    "hdk_hip_fill_baseline_hash_join_buff": (i32, [v, i64, i32, i32, sz, i32, i32, v, C.POINTER(A.JoinColumn),
+                                                   C.POINTER(A.JoinColumnTypeInfo), i32, v]),
+    "hdk_hip_fill_one_to_many_baseline_hash_table": (i32, [v, v, i64, i32, sz, i32, C.POINTER(A.JoinColumn),
+                                                           C.POINTER(A.JoinColumnTypeInfo), i32, v]),
     "hdk_hip_build_fused_join_table": (i32, [v, i64, C.POINTER(v), C.POINTER(i32), C.POINTER(i32), i32, v, i32, v]),
     "hdk_hip_init_hash_join_buff": (i32, [v, i64, i32, i32, v]),
     "hdk_hip_fill_hash_join_buff": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i32, v]),

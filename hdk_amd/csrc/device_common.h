@@ -199,6 +199,11 @@ HDK_DEV int64_t load_leaf(const RowCtx& c, const hdk_hip_leaf& l) {
     } else if (col.table == 2) {
       row = c.join_row[1];
     }
+    if (row < 0) {
+      // LEFT join without a match: the inner table's columns are NULL
+      // (codegenOuterJoinNullPlaceholder, QE/ColumnIR.cpp)
+      return l.null_val;
+    }
     return decode_col(c.cols[col.buf_idx], col.width, col.kind, row);
   }
   return l.ival;
@@ -369,33 +374,179 @@ HDK_DEV int64_t probe_join_g(const hdk_hip_join& jn, const int32_t* table, int64
   return -1;
 }
 
-// filter + join probes; returns false when the row is dropped
-HDK_DEV bool row_passes(RowCtx& c, const int64_t* join_hash_tables, int32_t& err) {
+// ---- matching sets ------------------------------------------------------------------------------
+// MurmurHash1 (QE/MurmurHash1Inl.h:6-52) over a key of `n` 32-bit words
+HDK_DEV uint32_t murmur_hash1_words(const uint32_t* w, int n) {
+  const uint32_t m = 0xc6a4a793;
+  uint32_t h = 0u ^ (static_cast<uint32_t>(n * 4) * m);
+  for (int i = 0; i < n; ++i) {
+    h += w[i];
+    h *= m;
+    h ^= h >> 16;
+  }
+  h *= m;
+  h ^= h >> 10;
+  h *= m;
+  h ^= h >> 17;
+  return h;
+}
+
+// The inner rows matching the current outer row at one join level (HashJoin::codegenMatchingSet,
+// QE/JoinHashTable/HashJoin.cpp:149-197; keyed tables: BaselineJoinHashTable.cpp:769-811 with
+// baseline_hash_join_idx / get_composite_key_index, JoinHashTableQueryRuntime.cpp:42-172).
+struct MatchSet {
+  const int32_t* ids;  // one-to-many: the bin's row ids; nullptr for a one-to-one match
+  int64_t single;      // one-to-one: the row id
+  int32_t n;
+};
+
+template <typename T>
+HDK_DEV MatchSet keyed_matching_set(const hdk_hip_join& jn, const int8_t* table, const int64_t* key) {
+  MatchSet ms;
+  ms.ids = nullptr;
+  ms.single = -1;
+  ms.n = 0;
+  const int kc = jn.key_component_count;
+  const uint32_t entries = static_cast<uint32_t>(jn.entry_count);
+  if (entries == 0) {
+    return ms;
+  }
+  uint32_t words[2 * HDK_HIP_MAX_JOIN_KEYS];
+  int nw = 0;
+#pragma unroll
+  for (int i = 0; i < HDK_HIP_MAX_JOIN_KEYS; ++i) {
+    if (i < kc) {
+      if constexpr (sizeof(T) == 8) {
+        words[nw++] = static_cast<uint32_t>(static_cast<uint64_t>(key[i]));
+        words[nw++] = static_cast<uint32_t>(static_cast<uint64_t>(key[i]) >> 32);
+      } else {
+        words[nw++] = static_cast<uint32_t>(key[i]);
+      }
+    }
+  }
+  const T invalid = sizeof(T) == 8 ? static_cast<T>(HDK_EMPTY_KEY_64) : static_cast<T>(HDK_EMPTY_KEY_32);
+  const bool many = jn.kind == HDK_JOIN_KEYED_ONE_TO_MANY;
+  const int comps = kc + (many ? 0 : 1);
+  const T* dict = reinterpret_cast<const T*>(table);
+  const uint32_t h = murmur_hash1_words(words, nw) % entries;
+  uint32_t hp = h;
+  int64_t slot = -1;
+  do {
+    const T* e = dict + static_cast<size_t>(hp) * comps;
+    bool eq = true;
+    for (int i = 0; i < kc; ++i) {
+      eq = eq && e[i] == static_cast<T>(key[i]);
+    }
+    if (eq) {
+      slot = hp;
+      break;
+    }
+    if (e[0] == invalid) {
+      break;  // kNotPresent / -1
+    }
+    hp = hp + 1 == entries ? 0 : hp + 1;
+  } while (hp != h);
+  if (slot < 0) {
+    return ms;
+  }
+  if (!many) {
+    ms.single = static_cast<int64_t>(dict[static_cast<size_t>(slot) * comps + kc]);
+    ms.n = ms.single >= 0 ? 1 : 0;
+    return ms;
+  }
+  const int32_t* otm = reinterpret_cast<const int32_t*>(table + static_cast<size_t>(entries) * kc * sizeof(T));
+  const int32_t pos = otm[slot];
+  if (pos < 0) {
+    return ms;
+  }
+  ms.ids = otm + 2 * static_cast<size_t>(entries) + pos;
+  ms.n = otm[static_cast<size_t>(entries) + slot];
+  return ms;
+}
+
+HDK_DEV MatchSet matching_set(const RowCtx& c, const hdk_hip_join& jn, const int64_t* join_hash_tables, int nj,
+                              int32_t& err) {
+  const int8_t* table = (nj == 1 && jn.table_idx == 0) ? reinterpret_cast<const int8_t*>(join_hash_tables)
+                                                       : reinterpret_cast<const int8_t*>(join_hash_tables[jn.table_idx]);
+  if (jn.kind == HDK_JOIN_KEYED_ONE_TO_ONE || jn.kind == HDK_JOIN_KEYED_ONE_TO_MANY) {
+    int64_t key[HDK_HIP_MAX_JOIN_KEYS];
+    const int kc = jn.key_component_count;
+#pragma unroll
+    for (int i = 0; i < HDK_HIP_MAX_JOIN_KEYS; ++i) {
+      key[i] = i < kc ? eval_expr(c, i == 0 ? jn.outer_key : jn.extra_keys[i > 0 ? i - 1 : 0], err) : 0;
+    }
+    return jn.key_component_width == 4 ? keyed_matching_set<int32_t>(jn, table, key)
+                                       : keyed_matching_set<int64_t>(jn, table, key);
+  }
+  MatchSet ms;
+  ms.ids = nullptr;
+  ms.single = -1;
+  ms.n = 0;
+  const int64_t key = eval_expr(c, jn.outer_key, err);
+  const int32_t* t = reinterpret_cast<const int32_t*>(table);
+  if (jn.kind == HDK_JOIN_ONE_TO_MANY) {
+    const int64_t pos = probe_join(jn, t, key);
+    if (pos >= 0) {
+      ms.ids = t + 2 * jn.entry_count + pos;
+      ms.n = static_cast<int32_t>(probe_join(jn, t + jn.entry_count, key));
+    }
+    return ms;
+  }
+  ms.single = probe_join(jn, t, key);
+  ms.n = ms.single >= 0 ? 1 : 0;
+  return ms;
+}
+
+HDK_DEV bool quals_pass(const RowCtx& c, int stage, int32_t& err) {
   const hdk_hip_plan* p = c.plan;
   const int nq = p->num_quals;
   for (int q = 0; q < nq; ++q) {
-    if (!eval_qual(c, p->quals[q], err)) {
+    if ((p->quals[q].after_joins != 0) == (stage != 0) && !eval_qual(c, p->quals[q], err)) {
       return false;
-    }
-  }
-  const int nj = p->num_joins;
-  for (int j = 0; j < nj; ++j) {
-    const hdk_hip_join& jn = p->joins[j];
-    const int64_t key = eval_expr(c, jn.outer_key, err);
-    const int32_t* table = (nj == 1 && jn.table_idx == 0)
-                               ? reinterpret_cast<const int32_t*>(join_hash_tables)
-                               : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
-    const int64_t idx = probe_join(jn, table, key);
-    if (idx < 0 && jn.type == HDK_JOIN_INNER) {
-      return false;
-    }
-    if (j == 0) {
-      c.join_row[0] = idx;
-    } else {
-      c.join_row[1] = idx;
     }
   }
   return true;
+}
+
+// The join loop nest of one outer row (Executor::buildJoinLoops, QE/IRCodegen.cpp:497-667): filters
+// on the outer table, one loop level per join (a LEFT join without a match runs once with the inner
+// row = -1, whose columns read as NULL), the filters that read joined columns, then `body()`.
+template <typename Body>
+HDK_DEV void for_each_row_match(RowCtx& c, const int64_t* join_hash_tables, int32_t& err, Body&& body) {
+  const hdk_hip_plan* p = c.plan;
+  if (!quals_pass(c, 0, err)) {
+    return;
+  }
+  const int nj = p->num_joins;
+  if (nj == 0) {
+    if (quals_pass(c, 1, err)) {
+      body();
+    }
+    return;
+  }
+  const hdk_hip_join& j0 = p->joins[0];
+  const MatchSet m0 = matching_set(c, j0, join_hash_tables, nj, err);
+  const bool left0 = m0.n <= 0 && j0.type == HDK_JOIN_LEFT;
+  const int n0 = left0 ? 1 : m0.n;
+  for (int i0 = 0; i0 < n0; ++i0) {
+    c.join_row[0] = left0 ? -1 : (m0.ids ? static_cast<int64_t>(m0.ids[i0]) : m0.single);
+    if (nj == 1) {
+      if (quals_pass(c, 1, err)) {
+        body();
+      }
+      continue;
+    }
+    const hdk_hip_join& j1 = p->joins[1];
+    const MatchSet m1 = matching_set(c, j1, join_hash_tables, nj, err);
+    const bool left1 = m1.n <= 0 && j1.type == HDK_JOIN_LEFT;
+    const int n1 = left1 ? 1 : m1.n;
+    for (int i1 = 0; i1 < n1; ++i1) {
+      c.join_row[1] = left1 ? -1 : (m1.ids ? static_cast<int64_t>(m1.ids[i1]) : m1.single);
+      if (quals_pass(c, 1, err)) {
+        body();
+      }
+    }
+  }
 }
 
 // group key #k with the perfect-hash NULL translation (translate_null_key_*)

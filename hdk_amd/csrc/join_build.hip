@@ -10,6 +10,7 @@
 // The reference walks the column with a per-thread strided iterator over JoinChunks
 // (JoinColumnIterator.h:30-100); here each chunk is swept by the whole grid with coalesced loads,
 // and the scan is a hand-written 3-kernel block scan instead of thrust::inclusive_scan.
+#include <cstring>
 #include "device_common.h"
 #include "host_common.h"
 
@@ -322,6 +323,204 @@ static int32_t one_to_many(int32_t* buff, int64_t hash_entry_count, int32_t inva
   return HDK_HIP_OK;
 }
 
+// ---- keyed ("baseline") tables: composite / wide keys, open addressing with MurmurHash1 ---------------
+// write_baseline_hash_slot + get_matching_baseline_hash_slot_at (HashJoinRuntime.cpp:357-452),
+// count_matches_baseline / fill_row_ids_baseline (:723-768, :889-950), key handler
+// HashJoinKeyHandlers.h:36-100 (a row with a NULL component is skipped).
+enum KeyedMode { KEYED_ONE_TO_ONE = 0, KEYED_DICT = 1, KEYED_COUNT = 2, KEYED_FILL_IDS = 3 };
+
+struct KeyedArgs {
+  int8_t* hash_buff;        // keys (+ payload for one-to-one)
+  int32_t* otm;             // one-to-many: [pos | count | ids] after the dictionary
+  int64_t entry_count;
+  int32_t invalid_slot_val;
+  int32_t for_semi_join;
+  int32_t kc;
+  int32_t* dev_err;
+  const hdk_hip_join_chunk* chunks[HDK_HIP_MAX_JOIN_KEYS];
+  size_t num_chunks;
+  hdk_hip_join_column_type_info ti[HDK_HIP_MAX_JOIN_KEYS];
+};
+
+template <typename T>
+HDK_DEV T keyed_invalid() {
+  return sizeof(T) == 8 ? static_cast<T>(HDK_EMPTY_KEY_64) : static_cast<T>(HDK_EMPTY_KEY_32);
+}
+
+template <typename T>
+HDK_DEV uint32_t keyed_hash(const int64_t* key, int kc) {
+  uint32_t words[2 * HDK_HIP_MAX_JOIN_KEYS];
+  int nw = 0;
+#pragma unroll
+  for (int i = 0; i < HDK_HIP_MAX_JOIN_KEYS; ++i) {
+    if (i < kc) {
+      if constexpr (sizeof(T) == 8) {
+        words[nw++] = static_cast<uint32_t>(static_cast<uint64_t>(key[i]));
+        words[nw++] = static_cast<uint32_t>(static_cast<uint64_t>(key[i]) >> 32);
+      } else {
+        words[nw++] = static_cast<uint32_t>(key[i]);
+      }
+    }
+  }
+  return murmur_hash1_words(words, nw);
+}
+
+// Find the slot of `key`, claiming an empty one when CLAIM.  Wave-safe publication: a reader that
+// finds the first component written but a later one still empty re-examines the slot on the next
+// trip of the loop instead of spinning (the writer may be a lane of the same wave).
+template <typename T, bool CLAIM>
+HDK_DEV int64_t keyed_slot(T* dict, uint32_t entries, int comps, int kc, const int64_t* key) {
+  const T invalid = keyed_invalid<T>();
+  uint32_t probe = keyed_hash<T>(key, kc) % entries;
+  uint32_t steps = 0;
+  int64_t result = -2;
+  while (result == -2) {
+    T* e = dict + static_cast<size_t>(probe) * comps;
+    T first;
+    bool won = false;
+    if (CLAIM) {
+      if constexpr (sizeof(T) == 8) {
+        first = static_cast<T>(atomicCAS(reinterpret_cast<unsigned long long*>(e), static_cast<unsigned long long>(invalid),
+                                         static_cast<unsigned long long>(static_cast<T>(key[0]))));
+      } else {
+        first = static_cast<T>(atomicCAS(reinterpret_cast<unsigned int*>(e), static_cast<unsigned int>(invalid),
+                                         static_cast<unsigned int>(static_cast<T>(key[0]))));
+      }
+      won = first == invalid;
+      if (won) {
+        for (int i = 1; i < kc; ++i) {
+          __hip_atomic_store(e + i, static_cast<T>(key[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        result = probe;
+      }
+    } else {
+      first = e[0];
+    }
+    bool advance = false;
+    if (!won) {
+      if (first == static_cast<T>(key[0]) && first != invalid) {
+        bool eq = true;
+        bool pending = false;
+        for (int i = 1; i < kc; ++i) {
+          const T v = __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == invalid && static_cast<T>(key[i]) != invalid) {
+            pending = true;
+          } else if (v != static_cast<T>(key[i])) {
+            eq = false;
+          }
+        }
+        if (!eq) {
+          advance = true;
+        } else if (!pending || !CLAIM) {
+          result = pending ? -1 : static_cast<int64_t>(probe);
+        }
+      } else if (!CLAIM && first == invalid) {
+        result = -1;
+      } else {
+        advance = true;
+      }
+    }
+    if (advance) {
+      probe = probe + 1 == entries ? 0 : probe + 1;
+      if (++steps >= entries) {
+        result = -1;
+      }
+    }
+  }
+  return result;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kJoinBlock) void k_keyed_build(KeyedArgs a) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kJoinBlock;
+  const size_t start = static_cast<size_t>(blockIdx.x) * kJoinBlock + threadIdx.x;
+  const int kc = a.kc;
+  const int comps = kc + (MODE == KEYED_ONE_TO_ONE ? 1 : 0);
+  const uint32_t entries = static_cast<uint32_t>(a.entry_count);
+  T* dict = reinterpret_cast<T*>(a.hash_buff);
+  size_t index_base = 0;
+  for (size_t c = 0; c < a.num_chunks; ++c) {
+    const size_t n = a.chunks[0][c].num_elems;
+    for (size_t i = start; i < n; i += stride) {
+      int64_t key[HDK_HIP_MAX_JOIN_KEYS];
+      bool skip = false;
+#pragma unroll
+      for (int k = 0; k < HDK_HIP_MAX_JOIN_KEYS; ++k) {
+        key[k] = 0;
+        if (k < kc) {
+          const int64_t elem = join_elem(a.chunks[k][c].col_buff, i, static_cast<int>(a.ti[k].elem_sz), a.ti[k].column_type);
+          if (elem == a.ti[k].null_val && !a.ti[k].uses_bw_eq) {
+            skip = true;
+          }
+          key[k] = elem;
+        }
+      }
+      if (skip) {
+        continue;
+      }
+      const int32_t index = static_cast<int32_t>(index_base + i);
+      const int64_t slot = keyed_slot<T, (MODE == KEYED_ONE_TO_ONE || MODE == KEYED_DICT)>(dict, entries, comps, kc, key);
+      if (slot < 0) {
+        if (a.dev_err) {
+          atomicMin(a.dev_err, -2);  // table full
+        }
+        continue;
+      }
+      if (MODE == KEYED_ONE_TO_ONE) {
+        T* val = dict + static_cast<size_t>(slot) * comps + kc;
+        T old;
+        if constexpr (sizeof(T) == 8) {
+          old = static_cast<T>(atomicCAS(reinterpret_cast<unsigned long long*>(val),
+                                         static_cast<unsigned long long>(static_cast<T>(a.invalid_slot_val)),
+                                         static_cast<unsigned long long>(static_cast<T>(index))));
+        } else {
+          old = static_cast<T>(atomicCAS(reinterpret_cast<unsigned int*>(val), static_cast<unsigned int>(a.invalid_slot_val),
+                                         static_cast<unsigned int>(index)));
+        }
+        if (old != static_cast<T>(a.invalid_slot_val) && !a.for_semi_join) {
+          atomicMin(a.dev_err, -1);  // duplicate key: the caller builds a one-to-many table instead
+        }
+      } else if (MODE == KEYED_COUNT) {
+        atomicAdd(a.otm + entries + slot, 1);
+      } else if (MODE == KEYED_FILL_IDS) {
+        const int32_t at = a.otm[slot] + atomicAdd(a.otm + entries + slot, 1);
+        a.otm[2 * static_cast<size_t>(entries) + at] = index;
+      }
+    }
+    index_base += n;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kJoinBlock) void k_keyed_init(T* buff, int64_t entry_count, int comps, int kc,
+                                                           int32_t invalid_slot_val) {
+  const int64_t n = entry_count * comps;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kJoinBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kJoinBlock + threadIdx.x; i < n; i += stride) {
+    buff[i] = (i % comps) < kc ? keyed_invalid<T>() : static_cast<T>(invalid_slot_val);
+  }
+}
+
+static int32_t keyed_args(KeyedArgs* a, size_t key_component_count, int32_t key_component_width,
+                          const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti) {
+  HDK_REQUIRE(key_component_count >= 1 && key_component_count <= HDK_HIP_MAX_JOIN_KEYS,
+              "key_component_count must be in [1, %d]", HDK_HIP_MAX_JOIN_KEYS);
+  HDK_REQUIRE(key_component_width == 4 || key_component_width == 8, "key_component_width must be 4 or 8");
+  HDK_REQUIRE(cols && ti, "NULL join columns");
+  memset(a, 0, sizeof(*a));
+  a->kc = static_cast<int32_t>(key_component_count);
+  for (size_t k = 0; k < key_component_count; ++k) {
+    const int32_t st = check_join_args(cols[k], ti[k]);
+    if (st) return st;
+    HDK_REQUIRE(cols[k].num_chunks == cols[0].num_chunks && cols[k].num_elems == cols[0].num_elems,
+                "key columns of one table must be fragmented alike");
+    a->chunks[k] = reinterpret_cast<const hdk_hip_join_chunk*>(cols[k].col_chunks_buff);
+    a->ti[k] = ti[k];
+  }
+  a->num_chunks = cols[0].num_chunks;
+  return HDK_HIP_OK;
+}
+
 // ---- fused one-to-one table: [row id | payload words] per slot (HDK_JOIN_ONE_TO_ONE_FUSED) ------------
 constexpr int kMaxFusedCols = 7;
 struct FusedArgs {
@@ -434,4 +633,111 @@ extern "C" int32_t hdk_hip_fill_one_to_many_hash_table_bucketized(int32_t* buff,
   const size_t n = hash_entry_info.hash_entry_count / b + (hash_entry_info.hash_entry_count % b ? 1 : 0);
   return one_to_many(buff, static_cast<int64_t>(n), invalid_slot_val, join_column, type_info,
                      hash_entry_info.bucket_normalization, device_id, stream);
+}
+
+extern "C" int32_t hdk_hip_init_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count,
+                                                        size_t key_component_count, int32_t key_component_width,
+                                                        int32_t with_val_slot, int32_t invalid_slot_val,
+                                                        int32_t device_id, void* stream) {
+  HDK_REQUIRE(hash_buff && entry_count > 0, "bad buffer / entry_count");
+  HDK_REQUIRE(key_component_count >= 1 && key_component_count <= HDK_HIP_MAX_JOIN_KEYS, "bad key_component_count");
+  HDK_REQUIRE(key_component_width == 4 || key_component_width == 8, "key_component_width must be 4 or 8");
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  const int kc = static_cast<int>(key_component_count);
+  const int comps = kc + (with_val_slot ? 1 : 0);
+  const unsigned g = grid_for(static_cast<size_t>(entry_count) * comps, device_id);
+  if (key_component_width == 4) {
+    hipLaunchKernelGGL(k_keyed_init<int32_t>, dim3(g), dim3(kJoinBlock), 0, s, reinterpret_cast<int32_t*>(hash_buff),
+                       entry_count, comps, kc, invalid_slot_val);
+  } else {
+    hipLaunchKernelGGL(k_keyed_init<int64_t>, dim3(g), dim3(kJoinBlock), 0, s, reinterpret_cast<int64_t*>(hash_buff),
+                       entry_count, comps, kc, invalid_slot_val);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                                        int32_t for_semi_join, size_t key_component_count,
+                                                        int32_t key_component_width, int32_t with_val_slot,
+                                                        int32_t* dev_err_buff, const hdk_hip_join_column* join_column_per_key,
+                                                        const hdk_hip_join_column_type_info* type_info_per_key,
+                                                        int32_t device_id, void* stream) {
+  HDK_REQUIRE(hash_buff && dev_err_buff && entry_count > 0 && entry_count < (int64_t(1) << 31), "bad arguments");
+  KeyedArgs a;
+  int32_t st = keyed_args(&a, key_component_count, key_component_width, join_column_per_key, type_info_per_key);
+  if (st) return st;
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  if (join_column_per_key[0].num_elems == 0) return HDK_HIP_OK;
+  a.hash_buff = hash_buff;
+  a.entry_count = entry_count;
+  a.invalid_slot_val = invalid_slot_val;
+  a.for_semi_join = for_semi_join;
+  a.dev_err = dev_err_buff;
+  const unsigned g = grid_for(join_column_per_key[0].num_elems, device_id);
+  if (key_component_width == 4) {
+    if (with_val_slot) {
+      hipLaunchKernelGGL((k_keyed_build<int32_t, KEYED_ONE_TO_ONE>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((k_keyed_build<int32_t, KEYED_DICT>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    }
+  } else if (with_val_slot) {
+    hipLaunchKernelGGL((k_keyed_build<int64_t, KEYED_ONE_TO_ONE>), dim3(g), dim3(kJoinBlock), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_keyed_build<int64_t, KEYED_DICT>), dim3(g), dim3(kJoinBlock), 0, s, a);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_fill_one_to_many_baseline_hash_table(int32_t* buff, const int8_t* composite_key_dict,
+                                                                int64_t hash_entry_count, int32_t invalid_slot_val,
+                                                                size_t key_component_count, int32_t key_component_width,
+                                                                const hdk_hip_join_column* join_column_per_key,
+                                                                const hdk_hip_join_column_type_info* type_info_per_key,
+                                                                int32_t device_id, void* stream) {
+  HDK_REQUIRE(buff && composite_key_dict && hash_entry_count > 0 && hash_entry_count < (int64_t(1) << 31),
+              "bad arguments");
+  KeyedArgs a;
+  int32_t st = keyed_args(&a, key_component_count, key_component_width, join_column_per_key, type_info_per_key);
+  if (st) return st;
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  a.hash_buff = const_cast<int8_t*>(composite_key_dict);
+  a.otm = buff;
+  a.entry_count = hash_entry_count;
+  a.invalid_slot_val = invalid_slot_val;
+  int32_t* pos_buff = buff;
+  int32_t* count_buff = buff + hash_entry_count;
+  const size_t n = join_column_per_key[0].num_elems;
+  const unsigned g = grid_for(n, device_id);
+  const unsigned ge = grid_for(static_cast<size_t>(hash_entry_count), device_id);
+  hipLaunchKernelGGL(k_fill_i32, dim3(ge), dim3(kJoinBlock), 0, s, pos_buff, hash_entry_count, invalid_slot_val);
+  HDK_HIP_CHECK(hipMemsetAsync(count_buff, 0, static_cast<size_t>(hash_entry_count) * sizeof(int32_t), s));
+  if (n) {
+    if (key_component_width == 4) {
+      hipLaunchKernelGGL((k_keyed_build<int32_t, KEYED_COUNT>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((k_keyed_build<int64_t, KEYED_COUNT>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    }
+  }
+  hipLaunchKernelGGL(k_set_valid_pos, dim3(ge), dim3(kJoinBlock), 0, s, pos_buff, count_buff, hash_entry_count, 0);
+  st = inclusive_scan_inplace(count_buff, hash_entry_count, s);
+  if (st) return st;
+  hipLaunchKernelGGL(k_set_valid_pos, dim3(ge), dim3(kJoinBlock), 0, s, pos_buff, count_buff, hash_entry_count, 1);
+  HDK_HIP_CHECK(hipMemsetAsync(count_buff, 0, static_cast<size_t>(hash_entry_count) * sizeof(int32_t), s));
+  if (n) {
+    if (key_component_width == 4) {
+      hipLaunchKernelGGL((k_keyed_build<int32_t, KEYED_FILL_IDS>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((k_keyed_build<int64_t, KEYED_FILL_IDS>), dim3(g), dim3(kJoinBlock), 0, s, a);
+    }
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
 }

@@ -109,15 +109,13 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
       const int64_t row_end = min(row0 + tile_rows, nrows);
       for (int64_t row = row0 + tid; row < row_end; row += kBlock) {
         c.pos = row;
-        if (!row_passes(c, a.kp.join_hash_tables, err)) {
-          continue;
-        }
+        for_each_row_match(c, a.kp.join_hash_tables, err, [&]() {
         int64_t entry = 0;
         if (grouped) {
           entry = perfect_hash_entry(c, err);
           if (static_cast<uint64_t>(entry) >= a.entry_count) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;  // key outside the range the layout was sized for
-            continue;
+            return;
           }
         }
         int64_t* base = lds + (static_cast<uint32_t>(entry) * wpe) * rep + my_rep;
@@ -149,6 +147,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
             }
           }
         }
+        });
       }
     }
     frag_tile_begin += ntiles;
@@ -420,6 +419,19 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   HDK_REQUIRE(p->num_quals >= 0 && p->num_quals <= HDK_HIP_MAX_QUALS, "bad num_quals");
   HDK_REQUIRE(p->num_joins >= 0 && p->num_joins <= HDK_HIP_MAX_JOINS, "bad num_joins");
   HDK_REQUIRE(p->key_count >= 0 && p->key_count <= HDK_HIP_MAX_KEYS, "bad key_count");
+  for (int j = 0; j < p->num_joins; ++j) {
+    const hdk_hip_join& jn = p->joins[j];
+    HDK_REQUIRE(jn.kind >= HDK_JOIN_ONE_TO_ONE && jn.kind <= HDK_JOIN_KEYED_ONE_TO_MANY, "bad join kind");
+    HDK_REQUIRE(jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_LEFT, "bad join type");
+    if (jn.kind == HDK_JOIN_ONE_TO_MANY || jn.kind >= HDK_JOIN_KEYED_ONE_TO_ONE) {
+      HDK_REQUIRE(jn.entry_count > 0 && jn.entry_count < (int64_t(1) << 31), "join table entry_count out of range");
+    }
+    if (jn.kind >= HDK_JOIN_KEYED_ONE_TO_ONE) {
+      HDK_REQUIRE(jn.key_component_count >= 1 && jn.key_component_count <= HDK_HIP_MAX_JOIN_KEYS,
+                  "bad key_component_count");
+      HDK_REQUIRE(jn.key_component_width == 4 || jn.key_component_width == 8, "bad key_component_width");
+    }
+  }
   HDK_REQUIRE(p->num_targets > 0 && p->num_targets <= HDK_HIP_MAX_TARGETS, "bad num_targets");
   HDK_REQUIRE(p->query_kind >= HDK_Q_NON_GROUPED && p->query_kind <= HDK_Q_PROJECTION,
               "bad query_kind");
@@ -660,10 +672,23 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
   }
 }
 
+// joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
+// LEFT joins (the batched interpreter handles inner one-to-one probes)
+static bool needs_join_loops(const hdk_hip_plan* p) {
+  for (int j = 0; j < p->num_joins; ++j) {
+    const hdk_hip_join& jn = p->joins[j];
+    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) {
+      return true;
+    }
+  }
+  return false;
+}
+
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
   FastArgs fa;
   int kw, vw;
   if (match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  if (needs_join_loops(p)) return "hdk_scan_agg_generic";
   return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
 }
 
@@ -683,7 +708,7 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
       default: return launch_direct_kw<8>(vw, fa, shape, s);
     }
   }
-  if (!force_scalar) {
+  if (!force_scalar && !needs_join_loops(plan)) {
     VecArgs v;
     v.plan = d_plan;
     v.kp = kp;
@@ -747,7 +772,9 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
   } else if (s.strategy == STRAT_PROJECT) {
-    snprintf(out, out_len, plan->num_joins ? "hdk_scan_project_join" : "hdk_scan_project");
+    snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
+                                 : plan->num_joins     ? "hdk_scan_project_join"
+                                                       : "hdk_scan_project");
   } else {
     snprintf(out, out_len, "hdk_scan_agg_global");
   }
@@ -772,13 +799,11 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   for (int j = 0; j < plan->num_joins; ++j) {
     if (plan->joins[j].kind == HDK_JOIN_ONE_TO_ONE_FUSED) {
       HDK_REQUIRE(plan->joins[j].fused_stride >= 1, "fused join table needs fused_stride >= 1");
-      if (shape.strategy == STRAT_GLOBAL || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
+      if (shape.strategy == STRAT_GLOBAL || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) ||
+          needs_join_loops(plan)) {
         set_error("fused join tables are only read by the batched interpreter kernels");
         return HDK_HIP_ERR_UNSUPPORTED;
       }
-    } else if (plan->joins[j].kind != HDK_JOIN_ONE_TO_ONE) {
-      set_error("one-to-many join probes are outside the fixed kernel library");
-      return HDK_HIP_ERR_UNSUPPORTED;
     }
   }
   HDK_REQUIRE(workspace && workspace_bytes >= workspace_bytes_for(shape),
@@ -839,7 +864,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     pa.plan = d_plan;
     pa.kp = kp;
     pa.entry_count = plan->entry_count;
-    if (plan->num_joins) {
+    if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
+      hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+    } else if (plan->num_joins) {
       hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
     } else {
       hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);

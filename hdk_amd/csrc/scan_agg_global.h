@@ -122,9 +122,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
       const int64_t row_end = min(row0 + tile_rows, nrows);
       for (int64_t row = row0 + tid; row < row_end; row += kGlobalBlock) {
         c.pos = row;
-        if (!row_passes(c, a.kp.join_hash_tables, err)) {
-          continue;
-        }
+        for_each_row_match(c, a.kp.join_hash_tables, err, [&]() {
         // ---- keys -> entry --------------------------------------------------------------------
         int64_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
         if (nk > 0) k0 = eval_key(c, 0, err);
@@ -144,7 +142,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
           }
           if (entry < 0) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;  // get_group_value returned NULL
-            continue;
+            return;
           }
         } else {
           // perfect hash: stride walk as perfect_key_hash does
@@ -161,7 +159,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
           }
           if (static_cast<uint64_t>(h) >= a.entry_count) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;
-            continue;
+            return;
           }
           entry = h;
           if (!p->keyless) {  // every writer stores the same key values: plain publication is enough
@@ -223,6 +221,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
             g_agg64(tg.agg, tg.arg_is_fp, tg.skip_null, tg.null_val, reinterpret_cast<int64_t*>(s1), v);
           }
         }
+        });
       }
     }
     frag_tile_begin += ntiles;

@@ -138,4 +138,80 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_join(P
   scan_project_body<true>(a);
 }
 
+// General form: any join the library accepts (one-to-many and keyed tables, LEFT joins), one row at
+// a time through the join loop nest of device_common.h.  Every surviving row combination claims an
+// output row; lanes that reach the claim together share one atomic (the active-lane mask is the
+// selection vector: ballot + popcount inside the divergent loop).
+extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_scalar(ProjArgs a) {
+  __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const bool columnar = p->output_columnar;
+  const int nt = p->num_targets;
+  if (columnar && tid < HDK_HIP_MAX_TARGETS) {
+    s_col_off[tid] = columnar_slot_off(p, a.entry_count, tid);
+  }
+  __syncthreads();
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const uint32_t max_matched = static_cast<uint32_t>(*a.kp.max_matched);
+  int64_t* buf = a.kp.groupby_buf[0];
+  constexpr int64_t kTileRows = kProjBlock;
+
+  RowCtx c;
+  c.plan = p;
+  c.join_row[0] = 0;
+  c.join_row[1] = 0;
+  int32_t err = 0;
+  int32_t slots_err = 0;
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    c.cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row = (tile - frag_tile_begin) * kTileRows + tid;
+      if (row >= nrows) {
+        continue;
+      }
+      c.pos = row;
+      for_each_row_match(c, a.kp.join_hash_tables, err, [&]() {
+        const uint64_t active = __ballot(1);
+        const int leader = __ffsll(static_cast<long long>(active)) - 1;
+        uint32_t base = 0;
+        if (lane == leader) {
+          base = static_cast<uint32_t>(atomicAdd(a.kp.total_matched, static_cast<int32_t>(__popcll(active))));
+        }
+        base = __shfl(base, leader, kWave);
+        const uint32_t pos = base + static_cast<uint32_t>(__popcll(active & ((1ull << lane) - 1)));
+        if (pos >= max_matched) {
+          slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
+          return;
+        }
+        if (columnar) {
+          buf[pos] = row;
+        } else {
+          buf[static_cast<size_t>(pos) * p->row_size_quad] = row;
+        }
+        for (int t = 0; t < nt; ++t) {
+          const hdk_hip_target& tg = p->targets[t];
+          const int64_t v = eval_expr(c, tg.arg, err);
+          const int w = tg.slot_width;
+          int8_t* dst = columnar ? reinterpret_cast<int8_t*>(buf) + s_col_off[t] + static_cast<size_t>(pos) * w
+                                 : reinterpret_cast<int8_t*>(buf + static_cast<size_t>(pos) * p->row_size_quad) + tg.slot_off;
+          store_slot(dst, w, v);
+        }
+      });
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  } else if (slots_err) {
+    atomicCAS(a.kp.error_code, 0, slots_err);
+  }
+}
+
 }  // namespace hdk

@@ -271,7 +271,9 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
   const hdk_hip_plan* p = c.plan;
   const int nq = p->num_quals;
   for (int q = 0; q < nq; ++q) {
-    eval_qual_v(c, p->quals[q], pass, err);
+    if (!VecCtx::kJoins || !p->quals[q].after_joins) {
+      eval_qual_v(c, p->quals[q], pass, err);
+    }
   }
   const int nj = VecCtx::kJoins ? p->num_joins : 0;
   for (int j = 0; j < nj; ++j) {
@@ -344,6 +346,13 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
         c.jref0[r] = ref;
       } else {
         c.jref1[r] = ref;
+      }
+    }
+  }
+  if (VecCtx::kJoins) {  // filters that read joined columns
+    for (int q = 0; q < nq; ++q) {
+      if (p->quals[q].after_joins) {
+        eval_qual_v(c, p->quals[q], pass, err);
       }
     }
   }

@@ -206,11 +206,13 @@ class PreparedStep:
         """Replace each one-to-one join table by the fused [row id | payload ...] form when the batched
         interpreter (or the projection kernel) will run the plan: one gather per probing row instead of
         slot -> row id -> inner column (HDK_JOIN_ONE_TO_ONE_FUSED, include/hdk_hip.h)."""
-        names = self.kernel_names()
-        if not (names.startswith("hdk_scan_agg_vec") or names.startswith("hdk_scan_project")):
+        names = self.kernel_names().split(",")[0]
+        if names not in ("hdk_scan_agg_vec_join", "hdk_scan_project_join"):
             return
         cp, p, storage = self.cp, self.plan, self.ex.storage
         for ji, info in enumerate(cp.join_infos):
+            if info["kind"] != A.JOIN_ONE_TO_ONE:
+                continue
             cols = [ci for ci, (tn, cn, slot) in enumerate(cp.input_cols) if slot == ji + 1]
             entries = info["max"] - info["min"] + 1
             stride = 1 + len(cols)
@@ -313,43 +315,78 @@ class Executor:
     def compile(self, q: QueryUnit) -> CompiledPlan:
         return compile_query(self.storage, q)
 
+    def _join_columns(self, inner, info):
+        """JoinColumn / JoinColumnTypeInfo per key column: one JoinChunk per inner fragment."""
+        jcs, tis, keep = [], [], []
+        for k, col in enumerate(info["inner_cols"]):
+            chunks = (A.JoinChunk * inner.num_fragments)()
+            rid = 0
+            for f in range(inner.num_fragments):
+                chunks[f].col_buff = self.cache.chunk(inner, col, f).ptr
+                chunks[f].num_elems = inner.frag_rows[f]
+                chunks[f].row_id = rid
+                rid += inner.frag_rows[f]
+            raw = np.frombuffer(bytes(chunks), dtype=np.uint8)
+            d_chunks = self.mgr.to_device(raw, self.device_id)
+            keep.append(d_chunks)
+            jcs.append(A.JoinColumn(d_chunks.ptr, raw.nbytes, inner.num_fragments, inner.num_rows, info["elem_szs"][k]))
+            tis.append(A.JoinColumnTypeInfo(info["elem_szs"][k], info["mins"][k], info["maxs"][k], info["null_vals"][k],
+                                            0, A.JC_SIGNED, 0))
+        return jcs, tis, keep
+
     def _build_join_table(self, cp: CompiledPlan, ji: int) -> DeviceBuffer:
-        """PerfectJoinHashTable::reify for one device: init + one-to-one fill; a duplicate key
-        (NeedsOneToManyHash) is outside the probe kernels this round -> QueryMustRunOnCpu."""
+        """HashJoin::getInstance / PerfectJoinHashTable::reify / BaselineJoinHashTable::reify for one
+        device (QE/JoinHashTable/HashJoin.cpp:258-330): the table kind the plan names -- perfect or
+        keyed, one-to-one or one-to-many -- built with the *_on_device entry points.  The plan chose
+        one-to-one from the inner table's data; a duplicate showing up anyway (stale data) is reported
+        like the reference's NeedsOneToManyHash."""
         info = cp.join_infos[ji]
-        key = (info["inner_table"], info["inner_col"])
+        kind = info["kind"]
+        key = (info["inner_table"], tuple(info["inner_cols"]), kind)
         if key in self._join_cache:
             return self._join_cache[key]
         L = lib()
+        dev = self.device_id
         inner = self.storage.get(info["inner_table"])
-        entries = info["max"] - info["min"] + 1
-        if entries <= 0 or entries > 2**31 - 1:
-            raise QueryMustRunOnCpu("join key range too large for a perfect hash table (TooManyHashEntries)")
-        table = self.mgr.alloc(entries * 4, self.device_id)
-        check(L.hdk_hip_init_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, self.device_id, None))
-        # JoinColumn: one JoinChunk per inner fragment
-        chunks = (A.JoinChunk * inner.num_fragments)()
-        rid = 0
-        for f in range(inner.num_fragments):
-            chunks[f].col_buff = self.cache.chunk(inner, info["inner_col"], f).ptr
-            chunks[f].num_elems = inner.frag_rows[f]
-            chunks[f].row_id = rid
-            rid += inner.frag_rows[f]
-        raw = np.frombuffer(bytes(chunks), dtype=np.uint8)
-        d_chunks = self.mgr.to_device(raw, self.device_id)
-        jc = A.JoinColumn(d_chunks.ptr, raw.nbytes, inner.num_fragments, inner.num_rows, info["elem_sz"])
-        ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], 0, A.JC_SIGNED, 0)
-        d_err = self.mgr.to_device(np.zeros(1, dtype=np.int32), self.device_id)
-        check(L.hdk_hip_fill_hash_join_buff(table.ptr, A.JOIN_INVALID_SLOT, 0, d_err.ptr, jc, ti,
-                                            self.device_id, None))
-        self.mgr.synchronizeStream(self.device_id)
-        err = int(self.mgr.to_host(d_err.ptr, 4, self.device_id, np.int32)[0])
+        jcs, tis, keep = self._join_columns(inner, info)
+        d_err = self.mgr.to_device(np.zeros(1, dtype=np.int32), dev)
+        if kind in (A.JOIN_ONE_TO_ONE, A.JOIN_ONE_TO_MANY):
+            entries = info["max"] - info["min"] + 1
+            if entries <= 0 or entries > 2**31 - 1:
+                raise QueryMustRunOnCpu("join key range too large for a perfect hash table (TooManyHashEntries)")
+            if kind == A.JOIN_ONE_TO_ONE:
+                table = self.mgr.alloc(entries * 4, dev)
+                check(L.hdk_hip_init_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, dev, None))
+                check(L.hdk_hip_fill_hash_join_buff(table.ptr, A.JOIN_INVALID_SLOT, 0, d_err.ptr, jcs[0], tis[0], dev, None))
+            else:
+                n32 = 2 * entries + inner.num_rows
+                table = self.mgr.alloc(n32 * 4, dev)
+                check(L.hdk_hip_init_hash_join_buff(table.ptr, n32, A.JOIN_INVALID_SLOT, dev, None))
+                check(L.hdk_hip_fill_one_to_many_hash_table(table.ptr, A.HashEntryInfo(entries, 1), A.JOIN_INVALID_SLOT,
+                                                            jcs[0], tis[0], dev, None))
+        else:
+            kc, w, entries = len(info["inner_cols"]), info["key_width"], info["entry_count"]
+            jc_arr = (A.JoinColumn * kc)(*jcs)
+            ti_arr = (A.JoinColumnTypeInfo * kc)(*tis)
+            one = kind == A.JOIN_KEYED_ONE_TO_ONE
+            dict_bytes = entries * (kc + (1 if one else 0)) * w
+            table = self.mgr.alloc(dict_bytes + (0 if one else (2 * entries + inner.num_rows) * 4), dev)
+            check(L.hdk_hip_init_baseline_hash_join_buff(table.ptr, entries, kc, w, 1 if one else 0,
+                                                         A.JOIN_INVALID_SLOT, dev, None))
+            check(L.hdk_hip_fill_baseline_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, 0, kc, w,
+                                                         1 if one else 0, d_err.ptr, jc_arr, ti_arr, dev, None))
+            if not one:
+                check(L.hdk_hip_fill_one_to_many_baseline_hash_table(table.ptr + dict_bytes, table.ptr, entries,
+                                                                     A.JOIN_INVALID_SLOT, kc, w, jc_arr, ti_arr, dev, None))
+        self.mgr.synchronizeStream(dev)
+        err = int(self.mgr.to_host(d_err.ptr, 4, dev, np.int32)[0])
         d_err.free()
-        d_chunks.free()
+        for d in keep:
+            d.free()
         if err != 0:
             table.free()
-            raise QueryMustRunOnCpu("join keys are not unique: one-to-many probe is outside the fixed kernel "
-                                    "library this round (PerfectHashTableBuilder.h:134-141 NeedsOneToManyHash)")
+            raise QueryMustRunOnCpu(f"join table build failed with code {err} (-1: duplicate key in a one-to-one "
+                                    "table, PerfectHashTableBuilder.h:134-141 NeedsOneToManyHash; -2: stale metadata)")
         self._join_cache[key] = table
         return table
 

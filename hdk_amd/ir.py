@@ -6,7 +6,7 @@ groupby_exprs, target_exprs.  The full `hdk::ir` DAG (omniscidb/IR/) stays out o
 integration pattern-matches its work unit into this shape.
 """
 from dataclasses import dataclass, field
-from typing import List, Optional, Union
+from typing import Sequence, List, Optional, Union
 
 from . import _abi as A
 
@@ -158,11 +158,22 @@ class Proj:
 
 @dataclass(frozen=True)
 class JoinSpec:
-    """Equi-join of the outer table with `inner_table` on outer_key == inner_col (perfect hash)."""
+    """Equi-join of the outer table with `inner_table` on outer_key == inner_col.  Both sides may be
+    lists of equal length (composite key -> keyed/"baseline" hash table, BaselineJoinHashTable); the
+    table kind (one-to-one / one-to-many, perfect / keyed) is chosen from the inner table's data the
+    way PerfectJoinHashTable::reify / HashJoin::getInstance do (QE/JoinHashTable/HashJoin.cpp:258-330)."""
     inner_table: str
-    outer_key: Expr
-    inner_col: str
+    outer_key: Union[Expr, Sequence[Expr]]
+    inner_col: Union[str, Sequence[str]]
     type: str = "inner"  # inner | left
+
+    @property
+    def outer_keys(self) -> list:
+        return list(self.outer_key) if isinstance(self.outer_key, (list, tuple)) else [self.outer_key]
+
+    @property
+    def inner_cols(self) -> list:
+        return list(self.inner_col) if isinstance(self.inner_col, (list, tuple)) else [self.inner_col]
 
 
 @dataclass

@@ -94,9 +94,14 @@ class _Binder:
         return self.cols.index(key)
 
     # ----- types -------------------------------------------------------------------------
+    def _left_joined(self, slot: int) -> bool:
+        return slot > 0 and self.q.joins[slot - 1].type == "left"
+
     def type_of(self, e: Expr) -> Type:
         if isinstance(e, ColRef):
-            return self.resolve(e)[2].type
+            slot, _, col = self.resolve(e)
+            # a LEFT join without a match yields NULL for every column of the inner table
+            return col.type.with_nullable(True) if self._left_joined(slot) else col.type
         if isinstance(e, Lit):
             return Type("fp", 8, False) if isinstance(e.value, float) else Type("int", 8, False)
         if isinstance(e, BinOp):
@@ -118,13 +123,14 @@ class _Binder:
     # ----- ranges ------------------------------------------------------------------------
     def range_of(self, e: Expr) -> Range:
         if isinstance(e, ColRef):
-            col = self.resolve(e)[2]
+            slot, _, col = self.resolve(e)
             st = col.table_stats()
+            has_nulls = st.has_nulls or self._left_joined(slot)
             if st.min is None:
-                return Range("invalid", has_nulls=st.has_nulls)
+                return Range("invalid", has_nulls=has_nulls)
             if col.type.is_fp:
-                return Range("fp", st.min, st.max, 0, st.has_nulls)
-            return Range("int", st.min, st.max, 0, st.has_nulls)
+                return Range("fp", st.min, st.max, 0, has_nulls)
+            return Range("int", st.min, st.max, 0, has_nulls)
         if isinstance(e, Lit):
             if isinstance(e.value, float):
                 return Range("fp", e.value, e.value)
@@ -329,40 +335,122 @@ def _agg_init_val(kind: str, arg_t: Optional[Type], nullable: bool, width: int) 
     raise ValueError(kind)
 
 
+def _expr_refs_inner(b: "_Binder", e) -> bool:
+    """Does the expression read a column of a joined (inner) table?"""
+    if isinstance(e, ColRef):
+        return b.resolve(e)[0] > 0
+    if isinstance(e, BinOp):
+        return _expr_refs_inner(b, e.lhs) or _expr_refs_inner(b, e.rhs)
+    if isinstance(e, (ExtractYear, Cast)):
+        return _expr_refs_inner(b, e.arg)
+    return False
+
+
+def _inner_keys_unique(inner: Table, cols: List[str]) -> bool:
+    """Would the one-to-one fill succeed (no duplicate non-NULL key)?  The reference finds out by
+    trying (fill_one_to_one_hashtable returns -1 -> NeedsOneToManyHash, PerfectHashTableBuilder.h:134-141);
+    the storage layer answers from the data so that the plan names the table kind up front."""
+    cache = inner.__dict__.setdefault("_unique_keys_cache", {})
+    key = tuple(cols)
+    if key not in cache:
+        arrs = [np.concatenate(inner.columns[c].fragments) if inner.columns[c].fragments else np.zeros(0, np.int64)
+                for c in cols]
+        keep = np.ones(len(arrs[0]), dtype=bool)
+        for c, a in zip(cols, arrs):
+            keep &= a != inner.columns[c].type.null_value()
+        if len(cols) == 1:
+            _, cnt = np.unique(arrs[0][keep], return_counts=True)
+        else:
+            m = np.stack([a[keep].astype(np.int64) for a in arrs], axis=1)
+            _, cnt = np.unique(m, axis=0, return_counts=True)
+        cache[key] = int(cnt.max()) if cnt.size else 1  # largest matching set
+    return cache[key] <= 1
+
+
+def _inner_max_matches(inner: Table, cols: List[str]) -> int:
+    _inner_keys_unique(inner, cols)
+    return inner.__dict__["_unique_keys_cache"][tuple(cols)]
+
+
 def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
+    """Join descriptors (joins first: inner-table columns need their table slot), then the filter
+    conjuncts, each tagged with the stage it can run at."""
     join_infos = []
     p.num_joins = len(q.joins)
     for ji, j in enumerate(q.joins):
         inner = b.inner[ji]
-        icol = inner.columns[j.inner_col]
-        if not icol.type.is_integer_like:
-            raise QueryMustRunOnCpu("join keys must be integers")
+        okeys, icols = j.outer_keys, j.inner_cols
+        if len(okeys) != len(icols) or not 1 <= len(okeys) <= A.MAX_JOIN_KEYS:
+            raise QueryMustRunOnCpu("join key lists must have 1..%d matching entries" % A.MAX_JOIN_KEYS)
+        for c in icols:
+            if not inner.columns[c].type.is_integer_like:
+                raise QueryMustRunOnCpu("join keys must be integers")
+        for k in okeys:
+            if _expr_refs_inner(b, k) and not all(b.resolve(r)[0] <= ji for r in _colrefs(k)):
+                raise QueryMustRunOnCpu("a join key may only read the outer table and earlier joins")
+        icol = inner.columns[icols[0]]
         st = icol.table_stats()
         if st.min is None:
             raise QueryMustRunOnCpu("empty join inner table")
         jn = p.joins[ji]
-        jn.outer_key = make_expr(b, j.outer_key)
+        jn.outer_key = make_expr(b, okeys[0])
+        for k in range(1, len(okeys)):
+            jn.extra_keys[k - 1] = make_expr(b, okeys[k])
         jn.min_key = int(st.min)
         jn.max_key = int(st.max)
-        okt = b.type_of(j.outer_key)
-        jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits()) if not okt.is_fp else 0
+        okt = b.type_of(okeys[0])
+        if okt.is_fp:
+            raise QueryMustRunOnCpu("join keys must be integers")
+        jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits())
         jn.null_mode = A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE
         jn.bucket = 0
-        jn.kind = A.JOIN_ONE_TO_ONE
         jn.type = A.JOIN_INNER if j.type == "inner" else A.JOIN_LEFT
-        if jn.type == A.JOIN_LEFT:
-            raise QueryMustRunOnCpu("LEFT joins are outside the fixed kernel library")
         jn.table_idx = ji
-        join_infos.append({"inner_table": inner.name, "inner_col": j.inner_col, "min": int(st.min),
-                           "max": int(st.max), "null_val": icol.type.null_value(),
-                           "elem_sz": icol.type.size})
+        range_entries = int(st.max) - int(st.min) + 1
+        keyed = len(okeys) > 1 or range_entries > 2**31 - 1  # TooManyHashEntries -> keyed table
+        unique = _inner_keys_unique(inner, icols)
+        if keyed:
+            jn.kind = A.JOIN_KEYED_ONE_TO_ONE if unique else A.JOIN_KEYED_ONE_TO_MANY
+            # BaselineJoinHashTable::getKeyComponentWidth: 8 if any key column is 8 bytes wide
+            jn.key_component_width = 8 if any(inner.columns[c].type.size == 8 for c in icols) or \
+                any(b.type_of(k).size == 8 for k in okeys) else 4
+            jn.key_component_count = len(okeys)
+            jn.entry_count = max(2 * inner.num_rows, 2)  # 2 x tuple-count upper bound
+            if jn.entry_count > 2**31 - 1:
+                raise QueryMustRunOnCpu("keyed join table too large")
+        else:
+            jn.kind = A.JOIN_ONE_TO_ONE if unique else A.JOIN_ONE_TO_MANY
+            jn.key_component_count = 1
+            jn.key_component_width = 8
+            jn.entry_count = range_entries
+        join_infos.append({"inner_table": inner.name, "inner_col": icols[0], "inner_cols": list(icols),
+                           "min": int(st.min), "max": int(st.max), "null_val": icol.type.null_value(),
+                           "elem_sz": icol.type.size,
+                           "null_vals": [inner.columns[c].type.null_value() for c in icols],
+                           "elem_szs": [inner.columns[c].type.size for c in icols],
+                           "mins": [int(inner.columns[c].table_stats().min) for c in icols],
+                           "maxs": [int(inner.columns[c].table_stats().max) for c in icols],
+                           "kind": int(jn.kind), "entry_count": int(jn.entry_count),
+                           "key_width": int(jn.key_component_width), "num_elems": inner.num_rows,
+                           "max_matches": _inner_max_matches(inner, icols)})
     p.num_quals = len(q.quals)
     for qi, c in enumerate(q.quals):
         ql = p.quals[qi]
         ql.lhs = make_expr(b, c.lhs)
         ql.rhs = _make_leaf(b, c.rhs)
         ql.cmp = _CMP[c.op]
+        ql.after_joins = 1 if (_expr_refs_inner(b, c.lhs) or _expr_refs_inner(b, c.rhs)) else 0
     return join_infos
+
+
+def _colrefs(e) -> list:
+    if isinstance(e, ColRef):
+        return [e]
+    if isinstance(e, BinOp):
+        return _colrefs(e.lhs) + _colrefs(e.rhs)
+    if isinstance(e, (ExtractYear, Cast)):
+        return _colrefs(e.arg)
+    return []
 
 
 def _fill_cols(storage: ArrowStorage, b: "_Binder", p: A.Plan):
@@ -398,7 +486,12 @@ def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
     p.key_width = 8
     columnar = bool(q.output_columnar)
     p.output_columnar = 1 if columnar else 0
-    entry_count = int(q.scan_limit) if q.scan_limit else max(b.outer.num_rows, 1)
+    # one output row per surviving row combination: outer rows x the largest matching set of each join
+    # (the reference guesses a size and re-runs with a bigger buffer when the kernel reports -pos)
+    fanout = 1
+    for info in join_infos:
+        fanout *= max(int(info["max_matches"]), 1)
+    entry_count = int(q.scan_limit) if q.scan_limit else max(b.outer.num_rows * fanout, 1)
     if entry_count >= 2**31:
         raise QueryMustRunOnCpu("projection of more than 2^31-1 rows")
     p.entry_count = entry_count
@@ -462,41 +555,7 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
             len(q.targets) > A.MAX_TARGETS:
         raise QueryMustRunOnCpu("query exceeds the fixed kernel library's limits")
 
-    # ---- joins first: inner-table columns need their table slot -------------------------
-    join_infos = []
-    p.num_joins = len(q.joins)
-    for ji, j in enumerate(q.joins):
-        inner = b.inner[ji]
-        icol = inner.columns[j.inner_col]
-        if not icol.type.is_integer_like:
-            raise QueryMustRunOnCpu("join keys must be integers")
-        st = icol.table_stats()
-        if st.min is None:
-            raise QueryMustRunOnCpu("empty join inner table")
-        jn = p.joins[ji]
-        jn.outer_key = make_expr(b, j.outer_key)
-        jn.min_key = int(st.min)
-        jn.max_key = int(st.max)
-        okt = b.type_of(j.outer_key)
-        jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits()) if not okt.is_fp else 0
-        jn.null_mode = A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE
-        jn.bucket = 0
-        jn.kind = A.JOIN_ONE_TO_ONE
-        jn.type = A.JOIN_INNER if j.type == "inner" else A.JOIN_LEFT
-        if jn.type == A.JOIN_LEFT:
-            raise QueryMustRunOnCpu("LEFT joins are outside the fixed kernel library")
-        jn.table_idx = ji
-        join_infos.append({"inner_table": inner.name, "inner_col": j.inner_col, "min": int(st.min),
-                           "max": int(st.max), "null_val": icol.type.null_value(),
-                           "elem_sz": icol.type.size})
-
-    # ---- quals ----------------------------------------------------------------------------
-    p.num_quals = len(q.quals)
-    for qi, c in enumerate(q.quals):
-        ql = p.quals[qi]
-        ql.lhs = make_expr(b, c.lhs)
-        ql.rhs = _make_leaf(b, c.rhs)
-        ql.cmp = _CMP[c.op]
+    join_infos = _compile_joins_and_quals(b, q, p)
 
     # ---- group-by keys + hash type (get_col_range_info) ---------------------------------
     nkeys = len(q.groupby)

@@ -135,6 +135,7 @@ int32_t hdk_hip_init_columnar_group_by_buffer(int64_t* groups_buffer, const int6
 #define HDK_HIP_MAX_TARGETS 8
 #define HDK_HIP_MAX_QUALS 6
 #define HDK_HIP_MAX_JOINS 2
+#define HDK_HIP_MAX_JOIN_KEYS 3 /* key components of a keyed (composite-key) join */
 #define HDK_HIP_MAX_EXPR_STEPS 3
 
 enum hdk_hip_value_class { HDK_VC_INT = 0, HDK_VC_FP = 1 };
@@ -201,18 +202,33 @@ typedef struct hdk_hip_qual {
   hdk_hip_expr lhs;
   hdk_hip_leaf rhs;
   int32_t cmp;
-  int32_t pad_;
+  int32_t after_joins; /* 0: reads outer-table columns only, evaluated before any probe (the reference
+                          hoists such filters in front of the join loops, IRCodegen.cpp:569-570);
+                          1: reads joined columns, evaluated once per matching row combination */
 } hdk_hip_qual;
 
-/* Perfect-hash equi-join probe (hash_join_idx family, QE/GroupByRuntime.cpp:274-366). */
+/* Equi-join probe.  Perfect-hash tables: hash_join_idx family (QE/GroupByRuntime.cpp:274-366);
+ * keyed ("baseline") tables: baseline_hash_join_idx_{32,64}
+ * (QE/JoinHashTable/Runtime/JoinHashTableQueryRuntime.cpp:42-98).  The join loops follow
+ * Executor::buildJoinLoops (QE/IRCodegen.cpp:497-667): a one-to-one table yields at most one inner
+ * row (JoinLoopKind::Singleton), a one-to-many table a set of them (JoinLoopKind::Set, the matching
+ * set of HashJoin::codegenMatchingSet, QE/JoinHashTable/HashJoin.cpp:149-197); a LEFT join with no
+ * match runs the rest of the row once with every column of the inner table NULL. */
 enum hdk_hip_join_kind {
   HDK_JOIN_ONE_TO_ONE = 0,  /* the reference's table: int32 row id per slot (PerfectHashTableBuilder.h:35-38) */
-  HDK_JOIN_ONE_TO_MANY = 1,
+  HDK_JOIN_ONE_TO_MANY = 1, /* int32 [offsets(entry_count) | counts(entry_count) | row ids]
+                               (fill_one_to_many_hash_table, HashJoinRuntime.cpp:770-853) */
   /* MI355X addition (no reference counterpart): int64 entries [row id | payload 1 | ... ] per slot,
    * `fused_stride` quads apart, built by hdk_hip_build_fused_join_table from the reference table and
    * the referenced inner columns.  One 16..32-B gather per probing row replaces the dependent
    * slot -> row id -> inner column chain (two cache lines) of the reference layout. */
-  HDK_JOIN_ONE_TO_ONE_FUSED = 2
+  HDK_JOIN_ONE_TO_ONE_FUSED = 2,
+  /* keyed tables (wide or composite keys), key components `key_component_width` bytes wide:
+   *   one-to-one : entry_count x [key components | row id]        (width-sized row id)
+   *   one-to-many: entry_count x [key components], then int32 [offsets | counts | row ids]
+   * (BaselineJoinHashTable layout, QE/JoinHashTable/Runtime/HashJoinRuntime.cpp:357-507,855-1000) */
+  HDK_JOIN_KEYED_ONE_TO_ONE = 3,
+  HDK_JOIN_KEYED_ONE_TO_MANY = 4
 };
 enum hdk_hip_join_type { HDK_JOIN_INNER = 0, HDK_JOIN_LEFT = 1 };
 enum hdk_hip_join_null { HDK_JOIN_NULL_NONE = 0, HDK_JOIN_NULL_NULLABLE = 1, HDK_JOIN_NULL_BITWISE = 2 };
@@ -228,7 +244,11 @@ typedef struct hdk_hip_join {
   int32_t null_mode;       /* hdk_hip_join_null */
   int32_t table_idx;       /* which entry of JOIN_HASH_TABLES */
   int32_t fused_stride;    /* HDK_JOIN_ONE_TO_ONE_FUSED: int64 words per slot (1 + payload columns) */
+  int32_t key_component_count; /* keyed tables: 1 + number of `extra_keys` in use */
+  int64_t entry_count;     /* slots of a one-to-many or keyed table */
+  int32_t key_component_width; /* keyed tables: 4 or 8 */
   int32_t pad_;
+  hdk_hip_expr extra_keys[HDK_HIP_MAX_JOIN_KEYS - 1]; /* keyed tables: outer-side components 2.. */
 } hdk_hip_join;
 
 /* Query shape: RS/QueryMemoryDescriptor.h `QueryDescriptionType`. */
@@ -294,7 +314,7 @@ typedef struct hdk_hip_plan {
   int32_t num_targets;
   hdk_hip_target targets[HDK_HIP_MAX_TARGETS];
 } hdk_hip_plan;
-#define HDK_HIP_PLAN_ABI 1u
+#define HDK_HIP_PLAN_ABI 2u
 
 /* ------------------------------------------------------------------------------------------
  * Kernel launch.
@@ -451,6 +471,32 @@ int32_t hdk_hip_fill_one_to_many_hash_table_bucketized(int32_t* buff,
                                                        hdk_hip_join_column join_column,
                                                        hdk_hip_join_column_type_info type_info,
                                                        int32_t device_id, void* stream);
+
+/* Keyed ("baseline") join tables for composite or wide keys -- the *_on_device_{32,64} functions of
+ * HashJoinRuntime.h:181-204,225-281 (GPU bodies HashJoinRuntimeGpu.cu:192-330), with the
+ * GenericKeyHandler (HashJoinKeyHandlers.h:36-100) passed as its two arrays: `join_column_per_key`
+ * and `type_info_per_key` are HOST arrays of `key_component_count` entries; `key_component_width`
+ * (4 or 8) selects the _32 / _64 form.  A row with a NULL component is skipped.
+ *   init : keys = EMPTY_KEY, payload (with_val_slot) = invalid_slot_val
+ *   fill : one-to-one table (with_val_slot=1; *dev_err_buff becomes -1 on a duplicate key, -2 when
+ *          the table is full) or just the composite-key dictionary (with_val_slot=0)
+ *   fill_one_to_many : `buff` = int32 [offsets | counts | row ids] right after the dictionary
+ *          `composite_key_dict` (which fill with_val_slot=0 built) */
+int32_t hdk_hip_init_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, size_t key_component_count,
+                                             int32_t key_component_width, int32_t with_val_slot,
+                                             int32_t invalid_slot_val, int32_t device_id, void* stream);
+int32_t hdk_hip_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                             int32_t for_semi_join, size_t key_component_count,
+                                             int32_t key_component_width, int32_t with_val_slot,
+                                             int32_t* dev_err_buff, const hdk_hip_join_column* join_column_per_key,
+                                             const hdk_hip_join_column_type_info* type_info_per_key,
+                                             int32_t device_id, void* stream);
+int32_t hdk_hip_fill_one_to_many_baseline_hash_table(int32_t* buff, const int8_t* composite_key_dict,
+                                                     int64_t hash_entry_count, int32_t invalid_slot_val,
+                                                     size_t key_component_count, int32_t key_component_width,
+                                                     const hdk_hip_join_column* join_column_per_key,
+                                                     const hdk_hip_join_column_type_info* type_info_per_key,
+                                                     int32_t device_id, void* stream);
 
 /* Build a fused join table (HDK_JOIN_ONE_TO_ONE_FUSED) from a one-to-one table:
  *   out[slot * (1 + ncols) + 0]     = table[slot]                      (row id or invalid)

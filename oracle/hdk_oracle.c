@@ -970,6 +970,178 @@ void orc_init_columnar_group_by_buffer(int64_t* groups_buffer, const int64_t* in
 }
 
 /* ============================================================================================
+ * Keyed ("baseline") join tables: composite or wide keys, open addressing with MurmurHash1.
+ * Probe: QE/JoinHashTable/Runtime/JoinHashTableQueryRuntime.cpp:25-98 (one-to-one),
+ * :130-172 (get_composite_key_index, one-to-many).  Build: HashJoinRuntime.cpp:357-507 (one-to-one),
+ * :723-768 + :889-950 (count_matches_baseline / fill_row_ids_baseline) with the key handler of
+ * HashJoinKeyHandlers.h:36-100 (rows with a NULL component are skipped).
+ * ========================================================================================== */
+static int compare_to_key(const int8_t* entry, const int8_t* key, size_t key_bytes) {
+  return memcmp(entry, key, key_bytes) == 0;
+}
+
+#define ORC_BASELINE_IDX(NAME, T, INVALID)                                                            \
+  int64_t NAME(const int8_t* hash_buff, const int8_t* key, size_t key_bytes, size_t entry_count) {    \
+    if (!entry_count) return -1; /* kNoMatch */                                                       \
+    const uint32_t h = orc_murmur_hash1(key, (int)key_bytes, 0) % entry_count;                        \
+    uint32_t hp = h;                                                                                  \
+    do {                                                                                              \
+      const int8_t* e = hash_buff + (size_t)hp * (key_bytes + sizeof(T));                             \
+      if (compare_to_key(e, key, key_bytes)) return *(const T*)(e + key_bytes);                       \
+      if (*(const T*)e == (INVALID)) return -2; /* kNotPresent */                                     \
+      hp = (hp + 1) % entry_count;                                                                    \
+    } while (hp != h);                                                                                \
+    return -1;                                                                                        \
+  }
+ORC_BASELINE_IDX(orc_baseline_hash_join_idx_32, int32_t, INT32_MAX)
+ORC_BASELINE_IDX(orc_baseline_hash_join_idx_64, int64_t, INT64_MAX)
+
+#define ORC_COMPOSITE_IDX(NAME, T, INVALID)                                                           \
+  int64_t NAME(const T* key, size_t key_component_count, const T* dict, size_t entry_count) {         \
+    const uint32_t h = orc_murmur_hash1(key, (int)(key_component_count * sizeof(T)), 0) % entry_count; \
+    uint32_t off = h * key_component_count;                                                           \
+    if (memcmp(&dict[off], key, key_component_count * sizeof(T)) == 0) return h;                      \
+    uint32_t hp = (h + 1) % entry_count;                                                              \
+    while (hp != h) {                                                                                 \
+      off = hp * key_component_count;                                                                 \
+      if (memcmp(&dict[off], key, key_component_count * sizeof(T)) == 0) return hp;                   \
+      if (dict[off] == (INVALID)) return -1;                                                          \
+      hp = (hp + 1) % entry_count;                                                                    \
+    }                                                                                                 \
+    return -1;                                                                                        \
+  }
+ORC_COMPOSITE_IDX(orc_get_composite_key_index_32, int32_t, INT32_MAX)
+ORC_COMPOSITE_IDX(orc_get_composite_key_index_64, int64_t, INT64_MAX)
+
+/* init_baseline_hash_join_buff (HashJoinRuntime.cpp:296-349): keys = invalid key, payload = invalid slot */
+void orc_init_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, size_t key_component_count,
+                                      int32_t key_component_width, int32_t with_val_slot,
+                                      int32_t invalid_slot_val) {
+  const size_t comps = key_component_count + (with_val_slot ? 1 : 0);
+  for (int64_t e = 0; e < entry_count; ++e) {
+    for (size_t i = 0; i < comps; ++i) {
+      const int is_val = with_val_slot && i == key_component_count;
+      if (key_component_width == 4) {
+        ((int32_t*)hash_buff)[e * comps + i] = is_val ? invalid_slot_val : INT32_MAX;
+      } else {
+        ((int64_t*)hash_buff)[e * comps + i] = is_val ? (int64_t)invalid_slot_val : INT64_MAX;
+      }
+    }
+  }
+}
+
+/* one row's composite key through the GenericKeyHandler; returns 0 when the row is skipped (NULL) */
+static int composite_key_of_row(const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti,
+                                size_t ncols, size_t row, int64_t* key) {
+  for (size_t k = 0; k < ncols; ++k) {
+    /* locate the chunk holding `row` (JoinColumnIterator, HashJoinRuntime.h:126-205) */
+    const hdk_hip_join_chunk* chunks = (const hdk_hip_join_chunk*)cols[k].col_chunks_buff;
+    size_t r = row;
+    size_t ci = 0;
+    while (r >= chunks[ci].num_elems) {
+      r -= chunks[ci].num_elems;
+      ++ci;
+    }
+    const int64_t elem = join_elem(&chunks[ci], r, &ti[k]);
+    if (elem == ti[k].null_val && !ti[k].uses_bw_eq) {
+      return 0;
+    }
+    key[k] = elem;
+  }
+  return 1;
+}
+
+/* find-or-insert of write_baseline_hash_slot / get_matching_baseline_hash_slot_at (sequential) */
+static int64_t keyed_slot_for_insert(int8_t* hash_buff, int64_t entry_count, const int64_t* key, size_t kc,
+                                     int32_t w, size_t entry_bytes) {
+  int32_t k32[HDK_HIP_MAX_JOIN_KEYS];
+  for (size_t i = 0; i < kc; ++i) k32[i] = (int32_t)key[i];
+  const void* kb = w == 4 ? (const void*)k32 : (const void*)key;
+  const size_t key_bytes = kc * (size_t)w;
+  const uint32_t h = orc_murmur_hash1(kb, (int)key_bytes, 0) % entry_count;
+  uint32_t hp = h;
+  do {
+    int8_t* e = hash_buff + (size_t)hp * entry_bytes;
+    const int empty = w == 4 ? *(int32_t*)e == INT32_MAX : *(int64_t*)e == INT64_MAX;
+    if (empty) {
+      memcpy(e, kb, key_bytes);
+      return hp;
+    }
+    if (memcmp(e, kb, key_bytes) == 0) {
+      return hp;
+    }
+    hp = (hp + 1) % entry_count;
+  } while (hp != h);
+  return -1;
+}
+
+/* fill_baseline_hash_join_buff (HashJoinRuntime.cpp:509-573): returns 0, -1 (duplicate key: the caller
+ * falls back to one-to-many) or -2 (table full) */
+int orc_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                     size_t key_component_count, int32_t key_component_width,
+                                     const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti) {
+  const size_t entry_bytes = (key_component_count + 1) * (size_t)key_component_width;
+  const size_t n = cols[0].num_elems;
+  for (size_t row = 0; row < n; ++row) {
+    int64_t key[HDK_HIP_MAX_JOIN_KEYS];
+    if (!composite_key_of_row(cols, ti, key_component_count, row, key)) continue;
+    const int64_t slot = keyed_slot_for_insert(hash_buff, entry_count, key, key_component_count,
+                                               key_component_width, entry_bytes);
+    if (slot < 0) return -2;
+    int8_t* val = hash_buff + (size_t)slot * entry_bytes + key_component_count * (size_t)key_component_width;
+    if (key_component_width == 4) {
+      if (*(int32_t*)val != invalid_slot_val) return -1;
+      *(int32_t*)val = (int32_t)row;
+    } else {
+      if (*(int64_t*)val != (int64_t)invalid_slot_val) return -1;
+      *(int64_t*)val = (int64_t)row;
+    }
+  }
+  return 0;
+}
+
+/* keyed one-to-many: composite key dictionary + [offsets | counts | row ids]
+ * (BaselineJoinHashTableBuilder; count_matches_baseline, inclusive scan, fill_row_ids_baseline) */
+int orc_fill_one_to_many_baseline_hash_table(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                             size_t key_component_count, int32_t key_component_width,
+                                             const hdk_hip_join_column* cols,
+                                             const hdk_hip_join_column_type_info* ti) {
+  const size_t entry_bytes = key_component_count * (size_t)key_component_width;
+  int32_t* pos_buff = (int32_t*)(hash_buff + (size_t)entry_count * entry_bytes);
+  int32_t* count_buff = pos_buff + entry_count;
+  int32_t* id_buff = count_buff + entry_count;
+  const size_t n = cols[0].num_elems;
+  for (int64_t e = 0; e < entry_count; ++e) {
+    pos_buff[e] = invalid_slot_val;
+    count_buff[e] = 0;
+  }
+  for (size_t row = 0; row < n; ++row) {
+    int64_t key[HDK_HIP_MAX_JOIN_KEYS];
+    if (!composite_key_of_row(cols, ti, key_component_count, row, key)) continue;
+    const int64_t slot = keyed_slot_for_insert(hash_buff, entry_count, key, key_component_count,
+                                               key_component_width, entry_bytes);
+    if (slot < 0) return -2;
+    count_buff[slot]++;
+  }
+  int32_t running = 0;
+  for (int64_t e = 0; e < entry_count; ++e) { /* set_valid_pos over the exclusive scan of the counts */
+    if (count_buff[e]) {
+      pos_buff[e] = running;
+      running += count_buff[e];
+      count_buff[e] = 0;
+    }
+  }
+  for (size_t row = 0; row < n; ++row) {
+    int64_t key[HDK_HIP_MAX_JOIN_KEYS];
+    if (!composite_key_of_row(cols, ti, key_component_count, row, key)) continue;
+    const int64_t slot = keyed_slot_for_insert(hash_buff, entry_count, key, key_component_count,
+                                               key_component_width, entry_bytes);
+    id_buff[pos_buff[slot] + count_buff[slot]++] = (int32_t)row;
+  }
+  return 0;
+}
+
+/* ============================================================================================
  * The row function for a plan
  * ========================================================================================== */
 
@@ -1002,8 +1174,15 @@ static inline int64_t load_col(const orc_row_ctx* c, int32_t col_idx) {
 
 static inline int64_t load_leaf(const orc_row_ctx* c, const hdk_hip_leaf* l) {
   switch (l->kind) {
-    case HDK_LEAF_COL:
+    case HDK_LEAF_COL: {
+      /* LEFT join without a match: every column of the inner table is NULL
+       * (codegenOuterJoinNullPlaceholder, QE/ColumnIR.cpp) */
+      const int32_t tb = c->plan->cols[l->col].table;
+      if (tb > 0 && c->join_row[tb - 1] < 0) {
+        return l->null_val;
+      }
       return load_col(c, l->col);
+    }
     case HDK_LEAF_INT:
     case HDK_LEAF_FP:
       return l->ival;
@@ -1321,46 +1500,146 @@ static inline int64_t target_arg(const orc_row_ctx* c, const hdk_hip_target* tg,
   return v;
 }
 
-static int32_t run_row(orc_row_ctx* c, const int64_t* join_hash_tables, int64_t* out) {
-  const hdk_hip_plan* p = c->plan;
-  int32_t err = 0;
-  /* filter */
-  for (int q = 0; q < p->num_quals; ++q) {
-    if (eval_qual(c, &p->quals[q], &err) != 1) {
-      return err;
-    }
+/* ---- join probes -------------------------------------------------------------------------------
+ * The matching set of one join level for the current outer row (HashJoin::codegenMatchingSet,
+ * QE/JoinHashTable/HashJoin.cpp:149-197; BaselineJoinHashTable::codegenMatchingSet / codegenSlot,
+ * QE/JoinHashTable/BaselineJoinHashTable.cpp:769-811).  `*single` receives the row id of a
+ * one-to-one match; one-to-many sets are returned as a pointer into the table's row-id section. */
+static inline const void* join_table_ptr(const hdk_hip_plan* p, const hdk_hip_join* jn,
+                                         const int64_t* join_hash_tables) {
+  return (const void*)(intptr_t)(p->num_joins == 1 && jn->table_idx == 0 ? (int64_t)(intptr_t)join_hash_tables
+                                                                          : join_hash_tables[jn->table_idx]);
+}
+
+static int64_t perfect_probe(const hdk_hip_join* jn, const int32_t* table, int64_t key) {
+  if (jn->bucket > 1) {
+    return (jn->null_mode == HDK_JOIN_NULL_NONE || key != jn->null_val)
+               ? orc_bucketized_hash_join_idx(table, key, jn->min_key, jn->max_key, jn->bucket)
+               : (jn->null_mode == HDK_JOIN_NULL_BITWISE
+                      ? orc_bucketized_hash_join_idx(table, jn->translated_null, jn->min_key,
+                                                     jn->translated_null, jn->bucket)
+                      : -1);
   }
-  /* join probes */
-  for (int j = 0; j < p->num_joins; ++j) {
-    const hdk_hip_join* jn = &p->joins[j];
-    const int64_t key = eval_expr(c, &jn->outer_key, &err);
-    const int32_t* table =
-        (const int32_t*)(intptr_t)(p->num_joins == 1 && jn->table_idx == 0
-                                        ? (int64_t)(intptr_t)join_hash_tables
-                                        : join_hash_tables[jn->table_idx]);
-    int64_t idx;
-    if (jn->bucket > 1) {
-      idx = (jn->null_mode == HDK_JOIN_NULL_NONE || key != jn->null_val)
-                ? orc_bucketized_hash_join_idx(table, key, jn->min_key, jn->max_key, jn->bucket)
-                : (jn->null_mode == HDK_JOIN_NULL_BITWISE
-                       ? orc_bucketized_hash_join_idx(table, jn->translated_null, jn->min_key,
-                                                      jn->translated_null, jn->bucket)
-                       : -1);
-    } else if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) {
-      idx = orc_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val);
-    } else if (jn->null_mode == HDK_JOIN_NULL_BITWISE) {
-      idx = orc_hash_join_idx_bitwise(table, key, jn->min_key, jn->max_key, jn->null_val,
-                                      jn->translated_null);
-    } else {
-      idx = orc_hash_join_idx(table, key, jn->min_key, jn->max_key);
+  if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) {
+    return orc_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val);
+  }
+  if (jn->null_mode == HDK_JOIN_NULL_BITWISE) {
+    return orc_hash_join_idx_bitwise(table, key, jn->min_key, jn->max_key, jn->null_val, jn->translated_null);
+  }
+  return orc_hash_join_idx(table, key, jn->min_key, jn->max_key);
+}
+
+static int64_t matching_set(const orc_row_ctx* c, const hdk_hip_join* jn, const int64_t* join_hash_tables,
+                            const int32_t** ids, int64_t* single, int32_t* err) {
+  const hdk_hip_plan* p = c->plan;
+  const void* table = join_table_ptr(p, jn, join_hash_tables);
+  *ids = NULL;
+  *single = -1;
+  if (jn->kind == HDK_JOIN_KEYED_ONE_TO_ONE || jn->kind == HDK_JOIN_KEYED_ONE_TO_MANY) {
+    /* codegenKey: the outer-side components packed at the table's component width */
+    int64_t k64[HDK_HIP_MAX_JOIN_KEYS];
+    int32_t k32[HDK_HIP_MAX_JOIN_KEYS];
+    const int kc = jn->key_component_count;
+    for (int i = 0; i < kc; ++i) {
+      const int64_t v = eval_expr(c, i == 0 ? &jn->outer_key : &jn->extra_keys[i - 1], err);
+      k64[i] = v;
+      k32[i] = (int32_t)v;
     }
-    if (idx < 0) {
-      if (jn->type == HDK_JOIN_INNER) {
-        return err;
+    const int w = jn->key_component_width;
+    const void* key = w == 4 ? (const void*)k32 : (const void*)k64;
+    if (jn->kind == HDK_JOIN_KEYED_ONE_TO_ONE) {
+      const int64_t idx = w == 4 ? orc_baseline_hash_join_idx_32((const int8_t*)table, (const int8_t*)key,
+                                                                 (size_t)kc * 4, (size_t)jn->entry_count)
+                                 : orc_baseline_hash_join_idx_64((const int8_t*)table, (const int8_t*)key,
+                                                                 (size_t)kc * 8, (size_t)jn->entry_count);
+      *single = idx;
+      return idx >= 0 ? 1 : 0;
+    }
+    const int64_t slot = w == 4 ? orc_get_composite_key_index_32(k32, (size_t)kc, (const int32_t*)table,
+                                                                 (size_t)jn->entry_count)
+                                : orc_get_composite_key_index_64(k64, (size_t)kc, (const int64_t*)table,
+                                                                 (size_t)jn->entry_count);
+    if (slot < 0) {
+      return 0;
+    }
+    const int32_t* otm = (const int32_t*)((const int8_t*)table + (size_t)jn->entry_count * kc * w);
+    const int64_t pos = orc_hash_join_idx(otm, slot, 0, jn->entry_count - 1);
+    if (pos < 0) {
+      return 0;
+    }
+    *ids = otm + 2 * jn->entry_count + pos;
+    return orc_hash_join_idx(otm + jn->entry_count, slot, 0, jn->entry_count - 1);
+  }
+  const int64_t key = eval_expr(c, &jn->outer_key, err);
+  if (jn->kind == HDK_JOIN_ONE_TO_MANY) {
+    const int32_t* t = (const int32_t*)table;
+    const int64_t pos = perfect_probe(jn, t, key);
+    if (pos < 0) {
+      return 0;
+    }
+    *ids = t + 2 * jn->entry_count + pos;
+    return perfect_probe(jn, t + jn->entry_count, key);
+  }
+  const int64_t idx = perfect_probe(jn, (const int32_t*)table, key);
+  *single = idx;
+  return idx >= 0 ? 1 : 0;
+}
+
+/* The join loop nest of one outer row (Executor::buildJoinLoops, QE/IRCodegen.cpp:497-667):
+ * filters on the outer table first, then one loop level per join (Singleton or Set; a LEFT join
+ * without a match continues once with the inner row "not found" = -1, whose columns read as NULL),
+ * then the filters that read joined columns, then `body`. */
+typedef int32_t (*orc_row_body)(orc_row_ctx* c, void* arg, int32_t* err);
+
+static int32_t join_level(orc_row_ctx* c, const int64_t* join_hash_tables, int level, orc_row_body body,
+                          void* arg, int32_t* err) {
+  const hdk_hip_plan* p = c->plan;
+  if (level == p->num_joins) {
+    for (int q = 0; q < p->num_quals; ++q) {
+      if (p->quals[q].after_joins && eval_qual(c, &p->quals[q], err) != 1) {
+        return 0;
       }
     }
-    c->join_row[j] = idx;
+    return body(c, arg, err);
   }
+  const hdk_hip_join* jn = &p->joins[level];
+  const int32_t* ids;
+  int64_t single;
+  const int64_t n = matching_set(c, jn, join_hash_tables, &ids, &single, err);
+  if (n <= 0) {
+    if (jn->type != HDK_JOIN_LEFT) {
+      return 0;
+    }
+    c->join_row[level] = -1;
+    return join_level(c, join_hash_tables, level + 1, body, arg, err);
+  }
+  for (int64_t m = 0; m < n; ++m) {
+    c->join_row[level] = ids ? ids[m] : single;
+    const int32_t rc = join_level(c, join_hash_tables, level + 1, body, arg, err);
+    if (rc) {
+      return rc;
+    }
+  }
+  return 0;
+}
+
+/* returns HDK_HIP_ERR_OUT_OF_SLOTS / a projection's -pos when the scan must stop, else 0;
+ * `*err` collects the row's soft error (division by zero) */
+static int32_t drive_row(orc_row_ctx* c, const int64_t* join_hash_tables, orc_row_body body, void* arg,
+                         int32_t* err) {
+  const hdk_hip_plan* p = c->plan;
+  for (int q = 0; q < p->num_quals; ++q) {
+    if (!p->quals[q].after_joins && eval_qual(c, &p->quals[q], err) != 1) {
+      return 0;
+    }
+  }
+  return join_level(c, join_hash_tables, 0, body, arg, err);
+}
+
+static int32_t aggregate_row(orc_row_ctx* c, void* arg, int32_t* errp) {
+  const hdk_hip_plan* p = c->plan;
+  int64_t* out = (int64_t*)arg;
+  int32_t err = 0;
   /* group lookup */
   int8_t* row_base = NULL; /* row-wise: start of the entry's slots region base (row start) */
   uint32_t entry = 0;
@@ -1465,7 +1744,10 @@ static int32_t run_row(orc_row_ctx* c, const int64_t* join_hash_tables, int64_t*
     }
     apply_target(tg, s1, s2, v);
   }
-  return err;
+  if (err && !*errp) {
+    *errp = err;
+  }
+  return 0;
 }
 
 int32_t orc_run_plan_range(const hdk_hip_plan* plan, const int8_t* const* const* col_buffers,
@@ -1480,12 +1762,13 @@ int32_t orc_run_plan_range(const hdk_hip_plan* plan, const int8_t* const* const*
     const int64_t n = num_rows[f * num_tables];
     for (int64_t pos = 0; pos < n; ++pos) { /* query_group_by_template: pos_start=0, pos_step=1 */
       c.pos = pos;
-      const int32_t err = run_row(&c, join_hash_tables, out);
+      int32_t err = 0;
+      const int32_t rc = drive_row(&c, join_hash_tables, aggregate_row, out, &err);
+      if (rc) {
+        return rc; /* out of slots stops the scan */
+      }
       if (err && !first_err) {
         first_err = err; /* record_error_code: first error sticks (RuntimeFunctions.cpp:1123-1135) */
-        if (err == HDK_HIP_ERR_OUT_OF_SLOTS) {
-          return err;
-        }
       }
     }
   }
@@ -1505,6 +1788,41 @@ int32_t orc_run_plan(const hdk_hip_plan* plan, const int8_t* const* const* col_b
  * (QE/GroupByRuntime.cpp:248-272) writes the row position and returns the slot base; targets are
  * stored with agg_id.  Rows beyond max_matched report "out of slots" as -pos.
  * ========================================================================================== */
+typedef struct {
+  int64_t* out;
+  int32_t max_matched;
+  int32_t* total_matched;
+  int32_t slots_err;
+} orc_proj_arg;
+
+static int32_t project_row(orc_row_ctx* c, void* arg, int32_t* err) {
+  const hdk_hip_plan* p = c->plan;
+  orc_proj_arg* a = (orc_proj_arg*)arg;
+  int64_t* out = a->out;
+  const uint32_t slot = (uint32_t)(*a->total_matched)++;
+  if (slot >= (uint32_t)a->max_matched) {
+    if (!a->slots_err) a->slots_err = -(int32_t)c->pos; /* out of slots: -pos (RowFuncBuilder.cpp:268-273) */
+    return 0;
+  }
+  int8_t* row_base = NULL;
+  if (p->output_columnar) {
+    out[slot] = c->pos; /* get_columnar_scan_output_offset */
+  } else {
+    int64_t* rp = out + (size_t)slot * p->row_size_quad; /* get_scan_output_slot */
+    rp[0] = c->pos;
+    row_base = (int8_t*)rp;
+  }
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target* tg = &p->targets[t];
+    int64_t v = eval_expr(c, &tg->arg, err);
+    int8_t* s1 = p->output_columnar
+                     ? (int8_t*)out + columnar_slot_off(p, p->entry_count, t) + (size_t)slot * tg->slot_width
+                     : row_base + tg->slot_off;
+    apply_target(tg, s1, NULL, v);
+  }
+  return 0;
+}
+
 int32_t orc_run_projection(const hdk_hip_plan* plan, const int8_t* const* const* col_buffers,
                            uint64_t num_fragments, const int64_t* num_rows, uint32_t num_tables,
                            const int64_t* join_hash_tables, int64_t* out, int32_t max_matched,
@@ -1513,55 +1831,15 @@ int32_t orc_run_projection(const hdk_hip_plan* plan, const int8_t* const* const*
   orc_row_ctx c;
   memset(&c, 0, sizeof(c));
   c.plan = plan;
-  const hdk_hip_plan* p = plan;
+  orc_proj_arg a = {out, max_matched, total_matched, 0};
   for (uint64_t f = 0; f < num_fragments; ++f) {
     c.cols = col_buffers[f];
     const int64_t n = num_rows[f * num_tables];
     for (int64_t pos = 0; pos < n; ++pos) {
       c.pos = pos;
       int32_t err = 0;
-      int passes = 1;
-      for (int q = 0; q < p->num_quals && passes; ++q) {
-        if (eval_qual(&c, &p->quals[q], &err) != 1) passes = 0;
-      }
-      for (int j = 0; j < p->num_joins && passes; ++j) {
-        const hdk_hip_join* jn = &p->joins[j];
-        const int64_t key = eval_expr(&c, &jn->outer_key, &err);
-        const int32_t* table = (const int32_t*)(intptr_t)(p->num_joins == 1 && jn->table_idx == 0
-                                                              ? (int64_t)(intptr_t)join_hash_tables
-                                                              : join_hash_tables[jn->table_idx]);
-        int64_t idx;
-        if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) idx = orc_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val);
-        else if (jn->null_mode == HDK_JOIN_NULL_BITWISE) idx = orc_hash_join_idx_bitwise(table, key, jn->min_key, jn->max_key, jn->null_val, jn->translated_null);
-        else idx = orc_hash_join_idx(table, key, jn->min_key, jn->max_key);
-        if (idx < 0 && jn->type == HDK_JOIN_INNER) passes = 0;
-        c.join_row[j] = idx;
-      }
-      if (!passes) {
-        if (err && !first_err) first_err = err;
-        continue;
-      }
-      const uint32_t slot = (uint32_t)(*total_matched)++;
-      if (slot >= (uint32_t)max_matched) {
-        if (!first_err) first_err = -(int32_t)pos; /* out of slots: -pos (RowFuncBuilder.cpp:268-273) */
-        continue;
-      }
-      int8_t* row_base = NULL;
-      if (p->output_columnar) {
-        out[slot] = pos; /* get_columnar_scan_output_offset */
-      } else {
-        int64_t* rp = out + (size_t)slot * p->row_size_quad; /* get_scan_output_slot */
-        rp[0] = pos;
-        row_base = (int8_t*)rp;
-      }
-      for (int t = 0; t < p->num_targets; ++t) {
-        const hdk_hip_target* tg = &p->targets[t];
-        int64_t v = eval_expr(&c, &tg->arg, &err);
-        int8_t* s1 = p->output_columnar
-                         ? (int8_t*)out + columnar_slot_off(p, p->entry_count, t) + (size_t)slot * tg->slot_width
-                         : row_base + tg->slot_off;
-        apply_target(tg, s1, NULL, v);
-      }
+      drive_row(&c, join_hash_tables, project_row, &a, &err);
+      if (a.slots_err && !first_err) first_err = a.slots_err;
       if (err && !first_err) first_err = err;
     }
   }

@@ -127,6 +127,26 @@ void orc_fill_one_to_many_hash_table(int32_t* buff, int64_t hash_entry_count,
                                      size_t num_chunks, const hdk_hip_join_column_type_info* type_info,
                                      int64_t bucket_normalization);
 
+/* keyed ("baseline") join tables: JoinHashTableQueryRuntime.cpp:25-172, HashJoinRuntime.cpp:296-573,723-950 */
+int64_t orc_baseline_hash_join_idx_32(const int8_t* hash_buff, const int8_t* key, size_t key_bytes,
+                                      size_t entry_count);
+int64_t orc_baseline_hash_join_idx_64(const int8_t* hash_buff, const int8_t* key, size_t key_bytes,
+                                      size_t entry_count);
+int64_t orc_get_composite_key_index_32(const int32_t* key, size_t key_component_count,
+                                       const int32_t* composite_key_dict, size_t entry_count);
+int64_t orc_get_composite_key_index_64(const int64_t* key, size_t key_component_count,
+                                       const int64_t* composite_key_dict, size_t entry_count);
+void orc_init_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, size_t key_component_count,
+                                      int32_t key_component_width, int32_t with_val_slot,
+                                      int32_t invalid_slot_val);
+int orc_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                     size_t key_component_count, int32_t key_component_width,
+                                     const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti);
+int orc_fill_one_to_many_baseline_hash_table(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                             size_t key_component_count, int32_t key_component_width,
+                                             const hdk_hip_join_column* cols,
+                                             const hdk_hip_join_column_type_info* ti);
+
 /* output buffer init: QE/GpuInitGroups.cu:17-166 (the CPU twin is
  * QE/QueryMemoryInitializer.cpp initGroupByBuffer/initColumnarGroups). */
 void orc_init_group_by_buffer(int64_t* groups_buffer, const int64_t* init_vals,

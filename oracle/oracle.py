@@ -52,6 +52,13 @@ def lib():
     _sig(L, "orc_murmur_hash1", C.c_uint32, v, C.c_int, C.c_uint32)
     _sig(L, "orc_murmur_hash64a", C.c_uint64, v, C.c_int, C.c_uint64)
     _sig(L, "orc_key_hash", C.c_uint32, v, C.c_uint32, C.c_uint32)
+    _sig(L, "orc_baseline_hash_join_idx_32", C.c_int64, v, v, C.c_size_t, C.c_size_t)
+    _sig(L, "orc_baseline_hash_join_idx_64", C.c_int64, v, v, C.c_size_t, C.c_size_t)
+    _sig(L, "orc_get_composite_key_index_32", C.c_int64, v, C.c_size_t, v, C.c_size_t)
+    _sig(L, "orc_get_composite_key_index_64", C.c_int64, v, C.c_size_t, v, C.c_size_t)
+    _sig(L, "orc_init_baseline_hash_join_buff", None, v, C.c_int64, C.c_size_t, C.c_int32, C.c_int32, C.c_int32)
+    _sig(L, "orc_fill_baseline_hash_join_buff", C.c_int, v, C.c_int64, C.c_int32, C.c_size_t, C.c_int32, v, v)
+    _sig(L, "orc_fill_one_to_many_baseline_hash_table", C.c_int, v, C.c_int64, C.c_int32, C.c_size_t, C.c_int32, v, v)
     _sig(L, "orc_fixed_width_int_decode", C.c_int64, v, C.c_int32, C.c_int64)
     _sig(L, "orc_fixed_width_unsigned_decode", C.c_int64, v, C.c_int32, C.c_int64)
     _sig(L, "orc_get_group_value", v, v, C.c_uint32, v, C.c_uint32, C.c_uint32, C.c_uint32)
@@ -175,6 +182,8 @@ def ref():
     _sig(R, "hash_join_idx_bitwise", C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
          C.c_int64)
     _sig(R, "translate_null_key_int64_t", C.c_int64, C.c_int64, C.c_int64, C.c_int64)
+    _sig(R, "baseline_hash_join_idx_32", C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
+    _sig(R, "baseline_hash_join_idx_64", C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
     _ref = R
     return R
 

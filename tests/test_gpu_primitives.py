@@ -169,3 +169,73 @@ def test_device_reduce_perfect_hash(mgr, oracle):
         cp2, full, err = run_oracle(oracle, st, cp)
         from util import assert_buffers_equal
         assert_buffers_equal(cp, got, full)
+
+
+@pytest.mark.parametrize("width", [4, 8])
+def test_keyed_join_build_on_device(mgr, oracle, width):
+    """hdk_hip_{init,fill}_baseline_hash_join_buff / fill_one_to_many_baseline_hash_table: the decoded table
+    ({key tuple: row ids}, JoinHashTableTest's toSet()) equals the oracle's; the reference KATs
+    (Tests/JoinHashTableTest.cpp:355-440) and a larger random case with duplicates and NULLs."""
+    from test_oracle_golden import decode_keyed
+    L = lib()
+    dt = np.int32 if width == 4 else np.int64
+    rng = np.random.default_rng(width)
+    big_a = rng.integers(0, 3000, 50_000).astype(dt)
+    big_b = rng.integers(-20, 20, 50_000).astype(dt)
+    big_a[rng.random(50_000) < 0.01] = np.iinfo(dt).min
+    uniq = rng.permutation(200_000)[:60_000].astype(dt)
+    cases = [([np.array([0, 1, 3], dtype=dt)] * 2, True), ([np.array([0, 1, 3, 3], dtype=dt)] * 2, False),
+             ([big_a, big_b], False), ([uniq, (uniq % 7).astype(dt), (uniq // 3).astype(dt)], True)]
+    for cols, unique in cases:
+        kc, n = len(cols), len(cols[0])
+        entries = 2 * n
+        parts = [[c[: n // 3], c[n // 3:]] for c in cols]
+        jcs, tis, keep = (A.JoinColumn * kc)(), (A.JoinColumnTypeInfo * kc)(), []
+        ojcs, otis, okeep = (A.JoinColumn * kc)(), (A.JoinColumnTypeInfo * kc)(), []
+        for k in range(kc):
+            jc, kp = _device_join_column(mgr, parts[k], width)
+            keep.append(kp)
+            jcs[k] = jc
+            tis[k] = A.JoinColumnTypeInfo(width, int(cols[k].min()), int(cols[k].max()), int(np.iinfo(dt).min), 0, A.JC_SIGNED, 0)
+            chunks = oracle.make_join_chunks(parts[k])
+            okeep.append(chunks)
+            ojcs[k] = A.JoinColumn(C.cast(chunks, C.c_void_p).value, C.sizeof(chunks), 2, n, width)
+            otis[k] = tis[k]
+        d_err = mgr.to_device(np.zeros(1, dtype=np.int32), 0)
+        one_bytes = entries * (kc + 1) * width
+        t1 = mgr.alloc(one_bytes, 0)
+        check(L.hdk_hip_init_baseline_hash_join_buff(t1.ptr, entries, kc, width, 1, -1, 0, None))
+        check(L.hdk_hip_fill_baseline_hash_join_buff(t1.ptr, entries, -1, 0, kc, width, 1, d_err.ptr, jcs, tis, 0, None))
+        mgr.synchronizeStream(0)
+        err = int(mgr.to_host(d_err.ptr, 4, 0, np.int32)[0])
+        want1 = np.empty(one_bytes, dtype=np.uint8)
+        oracle.lib().orc_init_baseline_hash_join_buff(want1.ctypes.data, entries, kc, width, 1, -1)
+        rc = oracle.lib().orc_fill_baseline_hash_join_buff(want1.ctypes.data, entries, -1, kc, width, ojcs, otis)
+        assert (err == 0) == unique == (rc == 0), (err, rc)
+        if unique:
+            assert decode_keyed(mgr.to_host(t1.ptr, one_bytes, 0, np.uint8), entries, kc, width, True, n) == \
+                decode_keyed(want1, entries, kc, width, True, n)
+        dict_bytes = entries * kc * width
+        many_bytes = dict_bytes + (2 * entries + n) * 4
+        t2 = mgr.alloc(many_bytes, 0)
+        check(mgr_zero(mgr, d_err))
+        check(L.hdk_hip_init_baseline_hash_join_buff(t2.ptr, entries, kc, width, 0, -1, 0, None))
+        check(L.hdk_hip_fill_baseline_hash_join_buff(t2.ptr, entries, -1, 0, kc, width, 0, d_err.ptr, jcs, tis, 0, None))
+        check(L.hdk_hip_fill_one_to_many_baseline_hash_table(t2.ptr + dict_bytes, t2.ptr, entries, -1, kc, width, jcs, tis,
+                                                             0, None))
+        mgr.synchronizeStream(0)
+        assert int(mgr.to_host(d_err.ptr, 4, 0, np.int32)[0]) == 0
+        want2 = np.empty(many_bytes, dtype=np.uint8)
+        oracle.lib().orc_init_baseline_hash_join_buff(want2.ctypes.data, entries, kc, width, 0, -1)
+        assert oracle.lib().orc_fill_one_to_many_baseline_hash_table(want2.ctypes.data, entries, -1, kc, width, ojcs, otis) == 0
+        got = decode_keyed(mgr.to_host(t2.ptr, many_bytes, 0, np.uint8), entries, kc, width, False, n)
+        assert got == decode_keyed(want2, entries, kc, width, False, n)
+        if n <= 4:
+            assert got == ({(0, 0): [0], (1, 1): [1], (3, 3): [2]} if unique else {(0, 0): [0], (1, 1): [1], (3, 3): [2, 3]})
+        for b in (t1, t2, d_err):
+            b.free()
+
+
+def mgr_zero(mgr, buf):
+    mgr.zeroDeviceMem(buf.ptr, 4, 0)
+    return 0

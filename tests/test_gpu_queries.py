@@ -65,11 +65,12 @@ def test_join_with_misses_and_nulls(oracle, gpu_executor_factory):
     _run(oracle, gpu_executor_factory, st, q)
 
 
-def test_duplicate_dim_keys_need_cpu(oracle, gpu_executor_factory):
-    from hdk_amd.ir import QueryMustRunOnCpu
+def test_duplicate_dim_keys_take_the_one_to_many_table(oracle, gpu_executor_factory):
     st = ArrowStorage()
     st.import_numpy("dim", {"key": np.array([0, 1, 2, 0], dtype=np.int64), "d": np.arange(4, dtype=np.int64)})
     st.import_numpy("fact", {"fk": np.array([0, 1, 2], dtype=np.int64)})
-    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=[Agg("sum", ColRef("d", "dim"))])
-    with pytest.raises(QueryMustRunOnCpu):
-        gpu_executor_factory(st).execute(q)
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=[Agg("sum", ColRef("d", "dim"), "s")])
+    ex = gpu_executor_factory(st)
+    cp = ex.compile(q)
+    assert cp.join_infos[0]["kind"] == A.JOIN_ONE_TO_MANY  # NeedsOneToManyHash (PerfectHashTableBuilder.h:134-141)
+    assert ex.execute(cp).to_columns()["s"] == [0 + 3 + 1 + 2]

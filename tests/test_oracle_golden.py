@@ -227,6 +227,62 @@ def test_join_build_one_to_many_kats(oracle):
     assert _build_one_to_many(oracle, [0, 2, 3, 4, 0, 2, 3, 4]) == {0: [0, 4], 2: [1, 5], 3: [2, 6], 4: [3, 7]}
 
 
+# ---- Tests/JoinHashTableTest.cpp:355-440 (Build.KeyedOneToOne / Build.KeyedOneToMany) -----------------
+def decode_keyed(buff, entries, kc, width, one_to_one, num_rows):
+    """HashTable::toSet for a keyed table: {key tuple: sorted row ids}."""
+    dt = np.int32 if width == 4 else np.int64
+    empty = np.iinfo(dt).max
+    comps = kc + (1 if one_to_one else 0)
+    d = buff[:entries * comps * width].view(dt).reshape(entries, comps)
+    out = {}
+    if one_to_one:
+        for e in range(entries):
+            if d[e, 0] != empty:
+                out[tuple(int(x) for x in d[e, :kc])] = [int(d[e, kc])]
+        return out
+    otm = buff[entries * comps * width:].view(np.int32)
+    pos, cnt, ids = otm[:entries], otm[entries:2 * entries], otm[2 * entries:2 * entries + num_rows]
+    for e in range(entries):
+        if d[e, 0] != empty:
+            out[tuple(int(x) for x in d[e, :kc])] = sorted(int(x) for x in ids[pos[e]:pos[e] + cnt[e]])
+    return out
+
+
+def keyed_columns(O, arrays, width):
+    kc = len(arrays)
+    jcs, tis, keep = (A.JoinColumn * kc)(), (A.JoinColumnTypeInfo * kc)(), []
+    for k, a in enumerate(arrays):
+        chunks = O.make_join_chunks([a])
+        keep.append(chunks)
+        jcs[k] = A.JoinColumn(C.cast(chunks, C.c_void_p).value, C.sizeof(chunks), 1, len(a), a.dtype.itemsize)
+        tis[k] = A.JoinColumnTypeInfo(a.dtype.itemsize, int(a.min()), int(a.max()),
+                                      int(np.iinfo(a.dtype).min), 0, A.JC_SIGNED, 0)
+    return jcs, tis, keep
+
+
+def test_join_build_keyed_kats(oracle):
+    L = oracle.lib()
+    # KeyedOneToOne: table2.b = 0,1,3 joined on (b, b): "| keyed one-to-one | keys * (1,1,1) (3,3,2) (0,0,0) * * |"
+    b = np.array([0, 1, 3], dtype=np.int32)
+    entries = 2 * len(b)
+    jcs, tis, keep = keyed_columns(oracle, [b, b], 4)
+    buff = np.empty(entries * 3 * 4, dtype=np.uint8)
+    L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, 2, 4, 1, -1)
+    assert L.orc_fill_baseline_hash_join_buff(buff.ctypes.data, entries, -1, 2, 4, jcs, tis) == 0
+    assert decode_keyed(buff, entries, 2, 4, True, 3) == {(0, 0): [0], (1, 1): [1], (3, 3): [2]}
+    # KeyedOneToMany: b = 0,1,3,3: "keys (1,1) (3,3) (0,0) | offsets 0 1 3 | counts 1 2 1 | payloads 1 2 3 0"
+    b = np.array([0, 1, 3, 3], dtype=np.int32)
+    entries = 2 * len(b)
+    jcs, tis, keep = keyed_columns(oracle, [b, b], 4)
+    buff = np.empty(entries * 3 * 4, dtype=np.uint8)
+    L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, 2, 4, 1, -1)
+    assert L.orc_fill_baseline_hash_join_buff(buff.ctypes.data, entries, -1, 2, 4, jcs, tis) == -1  # duplicate
+    buff = np.empty(entries * 2 * 4 + (2 * entries + 4) * 4, dtype=np.uint8)
+    L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, 2, 4, 0, -1)
+    assert L.orc_fill_one_to_many_baseline_hash_table(buff.ctypes.data, entries, -1, 2, 4, jcs, tis) == 0
+    assert decode_keyed(buff, entries, 2, 4, False, 4) == {(0, 0): [0], (1, 1): [1], (3, 3): [2, 3]}
+
+
 # ---- Tests/NoCatalogRelAlgTest.cpp:211-232 ----------------------------------------------------------------
 def test_nocatalog_group_by_single_column(oracle):
     import pyarrow as pa

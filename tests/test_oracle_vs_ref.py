@@ -125,3 +125,37 @@ def test_join_probe_random(oracle, ref):
         assert L.orc_hash_join_idx(table.ctypes.data, k, 3, 42) == ref.hash_join_idx(table.ctypes.data, k, 3, 42)
         assert L.orc_hash_join_idx_nullable(table.ctypes.data, k, 3, 42, 7) == \
             ref.hash_join_idx_nullable(table.ctypes.data, k, 3, 42, 7)
+
+
+@pytest.mark.parametrize("width,kc", [(8, 1), (8, 2), (4, 2), (4, 3)])
+def test_keyed_join_probe_vs_reference(oracle, ref, width, kc):
+    """The oracle's keyed ("baseline") table build, probed by the REFERENCE's baseline_hash_join_idx_{32,64}
+    (JoinHashTableQueryRuntime.cpp:42-98): every inserted key must come back with its row id, missing
+    keys with a negative code -- pins the oracle's MurmurHash1 slot choice, entry layout and probe."""
+    import ctypes as C
+    from hdk_amd import _abi as A
+    L = oracle.lib()
+    rng = np.random.default_rng(width * 10 + kc)
+    n, entries = 400, 1021
+    dt = np.int32 if width == 4 else np.int64
+    cols = [rng.permutation(5000)[:n].astype(dt) - 2000 for _ in range(kc)]  # unique per column => unique tuples
+    chunks_keep, jcs, tis = [], (A.JoinColumn * kc)(), (A.JoinColumnTypeInfo * kc)()
+    for k, c in enumerate(cols):
+        parts = [c[:150], c[150:]]
+        chunks = oracle.make_join_chunks(parts)
+        chunks_keep.append((parts, chunks))
+        jcs[k] = A.JoinColumn(C.cast(chunks, C.c_void_p).value, C.sizeof(chunks), 2, n, width)
+        tis[k] = A.JoinColumnTypeInfo(width, int(c.min()), int(c.max()), int(np.iinfo(dt).min), 0, A.JC_SIGNED, 0)
+    buff = np.empty(entries * (kc + 1) * width, dtype=np.uint8)
+    L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, kc, width, 1, -1)
+    assert L.orc_fill_baseline_hash_join_buff(buff.ctypes.data, entries, -1, kc, width, jcs, tis) == 0
+    ref_probe = ref.baseline_hash_join_idx_32 if width == 4 else ref.baseline_hash_join_idx_64
+    orc_probe = L.orc_baseline_hash_join_idx_32 if width == 4 else L.orc_baseline_hash_join_idx_64
+    for i in range(n):
+        key = np.array([c[i] for c in cols], dtype=dt)
+        assert ref_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries) == i
+        assert orc_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries) == i
+    for _ in range(300):
+        key = rng.integers(3000, 9000, kc).astype(dt)
+        r = ref_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries)
+        assert r < 0 and orc_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries) == r

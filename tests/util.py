@@ -31,20 +31,55 @@ def host_fragments(O, storage, cp, frag_ids=None):
 
 
 def oracle_join_tables(O, storage, cp):
-    """Build the perfect one-to-one join tables with the oracle's restatement of the CPU build."""
+    """Build the join tables of a plan with the oracle's restatement of the CPU builders: perfect
+    one-to-one / one-to-many (HashJoinRuntime.cpp:197-293,770-853) or keyed (:357-573,723-950)."""
     import ctypes as C
+    L = O.lib()
     tables = []
-    for info in cp.join_infos:
+    for ji, info in enumerate(cp.join_infos):
         inner = storage.get(info["inner_table"])
-        entries = info["max"] - info["min"] + 1
-        buff = np.empty(entries, dtype=np.int32)
-        O.lib().orc_init_hash_join_buff(buff.ctypes.data, entries, -1)
-        frs = inner.columns[info["inner_col"]].fragments
-        chunks = O.make_join_chunks(frs)
-        ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], 0, A.JC_SIGNED, 0)
-        rc = O.lib().orc_fill_hash_join_buff(buff.ctypes.data, -1, 0, C.cast(chunks, C.c_void_p), len(frs),
-                                             C.byref(ti), 1)
-        assert rc == 0
+        kind = info["kind"]
+        cols = info["inner_cols"]
+        if kind in (A.JOIN_ONE_TO_ONE, A.JOIN_ONE_TO_MANY):
+            entries = info["max"] - info["min"] + 1
+            frs = inner.columns[cols[0]].fragments
+            chunks = O.make_join_chunks(frs)
+            ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], 0, A.JC_SIGNED, 0)
+            if kind == A.JOIN_ONE_TO_ONE:
+                buff = np.empty(entries, dtype=np.int32)
+                L.orc_init_hash_join_buff(buff.ctypes.data, entries, -1)
+                rc = L.orc_fill_hash_join_buff(buff.ctypes.data, -1, 0, C.cast(chunks, C.c_void_p), len(frs),
+                                               C.byref(ti), 1)
+                assert rc == 0
+            else:
+                buff = np.empty(2 * entries + inner.num_rows, dtype=np.int32)
+                L.orc_init_hash_join_buff(buff.ctypes.data, buff.size, -1)
+                L.orc_fill_one_to_many_hash_table(buff.ctypes.data, entries, -1, C.cast(chunks, C.c_void_p), len(frs),
+                                                  C.byref(ti), 1)
+            tables.append(buff)
+            continue
+        kc, w, entries = len(cols), info["key_width"], info["entry_count"]
+        keep = []
+        jcs = (A.JoinColumn * kc)()
+        tis = (A.JoinColumnTypeInfo * kc)()
+        for k, c in enumerate(cols):
+            frs = inner.columns[c].fragments
+            chunks = O.make_join_chunks(frs)
+            keep.append(chunks)
+            jcs[k] = A.JoinColumn(C.cast(chunks, C.c_void_p).value, C.sizeof(chunks), len(frs), inner.num_rows,
+                                  info["elem_szs"][k])
+            tis[k] = A.JoinColumnTypeInfo(info["elem_szs"][k], info["mins"][k], info["maxs"][k], info["null_vals"][k],
+                                          0, A.JC_SIGNED, 0)
+        if kind == A.JOIN_KEYED_ONE_TO_ONE:
+            buff = np.empty(entries * (kc + 1) * w, dtype=np.uint8)
+            L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, kc, w, 1, -1)
+            rc = L.orc_fill_baseline_hash_join_buff(buff.ctypes.data, entries, -1, kc, w, jcs, tis)
+            assert rc == 0, rc
+        else:
+            buff = np.empty(entries * kc * w + (2 * entries + inner.num_rows) * 4, dtype=np.uint8)
+            L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, kc, w, 0, -1)
+            rc = L.orc_fill_one_to_many_baseline_hash_table(buff.ctypes.data, entries, -1, kc, w, jcs, tis)
+            assert rc == 0, rc
         tables.append(buff)
     return tables
 
