@@ -81,13 +81,23 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
     K* k0 = columnar ? reinterpret_cast<K*>(buf) + probe
                      : reinterpret_cast<K*>(buf + static_cast<size_t>(probe) * p->row_size_quad);
     const size_t kstride = columnar ? entry_count : 1;
+    // Look before claiming: a plain load is several times cheaper than an atomic on this part
+    // (scripts/microbench/atomics.hip: ~2.4e10 atomics/s chip-wide vs >5e10 random loads/s), and once
+    // a group exists every later row of it only needs the load.  A slot never returns to EMPTY.
     K old;
     if constexpr (sizeof(K) == 8) {
-      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(k0), static_cast<unsigned long long>(ek),
-                                     static_cast<unsigned long long>(key[0])));
+      old = static_cast<K>(atomic_load_i64(reinterpret_cast<const int64_t*>(k0)));
     } else {
-      old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(k0), static_cast<unsigned int>(ek),
-                                     static_cast<unsigned int>(key[0])));
+      old = static_cast<K>(atomic_load_i32(reinterpret_cast<const int32_t*>(k0)));
+    }
+    if (old == ek) {
+      if constexpr (sizeof(K) == 8) {
+        old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(k0), static_cast<unsigned long long>(ek),
+                                       static_cast<unsigned long long>(key[0])));
+      } else {
+        old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(k0), static_cast<unsigned int>(ek),
+                                       static_cast<unsigned int>(key[0])));
+      }
     }
     const bool won = old == ek;
     if (won) {

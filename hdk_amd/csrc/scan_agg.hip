@@ -505,10 +505,23 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     s.lds_bytes = 0;
     s.slab_words = 0;
   }
-  if (!(ko && ko->grid_dim_x) && plan_matches_direct(p, s)) {
-    // measured on C2 (1e9 rows): 512 blocks 2.60 ms, 1024 blocks 2.71 ms -- the streaming kernel wants
-    // 2 blocks per CU (fewer slabs to fold, same bytes in flight: 8 x 16 B per lane)
-    s.grid = 2u * static_cast<uint32_t>(props->num_cu);
+  FastArgs fa;
+  int kw = 0, vw = 0;
+  if (!(ko && ko->grid_dim_x) && match_fast(p, s, &fa, &kw, &vw)) {
+    // Blocks per CU of the streaming kernel, measured at 256 M rows (grid sweep 256..2048 blocks):
+    //   16 B/row, one LDS atomic per row (C2), or no key (C1): 2 per CU is best (C2 @1e9 rows: 512
+    //     blocks 2.60 ms, 1024 blocks 2.71 ms -- fewer slabs to fold, same bytes in flight);
+    //   narrow rows carry more LDS atomics per byte streamed and want more waves to hide them:
+    //     COUNT(*) by a 4-byte key (taxi Q1) 4 per CU (4.4 -> 5.6 TB/s), 2-byte key + AVG (taxi Q2,
+    //     three atomics per 10 B) 8 per CU (2.1 -> 3.4 TB/s).
+    const uint32_t cu = static_cast<uint32_t>(props->num_cu);
+    if (kw == 0 || kw + vw >= 16) {
+      s.grid = 2u * cu;
+    } else if (vw == 0) {
+      s.grid = 4u * cu;
+    } else {
+      s.grid = 8u * cu;
+    }
   }
   return s;
 }

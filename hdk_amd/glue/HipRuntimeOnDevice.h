@@ -100,4 +100,56 @@ inline void fill_one_to_many_hash_table_on_device(int32_t* buff, const RefHashEn
                                             device_id, nullptr));
 }
 
+// ---- keyed ("baseline") join tables: *_on_device_{32,64} of HashJoinRuntime.h:181-204,225-281 ----------
+// The reference passes a device-resident GenericKeyHandler; the ABI takes its two arrays on the host
+// (join_column_per_key / type_info_per_key, HashJoinKeyHandlers.h:36-50), so the HDK-side builder
+// (BaselineJoinHashTableBuilder::initHashTableOnGpu) forwards the vectors it already owns.
+template <int W>  // key component width in bytes: 4 -> *_32, 8 -> *_64
+inline void init_baseline_hash_join_buff_on_device(int8_t* hash_join_buff, const int64_t entry_count,
+                                                   const size_t key_component_count, const bool with_val_slot,
+                                                   const int32_t invalid_slot_val, const int device_id) {
+  check(hdk_hip_init_baseline_hash_join_buff(hash_join_buff, entry_count, key_component_count, W, with_val_slot,
+                                             invalid_slot_val, device_id, nullptr));
+}
+
+template <int W, class RefJoinColumn, class RefTypeInfo>
+inline void fill_baseline_hash_join_buff_on_device(int8_t* hash_buff, const int64_t entry_count,
+                                                   const int32_t invalid_slot_val, const bool for_semi_join,
+                                                   const size_t key_component_count, const bool with_val_slot,
+                                                   int* dev_err_buff, const RefJoinColumn* join_column_per_key,
+                                                   const RefTypeInfo* type_info_per_key, const int device_id) {
+  hdk_hip_join_column cols[HDK_HIP_MAX_JOIN_KEYS];
+  hdk_hip_join_column_type_info tis[HDK_HIP_MAX_JOIN_KEYS];
+  if (key_component_count > HDK_HIP_MAX_JOIN_KEYS) {
+    throw std::runtime_error("hdk_hip: more key components than the fixed kernel library takes");
+  }
+  for (size_t k = 0; k < key_component_count; ++k) {
+    cols[k] = to_abi_column(join_column_per_key[k]);
+    tis[k] = to_abi(type_info_per_key[k]);
+  }
+  check(hdk_hip_fill_baseline_hash_join_buff(hash_buff, entry_count, invalid_slot_val, for_semi_join,
+                                             key_component_count, W, with_val_slot, dev_err_buff, cols, tis, device_id,
+                                             nullptr));
+}
+
+template <int W, class RefJoinColumn, class RefTypeInfo>
+inline void fill_one_to_many_baseline_hash_table_on_device(int32_t* buff, const int8_t* composite_key_dict,
+                                                           const int64_t hash_entry_count,
+                                                           const int32_t invalid_slot_val,
+                                                           const size_t key_component_count,
+                                                           const RefJoinColumn* join_column_per_key,
+                                                           const RefTypeInfo* type_info_per_key, const int device_id) {
+  hdk_hip_join_column cols[HDK_HIP_MAX_JOIN_KEYS];
+  hdk_hip_join_column_type_info tis[HDK_HIP_MAX_JOIN_KEYS];
+  if (key_component_count > HDK_HIP_MAX_JOIN_KEYS) {
+    throw std::runtime_error("hdk_hip: more key components than the fixed kernel library takes");
+  }
+  for (size_t k = 0; k < key_component_count; ++k) {
+    cols[k] = to_abi_column(join_column_per_key[k]);
+    tis[k] = to_abi(type_info_per_key[k]);
+  }
+  check(hdk_hip_fill_one_to_many_baseline_hash_table(buff, composite_key_dict, hash_entry_count, invalid_slot_val,
+                                                     key_component_count, W, cols, tis, device_id, nullptr));
+}
+
 }  // namespace hip_rt

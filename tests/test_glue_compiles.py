@@ -24,3 +24,32 @@ def test_public_header_is_plain_c(tmp_path):
     src.write_text('#include "hdk_hip.h"\nint main(void) { return sizeof(hdk_hip_plan) > 0 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-pedantic", "-I",
                            os.path.join(ROOT, "include"), str(src)])
+
+
+def test_join_build_forwards_instantiate(tmp_path):
+    """The templated *_on_device forwards instantiate with structs that carry the reference's member
+    names (JoinColumn / JoinColumnTypeInfo / HashEntryInfo, HashJoinRuntime.h:43-57,100-124).  The real
+    header pulls in Logger.h -> Boost, absent here, so the test declares same-shaped structs itself:
+    this checks the templates, not the reference's layout."""
+    src = tmp_path / "fwd_check.cpp"
+    src.write_text('''
+#include <cstddef>
+#include <cstdint>
+enum ColumnType { SmallDate = 0, Signed = 1, Unsigned = 2, Double = 3 };
+struct JoinColumn { const int8_t* col_chunks_buff; size_t col_chunks_buff_sz; size_t num_chunks; size_t num_elems; size_t elem_sz; };
+struct JoinColumnTypeInfo { size_t elem_sz; int64_t min_val; int64_t max_val; int64_t null_val; bool uses_bw_eq;
+                            int64_t translated_null_val; ColumnType column_type; };
+struct HashEntryInfo { size_t hash_entry_count; int64_t bucket_normalization; };
+#include "HipRuntimeOnDevice.h"
+void f(int8_t* b, int32_t* otm, int* err, const JoinColumn* jc, const JoinColumnTypeInfo* ti, HashEntryInfo hei) {
+  hip_rt::init_hash_join_buff_on_device(otm, 10, -1, 0);
+  hip_rt::fill_hash_join_buff_on_device(otm, -1, false, err, jc[0], ti[0], 0);
+  hip_rt::fill_hash_join_buff_on_device_bucketized(otm, -1, false, err, jc[0], ti[0], 4, 0);
+  hip_rt::fill_one_to_many_hash_table_on_device(otm, hei, -1, jc[0], ti[0], 0);
+  hip_rt::init_baseline_hash_join_buff_on_device<8>(b, 100, 2, true, -1, 0);
+  hip_rt::fill_baseline_hash_join_buff_on_device<8>(b, 100, -1, false, 2, true, err, jc, ti, 0);
+  hip_rt::fill_one_to_many_baseline_hash_table_on_device<4>(otm, b, 100, -1, 2, jc, ti, 0);
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "hdk_amd", "glue"), str(src)])
