@@ -29,6 +29,9 @@ HDK_DEV void reduce_slot(const hdk_hip_target& tg, int8_t* this1, int8_t* this2,
                          const int8_t* that2, int64_t init_val) {
   const int agg = tg.agg;
   if (agg == HDK_AGG_ID) {
+    if (tg.slot_width == 0) {  // projected key of a baseline table: no slot (target_groupby_indices)
+      return;
+    }
     if (tg.slot_width == 4) {
       const int32_t rhs = *reinterpret_cast<const int32_t*>(that1);
       if (rhs != init_val) *reinterpret_cast<int32_t*>(this1) = rhs;
@@ -256,7 +259,9 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_baseline(const hdk_hip_pla
       slot_ptrs(p, this_buf, this_entry_count, static_cast<uint32_t>(dst), t, s, &a1, &a2);
       slot_ptrs(p, const_cast<int64_t*>(that_buf), that_entry_count, e, t, s, &b1, &b2);
       if (fresh) {  // fill_slots (ResultSetReduction.cpp:560-600): plain copy into the new entry
-        if (tg.slot_width == 4) {
+        if (tg.slot_width == 0) {
+          // no slot
+        } else if (tg.slot_width == 4) {
           *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
         } else {
           *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);
@@ -367,7 +372,9 @@ __global__ __launch_bounds__(kRedBlock) void k_partition_baseline(const hdk_hip_
       int8_t *a1, *a2, *b1, *b2;
       slot_ptrs(p, seg, seg_n, dst, t, s, &a1, &a2);
       slot_ptrs(p, const_cast<int64_t*>(buf), entry_count, e, t, s, &b1, &b2);
-      if (tg.slot_width == 4) {
+      if (tg.slot_width == 0) {
+        // no slot
+      } else if (tg.slot_width == 4) {
         *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
       } else {
         *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);

@@ -455,6 +455,12 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   }
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
+    if (tg.slot_width == 0) {
+      HDK_REQUIRE(p->query_kind == HDK_Q_BASELINE_HASH && tg.agg == HDK_AGG_ID && tg.key_idx >= 0 &&
+                      tg.key_idx < p->key_count,
+                  "only a projected key of a baseline-hash plan may have a zero-width slot");
+      continue;
+    }
     HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "slot width must be 4 or 8");
     if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
       set_error("float32 aggregate slots are outside the fixed kernel library");

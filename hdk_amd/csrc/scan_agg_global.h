@@ -196,8 +196,8 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
           slot_idx += tg.agg == HDK_AGG_AVG ? 2 : 1;
           // agg_id stores the same value for every row of a group: in a baseline table the row that
           // created the group does it once (one write less per row on the group's cache line)
-          if (tg.agg == HDK_AGG_ID && !fresh) {
-            continue;
+          if (tg.agg == HDK_AGG_ID && (!fresh || tg.slot_width == 0)) {
+            continue;  // (a baseline table keeps no slot for a projected key at all)
           }
           bool is_null;
           const int64_t v = eval_target_arg(c, tg, is_null, err);

@@ -143,7 +143,7 @@ def merge_baseline_on_device(cp, recv, recv_counts: np.ndarray, device_id: int, 
     """Owner side: initialise a fresh table and re-insert every received segment in rank order
     (reduceOneEntryBaseline semantics, QE/ResultSetReduction.cpp:694-731).  Returns (table, entry_count)."""
     from ._lib import check, lib
-    from .plan import compact_init_vals, eff_key_count
+    from .plan import columnar_init_vals, compact_init_vals, eff_key_count
     import torch
     L = lib()
     p = cp.plan
@@ -151,7 +151,7 @@ def merge_baseline_on_device(cp, recv, recv_counts: np.ndarray, device_id: int, 
     table = torch.empty(baseline_table_quads(cp, n), dtype=torch.int64, device=recv.device)
     block, grid = 1024, 1024  # launch shape of the fill kernel only
     if p.output_columnar:
-        d_init = torch.from_numpy(np.ascontiguousarray(cp.init_vals, dtype=np.int64)).to(recv.device)
+        d_init = torch.from_numpy(columnar_init_vals(cp)).to(recv.device)
         d_sizes = torch.from_numpy(np.array(cp.slot_widths, dtype=np.int8)).to(recv.device)
         check(L.hdk_hip_init_columnar_group_by_buffer(table.data_ptr(), d_init.data_ptr(), n, eff_key_count(p),
                                                       len(cp.slot_widths), d_sizes.data_ptr(), 1, p.keyless, 8, block,

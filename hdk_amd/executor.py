@@ -22,7 +22,7 @@ from . import result_set
 from ._lib import HdkHipError, check, lib
 from .hip_mgr import DeviceBuffer, HipMgr
 from .ir import QueryMustRunOnCpu, QueryUnit
-from .plan import CompiledPlan, compact_init_vals, compile_query, eff_key_count
+from .plan import CompiledPlan, columnar_init_vals, compact_init_vals, compile_query, eff_key_count
 from .storage import ArrowStorage
 
 
@@ -169,7 +169,7 @@ class PreparedStep:
         d_gb = self._dev(ptrs)
         if p.output_columnar:
             self.d_col_sizes = self._dev(np.array(cp.slot_widths, dtype=np.int8))
-            self.d_init_raw = self._dev(cp.init_vals)
+            self.d_init_raw = self._dev(columnar_init_vals(cp))
 
         params = (C.c_void_p * A.KP_COUNT)()
         params[A.KP_COL_BUFFERS] = d_frag_ptrs.ptr

@@ -712,7 +712,13 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
             tg.arg_is_fp = 0
             tg.null_val = 0
             init_vals.append(0)  # non-agg targets init to 0 (OutputBufferInitialization.cpp:45-47)
-            slot_widths.append(W)
+            if kind == A.Q_BASELINE_HASH:
+                # GroupByBaselineHash: a projected group key is read back from the key columns, its slot
+                # has size 0 (target_groupby_indices -> ColSlotContext::addSlotForColumn(0, 0),
+                # QE/MemoryLayoutBuilder.cpp:921-927, RS/ColSlotContext.cpp:43-48)
+                tg.slot_width = 0
+                tg.slot2_width = 0
+            slot_widths.append(int(tg.slot_width))
             src = q.groupby[t.idx]
             dic = b.resolve(src)[2].dictionary if isinstance(src, ColRef) else None
             out_cols.append(OutCol(t.name or (src.name if isinstance(src, ColRef) else f"key{t.idx}"),
@@ -772,6 +778,9 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
             out_cols.append(OutCol(t.name or f"{t.kind}_{ti}", "agg", rt, ti, agg=t.kind,
                                    scale=(at.scale if (at is not None and at.kind == "decimal") else 0)))
         # row-wise offsets (ColSlotContext::getColOnlyOffInBytes)
+        if tg.slot_width == 0:
+            tg.slot_off = row_off
+            continue
         if W == 8:
             row_off = align8(row_off)
         tg.slot_off = row_off
@@ -840,6 +849,13 @@ def columnar_slot_offsets(cp: CompiledPlan, entry_count: Optional[int] = None) -
     return offs
 
 
+def columnar_init_vals(cp: CompiledPlan) -> np.ndarray:
+    """init_agg_val_vec for the columnar init kernel: zero-width slots have no entry
+    (OutputBufferInitialization.cpp:45-47; init_columnar_group_by_buffer_gpu skips them without
+    consuming an init value, QE/GpuInitGroups.cu:133-166)."""
+    return np.array([v for v, w in zip(cp.init_vals, cp.slot_widths) if w], dtype=np.int64)
+
+
 def compact_init_vals(cp: CompiledPlan) -> np.ndarray:
     """Row-wise init values as the kernel's INIT_AGG_VALS param: one int64 word per quad of the
     row's slot region (QueryExecutionContext.cpp:829-836 compact_init_vals)."""
@@ -857,8 +873,9 @@ def compact_init_vals(cp: CompiledPlan) -> np.ndarray:
             off = (tg.slot_off if k == 0 else tg.slot2_off) - keys_bytes
             w = cp.slot_widths[s]
             v = int(cp.init_vals[s])
-            raw[off:off + w] = np.frombuffer(
-                (v & ((1 << (8 * w)) - 1)).to_bytes(w, "little"), dtype=np.uint8)
+            if w:  # zero-width slot: a projected key of a baseline table, nothing to initialise
+                raw[off:off + w] = np.frombuffer(
+                    (v & ((1 << (8 * w)) - 1)).to_bytes(w, "little"), dtype=np.uint8)
             s += 1
     return raw.view(np.int64).copy()
 
@@ -878,6 +895,8 @@ def init_buffer_host(cp: CompiledPlan, entry_count: Optional[int] = None) -> np.
         if not p.keyless:
             buf[:nk * align8(n * 8)].view(np.int64)[:] = A.EMPTY_KEY_64
         for off, w, v in zip(offs, cp.slot_widths, cp.init_vals):
+            if not w:
+                continue
             dt = {8: np.int64, 4: np.int32, 2: np.int16, 1: np.int8}[w]
             buf[off:off + n * w].view(dt)[:] = np.int64(v).astype(dt)
         return buf.view(np.int64).copy()

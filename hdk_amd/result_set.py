@@ -24,6 +24,9 @@ def _slot_arrays(cp: CompiledPlan, buf: np.ndarray, entry_count: int) -> List[np
         return [buf[i:i + 1].astype(np.int64) for i in range(len(cp.slot_widths))]
     if p.output_columnar:
         for off, w in zip(columnar_slot_offsets(cp, entry_count), cp.slot_widths):
+            if not w:  # zero-width slot (projected key of a baseline table): read from the key column
+                out.append(None)
+                continue
             dt = np.int64 if w == 8 else np.int32
             out.append(raw[off:off + entry_count * w].view(dt).astype(np.int64))
         return out
@@ -35,9 +38,12 @@ def _slot_arrays(cp: CompiledPlan, buf: np.ndarray, entry_count: int) -> List[np
         for k in range(2 if tg.agg == A.AGG_AVG else 1):
             off = tg.slot_off if k == 0 else tg.slot2_off
             w = cp.slot_widths[s]
+            s += 1
+            if not w:
+                out.append(None)
+                continue
             dt = np.int64 if w == 8 else np.int32
             out.append(np.ascontiguousarray(rows[:, off:off + w]).view(dt).reshape(-1).astype(np.int64))
-            s += 1
     return out
 
 
@@ -145,8 +151,9 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) 
     for oc in cp.out_cols:
         tg = p.targets[oc.target_idx]
         fs = first_slot[oc.target_idx]
-        vals = slots[fs][mask]
         w = cp.slot_widths[fs]
+        # a projected key without a slot of its own comes from the key columns (target_groupby_indices)
+        vals = (slots[fs] if slots[fs] is not None else keys[oc.key_idx])[mask]
         if oc.kind == "key":
             kt = cp.key_types[oc.key_idx]
             nullv = kt.null_value()

@@ -274,7 +274,10 @@ typedef struct hdk_hip_target {
   int32_t has_arg;    /* 0 => COUNT(*) */
   hdk_hip_expr arg;
   int32_t skip_null;  /* TargetInfo::skip_null_val -> *_skip_val runtime (RuntimeFunctions.cpp:612-875) */
-  int32_t slot_width; /* 4 or 8: padded slot width of the first slot (RS/ColSlotContext) */
+  int32_t slot_width; /* 4 or 8: padded slot width of the first slot (RS/ColSlotContext); 0 for a projected
+                         group key of a GroupByBaselineHash plan, which has no slot and is read back
+                         from the key columns (target_groupby_indices, QE/MemoryLayoutBuilder.cpp:921-927;
+                         ColSlotContext::addSlotForColumn(0, 0), RS/ColSlotContext.cpp:43-48) */
   int32_t slot_off;   /* row-wise: byte offset of the first slot inside the row (after keys);
                          columnar: byte offset of the slot column from the buffer start */
   int32_t slot2_width;/* AVG: width of the count slot */

@@ -1390,6 +1390,7 @@ static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2,
   const int skip = tg->skip_null;
   const int64_t nullv = tg->null_val;
   if (tg->agg == HDK_AGG_ID) { /* agg_id / agg_id_int32: RuntimeFunctions.cpp:473-476, 562-571 */
+    if (tg->slot_width == 0) return; /* projected key of a baseline table: no slot (target_groupby_indices) */
     if (tg->slot_width == 4) *(int32_t*)slot1 = (int32_t)val;
     else if (tg->slot_width == 2) *(int16_t*)slot1 = (int16_t)val;
     else if (tg->slot_width == 1) *(int8_t*)slot1 = (int8_t)val;
@@ -1908,6 +1909,9 @@ int32_t orc_is_empty_entry(const hdk_hip_plan* p, const int64_t* buf, uint32_t e
 static void reduce_one_target(const hdk_hip_target* tg, int8_t* this1, int8_t* this2,
                               const int8_t* that1, const int8_t* that2, int64_t init_val) {
   if (tg->agg == HDK_AGG_ID) { /* non-agg projection: ResultSetReduction.cpp:1329-1385 */
+    if (tg->slot_width == 0) { /* getTargetGroupbyIndex >= 0: nothing to reduce (:1248-1251) */
+      return;
+    }
     if (tg->slot_width == 4) {
       const int32_t rhs = *(const int32_t*)that1;
       if (rhs != init_val) *(int32_t*)this1 = rhs;

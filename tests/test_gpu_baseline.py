@@ -106,6 +106,7 @@ def test_perfect_hash_via_global_atomics(oracle, gpu_executor_factory):
     assert_buffers_equal(cp, res.buffer, want)
 
 
+@pytest.mark.timeout(900)  # the first `import torch` on a fresh box can take minutes while the image pages in
 @pytest.mark.parametrize("columnar,world", [(False, 2), (True, 4), (False, 3)])
 def test_multi_gpu_baseline_merge_emulated(oracle, gpu_executor_factory, columnar, world):
     """The N-GPU baseline merge (partition by owner -> all-to-all -> owner re-insert), with the ranks

@@ -49,12 +49,12 @@ def test_init_buffers_match_host_image(mgr, oracle, columnar, nkeys):
     step = Executor(st, 0, mgr).prepare(cp) if cp.plan.query_kind != A.Q_BASELINE_HASH else None
     want = init_buffer_host(cp)
     if step is None:  # baseline plans cannot launch yet on every build; initialise through the ABI directly
-        from hdk_amd.plan import compact_init_vals
+        from hdk_amd.plan import columnar_init_vals, compact_init_vals
         L = lib()
         out = mgr.alloc(cp.buffer_bytes, 0)
         p = cp.plan
         if columnar:
-            d_init = mgr.to_device(cp.init_vals, 0)
+            d_init = mgr.to_device(columnar_init_vals(cp), 0)  # zero-width slots have no init value
             d_sz = mgr.to_device(np.array(cp.slot_widths, dtype=np.int8), 0)
             check(L.hdk_hip_init_columnar_group_by_buffer(out.ptr, d_init.ptr, p.entry_count, p.key_count,
                                                           len(cp.slot_widths), d_sz.ptr, 1, p.keyless, 8, 256, 1024, 0, None))

@@ -87,13 +87,17 @@ def test_baseline_key_width_and_columnar_offsets():
                   targets=[KeyRef(0), KeyRef(1), Agg("avg", ColRef("v"))])
     cp = compile_query(st, q)
     assert cp.plan.key_width == 4  # pick_baseline_key_width: both ranges fit int32
-    assert cp.plan.row_size_quad == 1 + 4  # align8(2*4) + 4 slots of 8
+    # projected keys have zero-width slots in a baseline table (target_groupby_indices,
+    # MemoryLayoutBuilder.cpp:921-927 + ColSlotContext.cpp:43-48): row = align8(2*4) + AVG's two 8-byte slots
+    assert cp.plan.row_size_quad == 1 + 2
+    assert cp.slot_widths == [0, 0, 8, 8]
+    assert [cp.plan.targets[i].slot_width for i in range(3)] == [0, 0, 8]
     q.output_columnar = True
     cpc = compile_query(st, q)
     assert cpc.plan.key_width == 8  # columnar group keys are 64-bit (QueryMemoryDescriptor.cpp:344-372)
     offs = columnar_slot_offsets(cpc)
-    assert offs == [2 * 101 * 8 + i * 101 * 8 for i in range(4)]
-    assert cpc.buffer_bytes == 6 * 101 * 8
+    assert offs == [2 * 101 * 8, 2 * 101 * 8, 2 * 101 * 8, 3 * 101 * 8]
+    assert cpc.buffer_bytes == 4 * 101 * 8
 
 
 def test_non_grouped_init_is_null_sentinel_and_skip():
