@@ -403,6 +403,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "host_common.h"
 #include "launch_common.h"
 #include "scan_agg_fast.h"
+#include "scan_agg_baseline_fast.h"
 #include "scan_agg_global.h"
 #include "scan_agg_vec.h"
 #include "scan_project.h"
@@ -754,9 +755,59 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   return HDK_HIP_OK;
 }
 
+// the shape hdk_scan_agg_baseline_direct takes (scan_agg_baseline_fast.h)
+static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
+  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_quals || p->num_joins || p->key_count != 1) {
+    return false;
+  }
+  int kc;
+  if (!plain_outer_col(p, p->keys[0], &kc) || p->cols[kc].kind != HDK_COL_INT) return false;
+  memset(fa, 0, sizeof(*fa));
+  fa->key_buf_idx = p->cols[kc].buf_idx;
+  fa->key_width = p->cols[kc].width;
+  fa->key_kind = p->cols[kc].kind;
+  int n = 0;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_ID) {
+      if (tg.slot_width != 0) return false;  // (perfect-hash style key slots: generic kernel)
+      continue;
+    }
+    BaseFastTarget ft;
+    ft.target = t;
+    ft.buf_idx = -1;
+    ft.width = 8;
+    ft.kind = HDK_COL_INT;
+    if (tg.has_arg) {
+      int c;
+      if (!plain_outer_col(p, tg.arg, &c)) return false;
+      ft.buf_idx = p->cols[c].buf_idx;
+      ft.width = p->cols[c].width;
+      ft.kind = p->cols[c].kind;
+    } else if (tg.agg != HDK_AGG_COUNT) {
+      return false;
+    }
+    fa->tg[n++] = ft;
+  }
+  fa->ntargets = n;
+  return true;
+}
+
 static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
-                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s) {
-  (void)plan;
+                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic) {
+  BaseFastArgs fa;
+  if (!force_generic && match_baseline_fast(plan, &fa)) {
+    fa.plan = d_plan;
+    fa.kp = kp;
+    fa.entry_count = shape.entry_count;
+    if (plan->key_width == 4) {
+      hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int32_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, fa);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int64_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, fa);
+    }
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
+  }
   GlobalArgs a;
   a.plan = d_plan;
   a.kp = kp;
@@ -795,7 +846,10 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
                                  : plan->num_joins     ? "hdk_scan_project_join"
                                                        : "hdk_scan_project");
   } else {
-    snprintf(out, out_len, "hdk_scan_agg_global");
+    BaseFastArgs fa;
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    snprintf(out, out_len, "%s", !generic && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
+                                                                             : "hdk_scan_agg_global");
   }
   return HDK_HIP_OK;
 }
@@ -893,7 +947,8 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_HIP_CHECK(hipGetLastError());
     st = HDK_HIP_OK;
   } else {
-    st = launch_scan_global(plan, d_plan, kp, shape, s);
+    st = launch_scan_global(plan, d_plan, kp, shape, s,
+                            ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
   }
   if (st) return st;
   if (timed) {

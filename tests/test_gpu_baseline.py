@@ -46,9 +46,15 @@ def test_baseline_single_key(oracle, gpu_executor_factory, columnar):
                            Agg("min", ColRef("val"), "mn"), Agg("max", ColRef("val"), "mx")])
     cp, want, err = run_oracle(oracle, st, q)
     assert err == 0 and cp.plan.query_kind == A.Q_BASELINE_HASH
-    res = gpu_executor_factory(st).execute(cp)
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(cp)
+    # row-wise single-column shape -> the specialised kernel; columnar -> the general one
+    assert step.kernel_names() == ("hdk_scan_agg_global" if columnar else "hdk_scan_agg_baseline_direct")
+    res = step.run()
+    step.free()
     _check_rows(cp, res.buffer, want)
     assert res.row_count() == len(np.unique(key))
+    _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
 
 
 def test_baseline_multi_key_int32_and_fp(oracle, gpu_executor_factory):
@@ -165,3 +171,45 @@ def test_multi_gpu_baseline_merge_emulated(oracle, gpu_executor_factory, columna
     # balance: mulhi(hash, G) spreads the keys evenly
     per_owner = np.sum(np.array(counts, dtype=np.int64), axis=0)
     assert per_owner.min() > 0.8 * per_owner.mean()
+
+
+def test_baseline_fast_kernel_shapes(oracle, gpu_executor_factory):
+    """hdk_scan_agg_baseline_direct: 4- and 8-byte table keys, 16-byte and wider entries, int32 / double /
+    nullable arguments, ragged fragment tails, a table that fills up -- against the oracle and against
+    the general kernel."""
+    rng = np.random.default_rng(314)
+    n = 500_003
+    k32 = rng.integers(-70_000, 70_000, n).astype(np.int32)
+    k64 = rng.integers(0, 60_000, n, dtype=np.int64) * 3_000_000_019 - 2**40
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    i32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    i32[rng.random(n) < 0.05] = A.NULL_INT
+    d = rng.normal(size=n)
+    d[rng.random(n) < 0.05] = np.frombuffer(np.int64(A.NULL_DOUBLE_BITS).tobytes(), dtype=np.float64)[0]
+    st = ArrowStorage()
+    st.import_numpy("t", {"k32": k32, "k64": k64, "v": v, "i32": i32, "d": d}, fragment_size=99_991)
+    shapes = [
+        ("k32", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s")]),                                   # 16-byte entries
+        ("k64", [KeyRef(0, "k"), Agg("min", ColRef("v"), "mn")]),
+        ("k64", [KeyRef(0, "k"), Agg("count", None, "c"), Agg("avg", ColRef("d"), "ad"), Agg("max", ColRef("i32"), "mx"),
+                 Agg("count", ColRef("i32"), "ci"), Agg("sum", ColRef("d"), "sd")]),
+        ("k32", [KeyRef(0, "k"), Agg("count", None, "c")]),
+    ]
+    ex = gpu_executor_factory(st)
+    for kc, targets in shapes:
+        q = QueryUnit("t", groupby=[ColRef(kc)], force_baseline=True, baseline_entry_count=262_147, targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        step = ex.prepare(cp)
+        assert step.kernel_names() == "hdk_scan_agg_baseline_direct"
+        res = step.run()
+        step.free()
+        _check_rows(cp, res.buffer, want)
+        _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+    from hdk_amd._lib import HdkHipError
+    q = QueryUnit("t", groupby=[ColRef("k64")], force_baseline=True, baseline_entry_count=1_000,
+                  targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s")])
+    with pytest.raises(HdkHipError) as ei:
+        ex.execute(q)
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS
