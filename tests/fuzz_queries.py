@@ -1,0 +1,103 @@
+"""Seeded random query generator for the differential tests: random tables (mixed widths, NULLs, fp),
+random filters, joins, keys and aggregates inside the fixed library's limits.  Shapes the plan compiler
+rejects (QueryMustRunOnCpu) are skipped by the callers -- rejecting is a legal outcome, a wrong answer is not."""
+import numpy as np
+
+from hdk_amd import _abi as A
+from hdk_amd.ir import Agg, Cmp, ColRef, JoinSpec, KeyRef, Lit, Proj, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+
+def make_tables(rng, n, nd):
+    def with_nulls(a, null, frac):
+        a = a.copy()
+        if frac:
+            a[rng.random(len(a)) < frac] = null
+        return a
+    fact = {
+        "k8": with_nulls(rng.integers(0, 40, n).astype(np.int8), A.NULL_TINYINT, 0.02),
+        "k16": rng.integers(-300, 300, n).astype(np.int16),
+        "k32": with_nulls(rng.integers(0, 5000, n).astype(np.int32), A.NULL_INT, 0.03),
+        "k64": rng.integers(0, 900, n, dtype=np.int64) * 7_000_000_013,
+        "fk": with_nulls(rng.integers(-5, nd + 5, n).astype(np.int64), A.NULL_BIGINT, 0.02),
+        "fk2": rng.integers(0, 12, n).astype(np.int32),
+        "v64": with_nulls(rng.integers(-10**9, 10**9, n, dtype=np.int64), A.NULL_BIGINT, 0.05),
+        "v32": with_nulls(rng.integers(-1000, 1000, n).astype(np.int32), A.NULL_INT, 0.05),
+        "v16": rng.integers(-100, 100, n).astype(np.int16),
+        "d": with_nulls(rng.normal(size=n) * 100, np.frombuffer(np.int64(A.NULL_DOUBLE_BITS).tobytes(), np.float64)[0], 0.05),
+    }
+    dim = {
+        "key": rng.permutation(nd).astype(np.int64),
+        "dup": rng.integers(0, max(nd // 4, 1), nd).astype(np.int64),
+        "g": rng.integers(0, 9, nd).astype(np.int32),
+        "w": with_nulls(rng.integers(-50, 50, nd).astype(np.int64), A.NULL_BIGINT, 0.04),
+        "a": (np.arange(nd) % 12).astype(np.int32),
+    }
+    st = ArrowStorage()
+    st.import_numpy("fact", fact, fragment_size=int(rng.integers(n // 7 + 1, n // 2 + 2)))
+    st.import_numpy("dim", dim, fragment_size=int(rng.integers(nd // 3 + 1, nd + 1)))
+    return st
+
+
+INT_COLS = ["k8", "k16", "k32", "v64", "v32", "v16"]
+KEY_COLS = ["k8", "k16", "k32", "k64"]
+
+
+def random_query(rng, allow_join=True, projection=False):
+    joins, dim_cols = [], []
+    if allow_join and rng.random() < 0.45:
+        kind = rng.integers(0, 4)
+        typ = "left" if rng.random() < 0.3 else "inner"
+        if kind == 0:
+            joins = [JoinSpec("dim", ColRef("fk"), "key", typ)]                       # one-to-one
+        elif kind == 1:
+            joins = [JoinSpec("dim", ColRef("fk") / 4, "dup", typ)]                    # one-to-many, expression key
+        elif kind == 2:
+            joins = [JoinSpec("dim", [ColRef("fk"), ColRef("fk2")], ["key", "a"], typ)]  # keyed one-to-one
+        else:
+            joins = [JoinSpec("dim", [ColRef("fk2"), ColRef("k8")], ["a", "g"], typ)]    # keyed one-to-many
+        dim_cols = [ColRef("g", "dim"), ColRef("w", "dim")]
+    quals = []
+    for _ in range(int(rng.integers(0, 3))):
+        if dim_cols and rng.random() < 0.4:
+            quals.append(Cmp(dim_cols[1], rng.choice(["<", ">", "<>"]), Lit(int(rng.integers(-30, 30)))))
+        else:
+            c = str(rng.choice(INT_COLS + ["d"]))
+            lhs = ColRef(c)
+            if c != "d" and rng.random() < 0.3:
+                lhs = lhs * int(rng.integers(1, 4)) + int(rng.integers(-5, 5))
+            lit = Lit(float(rng.normal() * 50)) if c == "d" else Lit(int(rng.integers(-200, 2000)))
+            quals.append(Cmp(lhs, str(rng.choice(["<", "<=", ">", ">=", "=", "<>"])), lit))
+    def arg():
+        r = rng.random()
+        if dim_cols and r < 0.3:
+            return dim_cols[1] if rng.random() < 0.7 else dim_cols[1] + ColRef("v32")
+        if r < 0.5:
+            return ColRef(str(rng.choice(["v64", "v32", "v16"])))
+        if r < 0.65:
+            return ColRef("d")
+        if r < 0.8:
+            return ColRef("v32") * ColRef("v16")
+        return ColRef("v64") / int(rng.integers(2, 9)) - ColRef("k16")
+    if projection:
+        targets = [Proj(ColRef("k32"), "k32"), Proj(arg(), "e1"), Proj(ColRef("d"), "d")]
+        if dim_cols:
+            targets.append(Proj(dim_cols[0], "g"))
+        return QueryUnit("fact", quals=quals + [Cmp(ColRef("k16"), ">", Lit(int(rng.integers(150, 280))))], joins=joins,
+                         targets=targets, output_columnar=bool(rng.random() < 0.5))
+    nkeys = int(rng.choice([0, 1, 1, 2]))
+    groupby = []
+    for _ in range(nkeys):
+        if dim_cols and rng.random() < 0.35:
+            groupby.append(dim_cols[0])
+        else:
+            groupby.append(ColRef(str(rng.choice(KEY_COLS))))
+    targets = [KeyRef(i, f"key{i}") for i in range(len(groupby))]
+    aggs = ["count", "sum", "min", "max", "avg"]
+    for i in range(int(rng.integers(1, 5))):
+        kind = str(rng.choice(aggs))
+        a = None if (kind == "count" and rng.random() < 0.5) else arg()
+        targets.append(Agg(kind, a, f"t{i}"))
+    return QueryUnit("fact", quals=quals, joins=joins, groupby=groupby, targets=targets,
+                     output_columnar=bool(groupby and rng.random() < 0.3),
+                     force_baseline=bool(groupby and rng.random() < 0.25))
