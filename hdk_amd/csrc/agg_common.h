@@ -32,8 +32,11 @@ constexpr int kMaxWordsPerEntry = 1 + 2 * HDK_HIP_MAX_TARGETS;
 struct WordLayout {
   int32_t wpe;                             // words per entry
   int32_t vword[HDK_HIP_MAX_TARGETS];      // value word of target t, or -1
-  int32_t nword[HDK_HIP_MAX_TARGETS];      // non-null-count word of target t, or -1
+  int32_t nword[HDK_HIP_MAX_TARGETS];      // non-null-count word of target t, or -1.  In LDS the word counts
+                                           // the NULL rows instead (rare, so it costs an atomic only on a NULL);
+                                           // the slab flush stores rowcount - nulls
   int32_t wop[kMaxWordsPerEntry];          // combine op per word
+  int32_t is_nword[kMaxWordsPerEntry];     // word w is some target's non-null-count word
 };
 
 __host__ __device__ inline bool target_has_value_word(const hdk_hip_target& tg) {
@@ -46,6 +49,9 @@ __host__ __device__ inline bool target_has_nn_word(const hdk_hip_target& tg) {
 __host__ __device__ inline void make_word_layout(const hdk_hip_plan* p, WordLayout* wl) {
   int w = 1;
   wl->wop[0] = WOP_ADD_U64;
+  for (int i = 0; i < kMaxWordsPerEntry; ++i) {
+    wl->is_nword[i] = 0;
+  }
   for (int t = 0; t < HDK_HIP_MAX_TARGETS; ++t) {
     wl->vword[t] = -1;
     wl->nword[t] = -1;
@@ -66,6 +72,7 @@ __host__ __device__ inline void make_word_layout(const hdk_hip_plan* p, WordLayo
     if (target_has_nn_word(tg)) {
       wl->nword[t] = w;
       wl->wop[w] = WOP_ADD_U64;
+      wl->is_nword[w] = 1;
       ++w;
     }
   }

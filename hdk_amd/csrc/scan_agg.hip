@@ -130,10 +130,10 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
           bool is_null;
           const int64_t v = eval_target_arg(c, tg, is_null, err);
           if (is_null) {
+            if (nw >= 0) {
+              lds_add_u64(base + nw * rep, 1);  // counts NULLs; the flush turns it into the non-null count
+            }
             continue;
-          }
-          if (nw >= 0) {
-            lds_add_u64(base + nw * rep, 1);
           }
           if (vw >= 0) {
             int64_t* wp = base + vw * rep;
@@ -163,6 +163,14 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
     int64_t acc = lds[i * rep];
     for (uint32_t r = 1; r < rep; ++r) {
       acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    if (wl.is_nword[i % wpe]) {  // NULL count -> non-null count = rows of the entry - NULLs
+      const uint32_t w0 = (i / wpe) * wpe;
+      int64_t rows = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        rows += lds[w0 * rep + r];
+      }
+      acc = rows - acc;
     }
     slab[i] = acc;
   }
@@ -519,15 +527,19 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     //   16 B/row, one LDS atomic per row (C2), or no key (C1): 2 per CU is best (C2 @1e9 rows: 512
     //     blocks 2.60 ms, 1024 blocks 2.71 ms -- fewer slabs to fold, same bytes in flight);
     //   narrow rows carry more LDS atomics per byte streamed and want more waves to hide them:
-    //     COUNT(*) by a 4-byte key (taxi Q1) 4 per CU (4.4 -> 5.6 TB/s), 2-byte key + AVG (taxi Q2,
-    //     three atomics per 10 B) 8 per CU (2.1 -> 3.4 TB/s).
+    //     COUNT(*) by a 4-byte key (taxi Q1) 4 per CU (4.4 -> 5.6 TB/s), 2-byte key + AVG (taxi Q2)
+    //     3 per CU.
     const uint32_t cu = static_cast<uint32_t>(props->num_cu);
+    const bool static_ops = fa.nops == 1 || ((fa.nops == 2 || fa.nops == 3) && fa.op_kind[0] == FOP_ADD_ONE &&
+                                             (fa.op_kind[1] == FOP_ADD_U64 || fa.op_kind[1] == FOP_ADD_F64));
     if (kw == 0 || kw + vw >= 16) {
       s.grid = 2u * cu;
     } else if (vw == 0) {
       s.grid = 4u * cu;
+    } else if (static_ops) {
+      s.grid = 3u * cu;  // taxi Q2 with the compile-time op list: 768 blocks 0.419 ms, 512 0.507, 1024 0.440
     } else {
-      s.grid = 8u * cu;
+      s.grid = 8u * cu;  // run-time op list (scalar dispatch per op): more waves hide it
     }
   }
   return s;
@@ -649,7 +661,8 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
       if (fa->mask_mode) {
         fa->nn_words[fa->n_nn_words++] = wl.nword[t];
       } else {
-        push(FOP_ADD_ONE_NOT_NULL, wl.nword[t]);
+        push(FOP_ADD_ONE_IF_NULL, wl.nword[t]);
+        fa->nword_mask |= 1u << wl.nword[t];
       }
     }
   }
@@ -685,10 +698,22 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
       return launch_direct<KW, 0, -1>(fa, shape, s);
     case 4:
       return launch_direct<KW, 4, -1>(fa, shape, s);
-    default:
+    default: {
       if (only == FOP_ADD_U64) return launch_direct<KW, 8, FOP_ADD_U64>(fa, shape, s);
       if (only == FOP_ADD_F64) return launch_direct<KW, 8, FOP_ADD_F64>(fa, shape, s);
+      // "row count, sum[, NULL count]" (one AVG, or SUM + COUNT of the same column): compile-time list
+      const bool sum_list = (fa.nops == 2 || fa.nops == 3) && fa.op_kind[0] == FOP_ADD_ONE && fa.op_word[0] == 0 &&
+                            (fa.op_kind[1] == FOP_ADD_U64 || fa.op_kind[1] == FOP_ADD_F64) &&
+                            (fa.nops == 2 || fa.op_kind[2] == FOP_ADD_ONE_IF_NULL);
+      if (sum_list && KW != 0) {
+        const bool fp = fa.op_kind[1] == FOP_ADD_F64;
+        if (fa.nops == 3) {
+          return fp ? launch_direct<KW, 8, 101>(fa, shape, s) : launch_direct<KW, 8, 100>(fa, shape, s);
+        }
+        return fp ? launch_direct<KW, 8, 103>(fa, shape, s) : launch_direct<KW, 8, 102>(fa, shape, s);
+      }
       return launch_direct<KW, 8, -1>(fa, shape, s);
+    }
   }
 }
 

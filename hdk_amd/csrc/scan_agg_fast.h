@@ -23,7 +23,7 @@ constexpr int kFastMaxOps = 8;
 
 enum FastOpKind : int32_t {
   FOP_ADD_ONE = 0,        // rowcount: +1 for every row
-  FOP_ADD_ONE_NOT_NULL,   // non-null count: +1 when the value is not NULL
+  FOP_ADD_ONE_IF_NULL,    // NULL count: +1 when the value IS NULL (the flush stores rowcount - NULLs)
   FOP_ADD_U64,            // += value (non-NULL rows)
   FOP_ADD_F64,
   FOP_MIN_I64,
@@ -55,6 +55,7 @@ struct FastArgs {
   int32_t wop[kMaxWordsPerEntry];  // combine op per word (flush)
   int32_t nn_words[HDK_HIP_MAX_TARGETS];  // (mask mode) words that receive the non-null flag
   int32_t n_nn_words;
+  uint32_t nword_mask;  // (counting mode) bit w: word w holds a NULL count
 };
 
 // column buffers are plain hipMalloc'ed global memory: say so, or the pointers loaded from
@@ -107,7 +108,7 @@ HDK_DEV int64_t load_elem(gcol_t p, int64_t row) {
 HDK_DEV void fast_lds_op(int32_t kind, int64_t* wp, int64_t v) {
   switch (kind) {
     case FOP_ADD_ONE:
-    case FOP_ADD_ONE_NOT_NULL:
+    case FOP_ADD_ONE_IF_NULL:
       atomicAdd(reinterpret_cast<unsigned long long*>(wp), 1ull);
       break;
     case FOP_ADD_U64:
@@ -182,6 +183,19 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
     }
   }
   int64_t* base = lds + (entry * a.wpe) * a.rep + my_rep;
+  if (FIXED >= 100) {
+    // compile-time list "row count, sum, [NULL count]" (AVG / SUM+COUNT over one column; taxi Q2):
+    // 100/101 = integer/fp sum with a NULL-count word, 102/103 = without (argument cannot be NULL)
+    constexpr bool kFp = (FIXED & 1) != 0;
+    constexpr bool kHasNullWord = FIXED < 102;
+    fast_lds_op(FOP_ADD_ONE, base + ops.word[0] * a.rep, val);
+    if (!is_null) {
+      fast_lds_op(kFp ? FOP_ADD_F64 : FOP_ADD_U64, base + ops.word[1] * a.rep, val);
+    } else if (kHasNullWord) {
+      fast_lds_op(FOP_ADD_ONE_IF_NULL, base + ops.word[2] * a.rep, val);
+    }
+    return;
+  }
   if (FIXED >= 0) {
     if (FIXED == FOP_ADD_ONE || !is_null) {
       fast_lds_op(FIXED, base + ops.word[0] * a.rep, val);
@@ -192,7 +206,7 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
   for (int o = 0; o < kFastMaxOps; ++o) {
     if (o < ops.n) {
       const int32_t kind = ops.kind[o];
-      if (kind == FOP_ADD_ONE || !is_null) {
+      if (kind == FOP_ADD_ONE || (kind == FOP_ADD_ONE_IF_NULL ? is_null : !is_null)) {
         fast_lds_op(kind, base + ops.word[o] * a.rep, val);
       }
     }
@@ -293,6 +307,13 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
     int64_t acc = lds[i * rep];
     for (uint32_t r = 1; r < rep; ++r) {
       acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    if (!a.mask_mode && ((a.nword_mask >> w) & 1u)) {  // NULL count -> non-null count
+      int64_t rows = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        rows += lds[(e * wpe) * rep + r];
+      }
+      acc = rows - acc;
     }
     if (a.mask_mode) {
       if (w == 0) {

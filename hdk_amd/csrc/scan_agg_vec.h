@@ -128,11 +128,12 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
         const int32_t wop = vw >= 0 ? wl.wop[vw] : 0;
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          if (pass[r] && !is_null[r]) {
-            if (nw >= 0) {
-              atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[r] + nw * rep), 1ull);
-            }
-            if (vw >= 0) {
+          if (pass[r]) {
+            if (is_null[r]) {
+              if (nw >= 0) {  // counts NULLs; the flush turns it into the non-null count
+                atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[r] + nw * rep), 1ull);
+              }
+            } else if (vw >= 0) {
               vec_lds_op(wop, lds + base[r] + vw * rep, v[r]);
             }
           }
@@ -151,6 +152,14 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
     int64_t acc = lds[i * rep];
     for (uint32_t r = 1; r < rep; ++r) {
       acc = word_combine(op, acc, lds[i * rep + r]);
+    }
+    if (wl.is_nword[i % wpe]) {  // NULL count -> non-null count = rows of the entry - NULLs
+      const uint32_t w0 = (i / wpe) * wpe;
+      int64_t rows = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        rows += lds[w0 * rep + r];
+      }
+      acc = rows - acc;
     }
     slab[i] = acc;
   }
