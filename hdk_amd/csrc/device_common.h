@@ -352,7 +352,8 @@ HDK_DEV int64_t probe_join(const hdk_hip_join& jn, const int32_t* __restrict__ t
 }
 
 // same probe, table read through a global-address-space pointer; *slot_out = the slot index
-HDK_DEV int64_t probe_join_g(const hdk_hip_join& jn, const int32_t* table, int64_t key, int64_t* slot_out) {
+template <class JoinT>
+HDK_DEV int64_t probe_join_g(const JoinT& jn, const int32_t* table, int64_t key, int64_t* slot_out) {
   int64_t k = key;
   int64_t maxk = jn.max_key;
   *slot_out = 0;

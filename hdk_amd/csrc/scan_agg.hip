@@ -487,6 +487,21 @@ int32_t validate_plan(const hdk_hip_plan* p) {
 
 struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
+static bool needs_join_loops(const hdk_hip_plan* p);
+static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
+
+// Persistent grids are sized from what actually fits: blocks per CU (register / LDS limited) x CUs, so that
+// every block is resident and the static tile walk has no second, partly filled round (the batched
+// interpreter at 147 VGPRs fits 3 blocks per CU: 1024 blocks ran as 768 + 256 -- taxi Q3 1.43 ms -- while
+// 768 blocks take 1.14 ms).
+static uint32_t resident_grid(const void* kernel, int block, size_t lds_bytes, const hdk_hip_device_properties* props) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return static_cast<uint32_t>(props->grid_size);
+  }
+  return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
+}
 static bool plan_matches_direct(const hdk_hip_plan* p, const LaunchShape& shape);
 
 LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko,
@@ -540,6 +555,38 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
       s.grid = 3u * cu;  // taxi Q2 with the compile-time op list: 768 blocks 0.419 ms, 512 0.507, 1024 0.440
     } else {
       s.grid = 8u * cu;  // run-time op list (scalar dispatch per op): more waves hide it
+    }
+  } else if (!(ko && ko->grid_dim_x)) {
+    const bool scalar = (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) || needs_join_loops(p);
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    const void* k;
+    int block = kBlock;
+    if (s.strategy == STRAT_LDS) {
+      k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
+                 : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_agg_vec_join)
+                                 : reinterpret_cast<const void*>(hdk_scan_agg_vec));
+      block = scalar ? kBlock : kVecBlock;
+    } else if (s.strategy == STRAT_PROJECT) {
+      k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
+                 : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
+                                 : reinterpret_cast<const void*>(hdk_scan_project));
+      block = kProjBlock;
+    } else {
+      BaseFastArgs bf;
+      if (!generic && match_baseline_fast(p, &bf)) {
+        k = p->key_width == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t>)
+                              : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t>);
+        block = kBaseFastBlock;
+      } else {
+        k = reinterpret_cast<const void*>(hdk_scan_agg_global);
+        block = kGlobalBlock;
+      }
+    }
+    s.grid = resident_grid(k, block, s.lds_bytes, props);
+    if (s.strategy == STRAT_GLOBAL) {
+      // random atomics make block run times uneven: 4 waves of blocks rebalance the tail
+      // (C5 shape: 1792 blocks 21.5 ms, 3584 18.8 ms, 7168 17.6 ms)
+      s.grid *= 4;
     }
   }
   return s;

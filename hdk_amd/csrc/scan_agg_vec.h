@@ -54,10 +54,10 @@ template <bool J>
 HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
-  const hdk_hip_plan* __restrict__ p = a.plan;
+  const cplan_t p = to_const_as(a.plan);
   const int tid = threadIdx.x;
   if (tid == 0) {
-    make_word_layout(p, &wl);
+    make_word_layout(a.plan, &wl);
   }
   __syncthreads();
   const int wpe = wl.wpe;
@@ -121,7 +121,7 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
         if (vw < 0 && nw < 0) {
           continue;
         }
-        const hdk_hip_target& tg = p->targets[t];
+        ctarget_t tg = p->targets[t];
         int64_t v[VR];
         bool is_null[VR];
         eval_target_arg_v(c, tg, v, is_null, pass, err);

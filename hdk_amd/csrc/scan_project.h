@@ -35,13 +35,13 @@ HDK_DEV void store_slot(int8_t* p, int width, int64_t v) {
 template <bool J>
 HDK_DEV void scan_project_body(const ProjArgs& a) {
   __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
-  const hdk_hip_plan* __restrict__ p = a.plan;
+  const cplan_t p = to_const_as(a.plan);
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const bool columnar = p->output_columnar;
   const int nt = p->num_targets;
   if (columnar && tid < HDK_HIP_MAX_TARGETS) {
-    s_col_off[tid] = columnar_slot_off(p, a.entry_count, tid);
+    s_col_off[tid] = columnar_slot_off(a.plan, a.entry_count, tid);
   }
   __syncthreads();
   const uint64_t nfrag = *a.kp.num_fragments;
@@ -107,7 +107,7 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
         }
       }
       for (int t = 0; t < nt; ++t) {
-        const hdk_hip_target& tg = p->targets[t];
+        ctarget_t tg = p->targets[t];
         int64_t v[VR];
         eval_expr_v(c, tg.arg, v, pass, err);
         const int w = tg.slot_width;

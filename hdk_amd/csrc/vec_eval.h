@@ -13,12 +13,40 @@
 namespace hdk {
 
 constexpr int VR = 8;
+
+// The plan is read through the CONSTANT address space: the compiler then knows that none of the
+// kernel's stores and atomics can change it, so plan fields are loaded with scalar loads once and kept
+// (or re-materialised) instead of being re-read after every LDS atomic -- the batched interpreter is
+// bound by exactly those dependent scalar loads otherwise.
+#define HDK_CAS __attribute__((address_space(4)))
+typedef const HDK_CAS hdk_hip_plan* cplan_t;
+typedef const HDK_CAS hdk_hip_expr& cexpr_t;
+typedef const HDK_CAS hdk_hip_leaf& cleaf_t;
+typedef const HDK_CAS hdk_hip_step& cstep_t;
+typedef const HDK_CAS hdk_hip_qual& cqual_t;
+typedef const HDK_CAS hdk_hip_join& cjoin_t;
+typedef const HDK_CAS hdk_hip_target& ctarget_t;
+
+HDK_DEV bool leaf_is_fp_c(cplan_t p, cleaf_t l) {
+  if (l.kind == HDK_LEAF_FP) {
+    return true;
+  }
+  if (l.kind != HDK_LEAF_COL) {
+    return false;
+  }
+  const int32_t k = p->cols[l.col].kind;
+  return k == HDK_COL_FLOAT || k == HDK_COL_DOUBLE;
+}
+
+HDK_DEV cplan_t to_const_as(const hdk_hip_plan* p) {
+  return reinterpret_cast<cplan_t>(reinterpret_cast<uintptr_t>(p));
+}
 typedef long long __attribute__((ext_vector_type(2))) i64x2;
 
 template <bool J>
 struct VecCtxT {
   static constexpr bool kJoins = J;  // false: the plan has no joins; all probe state compiles away
-  const hdk_hip_plan* plan;
+  cplan_t plan;
   const int8_t* const* cols;  // col_buffers[frag]
   int64_t row0;               // first row of the tile; slot r of lane `tid` is row0 + r*blk + tid
   int32_t nlive;              // rows of the tile inside the fragment (dead slots re-read row0)
@@ -42,7 +70,7 @@ HDK_DEV int64_t vrow(const VecCtx& c, int r) {
 }
 
 template <class VecCtx>
-HDK_DEV void vec_ctx_init(VecCtx& c, const hdk_hip_plan* p, int tid, int blk) {
+HDK_DEV void vec_ctx_init(VecCtx& c, cplan_t p, int tid, int blk) {
   c.plan = p;
   c.tid = tid;
   c.blk = blk;
@@ -81,18 +109,31 @@ HDK_DEV void for_rows(F&& f) {
   }
 }
 
+// row of batch slot r in the table a column lives in (0 = outer; 1/2 = matched row of join 0/1)
 template <class VecCtx>
-HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[VR]) {
+HDK_DEV int64_t leaf_row(const VecCtx& c, int table, int r) {
+  if (VecCtx::kJoins && table == 1) {
+    return c.jref0[r];
+  }
+  if (VecCtx::kJoins && table == 2) {
+    return c.jref1[r];
+  }
+  return vrow(c, r);
+}
+
+template <class VecCtx>
+HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
   if (l.kind == HDK_LEAF_COL) {
-    const hdk_hip_col col = c.plan->cols[l.col];
-    const int width = col.width;
-    const int kind = col.kind;
-    const int table = col.table;
-    const int8_t* __restrict__ buf = table >= 0 ? c.cols[col.buf_idx] : nullptr;
+    const int32_t ci = l.col;
+    const int width = c.plan->cols[ci].width;
+    const int kind = c.plan->cols[ci].kind;
+    const int table = c.plan->cols[ci].table;
+    const int col_buf_idx = c.plan->cols[ci].buf_idx;
+    const int8_t* __restrict__ buf = table >= 0 ? c.cols[col_buf_idx] : nullptr;
     if (VecCtx::kJoins && table < 0) {  // payload word of a fused join table: same cache line as the probed row id
       const int64_t* __restrict__ ft = table == -1 ? c.fused0 : c.fused1;
       const int64_t stride = table == -1 ? c.fstride0 : c.fstride1;
-      const int word = col.buf_idx;
+      const int word = col_buf_idx;
       if (word == 1) {  // already in registers (rows_pass_v)
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
@@ -107,20 +148,35 @@ HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[
       }
       return;
     }
-#pragma unroll
-    for (int r = 0; r < VR; ++r) {
-      int64_t row;
-      if (VecCtx::kJoins && table == 1) {
-        row = c.jref0[r];
-      } else if (VecCtx::kJoins && table == 2) {
-        row = c.jref1[r];
-      } else {
-        row = vrow(c, r);
+    // outer-table columns are streamed exactly once: non-temporal; inner (joined) columns are gathered
+    // repeatedly and should stay cached.  The decoder switch is wave-uniform: it sits OUTSIDE the row
+    // loop (one scalar branch per batch, not per row).
+    const bool nt = table == 0;
+#define HDK_LOAD_ROWS(T, CONV)                  \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) { \
+    const T x = gload<T>(buf, leaf_row(c, table, r), nt); \
+    out[r] = CONV;                               \
+  }
+    if (kind == HDK_COL_DOUBLE) {
+      HDK_LOAD_ROWS(int64_t, x)
+    } else if (kind == HDK_COL_FLOAT) {
+      HDK_LOAD_ROWS(float, double_to_bits(static_cast<double>(x)))
+    } else if (kind == HDK_COL_UNSIGNED) {
+      switch (width) {
+        case 1: HDK_LOAD_ROWS(uint8_t, static_cast<int64_t>(x)) break;
+        case 2: HDK_LOAD_ROWS(uint16_t, static_cast<int64_t>(x)) break;
+        case 4: HDK_LOAD_ROWS(uint32_t, static_cast<int64_t>(x)) break;
+        default: HDK_LOAD_ROWS(int64_t, x) break;
       }
-      // outer-table columns are streamed exactly once: non-temporal; inner (joined) columns are
-      // gathered repeatedly and should stay cached
-      out[r] = decode_col_g(buf, width, kind, row, table == 0);
+    } else {
+      switch (width) {
+        case 1: HDK_LOAD_ROWS(int8_t, static_cast<int64_t>(x)) break;
+        case 2: HDK_LOAD_ROWS(int16_t, static_cast<int64_t>(x)) break;
+        case 4: HDK_LOAD_ROWS(int32_t, static_cast<int64_t>(x)) break;
+        default: HDK_LOAD_ROWS(int64_t, x) break;
+      }
     }
+#undef HDK_LOAD_ROWS
   } else {
     const int64_t v = l.ival;
 #pragma unroll
@@ -132,90 +188,124 @@ HDK_DEV void load_leaf_v(const VecCtx& c, const hdk_hip_leaf& l, int64_t (&out)[
 
 // `live[r]`: only live rows may raise ERR_DIV_BY_ZERO (dead rows are evaluated speculatively)
 template <class VecCtx>
-HDK_DEV void eval_expr_v(const VecCtx& c, const hdk_hip_expr& e, int64_t (&acc)[VR], const bool (&live)[VR],
+HDK_DEV void eval_expr_v(const VecCtx& c, cexpr_t e, int64_t (&acc)[VR], const bool (&live)[VR],
                          int32_t& err) {
-  const hdk_hip_plan* p = c.plan;
+  cplan_t p = c.plan;
   load_leaf_v(c, e.leaf0, acc);
-  bool acc_fp = leaf_is_fp(p, e.leaf0);
+  bool acc_fp = leaf_is_fp_c(p, e.leaf0);
   int64_t acc_null = e.leaf0.null_val;
   int32_t acc_nullable = e.leaf0.nullable;
   const int nsteps = e.nsteps;
   for (int s = 0; s < nsteps; ++s) {
-    const hdk_hip_step& st = e.steps[s];
+    cstep_t st = e.steps[s];
     const int op = st.op;
     const bool out_fp = st.out_class == HDK_VC_FP;
     const int64_t null_out = st.null_out;
     if (op <= HDK_OP_MOD) {
       int64_t rhs[VR];
       load_leaf_v(c, st.rhs, rhs);
-      const bool rhs_fp = leaf_is_fp(p, st.rhs);
+      const bool rhs_fp = leaf_is_fp_c(p, st.rhs);
       const int64_t rhs_null = st.rhs.null_val;
       const int32_t rhs_nullable = st.rhs.nullable;
+      bool isnull[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const bool isnull = is_null_val(acc[r], acc_null, acc_nullable, acc_fp) ||
-                            is_null_val(rhs[r], rhs_null, rhs_nullable, rhs_fp);
-        int64_t res;
-        bool bad = false;
-        if (out_fp) {
-          const double a = acc_fp ? bits_to_double(acc[r]) : static_cast<double>(acc[r]);
-          const double b = rhs_fp ? bits_to_double(rhs[r]) : static_cast<double>(rhs[r]);
-          double d;
-          switch (op) {
-            case HDK_OP_ADD: d = a + b; break;
-            case HDK_OP_SUB: d = a - b; break;
-            case HDK_OP_MUL: d = a * b; break;
-            default:
-              bad = b == 0.0;
-              d = bad ? 0.0 : a / b;
-              break;
-          }
-          res = double_to_bits(d);
-        } else {
-          const int64_t a = acc[r], b = rhs[r];
-          switch (op) {
-            case HDK_OP_ADD: res = static_cast<int64_t>(static_cast<uint64_t>(a) + static_cast<uint64_t>(b)); break;
-            case HDK_OP_SUB: res = static_cast<int64_t>(static_cast<uint64_t>(a) - static_cast<uint64_t>(b)); break;
-            case HDK_OP_MUL: res = static_cast<int64_t>(static_cast<uint64_t>(a) * static_cast<uint64_t>(b)); break;
-            case HDK_OP_DIV: {
-              bad = b == 0;
-              const int64_t bb = (bad || isnull) ? 1 : b;
-              res = (a == INT64_MIN && bb == -1) ? INT64_MIN : a / bb;
-              break;
-            }
-            default: {
-              bad = b == 0;
-              const int64_t bb = (bad || isnull) ? 1 : b;
-              res = bb == -1 ? 0 : a % bb;
-              break;
-            }
-          }
+        isnull[r] = is_null_val(acc[r], acc_null, acc_nullable, acc_fp) ||
+                    is_null_val(rhs[r], rhs_null, rhs_nullable, rhs_fp);
+      }
+      // the op switch is wave-uniform: one scalar dispatch per batch, the row loop inside each case
+      if (out_fp) {
+        double a[VR], b[VR];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          a[r] = acc_fp ? bits_to_double(acc[r]) : static_cast<double>(acc[r]);
+          b[r] = rhs_fp ? bits_to_double(rhs[r]) : static_cast<double>(rhs[r]);
         }
-        if (bad && !isnull && live[r]) {
-          err = HDK_HIP_ERR_DIV_BY_ZERO;
+#define HDK_FP_ROWS(EXPR)                                             \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                    \
+    acc[r] = isnull[r] ? null_out : double_to_bits(EXPR);             \
+  }
+        switch (op) {
+          case HDK_OP_ADD: HDK_FP_ROWS(a[r] + b[r]) break;
+          case HDK_OP_SUB: HDK_FP_ROWS(a[r] - b[r]) break;
+          case HDK_OP_MUL: HDK_FP_ROWS(a[r] * b[r]) break;
+          default:
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              const bool bad = b[r] == 0.0;
+              if (bad && !isnull[r] && live[r]) {
+                err = HDK_HIP_ERR_DIV_BY_ZERO;
+              }
+              acc[r] = (isnull[r] || bad) ? null_out : double_to_bits(a[r] / b[r]);
+            }
+            break;
         }
-        acc[r] = (isnull || bad) ? null_out : res;
+#undef HDK_FP_ROWS
+      } else {
+#define HDK_INT_ROWS(EXPR)                                                                   \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                           \
+    const uint64_t a = static_cast<uint64_t>(acc[r]), b = static_cast<uint64_t>(rhs[r]);    \
+    acc[r] = isnull[r] ? null_out : static_cast<int64_t>(EXPR);                              \
+  }
+        switch (op) {
+          case HDK_OP_ADD: HDK_INT_ROWS(a + b) break;
+          case HDK_OP_SUB: HDK_INT_ROWS(a - b) break;
+          case HDK_OP_MUL: HDK_INT_ROWS(a * b) break;
+          case HDK_OP_DIV:
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              const int64_t a = acc[r], b = rhs[r];
+              const bool bad = b == 0;
+              const int64_t bb = (bad || isnull[r]) ? 1 : b;
+              const int64_t res = (a == INT64_MIN && bb == -1) ? INT64_MIN : a / bb;
+              if (bad && !isnull[r] && live[r]) {
+                err = HDK_HIP_ERR_DIV_BY_ZERO;
+              }
+              acc[r] = (isnull[r] || bad) ? null_out : res;
+            }
+            break;
+          default:
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              const int64_t a = acc[r], b = rhs[r];
+              const bool bad = b == 0;
+              const int64_t bb = (bad || isnull[r]) ? 1 : b;
+              const int64_t res = bb == -1 ? 0 : a % bb;
+              if (bad && !isnull[r] && live[r]) {
+                err = HDK_HIP_ERR_DIV_BY_ZERO;
+              }
+              acc[r] = (isnull[r] || bad) ? null_out : res;
+            }
+            break;
+        }
+#undef HDK_INT_ROWS
       }
     } else {
       const int64_t param = st.rhs.ival;
+      bool isnull[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const bool isnull = is_null_val(acc[r], acc_null, acc_nullable, acc_fp);
-        int64_t res;
-        switch (op) {
-          case HDK_OP_EXTRACT_YEAR: res = extract_year(acc[r]); break;
-          case HDK_OP_SCALE_DOWN: res = scale_decimal_down(acc[r], param); break;
-          case HDK_OP_FLOOR_DIV: res = floor_div_lhs(acc[r], param); break;
-          case HDK_OP_CAST_INT_TO_FP: res = double_to_bits(static_cast<double>(acc[r])); break;
-          case HDK_OP_CAST_FP_TO_INT: {
-            const double d = bits_to_double(acc[r]);
-            res = static_cast<int64_t>(d + (d < 0.0 ? -0.5 : 0.5));
-            break;
-          }
-          default: res = null_out; break;
-        }
-        acc[r] = isnull ? null_out : res;
+        isnull[r] = is_null_val(acc[r], acc_null, acc_nullable, acc_fp);
       }
+#define HDK_UNARY_ROWS(EXPR)                           \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {     \
+    acc[r] = isnull[r] ? null_out : (EXPR);            \
+  }
+      switch (op) {
+        case HDK_OP_EXTRACT_YEAR: HDK_UNARY_ROWS(extract_year(acc[r])) break;
+        case HDK_OP_SCALE_DOWN: HDK_UNARY_ROWS(scale_decimal_down(acc[r], param)) break;
+        case HDK_OP_FLOOR_DIV: HDK_UNARY_ROWS(floor_div_lhs(acc[r], param)) break;
+        case HDK_OP_CAST_INT_TO_FP: HDK_UNARY_ROWS(double_to_bits(static_cast<double>(acc[r]))) break;
+        case HDK_OP_CAST_FP_TO_INT:
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const double d = bits_to_double(acc[r]);
+            acc[r] = isnull[r] ? null_out : static_cast<int64_t>(d + (d < 0.0 ? -0.5 : 0.5));
+          }
+          break;
+        default: HDK_UNARY_ROWS(null_out) break;
+      }
+#undef HDK_UNARY_ROWS
     }
     acc_fp = out_fp;
     acc_null = null_out;
@@ -225,13 +315,13 @@ HDK_DEV void eval_expr_v(const VecCtx& c, const hdk_hip_expr& e, int64_t (&acc)[
 
 // pass[r] &= (conjunct is TRUE)
 template <class VecCtx>
-HDK_DEV void eval_qual_v(const VecCtx& c, const hdk_hip_qual& q, bool (&pass)[VR], int32_t& err) {
+HDK_DEV void eval_qual_v(const VecCtx& c, cqual_t q, bool (&pass)[VR], int32_t& err) {
   int64_t lhs[VR];
   int64_t rhs[VR];
   eval_expr_v(c, q.lhs, lhs, pass, err);
   load_leaf_v(c, q.rhs, rhs);
   const bool lhs_fp = q.lhs.vclass == HDK_VC_FP;
-  const bool rhs_fp = leaf_is_fp(c.plan, q.rhs);
+  const bool rhs_fp = leaf_is_fp_c(c.plan, q.rhs);
   const int cmp = q.cmp;
   const int64_t lnull = q.lhs.null_val, rnull = q.rhs.null_val;
   const int32_t lnullable = q.lhs.nullable, rnullable = q.rhs.nullable;
@@ -268,7 +358,7 @@ HDK_DEV void eval_qual_v(const VecCtx& c, const hdk_hip_qual& q, bool (&pass)[VR
 // filter + join probes for the batch; dead slots stay dead
 template <class VecCtx>
 HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass)[VR], int32_t& err) {
-  const hdk_hip_plan* p = c.plan;
+  cplan_t p = c.plan;
   const int nq = p->num_quals;
   for (int q = 0; q < nq; ++q) {
     if (!VecCtx::kJoins || !p->quals[q].after_joins) {
@@ -277,7 +367,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
   }
   const int nj = VecCtx::kJoins ? p->num_joins : 0;
   for (int j = 0; j < nj; ++j) {
-    const hdk_hip_join& jn = p->joins[j];
+    cjoin_t jn = p->joins[j];
     int64_t key[VR];
     eval_expr_v(c, jn.outer_key, key, pass, err);
     const int32_t* __restrict__ table = (nj == 1 && jn.table_idx == 0)
@@ -361,7 +451,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
 // group key #k for the batch (perfect hash: NULL translated)
 template <class VecCtx>
 HDK_DEV void eval_key_v(const VecCtx& c, int k, int64_t (&out)[VR], const bool (&live)[VR], int32_t& err) {
-  const hdk_hip_plan* p = c.plan;
+  cplan_t p = c.plan;
   eval_expr_v(c, p->keys[k], out, live, err);
   if (p->query_kind == HDK_Q_PERFECT_HASH && p->key_has_nulls[k] && p->keys[k].nullable) {
     const int64_t nullv = p->keys[k].null_val;
@@ -375,7 +465,7 @@ HDK_DEV void eval_key_v(const VecCtx& c, int k, int64_t (&out)[VR], const bool (
 
 template <class VecCtx>
 HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const bool (&live)[VR], int32_t& err) {
-  const hdk_hip_plan* p = c.plan;
+  cplan_t p = c.plan;
   const int nk = p->key_count;
 #pragma unroll
   for (int r = 0; r < VR; ++r) {
@@ -401,7 +491,7 @@ HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const b
 
 // target argument for the batch; is_null[r] = the value is the skip value
 template <class VecCtx>
-HDK_DEV void eval_target_arg_v(const VecCtx& c, const hdk_hip_target& tg, int64_t (&v)[VR], bool (&is_null)[VR],
+HDK_DEV void eval_target_arg_v(const VecCtx& c, ctarget_t tg, int64_t (&v)[VR], bool (&is_null)[VR],
                                const bool (&live)[VR], int32_t& err) {
   if (!tg.has_arg) {
 #pragma unroll
