@@ -10,6 +10,9 @@ enum Strategy { STRAT_LDS = 0, STRAT_GLOBAL = 1, STRAT_PROJECT = 2 };
 // LDS budget for the privatised table: 32 KiB per 256-thread block keeps 4-5 blocks (16-20 waves)
 // resident per CU out of the 160 KiB LDS.
 constexpr uint64_t kLdsWordBudget = 4096;
+// Tables between 32 and 60 KiB still go to LDS, unreplicated (2 blocks per CU): LDS atomics on a few
+// thousand entries stream at HBM speed, the global-atomics alternative is capped at ~2.4e10 rows/s.
+constexpr uint64_t kLdsMaxTableWords = 7680;
 constexpr size_t kPlanRegionBytes = (sizeof(hdk_hip_plan) + 255) & ~static_cast<size_t>(255);
 
 struct LaunchShape {

@@ -520,7 +520,7 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     s.rep = 1;
     s.lds_bytes = 0;
     s.slab_words = 0;
-  } else if (p->query_kind != HDK_Q_BASELINE_HASH && words <= kLdsWordBudget && !force_global) {
+  } else if (p->query_kind != HDK_Q_BASELINE_HASH && words <= kLdsMaxTableWords && !force_global) {
     s.strategy = STRAT_LDS;
     uint32_t rep = 32;
     while (rep > 1 && words * rep > kLdsWordBudget) {
@@ -555,6 +555,10 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
       s.grid = 3u * cu;  // taxi Q2 with the compile-time op list: 768 blocks 0.419 ms, 512 0.507, 1024 0.440
     } else {
       s.grid = 8u * cu;  // run-time op list (scalar dispatch per op): more waves hide it
+    }
+    const uint32_t lds_limited = static_cast<uint32_t>((160u * 1024u) / (s.lds_bytes + 1024u)) * cu;
+    if (lds_limited >= cu && s.grid > lds_limited) {
+      s.grid = lds_limited;  // a large unreplicated table: fewer blocks fit per CU, keep them all resident
     }
   } else if (!(ko && ko->grid_dim_x)) {
     const bool scalar = (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) || needs_join_loops(p);

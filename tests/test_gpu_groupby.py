@@ -143,3 +143,28 @@ def test_multi_key_perfect_hash_taxi_like(oracle, gpu_executor_factory):
                   targets=[KeyRef(0, "passenger_count"), KeyRef(1, "pickup_year"), Agg("count", None, "cnt")])
     cp, res = _check(oracle, gpu_executor_factory, st, q)
     assert cp.plan.query_kind == A.Q_PERFECT_HASH and cp.plan.key_count == 2
+
+
+def test_mid_size_tables_stay_in_lds(oracle, gpu_executor_factory):
+    """Perfect-hash tables of 32-60 KiB (unreplicated, 2 blocks per CU) still take the LDS kernels; one word
+    more and the plan falls to global atomics.  Both must match the oracle."""
+    rng = np.random.default_rng(61)
+    n = 400_000
+    st = ArrowStorage()
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    v[rng.random(n) < 0.03] = A.NULL_BIGINT
+    st.import_numpy("t", {"k5": rng.integers(0, 5000, n).astype(np.int32), "k2": rng.integers(0, 2400, n).astype(np.int64),
+                          "k9": rng.integers(0, 9000, n).astype(np.int32), "v": v}, fragment_size=130_000)
+    cases = [("k5", [KeyRef(0), Agg("count")], "hdk_scan_agg_direct"),                        # 5000 x 1 word
+             ("k2", [KeyRef(0), Agg("sum", ColRef("v")), Agg("count")], "hdk_scan_agg_direct"),  # 2400 x 3 words
+             ("k2", [KeyRef(0), Agg("min", ColRef("v") * 2)], "hdk_scan_agg_vec"),            # expression -> batched kernel
+             ("k9", [KeyRef(0), Agg("count")], "hdk_scan_agg_global")]                          # 9000 words: too big
+    for key, targets, kernel in cases:
+        q = QueryUnit("t", groupby=[ColRef(key)], targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp)
+        assert step.kernel_names().split(",")[0] == kernel, (key, step.kernel_names())
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
