@@ -76,10 +76,40 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # HDK_BENCH_BACKEND=gloo is a TEST mode for boxes with fewer GPUs than ranks (ranks share devices, the
+    # collectives are staged through host memory): it exercises the N>1 control flow, not xGMI.
+    backend = os.environ.get("HDK_BENCH_BACKEND", "nccl")
+    dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+
+    def all_gather_tables(dst, src):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst, src)
+        else:
+            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.cat(parts))
+
+    def all_reduce_sum(t):
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+
+    def all_reduce_max(t):
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
     mgr = HipMgr()
     L = lib()
 
@@ -125,7 +155,11 @@ def main():
     cp = ex.compile(q)
     quads = cp.buffer_quads
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # One explicit (non-default) stream carries everything: the library treats a NULL stream as "my own
+    # stream", which would not be ordered with torch's default stream and hence with the RCCL collective.
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
+    assert stream != 0
     out_t = torch.empty(max(quads, 1), dtype=torch.int64, device="cuda")
     step = ex.prepare(cp, list(range(nfrag)), grid=args.grid, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
     gathered = torch.empty(world * max(quads, 1), dtype=torch.int64, device="cuda") if world > 1 else None
@@ -133,11 +167,15 @@ def main():
     init_vals = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
 
     def one_step():
+        with torch.cuda.stream(tstream):
+            _one_step()
+
+    def _one_step():
         step.init_output(stream)
         step.launch(stream)
         if world > 1:
             # ResultSetReduction over the per-GPU partial tables: all-gather (1.5 KB each) + device merge
-            dist.all_gather_into_tensor(gathered, out_t)
+            all_gather_tables(gathered, out_t)
             that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
             counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
             check(L.hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
@@ -164,7 +202,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_max(tt)
         elapsed = float(tt.item())
 
     ms_buf = (C.c_float * max(args.steps, 1))()
@@ -177,21 +215,30 @@ def main():
     from hdk_amd.executor import ExecutionResult
     res = ExecutionResult(cp, final, cp.entry_count)
     cols = res.to_columns()
+    if os.environ.get("HDK_BENCH_DEBUG"):
+        print(f"[rank {rank}] final[:6]={final[:6].tolist()} out_t[:6]={out_t[:6].cpu().numpy().tolist()} "
+              f"err={int(d_err.item())} quads={quads} keyless={cp.plan.keyless} final.dtype={final.dtype} "
+              f"cols={ {k: v[:3] for k, v in cols.items()} }", file=sys.stderr)
     checks = {}
+    # (1) size-independent property: sum of per-key sums == non-grouped SUM(val) over every rank's rows, and
+    # the row counts add up.  Every rank scans its own rows once more (non-grouped), the totals are combined
+    # with one all-reduce (two's-complement wrap-around is the same on both sides).
+    q2 = QueryUnit("t", targets=[Agg("sum", ColRef("val"), "s"), Agg("count", None, "c")])
+    tot = ex.execute(q2, frag_ids=list(range(nfrag))).to_columns()
+    local_tot = torch.tensor([np.int64(np.uint64(int(tot["s"][0] or 0) % (1 << 64))), int(tot["c"][0])],
+                             dtype=torch.int64, device="cuda")
+    if world > 1:
+        all_reduce_sum(local_tot)
+    all_sum, all_cnt = (int(x) for x in local_tot.cpu().tolist())
+    # (2) idempotence: one more step (all ranks: it contains the collective) gives the identical buffer
+    one_step()
+    torch.cuda.synchronize()
+    again = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
     if rank == 0:
-        # (1) size-independent property: sum of per-key sums == non-grouped SUM(val), counts add up
-        q2 = QueryUnit("t", targets=[Agg("sum", ColRef("val"), "s"), Agg("count", None, "c")])
-        r2 = ex.execute(q2, frag_ids=list(range(nfrag)))
-        tot = r2.to_columns()
         key_sum = sum(v for v in cols["sum_val"] if v is not None)
-        if world == 1:
-            checks["sum_of_sums"] = bool((key_sum - tot["s"][0]) % (1 << 64) == 0)
-            checks["row_count"] = bool(tot["c"][0] == args.rows)
+        checks["sum_of_sums"] = bool((key_sum - all_sum) % (1 << 64) == 0)
+        checks["row_count"] = bool(all_cnt == args.rows * world)
         checks["groups"] = len(cols["key"])
-        # (2) idempotence: a second run gives the identical buffer
-        one_step()
-        torch.cuda.synchronize()
-        again = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
         checks["idempotent"] = bool(np.array_equal(again, final))
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle's HDK-semantics path on a bounded sample -----

@@ -25,6 +25,39 @@ import numpy as np
 from . import _abi as A
 
 
+_side_streams = {}
+
+
+def torch_stream_for_library(device):
+    """(torch stream to run under, raw handle for the C ABI).  The library reads a NULL stream as "my own
+    per-device stream", which is not ordered with torch's default stream (handle 0) nor with the RCCL
+    collectives issued from it.  When the caller is on the default stream, a cached side stream is used
+    and fenced against it on both ends by `run_ordered`."""
+    import torch
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream != 0:
+        return cur, cur.cuda_stream, None
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
+    return side, side.cuda_stream, cur
+
+
+def run_ordered(device, fn):
+    """Run fn(raw_stream_handle) on a torch stream the library can share, ordered after the work already
+    queued on the caller's current stream and before whatever the caller queues next."""
+    import torch
+    ts, handle, fence = torch_stream_for_library(device)
+    if fence is None:
+        return fn(handle)
+    ts.wait_stream(fence)
+    with torch.cuda.stream(ts):
+        out = fn(handle)
+    fence.wait_stream(ts)
+    return out
+
+
 def shard_fragments(num_fragments: int, world_size: int, rank: int) -> List[int]:
     """Fragment f -> rank f mod G (cf. FragmentIDAssignmentExecutionPolicy,
     QE/CostModel/Dispatchers/DefaultExecutionPolicy.cpp:18-26)."""
@@ -66,8 +99,15 @@ def merge_gathered_on_device(cp, gathered, world_size: int, device_id: int, stre
     if d_err is None:
         d_err = torch.zeros(1, dtype=torch.int32, device=gathered.device)
     iv = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
-    check(lib().hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
-                                       world_size - 1, iv.ctypes.data, d_err.data_ptr(), device_id, stream))
+
+    def fold(h):
+        check(lib().hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
+                                           world_size - 1, iv.ctypes.data, d_err.data_ptr(), device_id, h))
+
+    if stream is None:
+        run_ordered(gathered.device, fold)  # never the library's private stream: `gathered` comes from torch
+    else:
+        fold(stream)
     return gathered[:quads]
 
 
@@ -182,10 +222,12 @@ def merge_baseline_on_device(cp, recv, recv_counts: np.ndarray, device_id: int, 
 def reduce_baseline_multi_gpu(cp, table, world_size: int, rank: int, device_id: int, group=None, stream=None):
     """partition -> all-to-all -> owner merge.  Every rank returns its owner table: the query result
     is the concatenation of the ranks' non-empty entries (keys are disjoint across owners)."""
-    import torch
+    def steps(h):
+        send, counts = partition_baseline_on_device(cp, table, world_size, device_id, h)
+        recv, recv_counts = exchange_owner_segments(cp, send, counts, world_size, rank, group)
+        return merge_baseline_on_device(cp, recv, recv_counts, device_id, None, h)
+
     if stream is None and table.is_cuda:
-        # everything -- library kernels, torch copies, the RCCL all-to-all -- is ordered on torch's current stream
-        stream = torch.cuda.current_stream(table.device).cuda_stream
-    send, counts = partition_baseline_on_device(cp, table, world_size, device_id, stream)
-    recv, recv_counts = exchange_owner_segments(cp, send, counts, world_size, rank, group)
-    return merge_baseline_on_device(cp, recv, recv_counts, device_id, None, stream)
+        # library kernels, torch copies and the RCCL all-to-all are all ordered on ONE torch stream
+        return run_ordered(table.device, steps)
+    return steps(stream)

@@ -239,3 +239,34 @@ def test_keyed_join_build_on_device(mgr, oracle, width):
 def mgr_zero(mgr, buf):
     mgr.zeroDeviceMem(buf.ptr, 4, 0)
     return 0
+
+
+@pytest.mark.timeout(900)
+def test_merge_gathered_on_device_orders_with_torch(mgr, oracle):
+    """distributed.merge_gathered_on_device on torch's default stream: the fold must be ordered after the
+    torch ops that produced `gathered` (it used to run on the library's private stream) and before the
+    torch ops that read the result -- no explicit synchronisation in between."""
+    import torch
+    from hdk_amd import distributed as D
+    from hdk_amd.executor import Executor
+    rng = np.random.default_rng(5)
+    n = 300_000
+    st = ArrowStorage()
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    v[rng.random(n) < 0.1] = A.NULL_BIGINT
+    st.import_numpy("t", {"k": rng.integers(0, 200, n).astype(np.int64), "v": v}, fragment_size=50_000)
+    q = QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v")), Agg("count"), Agg("avg", ColRef("v"))])
+    ex = Executor(st, 0, mgr)
+    cp = ex.compile(q)
+    world = 3
+    parts = [ex.execute(cp, frag_ids=D.shard_fragments(6, world, r)).buffer.view(np.int64)[:cp.buffer_quads] for r in range(world)]
+    want = parts[0].copy()
+    for r in range(1, world):
+        assert oracle.reduce(cp.plan, want, cp.entry_count, parts[r], cp.entry_count, cp.init_vals) == 0
+    for _ in range(5):
+        big = torch.randn(1 << 24, device="cuda")  # keep the default stream busy before the gather lands
+        big = big * 2 + 1
+        gathered = torch.cat([torch.from_numpy(p.copy()).cuda() for p in parts]) + (big[:1] * 0).to(torch.int64)
+        merged = D.merge_gathered_on_device(cp, gathered, world, 0)
+        got = (merged + 0).cpu().numpy()
+        assert np.array_equal(got, want)
