@@ -574,7 +574,7 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
                  : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
                                  : reinterpret_cast<const void*>(hdk_scan_project));
-      block = kProjBlock;
+      block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
     } else {
       BaseFastArgs bf;
       if (!generic && match_baseline_fast(p, &bf)) {
@@ -1016,9 +1016,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
       hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
     } else if (plan->num_joins) {
-      hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+      hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);
     } else {
-      hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+      hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlockPlain), 0, s, pa);
     }
     HDK_HIP_CHECK(hipGetLastError());
     st = HDK_HIP_OK;

@@ -15,7 +15,9 @@
 
 namespace hdk {
 
-constexpr int kProjBlock = 256;
+constexpr int kProjBlock = 256;       // row-at-a-time kernel
+constexpr int kProjBlockPlain = 1024;  // batched kernel without joins
+constexpr int kProjBlockJoin = 512;    // batched kernel with inner one-to-one probes
 
 struct ProjArgs {
   const hdk_hip_plan* plan;
@@ -32,9 +34,13 @@ HDK_DEV void store_slot(int8_t* p, int width, int64_t v) {
   }
 }
 
-template <bool J>
+template <bool J, int BLOCK>
 HDK_DEV void scan_project_body(const ProjArgs& a) {
   __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
+  __shared__ uint32_t s_wave_tot[2][BLOCK / kWave];
+  __shared__ uint32_t s_block_base[2];
+  const int wave = threadIdx.x / kWave;
+  uint32_t iter = 0;
   const cplan_t p = to_const_as(a.plan);
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -47,11 +53,11 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
   const uint32_t max_matched = static_cast<uint32_t>(*a.kp.max_matched);
-  constexpr int64_t kTileRows = static_cast<int64_t>(kProjBlock) * VR;
+  constexpr int64_t kTileRows = static_cast<int64_t>(BLOCK) * VR;
   int64_t* buf = a.kp.groupby_buf[0];
 
   VecCtxT<J> c;
-  vec_ctx_init(c, p, tid, kProjBlock);
+  vec_ctx_init(c, p, tid, BLOCK);
   int32_t err = 0;
   int32_t slots_err = 0;
 
@@ -80,14 +86,33 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
           incl += n;
         }
       }
+      // ONE claim per block and tile (2048 rows), not per wave: every claim is an atomic on the same
+      // address (TOTAL_MATCHED) and those serialise at ~10 ns each -- at one per wave-batch (512 rows) they
+      // alone took 5 ms per 256 M rows, whatever the selectivity.  Double-buffered by tile parity so that a
+      // fast wave cannot overwrite the totals a slow wave is still reading.
       const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
-      uint32_t wave_base = 0;
-      if (wave_total) {
-        if (lane == 0) {
-          wave_base = static_cast<uint32_t>(atomicAdd(a.kp.total_matched, static_cast<int32_t>(wave_total)));
-        }
-        wave_base = __shfl(wave_base, 0, kWave);
+      const int par = static_cast<int>(iter & 1);
+      if (lane == 0) {
+        s_wave_tot[par][wave] = wave_total;
       }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) {
+          t += s_wave_tot[par][w];
+        }
+        s_block_base[par] = t ? static_cast<uint32_t>(atomicAdd(a.kp.total_matched, static_cast<int32_t>(t))) : 0u;
+      }
+      __syncthreads();
+      uint32_t wave_base = s_block_base[par];
+#pragma unroll
+      for (int w = 0; w < BLOCK / kWave; ++w) {
+        if (w < wave) {
+          wave_base += s_wave_tot[par][w];
+        }
+      }
+      ++iter;
       uint32_t out_pos = wave_base + incl - mine;
       // ---- project ------------------------------------------------------------------------------
       uint32_t pos_r[VR];
@@ -99,10 +124,24 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
           if (pos_r[r] >= max_matched) {
             slots_err = -1 - static_cast<int32_t>(vrow(c, r) & 0x3fffffff);  // out of slots: negative
             pass[r] = false;
-          } else if (columnar) {
+          }
+        }
+      }
+      // All layout decisions below are wave-uniform and sit OUTSIDE the row loops (one scalar branch per
+      // batch instead of one per row): the kernel is instruction-issue bound, not bandwidth bound.
+      const size_t rq = p->row_size_quad;
+      if (columnar) {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r]) {
             buf[pos_r[r]] = vrow(c, r);  // get_columnar_scan_output_offset
-          } else {
-            buf[static_cast<size_t>(pos_r[r]) * p->row_size_quad] = vrow(c, r);  // get_scan_output_slot
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r]) {
+            buf[static_cast<size_t>(pos_r[r]) * rq] = vrow(c, r);  // get_scan_output_slot
           }
         }
       }
@@ -111,15 +150,21 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
         int64_t v[VR];
         eval_expr_v(c, tg.arg, v, pass, err);
         const int w = tg.slot_width;
-        const int off = tg.slot_off;
-#pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          if (pass[r]) {
-            int8_t* dst = columnar ? reinterpret_cast<int8_t*>(buf) + s_col_off[t] + static_cast<size_t>(pos_r[r]) * w
-                                   : reinterpret_cast<int8_t*>(buf + static_cast<size_t>(pos_r[r]) * p->row_size_quad) + off;
-            store_slot(dst, w, v[r]);
-          }
+        int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + s_col_off[t] : reinterpret_cast<int8_t*>(buf) + tg.slot_off;
+        const size_t stride = columnar ? static_cast<size_t>(w) : rq * 8;
+#define HDK_STORE_ROWS(T)                                                             \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                    \
+    if (pass[r]) {                                                                    \
+      *reinterpret_cast<T*>(base + static_cast<size_t>(pos_r[r]) * stride) = static_cast<T>(v[r]); \
+    }                                                                                 \
+  }
+        switch (w) {
+          case 1: HDK_STORE_ROWS(int8_t) break;
+          case 2: HDK_STORE_ROWS(int16_t) break;
+          case 4: HDK_STORE_ROWS(int32_t) break;
+          default: HDK_STORE_ROWS(int64_t) break;
         }
+#undef HDK_STORE_ROWS
       }
     }
     frag_tile_begin += ntiles;
@@ -131,11 +176,14 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
   }
 }
 
-extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project(ProjArgs a) {
-  scan_project_body<false>(a);
+// Large blocks: the output claim is one same-address atomic per block and tile, so rows per tile =
+// BLOCK x VR is what bounds the claim rate (1024 threads: 8192 rows per claim).  The join variant
+// needs ~190 VGPRs, which caps its block at 512 threads.
+extern "C" __global__ __launch_bounds__(kProjBlockPlain) void hdk_scan_project(ProjArgs a) {
+  scan_project_body<false, kProjBlockPlain>(a);
 }
-extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_join(ProjArgs a) {
-  scan_project_body<true>(a);
+extern "C" __global__ __launch_bounds__(kProjBlockJoin) void hdk_scan_project_join(ProjArgs a) {
+  scan_project_body<true, kProjBlockJoin>(a);
 }
 
 // General form: any join the library accepts (one-to-many and keyed tables, LEFT joins), one row at

@@ -41,7 +41,7 @@ def timed(step, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=256_000_000)
-    ap.add_argument("--only", default="c1,c2,c2n,c3,c3g,q1,q2,q3,q4,c5")
+    ap.add_argument("--only", default="c1,c2,c2n,c3,c3g,q1,q2,q3,q4,c5,p1,p50,pj")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
@@ -50,7 +50,7 @@ def main():
 
     from hdk_amd import _abi as A
     from hdk_amd.executor import Executor
-    from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
+    from hdk_amd.ir import Agg, Cast, Cmp, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, Lit, Proj, QueryUnit, Type
     from hdk_amd.storage import ArrowStorage
 
     n = args.rows
@@ -93,6 +93,13 @@ def main():
         "q4": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime")),
                                            Cast(ColRef("trip_distance"), INT32)],
                          targets=[KeyRef(0), KeyRef(1), KeyRef(2), Agg("count")]), 18),
+        # filter/project: SELECT key, val WHERE key < X (1 % / 50 % of the rows pass); bytes = 16 in + 24 out per passing row
+        "p1": (QueryUnit("t", quals=[Cmp(ColRef("val"), "<", Lit(-2**31 + 2**32 // 100))], output_columnar=True,
+                         targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val"), "val")]), 16 + 0.24),
+        "p50": (QueryUnit("t", quals=[Cmp(ColRef("val"), "<", Lit(0))], output_columnar=True,
+                          targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val"), "val")]), 16 + 12),
+        "pj": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("val"), "<", Lit(-2**31 + 2**32 // 20))],
+                         output_columnar=True, targets=[Proj(ColRef("val"), "val"), Proj(ColRef("dval", "dim"), "dval")]), 16 + 1.2),
         "c5": (QueryUnit("t", groupby=[ColRef("hk")], force_baseline=True,
                          targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
     }
