@@ -415,6 +415,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_agg_global.h"
 #include "scan_agg_vec.h"
 #include "scan_project.h"
+#include "scan_project_fast.h"
 
 using namespace hdk;
 
@@ -489,6 +490,7 @@ struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
 static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
+static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
 
 // Persistent grids are sized from what actually fits: blocks per CU (register / LDS limited) x CUs, so that
 // every block is resident and the static tile walk has no second, partly filled round (the batched
@@ -571,10 +573,16 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
                                  : reinterpret_cast<const void*>(hdk_scan_agg_vec));
       block = scalar ? kBlock : kVecBlock;
     } else if (s.strategy == STRAT_PROJECT) {
-      k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
-                 : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
-                                 : reinterpret_cast<const void*>(hdk_scan_project));
-      block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
+      ProjFastArgs pf;
+      if (!generic && match_project_fast(p, &pf)) {
+        k = reinterpret_cast<const void*>(hdk_scan_project_direct);
+        block = kProjFastBlock;
+      } else {
+        k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
+                   : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
+                                   : reinterpret_cast<const void*>(hdk_scan_project));
+        block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
+      }
     } else {
       BaseFastArgs bf;
       if (!generic && match_baseline_fast(p, &bf)) {
@@ -869,6 +877,60 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
   return true;
 }
 
+// the shape hdk_scan_project_direct takes (scan_project_fast.h)
+static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
+  if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
+  memset(fa, 0, sizeof(*fa));
+  for (int i = 0; i < p->num_quals; ++i) {
+    const hdk_hip_qual& q = p->quals[i];
+    int c;
+    if (!plain_outer_col(p, q.lhs, &c)) return false;
+    if (q.rhs.kind != HDK_LEAF_INT && q.rhs.kind != HDK_LEAF_FP) return false;
+    const hdk_hip_col& col = p->cols[c];
+    ProjFastQual& fq = fa->q[i];
+    fq.col.buf_idx = col.buf_idx;
+    fq.col.width = col.width;
+    fq.col.kind = col.kind;
+    fq.cmp = q.cmp;
+    fq.nullable = q.lhs.leaf0.nullable;
+    fq.null_val = q.lhs.leaf0.null_val;
+    fq.col_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
+    const bool rhs_fp = q.rhs.kind == HDK_LEAF_FP;
+    fq.fp = fq.col_fp || rhs_fp;
+    if (fq.fp && !rhs_fp) {
+      const double d = static_cast<double>(q.rhs.ival);
+      memcpy(&fq.rhs, &d, 8);
+    } else {
+      fq.rhs = q.rhs.ival;
+    }
+  }
+  fa->nquals = p->num_quals;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    int c;
+    if (tg.agg != HDK_AGG_ID || !plain_outer_col(p, tg.arg, &c)) return false;
+    const hdk_hip_col& col = p->cols[c];
+    if (col.kind == HDK_COL_FLOAT) return false;
+    fa->t[t].col.buf_idx = col.buf_idx;
+    fa->t[t].col.width = col.width;
+    fa->t[t].col.kind = col.kind;
+    fa->t[t].slot_width = tg.slot_width;
+    fa->t[t].slot_off = tg.slot_off;
+  }
+  fa->ntargets = p->num_targets;
+  fa->columnar = p->output_columnar;
+  fa->row_size_quad = p->row_size_quad;
+  fa->entry_count = p->entry_count;
+  // columnar target columns: [int64 row positions][target columns, each aligned to 8]
+  size_t off = (static_cast<size_t>(p->entry_count) * 8 + 7) & ~size_t(7);
+  for (int t = 0; t < p->num_targets; ++t) {
+    off = (off + 7) & ~size_t(7);
+    fa->col_off[t] = off;
+    off += static_cast<size_t>(p->entry_count) * p->targets[t].slot_width;
+  }
+  return true;
+}
+
 static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
                                   const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic) {
   BaseFastArgs fa;
@@ -918,6 +980,11 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
   } else if (s.strategy == STRAT_PROJECT) {
+    ProjFastArgs pf;
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    if (!generic && match_project_fast(plan, &pf)) {
+      snprintf(out, out_len, "hdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct");
+    } else
     snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
                                  : plan->num_joins     ? "hdk_scan_project_join"
                                                        : "hdk_scan_project");
@@ -1013,7 +1080,18 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     pa.plan = d_plan;
     pa.kp = kp;
     pa.entry_count = plan->entry_count;
-    if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
+    ProjFastArgs pf;
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    if (!generic && match_project_fast(plan, &pf)) {
+      pf.kp = kp;
+      uint32_t* counts = nullptr;  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
+      HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&counts), static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
+      pf.block_counts = counts;
+      hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
+      hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      HDK_HIP_CHECK(hipFreeAsync(counts, s));
+    } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
       hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
     } else if (plan->num_joins) {
       hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);

@@ -1,0 +1,344 @@
+// scan_project_fast.h -- filter/project, specialised for the plain shape: conjunction of
+// `outer column <cmp> literal` filters, targets that are plain outer columns, no join.
+// Same output contract as hdk_scan_project (RowFuncBuilder.cpp:162-215, GroupByRuntime.cpp:248-272:
+// row position + targets at densely claimed output rows, TOTAL_MATCHED counts every passing row, rows
+// past MAX_MATCHED report a negative code).  What the interpreter cannot do:
+//   * no per-batch interpretation at all: the filter columns are decoded and compared with compile-time
+//     row loops (the interpreter is instruction-issue bound at ~2 ms per 256 M rows);
+//   * target columns are loaded ONLY for passing rows (predicated gathers), so a selective filter reads
+//     little more than the filter columns;
+//   * no output claims at all: pass 1 (MODE 0) only counts the passing rows of each block's tiles, a
+//     one-block scan turns the per-block counts into output offsets (and adds the total to
+//     TOTAL_MATCHED), pass 2 (MODE 1) re-evaluates the filter and writes at offset + running count.
+//     A claim per tile is a same-address atomic on the critical path of every tile (its round trip
+//     under contention, not the bandwidth, set the pace: 1.7 ms per 256 M rows at any selectivity);
+//     reading the filter columns twice costs 8 B/row here and removes it.  Output rows come out in
+//     block-major row order, deterministically.
+#pragma once
+#include "scan_project.h"
+
+namespace hdk {
+
+constexpr int kProjFastBlock = 512;
+constexpr int kProjFastVR = 8;
+constexpr int kProjFastMaxQuals = 3;
+
+struct ProjFastCol {
+  int32_t buf_idx;
+  int32_t width;
+  int32_t kind;
+  int32_t pad_;
+};
+struct ProjFastQual {
+  ProjFastCol col;
+  int32_t cmp;       // hdk_hip_cmp
+  int32_t nullable;
+  int64_t null_val;  // in-band NULL of the column (int64-widened or double bits)
+  int64_t rhs;       // literal: int64, or double bits when the comparison is fp
+  int32_t fp;        // compare as double (column or literal is fp)
+  int32_t col_fp;    // the column holds fp values
+};
+struct ProjFastTarget {
+  ProjFastCol col;
+  int32_t slot_width;
+  int32_t slot_off;  // row-wise: byte offset inside the row
+};
+struct ProjFastArgs {
+  KernParams kp;
+  uint32_t entry_count;  // == *MAX_MATCHED
+  int32_t columnar;
+  uint32_t row_size_quad;
+  int32_t nquals;
+  int32_t ntargets;
+  ProjFastQual q[kProjFastMaxQuals];
+  ProjFastTarget t[HDK_HIP_MAX_TARGETS];
+  uint64_t col_off[HDK_HIP_MAX_TARGETS];  // columnar: byte offset of each target column
+  uint32_t* block_counts;                 // [gridDim.x]: pass-1 counts, then exclusive offsets
+};
+
+// Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
+// and 2k+1 are ADJACENT rows of an 8-byte column, one 16-byte load per lane.  Measured on this kernel the
+// paired form did not pay (counting pass 0.54 vs ~0.6 ms per 256 M rows, write pass 2x slower through
+// the extra predication), so only R = 1 is instantiated; the mapping is kept for the next attempt.
+template <int BLOCK, int R>
+HDK_DEV int64_t pf_row(int64_t tile_row0, int tid, int r) {
+  return R == 1 ? tile_row0 + static_cast<int64_t>(r) * BLOCK + tid
+                : tile_row0 + (static_cast<int64_t>(r >> 1) * BLOCK + tid) * 2 + (r & 1);
+}
+
+typedef long long __attribute__((ext_vector_type(2))) pf_i64x2;
+
+// VR rows of one column: the decoder switch is wave-uniform and sits outside the row loop
+template <int VR, int BLOCK, int R>
+HDK_DEV void load_rows(const int8_t* buf, int width, int kind, int64_t row0, int tid, const bool (&live)[VR], bool nt,
+                       int64_t (&out)[VR]) {
+  if (R == 2) {  // 8-byte columns only (int64 / double bits): pairs of adjacent rows
+#pragma unroll
+    for (int r = 0; r < VR; r += 2) {
+      out[r] = 0;
+      out[r + 1] = 0;
+      const int64_t row = pf_row<BLOCK, R>(row0, tid, r);
+      if (live[r + 1]) {  // both rows inside the fragment
+        const pf_i64x2 x = gload<pf_i64x2>(buf, row >> 1, nt);
+        out[r] = x.x;
+        out[r + 1] = x.y;
+      } else if (live[r]) {
+        out[r] = gload<int64_t>(buf, row, nt);
+      }
+    }
+    return;
+  }
+#define HDK_PF_ROWS(T, CONV)                                                   \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                             \
+    out[r] = 0;                                                                \
+    if (live[r]) {                                                             \
+      const T x = gload<T>(buf, pf_row<BLOCK, R>(row0, tid, r), nt);          \
+      out[r] = CONV;                                                           \
+    }                                                                          \
+  }
+  if (kind == HDK_COL_DOUBLE) {
+    HDK_PF_ROWS(int64_t, x)
+  } else if (kind == HDK_COL_FLOAT) {
+    HDK_PF_ROWS(float, double_to_bits(static_cast<double>(x)))
+  } else if (kind == HDK_COL_UNSIGNED) {
+    switch (width) {
+      case 1: HDK_PF_ROWS(uint8_t, static_cast<int64_t>(x)) break;
+      case 2: HDK_PF_ROWS(uint16_t, static_cast<int64_t>(x)) break;
+      case 4: HDK_PF_ROWS(uint32_t, static_cast<int64_t>(x)) break;
+      default: HDK_PF_ROWS(int64_t, x) break;
+    }
+  } else {
+    switch (width) {
+      case 1: HDK_PF_ROWS(int8_t, static_cast<int64_t>(x)) break;
+      case 2: HDK_PF_ROWS(int16_t, static_cast<int64_t>(x)) break;
+      case 4: HDK_PF_ROWS(int32_t, static_cast<int64_t>(x)) break;
+      default: HDK_PF_ROWS(int64_t, x) break;
+    }
+  }
+#undef HDK_PF_ROWS
+}
+
+HDK_DEV bool proj_fast_cmp(int cmp, bool fp, int64_t l, int64_t r) {
+  if (fp) {
+    const double a = bits_to_double(l), b = bits_to_double(r);
+    switch (cmp) {
+      case HDK_CMP_EQ: return a == b;
+      case HDK_CMP_NE: return a != b;
+      case HDK_CMP_LT: return a < b;
+      case HDK_CMP_GT: return a > b;
+      case HDK_CMP_LE: return a <= b;
+      default: return a >= b;
+    }
+  }
+  switch (cmp) {
+    case HDK_CMP_EQ: return l == r;
+    case HDK_CMP_NE: return l != r;
+    case HDK_CMP_LT: return l < r;
+    case HDK_CMP_GT: return l > r;
+    case HDK_CMP_LE: return l <= r;
+    default: return l >= r;
+  }
+}
+
+template <int MODE, int R>  // MODE 0: count passing rows per block; 1: write them.  R: see pf_row
+HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
+  constexpr int VR = kProjFastVR;
+  constexpr int kWaves = kProjFastBlock / kWave;
+  __shared__ uint32_t s_wave_tot[2][kWaves];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const uint32_t max_matched = static_cast<uint32_t>(*a.kp.max_matched);
+  constexpr int64_t kTileRows = static_cast<int64_t>(kProjFastBlock) * VR;
+  int64_t* buf = a.kp.groupby_buf[0];
+  const bool columnar = a.columnar != 0;
+  int32_t slots_err = 0;
+  uint32_t iter = 0;
+  uint32_t counted = 0;                                        // MODE 0: this thread's passing rows
+  uint32_t running = MODE == 1 ? a.block_counts[blockIdx.x] : 0;  // MODE 1: next output row of the block
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    const int8_t* const* cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
+      bool pass[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
+      }
+      // ---- filter: decode + compare, all VR loads of a column in flight together -----------------------
+      for (int qi = 0; qi < a.nquals; ++qi) {
+        const ProjFastQual q = a.q[qi];
+        const int8_t* qb = cols[q.col.buf_idx];
+        int64_t v[VR];
+        load_rows<VR, kProjFastBlock, R>(qb, q.col.width, q.col.kind, row0, tid, pass, MODE == 1, v);  // pass 1 leaves the lines cached
+        const bool fpc = q.fp != 0;
+        const bool col_fp = q.col_fp != 0;
+        const bool nullable = q.nullable != 0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
+          pass[r] = pass[r] && !isnull;
+          if (fpc && !col_fp) {
+            v[r] = double_to_bits(static_cast<double>(v[r]));
+          }
+        }
+        // the comparison operator is wave-uniform: one switch per batch, the row loop inside each case
+#define HDK_PF_CMP(OP)                                                                                   \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                       \
+    pass[r] = pass[r] && (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs));      \
+  }
+        switch (q.cmp) {
+          case HDK_CMP_EQ: HDK_PF_CMP(==) break;
+          case HDK_CMP_NE: HDK_PF_CMP(!=) break;
+          case HDK_CMP_LT: HDK_PF_CMP(<) break;
+          case HDK_CMP_GT: HDK_PF_CMP(>) break;
+          case HDK_CMP_LE: HDK_PF_CMP(<=) break;
+          default: HDK_PF_CMP(>=) break;
+        }
+#undef HDK_PF_CMP
+      }
+      uint32_t mine = 0;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        mine += pass[r] ? 1u : 0u;
+      }
+      if (MODE == 0) {
+        counted += mine;
+        continue;
+      }
+      // ---- selection vector -> dense output positions inside the block's range ------------------------
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t n = __shfl_up(incl, d, kWave);
+        if (lane >= d) {
+          incl += n;
+        }
+      }
+      const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one tile ahead
+      if (lane == kWave - 1) {
+        s_wave_tot[par][wave] = incl;
+      }
+      __syncthreads();
+      uint32_t out_pos = running + incl - mine;
+      uint32_t tile_total = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t t = s_wave_tot[par][w];
+        tile_total += t;
+        if (w < wave) {
+          out_pos += t;
+        }
+      }
+      running += tile_total;
+      ++iter;
+      uint32_t pos_r[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        pos_r[r] = out_pos;
+        if (pass[r]) {
+          ++out_pos;
+          if (pos_r[r] >= max_matched) {
+            slots_err = -1 - static_cast<int32_t>(pf_row<kProjFastBlock, R>(row0, tid, r) & 0x3fffffff);
+            pass[r] = false;
+          }
+        }
+      }
+      // ---- project: row position, then each target column (loads only for passing rows) ---------------
+      const size_t rq = a.row_size_quad;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        if (pass[r]) {
+          buf[columnar ? static_cast<size_t>(pos_r[r]) : static_cast<size_t>(pos_r[r]) * rq] =
+              pf_row<kProjFastBlock, R>(row0, tid, r);
+        }
+      }
+      for (int ti = 0; ti < a.ntargets; ++ti) {
+        const ProjFastTarget t = a.t[ti];
+        const int8_t* tb = cols[t.col.buf_idx];
+        int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
+        const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
+        int64_t v[VR];
+        load_rows<VR, kProjFastBlock, R>(tb, t.col.width, t.col.kind, row0, tid, pass, true, v);
+#define HDK_PF_STORE(T)                                                                              \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                   \
+    if (pass[r]) {                                                                                   \
+      *reinterpret_cast<T*>(base + static_cast<size_t>(pos_r[r]) * stride) = static_cast<T>(v[r]);   \
+    }                                                                                                \
+  }
+        switch (t.slot_width) {
+          case 1: HDK_PF_STORE(int8_t) break;
+          case 2: HDK_PF_STORE(int16_t) break;
+          case 4: HDK_PF_STORE(int32_t) break;
+          default: HDK_PF_STORE(int64_t) break;
+        }
+#undef HDK_PF_STORE
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (MODE == 0) {
+    // block total -> block_counts[block]
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      counted += __shfl_down(counted, d, kWave);
+    }
+    if (lane == 0) {
+      s_wave_tot[0][wave] = counted;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        t += s_wave_tot[0][w];
+      }
+      a.block_counts[blockIdx.x] = t;
+    }
+  } else if (slots_err) {
+    atomicCAS(a.kp.error_code, 0, slots_err);  // negative = ran out of slots (benign under a LIMIT)
+  }
+}
+
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_count(ProjFastArgs a) {
+  scan_project_direct_body<0, 1>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct(ProjFastArgs a) {
+  scan_project_direct_body<1, 1>(a);
+}
+// per-block counts -> exclusive offsets (in place); the grand total is added to TOTAL_MATCHED
+extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint32_t* counts, uint32_t n, int32_t* total_matched) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = tid * per;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    sum += counts[i];
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const uint32_t v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? s_part[tid - 1] : 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = counts[i];
+    counts[i] = run;
+    run += c;
+  }
+  if (tid == 1023) {
+    atomicAdd(total_matched, static_cast<int32_t>(s_part[1023]));
+  }
+}
+
+}  // namespace hdk

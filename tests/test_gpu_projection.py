@@ -64,3 +64,48 @@ def test_project_with_join_and_limit(oracle, gpu_executor_factory):
     cpf, wantf, _, nf_rows = run_projection_oracle(oracle, st, full)
     allrows = {tuple(r) for r in _sorted_rows(cpf, wantf, nf_rows).tolist()}
     assert all(tuple(r) in allrows for r in got.tolist())  # any 1000 of the qualifying rows
+
+
+@pytest.mark.parametrize("columnar", [False, True])
+def test_direct_filter_project_kernel(oracle, gpu_executor_factory, columnar):
+    """hdk_scan_project_direct (plain-column filters and targets): mixed widths, NULLs, fp and int compares,
+    ragged tails, a LIMIT that fills up -- against the oracle and against the interpreter kernel."""
+    rng = np.random.default_rng(18)
+    n = 900_001
+    a = rng.integers(0, 1000, n).astype(np.int64)
+    b = rng.integers(-500, 500, n).astype(np.int32)
+    b[rng.random(n) < 0.05] = A.NULL_INT
+    s = rng.integers(-100, 100, n).astype(np.int8)
+    h = rng.integers(0, 30000, n).astype(np.int16)
+    d = rng.normal(size=n)
+    d[rng.random(n) < 0.05] = np.frombuffer(np.int64(A.NULL_DOUBLE_BITS).tobytes(), dtype=np.float64)[0]
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": a, "b": b, "s": s, "h": h, "d": d}, fragment_size=230_003)
+    cases = [
+        ([Cmp(ColRef("a"), ">=", Lit(990))], ["a", "b", "d", "s", "h"]),
+        ([Cmp(ColRef("b"), "<", Lit(0)), Cmp(ColRef("d"), ">", Lit(0.25))], ["b", "d"]),
+        ([Cmp(ColRef("s"), "<>", Lit(7)), Cmp(ColRef("h"), "<=", Lit(20000)), Cmp(ColRef("b"), ">", Lit(1.5))], ["h", "a"]),
+        ([], ["s", "b"]),
+        ([Cmp(ColRef("d"), "<", Lit(-3))], ["d"]),
+    ]
+    ex = gpu_executor_factory(st)
+    for quals, cols in cases:
+        q = QueryUnit("t", quals=quals, output_columnar=columnar, targets=[Proj(ColRef(c), c) for c in cols])
+        cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+        assert err == 0
+        step = ex.prepare(cp)
+        assert step.kernel_names().endswith("hdk_scan_project_direct")
+        res = step.run()
+        step.free()
+        assert res.total_matched == nrows
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
+        res2 = ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC)
+        assert res2.total_matched == nrows
+        assert np.array_equal(_sorted_rows(cp, res2.buffer, nrows), _sorted_rows(cp, want, nrows))
+    q = QueryUnit("t", quals=[Cmp(ColRef("a"), "<", Lit(500))], output_columnar=columnar, scan_limit=5000,
+                  targets=[Proj(ColRef("a"), "a"), Proj(ColRef("b"), "b")])
+    cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+    res = ex.execute(cp)
+    assert res.total_matched == nrows == int((a < 500).sum()) and res.error_code < 0
+    got = rs.to_columns(cp, res.buffer, nrows=5000)
+    assert len(got["a"]) == 5000 and all(x < 500 for x in got["a"])
