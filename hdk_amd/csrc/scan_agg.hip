@@ -504,7 +504,6 @@ static uint32_t resident_grid(const void* kernel, int block, size_t lds_bytes, c
   }
   return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
 }
-static bool plan_matches_direct(const hdk_hip_plan* p, const LaunchShape& shape);
 
 LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko,
                          const hdk_hip_device_properties* props) {
@@ -730,12 +729,6 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   *kw_out = kw;
   *vw_out = vw;
   return true;
-}
-
-static bool plan_matches_direct(const hdk_hip_plan* p, const LaunchShape& shape) {
-  FastArgs fa;
-  int kw, vw;
-  return match_fast(p, shape, &fa, &kw, &vw);
 }
 
 template <int KW, int VW, int FIXED>

@@ -101,14 +101,6 @@ HDK_DEV void vec_ctx_tile(VecCtx& c, int64_t row0, int64_t nrows, bool (&pass)[V
   }
 }
 
-template <typename F>
-HDK_DEV void for_rows(F&& f) {
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    f(r);
-  }
-}
-
 // row of batch slot r in the table a column lives in (0 = outer; 1/2 = matched row of join 0/1)
 template <class VecCtx>
 HDK_DEV int64_t leaf_row(const VecCtx& c, int table, int r) {
