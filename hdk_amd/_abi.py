@@ -59,6 +59,7 @@ LAUNCH_FORCE_GLOBAL_ATOMICS = 1
 LAUNCH_RECORD_EVENTS = 2
 LAUNCH_FORCE_GENERIC = 4
 LAUNCH_FORCE_SCALAR = 8
+LAUNCH_FORCE_PARTITIONED = 16
 
 
 class Col(C.Structure):
@@ -119,7 +120,7 @@ class Plan(C.Structure):
 
 class KernelOptions(C.Structure):
     _fields_ = [("grid_dim_x", C.c_uint32), ("block_dim_x", C.c_uint32),
-                ("shared_mem_bytes", C.c_uint32), ("flags", C.c_uint32)]
+                ("shared_mem_bytes", C.c_uint32), ("flags", C.c_uint32), ("total_rows", C.c_uint64)]
 
 
 class DeviceProperties(C.Structure):

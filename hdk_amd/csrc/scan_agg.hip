@@ -412,6 +412,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "launch_common.h"
 #include "scan_agg_fast.h"
 #include "scan_agg_baseline_fast.h"
+#include "scan_agg_partitioned.h"
 #include "scan_agg_global.h"
 #include "scan_agg_vec.h"
 #include "scan_project.h"
@@ -870,6 +871,117 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
   return true;
 }
 
+// ---- radix-partitioned open-addressing group-by (scan_agg_partitioned.h) -------------------------------
+// Taken for the hdk_scan_agg_baseline_direct shape when the table is large enough that the memory-side
+// atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
+static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
+  BaseFastArgs bf;
+  if (!match_baseline_fast(p, &bf)) return false;
+  if (!ko || ko->total_rows == 0) return false;
+  const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
+  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
+  if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
+  if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < kPartP1) return false;
+  memset(pa, 0, sizeof(*pa));
+  pa->key_buf_idx = bf.key_buf_idx;
+  pa->key_width = bf.key_width;
+  pa->key_kind = bf.key_kind;
+  for (int t = 0; t < bf.ntargets; ++t) {
+    const BaseFastTarget& ft = bf.tg[t];
+    int word = 0;
+    if (ft.buf_idx >= 0) {
+      for (int k = 0; k < pa->nargs; ++k) {
+        if (pa->arg[k].buf_idx == ft.buf_idx) word = 1 + k;
+      }
+      if (!word) {
+        if (pa->nargs == kPartMaxArgs) return false;
+        pa->arg[pa->nargs] = ft;
+        word = 1 + pa->nargs++;
+      }
+    }
+    pa->tgt_index[t] = ft.target;
+    pa->tgt_arg[t] = word;
+  }
+  pa->ntargets = bf.ntargets;
+  pa->tw = 1 + pa->nargs;
+  pa->entry_count = p->entry_count;
+  // fine partitions: as many as it takes for a region (slots x row) to fit the LDS budget, a multiple of P1
+  uint32_t slots = kPartLdsWords / p->row_size_quad;
+  uint32_t pf = (p->entry_count + slots - 1) / slots;
+  uint32_t p2 = (pf + kPartP1 - 1) / kPartP1;
+  if (p2 > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 32 K fine partitions: a third level would be needed
+  pf = p2 * kPartP1;
+  slots = p->entry_count / pf;
+  if (slots < 16) return false;
+  pa->slots = slots;
+  pa->fine_count = pf;
+  pa->p2 = p2;
+  const uint64_t rows = ko->total_rows;
+  pa->cap1 = rows / kPartP1 + rows / (kPartP1 * 16) + 8192;  // uniform hash: sigma ~ sqrt(rows/P1); 6 % + 8 K slack
+  pa->cap2 = rows / pf + rows / (pf * 4) + 256;               // 25 % + 256
+  pa->cap_ovf = rows / 16 + 4096;
+  return true;
+}
+
+static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                       PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
+                                       hipStream_t s) {
+  pa.plan = d_plan;
+  pa.kp = kp;
+  const size_t tw = static_cast<size_t>(pa.tw);
+  const size_t b1 = static_cast<size_t>(kPartP1) * pa.cap1 * tw * 8;
+  const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
+  const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
+  const size_t bc = (static_cast<size_t>(kPartP1) + pa.fine_count + 2) * sizeof(uint32_t);
+  int8_t* scratch = nullptr;
+  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), b1 + b2 + bo + bc + 1024, s);
+  if (me != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("radix-partitioned group-by: %zu bytes of scratch: %s", b1 + b2 + bo + bc, hipGetErrorString(me));
+    return HDK_HIP_ERR_OUT_OF_GPU_MEM;
+  }
+  pa.slab1 = reinterpret_cast<int64_t*>(scratch);
+  pa.slab2 = reinterpret_cast<int64_t*>(scratch + b1);
+  pa.ovf = reinterpret_cast<int64_t*>(scratch + b1 + b2);
+  pa.fill1 = reinterpret_cast<uint32_t*>(scratch + b1 + b2 + bo);
+  pa.fill2 = pa.fill1 + kPartP1;
+  pa.fill_ovf = pa.fill2 + pa.fine_count;
+  pa.fallback = pa.fill_ovf + 1;
+  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
+  const bool k32 = plan->key_width == 4;
+  const size_t stage_bytes = static_cast<size_t>(kPartTile) * tw * 8;
+  const unsigned g1 = static_cast<unsigned>(props->num_cu) * 3;
+  const unsigned g2x = 16;
+  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
+  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
+  if (k32) {
+    hipLaunchKernelGGL((hdk_part_scatter<1, int32_t>), dim3(g1), dim3(kPartBlock), stage_bytes, s, pa);
+    hipLaunchKernelGGL((hdk_part_scatter<2, int32_t>), dim3(g2x, kPartP1), dim3(kPartBlock), stage_bytes, s, pa);
+    hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  } else {
+    hipLaunchKernelGGL((hdk_part_scatter<1, int64_t>), dim3(g1), dim3(kPartBlock), stage_bytes, s, pa);
+    hipLaunchKernelGGL((hdk_part_scatter<2, int64_t>), dim3(g2x, kPartP1), dim3(kPartBlock), stage_bytes, s, pa);
+    hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  }
+  // armed fallback: runs only if the scatter passes found the data too skewed for slabs
+  BaseFastArgs bf;
+  match_baseline_fast(plan, &bf);
+  bf.plan = d_plan;
+  bf.kp = kp;
+  bf.entry_count = shape.entry_count;
+  bf.run_if = pa.fallback;
+  if (k32) {
+    hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int32_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, bf);
+  } else {
+    hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int64_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, bf);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  HDK_HIP_CHECK(hipFreeAsync(scratch, s));
+  return HDK_HIP_OK;
+}
+
 // the shape hdk_scan_project_direct takes (scan_project_fast.h)
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
   if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
@@ -983,7 +1095,11 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
                                                        : "hdk_scan_project");
   } else {
     BaseFastArgs fa;
+    PartArgs part;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
+      snprintf(out, out_len, "hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate,hdk_part_overflow,hdk_scan_agg_baseline_direct");
+    } else
     snprintf(out, out_len, "%s", !generic && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
                                                                              : "hdk_scan_agg_global");
   }
@@ -1094,8 +1210,14 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_HIP_CHECK(hipGetLastError());
     st = HDK_HIP_OK;
   } else {
-    st = launch_scan_global(plan, d_plan, kp, shape, s,
-                            ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
+    PartArgs part;
+    if (shape.strategy == STRAT_GLOBAL && !(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) &&
+        match_partitioned(plan, ko, &part)) {
+      st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
+    } else {
+      st = launch_scan_global(plan, d_plan, kp, shape, s,
+                              ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
+    }
   }
   if (st) return st;
   if (timed) {

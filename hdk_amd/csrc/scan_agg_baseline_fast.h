@@ -37,6 +37,7 @@ struct BaseFastArgs {
   int32_t key_kind;
   int32_t ntargets;
   BaseFastTarget tg[HDK_HIP_MAX_TARGETS];
+  const uint32_t* run_if;  // nullptr: always run; else run only when *run_if != 0 (fallback of the partitioned path)
 };
 
 typedef long long __attribute__((ext_vector_type(2))) bf_i64x2;
@@ -55,6 +56,9 @@ HDK_DEV void g_agg64_seen(int agg, bool fp, bool skip, int64_t nullv, int64_t* s
 
 template <typename K>  // key type of the TABLE (int32_t or int64_t)
 __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(BaseFastArgs a) {
+  if (a.run_if && *a.run_if == 0) {
+    return;
+  }
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
   const uint64_t nfrag = *a.kp.num_fragments;

@@ -97,10 +97,11 @@ class PreparedStep:
         self.L = lib()
         self.keep: List[DeviceBuffer] = []
         p = cp.plan
-        self.ko = A.KernelOptions(grid, 0, 0, flags)
         storage = ex.storage
         outer = storage.get(cp.query.table)
         nfrag = len(self.frag_ids)
+        self.rows_in_step = int(sum(outer.frag_rows[f] for f in self.frag_ids))
+        self.ko = A.KernelOptions(grid, 0, 0, flags, self.rows_in_step)
         ntab = 1 + len(cp.inner_tables)
 
         # ---- join hash tables (built once per device, cached) ----------------------------

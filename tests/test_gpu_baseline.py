@@ -213,3 +213,42 @@ def test_baseline_fast_kernel_shapes(oracle, gpu_executor_factory):
     with pytest.raises(HdkHipError) as ei:
         ex.execute(q)
     assert ei.value.code == A.ERR_OUT_OF_SLOTS
+
+
+def test_radix_partitioned_group_by(oracle, gpu_executor_factory):
+    """The radix-partitioned open-addressing path (scatter x2 -> LDS aggregation per slot range -> overflow
+    tuples with atomics), forced on small inputs: uniform keys, 4- and 8-byte table keys, several targets,
+    and a heavy-hitter key that overflows its slab (pass 4)."""
+    rng = np.random.default_rng(2718)
+    n = 600_011
+    k32 = rng.integers(-90_000, 90_000, n).astype(np.int32)
+    k64 = rng.integers(0, 70_000, n, dtype=np.int64) * 3_000_000_019 - 2**40
+    hot = k64.copy()
+    hot[rng.random(n) < 0.4] = 12345678901234  # 40 % of the rows share one key: beyond the overflow area -> fallback
+    warm = k64.copy()
+    warm[rng.random(n) < 0.03] = 98765432101234  # 3 %: overflows its fine slab, fits the overflow area (pass 4)
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    i32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    i32[rng.random(n) < 0.05] = A.NULL_INT
+    d = rng.normal(size=n)
+    st = ArrowStorage()
+    st.import_numpy("t", {"k32": k32, "k64": k64, "hot": hot, "warm": warm, "v": v, "i32": i32, "d": d},
+                    fragment_size=149_993)
+    shapes = [
+        ("k32", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s")]),
+        ("warm", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")]),
+        ("k64", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c"), Agg("min", ColRef("v"), "mn")]),
+        ("k64", [KeyRef(0, "k"), Agg("avg", ColRef("d"), "ad"), Agg("max", ColRef("i32"), "mx"), Agg("count", ColRef("i32"), "ci")]),
+        ("hot", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")]),
+    ]
+    ex = gpu_executor_factory(st)
+    for kc, targets in shapes:
+        q = QueryUnit("t", groupby=[ColRef(kc)], force_baseline=True, baseline_entry_count=400_009, targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+        assert step.kernel_names().startswith("hdk_part_scatter"), step.kernel_names()
+        res = step.run()
+        step.free()
+        _check_rows(cp, res.buffer, want)
