@@ -85,6 +85,7 @@ EXTRA_SIGNATURES = {
     "hdk_hip_sizeof_qual": (sz, []),
     "hdk_hip_sizeof_join": (sz, []),
     "hdk_hip_sizeof_device_properties": (sz, []),
+    "hdk_hip_sizeof_kernel_options": (sz, []),
 }
 
 

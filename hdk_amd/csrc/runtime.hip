@@ -249,5 +249,6 @@ size_t hdk_hip_sizeof_target(void) { return sizeof(hdk_hip_target); }
 size_t hdk_hip_sizeof_qual(void) { return sizeof(hdk_hip_qual); }
 size_t hdk_hip_sizeof_join(void) { return sizeof(hdk_hip_join); }
 size_t hdk_hip_sizeof_device_properties(void) { return sizeof(hdk_hip_device_properties); }
+size_t hdk_hip_sizeof_kernel_options(void) { return sizeof(hdk_hip_kernel_options); }
 
 }  // extern "C"

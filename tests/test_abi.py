@@ -30,6 +30,7 @@ def test_struct_sizes_match():
     assert C.sizeof(A.Qual) == L.hdk_hip_sizeof_qual()
     assert C.sizeof(A.Join) == L.hdk_hip_sizeof_join()
     assert C.sizeof(A.DeviceProperties) == L.hdk_hip_sizeof_device_properties()
+    assert C.sizeof(A.KernelOptions) == L.hdk_hip_sizeof_kernel_options()
 
 
 def test_no_gpu_is_reported_not_hidden():
