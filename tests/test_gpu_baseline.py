@@ -252,3 +252,26 @@ def test_radix_partitioned_group_by(oracle, gpu_executor_factory):
         res = step.run()
         step.free()
         _check_rows(cp, res.buffer, want)
+
+
+def test_radix_partitioned_two_levels(oracle, gpu_executor_factory):
+    """A table large enough that the second scatter level really splits (P2 > 1): 2 M-entry table, 1.5 M
+    rows -> 640 fine partitions in 128 coarse slabs; every group and aggregate against the oracle."""
+    rng = np.random.default_rng(31415)
+    n = 1_500_007
+    key = rng.integers(0, 700_000, n, dtype=np.int64) * 1_000_003 - 10**11
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.03] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": key, "v": v}, fragment_size=400_000)
+    q = QueryUnit("t", groupby=[ColRef("key")], force_baseline=True, baseline_entry_count=2_000_003,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+    assert step.kernel_names().startswith("hdk_part_scatter")
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    assert res.row_count() == len(np.unique(key))
