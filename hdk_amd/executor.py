@@ -255,6 +255,11 @@ class PreparedStep:
             check(self.L.hdk_hip_init_group_by_buffer(
                 self.out_ptr, self.d_init.ptr, 1, 0, 8, len(self.cp.slot_widths), 1, 1,
                 props.max_threads_per_block, props.grid_size, self.dev, stream))
+        elif p.query_kind == A.Q_PROJECTION and not self.ex.init_projection_buffers:
+            # The reference fills projection buffers like any other (QueryMemoryInitializer.cpp:1103-1153), but
+            # every claimed output row is written completely (row position + each target) and nothing past
+            # TOTAL_MATCHED is ever read: the fill (6 GB for a 256 M-row scan) is skipped unless asked for.
+            pass
         elif p.output_columnar:
             check(self.L.hdk_hip_init_columnar_group_by_buffer(
                 self.out_ptr, self.d_init_raw.ptr, p.entry_count, eff_key_count(p), len(self.cp.slot_widths),
@@ -312,6 +317,7 @@ class Executor:
         self._join_cache: Dict[tuple, DeviceBuffer] = {}
         self._fused_cache: Dict[tuple, DeviceBuffer] = {}
         self.fuse_join_tables = True  # HDK_JOIN_ONE_TO_ONE_FUSED for the batched kernels
+        self.init_projection_buffers = False  # see PreparedStep.init_output
 
     def compile(self, q: QueryUnit) -> CompiledPlan:
         return compile_query(self.storage, q)
