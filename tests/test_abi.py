@@ -46,3 +46,39 @@ def test_no_gpu_is_reported_not_hidden():
 
 def test_version():
     assert _lib.lib().hdk_hip_version() >= 1000
+
+
+def test_plan_validation_errors_without_a_gpu():
+    """validate_plan runs on the host before anything touches a device: malformed plans come back as
+    HDK_HIP_ERR_INVALID_ARG / UNSUPPORTED with a message, never as a crash (no exception crosses the ABI)."""
+    import copy
+    import numpy as np
+    from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
+    from hdk_amd.plan import compile_query
+    from hdk_amd.storage import ArrowStorage
+    L = _lib.lib()
+    L.hdk_hip_last_error.restype = C.c_char_p
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": np.arange(100, dtype=np.int64) * 1_000_003, "v": np.arange(100, dtype=np.int64)})
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=1000,
+                                     targets=[KeyRef(0), Agg("sum", ColRef("v"))]))
+    q = C.c_int64(0)
+    assert L.hdk_hip_baseline_table_quads(C.byref(cp.plan), 10, C.byref(q)) == A.OK and q.value == 10 * cp.plan.row_size_quad
+
+    def broken(mutate):
+        p = copy.deepcopy(cp.plan) if False else type(cp.plan).from_buffer_copy(cp.plan)
+        mutate(p)
+        rc = L.hdk_hip_baseline_table_quads(C.byref(p), 10, C.byref(q))
+        return rc, (L.hdk_hip_last_error() or b"").decode()
+
+    rc, msg = broken(lambda p: setattr(p, "abi_version", 1))
+    assert rc == A.ERR_INVALID_ARG and "ABI" in msg
+    rc, msg = broken(lambda p: setattr(p, "num_targets", 99))
+    assert rc == A.ERR_INVALID_ARG and "num_targets" in msg
+    rc, msg = broken(lambda p: setattr(p, "query_kind", 17))
+    assert rc == A.ERR_INVALID_ARG
+    rc, msg = broken(lambda p: setattr(p.targets[1], "slot_width", 3))
+    assert rc == A.ERR_INVALID_ARG and "slot width" in msg
+    rc, msg = broken(lambda p: setattr(p, "query_kind", A.Q_PERFECT_HASH))  # not a baseline plan any more
+    assert rc == A.ERR_INVALID_ARG
+    assert L.hdk_hip_baseline_table_quads(None, 10, C.byref(q)) == A.ERR_INVALID_ARG
