@@ -833,9 +833,38 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   return HDK_HIP_OK;
 }
 
+// filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape
+static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
+  if (p->num_quals > kMaxPlainQuals) return false;
+  for (int i = 0; i < p->num_quals; ++i) {
+    const hdk_hip_qual& q = p->quals[i];
+    int c;
+    if (!plain_outer_col(p, q.lhs, &c)) return false;
+    if (q.rhs.kind != HDK_LEAF_INT && q.rhs.kind != HDK_LEAF_FP) return false;
+    const hdk_hip_col& col = p->cols[c];
+    ProjFastQual& fq = out[i];
+    fq.col.buf_idx = col.buf_idx;
+    fq.col.width = col.width;
+    fq.col.kind = col.kind;
+    fq.cmp = q.cmp;
+    fq.nullable = q.lhs.leaf0.nullable;
+    fq.null_val = q.lhs.leaf0.null_val;
+    fq.col_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
+    const bool rhs_fp = q.rhs.kind == HDK_LEAF_FP;
+    fq.fp = fq.col_fp || rhs_fp;
+    if (fq.fp && !rhs_fp) {
+      const double d = static_cast<double>(q.rhs.ival);
+      memcpy(&fq.rhs, &d, 8);
+    } else {
+      fq.rhs = q.rhs.ival;
+    }
+  }
+  return true;
+}
+
 // the shape hdk_scan_agg_baseline_direct takes (scan_agg_baseline_fast.h)
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
-  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_quals || p->num_joins || p->key_count != 1) {
+  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_joins || p->key_count != 1) {
     return false;
   }
   int kc;
@@ -844,6 +873,8 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
   fa->key_buf_idx = p->cols[kc].buf_idx;
   fa->key_width = p->cols[kc].width;
   fa->key_kind = p->cols[kc].kind;
+  if (!match_plain_quals(p, fa->q)) return false;
+  fa->nquals = p->num_quals;
   int n = 0;
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
@@ -886,6 +917,8 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->key_buf_idx = bf.key_buf_idx;
   pa->key_width = bf.key_width;
   pa->key_kind = bf.key_kind;
+  pa->nquals = bf.nquals;
+  for (int i = 0; i < bf.nquals; ++i) pa->q[i] = bf.q[i];
   for (int t = 0; t < bf.ntargets; ++t) {
     const BaseFastTarget& ft = bf.tg[t];
     int word = 0;
@@ -986,29 +1019,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
   if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
   memset(fa, 0, sizeof(*fa));
-  for (int i = 0; i < p->num_quals; ++i) {
-    const hdk_hip_qual& q = p->quals[i];
-    int c;
-    if (!plain_outer_col(p, q.lhs, &c)) return false;
-    if (q.rhs.kind != HDK_LEAF_INT && q.rhs.kind != HDK_LEAF_FP) return false;
-    const hdk_hip_col& col = p->cols[c];
-    ProjFastQual& fq = fa->q[i];
-    fq.col.buf_idx = col.buf_idx;
-    fq.col.width = col.width;
-    fq.col.kind = col.kind;
-    fq.cmp = q.cmp;
-    fq.nullable = q.lhs.leaf0.nullable;
-    fq.null_val = q.lhs.leaf0.null_val;
-    fq.col_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
-    const bool rhs_fp = q.rhs.kind == HDK_LEAF_FP;
-    fq.fp = fq.col_fp || rhs_fp;
-    if (fq.fp && !rhs_fp) {
-      const double d = static_cast<double>(q.rhs.ival);
-      memcpy(&fq.rhs, &d, 8);
-    } else {
-      fq.rhs = q.rhs.ival;
-    }
-  }
+  if (!match_plain_quals(p, fa->q)) return false;
   fa->nquals = p->num_quals;
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];

@@ -1,6 +1,7 @@
 // scan_agg_baseline_fast.h -- open-addressing group-by, specialised for the common shape
 // (BASELINE C5): GroupByBaselineHash, row-wise, ONE group key that is a plain integer column of the
-// outer table, no filter, no join, targets = projected key / COUNT / SUM / MIN / MAX / AVG over plain
+// outer table, filters of the form `column cmp literal` only, no join, targets = projected key / COUNT / SUM /
+// MIN / MAX / AVG over plain
 // outer columns.  Same table, same claim protocol, same agg_* semantics as hdk_scan_agg_global
 // (reference get_group_value + agg_*_shared, QE/cuda_mapd_rt.cu:167-261,424-478); what changes is
 // the shape of the memory traffic, priced against scripts/microbench/atomics.hip:
@@ -14,6 +15,7 @@
 //     slot that has since moved on; both fall into the atomic slow path (CAS), which is exact;
 //   * everything else (probe collisions, fresh claims, wide rows) takes find_or_claim / g_agg* as is.
 #pragma once
+#include "plain_quals.h"
 #include "scan_agg_global.h"
 
 namespace hdk {
@@ -38,6 +40,8 @@ struct BaseFastArgs {
   int32_t ntargets;
   BaseFastTarget tg[HDK_HIP_MAX_TARGETS];
   const uint32_t* run_if;  // nullptr: always run; else run only when *run_if != 0 (fallback of the partitioned path)
+  int32_t nquals;          // plain filters `outer column cmp literal` (plain_quals.h)
+  ProjFastQual q[kMaxPlainQuals];
 };
 
 typedef long long __attribute__((ext_vector_type(2))) bf_i64x2;
@@ -89,6 +93,12 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
         const int64_t rr = row0 + static_cast<int64_t>(r) * kBaseFastBlock + tid;
         live[r] = rr < nrows;
         row[r] = live[r] ? rr : row0;
+      }
+      if (a.nquals) {
+        plain_quals_pass<VR>(a.q, a.nquals, cols, row, live, true);
+      }
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
         key[r] = static_cast<K>(decode_col_g(keybuf, a.key_width, a.key_kind, row[r], true));
       }
 #pragma unroll

@@ -58,6 +58,8 @@ struct PartArgs {
   uint32_t* fill2;       // [fine_count]
   uint32_t* fill_ovf;    // [1]
   uint32_t* fallback;    // [1]: set when the overflow area is exhausted -> the atomics kernel takes over
+  int32_t nquals;        // plain filters, applied in pass 1
+  ProjFastQual q[kMaxPlainQuals];
 };
 
 template <typename K>
@@ -239,6 +241,14 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
           live[r] = row0 + static_cast<int64_t>(r) * kPartBlock < nrows;
+        }
+        if (a.nquals) {
+          int64_t rows[VR];
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            rows[r] = row0 + static_cast<int64_t>(r) * kPartBlock;
+          }
+          plain_quals_pass<VR>(a.q, a.nquals, cols, rows, live, true);
         }
 #pragma unroll
         for (int r = 0; r < VR; ++r) {

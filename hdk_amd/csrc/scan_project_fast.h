@@ -15,29 +15,15 @@
 //     reading the filter columns twice costs 8 B/row here and removes it.  Output rows come out in
 //     block-major row order, deterministically.
 #pragma once
+#include "plain_quals.h"
 #include "scan_project.h"
 
 namespace hdk {
 
 constexpr int kProjFastBlock = 512;
 constexpr int kProjFastVR = 8;
-constexpr int kProjFastMaxQuals = 3;
+constexpr int kProjFastMaxQuals = kMaxPlainQuals;
 
-struct ProjFastCol {
-  int32_t buf_idx;
-  int32_t width;
-  int32_t kind;
-  int32_t pad_;
-};
-struct ProjFastQual {
-  ProjFastCol col;
-  int32_t cmp;       // hdk_hip_cmp
-  int32_t nullable;
-  int64_t null_val;  // in-band NULL of the column (int64-widened or double bits)
-  int64_t rhs;       // literal: int64, or double bits when the comparison is fp
-  int32_t fp;        // compare as double (column or literal is fp)
-  int32_t col_fp;    // the column holds fp values
-};
 struct ProjFastTarget {
   ProjFastCol col;
   int32_t slot_width;

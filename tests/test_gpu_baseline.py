@@ -196,9 +196,13 @@ def test_baseline_fast_kernel_shapes(oracle, gpu_executor_factory):
                  Agg("count", ColRef("i32"), "ci"), Agg("sum", ColRef("d"), "sd")]),
         ("k32", [KeyRef(0, "k"), Agg("count", None, "c")]),
     ]
+    from hdk_amd.ir import Cmp, Lit
+    filters = [[], [Cmp(ColRef("i32"), ">", Lit(-200)), Cmp(ColRef("d"), "<", Lit(55.5))]]
     ex = gpu_executor_factory(st)
-    for kc, targets in shapes:
-        q = QueryUnit("t", groupby=[ColRef(kc)], force_baseline=True, baseline_entry_count=262_147, targets=targets)
+    for kc, targets in [(k, t) for k, t in shapes for _ in (0, 1)]:
+        filters.append(filters.pop(0))  # alternate: unfiltered / plain `column cmp literal` filters
+        q = QueryUnit("t", groupby=[ColRef(kc)], quals=filters[0], force_baseline=True, baseline_entry_count=262_147,
+                      targets=targets)
         cp, want, err = run_oracle(oracle, st, q)
         assert err == 0
         step = ex.prepare(cp)
@@ -242,9 +246,12 @@ def test_radix_partitioned_group_by(oracle, gpu_executor_factory):
         ("k64", [KeyRef(0, "k"), Agg("avg", ColRef("d"), "ad"), Agg("max", ColRef("i32"), "mx"), Agg("count", ColRef("i32"), "ci")]),
         ("hot", [KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")]),
     ]
+    from hdk_amd.ir import Cmp, Lit
     ex = gpu_executor_factory(st)
-    for kc, targets in shapes:
-        q = QueryUnit("t", groupby=[ColRef(kc)], force_baseline=True, baseline_entry_count=400_009, targets=targets)
+    for si, (kc, targets) in enumerate(shapes):
+        quals = [Cmp(ColRef("i32"), "<=", Lit(500)), Cmp(ColRef("v"), ">", Lit(-2**30))] if si % 2 else []
+        q = QueryUnit("t", groupby=[ColRef(kc)], quals=quals, force_baseline=True, baseline_entry_count=400_009,
+                      targets=targets)
         cp, want, err = run_oracle(oracle, st, q)
         assert err == 0
         step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
