@@ -60,6 +60,7 @@ LAUNCH_RECORD_EVENTS = 2
 LAUNCH_FORCE_GENERIC = 4
 LAUNCH_FORCE_SCALAR = 8
 LAUNCH_FORCE_PARTITIONED = 16
+LAUNCH_PLAN_RESIDENT = 32
 
 
 class Col(C.Structure):

@@ -59,6 +59,10 @@ SIGNATURES = {
     "hdk_hip_describe_launch": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.c_char_p, sz]),
     "hdk_hip_reduce_buffers": (i32, [C.POINTER(A.Plan), v, u32, C.POINTER(v), C.POINTER(u32), i32, v, v,
                                      i32, v]),
+    "hdk_hip_graph_begin_capture": (i32, [i32, v]),
+    "hdk_hip_graph_end_capture": (i32, [i32, v, C.POINTER(v)]),
+    "hdk_hip_graph_launch": (i32, [v, i32, v]),
+    "hdk_hip_graph_destroy": (i32, [v]),
     "hdk_hip_baseline_table_quads": (i32, [C.POINTER(A.Plan), u32, C.POINTER(i64)]),
     "hdk_hip_partition_baseline_count": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), i32, v]),
     "hdk_hip_partition_baseline": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), C.POINTER(v), i32, v]),

@@ -232,6 +232,47 @@ int32_t hdk_hip_mgr_get_stream(int32_t device_num, void** stream) {
   return HDK_HIP_OK;
 }
 
+// ---- hipGraph capture / replay of a launch sequence (include/hdk_hip.h) ----------------------------------
+int32_t hdk_hip_graph_begin_capture(int32_t device_id, void* stream) {
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_graph_end_capture(int32_t device_id, void* stream, void** graph_exec) {
+  HDK_REQUIRE(graph_exec, "graph_exec is NULL");
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  hipGraph_t graph = nullptr;
+  HDK_HIP_CHECK(hipStreamEndCapture(s, &graph));
+  HDK_REQUIRE(graph, "stream capture produced no graph (a captured call was not capturable)");
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HDK_HIP_CHECK(e);
+  *graph_exec = exec;
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_graph_launch(void* graph_exec, int32_t device_id, void* stream) {
+  HDK_REQUIRE(graph_exec, "graph_exec is NULL");
+  hipStream_t s;
+  const int32_t st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  HDK_HIP_CHECK(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), s));
+  return HDK_HIP_OK;
+}
+
+int32_t hdk_hip_graph_destroy(void* graph_exec) {
+  if (graph_exec) {
+    HDK_HIP_CHECK(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+  }
+  return HDK_HIP_OK;
+}
+
 int32_t hdk_hip_mgr_get_device_properties(int32_t device_num, hdk_hip_device_properties* out) {
   HDK_REQUIRE(out, "out is NULL");
   const hdk_hip_device_properties* p = device_props(device_num);

@@ -1148,7 +1148,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
 
   // the plan is read by the kernels from device memory (wave-uniform scalar loads)
   hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
-  HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_PLAN_RESIDENT))) {
+    HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  }
 
   KernParams kp;
   kp.col_buffers = reinterpret_cast<const int8_t* const* const*>(params[HDK_KP_COL_BUFFERS]);

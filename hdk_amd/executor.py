@@ -96,6 +96,7 @@ class PreparedStep:
         self.mgr, self.dev = ex.mgr, ex.device_id
         self.L = lib()
         self.keep: List[DeviceBuffer] = []
+        self._graph = None
         p = cp.plan
         storage = ex.storage
         outer = storage.get(cp.query.table)
@@ -299,7 +300,41 @@ class PreparedStep:
         self.launch(stream)
         return self.fetch()
 
+    # ---- hipGraph: record init + launch once, replay per execution (small inputs are launch-bound) --------
+    def capture_graph(self, stream=None):
+        """Record `init_output(); launch()` as a hipGraph on `stream` (None = the manager's stream).  Only the
+        LDS-strategy plans are captured (their launches are kernels only once the plan is resident in the
+        workspace); for anything else this is a no-op and replay() falls back to the plain sequence."""
+        if self._graph or not self.kernel_names().endswith("hdk_finalize"):
+            return self
+        self.init_output(stream)
+        self.launch(stream)  # uploads the plan into the workspace head
+        self.mgr.synchronizeStream(self.dev) if stream is None else None
+        saved = self.ko.flags
+        self.ko.flags = (saved | A.LAUNCH_PLAN_RESIDENT) & ~A.LAUNCH_RECORD_EVENTS
+        try:
+            check(self.L.hdk_hip_graph_begin_capture(self.dev, stream))
+            self.init_output(stream)
+            self.launch(stream)
+            g = C.c_void_p()
+            check(self.L.hdk_hip_graph_end_capture(self.dev, stream, C.byref(g)))
+            self._graph = g
+        finally:
+            self.ko.flags = saved
+        return self
+
+    def replay(self, stream=None):
+        """One execution: the recorded graph if there is one, else init_output() + launch()."""
+        if self._graph:
+            check(self.L.hdk_hip_graph_launch(self._graph, self.dev, stream))
+        else:
+            self.init_output(stream)
+            self.launch(stream)
+
     def free(self):
+        if self._graph:
+            self.L.hdk_hip_graph_destroy(self._graph)
+            self._graph = None
         for b in self.keep:
             b.free()
         self.keep.clear()

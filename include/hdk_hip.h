@@ -355,6 +355,10 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
 } hdk_hip_kernel_options;
 #define HDK_HIP_LAUNCH_FORCE_PARTITIONED 16u   /* take the radix-partitioned group-by whenever the plan shape
                                                   allows it, whatever the table size (testing) */
+#define HDK_HIP_LAUNCH_PLAN_RESIDENT 32u       /* the head of `workspace` already holds this plan (an earlier
+                                                  launch with the same workspace put it there): skip the
+                                                  host-to-device copy -- what makes a launch capturable as
+                                                  pure kernel nodes (hdk_hip_graph_*) */
 #define HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS 1u /* skip the LDS-privatised strategy (testing) */
 #define HDK_HIP_LAUNCH_FORCE_GENERIC 4u        /* use the (batched) plan-interpreter kernel even when a
                                                   specialised kernel matches (testing) */
@@ -372,6 +376,23 @@ int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_op
 int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
                        const hdk_hip_kernel_options* ko, int32_t device_id, void* stream,
                        void* workspace, size_t workspace_bytes);
+/* hipGraph capture of a launch sequence (no reference counterpart: the reference launches kernel by kernel
+ * through cuLaunchKernel, CudaMgr/DeviceKernel.cpp).  For callers that issue one small step at a time and
+ * wait for it, the step is launch latency; recording the sequence removes the per-kernel submission.
+ * (Measured here with back-to-back asynchronous steps of 1 M rows the replay is NOT faster -- 25.8 vs
+ * 20.7 us, scripts/small_query_latency.py -- so the Python executor does not use it by default.)  Record the
+ * sequence once and replay it:
+ *     hdk_hip_graph_begin_capture(dev, stream);
+ *       hdk_hip_init_*_group_by_buffer(..., stream);
+ *       hdk_hip_launch(plan, params, ko with HDK_HIP_LAUNCH_PLAN_RESIDENT, dev, stream, ws, ws_bytes);
+ *     hdk_hip_graph_end_capture(dev, stream, &graph);       then per execution:  hdk_hip_graph_launch(graph, dev, stream)
+ * Only sequences made of kernels are capturable: the LDS-strategy launches (perfect hash / non-grouped) with
+ * PLAN_RESIDENT and without RECORD_EVENTS.  `stream` NULL = the manager's stream. */
+int32_t hdk_hip_graph_begin_capture(int32_t device_id, void* stream);
+int32_t hdk_hip_graph_end_capture(int32_t device_id, void* stream, void** graph_exec);
+int32_t hdk_hip_graph_launch(void* graph_exec, int32_t device_id, void* stream);
+int32_t hdk_hip_graph_destroy(void* graph_exec);
+
 /* Elapsed milliseconds of every scan kernel launched with HDK_HIP_LAUNCH_RECORD_EVENTS on
  * `device_id` since the last call (waits for them); at most `capacity` values are written, `*count`
  * receives how many there were. */

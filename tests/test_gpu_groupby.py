@@ -168,3 +168,27 @@ def test_mid_size_tables_stay_in_lds(oracle, gpu_executor_factory):
         assert step.kernel_names().split(",")[0] == kernel, (key, step.kernel_names())
         assert_buffers_equal(cp, step.run().buffer, want)
         step.free()
+
+
+def test_graph_replay_matches_and_is_repeatable(oracle, gpu_executor_factory):
+    """PreparedStep.capture_graph(): init + scan + finalize recorded as a hipGraph; every replay must leave
+    the oracle's buffer (the init kernel is part of the graph, so replays do not accumulate)."""
+    rng = np.random.default_rng(9)
+    n = 200_000
+    st = ArrowStorage()
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    v[rng.random(n) < 0.1] = A.NULL_BIGINT
+    st.import_numpy("t", {"k": rng.integers(0, 50, n).astype(np.int32), "v": v, "d": rng.normal(size=n)}, fragment_size=70_000)
+    for q in (QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v")), Agg("count")]),
+              QueryUnit("t", quals=[Cmp(ColRef("v"), ">", Lit(0))], groupby=[ColRef("k")],
+                        targets=[KeyRef(0), Agg("avg", ColRef("d")), Agg("min", ColRef("v") * 2)]),
+              QueryUnit("t", targets=[Agg("sum", ColRef("v")), Agg("max", ColRef("d"))])):
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp).capture_graph()
+        assert step._graph is not None
+        for _ in range(3):
+            step.replay()
+            assert_buffers_equal(cp, step.fetch().buffer, want)
+        step.free()
