@@ -39,6 +39,16 @@ static void init_device(int32_t d) {
     s.status = HDK_HIP_ERR_RUNTIME;
     return;
   }
+  // Stream-ordered scratch (hipMallocAsync in the multi-pass strategies and the reductions) is recycled
+  // by the device's default pool; without a release threshold the pool hands freed memory back at every
+  // synchronisation and the next launch pays the mapping of its scratch again (measured: a 10 GB scratch
+  // turned a 9.5 ms launch into 58 ms).  Keep it cached.
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool) {
+    uint64_t keep = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
+  (void)hipGetLastError();
   memset(&s.props, 0, sizeof(s.props));
   s.props.global_mem = hp.totalGlobalMem;
   s.props.num_cu = hp.multiProcessorCount;
