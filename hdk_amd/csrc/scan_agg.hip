@@ -956,6 +956,8 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   return true;
 }
 
+constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
+
 static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                                        PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
                                        hipStream_t s) {
@@ -970,8 +972,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), b1 + b2 + bo + bc + 1024, s);
   if (me != hipSuccess) {
     (void)hipGetLastError();
-    set_error("radix-partitioned group-by: %zu bytes of scratch: %s", b1 + b2 + bo + bc, hipGetErrorString(me));
-    return HDK_HIP_ERR_OUT_OF_GPU_MEM;
+    return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
   }
   pa.slab1 = reinterpret_cast<int64_t*>(scratch);
   pa.slab2 = reinterpret_cast<int64_t*>(scratch + b1);
@@ -1227,6 +1228,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     if (shape.strategy == STRAT_GLOBAL && !(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) &&
         match_partitioned(plan, ko, &part)) {
       st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
+      if (st == kPartitionedNoScratch) {
+        st = launch_scan_global(plan, d_plan, kp, shape, s, false);
+      }
     } else {
       st = launch_scan_global(plan, d_plan, kp, shape, s,
                               ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
