@@ -490,6 +490,7 @@ int32_t validate_plan(const hdk_hip_plan* p) {
 struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
 static bool needs_join_loops(const hdk_hip_plan* p);
+static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
 
@@ -549,7 +550,9 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     const uint32_t cu = static_cast<uint32_t>(props->num_cu);
     const bool static_ops = fa.nops == 1 || ((fa.nops == 2 || fa.nops == 3) && fa.op_kind[0] == FOP_ADD_ONE &&
                                              (fa.op_kind[1] == FOP_ADD_U64 || fa.op_kind[1] == FOP_ADD_F64));
-    if (kw == 0 || kw + vw >= 16) {
+    if (fa.nquals) {
+      s.grid = 4u * cu;  // filtered: the filter-column gathers want more waves (C2 + WHERE: 1.09 vs 1.14 ms at 2 per CU)
+    } else if (kw == 0 || kw + vw >= 16) {
       s.grid = 2u * cu;
     } else if (vw == 0) {
       s.grid = 4u * cu;
@@ -636,7 +639,7 @@ static bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* c
 }
 
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out) {
-  if (shape.strategy != STRAT_LDS || p->num_quals || p->num_joins || p->key_count > 1) return false;
+  if (shape.strategy != STRAT_LDS || p->num_joins || p->key_count > 1) return false;
   if (p->query_kind == HDK_Q_BASELINE_HASH) return false;
   int kw = 0;
   memset(fa, 0, sizeof(*fa));
@@ -727,15 +730,20 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   }
   if (nops > kFastMaxOps) return false;
   fa->nops = nops;
+  if (p->num_quals) {
+    // filtered plans: only the instantiations launch_direct_kw has (grouped, 8-byte value column)
+    if (kw == 0 || vw != 8 || !match_plain_quals(p, fa->q)) return false;
+    fa->nquals = p->num_quals;
+  }
   *kw_out = kw;
   *vw_out = vw;
   return true;
 }
 
-template <int KW, int VW, int FIXED>
+template <int KW, int VW, int FIXED, bool Q = false>
 static int32_t launch_direct(const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
   constexpr int U = (KW != 0 && VW != 0) ? 4 : 8;
-  hipLaunchKernelGGL((hdk_scan_agg_direct<KW, VW, U, FIXED>), dim3(shape.grid), dim3(kFastBlock), shape.lds_bytes,
+  hipLaunchKernelGGL((hdk_scan_agg_direct<KW, VW, U, FIXED, Q>), dim3(shape.grid), dim3(kFastBlock), shape.lds_bytes,
                      s, fa);
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
@@ -745,6 +753,16 @@ static int32_t launch_direct(const FastArgs& fa, const LaunchShape& shape, hipSt
 template <int KW>
 static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
   const int only = fa.nops == 1 ? fa.op_kind[0] : -1;
+  if (fa.nquals) {  // filtered: KW != 0 and VW == 8 (match_fast); three op-list forms
+    if (KW == 0) return HDK_HIP_ERR_UNSUPPORTED;
+    constexpr int KQ = KW ? KW : 8;
+    if (only == FOP_ADD_U64) return launch_direct<KQ, 8, FOP_ADD_U64, true>(fa, shape, s);
+    if (fa.nops == 3 && fa.op_kind[0] == FOP_ADD_ONE && fa.op_word[0] == 0 && fa.op_kind[1] == FOP_ADD_U64 &&
+        fa.op_kind[2] == FOP_ADD_ONE_IF_NULL) {
+      return launch_direct<KQ, 8, 100, true>(fa, shape, s);
+    }
+    return launch_direct<KQ, 8, -1, true>(fa, shape, s);
+  }
   switch (vw) {
     case 0:
       if (KW != 0 && only == FOP_ADD_ONE) return launch_direct<KW, 0, FOP_ADD_ONE>(fa, shape, s);

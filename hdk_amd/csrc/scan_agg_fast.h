@@ -15,6 +15,7 @@
 // The slab format written at the end is the generic one (agg_common.h), so hdk_finalize is shared.
 #pragma once
 #include "agg_common.h"
+#include "plain_quals.h"
 
 namespace hdk {
 
@@ -56,6 +57,8 @@ struct FastArgs {
   int32_t nn_words[HDK_HIP_MAX_TARGETS];  // (mask mode) words that receive the non-null flag
   int32_t n_nn_words;
   uint32_t nword_mask;  // (counting mode) bit w: word w holds a NULL count
+  int32_t nquals;       // plain filters `outer column cmp literal` (Q instantiations only)
+  ProjFastQual q[kMaxPlainQuals];
 };
 
 // column buffers are plain hipMalloc'ed global memory: say so, or the pointers loaded from
@@ -214,7 +217,9 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
 }
 
 // R = rows per lane per step (16 B of the widest column); U = steps per tile.
-template <int KW, int VW, int U, int FIXED>
+// Q: the plan has plain filters (plain_quals.h); rows that fail them are skipped before the LDS update.  A
+// separate instantiation so that the unfiltered kernels (C1/C2) stay exactly as they were.
+template <int KW, int VW, int U, int FIXED, bool Q = false>
 __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ unsigned long long s_masks[2];
@@ -271,18 +276,44 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
           if (KW) load_bytes<(KB > 0 ? KB : 4)>(kcol + r * KW, kr[u]);
           if (VW) load_bytes<(VB > 0 ? VB : 4)>(vcol + r * VW, vr[u]);
         }
+        bool pass[U * R];
+#pragma unroll
+        for (int j = 0; j < U * R; ++j) {
+          pass[j] = true;
+        }
+        if (Q) {
+          int64_t rows[U * R];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              rows[u * R + i] = row0 + (static_cast<int64_t>(u) * kFastBlock + tid) * R + i;
+            }
+          }
+          plain_quals_pass<U * R>(a.q, a.nquals, cols, rows, pass, true);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
           for (int i = 0; i < R; ++i) {
             const int64_t key = KW ? extract_elem<(KW ? KW : 8)>(kr[u], i) : 0;
             const int64_t val = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
-            fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+            if (!Q || pass[u * R + i]) {
+              fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+            }
           }
         }
       } else {
         // ragged tail of a fragment: one row per lane per pass
         for (int64_t r = row0 + tid; r < nrows; r += kFastBlock) {
+          if (Q) {
+            const int64_t rows1[1] = {r};
+            bool pass1[1] = {true};
+            plain_quals_pass<1>(a.q, a.nquals, cols, rows1, pass1, true);
+            if (!pass1[0]) {
+              continue;
+            }
+          }
           const int64_t key = KW ? load_elem<(KW ? KW : 8)>(kcol, r) : 0;
           const int64_t val = VW ? load_elem<(VW ? VW : 8)>(vcol, r) : 0;
           fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);

@@ -41,7 +41,7 @@ def timed(step, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=256_000_000)
-    ap.add_argument("--only", default="c1,c2,c2n,c3,c3g,q1,q2,q3,q4,c5,p1,p50,pj")
+    ap.add_argument("--only", default="c1,c2,c2n,c2f,c3,c3g,q1,q2,q3,q4,c5,p1,p50,pj")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
@@ -81,6 +81,9 @@ def main():
         "c1": (QueryUnit("t", targets=[Agg("sum", ColRef("val"))]), 8),
         "c2": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
         "c2n": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("valn"))]), 16),
+        # C2 with a filter that half of the rows pass (filter column = a third 8-byte column: 24 B/row)
+        "c2f": (QueryUnit("t", quals=[Cmp(ColRef("valn"), "<", Lit(0))], groupby=[ColRef("key")],
+                          targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 24),
         "c3": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")],
                          targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"))]), 16),
         "c3g": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") / 15625],
