@@ -53,3 +53,36 @@ void f(int8_t* b, int32_t* otm, int* err, const JoinColumn* jc, const JoinColumn
 ''')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(ROOT, "hdk_amd", "glue"), str(src)])
+
+
+def test_hipkernel_glue_compiles(tmp_path):
+    """hdk_amd/glue/HipKernel.h against declarations shaped like the reference's QueryEngine/DeviceKernel.h:25-65
+    (DeviceClock, KernelOptions, DeviceKernel) and CompilationContext.h:23-26.  The real headers pull in LLVM and
+    Boost, absent here, so the test restates the four declarations: it checks that HipKernel overrides every pure
+    virtual with the reference's signatures, not the reference's file."""
+    src = tmp_path / "kernel_check.cpp"
+    src.write_text('''
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+class CompilationContext { public: virtual ~CompilationContext() {} };
+class DeviceClock { public: virtual void start() = 0; virtual int stop() = 0; virtual ~DeviceClock() = default; };
+struct KernelOptions { unsigned int gridDimX = 1, gridDimY = 1, gridDimZ = 1, blockDimX = 1, blockDimY = 1, blockDimZ = 1;
+                       unsigned int sharedMemBytes = 0, literalsOffset = 0; bool hoistLiterals = true; };
+class DeviceKernel {
+ public:
+  virtual void launch(const KernelOptions& ko, std::vector<int8_t*>& kernelParams) = 0;
+  virtual void initializeDynamicWatchdog(bool could_interrupt, uint64_t cycle_budget, size_t time_limit) {}
+  virtual void initializeRuntimeInterrupter() {}
+  virtual std::unique_ptr<DeviceClock> make_clock() = 0;
+  virtual ~DeviceKernel() = default;
+};
+#include "HipKernel.h"
+struct Arena : hip_rt::HipWorkspaceAllocator { int8_t* alloc(size_t) override { return nullptr; } };
+std::unique_ptr<DeviceKernel> make(const hip_rt::HipPlanContext* ctx, Arena* a) {
+  return std::make_unique<hip_rt::HipKernel>(ctx, 0, a, 1000, true);   // not abstract: every pure virtual is overridden
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "hdk_amd", "glue"), str(src)])
