@@ -493,6 +493,7 @@ static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
+static const void* baseline_direct_kernel(const hdk_hip_plan* p);
 
 // Persistent grids are sized from what actually fits: blocks per CU (register / LDS limited) x CUs, so that
 // every block is resident and the static tile walk has no second, partly filled round (the batched
@@ -589,8 +590,7 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     } else {
       BaseFastArgs bf;
       if (!generic && match_baseline_fast(p, &bf)) {
-        k = p->key_width == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t>)
-                              : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t>);
+        k = baseline_direct_kernel(p);
         block = kBaseFastBlock;
       } else {
         k = reinterpret_cast<const void*>(hdk_scan_agg_global);
@@ -880,9 +880,33 @@ static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
   return true;
 }
 
+static const void* baseline_direct_kernel(const hdk_hip_plan* p) {
+  if (p->key_width == 4) {
+    return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 2>)
+                             : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 1>);
+  }
+  return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 2>)
+                           : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 1>);
+}
+
+static void launch_baseline_direct(const hdk_hip_plan* p, const BaseFastArgs& fa, unsigned grid, hipStream_t s) {
+  if (p->key_width == 4) {
+    if (p->key_count == 2) {
+      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+    } else {
+      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+    }
+  } else if (p->key_count == 2) {
+    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+  } else {
+    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+  }
+}
+
 // the shape hdk_scan_agg_baseline_direct takes (scan_agg_baseline_fast.h)
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
-  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_joins || p->key_count != 1) {
+  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_joins || p->key_count < 1 ||
+      p->key_count > 2) {
     return false;
   }
   int kc;
@@ -891,6 +915,14 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
   fa->key_buf_idx = p->cols[kc].buf_idx;
   fa->key_width = p->cols[kc].width;
   fa->key_kind = p->cols[kc].kind;
+  fa->nkeys = p->key_count;
+  if (p->key_count == 2) {
+    int kc2;
+    if (!plain_outer_col(p, p->keys[1], &kc2) || p->cols[kc2].kind != HDK_COL_INT) return false;
+    fa->key2_buf_idx = p->cols[kc2].buf_idx;
+    fa->key2_width = p->cols[kc2].width;
+    fa->key2_kind = p->cols[kc2].kind;
+  }
   if (!match_plain_quals(p, fa->q)) return false;
   fa->nquals = p->num_quals;
   int n = 0;
@@ -925,7 +957,7 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
 // atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
 static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
   BaseFastArgs bf;
-  if (!match_baseline_fast(p, &bf)) return false;
+  if (!match_baseline_fast(p, &bf) || bf.nkeys != 1) return false;
   if (!ko || ko->total_rows == 0) return false;
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
@@ -1024,11 +1056,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   bf.kp = kp;
   bf.entry_count = shape.entry_count;
   bf.run_if = pa.fallback;
-  if (k32) {
-    hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int32_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, bf);
-  } else {
-    hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int64_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, bf);
-  }
+  launch_baseline_direct(plan, bf, shape.grid, s);
   HDK_HIP_CHECK(hipGetLastError());
   HDK_HIP_CHECK(hipFreeAsync(scratch, s));
   return HDK_HIP_OK;
@@ -1073,11 +1101,7 @@ static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* 
     fa.plan = d_plan;
     fa.kp = kp;
     fa.entry_count = shape.entry_count;
-    if (plan->key_width == 4) {
-      hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int32_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, fa);
-    } else {
-      hipLaunchKernelGGL(hdk_scan_agg_baseline_direct<int64_t>, dim3(shape.grid), dim3(kBaseFastBlock), 0, s, fa);
-    }
+    launch_baseline_direct(plan, fa, shape.grid, s);
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }

@@ -37,6 +37,8 @@ struct BaseFastArgs {
   int32_t key_buf_idx;
   int32_t key_width;   // of the input column
   int32_t key_kind;
+  int32_t nkeys;       // 1 or 2 group keys (plain outer columns)
+  int32_t key2_buf_idx, key2_width, key2_kind;
   int32_t ntargets;
   BaseFastTarget tg[HDK_HIP_MAX_TARGETS];
   const uint32_t* run_if;  // nullptr: always run; else run only when *run_if != 0 (fallback of the partitioned path)
@@ -58,7 +60,7 @@ HDK_DEV void g_agg64_seen(int agg, bool fp, bool skip, int64_t nullv, int64_t* s
   g_agg64(agg, fp, false, nullv, slot, v);
 }
 
-template <typename K>  // key type of the TABLE (int32_t or int64_t)
+template <typename K, int NK>  // key type of the TABLE (int32_t or int64_t); number of key columns (1 or 2)
 __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(BaseFastArgs a) {
   if (a.run_if && *a.run_if == 0) {
     return;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       int64_t row[VR];
       bool live[VR];
-      K key[VR];
+      K key[VR][NK];
       uint32_t home[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
@@ -99,13 +101,22 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
       }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        key[r] = static_cast<K>(decode_col_g(keybuf, a.key_width, a.key_kind, row[r], true));
+        key[r][0] = static_cast<K>(decode_col_g(keybuf, a.key_width, a.key_kind, row[r], true));
+      }
+      if (NK == 2) {
+        const int8_t* key2buf = cols[a.key2_buf_idx];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          key[r][NK - 1] = static_cast<K>(decode_col_g(key2buf, a.key2_width, a.key2_kind, row[r], true));
+        }
       }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        home[r] = key_hash_dev<K>(&key[r], 1) % a.entry_count;
+        home[r] = key_hash_dev<K>(key[r], NK) % a.entry_count;
       }
-      // speculative read of the home entries (one 16-byte or 8-byte load each, all VR in flight)
+      // speculative read of the home entries (16 bytes each, all VR in flight): the whole key region and,
+      // for 16-byte entries, the one slot
+      constexpr bool kKeys16 = sizeof(K) == 8 && NK == 2;  // two 8-byte keys: the key region alone is 16 bytes
       bf_i64x2 e[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
           e[r] = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(reinterpret_cast<uintptr_t>(ep));
         } else {
           e[r].x = *reinterpret_cast<const __attribute__((address_space(1))) long long*>(reinterpret_cast<uintptr_t>(ep));
-          e[r].y = 0;
+          e[r].y = kKeys16 ? *reinterpret_cast<const __attribute__((address_space(1))) long long*>(reinterpret_cast<uintptr_t>(ep + 1)) : 0;
         }
       }
       int64_t entry[VR];
@@ -122,18 +133,26 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
       bool have_slot[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const K resident = sizeof(K) == 8 ? static_cast<K>(e[r].x) : static_cast<K>(static_cast<int32_t>(e[r].x));
+        bool resident_is_mine;
+        if (sizeof(K) == 8) {
+          resident_is_mine = static_cast<K>(e[r].x) == key[r][0] && (NK == 1 || static_cast<K>(e[r].y) == key[r][NK - 1]);
+        } else if (NK == 1) {
+          resident_is_mine = static_cast<K>(static_cast<int32_t>(e[r].x)) == key[r][0];
+        } else {  // two 4-byte keys share the first quad: low half = key 0, high half = key 1
+          resident_is_mine = static_cast<K>(static_cast<int32_t>(e[r].x)) == key[r][0] &&
+                             static_cast<K>(static_cast<int32_t>(e[r].x >> 32)) == key[r][NK - 1];
+        }
         fresh[r] = false;
         have_slot[r] = false;
         entry[r] = -1;
         if (!live[r]) {
           continue;
         }
-        if (resident == key[r] && key[r] != empty_key<K>()) {
+        if (resident_is_mine && key[r][0] != empty_key<K>()) {
           entry[r] = home[r];
-          have_slot[r] = entry16;
+          have_slot[r] = entry16 && !kKeys16;
         } else {
-          entry[r] = find_or_claim<K>(p, buf, a.entry_count, &key[r], &fresh[r]);
+          entry[r] = find_or_claim<K>(p, buf, a.entry_count, key[r], &fresh[r]);
           if (entry[r] < 0) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;
             live[r] = false;

@@ -282,3 +282,37 @@ def test_radix_partitioned_two_levels(oracle, gpu_executor_factory):
     step.free()
     _check_rows(cp, res.buffer, want)
     assert res.row_count() == len(np.unique(key))
+
+
+def test_baseline_fast_kernel_two_keys(oracle, gpu_executor_factory):
+    """hdk_scan_agg_baseline_direct<K, 2>: two plain key columns, 4-byte (both keys in the first quad) and 8-byte
+    table keys, 16-byte and wider entries, with and without filters."""
+    from hdk_amd.ir import Cmp, Lit
+    rng = np.random.default_rng(4242)
+    n = 400_003
+    a32 = rng.integers(-300, 300, n).astype(np.int32)
+    b16 = rng.integers(0, 400, n).astype(np.int16)
+    a64 = rng.integers(0, 500, n, dtype=np.int64) * 5_000_000_029
+    b64 = rng.integers(-200, 200, n, dtype=np.int64)
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    d = rng.normal(size=n)
+    st = ArrowStorage()
+    st.import_numpy("t", {"a32": a32, "b16": b16, "a64": a64, "b64": b64, "v": v, "d": d}, fragment_size=130_000)
+    cases = [(["a32", "b16"], [KeyRef(0, "k0"), KeyRef(1, "k1"), Agg("sum", ColRef("v"), "s")], [], 4),
+             (["a64", "b64"], [KeyRef(0, "k0"), KeyRef(1, "k1"), Agg("count", None, "c"), Agg("avg", ColRef("d"), "ad")],
+              [Cmp(ColRef("v"), ">", Lit(0))], 8),
+             (["b16", "a32"], [KeyRef(1, "k1"), KeyRef(0, "k0"), Agg("min", ColRef("v"), "mn"), Agg("max", ColRef("d"), "mx")],
+              [Cmp(ColRef("d"), "<", Lit(1.0))], 4)]
+    ex = gpu_executor_factory(st)
+    for keys, targets, quals, kw in cases:
+        q = QueryUnit("t", groupby=[ColRef(k) for k in keys], quals=quals, force_baseline=True, baseline_entry_count=524_309,
+                      targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0 and cp.plan.key_width == kw and cp.plan.key_count == 2
+        step = ex.prepare(cp)
+        assert step.kernel_names() == "hdk_scan_agg_baseline_direct", step.kernel_names()
+        res = step.run()
+        step.free()
+        _check_rows(cp, res.buffer, want)
+        _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
