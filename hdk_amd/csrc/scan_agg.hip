@@ -957,7 +957,7 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
 // atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
 static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
   BaseFastArgs bf;
-  if (!match_baseline_fast(p, &bf) || bf.nkeys != 1) return false;
+  if (!match_baseline_fast(p, &bf)) return false;
   if (!ko || ko->total_rows == 0) return false;
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
@@ -967,6 +967,10 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->key_buf_idx = bf.key_buf_idx;
   pa->key_width = bf.key_width;
   pa->key_kind = bf.key_kind;
+  pa->nkeys = bf.nkeys;
+  pa->key2_buf_idx = bf.key2_buf_idx;
+  pa->key2_width = bf.key2_width;
+  pa->key2_kind = bf.key2_kind;
   pa->nquals = bf.nquals;
   for (int i = 0; i < bf.nquals; ++i) pa->q[i] = bf.q[i];
   for (int t = 0; t < bf.ntargets; ++t) {
@@ -977,16 +981,16 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
         if (pa->arg[k].buf_idx == ft.buf_idx) word = 1 + k;
       }
       if (!word) {
-        if (pa->nargs == kPartMaxArgs) return false;
+        if (pa->nkeys + pa->nargs == kPartMaxTW) return false;  // the tuple holds 3 words: keys + argument columns
         pa->arg[pa->nargs] = ft;
         word = 1 + pa->nargs++;
       }
     }
     pa->tgt_index[t] = ft.target;
-    pa->tgt_arg[t] = word;
+    pa->tgt_arg[t] = word ? word - 1 + pa->nkeys : 0;  // absolute tuple word of the argument
   }
   pa->ntargets = bf.ntargets;
-  pa->tw = 1 + pa->nargs;
+  pa->tw = pa->nkeys + pa->nargs;
   pa->entry_count = p->entry_count;
   // fine partitions: as many as it takes for a region (slots x row) to fit the LDS budget, a multiple of P1
   uint32_t slots = kPartLdsWords / p->row_size_quad;

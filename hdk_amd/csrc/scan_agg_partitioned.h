@@ -45,6 +45,8 @@ struct PartArgs {
   uint32_t p2;           // fine partitions per coarse partition
   int32_t tw;            // tuple words
   int32_t key_buf_idx, key_width, key_kind;
+  int32_t nkeys;         // 1 or 2 key columns: tuple = [key0, (key1), arguments...]
+  int32_t key2_buf_idx, key2_width, key2_kind;
   int32_t nargs;
   BaseFastTarget arg[kPartMaxArgs];  // argument columns (buf_idx / width / kind); .target unused
   int32_t ntargets;
@@ -63,9 +65,9 @@ struct PartArgs {
 };
 
 template <typename K>
-HDK_DEV uint32_t part_fine_id(int64_t key, uint32_t fine_count) {
-  const K k = static_cast<K>(key);
-  const uint32_t h = key_hash_dev<K>(&k, 1);
+HDK_DEV uint32_t part_fine_id(const int64_t* tup, int nkeys, uint32_t fine_count) {
+  const K k[2] = {static_cast<K>(tup[0]), nkeys == 2 ? static_cast<K>(tup[1]) : static_cast<K>(0)};
+  const uint32_t h = key_hash_dev<K>(k, nkeys);
   return static_cast<uint32_t>((static_cast<uint64_t>(h) * fine_count) >> 32);
 }
 
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
       bin[r] = 0;
       rank[r] = 0;
       if (live[r]) {
-        const uint32_t f = part_fine_id<K>(tup[r][0], a.fine_count);
+        const uint32_t f = part_fine_id<K>(tup[r], a.nkeys, a.fine_count);
         bin[r] = LEVEL == 1 ? f / a.p2 : f % a.p2;
         rank[r] = atomicAdd(&s_cnt[bin[r]], 1u);
       }
@@ -255,10 +257,17 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
           const int64_t row = row0 + static_cast<int64_t>(r) * kPartBlock;
           tup[r][0] = live[r] ? decode_col_g(cols[a.key_buf_idx], a.key_width, a.key_kind, row, true) : 0;
         }
+        const int nk = a.nkeys;
 #pragma unroll
         for (int w = 1; w < kPartMaxTW; ++w) {
-          if (w <= a.nargs) {
-            const BaseFastTarget c = a.arg[w - 1];
+          if (w < nk) {  // second key column
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              const int64_t row = row0 + static_cast<int64_t>(r) * kPartBlock;
+              tup[r][w] = live[r] ? decode_col_g(cols[a.key2_buf_idx], a.key2_width, a.key2_kind, row, true) : 0;
+            }
+          } else if (w - nk < a.nargs) {
+            const BaseFastTarget c = a.arg[w - nk > 0 ? 1 : 0];
 #pragma unroll
             for (int r = 0; r < VR; ++r) {
               const int64_t row = row0 + static_cast<int64_t>(r) * kPartBlock;
@@ -315,7 +324,7 @@ HDK_DEV void part_load_targets(const PartArgs& a, const hdk_hip_plan* p, PartTar
     d.slot_off = tg.slot_off;
     d.slot2_off = tg.slot2_off;
     d.arg_word = a.tgt_arg[t];
-    const int32_t kind = d.arg_word ? a.arg[d.arg_word - 1].kind : HDK_COL_INT;
+    const int32_t kind = d.arg_word ? a.arg[d.arg_word - a.nkeys].kind : HDK_COL_INT;
     d.arg_fp = kind == HDK_COL_FLOAT || kind == HDK_COL_DOUBLE;
     d.arg_nullable = tg.arg.nullable;
     d.pad_ = 0;
@@ -329,9 +338,9 @@ HDK_DEV void part_load_targets(const PartArgs& a, const hdk_hip_plan* p, PartTar
 template <typename K>
 HDK_DEV void part_apply_tuple(const hdk_hip_plan* p, const PartTarget* s_tg, int ntargets, uint32_t rq, int64_t* table,
                               uint32_t slots, const int64_t* tup, int32_t& err) {
-  const K key = static_cast<K>(tup[0]);
+  const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};  // (word 1 is only read as a key when key_count == 2)
   bool fresh;
-  const int64_t e = find_or_claim<K>(p, table, slots, &key, &fresh);
+  const int64_t e = find_or_claim<K>(p, table, slots, key, &fresh);
   if (e < 0) {
     err = HDK_HIP_ERR_OUT_OF_SLOTS;  // more groups in this slot range than it has entries
     return;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
     for (int w = 0; w < kPartMaxTW; ++w) {
       tup[w] = w < tw ? a.ovf[i * tw + w] : 0;
     }
-    const uint32_t f = part_fine_id<K>(tup[0], a.fine_count);
+    const uint32_t f = part_fine_id<K>(tup, a.nkeys, a.fine_count);
     int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(f) * a.slots * rq;
     part_apply_tuple<K>(p, s_tg, a.ntargets, rq, region, a.slots, tup, err);
   }

@@ -316,3 +316,27 @@ def test_baseline_fast_kernel_two_keys(oracle, gpu_executor_factory):
         step.free()
         _check_rows(cp, res.buffer, want)
         _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+
+
+def test_radix_partitioned_two_keys(oracle, gpu_executor_factory):
+    """Radix-partitioned path with two key columns (tuple = key0, key1, one argument), 4- and 8-byte table keys."""
+    rng = np.random.default_rng(777)
+    n = 900_001
+    a32 = rng.integers(-2000, 2000, n).astype(np.int32)
+    b16 = rng.integers(0, 150, n).astype(np.int16)
+    a64 = rng.integers(0, 3000, n, dtype=np.int64) * 5_000_000_029
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"a32": a32, "b16": b16, "a64": a64, "v": v}, fragment_size=250_000)
+    for keys, kw in ((["a32", "b16"], 4), (["a64", "b16"], 8)):
+        q = QueryUnit("t", groupby=[ColRef(k) for k in keys], force_baseline=True, baseline_entry_count=1_200_007,
+                      targets=[KeyRef(0, "k0"), KeyRef(1, "k1"), Agg("sum", ColRef("v"), "s"), Agg("count", ColRef("v"), "c")])
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0 and cp.plan.key_width == kw
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+        assert step.kernel_names().startswith("hdk_part_scatter"), step.kernel_names()
+        res = step.run()
+        step.free()
+        _check_rows(cp, res.buffer, want)
