@@ -87,16 +87,16 @@ def random_query(rng, allow_join=True, projection=False):
                          targets=targets, output_columnar=bool(rng.random() < 0.5))
     if not joins and rng.random() < 0.2:
         # the shape of the specialised open-addressing kernels: one plain key, plain arguments, plain filters
-        key = str(rng.choice(["k32", "k64", "k16"]))
+        keys = [str(k) for k in rng.choice(["k32", "k64", "k16", "k8"], size=int(rng.choice([1, 1, 2])), replace=False)]
         quals = [Cmp(ColRef(str(rng.choice(["v32", "v16", "d"]))), str(rng.choice(["<", ">", "<>"])),
                      Lit(float(rng.normal() * 40)) if rng.random() < 0.3 else Lit(int(rng.integers(-50, 50))))
                  for _ in range(int(rng.integers(0, 3)))]
-        targets = [KeyRef(0, "key0")]
+        targets = [KeyRef(i, f"key{i}") for i in range(len(keys))]
         for i in range(int(rng.integers(1, 4))):
             kind = str(rng.choice(["count", "sum", "min", "max", "avg"]))
             a = None if (kind == "count" and rng.random() < 0.5) else ColRef(str(rng.choice(["v64", "v32", "d"])))
             targets.append(Agg(kind, a, f"t{i}"))
-        return QueryUnit("fact", quals=quals, groupby=[ColRef(key)], targets=targets, force_baseline=True)
+        return QueryUnit("fact", quals=quals, groupby=[ColRef(k) for k in keys], targets=targets, force_baseline=True)
     nkeys = int(rng.choice([0, 1, 1, 2]))
     groupby = []
     for _ in range(nkeys):
