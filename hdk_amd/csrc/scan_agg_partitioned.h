@@ -66,8 +66,8 @@ struct PartArgs {
 
 template <typename K>
 HDK_DEV uint32_t part_fine_id(const int64_t* tup, int nkeys, uint32_t fine_count) {
-  const K k[2] = {static_cast<K>(tup[0]), nkeys == 2 ? static_cast<K>(tup[1]) : static_cast<K>(0)};
-  const uint32_t h = key_hash_dev<K>(k, nkeys);
+  const K k[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};
+  const uint32_t h = nkeys == 2 ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
   return static_cast<uint32_t>((static_cast<uint64_t>(h) * fine_count) >> 32);
 }
 
