@@ -9,7 +9,7 @@
 // (consumers iterate entries; the reference's own placement depends on thread timing).
 //
 //   fine partition f of a key = mulhi32(key_hash(key), PF)  ->  table entries [f*S, (f+1)*S)
-//   pass 1  scatter rows (key + argument columns -> tuples) into 128 coarse slabs      (c = f / P2)
+//   pass 1  filter rows, scatter (keys + argument columns -> tuples of <= 3 words) into 128 coarse slabs (c = f / P2)
 //   pass 2  scatter each coarse slab into its P2 fine slabs
 //   pass 3  one block per fine slab: load its (initialised) table region into LDS, insert/aggregate the
 //           slab's tuples there with the ordinary claim protocol and agg_* functions, store the region
@@ -32,8 +32,8 @@ constexpr int kPartVR = 8;
 constexpr int kPartTile = kPartBlock * kPartVR;  // tuples per scatter batch
 constexpr int kPartP1 = 128;                     // coarse partitions
 constexpr int kPartMaxBins = 256;                // bins a scatter pass distinguishes (P1, or P2 <= 256)
-constexpr int kPartMaxArgs = 2;                  // argument columns carried in a tuple
-constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: key + arguments
+constexpr int kPartMaxArgs = 2;                  // argument columns carried in a tuple (at most)
+constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: 1-2 keys + argument columns, 3 in all (LDS staging)
 constexpr uint32_t kPartLdsWords = 7680;         // 60 KiB LDS table per fine partition
 
 struct PartArgs {
@@ -51,7 +51,7 @@ struct PartArgs {
   BaseFastTarget arg[kPartMaxArgs];  // argument columns (buf_idx / width / kind); .target unused
   int32_t ntargets;
   int32_t tgt_index[HDK_HIP_MAX_TARGETS];  // plan target index
-  int32_t tgt_arg[HDK_HIP_MAX_TARGETS];    // tuple word of its argument (>= 1), or 0 for none
+  int32_t tgt_arg[HDK_HIP_MAX_TARGETS];    // tuple word of its argument (>= nkeys), or 0 for none
   uint64_t cap1, cap2, cap_ovf;            // slab capacities in tuples
   int64_t* slab1;        // [kPartP1][cap1][tw]
   int64_t* slab2;        // [fine_count][cap2][tw]
@@ -69,40 +69,6 @@ HDK_DEV uint32_t part_fine_id(const int64_t* tup, int nkeys, uint32_t fine_count
   const K k[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};
   const uint32_t h = nkeys == 2 ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
   return static_cast<uint32_t>((static_cast<uint64_t>(h) * fine_count) >> 32);
-}
-
-// word `W` of the VR tuples of a lane from a column: the decoder switch is wave-uniform, outside the row loop
-template <int W>
-HDK_DEV void part_load_col(const int8_t* buf, int width, int kind, int64_t row0, const bool (&live)[kPartVR],
-                           int64_t (&tup)[kPartVR][kPartMaxTW]) {
-#define HDK_PART_ROWS(T, CONV)                                                            \
-  _Pragma("unroll") for (int r = 0; r < kPartVR; ++r) {                                   \
-    tup[r][W] = 0;                                                                        \
-    if (live[r]) {                                                                        \
-      const T x = gload<T>(buf, row0 + static_cast<int64_t>(r) * kPartBlock, true);       \
-      tup[r][W] = CONV;                                                                   \
-    }                                                                                     \
-  }
-  if (kind == HDK_COL_DOUBLE) {
-    HDK_PART_ROWS(int64_t, x)
-  } else if (kind == HDK_COL_FLOAT) {
-    HDK_PART_ROWS(float, double_to_bits(static_cast<double>(x)))
-  } else if (kind == HDK_COL_UNSIGNED) {
-    switch (width) {
-      case 1: HDK_PART_ROWS(uint8_t, static_cast<int64_t>(x)) break;
-      case 2: HDK_PART_ROWS(uint16_t, static_cast<int64_t>(x)) break;
-      case 4: HDK_PART_ROWS(uint32_t, static_cast<int64_t>(x)) break;
-      default: HDK_PART_ROWS(int64_t, x) break;
-    }
-  } else {
-    switch (width) {
-      case 1: HDK_PART_ROWS(int8_t, static_cast<int64_t>(x)) break;
-      case 2: HDK_PART_ROWS(int16_t, static_cast<int64_t>(x)) break;
-      case 4: HDK_PART_ROWS(int32_t, static_cast<int64_t>(x)) break;
-      default: HDK_PART_ROWS(int64_t, x) break;
-    }
-  }
-#undef HDK_PART_ROWS
 }
 
 // ---- scatter: LEVEL 1 reads the columns, LEVEL 2 reads coarse slab blockIdx.y -------------------------
