@@ -1038,7 +1038,11 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
   const bool k32 = plan->key_width == 4;
   const size_t stage_bytes = static_cast<size_t>(kPartTile) * tw * 8;
-  const unsigned g1 = static_cast<unsigned>(props->num_cu) * 3;
+  // pass-1 grid: twice what is resident (LDS staging + ~110 VGPRs: 2 blocks of 512 threads per CU), so that the
+  // per-batch latency chains of one round overlap with the next
+  const void* k1 = k32 ? reinterpret_cast<const void*>(hdk_part_scatter<1, int32_t>)
+                       : reinterpret_cast<const void*>(hdk_part_scatter<1, int64_t>);
+  const unsigned g1 = resident_grid(k1, kPartBlock, stage_bytes, props) * 2;
   const unsigned g2x = 16;
   const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
   const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;

@@ -19,16 +19,16 @@
 //           scatter passes raise a device-side flag, the later passes return at once, and the launch's last
 //           kernel -- hdk_scan_agg_baseline_direct, armed by that flag -- redoes the job with global atomics on
 //           the still untouched table.  No host round trip.
-// Scatter = per 2048-row batch: LDS histogram by partition, ONE global cursor atomic per partition and
+// Scatter = per 2048-row batch (512 threads x 4 rows): LDS histogram by partition, ONE global cursor atomic per partition and
 // batch, LDS staging ordered by partition, coalesced copy-out of the runs (~16 tuples = 256 B each).
 #pragma once
 #include "scan_agg_baseline_fast.h"
 
 namespace hdk {
 
-constexpr int kPartBlock = 256;
+constexpr int kPartBlock = 512;               // scatter passes (sweep at C5: 256x8 3.7 ms, 512x4 2.9 ms, 1024x2 3.9 ms for pass 1)
 constexpr int kPartAggBlock = 1024;              // aggregation pass: 2 blocks x 60 KiB LDS per CU, all 32 wave slots busy
-constexpr int kPartVR = 8;
+constexpr int kPartVR = 4;
 constexpr int kPartTile = kPartBlock * kPartVR;  // tuples per scatter batch
 constexpr int kPartP1 = 128;                     // coarse partitions
 constexpr int kPartMaxBins = 256;                // bins a scatter pass distinguishes (P1, or P2 <= 256)
