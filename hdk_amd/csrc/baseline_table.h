@@ -57,16 +57,38 @@ HDK_DEV int32_t atomic_load_i32(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The plan fields find_or_claim needs, read once per kernel, pinned to SGPRs and expressed as integer
+// strides -- no boolean survives into the probe loop.  Background: with `columnar` kept as a bool,
+// hipcc (ROCm 7.2) materialises `!columnar` as a lane mask (v_cndmask + v_cmp) INSIDE the probe loop,
+// i.e. under that trip's shrinking EXEC, and when two inlined copies of find_or_claim follow each other
+// it reuses the first copy's mask for the second copy's uniform branch (`s_and vcc, exec, mask`): lanes
+// that left the first loop early then address the table with the wrong layout.  Seen as OUT_OF_SLOTS and
+// a 50x slowdown in hdk_part_aggregate once it applied two tuples per trip.
+struct TableShape {
+  int key_count;
+  uint32_t row_quads;
+  uint32_t entry_stride_bytes;  // from one entry's first key component to the next entry's
+  uint32_t columnar_mask;       // all ones for a columnar table, else 0: key stride = (entry_count & mask) | (~mask & 1)
+};
+HDK_DEV TableShape table_shape(const hdk_hip_plan* p) {
+  TableShape s;
+  s.key_count = __builtin_amdgcn_readfirstlane(p->key_count);
+  s.row_quads = __builtin_amdgcn_readfirstlane(p->row_size_quad);
+  const uint32_t columnar = __builtin_amdgcn_readfirstlane(static_cast<int>(p->output_columnar)) != 0 ? 1u : 0u;
+  const uint32_t key_width = __builtin_amdgcn_readfirstlane(p->key_width);
+  s.columnar_mask = 0u - columnar;
+  s.entry_stride_bytes = (key_width & s.columnar_mask) | ((s.row_quads * 8u) & ~s.columnar_mask);
+  return s;
+}
+
 // Find or claim the entry of `key` (packed components of width K) in a baseline table.
 // Returns the entry index or -1 (table full); *fresh tells whether this call created it.
 // Row-wise (get_matching_group_value, QE/cuda_mapd_rt.cu:167-203): CAS the first component, write
 // the rest, readers spin until the last component is published.  Columnar
 // (get_matching_group_value_columnar_slot, :229-261) likewise per key column.
 template <typename K>
-HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entry_count, const K* key,
-                              bool* fresh) {
-  const int nk = p->key_count;
-  const bool columnar = p->output_columnar;
+HDK_DEV int64_t find_or_claim(const TableShape shape, int64_t* buf, uint32_t entry_count, const K* key, bool* fresh) {
+  const int nk = shape.key_count;
   const uint32_t h = key_hash_dev<K>(key, nk) % entry_count;
   uint32_t probe = h;
   const K ek = empty_key<K>();
@@ -78,9 +100,8 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
   // wave, masked off until the branches reconverge) -- it re-examines the same slot on the next trip
   // of this loop, by which time every lane of the wave has passed the publishing block.
   while (result == -2) {
-    K* k0 = columnar ? reinterpret_cast<K*>(buf) + probe
-                     : reinterpret_cast<K*>(buf + static_cast<size_t>(probe) * p->row_size_quad);
-    const size_t kstride = columnar ? entry_count : 1;
+    K* k0 = reinterpret_cast<K*>(reinterpret_cast<int8_t*>(buf) + static_cast<size_t>(probe) * shape.entry_stride_bytes);
+    const size_t kstride = (entry_count & shape.columnar_mask) | (~shape.columnar_mask & 1u);
     // Look before claiming: a plain load is several times cheaper than an atomic on this part
     // (scripts/microbench/atomics.hip: ~2.4e10 atomics/s chip-wide vs >5e10 random loads/s), and once
     // a group exists every later row of it only needs the load.  A slot never returns to EMPTY.
@@ -141,6 +162,11 @@ HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entr
     }
   }
   return result;
+}
+
+template <typename K>
+HDK_DEV int64_t find_or_claim(const hdk_hip_plan* p, int64_t* buf, uint32_t entry_count, const K* key, bool* fresh) {
+  return find_or_claim<K>(table_shape(p), buf, entry_count, key, fresh);
 }
 
 }  // namespace hdk

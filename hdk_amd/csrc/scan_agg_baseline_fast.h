@@ -70,7 +70,8 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
   int64_t* buf = a.kp.groupby_buf[0];
-  const uint32_t rq = p->row_size_quad;
+  const TableShape shape = table_shape(p);  // scalar once: four inlined find_or_claim copies follow each other
+  const uint32_t rq = shape.row_quads;
   const bool entry16 = rq == 2;  // [key region 8 B | one 8-byte slot]
   const int nt = a.ntargets;
   constexpr int VR = kBaseFastVR;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
           entry[r] = home[r];
           have_slot[r] = entry16 && !kKeys16;
         } else {
-          entry[r] = find_or_claim<K>(p, buf, a.entry_count, key[r], &fresh[r]);
+          entry[r] = find_or_claim<K>(shape, buf, a.entry_count, key[r], &fresh[r]);
           if (entry[r] < 0) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;
             live[r] = false;

@@ -103,6 +103,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
   const int nt = p->num_targets;
   const int nk = p->key_count;
   const bool baseline = p->query_kind == HDK_Q_BASELINE_HASH;
+  const TableShape shape = table_shape(p);
   int64_t* buf = a.kp.groupby_buf[0];
 
   RowCtx c;
@@ -135,10 +136,10 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
           if (p->key_width == 4) {
             const int32_t key[HDK_HIP_MAX_KEYS] = {static_cast<int32_t>(k0), static_cast<int32_t>(k1),
                                                    static_cast<int32_t>(k2), static_cast<int32_t>(k3)};
-            entry = find_or_claim<int32_t>(p, buf, a.entry_count, key, &fresh);
+            entry = find_or_claim<int32_t>(shape, buf, a.entry_count, key, &fresh);
           } else {
             const int64_t key[HDK_HIP_MAX_KEYS] = {k0, k1, k2, k3};
-            entry = find_or_claim<int64_t>(p, buf, a.entry_count, key, &fresh);
+            entry = find_or_claim<int64_t>(shape, buf, a.entry_count, key, &fresh);
           }
           if (entry < 0) {
             err = HDK_HIP_ERR_OUT_OF_SLOTS;  // get_group_value returned NULL

@@ -302,11 +302,11 @@ HDK_DEV void part_load_targets(const PartArgs& a, const hdk_hip_plan* p, PartTar
 
 // one tuple -> its group in `table` (LDS image of a region, or the region itself): claim + aggregates
 template <typename K>
-HDK_DEV void part_apply_tuple(const hdk_hip_plan* p, const PartTarget* s_tg, int ntargets, uint32_t rq, int64_t* table,
+HDK_DEV void part_apply_tuple(const TableShape shape, const PartTarget* s_tg, int ntargets, uint32_t rq, int64_t* table,
                               uint32_t slots, const int64_t* tup, int32_t& err) {
   const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};  // (word 1 is only read as a key when key_count == 2)
   bool fresh;
-  const int64_t e = find_or_claim<K>(p, table, slots, key, &fresh);
+  const int64_t e = find_or_claim<K>(shape, table, slots, key, &fresh);
   if (e < 0) {
     err = HDK_HIP_ERR_OUT_OF_SLOTS;  // more groups in this slot range than it has entries
     return;
@@ -357,7 +357,10 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
   const uint32_t f = blockIdx.x;
-  const uint32_t rq = p->row_size_quad;
+  const TableShape shape = table_shape(p);
+  const uint32_t rq = shape.row_quads;
+  const int ntargets = a.ntargets;
+  const uint32_t slots = a.slots;
   part_load_targets(a, p, s_tg);
   const uint32_t words = a.slots * rq;
   int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(f) * words;
@@ -372,13 +375,30 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   const int tw = a.tw;
   const int64_t* in = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
   int32_t err = 0;
-  for (uint64_t i = tid; i < n; i += kPartAggBlock) {
-    int64_t tup[kPartMaxTW];
-#pragma unroll
-    for (int w = 0; w < kPartMaxTW; ++w) {
-      tup[w] = w < tw ? __builtin_nontemporal_load(in + i * tw + w) : 0;
+  // Two tuples per trip, the next pair's loads issued before the current pair is applied: the LDS
+  // claim/aggregate chain (ds_* ops, lgkmcnt) of one pair hides the HBM latency (vmcnt) of the next.
+  // Plain scalars on purpose -- no per-thread tuple arrays that could end up in scratch.
+  int64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+  auto fetch = [&](uint64_t i, int64_t& t0, int64_t& t1, int64_t& t2) {
+    if (i < n) {
+      const int64_t* q = in + i * tw;
+      t0 = __builtin_nontemporal_load(q);
+      t1 = tw > 1 ? __builtin_nontemporal_load(q + 1) : 0;
+      t2 = tw > 2 ? __builtin_nontemporal_load(q + 2) : 0;
     }
-    part_apply_tuple<K>(p, s_tg, a.ntargets, rq, lds_table, a.slots, tup, err);
+  };
+  fetch(tid, a0, a1, a2);
+  fetch(static_cast<uint64_t>(tid) + kPartAggBlock, b0, b1, b2);
+  for (uint64_t i = tid; i < n; i += 2 * kPartAggBlock) {
+    const int64_t ta[kPartMaxTW] = {a0, a1, a2};
+    const int64_t tb[kPartMaxTW] = {b0, b1, b2};
+    const bool has_b = i + kPartAggBlock < n;
+    fetch(i + 2 * kPartAggBlock, a0, a1, a2);
+    fetch(i + 3 * kPartAggBlock, b0, b1, b2);
+    part_apply_tuple<K>(shape, s_tg, ntargets, rq, lds_table, slots, ta, err);
+    if (has_b) {
+      part_apply_tuple<K>(shape, s_tg, ntargets, rq, lds_table, slots, tb, err);
+    }
   }
   if (err) {
     record_error(a.kp.error_code, err);
@@ -400,7 +420,8 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
   part_load_targets(a, p, s_tg);
   __syncthreads();
   const uint64_t n = min(static_cast<uint64_t>(*a.fill_ovf), a.cap_ovf);
-  const uint32_t rq = p->row_size_quad;
+  const TableShape shape = table_shape(p);
+  const uint32_t rq = shape.row_quads;
   const int tw = a.tw;
   int32_t err = 0;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kPartBlock + threadIdx.x; i < n;
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
     }
     const uint32_t f = part_fine_id<K>(tup, a.nkeys, a.fine_count);
     int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(f) * a.slots * rq;
-    part_apply_tuple<K>(p, s_tg, a.ntargets, rq, region, a.slots, tup, err);
+    part_apply_tuple<K>(shape, s_tg, a.ntargets, rq, region, a.slots, tup, err);
   }
   if (err) {
     record_error(a.kp.error_code, err);
