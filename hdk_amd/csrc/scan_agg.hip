@@ -415,6 +415,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_agg_partitioned.h"
 #include "scan_agg_global.h"
 #include "scan_agg_vec.h"
+#include "scan_agg_keys.h"
 #include "scan_project.h"
 #include "scan_project_fast.h"
 
@@ -491,6 +492,7 @@ struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
 static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
+static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
 static const void* baseline_direct_kernel(const hdk_hip_plan* p);
@@ -571,7 +573,11 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     const void* k;
     int block = kBlock;
-    if (s.strategy == STRAT_LDS) {
+    KeysArgs ka;
+    if (s.strategy == STRAT_LDS && !generic && match_keys(p, s, &ka)) {
+      k = reinterpret_cast<const void*>(hdk_scan_agg_keys);
+      block = kKeysBlock;
+    } else if (s.strategy == STRAT_LDS) {
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
                  : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_agg_vec_join)
                                  : reinterpret_cast<const void*>(hdk_scan_agg_vec));
@@ -804,6 +810,8 @@ static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s)
   FastArgs fa;
   int kw, vw;
   if (match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  KeysArgs ka;
+  if (match_keys(p, s, &ka)) return "hdk_scan_agg_keys";
   if (needs_join_loops(p)) return "hdk_scan_agg_generic";
   return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
 }
@@ -823,6 +831,14 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
       case 4: return launch_direct_kw<4>(vw, fa, shape, s);
       default: return launch_direct_kw<8>(vw, fa, shape, s);
     }
+  }
+  KeysArgs ka;
+  if (!force_generic && match_keys(plan, shape, &ka)) {
+    ka.kp = kp;
+    ka.slabs = slabs;
+    hipLaunchKernelGGL(hdk_scan_agg_keys, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
   }
   if (!force_scalar && !needs_join_loops(plan)) {
     VecArgs v;
@@ -849,6 +865,57 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   hipLaunchKernelGGL(hdk_scan_agg_generic, dim3(shape.grid), dim3(kBlock), shape.lds_bytes, s, a);
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
+}
+
+// the shape hdk_scan_agg_keys takes (scan_agg_keys.h): perfect hash on 1-3 integer outer columns, each
+// plain or under ONE of extract-year / decimal scale-down, row counts only, plain filters
+static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka) {
+  if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_PERFECT_HASH || p->num_joins) return false;
+  if (p->key_count < 1 || p->key_count > kKeysMax || shape.wpe != 1) return false;
+  if (!match_plain_quals(p, ka->q)) return false;
+  ka->nquals = p->num_quals;
+  ka->nkeys = p->key_count;
+  ka->entry_count = shape.entry_count;
+  ka->rep = shape.rep;
+  uint64_t stride = 1;
+  for (int k = 0; k < p->key_count; ++k) {
+    const hdk_hip_expr& e = p->keys[k];
+    if (e.leaf0.kind != HDK_LEAF_COL || e.nsteps > 1 || p->key_bucket[k]) return false;
+    const hdk_hip_col& c = p->cols[e.leaf0.col];
+    if (c.table != 0 || (c.kind != HDK_COL_INT && c.kind != HDK_COL_UNSIGNED)) return false;
+    KeysKey& kk = ka->key[k];
+    kk.buf_idx = c.buf_idx;
+    kk.width = c.width;
+    kk.is_unsigned = c.kind == HDK_COL_UNSIGNED;
+    kk.xf = KXF_NONE;
+    kk.param = 1;
+    kk.col_null = e.leaf0.null_val;
+    kk.col_nullable = e.leaf0.nullable;
+    kk.xf_null = 0;
+    if (e.nsteps == 1) {
+      const hdk_hip_step& st = e.steps[0];
+      if (st.out_class != HDK_VC_INT) return false;
+      if (st.op == HDK_OP_EXTRACT_YEAR) {
+        kk.xf = KXF_YEAR;
+      } else if (st.op == HDK_OP_SCALE_DOWN && st.rhs.ival > 0) {
+        kk.xf = KXF_SCALE_DOWN;
+        kk.param = st.rhs.ival;
+      } else {
+        return false;
+      }
+      kk.xf_null = st.null_out;
+    }
+    kk.translate = p->key_has_nulls[k] && e.nullable;
+    kk.key_null = e.null_val;
+    kk.translated = p->key_null_translated[k];
+    kk.kmin = p->key_min[k];
+    if (p->key_card[k] < 1 || static_cast<uint64_t>(p->key_card[k]) > shape.entry_count) return false;
+    kk.card = static_cast<uint32_t>(p->key_card[k]);
+    kk.stride = static_cast<uint32_t>(stride);
+    stride *= kk.card;
+    if (stride > shape.entry_count) return false;  // the table must hold every combination
+  }
+  return true;
 }
 
 // filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape

@@ -1,0 +1,181 @@
+// scan_agg_keys.h -- perfect-hash group-by on up to three TRANSFORMED keys, counting rows only.
+//
+// Shape: GroupByPerfectHash, no join, filters of the form `outer column cmp literal` (plain_quals.h),
+// 1-3 group keys each of which is an integer column of the outer table with at most one unary step
+// (EXTRACT(YEAR FROM ts) or the decimal scale-down of a CAST), and targets that need no value word:
+// projected keys and COUNT(*).  That is taxi Q3 (GROUP BY passenger_count, year(pickup_datetime)) and Q4
+// (... , cast(trip_distance as int)) of BASELINE config 4 (reference omniscidb/Benchmarks/taxi/
+// taxi_reduced_bench.cpp).  Same arithmetic as the batched interpreter (vec_eval.h: eval_key_v,
+// perfect_hash_entry_v; reference key computation QE/RuntimeFunctions.cpp get_columnar_perfect_hash*,
+// extract_year Utils/ExtractFromTime.cpp:150-190), same LDS table / slab / finalize protocol
+// (agg_common.h) -- what goes away is the interpreter: no expression walk, no 64-bit entry arithmetic
+// (the key terms are range-checked against their cardinalities and combined in 32 bits), one LDS atomic
+// per row.  The interpreter spends ~116 VALU instructions per row on these plans and is issue-bound at
+// 28-31 % of the HBM roofline; this kernel needs about 50.
+#pragma once
+#include "agg_common.h"
+#include "plain_quals.h"
+
+namespace hdk {
+
+constexpr int kKeysBlock = 256;
+constexpr int kKeysVR = 8;
+constexpr int kKeysMax = 3;
+
+enum KeyTransform : int32_t { KXF_NONE = 0, KXF_YEAR = 1, KXF_SCALE_DOWN = 2 };
+
+struct KeysKey {
+  int32_t buf_idx;
+  int32_t width;
+  int32_t is_unsigned;
+  int32_t xf;              // KeyTransform
+  int64_t param;           // KXF_SCALE_DOWN: the scale
+  int64_t col_null;        // in-band NULL of the column (widened)
+  int64_t xf_null;         // what the step yields for a NULL input (its null_out)
+  int64_t key_null;        // NULL of the key expression, replaced by `translated` when translate != 0
+  int64_t translated;
+  int64_t kmin;
+  int32_t col_nullable;
+  int32_t translate;
+  uint32_t card;
+  uint32_t stride;         // product of the cardinalities of the keys before this one
+};
+
+struct KeysArgs {
+  KernParams kp;
+  int64_t* slabs;
+  uint32_t entry_count;
+  uint32_t rep;
+  int32_t nkeys;
+  int32_t nquals;
+  KeysKey key[kKeysMax];
+  ProjFastQual q[kMaxPlainQuals];
+};
+
+extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  constexpr int VR = kKeysVR;
+  const int tid = threadIdx.x;
+  const uint32_t rep = a.rep;
+  const uint32_t total_words = a.entry_count * rep;  // one word (the row count) per entry
+  for (uint32_t i = tid; i < total_words; i += kKeysBlock) {
+    lds[i] = 0;
+  }
+  __syncthreads();
+
+  const uint32_t my_rep = tid & (rep - 1);
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  constexpr int64_t kTileRows = static_cast<int64_t>(kKeysBlock) * VR;
+  const int nk = a.nkeys;
+  int32_t err = 0;
+
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
+    const int8_t* const* cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTileRows + tid;
+      bool pass[VR];
+      int64_t row[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const int64_t rr = row0 + static_cast<int64_t>(r) * kKeysBlock;
+        pass[r] = rr < nrows;
+        row[r] = pass[r] ? rr : row0 - tid;  // dead slots re-read the tile's first row; their results are dropped
+      }
+      if (a.nquals) {
+        plain_quals_pass<VR>(a.q, a.nquals, cols, row, pass, true);
+      }
+      uint32_t entry[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        entry[r] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kKeysMax; ++k) {
+        if (k >= nk) {
+          break;
+        }
+        const KeysKey kk = a.key[k];
+        const int8_t* buf = cols[kk.buf_idx];
+        int64_t v[VR];
+        // the decoder switch is wave-uniform and sits outside the row loop
+#define HDK_KEYS_LOAD(T)                                \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {      \
+    v[r] = static_cast<int64_t>(gload<T>(buf, row[r], true)); \
+  }
+        if (kk.is_unsigned) {
+          switch (kk.width) {
+            case 1: HDK_KEYS_LOAD(uint8_t) break;
+            case 2: HDK_KEYS_LOAD(uint16_t) break;
+            case 4: HDK_KEYS_LOAD(uint32_t) break;
+            default: HDK_KEYS_LOAD(int64_t) break;
+          }
+        } else {
+          switch (kk.width) {
+            case 1: HDK_KEYS_LOAD(int8_t) break;
+            case 2: HDK_KEYS_LOAD(int16_t) break;
+            case 4: HDK_KEYS_LOAD(int32_t) break;
+            default: HDK_KEYS_LOAD(int64_t) break;
+          }
+        }
+#undef HDK_KEYS_LOAD
+        if (kk.xf != KXF_NONE) {  // unary step with the *_nullable convention: NULL in, the step's NULL out
+          const bool nullable = kk.col_nullable != 0;
+          if (kk.xf == KXF_YEAR) {
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              v[r] = (nullable && v[r] == kk.col_null) ? kk.xf_null : extract_year(v[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              v[r] = (nullable && v[r] == kk.col_null) ? kk.xf_null : scale_decimal_down(v[r], kk.param);
+            }
+          }
+        }
+        if (kk.translate) {  // perfect hash: the NULL key owns the slot past the range
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            v[r] = v[r] == kk.key_null ? kk.translated : v[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const uint64_t term = static_cast<uint64_t>(v[r] - kk.kmin);
+          if (term >= kk.card) {  // outside the range the table was sized for
+            if (pass[r]) {
+              err = HDK_HIP_ERR_OUT_OF_SLOTS;
+            }
+            pass[r] = false;
+          }
+          entry[r] += static_cast<uint32_t>(term) * kk.stride;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        if (pass[r]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + entry[r] * rep + my_rep), 1ull);
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+  __syncthreads();
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * a.entry_count;
+  for (uint32_t i = tid; i < a.entry_count; i += kKeysBlock) {
+    int64_t acc = 0;
+    for (uint32_t r = 0; r < rep; ++r) {
+      acc += lds[i * rep + r];
+    }
+    slab[i] = acc;
+  }
+}
+
+}  // namespace hdk

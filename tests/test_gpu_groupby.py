@@ -145,6 +145,44 @@ def test_multi_key_perfect_hash_taxi_like(oracle, gpu_executor_factory):
     assert cp.plan.query_kind == A.Q_PERFECT_HASH and cp.plan.key_count == 2
 
 
+def test_transformed_keys_kernel(oracle, gpu_executor_factory):
+    """hdk_scan_agg_keys (taxi Q3/Q4 shape: plain / year / decimal-cast keys, COUNT(*) only): NULL keys of every
+    kind, timestamps outside the 32-bit fast range of extract_year, negative decimals, a plain filter, 1-3 keys.
+    Checked against the oracle and against both interpreters."""
+    from hdk_amd.ir import Type
+    rng = np.random.default_rng(77)
+    n = 150_000
+    pc = rng.integers(0, 7, n).astype(np.int16)
+    pc[rng.random(n) < 0.02] = A.NULL_SMALLINT
+    ts = rng.integers(1230768000, 1451606400, n, dtype=np.int64)   # 2009..2015
+    ts[rng.random(n) < 0.01] = -8_640_000                           # 1969: the 64-bit path of extract_year
+    ts[rng.random(n) < 0.01] = 2_090_000_000                        # 2036: beyond the 32-bit fast range
+    ts[rng.random(n) < 0.02] = A.NULL_BIGINT
+    dist = rng.integers(-249, 850, n, dtype=np.int64)               # decimal(…,2): -2.49 .. 8.49 -> -2 .. 8
+    dist[rng.random(n) < 0.02] = A.NULL_BIGINT
+    flt = rng.integers(0, 100, n).astype(np.int32)
+    flt[rng.random(n) < 0.02] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("trips", {"pc": pc, "ts": ts, "dist": dist, "flt": flt}, fragment_size=40_001,
+                    types={"ts": Type("timestamp", 8, unit="s"), "dist": Type("decimal", 8, scale=2)})
+    cnt = Agg("count", None, "cnt")
+    cases = [
+        ([ColRef("pc"), ExtractYear(ColRef("ts"))], [KeyRef(0), KeyRef(1), cnt], []),
+        ([ColRef("pc"), ExtractYear(ColRef("ts")), Cast(ColRef("dist"), INT32)], [KeyRef(0), KeyRef(1), KeyRef(2), cnt], []),
+        ([ExtractYear(ColRef("ts"))], [KeyRef(0), cnt], [Cmp(ColRef("flt"), "<", Lit(30))]),
+        ([Cast(ColRef("dist"), INT32), ColRef("pc")], [cnt, KeyRef(1)], [Cmp(ColRef("flt"), ">=", Lit(50))]),
+    ]
+    for groupby, targets, quals in cases:
+        for columnar in (False, True):
+            q = QueryUnit("trips", quals=quals, groupby=groupby, targets=targets, output_columnar=columnar)
+            cp, res = _check(oracle, gpu_executor_factory, st, q)
+            ex = gpu_executor_factory(st)
+            step = ex.prepare(cp)
+            assert step.kernel_names().split(",")[0] == "hdk_scan_agg_keys", step.kernel_names()
+            step.free()
+            _check(oracle, gpu_executor_factory, st, q, grid=5)
+
+
 def test_mid_size_tables_stay_in_lds(oracle, gpu_executor_factory):
     """Perfect-hash tables of 32-60 KiB (unreplicated, 2 blocks per CU) still take the LDS kernels; one word
     more and the plan falls to global atomics.  Both must match the oracle."""
