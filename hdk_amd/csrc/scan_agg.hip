@@ -897,7 +897,7 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
       if (st.out_class != HDK_VC_INT) return false;
       if (st.op == HDK_OP_EXTRACT_YEAR) {
         kk.xf = KXF_YEAR;
-      } else if (st.op == HDK_OP_SCALE_DOWN && st.rhs.ival > 0) {
+      } else if (st.op == HDK_OP_SCALE_DOWN && st.rhs.ival > 0 && st.rhs.ival <= INT32_MAX) {
         kk.xf = KXF_SCALE_DOWN;
         kk.param = st.rhs.ival;
       } else {

@@ -94,11 +94,8 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
       for (int r = 0; r < VR; ++r) {
         entry[r] = 0;
       }
-#pragma unroll
-      for (int k = 0; k < kKeysMax; ++k) {
-        if (k >= nk) {
-          break;
-        }
+#pragma unroll 1  // one copy of the decoders and transforms: three unrolled copies spill SGPRs and triple the code
+      for (int k = 0; k < nk; ++k) {
         const KeysKey kk = a.key[k];
         const int8_t* buf = cols[kk.buf_idx];
         int64_t v[VR];
@@ -125,16 +122,67 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
 #undef HDK_KEYS_LOAD
         if (kk.xf != KXF_NONE) {  // unary step with the *_nullable convention: NULL in, the step's NULL out
           const bool nullable = kk.col_nullable != 0;
+          bool isnull[VR];
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            isnull[r] = nullable && v[r] == kk.col_null;
+          }
+          // Both transforms have a 32-bit form that covers practically every row and a 64-bit form that is
+          // 5-10x longer.  The short form runs straight-line for all VR rows (its result is simply unused
+          // where it does not apply); the long form is entered only by the lanes that hold such a row.
+          int64_t out[VR];
+          int need_long = 0;  // integer or-accumulation: a bool assigned under `if` compiles to an EXEC branch per row
           if (kk.xf == KXF_YEAR) {
+            // extract_year's fast range (device_common.h; reference Utils/ExtractFromTime.cpp:150-166)
+            constexpr uint32_t kEpochOffsetYear1900 = 2208988800u;
+            constexpr uint32_t kSecsJanToMar1900 = 5097600u;
+            constexpr uint32_t kSecondsPer4YearCycle = 126230400u;
+            constexpr uint32_t kSecsPerDay = 86400u;
+            constexpr uint32_t kSecondsPerNonLeapYear = 31536000u;
 #pragma unroll
             for (int r = 0; r < VR; ++r) {
-              v[r] = (nullable && v[r] == kk.col_null) ? kk.xf_null : extract_year(v[r]);
+              const bool fast = static_cast<uint64_t>(v[r]) <= static_cast<uint64_t>(UINT32_MAX - kEpochOffsetYear1900);
+              const uint32_t seconds_1900 = static_cast<uint32_t>(v[r]) + kEpochOffsetYear1900;
+              const uint32_t leap_years = (seconds_1900 - kSecsJanToMar1900) / kSecondsPer4YearCycle;
+              const uint32_t year = (seconds_1900 - leap_years * kSecsPerDay) / kSecondsPerNonLeapYear + 1900;
+              out[r] = static_cast<int32_t>(year);
+              need_long |= static_cast<int>(!fast) & static_cast<int>(!isnull[r]);
+            }
+            if (need_long) {
+#pragma unroll
+              for (int r = 0; r < VR; ++r) {
+                if (static_cast<uint64_t>(v[r]) > static_cast<uint64_t>(UINT32_MAX - kEpochOffsetYear1900) && !isnull[r]) {
+                  out[r] = extract_year(v[r]);
+                }
+              }
             }
           } else {
+            // scale_decimal_down (device_common.h; reference QE/RuntimeFunctions.cpp:245-262): round half away
+            // from zero, then divide by the scale (0 < scale <= INT32_MAX, checked by the matcher)
+            const int32_t scale32 = static_cast<int32_t>(kk.param);
+            const int64_t half = kk.param >> 1;
+            int64_t tmp[VR];
 #pragma unroll
             for (int r = 0; r < VR; ++r) {
-              v[r] = (nullable && v[r] == kk.col_null) ? kk.xf_null : scale_decimal_down(v[r], kk.param);
+              tmp[r] = v[r] >= 0 ? v[r] + half : v[r] - half;
+              const int32_t t32 = static_cast<int32_t>(tmp[r]);
+              const bool fast = t32 == tmp[r] && t32 != INT32_MIN;
+              out[r] = (fast ? t32 : 0) / scale32;
+              need_long |= static_cast<int>(!fast) & static_cast<int>(!isnull[r]);
             }
+            if (need_long) {
+#pragma unroll
+              for (int r = 0; r < VR; ++r) {
+                const int32_t t32 = static_cast<int32_t>(tmp[r]);
+                if (!(t32 == tmp[r] && t32 != INT32_MIN) && !isnull[r]) {
+                  out[r] = tmp[r] / kk.param;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            v[r] = isnull[r] ? kk.xf_null : out[r];
           }
         }
         if (kk.translate) {  // perfect hash: the NULL key owns the slot past the range
@@ -152,7 +200,7 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
             }
             pass[r] = false;
           }
-          entry[r] += static_cast<uint32_t>(term) * kk.stride;
+          entry[r] += __umul24(static_cast<uint32_t>(term), kk.stride);  // term < card, stride <= entry_count: both far below 2^24
         }
       }
 #pragma unroll
