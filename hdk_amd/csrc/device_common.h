@@ -116,35 +116,14 @@ HDK_DEV int64_t decode_col_g(const int8_t* buf, int32_t width, int32_t kind, int
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------------
-// 64-bit signed division is a ~150-instruction software sequence on this ISA; 32-bit division is ~25,
-// most of it (the reciprocal of a wave-uniform divisor) hoistable out of the row loops.  Operands that
-// fit 32 bits -- decimal scales, bucket sizes, literals, most column values -- take the short form; the
-// quotient/remainder is the same number either way.  (b != 0 and (a, b) != (INT64_MIN, -1) is the caller's job.)
-HDK_DEV bool fits_i32_div(int64_t a, int64_t b) {
-  const int32_t a32 = static_cast<int32_t>(a), b32 = static_cast<int32_t>(b);
-  return a32 == a && b32 == b && a32 != INT32_MIN;
-}
-HDK_DEV int64_t div_i64(int64_t a, int64_t b) {
-  if (fits_i32_div(a, b)) {
-    return static_cast<int32_t>(a) / static_cast<int32_t>(b);
-  }
-  return a / b;
-}
-HDK_DEV int64_t mod_i64(int64_t a, int64_t b) {
-  if (fits_i32_div(a, b)) {
-    return static_cast<int32_t>(a) % static_cast<int32_t>(b);
-  }
-  return a % b;
-}
-
 HDK_DEV int64_t floor_div_lhs(int64_t dividend, int64_t divisor) {
-  return div_i64(dividend < 0 ? dividend - (divisor - 1) : dividend, divisor);
+  return (dividend < 0 ? dividend - (divisor - 1) : dividend) / divisor;
 }
 
 HDK_DEV int64_t scale_decimal_down(int64_t operand, int64_t scale) {
   int64_t tmp = scale >> 1;
   tmp = operand >= 0 ? operand + tmp : operand - tmp;
-  return div_i64(tmp, scale);
+  return tmp / scale;
 }
 
 HDK_DEV int64_t extract_year(int64_t timeval) {
@@ -284,12 +263,12 @@ HDK_DEV int64_t eval_expr(const RowCtx& c, const hdk_hip_expr& e, int32_t& err) 
           case HDK_OP_DIV:
             if (b == 0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; }
             else if (a == INT64_MIN && b == -1) { r = INT64_MIN; }
-            else { r = div_i64(a, b); }
+            else { r = a / b; }
             break;
           default:  // MOD
             if (b == 0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; }
             else if (b == -1) { r = 0; }
-            else { r = mod_i64(a, b); }
+            else { r = a % b; }
             break;
         }
       }
@@ -365,7 +344,7 @@ HDK_DEV int64_t probe_join(const hdk_hip_join& jn, const int32_t* __restrict__ t
   if (k >= jn.min_key && k <= maxk) {
     int64_t off = k - jn.min_key;
     if (jn.bucket > 1) {
-      off = div_i64(off, jn.bucket);
+      off /= jn.bucket;
     }
     return table[off];
   }
@@ -388,7 +367,7 @@ HDK_DEV int64_t probe_join_g(const JoinT& jn, const int32_t* table, int64_t key,
   if (k >= jn.min_key && k <= maxk) {
     int64_t off = k - jn.min_key;
     if (jn.bucket > 1) {
-      off = div_i64(off, jn.bucket);
+      off /= jn.bucket;
     }
     *slot_out = off;
     return gload<int32_t>(reinterpret_cast<const int8_t*>(table), off, false);
@@ -593,7 +572,7 @@ HDK_DEV int64_t perfect_hash_entry(const RowCtx& c, int32_t& err) {
     const int64_t kv = eval_key(c, k, err);
     int64_t term = kv - p->key_min[k];
     if (p->key_bucket[k]) {
-      term = div_i64(term, p->key_bucket[k]);
+      term /= p->key_bucket[k];
     }
     h += term * stride;
     stride *= p->key_card[k];

@@ -249,7 +249,7 @@ HDK_DEV void eval_expr_v(const VecCtx& c, cexpr_t e, int64_t (&acc)[VR], const b
               const int64_t a = acc[r], b = rhs[r];
               const bool bad = b == 0;
               const int64_t bb = (bad || isnull[r]) ? 1 : b;
-              const int64_t res = (a == INT64_MIN && bb == -1) ? INT64_MIN : div_i64(a, bb);
+              const int64_t res = (a == INT64_MIN && bb == -1) ? INT64_MIN : a / bb;
               if (bad && !isnull[r] && live[r]) {
                 err = HDK_HIP_ERR_DIV_BY_ZERO;
               }
@@ -262,7 +262,7 @@ HDK_DEV void eval_expr_v(const VecCtx& c, cexpr_t e, int64_t (&acc)[VR], const b
               const int64_t a = acc[r], b = rhs[r];
               const bool bad = b == 0;
               const int64_t bb = (bad || isnull[r]) ? 1 : b;
-              const int64_t res = bb == -1 ? 0 : mod_i64(a, bb);
+              const int64_t res = bb == -1 ? 0 : a % bb;
               if (bad && !isnull[r] && live[r]) {
                 err = HDK_HIP_ERR_DIV_BY_ZERO;
               }
@@ -395,7 +395,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
           maxk = jn.translated_null;
         }
         in_range = in_range && k >= jn.min_key && k <= maxk;
-        slot = in_range ? (jn.bucket > 1 ? div_i64(k - jn.min_key, jn.bucket) : (k - jn.min_key)) : 0;
+        slot = in_range ? (jn.bucket > 1 ? (k - jn.min_key) / jn.bucket : (k - jn.min_key)) : 0;
         // one line fetch per probe: the row id and the first payload word come in together (a later,
         // separate payload gather would find the line evicted again -- 16 waves x 512 probes in flight
         // per CU dwarf the L1)
@@ -473,7 +473,7 @@ HDK_DEV void perfect_hash_entry_v(const VecCtx& c, int64_t (&entry)[VR], const b
     for (int r = 0; r < VR; ++r) {
       int64_t term = kv[r] - kmin;
       if (bucket) {
-        term = div_i64(term, bucket);
+        term /= bucket;
       }
       entry[r] += term * stride;
     }
