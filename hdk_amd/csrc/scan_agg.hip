@@ -872,17 +872,24 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka) {
   if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_PERFECT_HASH || p->num_joins) return false;
   if (p->key_count < 1 || p->key_count > kKeysMax || shape.wpe != 1) return false;
+  if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
   if (!match_plain_quals(p, ka->q)) return false;
   ka->nquals = p->num_quals;
   ka->nkeys = p->key_count;
   ka->entry_count = shape.entry_count;
   ka->rep = shape.rep;
+  ka->rep_shift = 0;
+  while ((1u << ka->rep_shift) < shape.rep) ++ka->rep_shift;
+  // 32-bit key terms wrap modulo 2^32: with |kmin| this far from the int32 limits no out-of-range value of a
+  // 32-bit key can wrap into [0, card)
+  constexpr int64_t kMinGuard = static_cast<int64_t>(INT32_MAX) - (1 << 25);
   uint64_t stride = 1;
   for (int k = 0; k < p->key_count; ++k) {
     const hdk_hip_expr& e = p->keys[k];
     if (e.leaf0.kind != HDK_LEAF_COL || e.nsteps > 1 || p->key_bucket[k]) return false;
     const hdk_hip_col& c = p->cols[e.leaf0.col];
     if (c.table != 0 || (c.kind != HDK_COL_INT && c.kind != HDK_COL_UNSIGNED)) return false;
+    if (c.width != 1 && c.width != 2 && c.width != 4 && c.width != 8) return false;
     KeysKey& kk = ka->key[k];
     kk.buf_idx = c.buf_idx;
     kk.width = c.width;
@@ -891,29 +898,63 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
     kk.param = 1;
     kk.col_null = e.leaf0.null_val;
     kk.col_nullable = e.leaf0.nullable;
-    kk.xf_null = 0;
+    kk.div_magic = 0;
+    kk.div_shift = 0;
+    int64_t step_null = 0;
     if (e.nsteps == 1) {
       const hdk_hip_step& st = e.steps[0];
       if (st.out_class != HDK_VC_INT) return false;
       if (st.op == HDK_OP_EXTRACT_YEAR) {
         kk.xf = KXF_YEAR;
-      } else if (st.op == HDK_OP_SCALE_DOWN && st.rhs.ival > 0 && st.rhs.ival <= INT32_MAX) {
+      } else if (st.op == HDK_OP_SCALE_DOWN && st.rhs.ival >= 2 && st.rhs.ival <= INT32_MAX) {
         kk.xf = KXF_SCALE_DOWN;
         kk.param = st.rhs.ival;
+        // unsigned 32-bit division by an invariant divisor, round-up method in its branch-free form
+        const uint32_t d = static_cast<uint32_t>(kk.param);
+        uint32_t log2d = 31;
+        while (!(d >> log2d)) --log2d;
+        if ((d & (d - 1)) == 0) {
+          kk.div_magic = 0;
+          kk.div_shift = static_cast<int32_t>(log2d) - 1;
+        } else {
+          const uint64_t two_k = 1ull << (32 + log2d);
+          uint64_t m = two_k / d;
+          const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
+          uint32_t m32 = static_cast<uint32_t>(m) * 2u;
+          const uint32_t twice_rem = rem * 2u;
+          if (twice_rem >= d || twice_rem < rem) m32 += 1;
+          kk.div_magic = m32 + 1u;
+          kk.div_shift = static_cast<int32_t>(log2d);
+        }
       } else {
         return false;
       }
-      kk.xf_null = st.null_out;
+      step_null = st.null_out;
     }
     kk.translate = p->key_has_nulls[k] && e.nullable;
     kk.key_null = e.null_val;
-    kk.translated = p->key_null_translated[k];
     kk.kmin = p->key_min[k];
     if (p->key_card[k] < 1 || static_cast<uint64_t>(p->key_card[k]) > shape.entry_count) return false;
     kk.card = static_cast<uint32_t>(p->key_card[k]);
     kk.stride = static_cast<uint32_t>(stride);
     stride *= kk.card;
     if (stride > shape.entry_count) return false;  // the table must hold every combination
+    const bool kmin_small = kk.kmin >= -kMinGuard && kk.kmin <= kMinGuard;
+    kk.kmin32 = kmin_small ? static_cast<int32_t>(kk.kmin) : 0;
+    // the value a NULL key takes (eval_key_v, vec_eval.h) and what it contributes
+    int64_t null_value;
+    if (kk.xf == KXF_NONE) {
+      null_value = p->key_null_translated[k];  // only reached when translate is on
+      const bool null32 = kk.key_null >= INT32_MIN && kk.key_null <= INT32_MAX;
+      kk.narrow = kmin_small && (c.width < 4 || (c.width == 4 && !kk.is_unsigned)) && (!kk.translate || null32);
+    } else {
+      if (!kmin_small) return false;  // the 32-bit forms of the transforms subtract kmin in 32 bits
+      null_value = (kk.translate && step_null == kk.key_null) ? p->key_null_translated[k] : step_null;
+      kk.narrow = 0;
+    }
+    const uint64_t nt = static_cast<uint64_t>(null_value) - static_cast<uint64_t>(kk.kmin);
+    kk.null_ok = nt < kk.card;
+    kk.null_term = static_cast<uint32_t>(nt);
   }
   return true;
 }

@@ -29,16 +29,21 @@ struct KeysKey {
   int32_t width;
   int32_t is_unsigned;
   int32_t xf;              // KeyTransform
-  int64_t param;           // KXF_SCALE_DOWN: the scale
+  int64_t param;           // KXF_SCALE_DOWN: the scale (2 .. INT32_MAX)
   int64_t col_null;        // in-band NULL of the column (widened)
-  int64_t xf_null;         // what the step yields for a NULL input (its null_out)
-  int64_t key_null;        // NULL of the key expression, replaced by `translated` when translate != 0
-  int64_t translated;
+  int64_t key_null;        // NULL of the key expression (plain keys: replaced by `translated` when translate != 0)
   int64_t kmin;
   int32_t col_nullable;
   int32_t translate;
   uint32_t card;
   uint32_t stride;         // product of the cardinalities of the keys before this one
+  // what a NULL key contributes: (translated or untranslated NULL) - kmin, worked out by the matcher
+  uint32_t null_term;
+  int32_t null_ok;         // that term is inside [0, card)
+  int32_t narrow;          // plain key whose column, NULL and kmin all fit 32 bits: the whole term is 32-bit
+  int32_t kmin32;
+  uint32_t div_magic;      // KXF_SCALE_DOWN: n / scale == (((n - mulhi(magic, n)) >> 1) + mulhi(magic, n)) >> div_shift
+  int32_t div_shift;       //   for every 32-bit unsigned n (round-up method, branch-free form)
 };
 
 struct KeysArgs {
@@ -46,6 +51,7 @@ struct KeysArgs {
   int64_t* slabs;
   uint32_t entry_count;
   uint32_t rep;
+  uint32_t rep_shift;      // rep == 1 << rep_shift
   int32_t nkeys;
   int32_t nquals;
   KeysKey key[kKeysMax];
@@ -94,119 +100,156 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
       for (int r = 0; r < VR; ++r) {
         entry[r] = 0;
       }
+      int bad = 0;  // some live row fell outside the range the table was sized for
 #pragma unroll 1  // one copy of the decoders and transforms: three unrolled copies spill SGPRs and triple the code
       for (int k = 0; k < nk; ++k) {
         const KeysKey kk = a.key[k];
         const int8_t* buf = cols[kk.buf_idx];
-        int64_t v[VR];
-        // the decoder switch is wave-uniform and sits outside the row loop
-#define HDK_KEYS_LOAD(T)                                \
-  _Pragma("unroll") for (int r = 0; r < VR; ++r) {      \
-    v[r] = static_cast<int64_t>(gload<T>(buf, row[r], true)); \
+        // term[r] = key - kmin as a 32-bit number, ok[r] = it lies in [0, card).  Everything that can be decided
+        // in 32 bits is: the 64-bit forms are kept for wide plain keys and for rows outside the fast ranges.
+        uint32_t term[VR];
+        bool ok[VR];
+#define HDK_KEYS_LOAD(DST, T)                              \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {         \
+    DST[r] = gload<T>(buf, row[r], true);                  \
   }
-        if (kk.is_unsigned) {
-          switch (kk.width) {
-            case 1: HDK_KEYS_LOAD(uint8_t) break;
-            case 2: HDK_KEYS_LOAD(uint16_t) break;
-            case 4: HDK_KEYS_LOAD(uint32_t) break;
-            default: HDK_KEYS_LOAD(int64_t) break;
+        if (kk.xf == KXF_NONE && kk.narrow) {
+          int32_t v[VR];
+          if (kk.is_unsigned) {
+            if (kk.width == 1) { HDK_KEYS_LOAD(v, uint8_t) } else { HDK_KEYS_LOAD(v, uint16_t) }
+          } else if (kk.width == 1) {
+            HDK_KEYS_LOAD(v, int8_t)
+          } else if (kk.width == 2) {
+            HDK_KEYS_LOAD(v, int16_t)
+          } else {
+            HDK_KEYS_LOAD(v, int32_t)
+          }
+          const int32_t null32 = static_cast<int32_t>(kk.key_null);
+          const bool translate = kk.translate != 0;
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const bool isnull = translate && v[r] == null32;  // perfect hash: the NULL key owns the slot past the range
+            const uint32_t d = static_cast<uint32_t>(v[r]) - static_cast<uint32_t>(kk.kmin32);
+            term[r] = isnull ? kk.null_term : d;
+            ok[r] = isnull ? kk.null_ok != 0 : d < kk.card;
           }
         } else {
-          switch (kk.width) {
-            case 1: HDK_KEYS_LOAD(int8_t) break;
-            case 2: HDK_KEYS_LOAD(int16_t) break;
-            case 4: HDK_KEYS_LOAD(int32_t) break;
-            default: HDK_KEYS_LOAD(int64_t) break;
+          int64_t v[VR];
+          if (kk.is_unsigned) {
+            switch (kk.width) {
+              case 1: HDK_KEYS_LOAD(v, uint8_t) break;
+              case 2: HDK_KEYS_LOAD(v, uint16_t) break;
+              case 4: HDK_KEYS_LOAD(v, uint32_t) break;
+              default: HDK_KEYS_LOAD(v, int64_t) break;
+            }
+          } else {
+            switch (kk.width) {
+              case 1: HDK_KEYS_LOAD(v, int8_t) break;
+              case 2: HDK_KEYS_LOAD(v, int16_t) break;
+              case 4: HDK_KEYS_LOAD(v, int32_t) break;
+              default: HDK_KEYS_LOAD(v, int64_t) break;
+            }
+          }
+          bool isnull[VR];
+          if (kk.xf == KXF_NONE) {  // wide plain key
+            const bool translate = kk.translate != 0;
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              isnull[r] = translate && v[r] == kk.key_null;
+              const uint64_t d = static_cast<uint64_t>(v[r]) - static_cast<uint64_t>(kk.kmin);
+              term[r] = static_cast<uint32_t>(d);
+              ok[r] = d < kk.card;
+            }
+          } else {
+            // unary step with the *_nullable convention (NULL in, the step's NULL out; the matcher folded what
+            // that NULL contributes into null_term / null_ok).  Both steps have a 32-bit form that covers
+            // practically every row and a 64-bit form that is 5-10x longer: the short form runs straight-line
+            // for all VR rows, the long form is entered only by lanes that hold a row outside the fast range.
+            const bool nullable = kk.col_nullable != 0;
+            int need_long = 0;  // integer or-accumulation: a bool assigned under `if` compiles to an EXEC branch per row
+            bool fast[VR];
+            if (kk.xf == KXF_YEAR) {
+              // extract_year's fast range (device_common.h; reference Utils/ExtractFromTime.cpp:150-166)
+              constexpr uint32_t kEpochOffsetYear1900 = 2208988800u;
+              constexpr uint32_t kSecsJanToMar1900 = 5097600u;
+              constexpr uint32_t kSecondsPer4YearCycle = 126230400u;
+              constexpr uint32_t kSecsPerDay = 86400u;
+              constexpr uint32_t kSecondsPerNonLeapYear = 31536000u;
+#pragma unroll
+              for (int r = 0; r < VR; ++r) {
+                isnull[r] = nullable && v[r] == kk.col_null;
+                fast[r] = static_cast<uint64_t>(v[r]) <= static_cast<uint64_t>(UINT32_MAX - kEpochOffsetYear1900);
+                const uint32_t seconds_1900 = static_cast<uint32_t>(v[r]) + kEpochOffsetYear1900;
+                const uint32_t leap_years = (seconds_1900 - kSecsJanToMar1900) / kSecondsPer4YearCycle;
+                const uint32_t year = (seconds_1900 - leap_years * kSecsPerDay) / kSecondsPerNonLeapYear + 1900;
+                const uint32_t d = year - static_cast<uint32_t>(kk.kmin32);
+                term[r] = d;
+                ok[r] = d < kk.card;
+                need_long |= static_cast<int>(!fast[r]) & static_cast<int>(!isnull[r]);
+              }
+              if (need_long) {
+#pragma unroll
+                for (int r = 0; r < VR; ++r) {
+                  if (!fast[r] && !isnull[r]) {
+                    const uint64_t d = static_cast<uint64_t>(extract_year(v[r])) - static_cast<uint64_t>(kk.kmin);
+                    term[r] = static_cast<uint32_t>(d);
+                    ok[r] = d < kk.card;
+                  }
+                }
+              }
+            } else {
+              // scale_decimal_down (device_common.h; reference QE/RuntimeFunctions.cpp:245-262): round half away
+              // from zero, then divide by the scale, truncating
+              const int64_t half = kk.param >> 1;
+              int64_t tmp[VR];
+#pragma unroll
+              for (int r = 0; r < VR; ++r) {
+                isnull[r] = nullable && v[r] == kk.col_null;
+                tmp[r] = v[r] >= 0 ? v[r] + half : v[r] - half;
+                const int32_t t32 = static_cast<int32_t>(tmp[r]);
+                fast[r] = t32 == tmp[r] && t32 != INT32_MIN;
+                const uint32_t n = static_cast<uint32_t>(t32 < 0 ? -t32 : t32);
+                const uint32_t hi = __umulhi(kk.div_magic, n);
+                const uint32_t q = (((n - hi) >> 1) + hi) >> kk.div_shift;
+                const uint32_t sq = t32 < 0 ? 0u - q : q;
+                const uint32_t d = sq - static_cast<uint32_t>(kk.kmin32);
+                term[r] = d;
+                ok[r] = d < kk.card;
+                need_long |= static_cast<int>(!fast[r]) & static_cast<int>(!isnull[r]);
+              }
+              if (need_long) {
+#pragma unroll
+                for (int r = 0; r < VR; ++r) {
+                  if (!fast[r] && !isnull[r]) {
+                    const uint64_t d = static_cast<uint64_t>(tmp[r] / kk.param) - static_cast<uint64_t>(kk.kmin);
+                    term[r] = static_cast<uint32_t>(d);
+                    ok[r] = d < kk.card;
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            term[r] = isnull[r] ? kk.null_term : term[r];
+            ok[r] = isnull[r] ? kk.null_ok != 0 : ok[r];
           }
         }
 #undef HDK_KEYS_LOAD
-        if (kk.xf != KXF_NONE) {  // unary step with the *_nullable convention: NULL in, the step's NULL out
-          const bool nullable = kk.col_nullable != 0;
-          bool isnull[VR];
-#pragma unroll
-          for (int r = 0; r < VR; ++r) {
-            isnull[r] = nullable && v[r] == kk.col_null;
-          }
-          // Both transforms have a 32-bit form that covers practically every row and a 64-bit form that is
-          // 5-10x longer.  The short form runs straight-line for all VR rows (its result is simply unused
-          // where it does not apply); the long form is entered only by the lanes that hold such a row.
-          int64_t out[VR];
-          int need_long = 0;  // integer or-accumulation: a bool assigned under `if` compiles to an EXEC branch per row
-          if (kk.xf == KXF_YEAR) {
-            // extract_year's fast range (device_common.h; reference Utils/ExtractFromTime.cpp:150-166)
-            constexpr uint32_t kEpochOffsetYear1900 = 2208988800u;
-            constexpr uint32_t kSecsJanToMar1900 = 5097600u;
-            constexpr uint32_t kSecondsPer4YearCycle = 126230400u;
-            constexpr uint32_t kSecsPerDay = 86400u;
-            constexpr uint32_t kSecondsPerNonLeapYear = 31536000u;
-#pragma unroll
-            for (int r = 0; r < VR; ++r) {
-              const bool fast = static_cast<uint64_t>(v[r]) <= static_cast<uint64_t>(UINT32_MAX - kEpochOffsetYear1900);
-              const uint32_t seconds_1900 = static_cast<uint32_t>(v[r]) + kEpochOffsetYear1900;
-              const uint32_t leap_years = (seconds_1900 - kSecsJanToMar1900) / kSecondsPer4YearCycle;
-              const uint32_t year = (seconds_1900 - leap_years * kSecsPerDay) / kSecondsPerNonLeapYear + 1900;
-              out[r] = static_cast<int32_t>(year);
-              need_long |= static_cast<int>(!fast) & static_cast<int>(!isnull[r]);
-            }
-            if (need_long) {
-#pragma unroll
-              for (int r = 0; r < VR; ++r) {
-                if (static_cast<uint64_t>(v[r]) > static_cast<uint64_t>(UINT32_MAX - kEpochOffsetYear1900) && !isnull[r]) {
-                  out[r] = extract_year(v[r]);
-                }
-              }
-            }
-          } else {
-            // scale_decimal_down (device_common.h; reference QE/RuntimeFunctions.cpp:245-262): round half away
-            // from zero, then divide by the scale (0 < scale <= INT32_MAX, checked by the matcher)
-            const int32_t scale32 = static_cast<int32_t>(kk.param);
-            const int64_t half = kk.param >> 1;
-            int64_t tmp[VR];
-#pragma unroll
-            for (int r = 0; r < VR; ++r) {
-              tmp[r] = v[r] >= 0 ? v[r] + half : v[r] - half;
-              const int32_t t32 = static_cast<int32_t>(tmp[r]);
-              const bool fast = t32 == tmp[r] && t32 != INT32_MIN;
-              out[r] = (fast ? t32 : 0) / scale32;
-              need_long |= static_cast<int>(!fast) & static_cast<int>(!isnull[r]);
-            }
-            if (need_long) {
-#pragma unroll
-              for (int r = 0; r < VR; ++r) {
-                const int32_t t32 = static_cast<int32_t>(tmp[r]);
-                if (!(t32 == tmp[r] && t32 != INT32_MIN) && !isnull[r]) {
-                  out[r] = tmp[r] / kk.param;
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < VR; ++r) {
-            v[r] = isnull[r] ? kk.xf_null : out[r];
-          }
-        }
-        if (kk.translate) {  // perfect hash: the NULL key owns the slot past the range
-#pragma unroll
-          for (int r = 0; r < VR; ++r) {
-            v[r] = v[r] == kk.key_null ? kk.translated : v[r];
-          }
-        }
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          const uint64_t term = static_cast<uint64_t>(v[r] - kk.kmin);
-          if (term >= kk.card) {  // outside the range the table was sized for
-            if (pass[r]) {
-              err = HDK_HIP_ERR_OUT_OF_SLOTS;
-            }
-            pass[r] = false;
-          }
-          entry[r] += __umul24(static_cast<uint32_t>(term), kk.stride);  // term < card, stride <= entry_count: both far below 2^24
+          bad |= static_cast<int>(pass[r]) & static_cast<int>(!ok[r]);
+          pass[r] = pass[r] && ok[r];
+          entry[r] += __umul24(term[r], kk.stride);  // term < card, stride <= entry_count: both far below 2^24
         }
+      }
+      if (bad) {
+        err = HDK_HIP_ERR_OUT_OF_SLOTS;
       }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
         if (pass[r]) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(lds + entry[r] * rep + my_rep), 1ull);
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + ((entry[r] << a.rep_shift) + my_rep)), 1ull);
         }
       }
     }
