@@ -79,6 +79,10 @@ HDK_DEV int64_t decode_col(const int8_t* __restrict__ buf, int32_t width, int32_
   }
 }
 
+// NOTE on `nt`: with a run-time flag the two loads of `nt ? nontemporal : plain` are merged by the optimiser into
+// ONE plain load (the hint is metadata and does not survive the merge) -- the generated ISA of the interpreter
+// kernels carries no `nt` bit.  Kernels that depend on the hint call __builtin_nontemporal_load directly
+// (scan_agg_keys.h, scan_agg_partitioned.h).
 // Same decode through an explicit GLOBAL address-space pointer (column buffers are hipMalloc'ed:
 // a pointer loaded from COL_BUFFERS is otherwise generic and compiles to flat_load), optionally
 // non-temporal: streamed outer-table columns should not evict the join tables from the

@@ -111,7 +111,8 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
         bool ok[VR];
 #define HDK_KEYS_LOAD(DST, T)                              \
   _Pragma("unroll") for (int r = 0; r < VR; ++r) {         \
-    DST[r] = gload<T>(buf, row[r], true);                  \
+    DST[r] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) T*>( \
+                                            reinterpret_cast<uintptr_t>(buf)) + row[r]);               \
   }
         if (kk.xf == KXF_NONE && kk.narrow) {
           int32_t v[VR];
