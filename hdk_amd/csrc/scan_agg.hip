@@ -1368,9 +1368,27 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       uint32_t* counts = nullptr;  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
       HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&counts), static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
       pf.block_counts = counts;
+      // selection bitmask handed from the counting pass to the writing pass: rows/8 bytes when the caller
+      // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
+      // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
+      pf.sel_mask = nullptr;
+      pf.sel_tiles = 0;
+      if (ko && ko->total_rows) {
+        const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
+        void* m = nullptr;
+        if (hipMallocAsync(&m, tiles * kProjFastBlock, s) == hipSuccess) {
+          pf.sel_mask = static_cast<uint8_t*>(m);
+          pf.sel_tiles = tiles;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
       hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
       hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      if (pf.sel_mask) {
+        HDK_HIP_CHECK(hipFreeAsync(pf.sel_mask, s));
+      }
       HDK_HIP_CHECK(hipFreeAsync(counts, s));
     } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
       hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);

@@ -9,7 +9,10 @@
 //     little more than the filter columns;
 //   * no output claims at all: pass 1 (MODE 0) only counts the passing rows of each block's tiles, a
 //     one-block scan turns the per-block counts into output offsets (and adds the total to
-//     TOTAL_MATCHED), pass 2 (MODE 1) re-evaluates the filter and writes at offset + running count.
+//     TOTAL_MATCHED), pass 2 (MODE 1) writes at offset + running count.  Pass 1 leaves its verdicts behind
+//     as a selection bitmask (one bit per row, rows/8 bytes of stream-ordered scratch), so pass 2 reads
+//     1 bit per row instead of decoding the filter columns again; without scratch (or past its end) it
+//     re-evaluates the filter.
 //     A claim per tile is a same-address atomic on the critical path of every tile (its round trip
 //     under contention, not the bandwidth, set the pace: 1.7 ms per 256 M rows at any selectivity);
 //     reading the filter columns twice costs 8 B/row here and removes it.  Output rows come out in
@@ -40,6 +43,8 @@ struct ProjFastArgs {
   ProjFastTarget t[HDK_HIP_MAX_TARGETS];
   uint64_t col_off[HDK_HIP_MAX_TARGETS];  // columnar: byte offset of each target column
   uint32_t* block_counts;                 // [gridDim.x]: pass-1 counts, then exclusive offsets
+  uint8_t* sel_mask;                      // pass 1 -> pass 2: one byte (VR pass bits) per thread and tile, or nullptr
+  uint64_t sel_tiles;                     // tiles the mask has room for; later tiles re-evaluate the filter in pass 2
 };
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
@@ -158,37 +163,55 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       for (int r = 0; r < VR; ++r) {
         pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
       }
-      // ---- filter: decode + compare, all VR loads of a column in flight together -----------------------
-      for (int qi = 0; qi < a.nquals; ++qi) {
-        const ProjFastQual q = a.q[qi];
-        const int8_t* qb = cols[q.col.buf_idx];
-        int64_t v[VR];
-        load_rows<VR, kProjFastBlock, R>(qb, q.col.width, q.col.kind, row0, tid, pass, MODE == 1, v);  // pass 1 leaves the lines cached
-        const bool fpc = q.fp != 0;
-        const bool col_fp = q.col_fp != 0;
-        const bool nullable = q.nullable != 0;
+      const bool masked = a.sel_mask != nullptr && static_cast<uint64_t>(tile) < a.sel_tiles;  // block-uniform
+      uint8_t* mask_at = a.sel_mask + static_cast<size_t>(tile) * kProjFastBlock + tid;
+      if (MODE == 1 && masked) {
+        const uint32_t m = __builtin_nontemporal_load(mask_at);
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
-          pass[r] = pass[r] && !isnull;
-          if (fpc && !col_fp) {
-            v[r] = double_to_bits(static_cast<double>(v[r]));
-          }
+          pass[r] = (m >> r) & 1u;
         }
-        // the comparison operator is wave-uniform: one switch per batch, the row loop inside each case
+      } else {
+        // ---- filter: decode + compare, all VR loads of a column in flight together -----------------------
+        for (int qi = 0; qi < a.nquals; ++qi) {
+          const ProjFastQual q = a.q[qi];
+          const int8_t* qb = cols[q.col.buf_idx];
+          int64_t v[VR];
+          load_rows<VR, kProjFastBlock, R>(qb, q.col.width, q.col.kind, row0, tid, pass, MODE == 1, v);  // pass 1 leaves the lines cached
+          const bool fpc = q.fp != 0;
+          const bool col_fp = q.col_fp != 0;
+          const bool nullable = q.nullable != 0;
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
+            pass[r] = pass[r] && !isnull;
+            if (fpc && !col_fp) {
+              v[r] = double_to_bits(static_cast<double>(v[r]));
+            }
+          }
+          // the comparison operator is wave-uniform: one switch per batch, the row loop inside each case
 #define HDK_PF_CMP(OP)                                                                                   \
   _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                       \
-    pass[r] = pass[r] && (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs));      \
-  }
-        switch (q.cmp) {
-          case HDK_CMP_EQ: HDK_PF_CMP(==) break;
-          case HDK_CMP_NE: HDK_PF_CMP(!=) break;
-          case HDK_CMP_LT: HDK_PF_CMP(<) break;
-          case HDK_CMP_GT: HDK_PF_CMP(>) break;
-          case HDK_CMP_LE: HDK_PF_CMP(<=) break;
-          default: HDK_PF_CMP(>=) break;
-        }
+      pass[r] = pass[r] && (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs));      \
+    }
+          switch (q.cmp) {
+            case HDK_CMP_EQ: HDK_PF_CMP(==) break;
+            case HDK_CMP_NE: HDK_PF_CMP(!=) break;
+            case HDK_CMP_LT: HDK_PF_CMP(<) break;
+            case HDK_CMP_GT: HDK_PF_CMP(>) break;
+            case HDK_CMP_LE: HDK_PF_CMP(<=) break;
+            default: HDK_PF_CMP(>=) break;
+          }
 #undef HDK_PF_CMP
+        }
+      }
+      if (MODE == 0 && masked) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          m |= (pass[r] ? 1u : 0u) << r;
+        }
+        *mask_at = static_cast<uint8_t>(m);
       }
       uint32_t mine = 0;
 #pragma unroll

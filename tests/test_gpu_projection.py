@@ -109,3 +109,28 @@ def test_direct_filter_project_kernel(oracle, gpu_executor_factory, columnar):
     assert res.total_matched == nrows == int((a < 500).sum()) and res.error_code < 0
     got = rs.to_columns(cp, res.buffer, nrows=5000)
     assert len(got["a"]) == 5000 and all(x < 500 for x in got["a"])
+
+
+def test_selection_mask_and_its_fallbacks(oracle, gpu_executor_factory):
+    """The counting pass hands a selection bitmask to the writing pass when the launch states its row count.
+    Same rows with the mask, without it (total_rows = 0: the filter is evaluated twice) and with a mask that is
+    too short (tiles past its end re-evaluate) -- 5 M rows = 1221 tiles against the 1024 tiles of slack."""
+    rng = np.random.default_rng(33)
+    n = 5_000_000
+    a = rng.integers(0, 1000, n).astype(np.int64)
+    b = rng.integers(-500, 500, n).astype(np.int32)
+    st = ArrowStorage()
+    st.import_numpy("t", {"a": a, "b": b}, fragment_size=1_300_007)
+    q = QueryUnit("t", quals=[Cmp(ColRef("a"), "<", Lit(37))], output_columnar=True,
+                  targets=[Proj(ColRef("a"), "a"), Proj(ColRef("b"), "b")])
+    cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+    assert err == 0 and nrows == int((a < 37).sum())
+    ex = gpu_executor_factory(st)
+    for total_rows in (n, 0, 1):
+        step = ex.prepare(cp)
+        assert step.kernel_names().endswith("hdk_scan_project_direct")
+        step.ko.total_rows = total_rows
+        res = step.run()
+        step.free()
+        assert res.total_matched == nrows, total_rows
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), total_rows
