@@ -45,6 +45,7 @@ struct ProjFastArgs {
   uint32_t* block_counts;                 // [gridDim.x]: pass-1 counts, then exclusive offsets
   uint8_t* sel_mask;                      // pass 1 -> pass 2: one byte (VR pass bits) per thread and tile, or nullptr
   uint64_t sel_tiles;                     // tiles the mask has room for; later tiles re-evaluate the filter in pass 2
+  uint32_t* wave_counts;                  // pass 1 -> pass 2: passing rows per (tile, wave), [sel_tiles][waves per block]
 };
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
@@ -136,6 +137,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   constexpr int VR = kProjFastVR;
   constexpr int kWaves = kProjFastBlock / kWave;
   __shared__ uint32_t s_wave_tot[2][kWaves];
+  __shared__ uint16_t s_rows[kWaves][kWave * kProjFastVR];  // MODE 1: per wave, tile-relative rows that pass, in output order
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
@@ -220,6 +222,16 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       }
       if (MODE == 0) {
         counted += mine;
+        if (masked) {  // per-wave total of the tile: pass 2 derives its output positions from these, no barrier
+          uint32_t wsum = mine;
+#pragma unroll
+          for (int d = kWave / 2; d > 0; d >>= 1) {
+            wsum += __shfl_down(wsum, d, kWave);
+          }
+          if (lane == 0) {
+            a.wave_counts[static_cast<size_t>(tile) * kWaves + wave] = wsum;
+          }
+        }
         continue;
       }
       // ---- selection vector -> dense output positions inside the block's range ------------------------
@@ -231,42 +243,68 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
           incl += n;
         }
       }
-      const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one tile ahead
-      if (lane == kWave - 1) {
-        s_wave_tot[par][wave] = incl;
-      }
-      __syncthreads();
       uint32_t out_pos = running + incl - mine;
       uint32_t tile_total = 0;
+      if (masked) {
+        // the tile's per-wave totals were left by pass 1: every wave adds up the ones before it on its own.
+        // No barrier, no LDS: the waves of a block run their load -> scan -> gather -> store chains independently
+        // (with the barrier a block advanced one memory round trip per tile: 0.8 ms per 256 M rows at 1 %)
+        const uint32_t* wc = a.wave_counts + static_cast<size_t>(tile) * kWaves;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-        const uint32_t t = s_wave_tot[par][w];
-        tile_total += t;
-        if (w < wave) {
-          out_pos += t;
+        for (int w = 0; w < kWaves; ++w) {
+          const uint32_t t = wc[w];
+          tile_total += t;
+          if (w < wave) {
+            out_pos += t;
+          }
         }
+      } else {
+        const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one tile ahead
+        if (lane == kWave - 1) {
+          s_wave_tot[par][wave] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          const uint32_t t = s_wave_tot[par][w];
+          tile_total += t;
+          if (w < wave) {
+            out_pos += t;
+          }
+        }
+        ++iter;
       }
       running += tile_total;
-      ++iter;
-      uint32_t pos_r[VR];
+      // ---- compact: the wave's passing rows, in output order, into its LDS strip ------------------------
+      // Lane j of the wave then handles the j-th passing row: every gather and store instruction has all its
+      // lanes busy and consecutive lanes write consecutive output rows (coalesced), instead of VR predicated
+      // load/store groups per lane in which a selective filter leaves 1 lane in 100 active.
+      const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+      const uint32_t wave_base = out_pos - (incl - mine);  // first output row of this wave's rows
+      {
+        uint32_t j = incl - mine;
 #pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        pos_r[r] = out_pos;
-        if (pass[r]) {
-          ++out_pos;
-          if (pos_r[r] >= max_matched) {
-            slots_err = -1 - static_cast<int32_t>(pf_row<kProjFastBlock, R>(row0, tid, r) & 0x3fffffff);
-            pass[r] = false;
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r]) {
+            s_rows[wave][j++] = static_cast<uint16_t>(r * kProjFastBlock + tid);  // row inside the tile (< 4096)
           }
         }
       }
-      // ---- project: row position, then each target column (loads only for passing rows) ---------------
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- project: row position, then each target column ---------------------------------------------
       const size_t rq = a.row_size_quad;
-#pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        if (pass[r]) {
-          buf[columnar ? static_cast<size_t>(pos_r[r]) : static_cast<size_t>(pos_r[r]) * rq] =
-              pf_row<kProjFastBlock, R>(row0, tid, r);
+      for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        if (j < wave_total) {
+          const int64_t row = row0 + s_rows[wave][j];
+          const uint32_t pos = wave_base + j;
+          if (pos >= max_matched) {
+            slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
+          } else {
+            buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
+          }
         }
       }
       for (int ti = 0; ti < a.ntargets; ++ti) {
@@ -274,22 +312,23 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
         const int8_t* tb = cols[t.col.buf_idx];
         int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
         const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
-        int64_t v[VR];
-        load_rows<VR, kProjFastBlock, R>(tb, t.col.width, t.col.kind, row0, tid, pass, true, v);
-#define HDK_PF_STORE(T)                                                                              \
-  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                   \
-    if (pass[r]) {                                                                                   \
-      *reinterpret_cast<T*>(base + static_cast<size_t>(pos_r[r]) * stride) = static_cast<T>(v[r]);   \
-    }                                                                                                \
-  }
-        switch (t.slot_width) {
-          case 1: HDK_PF_STORE(int8_t) break;
-          case 2: HDK_PF_STORE(int16_t) break;
-          case 4: HDK_PF_STORE(int32_t) break;
-          default: HDK_PF_STORE(int64_t) break;
+        for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+          const uint32_t j = j0 + lane;
+          const uint32_t pos = wave_base + j;
+          if (j < wave_total && pos < max_matched) {
+            const int64_t row = row0 + s_rows[wave][j];
+            const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
+            int8_t* dst = base + static_cast<size_t>(pos) * stride;
+            switch (t.slot_width) {
+              case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
+              case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v); break;
+              case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v); break;
+              default: *reinterpret_cast<int64_t*>(dst) = v; break;
+            }
+          }
         }
-#undef HDK_PF_STORE
       }
+      __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next tile
     }
     frag_tile_begin += ntiles;
   }
