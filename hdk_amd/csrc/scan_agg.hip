@@ -1372,15 +1372,12 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
       // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
       pf.sel_mask = nullptr;
-      pf.wave_counts = nullptr;
       pf.sel_tiles = 0;
       if (ko && ko->total_rows) {
         const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
-        constexpr uint64_t kWaveCountBytes = (kProjFastBlock / kWave) * sizeof(uint32_t);  // per tile, after the mask bytes
         void* m = nullptr;
-        if (hipMallocAsync(&m, tiles * (kProjFastBlock + kWaveCountBytes), s) == hipSuccess) {
+        if (hipMallocAsync(&m, tiles * kProjFastBlock, s) == hipSuccess) {
           pf.sel_mask = static_cast<uint8_t*>(m);
-          pf.wave_counts = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(m) + tiles * kProjFastBlock);
           pf.sel_tiles = tiles;
         } else {
           (void)hipGetLastError();

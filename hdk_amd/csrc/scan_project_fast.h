@@ -45,7 +45,6 @@ struct ProjFastArgs {
   uint32_t* block_counts;                 // [gridDim.x]: pass-1 counts, then exclusive offsets
   uint8_t* sel_mask;                      // pass 1 -> pass 2: one byte (VR pass bits) per thread and tile, or nullptr
   uint64_t sel_tiles;                     // tiles the mask has room for; later tiles re-evaluate the filter in pass 2
-  uint32_t* wave_counts;                  // pass 1 -> pass 2: passing rows per (tile, wave), [sel_tiles][waves per block]
 };
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
@@ -222,16 +221,6 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       }
       if (MODE == 0) {
         counted += mine;
-        if (masked) {  // per-wave total of the tile: pass 2 derives its output positions from these, no barrier
-          uint32_t wsum = mine;
-#pragma unroll
-          for (int d = kWave / 2; d > 0; d >>= 1) {
-            wsum += __shfl_down(wsum, d, kWave);
-          }
-          if (lane == 0) {
-            a.wave_counts[static_cast<size_t>(tile) * kWaves + wave] = wsum;
-          }
-        }
         continue;
       }
       // ---- selection vector -> dense output positions inside the block's range ------------------------
@@ -245,20 +234,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       }
       uint32_t out_pos = running + incl - mine;
       uint32_t tile_total = 0;
-      if (masked) {
-        // the tile's per-wave totals were left by pass 1: every wave adds up the ones before it on its own.
-        // No barrier, no LDS: the waves of a block run their load -> scan -> gather -> store chains independently
-        // (with the barrier a block advanced one memory round trip per tile: 0.8 ms per 256 M rows at 1 %)
-        const uint32_t* wc = a.wave_counts + static_cast<size_t>(tile) * kWaves;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          const uint32_t t = wc[w];
-          tile_total += t;
-          if (w < wave) {
-            out_pos += t;
-          }
-        }
-      } else {
+      {
         const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one tile ahead
         if (lane == kWave - 1) {
           s_wave_tot[par][wave] = incl;
