@@ -350,8 +350,10 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
   uint32_t shared_mem_bytes; /* ignored: LDS use is decided by the kernel choice */
   uint32_t flags;       /* HDK_HIP_LAUNCH_* */
   uint64_t total_rows;  /* upper bound on the outer rows of this launch (sum of NUM_ROWS), 0 = unknown.  NUM_ROWS is
-                           device memory; multi-pass strategies (the radix-partitioned group-by) size their
-                           stream-ordered scratch from this instead of reading it back, and are skipped when 0 */
+                           device memory; multi-pass strategies size their stream-ordered scratch from this instead
+                           of reading it back: the radix-partitioned group-by (skipped when 0) and the selection
+                           bitmask the filter/project counting pass hands to its writing pass (when 0, or for rows
+                           past the bound, the writing pass evaluates the filter again) */
 } hdk_hip_kernel_options;
 #define HDK_HIP_LAUNCH_FORCE_PARTITIONED 16u   /* take the radix-partitioned group-by whenever the plan shape
                                                   allows it, whatever the table size (testing) */
