@@ -135,20 +135,24 @@ def main():
 
     host_frags = {}
     t_upload = 0.0
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
-        for f, (key, val) in pool.map(produce, range(nfrag)):
-            has_null = bool(args.null_frac > 0 and (val == -(2**63)).any())
-            vv = val[val != -(2**63)] if has_null else val
-            kcol.stats[f] = ChunkStats(int(key.min()), int(key.max()), False)
-            vcol.stats[f] = ChunkStats(int(vv.min()), int(vv.max()), has_null)
-            # device-resident chunk (DataMgr GPU_LEVEL cache); the host copy is dropped unless sampled
-            tu = time.perf_counter()
-            ex.cache.put(("t", "key", f), mgr.to_device(key, dev))
-            ex.cache.put(("t", "val", f), mgr.to_device(val, dev))
-            t_upload += time.perf_counter() - tu
-            if f < keep_host:
-                host_frags[f] = (key, val)
-                kcol.fragments[f], vcol.fragments[f] = key, val
+    # Fragments are generated on the host a few at a time: pool.map submits everything it is given at once, and
+    # 32 fragments x 512 MB per rank, times 8 ranks on one node, is more host memory than the job needs to hold.
+    in_flight = 4 if world > 1 else 8
+    with ThreadPoolExecutor(max_workers=min(in_flight, os.cpu_count() or 1)) as pool:
+        for f0 in range(0, nfrag, in_flight):
+            for f, (key, val) in pool.map(produce, range(f0, min(f0 + in_flight, nfrag))):
+                has_null = bool(args.null_frac > 0 and (val == -(2**63)).any())
+                vv = val[val != -(2**63)] if has_null else val
+                kcol.stats[f] = ChunkStats(int(key.min()), int(key.max()), False)
+                vcol.stats[f] = ChunkStats(int(vv.min()), int(vv.max()), has_null)
+                # device-resident chunk (DataMgr GPU_LEVEL cache); the host copy is dropped unless sampled
+                tu = time.perf_counter()
+                ex.cache.put(("t", "key", f), mgr.to_device(key, dev))
+                ex.cache.put(("t", "val", f), mgr.to_device(val, dev))
+                t_upload += time.perf_counter() - tu
+                if f < keep_host:
+                    host_frags[f] = (key, val)
+                    kcol.fragments[f], vcol.fragments[f] = key, val
     t_gen = time.perf_counter() - t_gen
 
     q = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "sum_val")])
