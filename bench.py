@@ -249,12 +249,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and keep_host > 0:
         from oracle import oracle as O
-        from hdk_amd.plan import init_buffer_host
+        from util import oracle_init_buffer
         sample = list(range(keep_host))
         frags = [[host_frags[f][0], host_frags[f][1]] for f in sample]
         hf = O.HostFragments(frags, [frag_rows[f] for f in sample])
         threads = int(min(O.lib().orc_max_threads(), len(sample)))
-        init_buf = init_buffer_host(cp)
+        init_buf = oracle_init_buffer(O, cp)
         times = []
         cbuf = None
         for _ in range(3):

@@ -35,10 +35,10 @@ def _worker(rank, world, port, result_q):
         from hdk_amd import _abi as A
         from hdk_amd.distributed import all_gather_partials, merge_gathered, shard_fragments
         from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
-        from hdk_amd.plan import compile_query, init_buffer_host
+        from hdk_amd.plan import compile_query
         from hdk_amd.storage import ArrowStorage
         from oracle import oracle as O
-        from util import host_fragments, run_oracle
+        from util import host_fragments, oracle_init_buffer, run_oracle
         rng = np.random.default_rng(77)  # same table on every rank; each rank scans only its fragments
         n = 60_000
         v = rng.integers(-1000, 1000, n).astype(np.int64)
@@ -51,7 +51,7 @@ def _worker(rank, world, port, result_q):
                                Agg("avg", ColRef("f"))])
         cp = compile_query(st, q)
         mine = shard_fragments(st.get("t").num_fragments, world, rank)
-        local = init_buffer_host(cp)
+        local = oracle_init_buffer(O, cp)
         assert O.run_plan(cp.plan, host_fragments(O, st, cp, mine), local) == 0
         gathered = all_gather_partials(torch.from_numpy(local), world).numpy()
         merged = merge_gathered(cp, gathered, world, O.reduce)
@@ -99,10 +99,10 @@ def _baseline_worker(rank, world, port, result_q):
         from hdk_amd import result_set as rs
         from hdk_amd.distributed import baseline_table_quads, exchange_owner_segments, shard_fragments
         from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
-        from hdk_amd.plan import compile_query, init_buffer_host
+        from hdk_amd.plan import compile_query
         from hdk_amd.storage import ArrowStorage
         from oracle import oracle as O
-        from util import host_fragments, run_oracle
+        from util import host_fragments, oracle_init_buffer, run_oracle
         rng = np.random.default_rng(78)
         n = 50_000
         st = ArrowStorage()
@@ -116,7 +116,7 @@ def _baseline_worker(rank, world, port, result_q):
         rq = p.row_size_quad
         assert baseline_table_quads(cp, 10) == 10 * rq  # host-only ABI call: works without a GPU
         mine = shard_fragments(st.get("t").num_fragments, world, rank)
-        local = init_buffer_host(cp)
+        local = oracle_init_buffer(O, cp)
         assert O.run_plan(p, host_fragments(O, st, cp, mine), local) == 0
         # host stand-in for hdk_hip_partition_baseline (the HIP kernel is covered by the GPU test):
         # non-empty rows, owner = mulhi32(key_hash, G), compact row-wise segments in owner order
@@ -130,7 +130,7 @@ def _baseline_worker(rank, world, port, result_q):
                                                [np.zeros(1, dtype=np.int64)]))
         recv, recv_counts = exchange_owner_segments(cp, send, counts, world, rank)
         recv = recv.numpy()
-        owner_table = init_buffer_host(cp)
+        owner_table = oracle_init_buffer(O, cp)
         off = 0
         for c in recv_counts:
             seg = np.ascontiguousarray(recv[off:off + int(c) * rq])

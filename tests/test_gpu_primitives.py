@@ -9,7 +9,7 @@ from hdk_amd import _abi as A
 from hdk_amd._lib import check, lib
 from hdk_amd.hip_mgr import HipMgr
 from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
-from hdk_amd.plan import compile_query, init_buffer_host
+from hdk_amd.plan import compile_query
 from hdk_amd.storage import ArrowStorage
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,9 @@ def test_hipmgr_contract(mgr):
 
 @pytest.mark.parametrize("columnar", [False, True])
 @pytest.mark.parametrize("nkeys", [1, 2])
-def test_init_buffers_match_host_image(mgr, oracle, columnar, nkeys):
+def test_init_kernels_match_oracle_init(mgr, oracle, columnar, nkeys):
+    """hdk_hip_init_[columnar_]group_by_buffer against the oracle's restatement of QE/GpuInitGroups.cu:17-166
+    (not against anything the product computes)."""
     st = ArrowStorage()
     st.import_numpy("t", {"a": np.arange(50, dtype=np.int64) % 7, "b": (np.arange(50, dtype=np.int64) % 3) + (2**40),
                           "v": np.arange(50, dtype=np.int32)})
@@ -47,7 +49,8 @@ def test_init_buffers_match_host_image(mgr, oracle, columnar, nkeys):
     cp = compile_query(st, q)
     from hdk_amd.executor import Executor
     step = Executor(st, 0, mgr).prepare(cp) if cp.plan.query_kind != A.Q_BASELINE_HASH else None
-    want = init_buffer_host(cp)
+    from util import oracle_init_buffer
+    want = oracle_init_buffer(oracle, cp)
     if step is None:  # baseline plans cannot launch yet on every build; initialise through the ABI directly
         from hdk_amd.plan import columnar_init_vals, compact_init_vals
         L = lib()

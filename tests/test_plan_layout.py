@@ -143,3 +143,42 @@ def test_taxi_q4_plan_shape():
     assert p.query_kind == A.Q_PERFECT_HASH and p.key_count == 3
     assert p.keys[1].steps[0].op == A.OP_EXTRACT_YEAR and p.keys[2].steps[0].op == A.OP_SCALE_DOWN
     assert p.keys[2].steps[0].rhs.ival == 100
+
+
+@pytest.mark.parametrize("columnar", [False, True])
+@pytest.mark.parametrize("shape", ["perfect_keyed", "perfect_keyless", "compact4", "baseline8", "baseline4", "two_keys"])
+def test_host_init_image_equals_oracle_init(oracle, shape, columnar):
+    """The numpy image `init_buffer_host` (a host convenience) against the oracle's restatement of the reference's
+    init kernels (QE/GpuInitGroups.cu:17-166) -- every layout family; with two different background fills the
+    oracle's output may differ only in padding bytes, which the image has as zero."""
+    from util import oracle_init_buffer
+    rng = np.random.default_rng(5)
+    n = 500
+    st = ArrowStorage()
+    v = rng.integers(-100, 100, n).astype(np.int64)
+    v[::9] = A.NULL_BIGINT
+    st.import_numpy("t", {"k": rng.integers(0, 30, n).astype(np.int64), "w": rng.integers(0, 5, n).astype(np.int32) * 1000,
+                          "v": v, "d": rng.normal(size=n), "big": rng.integers(0, 30, n).astype(np.int64) * (2**33)})
+    tg_all = [KeyRef(0), Agg("count"), Agg("sum", ColRef("v")), Agg("min", ColRef("d")), Agg("avg", ColRef("v"))]
+    Q = {
+        "perfect_keyed": QueryUnit("t", groupby=[ColRef("k")], targets=tg_all),
+        "perfect_keyless": QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("count"), Agg("max", ColRef("d"))]),
+        "compact4": QueryUnit("t", groupby=[ColRef("w")], targets=[KeyRef(0), Agg("count")]),
+        "baseline8": QueryUnit("t", groupby=[ColRef("big")], force_baseline=True, targets=tg_all),
+        "baseline4": QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, targets=tg_all),
+        "two_keys": QueryUnit("t", groupby=[ColRef("k"), ColRef("w")], targets=[KeyRef(1), KeyRef(0)] + tg_all[1:]),
+    }
+    q = Q[shape]
+    q.output_columnar = columnar
+    if columnar and shape == "baseline4":
+        q.groupby = [ColRef("big")]  # columnar tables keep 8-byte keys
+    cp = compile_query(st, q)
+    img = init_buffer_host(cp)
+    a = oracle_init_buffer(oracle, cp, fill=0)
+    b = oracle_init_buffer(oracle, cp, fill=-1)
+    assert np.array_equal(img[:cp.buffer_quads], a[:cp.buffer_quads])
+    pad = (a != b)
+    if pad.any():  # only possible behind 4-byte keys (row-wise) or between columns (columnar)
+        assert cp.plan.key_width == 4 or columnar
+        ab, bb = a.view(np.uint8), b.view(np.uint8)
+        assert (ab != bb).sum() <= (8 * cp.entry_count if not columnar else 8 * (len(cp.slot_widths) + 4))

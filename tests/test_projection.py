@@ -5,15 +5,15 @@ import pyarrow as pa
 from hdk_amd import _abi as A
 from hdk_amd import result_set as rs
 from hdk_amd.ir import Cmp, ColRef, JoinSpec, Lit, Proj, QueryUnit
-from hdk_amd.plan import compile_query, init_buffer_host
+from hdk_amd.plan import compile_query
 from hdk_amd.storage import ArrowStorage
 
-from util import host_fragments, oracle_join_tables
+from util import host_fragments, oracle_init_buffer, oracle_join_tables
 
 
 def run_projection_oracle(O, st, q):
     cp = compile_query(st, q)
-    buf = init_buffer_host(cp)
+    buf = oracle_init_buffer(O, cp)
     err, n = O.run_projection(cp.plan, host_fragments(O, st, cp), buf, cp.entry_count, oracle_join_tables(O, st, cp))
     return cp, buf, err, n
 

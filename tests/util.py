@@ -3,7 +3,8 @@ reference's row function) and compare it with the HIP path bit for bit."""
 import numpy as np
 
 from hdk_amd import _abi as A
-from hdk_amd.plan import compile_query, init_buffer_host
+from hdk_amd.plan import (align8, columnar_init_vals, columnar_slot_offsets, compact_init_vals, compile_query,
+                          eff_key_count)
 
 
 def host_fragments(O, storage, cp, frag_ids=None):
@@ -84,9 +85,39 @@ def oracle_join_tables(O, storage, cp):
     return tables
 
 
+def oracle_init_buffer(O, cp, entry_count=None, fill=0):
+    """A freshly initialised output buffer written by the ORACLE's restatement of the reference's init
+    kernels (orc_init_group_by_buffer / orc_init_columnar_group_by_buffer <- QE/GpuInitGroups.cu:17-166),
+    called with the arguments QueryMemoryInitializer hands them (QE/QueryMemoryInitializer.cpp:1054-1156).
+    Nothing of the product's own buffer image (hdk_amd.plan.init_buffer_host) is involved.  Padding bytes
+    (behind 4-byte keys, between columnar columns) are written by neither the reference nor the oracle;
+    they keep `fill` (0, which is also what the product's init kernels leave there)."""
+    p = cp.plan
+    n = int(entry_count if entry_count is not None else p.entry_count)
+    L = O.lib()
+    if p.query_kind == A.Q_NON_GROUPED:
+        # out_vec slots start at init_agg_vals (QueryExecutionContext.cpp:452-458)
+        return np.ascontiguousarray(cp.init_vals, dtype=np.int64).copy()
+    if p.output_columnar:
+        offs = columnar_slot_offsets(cp, n)
+        nk = eff_key_count(p)
+        total = offs[-1] + n * cp.slot_widths[-1] if offs else nk * align8(n * 8)
+        buf = np.full(align8(total) // 8, fill, dtype=np.int64)
+        iv = np.ascontiguousarray(columnar_init_vals(cp), dtype=np.int64)
+        sizes = np.ascontiguousarray(cp.slot_widths, dtype=np.int8)
+        L.orc_init_columnar_group_by_buffer(buf.ctypes.data, iv.ctypes.data, n, nk, len(cp.slot_widths),
+                                            sizes.ctypes.data, 1, int(p.keyless), 8)
+        return buf
+    iv = np.ascontiguousarray(compact_init_vals(cp), dtype=np.int64)
+    buf = np.full(n * int(p.row_size_quad), fill, dtype=np.int64)
+    L.orc_init_group_by_buffer(buf.ctypes.data, iv.ctypes.data, n, eff_key_count(p), int(p.key_width),
+                               int(p.row_size_quad), int(p.keyless), 1)
+    return buf
+
+
 def run_oracle(O, storage, q_or_cp, frag_ids=None):
     cp = q_or_cp if hasattr(q_or_cp, "plan") else compile_query(storage, q_or_cp)
-    buf = init_buffer_host(cp)
+    buf = oracle_init_buffer(O, cp)
     hf = host_fragments(O, storage, cp, frag_ids)
     jt = oracle_join_tables(O, storage, cp)
     err = O.run_plan(cp.plan, hf, buf, jt)
