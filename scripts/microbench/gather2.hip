@@ -77,13 +77,26 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&out, 8));
   CK(hipMemset(val, 1, n * 8));
   std::vector<int64_t> h(n);
-  const int64_t nds[] = {1000000, 10000000, 30000000};
+  std::vector<int64_t> nds = {1000000, 10000000, 30000000};
+  if (argc > 1) {  // gather2 <entries> [norand]: one table size (so that a counter run attributes per size)
+    nds.clear();
+    nds.push_back(atoll(argv[1]));
+  }
   const int grid = 2048;
   for (int64_t nd : nds) {
     uint64_t s = 88172645463325252ull;
     for (int64_t i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (int64_t)(s % (uint64_t)nd); }
     CK(hipMemcpy(fk, h.data(), n * 8, hipMemcpyHostToDevice));
-    CK(hipMalloc(&table, nd * 16));
+    // table memory: default (cached in L2), "uc" = uncached MTYPE, "fg" = fine-grained
+    const char* mode = argc > 2 ? argv[2] : "default";
+    if (mode[0] == 'u') {
+      CK(hipExtMallocWithFlags((void**)&table, nd * 16, hipDeviceMallocUncached));
+    } else if (mode[0] == 'f') {
+      CK(hipExtMallocWithFlags((void**)&table, nd * 16, hipDeviceMallocFinegrained));
+    } else {
+      CK(hipMalloc(&table, nd * 16));
+    }
+    printf("# table memory: %s\n", mode);
     CK(hipMemset(table, 1, nd * 16));
     run<4, 0, 4>(fk, val, table, n, out, grid, nd, "rand");
     run<4, 1, 4>(fk, val, table, n, out, grid, nd, "rand");

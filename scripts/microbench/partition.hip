@@ -6,6 +6,10 @@
 //       bit 2: no copy-out (nothing is written)
 //       bit 4: no staging and no copy-out (load + hash + histogram only)
 //       bit 8: no LDS rank atomics (rank = lane-derived)
+//       bit 16: no global cursor atomics, every block appends to PRIVATE sub-slabs (cursor in LDS): what exact
+//               offsets from a counting pass -- or block-private chunk claims -- would give
+//       bit 32 / 64: global cursors padded to one per 128-B / 256-B line (instead of 128 cursors in 512 bytes)
+//       bit 128: 16-byte LDS staging and copy-out (ds_write_b128 / global_store_dwordx4)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +55,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
   __syncthreads();
   const int64_t ntiles = (a.n + T - 1) / T;
   uint32_t fake = blockIdx.x * 7919u;
+  __shared__ uint32_t s_cur[kMaxBins];
+  for (int i = tid; i < kMaxBins; i += kBlock) s_cur[i] = 0;
+  constexpr int CSTRIDE = (ABL & 32) ? 32 : ((ABL & 64) ? 64 : 1);
+  const uint64_t sub_cap = (a.cap / gridDim.x) & ~7ull;  // bit 16: tuples per (block, bin) sub-slab, whole 128-B lines
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * T + tid;
     bool live[VR];
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
     if (ABL & 8) {  // keep the counts plausible: every bin gets T / nbins
       if (tid < (int)a.nbins) s_cnt[tid] = T / a.nbins;
 #pragma unroll
-      for (int r = 0; r < VR; ++r) { bin[r] = (tid + r * 37) % a.nbins; rank[r] = (tid * VR + r) / a.nbins % (T / a.nbins); }
+      for (int r = 0; r < VR; ++r) { bin[r] = (tid + r * 37) % a.nbins; rank[r] = (tid / a.nbins) * VR + r; }
     }
     __syncthreads();
     if (ABL & 4) {
@@ -87,10 +95,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
     }
     if (tid < kMaxBins) {
       const uint32_t n = tid < (int)a.nbins ? s_cnt[tid] : 0;
-      if (ABL & 1) {
+      if (ABL & 16) {
+        const uint32_t c = s_cur[tid];
+        s_base[tid] = (uint32_t)(blockIdx.x * sub_cap) + (c + n <= sub_cap ? c : 0);
+        s_cur[tid] = c + n <= sub_cap ? c + n : n;
+      } else if (ABL & 1) {
         s_base[tid] = (fake + tid * 131u) % (uint32_t)(a.cap - T);
       } else {
-        s_base[tid] = n ? atomicAdd(a.fill + tid, n) : 0u;
+        s_base[tid] = n ? atomicAdd(a.fill + tid * CSTRIDE, n) : 0u;
       }
     }
     fake += 4099u;
@@ -116,8 +128,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
         const uint64_t pos = (uint64_t)s_base[bin[r]] + rank[r];
         s_bin[si] = (uint16_t)bin[r];
         s_pos[si] = (uint32_t)(pos < a.cap ? pos : a.cap - 1);
-        s_stage[(size_t)si * 2] = k[r];
-        s_stage[(size_t)si * 2 + 1] = v[r];
+        if (ABL & 128) {
+          typedef long long __attribute__((ext_vector_type(2))) i64x2;
+          i64x2 t; t.x = k[r]; t.y = v[r];
+          reinterpret_cast<i64x2*>(s_stage)[si] = t;
+        } else {
+          s_stage[(size_t)si * 2] = k[r];
+          s_stage[(size_t)si * 2 + 1] = v[r];
+        }
       }
     }
     __syncthreads();
@@ -126,8 +144,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
       for (uint32_t i = tid; i < total; i += kBlock) {
         const uint32_t b = s_bin[i];
         int64_t* q = a.out + ((size_t)b * a.cap + s_pos[i]) * 2;
-        q[0] = s_stage[(size_t)i * 2];
-        q[1] = s_stage[(size_t)i * 2 + 1];
+        if (ABL & 128) {
+          typedef long long __attribute__((ext_vector_type(2))) i64x2;
+          *reinterpret_cast<i64x2*>(q) = reinterpret_cast<const i64x2*>(s_stage)[i];
+        } else {
+          q[0] = s_stage[(size_t)i * 2];
+          q[1] = s_stage[(size_t)i * 2 + 1];
+        }
       }
     }
     __syncthreads();
@@ -143,7 +166,7 @@ static void run_v0(Args a, int grid, const char* label) {
   const size_t lds = (size_t)kBlock * VR * 16;
   float best = 1e9f;
   for (int rep = 0; rep < 3; ++rep) {
-    CK(hipMemsetAsync(a.fill, 0, kMaxBins * 4, 0));
+    CK(hipMemsetAsync(a.fill, 0, kMaxBins * 4 * 64, 0));
     CK(hipEventRecord(e0));
     k_scatter_v0<VR, ABL><<<grid, kBlock, lds>>>(a);
     CK(hipEventRecord(e1));
@@ -169,22 +192,27 @@ int main() {
   CK(hipMemset(val, 1, n * 8));
   a.key = key; a.val = val; a.n = n;
   a.nbins = 128; a.p2 = 105; a.fine_count = 128 * 105;
-  a.cap = n / a.nbins + n / (a.nbins * 16) + 8192;
+  a.cap = (n / a.nbins + n / (a.nbins * 16) + 8192) & ~7ull;  // whole 128-B lines: slab bases stay line-aligned
   CK(hipMalloc(&a.out, (size_t)a.nbins * a.cap * 16));
-  CK(hipMalloc(&a.fill, kMaxBins * 4));
+  CK(hipMalloc(&a.fill, kMaxBins * 4 * 64));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cu = prop.multiProcessorCount;
-  for (int g : {cu * 3, cu * 6}) {
+  for (int g : {cu * 3}) {
     run_v0<4, 0>(a, g, "v0 full");
-    run_v0<4, 1>(a, g, "v0 no global cursor atomics");
-    run_v0<4, 2>(a, g, "v0 no copy-out");
+    run_v0<4, 64 + 128>(a, g, "v0 padded 256 B + 16-B stores");
+    run_v0<4, 16 + 128>(a, g, "v0 private sub-slabs + 16-B stores");
     run_v0<4, 3>(a, g, "v0 no atomics, no copy-out");
-    run_v0<4, 4>(a, g, "v0 load+hash+hist only");
-    run_v0<4, 12>(a, g, "v0 load+hash only");
-    run_v0<4, 9>(a, g, "v0 no LDS rank, no cursor atomics");
   }
+  for (int g : {cu * 2, cu * 3, cu * 4, cu * 6}) {
+    run_v0<4, 8 + 16 + 128>(a, g, "aligned 256-B runs, private, 16-B st");
+  }
+  // exact 16-tuple runs per bin and batch (no LDS rank), private sub-slabs: every run is two aligned 128-B lines
+  run_v0<4, 8 + 16>(a, cu * 3, "aligned 256-B runs, private, 8-B st");
+  run_v0<4, 8 + 16 + 128>(a, cu * 3, "aligned 256-B runs, private, 16-B st");
+  run_v0<4, 8 + 64 + 128>(a, cu * 3, "aligned 256-B runs, padded cursors");
+  run_v0<4, 8 + 2>(a, cu * 3, "no LDS rank, no copy-out");
   run_v0<8, 0>(a, cu * 2, "v0 full");
-  run_v0<8, 1>(a, cu * 2, "v0 no global cursor atomics");
-  run_v0<8, 4>(a, cu * 2, "v0 load+hash+hist only");
+  run_v0<8, 64 + 128>(a, cu * 2, "v0 padded 256 B + 16-B stores");
+  run_v0<8, 16 + 128>(a, cu * 2, "v0 private sub-slabs + 16-B stores");
   return 0;
 }
