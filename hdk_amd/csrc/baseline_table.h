@@ -86,11 +86,15 @@ HDK_DEV TableShape table_shape(const hdk_hip_plan* p) {
 // Row-wise (get_matching_group_value, QE/cuda_mapd_rt.cu:167-203): CAS the first component, write
 // the rest, readers spin until the last component is published.  Columnar
 // (get_matching_group_value_columnar_slot, :229-261) likewise per key column.
-template <typename K>
-HDK_DEV int64_t find_or_claim(const TableShape shape, int64_t* buf, uint32_t entry_count, const K* key, bool* fresh) {
+// WRAP = true: the reference's probe sequence over the whole table, (start + i) % entry_count, -1 once every entry
+// has been looked at.  WRAP = false: probe from `start` to the END of the `entry_count` entries and stop there (-1):
+// a table region aggregated on its own (scan_agg_partitioned.h) places a group exactly where the whole-table
+// sequence would, or not at all.
+template <typename K, bool WRAP>
+HDK_DEV int64_t find_or_claim_from(const TableShape shape, int64_t* buf, uint32_t entry_count, uint32_t start, const K* key,
+                                   bool* fresh) {
   const int nk = shape.key_count;
-  const uint32_t h = key_hash_dev<K>(key, nk) % entry_count;
-  uint32_t probe = h;
+  uint32_t probe = start;
   const K ek = empty_key<K>();
   uint32_t steps = 0;
   int64_t result = -2;  // -2: still probing
@@ -155,13 +159,22 @@ HDK_DEV int64_t find_or_claim(const TableShape shape, int64_t* buf, uint32_t ent
       }
     }
     if (result == -2 && advance) {
-      probe = (probe + 1) % entry_count;
-      if (++steps >= entry_count) {
-        result = -1;  // wrapped around: table full
+      if (WRAP) {
+        probe = probe + 1 == entry_count ? 0 : probe + 1;
+        if (++steps >= entry_count) {
+          result = -1;  // wrapped around: table full
+        }
+      } else if (++probe == entry_count) {
+        result = -1;  // ran off the end of the region
       }
     }
   }
   return result;
+}
+
+template <typename K>
+HDK_DEV int64_t find_or_claim(const TableShape shape, int64_t* buf, uint32_t entry_count, const K* key, bool* fresh) {
+  return find_or_claim_from<K, true>(shape, buf, entry_count, key_hash_dev<K>(key, shape.key_count) % entry_count, key, fresh);
 }
 
 template <typename K>

@@ -5,6 +5,7 @@
 // L0Manager.  One HIP-runtime function per virtual, exported through the C ABI so that a
 // `class HipMgr : public GpuMgr` in HDK is a list of one-line forwards.
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "host_common.h"
@@ -42,10 +43,14 @@ static void init_device(int32_t d) {
   // Stream-ordered scratch (hipMallocAsync in the multi-pass strategies and the reductions) is recycled
   // by the device's default pool; without a release threshold the pool hands freed memory back at every
   // synchronisation and the next launch pays the mapping of its scratch again (measured: a 10 GB scratch
-  // turned a 9.5 ms launch into 58 ms).  Keep it cached.
+  // turned a 9.5 ms launch into 58 ms).  Keep up to a quarter of the device's memory cached (HDK_HIP_POOL_KEEP_MB
+  // overrides); hdk_hip_mgr_allocate_device_mem trims the pool and retries when a plain hipMalloc runs out.
   hipMemPool_t pool = nullptr;
   if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool) {
-    uint64_t keep = UINT64_MAX;
+    uint64_t keep = static_cast<uint64_t>(hp.totalGlobalMem) / 4;
+    if (const char* e = getenv("HDK_HIP_POOL_KEEP_MB")) {
+      keep = static_cast<uint64_t>(strtoull(e, nullptr, 10)) << 20;
+    }
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
   }
   (void)hipGetLastError();
@@ -132,7 +137,18 @@ int32_t hdk_hip_mgr_allocate_device_mem(size_t num_bytes, int32_t device_num, in
   const int32_t st = device_enter(device_num, nullptr, &s);
   if (st) return st;
   void* p = nullptr;
-  HDK_HIP_CHECK(hipMalloc(&p, num_bytes ? num_bytes : 1));
+  hipError_t e = hipMalloc(&p, num_bytes ? num_bytes : 1);
+  if (e == hipErrorOutOfMemory) {
+    // the stream-ordered pool may be sitting on freed scratch: give it back to the driver and try once more
+    (void)hipGetLastError();
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceSynchronize() == hipSuccess && hipDeviceGetDefaultMemPool(&pool, device_num) == hipSuccess && pool) {
+      (void)hipMemPoolTrimTo(pool, 0);
+    }
+    (void)hipGetLastError();
+    e = hipMalloc(&p, num_bytes ? num_bytes : 1);
+  }
+  HDK_HIP_CHECK(e);
   *device_ptr = static_cast<int8_t*>(p);
   return HDK_HIP_OK;
 }

@@ -474,6 +474,11 @@ int32_t validate_plan(const hdk_hip_plan* p) {
       continue;
     }
     HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "slot width must be 4 or 8");
+    if (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED) {
+      // a group-by plan writes a non-aggregate target from key #key_idx (hdk_finalize, the global kernels)
+      HDK_REQUIRE(tg.key_idx >= 0 && tg.key_idx < p->key_count,
+                  "target %d: HDK_AGG_ID in a group-by plan needs 0 <= key_idx < key_count (got %d)", t, tg.key_idx);
+    }
     if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
       set_error("float32 aggregate slots are outside the fixed kernel library");
       return HDK_HIP_ERR_UNSUPPORTED;
@@ -1063,6 +1068,12 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
 // ---- radix-partitioned open-addressing group-by (scan_agg_partitioned.h) -------------------------------
 // Taken for the hdk_scan_agg_baseline_direct shape when the table is large enough that the memory-side
 // atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
+static uint32_t pow2_ceil_log2(uint64_t x) {
+  uint32_t l = 0;
+  while ((1ull << l) < x) ++l;
+  return l;
+}
+
 static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
@@ -1070,7 +1081,7 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
   if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
-  if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < kPartP1) return false;
+  if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
   memset(pa, 0, sizeof(*pa));
   pa->key_buf_idx = bf.key_buf_idx;
   pa->key_width = bf.key_width;
@@ -1100,68 +1111,113 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->ntargets = bf.ntargets;
   pa->tw = pa->nkeys + pa->nargs;
   pa->entry_count = p->entry_count;
-  // fine partitions: as many as it takes for a region (slots x row) to fit the LDS budget, a multiple of P1
-  uint32_t slots = kPartLdsWords / p->row_size_quad;
-  uint32_t pf = (p->entry_count + slots - 1) / slots;
-  uint32_t p2 = (pf + kPartP1 - 1) / kPartP1;
-  if (p2 > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 32 K fine partitions: a third level would be needed
-  pf = p2 * kPartP1;
-  slots = p->entry_count / pf;
-  if (slots < 16) return false;
-  pa->slots = slots;
-  pa->fine_count = pf;
-  pa->p2 = p2;
+  pa->mod_magic = UINT64_C(0xFFFFFFFFFFFFFFFF) / p->entry_count + 1;
+  // regions: the largest power of two of entries whose rows fit the LDS image
+  uint32_t slots_log2 = 0;
+  while ((2ull << slots_log2) * p->row_size_quad * 8 <= kPartLdsBytes) ++slots_log2;
+  pa->slots_log2 = slots_log2;
+  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + (1ull << slots_log2) - 1) >> slots_log2;
+  // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch)
+  uint32_t p2_log2 = (pow2_ceil_log2(pf) + 1) / 2;
+  while (((pf + (1ull << p2_log2) - 1) >> p2_log2) > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
+  if ((1u << p2_log2) > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 64 K regions: a third level would be needed
+  pa->fine_count = static_cast<uint32_t>(pf);
+  pa->p2_log2 = p2_log2;
+  pa->p1 = static_cast<uint32_t>((pf + (1ull << p2_log2) - 1) >> p2_log2);
+  // flush granule: whole 128-byte lines (8 tuples of 16 B; 16 tuples of 8 or 24 B), as long as the carried tuples
+  // of all bins fit the threads that take them along
+  const uint32_t max_bins = pa->p1 > (1u << p2_log2) ? pa->p1 : (1u << p2_log2);
+  pa->g_log2 = pa->tw == 2 ? 3 : 4;
+  while (pa->g_log2 > 0 && max_bins * ((1u << pa->g_log2) - 1) > static_cast<uint32_t>(kPartBlock * kPartLV)) --pa->g_log2;
+  const uint64_t g = 1ull << pa->g_log2;
   const uint64_t rows = ko->total_rows;
-  pa->cap1 = rows / kPartP1 + rows / (kPartP1 * 16) + 8192;  // uniform hash: sigma ~ sqrt(rows/P1); 6 % + 8 K slack
-  pa->cap2 = rows / pf + rows / (pf * 4) + 256;               // 25 % + 256
+  pa->total_rows = rows;
+  auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
+  pa->cap1 = round_g(rows / pa->p1 + rows / (static_cast<uint64_t>(pa->p1) * 16) + 8192);  // uniform hash: sigma ~ sqrt(rows/P1); 6 % + 8 K slack
+  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256);                                   // 25 % + 256
   pa->cap_ovf = rows / 16 + 4096;
+  pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
+  if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFFFFF0ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
   return true;
 }
 
 constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
+
+template <int LEVEL, typename K>
+static void launch_part_scatter(int tw, dim3 grid, size_t lds, hipStream_t s, const PartArgs& pa) {
+  switch (tw) {
+    case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
+    case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
+    default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
+  }
+}
+
+template <int LEVEL, typename K>
+static const void* part_scatter_kernel(int tw) {
+  switch (tw) {
+    case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 1>);
+    case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 2>);
+    default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 3>);
+  }
+}
 
 static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                                        PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
                                        hipStream_t s) {
   pa.plan = d_plan;
   pa.kp = kp;
+  const bool k32 = plan->key_width == 4;
   const size_t tw = static_cast<size_t>(pa.tw);
-  const size_t b1 = static_cast<size_t>(kPartP1) * pa.cap1 * tw * 8;
+  const uint32_t gmask = (1u << pa.g_log2) - 1;
+  const uint32_t p2 = 1u << pa.p2_log2;
+  const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw);
+  const size_t lds2 = part_scatter_lds_bytes(p2, gmask, pa.tw);
+  // pass-1 grid: what is resident (the staging area allows two 512-thread blocks per CU); every block ends with one
+  // partial flush per bin into the tail slabs
+  const void* k1 = k32 ? part_scatter_kernel<1, int32_t>(pa.tw) : part_scatter_kernel<1, int64_t>(pa.tw);
+  unsigned g1 = resident_grid(k1, kPartBlock, lds1, props);
+  const uint64_t tiles = (pa.total_rows + kPartTile - 1) / kPartTile;
+  if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
+  pa.tcap1 = g1 * (gmask ? gmask : 1);
+  pa.tcap2 = static_cast<uint32_t>(kPartG2X) * (gmask ? gmask : 1);
+  const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
+  const size_t bt1 = static_cast<size_t>(pa.p1) * pa.tcap1 * tw * 8;
   const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
+  const size_t bt2 = static_cast<size_t>(pa.fine_count) * pa.tcap2 * tw * 8;
   const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
-  const size_t bc = (static_cast<size_t>(kPartP1) + pa.fine_count + 2) * sizeof(uint32_t);
+  const size_t nc = static_cast<size_t>(pa.p1) * kPartCursorStride + pa.p1 + 2 * static_cast<size_t>(pa.fine_count) + 4;
+  const size_t bc = nc * sizeof(uint32_t);
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   int8_t* scratch = nullptr;
-  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), b1 + b2 + bo + bc + 1024, s);
+  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), up(b1) + up(bt1) + up(b2) + up(bt2) + up(bo) + up(bc), s);
   if (me != hipSuccess) {
     (void)hipGetLastError();
     return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
   }
-  pa.slab1 = reinterpret_cast<int64_t*>(scratch);
-  pa.slab2 = reinterpret_cast<int64_t*>(scratch + b1);
-  pa.ovf = reinterpret_cast<int64_t*>(scratch + b1 + b2);
-  pa.fill1 = reinterpret_cast<uint32_t*>(scratch + b1 + b2 + bo);
-  pa.fill2 = pa.fill1 + kPartP1;
-  pa.fill_ovf = pa.fill2 + pa.fine_count;
-  pa.fallback = pa.fill_ovf + 1;
+  int8_t* q = scratch;
+  pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
+  pa.tail1 = reinterpret_cast<int64_t*>(q); q += up(bt1);
+  pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
+  pa.tail2 = reinterpret_cast<int64_t*>(q); q += up(bt2);
+  pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
+  pa.fill1 = reinterpret_cast<uint32_t*>(q);
+  pa.tfill1 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartCursorStride;
+  pa.fill2 = pa.tfill1 + pa.p1;
+  pa.tfill2 = pa.fill2 + pa.fine_count;
+  pa.fill_ovf = pa.tfill2 + pa.fine_count;
+  pa.fill_spill = pa.fill_ovf + 1;
+  pa.fallback = pa.fill_spill + 1;
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
-  const bool k32 = plan->key_width == 4;
-  const size_t stage_bytes = static_cast<size_t>(kPartTile) * tw * 8;
-  // pass-1 grid: twice what is resident (LDS staging + ~110 VGPRs: 2 blocks of 512 threads per CU), so that the
-  // per-batch latency chains of one round overlap with the next
-  const void* k1 = k32 ? reinterpret_cast<const void*>(hdk_part_scatter<1, int32_t>)
-                       : reinterpret_cast<const void*>(hdk_part_scatter<1, int64_t>);
-  const unsigned g1 = resident_grid(k1, kPartBlock, stage_bytes, props) * 2;
-  const unsigned g2x = 16;
   const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
-  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
+  const size_t table_bytes = (static_cast<size_t>(1) << pa.slots_log2) * plan->row_size_quad * 8;
   if (k32) {
-    hipLaunchKernelGGL((hdk_part_scatter<1, int32_t>), dim3(g1), dim3(kPartBlock), stage_bytes, s, pa);
-    hipLaunchKernelGGL((hdk_part_scatter<2, int32_t>), dim3(g2x, kPartP1), dim3(kPartBlock), stage_bytes, s, pa);
+    launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
+    launch_part_scatter<2, int32_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
     hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   } else {
-    hipLaunchKernelGGL((hdk_part_scatter<1, int64_t>), dim3(g1), dim3(kPartBlock), stage_bytes, s, pa);
-    hipLaunchKernelGGL((hdk_part_scatter<2, int64_t>), dim3(g2x, kPartP1), dim3(kPartBlock), stage_bytes, s, pa);
+    launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
+    launch_part_scatter<2, int64_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
     hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   }

@@ -335,7 +335,8 @@ extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_co
 extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct(ProjFastArgs a) {
   scan_project_direct_body<1, 1>(a);
 }
-// per-block counts -> exclusive offsets (in place); the grand total is added to TOTAL_MATCHED
+// per-block counts -> exclusive offsets (in place), starting at what TOTAL_MATCHED already holds (like the claiming
+// kernels of scan_project.h, which append with atomicAdd); the grand total is added to TOTAL_MATCHED
 extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint32_t* counts, uint32_t n, int32_t* total_matched) {
   __shared__ uint32_t s_part[1024];
   const uint32_t tid = threadIdx.x;
@@ -354,7 +355,9 @@ extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint
     s_part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = tid ? s_part[tid - 1] : 0;
+  const uint32_t already = static_cast<uint32_t>(*total_matched);  // (single block: read by all before thread 1023 adds)
+  __syncthreads();
+  uint32_t run = already + (tid ? s_part[tid - 1] : 0);
   for (uint32_t i = lo; i < hi; ++i) {
     const uint32_t c = counts[i];
     counts[i] = run;

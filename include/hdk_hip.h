@@ -409,7 +409,11 @@ int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_o
  * perfect hash = slot-wise reduceOneSlot :1234-1330; baseline = reduceOneEntryBaseline :694-731)
  * for per-GPU / per-launch partial buffers that already sit in HBM (e.g. after an RCCL
  * all-gather).  `that_bufs[i]` are merged into `this_buf`; layouts come from `plan`.
- * For HDK_Q_BASELINE_HASH `this_entry_count` may exceed `plan->entry_count` (Execute.cpp:1241-1253).
+ * For HDK_Q_BASELINE_HASH `this_entry_count` may exceed `plan->entry_count` (Execute.cpp:1241-1253), and `this_buf`
+ * may be a fresh (initialised) table or the output of ANY launch of this library: every kernel, the
+ * radix-partitioned group-by included, leaves a group on the reference's probe sequence
+ * (key_hash % entry_count, then linearly on), which is where the re-insert looks for it
+ * (tests/test_gpu_baseline.py::test_reduce_and_relaunch_into_a_partitioned_table).
  * ---------------------------------------------------------------------------------------- */
 int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* this_buf, uint32_t this_entry_count,
                                const int64_t* const* that_bufs, const uint32_t* that_entry_counts,
@@ -444,8 +448,11 @@ int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf,
 /* ------------------------------------------------------------------------------------------
  * Hash-join table build (perfect hash).
  * Replaces the *_on_device free functions of QE/JoinHashTable/Runtime/HashJoinRuntime.h:66-68,
- * 158-200 (GPU bodies QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:32-190).  Structs are the
- * reference's PODs (HashJoinRuntime.h:43-57,100-124) with fixed-width members.
+ * 158-200 (GPU bodies QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:32-190).  The structs carry the same fields
+ * as the reference's PODs (HashJoinRuntime.h:43-57,100-124) but are NOT layout-compatible with them: fixed-width
+ * members, `bool` widened to int32, and hdk_hip_join_column_type_info keeps column_type in front of
+ * translated_null_val (the reference: `translated_null_val, uses_bw_eq, column_type`).  Convert field by field
+ * (hdk_amd/glue/HipRuntimeOnDevice.h: to_abi / to_abi_column), never by memcpy.
  * ---------------------------------------------------------------------------------------- */
 typedef struct hdk_hip_join_chunk {  /* JoinChunk */
   const int8_t* col_buff;

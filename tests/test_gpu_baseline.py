@@ -340,3 +340,131 @@ def test_radix_partitioned_two_keys(oracle, gpu_executor_factory):
         res = step.run()
         step.free()
         _check_rows(cp, res.buffer, want)
+
+
+def _assert_reference_placement(oracle, cp, buf):
+    """Every group must sit where the reference's probe sequence finds it (get_group_value, QE/GroupByRuntime.cpp:31-55:
+    h = key_hash % entry_count, then linearly on): all entries from a group's home up to its entry are occupied."""
+    p = cp.plan
+    n, rq, nk = int(p.entry_count), int(p.row_size_quad), int(p.key_count)
+    rows = np.ascontiguousarray(buf[:n * rq]).reshape(n, rq)
+    if p.key_width == 8:
+        keys = rows[:, :nk].copy()
+        occupied = keys[:, 0] != A.EMPTY_KEY_64
+    else:
+        keys = rows.view(np.int32)[:, :nk].copy()
+        occupied = keys[:, 0] != A.EMPTY_KEY_32
+    L = oracle.lib()
+    # positions of the empty entries, for "is there an empty entry in [home, e)?"
+    empties = np.flatnonzero(~occupied)
+    assert empties.size, "test needs a table with free entries"
+    for e in np.flatnonzero(occupied):
+        k = np.ascontiguousarray(keys[e])
+        home = L.orc_key_hash(k.ctypes.data, nk, int(p.key_width)) % n
+        if home <= e:
+            lo = np.searchsorted(empties, home)
+            assert lo == empties.size or empties[lo] >= e, (int(e), int(home))
+        else:  # wrapped around the end of the table
+            assert empties[-1] < home and empties[0] >= e, (int(e), int(home))
+
+
+@pytest.mark.parametrize("entries,kcol", [(400_009, "k64"), (262_144, "k32"), (70_001, "k64")])
+def test_partitioned_table_has_the_reference_placement(oracle, gpu_executor_factory, entries, kcol):
+    """A table written by the radix-partitioned path can be probed like any other open-addressing table: groups sit on
+    the reference's probe sequence (also at a load factor of 0.9, where many probes run off their region's end and are
+    placed by the overflow pass)."""
+    rng = np.random.default_rng(55)
+    n = 500_009
+    st = ArrowStorage()
+    st.import_numpy("t", {"k64": rng.integers(0, 63_000, n, dtype=np.int64) * 3_000_000_019 - 2**40,
+                          "k32": rng.integers(-90_000, 90_000, n).astype(np.int32),
+                          "v": rng.integers(-2**31, 2**31, n, dtype=np.int64)}, fragment_size=130_000)
+    q = QueryUnit("t", groupby=[ColRef(kcol)], force_baseline=True, baseline_entry_count=entries,
+                  targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+    assert step.kernel_names().startswith("hdk_part_scatter")
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    _assert_reference_placement(oracle, cp, res.buffer)
+
+
+def test_reduce_and_relaunch_into_a_partitioned_table(oracle, gpu_executor_factory):
+    """VERDICT r1 hazard: hdk_hip_reduce_buffers (find_or_claim from key_hash % entry_count) and a second launch must
+    find the groups a radix-partitioned launch left in `this_buf` -- no duplicates, {key -> slots} = the oracle's."""
+    import ctypes as C
+    from hdk_amd._lib import check, lib
+    rng = np.random.default_rng(56)
+    n = 800_000
+    key = rng.integers(0, 90_000, n, dtype=np.int64) * 1_000_003 - 10**10
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.04] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": key, "v": v}, fragment_size=100_000)
+    q = QueryUnit("t", groupby=[ColRef("key")], force_baseline=True, baseline_entry_count=300_007,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c"),
+                           Agg("max", ColRef("v"), "mx")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    mgr = ex.mgr
+    # (1) reduce: fragments 0-3 partitioned -> this_buf; fragments 4-7 atomics kernel -> that_buf; merge on the device
+    a = ex.prepare(cp, frag_ids=[0, 1, 2, 3], flags=A.LAUNCH_FORCE_PARTITIONED)
+    assert a.kernel_names().startswith("hdk_part_scatter")
+    a.init_output()
+    a.launch()
+    b = ex.prepare(cp, frag_ids=[4, 5, 6, 7], flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS)
+    b.init_output()
+    b.launch()
+    mgr.synchronizeStream(0)
+    that = (C.c_void_p * 1)(b.out_ptr)
+    counts = (C.c_uint32 * 1)(cp.entry_count)
+    d_err = mgr.to_device(np.zeros(1, dtype=np.int32), 0)
+    iv = np.ascontiguousarray(cp.init_vals)
+    check(lib().hdk_hip_reduce_buffers(C.byref(cp.plan), a.out_ptr, cp.entry_count, that, counts, 1, iv.ctypes.data,
+                                       d_err.ptr, 0, None))
+    mgr.synchronizeStream(0)
+    assert int(mgr.to_host(d_err.ptr, 4, 0, np.int32)[0]) == 0
+    merged = mgr.to_host(a.out_ptr, cp.buffer_bytes, 0)
+    _check_rows(cp, merged, want)
+    assert len(_rows(cp, merged)) == len(np.unique(key))  # no group twice
+    _assert_reference_placement(oracle, cp, merged)
+    a.free()
+    b.free()
+    # (2) second launch into the same buffer: partitioned first, then the atomics kernel WITHOUT re-initialising, and
+    # the other way round (the partitioned pass loads the region images an earlier launch left)
+    for first, second in ((A.LAUNCH_FORCE_PARTITIONED, A.LAUNCH_FORCE_GLOBAL_ATOMICS),
+                          (A.LAUNCH_FORCE_GLOBAL_ATOMICS, A.LAUNCH_FORCE_PARTITIONED)):
+        s1 = ex.prepare(cp, frag_ids=[0, 2, 4, 6], flags=first)
+        s1.init_output()
+        s1.launch()
+        s2 = ex.prepare(cp, frag_ids=[1, 3, 5, 7], flags=second, out_ptr=s1.out_ptr)
+        s2.launch()
+        mgr.synchronizeStream(0)
+        both = mgr.to_host(s1.out_ptr, cp.buffer_bytes, 0)
+        assert int(mgr.to_host(s1.d_err.ptr, 4, 0, np.int32)[0]) == 0
+        assert int(mgr.to_host(s2.d_err.ptr, 4, 0, np.int32)[0]) == 0
+        _check_rows(cp, both, want)
+        _assert_reference_placement(oracle, cp, both)
+        s2.free()
+        s1.free()
+
+
+def test_partitioned_full_table_reports_out_of_slots(oracle, gpu_executor_factory):
+    """More groups than entries: the overflow pass walks the whole table and reports ERR_OUT_OF_SLOTS like
+    get_group_value returning NULL (QE/GroupByRuntime.cpp:31-55)."""
+    from hdk_amd._lib import HdkHipError
+    rng = np.random.default_rng(57)
+    n = 300_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 40_000, n, dtype=np.int64) * 7919, "v": np.ones(n, dtype=np.int64)},
+                    fragment_size=100_000)
+    q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=30_011,
+                  targets=[KeyRef(0), Agg("sum", ColRef("v"))])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == A.ERR_OUT_OF_SLOTS
+    with pytest.raises(HdkHipError) as ei:
+        gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS

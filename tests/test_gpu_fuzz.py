@@ -30,7 +30,7 @@ def test_random_aggregate_plans(oracle, gpu_executor_factory, seed):
     rng = np.random.default_rng(seed)
     st = make_tables(rng, 60_000, 700)
     ex = gpu_executor_factory(st)
-    ran, kernels = 0, set()
+    ran, kernels, div0 = 0, set(), 0
     for i in range(40):
         q = random_query(rng)
         try:
@@ -38,6 +38,16 @@ def test_random_aggregate_plans(oracle, gpu_executor_factory, seed):
         except QueryMustRunOnCpu:
             continue
         if err == A.ERR_DIV_BY_ZERO:
+            # the device must report the same error (record_error_code, QE/RuntimeFunctions.cpp:1123-1135), whatever
+            # kernel runs the plan
+            from hdk_amd._lib import HdkHipError
+            for flags in (0, A.LAUNCH_FORCE_GLOBAL_ATOMICS, A.LAUNCH_FORCE_SCALAR):
+                exd = gpu_executor_factory(st)
+                exd.fuse_join_tables = flags == 0
+                with pytest.raises(HdkHipError) as ei:
+                    exd.execute(cp, flags=flags)
+                assert ei.value.code == A.ERR_DIV_BY_ZERO, (seed, i, q, flags)
+            div0 += 1
             continue
         assert err == 0, (seed, i, q)
         step = ex.prepare(cp)
