@@ -1074,6 +1074,26 @@ static uint32_t pow2_ceil_log2(uint64_t x) {
   return l;
 }
 
+// unsigned 32-bit division by an invariant divisor d >= 2, round-up method in its branch-free form:
+//   t = mulhi(magic, n);  q = (((n - t) >> 1) + t) >> shift        (exact for every 32-bit n)
+static void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  uint32_t log2d = 31;
+  while (!(d >> log2d)) --log2d;
+  if ((d & (d - 1)) == 0) {
+    *magic = 0;
+    *shift = log2d - 1;
+    return;
+  }
+  const uint64_t two_k = 1ull << (32 + log2d);
+  const uint64_t m = two_k / d;
+  const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
+  uint32_t m32 = static_cast<uint32_t>(m) * 2u;
+  const uint32_t twice_rem = rem * 2u;
+  if (twice_rem >= d || twice_rem < rem) m32 += 1;
+  *magic = m32 + 1u;
+  *shift = log2d;
+}
+
 static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
@@ -1111,7 +1131,7 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->ntargets = bf.ntargets;
   pa->tw = pa->nkeys + pa->nargs;
   pa->entry_count = p->entry_count;
-  pa->mod_magic = UINT64_C(0xFFFFFFFFFFFFFFFF) / p->entry_count + 1;
+  magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
   // regions: the largest power of two of entries whose rows fit the LDS image
   uint32_t slots_log2 = 0;
   while ((2ull << slots_log2) * p->row_size_quad * 8 <= kPartLdsBytes) ++slots_log2;
@@ -1133,7 +1153,9 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   const uint64_t rows = ko->total_rows;
   pa->total_rows = rows;
   auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
-  pa->cap1 = round_g(rows / pa->p1 + rows / (static_cast<uint64_t>(pa->p1) * 16) + 8192);  // uniform hash: sigma ~ sqrt(rows/P1); 6 % + 8 K slack
+  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack
+  const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / pf) + 1;
+  pa->cap1 = round_g(share1 + share1 / 16 + 8192);
   pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256);                                   // 25 % + 256
   pa->cap_ovf = rows / 16 + 4096;
   pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused

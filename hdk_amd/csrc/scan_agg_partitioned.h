@@ -60,7 +60,7 @@ struct PartArgs {
   uint32_t fine_count;   // PF = ceil(entry_count / S) regions
   uint32_t p2_log2;      // regions per coarse partition = 1 << p2_log2
   uint32_t p1;           // coarse partitions = ceil(PF / P2)
-  uint64_t mod_magic;    // ceil(2^64 / entry_count): h % entry_count without a division
+  uint32_t mod_magic, mod_shift;  // h % entry_count without a division (fastmod_u32)
   int32_t tw;            // tuple words
   int32_t g_log2;        // flush granule G = 1 << g_log2 tuples (whole 128-byte lines)
   int32_t key_buf_idx, key_width, key_kind;
@@ -89,9 +89,12 @@ struct PartArgs {
   ProjFastQual q[kMaxPlainQuals];
 };
 
-// h % d for 32-bit h with M = ceil(2^64 / d) (Lemire, "Faster remainder by direct computation")
-HDK_DEV uint32_t fastmod_u32(uint32_t h, uint64_t M, uint32_t d) {
-  return static_cast<uint32_t>(__umul64hi(M * h, d));
+// h % d for any 32-bit h: unsigned division by an invariant divisor, round-up method in its branch-free form
+// (33-bit magic number, low 32 bits in `magic`): one v_mul_hi_u32 + one v_mul_lo_u32 instead of a division
+HDK_DEV uint32_t fastmod_u32(uint32_t h, uint32_t magic, uint32_t shift, uint32_t d) {
+  const uint32_t t = __umulhi(magic, h);
+  const uint32_t q = (((h - t) >> 1) + t) >> shift;
+  return h - q * d;
 }
 
 // the reference's first probe position of a tuple's key
@@ -99,7 +102,7 @@ template <typename K, int TW = kPartMaxTW>
 HDK_DEV uint32_t part_home(const PartArgs& a, const int64_t* tup) {
   const K k[2] = {static_cast<K>(tup[0]), TW > 1 ? static_cast<K>(tup[TW > 1 ? 1 : 0]) : K(0)};
   const uint32_t h = (TW > 1 && a.nkeys == 2) ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
-  return fastmod_u32(h, a.mod_magic, a.entry_count);
+  return fastmod_u32(h, a.mod_magic, a.mod_shift, a.entry_count);
 }
 
 // staging capacity of a scatter batch: the new tuples plus at most G - 1 carried ones per bin (multiple of 8)
@@ -118,9 +121,12 @@ template <int LEVEL, typename K, int TW>
 __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   __shared__ uint32_t s_cnt[kPartMaxBins];     // tuples of the bin in this batch (carried + new); rank source
   __shared__ uint32_t s_lpos[kPartMaxBins];    // start of the bin's run in the staging area
-  __shared__ uint32_t s_base[kPartMaxBins];    // first position claimed for the run
-  __shared__ uint32_t s_nflush[kPartMaxBins];  // tuples of the run that leave in this batch
-  __shared__ uint32_t s_kind[kPartMaxBins];    // where they go: 0 slab, 1 tail slab, 2 overflow area, 3 dropped
+  // per bin and batch, read as one 16-byte word by the copy-out: .x start of the run in the staging area, .y tuples
+  // of the run that leave in this batch, .z first position claimed for them, .w 0 slab, 1 tail slab, 2 slab +
+  // overflow area, 3 slab + dropped (fallback armed)
+  __shared__ uint4 s_run[kPartMaxBins];
+  __shared__ uint32_t s_nfit[kPartMaxBins];    // kinds 2, 3: how many of them still fit the slab
+  __shared__ uint32_t s_obase[kPartMaxBins];   // kind 2: overflow-area position of the rest
   __shared__ uint32_t s_total, s_nleft, s_stop;
   extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
   constexpr int VR = kPartVR, LV = kPartLV;
@@ -192,26 +198,31 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
     if (tid < kPartMaxBins) {
       const uint32_t n = tid < static_cast<int>(nbins) ? s_cnt[tid] : 0;
       const uint32_t nf = last ? n : n & ~gmask;
-      uint32_t kind = 0, base = 0;
+      uint32_t kind = 0, base = 0, nfit = nf, obase = 0;
       if (nf) {
         if (last) {  // < G tuples: the bin's tail slab, exact count (tcap = writers x (G - 1): cannot overflow)
           kind = 1;
           base = atomicAdd(tfill + tid, nf);
         } else {
           base = atomicAdd(fill + static_cast<size_t>(tid) * cstride, nf);
-          if (static_cast<uint64_t>(base) + nf > cap) {  // the slab is full (heavy hitter): overflow area
-            base = atomicAdd(a.fill_ovf, nf);
+          // what does not fit the slab any more (heavy hitter) goes to the overflow area -- split at the slab's end, a
+          // multiple of G like `base`: readers take the slab as [0, min(cursor, cap)), every position of it is written
+          nfit = static_cast<uint64_t>(base) >= cap ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(nf), cap - base));
+          if (nfit < nf) {
+            obase = atomicAdd(a.fill_ovf, nf - nfit);
             kind = 2;
-            if (static_cast<uint64_t>(base) + nf > a.cap_ovf) {
+            if (static_cast<uint64_t>(obase) + (nf - nfit) > a.cap_ovf) {
               kind = 3;
               atomicExch(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel
             }
           }
         }
       }
-      s_base[tid] = base;
-      s_nflush[tid] = nf;
-      s_kind[tid] = kind;
+      s_run[tid].y = nf;
+      s_run[tid].z = base;
+      s_run[tid].w = kind;
+      s_nfit[tid] = nfit;
+      s_obase[tid] = obase;
     }
     if (tid < kWave) {
       uint32_t carry = 0;
@@ -226,6 +237,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
           }
         }
         s_lpos[c0 + tid] = carry + incl - n;
+        s_run[c0 + tid].x = carry + incl - n;
         carry += __shfl(incl, kWave - 1, kWave);
       }
       if (tid == 0) {
@@ -260,23 +272,46 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
     }
     __syncthreads();
     // 4. copy out whole lines: consecutive staging slots of a bin go to consecutive slab positions; what stays
-    //    behind (< G per bin) is listed for the next batch
+    //    behind (< G per bin) is listed for the next batch (one list claim per wave)
     const uint32_t total = s_total;
-    for (uint32_t i = tid; i < total; i += kPartBlock) {
-      const uint32_t b = s_binof[i];
-      const uint32_t r = i - s_lpos[b];
-      if (r >= s_nflush[b]) {
-        s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(i);
+    for (uint32_t i0 = 0; i0 < total; i0 += kPartBlock) {
+      const uint32_t i = i0 + tid;
+      const bool in = i < total;
+      uint4 run = make_uint4(0, 0, 0, 0);
+      uint32_t b = 0, r = 0;
+      if (in) {
+        b = s_binof[i];
+        run = s_run[b];
+        r = i - run.x;
+      }
+      const bool stays = in && r >= run.y;
+      const uint64_t stay_mask = __ballot(stays);
+      if (stay_mask) {
+        const int lane = tid & (kWave - 1);
+        uint32_t lbase = 0;
+        if (lane == __ffsll(static_cast<long long>(stay_mask)) - 1) {
+          lbase = atomicAdd(&s_nleft, static_cast<uint32_t>(__popcll(stay_mask)));
+        }
+        lbase = __shfl(lbase, __ffsll(static_cast<long long>(stay_mask)) - 1, kWave);
+        if (stays) {
+          s_left[lbase + __popcll(stay_mask & ((1ull << lane) - 1))] = static_cast<uint16_t>(i);
+        }
+      }
+      if (!in || stays) {
         continue;
       }
-      const uint32_t kind = s_kind[b];
-      if (kind == 3) {
-        continue;
+      const uint32_t kind = run.w;
+      uint32_t nfit = run.y;
+      if (kind >= 2) {
+        nfit = s_nfit[b];
+        if (r >= nfit && kind == 3) {
+          continue;
+        }
       }
-      const size_t pos = static_cast<size_t>(s_base[b]) + r;
-      int64_t* q = kind == 0   ? out + (static_cast<size_t>(b) * cap + pos) * tw
+      const size_t pos = static_cast<size_t>(run.z) + r;
+      int64_t* q = r >= nfit   ? a.ovf + (static_cast<size_t>(s_obase[b]) + (r - nfit)) * tw
                    : kind == 1 ? tout + (static_cast<size_t>(b) * tcap + pos) * tw
-                               : a.ovf + pos * tw;
+                               : out + (static_cast<size_t>(b) * cap + pos) * tw;
       if (TW == 2) {
         *reinterpret_cast<bf_i64x2*>(q) = *reinterpret_cast<const bf_i64x2*>(s_stage + static_cast<size_t>(i) * 2);
       } else {
