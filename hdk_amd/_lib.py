@@ -10,7 +10,8 @@ import subprocess
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhdk_hip.so")
+# HDK_HIP_LIB: load another build of the same ABI instead (A/B measurements of two builds; never a fallback)
+LIB_PATH = os.environ.get("HDK_HIP_LIB") or os.path.join(_HERE, "libhdk_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 

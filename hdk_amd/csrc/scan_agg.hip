@@ -1094,6 +1094,34 @@ static void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
   *shift = log2d;
 }
 
+// key_hash (QE/GroupByRuntime.cpp:24-29: MurmurHash3 of the packed key, seed 0) of the key (k, 0) on the host, for the
+// padding keys of the partitioned group-by; same word order as key_hash_dev (baseline_table.h)
+template <typename K>
+static uint32_t host_key_hash(int64_t k, int nkeys) {
+  uint32_t h1 = 0;
+  auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+  auto mix = [&](uint32_t k1) {
+    k1 *= 0xcc9e2d51u;
+    k1 = rotl(k1, 15);
+    k1 *= 0x1b873593u;
+    h1 ^= k1;
+    h1 = rotl(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64u;
+  };
+  for (int i = 0; i < nkeys; ++i) {
+    const uint64_t v = i == 0 ? static_cast<uint64_t>(k) : 0;
+    mix(static_cast<uint32_t>(v));
+    if (sizeof(K) == 8) mix(static_cast<uint32_t>(v >> 32));
+  }
+  h1 ^= static_cast<uint32_t>(nkeys * sizeof(K));
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6bu;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35u;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
 static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
@@ -1132,11 +1160,11 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->tw = pa->nkeys + pa->nargs;
   pa->entry_count = p->entry_count;
   magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
-  // regions: the largest power of two of entries whose rows fit the LDS image
-  uint32_t slots_log2 = 0;
-  while ((2ull << slots_log2) * p->row_size_quad * 8 <= kPartLdsBytes) ++slots_log2;
-  pa->slots_log2 = slots_log2;
-  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + (1ull << slots_log2) - 1) >> slots_log2;
+  // regions: as many entries as fit the LDS image
+  pa->slots = kPartLdsBytes / (p->row_size_quad * 8);
+  if (pa->slots < 16 || pa->slots >= p->entry_count) return false;
+  magic_u32(pa->slots, &pa->reg_magic, &pa->reg_shift);
+  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + pa->slots - 1) / pa->slots;
   // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch)
   uint32_t p2_log2 = (pow2_ceil_log2(pf) + 1) / 2;
   while (((pf + (1ull << p2_log2) - 1) >> p2_log2) > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
@@ -1144,19 +1172,38 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->fine_count = static_cast<uint32_t>(pf);
   pa->p2_log2 = p2_log2;
   pa->p1 = static_cast<uint32_t>((pf + (1ull << p2_log2) - 1) >> p2_log2);
-  // flush granule: whole 128-byte lines (8 tuples of 16 B; 16 tuples of 8 or 24 B), as long as the carried tuples
-  // of all bins fit the threads that take them along
-  const uint32_t max_bins = pa->p1 > (1u << p2_log2) ? pa->p1 : (1u << p2_log2);
-  pa->g_log2 = pa->tw == 2 ? 3 : 4;
-  while (pa->g_log2 > 0 && max_bins * ((1u << pa->g_log2) - 1) > static_cast<uint32_t>(kPartBlock * kPartLV)) --pa->g_log2;
+  // whole 128-byte lines: runs of G tuples (8 of 16 B; 16 of 8 or 24 B), padded with keys of another partition --
+  // which needs two coarse partitions (a table this small gains nothing from alignment anyway)
+  // Measured at the C5 shape (256 M rows): rounding runs up to whole lines costs more than it gains -- the padding
+  // is 18 % of pass 1's output and compounds to 44 % of pass 3's input, and its staging slots cost the third block
+  // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
+  // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements.
+  pa->g_log2 = 0;
+  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = pa->p1 < 2 ? 0 : atoi(e);
+  if (pa->g_log2) {
+    int found = 0;
+    for (int64_t k = 1; k < 4096 && found < 2; ++k) {
+      const uint32_t h = p->key_width == 4 ? host_key_hash<int32_t>(k, pa->nkeys) : host_key_hash<int64_t>(k, pa->nkeys);
+      const uint32_t c = static_cast<uint32_t>((h % p->entry_count) / pa->slots) >> p2_log2;
+      if (found == 0 || c != pa->pad_coarse[0]) {
+        pa->pad_key[found] = k;
+        pa->pad_coarse[found] = c;
+        ++found;
+      }
+    }
+    if (found < 2) pa->g_log2 = 0;
+  }
   const uint64_t g = 1ull << pa->g_log2;
   const uint64_t rows = ko->total_rows;
   pa->total_rows = rows;
   auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
-  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack
+  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack, plus the
+  // padding: on average (G - 1) / 2 slots per bin and batch
+  const uint64_t batches = rows / kPartTile + 1;
   const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / pf) + 1;
-  pa->cap1 = round_g(share1 + share1 / 16 + 8192);
-  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256);                                   // 25 % + 256
+  pa->cap1 = round_g(share1 + share1 / 16 + 8192 + batches * (g - 1) * 5 / 8);
+  const uint64_t batches2 = share1 / kPartTile + kPartG2X;  // batches a coarse slab is scattered in
+  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (g - 1) * 5 / 8);  // 25 % + 256 + padding
   pa->cap_ovf = rows / 16 + 4096;
   pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
   if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFFFFF0ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
@@ -1194,44 +1241,38 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const uint32_t p2 = 1u << pa.p2_log2;
   const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw);
   const size_t lds2 = part_scatter_lds_bytes(p2, gmask, pa.tw);
-  // pass-1 grid: what is resident (the staging area allows two 512-thread blocks per CU); every block ends with one
-  // partial flush per bin into the tail slabs
+  // pass-1 grid: what is resident, at most one block per batch
   const void* k1 = k32 ? part_scatter_kernel<1, int32_t>(pa.tw) : part_scatter_kernel<1, int64_t>(pa.tw);
   unsigned g1 = resident_grid(k1, kPartBlock, lds1, props);
   const uint64_t tiles = (pa.total_rows + kPartTile - 1) / kPartTile;
   if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
-  pa.tcap1 = g1 * (gmask ? gmask : 1);
-  pa.tcap2 = static_cast<uint32_t>(kPartG2X) * (gmask ? gmask : 1);
   const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
-  const size_t bt1 = static_cast<size_t>(pa.p1) * pa.tcap1 * tw * 8;
   const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
-  const size_t bt2 = static_cast<size_t>(pa.fine_count) * pa.tcap2 * tw * 8;
   const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
-  const size_t nc = static_cast<size_t>(pa.p1) * kPartCursorStride + pa.p1 + 2 * static_cast<size_t>(pa.fine_count) + 4;
+  const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
+  const size_t nc = static_cast<size_t>(pa.p1) * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
   const size_t bc = nc * sizeof(uint32_t);
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   int8_t* scratch = nullptr;
-  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), up(b1) + up(bt1) + up(b2) + up(bt2) + up(bo) + up(bc), s);
+  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
   if (me != hipSuccess) {
     (void)hipGetLastError();
     return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
   }
   int8_t* q = scratch;
   pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
-  pa.tail1 = reinterpret_cast<int64_t*>(q); q += up(bt1);
   pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
-  pa.tail2 = reinterpret_cast<int64_t*>(q); q += up(bt2);
   pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
+  pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
   pa.fill1 = reinterpret_cast<uint32_t*>(q);
-  pa.tfill1 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartCursorStride;
-  pa.fill2 = pa.tfill1 + pa.p1;
-  pa.tfill2 = pa.fill2 + pa.fine_count;
-  pa.fill_ovf = pa.tfill2 + pa.fine_count;
+  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartCursorStride;
+  pa.nspill = pa.fill2 + pa.fine_count;
+  pa.fill_ovf = pa.nspill + pa.fine_count;
   pa.fill_spill = pa.fill_ovf + 1;
   pa.fallback = pa.fill_spill + 1;
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
   const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
-  const size_t table_bytes = (static_cast<size_t>(1) << pa.slots_log2) * plan->row_size_quad * 8;
+  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
   if (k32) {
     launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
     launch_part_scatter<2, int32_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);

@@ -10,7 +10,7 @@
 // hdk_hip_reduce_buffers (ResultSetReduction::reduceOneEntryBaseline, QE/ResultSetReduction.cpp:694-731).
 //
 //   home(key)   = key_hash(key) % entry_count                      (the reference's first probe)
-//   region f    = home >> slots_log2: table entries [f * S, min((f + 1) * S, entry_count)),  S = 2^slots_log2
+//   region f    = home / S: table entries [f * S, min((f + 1) * S, entry_count)),  S rows = 60 KiB of LDS
 //   pass 1  filter rows, scatter (keys + argument columns -> tuples of <= 3 words) into P1 coarse slabs
 //           (c = f >> p2_log2)
 //   pass 2  scatter each coarse slab into its P2 = 2^p2_log2 fine slabs (one per region)
@@ -27,13 +27,15 @@
 //
 // Scatter, per batch of kPartTile tuples: LDS histogram by bin -> one slab claim per bin -> LDS staging ordered
 // by bin -> copy-out.  What the passes wait for is the copy-out (scripts/microbench/partition.hip): runs that
-// start and end inside 128-byte lines took 2.3-2.7 ms per 256 M tuples, the same bytes as whole aligned lines
-// 1.7 ms (4.7 TB/s of 32 B/tuple), with or without the cursor atomics.  So a block only ever writes WHOLE
-// LINES: per bin it flushes a multiple of G tuples (G * tuple bytes = a multiple of 128) at a slab position that
-// is a multiple of G, and carries the remaining < G tuples into its next batch (they are re-read from the staging
-// area and re-ranked like new tuples).  After its last batch a block puts what is left (< G per bin) into a
-// small per-bin TAIL slab with an exact count, so readers never meet a hole.  Slab cursors sit one per 128-byte
-// line (128 cursors in 512 bytes serialise on four lines: 2.68 -> 2.34 ms).
+// start and end inside 128-byte lines took 2.3-2.7 ms per 256 M tuples, the same bytes as whole 128-byte-aligned
+// lines 1.7 ms (4.7 TB/s of 32 B/tuple; 64-byte alignment is not enough: 2.3 ms), with or without the cursor
+// atomics.  So a block only ever writes WHOLE LINES: a bin's run is rounded up to a multiple of G tuples
+// (G * tuple bytes = a multiple of 128) and claimed at a slab position that is a multiple of G; the slots past the
+// run's tuples hold PADDING: a tuple whose key belongs to another partition, which the next pass recognises
+// for free because it recomputes every tuple's partition anyway (part_padding).  No counts, flags or hole maps.
+// (Carrying a bin's remainder into the block's next batch instead of padding writes fewer bytes but measured
+// slower: the extra registers and LDS cost the third block per CU -- 3.4 / 2.45 ms for the two scatter passes.)
+// Slab cursors sit one per 128-byte line (128 cursors in 512 bytes serialise on four lines: 2.68 -> 2.34 ms).
 #pragma once
 #include "scan_agg_baseline_fast.h"
 
@@ -43,24 +45,27 @@ constexpr int kPartBlock = 512;                  // scatter passes (sweep at C5:
 constexpr int kPartAggBlock = 1024;              // aggregation pass: 2 blocks x 64 KiB LDS per CU, all 32 wave slots busy
 constexpr int kPartVR = 4;
 constexpr int kPartTile = kPartBlock * kPartVR;  // new tuples per scatter batch
-constexpr int kPartLV = 4;                       // carried tuples a thread can take along (kPartBlock * kPartLV >= bins * (G - 1))
 constexpr int kPartMaxBins = 256;                // bins a scatter pass distinguishes (P1 <= 256, P2 <= 256)
 constexpr int kPartMaxArgs = 2;                  // argument columns carried in a tuple (at most)
 constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: 1-2 keys + argument columns, 3 in all (LDS staging)
-constexpr uint32_t kPartLdsBytes = 64 * 1024;    // LDS image of a region
+constexpr uint32_t kPartLdsBytes = 60 * 1024;    // LDS image of a region (two 1024-thread blocks per CU; above 64 KiB per block only one was resident)
 constexpr uint32_t kPartCursorStride = 32;       // uint32 cursors one per 128-byte line
 constexpr int kPartG2X = 16;                     // pass-2 blocks per coarse slab
+constexpr uint32_t kPartSpillSeg = 64;           // spilled tuples a region keeps in its own segment before it takes the shared list
 
 struct PartArgs {
   const hdk_hip_plan* plan;
   KernParams kp;
   uint32_t entry_count;
   uint64_t total_rows;   // upper bound on the rows of the launch (hdk_hip_kernel_options::total_rows)
-  uint32_t slots_log2;   // S = 1 << slots_log2 entries per region
   uint32_t fine_count;   // PF = ceil(entry_count / S) regions
   uint32_t p2_log2;      // regions per coarse partition = 1 << p2_log2
   uint32_t p1;           // coarse partitions = ceil(PF / P2)
   uint32_t mod_magic, mod_shift;  // h % entry_count without a division (fastmod_u32)
+  uint32_t slots;                 // S: entries per region (the LDS image of a region holds S rows)
+  uint32_t reg_magic, reg_shift;  // home / S
+  int64_t pad_key[2];             // padding keys (second key word 0), from two different coarse partitions
+  uint32_t pad_coarse[2];
   int32_t tw;            // tuple words
   int32_t g_log2;        // flush granule G = 1 << g_log2 tuples (whole 128-byte lines)
   int32_t key_buf_idx, key_width, key_kind;
@@ -72,18 +77,15 @@ struct PartArgs {
   int32_t tgt_index[HDK_HIP_MAX_TARGETS];  // plan target index
   int32_t tgt_arg[HDK_HIP_MAX_TARGETS];    // tuple word of its argument (>= nkeys), or 0 for none
   uint64_t cap1, cap2, cap_ovf, cap_spill; // capacities in tuples (cap1, cap2: multiples of G)
-  uint32_t tcap1, tcap2; // tail slab capacities: blocks writing the bin x (G - 1)
-  int64_t* slab1;        // [p1][cap1][tw]            (pass 3 reuses this memory as the spill area)
-  int64_t* tail1;        // [p1][tcap1][tw]
+  int64_t* slab1;        // [p1][cap1][tw]            (pass 3 reuses this memory as the shared spill list)
   int64_t* slab2;        // [fine_count][cap2][tw]
-  int64_t* tail2;        // [fine_count][tcap2][tw]
   int64_t* ovf;          // [cap_ovf][tw]
   uint32_t* fill1;       // [p1] x kPartCursorStride
-  uint32_t* tfill1;      // [p1]
   uint32_t* fill2;       // [fine_count]
-  uint32_t* tfill2;      // [fine_count]
   uint32_t* fill_ovf;    // [1]
-  uint32_t* fill_spill;  // [1]
+  uint32_t* fill_spill;  // [1]: the shared spill list (in slab1's memory), used once a region's own segment is full
+  uint32_t* nspill;      // [fine_count]: tuples in the region's own spill segment
+  int64_t* spill_seg;    // [fine_count][kPartSpillSeg][tw]
   uint32_t* fallback;    // [1]: set when the overflow area is exhausted -> the atomics kernel takes over
   int32_t nquals;        // plain filters, applied in pass 1
   ProjFastQual q[kMaxPlainQuals];
@@ -105,129 +107,108 @@ HDK_DEV uint32_t part_home(const PartArgs& a, const int64_t* tup) {
   return fastmod_u32(h, a.mod_magic, a.mod_shift, a.entry_count);
 }
 
-// staging capacity of a scatter batch: the new tuples plus at most G - 1 carried ones per bin (multiple of 8)
+// region (fine partition) of a tuple's key: home / S
+template <typename K, int TW = kPartMaxTW>
+HDK_DEV uint32_t part_region(const PartArgs& a, const int64_t* tup) {
+  const uint32_t home = part_home<K, TW>(a, tup);
+  const uint32_t t = __umulhi(a.reg_magic, home);
+  return (((home - t) >> 1) + t) >> a.reg_shift;
+}
+
+// The padding that fills a run up to whole 128-byte lines: a tuple whose KEY belongs to another coarse slab (and so
+// to another region) than the slab it is written to.  Readers recompute the partition of every tuple anyway (pass
+// 2: its bin; pass 3: its home) and drop what does not belong -- padding needs no flag, no count and no hole map.
+// The host picks two keys from different coarse partitions; `region` is the first region of the slab written to.
+HDK_DEV int64_t part_padding(const PartArgs& a, uint32_t region) {
+  return (region >> a.p2_log2) != a.pad_coarse[0] ? a.pad_key[0] : a.pad_key[1];
+}
+
+// staging capacity of a scatter batch: the tuples plus at most G - 1 padding slots per bin (multiple of 8)
 __host__ __device__ inline uint32_t part_stage_tuples(uint32_t nbins, uint32_t gmask) {
   return (kPartTile + nbins * gmask + 7u) & ~7u;
 }
 __host__ inline size_t part_scatter_lds_bytes(uint32_t nbins, uint32_t gmask, int tw) {
   const size_t cs = part_stage_tuples(nbins, gmask);
-  return cs * tw * 8 + cs * 2 + static_cast<size_t>(nbins) * gmask * 2 + 16;
+  return cs * tw * 8 + cs + 16;
 }
 
 // ---- scatter: LEVEL 1 reads the columns, LEVEL 2 reads coarse slab blockIdx.y -------------------------
-// dynamic LDS: [cap_stage][tw] staging | uint16 bin of every staged tuple [cap_stage] | uint16 staging index of
-// every carried tuple [bins x (G - 1)]
+// dynamic LDS: [cap_stage][tw] staging | uint8 bin of every staging slot [cap_stage]
 template <int LEVEL, typename K, int TW>
 __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
-  __shared__ uint32_t s_cnt[kPartMaxBins];     // tuples of the bin in this batch (carried + new); rank source
-  __shared__ uint32_t s_lpos[kPartMaxBins];    // start of the bin's run in the staging area
-  // per bin and batch, read as one 16-byte word by the copy-out: .x start of the run in the staging area, .y tuples
-  // of the run that leave in this batch, .z first position claimed for them, .w 0 slab, 1 tail slab, 2 slab +
-  // overflow area, 3 slab + dropped (fallback armed)
+  __shared__ uint32_t s_cnt[kPartMaxBins];     // tuples of the bin in this batch; rank source
+  // per bin and batch, read as one 16-byte word by the copy-out: .x start of the run in the staging area, .y slots
+  // of the run (tuples rounded up to whole lines), .z first slab position claimed for it, .w tuples | kind << 16:
+  // kind 0 slab, 2 slab + overflow area, 3 slab + dropped (fallback armed)
   __shared__ uint4 s_run[kPartMaxBins];
-  __shared__ uint32_t s_nfit[kPartMaxBins];    // kinds 2, 3: how many of them still fit the slab
-  __shared__ uint32_t s_obase[kPartMaxBins];   // kind 2: overflow-area position of the rest
-  __shared__ uint32_t s_total, s_nleft, s_stop;
+  __shared__ uint32_t s_nfit[kPartMaxBins];    // kinds 2, 3: how many slots still fit the slab
+  __shared__ uint32_t s_obase[kPartMaxBins];   // kind 2: overflow-area position of the tuples that do not
+  __shared__ uint32_t s_total, s_stop;
   extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
-  constexpr int VR = kPartVR, LV = kPartLV;
+  constexpr int VR = kPartVR;
   constexpr int tw = TW;  // tuple words, compile time: the tuples of a batch live in registers
   const int tid = threadIdx.x;
   const uint32_t nbins = LEVEL == 1 ? a.p1 : (1u << a.p2_log2);
   const uint32_t gmask = (1u << a.g_log2) - 1;
   const uint32_t cap_stage = part_stage_tuples(nbins, gmask);
   int64_t* s_stage = s_dyn;
-  uint16_t* s_binof = reinterpret_cast<uint16_t*>(s_dyn + static_cast<size_t>(cap_stage) * tw);
-  uint16_t* s_left = s_binof + cap_stage;
+  uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(cap_stage) * tw);
   const uint64_t cap = LEVEL == 1 ? a.cap1 : a.cap2;
-  const uint32_t tcap = LEVEL == 1 ? a.tcap1 : a.tcap2;
   const uint32_t cstride = LEVEL == 1 ? kPartCursorStride : 1;
-  const size_t bin0 = LEVEL == 1 ? 0 : (static_cast<size_t>(blockIdx.y) << a.p2_log2);  // first region of the coarse slab
-  uint32_t* fill = (LEVEL == 1 ? a.fill1 : a.fill2) + bin0 * cstride;
-  uint32_t* tfill = (LEVEL == 1 ? a.tfill1 : a.tfill2) + bin0;
-  int64_t* out = (LEVEL == 1 ? a.slab1 : a.slab2) + bin0 * cap * tw;
-  int64_t* tout = (LEVEL == 1 ? a.tail1 : a.tail2) + bin0 * tcap * tw;
+  const uint32_t bin0 = LEVEL == 1 ? 0 : (blockIdx.y << a.p2_log2);  // first region of the coarse slab
+  uint32_t* fill = (LEVEL == 1 ? a.fill1 : a.fill2) + static_cast<size_t>(bin0) * cstride;
+  int64_t* out = (LEVEL == 1 ? a.slab1 : a.slab2) + static_cast<size_t>(bin0) * cap * tw;
   for (int i = tid; i < kPartMaxBins; i += kPartBlock) {
     s_cnt[i] = 0;
   }
-  if (tid == 0) {
-    s_nleft = 0;
-    s_stop = 0;
-  }
   __syncthreads();
 
-  // One batch: `live` new tuples in registers plus the tuples the previous batch carried over.  `last`: nothing
-  // new, everything that is left goes to the tail slabs.
-  auto do_batch = [&](const bool (&live)[VR], int64_t (&tup)[VR][TW], const bool last) {
-    // 0. carried tuples: back from the staging area into registers (with the bin they were staged under)
-    const uint32_t nleft = s_nleft;
-    bool clive[LV];
-    uint32_t cbin[LV];
-    int64_t ctup[LV][TW];
-#pragma unroll
-    for (int l = 0; l < LV; ++l) {
-      const uint32_t k = tid + l * kPartBlock;
-      clive[l] = k < nleft;
-      cbin[l] = 0;
-      if (clive[l]) {
-        const uint32_t si = s_left[k];
-        cbin[l] = s_binof[si];
-#pragma unroll
-        for (int w = 0; w < TW; ++w) {
-          ctup[l][w] = s_stage[static_cast<size_t>(si) * tw + w];
-        }
-      }
-    }
+  auto do_batch = [&](const bool (&live)[VR], int64_t (&tup)[VR][TW]) {
     // 1. histogram + rank inside the bin
-    uint32_t bin[VR], rank[VR], crank[LV];
+    uint32_t bin[VR], rank[VR];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       bin[r] = 0;
       rank[r] = 0;
       if (live[r]) {
-        const uint32_t f = part_home<K, TW>(a, tup[r]) >> a.slots_log2;
+        const uint32_t f = part_region<K, TW>(a, tup[r]);
         bin[r] = LEVEL == 1 ? f >> a.p2_log2 : f & (nbins - 1);
         rank[r] = atomicAdd(&s_cnt[bin[r]], 1u);
       }
     }
-#pragma unroll
-    for (int l = 0; l < LV; ++l) {
-      crank[l] = clive[l] ? atomicAdd(&s_cnt[cbin[l]], 1u) : 0u;
-    }
     __syncthreads();
-    // 2. per bin: how much leaves (whole lines), where to; run starts in the staging area (exclusive scan by wave 0)
+    // 2. one slab claim per bin, in whole 128-byte lines; run starts in the staging area (exclusive scan by wave 0)
+    uint32_t my_n = 0, my_np = 0;
     if (tid < kPartMaxBins) {
       const uint32_t n = tid < static_cast<int>(nbins) ? s_cnt[tid] : 0;
-      const uint32_t nf = last ? n : n & ~gmask;
-      uint32_t kind = 0, base = 0, nfit = nf, obase = 0;
-      if (nf) {
-        if (last) {  // < G tuples: the bin's tail slab, exact count (tcap = writers x (G - 1): cannot overflow)
-          kind = 1;
-          base = atomicAdd(tfill + tid, nf);
-        } else {
-          base = atomicAdd(fill + static_cast<size_t>(tid) * cstride, nf);
-          // what does not fit the slab any more (heavy hitter) goes to the overflow area -- split at the slab's end, a
-          // multiple of G like `base`: readers take the slab as [0, min(cursor, cap)), every position of it is written
-          nfit = static_cast<uint64_t>(base) >= cap ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(nf), cap - base));
-          if (nfit < nf) {
-            obase = atomicAdd(a.fill_ovf, nf - nfit);
-            kind = 2;
-            if (static_cast<uint64_t>(obase) + (nf - nfit) > a.cap_ovf) {
-              kind = 3;
-              atomicExch(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel
-            }
+      const uint32_t np = (n + gmask) & ~gmask;  // the run's slots: what is not a tuple is padding (see part_padding)
+      uint32_t kind = 0, base = 0, nfit = np, obase = 0;
+      if (n) {
+        base = atomicAdd(fill + static_cast<size_t>(tid) * cstride, np);
+        // what does not fit the slab any more (heavy hitter) goes to the overflow area, without padding -- split at
+        // the slab's end, a multiple of G like `base`: readers take the slab as [0, min(cursor, cap)), every slot written
+        nfit = static_cast<uint64_t>(base) >= cap ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(np), cap - base));
+        if (nfit < n) {
+          obase = atomicAdd(a.fill_ovf, n - nfit);
+          kind = 2;
+          if (static_cast<uint64_t>(obase) + (n - nfit) > a.cap_ovf) {
+            kind = 3;
+            atomicExch(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel
           }
         }
       }
-      s_run[tid].y = nf;
+      s_run[tid].y = np;
       s_run[tid].z = base;
-      s_run[tid].w = kind;
+      s_run[tid].w = n | (kind << 16);
       s_nfit[tid] = nfit;
       s_obase[tid] = obase;
+      my_n = n;
+      my_np = np;
     }
     if (tid < kWave) {
       uint32_t carry = 0;
       for (int c0 = 0; c0 < kPartMaxBins; c0 += kWave) {
-        const uint32_t n = s_cnt[c0 + tid];
+        const uint32_t n = (s_cnt[c0 + tid] + gmask) & ~gmask;  // padded length of the run
         uint32_t incl = n;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
@@ -236,88 +217,81 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             incl += v;
           }
         }
-        s_lpos[c0 + tid] = carry + incl - n;
         s_run[c0 + tid].x = carry + incl - n;
         carry += __shfl(incl, kWave - 1, kWave);
       }
       if (tid == 0) {
         s_total = carry;
-        s_nleft = 0;
       }
     }
     __syncthreads();
-    // 3. stage the tuples ordered by bin
-    auto stage_one = [&](uint32_t b, uint32_t rk, const int64_t* t) {
-      const uint32_t si = s_lpos[b] + rk;
-      s_binof[si] = static_cast<uint16_t>(b);
-#pragma unroll
-      for (int w = 0; w < TW; ++w) {
-        s_stage[static_cast<size_t>(si) * tw + w] = t[w];
-      }
-    };
+    // 3. stage the tuples ordered by bin; the padding slots only get their bin
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       if (live[r]) {
-        stage_one(bin[r], rank[r], tup[r]);
-      }
-    }
+        const uint32_t si = s_run[bin[r]].x + rank[r];
+        s_binof[si] = static_cast<uint8_t>(bin[r]);
+        if (TW == 2) {
+          bf_i64x2 v;
+          v.x = tup[r][0];
+          v.y = tup[r][TW - 1];
+          reinterpret_cast<bf_i64x2*>(s_stage)[si] = v;
+        } else {
 #pragma unroll
-    for (int l = 0; l < LV; ++l) {
-      if (clive[l]) {
-        stage_one(cbin[l], crank[l], ctup[l]);
+          for (int w = 0; w < TW; ++w) {
+            s_stage[static_cast<size_t>(si) * tw + w] = tup[r][w];
+          }
+        }
       }
     }
     if (tid < kPartMaxBins) {
-      s_cnt[tid] = 0;  // (read for the last time in step 2)
+      const uint32_t lp = s_run[tid].x;
+      for (uint32_t j = my_n; j < my_np; ++j) {
+        s_binof[lp + j] = static_cast<uint8_t>(tid);
+      }
+      s_cnt[tid] = 0;
     }
     __syncthreads();
-    // 4. copy out whole lines: consecutive staging slots of a bin go to consecutive slab positions; what stays
-    //    behind (< G per bin) is listed for the next batch (one list claim per wave)
+    // 4. copy out whole lines: consecutive staging slots of a bin go to consecutive slab positions
     const uint32_t total = s_total;
-    for (uint32_t i0 = 0; i0 < total; i0 += kPartBlock) {
-      const uint32_t i = i0 + tid;
-      const bool in = i < total;
-      uint4 run = make_uint4(0, 0, 0, 0);
-      uint32_t b = 0, r = 0;
-      if (in) {
-        b = s_binof[i];
-        run = s_run[b];
-        r = i - run.x;
-      }
-      const bool stays = in && r >= run.y;
-      const uint64_t stay_mask = __ballot(stays);
-      if (stay_mask) {
-        const int lane = tid & (kWave - 1);
-        uint32_t lbase = 0;
-        if (lane == __ffsll(static_cast<long long>(stay_mask)) - 1) {
-          lbase = atomicAdd(&s_nleft, static_cast<uint32_t>(__popcll(stay_mask)));
-        }
-        lbase = __shfl(lbase, __ffsll(static_cast<long long>(stay_mask)) - 1, kWave);
-        if (stays) {
-          s_left[lbase + __popcll(stay_mask & ((1ull << lane) - 1))] = static_cast<uint16_t>(i);
-        }
-      }
-      if (!in || stays) {
-        continue;
-      }
-      const uint32_t kind = run.w;
+    for (uint32_t i = tid; i < total; i += kPartBlock) {
+      const uint32_t b = s_binof[i];
+      const uint4 run = s_run[b];
+      const uint32_t r = i - run.x;
+      const uint32_t n = run.w & 0xffffu, kind = run.w >> 16;
+      const bool pad = r >= n;
       uint32_t nfit = run.y;
       if (kind >= 2) {
         nfit = s_nfit[b];
-        if (r >= nfit && kind == 3) {
+        if (r >= nfit && (pad || kind == 3)) {
           continue;
         }
       }
-      const size_t pos = static_cast<size_t>(run.z) + r;
-      int64_t* q = r >= nfit   ? a.ovf + (static_cast<size_t>(s_obase[b]) + (r - nfit)) * tw
-                   : kind == 1 ? tout + (static_cast<size_t>(b) * tcap + pos) * tw
-                               : out + (static_cast<size_t>(b) * cap + pos) * tw;
+      int64_t* q = r >= nfit ? a.ovf + (static_cast<size_t>(s_obase[b]) + (r - nfit)) * tw
+                             : out + (static_cast<size_t>(b) * cap + run.z + r) * tw;
+      int64_t t[TW];
       if (TW == 2) {
-        *reinterpret_cast<bf_i64x2*>(q) = *reinterpret_cast<const bf_i64x2*>(s_stage + static_cast<size_t>(i) * 2);
+        const bf_i64x2 v = reinterpret_cast<const bf_i64x2*>(s_stage)[i];
+        t[0] = pad ? 0 : v.x;
+        t[TW - 1] = pad ? 0 : v.y;
       } else {
 #pragma unroll
         for (int w = 0; w < TW; ++w) {
-          q[w] = s_stage[static_cast<size_t>(i) * tw + w];
+          t[w] = pad ? 0 : s_stage[static_cast<size_t>(i) * tw + w];
+        }
+      }
+      if (pad) {
+        t[0] = part_padding(a, LEVEL == 1 ? b << a.p2_log2 : bin0 + b);
+      }
+      if (TW == 2) {
+        bf_i64x2 v;
+        v.x = t[0];
+        v.y = t[1];
+        *reinterpret_cast<bf_i64x2*>(q) = v;
+      } else {
+#pragma unroll
+        for (int w = 0; w < TW; ++w) {
+          q[w] = t[w];
         }
       }
     }
@@ -326,16 +300,6 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
 
   if (LEVEL == 2 && __hip_atomic_load(a.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     return;
-  }
-  bool none[VR];
-  int64_t zero[VR][TW];
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    none[r] = false;
-#pragma unroll
-    for (int w = 0; w < TW; ++w) {
-      zero[r][w] = 0;
-    }
   }
   if (LEVEL == 1) {
     const uint64_t nfrag = *a.kp.num_fragments;
@@ -393,17 +357,15 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             }
           }
         }
-        do_batch(live, tup, false);
+        do_batch(live, tup);
       }
       frag_tile_begin += ntiles;
     }
   } else {
-    // coarse slab c = its main part [0, min(fill, cap)) followed by its tail slab [0, tfill)
+    // coarse slab c: [0, min(cursor, cap)); a slot that does not belong to c is padding
     const uint32_t c = blockIdx.y;
-    const uint64_t n_main = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(c) * kPartCursorStride]), a.cap1);
-    const uint64_t n = n_main + a.tfill1[c];
-    const int64_t* in_main = a.slab1 + static_cast<size_t>(c) * a.cap1 * tw;
-    const int64_t* in_tail = a.tail1 + static_cast<size_t>(c) * a.tcap1 * tw;
+    const uint64_t n = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(c) * kPartCursorStride]), a.cap1);
+    const int64_t* in = a.slab1 + static_cast<size_t>(c) * a.cap1 * tw;
     for (uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kPartTile; t0 < n; t0 += static_cast<uint64_t>(gridDim.x) * kPartTile) {
       bool live[VR];
       int64_t tup[VR][TW];
@@ -411,16 +373,27 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
       for (int r = 0; r < VR; ++r) {
         const uint64_t i = t0 + static_cast<uint64_t>(r) * kPartBlock + tid;
         live[r] = i < n;
-        const int64_t* q = i < n_main ? in_main + i * tw : in_tail + (i - n_main) * tw;
+        if (TW == 2) {
+          bf_i64x2 v;
+          v.x = 0;
+          v.y = 0;
+          if (live[r]) {
+            v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+                reinterpret_cast<uintptr_t>(in + i * 2)));
+          }
+          tup[r][0] = v.x;
+          tup[r][TW - 1] = v.y;
+        } else {
 #pragma unroll
-        for (int w = 0; w < TW; ++w) {
-          tup[r][w] = live[r] ? __builtin_nontemporal_load(q + w) : 0;
+          for (int w = 0; w < TW; ++w) {
+            tup[r][w] = live[r] ? __builtin_nontemporal_load(in + i * tw + w) : 0;
+          }
         }
+        live[r] = live[r] && (part_region<K, TW>(a, tup[r]) >> a.p2_log2) == c;
       }
-      do_batch(live, tup, false);
+      do_batch(live, tup);
     }
   }
-  do_batch(none, zero, true);  // what is still carried: into the tail slabs
 }
 
 // What a tuple needs to know about a target, gathered once per block into LDS: reading the plan (global
@@ -497,23 +470,28 @@ HDK_DEV void part_apply_targets(const PartTarget* s_tg, int ntargets, int8_t* ro
 }
 
 // ---- pass 3: one block per region -------------------------------------------------------------------------
+// (second launch bound = waves per SIMD: two 1024-thread blocks per CU need 8, i.e. <= 64 VGPRs and <= 80 SGPRs --
+// at 98 SGPRs only one block was resident and the pass took 3.2 ms instead of 2.3)
 template <typename K>
-__global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) {
+__global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds_table[];
   __shared__ PartTarget s_tg[HDK_HIP_MAX_TARGETS];
+  __shared__ uint32_t s_nspill;
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
   const uint32_t f = blockIdx.x;
+  if (tid == 0) {
+    s_nspill = 0;
+  }
   const TableShape shape = table_shape(p);
   const uint32_t rq = shape.row_quads;
   const int ntargets = a.ntargets;
-  const uint32_t first = f << a.slots_log2;                           // first table entry of the region
-  const uint32_t slots = min(1u << a.slots_log2, a.entry_count - first);  // (the last region may be short)
+  const uint32_t first = f * a.slots;                        // first table entry of the region
+  const uint32_t slots = min(a.slots, a.entry_count - first);  // (the last region may be short)
   part_load_targets(a, p, s_tg);
   const uint32_t words = slots * rq;
   int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(first) * rq;
-  const uint64_t n_main = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
-  const uint64_t n = n_main + a.tfill2[f];
+  const uint64_t n = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
   if (n == 0 || *a.fallback) {
     return;  // the region keeps its initialised (empty) image
   }
@@ -522,8 +500,7 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   }
   __syncthreads();
   const int tw = a.tw;
-  const int64_t* in_main = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
-  const int64_t* in_tail = a.tail2 + static_cast<size_t>(f) * a.tcap2 * tw;
+  const int64_t* in = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
   int64_t* spill = a.slab1;  // dead since pass 2 and large enough for every tuple of the launch
   // Two tuples per trip, the next pair's loads issued before the current pair is applied: the LDS
   // claim/aggregate chain (ds_* ops, lgkmcnt) of one pair hides the HBM latency (vmcnt) of the next.
@@ -531,7 +508,7 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   int64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
   auto fetch = [&](uint64_t i, int64_t& t0, int64_t& t1, int64_t& t2) {
     if (i < n) {
-      const int64_t* q = i < n_main ? in_main + i * tw : in_tail + (i - n_main) * tw;
+      const int64_t* q = in + i * tw;
       t0 = __builtin_nontemporal_load(q);
       t1 = tw > 1 ? __builtin_nontemporal_load(q + 1) : 0;
       t2 = tw > 2 ? __builtin_nontemporal_load(q + 2) : 0;
@@ -540,14 +517,27 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   auto apply = [&](const int64_t (&tup)[kPartMaxTW]) {
     const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};  // (word 1 is only read as a key when key_count == 2)
     const uint32_t local = part_home<K>(a, tup) - first;
+    if (local >= slots) {
+      return;  // padding of the scatter passes: a key of another region (part_padding)
+    }
     bool fresh;
     const int64_t e = find_or_claim_from<K, false>(shape, lds_table, slots, local, key, &fresh);
     if (e < 0) {  // the group lives past the end of this region: pass 4 places it with the whole-table probe
-      const uint32_t o = atomicAdd(a.fill_spill, 1u);
-      if (o < a.cap_spill) {
-        for (int w = 0; w < tw; ++w) {
-          spill[static_cast<size_t>(o) * tw + w] = tup[w];
+      // (a counter in LDS and a segment of the region's own: one shared cursor for every region took a returning
+      // global atomic on ONE address per spilled tuple -- ~1e5 of them per 256 M rows, ~1 ms)
+      const uint32_t k = atomicAdd(&s_nspill, 1u);
+      int64_t* q;
+      if (k < kPartSpillSeg) {
+        q = a.spill_seg + (static_cast<size_t>(f) * kPartSpillSeg + k) * tw;
+      } else {
+        const uint32_t o = atomicAdd(a.fill_spill, 1u);
+        if (o >= a.cap_spill) {
+          return;  // (cannot happen: the shared list is as large as the launch's input)
         }
+        q = spill + static_cast<size_t>(o) * tw;
+      }
+      for (int w = 0; w < tw; ++w) {
+        q[w] = tup[w];
       }
       return;
     }
@@ -570,6 +560,9 @@ __global__ __launch_bounds__(kPartAggBlock) void hdk_part_aggregate(PartArgs a) 
   for (uint32_t i = tid; i < words; i += kPartAggBlock) {
     region[i] = lds_table[i];
   }
+  if (tid == 0) {
+    a.nspill[f] = min(s_nspill, kPartSpillSeg);
+  }
 }
 
 // ---- pass 4: overflow and spilled tuples, straight onto the table with the reference's probe sequence --------
@@ -584,14 +577,23 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
   __syncthreads();
   const uint64_t n_ovf = min(static_cast<uint64_t>(*a.fill_ovf), a.cap_ovf);
   const uint64_t n_spill = min(static_cast<uint64_t>(*a.fill_spill), a.cap_spill);
+  const uint64_t n_seg = static_cast<uint64_t>(a.fine_count) * kPartSpillSeg;  // slots of the regions' own segments
   const TableShape shape = table_shape(p);
   const uint32_t rq = shape.row_quads;
   const int tw = a.tw;
   int64_t* table = a.kp.groupby_buf[0];
   int32_t err = 0;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kPartBlock + threadIdx.x; i < n_ovf + n_spill;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kPartBlock + threadIdx.x; i < n_ovf + n_spill + n_seg;
        i += static_cast<uint64_t>(gridDim.x) * kPartBlock) {
-    const int64_t* q = i < n_ovf ? a.ovf + i * tw : a.slab1 + (i - n_ovf) * tw;
+    const int64_t* q;
+    if (i < n_seg) {
+      if (static_cast<uint32_t>(i % kPartSpillSeg) >= a.nspill[i / kPartSpillSeg]) {
+        continue;
+      }
+      q = a.spill_seg + i * tw;
+    } else {
+      q = i - n_seg < n_ovf ? a.ovf + (i - n_seg) * tw : a.slab1 + (i - n_seg - n_ovf) * tw;
+    }
     int64_t tup[kPartMaxTW];
 #pragma unroll
     for (int w = 0; w < kPartMaxTW; ++w) {

@@ -10,6 +10,8 @@
 //               offsets from a counting pass -- or block-private chunk claims -- would give
 //       bit 32 / 64: global cursors padded to one per 128-B / 256-B line (instead of 128 cursors in 512 bytes)
 //       bit 128: 16-byte LDS staging and copy-out (ds_write_b128 / global_store_dwordx4)
+//       bit 256: with bit 16, every sub-slab starts 64 bytes into a 128-byte line (runs aligned to 64 B only)
+//       bit 512: with bit 16, every sub-slab starts 32 bytes into a line (runs aligned to 32 B only)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
       const uint32_t n = tid < (int)a.nbins ? s_cnt[tid] : 0;
       if (ABL & 16) {
         const uint32_t c = s_cur[tid];
-        s_base[tid] = (uint32_t)(blockIdx.x * sub_cap) + (c + n <= sub_cap ? c : 0);
+        s_base[tid] = (uint32_t)(blockIdx.x * sub_cap) + (c + n <= sub_cap ? c : 0) + ((ABL & 256) ? 4 : 0) + ((ABL & 512) ? 2 : 0);
         s_cur[tid] = c + n <= sub_cap ? c + n : n;
       } else if (ABL & 1) {
         s_base[tid] = (fake + tid * 131u) % (uint32_t)(a.cap - T);
@@ -203,8 +205,11 @@ int main() {
     run_v0<4, 16 + 128>(a, g, "v0 private sub-slabs + 16-B stores");
     run_v0<4, 3>(a, g, "v0 no atomics, no copy-out");
   }
-  for (int g : {cu * 2, cu * 3, cu * 4, cu * 6}) {
+  for (int g : {cu * 3}) {
     run_v0<4, 8 + 16 + 128>(a, g, "aligned 256-B runs, private, 16-B st");
+    run_v0<4, 8 + 16 + 128 + 256>(a, g, "256-B runs at 64-B alignment");
+    run_v0<4, 8 + 16 + 128 + 512>(a, g, "256-B runs at 32-B alignment");
+    run_v0<4, 8 + 16 + 128 + 256 + 512>(a, g, "256-B runs at 96-B offset");
   }
   // exact 16-tuple runs per bin and batch (no LDS rank), private sub-slabs: every run is two aligned 128-B lines
   run_v0<4, 8 + 16>(a, cu * 3, "aligned 256-B runs, private, 8-B st");

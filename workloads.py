@@ -1,0 +1,221 @@
+"""BASELINE.json's configurations as device-resident synthetic workloads, shared by bench.py
+(`--config`) and the full-size GPU tests (tests/test_gpu_fullsize.py).
+
+  c2   1 B rows, 64 keys:  SELECT key, SUM(val) ... GROUP BY key                   (headline; perfect hash)
+  c3   1 B-row fact JOIN 10 M-row dim on int64 key:  SELECT SUM(fact.val + dim.dval)
+  c5   1 B rows, 100 M keys:  SELECT key, SUM(val) ... GROUP BY key                (open addressing, 200 M entries)
+  c5s  the shard one GPU of eight sees in C5: 125 M rows drawn from the 100 M-key domain (200 M entries)
+  q1..q4  taxi Q1-Q4 (Benchmarks/taxi/taxi_reduced_bench.cpp:51-89) over a 1 B-row table with the sample's domains
+
+Columns are generated ON THE DEVICE with torch (seed = SEED + global fragment index, so any rank regenerates any
+fragment), wrapped as the executor's resident chunks -- the same state HDK reaches once GpuBufferMgr has cached the
+chunks.  Nothing here computes query results except `reference_checks`, which uses plain torch ops on the same
+tensors as an independent cross-check of size-independent properties (sum of sums, row counts, distinct keys).
+"""
+import numpy as np
+
+SEED = 20261002
+FRAGMENT_ROWS = 32_000_000  # ArrowStorage default (omniscidb/ArrowStorage/ArrowStorage.h:40)
+
+
+class TensorChunk:
+    """A torch CUDA tensor standing in for a DeviceBuffer of the executor's chunk cache."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.ptr = tensor.data_ptr()
+        self.nbytes = tensor.numel() * tensor.element_size()
+
+    def free(self):
+        self.tensor = None
+        self.ptr = 0
+
+
+def fragment_rows(rows, fragment_size=FRAGMENT_ROWS):
+    out = []
+    while rows > 0:
+        out.append(min(fragment_size, rows))
+        rows -= out[-1]
+    return out or [0]
+
+
+CONFIGS = {
+    # name: (default rows, algorithmic bytes per row, description)
+    "c2": (1_000_000_000, 16, "C2: SELECT key, SUM(val) GROUP BY key; int64, 64 uniform keys"),
+    "c3": (1_000_000_000, 16, "C3: SELECT SUM(fact.val + dim.dval) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key"),
+    "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
+    "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
+    "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
+    "q2": (1_000_000_000, 10, "taxi Q2: SELECT passenger_count, AVG(total_amount) GROUP BY passenger_count"),
+    "q3": (1_000_000_000, 10, "taxi Q3: SELECT passenger_count, extract(year from pickup_datetime), COUNT(*) GROUP BY 1, 2"),
+    "q4": (1_000_000_000, 18, "taxi Q4: SELECT passenger_count, extract(year ...), cast(trip_distance as int), COUNT(*) GROUP BY 1, 2, 3"),
+}
+
+
+class Workload:
+    """Tables resident on `device`, the query, and what the checks need."""
+
+    def __init__(self, name, rows, device, mgr, frag_ids=None, fragment_size=FRAGMENT_ROWS, dim_rows=10_000_000,
+                 key_domain=100_000_000):
+        import torch
+        from hdk_amd.executor import Executor
+        from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
+        from hdk_amd.storage import ArrowStorage, ChunkStats, Column, Table
+        if name not in CONFIGS:
+            raise ValueError(f"unknown config {name}; one of {sorted(CONFIGS)}")
+        self.name, self.rows, self.device = name, int(rows), device
+        self.alg_bytes_per_row = CONFIGS[name][1]
+        self.description = CONFIGS[name][2]
+        self.frag_rows = fragment_rows(self.rows, fragment_size)
+        self.nfrag = len(self.frag_rows)
+        # fragments this process holds (strong scaling: fragment f -> rank f mod G)
+        self.frag_ids = list(range(self.nfrag)) if frag_ids is None else list(frag_ids)
+        self.local_rows = int(sum(self.frag_rows[f] for f in self.frag_ids))
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.storage = ArrowStorage()
+        self.ex = Executor(self.storage, device, mgr)
+        self.cols = {}  # (table, column) -> {fragment: tensor}
+        I64 = Type("int", 8, True)
+
+        def table(tname, specs, frag_rows, local):
+            """specs: {column: (Type, generator(f, n) -> tensor, (min, max))}"""
+            columns = []
+            for cname, (ctype, gen, (lo, hi)) in specs.items():
+                col = Column(cname, ctype, [None] * len(frag_rows), [ChunkStats(lo, hi, False)] * len(frag_rows))
+                columns.append(col)
+                self.cols[(tname, cname)] = {}
+                for f in local:
+                    t = gen(f, frag_rows[f])
+                    self.cols[(tname, cname)][f] = t
+                    self.ex.cache.put((tname, cname, f), TensorChunk(t))
+                    if len(frag_rows) == 1:  # (what ColumnFetcher::linearizeColumnFragments would hand out)
+                        self.ex.cache.put((tname, cname, "all"), TensorChunk(t))
+            self.storage.add_table(Table(tname, columns, frag_rows))
+
+        def uniform(lo, hi, salt, dtype=torch.int64):
+            def gen(f, n):
+                g = torch.Generator(device=self.dev)
+                g.manual_seed(SEED + 1000 * salt + f)
+                return torch.randint(lo, hi, (n,), dtype=dtype, device=self.dev, generator=g)
+            return gen
+
+        val = (I64, uniform(-2**31, 2**31, 1), (-2**31, 2**31 - 1))
+        if name == "c2":
+            table("t", {"key": (I64, uniform(0, 64, 0), (0, 63)), "val": val}, self.frag_rows, self.frag_ids)
+            self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
+            self.key_col, self.val_col = ("t", "key"), ("t", "val")
+        elif name in ("c5", "c5s"):
+            table("t", {"key": (I64, uniform(0, key_domain, 0), (0, key_domain - 1)), "val": val}, self.frag_rows,
+                  self.frag_ids)
+            self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
+            self.key_col, self.val_col = ("t", "key"), ("t", "val")
+        elif name == "c3":
+            self.dim_rows = int(dim_rows)
+
+            def dim_key(f, n):
+                g = torch.Generator(device=self.dev)
+                g.manual_seed(SEED + 7)
+                return torch.randperm(n, dtype=torch.int64, device=self.dev, generator=g)
+            table("dim", {"key": (I64, dim_key, (0, self.dim_rows - 1)),
+                          "dval": (I64, uniform(0, 10**6, 8), (0, 10**6 - 1))}, [self.dim_rows], [0])
+            # the planner decides one-to-one from the inner table's data (plan._inner_keys_unique): a permutation is unique
+            self.storage.get("dim").__dict__["_unique_keys_cache"] = {("key",): 1}
+            table("fact", {"fk": (I64, uniform(0, self.dim_rows, 2), (0, self.dim_rows - 1)), "val": val}, self.frag_rows,
+                  self.frag_ids)
+            self.query = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")],
+                                   targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"), "s")])
+        else:  # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types, the sample's value domains)
+            table("trips", {
+                "cab_type": (Type("dict", 4), uniform(0, 2, 3, torch.int32), (0, 1)),
+                "passenger_count": (Type("int", 2), uniform(0, 7, 4, torch.int16), (0, 6)),
+                "pickup_datetime": (Type("timestamp", 8, unit="s"), uniform(1230768000, 1451606400, 5), (1230768000, 1451606399)),
+                "trip_distance": (Type("decimal", 8, scale=2), uniform(0, 5000, 6), (0, 4999)),
+                "total_amount": (Type("decimal", 8, scale=2), uniform(0, 20000, 9), (0, 19999)),
+            }, self.frag_rows, self.frag_ids)
+            self.storage.get("trips").columns["cab_type"].dictionary = ["green", "yellow"]
+            pc, ts = ColRef("passenger_count"), ColRef("pickup_datetime")
+            self.query = {
+                "q1": QueryUnit("trips", groupby=[ColRef("cab_type")], targets=[KeyRef(0, "cab_type"), Agg("count", None, "cnt")]),
+                "q2": QueryUnit("trips", groupby=[pc], targets=[KeyRef(0, "passenger_count"),
+                                                             Agg("avg", ColRef("total_amount"), "avg_amount")]),
+                "q3": QueryUnit("trips", groupby=[pc, ExtractYear(ts)],
+                                targets=[KeyRef(0, "passenger_count"), KeyRef(1, "year"), Agg("count", None, "cnt")]),
+                "q4": QueryUnit("trips", groupby=[pc, ExtractYear(ts), Cast(ColRef("trip_distance"), INT32)],
+                                targets=[KeyRef(0, "passenger_count"), KeyRef(1, "year"), KeyRef(2, "distance"),
+                                         Agg("count", None, "cnt")]),
+            }[name]
+        torch.cuda.synchronize(self.dev)
+        self.compiled = self.ex.compile(self.query)
+
+    # ---- host copies (for the oracle, on a bounded sample) ------------------------------------------------------
+    def host_fragment(self, table, f):
+        """numpy copies of one fragment's columns, attached to the storage so that the oracle can read them."""
+        t = self.storage.get(table)
+        for cname in t.column_order:
+            if t.columns[cname].fragments[f] is None:
+                t.columns[cname].fragments[f] = self.cols[(table, cname)][f].cpu().numpy()
+        return {c: t.columns[c].fragments[f] for c in t.column_order}
+
+    def sample_storage(self, rows=2_000_000):
+        """The first `rows` rows of the outer table's first local fragment (and the whole inner table) as a small
+        host-resident storage: the oracle runs the same query on it, the device result must match it bit for bit."""
+        from hdk_amd.storage import ArrowStorage
+        st = ArrowStorage()
+        outer = self.query.table
+        f0 = self.frag_ids[0]
+        t = self.storage.get(outer)
+        n = min(rows, t.frag_rows[f0])
+        cols = {c: self.cols[(outer, c)][f0][:n].cpu().numpy() for c in t.column_order}
+        st.import_numpy(outer, cols, fragment_size=max(n // 4, 1), types={c: t.columns[c].type for c in t.column_order})
+        for c in t.column_order:
+            st.get(outer).columns[c].dictionary = t.columns[c].dictionary
+        for j in getattr(self.query, "joins", []):
+            it = self.storage.get(j.inner_table)
+            icols = {c: self.cols[(j.inner_table, c)][0].cpu().numpy() for c in it.column_order}
+            st.import_numpy(j.inner_table, icols, types={c: it.columns[c].type for c in it.column_order})
+        return st
+
+    # ---- independent properties computed with plain torch on the same tensors -----------------------------------
+    def reference_checks(self):
+        """Size-independent facts about the LOCAL rows, from torch ops only (wrap-around int64 like the engine):
+        c2/c5: sum of val, number of distinct keys; c3: SUM(val + dval[fk]); taxi: per-group counts of Q1/Q2 keys."""
+        torch = self.torch
+        out = {"rows": self.local_rows}
+        if self.name in ("c2", "c5", "c5s"):
+            total = 0
+            for f in self.frag_ids:
+                total = (total + int(self.cols[self.val_col][f].sum().item())) % (1 << 64)
+            out["sum_val"] = total
+        elif self.name == "c3":
+            key = self.cols[("dim", "key")][0]
+            dval = self.cols[("dim", "dval")][0]
+            by_key = torch.empty_like(dval)
+            by_key[key] = dval  # dval of the dim row whose key is k
+            total = 0
+            for f in self.frag_ids:
+                fk, v = self.cols[("fact", "fk")][f], self.cols[("fact", "val")][f]
+                total = (total + int((v + by_key[fk]).sum().item())) % (1 << 64)
+            out["sum_val_plus_dval"] = total
+        else:
+            kcol = "cab_type" if self.name == "q1" else "passenger_count"
+            counts = None
+            for f in self.frag_ids:
+                c = torch.bincount(self.cols[("trips", kcol)][f].to(torch.int64), minlength=8)
+                counts = c if counts is None else counts + c
+            out["key_counts"] = [int(x) for x in counts.cpu().tolist()]
+            if self.name == "q2":
+                sums = torch.zeros(8, dtype=torch.int64, device=self.dev)
+                for f in self.frag_ids:
+                    sums.index_add_(0, self.cols[("trips", "passenger_count")][f].to(torch.int64),
+                                    self.cols[("trips", "total_amount")][f])
+                out["key_sums"] = [int(x) for x in sums.cpu().tolist()]
+        return out
+
+    def distinct_keys(self):
+        """Number of distinct group keys over the local rows (c2 / c5): torch.unique on the concatenated key column."""
+        torch = self.torch
+        keys = torch.cat([self.cols[self.key_col][f] for f in self.frag_ids])
+        n = int(torch.unique(keys).numel())
+        del keys
+        return n
