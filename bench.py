@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric: rows/sec on a 1 B-row, 64-key int64
-`SELECT key, SUM(val) FROM t GROUP BY key` (config C2), plus % of the HBM roofline and the
+`SELECT key, SUM(val) FROM t GROUP BY key` (config C2) at 1/2/4/8 GPUs, plus % of the HBM roofline and the
 HDK-semantics CPU path timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5|c5s|q1..q4] [--scaling strong|weak]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over the rank's resident fragments: output-buffer init, the
-multi-fragment scan/aggregate launch, finalize and -- for N > 1 -- the partial-aggregate merge
-(RCCL all-gather of the per-GPU tables over xGMI + the device reduction kernel).  Inputs are
-resident in HBM before the timed region (as HDK keeps chunks cached in GpuBufferMgr).
+A step = one pass of the hot path over the rank's resident fragments: output-buffer init, the multi-fragment
+scan/aggregate launch (every pass of it), finalize and -- for N > 1 -- the partial-aggregate merge over RCCL/xGMI:
+all-gather of the per-GPU tables + device fold (perfect hash / non-grouped), or owner partition + all-to-all +
+owner re-insert (open addressing, C5).  Inputs are resident in HBM before the timed region (as HDK keeps chunks
+cached in GpuBufferMgr).
 
-Scaling is WEAK: every rank holds its own 1 B-row table (32 fragments x 32 M rows, regenerated
-from per-fragment seeds), value = rows all ranks processed / max-over-ranks time.
+Scaling: STRONG by default -- ONE table of `--rows` rows in 32 M-row fragments, fragment f on rank
+f mod N, value = table rows / max-over-ranks step time.  `--scaling weak` gives every rank its own table.
+At N = 1 the line also carries, under "configs", the other BASELINE configurations at BASELINE size (C3 join probe,
+C5 open addressing and its per-GPU shard shape, taxi Q1-Q4), each with its own roofline object.
 """
 import argparse
 import ctypes as C
@@ -20,7 +23,6 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -28,18 +30,355 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SEED = 20261002
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-ALG_BYTES_PER_ROW = 16  # key 8 B + val 8 B
 
 
-def gen_fragment(seed_idx, rows, nkeys, null_frac):
-    rng = np.random.Generator(np.random.PCG64(SEED + seed_idx))
-    key = rng.integers(0, nkeys, rows, dtype=np.int64)
-    val = rng.integers(-2**31, 2**31, rows, dtype=np.int64)
-    if null_frac > 0:
-        val[rng.random(rows) < null_frac] = -(2**63)
-    return key, val
+class Comm:
+    """torch.distributed with a host-staged test mode (HDK_BENCH_BACKEND=gloo) for boxes with fewer GPUs than ranks."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        self.backend = os.environ.get("HDK_BENCH_BACKEND", "nccl")
+        self.dev = self.local_rank if self.backend == "nccl" else self.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev))
+            else:
+                dist.init_process_group(self.backend)
+        self.group = None if self.backend == "nccl" else "host"
+
+    def all_gather(self, dst, src):
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(dst, src)
+        else:
+            parts = [self.torch.empty(src.numel(), dtype=src.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, src.cpu())
+            dst.copy_(self.torch.cat(parts))
+
+    def all_reduce(self, t, op="sum"):
+        if self.world == 1:
+            return t
+        o = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=o)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=o)
+            t.copy_(h)
+        return t
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def c2_numpy_generator(torch, dev, frag_offset=0):
+    """C2's inputs as BASELINE.md section 2 fixes them: numpy PCG64(SEED + global fragment index) per fragment."""
+    from workloads import SEED
+
+    def gen(col):
+        def g(f, n):
+            rng = np.random.Generator(np.random.PCG64(SEED + frag_offset + f))
+            key = rng.integers(0, 64, n, dtype=np.int64)
+            if col == "key":
+                return torch.from_numpy(key).to(dev)
+            return torch.from_numpy(rng.integers(-2**31, 2**31, n, dtype=np.int64)).to(dev)
+        return g
+    return gen
+
+
+def run_config(name, args, comm, mgr, steps, warmup, primary):
+    """Build the workload, time `steps` steps, check the result at full size.  Returns the dict of one bench line."""
+    import torch
+    from hdk_amd import _abi as A
+    from hdk_amd._lib import check, lib
+    from hdk_amd import distributed as D
+    from hdk_amd.executor import ExecutionResult
+    from workloads import CONFIGS, Workload
+    L = lib()
+    world, rank, dev = comm.world, comm.rank, comm.dev
+    rows = int(args.rows) if (args.rows and primary) else CONFIGS[name][0]
+    strong = args.scaling == "strong"
+    nfrag_total = len(__import__("workloads").fragment_rows(rows))
+    frag_ids = D.shard_fragments(nfrag_total, world, rank) if (strong and world > 1) else None
+    t_gen = time.perf_counter()
+    w = Workload(name, rows, dev, mgr, frag_ids=frag_ids, seed_offset=0 if strong else rank * 100_003,
+                 generators=c2_numpy_generator(torch, torch.device("cuda", dev), 0 if strong else rank * nfrag_total)
+                 if name == "c2" else None)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    cp = w.compiled
+    quads = max(cp.buffer_quads, 1)
+    baseline = cp.plan.query_kind == A.Q_BASELINE_HASH
+
+    # One explicit (non-default) stream carries everything: the library treats a NULL stream as "my own stream", which
+    # would not be ordered with torch's default stream and hence with the RCCL collectives.
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
+    out_t = torch.empty(quads, dtype=torch.int64, device="cuda")
+    step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS,
+                        out_ptr=out_t.data_ptr())
+    gathered = torch.empty(world * quads, dtype=torch.int64, device="cuda") if (world > 1 and not baseline) else None
+    d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    init_vals = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
+    merge_ms, owner = [], {}
+
+    def _one_step():
+        step.init_output(stream)
+        step.launch(stream)
+        if world == 1:
+            return
+        if not baseline:
+            # ResultSetReduction over the per-GPU partial tables: all-gather (1.5 KB each for C2) + device fold
+            comm.all_gather(gathered, out_t)
+            that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
+            counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
+            check(L.hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
+                                           world - 1, init_vals.ctypes.data, d_err.data_ptr(), dev, stream))
+        else:
+            # open addressing: entries to their owner rank (one all-to-all over xGMI), owners re-insert
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(tstream)
+            send, counts = D.partition_baseline_on_device(cp, out_t, world, dev, stream)
+            if comm.backend == "nccl":
+                recv, rc = D.exchange_owner_segments(cp, send, counts, world, rank)
+            else:
+                r_h, rc = D.exchange_owner_segments(cp, send.cpu(), counts, world, rank)
+                recv = r_h.to("cuda")
+            owner["table"], owner["entries"] = D.merge_baseline_on_device(cp, recv, rc, dev, None, stream)
+            e1.record(tstream)
+            owner["sent_bytes"] = int(sum(D.baseline_table_quads(cp, int(c)) for i, c in enumerate(counts) if i != rank)) * 8
+            owner["events"] = (e0, e1)
+
+    def one_step():
+        with torch.cuda.stream(tstream):
+            _one_step()
+        if world > 1 and baseline:
+            torch.cuda.synchronize()
+            merge_ms.append(owner["events"][0].elapsed_time(owner["events"][1]))
+
+    for _ in range(warmup):
+        one_step()
+    comm.barrier()
+    n_ev = C.c_int32(0)
+    check(L.hdk_hip_collect_scan_times(dev, None, 0, C.byref(n_ev)))  # drop warm-up events
+    merge_ms.clear()
+
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        comm.dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    elapsed = float(comm.all_reduce(tt, "max").item())
+
+    ms_buf = (C.c_float * max(steps, 1))()
+    check(L.hdk_hip_collect_scan_times(dev, ms_buf, steps, C.byref(n_ev)))
+    scan_ms = [ms_buf[i] for i in range(min(n_ev.value, steps))]
+    avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
+
+    # ---- correctness at full size: size-independent properties (every rank takes part in the collectives) ----------
+    checks = {}
+    ref = w.reference_checks()
+    if name in ("c2", "c5", "c5s"):
+        if baseline:
+            tbl = owner["table"] if world > 1 else out_t
+            n_e = owner["entries"] if world > 1 else cp.entry_count
+            k, s = _baseline_groups(torch, cp, tbl, n_e)
+            mine = torch.tensor([int(s.sum().item()), int(k.numel()), ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64,
+                                 w.local_rows], dtype=torch.int64, device="cuda")
+            comm.all_reduce(mine)
+            got_sum, groups, want_sum, all_rows = (int(x) for x in mine.cpu().tolist())
+            checks["sum_of_sums"] = bool((got_sum - want_sum) % (1 << 64) == 0)
+            checks["groups"] = groups
+            if world == 1:
+                checks["groups_equal_distinct_keys"] = bool(groups == w.distinct_keys())
+            first = (k.clone(), s.clone())
+            one_step()
+            torch.cuda.synchronize()
+            tbl = owner["table"] if world > 1 else out_t
+            k2, s2 = _baseline_groups(torch, cp, tbl, n_e)
+            checks["idempotent"] = bool(torch.equal(first[0], k2) and torch.equal(first[1], s2))
+        else:
+            final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+            cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
+            mine = torch.tensor([ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64, w.local_rows],
+                                dtype=torch.int64, device="cuda")
+            comm.all_reduce(mine)
+            want_sum, all_rows = (int(x) for x in mine.cpu().tolist())
+            checks["sum_of_sums"] = bool((sum(v for v in cols["s"] if v is not None) - want_sum) % (1 << 64) == 0)
+            checks["groups"] = len(cols["key"])
+            one_step()
+            torch.cuda.synchronize()
+            again = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+            checks["idempotent"] = bool(np.array_equal(again, final))
+        checks["row_count"] = bool(all_rows == (rows if strong else rows * world))
+    elif name == "c3":
+        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        want = ref["sum_val_plus_dval"]
+        mine = torch.tensor([want if want < 2**63 else want - 2**64], dtype=torch.int64, device="cuda")
+        comm.all_reduce(mine)
+        checks["sum_equals_torch_gather_sum"] = bool((int(final[0]) - int(mine.item())) % (1 << 64) == 0)
+    else:
+        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
+        mine = torch.tensor(ref["key_counts"] + [w.local_rows], dtype=torch.int64, device="cuda")
+        comm.all_reduce(mine)
+        kc = [int(x) for x in mine.cpu().tolist()]
+        checks["counts_add_up"] = bool(name == "q2" or sum(cols["cnt"]) == kc[-1])
+        keyname = "cab_type" if name == "q1" else "passenger_count"
+        per = {}
+        for i, k in enumerate(cols[keyname]):
+            kk = {"green": 0, "yellow": 1}.get(k, k)
+            per[kk] = per.get(kk, 0) + (cols["cnt"][i] if "cnt" in cols else 0)
+        checks["groups"] = len(cols[keyname])
+        if name != "q2":
+            checks["per_key_counts_equal_torch_bincount"] = bool([per.get(i, 0) for i in range(8)] == kc[:8])
+
+    # ---- bit-exact parity with the oracle on a sample of the same data (rank 0) ------------------------------------
+    if rank == 0 and not args.no_oracle_sample:
+        from oracle import oracle as O
+        from hdk_amd.executor import Executor
+        from util import assert_buffers_equal, run_oracle
+        st = w.sample_storage(2_000_000)
+        scp, want_buf, err = run_oracle(O, st, w.query)
+        res = Executor(st, dev, mgr).execute(scp, flags=A.LAUNCH_FORCE_PARTITIONED if baseline else 0)
+        try:
+            if baseline:
+                from test_gpu_baseline import _check_rows
+                _check_rows(scp, res.buffer, want_buf)
+            else:
+                assert_buffers_equal(scp, res.buffer, want_buf)
+            checks["oracle_bit_exact_on_sample"] = err == 0
+        except AssertionError:
+            checks["oracle_bit_exact_on_sample"] = False
+
+    total_rows = rows if strong else rows * world
+    value = total_rows * steps / elapsed
+    achieved = w.local_rows * w.alg_bytes_per_row / (avg_scan_ms * 1e-3) / 1e9 if scan_ms else None
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", f"r02_{name}_pmc.json")
+    if os.path.exists(pmc_path) and rows == CONFIGS[name][0] and world == 1:
+        with open(pmc_path) as fpmc:
+            traffic = json.load(fpmc).get("traffic_bytes_per_launch")
+    kernels = step.kernel_names()
+    out = {
+        "metric": "rows/sec, 1B-row int64 GROUP BY SUM" if name == "c2" else f"rows/sec, {name}",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": w.description, "rows": rows, "rows_per_gpu": w.local_rows,
+                   "fragments": nfrag_total, "fragments_per_gpu": len(w.frag_ids), "fragment_rows": 32_000_000,
+                   "layout": ("open addressing" if baseline else "perfect hash" if cp.plan.key_count else "non-grouped") +
+                             (", keyless" if cp.plan.keyless else "") + f", {cp.entry_count} entries",
+                   "parallelism": (f"fragment f -> GPU f mod {world}; " if strong else f"one table per GPU x {world}; ") +
+                                  ("owner partition + all-to-all + owner re-insert" if baseline
+                                   else "all-gather of the partial tables + device fold")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "kernel": kernels if baseline else kernels.split(",")[0], "avg_kernel_ms": avg_scan_ms,
+                     "alg_bytes_per_row": w.alg_bytes_per_row,
+                     "note": "per GPU: this rank's rows x algorithmic bytes / mean HIP-event time of the scan launch "
+                             "(all of its passes)"},
+        "checks": checks,
+        "setup_s": {"generate": t_gen},
+    }
+    if world > 1 and baseline and merge_ms:
+        out["merge"] = {"ms": float(np.mean(merge_ms)), "bytes_sent_over_xgmi_per_gpu": owner.get("sent_bytes"),
+                        "what": "owner partition + all_to_all_single + owner re-insert, HIP events on the step's stream"}
+    step.free()
+    return out, w
+
+
+def _baseline_groups(torch, cp, table, entry_count):
+    from hdk_amd import _abi as A
+    p = cp.plan
+    rq, n = int(p.row_size_quad), int(entry_count)
+    rows = table[:n * rq].view(n, rq)
+    if p.key_width == 4:
+        keys = (rows[:, 0] << 32) >> 32
+        live = keys != A.EMPTY_KEY_32
+    else:
+        keys = rows[:, 0]
+        live = keys != A.EMPTY_KEY_64
+    sq = int(p.targets[1].slot_off) // 8
+    k, s = keys[live], rows[:, sq][live]
+    order = torch.argsort(k)
+    return k[order], s[order]
+
+
+def cpu_baseline(w, args):
+    """The oracle's HDK-semantics CPU path on the host cores, kernel per fragment + reduction
+    (QE/Execute.cpp:2776-2788, :1290-1317), on every fragment of the table, median of 5; plus the sub-task variant
+    (QE/ExecutionKernel.cpp:341-358: fragments cut into sub-ranges so that every core has work)."""
+    from oracle import oracle as O
+    from util import oracle_init_buffer
+    cp = w.compiled
+    nproc = os.cpu_count() or 1
+    sample = w.frag_ids[:args.cpu_sample_frags] if args.cpu_sample_frags else w.frag_ids
+    frags = []
+    for f in sample:
+        h = w.host_fragment(w.query.table, f)
+        frags.append([h["key"], h["val"]])
+    rows = [w.frag_rows[f] for f in sample]
+    srows = int(sum(rows))
+    init_buf = oracle_init_buffer(O, cp)
+
+    def timed(fr, nr, threads):
+        hf = O.HostFragments(fr, nr)
+        times = []
+        for _ in range(5):
+            tc = time.perf_counter()
+            err, _ = O.run_plan_parallel(cp.plan, hf, init_buf, cp.init_vals, threads)
+            times.append(time.perf_counter() - tc)
+            assert err == 0
+        return srows / float(np.median(times))
+
+    threads = int(min(nproc, len(sample), O.lib().orc_max_threads()))
+    per_fragment = timed(frags, rows, threads)
+    variants = {"kernel_per_fragment": {"rows_per_s": per_fragment, "threads": threads}}
+    pieces = max(1, -(-nproc // len(sample)))
+    if pieces > 1:
+        sub, subrows = [], []
+        for cols, n in zip(frags, rows):
+            cut = [n * i // pieces for i in range(pieces + 1)]
+            for a, b in zip(cut[:-1], cut[1:]):
+                sub.append([c[a:b] for c in cols])
+                subrows.append(b - a)
+        t_all = int(min(nproc, O.lib().orc_max_threads()))
+        variants["sub_tasks_all_cores"] = {"rows_per_s": timed(sub, subrows, t_all), "threads": t_all}
+    best = max(variants.values(), key=lambda v: v["rows_per_s"])
+    return {"value": best["rows_per_s"], "unit": "rows/s", "cores": best["threads"], "host_cores": nproc, "kind": "port",
+            "sample": f"{len(sample)} of {w.nfrag} fragments = {srows} rows of the same table; oracle row function, one kernel "
+                      f"per fragment (or per sub-range) on OpenMP threads + reduction of the partials; median of 5",
+            "variants": variants}
 
 
 def main():
@@ -47,273 +386,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
-    ap.add_argument("--fragment-size", type=int, default=32_000_000)
-    ap.add_argument("--keys", type=int, default=64)
-    ap.add_argument("--null-frac", type=float, default=0.0)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--rows", type=int, default=0, help="rows of the table (default: the config's BASELINE size)")
     ap.add_argument("--grid", type=int, default=0)
-    ap.add_argument("--cpu-sample-frags", type=int, default=8)
+    ap.add_argument("--extra", default="auto", help="other configs to report under 'configs' (auto: all at N=1, none otherwise)")
+    ap.add_argument("--cpu-sample-frags", type=int, default=0, help="fragments the CPU baseline runs on (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-sample", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-    import torch
-    import torch.distributed as dist
-
-    from hdk_amd import _abi as A
+    comm = Comm(args)
     from hdk_amd._lib import check, lib
-    from hdk_amd.executor import Executor
     from hdk_amd.hip_mgr import HipMgr
-    from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
-    from hdk_amd.storage import ArrowStorage, ChunkStats, Column, Table
-    from hdk_amd.ir import Type
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # HDK_BENCH_BACKEND=gloo is a TEST mode for boxes with fewer GPUs than ranks (ranks share devices, the
-    # collectives are staged through host memory): it exercises the N>1 control flow, not xGMI.
-    backend = os.environ.get("HDK_BENCH_BACKEND", "nccl")
-    dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend)
-
-    def all_gather_tables(dst, src):
-        if backend == "nccl":
-            dist.all_gather_into_tensor(dst, src)
-        else:
-            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
-            dist.all_gather(parts, src.cpu())
-            dst.copy_(torch.cat(parts))
-
-    def all_reduce_sum(t):
-        if backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-
-    def all_reduce_max(t):
-        if backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX)
-            t.copy_(h)
     mgr = HipMgr()
-    L = lib()
-
-    # ---- synthetic data: per-fragment seeds, generated on the host, made resident in HBM ----------
-    frag_rows = []
-    r = args.rows
-    while r > 0:
-        frag_rows.append(min(args.fragment_size, r))
-        r -= frag_rows[-1]
-    nfrag = len(frag_rows)
-    keep_host = 0 if (args.no_cpu_baseline or rank != 0) else min(args.cpu_sample_frags, nfrag)
-    t_gen = time.perf_counter()
-    st = ArrowStorage()
-    ex = Executor(st, dev, mgr)
-    ktype, vtype = Type("int", 8, True), Type("int", 8, True)
-    kcol = Column("key", ktype, [None] * nfrag, [None] * nfrag)
-    vcol = Column("val", vtype, [None] * nfrag, [None] * nfrag)
-    table = Table("t", [kcol, vcol], frag_rows)
-    st.add_table(table)
-
-    def produce(f):
-        return f, gen_fragment(rank * nfrag + f, frag_rows[f], args.keys, args.null_frac)
-
-    host_frags = {}
-    t_upload = 0.0
-    # Fragments are generated on the host a few at a time: pool.map submits everything it is given at once, and
-    # 32 fragments x 512 MB per rank, times 8 ranks on one node, is more host memory than the job needs to hold.
-    in_flight = 4 if world > 1 else 8
-    with ThreadPoolExecutor(max_workers=min(in_flight, os.cpu_count() or 1)) as pool:
-        for f0 in range(0, nfrag, in_flight):
-            for f, (key, val) in pool.map(produce, range(f0, min(f0 + in_flight, nfrag))):
-                has_null = bool(args.null_frac > 0 and (val == -(2**63)).any())
-                vv = val[val != -(2**63)] if has_null else val
-                kcol.stats[f] = ChunkStats(int(key.min()), int(key.max()), False)
-                vcol.stats[f] = ChunkStats(int(vv.min()), int(vv.max()), has_null)
-                # device-resident chunk (DataMgr GPU_LEVEL cache); the host copy is dropped unless sampled
-                tu = time.perf_counter()
-                ex.cache.put(("t", "key", f), mgr.to_device(key, dev))
-                ex.cache.put(("t", "val", f), mgr.to_device(val, dev))
-                t_upload += time.perf_counter() - tu
-                if f < keep_host:
-                    host_frags[f] = (key, val)
-                    kcol.fragments[f], vcol.fragments[f] = key, val
-    t_gen = time.perf_counter() - t_gen
-
-    q = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "sum_val")])
-    cp = ex.compile(q)
-    quads = cp.buffer_quads
-
-    # One explicit (non-default) stream carries everything: the library treats a NULL stream as "my own
-    # stream", which would not be ordered with torch's default stream and hence with the RCCL collective.
-    tstream = torch.cuda.Stream(device=dev)
-    stream = tstream.cuda_stream
-    assert stream != 0
-    out_t = torch.empty(max(quads, 1), dtype=torch.int64, device="cuda")
-    step = ex.prepare(cp, list(range(nfrag)), grid=args.grid, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
-    gathered = torch.empty(world * max(quads, 1), dtype=torch.int64, device="cuda") if world > 1 else None
-    d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
-    init_vals = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
-
-    def one_step():
-        with torch.cuda.stream(tstream):
-            _one_step()
-
-    def _one_step():
-        step.init_output(stream)
-        step.launch(stream)
-        if world > 1:
-            # ResultSetReduction over the per-GPU partial tables: all-gather (1.5 KB each) + device merge
-            all_gather_tables(gathered, out_t)
-            that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
-            counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
-            check(L.hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
-                                           world - 1, init_vals.ctypes.data, d_err.data_ptr(), dev, stream))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    n_ev = C.c_int32(0)
-    check(L.hdk_hip_collect_scan_times(dev, None, 0, C.byref(n_ev)))  # drop warm-up events
-
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        all_reduce_max(tt)
-        elapsed = float(tt.item())
-
-    ms_buf = (C.c_float * max(args.steps, 1))()
-    check(L.hdk_hip_collect_scan_times(dev, ms_buf, args.steps, C.byref(n_ev)))
-    scan_ms = [ms_buf[i] for i in range(min(n_ev.value, args.steps))]
-    avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
-
-    # ---- correctness at full size ---------------------------------------------------------------------
-    final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
-    from hdk_amd.executor import ExecutionResult
-    res = ExecutionResult(cp, final, cp.entry_count)
-    cols = res.to_columns()
-    if os.environ.get("HDK_BENCH_DEBUG"):
-        print(f"[rank {rank}] final[:6]={final[:6].tolist()} out_t[:6]={out_t[:6].cpu().numpy().tolist()} "
-              f"err={int(d_err.item())} quads={quads} keyless={cp.plan.keyless} final.dtype={final.dtype} "
-              f"cols={ {k: v[:3] for k, v in cols.items()} }", file=sys.stderr)
-    checks = {}
-    # (1) size-independent property: sum of per-key sums == non-grouped SUM(val) over every rank's rows, and
-    # the row counts add up.  Every rank scans its own rows once more (non-grouped), the totals are combined
-    # with one all-reduce (two's-complement wrap-around is the same on both sides).
-    q2 = QueryUnit("t", targets=[Agg("sum", ColRef("val"), "s"), Agg("count", None, "c")])
-    tot = ex.execute(q2, frag_ids=list(range(nfrag))).to_columns()
-    local_tot = torch.tensor([np.int64(np.uint64(int(tot["s"][0] or 0) % (1 << 64))), int(tot["c"][0])],
-                             dtype=torch.int64, device="cuda")
-    if world > 1:
-        all_reduce_sum(local_tot)
-    all_sum, all_cnt = (int(x) for x in local_tot.cpu().tolist())
-    # (2) idempotence: one more step (all ranks: it contains the collective) gives the identical buffer
-    one_step()
-    torch.cuda.synchronize()
-    again = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
-    if rank == 0:
-        key_sum = sum(v for v in cols["sum_val"] if v is not None)
-        checks["sum_of_sums"] = bool((key_sum - all_sum) % (1 << 64) == 0)
-        checks["row_count"] = bool(all_cnt == args.rows * world)
-        checks["groups"] = len(cols["key"])
-        checks["idempotent"] = bool(np.array_equal(again, final))
-
-    # ---- CPU baseline (rank 0, N = 1 only): the oracle's HDK-semantics path on a bounded sample -----
-    cpu = None
-    if rank == 0 and world == 1 and keep_host > 0:
-        from oracle import oracle as O
-        from util import oracle_init_buffer
-        sample = list(range(keep_host))
-        frags = [[host_frags[f][0], host_frags[f][1]] for f in sample]
-        hf = O.HostFragments(frags, [frag_rows[f] for f in sample])
-        threads = int(min(O.lib().orc_max_threads(), len(sample)))
-        init_buf = oracle_init_buffer(O, cp)
-        times = []
-        cbuf = None
-        for _ in range(3):
-            tc = time.perf_counter()
-            err, cbuf = O.run_plan_parallel(cp.plan, hf, init_buf, cp.init_vals, threads)
-            times.append(time.perf_counter() - tc)
-            assert err == 0
-        srows = sum(frag_rows[f] for f in sample)
-        cpu = {"value": srows / float(np.median(times)), "unit": "rows/s", "cores": threads, "kind": "port",
-               "sample": f"{len(sample)} fragments = {srows} rows of the same workload, kernel-per-fragment on "
-                         f"{threads} OpenMP threads + reduction, median of 3"}
-        # (3) bit-exact parity of the HIP path with the oracle on the same sample
-        gres = ex.execute(cp, frag_ids=sample)
-        checks["oracle_bit_exact_on_sample"] = bool(np.array_equal(gres.buffer, cbuf[:quads]))
-
-    if rank == 0:
-        total_rows = args.rows * world
-        value = total_rows * args.steps / elapsed
-        achieved = args.rows * ALG_BYTES_PER_ROW / (avg_scan_ms * 1e-3) / 1e9 if scan_ms else None
-        # HBM traffic per launch from the committed PMC passes of this same workload (profiles/), taken
-        # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs and corrected as the guide says
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-        if os.path.exists(pmc_path) and args.rows == 1_000_000_000 and args.keys == 64 and args.null_frac == 0:
-            with open(pmc_path) as fpmc:
-                traffic = json.load(fpmc).get("traffic_bytes_per_launch")
-        out = {
-            "metric": "rows/sec, 1B-row int64 GROUP BY SUM",
-            "value": value,
-            "unit": "rows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int64",
-            "data": "synthetic",
-            "config": {"workload": "C2: SELECT key, SUM(val) GROUP BY key; int64, uniform keys",
-                       "rows_per_gpu": args.rows, "keys": args.keys, "fragments_per_gpu": nfrag,
-                       "fragment_rows": args.fragment_size, "null_frac": args.null_frac,
-                       "layout": "perfect hash, %s, %d entries" % ("keyless" if cp.plan.keyless else "keyed",
-                                                                   cp.entry_count),
-                       "parallelism": f"fragments sharded over {world} GPU(s), all-gather + device reduce"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "kernel": step.kernel_names().split(",")[0], "avg_kernel_ms": avg_scan_ms,
-                         "alg_bytes_per_row": ALG_BYTES_PER_ROW},
-            "cpu_baseline": cpu,
-            "checks": checks,
-            "setup_s": {"generate_and_upload": t_gen, "upload_h2d": t_upload},
-            "pcie_inclusive": {"note": "informational: one cold pass incl. pageable-host -> HBM upload of the 16 B/row inputs",
-                               "h2d_GBps": args.rows * ALG_BYTES_PER_ROW / t_upload / 1e9 if t_upload else None,
-                               "rows_per_s": args.rows / (t_upload + elapsed / args.steps) if t_upload else None},
-        }
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    line, w = run_config(args.config, args, comm, mgr, args.steps, args.warmup, primary=True)
+    if comm.rank == 0:
+        copy_gbps, read_gbps = C.c_double(0), C.c_double(0)
+        check(lib().hdk_hip_mgr_measure_hbm(comm.dev, 4 << 30, 3, C.byref(copy_gbps), C.byref(read_gbps)))
+        line["roofline"]["peak_measured"] = {"read_GBps": read_gbps.value, "copy_GBps": copy_gbps.value,
+                                             "what": "16 B/lane streaming read / copy (read + written bytes) of 4 GiB, best of 3"}
+        if line["roofline"]["achieved"]:
+            line["roofline"]["frac_of_measured_read"] = line["roofline"]["achieved"] / read_gbps.value
+    if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline and args.config == "c2":
+        line["cpu_baseline"] = cpu_baseline(w, args)
+    else:
+        line["cpu_baseline"] = None
+    del w
+    extra = args.extra
+    if extra == "auto":
+        extra = "c3,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
+    configs = []
+    for name in [x for x in extra.split(",") if x]:
+        import gc
+        import torch
+        gc.collect()
+        torch.cuda.empty_cache()
+        o, ww = run_config(name, args, comm, mgr, min(args.steps, 5), min(args.warmup, 2), primary=False)
+        del ww
+        configs.append({k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "checks")})
+    if configs:
+        line["configs"] = configs
+    if comm.rank == 0:
+        print(json.dumps(line))
+    comm.close()
 
 
 if __name__ == "__main__":

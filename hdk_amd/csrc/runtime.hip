@@ -4,6 +4,7 @@
 // two implementations are CudaMgr (omniscidb/CudaMgr/CudaMgr.h:83-260, CUDA driver API) and
 // L0Manager.  One HIP-runtime function per virtual, exported through the C ABI so that a
 // `class HipMgr : public GpuMgr` in HDK is a list of one-line forwards.
+#include <algorithm>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -306,6 +307,82 @@ int32_t hdk_hip_mgr_get_device_properties(int32_t device_num, hdk_hip_device_pro
     return HDK_HIP_ERR_RUNTIME;
   }
   *out = *p;
+  return HDK_HIP_OK;
+}
+
+// ---- HBM calibration (measurement helper): what a plain streaming kernel reaches on THIS device -------------------
+// SURVEY.md 8(d) asks for the measured peak next to the nominal one.  16 bytes per lane per load, 8 loads in flight,
+// persistent grid -- the access shape of the scan kernels.
+}  // extern "C"
+namespace {
+typedef float __attribute__((ext_vector_type(4))) cal_f4;
+__global__ __launch_bounds__(256) void k_cal_copy(const cal_f4* __restrict__ src, cal_f4* __restrict__ dst, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  }
+}
+__global__ __launch_bounds__(256) void k_cal_read(const cal_f4* __restrict__ src, float* sink, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+  cal_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const cal_f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc += a + b + c + d;
+  }
+  for (; i < n; i += stride) {
+    acc += __builtin_nontemporal_load(src + i);
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) {
+    *sink = acc.x;
+  }
+}
+}  // namespace
+extern "C" {
+
+int32_t hdk_hip_mgr_measure_hbm(int32_t device_num, size_t bytes, int32_t reps, double* copy_gbps, double* read_gbps) {
+  HDK_REQUIRE(copy_gbps && read_gbps && reps > 0 && bytes >= (1u << 20), "bad arguments");
+  hipStream_t s;
+  const int32_t st = device_enter(device_num, nullptr, &s);
+  if (st) return st;
+  const hdk_hip_device_properties* props = device_props(device_num);
+  const size_t n = bytes / 16;
+  void *a = nullptr, *b = nullptr;
+  HDK_HIP_CHECK(hipMalloc(&a, n * 16));
+  if (hipMalloc(&b, n * 16) != hipSuccess) {
+    (void)hipFree(a);
+    set_error("hipMalloc failed for the calibration buffers");
+    return HDK_HIP_ERR_OUT_OF_GPU_MEM;
+  }
+  HDK_HIP_CHECK(hipMemsetAsync(a, 1, n * 16, s));
+  HDK_HIP_CHECK(hipMemsetAsync(b, 0, n * 16, s));
+  hipEvent_t e0, e1;
+  HDK_HIP_CHECK(hipEventCreate(&e0));
+  HDK_HIP_CHECK(hipEventCreate(&e1));
+  const unsigned grid = static_cast<unsigned>(props->num_cu) * 8;
+  float ms = 0.f;
+  double best_copy = 0, best_read = 0;
+  for (int r = 0; r < reps + 1; ++r) {  // (first round warms up)
+    HDK_HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_cal_copy, dim3(grid), dim3(256), 0, s, static_cast<const cal_f4*>(a), static_cast<cal_f4*>(b), n);
+    HDK_HIP_CHECK(hipEventRecord(e1, s));
+    HDK_HIP_CHECK(hipEventSynchronize(e1));
+    HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r && ms > 0) best_copy = std::max(best_copy, 2.0 * n * 16 / (ms * 1e-3) / 1e9);
+    HDK_HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_cal_read, dim3(grid), dim3(256), 0, s, static_cast<const cal_f4*>(a), static_cast<float*>(b), n);
+    HDK_HIP_CHECK(hipEventRecord(e1, s));
+    HDK_HIP_CHECK(hipEventSynchronize(e1));
+    HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r && ms > 0) best_read = std::max(best_read, 1.0 * n * 16 / (ms * 1e-3) / 1e9);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  *copy_gbps = best_copy;
+  *read_gbps = best_read;
   return HDK_HIP_OK;
 }
 

@@ -107,6 +107,10 @@ typedef struct hdk_hip_device_properties { /* CudaMgr.h:43-66 `DeviceProperties`
   char arch_name[64];               /* "gfx950..." */
 } hdk_hip_device_properties;
 int32_t hdk_hip_mgr_get_device_properties(int32_t device_num, hdk_hip_device_properties* out);
+/* Measurement helper (no reference counterpart): what plain streaming kernels reach on this device -- a 16 B/lane
+ * copy (bytes read + written per second) and a 16 B/lane read, best of `reps` over `bytes` of scratch.  bench.py
+ * reports them as roofline.peak_measured next to the nominal 8 TB/s. */
+int32_t hdk_hip_mgr_measure_hbm(int32_t device_num, size_t bytes, int32_t reps, double* copy_gbps, double* read_gbps);
 
 /* ------------------------------------------------------------------------------------------
  * Output-buffer initialisation (kernel #1 of every group-by launch).

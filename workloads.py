@@ -56,7 +56,7 @@ class Workload:
     """Tables resident on `device`, the query, and what the checks need."""
 
     def __init__(self, name, rows, device, mgr, frag_ids=None, fragment_size=FRAGMENT_ROWS, dim_rows=10_000_000,
-                 key_domain=100_000_000):
+                 key_domain=100_000_000, seed_offset=0, generators=None):
         import torch
         from hdk_amd.executor import Executor
         from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
@@ -96,13 +96,15 @@ class Workload:
         def uniform(lo, hi, salt, dtype=torch.int64):
             def gen(f, n):
                 g = torch.Generator(device=self.dev)
-                g.manual_seed(SEED + 1000 * salt + f)
+                g.manual_seed(SEED + seed_offset + 1000 * salt + f)
                 return torch.randint(lo, hi, (n,), dtype=dtype, device=self.dev, generator=g)
             return gen
 
         val = (I64, uniform(-2**31, 2**31, 1), (-2**31, 2**31 - 1))
         if name == "c2":
-            table("t", {"key": (I64, uniform(0, 64, 0), (0, 63)), "val": val}, self.frag_rows, self.frag_ids)
+            kgen = generators("key") if generators else uniform(0, 64, 0)
+            vgen = generators("val") if generators else val[1]
+            table("t", {"key": (I64, kgen, (0, 63)), "val": (I64, vgen, val[2])}, self.frag_rows, self.frag_ids)
             self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
         elif name in ("c5", "c5s"):
