@@ -86,7 +86,7 @@ def test_two_rank_gather_and_merge_gloo():
     assert all(r[1] == "ok" for r in res), res
 
 
-def _baseline_worker(rank, world, port, result_q):
+def _baseline_worker(rank, world, port, result_q, nkeys=3000):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -106,7 +106,7 @@ def _baseline_worker(rank, world, port, result_q):
         rng = np.random.default_rng(78)
         n = 50_000
         st = ArrowStorage()
-        st.import_numpy("t", {"k": rng.integers(0, 3000, n).astype(np.int64) * 1_000_003,
+        st.import_numpy("t", {"k": rng.integers(0, nkeys, n).astype(np.int64) * (1_000_003 if nkeys > 100 else 2**35 + 11),
                               "v": rng.integers(-1000, 1000, n).astype(np.int64)}, fragment_size=6_000)
         q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=8_191,
                       targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
@@ -146,9 +146,11 @@ def _baseline_worker(rank, world, port, result_q):
             if (L.orc_key_hash(np.array([k], dtype=np.int64).ctypes.data, 1, 8) * world) >> 32 == rank:
                 want_mine[k] = (s, c)
         assert {k: (s, c) for k, s, c in zip(got["k"], got["s"], got["c"])} == want_mine
-        tot = torch.tensor([len(got["k"])])
+        tot = torch.tensor([len(got["k"]), 1 if len(got["k"]) == 0 else 0])
         dist.all_reduce(tot)
-        assert int(tot.item()) == len(want["k"])
+        assert int(tot[0].item()) == len(want["k"])
+        if nkeys < world:
+            assert int(tot[1].item()) >= world - nkeys  # owners that received nothing still took part in the exchange
         result_q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -157,15 +159,29 @@ def _baseline_worker(rank, world, port, result_q):
         dist.destroy_process_group()
 
 
-def test_two_rank_baseline_owner_exchange_gloo():
+def _spawn(target, world, port, *extra):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_baseline_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_two_rank_baseline_owner_exchange_gloo():
+    _spawn(_baseline_worker, 2, 31500 + (os.getpid() % 2000))
+
+
+def test_four_rank_owner_exchange_uneven_splits_and_empty_owners_gloo():
+    """World size 4, 9 fragments (ranks hold 3/2/2/2), uneven all_to_all splits; with only 3 distinct keys at least
+    one owner receives nothing and must still come out of the exchange with an empty table."""
+    _spawn(_baseline_worker, 4, 33500 + (os.getpid() % 2000))
+    _spawn(_baseline_worker, 4, 35500 + (os.getpid() % 2000), 3)
+
+
+def test_four_rank_gather_and_merge_gloo():
+    _spawn(_worker, 4, 37500 + (os.getpid() % 2000))
