@@ -61,8 +61,9 @@ def _worker(rank, world, port, result_q):
         assert_buffers_equal(cp, merged, full)
         # and the fold order is rank order: merging by hand gives the identical bits
         byhand = gathered[:cp.buffer_quads].copy()
-        O.reduce(cp.plan, byhand, cp.entry_count, gathered[cp.buffer_quads:2 * cp.buffer_quads], cp.entry_count,
-                 cp.init_vals)
+        for r in range(1, world):
+            O.reduce(cp.plan, byhand, cp.entry_count, gathered[r * cp.buffer_quads:(r + 1) * cp.buffer_quads],
+                     cp.entry_count, cp.init_vals)
         assert np.array_equal(byhand, merged)
         result_q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
