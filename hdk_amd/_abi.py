@@ -14,7 +14,9 @@ MAX_QUALS = 6
 MAX_JOINS = 2
 MAX_JOIN_KEYS = 3
 MAX_EXPR_STEPS = 3
-PLAN_ABI = 2
+MAX_FILTER_OPS = 16
+F_AND, F_OR, F_NOT = 64, 65, 66
+PLAN_ABI = 3
 
 # --- sentinels: reference omniscidb/Shared/InlineNullValues.h:33-39, QueryEngine/GpuRtConstants.h:29-32
 EMPTY_KEY_64 = 2**63 - 1
@@ -35,6 +37,8 @@ ERR_DIV_BY_ZERO = 1
 ERR_OUT_OF_GPU_MEM = 2
 ERR_OUT_OF_SLOTS = 3
 ERR_OVERFLOW_OR_UNDERFLOW = 7
+ERR_OUT_OF_TIME = 9
+ERR_INTERRUPTED = 10
 ERR_UNSUPPORTED = 100
 ERR_INVALID_ARG = 101
 ERR_RUNTIME = 102
@@ -61,6 +65,7 @@ LAUNCH_FORCE_GENERIC = 4
 LAUNCH_FORCE_SCALAR = 8
 LAUNCH_FORCE_PARTITIONED = 16
 LAUNCH_PLAN_RESIDENT = 32
+LAUNCH_CHECK_INTERRUPT = 64
 
 
 class Col(C.Structure):
@@ -75,7 +80,7 @@ class Leaf(C.Structure):
 
 class Step(C.Structure):
     _fields_ = [("op", C.c_int32), ("out_class", C.c_int32), ("rhs", Leaf),
-                ("null_out", C.c_int64)]
+                ("null_out", C.c_int64), ("check_width", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Expr(C.Structure):
@@ -108,6 +113,8 @@ class Plan(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("query_kind", C.c_int32),
                 ("num_cols", C.c_int32), ("cols", Col * MAX_COLS),
                 ("num_quals", C.c_int32), ("quals", Qual * MAX_QUALS),
+                ("num_filter_ops", C.c_int32), ("filter_after_joins", C.c_int32),
+                ("filter_ops", C.c_uint8 * MAX_FILTER_OPS),
                 ("num_joins", C.c_int32), ("joins", Join * MAX_JOINS),
                 ("key_count", C.c_int32), ("keys", Expr * MAX_KEYS),
                 ("key_min", C.c_int64 * MAX_KEYS), ("key_bucket", C.c_int64 * MAX_KEYS),
@@ -121,7 +128,8 @@ class Plan(C.Structure):
 
 class KernelOptions(C.Structure):
     _fields_ = [("grid_dim_x", C.c_uint32), ("block_dim_x", C.c_uint32),
-                ("shared_mem_bytes", C.c_uint32), ("flags", C.c_uint32), ("total_rows", C.c_uint64)]
+                ("shared_mem_bytes", C.c_uint32), ("flags", C.c_uint32), ("total_rows", C.c_uint64),
+                ("watchdog_ms", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class DeviceProperties(C.Structure):

@@ -38,6 +38,7 @@ SIGNATURES = {
     "hdk_hip_version": (i32, []),
     "hdk_hip_mgr_get_device_count": (i32, [C.POINTER(i32)]),
     "hdk_hip_mgr_set_context": (i32, [i32]),
+    "hdk_hip_set_interrupt": (i32, [i32, i32]),
     "hdk_hip_mgr_measure_hbm": (i32, [i32, sz, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hdk_hip_mgr_allocate_device_mem": (i32, [sz, i32, C.POINTER(v)]),
     "hdk_hip_mgr_free_device_mem": (i32, [v]),

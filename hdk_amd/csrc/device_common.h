@@ -224,6 +224,28 @@ HDK_DEV bool is_null_val(int64_t v, int64_t null_val, int32_t nullable, bool fp)
   return fp ? (bits_to_double(v) == bits_to_double(null_val)) : (v == null_val);
 }
 
+// + - * with the reference's overflow check (QE/ArithmeticIR.cpp:277-520: the operation's SQL type is `width` bytes
+// wide; a result outside that type's range is an error).  Values are carried as int64, so for widths below 8 the
+// exact result is at hand; width 8 uses the overflow-detecting builtins.  Returns true on overflow; *r wraps.
+HDK_DEV bool checked_arith(int op, int64_t a, int64_t b, int32_t width, int64_t* r) {
+  long long res;
+  bool ovf;
+  switch (op) {
+    case HDK_OP_ADD: ovf = __builtin_saddll_overflow(a, b, &res); break;
+    case HDK_OP_SUB: ovf = __builtin_ssubll_overflow(a, b, &res); break;
+    default: ovf = __builtin_smulll_overflow(a, b, &res); break;
+  }
+  *r = res;
+  if (width <= 0) {
+    return false;
+  }
+  if (width < 8) {
+    const int64_t lim = int64_t(1) << (8 * width - 1);
+    return ovf || res > lim - 1 || res < -lim;
+  }
+  return ovf;
+}
+
 // expression chain; err receives ERR_DIV_BY_ZERO like the reference's division guard.
 HDK_DEV int64_t eval_expr(const RowCtx& c, const hdk_hip_expr& e, int32_t& err) {
   const hdk_hip_plan* p = c.plan;
@@ -261,9 +283,13 @@ HDK_DEV int64_t eval_expr(const RowCtx& c, const hdk_hip_expr& e, int32_t& err) 
       } else {
         const int64_t a = acc, b = rhs;
         switch (op) {
-          case HDK_OP_ADD: r = static_cast<int64_t>(static_cast<uint64_t>(a) + static_cast<uint64_t>(b)); break;
-          case HDK_OP_SUB: r = static_cast<int64_t>(static_cast<uint64_t>(a) - static_cast<uint64_t>(b)); break;
-          case HDK_OP_MUL: r = static_cast<int64_t>(static_cast<uint64_t>(a) * static_cast<uint64_t>(b)); break;
+          case HDK_OP_ADD:
+          case HDK_OP_SUB:
+          case HDK_OP_MUL:
+            if (checked_arith(op, a, b, st.check_width, &r)) {
+              err = HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW;
+            }
+            break;
           case HDK_OP_DIV:
             if (b == 0) { err = HDK_HIP_ERR_DIV_BY_ZERO; r_null = true; }
             else if (a == INT64_MIN && b == -1) { r = INT64_MIN; }
@@ -302,14 +328,20 @@ HDK_DEV int64_t eval_expr(const RowCtx& c, const hdk_hip_expr& e, int32_t& err) 
   return acc;
 }
 
-// one filter conjunct: true iff the three-valued comparison is TRUE
-HDK_DEV bool eval_qual(const RowCtx& c, const hdk_hip_qual& q, int32_t& err) {
+// one filter conjunct: true iff the three-valued comparison is TRUE; *is_null (when asked for) tells NULL from FALSE
+HDK_DEV bool eval_qual(const RowCtx& c, const hdk_hip_qual& q, int32_t& err, bool* is_null = nullptr) {
   const int64_t lhs = eval_expr(c, q.lhs, err);
   const int64_t rhs = load_leaf(c, q.rhs);
   const bool lhs_fp = q.lhs.vclass == HDK_VC_FP;
   const bool rhs_fp = leaf_is_fp(c.plan, q.rhs);
+  if (is_null) {
+    *is_null = false;
+  }
   if (is_null_val(lhs, q.lhs.null_val, q.lhs.nullable, lhs_fp) ||
       is_null_val(rhs, q.rhs.null_val, q.rhs.nullable, rhs_fp)) {
+    if (is_null) {
+      *is_null = true;
+    }
     return false;
   }
   if (lhs_fp || rhs_fp) {
@@ -502,8 +534,51 @@ HDK_DEV MatchSet matching_set(const RowCtx& c, const hdk_hip_join& jn, const int
   return ms;
 }
 
+// The filter as a postfix program over the conjuncts (hdk_hip_plan::filter_ops) with the reference's three-valued
+// logical_and / logical_or / logical_not (QE/RuntimeFunctions.cpp:357-384).  The value stack lives in two bit masks
+// (bit i of `t`: entry i is TRUE; of `n`: entry i is NULL), indexed by the wave-uniform stack pointer.
+HDK_DEV bool filter_program_pass(const RowCtx& c, int32_t& err) {
+  const hdk_hip_plan* p = c.plan;
+  uint32_t t = 0, n = 0;
+  int sp = 0;
+  const int nops = p->num_filter_ops;
+  for (int i = 0; i < nops; ++i) {
+    const uint32_t op = p->filter_ops[i];
+    if (op < HDK_F_AND) {
+      bool isnull;
+      const bool v = eval_qual(c, p->quals[op], err, &isnull);
+      t = (t & ~(1u << sp)) | (static_cast<uint32_t>(v) << sp);
+      n = (n & ~(1u << sp)) | (static_cast<uint32_t>(isnull) << sp);
+      ++sp;
+    } else if (op == HDK_F_NOT) {
+      const uint32_t m = 1u << (sp - 1);
+      t = (t & ~m) | (~(t | n) & m);  // NULL stays NULL, TRUE <-> FALSE
+    } else {
+      const uint32_t ta = (t >> (sp - 2)) & 1u, tb = (t >> (sp - 1)) & 1u;
+      const uint32_t na = (n >> (sp - 2)) & 1u, nb = (n >> (sp - 1)) & 1u;
+      uint32_t tr, nr;
+      if (op == HDK_F_AND) {
+        const uint32_t fa = (ta | na) ^ 1u, fb = (tb | nb) ^ 1u;  // FALSE operands
+        tr = ta & tb;
+        nr = (tr | fa | fb) ^ 1u;
+      } else {
+        tr = ta | tb;
+        nr = (tr ^ 1u) & (na | nb);
+      }
+      sp -= 1;
+      const uint32_t m = 1u << (sp - 1);
+      t = (t & ~m) | (tr << (sp - 1));
+      n = (n & ~m) | (nr << (sp - 1));
+    }
+  }
+  return sp == 1 && (t & 1u);
+}
+
 HDK_DEV bool quals_pass(const RowCtx& c, int stage, int32_t& err) {
   const hdk_hip_plan* p = c.plan;
+  if (p->num_filter_ops) {
+    return (p->filter_after_joins != 0) == (stage != 0) ? filter_program_pass(c, err) : true;
+  }
   const int nq = p->num_quals;
   for (int q = 0; q < nq; ++q) {
     if ((p->quals[q].after_joins != 0) == (stage != 0) && !eval_qual(c, p->quals[q], err)) {

@@ -16,6 +16,7 @@
 //   * one slab store per block, then `k_finalize` folds the slabs into the output buffer with the
 //     reference's exact agg_*[_skip_val] semantics -- no global atomics, deterministic slab order.
 #include "agg_common.h"
+#include "watch.h"
 
 namespace hdk {
 
@@ -100,11 +101,13 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
 
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
+  const Watch watch = watch_begin();
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
     c.cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * tile_rows;
       const int64_t row_end = min(row0 + tile_rows, nrows);
       for (int64_t row = row0 + tid; row < row_end; row += kBlock) {
@@ -406,6 +409,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include <utility>
 #include <vector>
 
+#include <stddef.h>
 #include <string.h>
 
 #include "host_common.h"
@@ -443,6 +447,25 @@ int32_t validate_plan(const hdk_hip_plan* p) {
                   "bad key_component_count");
       HDK_REQUIRE(jn.key_component_width == 4 || jn.key_component_width == 8, "bad key_component_width");
     }
+  }
+  HDK_REQUIRE(p->num_filter_ops >= 0 && p->num_filter_ops <= HDK_HIP_MAX_FILTER_OPS, "bad num_filter_ops");
+  if (p->num_filter_ops) {  // a well-formed postfix program that leaves exactly one value
+    int depth = 0;
+    for (int i = 0; i < p->num_filter_ops; ++i) {
+      const uint32_t op = p->filter_ops[i];
+      if (op < HDK_F_AND) {
+        HDK_REQUIRE(static_cast<int>(op) < p->num_quals, "filter program: qual %u out of range", op);
+        ++depth;
+      } else if (op == HDK_F_NOT) {
+        HDK_REQUIRE(depth >= 1, "filter program: NOT on an empty stack");
+      } else {
+        HDK_REQUIRE(op == HDK_F_AND || op == HDK_F_OR, "filter program: unknown op %u", op);
+        HDK_REQUIRE(depth >= 2, "filter program: AND / OR needs two values");
+        --depth;
+      }
+      HDK_REQUIRE(depth <= 16, "filter program: more than 16 values on the stack");
+    }
+    HDK_REQUIRE(depth == 1, "filter program: leaves %d values", depth);
   }
   HDK_REQUIRE(p->num_targets > 0 && p->num_targets <= HDK_HIP_MAX_TARGETS, "bad num_targets");
   HDK_REQUIRE(p->query_kind >= HDK_Q_NON_GROUPED && p->query_kind <= HDK_Q_PROJECTION,
@@ -802,6 +825,9 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
 // joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
 // LEFT joins (the batched interpreter handles inner one-to-one probes)
 static bool needs_join_loops(const hdk_hip_plan* p) {
+  if (p->num_filter_ops) {
+    return true;  // OR / NOT over the conjuncts: evaluated by the row-at-a-time interpreter (filter_program_pass)
+  }
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) {
@@ -966,7 +992,7 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
 
 // filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
-  if (p->num_quals > kMaxPlainQuals) return false;
+  if (p->num_quals > kMaxPlainQuals || p->num_filter_ops) return false;
   for (int i = 0; i < p->num_quals; ++i) {
     const hdk_hip_qual& q = p->quals[i];
     int c;
@@ -1430,6 +1456,18 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
   }
 
+  // runtime interrupt / dynamic watchdog (watch.h): armed per launch by a one-thread kernel on the launch stream;
+  // launches that ask for neither only pay for it right after one that did (to disarm)
+  {
+    static bool armed[16];
+    const uint32_t wf = ((ko && (ko->flags & HDK_HIP_LAUNCH_CHECK_INTERRUPT)) ? 1u : 0u) | ((ko && ko->watchdog_ms) ? 2u : 0u);
+    if (wf || armed[device_id & 15]) {
+      hipLaunchKernelGGL(k_arm_watch, dim3(1), dim3(1), 0, s, wf, ko ? ko->watchdog_ms : 0u);
+      HDK_HIP_CHECK(hipGetLastError());
+      armed[device_id & 15] = wf != 0;
+    }
+  }
+
   KernParams kp;
   kp.col_buffers = reinterpret_cast<const int8_t* const* const*>(params[HDK_KP_COL_BUFFERS]);
   kp.num_fragments = reinterpret_cast<const uint64_t*>(params[HDK_KP_NUM_FRAGMENTS]);
@@ -1535,6 +1573,24 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   if (timed) {
     HDK_HIP_CHECK(hipEventRecord(e1, s));
   }
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value) {
+  hipStream_t main_stream;
+  const int32_t st = device_enter(device_id, nullptr, &main_stream);
+  if (st) return st;
+  static hipStream_t side[16];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  hipStream_t& ss = side[device_id & 15];
+  if (!ss) {
+    HDK_HIP_CHECK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+  }
+  // on a stream of its own: the write overtakes the kernels it is meant to stop
+  HDK_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_watch), &value, sizeof(int32_t), offsetof(WatchState, interrupt),
+                                       hipMemcpyHostToDevice, ss));
+  HDK_HIP_CHECK(hipStreamSynchronize(ss));
   return HDK_HIP_OK;
 }
 

@@ -15,6 +15,7 @@
 //     slot that has since moved on; both fall into the atomic slow path (CAS), which is exact;
 //   * everything else (probe collisions, fresh claims, wide rows) takes find_or_claim / g_agg* as is.
 #pragma once
+#include "watch.h"
 #include "plain_quals.h"
 #include "scan_agg_global.h"
 
@@ -62,8 +63,8 @@ HDK_DEV void g_agg64_seen(int agg, bool fp, bool skip, int64_t nullv, int64_t* s
 
 template <typename K, int NK>  // key type of the TABLE (int32_t or int64_t); number of key columns (1 or 2)
 __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(BaseFastArgs a) {
-  if (a.run_if && *a.run_if == 0) {
-    return;
+  if (a.run_if && *a.run_if != 1) {
+    return;  // (armed fallback of the partitioned path: 1 = take over; 2 = the launch was interrupted)
   }
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
+  const Watch watch = watch_begin();
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
     const int8_t* const* cols = a.kp.col_buffers[f];
     const int8_t* keybuf = cols[a.key_buf_idx];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       int64_t row[VR];
       bool live[VR];

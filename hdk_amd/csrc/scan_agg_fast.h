@@ -14,6 +14,7 @@
 //   * non-grouped plans accumulate in registers and touch LDS once per lane.
 // The slab format written at the end is the generic one (agg_common.h), so hdk_finalize is shared.
 #pragma once
+#include "watch.h"
 #include "agg_common.h"
 #include "plain_quals.h"
 
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
+  const Watch watch = watch_begin();
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
     const gcol_t kcol = KW ? (gcol_t)cols[a.key_buf_idx] : nullptr;
     const gcol_t vcol = VW ? (gcol_t)cols[a.val_buf_idx] : nullptr;
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       if (row0 + kTileRows <= nrows) {
         // full tile: U coalesced 16-B steps per column, all issued before the first use

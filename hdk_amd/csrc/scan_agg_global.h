@@ -7,6 +7,7 @@
 // JIT'ed code, native global_atomic_add_f64 / 64-bit min-max instead of CAS loops, and a
 // "CAS-the-sentinel-then-add" form for *_skip_val that needs no atomicExch spin.
 #pragma once
+#include "watch.h"
 #include "agg_common.h"
 #include "baseline_table.h"
 
@@ -113,12 +114,14 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
+  const Watch watch = watch_begin();
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
     c.cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * tile_rows;
       const int64_t row_end = min(row0 + tile_rows, nrows);
       for (int64_t row = row0 + tid; row < row_end; row += kGlobalBlock) {

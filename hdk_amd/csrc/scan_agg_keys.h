@@ -13,6 +13,7 @@
 // per row.  The interpreter spends ~116 VALU instructions per row on these plans and is issue-bound at
 // 28-31 % of the HBM roofline; this kernel needs about 50.
 #pragma once
+#include "watch.h"
 #include "agg_common.h"
 #include "plain_quals.h"
 
@@ -77,12 +78,14 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
+  const Watch watch = watch_begin();
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
     const int8_t* const* cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows + tid;
       bool pass[VR];
       int64_t row[VR];

@@ -38,6 +38,7 @@
 // Slab cursors sit one per 128-byte line (128 cursors in 512 bytes serialise on four lines: 2.68 -> 2.34 ms).
 #pragma once
 #include "scan_agg_baseline_fast.h"
+#include "watch.h"
 
 namespace hdk {
 
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   if (LEVEL == 1) {
     const uint64_t nfrag = *a.kp.num_fragments;
     const uint32_t ntab = *a.kp.num_tables;
+    const Watch watch = watch_begin();
     int64_t tile = blockIdx.x;
     int64_t frag_tile_begin = 0;
     for (uint64_t f = 0; f < nfrag; ++f) {
@@ -313,7 +315,15 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
       for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
         // block-uniform exit: thread 0 samples the flag, everyone agrees before the batch's barriers
         if (tid == 0) {
-          s_stop = __hip_atomic_load(a.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t stop = __hip_atomic_load(a.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (watch.flags) {
+            if (const int32_t w_ = watch_poll(watch)) {  // interrupt / watchdog: the launch ends with that error
+              record_error(a.kp.error_code, w_);
+              atomicExch(a.fallback, 2u);  // the later passes return at once; the armed atomics kernel runs only for 1
+              stop = 2;
+            }
+          }
+          s_stop = stop;
         }
         __syncthreads();
         if (s_stop) {

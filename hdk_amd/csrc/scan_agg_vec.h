@@ -4,6 +4,7 @@
 // multi-column perfect hash (taxi Q3/Q4, BASELINE C3).  Same LDS table, slab and finalize protocol as
 // the other scan kernels (agg_common.h).
 #pragma once
+#include "watch.h"
 #include "agg_common.h"
 #include "vec_eval.h"
 
@@ -81,12 +82,14 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
+  const Watch watch = watch_begin();
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
     c.cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       bool pass[VR];
       vec_ctx_tile(c, row0, nrows, pass);  // dead slots re-read a valid row; their results are dropped

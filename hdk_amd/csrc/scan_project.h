@@ -11,6 +11,7 @@
 // Output row order is therefore a permutation of the reference's (which is itself scheduling-dependent
 // on a GPU); the set of rows is identical.
 #pragma once
+#include "watch.h"
 #include "vec_eval.h"
 
 namespace hdk {
@@ -60,6 +61,8 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
   vec_ctx_init(c, p, tid, BLOCK);
   int32_t err = 0;
   int32_t slots_err = 0;
+  __shared__ int32_t s_watch;
+  const Watch watch = watch_begin();
 
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
@@ -68,6 +71,13 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
     c.cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      if (watch.flags) {  // (this loop has barriers: the block decides together)
+        if (const int32_t w_ = watch_poll_block(watch, &s_watch)) {
+          err = w_;
+          tile = INT64_MAX - gridDim.x;
+          break;
+        }
+      }
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       bool pass[VR];
       vec_ctx_tile(c, row0, nrows, pass);
@@ -215,11 +225,13 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_scalar
   int32_t slots_err = 0;
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
+  const Watch watch = watch_begin();
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
     c.cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      HDK_WATCH_TILE(watch, err, tile)
       const int64_t row = (tile - frag_tile_begin) * kTileRows + tid;
       if (row >= nrows) {
         continue;

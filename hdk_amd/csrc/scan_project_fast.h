@@ -18,6 +18,7 @@
 //     reading the filter columns twice costs 8 B/row here and removes it.  Output rows come out in
 //     block-major row order, deterministically.
 #pragma once
+#include "watch.h"
 #include "plain_quals.h"
 #include "scan_project.h"
 
@@ -153,11 +154,22 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
 
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
+  __shared__ int32_t s_watch;
+  const Watch watch = watch_begin();
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;
     const int8_t* const* cols = a.kp.col_buffers[f];
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      if (watch.flags) {  // (this loop has barriers: the block decides together)
+        if (const int32_t w_ = watch_poll_block(watch, &s_watch)) {
+          if (tid == 0) {
+            record_error(a.kp.error_code, w_);
+          }
+          tile = INT64_MAX - gridDim.x;
+          break;
+        }
+      }
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       bool pass[VR];
 #pragma unroll

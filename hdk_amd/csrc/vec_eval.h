@@ -239,6 +239,18 @@ HDK_DEV void eval_expr_v(const VecCtx& c, cexpr_t e, int64_t (&acc)[VR], const b
     const uint64_t a = static_cast<uint64_t>(acc[r]), b = static_cast<uint64_t>(rhs[r]);    \
     acc[r] = isnull[r] ? null_out : static_cast<int64_t>(EXPR);                              \
   }
+        const int32_t cw = st.check_width;
+        if (cw > 0 && op <= HDK_OP_MUL) {  // the reference's checked + - * (checked_arith, device_common.h)
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            int64_t res;
+            const bool ovf = checked_arith(op, acc[r], rhs[r], cw, &res);
+            if (ovf && !isnull[r] && live[r]) {
+              err = HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW;
+            }
+            acc[r] = isnull[r] ? null_out : res;
+          }
+        } else
         switch (op) {
           case HDK_OP_ADD: HDK_INT_ROWS(a + b) break;
           case HDK_OP_SUB: HDK_INT_ROWS(a - b) break;

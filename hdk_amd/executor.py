@@ -91,7 +91,7 @@ class PreparedStep:
     """Everything one (multi-fragment) kernel launch needs, resident on the device."""
 
     def __init__(self, ex: "Executor", cp: CompiledPlan, frag_ids: List[int], grid=0, flags=0,
-                 out_ptr: Optional[int] = None):
+                 out_ptr: Optional[int] = None, watchdog_ms: int = 0):
         self.ex, self.cp, self.frag_ids = ex, cp, list(frag_ids)
         self.mgr, self.dev = ex.mgr, ex.device_id
         self.L = lib()
@@ -102,7 +102,7 @@ class PreparedStep:
         outer = storage.get(cp.query.table)
         nfrag = len(self.frag_ids)
         self.rows_in_step = int(sum(outer.frag_rows[f] for f in self.frag_ids))
-        self.ko = A.KernelOptions(grid, 0, 0, flags, self.rows_in_step)
+        self.ko = A.KernelOptions(grid, 0, 0, flags, self.rows_in_step, int(watchdog_ms), 0)
         ntab = 1 + len(cp.inner_tables)
 
         # ---- join hash tables (built once per device, cached) ----------------------------
@@ -432,13 +432,18 @@ class Executor:
         self._join_cache[key] = table
         return table
 
+    def interrupt(self, value: int = 1):
+        """Executor::interrupt (QE/GpuInterrupt.cpp): launches started with LAUNCH_CHECK_INTERRUPT stop with
+        ERR_INTERRUPTED; interrupt(0) re-arms (DeviceKernel::initializeRuntimeInterrupter)."""
+        check(lib().hdk_hip_set_interrupt(self.device_id, int(value)))
+
     def prepare(self, q, frag_ids: Optional[List[int]] = None, grid=0, flags=0,
-                out_ptr: Optional[int] = None) -> PreparedStep:
+                out_ptr: Optional[int] = None, watchdog_ms: int = 0) -> PreparedStep:
         cp = q if isinstance(q, CompiledPlan) else self.compile(q)
         outer = self.storage.get(cp.query.table)
         if frag_ids is None:
             frag_ids = list(range(outer.num_fragments))
-        return PreparedStep(self, cp, frag_ids, grid=grid, flags=flags, out_ptr=out_ptr)
+        return PreparedStep(self, cp, frag_ids, grid=grid, flags=flags, out_ptr=out_ptr, watchdog_ms=watchdog_ms)
 
     def execute(self, q: QueryUnit, device_type: str = "GPU", frag_ids=None, **kw) -> ExecutionResult:
         if device_type != "GPU":

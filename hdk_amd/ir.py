@@ -135,6 +135,29 @@ class Cmp:
 
 
 @dataclass(frozen=True)
+class And:
+    """lhs AND rhs over filter conditions, three-valued (logical_and, QE/RuntimeFunctions.cpp:361-372)."""
+    lhs: "Cond"
+    rhs: "Cond"
+
+
+@dataclass(frozen=True)
+class Or:
+    """lhs OR rhs, three-valued (logical_or, QE/RuntimeFunctions.cpp:374-384)."""
+    lhs: "Cond"
+    rhs: "Cond"
+
+
+@dataclass(frozen=True)
+class Not:
+    """NOT arg, three-valued (logical_not, QE/RuntimeFunctions.cpp:355-358)."""
+    arg: "Cond"
+
+
+Cond = Union[Cmp, And, Or, Not]
+
+
+@dataclass(frozen=True)
 class Agg:
     """Aggregate target: kind in count/sum/min/max/avg; arg None = COUNT(*)."""
     kind: str
@@ -180,7 +203,7 @@ class JoinSpec:
 class QueryUnit:
     """What one execution step needs (cf. RelAlgExecutionUnit)."""
     table: str
-    quals: List[Cmp] = field(default_factory=list)
+    quals: List[Cond] = field(default_factory=list)  # conjunction of conditions (each a Cmp or an And / Or / Not tree)
     joins: List[JoinSpec] = field(default_factory=list)
     groupby: List[Expr] = field(default_factory=list)
     targets: List[Union[Agg, KeyRef, Proj]] = field(default_factory=list)

@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _abi as A
-from .ir import (Agg, BinOp, Cast, Cmp, ColRef, Expr, ExtractYear, KeyRef, Lit, QueryMustRunOnCpu,
+from .ir import (Agg, And, BinOp, Cast, Cmp, ColRef, Expr, ExtractYear, KeyRef, Lit, Not, Or, QueryMustRunOnCpu,
                  QueryUnit, Type)
 from .storage import ArrowStorage, Table
 
@@ -235,6 +235,18 @@ def _flatten(b: _Binder, e: Expr):
     raise QueryMustRunOnCpu(f"unsupported expression {e!r}")
 
 
+def _sql_int_width(b: _Binder, e) -> int:
+    """Byte width of an integer operand's SQL type, for the overflow check of + - * (the reference checks in the
+    operation's own type: the wider of the two operand types, QE/ArithmeticIR.cpp:277-520; an integer literal is
+    INTEGER when it fits 32 bits, else BIGINT).  0 for floating point."""
+    if isinstance(e, Lit):
+        if isinstance(e.value, float):
+            return 0
+        return 4 if -(2**31) <= int(e.value) < 2**31 else 8
+    t = b.type_of(e)
+    return 0 if t.is_fp else t.size
+
+
 def make_expr(b: _Binder, e: Expr) -> A.Expr:
     l0, steps = _flatten(b, e)
     if len(steps) > A.MAX_EXPR_STEPS:
@@ -242,6 +254,7 @@ def make_expr(b: _Binder, e: Expr) -> A.Expr:
     x = A.Expr()
     x.leaf0 = _make_leaf(b, l0)
     x.nsteps = len(steps)
+    cur_w = _sql_int_width(b, l0)
     for i, (op, rhs, out_t) in enumerate(steps):
         st = x.steps[i]
         st.op = op
@@ -249,6 +262,13 @@ def make_expr(b: _Binder, e: Expr) -> A.Expr:
         if rhs is not None:
             st.rhs = _make_leaf(b, rhs)
         st.null_out = A.to_i64(_result_null(out_t))
+        # the SQL type the step computes in: the wider operand for binary integer ops; what a unary op yields
+        if op in (A.OP_ADD, A.OP_SUB, A.OP_MUL, A.OP_DIV, A.OP_MOD):
+            rw = _sql_int_width(b, rhs)
+            cur_w = 0 if (out_t.is_fp or not cur_w or not rw) else max(cur_w, rw)
+            st.check_width = cur_w if op in (A.OP_ADD, A.OP_SUB, A.OP_MUL) else 0
+        else:
+            cur_w = 0 if out_t.is_fp else 8  # extract / scale-down / casts: BIGINT results
     t = b.type_of(e)
     x.vclass = A.VC_FP if t.is_fp else A.VC_INT
     if steps:
@@ -433,13 +453,48 @@ def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
                            "kind": int(jn.kind), "entry_count": int(jn.entry_count),
                            "key_width": int(jn.key_component_width), "num_elems": inner.num_rows,
                            "max_matches": _inner_max_matches(inner, icols)})
-    p.num_quals = len(q.quals)
-    for qi, c in enumerate(q.quals):
+    # filter: a plain conjunction of comparisons keeps the per-conjunct staging; anything with OR / NOT becomes a
+    # postfix program over the comparisons (hdk_hip_plan::filter_ops), evaluated at one stage
+    leaves: List[Cmp] = []
+    prog: List[int] = []
+
+    def emit(c):
+        if isinstance(c, Cmp):
+            if c not in leaves:
+                leaves.append(c)
+            prog.append(leaves.index(c))
+        elif isinstance(c, Not):
+            emit(c.arg)
+            prog.append(A.F_NOT)
+        elif isinstance(c, (And, Or)):
+            emit(c.lhs)
+            emit(c.rhs)
+            prog.append(A.F_AND if isinstance(c, And) else A.F_OR)
+        else:
+            raise QueryMustRunOnCpu(f"unsupported filter condition {c!r}")
+
+    for i, c in enumerate(q.quals):
+        emit(c)
+        if i:
+            prog.append(A.F_AND)
+    if len(leaves) > A.MAX_QUALS:
+        raise QueryMustRunOnCpu("too many filter comparisons for the fixed kernel library")
+    p.num_quals = len(leaves)
+    for qi, c in enumerate(leaves):
         ql = p.quals[qi]
         ql.lhs = make_expr(b, c.lhs)
         ql.rhs = _make_leaf(b, c.rhs)
         ql.cmp = _CMP[c.op]
         ql.after_joins = 1 if (_expr_refs_inner(b, c.lhs) or _expr_refs_inner(b, c.rhs)) else 0
+    if all(isinstance(c, Cmp) for c in q.quals):
+        p.num_filter_ops = 0
+    else:
+        if len(prog) > A.MAX_FILTER_OPS:
+            raise QueryMustRunOnCpu("filter expression too long for the fixed kernel library")
+        p.num_filter_ops = len(prog)
+        for i, op in enumerate(prog):
+            p.filter_ops[i] = op
+        p.filter_after_joins = 1 if any(p.quals[i].after_joins for i in range(len(leaves))) else 0
     return join_infos
 
 
@@ -476,7 +531,7 @@ def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
     b = _Binder(storage, q)
     p = A.Plan()
     p.abi_version = A.PLAN_ABI
-    if len(q.targets) > A.MAX_TARGETS or len(q.quals) > A.MAX_QUALS or len(q.joins) > A.MAX_JOINS:
+    if len(q.targets) > A.MAX_TARGETS or len(q.joins) > A.MAX_JOINS:
         raise QueryMustRunOnCpu("query exceeds the fixed kernel library's limits")
     join_infos = _compile_joins_and_quals(b, q, p)
     p.query_kind = A.Q_PROJECTION
@@ -551,8 +606,7 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
     b = _Binder(storage, q)
     p = A.Plan()
     p.abi_version = A.PLAN_ABI
-    if len(q.quals) > A.MAX_QUALS or len(q.joins) > A.MAX_JOINS or len(q.groupby) > A.MAX_KEYS or \
-            len(q.targets) > A.MAX_TARGETS:
+    if len(q.joins) > A.MAX_JOINS or len(q.groupby) > A.MAX_KEYS or len(q.targets) > A.MAX_TARGETS:
         raise QueryMustRunOnCpu("query exceeds the fixed kernel library's limits")
 
     join_infos = _compile_joins_and_quals(b, q, p)

@@ -141,6 +141,8 @@ int32_t hdk_hip_init_columnar_group_by_buffer(int64_t* groups_buffer, const int6
 #define HDK_HIP_MAX_JOINS 2
 #define HDK_HIP_MAX_JOIN_KEYS 3 /* key components of a keyed (composite-key) join */
 #define HDK_HIP_MAX_EXPR_STEPS 3
+#define HDK_HIP_MAX_FILTER_OPS 16
+enum hdk_hip_filter_op { HDK_F_AND = 64, HDK_F_OR = 65, HDK_F_NOT = 66 }; /* < 64: push quals[op] */
 
 enum hdk_hip_value_class { HDK_VC_INT = 0, HDK_VC_FP = 1 };
 
@@ -188,6 +190,10 @@ typedef struct hdk_hip_step {
   int32_t out_class; /* hdk_hip_value_class of the result */
   hdk_hip_leaf rhs;  /* second operand (unused by unary ops) */
   int64_t null_out;  /* in-band NULL of the result */
+  int32_t check_width; /* + - * on integers: byte width (1/2/4/8) of the operation's SQL type; a result outside that
+                          type's range ends the query with ERR_OVERFLOW_OR_UNDERFLOW, like the checked arithmetic the
+                          reference generates (QE/ArithmeticIR.cpp:277-520; NULL operands are not checked).  0: unchecked */
+  int32_t pad_;
 } hdk_hip_step;
 typedef struct hdk_hip_expr {
   int32_t vclass;    /* value class of the final result */
@@ -300,6 +306,15 @@ typedef struct hdk_hip_plan {
   hdk_hip_col cols[HDK_HIP_MAX_COLS];
   int32_t num_quals;
   hdk_hip_qual quals[HDK_HIP_MAX_QUALS];
+  /* Filter as a boolean expression over the conjuncts above, in postfix order (AND / OR / NOT with the reference's
+   * three-valued logical_and / logical_or / logical_not, QE/RuntimeFunctions.cpp:357-384): a byte < HDK_F_AND pushes
+   * the value of quals[byte] (TRUE / FALSE / NULL), HDK_F_AND and HDK_F_OR combine the two topmost values, HDK_F_NOT
+   * negates the topmost; a row passes when the result is TRUE.  num_filter_ops == 0: the plain conjunction of all
+   * quals (each staged by its own after_joins).  With a program the whole filter is evaluated at one stage:
+   * filter_after_joins. */
+  int32_t num_filter_ops;
+  int32_t filter_after_joins;
+  uint8_t filter_ops[HDK_HIP_MAX_FILTER_OPS];
   int32_t num_joins;
   hdk_hip_join joins[HDK_HIP_MAX_JOINS];
   /* group-by keys */
@@ -321,7 +336,7 @@ typedef struct hdk_hip_plan {
   int32_t num_targets;
   hdk_hip_target targets[HDK_HIP_MAX_TARGETS];
 } hdk_hip_plan;
-#define HDK_HIP_PLAN_ABI 2u
+#define HDK_HIP_PLAN_ABI 3u
 
 /* ------------------------------------------------------------------------------------------
  * Kernel launch.
@@ -358,7 +373,15 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
                            of reading it back: the radix-partitioned group-by (skipped when 0) and the selection
                            bitmask the filter/project counting pass hands to its writing pass (when 0, or for rows
                            past the bound, the writing pass evaluates the filter again) */
+  uint32_t watchdog_ms; /* > 0: the launch's kernels give up with ERR_OUT_OF_TIME once this much time has passed
+                           since the launch reached the device (dynamic watchdog: QE/DynamicWatchdog.cpp:36-84,
+                           QE/cuda_mapd_rt.cu:105-135; the reference counts cycles, this counts the 100 MHz
+                           s_memrealtime clock) */
+  uint32_t reserved_;
 } hdk_hip_kernel_options;
+#define HDK_HIP_LAUNCH_CHECK_INTERRUPT 64u     /* poll the device's interrupt flag (hdk_hip_set_interrupt) once per
+                                                  tile and stop with ERR_INTERRUPTED when it is set
+                                                  (check_interrupt, QE/cuda_mapd_rt.cu:137-148) */
 #define HDK_HIP_LAUNCH_FORCE_PARTITIONED 16u   /* take the radix-partitioned group-by whenever the plan shape
                                                   allows it, whatever the table size (testing) */
 #define HDK_HIP_LAUNCH_PLAN_RESIDENT 32u       /* the head of `workspace` already holds this plan (an earlier
@@ -371,6 +394,13 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
 #define HDK_HIP_LAUNCH_FORCE_SCALAR 8u         /* use the row-at-a-time interpreter kernel (testing) */
 #define HDK_HIP_LAUNCH_RECORD_EVENTS 2u        /* bracket the scan kernel with HIP events on the launch
                                                   stream (DeviceClock, QE/DeviceKernel.cpp:25-43) */
+
+/* Runtime interrupt (Executor::interrupt -> the `runtime_interrupt_flag` of the GPU module, QE/GpuInterrupt.cpp,
+ * QE/cuda_mapd_rt.cu:137-148): value != 0 makes every running and future launch on `device_id` that was started with
+ * HDK_HIP_LAUNCH_CHECK_INTERRUPT record ERR_INTERRUPTED and stop at its next tile; 0 re-arms (what
+ * DeviceKernel::initializeRuntimeInterrupter does before a launch).  Written on a stream of its own, so it overtakes
+ * the kernels it is meant to stop. */
+int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value);
 
 /* Bytes of device scratch `hdk_hip_launch` needs for this plan (per-block partial tables). */
 int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,

@@ -1212,6 +1212,33 @@ static inline int is_null_f(int64_t v, int64_t null_val, int nullable) {
 
 /* Evaluate an expression chain; *err receives ERR_DIV_BY_ZERO when the reference's
  * div-by-zero check (QE/ArithmeticIR.cpp codegenDivZeroCheck) would fire. */
+/* + - * with the overflow check the reference generates around them (QE/ArithmeticIR.cpp: codegenAdd :277-337,
+ * codegenSub :339-417, codegenMul :419-520): with chosen_max / chosen_min the limits of the operation's SQL type
+ * (`width` bytes),
+ *   add: (lhs > 0 && rhs > max - lhs) || (lhs < 0 && rhs < min - lhs)
+ *   sub: the mirrored test;   mul: |lhs| > limit / |rhs| with limit = max (+1 when the signs differ)
+ * i.e. exactly "the mathematical result does not fit the type".  NULL operands are not checked (the caller has
+ * already handled them).  Values are carried as int64: for widths below 8 the exact result is compared with the
+ * type's range, width 8 uses the overflow-detecting builtins.  Returns 1 on overflow; *r receives the wrapped result. */
+static int checked_arith(int op, int64_t a, int64_t b, int32_t width, int64_t* r) {
+  long long res;
+  int ovf;
+  switch (op) {
+    case HDK_OP_ADD: ovf = __builtin_saddll_overflow(a, b, &res); break;
+    case HDK_OP_SUB: ovf = __builtin_ssubll_overflow(a, b, &res); break;
+    default: ovf = __builtin_smulll_overflow(a, b, &res); break;
+  }
+  *r = res;
+  if (width <= 0) {
+    return 0;
+  }
+  if (width < 8) {
+    const int64_t lim = (int64_t)1 << (8 * width - 1);
+    return ovf || res > lim - 1 || res < -lim;
+  }
+  return ovf;
+}
+
 static int64_t eval_expr(const orc_row_ctx* c, const hdk_hip_expr* e, int32_t* err) {
   const hdk_hip_plan* p = c->plan;
   int64_t acc = load_leaf(c, &e->leaf0);
@@ -1256,9 +1283,13 @@ static int64_t eval_expr(const orc_row_ctx* c, const hdk_hip_expr* e, int32_t* e
         } else {
           const int64_t a = acc, b = rhs;
           switch (st->op) {
-            case HDK_OP_ADD: r = (int64_t)((uint64_t)a + (uint64_t)b); break;
-            case HDK_OP_SUB: r = (int64_t)((uint64_t)a - (uint64_t)b); break;
-            case HDK_OP_MUL: r = (int64_t)((uint64_t)a * (uint64_t)b); break;
+            case HDK_OP_ADD:
+            case HDK_OP_SUB:
+            case HDK_OP_MUL:
+              if (checked_arith(st->op, a, b, st->check_width, &r)) {
+                *err = HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW;
+              }
+              break;
             case HDK_OP_DIV:
               if (b == 0) { *err = HDK_HIP_ERR_DIV_BY_ZERO; r_is_null = 1; }
               else if (a == INT64_MIN && b == -1) r = INT64_MIN;
@@ -1339,6 +1370,38 @@ static int8_t eval_qual(const orc_row_ctx* c, const hdk_hip_qual* q, int32_t* er
     }
   }
   return 0;
+}
+
+/* The filter of a plan at one stage (0: before the joins, 1: after them): the conjunction of the stage's quals, or --
+ * with a filter program -- the postfix expression over all quals, combined with the reference's three-valued
+ * logical_and / logical_or / logical_not (orc_logical_*, pinned against RuntimeFunctions.cpp:357-384). */
+static int filter_pass(const orc_row_ctx* c, int stage, int32_t* err) {
+  const hdk_hip_plan* p = c->plan;
+  if (p->num_filter_ops) {
+    if ((p->filter_after_joins != 0) != (stage != 0)) {
+      return 1;
+    }
+    int8_t stack[HDK_HIP_MAX_FILTER_OPS + 1];
+    int sp = 0;
+    for (int i = 0; i < p->num_filter_ops; ++i) {
+      const uint8_t op = p->filter_ops[i];
+      if (op < HDK_F_AND) {
+        stack[sp++] = eval_qual(c, &p->quals[op], err);
+      } else if (op == HDK_F_NOT) {
+        stack[sp - 1] = orc_logical_not(stack[sp - 1], INT8_MIN);
+      } else {
+        const int8_t b = stack[--sp], a = stack[sp - 1];
+        stack[sp - 1] = op == HDK_F_AND ? orc_logical_and(a, b, INT8_MIN) : orc_logical_or(a, b, INT8_MIN);
+      }
+    }
+    return sp == 1 && stack[0] == 1;
+  }
+  for (int q = 0; q < p->num_quals; ++q) {
+    if ((p->quals[q].after_joins != 0) == (stage != 0) && eval_qual(c, &p->quals[q], err) != 1) {
+      return 0;
+    }
+  }
+  return 1;
 }
 
 static inline size_t columnar_keys_bytes(const hdk_hip_plan* p, uint32_t entry_count) {
@@ -1596,10 +1659,8 @@ static int32_t join_level(orc_row_ctx* c, const int64_t* join_hash_tables, int l
                           void* arg, int32_t* err) {
   const hdk_hip_plan* p = c->plan;
   if (level == p->num_joins) {
-    for (int q = 0; q < p->num_quals; ++q) {
-      if (p->quals[q].after_joins && eval_qual(c, &p->quals[q], err) != 1) {
-        return 0;
-      }
+    if (!filter_pass(c, 1, err)) {
+      return 0;
     }
     return body(c, arg, err);
   }
@@ -1628,11 +1689,8 @@ static int32_t join_level(orc_row_ctx* c, const int64_t* join_hash_tables, int l
  * `*err` collects the row's soft error (division by zero) */
 static int32_t drive_row(orc_row_ctx* c, const int64_t* join_hash_tables, orc_row_body body, void* arg,
                          int32_t* err) {
-  const hdk_hip_plan* p = c->plan;
-  for (int q = 0; q < p->num_quals; ++q) {
-    if (!p->quals[q].after_joins && eval_qual(c, &p->quals[q], err) != 1) {
-      return 0;
-    }
+  if (!filter_pass(c, 0, err)) {
+    return 0;
   }
   return join_level(c, join_hash_tables, 0, body, arg, err);
 }

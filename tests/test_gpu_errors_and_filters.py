@@ -1,0 +1,155 @@
+"""Error protocol and filter logic on the device: OR / NOT filters against the oracle;
+ERR_DIV_BY_ZERO, ERR_OVERFLOW_OR_UNDERFLOW (checked + - *, QE/ArithmeticIR.cpp:277-520), ERR_INTERRUPTED and
+ERR_OUT_OF_TIME (QE/cuda_mapd_rt.cu:105-148) reported through ERROR_CODE[0] with the reference's codes
+(QE/Execute.h:1019-1031), whatever kernel runs the plan."""
+import numpy as np
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd._lib import HdkHipError
+from hdk_amd.ir import Agg, And, Cmp, ColRef, KeyRef, Lit, Not, Or, Proj, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+from test_gpu_baseline import _check_rows
+from util import assert_buffers_equal, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+STRATEGIES = (0, A.LAUNCH_FORCE_GENERIC, A.LAUNCH_FORCE_SCALAR, A.LAUNCH_FORCE_GLOBAL_ATOMICS)
+
+
+def _table(n=300_000, seed=5):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-50, 50, n).astype(np.int32)
+    a[rng.random(n) < 0.1] = A.NULL_INT
+    b = rng.integers(-50, 50, n).astype(np.int64)
+    b[rng.random(n) < 0.1] = A.NULL_BIGINT
+    d = rng.normal(size=n)
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 40, n).astype(np.int64), "a": a, "b": b, "d": d,
+                          "big": rng.integers(0, 9000, n).astype(np.int64) * (2**34)}, fragment_size=70_000)
+    return st
+
+
+def test_or_not_filters_match_the_oracle(oracle, gpu_executor_factory):
+    st = _table()
+    A_, B_, D_ = ColRef("a"), ColRef("b"), ColRef("d")
+    filters = [
+        [Or(Cmp(A_, "<", Lit(0)), Cmp(B_, ">", Lit(5)))],
+        [Not(Or(Cmp(A_, "<", Lit(0)), Cmp(B_, ">", Lit(5))))],
+        [Or(And(Cmp(A_, ">=", Lit(-5)), Cmp(A_, "<=", Lit(5))), Not(Cmp(D_, "<", Lit(0.25)))), Cmp(B_, "<>", Lit(3))],
+    ]
+    for quals in filters:
+        # perfect hash, open addressing, non-grouped, projection
+        queries = [
+            QueryUnit("t", quals=quals, groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("count", None, "c"),
+                                                                       Agg("sum", ColRef("b"), "s"), Agg("avg", D_, "ad")]),
+            QueryUnit("t", quals=quals, groupby=[ColRef("big")], force_baseline=True, baseline_entry_count=30_011,
+                      targets=[KeyRef(0, "k"), Agg("count", None, "c"), Agg("min", ColRef("b"), "mn")]),
+            QueryUnit("t", quals=quals, targets=[Agg("count", None, "c"), Agg("sum", ColRef("a"), "s")]),
+        ]
+        for q in queries:
+            cp, want, err = run_oracle(oracle, st, q)
+            assert err == 0 and cp.plan.num_filter_ops > 0
+            res = gpu_executor_factory(st).execute(cp)
+            if cp.plan.query_kind == A.Q_BASELINE_HASH:
+                _check_rows(cp, res.buffer, want)
+            else:
+                assert_buffers_equal(cp, res.buffer, want)
+        from test_gpu_projection import _sorted_rows
+        from test_projection import run_projection_oracle
+        qp = QueryUnit("t", quals=quals, targets=[Proj(ColRef("k"), "k"), Proj(ColRef("b"), "b")], output_columnar=True)
+        cp, want, err, nrows = run_projection_oracle(oracle, st, qp)
+        res = gpu_executor_factory(st).execute(cp)
+        assert err == 0 and res.total_matched == nrows
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
+
+
+def _expect_error(oracle, gpu_executor_factory, st, q, code):
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == code, err
+    for flags in STRATEGIES:
+        if flags == A.LAUNCH_FORCE_GLOBAL_ATOMICS and cp.plan.query_kind == A.Q_NON_GROUPED:
+            continue
+        with pytest.raises(HdkHipError) as ei:
+            gpu_executor_factory(st).execute(cp, flags=flags)
+        assert ei.value.code == code, (flags, ei.value.code)
+
+
+def test_division_by_zero_is_reported(oracle, gpu_executor_factory):
+    st = _table()
+    for q in (QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("b") / ColRef("a"))]),
+              QueryUnit("t", quals=[Cmp(ColRef("b") % ColRef("a"), "=", Lit(1))], targets=[Agg("count")]),
+              QueryUnit("t", targets=[Agg("sum", ColRef("d") / ColRef("a"))])):
+        _expect_error(oracle, gpu_executor_factory, st, q, A.ERR_DIV_BY_ZERO)
+
+
+def test_integer_overflow_is_reported(oracle, gpu_executor_factory):
+    """+ - * are checked in the operation's SQL type like the reference's generated code: int32 * int32 overflows at 32
+    bits although the value would fit the int64 it is carried in; int64 at 64 bits; rows with a NULL operand are not
+    checked; the same expressions on values that fit give results and no error."""
+    rng = np.random.default_rng(6)
+    n = 200_000
+    x32 = rng.integers(-60_000, 60_000, n).astype(np.int32)
+    y32 = rng.integers(-60_000, 60_000, n).astype(np.int32)
+    x64 = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    small = rng.integers(-1000, 1000, n).astype(np.int32)
+    y32n = y32.copy()
+    y32n[:] = A.NULL_INT  # every product has a NULL operand: nothing to check, nothing overflows
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 10, n).astype(np.int64), "x32": x32, "y32": y32, "x64": x64, "small": small,
+                          "y32n": y32n}, fragment_size=60_000)
+    bad = [QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("x32") * ColRef("y32"))]),
+           QueryUnit("t", targets=[Agg("max", ColRef("x64") * ColRef("x64"))]),
+           QueryUnit("t", quals=[Cmp(ColRef("x32") + Lit(2_147_480_000), ">", Lit(0))], targets=[Agg("count")]),
+           QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("min", ColRef("x64") * Lit(2**30))])]
+    for q in bad:
+        _expect_error(oracle, gpu_executor_factory, st, q, A.ERR_OVERFLOW_OR_UNDERFLOW)
+    good = [QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("small") * ColRef("small"))]),
+            QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("x32") * ColRef("y32n")),
+                                                          Agg("count", ColRef("x32") * ColRef("y32n"))]),
+            QueryUnit("t", targets=[Agg("sum", ColRef("x64") + ColRef("x64"))])]
+    for q in good:
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        for flags in STRATEGIES[:3]:
+            assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=flags).buffer, want)
+
+
+def test_interrupt_and_watchdog(oracle, gpu_executor_factory):
+    """hdk_hip_set_interrupt + HDK_HIP_LAUNCH_CHECK_INTERRUPT -> ERR_INTERRUPTED; watchdog_ms -> ERR_OUT_OF_TIME; a
+    launch that asks for neither is not affected by a raised flag; re-arming gives the normal result again."""
+    rng = np.random.default_rng(8)
+    n = 8_000_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 50, n).astype(np.int64), "v": rng.integers(-100, 100, n).astype(np.int64),
+                          "big": rng.integers(0, 200_000, n).astype(np.int64) * (2**33)}, fragment_size=1_000_000)
+    shapes = [(QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v"))]), (0, A.LAUNCH_FORCE_GENERIC,
+                                                                                                     A.LAUNCH_FORCE_SCALAR)),
+              (QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v") + ColRef("k"))]), (0,)),
+              (QueryUnit("t", groupby=[ColRef("big")], force_baseline=True, baseline_entry_count=600_011,
+                         targets=[KeyRef(0), Agg("sum", ColRef("v"))]), (0, A.LAUNCH_FORCE_GENERIC, A.LAUNCH_FORCE_PARTITIONED)),
+              (QueryUnit("t", quals=[Cmp(ColRef("v"), ">", Lit(90))], targets=[Proj(ColRef("k"), "k")], output_columnar=True),
+               (0, A.LAUNCH_FORCE_GENERIC, A.LAUNCH_FORCE_SCALAR))]
+    ex = gpu_executor_factory(st)
+    try:
+        for q, flag_set in shapes:
+            cp = ex.compile(q)
+            for flags in flag_set:
+                ex.interrupt(1)
+                with pytest.raises(HdkHipError) as ei:
+                    ex.execute(cp, flags=flags | A.LAUNCH_CHECK_INTERRUPT)
+                assert ei.value.code == A.ERR_INTERRUPTED, (flags, ei.value.code)
+                ex.execute(cp, flags=flags)  # not asked to look at the flag: runs to the end
+                ex.interrupt(0)
+                ex.execute(cp, flags=flags | A.LAUNCH_CHECK_INTERRUPT)
+        # watchdog: the row-at-a-time interpreter over 8 M rows takes far longer than 1 ms of device time
+        cp = ex.compile(shapes[0][0])
+        with pytest.raises(HdkHipError) as ei:
+            ex.execute(cp, flags=A.LAUNCH_FORCE_SCALAR, grid=8, watchdog_ms=1)
+        assert ei.value.code == A.ERR_OUT_OF_TIME
+        cp2, want, err = run_oracle(oracle, st, shapes[0][0], frag_ids=[0])
+        res = ex.execute(cp2, frag_ids=[0], watchdog_ms=60_000)
+        assert_buffers_equal(cp2, res.buffer, want)
+    finally:
+        ex.interrupt(0)

@@ -113,3 +113,36 @@ def test_join_vs_sqlite(oracle):
                            "fact": {"fk": fk.tolist(), "val": val.tolist()}},
                           "select dval / 100, sum(val) from fact join dim on fact.fk = dim.key group by dval / 100"))
     assert got == want
+
+
+def test_or_not_filters_vs_sqlite(oracle):
+    """OR / NOT over comparisons with NULLs: three-valued logic (logical_or / logical_not, QE/RuntimeFunctions.cpp:355-384)
+    through the plan's filter program, against SQLite on the same rows."""
+    from hdk_amd.ir import And, Not, Or
+    rng = np.random.default_rng(44)
+    n = 4000
+    a = [None if rng.random() < 0.15 else int(x) for x in rng.integers(-20, 20, n)]
+    b = [None if rng.random() < 0.15 else int(x) for x in rng.integers(-20, 20, n)]
+    d = [None if rng.random() < 0.15 else float(x) for x in rng.normal(size=n)]
+    k = rng.integers(0, 5, n).tolist()
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"a": pa.array(a, pa.int32()), "b": pa.array(b, pa.int64()), "d": pa.array(d, pa.float64()),
+                              "k": pa.array(k, pa.int16())}), "t", fragment_size=900)
+    A_, B_, D_ = ColRef("a"), ColRef("b"), ColRef("d")
+    cases = [
+        ([Or(Cmp(A_, "<", Lit(0)), Cmp(B_, ">", Lit(5)))], "a < 0 or b > 5"),
+        ([Not(Cmp(A_, "<", Lit(0)))], "not (a < 0)"),
+        ([Not(Or(Cmp(A_, "<", Lit(0)), Cmp(B_, ">", Lit(5))))], "not (a < 0 or b > 5)"),
+        ([Or(And(Cmp(A_, ">=", Lit(-5)), Cmp(A_, "<=", Lit(5))), Not(Cmp(D_, "<", Lit(0.25)))), Cmp(B_, "<>", Lit(3))],
+         "((a >= -5 and a <= 5) or not (d < 0.25)) and b <> 3"),
+        ([Or(Cmp(A_, "=", B_), Or(Cmp(A_, "<", Lit(-15)), Not(Cmp(B_, "<=", Lit(10)))))], "a = b or a < -15 or not (b <= 10)"),
+    ]
+    for quals, where in cases:
+        q = QueryUnit("t", quals=quals, groupby=[ColRef("k")],
+                      targets=[KeyRef(0, "k"), Agg("count", None, "c"), Agg("sum", ColRef("b"), "s")])
+        cp, buf, err = run_oracle(oracle, st, q)
+        assert err == 0 and cp.plan.num_filter_ops > 0
+        got = _rows(rs.to_columns(cp, buf), [0])
+        want = _sqlite({"t": {"a": a, "b": b, "d": d, "k": k}},
+                       f"select k, count(*), sum(b) from t where {where} group by k order by k")
+        assert got == [tuple(r) for r in want], where
