@@ -61,9 +61,12 @@ struct HipWorkspaceAllocator {
 
 class HipKernel : public DeviceKernel {
  public:
+  // default_grid: what HipMgr::getGridSize() answers; Executor::gridSize() hands that back through KernelOptions unless
+  // exec.override_gpu_grid_size is set (QE/Execute.cpp gridSize, QE/QueryExecutionContext.cpp:307-312)
   HipKernel(const HipPlanContext* ctx, int device_id, HipWorkspaceAllocator* allocator, uint64_t total_rows = 0,
-            bool timed = false)
-      : ctx_(ctx), device_id_(device_id), allocator_(allocator), total_rows_(total_rows), timed_(timed) {}
+            bool timed = false, unsigned default_grid = 0)
+      : ctx_(ctx), device_id_(device_id), allocator_(allocator), total_rows_(total_rows), timed_(timed),
+        default_grid_(default_grid) {}
 
   // kernelParams: the 12 device pointers of QueryExecutionContext::prepareKernelParams
   // (QE/QueryExecutionContext.h:111-125), same order, same contents
@@ -72,20 +75,32 @@ class HipKernel : public DeviceKernel {
       throw std::runtime_error("HipKernel: expected the 12-pointer kernel parameter block");
     }
     hdk_hip_kernel_options o{};
-    o.grid_dim_x = 0;  // CudaMgr's 2 x #SM grid is not what the persistent kernels want: let the library size it
+    // The library sizes its persistent grids per kernel (blocks that are resident); a grid HDK was
+    // explicitly configured with (anything but the manager's own answer) is passed on.  ko.literalsOffset /
+    // ko.hoistLiterals have nothing to act on: literals live in the plan, kernelParams[LITERALS] is not read.
+    o.grid_dim_x = (default_grid_ && ko.gridDimX != default_grid_) ? ko.gridDimX : 0;
     o.block_dim_x = ko.blockDimX;
     o.shared_mem_bytes = ko.sharedMemBytes;
-    o.flags = timed_ ? HDK_HIP_LAUNCH_RECORD_EVENTS : 0u;
+    o.flags = (timed_ ? HDK_HIP_LAUNCH_RECORD_EVENTS : 0u) | (interruptible_ ? HDK_HIP_LAUNCH_CHECK_INTERRUPT : 0u);
     o.total_rows = total_rows_;
+    o.watchdog_ms = watchdog_ms_;
     size_t ws_bytes = 0;
     check(hdk_hip_workspace_size(&ctx_->plan, &o, device_id_, &ws_bytes));
     int8_t* ws = allocator_->alloc(ws_bytes);
     check(hdk_hip_launch(&ctx_->plan, kernelParams.data(), &o, device_id_, /*stream=*/nullptr, ws, ws_bytes));
   }
 
-  // the kernels are bounded scans: no dynamic watchdog / interrupt flag to arm
-  void initializeDynamicWatchdog(bool, uint64_t, size_t) override {}
-  void initializeRuntimeInterrupter() override {}
+  // QueryExecutionContext::launchGpuCode calls these before launch() when the watchdog / interrupt are enabled
+  // (QE/QueryExecutionContext.cpp:314-340).  time_limit is the budget in ms (g_dynamic_watchdog_time_limit); the
+  // CUDA path converts it to cycles, the library counts the 100 MHz realtime clock itself.
+  void initializeDynamicWatchdog(bool could_interrupt, uint64_t /*cycle_budget*/, size_t time_limit) override {
+    watchdog_ms_ = static_cast<uint32_t>(time_limit);
+    interruptible_ = interruptible_ || could_interrupt;
+  }
+  void initializeRuntimeInterrupter() override {
+    check(hdk_hip_set_interrupt(device_id_, 0));  // re-arm: Executor::interrupt() raises it (hdk_hip_set_interrupt(dev, 1))
+    interruptible_ = true;
+  }
 
   std::unique_ptr<DeviceClock> make_clock() override { return std::make_unique<HipDeviceClock>(device_id_); }
 
@@ -100,6 +115,9 @@ class HipKernel : public DeviceKernel {
   HipWorkspaceAllocator* allocator_;
   uint64_t total_rows_;
   bool timed_;
+  unsigned default_grid_;
+  uint32_t watchdog_ms_{0};
+  bool interruptible_{false};
 };
 
 // the case create_device_kernel (QE/DeviceKernel.cpp:211-225) gains:

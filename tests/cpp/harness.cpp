@@ -1,0 +1,337 @@
+// C++ harness: the HDK-side bindings of hdk_amd/glue/ EXECUTED, with no Python between main() and the kernels.
+//
+//   GpuMgr (reference DataMgr/GpuMgr.h, the real header where /root/reference exists)  <- hip_mgr::HipMgr
+//   DeviceKernel / KernelOptions / CompilationContext (shaped like QE/DeviceKernel.h:25-65, hdk_decls.h) <- hip_rt::HipKernel
+//   QueryMemoryDescriptor accessors (qmd_standin.h)  -> hip_rt::make_plan -> hdk_hip_plan
+//   init_group_by_buffer_on_device / fill_hash_join_buff_on_device forwards (HipRuntimeOnDevice.h)
+//
+// It walks the steps of QueryExecutionContext::launchGpuCode (QE/QueryExecutionContext.cpp:236-480): fetch chunks to
+// the device, prepareKernelParams (the 12 pointers, :788-964), initialise the output buffer, create_device_kernel,
+// kernel->launch(ko, params), copy error codes and the buffer back.  Two steps:
+//   c2    SELECT key, SUM(val), COUNT(*) FROM t GROUP BY key           (GroupByPerfectHash, row-wise, 4 fragments)
+//   join  SELECT SUM(val + dval), COUNT(*) FROM fact JOIN dim ON fk = key   (NonGroupedAggregate, one-to-one table)
+// and the runtime interrupt.  Results go to stdout, one line per group; tests/test_gpu_cpp_harness.py compares them
+// with tests/golden/cpp_harness_output.txt (made by tests/golden/gen_cpp_harness_golden.py with numpy).
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "hdk_decls.h"
+#include "qmd_standin.h"
+
+#include "HipKernel.h"
+#include "HipMgr.h"
+#include "HipPlanBuilder.h"
+#include "HipRuntimeOnDevice.h"
+
+namespace {
+
+constexpr int64_t kNullBigint = std::numeric_limits<int64_t>::min();
+constexpr int kDevice = 0;
+
+uint64_t mix(uint64_t x) {  // splitmix64 finaliser: the data is a pure function of the row number
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+int64_t gen_val(uint64_t i) {
+  if (mix(i + (1ull << 41)) % 32 == 0) return kNullBigint;
+  return static_cast<int64_t>(mix(i + (1ull << 40)) % 2000001) - 1000000;
+}
+
+// what HDK reaches through Executor::getDataMgr(): the device manager and the per-kernel allocator
+struct DeviceServices : hip_rt::HipWorkspaceAllocator {
+  explicit DeviceServices(hip_mgr::HipMgr* m) : mgr(m) {}
+  ~DeviceServices() override {
+    for (int8_t* p : owned) mgr->freeDeviceMem(p);
+  }
+  int8_t* alloc(size_t num_bytes) override {
+    int8_t* p = mgr->allocateDeviceMem(num_bytes ? num_bytes : 8, kDevice);
+    owned.push_back(p);
+    return p;
+  }
+  template <class T>
+  int8_t* upload(const std::vector<T>& host) {
+    int8_t* d = alloc(host.size() * sizeof(T));
+    mgr->copyHostToDevice(d, reinterpret_cast<const int8_t*>(host.data()), host.size() * sizeof(T), kDevice);
+    return d;
+  }
+  template <class T>
+  std::vector<T> download(const int8_t* dev, size_t n) {
+    std::vector<T> host(n);
+    mgr->copyDeviceToHost(reinterpret_cast<int8_t*>(host.data()), dev, n * sizeof(T), kDevice);
+    return host;
+  }
+  hip_mgr::HipMgr* mgr;
+  std::vector<int8_t*> owned;
+  uint64_t rows_in_step{0};  // QueryExecutionContext knows the fragments of the step
+};
+DeviceServices* g_services = nullptr;
+
+}  // namespace
+
+// the factory of QE/DeviceKernel.cpp:211-225 with the case it gains
+std::unique_ptr<DeviceKernel> create_device_kernel(const CompilationContext* ctx, GpuMgrPlatform platform, int device_id) {
+  if (platform == HDK_GPU_PLATFORM_HIP) {
+    const auto* hip_ctx = dynamic_cast<const hip_rt::HipPlanContext*>(ctx);
+    if (!hip_ctx) throw std::runtime_error("create_device_kernel: not a HIP plan context");
+    return std::make_unique<hip_rt::HipKernel>(hip_ctx, device_id, g_services, g_services->rows_in_step, /*timed=*/true,
+                                               g_services->mgr->getGridSize());
+  }
+  throw std::runtime_error("create_device_kernel: platform not built");
+}
+
+namespace {
+
+struct ParamBlock {
+  std::vector<int8_t*> params;
+  int8_t* error_code;
+};
+
+// prepareKernelParams: col_buffers[frag][col], NUM_FRAGMENTS, NUM_ROWS / FRAG_ROW_OFFSETS [frag * num_tables + table] ...
+ParamBlock prepare_kernel_params(DeviceServices& dev, const std::vector<std::vector<int8_t*>>& col_buffers,
+                                 const std::vector<int64_t>& num_rows, const std::vector<uint64_t>& frag_offsets,
+                                 uint32_t num_tables, int32_t max_matched, const std::vector<int64_t>& init_agg_vals,
+                                 const std::vector<int8_t*>& group_by_buffers, int8_t* join_hash_table) {
+  const size_t nfrag = col_buffers.size();
+  std::vector<int8_t*> flat;
+  for (const auto& f : col_buffers) flat.insert(flat.end(), f.begin(), f.end());
+  int8_t* d_flat = dev.upload(flat);
+  std::vector<int8_t*> frag_ptrs(nfrag);
+  const size_t ncols = nfrag ? col_buffers[0].size() : 0;
+  for (size_t f = 0; f < nfrag; ++f) frag_ptrs[f] = d_flat + f * ncols * sizeof(int8_t*);
+  ParamBlock pb;
+  pb.params.assign(HDK_KP_COUNT, nullptr);
+  pb.params[HDK_KP_COL_BUFFERS] = dev.upload(frag_ptrs);
+  pb.params[HDK_KP_NUM_FRAGMENTS] = dev.upload(std::vector<uint64_t>{nfrag});
+  pb.params[HDK_KP_LITERALS] = nullptr;
+  pb.params[HDK_KP_NUM_ROWS] = dev.upload(num_rows);
+  pb.params[HDK_KP_FRAG_ROW_OFFSETS] = dev.upload(frag_offsets);
+  pb.params[HDK_KP_MAX_MATCHED] = dev.upload(std::vector<int32_t>{max_matched});
+  pb.params[HDK_KP_TOTAL_MATCHED] = dev.upload(std::vector<int32_t>{0, 0});
+  pb.params[HDK_KP_INIT_AGG_VALS] = dev.upload(init_agg_vals);
+  pb.params[HDK_KP_GROUPBY_BUF] = dev.upload(group_by_buffers);
+  pb.error_code = dev.upload(std::vector<int32_t>{0});
+  pb.params[HDK_KP_ERROR_CODE] = pb.error_code;
+  pb.params[HDK_KP_NUM_TABLES] = dev.upload(std::vector<uint32_t>{num_tables});
+  pb.params[HDK_KP_JOIN_HASH_TABLES] = join_hash_table;
+  return pb;
+}
+
+KernelOptions kernel_options(const hip_mgr::HipMgr& mgr) {  // Executor::gridSize()/blockSize() defaults
+  KernelOptions ko;
+  ko.gridDimX = mgr.getGridSize();
+  ko.blockDimX = mgr.getMaxBlockSize();
+  return ko;
+}
+
+int run_c2(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 4, kFragRows = 500000, kKeys = 64;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int64_t> key(kFragRows), val(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      key[r] = static_cast<int64_t>(mix(i) % kKeys);
+      val[r] = gen_val(i);
+    }
+    col_buffers.push_back({dev.upload(key), dev.upload(val)});
+    num_rows.push_back(kFragRows);
+    frag_offsets.push_back(f * kFragRows);
+  }
+
+  // what MemoryLayoutBuilder decides for one BIGINT key with range [0, 63] and three 8-byte slots
+  QmdStandIn qmd;
+  qmd.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+  qmd.group_col_widths_ = {8};
+  qmd.padded_slot_widths_ = {8, 8, 8};
+  qmd.entry_count_ = kKeys;
+  qmd.min_val_ = 0;
+  qmd.max_val_ = kKeys - 1;
+
+  hip_rt::HipWorkUnit wu;
+  wu.cols = {{0, 8, HDK_COL_INT}, {0, 8, HDK_COL_INT}};
+  wu.keys = {hip_rt::column_expr(0, kNullBigint, false)};
+  hip_rt::HipTargetDesc key_t{HDK_AGG_ID, true, hip_rt::column_expr(0, kNullBigint, false), false, false, 0, 0};
+  hip_rt::HipTargetDesc sum_t{HDK_AGG_SUM, true, hip_rt::column_expr(1, kNullBigint, true), true, false, -1, kNullBigint};
+  hip_rt::HipTargetDesc cnt_t{HDK_AGG_COUNT, false, hdk_hip_expr{}, false, false, -1, 0};
+  wu.targets = {key_t, sum_t, cnt_t};
+  const hip_rt::HipPlanContext ctx(hip_rt::make_plan(wu, qmd));
+
+  const std::vector<int64_t> init_agg_vals{0, kNullBigint, 0};  // init_agg_val_vec: key slot, nullable SUM, COUNT
+  int8_t* out = dev.alloc(qmd.getBufferSizeBytes());
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, 0, init_agg_vals, {out}, nullptr);
+  const KernelOptions ko = kernel_options(mgr);
+  hip_rt::init_group_by_buffer_on_device_hip(reinterpret_cast<int64_t*>(out),
+                                             reinterpret_cast<const int64_t*>(pb.params[HDK_KP_INIT_AGG_VALS]),
+                                             static_cast<uint32_t>(qmd.getEntryCount()), 1, 8,
+                                             static_cast<uint32_t>(qmd.getRowSize() / 8), false, 1, ko.blockDimX,
+                                             ko.gridDimX, kDevice);
+
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  auto clock = kernel->make_clock();
+  clock->start();
+  kernel->launch(ko, pb.params);
+  const int ms = clock->stop();
+  mgr.synchronizeStream(kDevice);
+  const int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  std::printf("c2 error_code %d\n", err);
+  const size_t quads = qmd.getRowSize() / 8;
+  const auto rows = dev.download<int64_t>(out, quads * qmd.getEntryCount());
+  for (size_t e = 0; e < qmd.getEntryCount(); ++e) {
+    const int64_t* row = &rows[e * quads];
+    if (row[0] == std::numeric_limits<int64_t>::max()) continue;  // EMPTY_KEY_64
+    std::printf("c2 key %" PRId64 " sum %" PRId64 " count %" PRId64 "\n", row[qmd.getColOffInBytes(0) / 8],
+                row[qmd.getColOffInBytes(1) / 8], row[qmd.getColOffInBytes(2) / 8]);
+  }
+  char names[256];
+  hdk_hip_kernel_options o{};
+  o.total_rows = dev.rows_in_step;
+  hip_rt::check(hdk_hip_describe_launch(&ctx.plan, &o, kDevice, names, sizeof(names)));
+  std::fprintf(stderr, "c2: %s, %d ms\n", names, ms);
+  g_services = nullptr;
+  return err;
+}
+
+int run_join(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 3, kFragRows = 400000, kDimRows = 1000, kFkDomain = 1200;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+
+  // inner table: one fragment; key is a permutation of [0, 1000), so the table is one-to-one
+  std::vector<int64_t> dkey(kDimRows), dval(kDimRows);
+  for (size_t i = 0; i < kDimRows; ++i) {
+    dkey[i] = static_cast<int64_t>((i * 37) % kDimRows);
+    dval[i] = static_cast<int64_t>(mix(i + (1ull << 42)) % 1000);
+  }
+  int8_t* d_dkey = dev.upload(dkey);
+  int8_t* d_dval = dev.upload(dval);
+
+  // PerfectJoinHashTable::reify -> PerfectHashTableBuilder::initOneToOneHashTableOnGpu (PerfectHashTableBuilder.h:93-145)
+  const JoinChunk chunk{d_dkey, kDimRows, 0};
+  int8_t* d_chunk = dev.upload(std::vector<JoinChunk>{chunk});
+  const JoinColumn join_column{d_chunk, sizeof(JoinChunk), 1, kDimRows, 8};
+  const JoinColumnTypeInfo type_info{8, 0, static_cast<int64_t>(kDimRows) - 1, kNullBigint, false, 0, Signed};
+  int32_t* hash_table = reinterpret_cast<int32_t*>(dev.alloc(kDimRows * sizeof(int32_t)));
+  int8_t* d_build_err = dev.upload(std::vector<int32_t>{0});
+  hip_rt::init_hash_join_buff_on_device(hash_table, kDimRows, -1, kDevice);
+  hip_rt::fill_hash_join_buff_on_device(hash_table, -1, false, reinterpret_cast<int*>(d_build_err), join_column, type_info,
+                                        kDevice);
+  mgr.synchronizeStream(kDevice);
+  const int32_t build_err = dev.download<int32_t>(d_build_err, 1)[0];
+  std::printf("join build_error %d\n", build_err);
+
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int64_t> fk(kFragRows), val(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      const uint64_t h = mix(i + (1ull << 43));
+      fk[r] = (h >> 32) % 64 == 0 ? kNullBigint : static_cast<int64_t>(h % kFkDomain);
+      val[r] = gen_val(i + (1ull << 44));
+    }
+    col_buffers.push_back({dev.upload(fk), dev.upload(val), d_dval});  // inner columns: the linearised column, per fragment
+    num_rows.push_back(kFragRows);
+    num_rows.push_back(kDimRows);
+    frag_offsets.push_back(f * kFragRows);
+    frag_offsets.push_back(0);
+  }
+
+  QmdStandIn qmd;
+  qmd.query_desc_type_ = QueryDescriptionType::NonGroupedAggregate;
+  qmd.padded_slot_widths_ = {8, 8};
+
+  hip_rt::HipWorkUnit wu;
+  wu.cols = {{0, 8, HDK_COL_INT}, {0, 8, HDK_COL_INT}, {1, 8, HDK_COL_INT}};
+  hdk_hip_join jn;
+  std::memset(&jn, 0, sizeof(jn));
+  jn.outer_key = hip_rt::column_expr(0, kNullBigint, true);
+  jn.min_key = type_info.min_val;
+  jn.max_key = type_info.max_val;
+  jn.null_val = kNullBigint;
+  jn.kind = HDK_JOIN_ONE_TO_ONE;
+  jn.type = HDK_JOIN_INNER;
+  jn.null_mode = HDK_JOIN_NULL_NULLABLE;
+  jn.table_idx = 0;
+  jn.key_component_count = 1;
+  jn.key_component_width = 8;
+  jn.entry_count = kDimRows;
+  wu.joins = {jn};
+  hdk_hip_expr val_plus_dval = hip_rt::column_expr(1, kNullBigint, true);  // val + dval, BIGINT, checked
+  val_plus_dval.nsteps = 1;
+  val_plus_dval.steps[0].op = HDK_OP_ADD;
+  val_plus_dval.steps[0].out_class = HDK_VC_INT;
+  val_plus_dval.steps[0].rhs = hip_rt::column_expr(2, kNullBigint, false).leaf0;
+  val_plus_dval.steps[0].null_out = kNullBigint;
+  val_plus_dval.steps[0].check_width = 8;
+  hip_rt::HipTargetDesc sum_t{HDK_AGG_SUM, true, val_plus_dval, true, false, -1, kNullBigint};
+  hip_rt::HipTargetDesc cnt_t{HDK_AGG_COUNT, false, hdk_hip_expr{}, false, false, -1, 0};
+  wu.targets = {sum_t, cnt_t};
+  const hip_rt::HipPlanContext ctx(hip_rt::make_plan(wu, qmd));
+
+  // non-grouped: out_vec, one int64 per slot, starting at init_agg_vals (QueryExecutionContext.cpp:452-458)
+  const std::vector<int64_t> init_agg_vals{kNullBigint, 0};
+  int8_t* out = dev.upload(init_agg_vals);
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 2, 0, init_agg_vals, {out, out + 8},
+                                        reinterpret_cast<int8_t*>(hash_table));
+  const KernelOptions ko = kernel_options(mgr);
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel->initializeRuntimeInterrupter();  // launchGpuCode arms it when the interrupt is enabled (:330-340)
+  kernel->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  const auto res = dev.download<int64_t>(out, 2);
+  std::printf("join error_code %d\n", err);
+  std::printf("join sum %" PRId64 " count %" PRId64 "\n", res[0], res[1]);
+
+  // Executor::interrupt() while the step is queued: the launch stops with ERR_INTERRUPTED (QE/Execute.h:1029)
+  mgr.copyHostToDevice(out, reinterpret_cast<const int8_t*>(init_agg_vals.data()), 16, kDevice);
+  auto kernel2 = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel2->initializeRuntimeInterrupter();
+  hip_rt::check(hdk_hip_set_interrupt(kDevice, 1));
+  kernel2->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  const int32_t ierr = dev.download<int32_t>(pb.error_code, 1)[0];
+  std::printf("interrupt error_code %d\n", ierr);
+  hip_rt::check(hdk_hip_set_interrupt(kDevice, 0));
+
+  char names[256];
+  hdk_hip_kernel_options o{};
+  o.total_rows = dev.rows_in_step;
+  hip_rt::check(hdk_hip_describe_launch(&ctx.plan, &o, kDevice, names, sizeof(names)));
+  std::fprintf(stderr, "join: %s\n", names);
+  g_services = nullptr;
+  return err || build_err || ierr != HDK_HIP_ERR_INTERRUPTED;
+}
+
+}  // namespace
+
+int main() {
+  try {
+    hip_mgr::HipMgr mgr(1, 0);
+    GpuMgr& as_reference_interface = mgr;  // everything below could go through the reference's interface
+    std::fprintf(stderr, "platform %d, %d device(s), wave %d, grid %u, block %u\n",
+                 static_cast<int>(as_reference_interface.getPlatform()), as_reference_interface.getDeviceCount(),
+                 static_cast<int>(as_reference_interface.getSubGroupSize()), as_reference_interface.getGridSize(),
+                 as_reference_interface.getMaxBlockSize());
+    int rc = run_c2(mgr);
+    rc |= run_join(mgr);
+    return rc ? 1 : 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "harness failed: %s\n", e.what());
+    return 2;
+  }
+}

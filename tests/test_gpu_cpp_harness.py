@@ -1,0 +1,25 @@
+"""The executed C++ binding: tests/cpp/harness.cpp drives HipMgr (over the reference's GpuMgr interface), make_plan
+(from a QueryMemoryDescriptor-shaped object), the *_on_device forwards and HipKernel::launch(ko, params) with the
+12-pointer block -- no Python between main() and the kernels.  Its output is compared with the committed golden
+(tests/golden/cpp_harness_output.txt, computed with numpy by tests/golden/gen_cpp_harness_golden.py)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "cpp_harness_output.txt")
+
+
+@pytest.mark.gpu
+def test_cpp_harness_matches_the_golden():
+    # make rebuilds only when a source is newer than the binary that travelled with the snapshot
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "--no-print-directory"])
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "harness")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = open(GOLDEN).read().split("\n")
+    got = r.stdout.strip().split("\n")
+    assert got == [w for w in want if w], r.stderr
+    # the steps ran on the specialised kernels, not on an interpreter fallback
+    assert "hdk_scan_agg" in r.stderr
