@@ -29,6 +29,7 @@ NULL_SMALLINT = -(2**15)
 NULL_TINYINT = -(2**7)
 NULL_DOUBLE_BITS = 0x0010000000000000  # DBL_MIN
 NULL_FLOAT_BITS = 0x00800000  # FLT_MIN
+FP_SLOT_NONE, FP_SLOT_DOUBLE, FP_SLOT_FLOAT = 0, 1, 2  # hdk_hip_fp_slot (target.arg_is_fp)
 JOIN_INVALID_SLOT = -1
 
 # --- status codes (reference QueryEngine/Execute.h:1019-1031 + library-level) ----------------

@@ -685,6 +685,11 @@ HDK_DEV int64_t eval_target_arg(const RowCtx& c, const hdk_hip_target& tg, bool&
   return v;
 }
 
+// the float sentinel of a float-accumulator target: tg.null_val carries it widened to double (what the scan compares)
+HDK_DEV int32_t float_slot_null(const hdk_hip_target& tg) {
+  return __float_as_int(static_cast<float>(bits_to_double(tg.null_val)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // columnar layout helpers (RS/QueryMemoryDescriptor.cpp getColOffInBytes)
 // ---------------------------------------------------------------------------------------------

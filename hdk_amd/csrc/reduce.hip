@@ -55,7 +55,32 @@ HDK_DEV void reduce_slot(const hdk_hip_target& tg, int8_t* this1, int8_t* this2,
     }
   }
   const bool skip = tg.skip_null;
-  if (tg.slot_width == 4) {  // integer only (float32 slots are rejected by validate_plan)
+  if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
+    // get_width_for_slot -> sizeof(float) (QE/ResultSetReduction.cpp:1176-1185): AGGREGATE_ONE_NULLABLE_VALUE on the
+    // low 4 bytes with agg_*_float[_skip_val]; the skip value is the low half of the slot's init value
+    int32_t* s = reinterpret_cast<int32_t*>(this1);
+    const int32_t obits = *reinterpret_cast<const int32_t*>(that1);
+    const int32_t nbits = static_cast<int32_t>(init_val);
+    const float o = __int_as_float(obits);
+    if (skip && o == __int_as_float(nbits)) return;  // `val != skip_val` is a value compare
+    const int32_t old = *s;
+    if (skip && old == nbits) {                      // the accumulator is compared bit-wise
+      *s = obits;
+      return;
+    }
+    const float a = __int_as_float(old);
+    float r;
+    if (agg == HDK_AGG_MIN) {
+      r = (o < a) ? o : a;
+    } else if (agg == HDK_AGG_MAX) {
+      r = (a < o) ? o : a;
+    } else {
+      r = a + o;
+    }
+    *s = __float_as_int(r);
+    return;
+  }
+  if (tg.slot_width == 4) {  // integers
     int32_t* s = reinterpret_cast<int32_t*>(this1);
     const int32_t o = *reinterpret_cast<const int32_t*>(that1);
     const int32_t nv = static_cast<int32_t>(init_val);

@@ -215,7 +215,29 @@ HDK_DEV void apply_value(const hdk_hip_target& tg, int8_t* slot, int64_t partial
     return;  // nothing but NULLs (or no rows): the slot keeps its value
   }
   const int agg = tg.agg;
-  if (tg.slot_width == 4) {  // int32 slots (only integer arguments reach here)
+  if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {  // float accumulator in the slot's low 4 bytes; the partial is a double
+    int32_t* s = reinterpret_cast<int32_t*>(slot);
+    const float v = static_cast<float>(bits_to_double(partial));
+    const int32_t old = *s;
+    if (skip && old == float_slot_null(tg)) {
+      *s = __float_as_int(v);
+      return;
+    }
+    const float o = __int_as_float(old);
+    float r;
+    if (agg == HDK_AGG_MIN) {
+      r = (v < o) ? v : o;
+    } else if (agg == HDK_AGG_MAX) {
+      r = (o < v) ? v : o;
+    } else {
+      // the block partials were summed in double: one rounding to float here (the reference's float atomics
+      // round at every row; tests compare float sums with a tolerance)
+      r = static_cast<float>(static_cast<double>(o) + bits_to_double(partial));
+    }
+    *s = __float_as_int(r);
+    return;
+  }
+  if (tg.slot_width == 4) {  // int32 slots (integer arguments)
     int32_t* s = reinterpret_cast<int32_t*>(slot);
     const int32_t v = static_cast<int32_t>(partial);
     const int32_t nullv = static_cast<int32_t>(tg.null_val);
@@ -502,8 +524,13 @@ int32_t validate_plan(const hdk_hip_plan* p) {
       HDK_REQUIRE(tg.key_idx >= 0 && tg.key_idx < p->key_count,
                   "target %d: HDK_AGG_ID in a group-by plan needs 0 <= key_idx < key_count (got %d)", t, tg.key_idx);
     }
-    if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
-      set_error("float32 aggregate slots are outside the fixed kernel library");
+    HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
+    if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
+      HDK_REQUIRE(tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX || tg.agg == HDK_AGG_AVG,
+                  "target %d: a float accumulator belongs to SUM / MIN / MAX / AVG", t);
+      HDK_REQUIRE(tg.has_arg && tg.arg.vclass == HDK_VC_FP, "target %d: a float accumulator needs a floating-point argument", t);
+    } else if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
+      set_error("a 4-byte slot cannot hold a double: float arguments use arg_is_fp = HDK_FP_SLOT_FLOAT");
       return HDK_HIP_ERR_UNSUPPORTED;
     }
   }
@@ -1071,6 +1098,7 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
       if (tg.slot_width != 0) return false;  // (perfect-hash style key slots: generic kernel)
       continue;
     }
+    if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;  // float accumulators: generic kernel
     BaseFastTarget ft;
     ft.target = t;
     ft.buf_idx = -1;

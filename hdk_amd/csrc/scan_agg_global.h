@@ -62,7 +62,30 @@ HDK_DEV void g_agg64(int agg, bool fp, bool skip, int64_t nullv, int64_t* slot, 
   }
 }
 
-// 4-byte slots: integers only (validate_plan rejects float32 aggregates)
+// float accumulators (takes_float_argument, Shared/TargetInfo.h:170-179): the slot's low 4 bytes hold a float whatever
+// the padded slot width (agg_{sum,min,max}_float[_skip_val]_shared, QE/cuda_mapd_rt.cu:448-480,666-680,981-1030)
+HDK_DEV void g_aggf32(int agg, bool skip, int32_t nullbits, int32_t* slot, float v) {
+  const int32_t vbits = __float_as_int(v);
+  if (skip) {
+    if (atomic_load_i32(slot) == nullbits) {
+      if (atomicCAS(slot, nullbits, vbits) == nullbits) {
+        return;
+      }
+    }
+  }
+  if (agg == HDK_AGG_MIN || agg == HDK_AGG_MAX) {
+    int32_t old = atomic_load_i32(slot);
+    while (agg == HDK_AGG_MIN ? (v < __int_as_float(old)) : (__int_as_float(old) < v)) {
+      const int32_t assumed = old;
+      old = atomicCAS(slot, assumed, vbits);
+      if (old == assumed) break;
+    }
+  } else {
+    atomicAdd(reinterpret_cast<float*>(slot), v);
+  }
+}
+
+// 4-byte slots: integers
 HDK_DEV void g_agg32(int agg, bool skip, int32_t nullv, int32_t* slot, int32_t v) {
   if (skip) {
     if (atomic_load_i32(slot) == nullv) {
@@ -223,7 +246,10 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
           if (tg.agg == HDK_AGG_AVG) {
             g_count(s2, tg.slot2_width);
           }
-          if (tg.slot_width == 4) {
+          if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
+            g_aggf32(tg.agg, tg.skip_null, float_slot_null(tg), reinterpret_cast<int32_t*>(s1),
+                     static_cast<float>(bits_to_double(v)));
+          } else if (tg.slot_width == 4) {
             g_agg32(tg.agg, tg.skip_null, static_cast<int32_t>(tg.null_val), reinterpret_cast<int32_t*>(s1),
                     static_cast<int32_t>(v));
           } else {

@@ -325,6 +325,11 @@ _CMP = {"=": A.CMP_EQ, "==": A.CMP_EQ, "<>": A.CMP_NE, "!=": A.CMP_NE, "<": A.CM
 _AGG = {"count": A.AGG_COUNT, "sum": A.AGG_SUM, "min": A.AGG_MIN, "max": A.AGG_MAX, "avg": A.AGG_AVG}
 
 
+def _bits_to_double(v: int) -> float:
+    import struct
+    return struct.unpack("<d", struct.pack("<q", int(v)))[0]
+
+
 def _agg_init_val(kind: str, arg_t: Optional[Type], nullable: bool, width: int) -> int:
     """get_agg_initial_val (OutputBufferInitialization.cpp:112-258) for an 8/4-byte slot."""
     is_fp = arg_t is not None and arg_t.is_fp
@@ -710,13 +715,17 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                             found = True
                     elif ar.kind != "invalid" and (ar.hi < 0 or ar.lo > 0):
                         found = True
-                elif t.kind == "min":
-                    init_max = np.finfo(np.float64).max if at.is_fp else 2**63 - 1
-                    if ar.kind != "invalid" and ar.hi < init_max:
-                        found = True
-                elif t.kind == "max":
-                    init_min = -np.finfo(np.float64).max if at.is_fp else -(2**63)
-                    if ar.kind != "invalid" and not ar.has_nulls and ar.lo > init_min:
+                elif t.kind in ("min", "max"):
+                    # the reference compares the range with get_agg_initial_val of the (nullable) argument type --
+                    # for a nullable argument that is the NULL sentinel -- and, for fp ranges, with that int64
+                    # REINTERPRETED as a double, 4-byte float patterns included (MemoryLayoutBuilder.cpp:326-394)
+                    fa = at.is_fp and at.size == 4
+                    init = A.to_i64(_agg_init_val(t.kind, at, at.nullable, 4 if fa else 8))
+                    bound = _bits_to_double(init) if ar.kind == "fp" else init
+                    if t.kind == "min":
+                        if ar.kind != "invalid" and ar.hi < bound:
+                            found = True
+                    elif ar.kind != "invalid" and not ar.has_nulls and ar.lo > bound:
                         found = True
                 else:
                     ok = False
@@ -788,16 +797,15 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                     raise QueryMustRunOnCpu(f"{t.kind} over {at.kind}")
             elif t.kind != "count":
                 raise ValueError(f"{t.kind} needs an argument")
-            if at is not None and at.is_fp and at.size == 4 and t.kind != "count":
-                # HDK accumulates float32 arguments in 4-byte float slots (takes_float_argument);
-                # that path is not in the fixed library
-                raise QueryMustRunOnCpu("aggregates over float32 are outside the fixed kernel library")
+            # takes_float_argument (Shared/TargetInfo.h:170-179): SUM / MIN / MAX / AVG over a FLOAT argument
+            # accumulate a float in the slot's low 4 bytes, whatever the padded slot width
+            float_acc = at is not None and at.is_fp and at.size == 4 and t.kind != "count"
             arg_nullable = at.nullable if at is not None else False
             # group-by: the declared nullability decides; non-grouped: always nullable and always
             # *_skip_val (OutputBufferInitialization.cpp:57-60, TargetExprBuilder.cpp:546-551)
             eff_nullable = True if kind == A.Q_NON_GROUPED else arg_nullable
             tg.skip_null = 1 if (t.arg is not None and eff_nullable) else 0
-            tg.arg_is_fp = 1 if (at is not None and at.is_fp) else 0
+            tg.arg_is_fp = A.FP_SLOT_FLOAT if float_acc else (A.FP_SLOT_DOUBLE if (at is not None and at.is_fp) else 0)
             if t.kind == "count":
                 # agg_count[_skip_val]: skip value = the argument type's NULL (widened)
                 tg.null_val = A.to_i64(at.null_as_int64_or_double_bits()) if at is not None else 0
@@ -812,7 +820,12 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                     # SUM / AVG: integer sums are BIGINT (TargetInfo.h:121-135), fp sums DOUBLE
                     nullv = A.NULL_DOUBLE_BITS if at.is_fp else A.NULL_BIGINT
                 tg.null_val = A.to_i64(nullv)
-                if eff_nullable:
+                if float_acc:
+                    # the scan compares doubles (the decoder widens): null_val = the float sentinel widened; the
+                    # slot starts at the 4-byte pattern, sign-extended (OutputBufferInitialization.cpp:52-65)
+                    tg.null_val = A.to_i64(at.null_as_int64_or_double_bits())
+                    iv = _agg_init_val("sum" if t.kind == "avg" else t.kind, at, eff_nullable, 4)
+                elif eff_nullable:
                     iv = nullv
                 else:
                     iv = _agg_init_val("sum" if t.kind == "avg" else t.kind, at, False, 8)
@@ -826,7 +839,7 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
             elif t.kind == "avg":
                 rt = Type("fp", 8, True)
             elif t.kind == "sum":
-                rt = Type("fp", 8, True) if at.is_fp else Type("int", 8, True)
+                rt = Type("fp", at.size, True) if at.is_fp else Type("int", 8, True)
             else:
                 rt = at
             out_cols.append(OutCol(t.name or f"{t.kind}_{ti}", "agg", rt, ti, agg=t.kind,

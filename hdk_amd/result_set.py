@@ -174,12 +174,21 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) 
         if w == 4:
             nullv = int(np.int64(nullv).astype(np.int32))
         nullable = bool(tg.skip_null)
+        float_slot = tg.arg_is_fp == A.FP_SLOT_FLOAT
+        if float_slot:
+            # takes_float_argument: the value is the float in the slot's low 4 bytes (ResultSetIteration.cpp:50-60,
+            # actual_compact_sz = sizeof(float)); NULL when those bits are the float sentinel
+            vals = (vals.astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+            fvals = vals.view(np.float32).astype(np.float64)
+            is_null = vals == np.uint32(A.NULL_FLOAT_BITS)
         if oc.agg == "avg":
             cnt = slots[fs + 1][mask]
             col = []
-            for sv, c in zip(vals.tolist(), cnt.tolist()):
+            for i, (sv, c) in enumerate(zip(vals.tolist(), cnt.tolist())):
                 if c == 0:
                     col.append(None)  # load_avg_*: null when count == 0
+                elif float_slot:
+                    col.append(float(fvals[i]) / c)
                 elif tg.arg_is_fp:
                     col.append(float(np.int64(sv).view(np.float64)) / c)
                 else:
@@ -190,8 +199,10 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) 
             res[oc.name] = col
             continue
         col = []
-        for v in vals.tolist():
-            if nullable and v == nullv:
+        for i, v in enumerate(vals.tolist()):
+            if float_slot:
+                col.append(None if (nullable and is_null[i]) else float(fvals[i]))
+            elif nullable and v == nullv:
                 col.append(None)
             elif tg.arg_is_fp:
                 col.append(float(np.int64(v).view(np.float64)))

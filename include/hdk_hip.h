@@ -279,6 +279,7 @@ enum hdk_hip_agg {
                     Group-by plans: a projected group-by key, `key_idx` names it and `arg` repeats its
                     expression.  Projection plans: any expression `arg`, key_idx = -1. */
 };
+enum hdk_hip_fp_slot { HDK_FP_SLOT_NONE = 0, HDK_FP_SLOT_DOUBLE = 1, HDK_FP_SLOT_FLOAT = 2 };
 typedef struct hdk_hip_target {
   int32_t agg;        /* hdk_hip_agg */
   int32_t has_arg;    /* 0 => COUNT(*) */
@@ -292,7 +293,14 @@ typedef struct hdk_hip_target {
                          columnar: byte offset of the slot column from the buffer start */
   int32_t slot2_width;/* AVG: width of the count slot */
   int32_t slot2_off;  /* AVG: offset of the count slot */
-  int32_t arg_is_fp;  /* the slot holds a double/float bit pattern */
+  int32_t arg_is_fp;  /* hdk_hip_fp_slot: 0 integer slot; 1 the slot holds a double bit pattern; 2 float accumulator
+                         (takes_float_argument, Shared/TargetInfo.h:170-179: SUM / MIN / MAX / AVG over a FLOAT
+                         argument): the slot's LOW 4 BYTES hold a float whatever its padded width, updated like
+                         agg_{sum,min,max}_float[_skip_val] (QE/RuntimeFunctions.cpp:770-875); the other bytes of an
+                         8-byte slot keep the init pattern.  Values travel through the scan as doubles (HDK_COL_FLOAT
+                         widens), so `null_val` is the float sentinel WIDENED to double; the slot's own sentinel is its
+                         float bits, and INIT_AGG_VALS carries that sign-extended from 32 bits, as the reference's
+                         init_agg_val_vec does (QE/OutputBufferInitialization.cpp:52-65) */
   int32_t key_idx;    /* HDK_AGG_ID: index of the projected group-by key */
   int32_t pad_;
   int64_t null_val;   /* skip value == init value of the slot for nullable args (slot-typed bits) */

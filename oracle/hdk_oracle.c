@@ -646,6 +646,27 @@ void orc_agg_sum_float_skip_val(int32_t* agg, float val, float skip_val) {
   }
 }
 
+void orc_agg_max_float(int32_t* agg, float val) { /* :777-784, std::max(*agg, val) */
+  const float a = bits_to_float(*agg);
+  *agg = float_to_bits(a < val ? val : a);
+}
+void orc_agg_min_float(int32_t* agg, float val) { /* :786-793, std::min(*agg, val) */
+  const float a = bits_to_float(*agg);
+  *agg = float_to_bits(val < a ? val : a);
+}
+void orc_agg_max_float_skip_val(int32_t* agg, float val, float skip_val) { /* DEF_SKIP_AGG :855-875 */
+  if (val != skip_val) {
+    if (*agg != float_to_bits(skip_val)) orc_agg_max_float(agg, val);
+    else *agg = float_to_bits(val);
+  }
+}
+void orc_agg_min_float_skip_val(int32_t* agg, float val, float skip_val) {
+  if (val != skip_val) {
+    if (*agg != float_to_bits(skip_val)) orc_agg_min_float(agg, val);
+    else *agg = float_to_bits(val);
+  }
+}
+
 /* ============================================================================================
  * Scalar helpers
  * ========================================================================================== */
@@ -1486,10 +1507,23 @@ static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2,
   if (tg->arg_is_fp) {
     const double d = bits_to_double(val);
     const double dn = bits_to_double(nullv);
-    if (w == 4) {
-      /* float slots: only SUM is used by the library's float path */
-      if (skip) orc_agg_sum_float_skip_val((int32_t*)slot1, (float)d, (float)dn);
-      else orc_agg_sum_float((int32_t*)slot1, (float)d);
+    if (tg->arg_is_fp == HDK_FP_SLOT_FLOAT) {
+      /* takes_float_argument: agg_chosen_bytes = sizeof(float), the value is cast to float and the *_float runtime
+       * function works on the slot's low 4 bytes (QE/TargetExprBuilder.cpp:361-384); nullv is the sentinel widened to double */
+      const float f = (float)d, fn = (float)dn;
+      int32_t* s = (int32_t*)slot1;
+      switch (tg->agg) {
+        case HDK_AGG_SUM:
+        case HDK_AGG_AVG:
+          if (skip) orc_agg_sum_float_skip_val(s, f, fn); else orc_agg_sum_float(s, f);
+          break;
+        case HDK_AGG_MIN:
+          if (skip) orc_agg_min_float_skip_val(s, f, fn); else orc_agg_min_float(s, f);
+          break;
+        case HDK_AGG_MAX:
+          if (skip) orc_agg_max_float_skip_val(s, f, fn); else orc_agg_max_float(s, f);
+          break;
+      }
       return;
     }
     switch (tg->agg) {
@@ -1991,11 +2025,22 @@ static void reduce_one_target(const hdk_hip_target* tg, int8_t* this1, int8_t* t
   const int w = tg->slot_width;
   const int skip = tg->skip_null;
   if (tg->arg_is_fp) {
-    if (w == 4) {
+    if (tg->arg_is_fp == HDK_FP_SLOT_FLOAT) { /* get_width_for_slot -> sizeof(float), ResultSetReduction.cpp:1176-1185 */
       const float o = bits_to_float(*(const int32_t*)that1);
       const float nv = bits_to_float((int32_t)init_val);
-      if (skip) orc_agg_sum_float_skip_val((int32_t*)this1, o, nv);
-      else orc_agg_sum_float((int32_t*)this1, o);
+      int32_t* s = (int32_t*)this1;
+      switch (tg->agg) {
+        case HDK_AGG_SUM:
+        case HDK_AGG_AVG:
+          if (skip) orc_agg_sum_float_skip_val(s, o, nv); else orc_agg_sum_float(s, o);
+          break;
+        case HDK_AGG_MIN:
+          if (skip) orc_agg_min_float_skip_val(s, o, nv); else orc_agg_min_float(s, o);
+          break;
+        case HDK_AGG_MAX:
+          if (skip) orc_agg_max_float_skip_val(s, o, nv); else orc_agg_max_float(s, o);
+          break;
+      }
       return;
     }
     const double o = bits_to_double(*(const int64_t*)that1);

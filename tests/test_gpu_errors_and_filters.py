@@ -153,3 +153,83 @@ def test_interrupt_and_watchdog(oracle, gpu_executor_factory):
         assert_buffers_equal(cp2, res.buffer, want)
     finally:
         ex.interrupt(0)
+
+
+# ---- float accumulators (takes_float_argument) ----------------------------------------------------------------------
+def _float_table(n=200_000, seed=23):
+    import pyarrow as pa
+    rng = np.random.default_rng(seed)
+    f = (rng.random(n) * 100).astype(np.float32)          # positive: the relative error of a float sum stays small
+    g = (rng.random(n) * 50 - 25).astype(np.float32)
+    null = rng.random(n) < 0.1
+    k = rng.integers(0, 300, n).astype(np.int32)
+    null[k == 7] = True                                   # a group with nothing but NULLs keeps the float sentinel
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array(k, pa.int32()), "f": pa.array(f, pa.float32(), mask=null),
+                              "g": pa.array(g, pa.float32()),
+                              "big": pa.array(rng.integers(0, 2000, n).astype(np.int64) * (2**34), pa.int64())}),
+                    "t", fragment_size=45_000)
+    return st
+
+
+def _float_targets():
+    F, G = ColRef("f"), ColRef("g")
+    return [Agg("sum", F, "s"), Agg("min", F, "lo"), Agg("max", F, "hi"), Agg("avg", F, "a"), Agg("count", F, "c"),
+            Agg("min", G, "glo"), Agg("max", G, "ghi")]
+
+
+@pytest.mark.parametrize("columnar", [False, True])
+def test_float_accumulators_match_the_oracle(oracle, gpu_executor_factory, columnar):
+    """SUM / MIN / MAX / AVG over FLOAT: a float in the low 4 bytes of the slot (agg_*_float[_skip_val],
+    QE/RuntimeFunctions.cpp:770-875).  MIN / MAX / COUNT and every other byte of the buffer bit-exact; float sums
+    within float32 summation error (the oracle adds row by row in float; the device's order differs)."""
+    st = _float_table()
+    q = QueryUnit("t", groupby=[ColRef("k")], output_columnar=columnar, targets=[KeyRef(0, "k")] + _float_targets())
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.targets[1].arg_is_fp == A.FP_SLOT_FLOAT
+    for flags in STRATEGIES:
+        res = gpu_executor_factory(st).execute(cp, flags=flags)
+        assert_buffers_equal(cp, res.buffer, want)
+    cols = res.to_columns()
+    i7 = cols["k"].index(7)
+    assert (cols["s"][i7], cols["lo"][i7], cols["hi"][i7], cols["a"][i7], cols["c"][i7]) == (None, None, None, None, 0)
+
+
+def test_float_accumulators_non_grouped_and_open_addressing(oracle, gpu_executor_factory):
+    st = _float_table()
+    q = QueryUnit("t", targets=_float_targets())
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    for flags in (0, A.LAUNCH_FORCE_GENERIC, A.LAUNCH_FORCE_SCALAR):
+        # 200 K rows in one float accumulator: the row-order float sum itself is only good to ~1e-3
+        assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=flags).buffer, want, float32_rtol=5e-3)
+    qb = QueryUnit("t", groupby=[ColRef("big")], force_baseline=True, baseline_entry_count=9001,
+                   targets=[KeyRef(0, "big")] + _float_targets())
+    cp, want, err = run_oracle(oracle, st, qb)
+    assert err == 0 and cp.plan.query_kind == A.Q_BASELINE_HASH
+    for flags in (0, A.LAUNCH_FORCE_GENERIC):
+        _check_rows(cp, gpu_executor_factory(st).execute(cp, flags=flags).buffer, want, rtol=2e-4)
+
+
+def test_float_accumulators_reduce_on_device(oracle, gpu_executor_factory):
+    """hdk_hip_reduce_buffers on float slots == the oracle's reduction of the same partials in the same order
+    (get_width_for_slot -> sizeof(float), QE/ResultSetReduction.cpp:1176-1185), bit for bit."""
+    import ctypes as C
+    from hdk_amd._lib import check, lib
+    st = _float_table(90_000, 29)
+    q = QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0, "k")] + _float_targets())
+    ex = gpu_executor_factory(st)
+    cp = ex.compile(q)
+    mgr = ex.mgr
+    partials = [ex.execute(cp, frag_ids=[fr]).buffer.copy() for fr in range(2)]
+    want = partials[0].copy()
+    assert oracle.reduce(cp.plan, want, cp.entry_count, partials[1], cp.entry_count, cp.init_vals) == 0
+    d0, d1 = mgr.to_device(partials[0], 0), mgr.to_device(partials[1], 0)
+    that = (C.c_void_p * 1)(d1.ptr)
+    counts = (C.c_uint32 * 1)(cp.entry_count)
+    d_err = mgr.to_device(np.zeros(1, dtype=np.int32), 0)
+    iv = np.ascontiguousarray(cp.init_vals)
+    check(lib().hdk_hip_reduce_buffers(C.byref(cp.plan), d0.ptr, cp.entry_count, that, counts, 1, iv.ctypes.data,
+                                       d_err.ptr, 0, None))
+    mgr.synchronizeStream(0)
+    assert np.array_equal(mgr.to_host(d0.ptr, cp.buffer_bytes, 0), want[:cp.buffer_bytes // 8])

@@ -146,3 +146,35 @@ def test_or_not_filters_vs_sqlite(oracle):
         want = _sqlite({"t": {"a": a, "b": b, "d": d, "k": k}},
                        f"select k, count(*), sum(b) from t where {where} group by k order by k")
         assert got == [tuple(r) for r in want], where
+
+
+def test_float_accumulators_follow_row_order_float_arithmetic(oracle):
+    """SUM / MIN / MAX / AVG over a FLOAT column: the oracle applies agg_*_float[_skip_val] row by row on a float in
+    the slot (QE/RuntimeFunctions.cpp:770-875); numpy float32 arithmetic in the same row order gives the same bits."""
+    rng = np.random.default_rng(17)
+    n = 5000
+    k = rng.integers(0, 7, n).astype(np.int32)
+    f = (rng.random(n) * 100 - 30).astype(np.float32)
+    null = rng.random(n) < 0.1
+    null[k == 3] = True                      # a group with nothing but NULLs
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array(k, pa.int32()), "f": pa.array(f, pa.float32(), mask=null)}), "t",
+                    fragment_size=1300)
+    q = QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("sum", ColRef("f"), "s"),
+                                                       Agg("min", ColRef("f"), "lo"), Agg("max", ColRef("f"), "hi"),
+                                                       Agg("avg", ColRef("f"), "a"), Agg("count", ColRef("f"), "c")])
+    cp, buf, err = run_oracle(oracle, st, q)
+    assert err == 0
+    cols = rs.to_columns(cp, buf)
+    got = {kk: (s, lo, hi, a, c) for kk, s, lo, hi, a, c in zip(cols["k"], cols["s"], cols["lo"], cols["hi"], cols["a"], cols["c"])}
+    for g in range(7):
+        v = f[(k == g) & ~null]
+        if len(v) == 0:
+            assert got[g] == (None, None, None, None, 0)
+            continue
+        acc = np.float32(v[0])
+        for x in v[1:]:
+            acc = np.float32(acc + x)
+        s, lo, hi, a, c = got[g]
+        assert (np.float32(s), np.float32(lo), np.float32(hi), c) == (acc, v.min(), v.max(), len(v))
+        assert a == float(acc) / len(v)

@@ -125,8 +125,6 @@ def test_unsupported_shapes_raise_query_must_run_on_cpu():
     st = ArrowStorage()
     st.import_numpy("t", {"a": np.arange(10, dtype=np.int64), "f": np.ones(10, dtype=np.float32), "d": np.ones(10)})
     with pytest.raises(QueryMustRunOnCpu):
-        compile_query(st, QueryUnit("t", targets=[Agg("sum", ColRef("f"))]))  # float32 accumulators
-    with pytest.raises(QueryMustRunOnCpu):
         compile_query(st, QueryUnit("t", groupby=[ColRef("d")], targets=[Agg("count")]))  # fp group key
     deep = BinOp("+", ColRef("a"), BinOp("*", ColRef("a"), Lit(2)))
     with pytest.raises(QueryMustRunOnCpu):
@@ -182,3 +180,30 @@ def test_host_init_image_equals_oracle_init(oracle, shape, columnar):
         assert cp.plan.key_width == 4 or columnar
         ab, bb = a.view(np.uint8), b.view(np.uint8)
         assert (ab != bb).sum() <= (8 * cp.entry_count if not columnar else 8 * (len(cp.slot_widths) + 4))
+
+
+def test_float_argument_targets_get_float_accumulators():
+    """takes_float_argument (Shared/TargetInfo.h:170-179): SUM / MIN / MAX / AVG over FLOAT keep a float in the low 4
+    bytes of an 8-byte slot; init values are the 4-byte patterns sign-extended (OutputBufferInitialization.cpp:52-65,
+    get_agg_initial_val :112-258); COUNT(float) stays an integer slot."""
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array([1, 1, 2], pa.int32()), "f": pa.array([1.5, None, 2.5], pa.float32())}), "t")
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("k")], targets=[
+        KeyRef(0), Agg("sum", ColRef("f")), Agg("min", ColRef("f")), Agg("max", ColRef("f")), Agg("avg", ColRef("f")),
+        Agg("count", ColRef("f"))]))
+    tg = cp.plan.targets
+    assert [tg[i].arg_is_fp for i in range(1, 6)] == [A.FP_SLOT_FLOAT] * 4 + [A.FP_SLOT_DOUBLE]
+    assert [tg[i].slot_width for i in range(1, 6)] == [8] * 5
+    widened = np.array([np.float32(np.finfo(np.float32).tiny)], dtype=np.float64).view(np.int64)[0]
+    assert all(tg[i].null_val == widened for i in range(1, 5))
+    assert cp.init_vals.tolist() == [0, A.NULL_FLOAT_BITS, A.NULL_FLOAT_BITS, A.NULL_FLOAT_BITS, A.NULL_FLOAT_BITS, 0, 0]
+    st2 = ArrowStorage()
+    st2.import_numpy("t", {"k": np.array([1, 2], dtype=np.int32), "f": np.array([1.0, 2.0], dtype=np.float32)},
+                     types=None)
+    from hdk_amd.ir import Type
+    st2.get("t").columns["f"].type = Type("fp", 4, False)
+    cp2 = compile_query(st2, QueryUnit("t", groupby=[ColRef("k")], targets=[
+        Agg("sum", ColRef("f")), Agg("min", ColRef("f")), Agg("max", ColRef("f"))]))
+    fmax = int(np.array([np.finfo(np.float32).max], dtype=np.float32).view(np.int32)[0])
+    fmin = int(np.array([-np.finfo(np.float32).max], dtype=np.float32).view(np.int32)[0])
+    assert cp2.init_vals.tolist() == [0, fmax, fmin] and fmin < 0   # -FLT_MAX sign-extends into the high bytes

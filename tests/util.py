@@ -124,7 +124,7 @@ def run_oracle(O, storage, q_or_cp, frag_ids=None):
     return cp, buf, err
 
 
-def assert_buffers_equal(cp, got, want, fp_rtol=1e-6):
+def assert_buffers_equal(cp, got, want, fp_rtol=1e-6, float32_rtol=2e-4):
     """Bit-exact for every integer slot / key; fp SUM/AVG slots within `fp_rtol` relative
     (north_star tolerance: GPU summation order differs from the CPU's row order)."""
     from hdk_amd import result_set as rs
@@ -145,7 +145,18 @@ def assert_buffers_equal(cp, got, want, fp_rtol=1e-6):
     for t in range(cp.plan.num_targets):
         tg = cp.plan.targets[t]
         nsl = 2 if tg.agg == A.AGG_AVG else 1
-        if tg.arg_is_fp and tg.agg in (A.AGG_SUM, A.AGG_AVG):
+        if tg.arg_is_fp == A.FP_SLOT_FLOAT and tg.agg in (A.AGG_SUM, A.AGG_AVG):
+            # float accumulator in the low 4 bytes: the reference adds row by row in float, the device folds block
+            # partials held in double and rounds once -- compared within float32 summation error; the slot's other
+            # bytes (the init pattern) are compared exactly
+            gi, wi = gs[s].astype(np.int64), ws[s].astype(np.int64)
+            assert np.array_equal(gi >> 32, wi >> 32)
+            a = (gi & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+            b = (wi & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+            np.testing.assert_allclose(a, b, rtol=float32_rtol, atol=0)
+            for k in range(1, nsl):
+                assert np.array_equal(gs[s + k], ws[s + k])
+        elif tg.arg_is_fp and tg.agg in (A.AGG_SUM, A.AGG_AVG):
             a, b = gs[s].view(np.float64), ws[s].view(np.float64)
             np.testing.assert_allclose(a, b, rtol=fp_rtol, atol=0)
             for k in range(1, nsl):
