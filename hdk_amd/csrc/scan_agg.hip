@@ -548,6 +548,7 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
 static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
+static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
 static const void* baseline_direct_kernel(const hdk_hip_plan* p);
@@ -630,7 +631,8 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     int block = kBlock;
     KeysArgs ka;
     if (s.strategy == STRAT_LDS && !generic && match_keys(p, s, &ka)) {
-      k = reinterpret_cast<const void*>(hdk_scan_agg_keys);
+      k = ka.nvals ? reinterpret_cast<const void*>(hdk_scan_agg_keys<true>)
+                   : reinterpret_cast<const void*>(hdk_scan_agg_keys<false>);
       block = kKeysBlock;
     } else if (s.strategy == STRAT_LDS) {
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
@@ -869,7 +871,7 @@ static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s)
   int kw, vw;
   if (match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
   KeysArgs ka;
-  if (match_keys(p, s, &ka)) return "hdk_scan_agg_keys";
+  if (match_keys(p, s, &ka)) return ka.nvals ? "hdk_scan_agg_keys_values" : "hdk_scan_agg_keys";
   if (needs_join_loops(p)) return "hdk_scan_agg_generic";
   return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
 }
@@ -894,7 +896,11 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   if (!force_generic && match_keys(plan, shape, &ka)) {
     ka.kp = kp;
     ka.slabs = slabs;
-    hipLaunchKernelGGL(hdk_scan_agg_keys, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
+    if (ka.nvals) {
+      hipLaunchKernelGGL(hdk_scan_agg_keys<true>, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_agg_keys<false>, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
+    }
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }
@@ -925,13 +931,84 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   return HDK_HIP_OK;
 }
 
+// value form of hdk_scan_agg_keys: every aggregate argument is a plain column of the outer table (at most two of
+// them), the slot type follows the column (no int -> fp promotion); the per-row update list comes from the word layout
+static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka) {
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  if (wl.wpe != ka->wpe) return false;
+  for (int w = 0; w < wl.wpe; ++w) ka->wop[w] = wl.wop[w];
+  int nops = 0;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (wl.vword[t] < 0 && wl.nword[t] < 0) continue;  // projected key, COUNT(*), COUNT(not-null column)
+    int c;
+    if (!tg.has_arg || !plain_outer_col(p, tg.arg, &c)) return false;
+    const hdk_hip_col& col = p->cols[c];
+    const bool fp = col.kind == HDK_COL_DOUBLE || col.kind == HDK_COL_FLOAT;
+    if (col.width != 1 && col.width != 2 && col.width != 4 && col.width != 8) return false;
+    if (col.kind == HDK_COL_UNSIGNED && col.width == 8) return false;
+    if (target_has_value_word(tg) && (tg.arg_is_fp != 0) != fp) return false;
+    const int nullable = tg.skip_null && tg.arg.nullable;
+    int vi = -1;
+    for (int k = 0; k < ka->nvals; ++k) {
+      if (ka->val[k].buf_idx == col.buf_idx) vi = k;
+    }
+    if (vi < 0) {
+      if (ka->nvals == kKeysMaxVals) return false;
+      vi = ka->nvals++;
+      KeysVal& kv = ka->val[vi];
+      kv.buf_idx = col.buf_idx;
+      kv.width = col.width;
+      kv.kind = col.kind;
+      kv.nullable = nullable;
+      kv.null_val = tg.arg.null_val;
+    } else if (ka->val[vi].nullable != nullable) {
+      return false;  // one column, two NULL conventions: the interpreter sorts that out
+    }
+    auto push = [&](int kind, int word) {
+      if (nops < kKeysMaxOps) {
+        ka->op_kind[nops] = kind;
+        ka->op_word[nops] = word;
+        ka->op_val[nops] = vi;
+      }
+      ++nops;
+    };
+    if (wl.vword[t] >= 0) {
+      int kind;
+      switch (wl.wop[wl.vword[t]]) {
+        case WOP_ADD_U64: kind = FOP_ADD_U64; break;
+        case WOP_ADD_F64: kind = FOP_ADD_F64; break;
+        case WOP_MIN_I64: kind = FOP_MIN_I64; break;
+        case WOP_MAX_I64: kind = FOP_MAX_I64; break;
+        case WOP_MIN_F64: kind = FOP_MIN_F64; break;
+        default: kind = FOP_MAX_F64; break;
+      }
+      push(kind, wl.vword[t]);
+    }
+    if (wl.nword[t] >= 0) {
+      push(FOP_ADD_ONE_IF_NULL, wl.nword[t]);
+      ka->nword_mask |= 1u << wl.nword[t];
+    }
+  }
+  if (nops > kKeysMaxOps || ka->nvals == 0) return false;
+  ka->nops = nops;
+  return true;
+}
+
 // the shape hdk_scan_agg_keys takes (scan_agg_keys.h): perfect hash on 1-3 integer outer columns, each
-// plain or under ONE of extract-year / decimal scale-down, row counts only, plain filters
+// plain or under ONE of extract-year / decimal scale-down, plain filters; row counts only (the counting form) or
+// aggregates over at most two plain outer columns (the value form, match_keys_values)
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka) {
   if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_PERFECT_HASH || p->num_joins) return false;
-  if (p->key_count < 1 || p->key_count > kKeysMax || shape.wpe != 1) return false;
+  if (p->key_count < 1 || p->key_count > kKeysMax) return false;
   if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
   if (!match_plain_quals(p, ka->q)) return false;
+  ka->wpe = shape.wpe;
+  ka->nvals = 0;
+  ka->nops = 0;
+  ka->nword_mask = 0;
+  if (shape.wpe != 1 && !match_keys_values(p, ka)) return false;
   ka->nquals = p->num_quals;
   ka->nkeys = p->key_count;
   ka->entry_count = shape.entry_count;

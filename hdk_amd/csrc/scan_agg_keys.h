@@ -1,9 +1,10 @@
-// scan_agg_keys.h -- perfect-hash group-by on up to three TRANSFORMED keys, counting rows only.
+// scan_agg_keys.h -- perfect-hash group-by on up to three TRANSFORMED keys: row counts (hdk_scan_agg_keys<false>)
+// or row counts plus SUM / AVG / MIN / MAX / COUNT over up to two plain outer columns (hdk_scan_agg_keys<true>).
 //
 // Shape: GroupByPerfectHash, no join, filters of the form `outer column cmp literal` (plain_quals.h),
 // 1-3 group keys each of which is an integer column of the outer table with at most one unary step
-// (EXTRACT(YEAR FROM ts) or the decimal scale-down of a CAST), and targets that need no value word:
-// projected keys and COUNT(*).  That is taxi Q3 (GROUP BY passenger_count, year(pickup_datetime)) and Q4
+// (EXTRACT(YEAR FROM ts) or the decimal scale-down of a CAST).  The counting form takes targets that need no value
+// word: projected keys and COUNT(*).  That is taxi Q3 (GROUP BY passenger_count, year(pickup_datetime)) and Q4
 // (... , cast(trip_distance as int)) of BASELINE config 4 (reference omniscidb/Benchmarks/taxi/
 // taxi_reduced_bench.cpp).  Same arithmetic as the batched interpreter (vec_eval.h: eval_key_v,
 // perfect_hash_entry_v; reference key computation QE/RuntimeFunctions.cpp get_columnar_perfect_hash*,
@@ -16,10 +17,13 @@
 #include "watch.h"
 #include "agg_common.h"
 #include "plain_quals.h"
+#include "scan_agg_fast.h"  // FastOpKind, fast_lds_op: the per-row LDS update list of the value form
 
 namespace hdk {
 
 constexpr int kKeysBlock = 256;
+constexpr int kKeysMaxVals = 2;
+constexpr int kKeysMaxOps = 8;
 constexpr int kKeysVR = 8;   // rows per lane and tile (taxi Q3/Q4 at 256 M rows: 4 -> 0.79/1.23 ms, 8 -> 0.60/1.00, 12 -> 0.66/1.02)
 constexpr int kKeysMax = 3;
 
@@ -47,6 +51,14 @@ struct KeysKey {
   int32_t div_shift;       //   for every 32-bit unsigned n (round-up method, branch-free form)
 };
 
+struct KeysVal {           // an aggregate argument: a plain column of the outer table
+  int32_t buf_idx;
+  int32_t width;
+  int32_t kind;            // hdk_hip_col_kind (FLOAT is widened to double, like the decoder of the interpreter)
+  int32_t nullable;        // some target skips its NULLs
+  int64_t null_val;        // widened (int) / double bits (fp)
+};
+
 struct KeysArgs {
   KernParams kp;
   int64_t* slabs;
@@ -57,16 +69,34 @@ struct KeysArgs {
   int32_t nquals;
   KeysKey key[kKeysMax];
   ProjFastQual q[kMaxPlainQuals];
+  // value form only: words per entry, the argument columns and the per-row update list (word 0 = row count)
+  int32_t wpe;
+  int32_t nvals;
+  KeysVal val[kKeysMaxVals];
+  int32_t nops;
+  int32_t op_kind[kKeysMaxOps];  // FastOpKind
+  int32_t op_word[kKeysMaxOps];
+  int32_t op_val[kKeysMaxOps];   // which argument column
+  int32_t wop[kMaxWordsPerEntry];
+  uint32_t nword_mask;           // bit w: word w counts NULLs (the flush stores row count - NULLs)
 };
 
-extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysArgs a) {
+#define HDK_KEYS_LOAD(DST, T)                              \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {         \
+    DST[r] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) T*>( \
+                                            reinterpret_cast<uintptr_t>(buf)) + row[r]);               \
+  }
+
+template <bool VALS>
+__global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   constexpr int VR = kKeysVR;
   const int tid = threadIdx.x;
   const uint32_t rep = a.rep;
-  const uint32_t total_words = a.entry_count * rep;  // one word (the row count) per entry
+  const uint32_t wpe = VALS ? static_cast<uint32_t>(a.wpe) : 1u;  // counting form: one word (the row count) per entry
+  const uint32_t total_words = a.entry_count * wpe * rep;
   for (uint32_t i = tid; i < total_words; i += kKeysBlock) {
-    lds[i] = 0;
+    lds[i] = VALS ? word_identity(a.wop[(i >> a.rep_shift) % wpe]) : 0;
   }
   __syncthreads();
 
@@ -112,11 +142,6 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
         // in 32 bits is: the 64-bit forms are kept for wide plain keys and for rows outside the fast ranges.
         uint32_t term[VR];
         bool ok[VR];
-#define HDK_KEYS_LOAD(DST, T)                              \
-  _Pragma("unroll") for (int r = 0; r < VR; ++r) {         \
-    DST[r] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) T*>( \
-                                            reinterpret_cast<uintptr_t>(buf)) + row[r]);               \
-  }
         if (kk.xf == KXF_NONE && kk.narrow) {
           int32_t v[VR];
           if (kk.is_unsigned) {
@@ -239,7 +264,6 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
             ok[r] = isnull[r] ? kk.null_ok != 0 : ok[r];
           }
         }
-#undef HDK_KEYS_LOAD
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
           bad |= static_cast<int>(pass[r]) & static_cast<int>(!ok[r]);
@@ -250,26 +274,114 @@ extern "C" __global__ __launch_bounds__(kKeysBlock) void hdk_scan_agg_keys(KeysA
       if (bad) {
         err = HDK_HIP_ERR_OUT_OF_SLOTS;
       }
+      if (!VALS) {
 #pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        if (pass[r]) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(lds + ((entry[r] << a.rep_shift) + my_rep)), 1ull);
+        for (int r = 0; r < VR; ++r) {
+          if (pass[r]) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(lds + ((entry[r] << a.rep_shift) + my_rep)), 1ull);
+          }
+        }
+      } else {
+        uint32_t base[VR];  // word 0 of the row's entry, this lane's replica
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          base[r] = ((entry[r] * wpe) << a.rep_shift) + my_rep;
+          if (pass[r]) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[r]), 1ull);
+          }
+        }
+#pragma unroll 1
+        for (int vi = 0; vi < a.nvals; ++vi) {
+          const KeysVal kv = a.val[vi];
+          const int8_t* buf = cols[kv.buf_idx];
+          int64_t v[VR];
+          bool isnull[VR];
+          if (kv.kind == HDK_COL_DOUBLE || kv.kind == HDK_COL_FLOAT) {
+            if (kv.kind == HDK_COL_DOUBLE) {
+              HDK_KEYS_LOAD(v, int64_t)
+            } else {
+              float f[VR];
+              HDK_KEYS_LOAD(f, float)
+#pragma unroll
+              for (int r = 0; r < VR; ++r) {
+                v[r] = double_to_bits(static_cast<double>(f[r]));
+              }
+            }
+            const double dn = bits_to_double(kv.null_val);
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              isnull[r] = kv.nullable && bits_to_double(v[r]) == dn;  // `val != skip_val`: a value compare
+            }
+          } else {
+            if (kv.kind == HDK_COL_UNSIGNED) {
+              switch (kv.width) {
+                case 1: HDK_KEYS_LOAD(v, uint8_t) break;
+                case 2: HDK_KEYS_LOAD(v, uint16_t) break;
+                default: HDK_KEYS_LOAD(v, uint32_t) break;
+              }
+            } else {
+              switch (kv.width) {
+                case 1: HDK_KEYS_LOAD(v, int8_t) break;
+                case 2: HDK_KEYS_LOAD(v, int16_t) break;
+                case 4: HDK_KEYS_LOAD(v, int32_t) break;
+                default: HDK_KEYS_LOAD(v, int64_t) break;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              isnull[r] = kv.nullable && v[r] == kv.null_val;
+            }
+          }
+#pragma unroll 1
+          for (int o = 0; o < a.nops; ++o) {
+            if (a.op_val[o] != vi) {
+              continue;
+            }
+            const int32_t kind = a.op_kind[o];
+            const uint32_t woff = static_cast<uint32_t>(a.op_word[o]) << a.rep_shift;
+            const bool on_null = kind == FOP_ADD_ONE_IF_NULL;
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              if (pass[r] && isnull[r] == on_null) {
+                fast_lds_op(kind, lds + base[r] + woff, v[r]);
+              }
+            }
+          }
         }
       }
     }
     frag_tile_begin += ntiles;
   }
+#undef HDK_KEYS_LOAD
   if (err) {
     record_error(a.kp.error_code, err);
   }
   __syncthreads();
-  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * a.entry_count;
-  for (uint32_t i = tid; i < a.entry_count; i += kKeysBlock) {
-    int64_t acc = 0;
-    for (uint32_t r = 0; r < rep; ++r) {
-      acc += lds[i * rep + r];
+  const uint32_t ew = a.entry_count * wpe;
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += kKeysBlock) {
+    if (!VALS) {
+      int64_t acc = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        acc += lds[i * rep + r];
+      }
+      slab[i] = acc;
+    } else {
+      const uint32_t w = i % wpe;
+      const int32_t op = a.wop[w];
+      int64_t acc = lds[i * rep];
+      for (uint32_t r = 1; r < rep; ++r) {
+        acc = word_combine(op, acc, lds[i * rep + r]);
+      }
+      if ((a.nword_mask >> w) & 1u) {  // NULL count -> non-null count
+        int64_t rows = 0;
+        for (uint32_t r = 0; r < rep; ++r) {
+          rows += lds[(i - w) * rep + r];
+        }
+        acc = rows - acc;
+      }
+      slab[i] = acc;
     }
-    slab[i] = acc;
   }
 }
 

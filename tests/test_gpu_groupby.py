@@ -291,3 +291,75 @@ def test_transformed_keys_kernel_random(oracle, gpu_executor_factory):
             raise AssertionError(f"case {i}: {q}\n{e}") from e
         ran += 1
     assert ran >= 8, ran
+
+
+def test_transformed_keys_kernel_with_value_aggregates(oracle, gpu_executor_factory):
+    """The value form of hdk_scan_agg_keys: SUM / AVG / MIN / MAX / COUNT over one or two plain columns (every width,
+    signed, decimal, double, float; nullable or not) grouped by plain / year / decimal-cast keys, with filters --
+    against the oracle and both interpreters.  Seeded random combinations."""
+    from hdk_amd.ir import Type
+    rng = np.random.default_rng(777)
+    n = 120_000
+
+    def with_nulls(a, null, frac=0.03):
+        a = a.copy()
+        a[rng.random(n) < frac] = null
+        return a
+
+    ts = rng.integers(1230768000, 1451606400, n, dtype=np.int64)
+    ts[rng.random(n) < 0.01] = 2_090_000_000
+    d = rng.normal(size=n) * 100
+    d[rng.random(n) < 0.03] = np.finfo(np.float64).tiny      # NULL_DOUBLE
+    f32 = (rng.random(n) * 100).astype(np.float32)
+    f32[rng.random(n) < 0.03] = np.finfo(np.float32).tiny    # NULL_FLOAT
+    cols = {
+        "k16": with_nulls(rng.integers(0, 7, n).astype(np.int16), A.NULL_SMALLINT),
+        "k32": rng.integers(100, 106, n).astype(np.int32),
+        "ts": with_nulls(ts, A.NULL_BIGINT),
+        "dec": with_nulls(rng.integers(-249, 850, n, dtype=np.int64), A.NULL_BIGINT),
+        "v8": with_nulls(rng.integers(-100, 100, n).astype(np.int8), -128),
+        "v16": with_nulls(rng.integers(-3000, 3000, n).astype(np.int16), A.NULL_SMALLINT),
+        "v32": with_nulls(rng.integers(-10**6, 10**6, n).astype(np.int32), A.NULL_INT),
+        "v64": with_nulls(rng.integers(-2**40, 2**40, n, dtype=np.int64), A.NULL_BIGINT),
+        "nn": rng.integers(0, 1000, n, dtype=np.int64),
+        "amt": with_nulls(rng.integers(0, 20000, n, dtype=np.int64), A.NULL_BIGINT),
+        "d": d, "f32": f32,
+        "flt": with_nulls(rng.integers(0, 100, n).astype(np.int32), A.NULL_INT),
+    }
+    st = ArrowStorage()
+    st.import_numpy("t", cols, fragment_size=33_333,
+                    types={"ts": Type("timestamp", 8, unit="s"), "dec": Type("decimal", 8, scale=2),
+                           "amt": Type("decimal", 8, scale=2), "nn": Type("int", 8, False)})
+    keys = [lambda: ColRef("k16"), lambda: ColRef("k32"), lambda: ExtractYear(ColRef("ts")),
+            lambda: Cast(ColRef("dec"), INT32)]
+    vals = ["v8", "v16", "v32", "v64", "nn", "amt", "d", "f32"]
+    ran = 0
+    for i in range(28):
+        nk = int(rng.integers(1, 4))
+        groupby = [keys[int(p)]() for p in rng.choice(len(keys), size=nk, replace=False)]
+        if nk == 1 and isinstance(groupby[0], ColRef):
+            groupby.append(ExtractYear(ColRef("ts")))  # a single plain key belongs to the streaming kernel
+            nk = 2
+        vcols = [vals[int(p)] for p in rng.choice(len(vals), size=int(rng.integers(1, 3)), replace=False)]
+        targets = [KeyRef(j) for j in range(nk)]
+        for t in range(int(rng.integers(1, 5))):
+            targets.append(Agg(str(rng.choice(["sum", "avg", "min", "max", "count"])), ColRef(str(rng.choice(vcols)))))
+        if rng.random() < 0.5:
+            targets.append(Agg("count", None))
+        quals = [Cmp(ColRef("flt"), str(rng.choice(["<", ">="])), Lit(int(rng.integers(20, 80))))] if rng.random() < 0.4 else []
+        q = QueryUnit("t", quals=quals, groupby=groupby, targets=targets, output_columnar=bool(rng.random() < 0.3))
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, (i, q)
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp)
+        name = step.kernel_names().split(",")[0]
+        step.free()
+        if name != "hdk_scan_agg_keys_values":  # e.g. the table does not fit LDS with this many words per entry
+            continue
+        try:
+            _check(oracle, gpu_executor_factory, st, q)
+            _check(oracle, gpu_executor_factory, st, q, grid=7)
+        except AssertionError as e:
+            raise AssertionError(f"case {i}: {q}\n{e}") from e
+        ran += 1
+    assert ran >= 12, ran
