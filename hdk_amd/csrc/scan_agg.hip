@@ -549,6 +549,22 @@ static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
 static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
+// the counting form keeps 32-bit counters: half the bytes of the 8-byte words the shape was sized for
+static uint32_t keys_lds_bytes(const KeysArgs& ka, const LaunchShape& shape) {
+  return ka.nvals ? shape.lds_bytes : shape.lds_bytes / 2;
+}
+// counting / value form, rows dealt 2 (some 8-byte column is read) or 4 at a time
+static const void* keys_kernel(const KeysArgs& ka) {
+  int wmax = 1;
+  for (int k = 0; k < ka.nkeys; ++k) wmax = ka.key[k].width > wmax ? ka.key[k].width : wmax;
+  for (int v = 0; v < ka.nvals; ++v) wmax = ka.val[v].width > wmax ? ka.val[v].width : wmax;
+  if (ka.nvals) {
+    return wmax == 8 ? reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 2>)
+                     : reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 4>);
+  }
+  return wmax == 8 ? reinterpret_cast<const void*>(hdk_scan_agg_keys<false, 2>)
+                   : reinterpret_cast<const void*>(hdk_scan_agg_keys<false, 4>);
+}
 static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
 static const void* baseline_direct_kernel(const hdk_hip_plan* p);
@@ -629,11 +645,12 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     const void* k;
     int block = kBlock;
+    size_t lds_for_occupancy = s.lds_bytes;
     KeysArgs ka;
     if (s.strategy == STRAT_LDS && !generic && match_keys(p, s, &ka)) {
-      k = ka.nvals ? reinterpret_cast<const void*>(hdk_scan_agg_keys<true>)
-                   : reinterpret_cast<const void*>(hdk_scan_agg_keys<false>);
+      k = keys_kernel(ka);
       block = kKeysBlock;
+      lds_for_occupancy = keys_lds_bytes(ka, s);
     } else if (s.strategy == STRAT_LDS) {
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
                  : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_agg_vec_join)
@@ -660,7 +677,7 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
         block = kGlobalBlock;
       }
     }
-    s.grid = resident_grid(k, block, s.lds_bytes, props);
+    s.grid = resident_grid(k, block, lds_for_occupancy, props);
     if (s.strategy == STRAT_GLOBAL) {
       // random atomics make block run times uneven: 4 waves of blocks rebalance the tail
       // (C5 shape: 1792 blocks 21.5 ms, 3584 18.8 ms, 7168 17.6 ms)
@@ -896,11 +913,8 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   if (!force_generic && match_keys(plan, shape, &ka)) {
     ka.kp = kp;
     ka.slabs = slabs;
-    if (ka.nvals) {
-      hipLaunchKernelGGL(hdk_scan_agg_keys<true>, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
-    } else {
-      hipLaunchKernelGGL(hdk_scan_agg_keys<false>, dim3(shape.grid), dim3(kKeysBlock), shape.lds_bytes, s, ka);
-    }
+    void* kargs[] = {&ka};
+    HDK_HIP_CHECK(hipLaunchKernel(keys_kernel(ka), dim3(shape.grid), dim3(kKeysBlock), kargs, keys_lds_bytes(ka, shape), s));
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }
@@ -1076,6 +1090,7 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
     if (stride > shape.entry_count) return false;  // the table must hold every combination
     const bool kmin_small = kk.kmin >= -kMinGuard && kk.kmin <= kMinGuard;
     kk.kmin32 = kmin_small ? static_cast<int32_t>(kk.kmin) : 0;
+    kk.year_base = 1900u - static_cast<uint32_t>(kk.kmin32);
     // the value a NULL key takes (eval_key_v, vec_eval.h) and what it contributes
     int64_t null_value;
     if (kk.xf == KXF_NONE) {
@@ -1090,6 +1105,23 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
     const uint64_t nt = static_cast<uint64_t>(null_value) - static_cast<uint64_t>(kk.kmin);
     kk.null_ok = nt < kk.card;
     kk.null_term = static_cast<uint32_t>(nt);
+    kk.null_term_p = kk.null_ok ? kk.null_term : kKeysPoison;
+    if (kk.xf != KXF_NONE && kk.col_nullable) {
+      // the tile body recognises a NULL of a transformed column only among the rows outside the transform's 32-bit
+      // fast range (scan_agg_keys.h): true of every signed 4- and 8-byte column, checked here with the kernel's tests
+      bool null_is_fast;
+      if (kk.xf == KXF_YEAR) {
+        null_is_fast = static_cast<uint64_t>(kk.col_null) <= static_cast<uint64_t>(UINT32_MAX - 2208988800u);
+      } else {
+        const uint64_t half = static_cast<uint64_t>(kk.param >> 1);
+        const int64_t tmp = static_cast<int64_t>(kk.col_null >= 0 ? static_cast<uint64_t>(kk.col_null) + half
+                                                                  : static_cast<uint64_t>(kk.col_null) - half);
+        const int32_t t32 = static_cast<int32_t>(tmp);
+        null_is_fast = t32 == tmp && t32 != INT32_MIN;
+      }
+      if (null_is_fast) return false;
+    }
+    if (shape.entry_count >= kKeysPoison) return false;  // (cannot happen: kLdsMaxTableWords < kKeysPoison)
   }
   return true;
 }

@@ -58,21 +58,28 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    key = rng.integers(0, 64, n, dtype=np.int64)
-    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c3", "c3g", "p1", "p50", "pj", "c5"}) else 1000
+    key = rng.integers(0, 64, n_t0, dtype=np.int64)
+    val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
-    valn[rng.random(n) < 0.01] = A.NULL_BIGINT
+    valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    st.import_numpy("t", {"key": key, "val": val, "valn": valn, "fk": rng.integers(0, nd, n, dtype=np.int64),
-                          "hk": rng.integers(0, max(n // 10, 1000), n, dtype=np.int64)}, fragment_size=frag)
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c3", "c3g", "p1", "p50", "pj", "c5"})
+    need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
+    if not need_t:
+        n_t = 1000
+        key, val, valn = key[:n_t], val[:n_t], valn[:n_t]
+    st.import_numpy("t", {"key": key, "val": val, "valn": valn, "fk": rng.integers(0, nd, len(key), dtype=np.int64),
+                          "hk": rng.integers(0, max(n // 10, 1000), len(key), dtype=np.int64)}, fragment_size=frag)
     st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64)},
                     fragment_size=frag)
     # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types)
-    st.import_numpy("trips", {"cab_type": rng.integers(0, 2, n).astype(np.int32),
-                              "passenger_count": rng.integers(0, 7, n).astype(np.int16),
-                              "pickup_datetime": rng.integers(1230768000, 1451606400, n, dtype=np.int64),
-                              "trip_distance": rng.integers(0, 5000, n, dtype=np.int64),
-                              "total_amount": rng.integers(0, 20000, n, dtype=np.int64)}, fragment_size=frag,
+    nt = n if need_trips else 1000
+    st.import_numpy("trips", {"cab_type": rng.integers(0, 2, nt).astype(np.int32),
+                              "passenger_count": rng.integers(0, 7, nt).astype(np.int16),
+                              "pickup_datetime": rng.integers(1230768000, 1451606400, nt, dtype=np.int64),
+                              "trip_distance": rng.integers(0, 5000, nt, dtype=np.int64),
+                              "total_amount": rng.integers(0, 20000, nt, dtype=np.int64)}, fragment_size=frag,
                     types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
                            "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
     ex = Executor(st, 0)
@@ -96,6 +103,15 @@ def main():
         "q4": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime")),
                                            Cast(ColRef("trip_distance"), INT32)],
                          targets=[KeyRef(0), KeyRef(1), KeyRef(2), Agg("count")]), 18),
+        # Q3 / Q4 with measures: the value form of the keys kernel
+        "q3v": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime"))],
+                          targets=[KeyRef(0), KeyRef(1), Agg("count"), Agg("avg", ColRef("total_amount"))]), 18),
+        "q3m": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime"))],
+                          targets=[KeyRef(0), KeyRef(1), Agg("sum", ColRef("total_amount")), Agg("min", ColRef("trip_distance")),
+                                   Agg("max", ColRef("trip_distance"))]), 26),
+        "q4v": (QueryUnit("trips", groupby=[ColRef("passenger_count"), ExtractYear(ColRef("pickup_datetime")),
+                                            Cast(ColRef("trip_distance"), INT32)],
+                          targets=[KeyRef(0), KeyRef(1), KeyRef(2), Agg("count"), Agg("sum", ColRef("total_amount"))]), 26),
         # filter/project: SELECT key, val WHERE key < X (1 % / 50 % of the rows pass); bytes = 16 in + 24 out per passing row
         "p1": (QueryUnit("t", quals=[Cmp(ColRef("val"), "<", Lit(-2**31 + 2**32 // 100))], output_columnar=True,
                          targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val"), "val")]), 16 + 0.24),
@@ -115,6 +131,7 @@ def main():
             wall, kern = timed(step)
             res = step.fetch()
             t = kern or wall
+            n = st.get(q.table).num_rows
             print(json.dumps({"config": name, "kernel": step.kernel_names(), "rows": n, "entries": cp.entry_count,
                               "rows_per_s": n / wall, "kernel_ms": None if kern is None else kern * 1e3,
                               "step_ms": wall * 1e3, "alg_bytes_per_row": bpr, "alg_GBps": n * bpr / t / 1e9,
