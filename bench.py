@@ -140,8 +140,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     merge_ms, owner = [], {}
 
     def _one_step():
-        step.init_output(stream)
-        step.launch(stream)
+        step.enqueue(stream)  # output-buffer initialisation + launch (fused for the open-addressing tables)
         if world == 1:
             return
         if not baseline:

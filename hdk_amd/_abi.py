@@ -67,6 +67,7 @@ LAUNCH_FORCE_SCALAR = 8
 LAUNCH_FORCE_PARTITIONED = 16
 LAUNCH_PLAN_RESIDENT = 32
 LAUNCH_CHECK_INTERRUPT = 64
+LAUNCH_INIT_OUTPUT = 128
 
 
 class Col(C.Structure):

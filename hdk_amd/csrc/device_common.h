@@ -685,6 +685,24 @@ HDK_DEV int64_t eval_target_arg(const RowCtx& c, const hdk_hip_target& tg, bool&
   return v;
 }
 
+// Quad q of an initialised row-wise group-by row: [keys: key_count x key_width, padded to 8][init_vals...]
+// (init_group_by_buffer_gpu, QE/GpuInitGroups.cu:110-160): the one definition the init kernel and the fused
+// initialisation of the partitioned group-by share.
+HDK_DEV int64_t init_row_quad(uint32_t q, uint32_t keys_quads, uint32_t key_count, uint32_t key_width,
+                              const int64_t* __restrict__ init_vals) {
+  if (q >= keys_quads) {
+    return init_vals[q - keys_quads];
+  }
+  if (key_width == 8) {
+    return HDK_EMPTY_KEY_64;
+  }
+  // two int32 key components per quad; components past key_count keep zero bits
+  const uint32_t c0 = q * 2;
+  const uint32_t lo = c0 < key_count ? static_cast<uint32_t>(HDK_EMPTY_KEY_32) : 0u;
+  const uint32_t hi = (c0 + 1) < key_count ? static_cast<uint32_t>(HDK_EMPTY_KEY_32) : 0u;
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // the float sentinel of a float-accumulator target: tg.null_val carries it widened to double (what the scan compares)
 HDK_DEV int32_t float_slot_null(const hdk_hip_target& tg) {
   return __float_as_int(static_cast<float>(bits_to_double(tg.null_val)));

@@ -6,6 +6,7 @@
 // streaming write: each lane writes whole 16-B quads of the destination in row order, so the 3.2 GB
 // C5 table initialises at the HBM write rate.  The byte image produced is identical.
 #include "host_common.h"
+#include "device_common.h"
 
 namespace hdk {
 
@@ -23,22 +24,40 @@ __global__ __launch_bounds__(kInitBlock) void k_init_row_wise(int64_t* __restric
   const uint32_t keys_quads = keyless ? 0 : (key_count * key_width + 7) / 8;
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kInitBlock;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kInitBlock + threadIdx.x; i < total_quads; i += stride) {
-    const uint32_t q = static_cast<uint32_t>(i % row_size_quad);
-    int64_t v;
-    if (q < keys_quads) {
-      if (key_width == 8) {
-        v = HDK_EMPTY_KEY_64;
-      } else {  // two int32 key components per quad; components past key_count keep zero bits
-        const uint32_t c0 = q * 2;
-        const uint32_t lo = c0 < key_count ? static_cast<uint32_t>(HDK_EMPTY_KEY_32) : 0u;
-        const uint32_t hi = (c0 + 1) < key_count ? static_cast<uint32_t>(HDK_EMPTY_KEY_32) : 0u;
-        v = static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
-      }
-    } else {
-      v = init_vals[q - keys_quads];
-    }
+    const int64_t v = init_row_quad(static_cast<uint32_t>(i % row_size_quad), keys_quads, key_count, key_width, init_vals);
     buf[i] = v;
   }
+}
+
+// the same fill for a buffer known only through GROUPBY_BUF (a device array of pointers: [0] is the buffer):
+// hdk_hip_launch with HDK_HIP_LAUNCH_INIT_OUTPUT
+__global__ __launch_bounds__(kInitBlock) void k_init_row_wise_indirect(int64_t* const* __restrict__ groupby_buf,
+                                                                       const int64_t* __restrict__ init_vals,
+                                                                       uint64_t total_quads, uint32_t row_size_quad,
+                                                                       uint32_t key_count, uint32_t key_width,
+                                                                       int keyless) {
+  int64_t* __restrict__ buf = groupby_buf[0];
+  const uint32_t keys_quads = keyless ? 0 : (key_count * key_width + 7) / 8;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kInitBlock;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kInitBlock + threadIdx.x; i < total_quads; i += stride) {
+    buf[i] = init_row_quad(static_cast<uint32_t>(i % row_size_quad), keys_quads, key_count, key_width, init_vals);
+  }
+}
+
+int32_t launch_init_row_wise_indirect(int64_t* const* groupby_buf, const int64_t* init_vals, uint32_t entry_count,
+                                      uint32_t key_count, uint32_t key_width, uint32_t row_size_quad, int keyless,
+                                      const hdk_hip_device_properties* props, hipStream_t s) {
+  const uint64_t total_quads = static_cast<uint64_t>(entry_count) * row_size_quad;
+  if (total_quads == 0) {
+    return HDK_HIP_OK;
+  }
+  uint64_t blocks = (total_quads + kInitBlock - 1) / kInitBlock;
+  const uint64_t cap = static_cast<uint64_t>(props->num_cu) * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_init_row_wise_indirect, dim3(static_cast<unsigned>(blocks)), dim3(kInitBlock), 0, s, groupby_buf,
+                     init_vals, total_quads, row_size_quad, key_count, key_width, keyless);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
 }
 
 // Columnar: a sequence of columns, each `entry_count` elements of `width` bytes, 8-byte aligned

@@ -322,17 +322,23 @@ __global__ __launch_bounds__(256) void k_cal_copy(const cal_f4* __restrict__ src
     __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
   }
 }
+// read: the access shape of the streaming scan kernels -- tiles of 256 lanes x 8 x 16 B, a lane's eight loads issued
+// back to back, blocks striding over the tiles
 __global__ __launch_bounds__(256) void k_cal_read(const cal_f4* __restrict__ src, float* sink, size_t n) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+  constexpr size_t kTile = 256 * 8;
   cal_f4 acc = {0.f, 0.f, 0.f, 0.f};
-  size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const cal_f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    acc += a + b + c + d;
-  }
-  for (; i < n; i += stride) {
-    acc += __builtin_nontemporal_load(src + i);
+  const size_t ntiles = n / kTile;
+  for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const cal_f4* p = src + t * kTile + threadIdx.x;
+    cal_f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = __builtin_nontemporal_load(p + u * 256);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc += v[u];
+    }
   }
   if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) {
     *sink = acc.x;
@@ -370,12 +376,15 @@ int32_t hdk_hip_mgr_measure_hbm(int32_t device_num, size_t bytes, int32_t reps, 
     HDK_HIP_CHECK(hipEventSynchronize(e1));
     HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (r && ms > 0) best_copy = std::max(best_copy, 2.0 * n * 16 / (ms * 1e-3) / 1e9);
-    HDK_HIP_CHECK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(k_cal_read, dim3(grid), dim3(256), 0, s, static_cast<const cal_f4*>(a), static_cast<float*>(b), n);
-    HDK_HIP_CHECK(hipEventRecord(e1, s));
-    HDK_HIP_CHECK(hipEventSynchronize(e1));
-    HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    if (r && ms > 0) best_read = std::max(best_read, 1.0 * n * 16 / (ms * 1e-3) / 1e9);
+    for (unsigned per_cu = 2; per_cu <= 8; per_cu *= 2) {  // the streaming kernels run 2-4 blocks per CU
+      HDK_HIP_CHECK(hipEventRecord(e0, s));
+      hipLaunchKernelGGL(k_cal_read, dim3(static_cast<unsigned>(props->num_cu) * per_cu), dim3(256), 0, s,
+                         static_cast<const cal_f4*>(a), static_cast<float*>(b), n);
+      HDK_HIP_CHECK(hipEventRecord(e1, s));
+      HDK_HIP_CHECK(hipEventSynchronize(e1));
+      HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (r && ms > 0) best_read = std::max(best_read, 1.0 * (n / 2048 * 2048) * 16 / (ms * 1e-3) / 1e9);
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

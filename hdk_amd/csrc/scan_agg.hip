@@ -1349,7 +1349,8 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
       const uint32_t h = p->key_width == 4 ? host_key_hash<int32_t>(k, pa->nkeys) : host_key_hash<int64_t>(k, pa->nkeys);
       const uint32_t c = static_cast<uint32_t>((h % p->entry_count) / pa->slots) >> p2_log2;
       if (found == 0 || c != pa->pad_coarse[0]) {
-        pa->pad_key[found] = k;
+        // (tuples of 4-byte keys carry their home in the upper half of word 0: part_pack_home)
+        pa->pad_key[found] = p->key_width == 4 ? static_cast<int64_t>((static_cast<uint64_t>(h % p->entry_count) << 32) | static_cast<uint32_t>(k)) : k;
         pa->pad_coarse[found] = c;
         ++found;
       }
@@ -1391,6 +1392,32 @@ static const void* part_scatter_kernel(int tw) {
     case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 2>);
     default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 3>);
   }
+}
+
+// does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
+static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
+  pa->simple_agg = -1;
+  if (p->row_size_quad != 2 || pa->nkeys != 1 || pa->tw > 2) return false;
+  int found = -1;
+  for (int i = 0; i < pa->ntargets; ++i) {
+    const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
+    if (tg.agg == HDK_AGG_ID && tg.slot_width == 0) continue;
+    if (found >= 0) return false;
+    found = i;
+  }
+  if (found < 0) return false;
+  const hdk_hip_target& tg = p->targets[pa->tgt_index[found]];
+  if (tg.slot_width != 8 || tg.slot_off != 8 || tg.arg_is_fp) return false;
+  if (tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_COUNT) return false;
+  if (tg.has_arg && (pa->tgt_arg[found] != 1 || pa->arg[0].kind != HDK_COL_INT)) return false;
+  if (!tg.has_arg && tg.agg != HDK_AGG_COUNT) return false;
+  pa->simple_agg = tg.agg;
+  pa->simple_has_arg = tg.has_arg;
+  pa->simple_skip = tg.skip_null;
+  pa->simple_arg_nullable = tg.arg.nullable;
+  pa->simple_null = tg.null_val;
+  pa->simple_arg_null = tg.arg.null_val;
+  return true;
 }
 
 static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
@@ -1436,15 +1463,24 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
   const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
   const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
+  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
   if (k32) {
     launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
     launch_part_scatter<2, int32_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
-    hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    if (simple) {
+      hipLaunchKernelGGL(hdk_part_aggregate_simple<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    }
     hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   } else {
     launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
     launch_part_scatter<2, int64_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
-    hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    if (simple) {
+      hipLaunchKernelGGL(hdk_part_aggregate_simple<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    }
     hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   }
   // armed fallback: runs only if the scatter passes found the data too skewed for slabs
@@ -1558,6 +1594,16 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   return HDK_HIP_OK;
 }
 
+// HDK_HIP_LAUNCH_INIT_OUTPUT for the strategies that do not fuse it: the init kernel, on the launch stream
+static int32_t init_row_wise_output(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], int32_t device_id,
+                                    hipStream_t s) {
+  const uint32_t key_count = plan->keyless ? 0u : static_cast<uint32_t>(plan->key_count);
+  return launch_init_row_wise_indirect(reinterpret_cast<int64_t* const*>(params[HDK_KP_GROUPBY_BUF]),
+                                       reinterpret_cast<const int64_t*>(params[HDK_KP_INIT_AGG_VALS]), plan->entry_count,
+                                       key_count, static_cast<uint32_t>(plan->key_width), plan->row_size_quad,
+                                       plan->keyless, device_props(device_id), s);
+}
+
 extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
                                   const hdk_hip_kernel_options* ko, int32_t device_id, void* stream,
                                   void* workspace, size_t workspace_bytes) {
@@ -1620,11 +1666,20 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
 
   const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
+  bool init_output = ko && (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT);
+  if (init_output) {
+    HDK_REQUIRE((plan->query_kind == HDK_Q_PERFECT_HASH || plan->query_kind == HDK_Q_BASELINE_HASH) && !plan->output_columnar,
+                "HDK_HIP_LAUNCH_INIT_OUTPUT is for row-wise group-by buffers");
+  }
   if (shape.strategy == STRAT_LDS) {
     int64_t* slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(workspace) + kPlanRegionBytes);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
       st = scan_events_begin(device_id, s, &e0, &e1);
+      if (st) return st;
+    }
+    if (init_output) {
+      st = init_row_wise_output(plan, params, device_id, s);
       if (st) return st;
     }
     st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
@@ -1697,11 +1752,21 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     PartArgs part;
     if (shape.strategy == STRAT_GLOBAL && !(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) &&
         match_partitioned(plan, ko, &part)) {
+      part.init_output = init_output;
       st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
       if (st == kPartitionedNoScratch) {
+        if (init_output) {
+          st = init_row_wise_output(plan, params, device_id, s);
+          if (st) return st;
+        }
         st = launch_scan_global(plan, d_plan, kp, shape, s, false);
       }
+      init_output = false;  // done (fused into pass 3, or just above)
     } else {
+      if (init_output) {
+        st = init_row_wise_output(plan, params, device_id, s);
+        if (st) return st;
+      }
       st = launch_scan_global(plan, d_plan, kp, shape, s,
                               ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
     }

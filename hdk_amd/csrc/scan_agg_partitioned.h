@@ -88,6 +88,14 @@ struct PartArgs {
   uint32_t* nspill;      // [fine_count]: tuples in the region's own spill segment
   int64_t* spill_seg;    // [fine_count][kPartSpillSeg][tw]
   uint32_t* fallback;    // [1]: set when the overflow area is exhausted -> the atomics kernel takes over
+  int32_t init_output;   // HDK_HIP_LAUNCH_INIT_OUTPUT: the table holds nothing yet, pass 3 writes every region's image
+  // hdk_part_aggregate_simple: rows of [key quad | one 8-byte integer slot], one aggregate
+  int32_t simple_agg;          // hdk_hip_agg of that slot (SUM / MIN / MAX / COUNT), -1: the shape does not apply
+  int32_t simple_has_arg;      // the aggregate reads tuple word 1
+  int32_t simple_skip;         // *_skip_val: NULL arguments are skipped and the slot starts at its sentinel
+  int32_t simple_arg_nullable;
+  int64_t simple_null;         // the slot's sentinel
+  int64_t simple_arg_null;     // in-band NULL of the argument column
   int32_t nquals;        // plain filters, applied in pass 1
   ProjFastQual q[kMaxPlainQuals];
 };
@@ -100,12 +108,26 @@ HDK_DEV uint32_t fastmod_u32(uint32_t h, uint32_t magic, uint32_t shift, uint32_
   return h - q * d;
 }
 
-// the reference's first probe position of a tuple's key
+// the reference's first probe position of a tuple's key: key_hash % entry_count
 template <typename K, int TW = kPartMaxTW>
-HDK_DEV uint32_t part_home(const PartArgs& a, const int64_t* tup) {
+HDK_DEV uint32_t part_home_of_key(const PartArgs& a, const int64_t* tup) {
   const K k[2] = {static_cast<K>(tup[0]), TW > 1 ? static_cast<K>(tup[TW > 1 ? 1 : 0]) : K(0)};
   const uint32_t h = (TW > 1 && a.nkeys == 2) ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
   return fastmod_u32(h, a.mod_magic, a.mod_shift, a.entry_count);
+}
+// 4-byte keys leave the upper half of a tuple's first word free: pass 1 stores the home there, so that the hash
+// (MurmurHash3 over the key: ~25 instructions, a third of them quarter-rate multiplies) and the modulo are worked
+// out once per row instead of once per pass.  Every reader takes the key as static_cast<K>(word 0).
+template <typename K>
+HDK_DEV int64_t part_pack_home(int64_t word0, uint32_t home) {
+  return sizeof(K) == 4 ? static_cast<int64_t>((static_cast<uint64_t>(home) << 32) | static_cast<uint32_t>(word0)) : word0;
+}
+template <typename K, int TW = kPartMaxTW>
+HDK_DEV uint32_t part_home(const PartArgs& a, const int64_t* tup) {
+  if (sizeof(K) == 4) {
+    return static_cast<uint32_t>(static_cast<uint64_t>(tup[0]) >> 32);
+  }
+  return part_home_of_key<K, TW>(a, tup);
 }
 
 // region (fine partition) of a tuple's key: home / S
@@ -367,6 +389,12 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             }
           }
         }
+        if (sizeof(K) == 4) {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            tup[r][0] = part_pack_home<K>(tup[r][0], part_home_of_key<K, TW>(a, tup[r]));
+          }
+        }
         do_batch(live, tup);
       }
       frag_tile_begin += ntiles;
@@ -502,11 +530,28 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
   const uint32_t words = slots * rq;
   int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(first) * rq;
   const uint64_t n = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
-  if (n == 0 || *a.fallback) {
-    return;  // the region keeps its initialised (empty) image
-  }
-  for (uint32_t i = tid; i < words; i += kPartAggBlock) {
-    lds_table[i] = region[i];  // the init kernel's image (or an earlier launch's groups), whatever the layout
+  const bool idle = n == 0 || *a.fallback;  // nothing to aggregate here (or the atomics kernel will redo the launch)
+  if (a.init_output) {
+    // the table is uninitialised memory: build the region's image here -- the bytes the init kernel writes -- and
+    // store it whatever happens next (an idle region still has to read as empty; so does the fallback's table)
+    const uint32_t keys_quads = (static_cast<uint32_t>(p->key_count) * static_cast<uint32_t>(p->key_width) + 7) / 8;
+    for (uint32_t i = tid; i < words; i += kPartAggBlock) {
+      const int64_t v = init_row_quad(i % rq, keys_quads, p->key_count, p->key_width, a.kp.init_agg_vals);
+      lds_table[i] = v;
+      if (idle) {
+        region[i] = v;
+      }
+    }
+    if (idle) {
+      return;
+    }
+  } else {
+    if (idle) {
+      return;  // the region keeps its initialised (empty) image
+    }
+    for (uint32_t i = tid; i < words; i += kPartAggBlock) {
+      lds_table[i] = region[i];  // the init kernel's image (or an earlier launch's groups), whatever the layout
+    }
   }
   __syncthreads();
   const int tw = a.tw;
@@ -569,6 +614,151 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
   __syncthreads();
   for (uint32_t i = tid; i < words; i += kPartAggBlock) {
     region[i] = lds_table[i];
+  }
+  if (tid == 0) {
+    a.nspill[f] = min(s_nspill, kPartSpillSeg);
+  }
+}
+
+// ---- pass 3 for the common shape: one key, one 8-byte integer aggregate (C5: GROUP BY key, SUM(val)) ---------------
+// Same contract as hdk_part_aggregate -- image, bounded probe, spill segment -- with everything the general kernel
+// looks up per tuple (table shape, target descriptors, aggregate kind) fixed or block-uniform: the general kernel
+// spends ~210 vector + ~220 scalar instructions per tuple, most of them on its per-target interpreter.
+template <typename K>
+__global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(PartArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds_table[];
+  __shared__ uint32_t s_nspill;
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  const int tid = threadIdx.x;
+  const uint32_t f = blockIdx.x;
+  if (tid == 0) {
+    s_nspill = 0;
+  }
+  constexpr uint32_t rq = 2;
+  const uint32_t first = f * a.slots;
+  const uint32_t slots = min(a.slots, a.entry_count - first);
+  int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(first) * rq;
+  const uint64_t n = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
+  const bool idle = n == 0 || *a.fallback;
+  bf_i64x2* lds_rows = reinterpret_cast<bf_i64x2*>(lds_table);
+  bf_i64x2* region_rows = reinterpret_cast<bf_i64x2*>(region);  // (first * 16 bytes: aligned)
+  if (a.init_output) {
+    bf_i64x2 row;
+    row.x = init_row_quad(0, 1, 1, p->key_width, a.kp.init_agg_vals);
+    row.y = a.kp.init_agg_vals[0];
+    for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+      lds_rows[i] = row;
+      if (idle) {
+        region_rows[i] = row;
+      }
+    }
+    if (idle) {
+      return;
+    }
+  } else {
+    if (idle) {
+      return;
+    }
+    for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+      lds_rows[i] = region_rows[i];
+    }
+  }
+  __syncthreads();
+  const int agg = a.simple_agg;
+  const bool has_arg = a.simple_has_arg != 0;
+  const bool skip = a.simple_skip != 0;
+  const bool arg_nullable = a.simple_arg_nullable != 0;
+  const int64_t slot_null = a.simple_null;
+  const int64_t arg_null = a.simple_arg_null;
+  const int tw = a.tw;
+  const int64_t* in = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
+  const K ek = empty_key<K>();
+  auto apply = [&](int64_t t0, int64_t t1) {
+    const int64_t tup[2] = {t0, t1};
+    const uint32_t local = part_home<K, 2>(a, tup) - first;
+    if (local >= slots) {
+      return;  // padding of the scatter passes
+    }
+    const K key = static_cast<K>(t0);
+    uint32_t pos = local;
+    for (;;) {
+      K* kp = reinterpret_cast<K*>(lds_table + static_cast<size_t>(pos) * rq);
+      K old = *reinterpret_cast<volatile K*>(kp);  // look before claiming; a slot never returns to EMPTY
+      if (old == ek) {
+        if constexpr (sizeof(K) == 8) {
+          old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(kp), static_cast<unsigned long long>(ek),
+                                         static_cast<unsigned long long>(key)));
+        } else {
+          old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(kp), static_cast<unsigned int>(ek),
+                                         static_cast<unsigned int>(key)));
+        }
+        if (old == ek) {
+          break;  // claimed
+        }
+      }
+      if (old == key) {
+        break;
+      }
+      if (++pos == slots) {  // the group lives past the end of this region: pass 4 places it
+        const uint32_t k = atomicAdd(&s_nspill, 1u);
+        int64_t* q;
+        if (k < kPartSpillSeg) {
+          q = a.spill_seg + (static_cast<size_t>(f) * kPartSpillSeg + k) * tw;
+        } else {
+          const uint32_t o = atomicAdd(a.fill_spill, 1u);
+          if (o >= a.cap_spill) {
+            return;
+          }
+          q = a.slab1 + static_cast<size_t>(o) * tw;
+        }
+        q[0] = t0;
+        if (tw > 1) {
+          q[1] = t1;
+        }
+        return;
+      }
+    }
+    int64_t* slot = lds_table + static_cast<size_t>(pos) * rq + 1;
+    // NULL argument, or a value that collides with the skip value (`val != skip_val`): as part_apply_targets
+    if (has_arg && skip && ((arg_nullable && t1 == arg_null) || t1 == slot_null)) {
+      return;
+    }
+    if (agg == HDK_AGG_COUNT) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(slot), 1ull);
+    } else {
+      g_agg64(agg, false, skip, slot_null, slot, t1);
+    }
+  };
+  // two tuples per trip, the next pair's loads issued before the current pair is applied (see hdk_part_aggregate)
+  int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+  auto fetch = [&](uint64_t i, int64_t& t0, int64_t& t1) {
+    if (i < n) {
+      if (tw == 2) {
+        const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+            reinterpret_cast<uintptr_t>(in + i * 2)));
+        t0 = v.x;
+        t1 = v.y;
+      } else {
+        t0 = __builtin_nontemporal_load(in + i);
+        t1 = 0;
+      }
+    }
+  };
+  fetch(tid, a0, a1);
+  fetch(static_cast<uint64_t>(tid) + kPartAggBlock, b0, b1);
+  for (uint64_t i = tid; i < n; i += 2 * kPartAggBlock) {
+    const int64_t ta0 = a0, ta1 = a1, tb0 = b0, tb1 = b1;
+    const bool has_b = i + kPartAggBlock < n;
+    fetch(i + 2 * kPartAggBlock, a0, a1);
+    fetch(i + 3 * kPartAggBlock, b0, b1);
+    apply(ta0, ta1);
+    if (has_b) {
+      apply(tb0, tb1);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+    region_rows[i] = lds_rows[i];
   }
   if (tid == 0) {
     a.nspill[f] = min(s_nspill, kPartSpillSeg);

@@ -277,9 +277,30 @@ class PreparedStep:
                 self.d_total_matched.ptr, self.d_zero.ptr, 1, 0, 8, 1, 1, 1,
                 props.max_threads_per_block, props.grid_size, self.dev, stream))
 
-    def launch(self, stream=None):
-        check(self.L.hdk_hip_launch(C.byref(self.plan), self._params, C.byref(self.ko), self.dev, stream,
+    def launch(self, stream=None, init_output=False):
+        """hdk_hip_launch into the (initialised) output buffer; init_output=True hands the initialisation to the launch
+        (HDK_HIP_LAUNCH_INIT_OUTPUT: row-wise group-by buffers only, and only for a buffer that holds nothing yet)."""
+        ko = self.ko
+        if init_output:
+            ko = A.KernelOptions.from_buffer_copy(self.ko)
+            ko.flags |= A.LAUNCH_INIT_OUTPUT
+        check(self.L.hdk_hip_launch(C.byref(self.plan), self._params, C.byref(ko), self.dev, stream,
                                     self.workspace.ptr, self.workspace.nbytes))
+
+    @property
+    def launch_initialises(self) -> bool:
+        """A fresh row-wise open-addressing table: the launch writes the empty image itself -- the radix-partitioned
+        group-by builds it region by region in LDS, which saves a write and a read of the whole table."""
+        p = self.cp.plan
+        return p.query_kind == A.Q_BASELINE_HASH and not p.output_columnar
+
+    def enqueue(self, stream=None):
+        """One complete step on the stream: initialise the output buffer and launch (fused where the library can)."""
+        if self.launch_initialises:
+            self.launch(stream, init_output=True)
+        else:
+            self.init_output(stream)
+            self.launch(stream)
 
     def fetch(self, stream_synced=False) -> ExecutionResult:
         if not stream_synced:
@@ -296,8 +317,7 @@ class PreparedStep:
         return ExecutionResult(self.cp, buf[:self.buffer_bytes // 8], self.cp.entry_count, err, total)
 
     def run(self, stream=None) -> ExecutionResult:
-        self.init_output(stream)
-        self.launch(stream)
+        self.enqueue(stream)
         return self.fetch()
 
     # ---- hipGraph: record init + launch once, replay per execution (small inputs are launch-bound) --------
@@ -328,8 +348,7 @@ class PreparedStep:
         if self._graph:
             check(self.L.hdk_hip_graph_launch(self._graph, self.dev, stream))
         else:
-            self.init_output(stream)
-            self.launch(stream)
+            self.enqueue(stream)
 
     def free(self):
         if self._graph:

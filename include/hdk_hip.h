@@ -390,6 +390,13 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
 #define HDK_HIP_LAUNCH_CHECK_INTERRUPT 64u     /* poll the device's interrupt flag (hdk_hip_set_interrupt) once per
                                                   tile and stop with ERR_INTERRUPTED when it is set
                                                   (check_interrupt, QE/cuda_mapd_rt.cu:137-148) */
+#define HDK_HIP_LAUNCH_INIT_OUTPUT 128u        /* row-wise group-by plans: the output buffer is NOT initialised yet -- the
+                                                  launch writes the image hdk_hip_init_group_by_buffer would have (EMPTY
+                                                  keys, INIT_AGG_VALS) itself.  The radix-partitioned group-by builds each
+                                                  region's image in LDS instead of loading it and stores every region, which
+                                                  saves one write and one read of the whole table (a 200 M-entry table is
+                                                  3.2 GB); every other strategy simply runs the init kernel first.  Never
+                                                  set it when launching into a buffer that holds an earlier launch's groups */
 #define HDK_HIP_LAUNCH_FORCE_PARTITIONED 16u   /* take the radix-partitioned group-by whenever the plan shape
                                                   allows it, whatever the table size (testing) */
 #define HDK_HIP_LAUNCH_PLAN_RESIDENT 32u       /* the head of `workspace` already holds this plan (an earlier

@@ -21,15 +21,13 @@ def timed(step, reps=5, warm=2):
     from hdk_amd._lib import check, lib
     L = lib()
     for _ in range(warm):
-        step.init_output()
-        step.launch()
+        step.enqueue()
     step.mgr.synchronizeStream(step.dev)
     n = C.c_int32(0)
     check(L.hdk_hip_collect_scan_times(step.dev, None, 0, C.byref(n)))
     t0 = time.perf_counter()
     for _ in range(reps):
-        step.init_output()
-        step.launch()
+        step.enqueue()
     step.mgr.synchronizeStream(step.dev)
     wall = (time.perf_counter() - t0) / reps
     buf = (C.c_float * reps)()

@@ -6,7 +6,7 @@ import pytest
 
 from hdk_amd import _abi as A
 from hdk_amd import result_set as rs
-from hdk_amd.ir import Agg, ColRef, KeyRef, QueryUnit
+from hdk_amd.ir import Agg, Cmp, ColRef, KeyRef, Lit, QueryUnit
 from hdk_amd.storage import ArrowStorage
 
 from util import assert_buffers_equal, run_oracle
@@ -468,3 +468,41 @@ def test_partitioned_full_table_reports_out_of_slots(oracle, gpu_executor_factor
     with pytest.raises(HdkHipError) as ei:
         gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
     assert ei.value.code == A.ERR_OUT_OF_SLOTS
+
+
+def test_launch_initialises_a_poisoned_table(oracle, gpu_executor_factory):
+    """HDK_HIP_LAUNCH_INIT_OUTPUT: the launch itself produces the empty image (the partitioned group-by region by region
+    in LDS, the other strategies through the init kernel).  The buffer is filled with garbage first; uniform keys, a
+    heavy hitter that drives the partitioned passes into their atomics fallback, and a filter that leaves regions
+    without a single tuple."""
+    rng = np.random.default_rng(2026)
+    n = 600_000
+    cases = {"uniform": rng.integers(0, 90_000, n, dtype=np.int64) * 7919,
+             "heavy": np.where(rng.random(n) < 0.7, 12345, rng.integers(0, 50_000, n, dtype=np.int64))}
+    for name, key in cases.items():
+        v = rng.integers(-1000, 1000, n).astype(np.int64)
+        v[rng.random(n) < 0.05] = A.NULL_BIGINT
+        st = ArrowStorage()
+        st.import_numpy("t", {"key": key, "v": v}, fragment_size=150_000)
+        for quals in ([], [Cmp(ColRef("key"), "<", Lit(2000))]):
+            q = QueryUnit("t", quals=quals, groupby=[ColRef("key")], force_baseline=True, baseline_entry_count=400_009,
+                          targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+            cp, want, err = run_oracle(oracle, st, q)
+            assert err == 0
+            ex = gpu_executor_factory(st)
+            for flags in (A.LAUNCH_FORCE_PARTITIONED, 0, A.LAUNCH_FORCE_GENERIC):
+                step = ex.prepare(cp, flags=flags)
+                assert step.launch_initialises
+                ex.mgr.setDeviceMem(step.out_ptr, 0xAB, cp.buffer_bytes, 0)
+                res = step.run()
+                step.free()
+                _check_rows(cp, res.buffer, want)
+                _assert_reference_placement(oracle, cp, res.buffer)
+                # every entry that holds no group reads as the init image
+                keys = rs._key_arrays(cp, res.buffer, cp.entry_count)[0]
+                empty = keys == (A.EMPTY_KEY_32 if cp.plan.key_width == 4 else A.EMPTY_KEY_64)
+                assert np.count_nonzero(empty) == cp.entry_count - len(_rows(cp, res.buffer))
+                slots = rs._slot_arrays(cp, res.buffer, cp.entry_count)
+                for arr, w, iv in zip(slots, cp.slot_widths, cp.init_vals):
+                    if w:
+                        assert np.all(arr[empty] == iv)

@@ -42,8 +42,7 @@ def _run_into(w, out, flags=0):
     import torch
     step = w.ex.prepare(w.compiled, w.frag_ids, flags=flags, out_ptr=out.data_ptr())
     names = step.kernel_names()
-    step.init_output()
-    step.launch()
+    step.enqueue()
     w.ex.mgr.synchronizeStream(0)
     err = int(w.ex.mgr.to_host(step.d_err.ptr, 4, 0, np.int32)[0])
     step.free()
