@@ -1518,6 +1518,15 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
   fa->columnar = p->output_columnar;
   fa->row_size_quad = p->row_size_quad;
   fa->entry_count = p->entry_count;
+  // rows dealt in adjacent pairs (16-byte loads, scan_project_fast.h): every filter column is an 8-byte integer or
+  // double column compared in its own class
+  fa->pairs = fa->nquals > 0;
+  for (int i = 0; i < fa->nquals; ++i) {
+    const ProjFastQual& fq = fa->q[i];
+    if (fq.col.width != 8 || (fq.col.kind != HDK_COL_INT && fq.col.kind != HDK_COL_DOUBLE) || (fq.fp != 0) != (fq.col_fp != 0)) {
+      fa->pairs = 0;
+    }
+  }
   // columnar target columns: [int64 row positions][target columns, each aligned to 8]
   size_t off = (static_cast<size_t>(p->entry_count) * 8 + 7) & ~size_t(7);
   for (int t = 0; t < p->num_targets; ++t) {
@@ -1732,9 +1741,17 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
           (void)hipGetLastError();
         }
       }
-      hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      if (pf.pairs) {
+        hipLaunchKernelGGL(hdk_scan_project_count_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      } else {
+        hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      }
       hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
-      hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      if (pf.pairs) {
+        hipLaunchKernelGGL(hdk_scan_project_direct_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      } else {
+        hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+      }
       if (pf.sel_mask) {
         HDK_HIP_CHECK(hipFreeAsync(pf.sel_mask, s));
       }

@@ -46,12 +46,14 @@ struct ProjFastArgs {
   uint32_t* block_counts;                 // [gridDim.x]: pass-1 counts, then exclusive offsets
   uint8_t* sel_mask;                      // pass 1 -> pass 2: one byte (VR pass bits) per thread and tile, or nullptr
   uint64_t sel_tiles;                     // tiles the mask has room for; later tiles re-evaluate the filter in pass 2
+  int32_t pairs;                          // every filter column is 8 bytes wide: the *_pairs kernels (rows dealt two at a time)
 };
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
 // and 2k+1 are ADJACENT rows of an 8-byte column, one 16-byte load per lane.  Measured on this kernel the
-// paired form did not pay (counting pass 0.54 vs ~0.6 ms per 256 M rows, write pass 2x slower through
-// the extra predication), so only R = 1 is instantiated; the mapping is kept for the next attempt.
+// paired form did not pay as long as it went through the predicated loaders below (counting pass 0.54 vs ~0.6 ms
+// per 256 M rows); the *_pairs kernels take it with pf_filter_full_tile_pairs for the counting pass, and the
+// writing pass only reads the verdict bits.
 template <int BLOCK, int R>
 HDK_DEV int64_t pf_row(int64_t tile_row0, int tid, int r) {
   return R == 1 ? tile_row0 + static_cast<int64_t>(r) * BLOCK + tid
@@ -132,12 +134,67 @@ HDK_DEV bool proj_fast_cmp(int cmp, bool fp, int64_t l, int64_t r) {
   }
 }
 
+// The filter over one FULL tile whose filter columns are all 8 bytes wide, rows dealt in adjacent pairs (R = 2): every
+// lane reads 16 bytes per load, lane after lane contiguous, no bounds tests, and the verdicts live in ONE register per
+// lane (bit r = slot r passes) -- a bool per row carried round the conjunct loop is kept by the compiler as a 0/1 byte
+// in a VGPR and converted back and forth every trip.
+HDK_DEV uint32_t pf_filter_full_tile_pairs(const ProjFastArgs& a, const int8_t* const* cols, int64_t row0, int tid) {
+  constexpr int VR = kProjFastVR;
+  uint32_t m = (1u << VR) - 1u;
+#pragma unroll 1
+  for (int qi = 0; qi < a.nquals; ++qi) {
+    const ProjFastQual q = a.q[qi];
+    const uint64_t b = reinterpret_cast<uintptr_t>(cols[q.col.buf_idx]) + static_cast<uint64_t>(row0) * 8;
+    const uint32_t b_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
+    const uint32_t b_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b >> 32));
+    const __attribute__((address_space(1))) int8_t* base =
+        reinterpret_cast<const __attribute__((address_space(1))) int8_t*>((static_cast<uint64_t>(b_hi) << 32) | b_lo);
+    int64_t v[VR];
+#pragma unroll
+    for (int u = 0; u < VR / 2; ++u) {
+      const uint32_t off = static_cast<uint32_t>(u * kProjFastBlock + tid) * 16u;
+      const pf_i64x2 x = *reinterpret_cast<const __attribute__((address_space(1))) pf_i64x2*>(base + off);
+      v[2 * u] = x.x;
+      v[2 * u + 1] = x.y;
+    }
+    const bool fp = q.fp != 0;  // an 8-byte column compared as doubles is a double column (col_fp == fp here)
+    uint32_t fail = 0;
+    if (q.nullable) {
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const bool isnull = fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val;
+        fail |= isnull ? (1u << r) : 0u;
+      }
+    }
+#define HDK_PF_FAIL(OP)                                                                               \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                     \
+    const bool ok = fp ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs);            \
+    fail |= ok ? 0u : (1u << r);                                                                       \
+  }
+    switch (q.cmp) {
+      case HDK_CMP_EQ: HDK_PF_FAIL(==) break;
+      case HDK_CMP_NE: HDK_PF_FAIL(!=) break;
+      case HDK_CMP_LT: HDK_PF_FAIL(<) break;
+      case HDK_CMP_GT: HDK_PF_FAIL(>) break;
+      case HDK_CMP_LE: HDK_PF_FAIL(<=) break;
+      default: HDK_PF_FAIL(>=) break;
+    }
+#undef HDK_PF_FAIL
+    m &= ~fail;
+  }
+  return m;
+}
+
+constexpr int kProjFastGroup = 4;  // writing pass: tiles handled per block-wide scan (one barrier per group, not per tile)
+
 template <int MODE, int R>  // MODE 0: count passing rows per block; 1: write them.  R: see pf_row
 HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   constexpr int VR = kProjFastVR;
+  constexpr int G = kProjFastGroup;
   constexpr int kWaves = kProjFastBlock / kWave;
   __shared__ uint32_t s_wave_tot[2][kWaves];
-  __shared__ uint16_t s_rows[kWaves][kWave * kProjFastVR];  // MODE 1: per wave, tile-relative rows that pass, in output order
+  // MODE 1: per wave, the passing rows of the group in output order: (tile of the group) << 12 | row inside the tile
+  __shared__ uint16_t s_rows[MODE == 1 ? kWaves : 1][MODE == 1 ? kWave * kProjFastVR * G : 1];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
@@ -171,20 +228,36 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
         }
       }
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
-      bool pass[VR];
-#pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
-      }
       const bool masked = a.sel_mask != nullptr && static_cast<uint64_t>(tile) < a.sel_tiles;  // block-uniform
       uint8_t* mask_at = a.sel_mask + static_cast<size_t>(tile) * kProjFastBlock + tid;
-      if (MODE == 1 && masked) {
-        const uint32_t m = __builtin_nontemporal_load(mask_at);
+      if (MODE == 0 && R == 2 && row0 + kTileRows <= nrows) {  // the counting pass over a full tile: straight line
+        const uint32_t m = pf_filter_full_tile_pairs(a, cols, row0, tid);
+        if (masked) {
+          *mask_at = static_cast<uint8_t>(m);
+        }
+        counted += __builtin_popcount(m);
+        continue;
+      }
+      // verdict bits of this lane: bit g * VR + r = slot r of the group's g-th tile passes
+      uint32_t bits = 0;
+      int group = 1;
+      const int64_t group_last = tile + static_cast<int64_t>(G - 1) * gridDim.x;
+      if (MODE == 1 && masked && group_last < frag_tile_begin + ntiles && static_cast<uint64_t>(group_last) < a.sel_tiles) {
+        // the block's next G tiles of this fragment all have their verdicts in the mask: one scan, one barrier
+        group = G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          bits |= static_cast<uint32_t>(__builtin_nontemporal_load(mask_at + static_cast<size_t>(g) * gridDim.x * kProjFastBlock))
+                  << (g * VR);
+        }
+      } else if (MODE == 1 && masked) {
+        bits = __builtin_nontemporal_load(mask_at);
+      } else {
+        bool pass[VR];
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          pass[r] = (m >> r) & 1u;
+          pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
         }
-      } else {
         // ---- filter: decode + compare, all VR loads of a column in flight together -----------------------
         for (int qi = 0; qi < a.nquals; ++qi) {
           const ProjFastQual q = a.q[qi];
@@ -217,20 +290,15 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
           }
 #undef HDK_PF_CMP
         }
-      }
-      if (MODE == 0 && masked) {
-        uint32_t m = 0;
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          m |= (pass[r] ? 1u : 0u) << r;
+          bits |= (pass[r] ? 1u : 0u) << r;
         }
-        *mask_at = static_cast<uint8_t>(m);
+        if (MODE == 0 && masked) {
+          *mask_at = static_cast<uint8_t>(bits);
+        }
       }
-      uint32_t mine = 0;
-#pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        mine += pass[r] ? 1u : 0u;
-      }
+      const uint32_t mine = __builtin_popcount(bits);
       if (MODE == 0) {
         counted += mine;
         continue;
@@ -247,7 +315,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       uint32_t out_pos = running + incl - mine;
       uint32_t tile_total = 0;
       {
-        const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one tile ahead
+        const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one group ahead
         if (lane == kWave - 1) {
           s_wave_tot[par][wave] = incl;
         }
@@ -271,22 +339,25 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       const uint32_t wave_base = out_pos - (incl - mine);  // first output row of this wave's rows
       {
         uint32_t j = incl - mine;
-#pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          if (pass[r]) {
-            s_rows[wave][j++] = static_cast<uint16_t>(r * kProjFastBlock + tid);  // row inside the tile (< 4096)
-          }
+        uint32_t left = bits;
+        while (left) {
+          const int b = __ffs(left) - 1;
+          left &= left - 1;
+          s_rows[wave][j++] = static_cast<uint16_t>(((b / VR) << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, b % VR)));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // row of a strip entry: the group's g-th tile is `g * gridDim.x` tiles further on
+      const int64_t group_stride_rows = static_cast<int64_t>(gridDim.x) * kTileRows;
+      auto row_of = [&](uint32_t e) { return row0 + static_cast<int64_t>(e >> 12) * group_stride_rows + (e & 4095u); };
       // ---- project: row position, then each target column ---------------------------------------------
       const size_t rq = a.row_size_quad;
       for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
         const uint32_t j = j0 + lane;
         if (j < wave_total) {
-          const int64_t row = row0 + s_rows[wave][j];
+          const int64_t row = row_of(s_rows[wave][j]);
           const uint32_t pos = wave_base + j;
           if (pos >= max_matched) {
             slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
@@ -304,7 +375,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
           const uint32_t j = j0 + lane;
           const uint32_t pos = wave_base + j;
           if (j < wave_total && pos < max_matched) {
-            const int64_t row = row0 + s_rows[wave][j];
+            const int64_t row = row_of(s_rows[wave][j]);
             const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
             int8_t* dst = base + static_cast<size_t>(pos) * stride;
             switch (t.slot_width) {
@@ -316,7 +387,8 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next tile
+      __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
+      tile += static_cast<int64_t>(group - 1) * gridDim.x;
     }
     frag_tile_begin += ntiles;
   }
@@ -346,6 +418,13 @@ extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_co
 }
 extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct(ProjFastArgs a) {
   scan_project_direct_body<1, 1>(a);
+}
+// rows dealt in adjacent pairs: every filter column is 8 bytes wide (match_project_fast: pairs)
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_count_pairs(ProjFastArgs a) {
+  scan_project_direct_body<0, 2>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct_pairs(ProjFastArgs a) {
+  scan_project_direct_body<1, 2>(a);
 }
 // per-block counts -> exclusive offsets (in place), starting at what TOTAL_MATCHED already holds (like the claiming
 // kernels of scan_project.h, which append with atomicAdd); the grand total is added to TOTAL_MATCHED
