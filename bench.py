@@ -415,6 +415,8 @@ def main():
     extra = args.extra
     if extra == "auto":
         extra = "c3,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
+    if extra == "none":
+        extra = ""
     configs = []
     for name in [x for x in extra.split(",") if x]:
         import gc
