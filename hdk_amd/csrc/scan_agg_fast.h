@@ -80,24 +80,31 @@ HDK_DEV int64_t extract_elem(const uint32_t* regs, int i) {
   }
 }
 
-// load NB bytes (4, 8 or 16; or 2/1 for the narrowest cases) for this lane
+// load NB bytes (4, 8 or 16; or 2/1 for the narrowest cases) for this lane.  NT: non-temporal -- a column is read once
+// and 16 GB of it streaming through L2 and the Infinity Cache as ordinary (allocating) loads cost C2 9 %
+// (6.1 -> 6.7 TB/s at 1 B rows with the hint, same kernel otherwise)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int NB>
+template <int NB, bool NT = false>
 HDK_DEV void load_bytes(gcol_t p, uint32_t* regs) {
   if (NB == 16) {
-    const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(p);
+    const __attribute__((address_space(1))) u32x4* q = reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(p);
+    const u32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
     regs[0] = v.x; regs[1] = v.y; regs[2] = v.z; regs[3] = v.w;
   } else if (NB == 8) {
-    const u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x2*>(p);
+    const __attribute__((address_space(1))) u32x2* q = reinterpret_cast<const __attribute__((address_space(1))) u32x2*>(p);
+    const u32x2 v = NT ? __builtin_nontemporal_load(q) : *q;
     regs[0] = v.x; regs[1] = v.y;
   } else if (NB == 4) {
-    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(p);
+    const __attribute__((address_space(1))) uint32_t* q = reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(p);
+    regs[0] = NT ? __builtin_nontemporal_load(q) : *q;
   } else if (NB == 2) {
-    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint16_t*>(p);
+    const __attribute__((address_space(1))) uint16_t* q = reinterpret_cast<const __attribute__((address_space(1))) uint16_t*>(p);
+    regs[0] = NT ? __builtin_nontemporal_load(q) : *q;
   } else {
-    regs[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(p);
+    const __attribute__((address_space(1))) uint8_t* q = reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(p);
+    regs[0] = NT ? __builtin_nontemporal_load(q) : *q;
   }
 }
 
@@ -270,14 +277,15 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
       HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       if (row0 + kTileRows <= nrows) {
-        // full tile: U coalesced 16-B steps per column, all issued before the first use
+        // full tile: U coalesced 16-B steps per column, all issued before the first use.  (Issuing the NEXT tile's
+        // loads before applying this one -- a second register set -- measured 2-3 % slower: 6.6 against 6.75 TB/s.)
         uint32_t kr[U][KREGS];
         uint32_t vr[U][VREGS];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t r = row0 + (static_cast<int64_t>(u) * kFastBlock + tid) * R;
-          if (KW) load_bytes<(KB > 0 ? KB : 4)>(kcol + r * KW, kr[u]);
-          if (VW) load_bytes<(VB > 0 ? VB : 4)>(vcol + r * VW, vr[u]);
+          if (KW) load_bytes<(KB > 0 ? KB : 4), true>(kcol + r * KW, kr[u]);
+          if (VW) load_bytes<(VB > 0 ? VB : 4), true>(vcol + r * VW, vr[u]);
         }
         bool pass[U * R];
 #pragma unroll

@@ -153,7 +153,7 @@ HDK_DEV uint32_t pf_filter_full_tile_pairs(const ProjFastArgs& a, const int8_t* 
 #pragma unroll
     for (int u = 0; u < VR / 2; ++u) {
       const uint32_t off = static_cast<uint32_t>(u * kProjFastBlock + tid) * 16u;
-      const pf_i64x2 x = *reinterpret_cast<const __attribute__((address_space(1))) pf_i64x2*>(base + off);
+      const pf_i64x2 x = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) pf_i64x2*>(base + off));
       v[2 * u] = x.x;
       v[2 * u + 1] = x.y;
     }
