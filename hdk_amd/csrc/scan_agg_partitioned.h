@@ -44,6 +44,10 @@ namespace hdk {
 
 constexpr int kPartBlock = 512;                  // scatter passes (sweep at C5: 256x8 3.7 ms, 512x4 2.9 ms, 1024x2 3.9 ms for pass 1)
 constexpr int kPartAggBlock = 1024;              // aggregation pass: 2 blocks x 64 KiB LDS per CU, all 32 wave slots busy
+#ifndef HDK_PART_NT_STORES
+#define HDK_PART_NT_STORES 0  // measured: non-temporal copy-out and write-back stores are SLOWER (3.04 + 2.85 + 1.89 ms against 2.73 + 2.59 + 1.70): partial lines are merged in L2
+#endif
+constexpr bool kPartNtStores = HDK_PART_NT_STORES != 0;
 constexpr int kPartVR = 4;
 constexpr int kPartTile = kPartBlock * kPartVR;  // new tuples per scatter batch
 constexpr int kPartMaxBins = 256;                // bins a scatter pass distinguishes (P1 <= 256, P2 <= 256)
@@ -310,7 +314,11 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         bf_i64x2 v;
         v.x = t[0];
         v.y = t[1];
-        *reinterpret_cast<bf_i64x2*>(q) = v;
+        if (kPartNtStores) {
+          __builtin_nontemporal_store(v, reinterpret_cast<bf_i64x2*>(q));
+        } else {
+          *reinterpret_cast<bf_i64x2*>(q) = v;
+        }
       } else {
 #pragma unroll
         for (int w = 0; w < TW; ++w) {
@@ -758,7 +766,11 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
   }
   __syncthreads();
   for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
-    region_rows[i] = lds_rows[i];
+    if (kPartNtStores) {
+      __builtin_nontemporal_store(lds_rows[i], region_rows + i);
+    } else {
+      region_rows[i] = lds_rows[i];
+    }
   }
   if (tid == 0) {
     a.nspill[f] = min(s_nspill, kPartSpillSeg);
