@@ -1321,6 +1321,10 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   }
   pa->ntargets = bf.ntargets;
   pa->tw = pa->nkeys + pa->nargs;
+  pa->all_wide = pa->key_width == 8 && pa->key_kind == HDK_COL_INT && (pa->nkeys < 2 || (pa->key2_width == 8 && pa->key2_kind == HDK_COL_INT));
+  for (int k = 0; k < pa->nargs; ++k) {
+    if (pa->arg[k].width != 8 || (pa->arg[k].kind != HDK_COL_INT && pa->arg[k].kind != HDK_COL_DOUBLE)) pa->all_wide = 0;
+  }
   pa->entry_count = p->entry_count;
   magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
   // regions: as many entries as fit the LDS image
@@ -1369,6 +1373,8 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   const uint64_t batches2 = share1 / kPartTile + kPartG2X;  // batches a coarse slab is scattered in
   pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (g - 1) * 5 / 8);  // 25 % + 256 + padding
   pa->cap_ovf = rows / 16 + 4096;
+  pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
+  pa->cap1 = pa->sub1 * kPartXcds;
   pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
   if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFFFFF0ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
   return true;
@@ -1440,7 +1446,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
   const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
   const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
-  const size_t nc = static_cast<size_t>(pa.p1) * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
+  const size_t nc = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
   const size_t bc = nc * sizeof(uint32_t);
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   int8_t* scratch = nullptr;
@@ -1455,18 +1461,20 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
   pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
   pa.fill1 = reinterpret_cast<uint32_t*>(q);
-  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartCursorStride;
+  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride;
   pa.nspill = pa.fill2 + pa.fine_count;
   pa.fill_ovf = pa.nspill + pa.fine_count;
   pa.fill_spill = pa.fill_ovf + 1;
   pa.fallback = pa.fill_spill + 1;
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
   const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
+  // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
+  const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
   const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
   const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
   if (k32) {
     launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int32_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
+    launch_part_scatter<2, int32_t>(pa.tw, dim3(g2), lds2, s, pa);
     if (simple) {
       hipLaunchKernelGGL(hdk_part_aggregate_simple<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     } else {
@@ -1475,7 +1483,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
     hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   } else {
     launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int64_t>(pa.tw, dim3(kPartG2X, pa.p1), lds2, s, pa);
+    launch_part_scatter<2, int64_t>(pa.tw, dim3(g2), lds2, s, pa);
     if (simple) {
       hipLaunchKernelGGL(hdk_part_aggregate_simple<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     } else {

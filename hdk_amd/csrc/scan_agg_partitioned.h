@@ -56,6 +56,7 @@ constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: 1-2 keys + argu
 constexpr uint32_t kPartLdsBytes = 60 * 1024;    // LDS image of a region (two 1024-thread blocks per CU; above 64 KiB per block only one was resident)
 constexpr uint32_t kPartCursorStride = 32;       // uint32 cursors one per 128-byte line
 constexpr int kPartG2X = 16;                     // pass-2 blocks per coarse slab
+constexpr int kPartXcds = 8;                     // L2 domains: a line of a slab should only ever be written from one of them
 constexpr uint32_t kPartSpillSeg = 64;           // spilled tuples a region keeps in its own segment before it takes the shared list
 
 struct PartArgs {
@@ -77,15 +78,17 @@ struct PartArgs {
   int32_t nkeys;         // 1 or 2 key columns: tuple = [key0, (key1), arguments...]
   int32_t key2_buf_idx, key2_width, key2_kind;
   int32_t nargs;
+  int32_t all_wide;      // key and argument columns are all 8 bytes wide (int64 / double): pass 1 reads full tiles with 16-byte loads
   BaseFastTarget arg[kPartMaxArgs];  // argument columns (buf_idx / width / kind); .target unused
   int32_t ntargets;
   int32_t tgt_index[HDK_HIP_MAX_TARGETS];  // plan target index
   int32_t tgt_arg[HDK_HIP_MAX_TARGETS];    // tuple word of its argument (>= nkeys), or 0 for none
   uint64_t cap1, cap2, cap_ovf, cap_spill; // capacities in tuples (cap1, cap2: multiples of G)
+  uint64_t sub1;         // a coarse slab is kPartXcds sub-slabs of sub1 tuples, one per XCD that writes (cap1 = 8 * sub1)
   int64_t* slab1;        // [p1][cap1][tw]            (pass 3 reuses this memory as the shared spill list)
   int64_t* slab2;        // [fine_count][cap2][tw]
   int64_t* ovf;          // [cap_ovf][tw]
-  uint32_t* fill1;       // [p1] x kPartCursorStride
+  uint32_t* fill1;       // [p1][kPartXcds] x kPartCursorStride
   uint32_t* fill2;       // [fine_count]
   uint32_t* fill_ovf;    // [1]
   uint32_t* fill_spill;  // [1]: the shared spill list (in slab1's memory), used once a region's own segment is full
@@ -180,11 +183,26 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   const uint32_t cap_stage = part_stage_tuples(nbins, gmask);
   int64_t* s_stage = s_dyn;
   uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(cap_stage) * tw);
-  const uint64_t cap = LEVEL == 1 ? a.cap1 : a.cap2;
-  const uint32_t cstride = LEVEL == 1 ? kPartCursorStride : 1;
-  const uint32_t bin0 = LEVEL == 1 ? 0 : (blockIdx.y << a.p2_log2);  // first region of the coarse slab
-  uint32_t* fill = (LEVEL == 1 ? a.fill1 : a.fill2) + static_cast<size_t>(bin0) * cstride;
-  int64_t* out = (LEVEL == 1 ? a.slab1 : a.slab2) + static_cast<size_t>(bin0) * cap * tw;
+  // Partial lines at the ends of a run are completed by whoever claims the neighbouring run; the two halves merge in
+  // L2 only if both writers sit behind the SAME L2 (scripts/microbench/partition.hip: one cursor and sub-slab per
+  // (bin, XCD) 1.9 ms per 256 M tuples, shared cursors 2.45).  Level 1: a coarse slab is eight sub-slabs, a block
+  // appends to the one of its XCD (block b runs on XCD b % 8 -- affinity for speed only, any mapping is correct).
+  // Level 2: all blocks of a coarse slab are launched on one XCD (see the id -> (c, member) mapping below), so the
+  // fine slabs need no split.
+  // (level 1 asks the hardware which XCD it runs on -- HW_REG_XCC_ID, bits 3:0; level 2 needs the launch-order mapping)
+  const uint32_t xcd = LEVEL == 1 ? (static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (kPartXcds - 1))
+                                  : (blockIdx.x & (kPartXcds - 1));
+  const uint32_t l2_c = LEVEL == 2 ? (blockIdx.x / (kPartXcds * kPartG2X)) * kPartXcds + xcd : 0;  // coarse slab of this block
+  const uint32_t l2_m = LEVEL == 2 ? (blockIdx.x / kPartXcds) % kPartG2X : 0;                        // its member number
+  if (LEVEL == 2 && l2_c >= a.p1) {
+    return;
+  }
+  const uint64_t cap = LEVEL == 1 ? a.sub1 : a.cap2;  // what a cursor may hand out
+  const uint64_t bin_stride = LEVEL == 1 ? a.cap1 : a.cap2;  // tuples from one bin's slab to the next
+  const uint32_t cstride = LEVEL == 1 ? kPartCursorStride * kPartXcds : 1;
+  const uint32_t bin0 = LEVEL == 1 ? 0 : (l2_c << a.p2_log2);  // first region of the coarse slab
+  uint32_t* fill = (LEVEL == 1 ? a.fill1 + static_cast<size_t>(xcd) * kPartCursorStride : a.fill2) + static_cast<size_t>(bin0) * cstride;
+  int64_t* out = (LEVEL == 1 ? a.slab1 + static_cast<size_t>(xcd) * a.sub1 * tw : a.slab2) + static_cast<size_t>(bin0) * bin_stride * tw;
   for (int i = tid; i < kPartMaxBins; i += kPartBlock) {
     s_cnt[i] = 0;
   }
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         }
       }
       int64_t* q = r >= nfit ? a.ovf + (static_cast<size_t>(s_obase[b]) + (r - nfit)) * tw
-                             : out + (static_cast<size_t>(b) * cap + run.z + r) * tw;
+                             : out + (static_cast<size_t>(b) * bin_stride + run.z + r) * tw;
       int64_t t[TW];
       if (TW == 2) {
         const bf_i64x2 v = reinterpret_cast<const bf_i64x2*>(s_stage)[i];
@@ -362,6 +380,39 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         const int64_t row0 = (tile - frag_tile_begin) * kPartTile + tid;
         bool live[VR];
         int64_t tup[VR][TW];
+        if (a.all_wide && !a.nquals && (tile - frag_tile_begin + 1) * kPartTile <= nrows) {
+          // full tile, every tuple column 8 bytes wide, no filter: rows dealt in adjacent pairs, one 16-byte
+          // non-temporal load per lane and pair, no bounds tests (which rows a lane takes does not matter to a scatter)
+          const uint64_t tile_byte0 = static_cast<uint64_t>(tile - frag_tile_begin) * kPartTile * 8;
+#pragma unroll
+          for (int w = 0; w < TW; ++w) {
+            const int bi = w == 0 ? a.key_buf_idx : (w < a.nkeys ? a.key2_buf_idx : a.arg[w - a.nkeys > 0 ? 1 : 0].buf_idx);
+            const uint64_t b = reinterpret_cast<uintptr_t>(cols[bi]) + tile_byte0;
+            const uint32_t b_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
+            const uint32_t b_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b >> 32));
+            const __attribute__((address_space(1))) int8_t* base =
+                reinterpret_cast<const __attribute__((address_space(1))) int8_t*>((static_cast<uint64_t>(b_hi) << 32) | b_lo);
+#pragma unroll
+            for (int u = 0; u < VR / 2; ++u) {
+              const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+                  base + static_cast<uint32_t>(u * kPartBlock + tid) * 16u));
+              tup[2 * u][w] = v.x;
+              tup[2 * u + 1][w] = v.y;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            live[r] = true;
+          }
+          if (sizeof(K) == 4) {
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              tup[r][0] = part_pack_home<K>(tup[r][0], part_home_of_key<K, TW>(a, tup[r]));
+            }
+          }
+          do_batch(live, tup);
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
           live[r] = row0 + static_cast<int64_t>(r) * kPartBlock < nrows;
@@ -408,13 +459,46 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
       frag_tile_begin += ntiles;
     }
   } else {
-    // coarse slab c: [0, min(cursor, cap)); a slot that does not belong to c is padding
-    const uint32_t c = blockIdx.y;
-    const uint64_t n = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(c) * kPartCursorStride]), a.cap1);
-    const int64_t* in = a.slab1 + static_cast<size_t>(c) * a.cap1 * tw;
-    for (uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kPartTile; t0 < n; t0 += static_cast<uint64_t>(gridDim.x) * kPartTile) {
+    // coarse slab c = eight sub-slabs [0, min(cursor, sub1)); a slot that does not belong to c is padding.  The
+    // block walks the tiles of the eight sub-slabs as one sequence, member m taking tiles m, m + G, ...
+    const uint32_t c = l2_c;
+    uint32_t sub_n[kPartXcds], sub_tiles_before[kPartXcds + 1];
+    sub_tiles_before[0] = 0;
+#pragma unroll
+    for (int x = 0; x < kPartXcds; ++x) {
+      sub_n[x] = static_cast<uint32_t>(min(static_cast<uint64_t>(a.fill1[(static_cast<size_t>(c) * kPartXcds + x) * kPartCursorStride]), a.sub1));
+      sub_tiles_before[x + 1] = sub_tiles_before[x] + (sub_n[x] + kPartTile - 1) / kPartTile;
+    }
+    for (uint32_t vt = l2_m; vt < sub_tiles_before[kPartXcds]; vt += kPartG2X) {
+      uint32_t sx = 0;
+#pragma unroll
+      for (int x = 1; x < kPartXcds; ++x) {
+        sx += vt >= sub_tiles_before[x] ? 1u : 0u;
+      }
+      uint64_t n = 0, t0 = 0;
+#pragma unroll
+      for (int x = 0; x < kPartXcds; ++x) {  // (static indexing: the arrays stay in scalar registers)
+        if (sx == static_cast<uint32_t>(x)) {
+          n = sub_n[x];
+          t0 = static_cast<uint64_t>(vt - sub_tiles_before[x]) * kPartTile;
+        }
+      }
+      const int64_t* in = a.slab1 + (static_cast<size_t>(c) * a.cap1 + static_cast<size_t>(sx) * a.sub1) * tw;
       bool live[VR];
       int64_t tup[VR][TW];
+      if (TW == 2 && t0 + kPartTile <= n) {  // full tile of 16-byte tuples: unconditional loads
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const uint64_t i = t0 + static_cast<uint64_t>(r) * kPartBlock + tid;
+          const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+              reinterpret_cast<uintptr_t>(in + i * 2)));
+          tup[r][0] = v.x;
+          tup[r][TW - 1] = v.y;
+          live[r] = (part_region<K, TW>(a, tup[r]) >> a.p2_log2) == c;
+        }
+        do_batch(live, tup);
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
         const uint64_t i = t0 + static_cast<uint64_t>(r) * kPartBlock + tid;

@@ -12,6 +12,7 @@
 //       bit 128: 16-byte LDS staging and copy-out (ds_write_b128 / global_store_dwordx4)
 //       bit 256: with bit 16, every sub-slab starts 64 bytes into a 128-byte line (runs aligned to 64 B only)
 //       bit 512: with bit 16, every sub-slab starts 32 bytes into a line (runs aligned to 32 B only)
+//       bit 1024: one global cursor and one sub-slab per (bin, XCD = block % 8), cursors one per 128-B line
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +104,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter_v0(Args a) {
         s_cur[tid] = c + n <= sub_cap ? c + n : n;
       } else if (ABL & 1) {
         s_base[tid] = (fake + tid * 131u) % (uint32_t)(a.cap - T);
+      } else if (ABL & 1024) {  // one cursor and one sub-slab per (bin, XCD): a line is only ever written by one XCD's L2
+        const uint32_t x = blockIdx.x & 7u;
+        const uint32_t sub = (uint32_t)((a.cap / 8) & ~7ull);
+        s_base[tid] = x * sub + (n ? atomicAdd(a.fill + (tid * 8 + x) * 32, n) : 0u);
       } else {
         s_base[tid] = n ? atomicAdd(a.fill + tid * CSTRIDE, n) : 0u;
       }
@@ -168,7 +173,7 @@ static void run_v0(Args a, int grid, const char* label) {
   const size_t lds = (size_t)kBlock * VR * 16;
   float best = 1e9f;
   for (int rep = 0; rep < 3; ++rep) {
-    CK(hipMemsetAsync(a.fill, 0, kMaxBins * 4 * 64, 0));
+    CK(hipMemsetAsync(a.fill, 0, kMaxBins * 4 * 64 * 8, 0));
     CK(hipEventRecord(e0));
     k_scatter_v0<VR, ABL><<<grid, kBlock, lds>>>(a);
     CK(hipEventRecord(e1));
@@ -196,10 +201,14 @@ int main() {
   a.nbins = 128; a.p2 = 105; a.fine_count = 128 * 105;
   a.cap = (n / a.nbins + n / (a.nbins * 16) + 8192) & ~7ull;  // whole 128-B lines: slab bases stay line-aligned
   CK(hipMalloc(&a.out, (size_t)a.nbins * a.cap * 16));
-  CK(hipMalloc(&a.fill, kMaxBins * 4 * 64));
+  CK(hipMalloc(&a.fill, kMaxBins * 4 * 64 * 8));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cu = prop.multiProcessorCount;
   for (int g : {cu * 3}) {
+    run_v0<4, 32 + 128>(a, g, "v0 padded 128 B + 16-B stores");
+    run_v0<4, 1024 + 128>(a, g, "v0 per-XCD cursors and sub-slabs");
+    run_v0<4, 32 + 128>(a, g, "v0 padded 128 B + 16-B stores");
+    run_v0<4, 1024 + 128>(a, g, "v0 per-XCD cursors and sub-slabs");
     run_v0<4, 0>(a, g, "v0 full");
     run_v0<4, 64 + 128>(a, g, "v0 padded 256 B + 16-B stores");
     run_v0<4, 16 + 128>(a, g, "v0 private sub-slabs + 16-B stores");
