@@ -733,7 +733,9 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
   const uint64_t n = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
   const bool idle = n == 0 || *a.fallback;
   bf_i64x2* lds_rows = reinterpret_cast<bf_i64x2*>(lds_table);
-  bf_i64x2* region_rows = reinterpret_cast<bf_i64x2*>(region);  // (first * 16 bytes: aligned)
+  // (first * 16 bytes: aligned; the table is hipMalloc'ed global memory -- as a generic pointer every access is a flat_*)
+  __attribute__((address_space(1))) bf_i64x2* region_rows =
+      reinterpret_cast<__attribute__((address_space(1))) bf_i64x2*>(reinterpret_cast<uintptr_t>(region));
   if (a.init_output) {
     bf_i64x2 row;
     row.x = init_row_quad(0, 1, 1, p->key_width, a.kp.init_agg_vals);
@@ -775,7 +777,9 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     uint32_t pos = local;
     for (;;) {
       K* kp = reinterpret_cast<K*>(lds_table + static_cast<size_t>(pos) * rq);
-      K old = *reinterpret_cast<volatile K*>(kp);  // look before claiming; a slot never returns to EMPTY
+      // look before claiming (a slot never returns to EMPTY).  A relaxed workgroup-scope atomic load: the `volatile`
+      // this used to be lost the LDS address space and compiled to a system-coherent flat_load + full waitcnt per step
+      K old = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (old == ek) {
         if constexpr (sizeof(K) == 8) {
           old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(kp), static_cast<unsigned long long>(ek),
