@@ -1476,7 +1476,13 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
     launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
     launch_part_scatter<2, int32_t>(pa.tw, dim3(g2), lds2, s, pa);
     if (simple) {
-      hipLaunchKernelGGL(hdk_part_aggregate_simple<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      }
     } else {
       hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     }
@@ -1485,7 +1491,13 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
     launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
     launch_part_scatter<2, int64_t>(pa.tw, dim3(g2), lds2, s, pa);
     if (simple) {
-      hipLaunchKernelGGL(hdk_part_aggregate_simple<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      }
     } else {
       hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
     }

@@ -716,7 +716,9 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
 // Same contract as hdk_part_aggregate -- image, bounded probe, spill segment -- with everything the general kernel
 // looks up per tuple (table shape, target descriptors, aggregate kind) fixed or block-uniform: the general kernel
 // spends ~210 vector + ~220 scalar instructions per tuple, most of them on its per-target interpreter.
-template <typename K>
+// TW_T / AGG_T / SKIP_T >= 0 fix the tuple width, the aggregate and its NULL handling at compile time (C5: two words,
+// SUM); -1 reads them from the arguments
+template <typename K, int TW_T = -1, int AGG_T = -1, int SKIP_T = -1>
 __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(PartArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds_table[];
   __shared__ uint32_t s_nspill;
@@ -758,13 +760,13 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     }
   }
   __syncthreads();
-  const int agg = a.simple_agg;
+  const int agg = AGG_T >= 0 ? AGG_T : a.simple_agg;
   const bool has_arg = a.simple_has_arg != 0;
-  const bool skip = a.simple_skip != 0;
+  const bool skip = SKIP_T >= 0 ? SKIP_T != 0 : a.simple_skip != 0;
   const bool arg_nullable = a.simple_arg_nullable != 0;
   const int64_t slot_null = a.simple_null;
   const int64_t arg_null = a.simple_arg_null;
-  const int tw = a.tw;
+  const int tw = TW_T > 0 ? TW_T : a.tw;
   const int64_t* in = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
   const K ek = empty_key<K>();
   auto apply = [&](int64_t t0, int64_t t1) {
