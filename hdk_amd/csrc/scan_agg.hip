@@ -1376,7 +1376,7 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
   pa->cap1 = pa->sub1 * kPartXcds;
   pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
-  if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFFFFF0ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
+  if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFF0000ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors (and 32-bit tuple indices with look-ahead in pass 3)
   return true;
 }
 

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
   const uint32_t first = f * a.slots;
   const uint32_t slots = min(a.slots, a.entry_count - first);
   int64_t* region = a.kp.groupby_buf[0] + static_cast<size_t>(first) * rq;
-  const uint64_t n = min(static_cast<uint64_t>(a.fill2[f]), a.cap2);
+  const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(a.fill2[f]), a.cap2));  // (cursors are 32-bit)
   const bool idle = n == 0 || *a.fallback;
   bf_i64x2* lds_rows = reinterpret_cast<bf_i64x2*>(lds_table);
   // (first * 16 bytes: aligned; the table is hipMalloc'ed global memory -- as a generic pointer every access is a flat_*)
@@ -777,11 +777,16 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     }
     const K key = static_cast<K>(t0);
     uint32_t pos = local;
+    int64_t seen = 0;  // the slot as it was when the row was looked at
     for (;;) {
-      K* kp = reinterpret_cast<K*>(lds_table + static_cast<size_t>(pos) * rq);
-      // look before claiming (a slot never returns to EMPTY).  A relaxed workgroup-scope atomic load: the `volatile`
-      // this used to be lost the LDS address space and compiled to a system-coherent flat_load + full waitcnt per step
-      K old = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      K* kp = reinterpret_cast<K*>(lds_rows + pos);
+      // Look before claiming (a slot never returns to EMPTY), key and slot in ONE 16-byte LDS read.  The two halves may
+      // be from different moments: harmless -- a key that reads EMPTY goes through the CAS, a slot that reads as the
+      // sentinel goes through the CAS of g_agg64_seen, and neither ever returns to that state.  (A `volatile` read here
+      // lost the LDS address space and compiled to a system-coherent flat_load + full waitcnt per probe step.)
+      const bf_i64x2 row = lds_rows[pos];
+      K old = static_cast<K>(row.x);
+      seen = row.y;
       if (old == ek) {
         if constexpr (sizeof(K) == 8) {
           old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned long long*>(kp), static_cast<unsigned long long>(ek),
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
         return;
       }
     }
-    int64_t* slot = lds_table + static_cast<size_t>(pos) * rq + 1;
+    int64_t* slot = reinterpret_cast<int64_t*>(lds_rows + pos) + 1;
     // NULL argument, or a value that collides with the skip value (`val != skip_val`): as part_apply_targets
     if (has_arg && skip && ((arg_nullable && t1 == arg_null) || t1 == slot_null)) {
       return;
@@ -824,16 +829,18 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     if (agg == HDK_AGG_COUNT) {
       atomicAdd(reinterpret_cast<unsigned long long*>(slot), 1ull);
     } else {
-      g_agg64(agg, false, skip, slot_null, slot, t1);
+      g_agg64_seen(agg, false, skip, slot_null, slot, t1, seen);
     }
   };
   // two tuples per trip, the next pair's loads issued before the current pair is applied (see hdk_part_aggregate)
   int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-  auto fetch = [&](uint64_t i, int64_t& t0, int64_t& t1) {
+  const __attribute__((address_space(1))) int8_t* in_bytes =
+      reinterpret_cast<const __attribute__((address_space(1))) int8_t*>(reinterpret_cast<uintptr_t>(in));
+  auto fetch = [&](uint32_t i, int64_t& t0, int64_t& t1) {  // 32-bit indices: cap2 <= 0xFFFF0000 (match_partitioned)
     if (i < n) {
       if (tw == 2) {
-        const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
-            reinterpret_cast<uintptr_t>(in + i * 2)));
+        const bf_i64x2 v = __builtin_nontemporal_load(
+            reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(i) * 16));
         t0 = v.x;
         t1 = v.y;
       } else {
@@ -843,8 +850,9 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     }
   };
   fetch(tid, a0, a1);
-  fetch(static_cast<uint64_t>(tid) + kPartAggBlock, b0, b1);
-  for (uint64_t i = tid; i < n; i += 2 * kPartAggBlock) {
+  fetch(static_cast<uint32_t>(tid) + kPartAggBlock, b0, b1);
+  // (i + 3 * kPartAggBlock cannot wrap: n <= cap2 <= 0xFFFF0000)
+  for (uint32_t i = tid; i < n; i += 2 * kPartAggBlock) {
     const int64_t ta0 = a0, ta1 = a1, tb0 = b0, tb1 = b1;
     const bool has_b = i + kPartAggBlock < n;
     fetch(i + 2 * kPartAggBlock, a0, a1);
