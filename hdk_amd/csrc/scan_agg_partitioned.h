@@ -26,16 +26,23 @@
 //           the still untouched table.  No host round trip.
 //
 // Scatter, per batch of kPartTile tuples: LDS histogram by bin -> one slab claim per bin -> LDS staging ordered
-// by bin -> copy-out.  What the passes wait for is the copy-out (scripts/microbench/partition.hip): runs that
-// start and end inside 128-byte lines took 2.3-2.7 ms per 256 M tuples, the same bytes as whole 128-byte-aligned
-// lines 1.7 ms (4.7 TB/s of 32 B/tuple; 64-byte alignment is not enough: 2.3 ms), with or without the cursor
-// atomics.  So a block only ever writes WHOLE LINES: a bin's run is rounded up to a multiple of G tuples
-// (G * tuple bytes = a multiple of 128) and claimed at a slab position that is a multiple of G; the slots past the
-// run's tuples hold PADDING: a tuple whose key belongs to another partition, which the next pass recognises
-// for free because it recomputes every tuple's partition anyway (part_padding).  No counts, flags or hole maps.
-// (Carrying a bin's remainder into the block's next batch instead of padding writes fewer bytes but measured
-// slower: the extra registers and LDS cost the third block per CU -- 3.4 / 2.45 ms for the two scatter passes.)
+// by bin -> 16-byte copy-out of the runs as they come (a run is ~20 tuples: it starts and ends inside 128-byte lines
+// that the neighbouring runs complete).  What the passes wait for is that copy-out (scripts/microbench/partition.hip):
+// whole 128-byte-aligned lines 1.7 ms per 256 M tuples (4.7 TB/s of 32 B/tuple), unaligned runs with cursors shared
+// by the whole chip 2.45 ms -- and 1.9 ms when a line is only ever written from ONE XCD, because the two halves of
+// a line then merge in that XCD's L2 (the eight L2s are not coherent with each other; a line written from two of them
+// reaches memory as two partial writes).  Hence:
+//   * level 1: a coarse slab is kPartXcds sub-slabs with a cursor each, a block appends to the sub-slab of the XCD it
+//     runs on (HW_REG_XCC_ID); pass 2 reads the eight sub-slabs as one tile sequence;
+//   * level 2: all kPartG2X blocks of a coarse slab are launched on one XCD (block id % 8 selects the slab inside a
+//     set of eight), so the fine slabs need no split.
+//   (Placement is an affinity for speed; any block may write any sub-slab and the result is the same.)
 // Slab cursors sit one per 128-byte line (128 cursors in 512 bytes serialise on four lines: 2.68 -> 2.34 ms).
+// Two other ways to whole-line writes were measured and lost: padding every run to whole lines with tuples of another
+// partition -- which the next pass drops for free because it recomputes every tuple's partition anyway (part_padding;
+// still selectable with HDK_HIP_PART_G_LOG2=3 for measurements: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 at the time)
+// -- and carrying a bin's remainder into the block's next batch (3.4 / 2.45 ms: the extra registers and LDS cost the
+// third block per CU).
 #pragma once
 #include "scan_agg_baseline_fast.h"
 #include "watch.h"
