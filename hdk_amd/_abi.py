@@ -68,6 +68,8 @@ LAUNCH_FORCE_PARTITIONED = 16
 LAUNCH_PLAN_RESIDENT = 32
 LAUNCH_CHECK_INTERRUPT = 64
 LAUNCH_INIT_OUTPUT = 128
+LAUNCH_CLUSTER_PROBES = 256
+LAUNCH_NO_CLUSTER_PROBES = 512
 
 
 class Col(C.Structure):

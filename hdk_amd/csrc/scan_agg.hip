@@ -444,6 +444,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_agg_keys.h"
 #include "scan_project.h"
 #include "scan_project_fast.h"
+#include "scan_cluster.h"
 
 using namespace hdk;
 
@@ -1591,6 +1592,8 @@ extern "C" int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hi
   return HDK_HIP_OK;
 }
 
+static bool match_cluster_join(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, ClusterArgs* ca);
+
 extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                            int32_t device_id, char* out, size_t out_len) {
   HDK_REQUIRE(out && out_len, "out is NULL");
@@ -1599,6 +1602,16 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   const hdk_hip_device_properties* props = device_props(device_id);
   if (!props) return HDK_HIP_ERR_RUNTIME;
   const LaunchShape s = choose_shape(plan, ko, props);
+  {
+    ClusterArgs ca;
+    if (match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
+      const int n = snprintf(out, out_len, "hdk_cluster_by_key,hdk_cluster_params,");
+      if (n > 0 && static_cast<size_t>(n) < out_len) {
+        out += n;
+        out_len -= static_cast<size_t>(n);
+      }
+    }
+  }
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
   } else if (s.strategy == STRAT_PROJECT) {
@@ -1620,6 +1633,99 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     snprintf(out, out_len, "%s", !generic && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
                                                                              : "hdk_scan_agg_global");
   }
+  return HDK_HIP_OK;
+}
+
+// ---- clustering pre-pass for join probes (scan_cluster.h) -----------------------------------------------------------
+static bool match_cluster_join(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, ClusterArgs* ca) {
+  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES)) return false;
+  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_SCALAR | HDK_HIP_LAUNCH_FORCE_GENERIC)) return false;
+  if (p->num_joins != 1 || p->query_kind == HDK_Q_PROJECTION || needs_join_loops(p)) return false;
+  const hdk_hip_join& jn = p->joins[0];
+  if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) return false;
+  if (jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.bucket > 1) return false;  // (a NULL key that matches: not dropped)
+  int kc;
+  if (!plain_outer_col(p, jn.outer_key, &kc)) return false;
+  if (jn.max_key < jn.min_key || static_cast<uint64_t>(jn.max_key - jn.min_key) >= 0xFFFFFFFFull) return false;
+  const uint64_t range = static_cast<uint64_t>(jn.max_key - jn.min_key) + 1;
+  const uint64_t entry_bytes = jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED ? 8ull * static_cast<uint64_t>(jn.fused_stride) : 4ull;
+  // Only on request.  Measured on C3 (256 M rows, 10 M-key dimension, 160 MB fused table): pre-pass 2.2 ms + probes over
+  // the clustered rows 4.2 ms against 5.0 ms for probes in row order -- the batched interpreter that consumes the rows
+  // needs 3.1 ms even when the whole table sits in L2, so the locality cannot pay for the pre-pass until a specialised
+  // consumer exists.
+  (void)entry_bytes;
+  if (!(ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES)) return false;
+  memset(ca, 0, sizeof(*ca));
+  for (int i = 0; i < HDK_HIP_MAX_COLS; ++i) ca->outer_slot[i] = -1;
+  // the join key first, then every other outer column of the plan: all of them 8 bytes wide
+  ca->buf_idx[0] = p->cols[kc].buf_idx;
+  ca->outer_slot[kc] = 0;
+  ca->ncols = 1;
+  for (int i = 0; i < p->num_cols; ++i) {
+    const hdk_hip_col& c = p->cols[i];
+    if (c.table < 0) continue;  // payload word of a fused table: no buffer
+    if (c.table != 0) continue;
+    if (c.width != 8 || (c.kind != HDK_COL_INT && c.kind != HDK_COL_DOUBLE)) return false;
+    if (c.buf_idx != i) return false;  // (plan.py numbers them alike; the parameter builder relies on it)
+    if (i == kc) continue;
+    if (ca->ncols == kClusterMaxCols) return false;
+    ca->buf_idx[ca->ncols] = c.buf_idx;
+    ca->outer_slot[i] = ca->ncols++;
+  }
+  if (p->cols[kc].width != 8 || p->cols[kc].kind != HDK_COL_INT || p->cols[kc].buf_idx != kc) return false;
+  ca->ncols_total = p->num_cols;
+  ca->key_min = jn.min_key;
+  ca->key_range = range;
+  ca->bin_mult = (static_cast<uint64_t>(kClusterBins) << 32) / range;  // floor: bin <= kClusterBins - 1 for every key in range
+  const uint64_t rows = ko->total_rows;
+  ca->sub = ((rows / (kClusterBins * kClusterXcds)) * 17 / 16 + 4096 + 15) & ~15ull;
+  ca->cap_ovf = rows;
+  return true;
+}
+
+// runs the pre-pass and points `kp` at the permuted data; *scratch is freed (stream-ordered) by the caller after the scan.
+// Out of scratch memory is not an error: the launch then simply probes in row order.
+static int32_t launch_cluster_join(ClusterArgs ca, KernParams* kp, const hdk_hip_device_properties* props, hipStream_t s,
+                                   void** scratch) {
+  const uint64_t nsub = static_cast<uint64_t>(kClusterBins) * kClusterXcds;
+  const uint64_t col_rows = nsub * ca.sub + ca.cap_ovf;
+  const uint64_t nfr = nsub + 1;
+  const uint32_t ntab_max = 1 + HDK_HIP_MAX_JOINS;
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t b_cols = up(col_rows * 8) * ca.ncols;
+  const size_t b_fill = up((nsub * kClusterCursorStride + 4) * sizeof(uint32_t));
+  const size_t b_colptrs = up(nfr * ca.ncols_total * sizeof(void*));
+  const size_t b_fragptrs = up(nfr * sizeof(void*));
+  const size_t b_rows = up(nfr * ntab_max * sizeof(int64_t));
+  int8_t* q = nullptr;
+  if (hipMallocAsync(reinterpret_cast<void**>(&q), b_cols + b_fill + b_colptrs + b_fragptrs + 2 * b_rows + 256, s) != hipSuccess) {
+    (void)hipGetLastError();
+    return HDK_HIP_OK;
+  }
+  *scratch = q;
+  for (int c = 0; c < ca.ncols; ++c) {
+    ca.out[c] = reinterpret_cast<int64_t*>(q);
+    q += up(col_rows * 8);
+  }
+  ca.fill = reinterpret_cast<uint32_t*>(q);
+  ca.fill_ovf = ca.fill + nsub * kClusterCursorStride;
+  HDK_HIP_CHECK(hipMemsetAsync(ca.fill, 0, b_fill, s));
+  q += b_fill;
+  ca.col_ptrs = reinterpret_cast<const int8_t**>(q); q += b_colptrs;
+  ca.frag_ptrs = reinterpret_cast<const int8_t* const**>(q); q += b_fragptrs;
+  ca.num_rows = reinterpret_cast<int64_t*>(q); q += b_rows;
+  ca.frag_offs = reinterpret_cast<uint64_t*>(q); q += b_rows;
+  ca.num_fragments = reinterpret_cast<uint64_t*>(q);
+  ca.kp = *kp;
+  const size_t lds = static_cast<size_t>(kClusterTile) * ca.ncols * 8 + kClusterTile + 16;
+  unsigned grid = resident_grid(reinterpret_cast<const void*>(hdk_cluster_by_key), kClusterBlock, lds, props);
+  hipLaunchKernelGGL(hdk_cluster_by_key, dim3(grid), dim3(kClusterBlock), lds, s, ca);
+  hipLaunchKernelGGL(hdk_cluster_params, dim3(8), dim3(256), 0, s, ca);
+  HDK_HIP_CHECK(hipGetLastError());
+  kp->col_buffers = reinterpret_cast<const int8_t* const* const*>(ca.frag_ptrs);
+  kp->num_fragments = ca.num_fragments;
+  kp->num_rows = ca.num_rows;
+  kp->frag_row_offsets = ca.frag_offs;
   return HDK_HIP_OK;
 }
 
@@ -1695,6 +1801,20 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
 
   const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {  // everything the launch enqueues from here on is inside the recorded interval
+    st = scan_events_begin(device_id, s, &e0, &e1);
+    if (st) return st;
+  }
+  // join probes over a table far larger than L2: permute the outer columns by key range first (scan_cluster.h)
+  void* cluster_scratch = nullptr;
+  {
+    ClusterArgs ca;
+    if (match_cluster_join(plan, ko, &ca)) {
+      st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch);
+      if (st) return st;
+    }
+  }
   bool init_output = ko && (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT);
   if (init_output) {
     HDK_REQUIRE((plan->query_kind == HDK_Q_PERFECT_HASH || plan->query_kind == HDK_Q_BASELINE_HASH) && !plan->output_columnar,
@@ -1702,11 +1822,6 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   }
   if (shape.strategy == STRAT_LDS) {
     int64_t* slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(workspace) + kPlanRegionBytes);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) {
-      st = scan_events_begin(device_id, s, &e0, &e1);
-      if (st) return st;
-    }
     if (init_output) {
       st = init_row_wise_output(plan, params, device_id, s);
       if (st) return st;
@@ -1726,12 +1841,10 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     const unsigned fblocks = (shape.entry_count + (kBlock / kWave) - 1) / (kBlock / kWave);
     hipLaunchKernelGGL(hdk_finalize, dim3(fblocks), dim3(kBlock), 0, s, fa);
     HDK_HIP_CHECK(hipGetLastError());
+    if (cluster_scratch) {
+      HDK_HIP_CHECK(hipFreeAsync(cluster_scratch, s));
+    }
     return HDK_HIP_OK;
-  }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timed) {
-    st = scan_events_begin(device_id, s, &e0, &e1);
-    if (st) return st;
   }
   if (shape.strategy == STRAT_PROJECT) {
     HDK_REQUIRE(params[HDK_KP_MAX_MATCHED] && params[HDK_KP_TOTAL_MATCHED], "MAX_MATCHED / TOTAL_MATCHED is NULL");
@@ -1811,6 +1924,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   if (st) return st;
   if (timed) {
     HDK_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  if (cluster_scratch) {
+    HDK_HIP_CHECK(hipFreeAsync(cluster_scratch, s));
   }
   return HDK_HIP_OK;
 }

@@ -113,6 +113,37 @@ HDK_DEV int64_t leaf_row(const VecCtx& c, int table, int r) {
   return vrow(c, r);
 }
 
+// VR rows of one column, decoded; the decoder switch is wave-uniform and sits OUTSIDE the row loop (one scalar branch
+// per batch, not per row)
+template <class VecCtx, bool NT>
+HDK_DEV void load_rows_decoded(const VecCtx& c, const int8_t* __restrict__ buf, int kind, int width, int table, int64_t (&out)[VR]) {
+#define HDK_LOAD_ROWS(T, CONV)                  \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) { \
+    const T x = gload<T>(buf, leaf_row(c, table, r), NT); \
+    out[r] = CONV;                               \
+  }
+  if (kind == HDK_COL_DOUBLE) {
+    HDK_LOAD_ROWS(int64_t, x)
+  } else if (kind == HDK_COL_FLOAT) {
+    HDK_LOAD_ROWS(float, double_to_bits(static_cast<double>(x)))
+  } else if (kind == HDK_COL_UNSIGNED) {
+    switch (width) {
+      case 1: HDK_LOAD_ROWS(uint8_t, static_cast<int64_t>(x)) break;
+      case 2: HDK_LOAD_ROWS(uint16_t, static_cast<int64_t>(x)) break;
+      case 4: HDK_LOAD_ROWS(uint32_t, static_cast<int64_t>(x)) break;
+      default: HDK_LOAD_ROWS(int64_t, x) break;
+    }
+  } else {
+    switch (width) {
+      case 1: HDK_LOAD_ROWS(int8_t, static_cast<int64_t>(x)) break;
+      case 2: HDK_LOAD_ROWS(int16_t, static_cast<int64_t>(x)) break;
+      case 4: HDK_LOAD_ROWS(int32_t, static_cast<int64_t>(x)) break;
+      default: HDK_LOAD_ROWS(int64_t, x) break;
+    }
+  }
+#undef HDK_LOAD_ROWS
+}
+
 template <class VecCtx>
 HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
   if (l.kind == HDK_LEAF_COL) {
@@ -141,34 +172,14 @@ HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
       return;
     }
     // outer-table columns are streamed exactly once: non-temporal; inner (joined) columns are gathered
-    // repeatedly and should stay cached.  The decoder switch is wave-uniform: it sits OUTSIDE the row
-    // loop (one scalar branch per batch, not per row).
-    const bool nt = table == 0;
-#define HDK_LOAD_ROWS(T, CONV)                  \
-  _Pragma("unroll") for (int r = 0; r < VR; ++r) { \
-    const T x = gload<T>(buf, leaf_row(c, table, r), nt); \
-    out[r] = CONV;                               \
-  }
-    if (kind == HDK_COL_DOUBLE) {
-      HDK_LOAD_ROWS(int64_t, x)
-    } else if (kind == HDK_COL_FLOAT) {
-      HDK_LOAD_ROWS(float, double_to_bits(static_cast<double>(x)))
-    } else if (kind == HDK_COL_UNSIGNED) {
-      switch (width) {
-        case 1: HDK_LOAD_ROWS(uint8_t, static_cast<int64_t>(x)) break;
-        case 2: HDK_LOAD_ROWS(uint16_t, static_cast<int64_t>(x)) break;
-        case 4: HDK_LOAD_ROWS(uint32_t, static_cast<int64_t>(x)) break;
-        default: HDK_LOAD_ROWS(int64_t, x) break;
-      }
+    // repeatedly and should stay cached.  The hint has to be a compile-time constant: with a run-time flag the
+    // optimiser merges `nt ? nontemporal : plain` into ONE plain load and the streamed columns evict the join table
+    // from L2 and the Infinity Cache (device_common.h: gload).
+    if (table == 0) {
+      load_rows_decoded<VecCtx, true>(c, buf, kind, width, table, out);
     } else {
-      switch (width) {
-        case 1: HDK_LOAD_ROWS(int8_t, static_cast<int64_t>(x)) break;
-        case 2: HDK_LOAD_ROWS(int16_t, static_cast<int64_t>(x)) break;
-        case 4: HDK_LOAD_ROWS(int32_t, static_cast<int64_t>(x)) break;
-        default: HDK_LOAD_ROWS(int64_t, x) break;
-      }
+      load_rows_decoded<VecCtx, false>(c, buf, kind, width, table, out);
     }
-#undef HDK_LOAD_ROWS
   } else {
     const int64_t v = l.ival;
 #pragma unroll

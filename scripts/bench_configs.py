@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra HDK_HIP_LAUNCH_* flags")
     args = ap.parse_args()
     only = set(args.only.split(","))
 
@@ -125,7 +126,7 @@ def main():
             continue
         try:
             cp = ex.compile(q)
-            step = ex.prepare(cp, grid=args.grid, flags=A.LAUNCH_RECORD_EVENTS)
+            step = ex.prepare(cp, grid=args.grid, flags=A.LAUNCH_RECORD_EVENTS | args.flags)
             wall, kern = timed(step)
             res = step.fetch()
             t = kern or wall
