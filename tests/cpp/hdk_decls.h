@@ -5,8 +5,8 @@
 //   QueryEngine/JoinHashTable/Runtime/HashJoinRuntime.h:43-57,100-124  HashEntryInfo, ColumnType, JoinChunk,
 //                                           JoinColumn, JoinColumnTypeInfo  (the header includes Logger.h -> Boost)
 //   ResultSet/ResultType.h:28-34            QueryDescriptionType
-// Same names, members, member order and signatures; nothing else.  DataMgr/GpuMgr.h is NOT restated here: the
-// harness includes the real one where /root/reference exists.
+// Same names, members, member order and signatures; nothing else.  DataMgr/GpuMgr.h is NOT restated anywhere: the
+// harness is built against the reference's own header (tests/cpp/Makefile).
 #pragma once
 
 #include <cstddef>

@@ -13,9 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "cpp_harness_output.txt")
 
 @pytest.mark.gpu
 def test_cpp_harness_matches_the_golden():
-    # make rebuilds only when a source is newer than the binary that travelled with the snapshot
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "--no-print-directory"])
+    # built in the build container against the reference's own GpuMgr.h (__graft_entry__.build()); the binary travels
+    # with the snapshot.  Where the reference tree exists it is brought up to date first.
     exe = os.path.join(ROOT, "tests", "cpp", "_build", "harness")
+    if os.path.isdir("/root/reference/omniscidb"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "--no-print-directory"])
+    assert os.path.exists(exe), "tests/cpp/_build/harness is missing: run __graft_entry__.build() in the build container"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     want = open(GOLDEN).read().split("\n")
