@@ -445,6 +445,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_project.h"
 #include "scan_project_fast.h"
 #include "scan_cluster.h"
+#include "scan_join_direct.h"
 
 using namespace hdk;
 
@@ -550,6 +551,8 @@ static bool needs_join_loops(const hdk_hip_plan* p);
 static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
 static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
+static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, JoinDirectArgs* ja);
+static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko);
 // the counting form keeps 32-bit counters: half the bytes of the 8-byte words the shape was sized for
 static uint32_t keys_lds_bytes(const KeysArgs& ka, const LaunchShape& shape) {
   return ka.nvals ? shape.lds_bytes : shape.lds_bytes / 2;
@@ -884,19 +887,179 @@ static bool needs_join_loops(const hdk_hip_plan* p) {
   return false;
 }
 
-static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s) {
+// (same decisions as launch_scan_lds)
+static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, bool force_generic, bool force_scalar) {
   FastArgs fa;
   int kw, vw;
-  if (match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  if (!force_generic && match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
   KeysArgs ka;
-  if (match_keys(p, s, &ka)) return ka.nvals ? "hdk_scan_agg_keys_values" : "hdk_scan_agg_keys";
-  if (needs_join_loops(p)) return "hdk_scan_agg_generic";
+  if (!force_generic && match_keys(p, s, &ka)) return ka.nvals ? "hdk_scan_agg_keys_values" : "hdk_scan_agg_keys";
+  JoinDirectArgs ja;
+  if (!force_generic && match_join_direct(p, s, &ja)) return "hdk_join_agg_direct";
+  if (needs_join_loops(p) || force_scalar) return "hdk_scan_agg_generic";
   return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
+}
+
+// ---- hdk_join_agg_direct (scan_join_direct.h): the matcher ------------------------------------------------------------
+static bool jd_leaf_from(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int xc, JdLeaf* out) {
+  out->nullable = l.nullable;
+  out->null_val = l.null_val;
+  out->ival = l.ival;
+  if (l.kind == HDK_LEAF_INT) {
+    out->kind = JD_LITERAL;
+    out->nullable = 0;
+    return true;
+  }
+  if (l.kind != HDK_LEAF_COL) return false;
+  const hdk_hip_col& c = p->cols[l.col];
+  if (c.table == 0 && l.col == xc && l.col != kc) {
+    out->kind = JD_X;
+    return true;
+  }
+  if (c.table == -1 && c.buf_idx == 1) {  // payload word 1 of join 0's fused entry
+    out->kind = JD_PAYLOAD;
+    return true;
+  }
+  return false;
+}
+
+static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, JoinDirectArgs* ja) {
+  if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_NON_GROUPED || p->num_joins != 1 || p->num_quals ||
+      p->num_filter_ops || p->num_targets > kJdMaxTargets) {
+    return false;
+  }
+  if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
+  const hdk_hip_join& jn = p->joins[0];
+  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || jn.fused_stride != 2 || jn.type != HDK_JOIN_INNER || jn.bucket > 1 ||
+      jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.table_idx != 0) {
+    return false;
+  }
+  int kc;
+  if (!plain_outer_col(p, jn.outer_key, &kc) || p->cols[kc].width != 8 || p->cols[kc].kind != HDK_COL_INT) return false;
+  int xc = -1;
+  for (int i = 0; i < p->num_cols; ++i) {
+    const hdk_hip_col& c = p->cols[i];
+    if (c.table == 0) {
+      if (i == kc) continue;
+      if (xc >= 0 || c.width != 8 || c.kind != HDK_COL_INT) return false;  // one more outer column, 8-byte integer
+      xc = i;
+    } else if (!(c.table == -1 && c.buf_idx == 1)) {
+      return false;  // an inner column read through the row id, or a second payload word
+    }
+  }
+  memset(ja, 0, sizeof(*ja));
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  if (wl.wpe != static_cast<int>(shape.wpe)) return false;
+  ja->wpe = wl.wpe;
+  for (int w = 0; w < wl.wpe; ++w) ja->wop[w] = wl.wop[w];
+  ja->rep = shape.rep;
+  ja->key_buf_idx = p->cols[kc].buf_idx;
+  ja->x_buf_idx = xc >= 0 ? p->cols[xc].buf_idx : -1;
+  ja->min_key = jn.min_key;
+  ja->max_key = jn.max_key;
+  ja->key_null = jn.null_val;
+  ja->key_nullable = jn.null_mode == HDK_JOIN_NULL_NULLABLE;
+  ja->ntargets = p->num_targets;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    JdTarget& jt = ja->t[t];
+    if (tg.agg == HDK_AGG_ID || tg.slot_width != 8 || tg.arg_is_fp) return false;
+    if (tg.agg == HDK_AGG_AVG && tg.slot2_width != 8) return false;
+    jt.has_arg = tg.has_arg;
+    jt.vword = wl.vword[t];
+    jt.nword = wl.nword[t];
+    jt.wop = wl.vword[t] >= 0 ? wl.wop[wl.vword[t]] : WOP_ADD_U64;
+    if (jt.wop != WOP_ADD_U64 && jt.wop != WOP_MIN_I64 && jt.wop != WOP_MAX_I64) return false;
+    if (wl.nword[t] >= 0) ja->nword_mask |= 1u << wl.nword[t];
+    if (!tg.has_arg) {
+      if (tg.agg != HDK_AGG_COUNT) return false;
+      continue;
+    }
+    const hdk_hip_expr& e = tg.arg;
+    if (e.vclass != HDK_VC_INT || e.nsteps > 1 || !jd_leaf_from(p, e.leaf0, kc, xc, &jt.a) || jt.a.kind == JD_LITERAL) return false;
+    jt.nsteps = e.nsteps;
+    if (e.nsteps == 1) {
+      const hdk_hip_step& st = e.steps[0];
+      if ((st.op != HDK_OP_ADD && st.op != HDK_OP_SUB && st.op != HDK_OP_MUL) || st.out_class != HDK_VC_INT) return false;
+      if (!jd_leaf_from(p, st.rhs, kc, xc, &jt.b)) return false;
+      jt.op = st.op;
+      jt.check_width = st.check_width;
+      jt.step_null = st.null_out;
+    }
+    // what eval_target_arg tests: after a step the value is nullable with the step's NULL (eval_expr), else the leaf's
+    jt.arg_null = e.null_val;
+    jt.arg_nullable = e.nullable;
+    jt.skip_null = tg.skip_null;
+    jt.slot_null = tg.null_val;
+  }
+  return true;
+}
+
+// does the direct join kernel read key-range-clustered tuples?
+static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
+  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES)) return false;
+  // Only on request.  Measured on C3 (256 M rows, 160 MB table): pre-pass 1.96 ms + probes over the clustered tuples
+  // 3.19 ms (a quarter of them still miss L2: several key ranges are in flight at once) against 5.08 ms in row order --
+  // no gain yet; with the table L2-resident this kernel needs 2.06 ms (the interpreter 3.09).
+  (void)p;
+  return (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
+}
+
+static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, const hdk_hip_kernel_options* ko,
+                                  const LaunchShape& shape, const hdk_hip_device_properties* props, hipStream_t s) {
+  void* scratch = nullptr;
+  const hdk_hip_join& jn = plan->joins[0];
+  if (join_direct_clusters(plan, ko) && static_cast<uint64_t>(jn.max_key - jn.min_key) < 0xFFFFFFFFull) {
+    ClusterArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.kp = ja.kp;
+    ca.aos = 1;
+    ca.ncols = ja.x_buf_idx >= 0 ? 2 : 1;
+    ca.buf_idx[0] = ja.key_buf_idx;
+    ca.buf_idx[1] = ja.x_buf_idx;
+    ca.key_min = jn.min_key;
+    ca.key_range = static_cast<uint64_t>(jn.max_key - jn.min_key) + 1;
+    ca.bin_mult = (static_cast<uint64_t>(kClusterBins) << 32) / ca.key_range;
+    const uint64_t rows = ko->total_rows;
+    ca.sub = ((rows / (kClusterBins * kClusterXcds)) * 17 / 16 + 4096 + 15) & ~15ull;
+    ca.cap_ovf = rows;
+    const uint64_t nsub = static_cast<uint64_t>(kClusterBins) * kClusterXcds;
+    auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+    const size_t b_tuples = up((nsub * ca.sub + ca.cap_ovf) * ca.ncols * 8);
+    const size_t b_fill = up((nsub * kClusterCursorStride + 4) * sizeof(uint32_t));
+    int8_t* q = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&q), b_tuples + b_fill, s) == hipSuccess) {
+      scratch = q;
+      ca.out[0] = reinterpret_cast<int64_t*>(q);
+      ca.fill = reinterpret_cast<uint32_t*>(q + b_tuples);
+      ca.fill_ovf = ca.fill + nsub * kClusterCursorStride;
+      HDK_HIP_CHECK(hipMemsetAsync(ca.fill, 0, b_fill, s));
+      const size_t lds = static_cast<size_t>(kClusterTile) * ca.ncols * 8 + kClusterTile + 16;
+      const unsigned grid = resident_grid(reinterpret_cast<const void*>(hdk_cluster_by_key), kClusterBlock, lds, props);
+      hipLaunchKernelGGL(hdk_cluster_by_key, dim3(grid), dim3(kClusterBlock), lds, s, ca);
+      ja.clustered = 1;
+      ja.tw = ca.ncols;
+      ja.tuples = ca.out[0];
+      ja.fill = ca.fill;
+      ja.fill_ovf = ca.fill_ovf;
+      ja.sub = ca.sub;
+      ja.cap_ovf = ca.cap_ovf;
+    } else {
+      (void)hipGetLastError();  // no scratch: probe in row order
+    }
+  }
+  hipLaunchKernelGGL(hdk_join_agg_direct, dim3(shape.grid), dim3(kJdBlock), shape.lds_bytes, s, ja);
+  HDK_HIP_CHECK(hipGetLastError());
+  if (scratch) {
+    HDK_HIP_CHECK(hipFreeAsync(scratch, s));
+  }
+  return HDK_HIP_OK;
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                                const LaunchShape& shape, int64_t* slabs, hipStream_t s, bool force_generic,
-                               bool force_scalar) {
+                               bool force_scalar, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
   FastArgs fa;
   int kw, vw;
   if (!force_generic && match_fast(plan, shape, &fa, &kw, &vw)) {
@@ -909,6 +1072,12 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
       case 4: return launch_direct_kw<4>(vw, fa, shape, s);
       default: return launch_direct_kw<8>(vw, fa, shape, s);
     }
+  }
+  JoinDirectArgs ja;
+  if (!force_generic && match_join_direct(plan, shape, &ja)) {
+    ja.kp = kp;
+    ja.slabs = slabs;
+    return launch_join_direct(plan, ja, ko, shape, props, s);
   }
   KeysArgs ka;
   if (!force_generic && match_keys(plan, shape, &ka)) {
@@ -1604,7 +1773,16 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   const LaunchShape s = choose_shape(plan, ko, props);
   {
     ClusterArgs ca;
-    if (match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
+    JoinDirectArgs jd;
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    const bool direct = !generic && match_join_direct(plan, s, &jd);
+    if (direct && join_direct_clusters(plan, ko)) {
+      const int n = snprintf(out, out_len, "hdk_cluster_by_key,");
+      if (n > 0 && static_cast<size_t>(n) < out_len) {
+        out += n;
+        out_len -= static_cast<size_t>(n);
+      }
+    } else if (!direct && match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
       const int n = snprintf(out, out_len, "hdk_cluster_by_key,hdk_cluster_params,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
@@ -1613,7 +1791,9 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     }
   }
   if (s.strategy == STRAT_LDS) {
-    snprintf(out, out_len, "%s,hdk_finalize", scan_kernel_name(plan, s));
+    snprintf(out, out_len, "%s,hdk_finalize",
+             scan_kernel_name(plan, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
+                              ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)));
   } else if (s.strategy == STRAT_PROJECT) {
     ProjFastArgs pf;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
@@ -1810,7 +1990,10 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   void* cluster_scratch = nullptr;
   {
     ClusterArgs ca;
-    if (match_cluster_join(plan, ko, &ca)) {
+    JoinDirectArgs jd;
+    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+    const bool direct = !generic && match_join_direct(plan, shape, &jd);  // (clusters its own input, as tuples)
+    if (!direct && match_cluster_join(plan, ko, &ca)) {
       st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch);
       if (st) return st;
     }
@@ -1827,7 +2010,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       if (st) return st;
     }
     st = launch_scan_lds(plan, d_plan, kp, shape, slabs, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
-                         ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR));
+                         ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR), ko, props);
     if (st) return st;
     if (timed) {
       HDK_HIP_CHECK(hipEventRecord(e1, s));

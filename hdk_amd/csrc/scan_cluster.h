@@ -43,6 +43,7 @@ struct ClusterArgs {
   uint64_t sub;                       // rows of a (bin, XCD) sub-slab (multiple of 16)
   uint64_t cap_ovf;                   // rows of the overflow fragment
   int64_t* out[kClusterMaxCols];      // permuted columns: [kClusterBins * kClusterXcds * sub | cap_ovf] rows each
+  int32_t aos;                        // 1: out[0] holds ROWS of ncols words instead (tuples for hdk_join_agg_direct)
   uint32_t* fill;                     // [kClusterBins][kClusterXcds] x kClusterCursorStride
   uint32_t* fill_ovf;
   // pass 2 outputs
@@ -188,8 +189,18 @@ __global__ __launch_bounds__(kClusterBlock) void hdk_cluster_by_key(ClusterArgs 
         const uint32_t r = i - run.x;
         const uint64_t dest = r < run.y ? (static_cast<uint64_t>(b) * kClusterXcds + xcd) * a.sub + run.z + r
                                         : static_cast<uint64_t>(kClusterBins) * kClusterXcds * a.sub + run.w + (r - run.y);
-        for (int c = 0; c < nc; ++c) {
-          a.out[c][dest] = s_stage[static_cast<size_t>(i) * nc + c];
+        if (a.aos) {
+          if (nc == 2) {
+            reinterpret_cast<bf_i64x2*>(a.out[0])[dest] = reinterpret_cast<const bf_i64x2*>(s_stage)[i];
+          } else {
+            for (int c = 0; c < nc; ++c) {
+              a.out[0][dest * nc + c] = s_stage[static_cast<size_t>(i) * nc + c];
+            }
+          }
+        } else {
+          for (int c = 0; c < nc; ++c) {
+            a.out[c][dest] = s_stage[static_cast<size_t>(i) * nc + c];
+          }
         }
       }
       __syncthreads();

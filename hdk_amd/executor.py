@@ -208,8 +208,7 @@ class PreparedStep:
         """Replace each one-to-one join table by the fused [row id | payload ...] form when the batched
         interpreter (or the projection kernel) will run the plan: one gather per probing row instead of
         slot -> row id -> inner column (HDK_JOIN_ONE_TO_ONE_FUSED, include/hdk_hip.h)."""
-        names = self.kernel_names().split(",")[0]
-        if names not in ("hdk_scan_agg_vec_join", "hdk_scan_project_join"):
+        if not ({"hdk_scan_agg_vec_join", "hdk_scan_project_join"} & set(self.kernel_names().split(","))):
             return
         cp, p, storage = self.cp, self.plan, self.ex.storage
         for ji, info in enumerate(cp.join_infos):

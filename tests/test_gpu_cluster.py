@@ -57,7 +57,11 @@ def test_clustered_probes_match_the_oracle(oracle, gpu_executor_factory, key_kin
             ex = gpu_executor_factory(st)
             ex.fuse_join_tables = fuse
             step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
-            assert step.kernel_names().startswith("hdk_cluster_by_key,hdk_cluster_params,hdk_scan_agg_vec_join"), step.kernel_names()
+            names = step.kernel_names()
+            # the C3 shape over a fused table has a kernel of its own that reads clustered TUPLES; everything else runs the
+            # batched interpreter over the permuted columns
+            assert names.startswith("hdk_cluster_by_key,hdk_cluster_params,hdk_scan_agg_vec_join") or \
+                names.startswith("hdk_cluster_by_key,hdk_join_agg_direct"), names
             assert_buffers_equal(cp, step.run().buffer, want)
             # a second run of the same prepared step: the scratch of the first is gone, the result is not
             assert_buffers_equal(cp, step.run().buffer, want)
@@ -74,3 +78,52 @@ def test_clustering_is_off_for_shapes_it_does_not_cover(gpu_executor_factory):
     assert "cluster" not in ex.prepare(q, flags=A.LAUNCH_CLUSTER_PROBES | A.LAUNCH_NO_CLUSTER_PROBES).kernel_names()
     ql = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key", type="left")], targets=[Agg("count", None, "c")])
     assert "cluster" not in ex.prepare(ql, flags=A.LAUNCH_CLUSTER_PROBES).kernel_names()
+
+
+def _direct_targets():
+    V, D = ColRef("val"), ColRef("dval", "dim")
+    return [
+        [Agg("sum", V + D, "s"), Agg("count", None, "c")],                                   # BASELINE config 3
+        [Agg("sum", V * D, "p"), Agg("min", V - D, "lo"), Agg("max", D, "hi"), Agg("count", V, "cv")],
+        [Agg("avg", V, "a"), Agg("sum", D + 5, "s5")],
+        [Agg("max", V, "mv"), Agg("min", D - V, "md"), Agg("sum", V, "sv"), Agg("count", None, "c")],
+    ]
+
+
+@pytest.mark.parametrize("key_kind", ["uniform", "hot"])
+def test_direct_join_kernel_matches_the_oracle(oracle, gpu_executor_factory, key_kind):
+    """hdk_join_agg_direct (scan_join_direct.h): the C3 shape without the interpreter -- in row order, over clustered
+    tuples, and against the interpreters; NULL keys, keys without a partner, NULL arguments, every aggregate."""
+    st = _tables(600_000, 30_000, key_kind, 17)
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    for targets in _direct_targets():
+        q = QueryUnit("fact", joins=j, targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        for flags, prefix in ((0, "hdk_join_agg_direct"), (A.LAUNCH_CLUSTER_PROBES, "hdk_cluster_by_key,hdk_join_agg_direct"),
+                              (A.LAUNCH_FORCE_GENERIC, "hdk_scan_agg_vec_join")):
+            ex = gpu_executor_factory(st)
+            ex.fuse_join_tables = True
+            step = ex.prepare(cp, flags=flags, grid=(0 if flags else 5))
+            assert step.kernel_names().startswith(prefix) or flags == A.LAUNCH_FORCE_GENERIC, step.kernel_names()
+            assert_buffers_equal(cp, step.run().buffer, want)
+            step.free()
+
+
+def test_direct_join_kernel_reports_overflow(oracle, gpu_executor_factory):
+    from hdk_amd._lib import HdkHipError
+    st = _tables(200_000, 5_000, "uniform", 3)
+    t = st.get("fact")
+    big = t.columns["val"].fragments[0]
+    big[5] = 2**62                                          # val * dval leaves BIGINT for any dval >= 2
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=[Agg("sum", ColRef("val") * ColRef("dval", "dim"), "p")])
+    cp, want, err = run_oracle(oracle, st, q)
+    if err == 0:
+        pytest.skip("the planted row found no partner")
+    assert err == A.ERR_OVERFLOW_OR_UNDERFLOW
+    for flags in (0, A.LAUNCH_CLUSTER_PROBES):
+        ex = gpu_executor_factory(st)
+        ex.fuse_join_tables = True
+        with pytest.raises(HdkHipError) as ei:
+            ex.execute(cp, flags=flags)
+        assert ei.value.code == A.ERR_OVERFLOW_OR_UNDERFLOW

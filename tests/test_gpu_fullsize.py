@@ -124,10 +124,12 @@ def test_c3_join_probe_at_baseline_size(mgr, oracle):
     cp = w.compiled
     out = torch.empty(max(cp.buffer_quads, 1), dtype=torch.int64, device="cuda")
     names = _run_into(w, out)
-    assert names.startswith("hdk_scan_agg_vec_join"), names
+    assert names.startswith("hdk_join_agg_direct"), names  # the shape's own kernel over the fused table
     ref = w.reference_checks()
     got = int(out[0].item()) % (1 << 64)
     assert got == ref["sum_val_plus_dval"]
+    assert _run_into(w, out, flags=A.LAUNCH_FORCE_GENERIC).startswith("hdk_scan_agg_vec_join")  # the batched interpreter
+    assert int(out[0].item()) % (1 << 64) == got
     w.ex.fuse_join_tables = False  # the reference's table layout (slot -> row id -> inner column)
     _run_into(w, out)
     assert int(out[0].item()) % (1 << 64) == got
