@@ -132,7 +132,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     out_t = torch.empty(quads, dtype=torch.int64, device="cuda")
-    step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS,
+    step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS | int(os.environ.get("HDK_BENCH_FLAGS", "0")),
                         out_ptr=out_t.data_ptr())
     gathered = torch.empty(world * quads, dtype=torch.int64, device="cuda") if (world > 1 and not baseline) else None
     d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
