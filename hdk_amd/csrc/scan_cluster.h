@@ -187,6 +187,12 @@ __global__ __launch_bounds__(kClusterBlock) void hdk_cluster_by_key(ClusterArgs 
         const uint32_t b = s_binof[i];
         const uint4 run = s_run[b];
         const uint32_t r = i - run.x;
+        if (r >= run.y && static_cast<uint64_t>(run.w) + (r - run.y) >= a.cap_ovf) {
+          // cannot happen while total_rows really bounds the rows of the launch (the overflow area holds that many);
+          // a caller that understated it gets an error instead of a write past the scratch buffer
+          record_error(a.kp.error_code, HDK_HIP_ERR_OUT_OF_SLOTS);
+          continue;
+        }
         const uint64_t dest = r < run.y ? (static_cast<uint64_t>(b) * kClusterXcds + xcd) * a.sub + run.z + r
                                         : static_cast<uint64_t>(kClusterBins) * kClusterXcds * a.sub + run.w + (r - run.y);
         if (a.aos) {
