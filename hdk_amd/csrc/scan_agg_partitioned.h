@@ -809,24 +809,27 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
       if (old == key) {
         break;
       }
-      if (++pos == slots) {  // the group lives past the end of this region: pass 4 places it
-        const uint32_t k = atomicAdd(&s_nspill, 1u);
-        int64_t* q;
-        if (k < kPartSpillSeg) {
-          q = a.spill_seg + (static_cast<size_t>(f) * kPartSpillSeg + k) * tw;
-        } else {
-          const uint32_t o = atomicAdd(a.fill_spill, 1u);
-          if (o >= a.cap_spill) {
-            return;
-          }
-          q = a.slab1 + static_cast<size_t>(o) * tw;
-        }
-        q[0] = t0;
-        if (tw > 1) {
-          q[1] = t1;
-        }
-        return;
+      if (++pos == slots) {
+        break;
       }
+    }
+    if (pos == slots) {  // the group lives past the end of this region: pass 4 places it (kept out of the probe loop)
+      const uint32_t k = atomicAdd(&s_nspill, 1u);
+      int64_t* q;
+      if (k < kPartSpillSeg) {
+        q = a.spill_seg + (static_cast<size_t>(f) * kPartSpillSeg + k) * tw;
+      } else {
+        const uint32_t o = atomicAdd(a.fill_spill, 1u);
+        if (o >= a.cap_spill) {
+          return;
+        }
+        q = a.slab1 + static_cast<size_t>(o) * tw;
+      }
+      q[0] = t0;
+      if (tw > 1) {
+        q[1] = t1;
+      }
+      return;
     }
     int64_t* slot = reinterpret_cast<int64_t*>(lds_rows + pos) + 1;
     // NULL argument, or a value that collides with the skip value (`val != skip_val`): as part_apply_targets

@@ -225,6 +225,10 @@ int main() {
   run_v0<4, 8 + 16 + 128>(a, cu * 3, "aligned 256-B runs, private, 16-B st");
   run_v0<4, 8 + 64 + 128>(a, cu * 3, "aligned 256-B runs, padded cursors");
   run_v0<4, 8 + 2>(a, cu * 3, "no LDS rank, no copy-out");
+  // longer runs: 4096-tuple batches (32 tuples = 512 B per bin and batch), LDS-limited to one block per CU
+  run_v0<8, 8 + 16 + 128>(a, cu, "aligned 512-B runs, private, 1/CU");
+  run_v0<8, 1024 + 128>(a, cu, "per-XCD cursors, 4096 batch, 1/CU");
+  run_v0<8, 1024 + 128>(a, cu * 2, "per-XCD cursors, 4096 batch, 2/CU");
   run_v0<8, 0>(a, cu * 2, "v0 full");
   run_v0<8, 64 + 128>(a, cu * 2, "v0 padded 256 B + 16-B stores");
   run_v0<8, 16 + 128>(a, cu * 2, "v0 private sub-slabs + 16-B stores");

@@ -9,7 +9,8 @@ import pytest
 
 from hdk_amd import _abi as A
 
-pytestmark = pytest.mark.gpu
+# (every test here imports torch for the device buffers; the first import on a fresh box can take minutes)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 SCALE = float(os.environ.get("HDK_FULLSIZE_SCALE", "1"))
 
