@@ -60,6 +60,15 @@ int32_t launch_init_row_wise_indirect(int64_t* const* groupby_buf, const int64_t
   return HDK_HIP_OK;
 }
 
+// The bytes between the end of a narrow column and the next 8-byte boundary.  The reference leaves them as the
+// allocator handed them out (nothing reads them); zeroing them makes the buffer image deterministic, so that whole
+// buffers can be compared and checksummed.
+__device__ inline void zero_gap(int8_t* buf, size_t from, size_t to) {
+  for (size_t b = from; b < to; ++b) {
+    buf[b] = 0;
+  }
+}
+
 // Columnar: a sequence of columns, each `entry_count` elements of `width` bytes, 8-byte aligned
 // (init_columnar_group_by_buffer_gpu_impl, QE/GpuInitGroups.cu:17-108).  `init_vals` and
 // `col_sizes` are DEVICE arrays, as in the reference.
@@ -83,13 +92,21 @@ __global__ __launch_bounds__(kInitBlock) void k_init_columnar(int8_t* __restrict
           default: reinterpret_cast<int64_t*>(col)[i] = HDK_EMPTY_KEY_64; break;
         }
       }
-      off = (off + static_cast<size_t>(entry_count) * key_size + 7) & ~static_cast<size_t>(7);
+      const size_t end = off + static_cast<size_t>(entry_count) * key_size;
+      off = (end + 7) & ~static_cast<size_t>(7);
+      if (start == 0) {
+        zero_gap(buf, end, off);
+      }
     }
   }
   int init_idx = 0;
   for (uint32_t c = 0; c < agg_col_count; ++c) {
     if (need_padding) {
+      const size_t end = off;
       off = (off + 7) & ~static_cast<size_t>(7);
+      if (start == 0) {
+        zero_gap(buf, end, off);
+      }
     }
     const int w = col_sizes[c];
     if (w == 0) {
@@ -106,6 +123,9 @@ __global__ __launch_bounds__(kInitBlock) void k_init_columnar(int8_t* __restrict
       }
     }
     off += static_cast<size_t>(entry_count) * w;
+  }
+  if (start == 0) {
+    zero_gap(buf, off, (off + 7) & ~static_cast<size_t>(7));  // the buffer is a whole number of int64 words
   }
 }
 

@@ -15,7 +15,13 @@ from test_gpu_projection import _sorted_rows
 from test_projection import run_projection_oracle
 from util import assert_buffers_equal, run_oracle
 
+import os
+
 pytestmark = pytest.mark.gpu
+
+# HDK_FUZZ_SEEDS="100:160" adds a range of seeds for a soak run (scripts/gpu/soak.sh); the default set stays small
+_EXTRA = os.environ.get("HDK_FUZZ_SEEDS", "")
+_EXTRA_SEEDS = list(range(*map(int, _EXTRA.split(":")))) if _EXTRA else []
 
 
 def _compare(cp, got, want):
@@ -25,7 +31,7 @@ def _compare(cp, got, want):
         assert_buffers_equal(cp, got, want)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3] + _EXTRA_SEEDS)
 def test_random_aggregate_plans(oracle, gpu_executor_factory, seed):
     rng = np.random.default_rng(seed)
     st = make_tables(rng, 60_000, 700)
@@ -67,11 +73,13 @@ def test_random_aggregate_plans(oracle, gpu_executor_factory, seed):
         except AssertionError as e:
             raise AssertionError(f"seed {seed} query {i}: {q}\n{e}") from e
         ran += 1
-    assert ran >= 25 and len(kernels) >= 3, (ran, kernels)
+    if seed in (1, 2, 3):  # (soak seeds only have to agree with the oracle)
+        assert ran >= 25 and len(kernels) >= 3, (ran, kernels)
 
 
-def test_random_projection_plans(oracle, gpu_executor_factory):
-    rng = np.random.default_rng(77)
+@pytest.mark.parametrize("seed", [77] + _EXTRA_SEEDS)
+def test_random_projection_plans(oracle, gpu_executor_factory, seed):
+    rng = np.random.default_rng(seed)
     st = make_tables(rng, 50_000, 500)
     ex = gpu_executor_factory(st)
     ran = 0
@@ -87,4 +95,4 @@ def test_random_projection_plans(oracle, gpu_executor_factory):
         assert res.total_matched == nrows, (i, q)
         assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), (i, q)
         ran += 1
-    assert ran >= 15
+    assert ran >= (15 if seed == 77 else 8), ran
