@@ -113,3 +113,52 @@ def random_query(rng, allow_join=True, projection=False):
     return QueryUnit("fact", quals=quals, joins=joins, groupby=groupby, targets=targets,
                      output_columnar=bool(groupby and rng.random() < 0.3),
                      force_baseline=bool(groupby and rng.random() < 0.25))
+
+
+# ---- the wider generator of the soak runs: float32 measures, OR / NOT trees, transformed keys, 64-bit COUNT -----------
+
+def make_tables_wide(rng, n, nd):
+    """make_tables plus a float column, a timestamp and a decimal on the fact side (drawn AFTER the base columns)."""
+    from hdk_amd.ir import Type
+    st = make_tables(rng, n, nd)
+    fact = st.get("fact")
+    frag = fact.frag_rows[0]
+    cols = {name: np.concatenate(fact.columns[name].fragments) for name in fact.column_order}
+    null_f = np.array([A.NULL_FLOAT_BITS], dtype=np.int32).view(np.float32)[0]
+    f32 = (rng.normal(size=n) * 30).astype(np.float32)
+    f32[rng.random(n) < 0.04] = null_f
+    ts = rng.integers(1_230_768_000, 1_483_228_800, n, dtype=np.int64)  # 2009-01-01 .. 2017-01-01
+    ts[rng.random(n) < 0.02] = A.NULL_BIGINT
+    dec = rng.integers(-300, 900, n, dtype=np.int64)
+    dec[rng.random(n) < 0.03] = A.NULL_BIGINT
+    cols.update({"f32": f32, "ts": ts, "dec": dec})
+    st.import_numpy("fact", cols, fragment_size=frag,
+                    types={"ts": Type("timestamp", 8, unit="s"), "dec": Type("decimal", 8, scale=2)})
+    return st
+
+
+def random_query_wide(rng, projection=False):
+    """random_query, then seeded rewrites towards the rows the base generator never draws."""
+    from dataclasses import replace
+    from hdk_amd.ir import And, Cast, ExtractYear, INT32, Not, Or
+    q = random_query(rng, projection=projection)
+    quals = list(q.quals)
+    if len(quals) >= 2 and rng.random() < 0.6:
+        a, b = quals[0], quals[1]
+        tree = [Or(a, b), Or(Not(a), b), Not(And(a, b)), And(Or(a, b), Not(b))][int(rng.integers(0, 4))]
+        quals = [tree] + quals[2:]
+    elif quals and rng.random() < 0.3:
+        quals = [Not(quals[0])] + quals[1:]
+    if rng.random() < 0.25:
+        quals.append(Cmp(ColRef("f32"), str(rng.choice(["<", ">", "<>"])), Lit(float(rng.normal() * 20))))
+    targets = list(q.targets)
+    for i, t in enumerate(targets):
+        if isinstance(t, Agg) and t.arg is not None and rng.random() < 0.3:
+            targets[i] = Agg(t.kind, ColRef("f32"), t.name)
+        elif isinstance(t, Proj) and t.name == "d" and rng.random() < 0.5:
+            targets[i] = Proj(ColRef("f32"), "d")
+    groupby = list(q.groupby)
+    if groupby and not q.force_baseline and rng.random() < 0.4:
+        j = int(rng.integers(0, len(groupby)))
+        groupby[j] = ExtractYear(ColRef("ts")) if rng.random() < 0.5 else Cast(ColRef("dec"), INT32)
+    return replace(q, quals=quals, targets=targets, groupby=groupby, bigint_count=bool(rng.random() < 0.3))

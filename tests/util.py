@@ -124,7 +124,7 @@ def run_oracle(O, storage, q_or_cp, frag_ids=None):
     return cp, buf, err
 
 
-def assert_buffers_equal(cp, got, want, fp_rtol=1e-6, float32_rtol=2e-4):
+def assert_buffers_equal(cp, got, want, fp_rtol=1e-6, float32_rtol=2e-4, float32_atol=0.0):
     """Bit-exact for every integer slot / key; fp SUM/AVG slots within `fp_rtol` relative
     (north_star tolerance: GPU summation order differs from the CPU's row order)."""
     from hdk_amd import result_set as rs
@@ -153,7 +153,7 @@ def assert_buffers_equal(cp, got, want, fp_rtol=1e-6, float32_rtol=2e-4):
             assert np.array_equal(gi >> 32, wi >> 32)
             a = (gi & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
             b = (wi & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
-            np.testing.assert_allclose(a, b, rtol=float32_rtol, atol=0)
+            np.testing.assert_allclose(a, b, rtol=float32_rtol, atol=float32_atol)
             for k in range(1, nsl):
                 assert np.array_equal(gs[s + k], ws[s + k])
         elif tg.arg_is_fp and tg.agg in (A.AGG_SUM, A.AGG_AVG):
