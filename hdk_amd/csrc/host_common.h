@@ -36,4 +36,17 @@ int32_t launch_init_row_wise_indirect(int64_t* const* groupby_buf, const int64_t
     }                                   \
   } while (0)
 
+// Stream-ordered scratch of a launch: handed back with hipFreeAsync on EVERY way out of the scope, error returns
+// included (the free is ordered after the kernels already enqueued on the stream).
+struct AsyncScratch {
+  void* p = nullptr;
+  hipStream_t s = nullptr;
+  explicit AsyncScratch(hipStream_t stream) : s(stream) {}
+  AsyncScratch(const AsyncScratch&) = delete;
+  AsyncScratch& operator=(const AsyncScratch&) = delete;
+  ~AsyncScratch() {
+    if (p) (void)hipFreeAsync(p, s);
+  }
+};
+
 }  // namespace hdk

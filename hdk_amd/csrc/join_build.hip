@@ -236,13 +236,13 @@ static int32_t inclusive_scan_inplace(int32_t* data, int64_t n, hipStream_t s) {
     return HDK_HIP_OK;
   }
   const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
-  int32_t* sums = nullptr;
-  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sums), static_cast<size_t>(nb) * sizeof(int32_t), s));
+  AsyncScratch sums_mem(s);
+  HDK_HIP_CHECK(hipMallocAsync(&sums_mem.p, static_cast<size_t>(nb) * sizeof(int32_t), s));
+  int32_t* sums = static_cast<int32_t*>(sums_mem.p);
   hipLaunchKernelGGL(k_scan_block_sums, dim3(static_cast<unsigned>(nb)), dim3(kJoinBlock), 0, s, data, n, sums);
   hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(kJoinBlock), 0, s, sums, nb);
   hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<unsigned>(nb)), dim3(kJoinBlock), 0, s, data, n, sums);
   HDK_HIP_CHECK(hipGetLastError());
-  HDK_HIP_CHECK(hipFreeAsync(sums, s));
   return HDK_HIP_OK;
 }
 

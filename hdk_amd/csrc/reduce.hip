@@ -455,9 +455,10 @@ static int32_t run_partition(const hdk_hip_plan* plan, const int64_t* buf, uint3
                              hipStream_t s) {
   SlotInit init;
   fill_slot_init(plan, init_vals, &init);
-  int8_t* scratch = nullptr;  // [plan | cursors]
+  AsyncScratch mem(s);  // [plan | cursors]
   constexpr size_t kPlanBytes = (sizeof(hdk_hip_plan) + 255) & ~size_t(255);
-  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), kPlanBytes + kMaxOwners * sizeof(uint32_t), s));
+  HDK_HIP_CHECK(hipMallocAsync(&mem.p, kPlanBytes + kMaxOwners * sizeof(uint32_t), s));
+  int8_t* scratch = static_cast<int8_t*>(mem.p);
   hdk_hip_plan* d_plan = reinterpret_cast<hdk_hip_plan*>(scratch);
   uint32_t* cursors = reinterpret_cast<uint32_t*>(scratch + kPlanBytes);
   HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
@@ -480,7 +481,6 @@ static int32_t run_partition(const hdk_hip_plan* plan, const int64_t* buf, uint3
     HDK_HIP_CHECK(hipMemcpyAsync(counts_out, cursors, num_owners * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HDK_HIP_CHECK(hipStreamSynchronize(s));
   }
-  HDK_HIP_CHECK(hipFreeAsync(scratch, s));
   return HDK_HIP_OK;
 }
 
@@ -513,8 +513,9 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
     init.v[i] = i < nslots ? init_vals[i] : 0;  // init_vals is a HOST array (ResultSetStorage::target_init_vals_)
   }
   // device copy of the plan (stream-ordered scratch)
-  hdk_hip_plan* d_plan = nullptr;
-  HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_plan), sizeof(hdk_hip_plan), s));
+  AsyncScratch plan_mem(s);
+  HDK_HIP_CHECK(hipMallocAsync(&plan_mem.p, sizeof(hdk_hip_plan), s));
+  hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(plan_mem.p);
   HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
   const hdk_hip_device_properties* props = device_props(device_id);
   if (plan->query_kind != HDK_Q_BASELINE_HASH) {
@@ -523,7 +524,6 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
       if (plan->query_kind != HDK_Q_NON_GROUPED && that_entry_counts[i] != this_entry_count) {
         set_error("perfect-hash partials must have the same entry count (%u != %u)", that_entry_counts[i],
                   this_entry_count);
-        (void)hipFreeAsync(d_plan, s);
         return HDK_HIP_ERR_INVALID_ARG;
       }
     }
@@ -553,7 +553,6 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
     }
   }
   HDK_HIP_CHECK(hipGetLastError());
-  HDK_HIP_CHECK(hipFreeAsync(d_plan, s));
   return HDK_HIP_OK;
 }
 

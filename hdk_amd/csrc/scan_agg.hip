@@ -1008,7 +1008,7 @@ static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_opt
 
 static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, const hdk_hip_kernel_options* ko,
                                   const LaunchShape& shape, const hdk_hip_device_properties* props, hipStream_t s) {
-  void* scratch = nullptr;
+  AsyncScratch scratch(s);
   const hdk_hip_join& jn = plan->joins[0];
   if (join_direct_clusters(plan, ko) && static_cast<uint64_t>(jn.max_key - jn.min_key) < 0xFFFFFFFFull) {
     ClusterArgs ca;
@@ -1028,9 +1028,8 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
     auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
     const size_t b_tuples = up((nsub * ca.sub + ca.cap_ovf) * ca.ncols * 8);
     const size_t b_fill = up((nsub * kClusterCursorStride + 4) * sizeof(uint32_t));
-    int8_t* q = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&q), b_tuples + b_fill, s) == hipSuccess) {
-      scratch = q;
+    if (hipMallocAsync(&scratch.p, b_tuples + b_fill, s) == hipSuccess) {
+      int8_t* q = static_cast<int8_t*>(scratch.p);
       ca.out[0] = reinterpret_cast<int64_t*>(q);
       ca.fill = reinterpret_cast<uint32_t*>(q + b_tuples);
       ca.fill_ovf = ca.fill + nsub * kClusterCursorStride;
@@ -1047,14 +1046,12 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
       ja.cap_ovf = ca.cap_ovf;
     } else {
       (void)hipGetLastError();  // no scratch: probe in row order
+      scratch.p = nullptr;
     }
   }
   hipLaunchKernelGGL(hdk_join_agg_direct, dim3(shape.grid), dim3(kJdBlock), shape.lds_bytes, s, ja);
   HDK_HIP_CHECK(hipGetLastError());
-  if (scratch) {
-    HDK_HIP_CHECK(hipFreeAsync(scratch, s));
-  }
-  return HDK_HIP_OK;
+  return HDK_HIP_OK;  // (`scratch` is freed here, stream-ordered after the kernels above)
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
@@ -1619,13 +1616,14 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const size_t nc = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
   const size_t bc = nc * sizeof(uint32_t);
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  int8_t* scratch = nullptr;
-  const hipError_t me = hipMallocAsync(reinterpret_cast<void**>(&scratch), up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
+  AsyncScratch scratch(s);
+  const hipError_t me = hipMallocAsync(&scratch.p, up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
   if (me != hipSuccess) {
     (void)hipGetLastError();
+    scratch.p = nullptr;
     return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
   }
-  int8_t* q = scratch;
+  int8_t* q = static_cast<int8_t*>(scratch.p);
   pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
   pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
   pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
@@ -1682,8 +1680,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   bf.run_if = pa.fallback;
   launch_baseline_direct(plan, bf, shape.grid, s);
   HDK_HIP_CHECK(hipGetLastError());
-  HDK_HIP_CHECK(hipFreeAsync(scratch, s));
-  return HDK_HIP_OK;
+  return HDK_HIP_OK;  // (`scratch` goes back to the pool here, stream-ordered)
 }
 
 // the shape hdk_scan_project_direct takes (scan_project_fast.h)
@@ -1929,6 +1926,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
                   params[HDK_KP_GROUPBY_BUF] && params[HDK_KP_ERROR_CODE],
               "a required kernel parameter is NULL");
   HDK_REQUIRE(plan->num_joins == 0 || params[HDK_KP_JOIN_HASH_TABLES], "JOIN_HASH_TABLES is NULL");
+  // aggregate kernels start their private tables from the init values (the reference always passes them,
+  // QE/QueryExecutionContext.cpp:788-964); a projection has no slots
+  HDK_REQUIRE(plan->query_kind == HDK_Q_PROJECTION || params[HDK_KP_INIT_AGG_VALS], "INIT_AGG_VALS is NULL");
   hipStream_t s;
   st = device_enter(device_id, stream, &s);
   if (st) return st;
@@ -1947,6 +1947,12 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   HDK_REQUIRE(workspace && workspace_bytes >= workspace_bytes_for(shape),
               "workspace too small: %zu < %zu", workspace_bytes, workspace_bytes_for(shape));
   HDK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "workspace must be 16-byte aligned");
+  bool init_output = ko && (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT);
+  if (init_output) {  // (checked before anything is enqueued or allocated)
+    HDK_REQUIRE((plan->query_kind == HDK_Q_PERFECT_HASH || plan->query_kind == HDK_Q_BASELINE_HASH) && !plan->output_columnar,
+                "HDK_HIP_LAUNCH_INIT_OUTPUT is for row-wise group-by buffers");
+    HDK_REQUIRE(params[HDK_KP_INIT_AGG_VALS], "HDK_HIP_LAUNCH_INIT_OUTPUT needs INIT_AGG_VALS");
+  }
 
   // the plan is read by the kernels from device memory (wave-uniform scalar loads)
   hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
@@ -1987,21 +1993,16 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     if (st) return st;
   }
   // join probes over a table far larger than L2: permute the outer columns by key range first (scan_cluster.h)
-  void* cluster_scratch = nullptr;
+  AsyncScratch cluster_scratch(s);  // (freed on every way out of the launch)
   {
     ClusterArgs ca;
     JoinDirectArgs jd;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     const bool direct = !generic && match_join_direct(plan, shape, &jd);  // (clusters its own input, as tuples)
     if (!direct && match_cluster_join(plan, ko, &ca)) {
-      st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch);
+      st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch.p);
       if (st) return st;
     }
-  }
-  bool init_output = ko && (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT);
-  if (init_output) {
-    HDK_REQUIRE((plan->query_kind == HDK_Q_PERFECT_HASH || plan->query_kind == HDK_Q_BASELINE_HASH) && !plan->output_columnar,
-                "HDK_HIP_LAUNCH_INIT_OUTPUT is for row-wise group-by buffers");
   }
   if (shape.strategy == STRAT_LDS) {
     int64_t* slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(workspace) + kPlanRegionBytes);
@@ -2024,9 +2025,6 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     const unsigned fblocks = (shape.entry_count + (kBlock / kWave) - 1) / (kBlock / kWave);
     hipLaunchKernelGGL(hdk_finalize, dim3(fblocks), dim3(kBlock), 0, s, fa);
     HDK_HIP_CHECK(hipGetLastError());
-    if (cluster_scratch) {
-      HDK_HIP_CHECK(hipFreeAsync(cluster_scratch, s));
-    }
     return HDK_HIP_OK;
   }
   if (shape.strategy == STRAT_PROJECT) {
@@ -2039,8 +2037,9 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     if (!generic && match_project_fast(plan, &pf)) {
       pf.kp = kp;
-      uint32_t* counts = nullptr;  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
-      HDK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&counts), static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
+      AsyncScratch counts_mem(s), mask_mem(s);  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
+      HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
+      uint32_t* counts = static_cast<uint32_t*>(counts_mem.p);
       pf.block_counts = counts;
       // selection bitmask handed from the counting pass to the writing pass: rows/8 bytes when the caller
       // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
@@ -2049,12 +2048,12 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       pf.sel_tiles = 0;
       if (ko && ko->total_rows) {
         const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
-        void* m = nullptr;
-        if (hipMallocAsync(&m, tiles * kProjFastBlock, s) == hipSuccess) {
-          pf.sel_mask = static_cast<uint8_t*>(m);
+        if (hipMallocAsync(&mask_mem.p, tiles * kProjFastBlock, s) == hipSuccess) {
+          pf.sel_mask = static_cast<uint8_t*>(mask_mem.p);
           pf.sel_tiles = tiles;
         } else {
           (void)hipGetLastError();
+          mask_mem.p = nullptr;
         }
       }
       if (pf.pairs) {
@@ -2068,10 +2067,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       } else {
         hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
       }
-      if (pf.sel_mask) {
-        HDK_HIP_CHECK(hipFreeAsync(pf.sel_mask, s));
-      }
-      HDK_HIP_CHECK(hipFreeAsync(counts, s));
+      HDK_HIP_CHECK(hipGetLastError());
     } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
       hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
     } else if (plan->num_joins) {
@@ -2107,9 +2103,6 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   if (st) return st;
   if (timed) {
     HDK_HIP_CHECK(hipEventRecord(e1, s));
-  }
-  if (cluster_scratch) {
-    HDK_HIP_CHECK(hipFreeAsync(cluster_scratch, s));
   }
   return HDK_HIP_OK;
 }
