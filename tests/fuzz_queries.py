@@ -132,6 +132,8 @@ def make_tables_wide(rng, n, nd):
     dec = rng.integers(-300, 900, n, dtype=np.int64)
     dec[rng.random(n) < 0.03] = A.NULL_BIGINT
     cols.update({"f32": f32, "ts": ts, "dec": dec})
+    # fragment shapes the base generator never draws: many fragments shorter than a tile, exactly one tile, one row more
+    frag = int(rng.choice([frag, frag, n // 61 + 1, 2048, 8193]))
     st.import_numpy("fact", cols, fragment_size=frag,
                     types={"ts": Type("timestamp", 8, unit="s"), "dec": Type("decimal", 8, scale=2)})
     return st
