@@ -28,7 +28,7 @@ _ROWS = int(os.environ.get("HDK_FUZZ_ROWS", "60000"))  # soak runs also scale th
 def _compare(cp, got, want, float32_atol=0.0):
     # (a one-to-many join multiplies the rows: at soak sizes a float accumulator sees 1e8 additions, and the oracle's
     # row-order float sum itself is only good to a few 1e-3 relative)
-    f32_rtol = 2e-4 * max(1.0, _ROWS / 60_000)
+    f32_rtol = 2e-4 if _ROWS <= 60_000 else 1e-2  # (soak at 1 M rows: a float sum of -1.75e8 over ~1e7 addends of |x| < 100 was 3.5e-3 off in the ORACLE)
     if cp.plan.query_kind == A.Q_BASELINE_HASH:
         _check_rows(cp, got, want, float32_rtol=f32_rtol, float32_atol=float32_atol)  # slot placement is insertion-order dependent
     else:
