@@ -1059,9 +1059,7 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
                                bool force_scalar, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
   FastArgs fa;
   int kw, vw;
-  KeysArgs ka_first;
-  const bool prefer_keys = getenv("HDK_HIP_PREFER_KEYS") && !force_generic && match_keys(plan, shape, &ka_first);  // (A/B measurements)
-  if (!force_generic && !prefer_keys && match_fast(plan, shape, &fa, &kw, &vw)) {
+  if (!force_generic && match_fast(plan, shape, &fa, &kw, &vw)) {
     fa.kp = kp;
     fa.slabs = slabs;
     switch (kw) {
