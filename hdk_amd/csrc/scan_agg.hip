@@ -738,6 +738,11 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     fa->key_null = p->keys[0].null_val;
     fa->key_null_translated = p->key_null_translated[0];
     fa->key_translate_null = p->key_has_nulls[0] && p->keys[0].nullable;
+    if (kw <= 4) {  // the kernel does a narrow key's arithmetic in 32 bits (fast_row): the rare plan that cannot goes to the interpreter
+      constexpr int64_t kLim = 1ll << 30;
+      if (fa->key_min < -kLim || fa->key_min > kLim) return false;
+      if (fa->key_translate_null && fa->key_null_translated != static_cast<int32_t>(fa->key_null_translated)) return false;
+    }
   }
   int vcol = -1;
   int vw = 0;

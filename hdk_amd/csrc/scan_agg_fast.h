@@ -14,6 +14,7 @@
 //   * non-grouped plans accumulate in registers and touch LDS once per lane.
 // The slab format written at the end is the generic one (agg_common.h), so hdk_finalize is shared.
 #pragma once
+#include <type_traits>
 #include "watch.h"
 #include "agg_common.h"
 #include "plain_quals.h"
@@ -167,11 +168,26 @@ struct OpList {  // the per-row LDS update list, hoisted into scalar registers
 
 // One row: entry lookup + the LDS update list.  KW == 0 => non-grouped (entry 0).
 // FIXED >= 0: the list is exactly one op of that kind (compile-time), at word ops.word[0].
-template <int KW, int FIXED>
-HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32_t my_rep, int64_t key,
+template <int KW, int FIXED, bool MASK>
+HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32_t my_rep, uint32_t estride, int64_t key,
                       int64_t val, bool has_val, uint64_t& touched, uint64_t& nonnull, int32_t& err) {
   uint32_t entry = 0;
-  if (KW != 0) {
+  if (KW != 0 && KW <= 4) {
+    // narrow key column: everything in 32 bits.  match_fast only lets a plan in when |key_min| <= 2^30 and the
+    // translated NULL fits 32 bits; the table fits LDS, so entry_count is tiny: k - min cannot wrap onto a valid
+    // entry (k in [-2^31, 2^31): the difference is >= -3 * 2^30, i.e. >= 2^30 as an unsigned 32-bit number).
+    // (The 64-bit form costs 9 vector instructions more per row: taxi Q1 is 4 bytes per row.)
+    int32_t k = static_cast<int32_t>(key);
+    if (a.key_translate_null && k == static_cast<int32_t>(a.key_null)) {
+      k = static_cast<int32_t>(a.key_null_translated);
+    }
+    const uint32_t e = static_cast<uint32_t>(k) - static_cast<uint32_t>(a.key_min);
+    if (e >= a.entry_count) {
+      err = HDK_HIP_ERR_OUT_OF_SLOTS;
+      return;
+    }
+    entry = e;
+  } else if (KW != 0) {
     if (a.key_translate_null && key == a.key_null) {
       key = a.key_null_translated;
     }
@@ -186,14 +202,15 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
   if (has_val && a.val_nullable) {
     is_null = a.val_is_fp ? (bits_to_double(val) == bits_to_double(a.val_null)) : (val == a.val_null);
   }
-  if (a.mask_mode) {
+  if (MASK) {  // (compile time: as a run-time flag this was seven predicated vector instructions on every row)
     const uint64_t bit = 1ull << entry;
     touched |= bit;
     if (!is_null) {
       nonnull |= bit;
     }
   }
-  int64_t* base = lds + (entry * a.wpe) * a.rep + my_rep;
+  // (entry * words per entry * replicas < 2^24: the table lives in LDS -- one full-rate 24-bit multiply)
+  int64_t* base = lds + __umul24(entry, estride) + my_rep;
   if (FIXED >= 100) {
     // compile-time list "row count, sum, [NULL count]" (AVG / SUM+COUNT over one column; taxi Q2):
     // 100/101 = integer/fp sum with a NULL-count word, 102/103 = without (argument cannot be NULL)
@@ -264,8 +281,12 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
   uint64_t touched = 0, nonnull = 0;
   int32_t err = 0;
 
-  int64_t tile = blockIdx.x;
+  const uint32_t estride = static_cast<uint32_t>(wpe) * rep;
   const Watch watch = watch_begin();
+  // the whole scan twice in the code, once per value of mask_mode: inside the row body the flag is a compile-time constant
+  auto scan = [&](auto mask_tag) {
+  constexpr bool MASK = decltype(mask_tag)::value;
+  int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
             const int64_t key = KW ? extract_elem<(KW ? KW : 8)>(kr[u], i) : 0;
             const int64_t val = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
             if (!Q || pass[u * R + i]) {
-              fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+              fast_row<KW, FIXED, MASK>(a, ops, lds, my_rep, estride, key, val, VW != 0, touched, nonnull, err);
             }
           }
         }
@@ -327,11 +348,17 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
           }
           const int64_t key = KW ? load_elem<(KW ? KW : 8)>(kcol, r) : 0;
           const int64_t val = VW ? load_elem<(VW ? VW : 8)>(vcol, r) : 0;
-          fast_row<KW, FIXED>(a, ops, lds, my_rep, key, val, VW != 0, touched, nonnull, err);
+          fast_row<KW, FIXED, MASK>(a, ops, lds, my_rep, estride, key, val, VW != 0, touched, nonnull, err);
         }
       }
     }
     frag_tile_begin += ntiles;
+  }
+  };
+  if (a.mask_mode) {
+    scan(std::true_type{});
+  } else {
+    scan(std::false_type{});
   }
   if (err) {
     record_error(a.kp.error_code, err);
