@@ -1,6 +1,8 @@
 """GPU parity for the global-atomics strategy: GroupByBaselineHash (open addressing, config C5's
 shape) and perfect-hash tables forced off LDS.  Slot positions of a baseline table depend on
 insertion order, so buffers are compared as {key -> slots} after decoding; keys/ints bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -512,3 +514,85 @@ def test_launch_initialises_a_poisoned_table(oracle, gpu_executor_factory):
                 for arr, w, iv in zip(slots, cp.slot_widths, cp.init_vals):
                     if w:
                         assert np.all(arr[empty] == iv)
+
+
+_SOAK = os.environ.get("HDK_FUZZ_SEEDS", "")
+_SOAK_SEEDS = list(range(*map(int, _SOAK.split(":")))) if _SOAK else []
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", [1, 2] + _SOAK_SEEDS)
+def test_radix_partitioned_random_shapes(oracle, gpu_executor_factory, seed):
+    """Seeded random shapes through the radix-partitioned path: row counts from one batch to millions, uniform / zipf /
+    heavy-hitter keys (slab overflow, armed fallback), 4- and 8-byte keys, one or two keys, 1-3 aggregates over int64 /
+    int32 / double columns with NULLs, optional filters, load factors from 0.3 to more groups than entries (the oracle
+    then reports ERR_OUT_OF_SLOTS and so must the device), ragged fragments.  Rows and the reference's placement are
+    checked; HDK_FUZZ_SEEDS adds seeds for soak runs."""
+    from hdk_amd._lib import HdkHipError
+    from hdk_amd.ir import Cmp, Lit
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([3_000, 70_000, 400_000, 1_200_000, 3_000_000]))
+    ndv = int(rng.choice([50, 5_000, 60_000, 400_000]))
+    ndv = min(ndv, max(n // 2, 10))
+    mode = str(rng.choice(["uniform", "zipf", "hot", "warm"]))
+    base = rng.integers(0, ndv, n, dtype=np.int64)
+    if mode == "zipf":
+        base = np.minimum(rng.zipf(1.3, n) - 1, ndv - 1).astype(np.int64)
+    elif mode == "hot":
+        base[rng.random(n) < 0.45] = 7
+    elif mode == "warm":
+        base[rng.random(n) < 0.04] = 7
+    k64 = base * 3_000_000_019 - 2**40
+    k32 = (base * 7 - 100_000).astype(np.int32)
+    k2 = rng.integers(0, 3, n).astype(np.int32)
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    i32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    i32[rng.random(n) < 0.05] = A.NULL_INT
+    d = rng.normal(size=n)
+    st = ArrowStorage()
+    st.import_numpy("t", {"k64": k64, "k32": k32, "k2": k2, "v": v, "i32": i32, "d": d},
+                    fragment_size=int(rng.integers(n // 5 + 1, n + 2)))
+    ex = gpu_executor_factory(st)
+    ran = 0
+    for qi in range(4):
+        two = rng.random() < 0.3
+        kc = str(rng.choice(["k64", "k32"]))
+        groupby = [ColRef(kc)] + ([ColRef("k2")] if two else [])
+        groups = ndv * (3 if two else 1)
+        load = float(rng.choice([0.3, 0.5, 0.9, 1.5]))
+        entries = max(int(groups / load) | 1, 1025)
+        targets = [KeyRef(i, f"k{i}") for i in range(len(groupby))]
+        for ti in range(int(rng.integers(1, 4))):
+            kind = str(rng.choice(["sum", "count", "min", "max", "avg"]))
+            arg = None if (kind == "count" and rng.random() < 0.5) else ColRef(str(rng.choice(["v", "v", "i32", "d"])))
+            targets.append(Agg(kind, arg, f"t{ti}"))
+        quals = [Cmp(ColRef("i32"), "<=", Lit(int(rng.integers(-200, 900))))] if rng.random() < 0.4 else []
+        q = QueryUnit("t", groupby=groupby, quals=quals, force_baseline=True, baseline_entry_count=entries, targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        what = (seed, qi, n, ndv, mode, entries, q)
+        if os.environ.get("HDK_SOAK_LOG"):  # what the soak actually covered
+            probe = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+            first = probe.kernel_names().split(",")[0]
+            probe.free()
+            with open(os.environ["HDK_SOAK_LOG"], "a") as f:
+                f.write(f"{seed} {qi} rows={n} ndv={ndv} {mode} entries={entries} keys={len(groupby)}x{kc} "
+                        f"targets={len(targets) - len(groupby)} quals={len(quals)} oracle_err={err} kernel={first}\n")
+        if err:
+            assert err == A.ERR_OUT_OF_SLOTS, what
+            with pytest.raises(HdkHipError) as ei:
+                ex.execute(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+            assert ei.value.code == A.ERR_OUT_OF_SLOTS, what
+            continue
+        step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+        names = step.kernel_names()
+        res = step.run()
+        step.free()
+        try:
+            _check_rows(cp, res.buffer, want)
+            if res.row_count() < cp.plan.entry_count and not cp.plan.output_columnar:
+                _assert_reference_placement(oracle, cp, res.buffer)
+        except AssertionError as e:
+            raise AssertionError(f"{what} kernels {names}\n{e}") from e
+        ran += names.startswith("hdk_part_scatter")
+    assert ran >= 1 or seed not in (1, 2)
