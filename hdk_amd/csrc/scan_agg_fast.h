@@ -200,7 +200,10 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
   }
   bool is_null = false;
   if (has_val && a.val_nullable) {
-    is_null = a.val_is_fp ? (bits_to_double(val) == bits_to_double(a.val_null)) : (val == a.val_null);
+    // (the compile-time op lists fix the argument's class: as a run-time flag both compares and a select ran per row)
+    constexpr int kFpKnown = FIXED >= 100 ? (FIXED & 1) : FIXED == FOP_ADD_U64 ? 0 : FIXED == FOP_ADD_F64 ? 1 : -1;
+    const bool fp = kFpKnown >= 0 ? kFpKnown != 0 : a.val_is_fp != 0;
+    is_null = fp ? (bits_to_double(val) == bits_to_double(a.val_null)) : (val == a.val_null);
   }
   if (MASK) {  // (compile time: as a run-time flag this was seven predicated vector instructions on every row)
     const uint64_t bit = 1ull << entry;
