@@ -1,17 +1,5 @@
 #!/bin/bash
-# quick check of the partitioned group-by: its GPU tests + per-kernel times at 256 M rows
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/c5q; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_baseline.py tests/test_gpu_fuzz.py -m gpu -x -q -k "not multi_gpu" --durations=5 > $O/pytest.txt 2>&1
-echo "pytest rc=$?" >> $O/pytest.txt
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o c5 --output-format csv -- python3 scripts/bench_configs.py --rows 256000000 --only c5 > $O/c5_prof.log 2>&1
-find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/c5_kernel_stats.csv \;
-rm -rf $O/prof
-python3 - <<'PY' > $O/summary.txt
-import csv
-for r in csv.DictReader(open('gpurun_out/c5q/c5_kernel_stats.csv')):
-    n=r['Name']
-    if 'part' in n or 'baseline' in n:
-        print(n[:70], r['Calls'], 'avg ms %.3f' % (float(r['AverageNs'])/1e6))
-PY
-grep rows_per_s $O/c5_prof.log >> $O/summary.txt
+bash scripts/gpu/c5_stats.sh 2>&1 | tail -7 | cut -c1-300
+python bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --extra none 2>/dev/null | cut -c1-260
+python bench.py --config c5s --steps 5 --warmup 2 --no-cpu-baseline --extra none 2>/dev/null | cut -c1-260
+python -m pytest tests/test_gpu_baseline.py -m gpu -x -q -k "not multi_gpu" 2>&1 | tail -2
