@@ -62,7 +62,9 @@ constexpr int kPartMaxArgs = 2;                  // argument columns carried in 
 constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: 1-2 keys + argument columns, 3 in all (LDS staging)
 constexpr uint32_t kPartLdsBytes = 60 * 1024;    // LDS image of a region (two 1024-thread blocks per CU; above 64 KiB per block only one was resident)
 constexpr uint32_t kPartCursorStride = 32;       // uint32 cursors one per 128-byte line
-constexpr int kPartG2X = 16;                     // pass-2 blocks per coarse slab
+// pass-2 blocks per coarse slab.  Same box, C5 at 1 B rows: 8 -> 19.45 ms, 16 -> 18.3-18.7, 32 -> 18.2-18.3, 64 -> 18.0-18.2;
+// at 256 M rows 16 -> 4.69 ms, 32 -> 4.55, 64 -> 4.50 (more, shorter blocks even out the tail of the pass)
+constexpr int kPartG2X = 64;
 constexpr int kPartXcds = 8;                     // L2 domains: a line of a slab should only ever be written from one of them
 constexpr uint32_t kPartSpillSeg = 64;           // spilled tuples a region keeps in its own segment before it takes the shared list
 
