@@ -36,7 +36,12 @@ struct KernParams {
   int32_t* error_code;                      // ERROR_CODE
   const uint32_t* num_tables;               // NUM_TABLES
   const int64_t* join_hash_tables;          // JOIN_HASH_TABLES
+  const struct LaunchWatch* watch;          // this launch's interrupt / watchdog words (workspace head, watch.h)
+  const int32_t* interrupt;                 // the device's interrupt word (hdk_hip_set_interrupt)
 };
+
+// two 64-bit words moved by ONE 16-byte load / store (global_load_dwordx4, ds_read_b128)
+typedef long long __attribute__((ext_vector_type(2))) bf_i64x2;
 
 // record_error_code (QE/RuntimeFunctions.cpp:1123-1135): positive codes are sticky.
 HDK_DEV void record_error(int32_t* error_code, int32_t err) {

@@ -14,6 +14,8 @@ void clear_error();
 // per-device state (lazy): sets the device and returns the stream to use (`stream` or the manager's)
 int32_t device_enter(int32_t device_id, void* stream, hipStream_t* out);
 const hdk_hip_device_properties* device_props(int32_t device_id);
+// the device's interrupt word (device memory, 0 = run): polled by launches with HDK_HIP_LAUNCH_CHECK_INTERRUPT
+const int32_t* device_interrupt_word(int32_t device_id);
 // init_groups.hip: the row-wise fill for a buffer named by GROUPBY_BUF[0] (device memory)
 int32_t launch_init_row_wise_indirect(int64_t* const* groupby_buf, const int64_t* init_vals, uint32_t entry_count,
                                       uint32_t key_count, uint32_t key_width, uint32_t row_size_quad, int keyless,

@@ -1,0 +1,98 @@
+// host_match.h -- host-side helpers shared by the scan translation units (scan_agg.hip: API + LDS strategies;
+// scan_baseline.hip: open-addressing strategies; scan_project.hip: filter/project), and what they export to each other.
+#pragma once
+#include <string.h>
+
+#include "host_common.h"
+#include "launch_common.h"
+#include "plain_quals.h"
+
+namespace hdk {
+
+// Persistent grids are sized from what actually fits: blocks per CU (register / LDS limited) x CUs, so that
+// every block is resident and the static tile walk has no second, partly filled round (the batched
+// interpreter at 147 VGPRs fits 3 blocks per CU: 1024 blocks ran as 768 + 256 -- taxi Q3 1.43 ms -- while
+// 768 blocks take 1.14 ms).
+inline uint32_t resident_grid(const void* kernel, int block, size_t lds_bytes, const hdk_hip_device_properties* props) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return static_cast<uint32_t>(props->grid_size);
+  }
+  return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
+}
+
+inline bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* col) {
+  if (e.nsteps != 0 || e.leaf0.kind != HDK_LEAF_COL) return false;
+  const hdk_hip_col& c = p->cols[e.leaf0.col];
+  if (c.table != 0) return false;
+  *col = e.leaf0.col;
+  return true;
+}
+
+// joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
+// LEFT joins (the batched interpreter handles inner one-to-one probes)
+inline bool needs_join_loops(const hdk_hip_plan* p) {
+  if (p->num_filter_ops) {
+    return true;  // OR / NOT over the conjuncts: evaluated by the row-at-a-time interpreter (filter_program_pass)
+  }
+  for (int j = 0; j < p->num_joins; ++j) {
+    const hdk_hip_join& jn = p->joins[j];
+    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) {
+      return true;
+    }
+  }
+  return false;
+}
+
+// filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape
+inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
+  if (p->num_quals > kMaxPlainQuals || p->num_filter_ops) return false;
+  for (int i = 0; i < p->num_quals; ++i) {
+    const hdk_hip_qual& q = p->quals[i];
+    int c;
+    if (!plain_outer_col(p, q.lhs, &c)) return false;
+    if (q.rhs.kind != HDK_LEAF_INT && q.rhs.kind != HDK_LEAF_FP) return false;
+    const hdk_hip_col& col = p->cols[c];
+    ProjFastQual& fq = out[i];
+    fq.col.buf_idx = col.buf_idx;
+    fq.col.width = col.width;
+    fq.col.kind = col.kind;
+    fq.cmp = q.cmp;
+    fq.nullable = q.lhs.leaf0.nullable;
+    fq.null_val = q.lhs.leaf0.null_val;
+    fq.col_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
+    const bool rhs_fp = q.rhs.kind == HDK_LEAF_FP;
+    fq.fp = fq.col_fp || rhs_fp;
+    if (fq.fp && !rhs_fp) {
+      const double d = static_cast<double>(q.rhs.ival);
+      memcpy(&fq.rhs, &d, 8);
+    } else {
+      fq.rhs = q.rhs.ival;
+    }
+  }
+  return true;
+}
+
+inline bool launch_forces_generic(const hdk_hip_kernel_options* ko) {
+  return ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+}
+
+// ---- scan_baseline.hip: GroupByBaselineHash plans and perfect-hash tables too big for LDS (STRAT_GLOBAL) ----------
+// persistent grid of the kernel that will run (x 4: random atomics make block run times uneven)
+uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);
+// kernel names of the launch, comma separated
+void baseline_describe(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, char* out, size_t out_len);
+// the whole strategy: radix-partitioned passes when the shape allows, else the global-atomics kernels.  `init_output`
+// = HDK_HIP_LAUNCH_INIT_OUTPUT (fused into the partitioned pass 3, or the init kernel first)
+int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                        const hdk_hip_kernel_options* ko, const LaunchShape& shape, bool init_output,
+                        const hdk_hip_device_properties* props, hipStream_t s);
+
+// ---- scan_project.hip: Projection plans (STRAT_PROJECT) ---------------------------------------------------------------
+uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);
+void project_describe(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, char* out, size_t out_len);
+int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, hipStream_t s);
+
+}  // namespace hdk

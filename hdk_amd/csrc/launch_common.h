@@ -13,7 +13,9 @@ constexpr uint64_t kLdsWordBudget = 4096;
 // Tables between 32 and 60 KiB still go to LDS, unreplicated (2 blocks per CU): LDS atomics on a few
 // thousand entries stream at HBM speed, the global-atomics alternative is capped at ~2.4e10 rows/s.
 constexpr uint64_t kLdsMaxTableWords = 7680;
-constexpr size_t kPlanRegionBytes = (sizeof(hdk_hip_plan) + 255) & ~static_cast<size_t>(255);
+// head of a launch's workspace: [plan copy | LaunchWatch (watch.h)], padded to 256 bytes
+constexpr size_t kWatchOffset = (sizeof(hdk_hip_plan) + 15) & ~static_cast<size_t>(15);
+constexpr size_t kPlanRegionBytes = (kWatchOffset + 16 + 255) & ~static_cast<size_t>(255);
 
 struct LaunchShape {
   Strategy strategy;

@@ -30,6 +30,9 @@ struct DeviceState {
   hipStream_t stream = nullptr;
   hdk_hip_device_properties props;
   int32_t status = HDK_HIP_OK;
+  int32_t* interrupt_word = nullptr;  // device memory: != 0 stops launches that poll it (hdk_hip_set_interrupt)
+  hipStream_t interrupt_stream = nullptr;  // the flag travels on a stream of its own: it overtakes the kernels it stops
+  std::mutex interrupt_mu;
 };
 static DeviceState g_dev[kMaxDevices];
 
@@ -37,7 +40,10 @@ static void init_device(int32_t d) {
   DeviceState& s = g_dev[d];
   hipDeviceProp_t hp;
   if (hipSetDevice(d) != hipSuccess || hipGetDeviceProperties(&hp, d) != hipSuccess ||
-      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&s.interrupt_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&s.interrupt_word), 256) != hipSuccess ||
+      hipMemset(s.interrupt_word, 0, 256) != hipSuccess) {
     s.status = HDK_HIP_ERR_RUNTIME;
     return;
   }
@@ -105,9 +111,24 @@ const hdk_hip_device_properties* device_props(int32_t device_id) {
   return ensure_device(device_id) == HDK_HIP_OK ? &g_dev[device_id].props : nullptr;
 }
 
+const int32_t* device_interrupt_word(int32_t device_id) {
+  return ensure_device(device_id) == HDK_HIP_OK ? g_dev[device_id].interrupt_word : nullptr;
+}
+
 }  // namespace hdk
 
 using namespace hdk;
+
+extern "C" int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value) {
+  hipStream_t main_stream;
+  const int32_t st = device_enter(device_id, nullptr, &main_stream);
+  if (st) return st;
+  DeviceState& d = g_dev[device_id];
+  std::lock_guard<std::mutex> lk(d.interrupt_mu);
+  HDK_HIP_CHECK(hipMemcpyAsync(d.interrupt_word, &value, sizeof(int32_t), hipMemcpyHostToDevice, d.interrupt_stream));
+  HDK_HIP_CHECK(hipStreamSynchronize(d.interrupt_stream));
+  return HDK_HIP_OK;
+}
 
 extern "C" {
 
@@ -354,24 +375,35 @@ int32_t hdk_hip_mgr_measure_hbm(int32_t device_num, size_t bytes, int32_t reps, 
   if (st) return st;
   const hdk_hip_device_properties* props = device_props(device_num);
   const size_t n = bytes / 16;
-  void *a = nullptr, *b = nullptr;
-  HDK_HIP_CHECK(hipMalloc(&a, n * 16));
-  if (hipMalloc(&b, n * 16) != hipSuccess) {
-    (void)hipFree(a);
+  // (every early return below -- HDK_HIP_CHECK -- releases the calibration buffers and the events)
+  struct Guard {
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Guard() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+    }
+  } g;
+  if (hipMalloc(&g.a, n * 16) != hipSuccess || hipMalloc(&g.b, n * 16) != hipSuccess) {
+    (void)hipGetLastError();
     set_error("hipMalloc failed for the calibration buffers");
     return HDK_HIP_ERR_OUT_OF_GPU_MEM;
   }
+  void *const a = g.a, *const b = g.b;
   HDK_HIP_CHECK(hipMemsetAsync(a, 1, n * 16, s));
   HDK_HIP_CHECK(hipMemsetAsync(b, 0, n * 16, s));
-  hipEvent_t e0, e1;
-  HDK_HIP_CHECK(hipEventCreate(&e0));
-  HDK_HIP_CHECK(hipEventCreate(&e1));
+  HDK_HIP_CHECK(hipEventCreate(&g.e0));
+  HDK_HIP_CHECK(hipEventCreate(&g.e1));
+  const hipEvent_t e0 = g.e0, e1 = g.e1;
   const unsigned grid = static_cast<unsigned>(props->num_cu) * 8;
   float ms = 0.f;
   double best_copy = 0, best_read = 0;
   for (int r = 0; r < reps + 1; ++r) {  // (first round warms up)
     HDK_HIP_CHECK(hipEventRecord(e0, s));
     hipLaunchKernelGGL(k_cal_copy, dim3(grid), dim3(256), 0, s, static_cast<const cal_f4*>(a), static_cast<cal_f4*>(b), n);
+    HDK_HIP_CHECK(hipGetLastError());
     HDK_HIP_CHECK(hipEventRecord(e1, s));
     HDK_HIP_CHECK(hipEventSynchronize(e1));
     HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -380,16 +412,13 @@ int32_t hdk_hip_mgr_measure_hbm(int32_t device_num, size_t bytes, int32_t reps, 
       HDK_HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(k_cal_read, dim3(static_cast<unsigned>(props->num_cu) * per_cu), dim3(256), 0, s,
                          static_cast<const cal_f4*>(a), static_cast<float*>(b), n);
+      HDK_HIP_CHECK(hipGetLastError());
       HDK_HIP_CHECK(hipEventRecord(e1, s));
       HDK_HIP_CHECK(hipEventSynchronize(e1));
       HDK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       if (r && ms > 0) best_read = std::max(best_read, 1.0 * (n / 2048 * 2048) * 16 / (ms * 1e-3) / 1e9);
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(a);
-  (void)hipFree(b);
   *copy_gbps = best_copy;
   *read_gbps = best_read;
   return HDK_HIP_OK;

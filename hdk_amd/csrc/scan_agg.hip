@@ -101,7 +101,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_scan_agg_generic(ScanAr
 
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
@@ -434,16 +434,10 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include <stddef.h>
 #include <string.h>
 
-#include "host_common.h"
-#include "launch_common.h"
+#include "host_match.h"
 #include "scan_agg_fast.h"
-#include "scan_agg_baseline_fast.h"
-#include "scan_agg_partitioned.h"
-#include "scan_agg_global.h"
 #include "scan_agg_vec.h"
 #include "scan_agg_keys.h"
-#include "scan_project.h"
-#include "scan_project_fast.h"
 #include "scan_cluster.h"
 #include "scan_join_direct.h"
 
@@ -547,8 +541,6 @@ int32_t validate_plan(const hdk_hip_plan* p) {
 
 struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
-static bool needs_join_loops(const hdk_hip_plan* p);
-static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out);
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
 static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
 static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, JoinDirectArgs* ja);
@@ -569,21 +561,12 @@ static const void* keys_kernel(const KeysArgs& ka) {
   return wmax == 8 ? reinterpret_cast<const void*>(hdk_scan_agg_keys<false, 2>)
                    : reinterpret_cast<const void*>(hdk_scan_agg_keys<false, 4>);
 }
-static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa);
-static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa);
-static const void* baseline_direct_kernel(const hdk_hip_plan* p);
 
-// Persistent grids are sized from what actually fits: blocks per CU (register / LDS limited) x CUs, so that
-// every block is resident and the static tile walk has no second, partly filled round (the batched
-// interpreter at 147 VGPRs fits 3 blocks per CU: 1024 blocks ran as 768 + 256 -- taxi Q3 1.43 ms -- while
-// 768 blocks take 1.14 ms).
-static uint32_t resident_grid(const void* kernel, int block, size_t lds_bytes, const hdk_hip_device_properties* props) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) {
-    (void)hipGetLastError();
-    return static_cast<uint32_t>(props->grid_size);
-  }
-  return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
+
+// arms a launch's own interrupt / watchdog words (watch.h)
+__global__ void k_arm_watch(LaunchWatch* w, uint32_t flags, uint32_t watchdog_ms) {
+  w->flags = flags;
+  w->deadline = __builtin_amdgcn_s_memrealtime() + static_cast<uint64_t>(watchdog_ms) * 100000ull;
 }
 
 LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko,
@@ -661,32 +644,13 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
                                  : reinterpret_cast<const void*>(hdk_scan_agg_vec));
       block = scalar ? kBlock : kVecBlock;
     } else if (s.strategy == STRAT_PROJECT) {
-      ProjFastArgs pf;
-      if (!generic && match_project_fast(p, &pf)) {
-        k = reinterpret_cast<const void*>(hdk_scan_project_direct);
-        block = kProjFastBlock;
-      } else {
-        k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
-                   : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
-                                   : reinterpret_cast<const void*>(hdk_scan_project));
-        block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
-      }
+      s.grid = project_grid(p, ko, props);
+      return s;
     } else {
-      BaseFastArgs bf;
-      if (!generic && match_baseline_fast(p, &bf)) {
-        k = baseline_direct_kernel(p);
-        block = kBaseFastBlock;
-      } else {
-        k = reinterpret_cast<const void*>(hdk_scan_agg_global);
-        block = kGlobalBlock;
-      }
+      s.grid = baseline_grid(p, ko, props);
+      return s;
     }
     s.grid = resident_grid(k, block, lds_for_occupancy, props);
-    if (s.strategy == STRAT_GLOBAL) {
-      // random atomics make block run times uneven: 4 waves of blocks rebalance the tail
-      // (C5 shape: 1792 blocks 21.5 ms, 3584 18.8 ms, 7168 17.6 ms)
-      s.grid *= 4;
-    }
   }
   return s;
 }
@@ -714,13 +678,6 @@ static int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e
 }
 
 // ---- fast-path matcher: plan -> FastArgs (scan_agg_fast.h) -----------------------------------------
-static bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* col) {
-  if (e.nsteps != 0 || e.leaf0.kind != HDK_LEAF_COL) return false;
-  const hdk_hip_col& c = p->cols[e.leaf0.col];
-  if (c.table != 0) return false;
-  *col = e.leaf0.col;
-  return true;
-}
 
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out) {
   if (shape.strategy != STRAT_LDS || p->num_joins || p->key_count > 1) return false;
@@ -877,20 +834,6 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
   }
 }
 
-// joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
-// LEFT joins (the batched interpreter handles inner one-to-one probes)
-static bool needs_join_loops(const hdk_hip_plan* p) {
-  if (p->num_filter_ops) {
-    return true;  // OR / NOT over the conjuncts: evaluated by the row-at-a-time interpreter (filter_program_pass)
-  }
-  for (int j = 0; j < p->num_joins; ++j) {
-    const hdk_hip_join& jn = p->joins[j];
-    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) {
-      return true;
-    }
-  }
-  return false;
-}
 
 // (same decisions as launch_scan_lds)
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, bool force_generic, bool force_scalar) {
@@ -1298,457 +1241,9 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
   return true;
 }
 
-// filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape
-static bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
-  if (p->num_quals > kMaxPlainQuals || p->num_filter_ops) return false;
-  for (int i = 0; i < p->num_quals; ++i) {
-    const hdk_hip_qual& q = p->quals[i];
-    int c;
-    if (!plain_outer_col(p, q.lhs, &c)) return false;
-    if (q.rhs.kind != HDK_LEAF_INT && q.rhs.kind != HDK_LEAF_FP) return false;
-    const hdk_hip_col& col = p->cols[c];
-    ProjFastQual& fq = out[i];
-    fq.col.buf_idx = col.buf_idx;
-    fq.col.width = col.width;
-    fq.col.kind = col.kind;
-    fq.cmp = q.cmp;
-    fq.nullable = q.lhs.leaf0.nullable;
-    fq.null_val = q.lhs.leaf0.null_val;
-    fq.col_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
-    const bool rhs_fp = q.rhs.kind == HDK_LEAF_FP;
-    fq.fp = fq.col_fp || rhs_fp;
-    if (fq.fp && !rhs_fp) {
-      const double d = static_cast<double>(q.rhs.ival);
-      memcpy(&fq.rhs, &d, 8);
-    } else {
-      fq.rhs = q.rhs.ival;
-    }
-  }
-  return true;
-}
 
-static const void* baseline_direct_kernel(const hdk_hip_plan* p) {
-  if (p->key_width == 4) {
-    return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 2>)
-                             : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 1>);
-  }
-  return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 2>)
-                           : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 1>);
-}
 
-static void launch_baseline_direct(const hdk_hip_plan* p, const BaseFastArgs& fa, unsigned grid, hipStream_t s) {
-  if (p->key_width == 4) {
-    if (p->key_count == 2) {
-      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
-    } else {
-      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
-    }
-  } else if (p->key_count == 2) {
-    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
-  } else {
-    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
-  }
-}
 
-// the shape hdk_scan_agg_baseline_direct takes (scan_agg_baseline_fast.h)
-static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
-  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_joins || p->key_count < 1 ||
-      p->key_count > 2) {
-    return false;
-  }
-  int kc;
-  if (!plain_outer_col(p, p->keys[0], &kc) || p->cols[kc].kind != HDK_COL_INT) return false;
-  memset(fa, 0, sizeof(*fa));
-  fa->key_buf_idx = p->cols[kc].buf_idx;
-  fa->key_width = p->cols[kc].width;
-  fa->key_kind = p->cols[kc].kind;
-  fa->nkeys = p->key_count;
-  if (p->key_count == 2) {
-    int kc2;
-    if (!plain_outer_col(p, p->keys[1], &kc2) || p->cols[kc2].kind != HDK_COL_INT) return false;
-    fa->key2_buf_idx = p->cols[kc2].buf_idx;
-    fa->key2_width = p->cols[kc2].width;
-    fa->key2_kind = p->cols[kc2].kind;
-  }
-  if (!match_plain_quals(p, fa->q)) return false;
-  fa->nquals = p->num_quals;
-  int n = 0;
-  for (int t = 0; t < p->num_targets; ++t) {
-    const hdk_hip_target& tg = p->targets[t];
-    if (tg.agg == HDK_AGG_ID) {
-      if (tg.slot_width != 0) return false;  // (perfect-hash style key slots: generic kernel)
-      continue;
-    }
-    if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;  // float accumulators: generic kernel
-    BaseFastTarget ft;
-    ft.target = t;
-    ft.buf_idx = -1;
-    ft.width = 8;
-    ft.kind = HDK_COL_INT;
-    if (tg.has_arg) {
-      int c;
-      if (!plain_outer_col(p, tg.arg, &c)) return false;
-      ft.buf_idx = p->cols[c].buf_idx;
-      ft.width = p->cols[c].width;
-      ft.kind = p->cols[c].kind;
-    } else if (tg.agg != HDK_AGG_COUNT) {
-      return false;
-    }
-    fa->tg[n++] = ft;
-  }
-  fa->ntargets = n;
-  return true;
-}
-
-// ---- radix-partitioned open-addressing group-by (scan_agg_partitioned.h) -------------------------------
-// Taken for the hdk_scan_agg_baseline_direct shape when the table is large enough that the memory-side
-// atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
-static uint32_t pow2_ceil_log2(uint64_t x) {
-  uint32_t l = 0;
-  while ((1ull << l) < x) ++l;
-  return l;
-}
-
-// unsigned 32-bit division by an invariant divisor d >= 2, round-up method in its branch-free form:
-//   t = mulhi(magic, n);  q = (((n - t) >> 1) + t) >> shift        (exact for every 32-bit n)
-static void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
-  uint32_t log2d = 31;
-  while (!(d >> log2d)) --log2d;
-  if ((d & (d - 1)) == 0) {
-    *magic = 0;
-    *shift = log2d - 1;
-    return;
-  }
-  const uint64_t two_k = 1ull << (32 + log2d);
-  const uint64_t m = two_k / d;
-  const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
-  uint32_t m32 = static_cast<uint32_t>(m) * 2u;
-  const uint32_t twice_rem = rem * 2u;
-  if (twice_rem >= d || twice_rem < rem) m32 += 1;
-  *magic = m32 + 1u;
-  *shift = log2d;
-}
-
-// key_hash (QE/GroupByRuntime.cpp:24-29: MurmurHash3 of the packed key, seed 0) of the key (k, 0) on the host, for the
-// padding keys of the partitioned group-by; same word order as key_hash_dev (baseline_table.h)
-template <typename K>
-static uint32_t host_key_hash(int64_t k, int nkeys) {
-  uint32_t h1 = 0;
-  auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
-  auto mix = [&](uint32_t k1) {
-    k1 *= 0xcc9e2d51u;
-    k1 = rotl(k1, 15);
-    k1 *= 0x1b873593u;
-    h1 ^= k1;
-    h1 = rotl(h1, 13);
-    h1 = h1 * 5 + 0xe6546b64u;
-  };
-  for (int i = 0; i < nkeys; ++i) {
-    const uint64_t v = i == 0 ? static_cast<uint64_t>(k) : 0;
-    mix(static_cast<uint32_t>(v));
-    if (sizeof(K) == 8) mix(static_cast<uint32_t>(v >> 32));
-  }
-  h1 ^= static_cast<uint32_t>(nkeys * sizeof(K));
-  h1 ^= h1 >> 16;
-  h1 *= 0x85ebca6bu;
-  h1 ^= h1 >> 13;
-  h1 *= 0xc2b2ae35u;
-  h1 ^= h1 >> 16;
-  return h1;
-}
-
-static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
-  BaseFastArgs bf;
-  if (!match_baseline_fast(p, &bf)) return false;
-  if (!ko || ko->total_rows == 0) return false;
-  const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
-  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
-  if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
-  if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
-  memset(pa, 0, sizeof(*pa));
-  pa->key_buf_idx = bf.key_buf_idx;
-  pa->key_width = bf.key_width;
-  pa->key_kind = bf.key_kind;
-  pa->nkeys = bf.nkeys;
-  pa->key2_buf_idx = bf.key2_buf_idx;
-  pa->key2_width = bf.key2_width;
-  pa->key2_kind = bf.key2_kind;
-  pa->nquals = bf.nquals;
-  for (int i = 0; i < bf.nquals; ++i) pa->q[i] = bf.q[i];
-  for (int t = 0; t < bf.ntargets; ++t) {
-    const BaseFastTarget& ft = bf.tg[t];
-    int word = 0;
-    if (ft.buf_idx >= 0) {
-      for (int k = 0; k < pa->nargs; ++k) {
-        if (pa->arg[k].buf_idx == ft.buf_idx) word = 1 + k;
-      }
-      if (!word) {
-        if (pa->nkeys + pa->nargs == kPartMaxTW) return false;  // the tuple holds 3 words: keys + argument columns
-        pa->arg[pa->nargs] = ft;
-        word = 1 + pa->nargs++;
-      }
-    }
-    pa->tgt_index[t] = ft.target;
-    pa->tgt_arg[t] = word ? word - 1 + pa->nkeys : 0;  // absolute tuple word of the argument
-  }
-  pa->ntargets = bf.ntargets;
-  pa->tw = pa->nkeys + pa->nargs;
-  pa->all_wide = pa->key_width == 8 && pa->key_kind == HDK_COL_INT && (pa->nkeys < 2 || (pa->key2_width == 8 && pa->key2_kind == HDK_COL_INT));
-  for (int k = 0; k < pa->nargs; ++k) {
-    if (pa->arg[k].width != 8 || (pa->arg[k].kind != HDK_COL_INT && pa->arg[k].kind != HDK_COL_DOUBLE)) pa->all_wide = 0;
-  }
-  pa->entry_count = p->entry_count;
-  magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
-  // regions: as many entries as fit the LDS image
-  pa->slots = kPartLdsBytes / (p->row_size_quad * 8);
-  if (pa->slots < 16 || pa->slots >= p->entry_count) return false;
-  magic_u32(pa->slots, &pa->reg_magic, &pa->reg_shift);
-  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + pa->slots - 1) / pa->slots;
-  // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch)
-  uint32_t p2_log2 = (pow2_ceil_log2(pf) + 1) / 2;
-  while (((pf + (1ull << p2_log2) - 1) >> p2_log2) > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
-  if ((1u << p2_log2) > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 64 K regions: a third level would be needed
-  pa->fine_count = static_cast<uint32_t>(pf);
-  pa->p2_log2 = p2_log2;
-  pa->p1 = static_cast<uint32_t>((pf + (1ull << p2_log2) - 1) >> p2_log2);
-  // whole 128-byte lines: runs of G tuples (8 of 16 B; 16 of 8 or 24 B), padded with keys of another partition --
-  // which needs two coarse partitions (a table this small gains nothing from alignment anyway)
-  // Measured at the C5 shape (256 M rows): rounding runs up to whole lines costs more than it gains -- the padding
-  // is 18 % of pass 1's output and compounds to 44 % of pass 3's input, and its staging slots cost the third block
-  // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
-  // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements.
-  pa->g_log2 = 0;
-  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = pa->p1 < 2 ? 0 : atoi(e);
-  if (pa->g_log2) {
-    int found = 0;
-    for (int64_t k = 1; k < 4096 && found < 2; ++k) {
-      const uint32_t h = p->key_width == 4 ? host_key_hash<int32_t>(k, pa->nkeys) : host_key_hash<int64_t>(k, pa->nkeys);
-      const uint32_t c = static_cast<uint32_t>((h % p->entry_count) / pa->slots) >> p2_log2;
-      if (found == 0 || c != pa->pad_coarse[0]) {
-        // (tuples of 4-byte keys carry their home in the upper half of word 0: part_pack_home)
-        pa->pad_key[found] = p->key_width == 4 ? static_cast<int64_t>((static_cast<uint64_t>(h % p->entry_count) << 32) | static_cast<uint32_t>(k)) : k;
-        pa->pad_coarse[found] = c;
-        ++found;
-      }
-    }
-    if (found < 2) pa->g_log2 = 0;
-  }
-  const uint64_t g = 1ull << pa->g_log2;
-  const uint64_t rows = ko->total_rows;
-  pa->total_rows = rows;
-  auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
-  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack, plus the
-  // padding: on average (G - 1) / 2 slots per bin and batch
-  const uint64_t batches = rows / kPartTile + 1;
-  const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / pf) + 1;
-  pa->cap1 = round_g(share1 + share1 / 16 + 8192 + batches * (g - 1) * 5 / 8);
-  const uint64_t batches2 = share1 / kPartTile + kPartG2X;  // batches a coarse slab is scattered in
-  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (g - 1) * 5 / 8);  // 25 % + 256 + padding
-  pa->cap_ovf = rows / 16 + 4096;
-  pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
-  pa->cap1 = pa->sub1 * kPartXcds;
-  pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
-  if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFF0000ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors (and 32-bit tuple indices with look-ahead in pass 3)
-  return true;
-}
-
-constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
-
-template <int LEVEL, typename K>
-static void launch_part_scatter(int tw, dim3 grid, size_t lds, hipStream_t s, const PartArgs& pa) {
-  switch (tw) {
-    case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
-    case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
-    default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
-  }
-}
-
-template <int LEVEL, typename K>
-static const void* part_scatter_kernel(int tw) {
-  switch (tw) {
-    case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 1>);
-    case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 2>);
-    default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 3>);
-  }
-}
-
-// does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
-static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
-  pa->simple_agg = -1;
-  if (p->row_size_quad != 2 || pa->nkeys != 1 || pa->tw > 2) return false;
-  int found = -1;
-  for (int i = 0; i < pa->ntargets; ++i) {
-    const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
-    if (tg.agg == HDK_AGG_ID && tg.slot_width == 0) continue;
-    if (found >= 0) return false;
-    found = i;
-  }
-  if (found < 0) return false;
-  const hdk_hip_target& tg = p->targets[pa->tgt_index[found]];
-  if (tg.slot_width != 8 || tg.slot_off != 8 || tg.arg_is_fp) return false;
-  if (tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_COUNT) return false;
-  if (tg.has_arg && (pa->tgt_arg[found] != 1 || pa->arg[0].kind != HDK_COL_INT)) return false;
-  if (!tg.has_arg && tg.agg != HDK_AGG_COUNT) return false;
-  pa->simple_agg = tg.agg;
-  pa->simple_has_arg = tg.has_arg;
-  pa->simple_skip = tg.skip_null;
-  pa->simple_arg_nullable = tg.arg.nullable;
-  pa->simple_null = tg.null_val;
-  pa->simple_arg_null = tg.arg.null_val;
-  return true;
-}
-
-static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
-                                       PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
-                                       hipStream_t s) {
-  pa.plan = d_plan;
-  pa.kp = kp;
-  const bool k32 = plan->key_width == 4;
-  const size_t tw = static_cast<size_t>(pa.tw);
-  const uint32_t gmask = (1u << pa.g_log2) - 1;
-  const uint32_t p2 = 1u << pa.p2_log2;
-  const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw);
-  const size_t lds2 = part_scatter_lds_bytes(p2, gmask, pa.tw);
-  // pass-1 grid: what is resident, at most one block per batch
-  const void* k1 = k32 ? part_scatter_kernel<1, int32_t>(pa.tw) : part_scatter_kernel<1, int64_t>(pa.tw);
-  unsigned g1 = resident_grid(k1, kPartBlock, lds1, props);
-  const uint64_t tiles = (pa.total_rows + kPartTile - 1) / kPartTile;
-  if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
-  const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
-  const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
-  const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
-  const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
-  const size_t nc = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
-  const size_t bc = nc * sizeof(uint32_t);
-  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  AsyncScratch scratch(s);
-  const hipError_t me = hipMallocAsync(&scratch.p, up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
-  if (me != hipSuccess) {
-    (void)hipGetLastError();
-    scratch.p = nullptr;
-    return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
-  }
-  int8_t* q = static_cast<int8_t*>(scratch.p);
-  pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
-  pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
-  pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
-  pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
-  pa.fill1 = reinterpret_cast<uint32_t*>(q);
-  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride;
-  pa.nspill = pa.fill2 + pa.fine_count;
-  pa.fill_ovf = pa.nspill + pa.fine_count;
-  pa.fill_spill = pa.fill_ovf + 1;
-  pa.fallback = pa.fill_spill + 1;
-  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
-  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
-  // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
-  const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
-  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
-  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
-  if (k32) {
-    launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int32_t>(pa.tw, dim3(g2), lds2, s, pa);
-    if (simple) {
-      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      }
-    } else {
-      hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-    }
-    hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
-  } else {
-    launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int64_t>(pa.tw, dim3(g2), lds2, s, pa);
-    if (simple) {
-      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      }
-    } else {
-      hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-    }
-    hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
-  }
-  // armed fallback: runs only if the scatter passes found the data too skewed for slabs
-  BaseFastArgs bf;
-  match_baseline_fast(plan, &bf);
-  bf.plan = d_plan;
-  bf.kp = kp;
-  bf.entry_count = shape.entry_count;
-  bf.run_if = pa.fallback;
-  launch_baseline_direct(plan, bf, shape.grid, s);
-  HDK_HIP_CHECK(hipGetLastError());
-  return HDK_HIP_OK;  // (`scratch` goes back to the pool here, stream-ordered)
-}
-
-// the shape hdk_scan_project_direct takes (scan_project_fast.h)
-static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
-  if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
-  memset(fa, 0, sizeof(*fa));
-  if (!match_plain_quals(p, fa->q)) return false;
-  fa->nquals = p->num_quals;
-  for (int t = 0; t < p->num_targets; ++t) {
-    const hdk_hip_target& tg = p->targets[t];
-    int c;
-    if (tg.agg != HDK_AGG_ID || !plain_outer_col(p, tg.arg, &c)) return false;
-    const hdk_hip_col& col = p->cols[c];
-    if (col.kind == HDK_COL_FLOAT) return false;
-    fa->t[t].col.buf_idx = col.buf_idx;
-    fa->t[t].col.width = col.width;
-    fa->t[t].col.kind = col.kind;
-    fa->t[t].slot_width = tg.slot_width;
-    fa->t[t].slot_off = tg.slot_off;
-  }
-  fa->ntargets = p->num_targets;
-  fa->columnar = p->output_columnar;
-  fa->row_size_quad = p->row_size_quad;
-  fa->entry_count = p->entry_count;
-  // rows dealt in adjacent pairs (16-byte loads, scan_project_fast.h): every filter column is an 8-byte integer or
-  // double column compared in its own class
-  fa->pairs = fa->nquals > 0;
-  for (int i = 0; i < fa->nquals; ++i) {
-    const ProjFastQual& fq = fa->q[i];
-    if (fq.col.width != 8 || (fq.col.kind != HDK_COL_INT && fq.col.kind != HDK_COL_DOUBLE) || (fq.fp != 0) != (fq.col_fp != 0)) {
-      fa->pairs = 0;
-    }
-  }
-  // columnar target columns: [int64 row positions][target columns, each aligned to 8]
-  size_t off = (static_cast<size_t>(p->entry_count) * 8 + 7) & ~size_t(7);
-  for (int t = 0; t < p->num_targets; ++t) {
-    off = (off + 7) & ~size_t(7);
-    fa->col_off[t] = off;
-    off += static_cast<size_t>(p->entry_count) * p->targets[t].slot_width;
-  }
-  return true;
-}
-
-static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
-                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic) {
-  BaseFastArgs fa;
-  if (!force_generic && match_baseline_fast(plan, &fa)) {
-    fa.plan = d_plan;
-    fa.kp = kp;
-    fa.entry_count = shape.entry_count;
-    launch_baseline_direct(plan, fa, shape.grid, s);
-    HDK_HIP_CHECK(hipGetLastError());
-    return HDK_HIP_OK;
-  }
-  GlobalArgs a;
-  a.plan = d_plan;
-  a.kp = kp;
-  a.entry_count = shape.entry_count;
-  a.rows_per_tile = kGlobalBlock * 4;
-  hipLaunchKernelGGL(hdk_scan_agg_global, dim3(shape.grid), dim3(kGlobalBlock), 0, s, a);
-  HDK_HIP_CHECK(hipGetLastError());
-  return HDK_HIP_OK;
-}
 
 }  // namespace hdk
 
@@ -1797,23 +1292,9 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
              scan_kernel_name(plan, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
                               ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)));
   } else if (s.strategy == STRAT_PROJECT) {
-    ProjFastArgs pf;
-    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
-    if (!generic && match_project_fast(plan, &pf)) {
-      snprintf(out, out_len, "hdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct");
-    } else
-    snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
-                                 : plan->num_joins     ? "hdk_scan_project_join"
-                                                       : "hdk_scan_project");
+    project_describe(plan, ko, out, out_len);
   } else {
-    BaseFastArgs fa;
-    PartArgs part;
-    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
-    if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
-      snprintf(out, out_len, "hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate,hdk_part_overflow,hdk_scan_agg_baseline_direct");
-    } else
-    snprintf(out, out_len, "%s", !generic && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
-                                                                             : "hdk_scan_agg_global");
+    baseline_describe(plan, ko, out, out_len);
   }
   return HDK_HIP_OK;
 }
@@ -1959,21 +1440,27 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_REQUIRE(params[HDK_KP_INIT_AGG_VALS], "HDK_HIP_LAUNCH_INIT_OUTPUT needs INIT_AGG_VALS");
   }
 
-  // the plan is read by the kernels from device memory (wave-uniform scalar loads)
+  // the plan is read by the kernels from device memory (wave-uniform scalar loads); behind it sit the launch's own
+  // interrupt / watchdog words (watch.h): zeros travel with the plan upload, anything else is written by k_arm_watch
+  // on the launch stream.  A PLAN_RESIDENT launch always runs k_arm_watch: its workspace may hold the words of an
+  // earlier launch, and as a captured kernel node it re-arms every replay of the graph.
   hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
-  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_PLAN_RESIDENT))) {
-    HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  LaunchWatch* d_watch = reinterpret_cast<LaunchWatch*>(static_cast<int8_t*>(workspace) + kWatchOffset);
+  const bool plan_resident = ko && (ko->flags & HDK_HIP_LAUNCH_PLAN_RESIDENT);
+  if (!plan_resident) {
+    struct alignas(16) Head {
+      int8_t bytes[kWatchOffset + sizeof(LaunchWatch)];
+    } head;
+    static_assert(sizeof(LaunchWatch) == 16, "LaunchWatch is 16 bytes");
+    memcpy(head.bytes, plan, sizeof(hdk_hip_plan));
+    memset(head.bytes + sizeof(hdk_hip_plan), 0, sizeof(head.bytes) - sizeof(hdk_hip_plan));
+    HDK_HIP_CHECK(hipMemcpyAsync(d_plan, head.bytes, sizeof(head.bytes), hipMemcpyHostToDevice, s));
   }
-
-  // runtime interrupt / dynamic watchdog (watch.h): armed per launch by a one-thread kernel on the launch stream;
-  // launches that ask for neither only pay for it right after one that did (to disarm)
   {
-    static bool armed[16];
     const uint32_t wf = ((ko && (ko->flags & HDK_HIP_LAUNCH_CHECK_INTERRUPT)) ? 1u : 0u) | ((ko && ko->watchdog_ms) ? 2u : 0u);
-    if (wf || armed[device_id & 15]) {
-      hipLaunchKernelGGL(k_arm_watch, dim3(1), dim3(1), 0, s, wf, ko ? ko->watchdog_ms : 0u);
+    if (wf || plan_resident) {
+      hipLaunchKernelGGL(k_arm_watch, dim3(1), dim3(1), 0, s, d_watch, wf, ko ? ko->watchdog_ms : 0u);
       HDK_HIP_CHECK(hipGetLastError());
-      armed[device_id & 15] = wf != 0;
     }
   }
 
@@ -1990,6 +1477,8 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   kp.error_code = reinterpret_cast<int32_t*>(params[HDK_KP_ERROR_CODE]);
   kp.num_tables = reinterpret_cast<const uint32_t*>(params[HDK_KP_NUM_TABLES]);
   kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
+  kp.watch = d_watch;
+  kp.interrupt = device_interrupt_word(device_id);
 
   const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -2034,99 +1523,14 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   }
   if (shape.strategy == STRAT_PROJECT) {
     HDK_REQUIRE(params[HDK_KP_MAX_MATCHED] && params[HDK_KP_TOTAL_MATCHED], "MAX_MATCHED / TOTAL_MATCHED is NULL");
-    ProjArgs pa;
-    pa.plan = d_plan;
-    pa.kp = kp;
-    pa.entry_count = plan->entry_count;
-    ProjFastArgs pf;
-    const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
-    if (!generic && match_project_fast(plan, &pf)) {
-      pf.kp = kp;
-      AsyncScratch counts_mem(s), mask_mem(s);  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
-      HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
-      uint32_t* counts = static_cast<uint32_t*>(counts_mem.p);
-      pf.block_counts = counts;
-      // selection bitmask handed from the counting pass to the writing pass: rows/8 bytes when the caller
-      // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
-      // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
-      pf.sel_mask = nullptr;
-      pf.sel_tiles = 0;
-      if (ko && ko->total_rows) {
-        const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
-        if (hipMallocAsync(&mask_mem.p, tiles * kProjFastBlock, s) == hipSuccess) {
-          pf.sel_mask = static_cast<uint8_t*>(mask_mem.p);
-          pf.sel_tiles = tiles;
-        } else {
-          (void)hipGetLastError();
-          mask_mem.p = nullptr;
-        }
-      }
-      if (pf.pairs) {
-        hipLaunchKernelGGL(hdk_scan_project_count_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
-      } else {
-        hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
-      }
-      hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
-      if (pf.pairs) {
-        hipLaunchKernelGGL(hdk_scan_project_direct_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
-      } else {
-        hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
-      }
-      HDK_HIP_CHECK(hipGetLastError());
-    } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
-      hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
-    } else if (plan->num_joins) {
-      hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);
-    } else {
-      hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlockPlain), 0, s, pa);
-    }
-    HDK_HIP_CHECK(hipGetLastError());
-    st = HDK_HIP_OK;
+    st = launch_project(plan, d_plan, kp, ko, shape, s);
   } else {
-    PartArgs part;
-    if (shape.strategy == STRAT_GLOBAL && !(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) &&
-        match_partitioned(plan, ko, &part)) {
-      part.init_output = init_output;
-      st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
-      if (st == kPartitionedNoScratch) {
-        if (init_output) {
-          st = init_row_wise_output(plan, params, device_id, s);
-          if (st) return st;
-        }
-        st = launch_scan_global(plan, d_plan, kp, shape, s, false);
-      }
-      init_output = false;  // done (fused into pass 3, or just above)
-    } else {
-      if (init_output) {
-        st = init_row_wise_output(plan, params, device_id, s);
-        if (st) return st;
-      }
-      st = launch_scan_global(plan, d_plan, kp, shape, s,
-                              ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)));
-    }
+    st = launch_baseline(plan, d_plan, kp, ko, shape, init_output, props, s);
   }
   if (st) return st;
   if (timed) {
     HDK_HIP_CHECK(hipEventRecord(e1, s));
   }
-  return HDK_HIP_OK;
-}
-
-extern "C" int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value) {
-  hipStream_t main_stream;
-  const int32_t st = device_enter(device_id, nullptr, &main_stream);
-  if (st) return st;
-  static hipStream_t side[16];
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  hipStream_t& ss = side[device_id & 15];
-  if (!ss) {
-    HDK_HIP_CHECK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
-  }
-  // on a stream of its own: the write overtakes the kernels it is meant to stop
-  HDK_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_watch), &value, sizeof(int32_t), offsetof(WatchState, interrupt),
-                                       hipMemcpyHostToDevice, ss));
-  HDK_HIP_CHECK(hipStreamSynchronize(ss));
   return HDK_HIP_OK;
 }
 

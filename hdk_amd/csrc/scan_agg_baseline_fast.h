@@ -47,7 +47,6 @@ struct BaseFastArgs {
   ProjFastQual q[kMaxPlainQuals];
 };
 
-typedef long long __attribute__((ext_vector_type(2))) bf_i64x2;
 
 // g_agg64 with the slot's value already observed (`seen`): skips the pre-check load
 HDK_DEV void g_agg64_seen(int agg, bool fp, bool skip, int64_t nullv, int64_t* slot, int64_t v, int64_t seen) {
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(kBaseFastBlock) void hdk_scan_agg_baseline_direct(B
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];

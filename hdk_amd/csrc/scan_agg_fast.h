@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
   int32_t err = 0;
 
   const uint32_t estride = static_cast<uint32_t>(wpe) * rep;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   // the whole scan twice in the code, once per value of mask_mode: inside the row body the flag is a compile-time constant
   auto scan = [&](auto mask_tag) {
   constexpr bool MASK = decltype(mask_tag)::value;

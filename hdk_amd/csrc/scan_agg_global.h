@@ -137,7 +137,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];

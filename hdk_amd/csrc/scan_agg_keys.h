@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(Ke
   constexpr uint32_t kFoldEvery = (1u << 31) / static_cast<uint32_t>(kTileRows);
 
   int64_t tile = blockIdx.x;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];

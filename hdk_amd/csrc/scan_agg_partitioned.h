@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
           kind = 2;
           if (static_cast<uint64_t>(obase) + (n - nfit) > a.cap_ovf) {
             kind = 3;
-            atomicExch(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel
+            atomicMax(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel (2 = interrupted sticks)
           }
         }
       }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   if (LEVEL == 1) {
     const uint64_t nfrag = *a.kp.num_fragments;
     const uint32_t ntab = *a.kp.num_tables;
-    const Watch watch = watch_begin();
+    const Watch watch = watch_begin(a.kp);
     int64_t tile = blockIdx.x;
     int64_t frag_tile_begin = 0;
     for (uint64_t f = 0; f < nfrag; ++f) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
           if (watch.flags) {
             if (const int32_t w_ = watch_poll(watch)) {  // interrupt / watchdog: the launch ends with that error
               record_error(a.kp.error_code, w_);
-              atomicExch(a.fallback, 2u);  // the later passes return at once; the armed atomics kernel runs only for 1
+              atomicMax(a.fallback, 2u);  // the later passes return at once; the armed atomics kernel runs only for 1
               stop = 2;
             }
           }

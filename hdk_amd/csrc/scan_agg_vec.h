@@ -82,7 +82,7 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   int32_t err = 0;
 
   int64_t tile = blockIdx.x;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];

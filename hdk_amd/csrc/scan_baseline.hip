@@ -1,0 +1,452 @@
+// scan_baseline.hip -- open-addressing group-by strategies: the radix-partitioned passes (scan_agg_partitioned.h), the
+// specialised global-atomics kernel (scan_agg_baseline_fast.h) and the general one (scan_agg_global.h), with their
+// matchers.  A translation unit of its own (scan_agg.hip holds the API and the LDS strategies): the kernels of one
+// strategy family are compiled together and nothing else.
+#include "host_match.h"
+#include "scan_agg_baseline_fast.h"
+#include "scan_agg_global.h"
+#include "scan_agg_partitioned.h"
+
+namespace hdk {
+
+static const void* baseline_direct_kernel(const hdk_hip_plan* p) {
+  if (p->key_width == 4) {
+    return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 2>)
+                             : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int32_t, 1>);
+  }
+  return p->key_count == 2 ? reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 2>)
+                           : reinterpret_cast<const void*>(hdk_scan_agg_baseline_direct<int64_t, 1>);
+}
+
+static void launch_baseline_direct(const hdk_hip_plan* p, const BaseFastArgs& fa, unsigned grid, hipStream_t s) {
+  if (p->key_width == 4) {
+    if (p->key_count == 2) {
+      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+    } else {
+      hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int32_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+    }
+  } else if (p->key_count == 2) {
+    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 2>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+  } else {
+    hipLaunchKernelGGL((hdk_scan_agg_baseline_direct<int64_t, 1>), dim3(grid), dim3(kBaseFastBlock), 0, s, fa);
+  }
+}
+
+// the shape hdk_scan_agg_baseline_direct takes (scan_agg_baseline_fast.h)
+static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
+  if (p->query_kind != HDK_Q_BASELINE_HASH || p->output_columnar || p->num_joins || p->key_count < 1 ||
+      p->key_count > 2) {
+    return false;
+  }
+  int kc;
+  if (!plain_outer_col(p, p->keys[0], &kc) || p->cols[kc].kind != HDK_COL_INT) return false;
+  memset(fa, 0, sizeof(*fa));
+  fa->key_buf_idx = p->cols[kc].buf_idx;
+  fa->key_width = p->cols[kc].width;
+  fa->key_kind = p->cols[kc].kind;
+  fa->nkeys = p->key_count;
+  if (p->key_count == 2) {
+    int kc2;
+    if (!plain_outer_col(p, p->keys[1], &kc2) || p->cols[kc2].kind != HDK_COL_INT) return false;
+    fa->key2_buf_idx = p->cols[kc2].buf_idx;
+    fa->key2_width = p->cols[kc2].width;
+    fa->key2_kind = p->cols[kc2].kind;
+  }
+  if (!match_plain_quals(p, fa->q)) return false;
+  fa->nquals = p->num_quals;
+  int n = 0;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_ID) {
+      if (tg.slot_width != 0) return false;  // (perfect-hash style key slots: generic kernel)
+      continue;
+    }
+    if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;  // float accumulators: generic kernel
+    BaseFastTarget ft;
+    ft.target = t;
+    ft.buf_idx = -1;
+    ft.width = 8;
+    ft.kind = HDK_COL_INT;
+    if (tg.has_arg) {
+      int c;
+      if (!plain_outer_col(p, tg.arg, &c)) return false;
+      ft.buf_idx = p->cols[c].buf_idx;
+      ft.width = p->cols[c].width;
+      ft.kind = p->cols[c].kind;
+    } else if (tg.agg != HDK_AGG_COUNT) {
+      return false;
+    }
+    fa->tg[n++] = ft;
+  }
+  fa->ntargets = n;
+  return true;
+}
+
+// ---- radix-partitioned open-addressing group-by (scan_agg_partitioned.h) -------------------------------
+// Taken for the hdk_scan_agg_baseline_direct shape when the table is large enough that the memory-side
+// atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
+static uint32_t pow2_ceil_log2(uint64_t x) {
+  uint32_t l = 0;
+  while ((1ull << l) < x) ++l;
+  return l;
+}
+
+// unsigned 32-bit division by an invariant divisor d >= 2, round-up method in its branch-free form:
+//   t = mulhi(magic, n);  q = (((n - t) >> 1) + t) >> shift        (exact for every 32-bit n)
+static void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  uint32_t log2d = 31;
+  while (!(d >> log2d)) --log2d;
+  if ((d & (d - 1)) == 0) {
+    *magic = 0;
+    *shift = log2d - 1;
+    return;
+  }
+  const uint64_t two_k = 1ull << (32 + log2d);
+  const uint64_t m = two_k / d;
+  const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
+  uint32_t m32 = static_cast<uint32_t>(m) * 2u;
+  const uint32_t twice_rem = rem * 2u;
+  if (twice_rem >= d || twice_rem < rem) m32 += 1;
+  *magic = m32 + 1u;
+  *shift = log2d;
+}
+
+// key_hash (QE/GroupByRuntime.cpp:24-29: MurmurHash3 of the packed key, seed 0) of the key (k, 0) on the host, for the
+// padding keys of the partitioned group-by; same word order as key_hash_dev (baseline_table.h)
+template <typename K>
+static uint32_t host_key_hash(int64_t k, int nkeys) {
+  uint32_t h1 = 0;
+  auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+  auto mix = [&](uint32_t k1) {
+    k1 *= 0xcc9e2d51u;
+    k1 = rotl(k1, 15);
+    k1 *= 0x1b873593u;
+    h1 ^= k1;
+    h1 = rotl(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64u;
+  };
+  for (int i = 0; i < nkeys; ++i) {
+    const uint64_t v = i == 0 ? static_cast<uint64_t>(k) : 0;
+    mix(static_cast<uint32_t>(v));
+    if (sizeof(K) == 8) mix(static_cast<uint32_t>(v >> 32));
+  }
+  h1 ^= static_cast<uint32_t>(nkeys * sizeof(K));
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6bu;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35u;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
+static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
+  BaseFastArgs bf;
+  if (!match_baseline_fast(p, &bf)) return false;
+  if (!ko || ko->total_rows == 0) return false;
+  const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
+  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
+  if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
+  if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
+  memset(pa, 0, sizeof(*pa));
+  pa->key_buf_idx = bf.key_buf_idx;
+  pa->key_width = bf.key_width;
+  pa->key_kind = bf.key_kind;
+  pa->nkeys = bf.nkeys;
+  pa->key2_buf_idx = bf.key2_buf_idx;
+  pa->key2_width = bf.key2_width;
+  pa->key2_kind = bf.key2_kind;
+  pa->nquals = bf.nquals;
+  for (int i = 0; i < bf.nquals; ++i) pa->q[i] = bf.q[i];
+  for (int t = 0; t < bf.ntargets; ++t) {
+    const BaseFastTarget& ft = bf.tg[t];
+    int word = 0;
+    if (ft.buf_idx >= 0) {
+      for (int k = 0; k < pa->nargs; ++k) {
+        if (pa->arg[k].buf_idx == ft.buf_idx) word = 1 + k;
+      }
+      if (!word) {
+        if (pa->nkeys + pa->nargs == kPartMaxTW) return false;  // the tuple holds 3 words: keys + argument columns
+        pa->arg[pa->nargs] = ft;
+        word = 1 + pa->nargs++;
+      }
+    }
+    pa->tgt_index[t] = ft.target;
+    pa->tgt_arg[t] = word ? word - 1 + pa->nkeys : 0;  // absolute tuple word of the argument
+  }
+  pa->ntargets = bf.ntargets;
+  pa->tw = pa->nkeys + pa->nargs;
+  pa->all_wide = pa->key_width == 8 && pa->key_kind == HDK_COL_INT && (pa->nkeys < 2 || (pa->key2_width == 8 && pa->key2_kind == HDK_COL_INT));
+  for (int k = 0; k < pa->nargs; ++k) {
+    if (pa->arg[k].width != 8 || (pa->arg[k].kind != HDK_COL_INT && pa->arg[k].kind != HDK_COL_DOUBLE)) pa->all_wide = 0;
+  }
+  pa->entry_count = p->entry_count;
+  magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
+  // regions: as many entries as fit the LDS image
+  pa->slots = kPartLdsBytes / (p->row_size_quad * 8);
+  if (pa->slots < 16 || pa->slots >= p->entry_count) return false;
+  magic_u32(pa->slots, &pa->reg_magic, &pa->reg_shift);
+  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + pa->slots - 1) / pa->slots;
+  // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch)
+  uint32_t p2_log2 = (pow2_ceil_log2(pf) + 1) / 2;
+  while (((pf + (1ull << p2_log2) - 1) >> p2_log2) > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
+  if ((1u << p2_log2) > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 64 K regions: a third level would be needed
+  pa->fine_count = static_cast<uint32_t>(pf);
+  pa->p2_log2 = p2_log2;
+  pa->p1 = static_cast<uint32_t>((pf + (1ull << p2_log2) - 1) >> p2_log2);
+  // whole 128-byte lines: runs of G tuples (8 of 16 B; 16 of 8 or 24 B), padded with keys of another partition --
+  // which needs two coarse partitions (a table this small gains nothing from alignment anyway)
+  // Measured at the C5 shape (256 M rows): rounding runs up to whole lines costs more than it gains -- the padding
+  // is 18 % of pass 1's output and compounds to 44 % of pass 3's input, and its staging slots cost the third block
+  // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
+  // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements.
+  pa->g_log2 = 0;
+  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = pa->p1 < 2 ? 0 : atoi(e);
+  if (pa->g_log2) {
+    int found = 0;
+    for (int64_t k = 1; k < 4096 && found < 2; ++k) {
+      const uint32_t h = p->key_width == 4 ? host_key_hash<int32_t>(k, pa->nkeys) : host_key_hash<int64_t>(k, pa->nkeys);
+      const uint32_t c = static_cast<uint32_t>((h % p->entry_count) / pa->slots) >> p2_log2;
+      if (found == 0 || c != pa->pad_coarse[0]) {
+        // (tuples of 4-byte keys carry their home in the upper half of word 0: part_pack_home)
+        pa->pad_key[found] = p->key_width == 4 ? static_cast<int64_t>((static_cast<uint64_t>(h % p->entry_count) << 32) | static_cast<uint32_t>(k)) : k;
+        pa->pad_coarse[found] = c;
+        ++found;
+      }
+    }
+    if (found < 2) pa->g_log2 = 0;
+  }
+  const uint64_t g = 1ull << pa->g_log2;
+  const uint64_t rows = ko->total_rows;
+  pa->total_rows = rows;
+  auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
+  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack, plus the
+  // padding: on average (G - 1) / 2 slots per bin and batch
+  const uint64_t batches = rows / kPartTile + 1;
+  const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / pf) + 1;
+  pa->cap1 = round_g(share1 + share1 / 16 + 8192 + batches * (g - 1) * 5 / 8);
+  const uint64_t batches2 = share1 / kPartTile + kPartG2X;  // batches a coarse slab is scattered in
+  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (g - 1) * 5 / 8);  // 25 % + 256 + padding
+  pa->cap_ovf = rows / 16 + 4096;
+  pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
+  pa->cap1 = pa->sub1 * kPartXcds;
+  pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
+  if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFF0000ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors (and 32-bit tuple indices with look-ahead in pass 3)
+  return true;
+}
+
+constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
+
+template <int LEVEL, typename K>
+static void launch_part_scatter(int tw, dim3 grid, size_t lds, hipStream_t s, const PartArgs& pa) {
+  switch (tw) {
+    case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
+    case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
+    default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
+  }
+}
+
+template <int LEVEL, typename K>
+static const void* part_scatter_kernel(int tw) {
+  switch (tw) {
+    case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 1>);
+    case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 2>);
+    default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 3>);
+  }
+}
+
+// does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
+static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
+  pa->simple_agg = -1;
+  if (p->row_size_quad != 2 || pa->nkeys != 1 || pa->tw > 2) return false;
+  int found = -1;
+  for (int i = 0; i < pa->ntargets; ++i) {
+    const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
+    if (tg.agg == HDK_AGG_ID && tg.slot_width == 0) continue;
+    if (found >= 0) return false;
+    found = i;
+  }
+  if (found < 0) return false;
+  const hdk_hip_target& tg = p->targets[pa->tgt_index[found]];
+  if (tg.slot_width != 8 || tg.slot_off != 8 || tg.arg_is_fp) return false;
+  if (tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_COUNT) return false;
+  if (tg.has_arg && (pa->tgt_arg[found] != 1 || pa->arg[0].kind != HDK_COL_INT)) return false;
+  if (!tg.has_arg && tg.agg != HDK_AGG_COUNT) return false;
+  pa->simple_agg = tg.agg;
+  pa->simple_has_arg = tg.has_arg;
+  pa->simple_skip = tg.skip_null;
+  pa->simple_arg_nullable = tg.arg.nullable;
+  pa->simple_null = tg.null_val;
+  pa->simple_arg_null = tg.arg.null_val;
+  return true;
+}
+
+static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                       PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
+                                       hipStream_t s) {
+  pa.plan = d_plan;
+  pa.kp = kp;
+  const bool k32 = plan->key_width == 4;
+  const size_t tw = static_cast<size_t>(pa.tw);
+  const uint32_t gmask = (1u << pa.g_log2) - 1;
+  const uint32_t p2 = 1u << pa.p2_log2;
+  const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw);
+  const size_t lds2 = part_scatter_lds_bytes(p2, gmask, pa.tw);
+  // pass-1 grid: what is resident, at most one block per batch
+  const void* k1 = k32 ? part_scatter_kernel<1, int32_t>(pa.tw) : part_scatter_kernel<1, int64_t>(pa.tw);
+  unsigned g1 = resident_grid(k1, kPartBlock, lds1, props);
+  const uint64_t tiles = (pa.total_rows + kPartTile - 1) / kPartTile;
+  if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
+  const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
+  const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
+  const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
+  const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
+  const size_t nc = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
+  const size_t bc = nc * sizeof(uint32_t);
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  AsyncScratch scratch(s);
+  const hipError_t me = hipMallocAsync(&scratch.p, up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
+  if (me != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return kPartitionedNoScratch;  // not an error: the caller takes the global-atomics kernel instead
+  }
+  int8_t* q = static_cast<int8_t*>(scratch.p);
+  pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
+  pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
+  pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
+  pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
+  pa.fill1 = reinterpret_cast<uint32_t*>(q);
+  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride;
+  pa.nspill = pa.fill2 + pa.fine_count;
+  pa.fill_ovf = pa.nspill + pa.fine_count;
+  pa.fill_spill = pa.fill_ovf + 1;
+  pa.fallback = pa.fill_spill + 1;
+  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
+  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
+  // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
+  const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
+  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
+  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
+  if (k32) {
+    launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
+    launch_part_scatter<2, int32_t>(pa.tw, dim3(g2), lds2, s, pa);
+    if (simple) {
+      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      }
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    }
+    hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  } else {
+    launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
+    launch_part_scatter<2, int64_t>(pa.tw, dim3(g2), lds2, s, pa);
+    if (simple) {
+      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      } else {
+        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+      }
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
+    }
+    hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  }
+  // armed fallback: runs only if the scatter passes found the data too skewed for slabs
+  BaseFastArgs bf;
+  match_baseline_fast(plan, &bf);
+  bf.plan = d_plan;
+  bf.kp = kp;
+  bf.entry_count = shape.entry_count;
+  bf.run_if = pa.fallback;
+  launch_baseline_direct(plan, bf, shape.grid, s);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;  // (`scratch` goes back to the pool here, stream-ordered)
+}
+
+static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
+                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic) {
+  BaseFastArgs fa;
+  if (!force_generic && match_baseline_fast(plan, &fa)) {
+    fa.plan = d_plan;
+    fa.kp = kp;
+    fa.entry_count = shape.entry_count;
+    launch_baseline_direct(plan, fa, shape.grid, s);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
+  }
+  GlobalArgs a;
+  a.plan = d_plan;
+  a.kp = kp;
+  a.entry_count = shape.entry_count;
+  a.rows_per_tile = kGlobalBlock * 4;
+  hipLaunchKernelGGL(hdk_scan_agg_global, dim3(shape.grid), dim3(kGlobalBlock), 0, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
+  BaseFastArgs bf;
+  const void* k;
+  int block;
+  if (!launch_forces_generic(ko) && match_baseline_fast(p, &bf)) {
+    k = baseline_direct_kernel(p);
+    block = kBaseFastBlock;
+  } else {
+    k = reinterpret_cast<const void*>(hdk_scan_agg_global);
+    block = kGlobalBlock;
+  }
+  // random atomics make block run times uneven: 4 waves of blocks rebalance the tail
+  // (C5 shape: 1792 blocks 21.5 ms, 3584 18.8 ms, 7168 17.6 ms)
+  return resident_grid(k, block, 0, props) * 4;
+}
+
+void baseline_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
+  BaseFastArgs fa;
+  PartArgs part;
+  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
+    snprintf(out, out_len, "hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate,hdk_part_overflow,hdk_scan_agg_baseline_direct");
+  } else {
+    snprintf(out, out_len, "%s", !launch_forces_generic(ko) && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
+                                                                                               : "hdk_scan_agg_global");
+  }
+}
+
+// HDK_HIP_LAUNCH_INIT_OUTPUT for the strategies that do not fuse it: the init kernel, on the launch stream
+static int32_t init_row_wise_output(const hdk_hip_plan* plan, const KernParams& kp, const hdk_hip_device_properties* props,
+                                    hipStream_t s) {
+  const uint32_t key_count = plan->keyless ? 0u : static_cast<uint32_t>(plan->key_count);
+  return launch_init_row_wise_indirect(kp.groupby_buf, kp.init_agg_vals, plan->entry_count, key_count,
+                                       static_cast<uint32_t>(plan->key_width), plan->row_size_quad, plan->keyless, props, s);
+}
+
+int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                        const hdk_hip_kernel_options* ko, const LaunchShape& shape, bool init_output,
+                        const hdk_hip_device_properties* props, hipStream_t s) {
+  PartArgs part;
+  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
+    part.init_output = init_output;
+    int32_t st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
+    if (st == kPartitionedNoScratch) {
+      if (init_output) {
+        st = init_row_wise_output(plan, kp, props, s);
+        if (st) return st;
+      }
+      st = launch_scan_global(plan, d_plan, kp, shape, s, false);
+    }
+    return st;
+  }
+  if (init_output) {
+    const int32_t st = init_row_wise_output(plan, kp, props, s);
+    if (st) return st;
+  }
+  return launch_scan_global(plan, d_plan, kp, shape, s, launch_forces_generic(ko));
+}
+
+}  // namespace hdk

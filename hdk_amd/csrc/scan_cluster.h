@@ -19,7 +19,6 @@
 //   then                          the plan's ordinary kernel runs over those fragments, unchanged.
 #pragma once
 #include "device_common.h"
-#include "scan_agg_baseline_fast.h"  // bf_i64x2
 
 namespace hdk {
 

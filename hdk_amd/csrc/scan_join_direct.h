@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kJdBlock) void hdk_join_agg_direct(JoinDirectArgs a
     acc.nulls[t] = 0;
   }
   int32_t err = 0;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   constexpr int64_t kTileRows = static_cast<int64_t>(kJdBlock) * VR;
   if (!a.clustered) {
     const uint64_t nfrag = *a.kp.num_fragments;

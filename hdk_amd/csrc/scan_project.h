@@ -62,7 +62,7 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
   int32_t err = 0;
   int32_t slots_err = 0;
   __shared__ int32_t s_watch;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
 
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
@@ -225,7 +225,7 @@ extern "C" __global__ __launch_bounds__(kProjBlock) void hdk_scan_project_scalar
   int32_t slots_err = 0;
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;

@@ -1,0 +1,131 @@
+// scan_project.hip -- filter/project strategies (Projection plans): the two-pass direct kernels
+// (scan_project_fast.h), the batched interpreter with and without join probes and the row-at-a-time one
+// (scan_project.h), with their matcher.  A translation unit of its own (see host_match.h).
+#include "host_match.h"
+#include "scan_project.h"
+#include "scan_project_fast.h"
+
+namespace hdk {
+
+// the shape hdk_scan_project_direct takes (scan_project_fast.h)
+static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
+  if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
+  memset(fa, 0, sizeof(*fa));
+  if (!match_plain_quals(p, fa->q)) return false;
+  fa->nquals = p->num_quals;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    int c;
+    if (tg.agg != HDK_AGG_ID || !plain_outer_col(p, tg.arg, &c)) return false;
+    const hdk_hip_col& col = p->cols[c];
+    if (col.kind == HDK_COL_FLOAT) return false;
+    fa->t[t].col.buf_idx = col.buf_idx;
+    fa->t[t].col.width = col.width;
+    fa->t[t].col.kind = col.kind;
+    fa->t[t].slot_width = tg.slot_width;
+    fa->t[t].slot_off = tg.slot_off;
+  }
+  fa->ntargets = p->num_targets;
+  fa->columnar = p->output_columnar;
+  fa->row_size_quad = p->row_size_quad;
+  fa->entry_count = p->entry_count;
+  // rows dealt in adjacent pairs (16-byte loads, scan_project_fast.h): every filter column is an 8-byte integer or
+  // double column compared in its own class
+  fa->pairs = fa->nquals > 0;
+  for (int i = 0; i < fa->nquals; ++i) {
+    const ProjFastQual& fq = fa->q[i];
+    if (fq.col.width != 8 || (fq.col.kind != HDK_COL_INT && fq.col.kind != HDK_COL_DOUBLE) || (fq.fp != 0) != (fq.col_fp != 0)) {
+      fa->pairs = 0;
+    }
+  }
+  // columnar target columns: [int64 row positions][target columns, each aligned to 8]
+  size_t off = (static_cast<size_t>(p->entry_count) * 8 + 7) & ~size_t(7);
+  for (int t = 0; t < p->num_targets; ++t) {
+    off = (off + 7) & ~size_t(7);
+    fa->col_off[t] = off;
+    off += static_cast<size_t>(p->entry_count) * p->targets[t].slot_width;
+  }
+  return true;
+}
+
+uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
+  const bool scalar = (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) || needs_join_loops(p);
+  const void* k;
+  int block;
+  ProjFastArgs pf;
+  if (!launch_forces_generic(ko) && match_project_fast(p, &pf)) {
+    k = reinterpret_cast<const void*>(hdk_scan_project_direct);
+    block = kProjFastBlock;
+  } else {
+    k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
+               : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
+                               : reinterpret_cast<const void*>(hdk_scan_project));
+    block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
+  }
+  return resident_grid(k, block, 0, props);
+}
+
+void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
+  ProjFastArgs pf;
+  if (!launch_forces_generic(ko) && match_project_fast(plan, &pf)) {
+    snprintf(out, out_len, "hdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct");
+  } else {
+    snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
+                                 : plan->num_joins     ? "hdk_scan_project_join"
+                                                       : "hdk_scan_project");
+  }
+}
+
+int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, hipStream_t s) {
+  ProjArgs pa;
+  pa.plan = d_plan;
+  pa.kp = kp;
+  pa.entry_count = plan->entry_count;
+  ProjFastArgs pf;
+  const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
+  if (!generic && match_project_fast(plan, &pf)) {
+    pf.kp = kp;
+    AsyncScratch counts_mem(s), mask_mem(s);  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
+    HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
+    uint32_t* counts = static_cast<uint32_t*>(counts_mem.p);
+    pf.block_counts = counts;
+    // selection bitmask handed from the counting pass to the writing pass: rows/8 bytes when the caller
+    // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
+    // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
+    pf.sel_mask = nullptr;
+    pf.sel_tiles = 0;
+    if (ko && ko->total_rows) {
+      const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
+      if (hipMallocAsync(&mask_mem.p, tiles * kProjFastBlock, s) == hipSuccess) {
+        pf.sel_mask = static_cast<uint8_t*>(mask_mem.p);
+        pf.sel_tiles = tiles;
+      } else {
+        (void)hipGetLastError();
+        mask_mem.p = nullptr;
+      }
+    }
+    if (pf.pairs) {
+      hipLaunchKernelGGL(hdk_scan_project_count_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+    }
+    hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
+    if (pf.pairs) {
+      hipLaunchKernelGGL(hdk_scan_project_direct_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+    } else {
+      hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
+    }
+    HDK_HIP_CHECK(hipGetLastError());
+  } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
+    hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+  } else if (plan->num_joins) {
+    hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);
+  } else {
+    hipLaunchKernelGGL(hdk_scan_project, dim3(shape.grid), dim3(kProjBlockPlain), 0, s, pa);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+}  // namespace hdk

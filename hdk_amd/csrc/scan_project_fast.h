@@ -212,7 +212,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   __shared__ int32_t s_watch;
-  const Watch watch = watch_begin();
+  const Watch watch = watch_begin(a.kp);
   for (uint64_t f = 0; f < nfrag; ++f) {
     const int64_t nrows = a.kp.num_rows[f * ntab];
     const int64_t ntiles = (nrows + kTileRows - 1) / kTileRows;

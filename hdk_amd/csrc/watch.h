@@ -2,38 +2,44 @@
 //
 // Reference: the GPU runtime keeps a `runtime_interrupt_flag` and a cycle budget in module globals, the row loop
 // polls them (check_interrupt / dynamic_watchdog, QE/cuda_mapd_rt.cu:105-148; host side QE/GpuInterrupt.cpp,
-// QE/DynamicWatchdog.cpp:36-84) and the query ends with ERR_INTERRUPTED / ERR_OUT_OF_TIME.  Here the state is one
-// device global, armed per launch by a one-thread kernel on the launch stream (hdk_hip_launch: flags
-// HDK_HIP_LAUNCH_CHECK_INTERRUPT, hdk_hip_kernel_options::watchdog_ms) and flipped from the host by
-// hdk_hip_set_interrupt on a stream of its own.  Kernels poll once per tile; a launch that asked for neither pays
-// one register test per tile.
+// QE/DynamicWatchdog.cpp:36-84) and the query ends with ERR_INTERRUPTED / ERR_OUT_OF_TIME.  The reference keeps that
+// state per module, i.e. per query; here `flags` and `deadline` belong to the LAUNCH: they live in the head of the
+// launch's workspace, right behind the plan copy (LaunchWatch at kWatchOffset), written on the launch stream -- zeros
+// together with the plan upload, or by the one-thread kernel k_arm_watch when the launch asks for the interrupt poll
+// (HDK_HIP_LAUNCH_CHECK_INTERRUPT) or a time budget (hdk_hip_kernel_options::watchdog_ms), and always for
+// PLAN_RESIDENT launches (whose workspace may still hold the words of an earlier launch; a kernel node when the
+// launch is captured into a hipGraph, so that a replay re-arms itself).  Launches on other streams or with other
+// workspaces neither see nor move them.  Only the `interrupt` word is per device (Executor::interrupt stops whatever
+// runs there); hdk_hip_set_interrupt flips it from a stream of its own.  Kernels poll once per tile; a launch that
+// asked for neither pays one register test per tile.
 #pragma once
 #include "device_common.h"
 
 namespace hdk {
 
-struct WatchState {
-  int32_t interrupt;  // != 0: stop (hdk_hip_set_interrupt)
-  uint32_t flags;     // bit 0: poll `interrupt`; bit 1: poll the deadline
-  uint64_t deadline;  // s_memrealtime ticks (100 MHz)
+struct LaunchWatch {   // per launch, at kWatchOffset of its workspace
+  uint32_t flags;      // bit 0: poll `interrupt`; bit 1: poll the deadline
+  uint32_t pad_;
+  uint64_t deadline;   // s_memrealtime ticks (100 MHz)
 };
-__device__ WatchState g_watch;
 
 struct Watch {
   uint32_t flags;
   uint64_t deadline;
+  const int32_t* interrupt;  // the device's interrupt word (runtime.hip: device_interrupt_word)
 };
 
-HDK_DEV Watch watch_begin() {
+HDK_DEV Watch watch_begin(const KernParams& kp) {
   Watch w;
-  w.flags = g_watch.flags;
-  w.deadline = g_watch.deadline;
+  w.flags = kp.watch->flags;
+  w.deadline = kp.watch->deadline;
+  w.interrupt = kp.interrupt;
   return w;
 }
 
 // 0, or the error the launch has to end with.  Every lane reads the same words.
 HDK_DEV int32_t watch_poll(const Watch& w) {
-  if ((w.flags & 1u) && __hip_atomic_load(&g_watch.interrupt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+  if ((w.flags & 1u) && __hip_atomic_load(w.interrupt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     return HDK_HIP_ERR_INTERRUPTED;
   }
   if ((w.flags & 2u) && __builtin_amdgcn_s_memrealtime() > w.deadline) {
@@ -64,10 +70,5 @@ HDK_DEV int32_t watch_poll_block(const Watch& w, int32_t* s_flag) {
       break;                                    \
     }                                           \
   }
-
-__global__ void k_arm_watch(uint32_t flags, uint32_t watchdog_ms) {
-  g_watch.flags = flags;
-  g_watch.deadline = __builtin_amdgcn_s_memrealtime() + static_cast<uint64_t>(watchdog_ms) * 100000ull;
-}
 
 }  // namespace hdk

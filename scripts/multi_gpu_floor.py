@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""What ONE rank of an 8-GPU job does per step, measured on one device (no multi-GPU box is available to the
+build; the wire is the only piece left out).
+
+  part A  perfect-hash / non-grouped configs (c2, q1..q4): rank 0 of 8 holds fragments 0, 8, 16, 24 of the 1 B-row
+          table (128 M rows).  Step = init + scan + finalize + [all-gather emulated by a device copy of the partial
+          into 8 slots] + fold of 7 partials.  Reported: GPU ms per step (HIP events), host enqueue time per step,
+          and the same with the plan resident in the workspace (HDK_HIP_LAUNCH_PLAN_RESIDENT).
+  part B  C5 (open addressing), the table-exchange merge of round 2: every rank aggregates its shard into a
+          200 M-entry table, splits the non-empty entries by owner, owners re-insert.  The eight ranks are run one
+          after another; owner 0's inbox is assembled from their segments.  Reported per piece: shard scan,
+          partition count (+ host sync), partition scatter, owner-table init, owner re-insert.
+
+    python scripts/multi_gpu_floor.py [--only a,b] [--world 8] [--steps 20]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def ev_ms(torch, stream, fn, reps=1):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def part_a(args, mgr):
+    import torch
+    from hdk_amd import _abi as A
+    from hdk_amd import distributed as D
+    from hdk_amd._lib import check, lib
+    from workloads import CONFIGS, Workload, fragment_rows
+    from bench import c2_numpy_generator
+    L = lib()
+    world, dev = args.world, 0
+    out = {}
+    for name in [c for c in ("c2", "q1", "q2", "q3", "q4") if c in args.configs]:
+        rows = CONFIGS[name][0]
+        nfrag = len(fragment_rows(rows))
+        frag_ids = D.shard_fragments(nfrag, world, 0)
+        w = Workload(name, rows, dev, mgr, frag_ids=frag_ids,
+                     generators=c2_numpy_generator(torch, torch.device("cuda", dev), 0) if name == "c2" else None)
+        cp = w.compiled
+        quads = max(cp.buffer_quads, 1)
+        ts = torch.cuda.Stream(device=dev)
+        h = ts.cuda_stream
+        out_t = torch.empty(quads, dtype=torch.int64, device="cuda")
+        gathered = torch.empty(world * quads, dtype=torch.int64, device="cuda")
+        d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        iv = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
+        that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
+        counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
+        res = {}
+        for label, flags in (("plan_uploaded", 0), ("plan_resident", A.LAUNCH_PLAN_RESIDENT)):
+            step = w.ex.prepare(cp, w.frag_ids, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
+            if flags:
+                step.enqueue(h)  # the first launch puts the plan into the workspace head
+                torch.cuda.synchronize()
+                step.ko.flags |= flags
+
+            def one():
+                step.enqueue(h)
+                gathered.view(world, quads).copy_(out_t)  # stands in for all_gather_into_tensor
+                check(L.hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
+                                               world - 1, iv.ctypes.data, d_err.data_ptr(), dev, h))
+
+            with torch.cuda.stream(ts):
+                for _ in range(3):
+                    one()
+                torch.cuda.synchronize()
+                n_ev = C.c_int32(0)
+                check(L.hdk_hip_collect_scan_times(dev, None, 0, C.byref(n_ev)))
+                t0 = time.perf_counter()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
+                for _ in range(args.steps):
+                    one()
+                e1.record(ts)
+                t_enq = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                t_wall = time.perf_counter() - t0
+            buf = (C.c_float * args.steps)()
+            check(L.hdk_hip_collect_scan_times(dev, buf, args.steps, C.byref(n_ev)))
+            scan = float(np.mean([buf[i] for i in range(min(n_ev.value, args.steps))]))
+            res[label] = {"gpu_ms_per_step": e0.elapsed_time(e1) / args.steps, "scan_kernel_ms": scan,
+                          "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "wall_ms_per_step": t_wall / args.steps * 1e3}
+            step.free()
+        res["rows_per_rank"] = w.local_rows
+        res["projected_rows_per_s_at_8_gpus_wire_excluded"] = rows / (res["plan_resident"]["wall_ms_per_step"] * 1e-3)
+        out[name] = res
+        print(json.dumps({name: res}), flush=True)
+        del w, step
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def part_b(args, mgr):
+    import torch
+    from hdk_amd import _abi as A
+    from hdk_amd import distributed as D
+    from hdk_amd._lib import check, lib
+    from workloads import Workload, fragment_rows
+    L = lib()
+    world, dev = args.world, 0
+    rows = 1_000_000_000
+    nfrag = len(fragment_rows(rows))
+    ts = torch.cuda.Stream(device=dev)
+    h = ts.cuda_stream
+    segs, seg_counts, per_rank = [], [], []
+    cp = None
+    for r in range(world if not args.one_rank else 1):
+        w = Workload("c5", rows, dev, mgr, frag_ids=D.shard_fragments(nfrag, world, r))
+        cp = w.compiled
+        quads = cp.buffer_quads
+        out_t = torch.empty(quads, dtype=torch.int64, device="cuda")
+        step = w.ex.prepare(cp, w.frag_ids, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
+        with torch.cuda.stream(ts):
+            step.enqueue(h)
+            torch.cuda.synchronize()
+            scan = ev_ms(torch, ts, lambda: step.enqueue(h), 3)
+            iv = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
+            counts = (C.c_uint32 * world)()
+            t0 = time.perf_counter()
+            check(L.hdk_hip_partition_baseline_count(C.byref(cp.plan), out_t.data_ptr(), cp.entry_count, iv.ctypes.data,
+                                                     world, counts, dev, h))
+            t_count = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            send, cnt = D.partition_baseline_on_device(cp, out_t, world, dev, h)
+            torch.cuda.synchronize()
+            t_part_both = (time.perf_counter() - t0) * 1e3
+        q = [D.baseline_table_quads(cp, int(c)) for c in cnt]
+        offs = np.concatenate([[0], np.cumsum(q)])
+        segs.append(send[int(offs[0]):int(offs[1])].clone())
+        seg_counts.append(int(cnt[0]))
+        per_rank.append({"rank": r, "rows": w.local_rows, "shard_scan_ms": scan, "groups": int(cnt.sum()),
+                         "partition_count_with_host_sync_ms": t_count, "partition_count_plus_scatter_ms": t_part_both,
+                         "bytes_to_other_owners": int(sum(q[1:])) * 8})
+        print(json.dumps(per_rank[-1]), flush=True)
+        step.free()
+        del w, step, send, out_t
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    if args.one_rank:
+        segs, seg_counts = segs * world, seg_counts * world
+    recv = torch.cat(segs + [torch.zeros(1, dtype=torch.int64, device="cuda")])
+    rc = np.array(seg_counts, dtype=np.uint32)
+    res = {"per_rank": per_rank, "owner0_inbox_entries": int(rc.sum())}
+    for label, n_owner in (("owner_table_200M_entries", None), ("owner_table_sized_to_its_keys", cp.entry_count // world)):
+        with torch.cuda.stream(ts):
+            D.merge_baseline_on_device(cp, recv, rc, dev, n_owner, h)  # warm-up (pool growth)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            table, ne = D.merge_baseline_on_device(cp, recv, rc, dev, n_owner, h)
+            torch.cuda.synchronize()
+            res[label] = {"init_plus_reinsert_ms": (time.perf_counter() - t0) * 1e3, "entries": ne}
+            rq = int(cp.plan.row_size_quad)
+            keys = (table[:ne * rq].view(ne, rq)[:, 0] << 32) >> 32 if cp.plan.key_width == 4 else table[:ne * rq].view(ne, rq)[:, 0]
+            empty = A.EMPTY_KEY_32 if cp.plan.key_width == 4 else A.EMPTY_KEY_64
+            res[label]["groups"] = int((keys != empty).sum().item())
+        del table
+        torch.cuda.empty_cache()
+    print(json.dumps({"c5_table_exchange_merge": res}), flush=True)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="a,b")
+    ap.add_argument("--configs", default="c2,q1,q2,q3,q4")
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--one-rank", action="store_true", help="part B: run rank 0 only and use its segment 8 times")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    args.configs = args.configs.split(",")
+    import torch
+    torch.cuda.set_device(0)
+    from hdk_amd.hip_mgr import HipMgr
+    mgr = HipMgr()
+    out = {}
+    if "a" in args.only:
+        out["perfect_hash_shard_floor"] = part_a(args, mgr)
+    if "b" in args.only:
+        out["c5_table_exchange_merge"] = part_b(args, mgr)
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,50 @@ def test_interrupt_and_watchdog(oracle, gpu_executor_factory):
         ex.interrupt(0)
 
 
+def test_watch_state_belongs_to_the_launch(oracle, gpu_executor_factory):
+    """The interrupt / watchdog words live in the launch's own workspace (csrc/watch.h), not in a device global:
+    (1) a watchdog launch that timed out does not leave a stale deadline behind for a hipGraph captured earlier
+    (replays of the graph keep giving the oracle's buffer); (2) a captured graph carries its own re-arming node, so
+    a replay after another step's watchdog launch on the SAME device is clean; (3) an unarmed launch on the same device
+    does not disarm the watchdog of another step."""
+    rng = np.random.default_rng(81)
+    n = 4_000_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 50, n).astype(np.int64), "v": rng.integers(-100, 100, n).astype(np.int64)},
+                    fragment_size=1_000_000)
+    q = QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v"))])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    graph_step = ex.prepare(cp).capture_graph()
+    assert graph_step._graph is not None
+    graph_step.replay()
+    assert_buffers_equal(cp, graph_step.fetch().buffer, want)
+    # a launch that runs out of its 1 ms budget (row-at-a-time interpreter, 8 blocks) ...
+    slow = ex.prepare(cp, flags=A.LAUNCH_FORCE_SCALAR, grid=8, watchdog_ms=1)
+    with pytest.raises(HdkHipError) as ei:
+        slow.run()
+    assert ei.value.code == A.ERR_OUT_OF_TIME
+    # ... leaves nothing behind: graph replays (no host-side arming happens for them) and plain launches are clean
+    for _ in range(2):
+        graph_step.replay()
+        assert_buffers_equal(cp, graph_step.fetch().buffer, want)
+    plain = ex.prepare(cp)
+    assert_buffers_equal(cp, plain.run().buffer, want)
+    # the slow step still times out after unarmed launches ran on the device (they do not touch its words),
+    # and its error word is its own
+    with pytest.raises(HdkHipError) as ei:
+        slow.run()
+    assert ei.value.code == A.ERR_OUT_OF_TIME
+    # the same step (its workspace last held an armed launch) relaunched WITHOUT a budget runs to the end
+    slow.ko.watchdog_ms = 0
+    slow.mgr.zeroDeviceMem(slow.d_err.ptr, 4, slow.dev)
+    assert_buffers_equal(cp, slow.run().buffer, want)
+    for s_ in (graph_step, plain):
+        s_.free()
+    slow.free()
+
+
 # ---- float accumulators (takes_float_argument) ----------------------------------------------------------------------
 def _float_table(n=200_000, seed=23):
     import pyarrow as pa
