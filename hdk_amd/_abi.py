@@ -16,7 +16,7 @@ MAX_JOIN_KEYS = 3
 MAX_EXPR_STEPS = 3
 MAX_FILTER_OPS = 16
 F_AND, F_OR, F_NOT = 64, 65, 66
-PLAN_ABI = 3
+PLAN_ABI = 4
 
 # --- sentinels: reference omniscidb/Shared/InlineNullValues.h:33-39, QueryEngine/GpuRtConstants.h:29-32
 EMPTY_KEY_64 = 2**63 - 1
@@ -43,6 +43,7 @@ ERR_INTERRUPTED = 10
 ERR_UNSUPPORTED = 100
 ERR_INVALID_ARG = 101
 ERR_RUNTIME = 102
+ERR_EXCHANGE_INCOMPLETE = 103
 
 # --- enums -----------------------------------------------------------------------------------
 VC_INT, VC_FP = 0, 1
@@ -74,7 +75,9 @@ LAUNCH_NO_CLUSTER_PROBES = 512
 
 class Col(C.Structure):
     _fields_ = [("buf_idx", C.c_int32), ("table", C.c_int32), ("width", C.c_int32),
-                ("kind", C.c_int32)]
+                ("kind", C.c_int32),
+                # ChunkStats of the column over the launch's fragments (DataMgr/ChunkMetadata.h); has_stats = 0: unknown
+                ("has_stats", C.c_int32), ("has_nulls", C.c_int32), ("min_val", C.c_int64), ("max_val", C.c_int64)]
 
 
 class Leaf(C.Structure):
@@ -128,6 +131,15 @@ class Plan(C.Structure):
                 ("idx_target_as_key", C.c_int32),
                 ("output_columnar", C.c_int32), ("row_size_quad", C.c_uint32),
                 ("num_targets", C.c_int32), ("targets", Target * MAX_TARGETS)]
+
+
+class ExchangeShape(C.Structure):
+    """hdk_hip_exchange_shape: geometry of the multi-GPU tuple exchange (include/hdk_hip.h)."""
+    _fields_ = [("num_owners", C.c_uint32), ("owner_entry_count", C.c_uint32), ("tuple_bytes", C.c_uint32),
+                ("coarse_per_owner", C.c_uint32), ("regions_log2", C.c_uint32), ("reserved_", C.c_uint32),
+                ("sub_slab_tuples", C.c_uint64), ("segment_header_bytes", C.c_uint64), ("segment_bytes", C.c_uint64),
+                ("rows_bound", C.c_uint64), ("scatter_workspace_bytes", C.c_uint64),
+                ("aggregate_workspace_bytes", C.c_uint64)]
 
 
 class KernelOptions(C.Structure):

@@ -69,6 +69,12 @@ SIGNATURES = {
     "hdk_hip_baseline_table_quads": (i32, [C.POINTER(A.Plan), u32, C.POINTER(i64)]),
     "hdk_hip_partition_baseline_count": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), i32, v]),
     "hdk_hip_partition_baseline": (i32, [C.POINTER(A.Plan), v, u32, v, i32, C.POINTER(u32), C.POINTER(v), i32, v]),
+    "hdk_hip_exchange_shape_for": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, u32, i32,
+                                         C.POINTER(A.ExchangeShape)]),
+    "hdk_hip_scatter_to_owners": (i32, [C.POINTER(A.Plan), C.POINTER(v), C.POINTER(A.KernelOptions),
+                                        C.POINTER(A.ExchangeShape), v, i32, v, v, sz]),
+    "hdk_hip_aggregate_from_ranks": (i32, [C.POINTER(A.Plan), C.POINTER(v), C.POINTER(A.KernelOptions),
+                                           C.POINTER(A.ExchangeShape), v, i32, v, v, sz]),
     "hdk_hip_init_baseline_hash_join_buff": (i32, [v, i64, sz, i32, i32, i32, i32, v]),
     "hdk_hip_fill_baseline_hash_join_buff": (i32, [v, i64, i32, i32, sz, i32, i32, v, C.POINTER(A.JoinColumn),
                                                    C.POINTER(A.JoinColumnTypeInfo), i32, v]),

@@ -78,6 +78,15 @@ inline bool launch_forces_generic(const hdk_hip_kernel_options* ko) {
   return ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
 }
 
+// ---- scan_agg.hip ---------------------------------------------------------------------------------------------------
+int32_t validate_plan(const hdk_hip_plan* p);
+// head of every launch: plan copy + the launch's interrupt / watchdog words into the front of `workspace`
+// (kPlanRegionBytes), the 12 launch pointers into a KernParams
+int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], const hdk_hip_kernel_options* ko,
+                    int32_t device_id, void* workspace, hipStream_t s, hdk_hip_plan** d_plan_out, KernParams* kp_out);
+// HIP events around a launch's dominant kernels (HDK_HIP_LAUNCH_RECORD_EVENTS): begin returns the pair to record
+int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
+
 // ---- scan_baseline.hip: GroupByBaselineHash plans and perfect-hash tables too big for LDS (STRAT_GLOBAL) ----------
 // persistent grid of the kernel that will run (x 4: random atomics make block run times uneven)
 uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);
@@ -88,6 +97,17 @@ void baseline_describe(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, 
 int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                         const hdk_hip_kernel_options* ko, const LaunchShape& shape, bool init_output,
                         const hdk_hip_device_properties* props, hipStream_t s);
+
+// multi-GPU tuple exchange (include/hdk_hip.h); `cursors` / `scratch`: the caller's workspace behind the plan region
+int32_t exchange_shape(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, int32_t num_owners,
+                       uint32_t owner_entry_count, struct PartArgs* pa, hdk_hip_exchange_shape* out);
+int32_t launch_scatter_to_owners(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                 const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape, int8_t* send,
+                                 int8_t* cursors, const hdk_hip_device_properties* props, hipStream_t s);
+int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                    const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                                    const int8_t* recv, int8_t* scratch, const hdk_hip_device_properties* props,
+                                    hipStream_t s);
 
 // ---- scan_project.hip: Projection plans (STRAT_PROJECT) ---------------------------------------------------------------
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);

@@ -668,7 +668,7 @@ struct ScanEventLog {
 };
 static ScanEventLog g_scan_events[16];
 
-static int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
   HDK_HIP_CHECK(hipEventCreate(e0));
   HDK_HIP_CHECK(hipEventCreate(e1));
   HDK_HIP_CHECK(hipEventRecord(*e0, s));
@@ -1245,6 +1245,54 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
 
 
 
+// Head of every launch: the plan copy and the launch's interrupt / watchdog words go to the front of `workspace`
+// (kPlanRegionBytes), the 12 launch pointers become a KernParams.
+int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], const hdk_hip_kernel_options* ko,
+                    int32_t device_id, void* workspace, hipStream_t s, hdk_hip_plan** d_plan_out, KernParams* kp_out) {
+  // the plan is read by the kernels from device memory (wave-uniform scalar loads); behind it sit the launch's own
+  // interrupt / watchdog words (watch.h): zeros travel with the plan upload, anything else is written by k_arm_watch
+  // on the launch stream.  A PLAN_RESIDENT launch always runs k_arm_watch: its workspace may hold the words of an
+  // earlier launch, and as a captured kernel node it re-arms every replay of the graph.
+  hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
+  *d_plan_out = d_plan;
+  LaunchWatch* d_watch = reinterpret_cast<LaunchWatch*>(static_cast<int8_t*>(workspace) + kWatchOffset);
+  const bool plan_resident = ko && (ko->flags & HDK_HIP_LAUNCH_PLAN_RESIDENT);
+  if (!plan_resident) {
+    struct alignas(16) Head {
+      int8_t bytes[kWatchOffset + sizeof(LaunchWatch)];
+    } head;
+    static_assert(sizeof(LaunchWatch) == 16, "LaunchWatch is 16 bytes");
+    memcpy(head.bytes, plan, sizeof(hdk_hip_plan));
+    memset(head.bytes + sizeof(hdk_hip_plan), 0, sizeof(head.bytes) - sizeof(hdk_hip_plan));
+    HDK_HIP_CHECK(hipMemcpyAsync(d_plan, head.bytes, sizeof(head.bytes), hipMemcpyHostToDevice, s));
+  }
+  {
+    const uint32_t wf = ((ko && (ko->flags & HDK_HIP_LAUNCH_CHECK_INTERRUPT)) ? 1u : 0u) | ((ko && ko->watchdog_ms) ? 2u : 0u);
+    if (wf || plan_resident) {
+      hipLaunchKernelGGL(k_arm_watch, dim3(1), dim3(1), 0, s, d_watch, wf, ko ? ko->watchdog_ms : 0u);
+      HDK_HIP_CHECK(hipGetLastError());
+    }
+  }
+
+  KernParams& kp = *kp_out;
+  kp.col_buffers = reinterpret_cast<const int8_t* const* const*>(params[HDK_KP_COL_BUFFERS]);
+  kp.num_fragments = reinterpret_cast<const uint64_t*>(params[HDK_KP_NUM_FRAGMENTS]);
+  kp.literals = params[HDK_KP_LITERALS];
+  kp.num_rows = reinterpret_cast<const int64_t*>(params[HDK_KP_NUM_ROWS]);
+  kp.frag_row_offsets = reinterpret_cast<const uint64_t*>(params[HDK_KP_FRAG_ROW_OFFSETS]);
+  kp.max_matched = reinterpret_cast<const int32_t*>(params[HDK_KP_MAX_MATCHED]);
+  kp.total_matched = reinterpret_cast<int32_t*>(params[HDK_KP_TOTAL_MATCHED]);
+  kp.init_agg_vals = reinterpret_cast<const int64_t*>(params[HDK_KP_INIT_AGG_VALS]);
+  kp.groupby_buf = reinterpret_cast<int64_t**>(params[HDK_KP_GROUPBY_BUF]);
+  kp.error_code = reinterpret_cast<int32_t*>(params[HDK_KP_ERROR_CODE]);
+  kp.num_tables = reinterpret_cast<const uint32_t*>(params[HDK_KP_NUM_TABLES]);
+  kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
+  kp.watch = d_watch;
+  kp.interrupt = device_interrupt_word(device_id);
+
+  return HDK_HIP_OK;
+}
+
 }  // namespace hdk
 
 extern "C" int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
@@ -1440,45 +1488,10 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     HDK_REQUIRE(params[HDK_KP_INIT_AGG_VALS], "HDK_HIP_LAUNCH_INIT_OUTPUT needs INIT_AGG_VALS");
   }
 
-  // the plan is read by the kernels from device memory (wave-uniform scalar loads); behind it sit the launch's own
-  // interrupt / watchdog words (watch.h): zeros travel with the plan upload, anything else is written by k_arm_watch
-  // on the launch stream.  A PLAN_RESIDENT launch always runs k_arm_watch: its workspace may hold the words of an
-  // earlier launch, and as a captured kernel node it re-arms every replay of the graph.
-  hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(workspace);
-  LaunchWatch* d_watch = reinterpret_cast<LaunchWatch*>(static_cast<int8_t*>(workspace) + kWatchOffset);
-  const bool plan_resident = ko && (ko->flags & HDK_HIP_LAUNCH_PLAN_RESIDENT);
-  if (!plan_resident) {
-    struct alignas(16) Head {
-      int8_t bytes[kWatchOffset + sizeof(LaunchWatch)];
-    } head;
-    static_assert(sizeof(LaunchWatch) == 16, "LaunchWatch is 16 bytes");
-    memcpy(head.bytes, plan, sizeof(hdk_hip_plan));
-    memset(head.bytes + sizeof(hdk_hip_plan), 0, sizeof(head.bytes) - sizeof(hdk_hip_plan));
-    HDK_HIP_CHECK(hipMemcpyAsync(d_plan, head.bytes, sizeof(head.bytes), hipMemcpyHostToDevice, s));
-  }
-  {
-    const uint32_t wf = ((ko && (ko->flags & HDK_HIP_LAUNCH_CHECK_INTERRUPT)) ? 1u : 0u) | ((ko && ko->watchdog_ms) ? 2u : 0u);
-    if (wf || plan_resident) {
-      hipLaunchKernelGGL(k_arm_watch, dim3(1), dim3(1), 0, s, d_watch, wf, ko ? ko->watchdog_ms : 0u);
-      HDK_HIP_CHECK(hipGetLastError());
-    }
-  }
-
+  hdk_hip_plan* d_plan = nullptr;
   KernParams kp;
-  kp.col_buffers = reinterpret_cast<const int8_t* const* const*>(params[HDK_KP_COL_BUFFERS]);
-  kp.num_fragments = reinterpret_cast<const uint64_t*>(params[HDK_KP_NUM_FRAGMENTS]);
-  kp.literals = params[HDK_KP_LITERALS];
-  kp.num_rows = reinterpret_cast<const int64_t*>(params[HDK_KP_NUM_ROWS]);
-  kp.frag_row_offsets = reinterpret_cast<const uint64_t*>(params[HDK_KP_FRAG_ROW_OFFSETS]);
-  kp.max_matched = reinterpret_cast<const int32_t*>(params[HDK_KP_MAX_MATCHED]);
-  kp.total_matched = reinterpret_cast<int32_t*>(params[HDK_KP_TOTAL_MATCHED]);
-  kp.init_agg_vals = reinterpret_cast<const int64_t*>(params[HDK_KP_INIT_AGG_VALS]);
-  kp.groupby_buf = reinterpret_cast<int64_t**>(params[HDK_KP_GROUPBY_BUF]);
-  kp.error_code = reinterpret_cast<int32_t*>(params[HDK_KP_ERROR_CODE]);
-  kp.num_tables = reinterpret_cast<const uint32_t*>(params[HDK_KP_NUM_TABLES]);
-  kp.join_hash_tables = reinterpret_cast<const int64_t*>(params[HDK_KP_JOIN_HASH_TABLES]);
-  kp.watch = d_watch;
-  kp.interrupt = device_interrupt_word(device_id);
+  st = launch_head(plan, params, ko, device_id, workspace, s, &d_plan, &kp);
+  if (st) return st;
 
   const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
   hipEvent_t e0 = nullptr, e1 = nullptr;

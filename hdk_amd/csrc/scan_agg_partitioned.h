@@ -43,6 +43,26 @@
 // still selectable with HDK_HIP_PART_G_LOG2=3 for measurements: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 at the time)
 // -- and carrying a bin's remainder into the block's next batch (3.4 / 2.45 ms: the extra registers and LDS cost the
 // third block per CU).
+//
+// Bytes are the lever once the passes run at the copy rate, so the tuple is as small as the plan's column statistics
+// allow (hdk_hip_col::has_stats -- the ChunkStats the reference's planner reads through getExpressionRange):
+//   narrow   one key that fits 32 bits and ONE integer argument column whose values fit 32 bits: a tuple is ONE word
+//            [argument as int32 : key as int32] -- 8 bytes instead of 16.  A nullable argument column gives up INT32_MIN
+//            for its in-band NULL (so its non-NULL minimum must be above it); the readers hand the aggregate functions
+//            the column's own 64-bit values and sentinel back.  The home is recomputed by each pass (the passes wait
+//            for memory, not for the hash); a batch holds twice the tuples, so a run is as many BYTES as before.  A
+//            value that contradicts the statistics raises the same device-side flag as skew: the atomics kernel
+//            redoes the launch from the columns, the answer is right whatever the metadata said.
+//
+// Multi-GPU (no reference counterpart -- the reference merges per-device tables on the host,
+// QE/Execute.cpp:1224-1336): with `owners` > 1 the keys are split by owner = mulhi32(key_hash, owners) and every
+// owner holds an open-addressing table of its own (`entry_count` is then the OWNER's).  Level 1 scatters a rank's
+// tuples into bins (owner, coarse slab of the owner's table), straight into the send buffer: one segment per owner,
+// [header: tuples per (coarse slab, XCD) | the sub-slabs], every segment the same size whatever the data -- the
+// exchange is one all-to-all with equal splits and no host round trip.  The owner runs level 2 over the sub-slabs
+// of ALL ranks' segments (`nsrc` sources), then passes 3 and 4 as on one GPU.  A rank exchanges tuples, not partial
+// tables: no local 200 M-entry table is built, scanned and re-inserted (measured in round 3: partition 530 ms +
+// re-insert 4.5 ms against a 2.9 ms shard scan, profiles/r03_multi_gpu_floor_before.json).
 #pragma once
 #include "scan_agg_baseline_fast.h"
 #include "watch.h"
@@ -55,8 +75,12 @@ constexpr int kPartAggBlock = 1024;              // aggregation pass: 2 blocks x
 #define HDK_PART_NT_STORES 0  // measured: non-temporal copy-out and write-back stores are SLOWER (3.04 + 2.85 + 1.89 ms against 2.73 + 2.59 + 1.70): partial lines are merged in L2
 #endif
 constexpr bool kPartNtStores = HDK_PART_NT_STORES != 0;
-constexpr int kPartVR = 4;
-constexpr int kPartTile = kPartBlock * kPartVR;  // new tuples per scatter batch
+constexpr int kPartVR = 4;                       // tuples per thread and scatter batch (16- and 24-byte tuples)
+constexpr int kPartVRNarrow = 8;                 // ... 8-byte tuples: same bytes per batch, so a run stays ~128 bytes
+constexpr int kPartTile = kPartBlock * kPartVR;  // tuples per scatter batch
+constexpr int kPartTileNarrow = kPartBlock * kPartVRNarrow;
+__host__ __device__ constexpr int part_tile(bool one_word) { return one_word ? kPartTileNarrow : kPartTile; }
+constexpr int kPartMaxSrc = 16;                  // ranks a level-2 pass reads sub-slabs from (1 on a single GPU)
 constexpr int kPartMaxBins = 256;                // bins a scatter pass distinguishes (P1 <= 256, P2 <= 256)
 constexpr int kPartMaxArgs = 2;                  // argument columns carried in a tuple (at most)
 constexpr int kPartMaxTW = 1 + kPartMaxArgs;     // tuple words: 1-2 keys + argument columns, 3 in all (LDS staging)
@@ -114,6 +138,20 @@ struct PartArgs {
   int64_t simple_arg_null;     // in-band NULL of the argument column
   int32_t nquals;        // plain filters, applied in pass 1
   ProjFastQual q[kMaxPlainQuals];
+  // narrow tuples: ONE word [argument as int32 : key as int32] (tw == 1 while the readers see [key, argument])
+  int32_t narrow;
+  int32_t narrow_null;       // the argument column may hold NULLs: INT32_MIN stands for its in-band NULL
+  int64_t narrow_arg_null;   // ... which the readers put back
+  // level-2 input: the sub-slabs of `nsrc` level-1 outputs (single GPU: this launch's own; owner: one per rank)
+  uint32_t nsrc;
+  uint32_t src_fill_stride;              // uint32 words between the cursors of neighbouring sub-slabs
+  const int64_t* src_slab[kPartMaxSrc];  // [p1][kPartXcds][sub1][tw]
+  const uint32_t* src_fill[kPartMaxSrc]; // [p1][kPartXcds] x src_fill_stride
+  // multi-GPU tuple exchange: level 1 writes owner segments
+  uint32_t owners;           // > 1: bins of level 1 are (owner, coarse slab of the owner's table)
+  int8_t* send;              // [owners] segments of seg_bytes: [header | p1 x kPartXcds sub-slabs of sub1 tuples]
+  uint64_t seg_bytes;
+  uint64_t seg_header_bytes; // header: uint32 tuples[p1 * kPartXcds], then uint32 flag (0 = complete)
 };
 
 // h % d for any 32-bit h: unsigned division by an invariant divisor, round-up method in its branch-free form
@@ -124,34 +162,48 @@ HDK_DEV uint32_t fastmod_u32(uint32_t h, uint32_t magic, uint32_t shift, uint32_
   return h - q * d;
 }
 
+// key_hash (QE/GroupByRuntime.cpp:24-29) of a tuple's key
+template <typename K, int TW = kPartMaxTW>
+HDK_DEV uint32_t part_hash_of_key(const PartArgs& a, const int64_t* tup) {
+  const K k[2] = {static_cast<K>(tup[0]), TW > 1 ? static_cast<K>(tup[TW > 1 ? 1 : 0]) : K(0)};
+  return (TW > 1 && a.nkeys == 2) ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
+}
 // the reference's first probe position of a tuple's key: key_hash % entry_count
 template <typename K, int TW = kPartMaxTW>
 HDK_DEV uint32_t part_home_of_key(const PartArgs& a, const int64_t* tup) {
-  const K k[2] = {static_cast<K>(tup[0]), TW > 1 ? static_cast<K>(tup[TW > 1 ? 1 : 0]) : K(0)};
-  const uint32_t h = (TW > 1 && a.nkeys == 2) ? key_hash_dev<K>(k, 2) : key_hash_dev<K>(k, 1);  // constant trip counts unroll
-  return fastmod_u32(h, a.mod_magic, a.mod_shift, a.entry_count);
+  return fastmod_u32(part_hash_of_key<K, TW>(a, tup), a.mod_magic, a.mod_shift, a.entry_count);
 }
 // 4-byte keys leave the upper half of a tuple's first word free: pass 1 stores the home there, so that the hash
 // (MurmurHash3 over the key: ~25 instructions, a third of them quarter-rate multiplies) and the modulo are worked
-// out once per row instead of once per pass.  Every reader takes the key as static_cast<K>(word 0).
+// out once per row instead of once per pass.  Every reader takes the key as static_cast<K>(word 0).  (Narrow tuples
+// keep the argument there instead and recompute the home.)
 template <typename K>
 HDK_DEV int64_t part_pack_home(int64_t word0, uint32_t home) {
   return sizeof(K) == 4 ? static_cast<int64_t>((static_cast<uint64_t>(home) << 32) | static_cast<uint32_t>(word0)) : word0;
 }
-template <typename K, int TW = kPartMaxTW>
+// NARROW: 1 / 0 known at compile time, -1 read from the arguments
+template <typename K, int TW = kPartMaxTW, int NARROW = -1>
 HDK_DEV uint32_t part_home(const PartArgs& a, const int64_t* tup) {
-  if (sizeof(K) == 4) {
+  const bool narrow = NARROW >= 0 ? NARROW != 0 : a.narrow != 0;
+  if (sizeof(K) == 4 && !narrow) {
     return static_cast<uint32_t>(static_cast<uint64_t>(tup[0]) >> 32);
   }
   return part_home_of_key<K, TW>(a, tup);
 }
+// narrow tuples: the argument as the column holds it (int64, the column's own NULL sentinel)
+HDK_DEV int64_t part_narrow_arg(const PartArgs& a, int64_t word) {
+  const int32_t v = static_cast<int32_t>(static_cast<uint64_t>(word) >> 32);
+  return (a.narrow_null && v == INT32_MIN) ? a.narrow_arg_null : static_cast<int64_t>(v);
+}
 
-// region (fine partition) of a tuple's key: home / S
-template <typename K, int TW = kPartMaxTW>
-HDK_DEV uint32_t part_region(const PartArgs& a, const int64_t* tup) {
-  const uint32_t home = part_home<K, TW>(a, tup);
+// region (fine partition) of a home: home / S
+HDK_DEV uint32_t part_region_of_home(const PartArgs& a, uint32_t home) {
   const uint32_t t = __umulhi(a.reg_magic, home);
   return (((home - t) >> 1) + t) >> a.reg_shift;
+}
+template <typename K, int TW = kPartMaxTW, int NARROW = -1>
+HDK_DEV uint32_t part_region(const PartArgs& a, const int64_t* tup) {
+  return part_region_of_home(a, part_home<K, TW, NARROW>(a, tup));
 }
 
 // The padding that fills a run up to whole 128-byte lines: a tuple whose KEY belongs to another coarse slab (and so
@@ -163,17 +215,18 @@ HDK_DEV int64_t part_padding(const PartArgs& a, uint32_t region) {
 }
 
 // staging capacity of a scatter batch: the tuples plus at most G - 1 padding slots per bin (multiple of 8)
-__host__ __device__ inline uint32_t part_stage_tuples(uint32_t nbins, uint32_t gmask) {
-  return (kPartTile + nbins * gmask + 7u) & ~7u;
+__host__ __device__ inline uint32_t part_stage_tuples(uint32_t nbins, uint32_t gmask, uint32_t tile) {
+  return (tile + nbins * gmask + 7u) & ~7u;
 }
-__host__ inline size_t part_scatter_lds_bytes(uint32_t nbins, uint32_t gmask, int tw) {
-  const size_t cs = part_stage_tuples(nbins, gmask);
+__host__ inline size_t part_scatter_lds_bytes(uint32_t nbins, uint32_t gmask, int tw, bool narrow) {
+  const size_t cs = part_stage_tuples(nbins, gmask, part_tile(narrow));
   return cs * tw * 8 + cs + 16;
 }
 
-// ---- scatter: LEVEL 1 reads the columns, LEVEL 2 reads coarse slab blockIdx.y -------------------------
+// ---- scatter: LEVEL 1 reads the columns, LEVEL 2 reads a coarse slab ------------------------------------
 // dynamic LDS: [cap_stage][tw] staging | uint8 bin of every staging slot [cap_stage]
-template <int LEVEL, typename K, int TW>
+// NARROW: one-word tuples [argument as int32 : key as int32] (K = int32_t, TW = 1), twice the tuples per batch
+template <int LEVEL, typename K, int TW, bool NARROW = false>
 __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   __shared__ uint32_t s_cnt[kPartMaxBins];     // tuples of the bin in this batch; rank source
   // per bin and batch, read as one 16-byte word by the copy-out: .x start of the run in the staging area, .y slots
@@ -182,14 +235,20 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
   __shared__ uint4 s_run[kPartMaxBins];
   __shared__ uint32_t s_nfit[kPartMaxBins];    // kinds 2, 3: how many slots still fit the slab
   __shared__ uint32_t s_obase[kPartMaxBins];   // kind 2: overflow-area position of the tuples that do not
+  __shared__ uint64_t s_binbase[kPartMaxBins]; // byte offset of the bin's slab (this block's sub-slab of it) from `out`
+  __shared__ uint32_t s_sub_before[kPartMaxSrc * kPartXcds + 1];  // level 2: tiles in front of every sub-slab
+  __shared__ uint32_t s_sub_n[kPartMaxSrc * kPartXcds];
   __shared__ uint32_t s_total, s_stop;
   extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
-  constexpr int VR = kPartVR;
+  constexpr int VR = NARROW ? kPartVRNarrow : kPartVR;
+  constexpr int kTile = kPartBlock * VR;
   constexpr int tw = TW;  // tuple words, compile time: the tuples of a batch live in registers
+  static_assert(!NARROW || (TW == 1 && sizeof(K) == 4), "narrow tuples: one word, 4-byte key");
   const int tid = threadIdx.x;
-  const uint32_t nbins = LEVEL == 1 ? a.p1 : (1u << a.p2_log2);
+  const bool dist = LEVEL == 1 && a.owners > 1;
+  const uint32_t nbins = LEVEL == 1 ? (dist ? a.owners * a.p1 : a.p1) : (1u << a.p2_log2);
   const uint32_t gmask = (1u << a.g_log2) - 1;
-  const uint32_t cap_stage = part_stage_tuples(nbins, gmask);
+  const uint32_t cap_stage = part_stage_tuples(nbins, gmask, kTile);
   int64_t* s_stage = s_dyn;
   uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(cap_stage) * tw);
   // Partial lines at the ends of a run are completed by whoever claims the neighbouring run; the two halves merge in
@@ -207,26 +266,34 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
     return;
   }
   const uint64_t cap = LEVEL == 1 ? a.sub1 : a.cap2;  // what a cursor may hand out
-  const uint64_t bin_stride = LEVEL == 1 ? a.cap1 : a.cap2;  // tuples from one bin's slab to the next
   const uint32_t cstride = LEVEL == 1 ? kPartCursorStride * kPartXcds : 1;
   const uint32_t bin0 = LEVEL == 1 ? 0 : (l2_c << a.p2_log2);  // first region of the coarse slab
   uint32_t* fill = (LEVEL == 1 ? a.fill1 + static_cast<size_t>(xcd) * kPartCursorStride : a.fill2) + static_cast<size_t>(bin0) * cstride;
-  int64_t* out = (LEVEL == 1 ? a.slab1 + static_cast<size_t>(xcd) * a.sub1 * tw : a.slab2) + static_cast<size_t>(bin0) * bin_stride * tw;
+  int8_t* out = LEVEL == 1 ? (dist ? a.send : reinterpret_cast<int8_t*>(a.slab1)) : reinterpret_cast<int8_t*>(a.slab2);
   for (int i = tid; i < kPartMaxBins; i += kPartBlock) {
     s_cnt[i] = 0;
+    // where the bin's tuples go: level 1 -- sub-slab `xcd` of coarse slab i (in owner i / p1's segment of the send
+    // buffer when the launch scatters to owners); level 2 -- fine slab bin0 + i
+    uint64_t off;
+    if (LEVEL == 2) {
+      off = static_cast<uint64_t>(bin0 + i) * a.cap2 * tw * 8;
+    } else if (dist) {
+      const uint32_t o = static_cast<uint32_t>(i) / a.p1, c = static_cast<uint32_t>(i) - o * a.p1;
+      off = static_cast<uint64_t>(o) * a.seg_bytes + a.seg_header_bytes + (static_cast<uint64_t>(c) * kPartXcds + xcd) * a.sub1 * tw * 8;
+    } else {
+      off = (static_cast<uint64_t>(i) * kPartXcds + xcd) * a.sub1 * tw * 8;
+    }
+    s_binbase[i] = off;
   }
   __syncthreads();
 
-  auto do_batch = [&](const bool (&live)[VR], int64_t (&tup)[VR][TW]) {
+  auto do_batch = [&](const bool (&live)[VR], int64_t (&tup)[VR][TW], const uint32_t (&bin)[VR]) {
     // 1. histogram + rank inside the bin
-    uint32_t bin[VR], rank[VR];
+    uint32_t rank[VR];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
-      bin[r] = 0;
       rank[r] = 0;
       if (live[r]) {
-        const uint32_t f = part_region<K, TW>(a, tup[r]);
-        bin[r] = LEVEL == 1 ? f >> a.p2_log2 : f & (nbins - 1);
         rank[r] = atomicAdd(&s_cnt[bin[r]], 1u);
       }
     }
@@ -243,11 +310,16 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         // the slab's end, a multiple of G like `base`: readers take the slab as [0, min(cursor, cap)), every slot written
         nfit = static_cast<uint64_t>(base) >= cap ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(np), cap - base));
         if (nfit < n) {
-          obase = atomicAdd(a.fill_ovf, n - nfit);
-          kind = 2;
-          if (static_cast<uint64_t>(obase) + (n - nfit) > a.cap_ovf) {
-            kind = 3;
-            atomicMax(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel (2 = interrupted sticks)
+          if (dist) {
+            kind = 3;  // (no overflow area travels with an owner segment: the exchange is flagged incomplete)
+            atomicMax(a.fallback, 1u);
+          } else {
+            obase = atomicAdd(a.fill_ovf, n - nfit);
+            kind = 2;
+            if (static_cast<uint64_t>(obase) + (n - nfit) > a.cap_ovf) {
+              kind = 3;
+              atomicMax(a.fallback, 1u);  // too skewed for slabs: hand the launch to the atomics kernel (2 = interrupted sticks)
+            }
           }
         }
       }
@@ -322,7 +394,7 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         }
       }
       int64_t* q = r >= nfit ? a.ovf + (static_cast<size_t>(s_obase[b]) + (r - nfit)) * tw
-                             : out + (static_cast<size_t>(b) * bin_stride + run.z + r) * tw;
+                             : reinterpret_cast<int64_t*>(out + s_binbase[b]) + static_cast<size_t>(run.z + r) * tw;
       int64_t t[TW];
       if (TW == 2) {
         const bf_i64x2 v = reinterpret_cast<const bf_i64x2*>(s_stage)[i];
@@ -363,11 +435,31 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
     const uint64_t nfrag = *a.kp.num_fragments;
     const uint32_t ntab = *a.kp.num_tables;
     const Watch watch = watch_begin(a.kp);
+    // level-1 bin of a row from its key hash; 4-byte keys of wide tuples get the home packed into word 0
+    auto bin_of = [&](int64_t (&t)[TW]) -> uint32_t {
+      const uint32_t h = part_hash_of_key<K, TW>(a, t);
+      const uint32_t home = fastmod_u32(h, a.mod_magic, a.mod_shift, a.entry_count);
+      if (sizeof(K) == 4 && !NARROW) {
+        t[0] = part_pack_home<K>(t[0], home);
+      }
+      const uint32_t c = part_region_of_home(a, home) >> a.p2_log2;
+      return dist ? static_cast<uint32_t>((static_cast<uint64_t>(h) * a.owners) >> 32) * a.p1 + c : c;
+    };
+    // narrow tuples: [argument as int32 : key as int32]; a value the statistics did not announce hands the launch to
+    // the atomics kernel (which reads the columns at their full width)
+    bool stale = false;
+    auto pack_narrow = [&](int64_t key, int64_t arg) -> int64_t {
+      const bool is_null = a.narrow_null && arg == a.narrow_arg_null;
+      const int32_t v32 = is_null ? INT32_MIN : static_cast<int32_t>(arg);
+      stale |= static_cast<int64_t>(static_cast<int32_t>(key)) != key ||
+               (!is_null && (static_cast<int64_t>(v32) != arg || (a.narrow_null && v32 == INT32_MIN)));
+      return static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(v32)) << 32) | static_cast<uint32_t>(key));
+    };
     int64_t tile = blockIdx.x;
     int64_t frag_tile_begin = 0;
     for (uint64_t f = 0; f < nfrag; ++f) {
       const int64_t nrows = a.kp.num_rows[f * ntab];
-      const int64_t ntiles = (nrows + kPartTile - 1) / kPartTile;
+      const int64_t ntiles = (nrows + kTile - 1) / kTile;
       const int8_t* const* cols = a.kp.col_buffers[f];
       for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
         // block-uniform exit: thread 0 samples the flag, everyone agrees before the batch's barriers
@@ -386,15 +478,18 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
         if (s_stop) {
           return;
         }
-        const int64_t row0 = (tile - frag_tile_begin) * kPartTile + tid;
+        const int64_t row0 = (tile - frag_tile_begin) * kTile + tid;
         bool live[VR];
         int64_t tup[VR][TW];
-        if (a.all_wide && !a.nquals && (tile - frag_tile_begin + 1) * kPartTile <= nrows) {
+        uint32_t bin[VR];
+        if (a.all_wide && !a.nquals && (tile - frag_tile_begin + 1) * kTile <= nrows) {
           // full tile, every tuple column 8 bytes wide, no filter: rows dealt in adjacent pairs, one 16-byte
           // non-temporal load per lane and pair, no bounds tests (which rows a lane takes does not matter to a scatter)
-          const uint64_t tile_byte0 = static_cast<uint64_t>(tile - frag_tile_begin) * kPartTile * 8;
+          const uint64_t tile_byte0 = static_cast<uint64_t>(tile - frag_tile_begin) * kTile * 8;
+          constexpr int NCOL = NARROW ? 2 : TW;  // columns read: a narrow tuple packs key and argument into one word
+          int64_t colv[VR][NCOL];
 #pragma unroll
-          for (int w = 0; w < TW; ++w) {
+          for (int w = 0; w < NCOL; ++w) {
             const int bi = w == 0 ? a.key_buf_idx : (w < a.nkeys ? a.key2_buf_idx : a.arg[w - a.nkeys > 0 ? 1 : 0].buf_idx);
             const uint64_t b = reinterpret_cast<uintptr_t>(cols[bi]) + tile_byte0;
             const uint32_t b_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
@@ -405,21 +500,24 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             for (int u = 0; u < VR / 2; ++u) {
               const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
                   base + static_cast<uint32_t>(u * kPartBlock + tid) * 16u));
-              tup[2 * u][w] = v.x;
-              tup[2 * u + 1][w] = v.y;
+              colv[2 * u][w] = v.x;
+              colv[2 * u + 1][w] = v.y;
             }
           }
 #pragma unroll
           for (int r = 0; r < VR; ++r) {
             live[r] = true;
-          }
-          if (sizeof(K) == 4) {
+            if (NARROW) {
+              tup[r][0] = pack_narrow(colv[r][0], colv[r][NCOL - 1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < VR; ++r) {
-              tup[r][0] = part_pack_home<K>(tup[r][0], part_home_of_key<K, TW>(a, tup[r]));
+              for (int w = 0; w < TW; ++w) {
+                tup[r][w] = colv[r][w < NCOL ? w : 0];
+              }
             }
+            bin[r] = bin_of(tup[r]);
           }
-          do_batch(live, tup);
+          do_batch(live, tup, bin);
           continue;
         }
 #pragma unroll
@@ -439,6 +537,15 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
           const int64_t row = row0 + static_cast<int64_t>(r) * kPartBlock;
           tup[r][0] = live[r] ? decode_col_g(cols[a.key_buf_idx], a.key_width, a.key_kind, row, true) : 0;
         }
+        if (NARROW) {
+          const BaseFastTarget c = a.arg[0];
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const int64_t row = row0 + static_cast<int64_t>(r) * kPartBlock;
+            const int64_t v = live[r] ? decode_col_g(cols[c.buf_idx], c.width, c.kind, row, true) : 0;
+            tup[r][0] = pack_narrow(tup[r][0], v);
+          }
+        }
         const int nk = a.nkeys;
 #pragma unroll
         for (int w = 1; w < TW; ++w) {
@@ -457,45 +564,51 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             }
           }
         }
-        if (sizeof(K) == 4) {
 #pragma unroll
-          for (int r = 0; r < VR; ++r) {
-            tup[r][0] = part_pack_home<K>(tup[r][0], part_home_of_key<K, TW>(a, tup[r]));
-          }
+        for (int r = 0; r < VR; ++r) {
+          bin[r] = bin_of(tup[r]);
         }
-        do_batch(live, tup);
+        do_batch(live, tup, bin);
       }
       frag_tile_begin += ntiles;
     }
-  } else {
-    // coarse slab c = eight sub-slabs [0, min(cursor, sub1)); a slot that does not belong to c is padding.  The
-    // block walks the tiles of the eight sub-slabs as one sequence, member m taking tiles m, m + G, ...
-    const uint32_t c = l2_c;
-    uint32_t sub_n[kPartXcds], sub_tiles_before[kPartXcds + 1];
-    sub_tiles_before[0] = 0;
-#pragma unroll
-    for (int x = 0; x < kPartXcds; ++x) {
-      sub_n[x] = static_cast<uint32_t>(min(static_cast<uint64_t>(a.fill1[(static_cast<size_t>(c) * kPartXcds + x) * kPartCursorStride]), a.sub1));
-      sub_tiles_before[x + 1] = sub_tiles_before[x] + (sub_n[x] + kPartTile - 1) / kPartTile;
+    if (NARROW && __any(stale) && (threadIdx.x & (kWave - 1)) == 0) {
+      atomicMax(a.fallback, 1u);
     }
-    for (uint32_t vt = l2_m; vt < sub_tiles_before[kPartXcds]; vt += kPartG2X) {
-      uint32_t sx = 0;
-#pragma unroll
-      for (int x = 1; x < kPartXcds; ++x) {
-        sx += vt >= sub_tiles_before[x] ? 1u : 0u;
+  } else {
+    // coarse slab c = the sub-slabs of every source (one per source and XCD), each [0, min(cursor, sub1)); a slot
+    // that does not belong to c is padding.  The block walks their tiles as one sequence, member m taking tiles
+    // m, m + G, ...
+    const uint32_t c = l2_c;
+    const uint32_t nsub = a.nsrc * kPartXcds;
+    for (uint32_t j = tid; j < nsub; j += kPartBlock) {
+      const uint32_t src = j / kPartXcds, x = j % kPartXcds;
+      s_sub_n[j] = static_cast<uint32_t>(min(static_cast<uint64_t>(a.src_fill[src][(static_cast<size_t>(c) * kPartXcds + x) * a.src_fill_stride]), a.sub1));
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t before = 0;
+      for (uint32_t j = 0; j < nsub; ++j) {
+        s_sub_before[j] = before;
+        before += (s_sub_n[j] + kTile - 1) / kTile;
       }
-      uint64_t n = 0, t0 = 0;
-#pragma unroll
-      for (int x = 0; x < kPartXcds; ++x) {  // (static indexing: the arrays stay in scalar registers)
-        if (sx == static_cast<uint32_t>(x)) {
-          n = sub_n[x];
-          t0 = static_cast<uint64_t>(vt - sub_tiles_before[x]) * kPartTile;
-        }
+      s_sub_before[nsub] = before;
+    }
+    __syncthreads();
+    const uint32_t ntiles = s_sub_before[nsub];
+    for (uint32_t vt = l2_m; vt < ntiles; vt += kPartG2X) {
+      uint32_t sj = 0;
+      for (uint32_t j = 1; j < nsub; ++j) {  // (uniform: scalar loop over at most 127 LDS words)
+        sj += vt >= s_sub_before[j] ? 1u : 0u;
       }
-      const int64_t* in = a.slab1 + (static_cast<size_t>(c) * a.cap1 + static_cast<size_t>(sx) * a.sub1) * tw;
+      sj = __builtin_amdgcn_readfirstlane(sj);
+      const uint64_t n = s_sub_n[sj];
+      const uint64_t t0 = static_cast<uint64_t>(vt - s_sub_before[sj]) * kTile;
+      const int64_t* in = a.src_slab[sj / kPartXcds] + (static_cast<size_t>(c) * kPartXcds + (sj % kPartXcds)) * a.sub1 * tw;
       bool live[VR];
       int64_t tup[VR][TW];
-      if (TW == 2 && t0 + kPartTile <= n) {  // full tile of 16-byte tuples: unconditional loads
+      uint32_t bin[VR];
+      if (TW == 2 && t0 + kTile <= n) {  // full tile of 16-byte tuples: unconditional loads
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
           const uint64_t i = t0 + static_cast<uint64_t>(r) * kPartBlock + tid;
@@ -503,9 +616,29 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
               reinterpret_cast<uintptr_t>(in + i * 2)));
           tup[r][0] = v.x;
           tup[r][TW - 1] = v.y;
-          live[r] = (part_region<K, TW>(a, tup[r]) >> a.p2_log2) == c;
+          const uint32_t f = part_region<K, TW, NARROW>(a, tup[r]);
+          live[r] = (f >> a.p2_log2) == c;
+          bin[r] = f & (nbins - 1);
         }
-        do_batch(live, tup);
+        do_batch(live, tup, bin);
+        continue;
+      }
+      if (TW == 1 && t0 + kTile <= n) {  // full tile of 8-byte tuples: adjacent pairs, one 16-byte load per pair
+#pragma unroll
+        for (int u = 0; u < VR / 2; ++u) {
+          const uint64_t i = t0 + (static_cast<uint64_t>(u) * kPartBlock + tid) * 2;
+          const bf_i64x2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+              reinterpret_cast<uintptr_t>(in + i)));
+          tup[2 * u][0] = v.x;
+          tup[2 * u + 1][0] = v.y;
+        }
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const uint32_t f = part_region<K, TW, NARROW>(a, tup[r]);
+          live[r] = (f >> a.p2_log2) == c;
+          bin[r] = f & (nbins - 1);
+        }
+        do_batch(live, tup, bin);
         continue;
       }
 #pragma unroll
@@ -528,10 +661,43 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
             tup[r][w] = live[r] ? __builtin_nontemporal_load(in + i * tw + w) : 0;
           }
         }
-        live[r] = live[r] && (part_region<K, TW>(a, tup[r]) >> a.p2_log2) == c;
+        const uint32_t f = part_region<K, TW, NARROW>(a, tup[r]);
+        live[r] = live[r] && (f >> a.p2_log2) == c;
+        bin[r] = f & (nbins - 1);
       }
-      do_batch(live, tup);
+      do_batch(live, tup, bin);
     }
+  }
+}
+
+// level 1 of a scatter to owners: the header of every owner segment -- tuples per (coarse slab, XCD) sub-slab, then the
+// flag word (0: complete; else the exchange cannot be used: a sub-slab overflowed, the statistics were stale, or the
+// launch was interrupted)
+__global__ void hdk_part_publish(PartArgs a) {
+  const uint32_t o = blockIdx.x;
+  uint32_t* header = reinterpret_cast<uint32_t*>(a.send + static_cast<uint64_t>(o) * a.seg_bytes);
+  const uint32_t nsub = a.p1 * kPartXcds;
+  for (uint32_t j = threadIdx.x; j < nsub; j += blockDim.x) {
+    const uint32_t n = a.fill1[(static_cast<size_t>(o) * nsub + j) * kPartCursorStride];
+    header[j] = static_cast<uint32_t>(min(static_cast<uint64_t>(n), a.sub1));
+  }
+  if (threadIdx.x == 0) {
+    header[nsub] = *a.fallback;
+  }
+}
+
+// owner side: any source whose segment is flagged makes the whole exchange unusable -- the owner's passes return at
+// once (fallback != 0) and the step ends with HDK_HIP_ERR_EXCHANGE_INCOMPLETE, which the caller answers with the
+// table exchange (partial tables, hdk_hip_partition_baseline) or a retry
+__global__ void hdk_part_collect_flags(PartArgs a) {
+  const uint32_t nsub = a.p1 * kPartXcds;
+  uint32_t bad = 0;
+  for (uint32_t r = threadIdx.x; r < a.nsrc; r += blockDim.x) {
+    bad |= a.src_fill[r][nsub];
+  }
+  if (bad) {
+    atomicMax(a.fallback, 3u);
+    record_error(a.kp.error_code, HDK_HIP_ERR_EXCHANGE_INCOMPLETE);
   }
 }
 
@@ -670,7 +836,9 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
       t2 = tw > 2 ? __builtin_nontemporal_load(q + 2) : 0;
     }
   };
-  auto apply = [&](const int64_t (&tup)[kPartMaxTW]) {
+  auto apply = [&](const int64_t (&raw)[kPartMaxTW]) {
+    // (a narrow tuple is one word; the aggregate functions see [key, argument] as the columns hold them)
+    const int64_t tup[kPartMaxTW] = {raw[0], a.narrow ? part_narrow_arg(a, raw[0]) : raw[1], raw[2]};
     const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};  // (word 1 is only read as a key when key_count == 2)
     const uint32_t local = part_home<K>(a, tup) - first;
     if (local >= slots) {
@@ -727,7 +895,8 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
 // spends ~210 vector + ~220 scalar instructions per tuple, most of them on its per-target interpreter.
 // TW_T / AGG_T / SKIP_T >= 0 fix the tuple width, the aggregate and its NULL handling at compile time (C5: two words,
 // SUM); -1 reads them from the arguments
-template <typename K, int TW_T = -1, int AGG_T = -1, int SKIP_T = -1>
+// NARROW: one-word tuples [argument as int32 : key as int32], read in adjacent pairs (16 bytes per lane and load)
+template <typename K, int TW_T = -1, int AGG_T = -1, int SKIP_T = -1, bool NARROW = false>
 __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(PartArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds_table[];
   __shared__ uint32_t s_nspill;
@@ -780,7 +949,7 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
   const K ek = empty_key<K>();
   auto apply = [&](int64_t t0, int64_t t1) {
     const int64_t tup[2] = {t0, t1};
-    const uint32_t local = part_home<K, 2>(a, tup) - first;
+    const uint32_t local = part_home<K, 2, NARROW ? 1 : 0>(a, tup) - first;
     if (local >= slots) {
       return;  // padding of the scatter passes
     }
@@ -848,30 +1017,54 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
   int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
   const __attribute__((address_space(1))) int8_t* in_bytes =
       reinterpret_cast<const __attribute__((address_space(1))) int8_t*>(reinterpret_cast<uintptr_t>(in));
-  auto fetch = [&](uint32_t i, int64_t& t0, int64_t& t1) {  // 32-bit indices: cap2 <= 0xFFFF0000 (match_partitioned)
-    if (i < n) {
-      if (tw == 2) {
+  if (NARROW) {
+    // lane-adjacent pairs: tuples 2j and 2j + 1 come in with one 16-byte load (cap2 is even, so every slab starts
+    // 16-byte aligned); (a0, b0) hold the pair being applied, (a1, b1) the pair in flight
+    const uint32_t npairs = (n + 1) / 2;
+    auto fetch_pair = [&](uint32_t j, int64_t& lo, int64_t& hi) {
+      if (j < npairs) {
         const bf_i64x2 v = __builtin_nontemporal_load(
-            reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(i) * 16));
-        t0 = v.x;
-        t1 = v.y;
-      } else {
-        t0 = __builtin_nontemporal_load(in + i);
-        t1 = 0;
+            reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(j) * 16));
+        lo = v.x;
+        hi = v.y;
+      }
+    };
+    fetch_pair(tid, a1, b1);
+    for (uint32_t j = tid; j < npairs; j += kPartAggBlock) {
+      a0 = a1;
+      b0 = b1;
+      fetch_pair(j + kPartAggBlock, a1, b1);
+      apply(a0, part_narrow_arg(a, a0));
+      if (2 * j + 1 < n) {
+        apply(b0, part_narrow_arg(a, b0));
       }
     }
-  };
-  fetch(tid, a0, a1);
-  fetch(static_cast<uint32_t>(tid) + kPartAggBlock, b0, b1);
-  // (i + 3 * kPartAggBlock cannot wrap: n <= cap2 <= 0xFFFF0000)
-  for (uint32_t i = tid; i < n; i += 2 * kPartAggBlock) {
-    const int64_t ta0 = a0, ta1 = a1, tb0 = b0, tb1 = b1;
-    const bool has_b = i + kPartAggBlock < n;
-    fetch(i + 2 * kPartAggBlock, a0, a1);
-    fetch(i + 3 * kPartAggBlock, b0, b1);
-    apply(ta0, ta1);
-    if (has_b) {
-      apply(tb0, tb1);
+  } else {
+    auto fetch = [&](uint32_t i, int64_t& t0, int64_t& t1) {  // 32-bit indices: cap2 <= 0xFFFF0000 (match_partitioned)
+      if (i < n) {
+        if (tw == 2) {
+          const bf_i64x2 v = __builtin_nontemporal_load(
+              reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(i) * 16));
+          t0 = v.x;
+          t1 = v.y;
+        } else {
+          t0 = __builtin_nontemporal_load(in + i);
+          t1 = 0;
+        }
+      }
+    };
+    fetch(tid, a0, a1);
+    fetch(static_cast<uint32_t>(tid) + kPartAggBlock, b0, b1);
+    // (i + 3 * kPartAggBlock cannot wrap: n <= cap2 <= 0xFFFF0000)
+    for (uint32_t i = tid; i < n; i += 2 * kPartAggBlock) {
+      const int64_t ta0 = a0, ta1 = a1, tb0 = b0, tb1 = b1;
+      const bool has_b = i + kPartAggBlock < n;
+      fetch(i + 2 * kPartAggBlock, a0, a1);
+      fetch(i + 3 * kPartAggBlock, b0, b1);
+      apply(ta0, ta1);
+      if (has_b) {
+        apply(tb0, tb1);
+      }
     }
   }
   __syncthreads();
@@ -920,6 +1113,9 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
 #pragma unroll
     for (int w = 0; w < kPartMaxTW; ++w) {
       tup[w] = w < tw ? q[w] : 0;
+    }
+    if (a.narrow) {
+      tup[1] = part_narrow_arg(a, tup[0]);
     }
     const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};
     bool fresh;

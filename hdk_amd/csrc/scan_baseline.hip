@@ -139,13 +139,17 @@ static uint32_t host_key_hash(int64_t k, int nkeys) {
   return h1;
 }
 
-static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
+// ---- what a tuple carries (independent of the table's geometry) ---------------------------------------------------
+static const hdk_hip_col* outer_col_of_buf(const hdk_hip_plan* p, int32_t buf_idx) {
+  for (int i = 0; i < p->num_cols && i < HDK_HIP_MAX_COLS; ++i) {
+    if (p->cols[i].table == 0 && p->cols[i].buf_idx == buf_idx) return &p->cols[i];
+  }
+  return nullptr;
+}
+
+static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
-  if (!ko || ko->total_rows == 0) return false;
-  const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
-  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
-  if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
   if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
   memset(pa, 0, sizeof(*pa));
   pa->key_buf_idx = bf.key_buf_idx;
@@ -179,16 +183,44 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   for (int k = 0; k < pa->nargs; ++k) {
     if (pa->arg[k].width != 8 || (pa->arg[k].kind != HDK_COL_INT && pa->arg[k].kind != HDK_COL_DOUBLE)) pa->all_wide = 0;
   }
-  pa->entry_count = p->entry_count;
-  magic_u32(p->entry_count, &pa->mod_magic, &pa->mod_shift);
+  // narrow tuples (scan_agg_partitioned.h): one 4-byte table key, one integer argument column that the statistics
+  // put inside 32 bits -- a nullable one gives up INT32_MIN for its in-band NULL
+  if (pa->nkeys == 1 && p->key_width == 4 && pa->nargs == 1 && pa->arg[0].kind == HDK_COL_INT && !getenv("HDK_HIP_PART_WIDE")) {
+    const hdk_hip_col* c = outer_col_of_buf(p, pa->arg[0].buf_idx);
+    if (c && c->has_stats && c->min_val >= static_cast<int64_t>(INT32_MIN) + (c->has_nulls ? 1 : 0) &&
+        c->max_val <= static_cast<int64_t>(INT32_MAX) && c->min_val <= c->max_val) {
+      pa->narrow = 1;
+      pa->narrow_null = c->has_nulls ? 1 : 0;
+      for (int t = 0; t < pa->ntargets; ++t) {  // the column's in-band NULL, as the targets' argument leaf names it
+        const hdk_hip_target& tg = p->targets[pa->tgt_index[t]];
+        if (pa->tgt_arg[t]) {
+          if (pa->narrow_null && !tg.arg.nullable) pa->narrow = 0;  // (statistics and type disagree: stay wide)
+          pa->narrow_arg_null = tg.arg.null_val;
+        }
+      }
+      if (pa->narrow) pa->tw = 1;
+    }
+  }
+  return true;
+}
+
+// ---- geometry of the passes for a table of `entry_count` entries (the plan's, or an owner's when `owners` > 1) ------
+static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_count, uint32_t owners, PartArgs* pa) {
+  if (entry_count < 128) return false;
+  pa->entry_count = entry_count;
+  pa->owners = owners > 1 ? owners : 0;
+  magic_u32(entry_count, &pa->mod_magic, &pa->mod_shift);
   // regions: as many entries as fit the LDS image
   pa->slots = kPartLdsBytes / (p->row_size_quad * 8);
-  if (pa->slots < 16 || pa->slots >= p->entry_count) return false;
+  if (pa->slots < 16 || pa->slots >= entry_count) return false;
   magic_u32(pa->slots, &pa->reg_magic, &pa->reg_shift);
-  const uint64_t pf = (static_cast<uint64_t>(p->entry_count) + pa->slots - 1) / pa->slots;
-  // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch)
-  uint32_t p2_log2 = (pow2_ceil_log2(pf) + 1) / 2;
-  while (((pf + (1ull << p2_log2) - 1) >> p2_log2) > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
+  const uint64_t pf = (static_cast<uint64_t>(entry_count) + pa->slots - 1) / pa->slots;
+  // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch); level 1
+  // also separates the owners
+  const uint64_t g = owners > 1 ? owners : 1;
+  uint32_t p2_log2 = (pow2_ceil_log2(pf * g) + 1) / 2;
+  if (p2_log2 > pow2_ceil_log2(pf)) p2_log2 = pow2_ceil_log2(pf);
+  while (((pf + (1ull << p2_log2) - 1) >> p2_log2) * g > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
   if ((1u << p2_log2) > static_cast<uint32_t>(kPartMaxBins)) return false;  // > 64 K regions: a third level would be needed
   pa->fine_count = static_cast<uint32_t>(pf);
   pa->p2_log2 = p2_log2;
@@ -198,66 +230,96 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   // Measured at the C5 shape (256 M rows): rounding runs up to whole lines costs more than it gains -- the padding
   // is 18 % of pass 1's output and compounds to 44 % of pass 3's input, and its staging slots cost the third block
   // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
-  // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements.
+  // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements (wide tuples on one GPU only).
   pa->g_log2 = 0;
-  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = pa->p1 < 2 ? 0 : atoi(e);
+  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = (pa->p1 < 2 || owners > 1 || pa->narrow) ? 0 : atoi(e);
   if (pa->g_log2) {
     int found = 0;
     for (int64_t k = 1; k < 4096 && found < 2; ++k) {
       const uint32_t h = p->key_width == 4 ? host_key_hash<int32_t>(k, pa->nkeys) : host_key_hash<int64_t>(k, pa->nkeys);
-      const uint32_t c = static_cast<uint32_t>((h % p->entry_count) / pa->slots) >> p2_log2;
+      const uint32_t c = static_cast<uint32_t>((h % entry_count) / pa->slots) >> p2_log2;
       if (found == 0 || c != pa->pad_coarse[0]) {
         // (tuples of 4-byte keys carry their home in the upper half of word 0: part_pack_home)
-        pa->pad_key[found] = p->key_width == 4 ? static_cast<int64_t>((static_cast<uint64_t>(h % p->entry_count) << 32) | static_cast<uint32_t>(k)) : k;
+        pa->pad_key[found] = p->key_width == 4 ? static_cast<int64_t>((static_cast<uint64_t>(h % entry_count) << 32) | static_cast<uint32_t>(k)) : k;
         pa->pad_coarse[found] = c;
         ++found;
       }
     }
     if (found < 2) pa->g_log2 = 0;
   }
-  const uint64_t g = 1ull << pa->g_log2;
-  const uint64_t rows = ko->total_rows;
+  const uint64_t gr = 1ull << pa->g_log2;
+  const uint64_t tile = static_cast<uint64_t>(part_tile(pa->narrow != 0));
   pa->total_rows = rows;
-  auto round_g = [&](uint64_t x) { return (x + g - 1) & ~(g - 1); };
-  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer): uniform hash, 6 % + 8 K slack, plus the
-  // padding: on average (G - 1) / 2 slots per bin and batch
-  const uint64_t batches = rows / kPartTile + 1;
-  const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / pf) + 1;
-  pa->cap1 = round_g(share1 + share1 / 16 + 8192 + batches * (g - 1) * 5 / 8);
-  const uint64_t batches2 = share1 / kPartTile + kPartG2X;  // batches a coarse slab is scattered in
-  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (g - 1) * 5 / 8);  // 25 % + 256 + padding
+  auto round_g = [&](uint64_t x) { return (x + gr - 1) & ~(gr - 1); };
+  // a coarse slab takes the rows of P2 regions out of PF (the last one fewer) -- of ONE owner out of G when the launch
+  // scatters to owners: uniform hash, 6 % + 8 K slack, plus the padding: on average (G - 1) / 2 slots per bin and batch
+  const uint64_t batches = rows / tile + 1;
+  const uint64_t share1 = static_cast<uint64_t>((static_cast<unsigned __int128>(rows) << p2_log2) / (pf * g)) + 1;
+  pa->cap1 = round_g(share1 + share1 / 16 + 8192 + batches * (gr - 1) * 5 / 8);
+  // level 2 scatters what ALL ranks sent for the coarse slab: g x share1 tuples
+  const uint64_t batches2 = share1 * g / tile + kPartG2X;  // batches a coarse slab is scattered in
+  pa->cap2 = round_g(rows / pf + rows / (pf * 4) + 256 + batches2 * (gr - 1) * 5 / 8);  // 25 % + 256 + padding
+  pa->cap2 = (pa->cap2 + 15) & ~15ull;  // (slabs of 8-byte tuples start 16-byte aligned; whole lines for every width)
   pa->cap_ovf = rows / 16 + 4096;
   pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
   pa->cap1 = pa->sub1 * kPartXcds;
-  pa->cap_spill = static_cast<uint64_t>(pa->p1) * pa->cap1;  // slab 1, reused
+  pa->cap_spill = owners > 1 ? rows / 16 + 4096 : static_cast<uint64_t>(pa->p1) * pa->cap1;  // one GPU: slab 1, reused
   if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFF0000ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors (and 32-bit tuple indices with look-ahead in pass 3)
   return true;
 }
 
+static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
+  if (!ko || ko->total_rows == 0) return false;
+  const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
+  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
+  if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
+  return part_tuple_shape(p, pa) && part_geometry(p, ko->total_rows, p->entry_count, 1, pa);
+}
+
 constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
 
-template <int LEVEL, typename K>
-static void launch_part_scatter(int tw, dim3 grid, size_t lds, hipStream_t s, const PartArgs& pa) {
-  switch (tw) {
-    case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
-    case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
-    default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, K, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
+// kernel of a scatter level for the tuple format of `pa`
+template <int LEVEL>
+static const void* part_scatter_kernel(const PartArgs& pa, bool k32) {
+  if (pa.narrow) return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int32_t, 1, true>);
+  if (k32) {
+    switch (pa.tw) {
+      case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int32_t, 1>);
+      case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int32_t, 2>);
+      default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int32_t, 3>);
+    }
+  }
+  switch (pa.tw) {
+    case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int64_t, 1>);
+    case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int64_t, 2>);
+    default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, int64_t, 3>);
   }
 }
 
-template <int LEVEL, typename K>
-static const void* part_scatter_kernel(int tw) {
-  switch (tw) {
-    case 1: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 1>);
-    case 2: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 2>);
-    default: return reinterpret_cast<const void*>(hdk_part_scatter<LEVEL, K, 3>);
+template <int LEVEL>
+static void launch_part_scatter(const PartArgs& pa, bool k32, dim3 grid, size_t lds, hipStream_t s) {
+  if (pa.narrow) {
+    hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int32_t, 1, true>), grid, dim3(kPartBlock), lds, s, pa);
+  } else if (k32) {
+    switch (pa.tw) {
+      case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int32_t, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
+      case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int32_t, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
+      default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int32_t, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
+    }
+  } else {
+    switch (pa.tw) {
+      case 1: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int64_t, 1>), grid, dim3(kPartBlock), lds, s, pa); break;
+      case 2: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int64_t, 2>), grid, dim3(kPartBlock), lds, s, pa); break;
+      default: hipLaunchKernelGGL((hdk_part_scatter<LEVEL, int64_t, 3>), grid, dim3(kPartBlock), lds, s, pa); break;
+    }
   }
 }
 
 // does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
 static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   pa->simple_agg = -1;
-  if (p->row_size_quad != 2 || pa->nkeys != 1 || pa->tw > 2) return false;
+  const int ltw = pa->narrow ? 2 : pa->tw;  // tuple words as the readers see them
+  if (p->row_size_quad != 2 || pa->nkeys != 1 || ltw > 2) return false;
   int found = -1;
   for (int i = 0; i < pa->ntargets; ++i) {
     const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
@@ -280,6 +342,85 @@ static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   return true;
 }
 
+// passes 2-4 (level-2 scatter, LDS aggregation, overflow) for the sources and scratch `pa` names
+static void launch_part_tail(const hdk_hip_plan* plan, PartArgs& pa, const hdk_hip_device_properties* props, hipStream_t s) {
+  const bool k32 = plan->key_width == 4;
+  const uint32_t gmask = (1u << pa.g_log2) - 1;
+  const size_t lds2 = part_scatter_lds_bytes(1u << pa.p2_log2, gmask, pa.tw, pa.narrow != 0);
+  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
+  // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
+  const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
+  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
+  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
+  const bool sum2 = simple && (pa.narrow || pa.tw == 2) && pa.simple_agg == HDK_AGG_SUM;
+  launch_part_scatter<2>(pa, k32, dim3(g2), lds2, s);
+  const dim3 ga(pa.fine_count), ba(kPartAggBlock);
+  if (pa.narrow && simple) {
+    if (sum2 && pa.simple_skip) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 1, HDK_AGG_SUM, 1, true>), ga, ba, table_bytes, s, pa);
+    } else if (sum2) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 1, HDK_AGG_SUM, 0, true>), ga, ba, table_bytes, s, pa);
+    } else {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 1, -1, -1, true>), ga, ba, table_bytes, s, pa);
+    }
+  } else if (k32) {
+    if (sum2 && pa.simple_skip) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 1>), ga, ba, table_bytes, s, pa);
+    } else if (sum2) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 0>), ga, ba, table_bytes, s, pa);
+    } else if (simple) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t>), ga, ba, table_bytes, s, pa);
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, ga, ba, table_bytes, s, pa);
+    }
+  } else {
+    if (sum2 && pa.simple_skip) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 1>), ga, ba, table_bytes, s, pa);
+    } else if (sum2) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 0>), ga, ba, table_bytes, s, pa);
+    } else if (simple) {
+      hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t>), ga, ba, table_bytes, s, pa);
+    } else {
+      hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, ga, ba, table_bytes, s, pa);
+    }
+  }
+  if (k32) {
+    hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  } else {
+    hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  }
+}
+
+// scratch of the passes behind level 1, carved from `q` (or just sized when q == nullptr): fine slabs, overflow area,
+// spill segments, [spill list when level 1's slabs are not ours to reuse], cursors
+static size_t part_carve_tail(PartArgs& pa, int8_t* q, bool own_spill_list, size_t* cursor_bytes, uint32_t** cursors) {
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t tw = static_cast<size_t>(pa.tw);
+  const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
+  const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
+  const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
+  const size_t bl = own_spill_list ? static_cast<size_t>(pa.cap_spill) * tw * 8 : 0;
+  const size_t nc = 2 * static_cast<size_t>(pa.fine_count) + 4;  // fill2 | nspill | fill_ovf, fill_spill, fallback
+  const size_t bc = nc * sizeof(uint32_t);
+  if (q) {
+    pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
+    pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
+    pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
+    if (own_spill_list) {
+      pa.slab1 = reinterpret_cast<int64_t*>(q);  // (pass 3 and 4 know the shared spill list as `slab1`)
+      q += up(bl);
+    }
+    pa.fill2 = reinterpret_cast<uint32_t*>(q);
+    pa.nspill = pa.fill2 + pa.fine_count;
+    pa.fill_ovf = pa.nspill + pa.fine_count;
+    pa.fill_spill = pa.fill_ovf + 1;
+    pa.fallback = pa.fill_spill + 1;
+    *cursors = pa.fill2;
+  }
+  *cursor_bytes = bc;
+  return up(b2) + up(bo) + up(bs) + up(bl) + up(bc);
+}
+
 static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                                        PartArgs pa, const LaunchShape& shape, const hdk_hip_device_properties* props,
                                        hipStream_t s) {
@@ -288,23 +429,20 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const bool k32 = plan->key_width == 4;
   const size_t tw = static_cast<size_t>(pa.tw);
   const uint32_t gmask = (1u << pa.g_log2) - 1;
-  const uint32_t p2 = 1u << pa.p2_log2;
-  const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw);
-  const size_t lds2 = part_scatter_lds_bytes(p2, gmask, pa.tw);
+  const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw, pa.narrow != 0);
   // pass-1 grid: what is resident, at most one block per batch
-  const void* k1 = k32 ? part_scatter_kernel<1, int32_t>(pa.tw) : part_scatter_kernel<1, int64_t>(pa.tw);
-  unsigned g1 = resident_grid(k1, kPartBlock, lds1, props);
-  const uint64_t tiles = (pa.total_rows + kPartTile - 1) / kPartTile;
+  unsigned g1 = resident_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
+  const uint64_t tile = static_cast<uint64_t>(part_tile(pa.narrow != 0));
+  const uint64_t tiles = (pa.total_rows + tile - 1) / tile;
   if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
-  const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
-  const size_t b2 = static_cast<size_t>(pa.fine_count) * pa.cap2 * tw * 8;
-  const size_t bo = static_cast<size_t>(pa.cap_ovf) * tw * 8;
-  const size_t bs = static_cast<size_t>(pa.fine_count) * kPartSpillSeg * tw * 8;
-  const size_t nc = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride + 2 * static_cast<size_t>(pa.fine_count) + 4;
-  const size_t bc = nc * sizeof(uint32_t);
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t b1 = static_cast<size_t>(pa.p1) * pa.cap1 * tw * 8;
+  const size_t bc1 = static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride * sizeof(uint32_t);
+  size_t bc2 = 0;
+  uint32_t* cur2 = nullptr;
+  const size_t tail = part_carve_tail(pa, nullptr, false, &bc2, &cur2);
   AsyncScratch scratch(s);
-  const hipError_t me = hipMallocAsync(&scratch.p, up(b1) + up(b2) + up(bo) + up(bs) + up(bc), s);
+  const hipError_t me = hipMallocAsync(&scratch.p, up(b1) + up(bc1) + tail, s);
   if (me != hipSuccess) {
     (void)hipGetLastError();
     scratch.p = nullptr;
@@ -312,53 +450,17 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   }
   int8_t* q = static_cast<int8_t*>(scratch.p);
   pa.slab1 = reinterpret_cast<int64_t*>(q); q += up(b1);
-  pa.slab2 = reinterpret_cast<int64_t*>(q); q += up(b2);
-  pa.ovf = reinterpret_cast<int64_t*>(q); q += up(bo);
-  pa.spill_seg = reinterpret_cast<int64_t*>(q); q += up(bs);
-  pa.fill1 = reinterpret_cast<uint32_t*>(q);
-  pa.fill2 = pa.fill1 + static_cast<size_t>(pa.p1) * kPartXcds * kPartCursorStride;
-  pa.nspill = pa.fill2 + pa.fine_count;
-  pa.fill_ovf = pa.nspill + pa.fine_count;
-  pa.fill_spill = pa.fill_ovf + 1;
-  pa.fallback = pa.fill_spill + 1;
-  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
-  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
-  // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
-  const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
-  const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
-  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
-  if (k32) {
-    launch_part_scatter<1, int32_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int32_t>(pa.tw, dim3(g2), lds2, s, pa);
-    if (simple) {
-      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      }
-    } else {
-      hipLaunchKernelGGL(hdk_part_aggregate<int32_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-    }
-    hipLaunchKernelGGL(hdk_part_overflow<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
-  } else {
-    launch_part_scatter<1, int64_t>(pa.tw, dim3(g1), lds1, s, pa);
-    launch_part_scatter<2, int64_t>(pa.tw, dim3(g2), lds2, s, pa);
-    if (simple) {
-      if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM && pa.simple_skip) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 1>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else if (pa.tw == 2 && pa.simple_agg == HDK_AGG_SUM) {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t, 2, HDK_AGG_SUM, 0>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      } else {
-        hipLaunchKernelGGL((hdk_part_aggregate_simple<int64_t>), dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-      }
-    } else {
-      hipLaunchKernelGGL(hdk_part_aggregate<int64_t>, dim3(pa.fine_count), dim3(kPartAggBlock), table_bytes, s, pa);
-    }
-    hipLaunchKernelGGL(hdk_part_overflow<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
-  }
-  // armed fallback: runs only if the scatter passes found the data too skewed for slabs
+  pa.fill1 = reinterpret_cast<uint32_t*>(q); q += up(bc1);
+  part_carve_tail(pa, q, false, &bc2, &cur2);
+  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc1, s));
+  HDK_HIP_CHECK(hipMemsetAsync(cur2, 0, bc2, s));
+  pa.nsrc = 1;
+  pa.src_slab[0] = pa.slab1;
+  pa.src_fill[0] = pa.fill1;
+  pa.src_fill_stride = kPartCursorStride;
+  launch_part_scatter<1>(pa, k32, dim3(g1), lds1, s);
+  launch_part_tail(plan, pa, props, s);
+  // armed fallback: runs only if the scatter passes found the data too skewed for slabs (or the statistics stale)
   BaseFastArgs bf;
   match_baseline_fast(plan, &bf);
   bf.plan = d_plan;
@@ -368,6 +470,109 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   launch_baseline_direct(plan, bf, shape.grid, s);
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;  // (`scratch` goes back to the pool here, stream-ordered)
+}
+
+// ---- multi-GPU tuple exchange (include/hdk_hip.h: hdk_hip_exchange_shape_for / scatter_to_owners / aggregate_from_ranks) ----
+static size_t exchange_cursor_bytes(const PartArgs& pa) {
+  // level-1 cursors one per 128-byte line, then the flag word
+  return (static_cast<size_t>(pa.owners) * pa.p1 * kPartXcds * kPartCursorStride + 64) * sizeof(uint32_t);
+}
+
+int32_t exchange_shape(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, int32_t num_owners,
+                       uint32_t owner_entry_count, PartArgs* pa, hdk_hip_exchange_shape* out) {
+  HDK_REQUIRE(num_owners >= 2 && num_owners <= kPartMaxSrc, "num_owners must be in [2, %d]", kPartMaxSrc);
+  HDK_REQUIRE(ko && ko->total_rows, "hdk_hip_kernel_options::total_rows (the per-rank row bound) is required");
+  if (plan->query_kind != HDK_Q_BASELINE_HASH || !part_tuple_shape(plan, pa) ||
+      !part_geometry(plan, ko->total_rows, owner_entry_count, static_cast<uint32_t>(num_owners), pa)) {
+    set_error("plan or table geometry outside the radix-partitioned group-by's shape");
+    return HDK_HIP_ERR_UNSUPPORTED;
+  }
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  pa->seg_header_bytes = up((static_cast<size_t>(pa->p1) * kPartXcds + 1) * sizeof(uint32_t));
+  pa->seg_bytes = pa->seg_header_bytes + up(static_cast<size_t>(pa->p1) * pa->cap1 * pa->tw * 8);
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    out->num_owners = static_cast<uint32_t>(num_owners);
+    out->owner_entry_count = owner_entry_count;
+    out->tuple_bytes = static_cast<uint32_t>(pa->tw * 8);
+    out->coarse_per_owner = pa->p1;
+    out->regions_log2 = pa->p2_log2;
+    out->sub_slab_tuples = pa->sub1;
+    out->segment_header_bytes = pa->seg_header_bytes;
+    out->segment_bytes = pa->seg_bytes;
+    out->rows_bound = ko->total_rows;
+    out->scatter_workspace_bytes = kPlanRegionBytes + up(exchange_cursor_bytes(*pa));
+    size_t bc2 = 0;
+    uint32_t* cur2 = nullptr;
+    PartArgs tmp = *pa;
+    out->aggregate_workspace_bytes = kPlanRegionBytes + part_carve_tail(tmp, nullptr, true, &bc2, &cur2);
+  }
+  return HDK_HIP_OK;
+}
+
+// the shape the caller hands back must be the one shape_for computes for the same arguments
+static int32_t exchange_args(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                             PartArgs* pa) {
+  HDK_REQUIRE(shape, "shape is NULL");
+  hdk_hip_exchange_shape want;
+  const int32_t st = exchange_shape(plan, ko, static_cast<int32_t>(shape->num_owners), shape->owner_entry_count, pa, &want);
+  if (st) return st;
+  HDK_REQUIRE(memcmp(&want, shape, sizeof(want)) == 0, "exchange shape does not belong to this plan / row bound");
+  return HDK_HIP_OK;
+}
+
+int32_t launch_scatter_to_owners(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                 const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape, int8_t* send,
+                                 int8_t* cursors, const hdk_hip_device_properties* props, hipStream_t s) {
+  PartArgs pa;
+  const int32_t st = exchange_args(plan, ko, shape, &pa);
+  if (st) return st;
+  pa.plan = d_plan;
+  pa.kp = kp;
+  pa.send = send;
+  const bool k32 = plan->key_width == 4;
+  const size_t bc = exchange_cursor_bytes(pa);
+  pa.fill1 = reinterpret_cast<uint32_t*>(cursors);
+  pa.fallback = pa.fill1 + static_cast<size_t>(pa.owners) * pa.p1 * kPartXcds * kPartCursorStride;
+  pa.fill_ovf = pa.fallback + 1;  // (never used: a scatter to owners has no overflow area)
+  HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
+  const size_t lds1 = part_scatter_lds_bytes(pa.owners * pa.p1, 0, pa.tw, pa.narrow != 0);
+  unsigned g1 = resident_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
+  const uint64_t tile = static_cast<uint64_t>(part_tile(pa.narrow != 0));
+  const uint64_t tiles = (pa.total_rows + tile - 1) / tile;
+  if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
+  launch_part_scatter<1>(pa, k32, dim3(g1), lds1, s);
+  hipLaunchKernelGGL(hdk_part_publish, dim3(pa.owners), dim3(256), 0, s, pa);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                    const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                                    const int8_t* recv, int8_t* scratch, const hdk_hip_device_properties* props,
+                                    hipStream_t s) {
+  PartArgs pa;
+  const int32_t st = exchange_args(plan, ko, shape, &pa);
+  if (st) return st;
+  pa.plan = d_plan;
+  pa.kp = kp;
+  pa.init_output = 1;  // pass 3 writes every region of the owner's table
+  size_t bc2 = 0;
+  uint32_t* cur2 = nullptr;
+  part_carve_tail(pa, scratch, true, &bc2, &cur2);
+  HDK_HIP_CHECK(hipMemsetAsync(cur2, 0, bc2, s));
+  pa.nsrc = pa.owners;
+  for (uint32_t r = 0; r < pa.owners; ++r) {
+    const int8_t* seg = recv + static_cast<size_t>(r) * pa.seg_bytes;
+    pa.src_fill[r] = reinterpret_cast<const uint32_t*>(seg);
+    pa.src_slab[r] = reinterpret_cast<const int64_t*>(seg + pa.seg_header_bytes);
+  }
+  pa.src_fill_stride = 1;
+  pa.owners = 0;  // from here on this is a one-table job: the owner's
+  hipLaunchKernelGGL(hdk_part_collect_flags, dim3(1), dim3(64), 0, s, pa);
+  launch_part_tail(plan, pa, props, s);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
 }
 
 static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
@@ -450,3 +655,87 @@ int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, co
 }
 
 }  // namespace hdk
+
+using namespace hdk;
+
+// ---- multi-GPU tuple exchange: the C ABI (include/hdk_hip.h) ---------------------------------------------------------
+extern "C" int32_t hdk_hip_exchange_shape_for(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
+                                              int32_t num_owners, uint32_t owner_entry_count, int32_t device_id,
+                                              hdk_hip_exchange_shape* shape) {
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(shape, "shape is NULL");
+  (void)device_id;  // (the geometry depends on the LDS budget of gfx950 only; kept for per-device tuning)
+  PartArgs pa;
+  return exchange_shape(plan, ko, num_owners, owner_entry_count, &pa, shape);
+}
+
+static int32_t exchange_enter(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], const hdk_hip_exchange_shape* shape,
+                              const void* buf, void* workspace, size_t workspace_bytes, size_t need, int32_t device_id,
+                              void* stream, hipStream_t* s) {
+  const int32_t st = validate_plan(plan);
+  if (st) return st;
+  HDK_REQUIRE(params && shape && buf, "NULL argument");
+  HDK_REQUIRE(params[HDK_KP_ERROR_CODE], "ERROR_CODE is NULL");
+  HDK_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 255) == 0, "exchange buffers must be 256-byte aligned");
+  HDK_REQUIRE(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu", workspace_bytes, need);
+  HDK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  return device_enter(device_id, stream, s);
+}
+
+extern "C" int32_t hdk_hip_scatter_to_owners(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                                             const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                                             int8_t* send, int32_t device_id, void* stream, void* workspace,
+                                             size_t workspace_bytes) {
+  hipStream_t s;
+  int32_t st = exchange_enter(plan, params, shape, send, workspace, workspace_bytes,
+                              shape ? static_cast<size_t>(shape->scatter_workspace_bytes) : 0, device_id, stream, &s);
+  if (st) return st;
+  HDK_REQUIRE(params[HDK_KP_COL_BUFFERS] && params[HDK_KP_NUM_FRAGMENTS] && params[HDK_KP_NUM_ROWS] && params[HDK_KP_NUM_TABLES],
+              "a required kernel parameter is NULL");
+  hdk_hip_plan* d_plan = nullptr;
+  KernParams kp;
+  st = launch_head(plan, params, ko, device_id, workspace, s, &d_plan, &kp);
+  if (st) return st;
+  const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    st = scan_events_begin(device_id, s, &e0, &e1);
+    if (st) return st;
+  }
+  st = launch_scatter_to_owners(plan, d_plan, kp, ko, shape, send, static_cast<int8_t*>(workspace) + kPlanRegionBytes,
+                                device_props(device_id), s);
+  if (st) return st;
+  if (timed) {
+    HDK_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  return HDK_HIP_OK;
+}
+
+extern "C" int32_t hdk_hip_aggregate_from_ranks(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                                                const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                                                const int8_t* recv, int32_t device_id, void* stream, void* workspace,
+                                                size_t workspace_bytes) {
+  hipStream_t s;
+  int32_t st = exchange_enter(plan, params, shape, recv, workspace, workspace_bytes,
+                              shape ? static_cast<size_t>(shape->aggregate_workspace_bytes) : 0, device_id, stream, &s);
+  if (st) return st;
+  HDK_REQUIRE(params[HDK_KP_GROUPBY_BUF] && params[HDK_KP_INIT_AGG_VALS], "GROUPBY_BUF / INIT_AGG_VALS is NULL");
+  hdk_hip_plan* d_plan = nullptr;
+  KernParams kp;
+  st = launch_head(plan, params, ko, device_id, workspace, s, &d_plan, &kp);
+  if (st) return st;
+  const bool timed = ko && (ko->flags & HDK_HIP_LAUNCH_RECORD_EVENTS);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    st = scan_events_begin(device_id, s, &e0, &e1);
+    if (st) return st;
+  }
+  st = launch_aggregate_from_ranks(plan, d_plan, kp, ko, shape, recv, static_cast<int8_t*>(workspace) + kPlanRegionBytes,
+                                   device_props(device_id), s);
+  if (st) return st;
+  if (timed) {
+    HDK_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  return HDK_HIP_OK;
+}

@@ -14,6 +14,11 @@ the devices:
     by owner = mulhi(key_hash, G), one all-to-all moves each entry to its owner, the owner re-inserts
     what it received (reduceOneEntryBaseline); the result is the concatenation of the owners'
     disjoint tables (reduce_baseline_multi_gpu).
+  * baseline-hash plans of the radix-partitioned shape (C5) exchange TUPLES instead (TupleExchange): a rank
+    never builds a table of its own -- pass 1 of the radix-partitioned group-by scatters its rows straight
+    into per-owner segments of fixed size, ONE all-to-all with equal splits moves them (no counts, no host
+    synchronisation), every owner runs passes 2-4 over what it received into a table sized for ITS keys.
+    The table exchange stays as the fallback for skewed keys and for plans outside that shape.
 The collective calls are backend-agnostic (gloo on CPU in the tests); the merge itself is the HIP
 kernel and needs a device.
 """
@@ -231,3 +236,69 @@ def reduce_baseline_multi_gpu(cp, table, world_size: int, rank: int, device_id: 
         # library kernels, torch copies and the RCCL all-to-all are all ordered on ONE torch stream
         return run_ordered(table.device, steps)
     return steps(stream)
+
+
+# ---- baseline hash: tuple exchange (include/hdk_hip.h: hdk_hip_exchange_shape_for & co) -----------------------------
+def owner_entry_count_for(entry_count: int, world_size: int) -> int:
+    """Entries of an owner's table: the plan's table (2 x the NDV estimate, QE/RelAlgExecutor.cpp:1553-1557) split
+    evenly -- an owner holds 1 / G of the keys (owner = mulhi32(key_hash, G))."""
+    return max(-(-int(entry_count) // int(world_size)), 1024)
+
+
+class TupleExchange:
+    """One rank's side of a multi-GPU open-addressing group-by: scatter -> all-to-all -> aggregate.
+
+    `step` is the rank's PreparedStep whose output buffer (GROUPBY_BUF[0]) is the OWNER table of this rank
+    (`owner_table_quads` words); `rows_bound` is the same upper bound on a rank's rows on every rank."""
+
+    def __init__(self, step, world_size: int, rows_bound: int, owner_entry_count: Optional[int] = None, flags: int = 0):
+        import torch
+        from ._lib import check, lib
+        self.torch, self.L, self.check = torch, lib(), check
+        self.step, self.world, self.dev = step, int(world_size), step.dev
+        cp = step.cp
+        self.owner_entries = int(owner_entry_count or owner_entry_count_for(cp.entry_count, world_size))
+        self.ko = A.KernelOptions.from_buffer_copy(step.ko)
+        self.ko.total_rows = int(rows_bound)
+        self.ko.flags = int(flags)
+        self.shape = A.ExchangeShape()
+        check(self.L.hdk_hip_exchange_shape_for(C.byref(step.plan), C.byref(self.ko), self.world, self.owner_entries,
+                                                self.dev, C.byref(self.shape)))
+        device = torch.device("cuda", self.dev)
+        n = self.world * int(self.shape.segment_bytes)
+        self.send = torch.empty(n, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(n, dtype=torch.uint8, device=device)
+        self.ws_scatter = torch.empty(int(self.shape.scatter_workspace_bytes), dtype=torch.uint8, device=device)
+        self.ws_aggregate = torch.empty(int(self.shape.aggregate_workspace_bytes), dtype=torch.uint8, device=device)
+
+    @property
+    def owner_table_quads(self) -> int:
+        return baseline_table_quads(self.step.cp, self.owner_entries)
+
+    @property
+    def bytes_sent_per_rank(self) -> int:
+        return (self.world - 1) * int(self.shape.segment_bytes)
+
+    def scatter(self, stream):
+        self.check(self.L.hdk_hip_scatter_to_owners(C.byref(self.step.plan), self.step._params, C.byref(self.ko),
+                                                    C.byref(self.shape), self.send.data_ptr(), self.dev, stream,
+                                                    self.ws_scatter.data_ptr(), self.ws_scatter.numel()))
+
+    def exchange(self, group=None):
+        """Segment o of `send` goes to rank o and lands as segment `rank` of its `recv`: equal splits, sizes known
+        up front (RCCL all-to-all over xGMI; gloo in the CPU tests)."""
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            self.recv.copy_(self.send)
+            return
+        dist.all_to_all_single(self.recv, self.send, group=group)
+
+    def aggregate(self, stream, recv=None):
+        r = self.recv if recv is None else recv
+        self.check(self.L.hdk_hip_aggregate_from_ranks(C.byref(self.step.plan), self.step._params, C.byref(self.ko),
+                                                       C.byref(self.shape), r.data_ptr(), self.dev, stream,
+                                                       self.ws_aggregate.data_ptr(), self.ws_aggregate.numel()))
+
+    def segment(self, buf, i):
+        n = int(self.shape.segment_bytes)
+        return buf[i * n:(i + 1) * n]

@@ -26,6 +26,11 @@ struct HipInputCol {
   int32_t table;  // 0 outer, j > 0 inner table of join j - 1
   int32_t width;
   int32_t kind;   // hdk_hip_col_kind
+  // ChunkStats over the fragments the step reads (ChunkMetadata::chunkStats, DataMgr/ChunkMetadata.h); 0 = unknown
+  int32_t has_stats = 0;
+  int32_t has_nulls = 0;
+  int64_t min_val = 0;
+  int64_t max_val = 0;
 };
 
 // one target as get_target_info sees it (Shared/TargetInfo.h:89-160), argument already in ABI form
@@ -83,6 +88,11 @@ hdk_hip_plan make_plan(const HipWorkUnit& wu, const QMD& qmd) {
     p.cols[i].table = wu.cols[i].table;
     p.cols[i].width = wu.cols[i].width;
     p.cols[i].kind = wu.cols[i].kind;
+    // ChunkStats of the column over the fragments of the work unit (DataMgr/ChunkMetadata.h; 0 = unknown)
+    p.cols[i].has_stats = wu.cols[i].has_stats;
+    p.cols[i].has_nulls = wu.cols[i].has_nulls;
+    p.cols[i].min_val = wu.cols[i].min_val;
+    p.cols[i].max_val = wu.cols[i].max_val;
   }
   p.num_quals = static_cast<int32_t>(wu.quals.size());
   for (size_t i = 0; i < wu.quals.size(); ++i) p.quals[i] = wu.quals[i];

@@ -525,6 +525,12 @@ def _fill_cols(storage: ArrowStorage, b: "_Binder", p: A.Plan):
             c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
         else:
             c.kind = A.COL_INT
+            # ChunkStats of the column (the reference's planner reads them through getExpressionRange,
+            # QE/ExpressionRange.cpp): lets multi-pass strategies move the column in fewer bytes than its width
+            st = storage.get(tn).columns[cn].table_stats()
+            if st.min is not None and st.max is not None and -(2**63) <= int(st.min) <= int(st.max) < 2**63:
+                c.has_stats, c.has_nulls = 1, 1 if st.has_nulls else 0
+                c.min_val, c.max_val = int(st.min), int(st.max)
 
 
 def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
@@ -886,6 +892,12 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
             c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
         else:
             c.kind = A.COL_INT
+            # ChunkStats of the column (the reference's planner reads them through getExpressionRange,
+            # QE/ExpressionRange.cpp): lets multi-pass strategies move the column in fewer bytes than its width
+            st = storage.get(tn).columns[cn].table_stats()
+            if st.min is not None and st.max is not None and -(2**63) <= int(st.min) <= int(st.max) < 2**63:
+                c.has_stats, c.has_nulls = 1, 1 if st.has_nulls else 0
+                c.min_val, c.max_val = int(st.min), int(st.max)
     return CompiledPlan(plan=p, query=q, init_vals=np.array(init_vals, dtype=np.int64),
                         slot_widths=slot_widths, input_cols=list(b.cols),
                         inner_tables=[t.name for t in b.inner], join_infos=join_infos,

@@ -55,6 +55,9 @@ extern "C" {
 #define HDK_HIP_ERR_UNSUPPORTED 100 /* plan shape outside the fixed library -> QueryMustRunOnCpu */
 #define HDK_HIP_ERR_INVALID_ARG 101
 #define HDK_HIP_ERR_RUNTIME 102 /* a HIP runtime call failed; see hdk_hip_last_error() */
+#define HDK_HIP_ERR_EXCHANGE_INCOMPLETE 103 /* device code of hdk_hip_aggregate_from_ranks: a rank's segment was flagged
+                                               (a sub-slab overflowed: skewed keys; stale column statistics; or the
+                                               scatter was interrupted) -- redo the step with the table exchange */
 #define HDK_HIP_ERR_JOIN_SLOT_TAKEN (-1) /* one-to-one build hit a duplicate key (JoinHashImpl.h:55-66) */
 
 const char* hdk_hip_last_error(void);
@@ -161,6 +164,17 @@ typedef struct hdk_hip_col {
                         HDK_JOIN_ONE_TO_ONE_FUSED): no column buffer is read */
   int32_t width;     /* bytes per element */
   int32_t kind;      /* hdk_hip_col_kind */
+  /* Statistics of the column over the fragments of the launch: the ChunkStats {min, max, has_nulls} every chunk's
+   * metadata carries (omniscidb/DataMgr/ChunkMetadata.h) and the reference's planner reads through
+   * getExpressionRange (QE/ExpressionRange.cpp) to choose hash layouts.  Here they also let a multi-pass strategy
+   * move a column in fewer bytes than its physical width (8-byte tuples in the radix-partitioned group-by when key
+   * and argument both fit 32 bits).  Optional: has_stats = 0 means unknown.  They must hold for every element read;
+   * the kernels that rely on them notice a value outside and redo the launch at full width (no wrong result from
+   * stale metadata, only a slower one). */
+  int32_t has_stats; /* 1: min_val / max_val / has_nulls below are valid (integer columns only) */
+  int32_t has_nulls; /* ChunkStats::has_nulls: some element is the in-band NULL */
+  int64_t min_val;   /* bounds of the non-NULL elements */
+  int64_t max_val;
 } hdk_hip_col;
 
 /* Expression: a short left-to-right chain  acc = leaf0; acc = op_i(acc, leaf_i)  i < nsteps.
@@ -344,7 +358,7 @@ typedef struct hdk_hip_plan {
   int32_t num_targets;
   hdk_hip_target targets[HDK_HIP_MAX_TARGETS];
 } hdk_hip_plan;
-#define HDK_HIP_PLAN_ABI 3u
+#define HDK_HIP_PLAN_ABI 4u
 
 /* ------------------------------------------------------------------------------------------
  * Kernel launch.
@@ -500,6 +514,61 @@ int32_t hdk_hip_partition_baseline_count(const hdk_hip_plan* plan, const int64_t
 int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf, uint32_t entry_count,
                                    const int64_t* init_vals, int32_t num_owners, const uint32_t* counts,
                                    int64_t* const* seg_bufs, int32_t device_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU open-addressing group-by by TUPLE exchange (MI355X addition; replaces, for plans of the
+ * radix-partitioned shape, per-device tables + host merge: Executor::reduceMultiDeviceResultSets,
+ * QE/Execute.cpp:1224-1336, reduceOneEntryBaseline, QE/ResultSetReduction.cpp:694-731).  Keys are split by owner =
+ * mulhi32(key_hash(key), num_owners); owner o ends with an open-addressing table of `owner_entry_count` entries in
+ * the plan's layout holding exactly its keys, each group where the reference's probe sequence
+ * (key_hash % owner_entry_count, then linearly on) finds it; the query result is the concatenation of the owners'
+ * tables.  One step of rank r:
+ *     hdk_hip_exchange_shape_for(plan, ko, G, owner_entry_count, &shape)      the same on every rank (host only)
+ *     hdk_hip_scatter_to_owners(plan, params, ko, &shape, send, ...)          pass 1 over the rank's fragments:
+ *                                                                              (filtered) rows -> tuples -> G segments
+ *     all-to-all with EQUAL splits of shape.segment_bytes (RCCL over xGMI; segment o of `send` goes to rank o and
+ *                                                          lands as segment r of its `recv`) -- sizes are static,
+ *                                                          no counts are exchanged and the host never waits
+ *     hdk_hip_aggregate_from_ranks(plan, params, ko, &shape, recv, ...)       passes 2-4 over the G received segments
+ *                                                                              into GROUPBY_BUF[0] (the owner's table,
+ *                                                                              initialised by the call itself)
+ * Tuples are as narrow as the plan's column statistics allow (8 bytes when key and argument fit 32 bits each, else
+ * 16 / 24).  `ko->total_rows` must be the SAME upper bound on a rank's outer rows on every rank (it sizes the
+ * segments).  Skewed keys (one owner sub-slab overflowing), stale statistics or an interrupt flag the segments; the
+ * owner's call then leaves ERROR_CODE = HDK_HIP_ERR_EXCHANGE_INCOMPLETE and the caller redoes the step with partial
+ * tables (hdk_hip_launch + hdk_hip_partition_baseline + hdk_hip_reduce_buffers), which has no such limit.
+ * Plans outside the radix-partitioned shape (hdk_scan_agg_baseline_direct's: row-wise, 1-2 plain integer key columns,
+ * plain-column arguments, `column cmp literal` filters) get HDK_HIP_ERR_UNSUPPORTED from shape_for.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hdk_hip_exchange_shape {
+  uint32_t num_owners;         /* G */
+  uint32_t owner_entry_count;  /* entries of every owner's table */
+  uint32_t tuple_bytes;        /* 8, 16 or 24 */
+  uint32_t coarse_per_owner;   /* level-1 bins per owner (G x this <= 256) */
+  uint32_t regions_log2;       /* regions of the owner's table per coarse slab = 1 << this */
+  uint32_t reserved_;
+  uint64_t sub_slab_tuples;    /* capacity of one (coarse slab, XCD) sub-slab */
+  uint64_t segment_header_bytes;
+  uint64_t segment_bytes;      /* one rank -> owner segment: header + coarse_per_owner x 8 sub-slabs; `send` and `recv`
+                                  are num_owners segments each */
+  uint64_t rows_bound;         /* ko->total_rows the shape was made for */
+  uint64_t scatter_workspace_bytes;   /* `workspace` of hdk_hip_scatter_to_owners */
+  uint64_t aggregate_workspace_bytes; /* `workspace` of hdk_hip_aggregate_from_ranks */
+} hdk_hip_exchange_shape;
+int32_t hdk_hip_exchange_shape_for(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, int32_t num_owners,
+                                   uint32_t owner_entry_count, int32_t device_id, hdk_hip_exchange_shape* shape);
+/* `params`: the 12 launch pointers of hdk_hip_launch (GROUPBY_BUF unused); `send`: num_owners x segment_bytes of device
+ * memory, 256-byte aligned.  Honours HDK_HIP_LAUNCH_CHECK_INTERRUPT / watchdog_ms / RECORD_EVENTS of `ko`. */
+int32_t hdk_hip_scatter_to_owners(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                                  const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape, int8_t* send,
+                                  int32_t device_id, void* stream, void* workspace, size_t workspace_bytes);
+/* `params`: GROUPBY_BUF[0] = the owner's table (hdk_hip_baseline_table_quads(plan, owner_entry_count) words, written
+ * completely: no initialisation needed), INIT_AGG_VALS and ERROR_CODE as for hdk_hip_launch; the other entries are
+ * not read.  `recv`: the num_owners segments this owner received, in rank order. */
+int32_t hdk_hip_aggregate_from_ranks(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT],
+                                     const hdk_hip_kernel_options* ko, const hdk_hip_exchange_shape* shape,
+                                     const int8_t* recv, int32_t device_id, void* stream, void* workspace,
+                                     size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Hash-join table build (perfect hash).

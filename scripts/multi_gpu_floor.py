@@ -11,7 +11,12 @@ build; the wire is the only piece left out).
           after another; owner 0's inbox is assembled from their segments.  Reported per piece: shard scan,
           partition count (+ host sync), partition scatter, owner-table init, owner re-insert.
 
-    python scripts/multi_gpu_floor.py [--only a,b] [--world 8] [--steps 20]
+  part C  C5, the tuple exchange (hdk_hip_scatter_to_owners / hdk_hip_aggregate_from_ranks): every rank scatters its
+          shard straight into per-owner segments, the all-to-all is emulated by device copies, every owner
+          aggregates its inbox into a table sized for its keys.  Reported: scatter ms per rank, aggregate ms per
+          owner, bytes on the wire, and the full-size checks (sum of sums, number of groups, owners disjoint).
+
+    python scripts/multi_gpu_floor.py [--only a,b,c] [--world 8] [--steps 20]
 """
 import argparse
 import ctypes as C
@@ -179,6 +184,81 @@ def part_b(args, mgr):
     return res
 
 
+def part_c(args, mgr):
+    import torch
+    from hdk_amd import _abi as A
+    from hdk_amd import distributed as D
+    from workloads import Workload, fragment_rows
+    world, dev = args.world, 0
+    rows = 1_000_000_000
+    nfrag = len(fragment_rows(rows))
+    frs = fragment_rows(rows)
+    bound = max(sum(frs[f] for f in D.shard_fragments(nfrag, world, r)) for r in range(world))
+    ts = torch.cuda.Stream(device=dev)
+    h = ts.cuda_stream
+    xs, tables, per_rank, want_sum, keys_seen = [], [], [], 0, []
+    for r in range(world):
+        w = Workload("c5", rows, dev, mgr, frag_ids=D.shard_fragments(nfrag, world, r))
+        cp = w.compiled
+        probe = w.ex.prepare(cp, w.frag_ids)
+        x = D.TupleExchange(probe, world, bound)
+        table = torch.empty(x.owner_table_quads, dtype=torch.int64, device="cuda")
+        probe.free()
+        step = w.ex.prepare(cp, w.frag_ids, out_ptr=table.data_ptr())
+        x = D.TupleExchange(step, world, bound)
+        with torch.cuda.stream(ts):
+            x.scatter(h)
+            torch.cuda.synchronize()
+            ms = ev_ms(torch, ts, lambda: x.scatter(h), args.steps)
+        want_sum = (want_sum + w.reference_checks()["sum_val"]) % (1 << 64)
+        keys_seen.append(torch.unique(torch.cat([w.cols[w.key_col][f] for f in w.frag_ids])))
+        per_rank.append({"rank": r, "rows": w.local_rows, "scatter_ms": ms, "tuple_bytes": int(x.shape.tuple_bytes),
+                         "segment_bytes": int(x.shape.segment_bytes), "bytes_to_other_owners": x.bytes_sent_per_rank,
+                         "coarse_per_owner": int(x.shape.coarse_per_owner)})
+        print(json.dumps(per_rank[-1]), flush=True)
+        xs.append(x)
+        tables.append(table)
+        # the inputs are not needed any more: only the send buffers are
+        w.ex.cache.clear() if hasattr(w.ex.cache, "clear") else None
+        for k in list(w.cols):
+            w.cols[k] = {}
+        del w
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    distinct = int(torch.unique(torch.cat(keys_seen)).numel())
+    del keys_seen
+    per_owner, got_sum, groups, all_keys = [], 0, 0, []
+    for o in range(world):
+        x = xs[o]
+        with torch.cuda.stream(ts):
+            for r in range(world):
+                x.segment(x.recv, r).copy_(xs[r].segment(xs[r].send, o))
+            x.aggregate(h)
+            torch.cuda.synchronize()
+            ms = ev_ms(torch, ts, lambda: x.aggregate(h), args.steps)
+        err = int(x.step.mgr.to_host(x.step.d_err.ptr, 4, dev, np.int32)[0])
+        cp = x.step.cp
+        rq, ne = int(cp.plan.row_size_quad), x.owner_entries
+        rows_t = tables[o][:ne * rq].view(ne, rq)
+        keys = (rows_t[:, 0] << 32) >> 32 if cp.plan.key_width == 4 else rows_t[:, 0]
+        live = keys != (A.EMPTY_KEY_32 if cp.plan.key_width == 4 else A.EMPTY_KEY_64)
+        sq = int(cp.plan.targets[1].slot_off) // 8
+        got_sum = (got_sum + int(rows_t[:, sq][live].sum().item())) % (1 << 64)
+        groups += int(live.sum().item())
+        all_keys.append(keys[live])
+        per_owner.append({"owner": o, "aggregate_ms": ms, "groups": int(live.sum().item()), "entries": ne, "error": err})
+        print(json.dumps(per_owner[-1]), flush=True)
+    allk = torch.cat(all_keys)
+    res = {"per_rank": per_rank, "per_owner": per_owner,
+           "step_ms_wire_excluded": max(p["scatter_ms"] for p in per_rank) + max(p["aggregate_ms"] for p in per_owner),
+           "checks": {"sum_of_sums": got_sum == want_sum, "groups": groups, "groups_equal_distinct_keys": groups == distinct,
+                      "owners_disjoint": int(torch.unique(allk).numel()) == int(allk.numel())}}
+    res["projected_rows_per_s_at_%d_gpus_wire_excluded" % world] = rows / (res["step_ms_wire_excluded"] * 1e-3)
+    print(json.dumps({"c5_tuple_exchange": {k: v for k, v in res.items() if k not in ("per_rank", "per_owner")}}), flush=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="a,b")
@@ -198,6 +278,8 @@ def main():
         out["perfect_hash_shard_floor"] = part_a(args, mgr)
     if "b" in args.only:
         out["c5_table_exchange_merge"] = part_b(args, mgr)
+    if "c" in args.only:
+        out["c5_tuple_exchange"] = part_c(args, mgr)
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)

@@ -16,8 +16,8 @@ from util import assert_buffers_equal, run_oracle
 pytestmark = pytest.mark.gpu
 
 
-def _rows(cp, buf):
-    cols = rs.to_columns(cp, buf)
+def _rows(cp, buf, entry_count=None):
+    cols = rs.to_columns(cp, buf, entry_count)
     names = list(cols)
     return sorted(zip(*[cols[n] for n in names]), key=lambda r: tuple((x is None, x) for x in r[:cp.plan.key_count]))
 
@@ -179,6 +179,142 @@ def test_multi_gpu_baseline_merge_emulated(oracle, gpu_executor_factory, columna
     # balance: mulhi(hash, G) spreads the keys evenly
     per_owner = np.sum(np.array(counts, dtype=np.int64), axis=0)
     assert per_owner.min() > 0.8 * per_owner.mean()
+
+
+def _exchange_tables(cp, ex, st, world, flags=0, rows_bound=None):
+    """The multi-GPU tuple exchange with the ranks emulated one after another on one device (hdk_amd.distributed.
+    TupleExchange): every rank scatters its fragments to `world` owner segments, the all-to-all is a device copy,
+    every owner aggregates its inbox.  Returns ([owner table (numpy int64)], owner entry count, [exchange])."""
+    import torch
+    from hdk_amd import distributed as D
+    nfrag = len(st.get(cp.query.table).frag_rows)
+    frag_rows = st.get(cp.query.table).frag_rows
+    shards = [D.shard_fragments(nfrag, world, r) for r in range(world)]
+    bound = rows_bound or max(sum(frag_rows[f] for f in sh) for sh in shards)
+    h = torch.cuda.current_stream().cuda_stream
+    xs, tables = [], []
+    for r in range(world):
+        probe = ex.prepare(cp, frag_ids=shards[r])
+        x = D.TupleExchange(probe, world, bound, flags=flags)
+        table = torch.empty(x.owner_table_quads, dtype=torch.int64, device="cuda")
+        probe.free()
+        step = ex.prepare(cp, frag_ids=shards[r], out_ptr=table.data_ptr())
+        x = D.TupleExchange(step, world, bound, flags=flags)
+        x.scatter(h)
+        xs.append(x)
+        tables.append(table)
+    torch.cuda.synchronize()
+    out = []
+    for o in range(world):  # what the all-to-all delivers to owner o: segment o of every rank, in rank order
+        x = xs[o]
+        for r in range(world):
+            x.segment(x.recv, r).copy_(xs[r].segment(xs[r].send, o))
+        x.aggregate(h)
+        torch.cuda.synchronize()
+        out.append(tables[o].cpu().numpy())
+    return out, xs[0].owner_entries, xs
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("shape,world", [("narrow", 8), ("narrow_nulls", 2), ("wide_key", 4), ("wide_val", 3),
+                                          ("multi_target", 4), ("count_only", 2), ("filtered", 8)])
+def test_multi_gpu_tuple_exchange_emulated(oracle, gpu_executor_factory, shape, world):
+    """hdk_hip_scatter_to_owners + hdk_hip_aggregate_from_ranks: the union of the owners' tables is the oracle's result
+    of the whole query, owners are disjoint, every owner's table has the reference's placement for ITS entry count,
+    and the error word stays 0.  Shapes: 8-byte tuples (key and argument fit 32 bits, with and without NULLs), 16-byte
+    tuples (8-byte table key / argument outside 32 bits), 24-byte tuples through the general aggregation kernel,
+    key-only tuples, a filtered scan."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 600_000
+    key_small = rng.integers(0, 40_000, n, dtype=np.int64) * 7 - 50_000          # fits 32 bits -> 4-byte table key
+    key_big = rng.integers(0, 40_000, n, dtype=np.int64) * 3_000_000_019 - 2**40  # 8-byte table key
+    val32 = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    val32n = rng.integers(-2**31 + 1, 2**31, n, dtype=np.int64)
+    val32n[rng.random(n) < 0.03] = A.NULL_BIGINT
+    val64 = rng.integers(-2**40, 2**40, n, dtype=np.int64)
+    val64[rng.random(n) < 0.03] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"ks": key_small, "kb": key_big, "v32": val32, "v32n": val32n, "v64": val64,
+                          "f": rng.normal(size=n), "c": rng.integers(0, 100, n).astype(np.int32)}, fragment_size=50_000)
+    K, tuple_bytes = {"narrow": ("ks", 8), "narrow_nulls": ("ks", 8), "wide_key": ("kb", 16), "wide_val": ("ks", 16),
+                      "multi_target": ("ks", 24), "count_only": ("kb", 8), "filtered": ("ks", 8)}[shape]
+    targets = {"narrow": [Agg("sum", ColRef("v32"), "s")],
+               "narrow_nulls": [Agg("sum", ColRef("v32n"), "s")],
+               "wide_key": [Agg("sum", ColRef("v32n"), "s")],
+               "wide_val": [Agg("max", ColRef("v64"), "m")],
+               "multi_target": [Agg("sum", ColRef("v64"), "s"), Agg("count", None, "c"), Agg("min", ColRef("v64"), "mn"),
+                                Agg("avg", ColRef("f"), "af")],
+               "count_only": [Agg("count", None, "c")],
+               "filtered": [Agg("min", ColRef("v32n"), "mn"), Agg("count", ColRef("v32n"), "cn")]}[shape]
+    quals = [Cmp(ColRef("c"), "<", Lit(37))] if shape == "filtered" else []
+    q = QueryUnit("t", groupby=[ColRef(K)], quals=quals, force_baseline=True, baseline_entry_count=131_071,
+                  targets=[KeyRef(0, "key")] + targets)
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    tables, owner_entries, xs = _exchange_tables(cp, ex, st, world)
+    assert xs[0].shape.tuple_bytes == tuple_bytes, (shape, xs[0].shape.tuple_bytes)
+    assert owner_entries < cp.entry_count  # an owner's table is sized for its share of the keys
+    all_rows = []
+    for o, t in enumerate(tables):
+        all_rows.extend(_rows(cp, t, owner_entries))
+        _assert_reference_placement(oracle, cp, t, owner_entries)
+    for x in xs:
+        assert int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) == 0
+    keys = [r[0] for r in all_rows]
+    assert len(keys) == len(set(keys))  # owners are disjoint
+    w = _rows(cp, want)
+    g = sorted(all_rows, key=lambda r: r[0])
+    assert len(g) == len(w)
+    for a, b in zip(g, w):
+        for x_, y in zip(a, b):
+            if isinstance(y, float):
+                assert abs(x_ - y) <= 1e-6 * max(1e-300, abs(y)), (a, b)
+            else:
+                assert x_ == y, (a, b)
+    per_owner = np.array([len(_rows(cp, t, owner_entries)) for t in tables])
+    assert per_owner.min() > 0.8 * per_owner.mean()  # mulhi(hash, G) spreads the keys evenly
+
+
+def test_tuple_exchange_flags_what_it_cannot_carry(oracle, gpu_executor_factory):
+    """Skew (one key owning most rows overflows its owner sub-slab) and stale column statistics (a value outside the
+    announced range) leave HDK_HIP_ERR_EXCHANGE_INCOMPLETE in the owner's error word -- never a wrong table; the
+    single-GPU radix-partitioned launch over the same stale statistics falls back to the atomics kernel and is exact."""
+    from hdk_amd.storage import ChunkStats
+    rng = np.random.default_rng(78)
+    n = 400_000
+    key = rng.integers(0, 30_000, n, dtype=np.int64)
+    heavy = key.copy()
+    heavy[rng.random(n) < 0.7] = 12_345
+    val = rng.integers(-1000, 1000, n, dtype=np.int64)
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": key, "h": heavy, "v": val}, fragment_size=50_000)
+    ex = gpu_executor_factory(st)
+    q = QueryUnit("t", groupby=[ColRef("h")], force_baseline=True, baseline_entry_count=131_071,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s")])
+    cp, want, err = run_oracle(oracle, st, q)
+    tables, owner_entries, xs = _exchange_tables(cp, ex, st, 4)
+    errs = [int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) for x in xs]
+    assert A.ERR_EXCHANGE_INCOMPLETE in errs, errs
+    for t, e in zip(tables, errs):
+        if e:  # a flagged owner's table reads as empty
+            assert len(_rows(cp, t, owner_entries)) == 0
+    # stale statistics: the planner believes v fits [-10, 10]
+    col = st.get("t").columns["v"]
+    col.stats = [ChunkStats(-10, 10, False) for _ in col.stats]
+    big = st.get("t").columns["v"].fragments[3]
+    big[17] = 2**40
+    q2 = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=131_071,
+                   targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s")])
+    ex2 = gpu_executor_factory(st)
+    cp2, want2, err2 = run_oracle(oracle, st, q2)
+    tables, owner_entries, xs = _exchange_tables(cp2, ex2, st, 2)
+    assert xs[0].shape.tuple_bytes == 8
+    errs = [int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) for x in xs]
+    assert errs.count(A.ERR_EXCHANGE_INCOMPLETE) >= 1, errs
+    res = ex2.execute(cp2, flags=A.LAUNCH_FORCE_PARTITIONED)
+    _check_rows(cp2, res.buffer, want2)
 
 
 def test_baseline_fast_kernel_shapes(oracle, gpu_executor_factory):
@@ -350,11 +486,11 @@ def test_radix_partitioned_two_keys(oracle, gpu_executor_factory):
         _check_rows(cp, res.buffer, want)
 
 
-def _assert_reference_placement(oracle, cp, buf):
+def _assert_reference_placement(oracle, cp, buf, entry_count=None):
     """Every group must sit where the reference's probe sequence finds it (get_group_value, QE/GroupByRuntime.cpp:31-55:
     h = key_hash % entry_count, then linearly on): all entries from a group's home up to its entry are occupied."""
     p = cp.plan
-    n, rq, nk = int(p.entry_count), int(p.row_size_quad), int(p.key_count)
+    n, rq, nk = int(entry_count or p.entry_count), int(p.row_size_quad), int(p.key_count)
     rows = np.ascontiguousarray(buf[:n * rq]).reshape(n, rq)
     if p.key_width == 8:
         keys = rows[:, :nk].copy()
