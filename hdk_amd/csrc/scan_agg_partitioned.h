@@ -139,6 +139,7 @@ struct PartArgs {
   int32_t nquals;        // plain filters, applied in pass 1
   ProjFastQual q[kMaxPlainQuals];
   // narrow tuples: ONE word [argument as int32 : key as int32] (tw == 1 while the readers see [key, argument])
+  int32_t soa;               // pass 3 keeps the region as [sums | keys | bits] (hdk_part_aggregate_soa); regions of kPartSoaSlots entries
   int32_t narrow;
   int32_t narrow_null;       // the argument column may hold NULLs: INT32_MIN stands for its in-band NULL
   int64_t narrow_arg_null;   // ... which the readers put back
@@ -226,8 +227,11 @@ __host__ inline size_t part_scatter_lds_bytes(uint32_t nbins, uint32_t gmask, in
 // ---- scatter: LEVEL 1 reads the columns, LEVEL 2 reads a coarse slab ------------------------------------
 // dynamic LDS: [cap_stage][tw] staging | uint8 bin of every staging slot [cap_stage]
 // NARROW: one-word tuples [argument as int32 : key as int32] (K = int32_t, TW = 1), twice the tuples per batch
+#ifndef HDK_PART_L1_WAVES
+#define HDK_PART_L1_WAVES 0  // waves per SIMD the narrow level-1 kernel is held to (0: the compiler's choice)
+#endif
 template <int LEVEL, typename K, int TW, bool NARROW = false>
-__global__ __launch_bounds__(kPartBlock) void hdk_part_scatter(PartArgs a) {
+__global__ __launch_bounds__(kPartBlock, (NARROW && LEVEL == 1) ? HDK_PART_L1_WAVES : 0) void hdk_part_scatter(PartArgs a) {
   __shared__ uint32_t s_cnt[kPartMaxBins];     // tuples of the bin in this batch; rank source
   // per bin and batch, read as one 16-byte word by the copy-out: .x start of the run in the staging area, .y slots
   // of the run (tuples rounded up to whole lines), .z first slab position claimed for it, .w tuples | kind << 16:
@@ -1074,6 +1078,209 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
     } else {
       region_rows[i] = lds_rows[i];
     }
+  }
+  if (tid == 0) {
+    a.nspill[f] = min(s_nspill, kPartSpillSeg);
+  }
+}
+
+// ---- pass 3, structure-of-arrays image: GROUP BY one 4-byte table key, SUM over one integer column ------------------
+// What bounds hdk_part_aggregate_simple once the tuples are 8 bytes is the LDS, not memory (3.8 ms per 1 B tuples for
+// 11 GB): a probe reads key AND slot as one ds_read_b128 at a random address -- four banks per lane, ~3 conflicts per
+// access -- to learn whether the slot still holds its NULL sentinel.  Here the image is [sums int64 | keys int32 |
+// "saw a non-NULL value" bits]: a probe is a 4-byte read, an update one non-returning ds_add_u64 (plus one ds_or_b32
+// on the bit when NULL arguments are possible), the sentinel rule of agg_sum_skip_val (QE/RuntimeFunctions.cpp:
+// 612-625: the first non-NULL value replaces the sentinel, later ones add) is applied once per entry when the image
+// is written back: slot = saw a value ? sum : sentinel.  12 bytes per entry instead of 16 also make a region a third
+// larger (kPartSoaSlots entries), i.e. a quarter fewer regions for the scatter passes to separate.
+// NULLS = false: no tuple carries a NULL argument (narrow tuples whose column statistics say so, checked in pass 1)
+// and the table is fresh, so "claimed" implies "saw a value" and the bits are not kept.
+constexpr uint32_t kPartSoaSlots = 5056;  // 5056 x 12 B + 5056 / 8 B = 61 304 B of LDS (two blocks per CU)
+__host__ __device__ constexpr uint32_t part_soa_lds_bytes(uint32_t slots) { return slots * 12u + ((slots + 31u) / 32u) * 4u; }
+
+template <bool NARROW, bool NULLS>
+__global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_soa(PartArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds_table[];
+  __shared__ uint32_t s_nspill;
+  using K = int32_t;
+  const int tid = threadIdx.x;
+  const uint32_t f = blockIdx.x;
+  if (tid == 0) {
+    s_nspill = 0;
+  }
+  const uint32_t first = f * a.slots;
+  const uint32_t slots = min(a.slots, a.entry_count - first);
+  int64_t* s_sum = lds_table;
+  K* s_key = reinterpret_cast<K*>(lds_table + a.slots);
+  uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_key + a.slots);
+  __attribute__((address_space(1))) bf_i64x2* region_rows = reinterpret_cast<__attribute__((address_space(1))) bf_i64x2*>(
+      reinterpret_cast<uintptr_t>(a.kp.groupby_buf[0] + static_cast<size_t>(first) * 2));
+  const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(a.fill2[f]), a.cap2));
+  const bool idle = n == 0 || *a.fallback;
+  const K ek = empty_key<K>();
+  const bool skip = a.simple_skip != 0;
+  const int64_t slot_null = a.simple_null;
+  const int64_t slot_init = a.kp.init_agg_vals[0];
+  if (a.init_output) {
+    if (idle) {  // nothing to aggregate here: the region still has to read as empty
+      bf_i64x2 row;
+      row.x = static_cast<int64_t>(static_cast<uint32_t>(ek));
+      row.y = slot_init;
+      for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+        region_rows[i] = row;
+      }
+      return;
+    }
+    for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+      s_sum[i] = 0;
+      s_key[i] = ek;
+    }
+    if (NULLS) {
+      for (uint32_t i = tid; i < (slots + 31) / 32; i += kPartAggBlock) {
+        s_mask[i] = 0;
+      }
+    }
+  } else {
+    if (idle) {
+      return;
+    }
+    // an earlier launch's groups: a slot at its sentinel has seen no value yet
+    for (uint32_t i = tid; i < (slots + 31) / 32; i += kPartAggBlock) {
+      s_mask[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+      const bf_i64x2 row = region_rows[i];
+      const K k = static_cast<K>(row.x);
+      const bool has = k != ek && !(skip && row.y == slot_null);
+      s_key[i] = k;
+      s_sum[i] = k == ek ? 0 : (has ? row.y : 0) - (skip ? 0 : slot_init);  // (without the sentinel rule the slot is init + sum)
+      if (has) {
+        atomicOr(&s_mask[i >> 5], 1u << (i & 31));
+      }
+    }
+  }
+  __syncthreads();
+  const bool arg_nullable = a.simple_arg_nullable != 0;
+  const int64_t arg_null = a.simple_arg_null;
+  const int tw = NARROW ? 1 : 2;
+  const int64_t* in = a.slab2 + static_cast<size_t>(f) * a.cap2 * tw;
+  auto apply = [&](int64_t t0, int64_t t1, bool is_null) {
+    const int64_t tup[2] = {t0, t1};
+    const uint32_t local = part_home<K, 2, NARROW ? 1 : 0>(a, tup) - first;
+    if (local >= slots) {
+      return;  // padding of the scatter passes
+    }
+    const K key = static_cast<K>(t0);
+    uint32_t pos = local;
+    for (;;) {
+      K old = s_key[pos];  // look before claiming (a key never returns to EMPTY)
+      if (old == ek) {
+        old = static_cast<K>(atomicCAS(reinterpret_cast<unsigned int*>(s_key + pos), static_cast<unsigned int>(ek),
+                                       static_cast<unsigned int>(key)));
+        if (old == ek) {
+          break;  // claimed
+        }
+      }
+      if (old == key) {
+        break;
+      }
+      if (++pos == slots) {
+        break;
+      }
+    }
+    if (pos == slots) {  // the group lives past the end of this region: pass 4 places it (kept out of the probe loop)
+      const uint32_t k = atomicAdd(&s_nspill, 1u);
+      int64_t* q;
+      if (k < kPartSpillSeg) {
+        q = a.spill_seg + (static_cast<size_t>(f) * kPartSpillSeg + k) * tw;
+      } else {
+        const uint32_t o = atomicAdd(a.fill_spill, 1u);
+        if (o >= a.cap_spill) {
+          return;
+        }
+        q = a.slab1 + static_cast<size_t>(o) * tw;
+      }
+      q[0] = t0;
+      if (tw > 1) {
+        q[1] = t1;
+      }
+      return;
+    }
+    if (is_null) {
+      return;
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(s_sum + pos), static_cast<unsigned long long>(t1));
+    if (NULLS) {
+      atomicOr(&s_mask[pos >> 5], 1u << (pos & 31));
+    }
+  };
+  const __attribute__((address_space(1))) int8_t* in_bytes =
+      reinterpret_cast<const __attribute__((address_space(1))) int8_t*>(reinterpret_cast<uintptr_t>(in));
+  if (NARROW) {
+    // lane-adjacent pairs of one-word tuples, one 16-byte load per pair, the next pair in flight while this one is applied
+    const uint32_t npairs = (n + 1) / 2;
+    int64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+    auto fetch_pair = [&](uint32_t j, int64_t& lo, int64_t& hi) {
+      if (j < npairs) {
+        const bf_i64x2 v = __builtin_nontemporal_load(
+            reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(j) * 16));
+        lo = v.x;
+        hi = v.y;
+      }
+    };
+    auto apply_word = [&](int64_t w) {
+      const int32_t v32 = static_cast<int32_t>(static_cast<uint64_t>(w) >> 32);
+      apply(w, static_cast<int64_t>(v32), NULLS && a.narrow_null && v32 == INT32_MIN);
+    };
+    fetch_pair(tid, a1, b1);
+    for (uint32_t j = tid; j < npairs; j += kPartAggBlock) {
+      a0 = a1;
+      b0 = b1;
+      fetch_pair(j + kPartAggBlock, a1, b1);
+      apply_word(a0);
+      if (2 * j + 1 < n) {
+        apply_word(b0);
+      }
+    }
+  } else {
+    int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    auto fetch = [&](uint32_t i, int64_t& t0, int64_t& t1) {
+      if (i < n) {
+        const bf_i64x2 v = __builtin_nontemporal_load(
+            reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(in_bytes + static_cast<uint64_t>(i) * 16));
+        t0 = v.x;
+        t1 = v.y;
+      }
+    };
+    auto null_arg = [&](int64_t t1) { return skip && ((arg_nullable && t1 == arg_null) || t1 == slot_null); };
+    fetch(tid, a0, a1);
+    fetch(static_cast<uint32_t>(tid) + kPartAggBlock, b0, b1);
+    for (uint32_t i = tid; i < n; i += 2 * kPartAggBlock) {
+      const int64_t ta0 = a0, ta1 = a1, tb0 = b0, tb1 = b1;
+      const bool has_b = i + kPartAggBlock < n;
+      fetch(i + 2 * kPartAggBlock, a0, a1);
+      fetch(i + 3 * kPartAggBlock, b0, b1);
+      apply(ta0, ta1, null_arg(ta1));
+      if (has_b) {
+        apply(tb0, tb1, null_arg(tb1));
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < slots; i += kPartAggBlock) {
+    const K k = s_key[i];
+    bf_i64x2 row;
+    row.x = static_cast<int64_t>(static_cast<uint32_t>(k));  // [key | zero padding], as the init kernel leaves the quad
+    if (k == ek) {
+      row.y = slot_init;
+    } else if (skip) {
+      const bool saw = NULLS ? ((s_mask[i >> 5] >> (i & 31)) & 1u) != 0 : true;
+      row.y = saw ? s_sum[i] : slot_null;
+    } else {
+      row.y = slot_init + s_sum[i];
+    }
+    region_rows[i] = row;
   }
   if (tid == 0) {
     a.nspill[f] = min(s_nspill, kPartSpillSeg);

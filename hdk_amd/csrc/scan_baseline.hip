@@ -147,6 +147,33 @@ static const hdk_hip_col* outer_col_of_buf(const hdk_hip_plan* p, int32_t buf_id
   return nullptr;
 }
 
+// does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
+static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
+  pa->simple_agg = -1;
+  const int ltw = pa->narrow ? 2 : pa->tw;  // tuple words as the readers see them
+  if (p->row_size_quad != 2 || pa->nkeys != 1 || ltw > 2) return false;
+  int found = -1;
+  for (int i = 0; i < pa->ntargets; ++i) {
+    const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
+    if (tg.agg == HDK_AGG_ID && tg.slot_width == 0) continue;
+    if (found >= 0) return false;
+    found = i;
+  }
+  if (found < 0) return false;
+  const hdk_hip_target& tg = p->targets[pa->tgt_index[found]];
+  if (tg.slot_width != 8 || tg.slot_off != 8 || tg.arg_is_fp) return false;
+  if (tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_COUNT) return false;
+  if (tg.has_arg && (pa->tgt_arg[found] != 1 || pa->arg[0].kind != HDK_COL_INT)) return false;
+  if (!tg.has_arg && tg.agg != HDK_AGG_COUNT) return false;
+  pa->simple_agg = tg.agg;
+  pa->simple_has_arg = tg.has_arg;
+  pa->simple_skip = tg.skip_null;
+  pa->simple_arg_nullable = tg.arg.nullable;
+  pa->simple_null = tg.null_val;
+  pa->simple_arg_null = tg.arg.null_val;
+  return true;
+}
+
 static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
@@ -201,6 +228,10 @@ static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
       if (pa->narrow) pa->tw = 1;
     }
   }
+  // pass 3 with a structure-of-arrays image (hdk_part_aggregate_soa): one 4-byte key, SUM over one integer column
+  const bool simple = part_simple_shape(p, pa);
+  pa->soa = simple && p->key_width == 4 && pa->simple_agg == HDK_AGG_SUM && pa->simple_has_arg && (pa->narrow || pa->tw == 2) &&
+            !getenv("HDK_HIP_PART_AOS");
   return true;
 }
 
@@ -211,7 +242,7 @@ static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_c
   pa->owners = owners > 1 ? owners : 0;
   magic_u32(entry_count, &pa->mod_magic, &pa->mod_shift);
   // regions: as many entries as fit the LDS image
-  pa->slots = kPartLdsBytes / (p->row_size_quad * 8);
+  pa->slots = pa->soa ? kPartSoaSlots : kPartLdsBytes / (p->row_size_quad * 8);
   if (pa->slots < 16 || pa->slots >= entry_count) return false;
   magic_u32(pa->slots, &pa->reg_magic, &pa->reg_shift);
   const uint64_t pf = (static_cast<uint64_t>(entry_count) + pa->slots - 1) / pa->slots;
@@ -315,33 +346,6 @@ static void launch_part_scatter(const PartArgs& pa, bool k32, dim3 grid, size_t 
   }
 }
 
-// does hdk_part_aggregate_simple apply?  rows of [key quad | one 8-byte integer slot]
-static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
-  pa->simple_agg = -1;
-  const int ltw = pa->narrow ? 2 : pa->tw;  // tuple words as the readers see them
-  if (p->row_size_quad != 2 || pa->nkeys != 1 || ltw > 2) return false;
-  int found = -1;
-  for (int i = 0; i < pa->ntargets; ++i) {
-    const hdk_hip_target& tg = p->targets[pa->tgt_index[i]];
-    if (tg.agg == HDK_AGG_ID && tg.slot_width == 0) continue;
-    if (found >= 0) return false;
-    found = i;
-  }
-  if (found < 0) return false;
-  const hdk_hip_target& tg = p->targets[pa->tgt_index[found]];
-  if (tg.slot_width != 8 || tg.slot_off != 8 || tg.arg_is_fp) return false;
-  if (tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_COUNT) return false;
-  if (tg.has_arg && (pa->tgt_arg[found] != 1 || pa->arg[0].kind != HDK_COL_INT)) return false;
-  if (!tg.has_arg && tg.agg != HDK_AGG_COUNT) return false;
-  pa->simple_agg = tg.agg;
-  pa->simple_has_arg = tg.has_arg;
-  pa->simple_skip = tg.skip_null;
-  pa->simple_arg_nullable = tg.arg.nullable;
-  pa->simple_null = tg.null_val;
-  pa->simple_arg_null = tg.arg.null_val;
-  return true;
-}
-
 // passes 2-4 (level-2 scatter, LDS aggregation, overflow) for the sources and scratch `pa` names
 static void launch_part_tail(const hdk_hip_plan* plan, PartArgs& pa, const hdk_hip_device_properties* props, hipStream_t s) {
   const bool k32 = plan->key_width == 4;
@@ -351,11 +355,26 @@ static void launch_part_tail(const hdk_hip_plan* plan, PartArgs& pa, const hdk_h
   // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
   const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
   const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
-  const bool simple = part_simple_shape(plan, &pa) && !getenv("HDK_HIP_PART_GENERAL");  // (env: A/B measurements)
+  const bool simple = pa.simple_agg >= 0 && !getenv("HDK_HIP_PART_GENERAL");  // (part_simple_shape; env: A/B measurements)
   const bool sum2 = simple && (pa.narrow || pa.tw == 2) && pa.simple_agg == HDK_AGG_SUM;
   launch_part_scatter<2>(pa, k32, dim3(g2), lds2, s);
   const dim3 ga(pa.fine_count), ba(kPartAggBlock);
-  if (pa.narrow && simple) {
+  if (pa.soa) {
+    // (the bits are needed when a tuple may carry a NULL argument, or the table holds an earlier launch's groups)
+    const bool nulls = pa.simple_skip && !(pa.narrow && !pa.narrow_null && pa.init_output);
+    const size_t lds = part_soa_lds_bytes(pa.slots);
+    if (pa.narrow) {
+      if (nulls) {
+        hipLaunchKernelGGL((hdk_part_aggregate_soa<true, true>), ga, ba, lds, s, pa);
+      } else {
+        hipLaunchKernelGGL((hdk_part_aggregate_soa<true, false>), ga, ba, lds, s, pa);
+      }
+    } else if (nulls) {
+      hipLaunchKernelGGL((hdk_part_aggregate_soa<false, true>), ga, ba, lds, s, pa);
+    } else {
+      hipLaunchKernelGGL((hdk_part_aggregate_soa<false, false>), ga, ba, lds, s, pa);
+    }
+  } else if (pa.narrow && simple) {
     if (sum2 && pa.simple_skip) {
       hipLaunchKernelGGL((hdk_part_aggregate_simple<int32_t, 1, HDK_AGG_SUM, 1, true>), ga, ba, table_bytes, s, pa);
     } else if (sum2) {
