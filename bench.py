@@ -8,14 +8,16 @@ HDK-semantics CPU path timed beside it.
 
 A step = one pass of the hot path over the rank's resident fragments: output-buffer init, the multi-fragment
 scan/aggregate launch (every pass of it), finalize and -- for N > 1 -- the partial-aggregate merge over RCCL/xGMI:
-all-gather of the per-GPU tables + device fold (perfect hash / non-grouped), or owner partition + all-to-all +
-owner re-insert (open addressing, C5).  Inputs are resident in HBM before the timed region (as HDK keeps chunks
-cached in GpuBufferMgr).
+all-gather of the per-GPU tables + device fold (perfect hash / non-grouped); open addressing (C5) exchanges TUPLES
+instead of tables: every rank scatters its rows into per-owner segments, one all-to-all with equal splits, every
+owner aggregates what it received (partial tables + owner re-insert remain as the fallback for skewed keys).
+Inputs are resident in HBM before the timed region (as HDK keeps chunks cached in GpuBufferMgr).
 
 Scaling: STRONG by default -- ONE table of `--rows` rows in 32 M-row fragments, fragment f on rank
 f mod N, value = table rows / max-over-ranks step time.  `--scaling weak` gives every rank its own table.
 At N = 1 the line also carries, under "configs", the other BASELINE configurations at BASELINE size (C3 join probe,
-C5 open addressing and its per-GPU shard shape, taxi Q1-Q4), each with its own roofline object.
+C5 open addressing and its per-GPU shard shape, taxi Q1-Q4), each with its own roofline object, and under
+"multi_gpu_emulated" the per-rank step of an 8-GPU job measured on this one device (wire excluded).
 """
 import argparse
 import ctypes as C
@@ -138,39 +140,96 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
     init_vals = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
     merge_ms, owner = [], {}
+    # ---- N > 1 ----------------------------------------------------------------------------------------------------
+    xch, xch_ev, mode = None, [], "single"
+    if world > 1 and not baseline:
+        mode = "gather+fold"
+        # (hoisted out of the step: the argument arrays of the fold; the plan stays resident in the workspace after
+        # the first launch, so a step uploads nothing)
+        that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
+        counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
+    if world > 1 and baseline:
+        # open addressing: TUPLES go to their owner rank (hdk_hip_scatter_to_owners -> one all-to-all with equal
+        # splits -> hdk_hip_aggregate_from_ranks); skewed keys fall back to the exchange of partial tables
+        bound = torch.tensor([w.local_rows], dtype=torch.int64, device="cuda")
+        comm.all_reduce(bound, "max")
+        try:
+            step.free()
+            n_owner = D.owner_entry_count_for(cp.entry_count, world)
+            owner_t = torch.empty(D.baseline_table_quads(cp, n_owner), dtype=torch.int64, device="cuda")
+            step = w.ex.prepare(cp, w.frag_ids, flags=int(os.environ.get("HDK_BENCH_FLAGS", "0")), out_ptr=owner_t.data_ptr())
+            xch = D.TupleExchange(step, world, int(bound.item()), n_owner)
+            owner["table"], owner["entries"] = owner_t, n_owner
+            mode = "tuples"
+        except Exception as e:  # plan outside the radix-partitioned shape
+            if rank == 0:
+                print(f"# tuple exchange not available ({e}); exchanging partial tables", file=sys.stderr)
+            step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
+            mode = "tables"
 
     def _one_step():
+        if mode == "tuples":
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(tstream)
+            xch.scatter(stream)
+            ev[1].record(tstream)
+            if comm.backend == "nccl":
+                xch.exchange()
+            else:  # host-staged test mode
+                r_h = torch.empty(xch.send.numel(), dtype=torch.uint8)
+                comm.dist.all_to_all_single(r_h, xch.send.cpu())
+                xch.recv.copy_(r_h)
+            ev[2].record(tstream)
+            xch.aggregate(stream)
+            ev[3].record(tstream)
+            xch_ev.append(ev)
+            return
         step.enqueue(stream)  # output-buffer initialisation + launch (fused for the open-addressing tables)
         if world == 1:
             return
-        if not baseline:
+        if mode == "gather+fold":
             # ResultSetReduction over the per-GPU partial tables: all-gather (1.5 KB each for C2) + device fold
             comm.all_gather(gathered, out_t)
-            that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
-            counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
             check(L.hdk_hip_reduce_buffers(C.byref(cp.plan), gathered.data_ptr(), cp.entry_count, that, counts,
                                            world - 1, init_vals.ctypes.data, d_err.data_ptr(), dev, stream))
         else:
-            # open addressing: entries to their owner rank (one all-to-all over xGMI), owners re-insert
+            # partial tables: entries to their owner rank (one all-to-all over xGMI), owners re-insert
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(tstream)
-            send, counts = D.partition_baseline_on_device(cp, out_t, world, dev, stream)
+            send, counts_o = D.partition_baseline_on_device(cp, out_t, world, dev, stream)
             if comm.backend == "nccl":
-                recv, rc = D.exchange_owner_segments(cp, send, counts, world, rank)
+                recv, rc = D.exchange_owner_segments(cp, send, counts_o, world, rank)
             else:
-                r_h, rc = D.exchange_owner_segments(cp, send.cpu(), counts, world, rank)
+                r_h, rc = D.exchange_owner_segments(cp, send.cpu(), counts_o, world, rank)
                 recv = r_h.to("cuda")
-            owner["table"], owner["entries"] = D.merge_baseline_on_device(cp, recv, rc, dev, None, stream)
+            owner["table"], owner["entries"] = D.merge_baseline_on_device(cp, recv, rc, dev, D.owner_entry_count_for(cp.entry_count, world), stream)
             e1.record(tstream)
-            owner["sent_bytes"] = int(sum(D.baseline_table_quads(cp, int(c)) for i, c in enumerate(counts) if i != rank)) * 8
+            owner["sent_bytes"] = int(sum(D.baseline_table_quads(cp, int(c)) for i, c in enumerate(counts_o) if i != rank)) * 8
             owner["events"] = (e0, e1)
 
     def one_step():
         with torch.cuda.stream(tstream):
             _one_step()
-        if world > 1 and baseline:
+        if mode == "tables":
             torch.cuda.synchronize()
             merge_ms.append(owner["events"][0].elapsed_time(owner["events"][1]))
+
+    if mode == "tuples":
+        # one probe step decides for all ranks: an incomplete exchange (skew, stale statistics) -> partial tables
+        one_step()
+        torch.cuda.synchronize()
+        bad = torch.tensor([int(step.mgr.to_host(step.d_err.ptr, 4, dev, np.int32)[0] == A.ERR_EXCHANGE_INCOMPLETE)],
+                           dtype=torch.int64, device="cuda")
+        comm.all_reduce(bad, "max")
+        if int(bad.item()):
+            step.free()
+            step = w.ex.prepare(cp, w.frag_ids, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
+            mode, xch = "tables", None
+        xch_ev.clear()
+    if mode == "gather+fold":
+        one_step()  # (puts the plan into the workspace head)
+        torch.cuda.synchronize()
+        step.ko.flags |= A.LAUNCH_PLAN_RESIDENT
 
     for _ in range(warmup):
         one_step()
@@ -193,6 +252,13 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     ms_buf = (C.c_float * max(steps, 1))()
     check(L.hdk_hip_collect_scan_times(dev, ms_buf, steps, C.byref(n_ev)))
     scan_ms = [ms_buf[i] for i in range(min(n_ev.value, steps))]
+    xch_ms = None
+    if mode == "tuples":
+        evs = xch_ev[-steps:]
+        xch_ms = {"scatter": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
+                  "all_to_all": float(np.mean([e[1].elapsed_time(e[2]) for e in evs])),
+                  "aggregate": float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))}
+        scan_ms = [xch_ms["scatter"] + xch_ms["aggregate"]]  # this rank's kernels (its rows scattered, its keys aggregated)
     avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
 
     # ---- correctness at full size: size-independent properties (every rank takes part in the collectives) ----------
@@ -275,10 +341,14 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     value = total_rows * steps / elapsed
     achieved = w.local_rows * w.alg_bytes_per_row / (avg_scan_ms * 1e-3) / 1e9 if scan_ms else None
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", f"r02_{name}_pmc.json")
-    if os.path.exists(pmc_path) and rows == CONFIGS[name][0] and world == 1:
-        with open(pmc_path) as fpmc:
-            traffic = json.load(fpmc).get("traffic_bytes_per_launch")
+    traffic_source = None
+    for rnd in ("r03", "r02"):  # counters are collected by separate rocprofv3 --pmc passes of this same command
+        pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
+        if os.path.exists(pmc_path) and rows == CONFIGS[name][0] and world == 1:
+            with open(pmc_path) as fpmc:
+                traffic = json.load(fpmc).get("traffic_bytes_per_launch")
+            traffic_source = f"profiles/{rnd}_{name}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured by this run)"
+            break
     kernels = step.kernel_names()
     out = {
         "metric": "rows/sec, 1B-row int64 GROUP BY SUM" if name == "c2" else f"rows/sec, {name}",
@@ -298,10 +368,11 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
                    "layout": ("open addressing" if baseline else "perfect hash" if cp.plan.key_count else "non-grouped") +
                              (", keyless" if cp.plan.keyless else "") + f", {cp.entry_count} entries",
                    "parallelism": (f"fragment f -> GPU f mod {world}; " if strong else f"one table per GPU x {world}; ") +
-                                  ("owner partition + all-to-all + owner re-insert" if baseline
-                                   else "all-gather of the partial tables + device fold")},
+                                  ({"tuples": "tuples scattered to owner segments + all-to-all (equal splits) + owner aggregation",
+                                    "tables": "owner partition of the partial table + all-to-all + owner re-insert",
+                                    "gather+fold": "all-gather of the partial tables + device fold", "single": "one GPU"}[mode])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernels if baseline else kernels.split(",")[0], "avg_kernel_ms": avg_scan_ms,
                      "alg_bytes_per_row": w.alg_bytes_per_row,
                      "note": "per GPU: this rank's rows x algorithmic bytes / mean HIP-event time of the scan launch "
@@ -309,9 +380,14 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         "checks": checks,
         "setup_s": {"generate": t_gen},
     }
-    if world > 1 and baseline and merge_ms:
+    if mode == "tables" and merge_ms:
         out["merge"] = {"ms": float(np.mean(merge_ms)), "bytes_sent_over_xgmi_per_gpu": owner.get("sent_bytes"),
                         "what": "owner partition + all_to_all_single + owner re-insert, HIP events on the step's stream"}
+    if mode == "tuples":
+        out["exchange"] = {"ms": xch_ms, "bytes_sent_over_xgmi_per_gpu": xch.bytes_sent_per_rank,
+                           "tuple_bytes": int(xch.shape.tuple_bytes), "owner_entries": xch.owner_entries,
+                           "what": "HIP events on the step's stream around hdk_hip_scatter_to_owners, all_to_all_single and "
+                                   "hdk_hip_aggregate_from_ranks"}
     step.free()
     return out, w
 
@@ -393,6 +469,7 @@ def main():
     ap.add_argument("--cpu-sample-frags", type=int, default=0, help="fragments the CPU baseline runs on (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-sample", action="store_true")
+    ap.add_argument("--no-multi-gpu-emulation", action="store_true")
     args = ap.parse_args()
 
     comm = Comm(args)
@@ -428,6 +505,36 @@ def main():
         configs.append({k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "checks")})
     if configs:
         line["configs"] = configs
+    if comm.rank == 0 and comm.world == 1 and args.config == "c2" and not args.rows and not args.no_multi_gpu_emulation:
+        # What one rank of an 8-GPU job does per step, measured here on one device (everything but the wire):
+        # C2's shard (4 of 32 fragments) incl. init, finalize, an emulated all-gather and the fold of 7 partials; C5's
+        # tuple exchange, all 8 ranks and owners one after another (scripts/multi_gpu_floor.py)
+        import gc
+        import types
+        import torch
+        gc.collect()
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import multi_gpu_floor as F
+        fa = types.SimpleNamespace(world=8, steps=10, configs=["c2"], one_rank=False)
+        a = F.part_a(fa, mgr, quiet=True)["c2"]
+        gc.collect()
+        torch.cuda.empty_cache()
+        c = F.part_c(types.SimpleNamespace(world=8, steps=5), mgr, quiet=True)
+        line["multi_gpu_emulated"] = {
+            "what": "per-rank step of an 8-GPU job measured on ONE device, wire excluded (no multi-GPU box was available "
+                    "to the build); the all-gather / all-to-all are device copies",
+            "c2_rank0_of_8": {"rows": a["rows_per_rank"], "step_ms": a["plan_resident"]["wall_ms_per_step"],
+                              "scan_kernel_ms": a["plan_resident"]["scan_kernel_ms"],
+                              "host_enqueue_ms": a["plan_resident"]["host_enqueue_ms_per_step"],
+                              "projected_rows_per_s_at_8_gpus": a["projected_rows_per_s_at_8_gpus_wire_excluded"]},
+            "c5_tuple_exchange_8_ranks": {"scatter_ms_max": max(p["scatter_ms"] for p in c["per_rank"]),
+                                          "aggregate_ms_max": max(p["aggregate_ms"] for p in c["per_owner"]),
+                                          "merge_emulated_ms": max(p["aggregate_ms"] for p in c["per_owner"]),
+                                          "step_ms": c["step_ms_wire_excluded"],
+                                          "bytes_sent_over_xgmi_per_gpu": c["per_rank"][0]["bytes_to_other_owners"],
+                                          "tuple_bytes": c["per_rank"][0]["tuple_bytes"], "checks": c["checks"],
+                                          "projected_rows_per_s_at_8_gpus": c["projected_rows_per_s_at_8_gpus_wire_excluded"]}}
     if comm.rank == 0:
         print(json.dumps(line))
     comm.close()

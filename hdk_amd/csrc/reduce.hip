@@ -10,11 +10,56 @@
 //       :694-731): CAS-claim of the key in `this_buf`, fill_slots for a fresh entry, reduceOneSlot
 //       otherwise.  Partials are merged one launch after another; inside one partial keys are
 //       unique, so an entry of `this_buf` has a single writer per launch.
+#include <mutex>
+#include <string.h>
+
 #include "baseline_table.h"
 #include "device_common.h"
 #include "host_common.h"
 
 namespace hdk {
+
+// Device copies of the plans the reductions run with.  A merge step is issued once per query step with the same
+// plan; allocating scratch and uploading 6 KB from pageable memory on every call put a host-side stall of the
+// whole stream into each step (scripts/multi_gpu_floor.py: host enqueue time = GPU time).  A handful of plans per
+// device are kept (byte-compared); the first upload is a blocking copy, so the copy is valid for every stream
+// afterwards.  Entries are recycled round-robin, never while a call that got one can still be running: a slot is
+// reused only after kPlanCacheSlots other plans have come by, and the reductions are short.
+constexpr int kPlanCacheSlots = 16;
+struct PlanCacheEntry {
+  hdk_hip_plan host;
+  hdk_hip_plan* dev = nullptr;
+  bool used = false;
+};
+struct PlanCache {
+  std::mutex mu;
+  PlanCacheEntry e[kPlanCacheSlots];
+  int next = 0;
+};
+static PlanCache g_plan_cache[16];
+
+static int32_t cached_device_plan(const hdk_hip_plan* plan, int32_t device_id, const hdk_hip_plan** out) {
+  PlanCache& c = g_plan_cache[device_id & 15];
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (int i = 0; i < kPlanCacheSlots; ++i) {
+    if (c.e[i].used && memcmp(&c.e[i].host, plan, sizeof(hdk_hip_plan)) == 0) {
+      *out = c.e[i].dev;
+      return HDK_HIP_OK;
+    }
+  }
+  PlanCacheEntry& e = c.e[c.next];
+  c.next = (c.next + 1) % kPlanCacheSlots;
+  if (!e.dev) {
+    HDK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.dev), sizeof(hdk_hip_plan)));
+  }
+  e.used = false;
+  HDK_HIP_CHECK(hipDeviceSynchronize());  // (a recycled slot: nothing still reads the old copy)
+  HDK_HIP_CHECK(hipMemcpy(e.dev, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice));
+  memcpy(&e.host, plan, sizeof(hdk_hip_plan));
+  e.used = true;
+  *out = e.dev;
+  return HDK_HIP_OK;
+}
 
 constexpr int kRedBlock = 256;
 constexpr int kMaxSlots = 2 * HDK_HIP_MAX_TARGETS;
@@ -338,80 +383,109 @@ HDK_DEV uint32_t entry_owner(const hdk_hip_plan* p, const int64_t* buf, uint32_t
 }
 
 // MODE 0: count entries per owner; MODE 1: scatter them into the owners' segments.
-// One atomic per wave and owner: lanes holding the same owner are ranked with a ballot.
+// Per tile of kRedBlock x kPartT entries: positions inside the tile come from LDS counters (one returning LDS atomic
+// per wave and owner: lanes holding the same owner are ranked with a ballot), the tile's share of every owner's
+// segment from ONE global atomic per owner.  (Round 2 took a global atomic per wave and owner: 25 M returning
+// atomics on eight addresses for a 200 M-entry table -- 266 ms per pass, profiles/r03_multi_gpu_floor_before.json.)
+constexpr int kPartT = 8;
 template <typename K, int MODE>
 __global__ __launch_bounds__(kRedBlock) void k_partition_baseline(const hdk_hip_plan* __restrict__ p,
                                                                   const int64_t* buf, uint32_t entry_count,
                                                                   uint32_t num_owners, SlotInit init,
                                                                   uint32_t* cursors, OwnerSegs segs) {
-  const uint32_t stride = gridDim.x * kRedBlock;
+  __shared__ uint32_t s_cnt[kMaxOwners], s_base[kMaxOwners];
   const uint32_t lane = threadIdx.x & 63;
   const int nk = p->key_count;
   const int nt = p->num_targets;
-  const uint32_t rounds = (entry_count + stride - 1) / stride;
-  for (uint32_t it = 0; it < rounds; ++it) {
-    const uint32_t e = it * stride + blockIdx.x * kRedBlock + threadIdx.x;
-    K key[HDK_HIP_MAX_KEYS];
-    uint32_t owner = 0xffffffffu;
-    if (e < entry_count && !is_empty_entry(p, buf, entry_count, e, init)) {
-      owner = entry_owner<K>(p, buf, entry_count, e, num_owners, key);
+  constexpr uint32_t kTile = kRedBlock * kPartT;
+  const uint32_t ntiles = (entry_count + kTile - 1) / kTile;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x < kMaxOwners) {
+      s_cnt[threadIdx.x] = 0;
     }
-    uint32_t dst = 0;
-    for (uint32_t o = 0; o < num_owners; ++o) {
-      const uint64_t mask = __ballot(owner == o);
-      if (mask == 0) {
-        continue;
-      }
-      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1;
-      uint32_t base = 0;
-      if (lane == leader) {
-        base = atomicAdd(cursors + o, static_cast<uint32_t>(__popcll(mask)));
-      }
-      base = __shfl(base, leader, 64);
-      if (owner == o) {
-        dst = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1)));
-      }
-    }
-    if (MODE == 0 || owner == 0xffffffffu) {
-      continue;
-    }
-    int64_t* seg = segs.buf[0];
-    uint32_t seg_n = segs.count[0];
+    __syncthreads();
+    uint32_t owner[kPartT], rank[kPartT];
 #pragma unroll
-    for (int k = 1; k < kMaxOwners; ++k) {
-      if (static_cast<uint32_t>(k) == owner) {
-        seg = segs.buf[k];
-        seg_n = segs.count[k];
+    for (int j = 0; j < kPartT; ++j) {
+      const uint32_t e = tile * kTile + static_cast<uint32_t>(j) * kRedBlock + threadIdx.x;
+      K key[HDK_HIP_MAX_KEYS];
+      owner[j] = 0xffffffffu;
+      rank[j] = 0;
+      if (e < entry_count && !is_empty_entry(p, buf, entry_count, e, init)) {
+        owner[j] = entry_owner<K>(p, buf, entry_count, e, num_owners, key);
       }
-    }
-    for (int k = 0; k < nk; ++k) {
-      if (p->output_columnar) {
-        reinterpret_cast<K*>(seg)[static_cast<size_t>(k) * seg_n + dst] = key[k];
-      } else {
-        reinterpret_cast<K*>(seg + static_cast<size_t>(dst) * p->row_size_quad)[k] = key[k];
-      }
-    }
-    int s = 0;
-    for (int t = 0; t < nt; ++t) {
-      const hdk_hip_target& tg = p->targets[t];
-      int8_t *a1, *a2, *b1, *b2;
-      slot_ptrs(p, seg, seg_n, dst, t, s, &a1, &a2);
-      slot_ptrs(p, const_cast<int64_t*>(buf), entry_count, e, t, s, &b1, &b2);
-      if (tg.slot_width == 0) {
-        // no slot
-      } else if (tg.slot_width == 4) {
-        *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
-      } else {
-        *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);
-      }
-      if (tg.agg == HDK_AGG_AVG) {
-        if (tg.slot2_width == 4) {
-          *reinterpret_cast<int32_t*>(a2) = *reinterpret_cast<const int32_t*>(b2);
-        } else {
-          *reinterpret_cast<int64_t*>(a2) = *reinterpret_cast<const int64_t*>(b2);
+      for (uint32_t o = 0; o < num_owners; ++o) {
+        const uint64_t mask = __ballot(owner[j] == o);
+        if (mask == 0) {
+          continue;
+        }
+        const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1;
+        uint32_t base = 0;
+        if (lane == leader) {
+          base = atomicAdd(&s_cnt[o], static_cast<uint32_t>(__popcll(mask)));
+        }
+        base = __shfl(base, leader, 64);
+        if (owner[j] == o) {
+          rank[j] = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1)));
         }
       }
-      s += tg.agg == HDK_AGG_AVG ? 2 : 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < num_owners) {
+      const uint32_t n = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = n ? atomicAdd(cursors + threadIdx.x, n) : 0;
+    }
+    __syncthreads();
+    if (MODE == 0) {
+      continue;  // (the barrier at the top of the next tile separates the reads of s_base from its next writes)
+    }
+#pragma unroll
+    for (int j = 0; j < kPartT; ++j) {
+      if (owner[j] == 0xffffffffu) {
+        continue;
+      }
+      const uint32_t e = tile * kTile + static_cast<uint32_t>(j) * kRedBlock + threadIdx.x;
+      const uint32_t dst = s_base[owner[j]] + rank[j];
+      int64_t* seg = segs.buf[0];
+      uint32_t seg_n = segs.count[0];
+#pragma unroll
+      for (int k = 1; k < kMaxOwners; ++k) {
+        if (static_cast<uint32_t>(k) == owner[j]) {
+          seg = segs.buf[k];
+          seg_n = segs.count[k];
+        }
+      }
+      for (int k = 0; k < nk; ++k) {
+        const K kv = p->output_columnar ? reinterpret_cast<const K*>(buf)[static_cast<size_t>(k) * entry_count + e]
+                                        : reinterpret_cast<const K*>(buf + static_cast<size_t>(e) * p->row_size_quad)[k];
+        if (p->output_columnar) {
+          reinterpret_cast<K*>(seg)[static_cast<size_t>(k) * seg_n + dst] = kv;
+        } else {
+          reinterpret_cast<K*>(seg + static_cast<size_t>(dst) * p->row_size_quad)[k] = kv;
+        }
+      }
+      int sl = 0;
+      for (int t = 0; t < nt; ++t) {
+        const hdk_hip_target& tg = p->targets[t];
+        int8_t *a1, *a2, *b1, *b2;
+        slot_ptrs(p, seg, seg_n, dst, t, sl, &a1, &a2);
+        slot_ptrs(p, const_cast<int64_t*>(buf), entry_count, e, t, sl, &b1, &b2);
+        if (tg.slot_width == 0) {
+          // no slot
+        } else if (tg.slot_width == 4) {
+          *reinterpret_cast<int32_t*>(a1) = *reinterpret_cast<const int32_t*>(b1);
+        } else {
+          *reinterpret_cast<int64_t*>(a1) = *reinterpret_cast<const int64_t*>(b1);
+        }
+        if (tg.agg == HDK_AGG_AVG) {
+          if (tg.slot2_width == 4) {
+            *reinterpret_cast<int32_t*>(a2) = *reinterpret_cast<const int32_t*>(b2);
+          } else {
+            *reinterpret_cast<int64_t*>(a2) = *reinterpret_cast<const int64_t*>(b2);
+          }
+        }
+        sl += tg.agg == HDK_AGG_AVG ? 2 : 1;
+      }
     }
   }
 }
@@ -464,7 +538,7 @@ static int32_t run_partition(const hdk_hip_plan* plan, const int64_t* buf, uint3
   HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
   HDK_HIP_CHECK(hipMemsetAsync(cursors, 0, kMaxOwners * sizeof(uint32_t), s));
   const hdk_hip_device_properties* props = device_props(device_id);
-  size_t blocks = (static_cast<size_t>(entry_count) + kRedBlock - 1) / kRedBlock;
+  size_t blocks = (static_cast<size_t>(entry_count) + kRedBlock * kPartT - 1) / (kRedBlock * kPartT);
   const size_t cap = static_cast<size_t>(props->num_cu) * 8;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
@@ -512,11 +586,10 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
   for (int i = 0; i < kMaxSlots; ++i) {
     init.v[i] = i < nslots ? init_vals[i] : 0;  // init_vals is a HOST array (ResultSetStorage::target_init_vals_)
   }
-  // device copy of the plan (stream-ordered scratch)
-  AsyncScratch plan_mem(s);
-  HDK_HIP_CHECK(hipMallocAsync(&plan_mem.p, sizeof(hdk_hip_plan), s));
-  hdk_hip_plan* d_plan = static_cast<hdk_hip_plan*>(plan_mem.p);
-  HDK_HIP_CHECK(hipMemcpyAsync(d_plan, plan, sizeof(hdk_hip_plan), hipMemcpyHostToDevice, s));
+  // device copy of the plan (cached per device)
+  const hdk_hip_plan* d_plan = nullptr;
+  st = cached_device_plan(plan, device_id, &d_plan);
+  if (st) return st;
   const hdk_hip_device_properties* props = device_props(device_id);
   if (plan->query_kind != HDK_Q_BASELINE_HASH) {
     const uint32_t n = plan->query_kind == HDK_Q_NON_GROUPED ? 1u : this_entry_count;

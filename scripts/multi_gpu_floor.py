@@ -42,7 +42,7 @@ def ev_ms(torch, stream, fn, reps=1):
     return e0.elapsed_time(e1) / reps
 
 
-def part_a(args, mgr):
+def part_a(args, mgr, quiet=False):
     import torch
     from hdk_amd import _abi as A
     from hdk_amd import distributed as D
@@ -106,7 +106,8 @@ def part_a(args, mgr):
         res["rows_per_rank"] = w.local_rows
         res["projected_rows_per_s_at_8_gpus_wire_excluded"] = rows / (res["plan_resident"]["wall_ms_per_step"] * 1e-3)
         out[name] = res
-        print(json.dumps({name: res}), flush=True)
+        if not quiet:
+            print(json.dumps({name: res}), flush=True)
         del w, step
         import gc
         gc.collect()
@@ -184,7 +185,7 @@ def part_b(args, mgr):
     return res
 
 
-def part_c(args, mgr):
+def part_c(args, mgr, quiet=False):
     import torch
     from hdk_amd import _abi as A
     from hdk_amd import distributed as D
@@ -215,7 +216,8 @@ def part_c(args, mgr):
         per_rank.append({"rank": r, "rows": w.local_rows, "scatter_ms": ms, "tuple_bytes": int(x.shape.tuple_bytes),
                          "segment_bytes": int(x.shape.segment_bytes), "bytes_to_other_owners": x.bytes_sent_per_rank,
                          "coarse_per_owner": int(x.shape.coarse_per_owner)})
-        print(json.dumps(per_rank[-1]), flush=True)
+        if not quiet:
+            print(json.dumps(per_rank[-1]), flush=True)
         xs.append(x)
         tables.append(table)
         # the inputs are not needed any more: only the send buffers are
@@ -248,14 +250,16 @@ def part_c(args, mgr):
         groups += int(live.sum().item())
         all_keys.append(keys[live])
         per_owner.append({"owner": o, "aggregate_ms": ms, "groups": int(live.sum().item()), "entries": ne, "error": err})
-        print(json.dumps(per_owner[-1]), flush=True)
+        if not quiet:
+            print(json.dumps(per_owner[-1]), flush=True)
     allk = torch.cat(all_keys)
     res = {"per_rank": per_rank, "per_owner": per_owner,
            "step_ms_wire_excluded": max(p["scatter_ms"] for p in per_rank) + max(p["aggregate_ms"] for p in per_owner),
            "checks": {"sum_of_sums": got_sum == want_sum, "groups": groups, "groups_equal_distinct_keys": groups == distinct,
                       "owners_disjoint": int(torch.unique(allk).numel()) == int(allk.numel())}}
     res["projected_rows_per_s_at_%d_gpus_wire_excluded" % world] = rows / (res["step_ms_wire_excluded"] * 1e-3)
-    print(json.dumps({"c5_tuple_exchange": {k: v for k, v in res.items() if k not in ("per_rank", "per_owner")}}), flush=True)
+    if not quiet:
+        print(json.dumps({"c5_tuple_exchange": {k: v for k, v in res.items() if k not in ("per_rank", "per_owner")}}), flush=True)
     return res
 
 
