@@ -245,6 +245,20 @@ def owner_entry_count_for(entry_count: int, world_size: int) -> int:
     return max(-(-int(entry_count) // int(world_size)), 1024)
 
 
+def exchange_equal_segments(send, recv, world_size: int, group=None):
+    """The one collective of the tuple exchange: `send` and `recv` are `world_size` segments of equal size; segment o of
+    rank r's `send` lands as segment r of rank o's `recv`.  Sizes are static (hdk_hip_exchange_shape::segment_bytes):
+    no counts travel and the host never waits for the device.  RCCL all-to-all over xGMI in production, gloo in the
+    CPU tests."""
+    import torch.distributed as dist
+    if world_size == 1 or not dist.is_initialized():
+        recv.copy_(send)
+        return
+    if send.numel() % world_size or recv.numel() != send.numel():
+        raise ValueError("send / recv must be world_size segments of equal size")
+    dist.all_to_all_single(recv, send, group=group)
+
+
 class TupleExchange:
     """One rank's side of a multi-GPU open-addressing group-by: scatter -> all-to-all -> aggregate.
 
@@ -285,13 +299,7 @@ class TupleExchange:
                                                     self.ws_scatter.data_ptr(), self.ws_scatter.numel()))
 
     def exchange(self, group=None):
-        """Segment o of `send` goes to rank o and lands as segment `rank` of its `recv`: equal splits, sizes known
-        up front (RCCL all-to-all over xGMI; gloo in the CPU tests)."""
-        import torch.distributed as dist
-        if self.world == 1 or not dist.is_initialized():
-            self.recv.copy_(self.send)
-            return
-        dist.all_to_all_single(self.recv, self.send, group=group)
+        exchange_equal_segments(self.send, self.recv, self.world, group)
 
     def aggregate(self, stream, recv=None):
         r = self.recv if recv is None else recv

@@ -186,3 +186,39 @@ def test_four_rank_owner_exchange_uneven_splits_and_empty_owners_gloo():
 
 def test_four_rank_gather_and_merge_gloo():
     _spawn(_worker, 4, 37500 + (os.getpid() % 2000))
+
+
+def _segments_worker(rank, world, port, result_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hdk_amd.distributed import exchange_equal_segments, owner_entry_count_for
+        seg = 4096 + 256  # bytes of a segment: [header | slabs], the same on every rank
+        send = torch.empty(world * seg, dtype=torch.uint8)
+        for o in range(world):  # segment o carries (sender, owner) in every byte pair
+            send[o * seg:(o + 1) * seg] = torch.tensor([rank, o] * (seg // 2), dtype=torch.uint8)
+        recv = torch.zeros(world * seg, dtype=torch.uint8)
+        exchange_equal_segments(send, recv, world)
+        for r in range(world):  # what rank r scattered for THIS owner sits in segment r
+            got = recv[r * seg:(r + 1) * seg].view(-1, 2)
+            assert bool((got[:, 0] == r).all()) and bool((got[:, 1] == rank).all()), (rank, r)
+        with pytest.raises(ValueError):
+            exchange_equal_segments(send[:-1], recv[:-1], world)
+        assert owner_entry_count_for(200_000_000, 8) == 25_000_000 and owner_entry_count_for(10, 4) == 1024
+        result_q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        result_q.put((rank, "fail: " + traceback.format_exc()))
+        raise e
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tuple_exchange_routes_equal_segments_gloo():
+    """The collective of the tuple exchange at world size 2 and 4: segment o of rank r arrives as segment r of rank o."""
+    _spawn(_segments_worker, 2, 39500 + (os.getpid() % 2000))
+    _spawn(_segments_worker, 4, 41500 + (os.getpid() % 2000))
