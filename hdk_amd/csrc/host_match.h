@@ -74,6 +74,32 @@ inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
   return true;
 }
 
+inline uint32_t pow2_ceil_log2(uint64_t x) {
+  uint32_t l = 0;
+  while ((1ull << l) < x) ++l;
+  return l;
+}
+
+// unsigned 32-bit division by an invariant divisor d >= 2, round-up method in its branch-free form:
+//   t = mulhi(magic, n);  q = (((n - t) >> 1) + t) >> shift        (exact for every 32-bit n)
+inline void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  uint32_t log2d = 31;
+  while (!(d >> log2d)) --log2d;
+  if ((d & (d - 1)) == 0) {
+    *magic = 0;
+    *shift = log2d - 1;
+    return;
+  }
+  const uint64_t two_k = 1ull << (32 + log2d);
+  const uint64_t m = two_k / d;
+  const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
+  uint32_t m32 = static_cast<uint32_t>(m) * 2u;
+  const uint32_t twice_rem = rem * 2u;
+  if (twice_rem >= d || twice_rem < rem) m32 += 1;
+  *magic = m32 + 1u;
+  *shift = log2d;
+}
+
 inline bool launch_forces_generic(const hdk_hip_kernel_options* ko) {
   return ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
 }

@@ -440,6 +440,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_agg_keys.h"
 #include "scan_cluster.h"
 #include "scan_join_direct.h"
+#include "scan_join_sliced.h"
 
 using namespace hdk;
 
@@ -954,11 +955,153 @@ static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_opt
   return (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
 }
 
+// ---- hdk_join_agg_sliced (scan_join_sliced.h): key-range slices of the join table probed out of LDS ----------------
+// Taken by default for the hdk_join_agg_direct shape when the table is far larger than the caches and the column
+// statistics let payload and key offset travel in 32 bits; HDK_HIP_LAUNCH_CLUSTER_PROBES takes it whatever the sizes
+// (tests), HDK_HIP_LAUNCH_NO_CLUSTER_PROBES never.
+static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, const hdk_hip_kernel_options* ko, SliceArgs* sa) {
+  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES)) return false;
+  const bool forced = (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
+  const hdk_hip_join& jn = p->joins[0];
+  if (jn.max_key < jn.min_key) return false;
+  const uint64_t range = static_cast<uint64_t>(jn.max_key - jn.min_key) + 1;
+  if (range >= 0xFFFFFFFFull) return false;
+  // worth it when a probe in row order costs a memory line: table beyond the 4 MB L2s and the 256 MB Infinity Cache's
+  // comfortable share, enough rows to pay for the scatter pass
+  if (!forced && (range * 16 < (32ull << 20) || ko->total_rows < (32ull << 20))) return false;
+  uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
+  if (slice < 64) slice = 64;
+  if (slice > kSliceMaxEntries) return false;  // > 10.2 M keys: a slice no longer fits the LDS of a CU
+  memset(sa, 0, sizeof(*sa));
+  // payload: in 32 bits with two values to spare (column statistics of the fused inner column)
+  const hdk_hip_col* pay = nullptr;
+  const hdk_hip_col* xcol = nullptr;
+  for (int i = 0; i < p->num_cols; ++i) {
+    if (p->cols[i].table == -1 && p->cols[i].buf_idx == 1) pay = &p->cols[i];
+    if (p->cols[i].table == 0 && p->cols[i].buf_idx == ja.x_buf_idx) xcol = &p->cols[i];
+  }
+  if (pay && !(pay->has_stats && pay->min_val > static_cast<int64_t>(INT32_MIN) + 1 && pay->max_val <= static_cast<int64_t>(INT32_MAX))) {
+    return false;
+  }
+  sa->key_buf_idx = ja.key_buf_idx;
+  sa->x_buf_idx = ja.x_buf_idx;
+  sa->key_min = jn.min_key;
+  sa->key_range = range;
+  sa->key_nullable = ja.key_nullable;
+  sa->key_null = ja.key_null;
+  sa->slice = slice;
+  magic_u32(slice, &sa->slice_magic, &sa->slice_shift);
+  sa->nbins = static_cast<uint32_t>((range + slice - 1) / slice);
+  // the NULL sentinels of x and of the payload, as the targets' leaves name them
+  for (int t = 0; t < ja.ntargets; ++t) {
+    for (const JdLeaf* l : {&ja.t[t].a, &ja.t[t].b}) {
+      if (!ja.t[t].has_arg) continue;
+      if (l->kind == JD_X && l->nullable) sa->x_null = l->null_val, sa->x_null32 = 1;
+      if (l->kind == JD_PAYLOAD && l->nullable) sa->pay_null = l->null_val, sa->pay_nullable = 1;
+    }
+  }
+  // x: 32 bits when the statistics allow (a nullable column gives up INT32_MIN for its NULL), else 16-byte tuples
+  sa->narrow = 1;
+  if (ja.x_buf_idx >= 0) {
+    const bool x_has_nulls = !xcol || !xcol->has_stats || xcol->has_nulls;
+    if (!(xcol && xcol->has_stats && xcol->min_val >= static_cast<int64_t>(INT32_MIN) + (x_has_nulls ? 1 : 0) &&
+          xcol->max_val <= static_cast<int64_t>(INT32_MAX)) || getenv("HDK_HIP_SLICE_WIDE")) {
+      sa->narrow = 0;
+    }
+    if (!x_has_nulls) sa->x_null32 = 0;  // (no NULLs announced: INT32_MIN is an ordinary value; a NULL showing up anyway is caught as stale)
+    else if (sa->narrow && !sa->x_null32) sa->narrow = 0;  // NULLs possible but no sentinel known from the leaves
+  } else {
+    sa->x_null32 = 0;
+  }
+  // the FAST form of the probe pass: ONE target, SUM(x + payload) in either order, into an ADD word
+  if (ja.ntargets == 1 && ja.t[0].has_arg && ja.t[0].nsteps == 1 && ja.t[0].op == HDK_OP_ADD && ja.t[0].vword >= 0 &&
+      ja.t[0].wop == WOP_ADD_U64 && !getenv("HDK_HIP_SLICE_GENERAL")) {
+    const JdLeaf &la = ja.t[0].a, &lb = ja.t[0].b;
+    const JdLeaf* lx = la.kind == JD_X ? &la : (lb.kind == JD_X ? &lb : nullptr);
+    const JdLeaf* lp = la.kind == JD_PAYLOAD ? &la : (lb.kind == JD_PAYLOAD ? &lb : nullptr);
+    if (lx && lp && lx != lp) {
+      sa->fast = 1;
+      sa->fast_x_nullable = lx->nullable;
+      sa->fast_x_null = lx->null_val;
+      sa->fast_p_nullable = lp->nullable;
+      sa->fast_p_null = lp->null_val;
+    }
+  }
+  const uint64_t rows = ko->total_rows;
+  const uint64_t nsub = static_cast<uint64_t>(sa->nbins) * kSliceXcds;
+  sa->sub = ((rows / nsub) * 17 / 16 + 4096 + 15) & ~15ull;
+  sa->cap_ovf = rows / 8 + 4096;
+  if (sa->sub > 0xFFFFFFF0ull || sa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
+  return true;
+}
+
+template <bool NARROW, bool FAST>
+static int32_t launch_sliced_kernels(SliceArgs& sa, const LaunchShape& shape, const hdk_hip_device_properties* props, hipStream_t s,
+                                     bool* launched) {
+  *launched = false;
+  const void* kagg = reinterpret_cast<const void*>(hdk_join_agg_sliced<NARROW, FAST>);
+  const size_t lds_agg = static_cast<size_t>(shape.wpe) * shape.rep * 8 + static_cast<size_t>(sa.slice) * 4;
+  if (lds_agg > 48 * 1024 &&
+      hipFuncSetAttribute(kagg, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_agg)) != hipSuccess) {
+    (void)hipGetLastError();
+    return HDK_HIP_OK;  // no block this large here: probe in row order
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kagg, kSliceAggBlock, lds_agg) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return HDK_HIP_OK;
+  }
+  constexpr int VR = NARROW ? 8 : 4;
+  constexpr int TW = NARROW ? 1 : 2;
+  const size_t lds_sc = static_cast<size_t>(kSliceBlock) * VR * TW * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
+  const unsigned g_sc = resident_grid(reinterpret_cast<const void*>(hdk_join_scatter_slices<NARROW>), kSliceBlock, lds_sc, props);
+  uint32_t members = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu) / sa.nbins;
+  if (members < 1) members = 1;
+  hipLaunchKernelGGL(hdk_join_order_probe, dim3(256), dim3(256), 0, s, sa);
+  hipLaunchKernelGGL(hdk_join_scatter_slices<NARROW>, dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
+  hipLaunchKernelGGL((hdk_join_agg_sliced<NARROW, FAST>), dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, sa);
+  HDK_HIP_CHECK(hipGetLastError());
+  *launched = true;
+  return HDK_HIP_OK;
+}
+
 static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, const hdk_hip_kernel_options* ko,
                                   const LaunchShape& shape, const hdk_hip_device_properties* props, hipStream_t s) {
   AsyncScratch scratch(s);
   const hdk_hip_join& jn = plan->joins[0];
-  if (join_direct_clusters(plan, ko) && static_cast<uint64_t>(jn.max_key - jn.min_key) < 0xFFFFFFFFull) {
+  SliceArgs sa;
+  if (match_join_sliced(plan, ja, ko, &sa)) {
+    // key-range slices probed out of LDS; the row-order kernel below stays armed for what the slices cannot carry
+    auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+    const size_t tw = sa.narrow ? 1 : 2;
+    const size_t nsub = static_cast<size_t>(sa.nbins) * kSliceXcds;
+    const size_t b_tuples = up((nsub * sa.sub + sa.cap_ovf) * tw * 8);
+    const size_t b_fill = up((nsub * kSliceCursorStride + 8) * sizeof(uint32_t));
+    if (hipMallocAsync(&scratch.p, b_tuples + b_fill, s) == hipSuccess) {
+      int8_t* q = static_cast<int8_t*>(scratch.p);
+      sa.kp = ja.kp;
+      sa.tuples = reinterpret_cast<int64_t*>(q);
+      sa.fill = reinterpret_cast<uint32_t*>(q + b_tuples);
+      sa.fill_ovf = sa.fill + nsub * kSliceCursorStride;
+      sa.mode = sa.fill_ovf + 1;
+      sa.probe = sa.mode + 1;
+      sa.jd = ja;
+      sa.num_slabs = shape.grid;
+      HDK_HIP_CHECK(hipMemsetAsync(sa.fill, 0, b_fill, s));
+      bool launched = false;
+      const int32_t st = sa.narrow ? (sa.fast ? launch_sliced_kernels<true, true>(sa, shape, props, s, &launched)
+                                              : launch_sliced_kernels<true, false>(sa, shape, props, s, &launched))
+                                   : (sa.fast ? launch_sliced_kernels<false, true>(sa, shape, props, s, &launched)
+                                              : launch_sliced_kernels<false, false>(sa, shape, props, s, &launched));
+      if (st) return st;
+      if (launched) {
+        ja.run_if = sa.mode;
+      }
+    } else {
+      (void)hipGetLastError();  // no scratch: probe in row order
+      scratch.p = nullptr;
+    }
+  } else if (join_direct_clusters(plan, ko) && static_cast<uint64_t>(jn.max_key - jn.min_key) < 0xFFFFFFFFull) {
     ClusterArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.kp = ja.kp;
@@ -1321,7 +1464,14 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     JoinDirectArgs jd;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     const bool direct = !generic && match_join_direct(plan, s, &jd);
-    if (direct && join_direct_clusters(plan, ko)) {
+    SliceArgs sl;
+    if (direct && match_join_sliced(plan, jd, ko, &sl)) {
+      const int n = snprintf(out, out_len, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,");
+      if (n > 0 && static_cast<size_t>(n) < out_len) {
+        out += n;
+        out_len -= static_cast<size_t>(n);
+      }
+    } else if (direct && join_direct_clusters(plan, ko)) {
       const int n = snprintf(out, out_len, "hdk_cluster_by_key,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;

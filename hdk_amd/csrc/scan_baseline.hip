@@ -85,32 +85,6 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
 // ---- radix-partitioned open-addressing group-by (scan_agg_partitioned.h) -------------------------------
 // Taken for the hdk_scan_agg_baseline_direct shape when the table is large enough that the memory-side
 // atomic rate is the bound (>= 2 M entries, >= 8 M rows) and the caller told us the row count.
-static uint32_t pow2_ceil_log2(uint64_t x) {
-  uint32_t l = 0;
-  while ((1ull << l) < x) ++l;
-  return l;
-}
-
-// unsigned 32-bit division by an invariant divisor d >= 2, round-up method in its branch-free form:
-//   t = mulhi(magic, n);  q = (((n - t) >> 1) + t) >> shift        (exact for every 32-bit n)
-static void magic_u32(uint32_t d, uint32_t* magic, uint32_t* shift) {
-  uint32_t log2d = 31;
-  while (!(d >> log2d)) --log2d;
-  if ((d & (d - 1)) == 0) {
-    *magic = 0;
-    *shift = log2d - 1;
-    return;
-  }
-  const uint64_t two_k = 1ull << (32 + log2d);
-  const uint64_t m = two_k / d;
-  const uint32_t rem = static_cast<uint32_t>(two_k - m * d);
-  uint32_t m32 = static_cast<uint32_t>(m) * 2u;
-  const uint32_t twice_rem = rem * 2u;
-  if (twice_rem >= d || twice_rem < rem) m32 += 1;
-  *magic = m32 + 1u;
-  *shift = log2d;
-}
-
 // key_hash (QE/GroupByRuntime.cpp:24-29: MurmurHash3 of the packed key, seed 0) of the key (k, 0) on the host, for the
 // padding keys of the partitioned group-by; same word order as key_hash_dev (baseline_table.h)
 template <typename K>

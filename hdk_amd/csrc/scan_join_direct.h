@@ -67,6 +67,7 @@ struct JoinDirectArgs {
   const uint32_t* fill_ovf;
   uint64_t sub;
   uint64_t cap_ovf;
+  const uint32_t* run_if;  // nullptr: always run; else only when *run_if == 1 (armed by the sliced path, scan_join_sliced.h)
 };
 
 HDK_DEV int64_t jd_leaf(const JdLeaf& l, int64_t x, int64_t pay) {
@@ -80,15 +81,8 @@ struct JdAcc {
   uint64_t nulls[kJdMaxTargets];
 };
 
-// one outer row: probe, then every target (the row function of this shape)
-HDK_DEV void jd_row(const JoinDirectArgs& a, const int64_t* __restrict__ table, int64_t key, int64_t x, JdAcc& acc, int32_t& err) {
-  const bool in_range = !(a.key_nullable && key == a.key_null) && key >= a.min_key && key <= a.max_key;
-  const int64_t slot = in_range ? key - a.min_key : 0;
-  const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(slot) * 16);
-  if (!(in_range && e.x >= 0)) {
-    return;  // INNER join: no partner, no row
-  }
-  const int64_t pay = e.y;
+// every target of one joined row (the row function of this shape behind the probe)
+HDK_DEV void jd_eval(const JoinDirectArgs& a, int64_t x, int64_t pay, JdAcc& acc, int32_t& err) {
   acc.rows += 1;
 #pragma unroll
   for (int t = 0; t < kJdMaxTargets; ++t) {
@@ -120,8 +114,60 @@ HDK_DEV void jd_row(const JoinDirectArgs& a, const int64_t* __restrict__ table, 
   }
 }
 
+// one outer row: probe the table in memory, then every target
+HDK_DEV void jd_row(const JoinDirectArgs& a, const int64_t* __restrict__ table, int64_t key, int64_t x, JdAcc& acc, int32_t& err) {
+  const bool in_range = !(a.key_nullable && key == a.key_null) && key >= a.min_key && key <= a.max_key;
+  const int64_t slot = in_range ? key - a.min_key : 0;
+  const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(slot) * 16);
+  if (!(in_range && e.x >= 0)) {
+    return;  // INNER join: no partner, no row
+  }
+  jd_eval(a, x, e.y, acc, err);
+}
+
+// end of a block: one LDS update per lane and word, then the block's slab
+HDK_DEV void jd_flush(const JoinDirectArgs& a, const JdAcc& acc, int64_t* lds, uint32_t my_rep, int tid, int block) {
+  const uint32_t rep = a.rep;
+  const uint32_t ew = static_cast<uint32_t>(a.wpe);
+  if (acc.rows) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(lds + my_rep), static_cast<unsigned long long>(acc.rows));
+#pragma unroll
+    for (int t = 0; t < kJdMaxTargets; ++t) {
+      if (t < a.ntargets && a.t[t].has_arg) {
+        if (a.t[t].vword >= 0) {
+          vec_lds_op(a.t[t].wop, lds + static_cast<uint32_t>(a.t[t].vword) * rep + my_rep, acc.val[t]);
+        }
+        if (a.t[t].nword >= 0 && acc.nulls[t]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + static_cast<uint32_t>(a.t[t].nword) * rep + my_rep),
+                    static_cast<unsigned long long>(acc.nulls[t]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += block) {
+    const int32_t op = a.wop[i];
+    int64_t v = lds[i * rep];
+    for (uint32_t r = 1; r < rep; ++r) {
+      v = word_combine(op, v, lds[i * rep + r]);
+    }
+    if ((a.nword_mask >> i) & 1u) {  // NULL count -> non-null count = rows - NULLs
+      int64_t rows = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        rows += lds[r];
+      }
+      v = rows - v;
+    }
+    slab[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(kJdBlock) void hdk_join_agg_direct(JoinDirectArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  if (a.run_if && *a.run_if != 1) {
+    return;  // (the sliced path did the job -- or the launch was interrupted: 2)
+  }
   constexpr int VR = kJdVR;
   const int tid = threadIdx.x;
   const int wpe = a.wpe;
@@ -224,39 +270,7 @@ __global__ __launch_bounds__(kJdBlock) void hdk_join_agg_direct(JoinDirectArgs a
   if (err) {
     record_error(a.kp.error_code, err);
   }
-  // one LDS update per lane and word
-  if (acc.rows) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(lds + my_rep), static_cast<unsigned long long>(acc.rows));
-#pragma unroll
-    for (int t = 0; t < kJdMaxTargets; ++t) {
-      if (t < a.ntargets && a.t[t].has_arg) {
-        if (a.t[t].vword >= 0) {
-          vec_lds_op(a.t[t].wop, lds + static_cast<uint32_t>(a.t[t].vword) * rep + my_rep, acc.val[t]);
-        }
-        if (a.t[t].nword >= 0 && acc.nulls[t]) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(lds + static_cast<uint32_t>(a.t[t].nword) * rep + my_rep),
-                    static_cast<unsigned long long>(acc.nulls[t]));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * ew;
-  for (uint32_t i = tid; i < ew; i += kJdBlock) {
-    const int32_t op = a.wop[i];
-    int64_t v = lds[i * rep];
-    for (uint32_t r = 1; r < rep; ++r) {
-      v = word_combine(op, v, lds[i * rep + r]);
-    }
-    if ((a.nword_mask >> i) & 1u) {  // NULL count -> non-null count = rows - NULLs
-      int64_t rows = 0;
-      for (uint32_t r = 0; r < rep; ++r) {
-        rows += lds[r];
-      }
-      v = rows - v;
-    }
-    slab[i] = v;
-  }
+  jd_flush(a, acc, lds, my_rep, tid, kJdBlock);
 }
 
 }  // namespace hdk

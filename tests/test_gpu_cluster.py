@@ -60,8 +60,9 @@ def test_clustered_probes_match_the_oracle(oracle, gpu_executor_factory, key_kin
             names = step.kernel_names()
             # the C3 shape over a fused table has a kernel of its own that reads clustered TUPLES; everything else runs the
             # batched interpreter over the permuted columns
+            # (and for tables whose key-range slices fit LDS, a path of its own: scan_join_sliced.h)
             assert names.startswith("hdk_cluster_by_key,hdk_cluster_params,hdk_scan_agg_vec_join") or \
-                names.startswith("hdk_cluster_by_key,hdk_join_agg_direct"), names
+                names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,hdk_join_agg_direct"), names
             assert_buffers_equal(cp, step.run().buffer, want)
             # a second run of the same prepared step: the scratch of the first is gone, the result is not
             assert_buffers_equal(cp, step.run().buffer, want)
@@ -100,7 +101,7 @@ def test_direct_join_kernel_matches_the_oracle(oracle, gpu_executor_factory, key
         q = QueryUnit("fact", joins=j, targets=targets)
         cp, want, err = run_oracle(oracle, st, q)
         assert err == 0
-        for flags, prefix in ((0, "hdk_join_agg_direct"), (A.LAUNCH_CLUSTER_PROBES, "hdk_cluster_by_key,hdk_join_agg_direct"),
+        for flags, prefix in ((0, "hdk_join_agg_direct"), (A.LAUNCH_CLUSTER_PROBES, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced"),
                               (A.LAUNCH_FORCE_GENERIC, "hdk_scan_agg_vec_join")):
             ex = gpu_executor_factory(st)
             ex.fuse_join_tables = True
@@ -127,3 +128,76 @@ def test_direct_join_kernel_reports_overflow(oracle, gpu_executor_factory):
         with pytest.raises(HdkHipError) as ei:
             ex.execute(cp, flags=flags)
         assert ei.value.code == A.ERR_OVERFLOW_OR_UNDERFLOW
+
+
+def _sliced_tables(nf, nd, seed, x_kind, key_kind="uniform", pay_nulls=False):
+    """fact(fk, x) JOIN dim(key, dval): x_kind picks what the slices' tuples look like -- "int32" (fits 32 bits, no
+    NULLs: 8-byte tuples), "int32_nulls" (8-byte tuples, INT32_MIN stands for NULL), "wide" (16-byte tuples)."""
+    rng = np.random.default_rng(seed)
+    st = ArrowStorage()
+    dval = rng.integers(-10**6, 10**6, nd).astype(np.int64)
+    if pay_nulls:
+        dval[rng.random(nd) < 0.1] = A.NULL_BIGINT
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * 3 - 77, "dval": dval})  # every third key only
+    lo, hi = -77, 3 * nd - 77
+    if key_kind == "uniform":
+        fk = rng.integers(lo - 20, hi + 20, nf).astype(np.int64)
+    elif key_kind == "hot":
+        fk = np.where(rng.random(nf) < 0.7, -77 + 3 * 1234, rng.integers(lo, hi, nf)).astype(np.int64)
+    else:
+        fk = np.sort(rng.integers(lo, hi, nf)).astype(np.int64)
+    fk[rng.random(nf) < 0.02] = A.NULL_BIGINT
+    if x_kind == "int32":
+        x = rng.integers(-2**31, 2**31, nf).astype(np.int64)
+    elif x_kind == "int32_nulls":
+        x = rng.integers(-2**31 + 1, 2**31, nf).astype(np.int64)
+        x[rng.random(nf) < 0.05] = A.NULL_BIGINT
+    else:
+        x = rng.integers(-2**45, 2**45, nf).astype(np.int64)
+        x[rng.random(nf) < 0.05] = A.NULL_BIGINT
+    st.import_numpy("fact", {"fk": fk, "x": x}, fragment_size=nf // 4 + 5)
+    return st
+
+
+@pytest.mark.parametrize("x_kind,key_kind,pay_nulls", [("int32", "uniform", False), ("int32_nulls", "uniform", True),
+                                                        ("wide", "uniform", True), ("int32", "hot", False),
+                                                        ("int32_nulls", "sorted", False), ("wide", "hot", False)])
+def test_sliced_join_matches_the_oracle(oracle, gpu_executor_factory, x_kind, key_kind, pay_nulls):
+    """scan_join_sliced.h: the join table's key-range slices probed out of LDS -- 8- and 16-byte tuples, NULL keys, keys
+    without a partner (two of three slots are empty), NULL payloads, a hot key (overflow area, probed in memory), an input
+    that is already clustered (the order probe hands the launch to the row-order kernel); every aggregate of the shape."""
+    st = _sliced_tables(900_000, 50_000, 23, x_kind, key_kind, pay_nulls)
+    X, D = ColRef("x"), ColRef("dval", "dim")
+    for targets in ([Agg("sum", X + D, "s"), Agg("count", None, "c")],
+                    [Agg("sum", X, "sx"), Agg("min", X - D, "lo"), Agg("max", D, "hi"), Agg("count", D, "cd")],
+                    [Agg("avg", D, "a"), Agg("count", X, "cx")]):
+        q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        assert step.kernel_names().startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced"), step.kernel_names()
+        assert_buffers_equal(cp, step.run().buffer, want)
+        assert_buffers_equal(cp, step.run().buffer, want)  # (scratch and mode word are per launch)
+        step.free()
+
+
+def test_sliced_join_survives_stale_statistics(oracle, gpu_executor_factory):
+    """Column statistics that no longer hold (an x outside the announced 32-bit range; a payload outside it) make the
+    launch fall back to the row-order kernel on the device: same answer as the oracle's."""
+    from hdk_amd.storage import ChunkStats
+    st = _sliced_tables(600_000, 40_000, 29, "int32")
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")],
+                  targets=[Agg("sum", ColRef("x") + ColRef("dval", "dim"), "s"), Agg("count", None, "c")])
+    for table, col in (("fact", "x"), ("dim", "dval")):
+        c = st.get(table).columns[col]
+        saved = c.fragments[0][11]
+        c.fragments[0][11] = 2**40 + 3  # the statistics (computed at import) still say +-2^31 / +-1e6
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        assert "hdk_join_agg_sliced" in step.kernel_names()
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+        c.fragments[0][11] = saved
