@@ -446,6 +446,33 @@ using namespace hdk;
 
 namespace hdk {
 
+// ---- plan validation: every index, width and enumerator a kernel or a host matcher will use unchecked ------------------
+static int32_t check_leaf(const hdk_hip_plan* p, const hdk_hip_leaf& l, bool may_be_none, const char* what) {
+  HDK_REQUIRE(l.kind >= (may_be_none ? HDK_LEAF_NONE : HDK_LEAF_COL) && l.kind <= HDK_LEAF_FP, "%s: bad leaf kind %d", what, l.kind);
+  if (l.kind == HDK_LEAF_COL) {
+    HDK_REQUIRE(l.col >= 0 && l.col < p->num_cols, "%s: column %d out of range (num_cols %d)", what, l.col, p->num_cols);
+  }
+  return HDK_HIP_OK;
+}
+
+static int32_t check_expr(const hdk_hip_plan* p, const hdk_hip_expr& e, const char* what) {
+  HDK_REQUIRE(e.nsteps >= 0 && e.nsteps <= HDK_HIP_MAX_EXPR_STEPS, "%s: nsteps %d out of range", what, e.nsteps);
+  HDK_REQUIRE(e.vclass == HDK_VC_INT || e.vclass == HDK_VC_FP, "%s: bad value class", what);
+  int32_t st = check_leaf(p, e.leaf0, false, what);
+  if (st) return st;
+  for (int i = 0; i < e.nsteps; ++i) {
+    const hdk_hip_step& sp = e.steps[i];
+    HDK_REQUIRE(sp.op >= HDK_OP_ADD && sp.op <= HDK_OP_CAST_FP_TO_INT, "%s: step %d: bad op %d", what, i, sp.op);
+    HDK_REQUIRE(sp.out_class == HDK_VC_INT || sp.out_class == HDK_VC_FP, "%s: step %d: bad out_class", what, i);
+    HDK_REQUIRE(sp.check_width == 0 || sp.check_width == 1 || sp.check_width == 2 || sp.check_width == 4 || sp.check_width == 8,
+                "%s: step %d: check_width must be 0/1/2/4/8", what, i);
+    const bool unary = sp.op == HDK_OP_EXTRACT_YEAR || sp.op == HDK_OP_CAST_INT_TO_FP || sp.op == HDK_OP_CAST_FP_TO_INT;
+    st = check_leaf(p, sp.rhs, unary, what);
+    if (st) return st;
+  }
+  return HDK_HIP_OK;
+}
+
 int32_t validate_plan(const hdk_hip_plan* p) {
   HDK_REQUIRE(p, "plan is NULL");
   HDK_REQUIRE(p->abi_version == HDK_HIP_PLAN_ABI, "plan ABI %u != library ABI %u", p->abi_version,
@@ -454,10 +481,53 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   HDK_REQUIRE(p->num_quals >= 0 && p->num_quals <= HDK_HIP_MAX_QUALS, "bad num_quals");
   HDK_REQUIRE(p->num_joins >= 0 && p->num_joins <= HDK_HIP_MAX_JOINS, "bad num_joins");
   HDK_REQUIRE(p->key_count >= 0 && p->key_count <= HDK_HIP_MAX_KEYS, "bad key_count");
+  int32_t st;
+  for (int i = 0; i < p->num_cols; ++i) {
+    const hdk_hip_col& c = p->cols[i];
+    HDK_REQUIRE(c.width == 1 || c.width == 2 || c.width == 4 || c.width == 8, "column %d: width %d is not 1/2/4/8", i, c.width);
+    HDK_REQUIRE(c.kind >= HDK_COL_INT && c.kind <= HDK_COL_DOUBLE, "column %d: bad kind %d", i, c.kind);
+    HDK_REQUIRE(c.kind != HDK_COL_FLOAT || c.width == 4, "column %d: a float column is 4 bytes wide", i);
+    HDK_REQUIRE(c.kind != HDK_COL_DOUBLE || c.width == 8, "column %d: a double column is 8 bytes wide", i);
+    HDK_REQUIRE(c.table >= -p->num_joins && c.table <= p->num_joins, "column %d: table %d out of range (%d joins)", i, c.table,
+                p->num_joins);
+    HDK_REQUIRE(c.buf_idx >= 0 && c.buf_idx < 4096, "column %d: buf_idx %d out of range", i, c.buf_idx);
+    if (c.table < 0) {  // payload word of a fused join table
+      const hdk_hip_join& jn = p->joins[-c.table - 1];
+      HDK_REQUIRE(jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED && c.buf_idx >= 1 && c.buf_idx < jn.fused_stride && c.width == 8,
+                  "column %d: not a payload word of join %d's fused table", i, -c.table - 1);
+    }
+    HDK_REQUIRE(c.has_stats == 0 || c.has_stats == 1, "column %d: has_stats must be 0 or 1", i);
+  }
+  for (int i = 0; i < p->num_quals; ++i) {
+    const hdk_hip_qual& q = p->quals[i];
+    if ((st = check_expr(p, q.lhs, "filter lhs"))) return st;
+    if ((st = check_leaf(p, q.rhs, false, "filter rhs"))) return st;
+    HDK_REQUIRE(q.cmp >= HDK_CMP_EQ && q.cmp <= HDK_CMP_GE, "filter %d: bad comparison %d", i, q.cmp);
+    HDK_REQUIRE(q.after_joins == 0 || q.after_joins == 1, "filter %d: after_joins must be 0 or 1", i);
+  }
+  HDK_REQUIRE(p->filter_after_joins == 0 || p->filter_after_joins == 1, "filter_after_joins must be 0 or 1");
+  for (int k = 0; k < p->key_count; ++k) {
+    if ((st = check_expr(p, p->keys[k], "group-by key"))) return st;
+  }
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     HDK_REQUIRE(jn.kind >= HDK_JOIN_ONE_TO_ONE && jn.kind <= HDK_JOIN_KEYED_ONE_TO_MANY, "bad join kind");
     HDK_REQUIRE(jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_LEFT, "bad join type");
+    HDK_REQUIRE(jn.null_mode >= HDK_JOIN_NULL_NONE && jn.null_mode <= HDK_JOIN_NULL_BITWISE, "join %d: bad null_mode", j);
+    HDK_REQUIRE(jn.table_idx >= 0 && jn.table_idx < p->num_joins, "join %d: table_idx %d out of range", j, jn.table_idx);
+    HDK_REQUIRE(jn.bucket >= 0, "join %d: negative bucket", j);
+    if ((st = check_expr(p, jn.outer_key, "join key"))) return st;
+    if (jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED) {
+      HDK_REQUIRE(jn.fused_stride >= 1 && jn.fused_stride <= 8, "join %d: fused_stride %d out of range", j, jn.fused_stride);
+    }
+    if (jn.kind <= HDK_JOIN_ONE_TO_ONE_FUSED) {
+      HDK_REQUIRE(jn.max_key >= jn.min_key, "join %d: empty key range", j);
+    }
+    if (jn.kind >= HDK_JOIN_KEYED_ONE_TO_ONE) {
+      for (int k = 0; k + 1 < jn.key_component_count && k < HDK_HIP_MAX_JOIN_KEYS - 1; ++k) {
+        if ((st = check_expr(p, jn.extra_keys[k], "join key component"))) return st;
+      }
+    }
     if (jn.kind == HDK_JOIN_ONE_TO_MANY || jn.kind >= HDK_JOIN_KEYED_ONE_TO_ONE) {
       HDK_REQUIRE(jn.entry_count > 0 && jn.entry_count < (int64_t(1) << 31), "join table entry_count out of range");
     }
@@ -496,6 +566,11 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     for (int t = 0; t < p->num_targets; ++t) {
       const hdk_hip_target& tg = p->targets[t];
       HDK_REQUIRE(tg.agg == HDK_AGG_ID && tg.has_arg, "projection targets are plain expressions");
+      HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
+      if ((st = check_expr(p, tg.arg, "projection target"))) return st;
+      HDK_REQUIRE(tg.slot_off >= 0 && (p->output_columnar || static_cast<int64_t>(tg.slot_off) + tg.slot_width <=
+                                                                  static_cast<int64_t>(p->row_size_quad) * 8),
+                  "target %d: slot at offset %d does not fit the row", t, tg.slot_off);
       HDK_REQUIRE(tg.slot_width == 1 || tg.slot_width == 2 || tg.slot_width == 4 || tg.slot_width == 8,
                   "slot width must be 1/2/4/8");
       HDK_REQUIRE(p->output_columnar || tg.slot_width == 8, "row-wise projection slots are 8 bytes");
@@ -507,8 +582,35 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     HDK_REQUIRE(p->key_count > 0, "group-by plan without keys");
     HDK_REQUIRE(p->output_columnar || p->row_size_quad > 0, "row_size_quad must be positive");
   }
+  HDK_REQUIRE(p->query_kind == HDK_Q_NON_GROUPED || p->key_width == 4 || p->key_width == 8, "key_width must be 4 or 8");
+  int nslots = 0;
+  for (int t = 0; t < p->num_targets; ++t) {
+    nslots += p->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
+  }
+  if (p->keyless) {
+    HDK_REQUIRE(p->query_kind == HDK_Q_PERFECT_HASH, "only perfect-hash plans can be keyless");
+    HDK_REQUIRE(p->idx_target_as_key >= 0 && p->idx_target_as_key < nslots, "idx_target_as_key %d out of range (%d slots)",
+                p->idx_target_as_key, nslots);
+  }
+  const int64_t row_bytes = static_cast<int64_t>(p->row_size_quad) * 8;
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
+    HDK_REQUIRE(tg.agg >= HDK_AGG_COUNT && tg.agg <= HDK_AGG_ID, "target %d: bad aggregate kind %d", t, tg.agg);
+    HDK_REQUIRE(tg.has_arg == 0 || tg.has_arg == 1, "target %d: has_arg must be 0 or 1", t);
+    HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
+    HDK_REQUIRE(tg.has_arg || tg.agg == HDK_AGG_COUNT || (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED),
+                "target %d: only COUNT(*) and projected keys have no argument", t);
+    if (tg.has_arg && (st = check_expr(p, tg.arg, "target argument"))) return st;
+    if (p->query_kind != HDK_Q_NON_GROUPED && tg.slot_width != 0) {
+      // a slot lies inside the row (row-wise) / starts on its own alignment (columnar)
+      HDK_REQUIRE(tg.slot_off >= 0 && (p->output_columnar || static_cast<int64_t>(tg.slot_off) + tg.slot_width <= row_bytes),
+                  "target %d: slot at offset %d does not fit a row of %lld bytes", t, tg.slot_off, static_cast<long long>(row_bytes));
+      if (tg.agg == HDK_AGG_AVG) {
+        HDK_REQUIRE(tg.slot2_width == 4 || tg.slot2_width == 8, "target %d: AVG count slot width must be 4 or 8", t);
+        HDK_REQUIRE(tg.slot2_off >= 0 && (p->output_columnar || static_cast<int64_t>(tg.slot2_off) + tg.slot2_width <= row_bytes),
+                    "target %d: AVG count slot at offset %d does not fit the row", t, tg.slot2_off);
+      }
+    }
     if (tg.slot_width == 0) {
       HDK_REQUIRE(p->query_kind == HDK_Q_BASELINE_HASH && tg.agg == HDK_AGG_ID && tg.key_idx >= 0 &&
                       tg.key_idx < p->key_count,
@@ -1437,6 +1539,8 @@ int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT]
 }
 
 }  // namespace hdk
+
+extern "C" int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan) { return validate_plan(plan); }
 
 extern "C" int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                           int32_t device_id, size_t* bytes) {

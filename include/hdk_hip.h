@@ -438,6 +438,11 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
  * the kernels it is meant to stop. */
 int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value);
 
+/* Host-only check of a plan: ABI version, every count, index, width and enumerator a kernel or a matcher reads
+ * (column widths and tables, leaf column indices, expression steps, comparison / join / aggregate kinds, slot
+ * offsets inside the row, the filter program).  Every entry point that takes a plan runs it first; a malformed plan
+ * gets HDK_HIP_ERR_INVALID_ARG (or _UNSUPPORTED) and a message, never an out-of-bounds read.  No device is touched. */
+int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan);
 /* Bytes of device scratch `hdk_hip_launch` needs for this plan (per-block partial tables). */
 int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                int32_t device_id, size_t* bytes);

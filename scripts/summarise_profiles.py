@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02/ (scripts/gpu/profile_r02.sh) -> profiles/r02_*: the kernel-stats CSV and bench line of the driver's
+"""gpurun_out/<round>/ (scripts/gpu/profile_<round>.sh) -> profiles/<round>_*  (round = argv[1], default r03): the kernel-stats CSV and bench line of the driver's
 bench command, and one PMC summary per config with the HBM traffic of a launch.
 
 Counters follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from separate
@@ -14,10 +14,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 ALG = {"c2": (16, 1_000_000_000), "c3": (16, 1_000_000_000), "c5": (16, 1_000_000_000), "c5s": (16, 125_000_000),
-       "q3": (10, 1_000_000_000), "q4": (18, 1_000_000_000)}
+       "q1": (4, 1_000_000_000), "q2": (10, 1_000_000_000), "q3": (10, 1_000_000_000), "q4": (18, 1_000_000_000)}
 
 
 def counters(path):
@@ -38,11 +39,13 @@ def short(k):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(os.path.join(SRC, "bench_default_kernel_stats.csv"), os.path.join(DST, "r02_bench_default_kernel_stats.csv"))
+    shutil.copy(os.path.join(SRC, "bench_default_kernel_stats.csv"), os.path.join(DST, f"{RND}_bench_default_kernel_stats.csv"))
     line = [l for l in open(os.path.join(SRC, "bench_default_bench.json")) if l.startswith("{")][-1]
-    with open(os.path.join(DST, "r02_bench_default.json"), "w") as f:
+    with open(os.path.join(DST, f"{RND}_bench_default.json"), "w") as f:
         f.write(line)
     for name, (bpr, rows) in ALG.items():
+        if not os.path.exists(os.path.join(SRC, f"{name}_fetch_counters.csv")):
+            continue
         fe = counters(os.path.join(SRC, f"{name}_fetch_counters.csv"))
         wr = counters(os.path.join(SRC, f"{name}_write_counters.csv"))
         main_k = max(fe, key=lambda k: fe[k][0].get("FETCH_SIZE", 0) * fe[k][1])
@@ -64,13 +67,13 @@ def main():
                "rows": rows, "algorithmic_bytes_per_row": bpr, "algorithmic_bytes": bpr * rows, "kernels": kernels,
                "traffic_bytes_per_launch": round(traffic), "traffic_bytes_per_row": round(traffic / rows, 2),
                "traffic_over_algorithmic": round(traffic / (bpr * rows), 3)}
-        for extra in ("tcc", "sq"):
+        for extra in ("tcc", "sq", "lds"):
             p = os.path.join(SRC, f"{name}_{extra}_counters.csv")
             if os.path.exists(p):
                 c = counters(p)
                 out[extra] = {short(k): {"dispatches": n, **{cn: round(v) for cn, v in vals.items()}}
                               for k, (vals, n) in c.items() if n >= n_main}
-        with open(os.path.join(DST, f"r02_{name}_pmc.json"), "w") as f:
+        with open(os.path.join(DST, f"{RND}_{name}_pmc.json"), "w") as f:
             json.dump(out, f, indent=1)
         print(name, "traffic/launch %.2f GB = %.1f B/row (%.2fx algorithmic)" % (traffic / 1e9, traffic / rows, traffic / (bpr * rows)))
 

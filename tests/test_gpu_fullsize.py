@@ -125,10 +125,13 @@ def test_c3_join_probe_at_baseline_size(mgr, oracle):
     cp = w.compiled
     out = torch.empty(max(cp.buffer_quads, 1), dtype=torch.int64, device="cuda")
     names = _run_into(w, out)
-    assert names.startswith("hdk_join_agg_direct"), names  # the shape's own kernel over the fused table
+    # a 160 MB table: key-range slices probed out of LDS (scan_join_sliced.h), the row-order kernel armed behind them
+    assert names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,hdk_join_agg_direct"), names
     ref = w.reference_checks()
     got = int(out[0].item()) % (1 << 64)
     assert got == ref["sum_val_plus_dval"]
+    assert _run_into(w, out, flags=A.LAUNCH_NO_CLUSTER_PROBES).startswith("hdk_join_agg_direct")  # in row order
+    assert int(out[0].item()) % (1 << 64) == got
     assert _run_into(w, out, flags=A.LAUNCH_FORCE_GENERIC).startswith("hdk_scan_agg_vec_join")  # the batched interpreter
     assert int(out[0].item()) % (1 << 64) == got
     w.ex.fuse_join_tables = False  # the reference's table layout (slot -> row id -> inner column)
