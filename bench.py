@@ -426,12 +426,14 @@ def cpu_baseline(w, args):
     srows = int(sum(rows))
     init_buf = oracle_init_buffer(O, cp)
 
+    last = {}
+
     def timed(fr, nr, threads):
         hf = O.HostFragments(fr, nr)
         times = []
         for _ in range(5):
             tc = time.perf_counter()
-            err, _ = O.run_plan_parallel(cp.plan, hf, init_buf, cp.init_vals, threads)
+            err, last["buf"] = O.run_plan_parallel(cp.plan, hf, init_buf, cp.init_vals, threads)
             times.append(time.perf_counter() - tc)
             assert err == 0
         return srows / float(np.median(times))
@@ -449,10 +451,34 @@ def cpu_baseline(w, args):
                 subrows.append(b - a)
         t_all = int(min(nproc, O.lib().orc_max_threads()))
         variants["sub_tasks_all_cores"] = {"rows_per_s": timed(sub, subrows, t_all), "threads": t_all}
-    best = max(variants.values(), key=lambda v: v["rows_per_s"])
+    # the row loop HDK's JIT would emit for this query, hand-inlined (oracle/hdk_oracle.c: orc_c2_jit_shaped): decoders ->
+    # get_group_value_fast -> agg_sum[_skip_val] with the plan's constants folded, one kernel per fragment on its own
+    # thread with a private buffer, fragments first touched by the thread that scans them; bit-exact vs the interpreter
+    want = np.array(last["buf"], copy=True)
+    for label, ft in (("jit_shaped", True), ("jit_shaped_no_first_touch", False)):
+        try:
+            sec, out = O.c2_jit_shaped([f[0] for f in frags], [f[1] for f in frags], cp.plan, init_buf, threads, first_touch=ft, reps=5)
+        except (ValueError, MemoryError) as e:
+            variants[label] = {"error": str(e)}
+            continue
+        variants[label] = {"rows_per_s": srows / sec, "threads": threads, "host_GBps": srows * w.alg_bytes_per_row / sec / 1e9,
+                           "bit_exact_vs_interpreter": bool(np.array_equal(out, want)), "timing": "best of 5, scan + reduction"}
+    if pieces > 1:  # every core busy: the fragments cut into sub-ranges (QE/ExecutionKernel.cpp:341-358)
+        try:
+            sec, out = O.c2_jit_shaped([c[0] for c in sub], [c[1] for c in sub], cp.plan, init_buf, t_all, first_touch=True, reps=5)
+            variants["jit_shaped_all_cores"] = {"rows_per_s": srows / sec, "threads": t_all,
+                                                "host_GBps": srows * w.alg_bytes_per_row / sec / 1e9,
+                                                "bit_exact_vs_interpreter": bool(np.array_equal(out, want)),
+                                                "timing": "best of 5, scan + reduction"}
+        except (ValueError, MemoryError) as e:
+            variants["jit_shaped_all_cores"] = {"error": str(e)}
+    best = max((v for v in variants.values() if "rows_per_s" in v), key=lambda v: v["rows_per_s"])
     return {"value": best["rows_per_s"], "unit": "rows/s", "cores": best["threads"], "host_cores": nproc, "kind": "port",
-            "sample": f"{len(sample)} of {w.nfrag} fragments = {srows} rows of the same table; oracle row function, one kernel "
-                      f"per fragment (or per sub-range) on OpenMP threads + reduction of the partials; median of 5",
+            "sample": f"{len(sample)} of {w.nfrag} fragments = {srows} rows of the same table; one kernel per fragment (or per "
+                      f"sub-range) on OpenMP threads + reduction of the partials.  kernel_per_fragment / sub_tasks_all_cores: the "
+                      f"oracle's plan INTERPRETER (median of 5); jit_shaped: the row loop HDK's LLVM JIT would emit for this query, "
+                      f"hand-inlined, fragments first-touched by their thread (best of 5) -- the figure to compare a GPU with",
+            "best_variant": next(k for k, v in variants.items() if v is best),
             "variants": variants}
 
 

@@ -7,12 +7,14 @@
  *
  * Plain C11, scalar, row-at-a-time, in the reference's own order of operations.
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime for the timed baseline loop */
 #include "hdk_oracle.h"
 
 #include <float.h>
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -2295,4 +2297,118 @@ int32_t orc_run_plan_parallel(const hdk_hip_plan* plan, const int8_t* const* con
   }
   free(partials);
   return err;
+}
+
+/* ---- CPU baseline, JIT-shaped (bench.py `cpu_baseline.variants.jit_shaped`; never part of the product) -------------
+ * What HDK's LLVM backend emits for `SELECT key, SUM(val) FROM t GROUP BY key` over a perfect-hash, row-wise layout,
+ * written out by hand: the row function is the decoders (fixed_width_int_decode, QE/DecodersImpl.h:30-61) feeding
+ * get_group_value_fast (QE/GroupByRuntime.cpp:198-213: off = (key - min) * row_size_quad; the first row of a group
+ * writes the key) and agg_sum / agg_sum_skip_val (QE/RuntimeFunctions.cpp:456-461, 612-625), all inlined into one
+ * loop per fragment with the plan's constants folded -- no plan interpretation per row, which is what
+ * orc_run_plan_range spends its time on.  Execution scheme as in orc_run_plan_parallel: one kernel per fragment on a
+ * thread pool with a private output buffer (QE/Execute.cpp:2776-2788), then the slot-wise reduction of the partials
+ * (QE/Execute.cpp:1290-1317).  `first_touch` != 0: every fragment is first copied into memory allocated and written
+ * by the thread that will scan it (NUMA-local pages, outside the timed region) -- numpy hands over buffers whose
+ * pages all sit on the node of the thread that filled them.
+ * key / val: 8-byte columns; buf: [entry_count][row_quads] quads, the projected key's slot at quad `key_slot` (or -1)
+ * and the SUM slot at quad `sum_slot`, initialised by the caller; returns the seconds of the
+ * timed region (scan + reduction) or a negative number on error. */
+double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals, const int64_t* num_rows,
+                         uint64_t num_fragments, int64_t min_key, uint32_t entry_count, uint32_t row_quads,
+                         int32_t keyless, int32_t key_slot, int32_t sum_slot, int32_t skip_null, int64_t null_val,
+                         const int64_t* init_buffer, int32_t num_threads, int32_t first_touch, int32_t reps,
+                         int64_t* out) {
+  const size_t rq = row_quads;
+  const size_t quads = (size_t)entry_count * rq;
+  if (num_threads < 1) num_threads = 1;
+  if (reps < 1) reps = 1;
+  int64_t** lk = (int64_t**)calloc(num_fragments, sizeof(int64_t*));
+  int64_t** lv = (int64_t**)calloc(num_fragments, sizeof(int64_t*));
+  int64_t* partials = (int64_t*)malloc(num_fragments * quads * sizeof(int64_t));
+  if (!lk || !lv || !partials) return -1.0;
+  int bad = 0;
+  /* same static fragment -> thread map for the copy and for the scans */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(num_threads)
+#endif
+  for (int64_t f = 0; f < (int64_t)num_fragments; ++f) {
+    if (first_touch) {
+      const size_t bytes = (size_t)num_rows[f] * 8;
+      lk[f] = (int64_t*)malloc(bytes ? bytes : 8);
+      lv[f] = (int64_t*)malloc(bytes ? bytes : 8);
+      if (!lk[f] || !lv[f]) {
+        bad = 1;
+      } else {
+        memcpy(lk[f], keys[f], bytes);
+        memcpy(lv[f], vals[f], bytes);
+      }
+    } else {
+      lk[f] = (int64_t*)keys[f];
+      lv[f] = (int64_t*)vals[f];
+    }
+  }
+  double best = -1.0;
+  for (int r = 0; r < reps && !bad; ++r) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(num_threads)
+#endif
+    for (int64_t f = 0; f < (int64_t)num_fragments; ++f) {
+      int64_t* restrict buf = partials + (size_t)f * quads;
+      memcpy(buf, init_buffer, quads * sizeof(int64_t));
+      const int64_t* restrict k = lk[f];
+      const int64_t* restrict v = lv[f];
+      const int64_t n = num_rows[f];
+      if (skip_null) {
+        for (int64_t i = 0; i < n; ++i) {
+          int64_t* row = buf + (size_t)(k[i] - min_key) * rq; /* get_group_value_fast[_keyless] */
+          if (!keyless && row[0] == HDK_EMPTY_KEY_64) row[0] = k[i];
+          if (key_slot >= 0) row[key_slot] = k[i]; /* agg_id: the projected key's own slot */
+          const int64_t x = v[i];
+          if (x != null_val) { /* agg_sum_skip_val */
+            row[sum_slot] = row[sum_slot] == null_val ? x : (int64_t)((uint64_t)row[sum_slot] + (uint64_t)x);
+          }
+        }
+      } else {
+        for (int64_t i = 0; i < n; ++i) {
+          int64_t* row = buf + (size_t)(k[i] - min_key) * rq;
+          if (!keyless && row[0] == HDK_EMPTY_KEY_64) row[0] = k[i];
+          if (key_slot >= 0) row[key_slot] = k[i];
+          row[sum_slot] = (int64_t)((uint64_t)row[sum_slot] + (uint64_t)v[i]); /* agg_sum */
+        }
+      }
+    }
+    memcpy(out, init_buffer, quads * sizeof(int64_t));
+    for (uint64_t f = 0; f < num_fragments; ++f) { /* reduceOneSlot over the partials, in fragment order */
+      const int64_t* p = partials + (size_t)f * quads;
+      for (uint32_t e = 0; e < entry_count; ++e) {
+        /* isEmptyEntry (RS/ResultSetStorage.cpp:439-547): the key, or -- keyless -- the slot idx_target_as_key names
+         * still at its init value (`keyless` = that quad + 1) */
+        if (keyless ? p[(size_t)e * rq + keyless - 1] == init_buffer[keyless - 1] : p[(size_t)e * rq] == HDK_EMPTY_KEY_64) continue;
+        if (!keyless) out[(size_t)e * rq] = p[(size_t)e * rq];
+        if (key_slot >= 0) out[(size_t)e * rq + key_slot] = p[(size_t)e * rq + key_slot];
+        const int64_t x = p[(size_t)e * rq + sum_slot];
+        int64_t* s = out + (size_t)e * rq + sum_slot;
+        if (skip_null) {
+          if (x != null_val) *s = *s == null_val ? x : (int64_t)((uint64_t)*s + (uint64_t)x);
+        } else {
+          *s = (int64_t)((uint64_t)*s + (uint64_t)x);
+        }
+      }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (best < 0 || sec < best) best = sec;
+  }
+  if (first_touch) {
+    for (uint64_t f = 0; f < num_fragments; ++f) {
+      free(lk[f]);
+      free(lv[f]);
+    }
+  }
+  free(lk);
+  free(lv);
+  free(partials);
+  return bad ? -1.0 : best;
 }

@@ -199,6 +199,12 @@ int32_t orc_run_plan_parallel(const hdk_hip_plan* plan, const int8_t* const* con
                               const int64_t* join_hash_tables, const int64_t* init_buffer,
                               size_t buffer_quads, const int64_t* init_vals, int32_t num_threads,
                               int64_t* out);
+/* CPU baseline only (bench.py): the row loop HDK's JIT would emit for C2, hand-inlined; see hdk_oracle.c */
+double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals, const int64_t* num_rows,
+                         uint64_t num_fragments, int64_t min_key, uint32_t entry_count, uint32_t row_quads,
+                         int32_t keyless, int32_t key_slot, int32_t sum_slot, int32_t skip_null, int64_t null_val,
+                         const int64_t* init_buffer, int32_t num_threads, int32_t first_touch, int32_t reps,
+                         int64_t* out);
 int32_t orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -13,7 +13,8 @@ import numpy as np
 from hdk_amd import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libhdk_oracle.so")
+# HDK_ORACLE_LIB: another build of the same checker (the sanitizer build, scripts/run_sanitizers.sh)
+_LIB = os.environ.get("HDK_ORACLE_LIB") or os.path.join(_HERE, "libhdk_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libhdk_ref_runtime.so")
 
 i8p = C.POINTER(C.c_int8)
@@ -27,7 +28,7 @@ def build(force=False):
     """(Re)build the oracle library (and _ref when /root/reference exists)."""
     # always go through make: it is a no-op when up to date and rebuilds when include/hdk_hip.h (the
     # plan POD the oracle's row function reads) changed
-    subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", "libhdk_oracle.so"],
+    subprocess.check_call(["make", "-C", _HERE, "--no-print-directory", os.path.basename(_LIB)],
                           stdout=subprocess.DEVNULL)
 
 
@@ -111,6 +112,8 @@ def lib():
     _sig(L, "orc_is_empty_entry", C.c_int32, C.POINTER(A.Plan), v, C.c_uint32, C.c_uint32, v)
     _sig(L, "orc_run_plan_parallel", C.c_int32, C.POINTER(A.Plan), v, C.c_uint64, v, C.c_uint32, v,
          v, C.c_size_t, v, C.c_int32, v)
+    _sig(L, "orc_c2_jit_shaped", C.c_double, v, v, v, C.c_uint64, C.c_int64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+         C.c_int32, C.c_int32, C.c_int64, v, C.c_int32, C.c_int32, C.c_int32, v)
     _sig(L, "orc_max_threads", C.c_int32)
     _sig(L, "orc_sizeof_plan", C.c_size_t)
     if L.orc_sizeof_plan() != C.sizeof(A.Plan):
@@ -286,3 +289,35 @@ def make_join_chunks(arrays):
         chunks[i].row_id = rid
         rid += a.size
     return chunks
+
+
+def c2_jit_shaped(keys, vals, plan, init_buffer, threads, first_touch=True, reps=3):
+    """CPU baseline leg of bench.py: GROUP BY key SUM(val) over 8-byte columns with the row loop HDK's JIT would emit
+    (hdk_oracle.c: orc_c2_jit_shaped).  keys / vals: lists of int64 numpy arrays, one per fragment.
+    Returns (seconds of the best of `reps` timed regions, output buffer)."""
+    n = len(keys)
+    kp = (C.c_void_p * n)(*[k.ctypes.data for k in keys])
+    vp = (C.c_void_p * n)(*[x.ctypes.data for x in vals])
+    nr = np.array([len(k) for k in keys], dtype=np.int64)
+    init = np.ascontiguousarray(init_buffer, dtype=np.int64)
+    out = np.empty_like(init)
+    # the C2 shape: perfect hash on one 8-byte key, row-wise, targets = [projected key,] SUM(8-byte integer column)
+    p = plan
+    if not (p.query_kind == A.Q_PERFECT_HASH and p.key_count == 1 and not p.output_columnar and
+            p.key_bucket[0] in (0, 1) and not p.key_has_nulls[0]):
+        raise ValueError("not the C2 shape")
+    key_slot, sum_slot, skip, nullv = -1, -1, 0, 0
+    for t in range(p.num_targets):
+        tg = p.targets[t]
+        if tg.agg == A.AGG_ID and tg.slot_width == 8:
+            key_slot = tg.slot_off // 8
+        elif tg.agg == A.AGG_SUM and tg.slot_width == 8 and not tg.arg_is_fp and sum_slot < 0:
+            sum_slot, skip, nullv = tg.slot_off // 8, int(tg.skip_null), int(tg.null_val)
+        else:
+            raise ValueError("not the C2 shape")
+    sec = lib().orc_c2_jit_shaped(kp, vp, nr.ctypes.data, n, int(p.key_min[0]), int(p.entry_count), int(p.row_size_quad),
+                                  (int(p.idx_target_as_key) + 1) if p.keyless else 0, key_slot, sum_slot, skip, nullv, init.ctypes.data, int(threads), int(bool(first_touch)),
+                                  int(reps), out.ctypes.data)
+    if sec < 0:
+        raise MemoryError("orc_c2_jit_shaped could not allocate its fragment copies")
+    return sec, out

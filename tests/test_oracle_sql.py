@@ -178,3 +178,29 @@ def test_float_accumulators_follow_row_order_float_arithmetic(oracle):
         s, lo, hi, a, c = got[g]
         assert (np.float32(s), np.float32(lo), np.float32(hi), c) == (acc, v.min(), v.max(), len(v))
         assert a == float(acc) / len(v)
+
+
+def test_jit_shaped_baseline_loop_is_bit_exact_with_the_interpreter(oracle):
+    """bench.py's CPU baseline (orc_c2_jit_shaped: the row loop HDK's JIT would emit for C2, hand-inlined) against the
+    oracle's plan interpreter on the same fragments: keyed and keyless layouts, NULLs, absent keys, 1 and 4 threads."""
+    from hdk_amd.plan import compile_query
+    from util import oracle_init_buffer, run_oracle
+    rng = np.random.default_rng(12)
+    n = 300_000
+    for nulls, domain in ((0.02, 64), (0.0, 64), (0.3, 50)):
+        key = rng.integers(3, 3 + domain, n, dtype=np.int64)
+        key[key == 17] = 18  # an empty entry in the middle of the table
+        val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+        if nulls:
+            val[rng.random(n) < nulls] = A.NULL_BIGINT
+        st = ArrowStorage()
+        st.import_numpy("t", {"key": key, "val": val}, fragment_size=41_000)
+        q = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        t = st.get("t")
+        for threads in (1, 4):
+            for ft in (True, False):
+                sec, out = oracle.c2_jit_shaped(t.columns["key"].fragments, t.columns["val"].fragments, cp.plan,
+                                                oracle_init_buffer(oracle, cp), threads, first_touch=ft, reps=2)
+                assert sec > 0 and np.array_equal(out, want), (nulls, domain, threads, ft, bool(cp.plan.keyless))
