@@ -56,7 +56,7 @@ SIGNATURES = {
     "hdk_hip_mgr_get_device_properties": (i32, [i32, C.POINTER(A.DeviceProperties)]),
     "hdk_hip_init_group_by_buffer": (i32, [v, v, u32, u32, u32, u32, i32, i8, sz, sz, i32, v]),
     "hdk_hip_init_columnar_group_by_buffer": (i32, [v, v, u32, u32, u32, v, i32, i32, i8, sz, sz, i32, v]),
-    "hdk_hip_validate_plan": (i32, [C.POINTER(A.Plan)]),
+    "hdk_hip_validate_plan": (i32, [C.POINTER(A.Plan), i32]),
     "hdk_hip_workspace_size": (i32, [C.POINTER(A.Plan), C.POINTER(A.KernelOptions), i32, C.POINTER(sz)]),
     "hdk_hip_launch": (i32, [C.POINTER(A.Plan), C.POINTER(v), C.POINTER(A.KernelOptions), i32, v, v, sz]),
     "hdk_hip_collect_scan_times": (i32, [i32, C.POINTER(C.c_float), i32, C.POINTER(i32)]),

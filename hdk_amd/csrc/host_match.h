@@ -105,7 +105,8 @@ inline bool launch_forces_generic(const hdk_hip_kernel_options* ko) {
 }
 
 // ---- scan_agg.hip ---------------------------------------------------------------------------------------------------
-int32_t validate_plan(const hdk_hip_plan* p);
+int32_t validate_plan(const hdk_hip_plan* p);         // everything a launch reads
+int32_t validate_plan_layout(const hdk_hip_plan* p);  // the output layout only (reductions, table helpers)
 // head of every launch: plan copy + the launch's interrupt / watchdog words into the front of `workspace`
 // (kPlanRegionBytes), the 12 launch pointers into a KernParams
 int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], const hdk_hip_kernel_options* ko,

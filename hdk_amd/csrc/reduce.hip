@@ -558,7 +558,7 @@ static int32_t run_partition(const hdk_hip_plan* plan, const int64_t* buf, uint3
   return HDK_HIP_OK;
 }
 
-int32_t validate_plan(const hdk_hip_plan* p);  // scan_agg.hip
+int32_t validate_plan_layout(const hdk_hip_plan* p);  // scan_agg.hip: the layout half of the plan check
 
 }  // namespace hdk
 
@@ -568,7 +568,7 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
                                           const int64_t* const* that_bufs, const uint32_t* that_entry_counts,
                                           int32_t num_that, const int64_t* init_vals, int32_t* dev_error,
                                           int32_t device_id, void* stream) {
-  int32_t st = validate_plan(plan);
+  int32_t st = validate_plan_layout(plan);
   if (st) return st;
   HDK_REQUIRE(this_buf && (num_that == 0 || (that_bufs && that_entry_counts)) && init_vals, "NULL argument");
   HDK_REQUIRE(num_that >= 0, "num_that must be >= 0");
@@ -630,7 +630,7 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
 }
 
 extern "C" int32_t hdk_hip_baseline_table_quads(const hdk_hip_plan* plan, uint32_t entry_count, int64_t* quads) {
-  const int32_t st = validate_plan(plan);
+  const int32_t st = validate_plan_layout(plan);
   if (st) return st;
   HDK_REQUIRE(quads, "quads is NULL");
   HDK_REQUIRE(plan->query_kind == HDK_Q_BASELINE_HASH, "not a baseline-hash plan");
@@ -640,7 +640,7 @@ extern "C" int32_t hdk_hip_baseline_table_quads(const hdk_hip_plan* plan, uint32
 
 static int32_t check_partition_args(const hdk_hip_plan* plan, const int64_t* buf, const int64_t* init_vals,
                                     int32_t num_owners) {
-  const int32_t st = validate_plan(plan);
+  const int32_t st = validate_plan_layout(plan);
   if (st) return st;
   HDK_REQUIRE(plan->query_kind == HDK_Q_BASELINE_HASH, "not a baseline-hash plan");
   HDK_REQUIRE(buf && init_vals, "NULL argument");

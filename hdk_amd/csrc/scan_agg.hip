@@ -473,7 +473,10 @@ static int32_t check_expr(const hdk_hip_plan* p, const hdk_hip_expr& e, const ch
   return HDK_HIP_OK;
 }
 
-int32_t validate_plan(const hdk_hip_plan* p) {
+// `exprs`: also every expression, column and join the scan kernels read.  The reductions and the table helpers are
+// handed plans that only describe the output layout (a QueryMemoryDescriptor's worth: hdk_amd/glue/HipPlanBuilder.h
+// make_plan; the reference's ResultSetReduction needs nothing else): they check with exprs = false.
+static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
   HDK_REQUIRE(p, "plan is NULL");
   HDK_REQUIRE(p->abi_version == HDK_HIP_PLAN_ABI, "plan ABI %u != library ABI %u", p->abi_version,
               HDK_HIP_PLAN_ABI);
@@ -482,7 +485,7 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   HDK_REQUIRE(p->num_joins >= 0 && p->num_joins <= HDK_HIP_MAX_JOINS, "bad num_joins");
   HDK_REQUIRE(p->key_count >= 0 && p->key_count <= HDK_HIP_MAX_KEYS, "bad key_count");
   int32_t st;
-  for (int i = 0; i < p->num_cols; ++i) {
+  for (int i = 0; exprs && i < p->num_cols; ++i) {
     const hdk_hip_col& c = p->cols[i];
     HDK_REQUIRE(c.width == 1 || c.width == 2 || c.width == 4 || c.width == 8, "column %d: width %d is not 1/2/4/8", i, c.width);
     HDK_REQUIRE(c.kind >= HDK_COL_INT && c.kind <= HDK_COL_DOUBLE, "column %d: bad kind %d", i, c.kind);
@@ -498,7 +501,7 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     }
     HDK_REQUIRE(c.has_stats == 0 || c.has_stats == 1, "column %d: has_stats must be 0 or 1", i);
   }
-  for (int i = 0; i < p->num_quals; ++i) {
+  for (int i = 0; exprs && i < p->num_quals; ++i) {
     const hdk_hip_qual& q = p->quals[i];
     if ((st = check_expr(p, q.lhs, "filter lhs"))) return st;
     if ((st = check_leaf(p, q.rhs, false, "filter rhs"))) return st;
@@ -506,10 +509,10 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     HDK_REQUIRE(q.after_joins == 0 || q.after_joins == 1, "filter %d: after_joins must be 0 or 1", i);
   }
   HDK_REQUIRE(p->filter_after_joins == 0 || p->filter_after_joins == 1, "filter_after_joins must be 0 or 1");
-  for (int k = 0; k < p->key_count; ++k) {
+  for (int k = 0; exprs && k < p->key_count; ++k) {
     if ((st = check_expr(p, p->keys[k], "group-by key"))) return st;
   }
-  for (int j = 0; j < p->num_joins; ++j) {
+  for (int j = 0; exprs && j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     HDK_REQUIRE(jn.kind >= HDK_JOIN_ONE_TO_ONE && jn.kind <= HDK_JOIN_KEYED_ONE_TO_MANY, "bad join kind");
     HDK_REQUIRE(jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_LEFT, "bad join type");
@@ -567,7 +570,7 @@ int32_t validate_plan(const hdk_hip_plan* p) {
       const hdk_hip_target& tg = p->targets[t];
       HDK_REQUIRE(tg.agg == HDK_AGG_ID && tg.has_arg, "projection targets are plain expressions");
       HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
-      if ((st = check_expr(p, tg.arg, "projection target"))) return st;
+      if (exprs && (st = check_expr(p, tg.arg, "projection target"))) return st;
       HDK_REQUIRE(tg.slot_off >= 0 && (p->output_columnar || static_cast<int64_t>(tg.slot_off) + tg.slot_width <=
                                                                   static_cast<int64_t>(p->row_size_quad) * 8),
                   "target %d: slot at offset %d does not fit the row", t, tg.slot_off);
@@ -598,9 +601,9 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     HDK_REQUIRE(tg.agg >= HDK_AGG_COUNT && tg.agg <= HDK_AGG_ID, "target %d: bad aggregate kind %d", t, tg.agg);
     HDK_REQUIRE(tg.has_arg == 0 || tg.has_arg == 1, "target %d: has_arg must be 0 or 1", t);
     HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
-    HDK_REQUIRE(tg.has_arg || tg.agg == HDK_AGG_COUNT || (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED),
+    HDK_REQUIRE(!exprs || tg.has_arg || tg.agg == HDK_AGG_COUNT || (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED),
                 "target %d: only COUNT(*) and projected keys have no argument", t);
-    if (tg.has_arg && (st = check_expr(p, tg.arg, "target argument"))) return st;
+    if (exprs && tg.has_arg && (st = check_expr(p, tg.arg, "target argument"))) return st;
     if (p->query_kind != HDK_Q_NON_GROUPED && tg.slot_width != 0) {
       // a slot lies inside the row (row-wise) / starts on its own alignment (columnar)
       HDK_REQUIRE(tg.slot_off >= 0 && (p->output_columnar || static_cast<int64_t>(tg.slot_off) + tg.slot_width <= row_bytes),
@@ -627,7 +630,7 @@ int32_t validate_plan(const hdk_hip_plan* p) {
     if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
       HDK_REQUIRE(tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX || tg.agg == HDK_AGG_AVG,
                   "target %d: a float accumulator belongs to SUM / MIN / MAX / AVG", t);
-      HDK_REQUIRE(tg.has_arg && tg.arg.vclass == HDK_VC_FP, "target %d: a float accumulator needs a floating-point argument", t);
+      HDK_REQUIRE(!exprs || (tg.has_arg && tg.arg.vclass == HDK_VC_FP), "target %d: a float accumulator needs a floating-point argument", t);
     } else if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
       set_error("a 4-byte slot cannot hold a double: float arguments use arg_is_fp = HDK_FP_SLOT_FLOAT");
       return HDK_HIP_ERR_UNSUPPORTED;
@@ -641,6 +644,9 @@ int32_t validate_plan(const hdk_hip_plan* p) {
   }
   return HDK_HIP_OK;
 }
+
+int32_t validate_plan(const hdk_hip_plan* p) { return validate_plan_impl(p, true); }
+int32_t validate_plan_layout(const hdk_hip_plan* p) { return validate_plan_impl(p, false); }
 
 struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
@@ -1540,7 +1546,9 @@ int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT]
 
 }  // namespace hdk
 
-extern "C" int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan) { return validate_plan(plan); }
+extern "C" int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan, int32_t layout_only) {
+  return layout_only ? validate_plan_layout(plan) : validate_plan(plan);
+}
 
 extern "C" int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                           int32_t device_id, size_t* bytes) {

@@ -441,8 +441,12 @@ int32_t hdk_hip_set_interrupt(int32_t device_id, int32_t value);
 /* Host-only check of a plan: ABI version, every count, index, width and enumerator a kernel or a matcher reads
  * (column widths and tables, leaf column indices, expression steps, comparison / join / aggregate kinds, slot
  * offsets inside the row, the filter program).  Every entry point that takes a plan runs it first; a malformed plan
- * gets HDK_HIP_ERR_INVALID_ARG (or _UNSUPPORTED) and a message, never an out-of-bounds read.  No device is touched. */
-int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan);
+ * gets HDK_HIP_ERR_INVALID_ARG (or _UNSUPPORTED) and a message, never an out-of-bounds read.  No device is touched.
+ * layout_only != 0: only what describes the OUTPUT buffer (query kind, keys' count and width, targets' aggregates and
+ * slots, entry count) -- what hdk_hip_reduce_buffers, hdk_hip_partition_baseline* and hdk_hip_baseline_table_quads
+ * need and check; a caller that reduces buffers may leave columns, filters, joins and expressions unset, as the
+ * reference's ResultSetReduction works from the QueryMemoryDescriptor alone. */
+int32_t hdk_hip_validate_plan(const hdk_hip_plan* plan, int32_t layout_only);
 /* Bytes of device scratch `hdk_hip_launch` needs for this plan (per-block partial tables). */
 int32_t hdk_hip_workspace_size(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,
                                int32_t device_id, size_t* bytes);

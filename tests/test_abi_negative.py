@@ -90,12 +90,12 @@ def test_planner_output_validates_and_corruptions_do_not():
     kinds = set()
     rejected = 0
     for cp in plans:
-        assert L.hdk_hip_validate_plan(C.byref(cp.plan)) == A.OK, L.hdk_hip_last_error()
+        assert L.hdk_hip_validate_plan(C.byref(cp.plan), 0) == A.OK, L.hdk_hip_last_error()
         kinds.add((int(cp.plan.query_kind), int(cp.plan.num_joins) > 0, bool(cp.plan.output_columnar)))
         for what, mutate in corruptions(cp):
             bad = A.Plan.from_buffer_copy(cp.plan)
             mutate(bad)
-            st = L.hdk_hip_validate_plan(C.byref(bad))
+            st = L.hdk_hip_validate_plan(C.byref(bad), 0)
             assert st in (A.ERR_INVALID_ARG, A.ERR_UNSUPPORTED), (what, st)
             assert L.hdk_hip_last_error()  # a message names the field
             rejected += 1
@@ -104,14 +104,39 @@ def test_planner_output_validates_and_corruptions_do_not():
 
 def test_null_and_garbage_plans():
     L = lib()
-    assert L.hdk_hip_validate_plan(None) == A.ERR_INVALID_ARG
+    assert L.hdk_hip_validate_plan(None, 0) == A.ERR_INVALID_ARG
     rng = np.random.default_rng(3)
     for _ in range(200):  # random bytes: must be rejected (or, by miracle, valid) -- never crash
         raw = rng.integers(0, 256, C.sizeof(A.Plan), dtype=np.uint8).tobytes()
         p = A.Plan.from_buffer_copy(raw)
         p.abi_version = A.PLAN_ABI
-        assert L.hdk_hip_validate_plan(C.byref(p)) in (A.OK, A.ERR_INVALID_ARG, A.ERR_UNSUPPORTED)
+        assert L.hdk_hip_validate_plan(C.byref(p), 0) in (A.OK, A.ERR_INVALID_ARG, A.ERR_UNSUPPORTED)
+        assert L.hdk_hip_validate_plan(C.byref(p), 1) in (A.OK, A.ERR_INVALID_ARG, A.ERR_UNSUPPORTED)
     # host-only entry points that take a plan run the same check
     q = C.c_int64(0)
     bad = A.Plan()
     assert L.hdk_hip_baseline_table_quads(C.byref(bad), 10, C.byref(q)) == A.ERR_INVALID_ARG
+
+
+def test_layout_only_plans_of_the_reduction_matrices_validate():
+    """hdk_hip_reduce_buffers takes plans that only describe the output layout (the reference's reduction works from
+    the QueryMemoryDescriptor alone): the reference's Reduce.* / ReduceRandomGroups.* descriptors pass the layout
+    check, and corrupting the layout half is still caught."""
+    import rs_matrix as M
+    from test_resultset_matrices import DOC, RANDOM, REDUCE
+    L = lib()
+    n = 0
+    for case in REDUCE + RANDOM:
+        lay = M.make_layout(DOC, case)
+        if not M.supported_by_library(lay):
+            continue
+        plan = M.make_plan(lay)
+        assert L.hdk_hip_validate_plan(C.byref(plan), 1) == A.OK, (case["name"], L.hdk_hip_last_error())
+        bad = A.Plan.from_buffer_copy(plan)
+        bad.targets[0].agg = 23
+        assert L.hdk_hip_validate_plan(C.byref(bad), 1) == A.ERR_INVALID_ARG
+        bad = A.Plan.from_buffer_copy(plan)
+        bad.entry_count = 0
+        assert L.hdk_hip_validate_plan(C.byref(bad), 1) == A.ERR_INVALID_ARG
+        n += 1
+    assert n >= 70
