@@ -39,7 +39,7 @@ struct HipTargetDesc {
   bool has_arg;       // false: COUNT(*)
   hdk_hip_expr arg;
   bool skip_null;     // TargetInfo::skip_null_val
-  bool arg_is_fp;
+  int32_t arg_is_fp;  // hdk_hip_fp_slot: NONE, DOUBLE (agg_*_double family), FLOAT (takes_float_argument: agg_*_float)
   int32_t key_idx;    // HDK_AGG_ID: projected group-by key
   int64_t null_val;   // the skip value TargetExprBuilder passes (QE/TargetExprBuilder.cpp:437-452)
 };
@@ -47,9 +47,18 @@ struct HipTargetDesc {
 struct HipWorkUnit {
   std::vector<HipInputCol> cols;
   std::vector<hdk_hip_qual> quals;     // simple_quals + quals of the RelAlgExecutionUnit
+  std::vector<uint8_t> filter_ops;     // postfix program over `quals` when the filter is not a plain conjunction
+  int32_t filter_after_joins{0};       // ... and the stage the program runs at
   std::vector<hdk_hip_join> joins;
   std::vector<hdk_hip_expr> keys;      // groupby_exprs
   std::vector<int64_t> key_card;       // ColRangeInfo::getBucketedCardinality per key (multi-column perfect hash)
+  // get_expr_range_info per group-by expression (QE/ColRangeInfo.cpp:28-66), for perfect hash over several keys: each
+  // key's own range feeds the key index (RowFuncBuilder.cpp:748-801).  Empty: the descriptor's single range is used.
+  struct KeyRange {
+    int64_t min, max, bucket;
+    bool has_nulls;
+  };
+  std::vector<KeyRange> key_ranges;
   std::vector<HipTargetDesc> targets;  // target_exprs
 };
 
@@ -96,13 +105,27 @@ hdk_hip_plan make_plan(const HipWorkUnit& wu, const QMD& qmd) {
   }
   p.num_quals = static_cast<int32_t>(wu.quals.size());
   for (size_t i = 0; i < wu.quals.size(); ++i) p.quals[i] = wu.quals[i];
+  if (wu.filter_ops.size() > HDK_HIP_MAX_FILTER_OPS) {
+    throw std::runtime_error("QueryMustRunOnCpu: filter program too long for the fixed kernel library");
+  }
+  p.num_filter_ops = static_cast<int32_t>(wu.filter_ops.size());
+  for (size_t i = 0; i < wu.filter_ops.size(); ++i) p.filter_ops[i] = wu.filter_ops[i];
+  p.filter_after_joins = wu.filter_after_joins;
   p.num_joins = static_cast<int32_t>(wu.joins.size());
   for (size_t i = 0; i < wu.joins.size(); ++i) p.joins[i] = wu.joins[i];
   const bool grouped = p.query_kind == HDK_Q_PERFECT_HASH || p.query_kind == HDK_Q_BASELINE_HASH;
   p.key_count = grouped ? static_cast<int32_t>(wu.keys.size()) : 0;
   for (int k = 0; k < p.key_count; ++k) {
     p.keys[k] = wu.keys[k];
-    if (p.query_kind == HDK_Q_PERFECT_HASH) {  // ColRangeInfo of the descriptor (single column) / per-key cardinalities
+    if (p.query_kind == HDK_Q_PERFECT_HASH && !wu.key_ranges.empty()) {  // several keys: every key's own range
+      const HipWorkUnit::KeyRange& r = wu.key_ranges.at(k);
+      const int64_t step = r.bucket ? r.bucket : 1;
+      p.key_min[k] = r.min;
+      p.key_bucket[k] = r.bucket;
+      p.key_has_nulls[k] = r.has_nulls ? 1 : 0;
+      p.key_null_translated[k] = r.max + step;  // RowFuncBuilder.cpp:456-461
+      p.key_card[k] = (r.max - r.min) / step + 1 + (r.has_nulls ? 1 : 0);  // getBucketedCardinality
+    } else if (p.query_kind == HDK_Q_PERFECT_HASH) {  // ColRangeInfo of the descriptor (single column) / per-key cardinalities
       p.key_min[k] = qmd.getMinVal();
       p.key_bucket[k] = qmd.getBucket();
       p.key_has_nulls[k] = qmd.hasNulls() ? 1 : 0;
@@ -127,11 +150,14 @@ hdk_hip_plan make_plan(const HipWorkUnit& wu, const QMD& qmd) {
     tg.has_arg = d.has_arg ? 1 : 0;
     tg.arg = d.arg;
     tg.skip_null = d.skip_null ? 1 : 0;
-    tg.arg_is_fp = d.arg_is_fp ? 1 : 0;
+    tg.arg_is_fp = d.arg_is_fp;
     tg.key_idx = d.key_idx;
     tg.null_val = d.null_val;
     tg.slot_width = static_cast<int32_t>(qmd.getPaddedSlotWidthBytes(slot));
     tg.slot_off = static_cast<int32_t>(qmd.getColOffInBytes(slot));
+    if (tg.slot_width == 4 && d.arg_is_fp == HDK_FP_SLOT_NONE && d.null_val == INT64_MIN) {
+      tg.null_val = INT32_MIN;  // the skip value is slot-typed: inline_int_null_val of the compacted slot (TargetExprBuilder.cpp:437-452)
+    }
     ++slot;
     if (d.agg == HDK_AGG_AVG) {  // the count slot (ColSlotContext: two slots for AVG)
       tg.slot2_width = static_cast<int32_t>(qmd.getPaddedSlotWidthBytes(slot));

@@ -1,0 +1,447 @@
+// HipPlanExtractor.h -- RelAlgExecutionUnit -> HipWorkUnit: the EXPRESSION half of hdk_hip_plan.
+//
+// What the reference does with a work unit in Executor::compileWorkUnit (QE/NativeCodegen.cpp:1403-1545) is emit IR:
+// filters through CodeGenerator::codegen (QE/LogicalIR.cpp, QE/CompareIR.cpp), join loops (QE/IRCodegen.cpp:497-667),
+// the group-by key and one runtime call per target (QE/RowFuncBuilder.cpp:597-745: codegenAggCalls ->
+// TargetExprCodegen::codegen, QE/TargetExprBuilder.cpp:407-460: which agg_* function, with or without _skip_val, on
+// which slot).  With the fixed kernel library that step becomes a pattern match: every expression the kernels can
+// evaluate is written into the POD forms of include/hdk_hip.h, everything else throws QueryMustRunOnCpu, the
+// reference's own signal for "retry on CPU" (QE/RelAlgExecutor.cpp:183-192).  The layout half (slot widths, offsets,
+// keyless, entry count) is HipPlanBuilder.h: make_plan(HipWorkUnit, QueryMemoryDescriptor).
+//
+// The extractor is a template over an IR access policy, because hdk::ir cannot be compiled outside an HDK build
+// (IR/Expr.h -> Logger -> Boost): `IR` names the node type and reads it.  HdkIrAccess (HipIrAccessHdk.h, compiled
+// only inside HDK) reads hdk::ir::Expr through the accessors of IR/Expr.h; tests/cpp/ir_standin.h is a 100-line tree
+// with the same shape that the harness runs the SAME extractor over -- with the reference's own enums
+// (hdk::ir::OpType / AggType / DateExtractField, IR/OpTypeEnums.h and IR/DateTimeEnums.h are self-contained headers).
+//
+// Policy:   using Expr = ...;                                    node type (hdk::ir::Expr)
+//           static ExprKind kind(const Expr*);                   which of the classes below
+//           static TypeDesc type(const Expr*);                   class, byte size, nullability, decimal scale
+//           static bool same(const Expr*, const Expr*);          Expr::operator== (targets vs group-by expressions)
+//           ColumnVar : rte_idx (0 = outer table, j = inner table of join j - 1)
+//           Constant  : const_is_null, const_int, const_fp
+//           BinOper   : bin_op (hdk::ir::OpType), left, right
+//           UOper     : un_op (kCast / kNot / kUMinus ...), operand
+//           ExtractExpr : extract_field, extract_from
+//           AggExpr   : agg_type, agg_arg (nullptr: COUNT(*)), agg_distinct
+#pragma once
+
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "HipPlanBuilder.h"
+#include "IR/DateTimeEnums.h"
+#include "IR/OpTypeEnums.h"
+
+namespace hip_rt {
+
+struct QueryMustRunOnCpu : std::runtime_error {  // (inside HDK: the class of QE/ErrorHandling.h)
+  explicit QueryMustRunOnCpu(const std::string& why) : std::runtime_error("QueryMustRunOnCpu: " + why) {}
+};
+
+enum class ExprKind { ColumnVar, Constant, BinOper, UOper, Extract, Agg, Other };
+
+struct TypeDesc {
+  enum Cls { Integer, Decimal, Fp, Timestamp, Boolean, Other };
+  Cls cls{Other};
+  int size{8};          // bytes of the physical value (logical size; fixed-width encodings are the column's business)
+  bool nullable{true};
+  int scale{0};         // Decimal
+  bool seconds{true};   // Timestamp: unit is seconds (TIMESTAMP(0))
+  bool is_fp() const { return cls == Fp; }
+  bool integer_like() const { return cls == Integer || cls == Decimal || cls == Timestamp || cls == Boolean; }
+};
+
+// in-band NULL of a value of this type, widened the way the decoders hand it to the kernels: integers sign-extended
+// to int64 (Shared/InlineNullValues.h:33-37), double / float as the bits of NULL_DOUBLE / of NULL_FLOAT widened to
+// double (HDK_COL_FLOAT widens)
+inline int64_t inline_null(const TypeDesc& t) {
+  if (t.is_fp()) {
+    if (t.size == 4) {
+      const double d = static_cast<double>(std::numeric_limits<float>::min());
+      int64_t bits;
+      std::memcpy(&bits, &d, 8);
+      return bits;
+    }
+    return HDK_NULL_DOUBLE_BITS;
+  }
+  switch (t.size) {
+    case 1: return INT8_MIN;
+    case 2: return INT16_MIN;
+    case 4: return INT32_MIN;
+    default: return INT64_MIN;
+  }
+}
+inline int64_t result_null(const TypeDesc& t) { return t.is_fp() ? HDK_NULL_DOUBLE_BITS : INT64_MIN; }  // computed values travel as int64 / double
+
+// what the hash table object of one join level knows (PerfectJoinHashTable / BaselineJoinHashTable): not in the IR
+struct JoinTableDesc {
+  int32_t kind{HDK_JOIN_ONE_TO_ONE};  // hdk_hip_join_kind: getHashType() and the table class
+  int64_t min_key{0}, max_key{0};     // col_range_ (perfect tables)
+  int64_t bucket{0};                  // bucket_normalization
+  int64_t entry_count{0};             // one-to-many / keyed tables
+  int32_t key_component_width{8};     // keyed tables
+};
+
+template <class IR>
+struct UnitView {  // the members of RelAlgExecutionUnit the hot path reads (QE/RelAlgExecutionUnit.h:131-216)
+  using Expr = typename IR::Expr;
+  std::vector<const Expr*> quals;  // simple_quals followed by quals
+  struct JoinLevel {
+    std::vector<const Expr*> quals;  // JoinCondition::quals of the nesting level
+    bool left{false};                // JoinCondition::type == JoinType::LEFT
+  };
+  std::vector<JoinLevel> joins;        // join_quals
+  std::vector<const Expr*> groupby;    // groupby_exprs ({nullptr} for a non-grouped unit in HDK: pass an empty vector)
+  std::vector<const Expr*> targets;    // target_exprs
+};
+
+template <class IR>
+class PlanExtractor {
+ public:
+  using Expr = typename IR::Expr;
+  // global column -> index into HipWorkUnit::cols (plan_state_->global_to_local_col_ids_ order = COL_BUFFERS order)
+  using ColumnResolver = std::function<int(const Expr*)>;
+
+  PlanExtractor(std::vector<HipInputCol> cols, ColumnResolver resolve) : resolve_(std::move(resolve)) { wu_.cols = std::move(cols); }
+
+  HipWorkUnit extract(const UnitView<IR>& unit, const std::vector<JoinTableDesc>& join_tables, bool projection) {
+    if (unit.joins.size() != join_tables.size() || unit.joins.size() > HDK_HIP_MAX_JOINS) {
+      throw QueryMustRunOnCpu("join levels outside the fixed kernel library");
+    }
+    for (size_t j = 0; j < unit.joins.size(); ++j) {
+      wu_.joins.push_back(join(unit.joins[j], join_tables[j], static_cast<int>(j)));
+    }
+    filters(unit.quals);
+    for (const Expr* k : unit.groupby) {
+      wu_.keys.push_back(expr(k));
+    }
+    if (wu_.keys.size() > HDK_HIP_MAX_KEYS || unit.targets.empty() || unit.targets.size() > HDK_HIP_MAX_TARGETS) {
+      throw QueryMustRunOnCpu("keys / targets outside the fixed kernel library");
+    }
+    for (const Expr* t : unit.targets) {
+      wu_.targets.push_back(target(t, unit.groupby, projection));
+    }
+    return wu_;
+  }
+
+  // ---- expressions: a left-deep chain ((leaf0 op leaf) op leaf) op leaf, at most HDK_HIP_MAX_EXPR_STEPS steps -------
+  hdk_hip_expr expr(const Expr* e) const {
+    hdk_hip_expr x;
+    std::memset(&x, 0, sizeof(x));
+    int width = 0;  // SQL integer width the chain has reached (checked arithmetic, QE/ArithmeticIR.cpp:277-520)
+    flatten(e, &x, &width);
+    const TypeDesc t = IR::type(e);
+    x.vclass = t.is_fp() ? HDK_VC_FP : HDK_VC_INT;
+    if (x.nsteps) {
+      x.null_val = result_null(t);
+      x.nullable = t.nullable ? 1 : 0;
+    } else {
+      x.null_val = x.leaf0.null_val;
+      x.nullable = x.leaf0.nullable;
+    }
+    return x;
+  }
+
+ private:
+  hdk_hip_leaf leaf(const Expr* e) const {
+    hdk_hip_leaf l;
+    std::memset(&l, 0, sizeof(l));
+    switch (IR::kind(e)) {
+      case ExprKind::ColumnVar: {
+        const TypeDesc t = IR::type(e);
+        l.kind = HDK_LEAF_COL;
+        l.col = resolve_(e);
+        if (l.col < 0 || l.col >= static_cast<int>(wu_.cols.size())) throw QueryMustRunOnCpu("column outside the input descriptors");
+        l.null_val = inline_null(t);
+        l.nullable = t.nullable ? 1 : 0;
+        return l;
+      }
+      case ExprKind::Constant: {
+        if (IR::const_is_null(e)) throw QueryMustRunOnCpu("NULL literal");
+        const TypeDesc t = IR::type(e);
+        if (t.is_fp()) {
+          const double d = IR::const_fp(e);
+          l.kind = HDK_LEAF_FP;
+          std::memcpy(&l.ival, &d, 8);
+        } else if (t.integer_like()) {
+          l.kind = HDK_LEAF_INT;
+          l.ival = IR::const_int(e);
+        } else {
+          throw QueryMustRunOnCpu("literal of a type outside the fixed kernel library");
+        }
+        return l;
+      }
+      default:
+        throw QueryMustRunOnCpu("right operand must be a column or a literal (expression too deep)");
+    }
+  }
+
+  static int literal_width(const Expr* e) {  // an integer literal is INTEGER when it fits 32 bits, else BIGINT
+    const int64_t v = IR::const_int(e);
+    return (v >= INT32_MIN && v <= INT32_MAX) ? 4 : 8;
+  }
+  int sql_width(const Expr* e) const {
+    const TypeDesc t = IR::type(e);
+    if (t.is_fp()) return 0;
+    return IR::kind(e) == ExprKind::Constant ? literal_width(e) : t.size;
+  }
+
+  void push(hdk_hip_expr* x, int32_t op, const TypeDesc& out, const Expr* rhs, int check_width) const {
+    if (x->nsteps == HDK_HIP_MAX_EXPR_STEPS) throw QueryMustRunOnCpu("expression chain too long for the fixed kernel library");
+    hdk_hip_step& st = x->steps[x->nsteps++];
+    std::memset(&st, 0, sizeof(st));
+    st.op = op;
+    st.out_class = out.is_fp() ? HDK_VC_FP : HDK_VC_INT;
+    if (rhs) st.rhs = leaf(rhs);
+    st.null_out = result_null(out);
+    st.check_width = check_width;
+  }
+
+  void flatten(const Expr* e, hdk_hip_expr* x, int* width) const {
+    switch (IR::kind(e)) {
+      case ExprKind::ColumnVar:
+      case ExprKind::Constant:
+        x->leaf0 = leaf(e);
+        *width = sql_width(e);
+        return;
+      case ExprKind::BinOper: {
+        const hdk::ir::OpType op = IR::bin_op(e);
+        if (!hdk::ir::isArithmetic(op)) throw QueryMustRunOnCpu("operator outside + - * / %");
+        flatten(IR::left(e), x, width);
+        const Expr* r = IR::right(e);
+        const TypeDesc out = IR::type(e);
+        const int rw = sql_width(r);
+        *width = (out.is_fp() || !*width || !rw) ? 0 : (*width > rw ? *width : rw);
+        int32_t code;
+        switch (op) {
+          case hdk::ir::OpType::kPlus: code = HDK_OP_ADD; break;
+          case hdk::ir::OpType::kMinus: code = HDK_OP_SUB; break;
+          case hdk::ir::OpType::kMul: code = HDK_OP_MUL; break;
+          case hdk::ir::OpType::kDiv: code = HDK_OP_DIV; break;
+          default: code = HDK_OP_MOD; break;
+        }
+        if (out.cls == TypeDesc::Decimal) throw QueryMustRunOnCpu("decimal arithmetic is outside the fixed kernel library");
+        push(x, code, out, r, (code == HDK_OP_ADD || code == HDK_OP_SUB || code == HDK_OP_MUL) ? *width : 0);
+        return;
+      }
+      case ExprKind::Extract: {
+        if (IR::extract_field(e) != hdk::ir::DateExtractField::kYear) throw QueryMustRunOnCpu("only extract(year) is in the fixed kernel library");
+        const Expr* from = IR::extract_from(e);
+        const TypeDesc ft = IR::type(from);
+        if (ft.cls != TypeDesc::Timestamp || !ft.seconds) throw QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) argument");
+        flatten(from, x, width);
+        push(x, HDK_OP_EXTRACT_YEAR, IR::type(e), nullptr, 0);
+        *width = 8;
+        return;
+      }
+      case ExprKind::UOper: {
+        if (IR::un_op(e) != hdk::ir::OpType::kCast) throw QueryMustRunOnCpu("unary operator outside CAST");
+        const Expr* arg = IR::operand(e);
+        const TypeDesc at = IR::type(arg), to = IR::type(e);
+        flatten(arg, x, width);
+        if (at.cls == TypeDesc::Decimal && to.cls == TypeDesc::Integer) {  // scale_decimal_down (RuntimeFunctions.cpp:245-262)
+          int64_t scale = 1;
+          for (int i = 0; i < at.scale; ++i) scale *= 10;
+          push(x, HDK_OP_SCALE_DOWN, to, nullptr, 0);
+          hdk_hip_leaf& l = x->steps[x->nsteps - 1].rhs;
+          l.kind = HDK_LEAF_INT;
+          l.ival = scale;
+          *width = 8;
+        } else if (at.integer_like() && at.cls != TypeDesc::Decimal && to.is_fp()) {
+          push(x, HDK_OP_CAST_INT_TO_FP, to, nullptr, 0);
+          *width = 0;
+        } else if (at.is_fp() && to.integer_like() && to.cls != TypeDesc::Decimal) {
+          push(x, HDK_OP_CAST_FP_TO_INT, to, nullptr, 0);
+          *width = 8;
+        } else if (at.integer_like() && to.integer_like() && at.cls != TypeDesc::Decimal && to.cls != TypeDesc::Decimal) {
+          // integer widening: values are carried as int64 already (the checked width becomes the target's)
+          *width = to.size;
+        } else {
+          throw QueryMustRunOnCpu("cast outside the fixed kernel library");
+        }
+        return;
+      }
+      default:
+        throw QueryMustRunOnCpu("expression outside the fixed kernel library");
+    }
+  }
+
+  // ---- filters: comparisons `expr cmp leaf`; AND / OR / NOT over them (QE/LogicalIR.cpp) ----------------------------
+  bool reads_inner(const Expr* e) const {
+    switch (IR::kind(e)) {
+      case ExprKind::ColumnVar: return IR::rte_idx(e) > 0;
+      case ExprKind::BinOper: return reads_inner(IR::left(e)) || reads_inner(IR::right(e));
+      case ExprKind::UOper: return reads_inner(IR::operand(e));
+      case ExprKind::Extract: return reads_inner(IR::extract_from(e));
+      default: return false;
+    }
+  }
+
+  int comparison(const Expr* e) {  // -> index into wu_.quals
+    hdk::ir::OpType op = IR::bin_op(e);
+    const Expr *l = IR::left(e), *r = IR::right(e);
+    const ExprKind rk = IR::kind(r);
+    if (rk != ExprKind::Constant && rk != ExprKind::ColumnVar) {  // literal on the left: commute (CompareIR normalises too)
+      std::swap(l, r);
+      op = hdk::ir::commuteComparison(op);
+    }
+    hdk_hip_qual q;
+    std::memset(&q, 0, sizeof(q));
+    q.lhs = expr(l);
+    q.rhs = leaf(r);
+    switch (op) {
+      case hdk::ir::OpType::kEq: q.cmp = HDK_CMP_EQ; break;
+      case hdk::ir::OpType::kNe: q.cmp = HDK_CMP_NE; break;
+      case hdk::ir::OpType::kLt: q.cmp = HDK_CMP_LT; break;
+      case hdk::ir::OpType::kGt: q.cmp = HDK_CMP_GT; break;
+      case hdk::ir::OpType::kLe: q.cmp = HDK_CMP_LE; break;
+      case hdk::ir::OpType::kGe: q.cmp = HDK_CMP_GE; break;
+      default: throw QueryMustRunOnCpu("comparison outside = <> < > <= >=");
+    }
+    q.after_joins = (reads_inner(l) || reads_inner(r)) ? 1 : 0;
+    if (wu_.quals.size() == HDK_HIP_MAX_QUALS) throw QueryMustRunOnCpu("too many comparisons for the fixed kernel library");
+    wu_.quals.push_back(q);
+    return static_cast<int>(wu_.quals.size()) - 1;
+  }
+
+  static bool is_comparison(const Expr* e) { return IR::kind(e) == ExprKind::BinOper && hdk::ir::isComparison(IR::bin_op(e)); }
+
+  void program(const Expr* e) {  // postfix over the comparisons (three-valued logical_and / or / not)
+    if (is_comparison(e)) {
+      emit(static_cast<uint8_t>(comparison(e)));
+    } else if (IR::kind(e) == ExprKind::BinOper && hdk::ir::isLogic(IR::bin_op(e))) {
+      program(IR::left(e));
+      program(IR::right(e));
+      emit(IR::bin_op(e) == hdk::ir::OpType::kAnd ? HDK_F_AND : HDK_F_OR);
+    } else if (IR::kind(e) == ExprKind::UOper && IR::un_op(e) == hdk::ir::OpType::kNot) {
+      program(IR::operand(e));
+      emit(HDK_F_NOT);
+    } else {
+      throw QueryMustRunOnCpu("filter outside comparisons combined by AND / OR / NOT");
+    }
+  }
+  void emit(uint8_t op) {
+    if (wu_.filter_ops.size() == HDK_HIP_MAX_FILTER_OPS) throw QueryMustRunOnCpu("filter program too long");
+    wu_.filter_ops.push_back(op);
+  }
+
+  void filters(const std::vector<const Expr*>& quals) {
+    bool plain = true;  // a conjunction of comparisons needs no program: each is staged by its own after_joins
+    for (const Expr* q : quals) plain = plain && is_comparison(q);
+    if (plain) {
+      for (const Expr* q : quals) comparison(q);
+      return;
+    }
+    bool first = true;
+    for (const Expr* q : quals) {  // the unit's quals are ANDed
+      program(q);
+      if (!first) emit(HDK_F_AND);
+      first = false;
+    }
+    wu_.filter_after_joins = 0;
+    for (const hdk_hip_qual& q : wu_.quals) wu_.filter_after_joins |= q.after_joins;
+  }
+
+  // ---- joins: one equality per level over a hash table the builder already made (QE/IRCodegen.cpp:497-667) ----------
+  hdk_hip_join join(const typename UnitView<IR>::JoinLevel& level, const JoinTableDesc& table, int j) {
+    hdk_hip_join jn;
+    std::memset(&jn, 0, sizeof(jn));
+    const bool keyed = table.kind == HDK_JOIN_KEYED_ONE_TO_ONE || table.kind == HDK_JOIN_KEYED_ONE_TO_MANY;
+    if (level.quals.empty() || level.quals.size() > (keyed ? HDK_HIP_MAX_JOIN_KEYS : 1u)) {
+      throw QueryMustRunOnCpu("join condition outside one equality per key component");
+    }
+    int component = 0;
+    for (const Expr* q : level.quals) {
+      if (IR::kind(q) != ExprKind::BinOper) throw QueryMustRunOnCpu("join condition is not an equality");
+      const hdk::ir::OpType op = IR::bin_op(q);
+      if (op != hdk::ir::OpType::kEq && op != hdk::ir::OpType::kBwEq) throw QueryMustRunOnCpu("join condition is not an equality");
+      const Expr *l = IR::left(q), *r = IR::right(q);
+      if (reads_inner_of(l, j + 1)) std::swap(l, r);  // the inner side is the level's own table
+      if (IR::kind(r) != ExprKind::ColumnVar || IR::rte_idx(r) != j + 1) throw QueryMustRunOnCpu("inner join key must be a column of the joined table");
+      const hdk_hip_expr outer = expr(l);
+      if (component == 0) {
+        jn.outer_key = outer;
+        jn.null_val = outer.null_val;
+        jn.null_mode = op == hdk::ir::OpType::kBwEq ? HDK_JOIN_NULL_BITWISE : (outer.nullable ? HDK_JOIN_NULL_NULLABLE : HDK_JOIN_NULL_NONE);
+        jn.translated_null = table.max_key + 1;  // hash_join_idx_bitwise's slot for NULL (PerfectJoinHashTable.cpp)
+      } else {
+        jn.extra_keys[component - 1] = outer;
+      }
+      ++component;
+    }
+    jn.kind = table.kind;
+    jn.type = level.left ? HDK_JOIN_LEFT : HDK_JOIN_INNER;
+    jn.min_key = table.min_key;
+    jn.max_key = table.max_key;
+    jn.bucket = table.bucket;
+    jn.table_idx = j;
+    jn.key_component_count = component;
+    jn.key_component_width = table.key_component_width;
+    jn.entry_count = table.entry_count;
+    return jn;
+  }
+  bool reads_inner_of(const Expr* e, int rte) const { return IR::kind(e) == ExprKind::ColumnVar && IR::rte_idx(e) == rte; }
+
+  // ---- targets: get_target_info (Shared/TargetInfo.h:89-160) + TargetExprCodegen (QE/TargetExprBuilder.cpp:407-460) ----
+  HipTargetDesc target(const Expr* e, const std::vector<const Expr*>& groupby, bool projection) const {
+    HipTargetDesc d;
+    std::memset(&d.arg, 0, sizeof(d.arg));
+    d.key_idx = -1;
+    d.null_val = 0;
+    d.skip_null = false;
+    d.arg_is_fp = HDK_FP_SLOT_NONE;
+    if (IR::kind(e) != ExprKind::Agg) {
+      d.agg = HDK_AGG_ID;
+      d.has_arg = true;
+      d.arg = expr(e);
+      if (!projection) {  // a projected group-by key: written with agg_id from key #key_idx (RowFuncBuilder.cpp:640-689)
+        for (size_t k = 0; k < groupby.size(); ++k) {
+          if (IR::same(e, groupby[k])) d.key_idx = static_cast<int>(k);
+        }
+        if (d.key_idx < 0) throw QueryMustRunOnCpu("non-aggregate target that is not a group-by expression");
+      }
+      return d;
+    }
+    if (IR::agg_distinct(e)) throw QueryMustRunOnCpu("DISTINCT aggregates are outside the fixed kernel library");
+    switch (IR::agg_type(e)) {
+      case hdk::ir::AggType::kCount: d.agg = HDK_AGG_COUNT; break;
+      case hdk::ir::AggType::kSum: d.agg = HDK_AGG_SUM; break;
+      case hdk::ir::AggType::kMin: d.agg = HDK_AGG_MIN; break;
+      case hdk::ir::AggType::kMax: d.agg = HDK_AGG_MAX; break;
+      case hdk::ir::AggType::kAvg: d.agg = HDK_AGG_AVG; break;
+      default: throw QueryMustRunOnCpu("aggregate outside COUNT / SUM / MIN / MAX / AVG");
+    }
+    const Expr* arg = IR::agg_arg(e);
+    d.has_arg = arg != nullptr;
+    if (!arg) {
+      if (d.agg != HDK_AGG_COUNT) throw QueryMustRunOnCpu("aggregate without an argument");
+      return d;
+    }
+    d.arg = expr(arg);
+    const TypeDesc at = IR::type(arg);
+    // skip_null_val: the argument can be NULL (TargetInfo.h:120-150); the skip value is the slot's own sentinel
+    // (TargetExprBuilder.cpp:437-452: inline_int_null_val / inline_fp_null_val of the argument's type)
+    d.skip_null = at.nullable;
+    if (at.is_fp()) {
+      // takes_float_argument (TargetInfo.h:170-179): SUM / MIN / MAX / AVG over a FLOAT keep a float accumulator
+      const bool float_acc = at.size == 4 && d.agg != HDK_AGG_COUNT;
+      d.arg_is_fp = float_acc ? HDK_FP_SLOT_FLOAT : HDK_FP_SLOT_DOUBLE;
+      d.null_val = float_acc ? inline_null(at) : HDK_NULL_DOUBLE_BITS;
+    } else {
+      d.null_val = INT64_MIN;  // (a 4-byte padded slot narrows it: make_plan knows the slot width)
+    }
+    if (d.agg == HDK_AGG_COUNT) d.arg_is_fp = at.is_fp() ? HDK_FP_SLOT_DOUBLE : HDK_FP_SLOT_NONE, d.null_val = d.arg.null_val;
+    return d;
+  }
+
+  ColumnResolver resolve_;
+  HipWorkUnit wu_;
+};
+
+}  // namespace hip_rt
