@@ -10,8 +10,18 @@
 // kernel->launch(ko, params), copy error codes and the buffer back.  Two steps:
 //   c2    SELECT key, SUM(val), COUNT(*) FROM t GROUP BY key           (GroupByPerfectHash, row-wise, 4 fragments)
 //   join  SELECT SUM(val + dval), COUNT(*) FROM fact JOIN dim ON fk = key   (NonGroupedAggregate, one-to-one table)
-// and the runtime interrupt.  Results go to stdout, one line per group; tests/test_gpu_cpp_harness.py compares them
+// and the runtime interrupt; then five steps whose plans come out of the PLAN EXTRACTOR (hdk_amd/glue/HipPlanExtractor.h
+// over the stand-in hdk::ir tree of ir_standin.h -- the pattern match NativeCodegen would do for the HIP platform):
+//   q3         taxi Q3: GROUP BY passenger_count, extract(year from pickup_datetime) -> COUNT(*)   (hdk_scan_agg_keys)
+//   c5         GROUP BY key SUM(val), open addressing, 6 M entries, 8.8 M rows: the radix-partitioned passes with
+//              8-byte tuples (column statistics in HipInputCol)
+//   projection SELECT key, val * 2 WHERE val < c   (filter/project, TOTAL_MATCHED)
+//   floats     GROUP BY k: SUM(f), AVG(f), COUNT(f) over a FLOAT column (float accumulators, HDK_FP_SLOT_FLOAT)
+//   reduce     two partial C2 buffers merged on the device with hdk_hip_reduce_buffers
+// Results go to stdout, one line per group; tests/test_gpu_cpp_harness.py compares them
 // with tests/golden/cpp_harness_output.txt (made by tests/golden/gen_cpp_harness_golden.py with numpy).
+#include <algorithm>
+#include <array>
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
@@ -25,7 +35,9 @@
 #include "HipKernel.h"
 #include "HipMgr.h"
 #include "HipPlanBuilder.h"
+#include "HipPlanExtractor.h"
 #include "HipRuntimeOnDevice.h"
+#include "ir_standin.h"
 
 namespace {
 
@@ -317,6 +329,332 @@ int run_join(hip_mgr::HipMgr& mgr) {
   return err || build_err || ierr != HDK_HIP_ERR_INTERRUPTED;
 }
 
+
+// ---- steps whose plan comes out of the extractor -------------------------------------------------------------------
+using namespace standin;
+using hdk::ir::AggType;
+using hdk::ir::OpType;
+using hip_rt::TypeDesc;
+
+hdk_hip_plan extract_plan(std::vector<hip_rt::HipInputCol> cols, const hip_rt::UnitView<StandInIr>& unit, const QmdStandIn& qmd,
+                          std::vector<hip_rt::HipWorkUnit::KeyRange> ranges = {}) {
+  hip_rt::PlanExtractor<StandInIr> ex(std::move(cols), [](const standin::Expr* e) { return e->column_id; });
+  hip_rt::HipWorkUnit wu = ex.extract(unit, {}, qmd.getQueryDescriptionType() == QueryDescriptionType::Projection);
+  wu.key_ranges = std::move(ranges);
+  return hip_rt::make_plan(wu, qmd);
+}
+
+void report_kernels(const char* step, const hdk_hip_plan& plan, uint64_t rows) {
+  char names[256];
+  hdk_hip_kernel_options o{};
+  o.total_rows = rows;
+  hip_rt::check(hdk_hip_describe_launch(&plan, &o, kDevice, names, sizeof(names)));
+  std::fprintf(stderr, "%s: %s\n", step, names);
+}
+
+int run_q3(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 3, kFragRows = 400000;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int16_t> pc(kFragRows);
+    std::vector<int64_t> ts(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      pc[r] = static_cast<int16_t>(mix(i + (1ull << 45)) % 7);
+      ts[r] = 1230768000 + static_cast<int64_t>(mix(i + (1ull << 46)) % 220838400ull);  // 2009-01-01 .. 2015-12-31
+    }
+    col_buffers.push_back({dev.upload(pc), dev.upload(ts)});
+    num_rows.push_back(kFragRows);
+    frag_offsets.push_back(f * kFragRows);
+  }
+  auto pc = column(type_of(TypeDesc::Integer, 2, true), 0, 0), ts = column(type_of(TypeDesc::Timestamp, 8, true), 0, 1);
+  auto year = extract(hdk::ir::DateExtractField::kYear, ts);
+  auto cnt = agg_expr(bigint(false), AggType::kCount, nullptr);
+  hip_rt::UnitView<StandInIr> u;
+  u.groupby = {pc.get(), year.get()};
+  u.targets = {pc.get(), year.get(), cnt.get()};
+  QmdStandIn qmd;  // MemoryLayoutBuilder: perfect hash over [0,6] x [2009,2015], three 8-byte slots behind two 8-byte keys
+  qmd.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+  qmd.group_col_widths_ = {8, 8};
+  qmd.padded_slot_widths_ = {8, 8, 8};
+  qmd.entry_count_ = 49;
+  const hip_rt::HipPlanContext ctx(extract_plan({{0, 2, HDK_COL_INT}, {0, 8, HDK_COL_INT}}, u, qmd, {{0, 6, 0, false}, {2009, 2015, 0, false}}));
+  const std::vector<int64_t> init_agg_vals{0, 0, 0};
+  int8_t* out = dev.alloc(qmd.getBufferSizeBytes());
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, 0, init_agg_vals, {out}, nullptr);
+  const KernelOptions ko = kernel_options(mgr);
+  hip_rt::init_group_by_buffer_on_device_hip(reinterpret_cast<int64_t*>(out), reinterpret_cast<const int64_t*>(pb.params[HDK_KP_INIT_AGG_VALS]),
+                                             49, 2, 8, static_cast<uint32_t>(qmd.getRowSize() / 8), false, 1, ko.blockDimX, ko.gridDimX, kDevice);
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  const int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  std::printf("q3 error_code %d\n", err);
+  const size_t quads = qmd.getRowSize() / 8;
+  const auto rows = dev.download<int64_t>(out, quads * 49);
+  std::vector<std::array<int64_t, 3>> groups;
+  for (size_t e = 0; e < 49; ++e) {
+    const int64_t* row = &rows[e * quads];
+    if (row[0] == std::numeric_limits<int64_t>::max()) continue;
+    groups.push_back({row[qmd.getColOffInBytes(0) / 8], row[qmd.getColOffInBytes(1) / 8], row[qmd.getColOffInBytes(2) / 8]});
+  }
+  std::sort(groups.begin(), groups.end());
+  for (const auto& g : groups) std::printf("q3 passenger_count %" PRId64 " year %" PRId64 " count %" PRId64 "\n", g[0], g[1], g[2]);
+  report_kernels("q3", ctx.plan, dev.rows_in_step);
+  g_services = nullptr;
+  return err;
+}
+
+int run_c5(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 8, kFragRows = 1100000, kKeys = 3000000, kEntries = 6000011;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int64_t> key(kFragRows), val(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      key[r] = static_cast<int64_t>(mix(i + (1ull << 47)) % kKeys);
+      val[r] = static_cast<int64_t>(mix(i + (1ull << 48)) % 2000001) - 1000000;
+    }
+    col_buffers.push_back({dev.upload(key), dev.upload(val)});
+    num_rows.push_back(kFragRows);
+    frag_offsets.push_back(f * kFragRows);
+  }
+  auto key = column(bigint(false), 0, 0), val = column(bigint(true), 0, 1);
+  auto sum = agg_expr(bigint(true), AggType::kSum, val);
+  hip_rt::UnitView<StandInIr> u;
+  u.groupby = {key.get()};
+  u.targets = {key.get(), sum.get()};
+  QmdStandIn qmd;  // GroupByBaselineHash: 4-byte table key (range fits), the projected key has no slot, one 8-byte slot
+  qmd.query_desc_type_ = QueryDescriptionType::GroupByBaselineHash;
+  qmd.group_col_widths_ = {8};
+  qmd.group_col_compact_width_ = 4;
+  qmd.padded_slot_widths_ = {0, 8};
+  qmd.entry_count_ = kEntries;
+  // ChunkStats of the two columns (ChunkMetadata::chunkStats): key and value both fit 32 bits -> 8-byte tuples
+  hip_rt::HipInputCol kcol{0, 8, HDK_COL_INT, 1, 0, 0, static_cast<int64_t>(kKeys) - 1};
+  hip_rt::HipInputCol vcol{0, 8, HDK_COL_INT, 1, 0, -1000000, 1000000};
+  const hip_rt::HipPlanContext ctx(extract_plan({kcol, vcol}, u, qmd));
+  const std::vector<int64_t> init_agg_vals{kNullBigint};  // compact_init_vals: one word per quad of the slot region
+  int8_t* out = dev.alloc(qmd.getBufferSizeBytes());
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, 0, init_agg_vals, {out}, nullptr);
+  const KernelOptions ko = kernel_options(mgr);
+  hip_rt::init_group_by_buffer_on_device_hip(reinterpret_cast<int64_t*>(out), reinterpret_cast<const int64_t*>(pb.params[HDK_KP_INIT_AGG_VALS]),
+                                             kEntries, 1, 4, 2, false, 1, ko.blockDimX, ko.gridDimX, kDevice);
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  const int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  std::printf("c5 error_code %d\n", err);
+  const auto rows = dev.download<int64_t>(out, 2 * kEntries);
+  uint64_t groups = 0, sum_of_sums = 0, mixed = 0;
+  for (size_t e = 0; e < kEntries; ++e) {
+    const int32_t k = static_cast<int32_t>(rows[2 * e]);  // [key int32 | padding][slot]
+    if (k == std::numeric_limits<int32_t>::max()) continue;
+    ++groups;
+    sum_of_sums += static_cast<uint64_t>(rows[2 * e + 1]);
+    mixed ^= mix(static_cast<uint64_t>(k) * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(rows[2 * e + 1]));
+  }
+  std::printf("c5 groups %" PRIu64 " sum_of_sums %" PRId64 " checksum %" PRIu64 "\n", groups, static_cast<int64_t>(sum_of_sums), mixed);
+  report_kernels("c5", ctx.plan, dev.rows_in_step);
+  g_services = nullptr;
+  return err;
+}
+
+int run_projection(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 2, kFragRows = 500000;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int64_t> val(kFragRows), key(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      key[r] = static_cast<int64_t>(mix(i) % 64);
+      val[r] = gen_val(i);
+    }
+    col_buffers.push_back({dev.upload(val), dev.upload(key)});  // COL_BUFFERS order: first use (the filter reads val)
+    num_rows.push_back(kFragRows);
+    frag_offsets.push_back(f * kFragRows);
+  }
+  auto val = column(bigint(true), 0, 0), key = column(bigint(false), 0, 1);
+  auto lt = bin_oper(type_of(TypeDesc::Boolean, 1, true), OpType::kLt, val, int_literal(-900000));
+  auto twice = bin_oper(bigint(true), OpType::kMul, val, int_literal(2));
+  hip_rt::UnitView<StandInIr> u;
+  u.quals = {lt.get()};
+  u.targets = {key.get(), twice.get()};
+  QmdStandIn qmd;  // Projection, row-wise: [int64 row position | two 8-byte slots], entry_count = the scan limit
+  qmd.query_desc_type_ = QueryDescriptionType::Projection;
+  qmd.group_col_widths_ = {8};
+  qmd.padded_slot_widths_ = {8, 8};
+  qmd.entry_count_ = kFragments * kFragRows;
+  const hip_rt::HipPlanContext ctx(extract_plan({{0, 8, HDK_COL_INT}, {0, 8, HDK_COL_INT}}, u, qmd));
+  int8_t* out = dev.alloc(qmd.getBufferSizeBytes());
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, static_cast<int32_t>(qmd.entry_count_), {0, 0}, {out}, nullptr);
+  const KernelOptions ko = kernel_options(mgr);
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  const int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  const int32_t matched = dev.download<int32_t>(pb.params[HDK_KP_TOTAL_MATCHED], 1)[0];
+  std::printf("projection error_code %d matched %d\n", err, matched);
+  const auto rows = dev.download<int64_t>(out, 3 * static_cast<size_t>(matched));
+  uint64_t sum_pos = 0, sum_key = 0, sum_v2 = 0;  // rows land in claim order: order-free sums
+  for (int32_t r = 0; r < matched; ++r) {
+    sum_pos += static_cast<uint64_t>(rows[3 * r]);
+    sum_key += static_cast<uint64_t>(rows[3 * r + 1]);
+    sum_v2 += static_cast<uint64_t>(rows[3 * r + 2]);
+  }
+  std::printf("projection sum_pos %" PRIu64 " sum_key %" PRIu64 " sum_v2 %" PRId64 "\n", sum_pos, sum_key, static_cast<int64_t>(sum_v2));
+  report_kernels("projection", ctx.plan, dev.rows_in_step);
+  g_services = nullptr;
+  return err;
+}
+
+int run_floats(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 2, kFragRows = 300000, kKeys = 10;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = kFragments * kFragRows;
+  std::vector<std::vector<int8_t*>> col_buffers;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> frag_offsets;
+  const float null_float = std::numeric_limits<float>::min();  // NULL_FLOAT (Shared/InlineNullValues.h:39)
+  for (size_t f = 0; f < kFragments; ++f) {
+    std::vector<int32_t> k(kFragRows);
+    std::vector<float> x(kFragRows);
+    for (size_t r = 0; r < kFragRows; ++r) {
+      const uint64_t i = f * kFragRows + r;
+      k[r] = static_cast<int32_t>(mix(i + (1ull << 49)) % kKeys);
+      const uint64_t h = mix(i + (1ull << 50));
+      x[r] = h % 16 == 0 ? null_float : static_cast<float>((h >> 8) % 16);  // small integers: float sums are exact in any order
+    }
+    col_buffers.push_back({dev.upload(k), dev.upload(x)});
+    num_rows.push_back(kFragRows);
+    frag_offsets.push_back(f * kFragRows);
+  }
+  auto k = column(type_of(TypeDesc::Integer, 4, false), 0, 0), x = column(type_of(TypeDesc::Fp, 4, true), 0, 1);
+  auto sf = agg_expr(type_of(TypeDesc::Fp, 4, true), AggType::kSum, x), af = agg_expr(fp64(true), AggType::kAvg, x),
+       cf = agg_expr(bigint(false), AggType::kCount, x);
+  hip_rt::UnitView<StandInIr> u;
+  u.groupby = {k.get()};
+  u.targets = {k.get(), sf.get(), af.get(), cf.get()};
+  QmdStandIn qmd;  // perfect hash on [0, 9]; slots: key, SUM(float) padded to 8, AVG = (float sum padded to 8, count), COUNT
+  qmd.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+  qmd.group_col_widths_ = {8};
+  qmd.padded_slot_widths_ = {8, 8, 8, 8, 8};
+  qmd.entry_count_ = kKeys;
+  qmd.max_val_ = kKeys - 1;
+  const hip_rt::HipPlanContext ctx(extract_plan({{0, 4, HDK_COL_INT}, {0, 4, HDK_COL_FLOAT}}, u, qmd));
+  int32_t nf_bits;
+  std::memcpy(&nf_bits, &null_float, 4);
+  const int64_t fnull = static_cast<int64_t>(nf_bits);  // init_agg_val_vec: the float sentinel sign-extended (OutputBufferInitialization.cpp:52-65)
+  const std::vector<int64_t> init_agg_vals{0, fnull, fnull, 0, 0};
+  int8_t* out = dev.alloc(qmd.getBufferSizeBytes());
+  ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, 0, init_agg_vals, {out}, nullptr);
+  const KernelOptions ko = kernel_options(mgr);
+  hip_rt::init_group_by_buffer_on_device_hip(reinterpret_cast<int64_t*>(out), reinterpret_cast<const int64_t*>(pb.params[HDK_KP_INIT_AGG_VALS]),
+                                             kKeys, 1, 8, static_cast<uint32_t>(qmd.getRowSize() / 8), false, 1, ko.blockDimX, ko.gridDimX, kDevice);
+  auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+  kernel->launch(ko, pb.params);
+  mgr.synchronizeStream(kDevice);
+  const int32_t err = dev.download<int32_t>(pb.error_code, 1)[0];
+  std::printf("floats error_code %d\n", err);
+  const size_t quads = qmd.getRowSize() / 8;
+  const auto rows = dev.download<int64_t>(out, quads * kKeys);
+  for (size_t e = 0; e < kKeys; ++e) {
+    const int64_t* row = &rows[e * quads];
+    if (row[0] == std::numeric_limits<int64_t>::max()) continue;
+    float s, a;  // a float accumulator lives in the LOW 4 bytes of its padded slot (takes_float_argument)
+    std::memcpy(&s, &row[qmd.getColOffInBytes(1) / 8], 4);
+    std::memcpy(&a, &row[qmd.getColOffInBytes(2) / 8], 4);
+    std::printf("floats key %" PRId64 " sum %.1f avg_sum %.1f avg_count %" PRId64 " count %" PRId64 "\n", row[qmd.getColOffInBytes(0) / 8],
+                static_cast<double>(s), static_cast<double>(a), row[qmd.getColOffInBytes(3) / 8], row[qmd.getColOffInBytes(4) / 8]);
+  }
+  report_kernels("floats", ctx.plan, dev.rows_in_step);
+  g_services = nullptr;
+  return err;
+}
+
+// ResultSetReduction on the device: C2 over fragments {0, 1} and {2, 3} into two buffers, merged with hdk_hip_reduce_buffers
+// (replaces the host's reduceMultiDeviceResultSets, QE/Execute.cpp:1224-1336)
+int run_reduce(hip_mgr::HipMgr& mgr) {
+  constexpr size_t kFragments = 4, kFragRows = 500000, kKeys = 64;
+  DeviceServices dev(&mgr);
+  g_services = &dev;
+  dev.rows_in_step = 2 * kFragRows;
+  auto key = column(bigint(false), 0, 0), val = column(bigint(true), 0, 1);
+  auto sum = agg_expr(bigint(true), AggType::kSum, val), cnt = agg_expr(bigint(false), AggType::kCount, nullptr);
+  hip_rt::UnitView<StandInIr> u;
+  u.groupby = {key.get()};
+  u.targets = {key.get(), sum.get(), cnt.get()};
+  QmdStandIn qmd;
+  qmd.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+  qmd.group_col_widths_ = {8};
+  qmd.padded_slot_widths_ = {8, 8, 8};
+  qmd.entry_count_ = kKeys;
+  qmd.max_val_ = kKeys - 1;
+  const hip_rt::HipPlanContext ctx(extract_plan({{0, 8, HDK_COL_INT}, {0, 8, HDK_COL_INT}}, u, qmd));
+  const std::vector<int64_t> init_agg_vals{0, kNullBigint, 0};
+  const KernelOptions ko = kernel_options(mgr);
+  int8_t* bufs[2];
+  int32_t err = 0;
+  for (int half = 0; half < 2; ++half) {
+    std::vector<std::vector<int8_t*>> col_buffers;
+    std::vector<int64_t> num_rows;
+    std::vector<uint64_t> frag_offsets;
+    for (size_t f = half * 2; f < static_cast<size_t>(half) * 2 + 2 && f < kFragments; ++f) {
+      std::vector<int64_t> k(kFragRows), v(kFragRows);
+      for (size_t r = 0; r < kFragRows; ++r) {
+        const uint64_t i = f * kFragRows + r;
+        k[r] = static_cast<int64_t>(mix(i) % kKeys);
+        v[r] = gen_val(i);
+      }
+      col_buffers.push_back({dev.upload(k), dev.upload(v)});
+      num_rows.push_back(kFragRows);
+      frag_offsets.push_back(f * kFragRows);
+    }
+    bufs[half] = dev.alloc(qmd.getBufferSizeBytes());
+    ParamBlock pb = prepare_kernel_params(dev, col_buffers, num_rows, frag_offsets, 1, 0, init_agg_vals, {bufs[half]}, nullptr);
+    hip_rt::init_group_by_buffer_on_device_hip(reinterpret_cast<int64_t*>(bufs[half]), reinterpret_cast<const int64_t*>(pb.params[HDK_KP_INIT_AGG_VALS]),
+                                               kKeys, 1, 8, static_cast<uint32_t>(qmd.getRowSize() / 8), false, 1, ko.blockDimX, ko.gridDimX, kDevice);
+    auto kernel = create_device_kernel(&ctx, mgr.getPlatform(), kDevice);
+    kernel->launch(ko, pb.params);
+    mgr.synchronizeStream(kDevice);
+    err |= dev.download<int32_t>(pb.error_code, 1)[0];
+  }
+  int8_t* d_err = dev.upload(std::vector<int32_t>{0});
+  const int64_t* that[1] = {reinterpret_cast<const int64_t*>(bufs[1])};
+  const uint32_t that_counts[1] = {kKeys};
+  hip_rt::check(hdk_hip_reduce_buffers(&ctx.plan, reinterpret_cast<int64_t*>(bufs[0]), kKeys, that, that_counts, 1, init_agg_vals.data(),
+                                       reinterpret_cast<int32_t*>(d_err), kDevice, nullptr));
+  mgr.synchronizeStream(kDevice);
+  err |= dev.download<int32_t>(d_err, 1)[0];
+  std::printf("reduce error_code %d\n", err);
+  const size_t quads = qmd.getRowSize() / 8;
+  const auto rows = dev.download<int64_t>(bufs[0], quads * kKeys);
+  for (size_t e = 0; e < kKeys; ++e) {
+    const int64_t* row = &rows[e * quads];
+    if (row[0] == std::numeric_limits<int64_t>::max()) continue;
+    std::printf("reduce key %" PRId64 " sum %" PRId64 " count %" PRId64 "\n", row[qmd.getColOffInBytes(0) / 8], row[qmd.getColOffInBytes(1) / 8],
+                row[qmd.getColOffInBytes(2) / 8]);
+  }
+  g_services = nullptr;
+  return err;
+}
+
 }  // namespace
 
 int main() {
@@ -329,6 +667,11 @@ int main() {
                  as_reference_interface.getMaxBlockSize());
     int rc = run_c2(mgr);
     rc |= run_join(mgr);
+    rc |= run_q3(mgr);
+    rc |= run_c5(mgr);
+    rc |= run_projection(mgr);
+    rc |= run_floats(mgr);
+    rc |= run_reduce(mgr);
     return rc ? 1 : 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "harness failed: %s\n", e.what());

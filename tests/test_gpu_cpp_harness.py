@@ -1,6 +1,8 @@
 """The executed C++ binding: tests/cpp/harness.cpp drives HipMgr (over the reference's GpuMgr interface), make_plan
-(from a QueryMemoryDescriptor-shaped object), the *_on_device forwards and HipKernel::launch(ko, params) with the
-12-pointer block -- no Python between main() and the kernels.  Its output is compared with the committed golden
+(from a QueryMemoryDescriptor-shaped object), the plan extractor (HipPlanExtractor.h over the stand-in hdk::ir tree:
+taxi Q3, the C5 shape through the radix-partitioned passes, a filter projection, float accumulators), the *_on_device
+forwards, hdk_hip_reduce_buffers and HipKernel::launch(ko, params) with the 12-pointer block -- no Python between
+main() and the kernels.  Its output is compared with the committed golden
 (tests/golden/cpp_harness_output.txt, computed with numpy by tests/golden/gen_cpp_harness_golden.py)."""
 import os
 import subprocess
@@ -25,4 +27,6 @@ def test_cpp_harness_matches_the_golden():
     got = r.stdout.strip().split("\n")
     assert got == [w for w in want if w], r.stderr
     # the steps ran on the specialised kernels, not on an interpreter fallback
-    assert "hdk_scan_agg" in r.stderr
+    err = r.stderr
+    assert "c2: hdk_scan_agg_direct" in err and "q3: hdk_scan_agg_keys" in err, err
+    assert "c5: hdk_part_scatter" in err and "projection: hdk_scan_project" in err and "floats: hdk_scan_agg_keys_values" in err, err
