@@ -690,6 +690,29 @@ HDK_DEV int64_t eval_target_arg(const RowCtx& c, const hdk_hip_target& tg, bool&
   return v;
 }
 
+// 8- and 16-bit MIN / MAX slots of a columnar buffer with logical-sized columns: agg_{min,max}_int{8,16}[_skip_val]
+// (QE/RuntimeFunctions.cpp:540-560,670-704) for a slot with ONE writer at a time (hdk_finalize, the reductions)
+HDK_DEV void small_min_max(int agg, bool skip, int w, int8_t* slot, int64_t val, int64_t nullv) {
+  if (w == 2) {
+    int16_t* s = reinterpret_cast<int16_t*>(slot);
+    const int16_t v = static_cast<int16_t>(val), n = static_cast<int16_t>(nullv);
+    if (skip && v == n) return;
+    if (skip && *s == n) {
+      *s = v;
+      return;
+    }
+    *s = agg == HDK_AGG_MIN ? (*s < v ? *s : v) : (*s > v ? *s : v);
+  } else {
+    const int8_t v = static_cast<int8_t>(val), n = static_cast<int8_t>(nullv);
+    if (skip && v == n) return;
+    if (skip && *slot == n) {
+      *slot = v;
+      return;
+    }
+    *slot = agg == HDK_AGG_MIN ? (*slot < v ? *slot : v) : (*slot > v ? *slot : v);
+  }
+}
+
 // Quad q of an initialised row-wise group-by row: [keys: key_count x key_width, padded to 8][init_vals...]
 // (init_group_by_buffer_gpu, QE/GpuInitGroups.cu:110-160): the one definition the init kernel and the fused
 // initialisation of the partitioned group-by share.

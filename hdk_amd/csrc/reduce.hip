@@ -100,6 +100,12 @@ HDK_DEV void reduce_slot(const hdk_hip_target& tg, int8_t* this1, int8_t* this2,
     }
   }
   const bool skip = tg.skip_null;
+  if (tg.slot_width == 1 || tg.slot_width == 2) {
+    // logical-sized MIN / MAX slots (AGGREGATE_ONE_NULLABLE_VALUE_SMALL, QE/ResultSetReduction.cpp:1136-1172)
+    small_min_max(agg, skip, tg.slot_width, this1, tg.slot_width == 2 ? static_cast<int64_t>(*reinterpret_cast<const int16_t*>(that1))
+                                                                      : static_cast<int64_t>(*that1), init_val);
+    return;
+  }
   if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
     // get_width_for_slot -> sizeof(float) (QE/ResultSetReduction.cpp:1176-1185): AGGREGATE_ONE_NULLABLE_VALUE on the
     // low 4 bytes with agg_*_float[_skip_val]; the skip value is the low half of the slot's init value

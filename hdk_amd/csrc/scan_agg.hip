@@ -237,6 +237,10 @@ HDK_DEV void apply_value(const hdk_hip_target& tg, int8_t* slot, int64_t partial
     *s = __float_as_int(r);
     return;
   }
+  if (tg.slot_width == 1 || tg.slot_width == 2) {  // logical-sized MIN / MAX slots (columnar)
+    small_min_max(agg, skip, tg.slot_width, slot, partial, tg.null_val);
+    return;
+  }
   if (tg.slot_width == 4) {  // int32 slots (integer arguments)
     int32_t* s = reinterpret_cast<int32_t*>(slot);
     const int32_t v = static_cast<int32_t>(partial);
@@ -620,7 +624,15 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
                   "only a projected key of a baseline-hash plan may have a zero-width slot");
       continue;
     }
-    HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "slot width must be 4 or 8");
+    if (tg.slot_width == 1 || tg.slot_width == 2) {
+      // logical-sized columns (RS/ColSlotContext.cpp, QE/MemoryLayoutBuilder.cpp:559-652): MIN / MAX over TINYINT /
+      // SMALLINT in a columnar buffer keep 1- / 2-byte slots (the reference's small-slot runtime exists for those two
+      // aggregates only: AGGREGATE_ONE_NULLABLE_VALUE_SMALL, QE/ResultSetReduction.cpp:1136-1172)
+      HDK_REQUIRE(p->output_columnar && (tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX) && !tg.arg_is_fp,
+                  "target %d: 1- and 2-byte slots hold integer MIN / MAX of a columnar buffer only", t);
+      continue;
+    }
+    HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "slot width must be 1, 2 (MIN / MAX, columnar), 4 or 8");
     if (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED) {
       // a group-by plan writes a non-aggregate target from key #key_idx (hdk_finalize, the global kernels)
       HDK_REQUIRE(tg.key_idx >= 0 && tg.key_idx < p->key_count,
@@ -1736,6 +1748,16 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       if (shape.strategy == STRAT_GLOBAL || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) ||
           needs_join_loops(plan)) {
         set_error("fused join tables are only read by the batched interpreter kernels");
+        return HDK_HIP_ERR_UNSUPPORTED;
+      }
+    }
+  }
+  if (shape.strategy == STRAT_GLOBAL) {
+    for (int t = 0; t < plan->num_targets; ++t) {
+      if (plan->targets[t].slot_width == 1 || plan->targets[t].slot_width == 2) {
+        // (global atomics on 1- and 2-byte slots would need CAS loops on the enclosing word: not in the library;
+        // tables that fit LDS are flushed by hdk_finalize, which has one writer per slot)
+        set_error("1- and 2-byte slots are only written by the LDS strategy");
         return HDK_HIP_ERR_UNSUPPORTED;
       }
     }

@@ -1470,6 +1470,25 @@ static inline int first_slot_of_target(const hdk_hip_plan* p, int t) {
   return s;
 }
 
+/* 8- and 16-bit MIN / MAX slots (agg_{min,max}_int{8,16}[_skip_val], QE/RuntimeFunctions.cpp:540-560,670-704; used by
+ * reduceOneSlot through AGGREGATE_ONE_NULLABLE_VALUE_SMALL, QE/ResultSetReduction.cpp:1136-1172 -- "8/16-bit kMin and
+ * kMax only").  `w` = 1 or 2. */
+static void small_min_max(int agg, int skip, int w, int8_t* slot, int64_t val, int64_t nullv) {
+  if (w == 2) {
+    int16_t* s = (int16_t*)slot;
+    const int16_t v = (int16_t)val, n = (int16_t)nullv;
+    if (skip && v == n) return;              /* DEF_SKIP_AGG: val != skip_val */
+    if (skip && *s == n) { *s = v; return; } /* ... first value replaces the sentinel */
+    *s = agg == HDK_AGG_MIN ? (*s < v ? *s : v) : (*s > v ? *s : v);
+  } else {
+    int8_t* s = slot;
+    const int8_t v = (int8_t)val, n = (int8_t)nullv;
+    if (skip && v == n) return;
+    if (skip && *s == n) { *s = v; return; }
+    *s = agg == HDK_AGG_MIN ? (*s < v ? *s : v) : (*s > v ? *s : v);
+  }
+}
+
 /* Apply one target's aggregate(s) to its slot(s): the call the JIT emits per target
  * (QE/TargetExprBuilder.cpp:341-460: name = agg_<kind>[_int32|_double|_float][_skip_val]). */
 static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2, int64_t val) {
@@ -1543,6 +1562,10 @@ static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2,
         else orc_agg_max_double((int64_t*)slot1, d);
         break;
     }
+    return;
+  }
+  if (w == 1 || w == 2) { /* logical-sized MIN / MAX slots of a columnar buffer */
+    small_min_max(tg->agg, skip, w, slot1, val, nullv);
     return;
   }
   if (w == 4) {
@@ -2006,7 +2029,12 @@ static void reduce_one_target(const hdk_hip_target* tg, int8_t* this1, int8_t* t
     if (tg->slot_width == 0) { /* getTargetGroupbyIndex >= 0: nothing to reduce (:1248-1251) */
       return;
     }
-    if (tg->slot_width == 4) {
+    if (tg->slot_width == 2) {
+      const int16_t rhs = *(const int16_t*)that1;
+      if (rhs != (int16_t)init_val) *(int16_t*)this1 = rhs;
+    } else if (tg->slot_width == 1) {
+      if (*that1 != (int8_t)init_val) *this1 = *that1;
+    } else if (tg->slot_width == 4) {
       const int32_t rhs = *(const int32_t*)that1;
       if (rhs != init_val) *(int32_t*)this1 = rhs;
     } else {
@@ -2062,6 +2090,10 @@ static void reduce_one_target(const hdk_hip_target* tg, int8_t* this1, int8_t* t
         else orc_agg_max_double((int64_t*)this1, o);
         break;
     }
+    return;
+  }
+  if (w == 1 || w == 2) {
+    small_min_max(tg->agg, skip, w, this1, w == 2 ? (int64_t)*(const int16_t*)that1 : (int64_t)*that1, init_val);
     return;
   }
   if (w == 4) {

@@ -235,8 +235,15 @@ _AGG = {"count": A.AGG_COUNT, "sum": A.AGG_SUM, "min": A.AGG_MIN, "max": A.AGG_M
 
 
 def supported_by_library(lay: Layout):
-    """The fixed library keeps 4- and 8-byte slots (include/hdk_hip.h: hdk_hip_target.slot_width)."""
-    return all(w in (4, 8) for w in lay.slot_widths)
+    """4- and 8-byte slots, plus the 1- and 2-byte MIN / MAX slots of columnar buffers with logical-sized columns
+    (include/hdk_hip.h: hdk_hip_target.slot_width; the reference's small-slot runtime covers those two aggregates only)."""
+    for ti, t in enumerate(lay.targets):
+        w = lay.slot_widths[lay.first_slot(ti)]
+        if w in (1, 2) and not (lay.columnar and t.is_agg and t.agg in ("min", "max")):
+            return False
+        if w not in (1, 2, 4, 8):
+            return False
+    return True
 
 
 def make_plan(lay: Layout) -> A.Plan:

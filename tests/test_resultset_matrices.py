@@ -65,7 +65,7 @@ def check_reduce_case(case, rl, rbuf):
 def test_reduce_matrix_oracle(oracle, case):
     lay = M.make_layout(DOC, case)
     if not M.supported_by_library(lay):
-        pytest.skip("1- and 2-byte slots are outside the fixed library's QueryMemoryDescriptor subset (DESIGN.md 8)")
+        pytest.skip("slot widths outside the library's descriptor subset (none of the reference's matrices since round 3)")
     rl, rbuf = run_reduce_case(oracle, case, reduce_with_oracle)
     check_reduce_case(case, rl, rbuf)
 
