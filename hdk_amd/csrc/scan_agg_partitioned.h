@@ -860,7 +860,10 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate(PartArgs 
       } else {
         const uint32_t o = atomicAdd(a.fill_spill, 1u);
         if (o >= a.cap_spill) {
-          return;  // (cannot happen: the shared list is as large as the launch's input)
+          // one GPU: cannot happen, the shared list is as large as the launch's input.  The owner of a tuple exchange
+          // has a list of its own, sized for the spill of a table that is not full: loud, not silent
+          record_error(a.kp.error_code, HDK_HIP_ERR_EXCHANGE_INCOMPLETE);
+          return;
         }
         q = spill + static_cast<size_t>(o) * tw;
       }
@@ -996,6 +999,7 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_simple(Pa
       } else {
         const uint32_t o = atomicAdd(a.fill_spill, 1u);
         if (o >= a.cap_spill) {
+          record_error(a.kp.error_code, HDK_HIP_ERR_EXCHANGE_INCOMPLETE);  // (see hdk_part_aggregate)
           return;
         }
         q = a.slab1 + static_cast<size_t>(o) * tw;
@@ -1197,6 +1201,7 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_soa(PartA
       } else {
         const uint32_t o = atomicAdd(a.fill_spill, 1u);
         if (o >= a.cap_spill) {
+          record_error(a.kp.error_code, HDK_HIP_ERR_EXCHANGE_INCOMPLETE);  // (see hdk_part_aggregate)
           return;
         }
         q = a.slab1 + static_cast<size_t>(o) * tw;
@@ -1287,6 +1292,29 @@ __global__ __launch_bounds__(kPartAggBlock, 8) void hdk_part_aggregate_soa(PartA
   }
 }
 
+// one tuple straight onto the table in global memory with the reference's probe sequence (passes 4 and the owner's
+// atomics kernel); false: the table is full
+template <typename K>
+HDK_DEV bool part_apply_global(const PartArgs& a, const TableShape& shape, int64_t* table, const PartTarget* s_tg, const int64_t* q) {
+  const int tw = a.tw;
+  int64_t tup[kPartMaxTW];
+#pragma unroll
+  for (int w = 0; w < kPartMaxTW; ++w) {
+    tup[w] = w < tw ? q[w] : 0;
+  }
+  if (a.narrow) {
+    tup[1] = part_narrow_arg(a, tup[0]);
+  }
+  const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};
+  bool fresh;
+  const int64_t e = find_or_claim_from<K, true>(shape, table, a.entry_count, part_home<K>(a, tup), key, &fresh);
+  if (e < 0) {
+    return false;  // (the reference's get_group_value returns NULL)
+  }
+  part_apply_targets(s_tg, a.ntargets, reinterpret_cast<int8_t*>(table + static_cast<size_t>(e) * shape.row_quads), tup);
+  return true;
+}
+
 // ---- pass 4: overflow and spilled tuples, straight onto the table with the reference's probe sequence --------
 template <typename K>
 __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
@@ -1301,7 +1329,6 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
   const uint64_t n_spill = min(static_cast<uint64_t>(*a.fill_spill), a.cap_spill);
   const uint64_t n_seg = static_cast<uint64_t>(a.fine_count) * kPartSpillSeg;  // slots of the regions' own segments
   const TableShape shape = table_shape(p);
-  const uint32_t rq = shape.row_quads;
   const int tw = a.tw;
   int64_t* table = a.kp.groupby_buf[0];
   int32_t err = 0;
@@ -1316,22 +1343,42 @@ __global__ __launch_bounds__(kPartBlock) void hdk_part_overflow(PartArgs a) {
     } else {
       q = i - n_seg < n_ovf ? a.ovf + (i - n_seg) * tw : a.slab1 + (i - n_seg - n_ovf) * tw;
     }
-    int64_t tup[kPartMaxTW];
-#pragma unroll
-    for (int w = 0; w < kPartMaxTW; ++w) {
-      tup[w] = w < tw ? q[w] : 0;
+    if (!part_apply_global<K>(a, shape, table, s_tg, q)) {
+      err = HDK_HIP_ERR_OUT_OF_SLOTS;  // the table is full
     }
-    if (a.narrow) {
-      tup[1] = part_narrow_arg(a, tup[0]);
+  }
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+}
+
+// ---- the owner of a tuple exchange whose inbox is too skewed for fine slabs (a heavy hitter: every rank's tuples of
+// the key meet in one slab and its overflow area): every tuple of every source segment straight onto the owner's
+// table, which pass 3 has left empty.  Armed like the one-GPU path's atomics kernel: it runs only when level 2 has
+// set *fallback to 1 (3: a SENDER could not carry its share -- the exchange is incomplete; 2: interrupted).
+template <typename K>
+__global__ __launch_bounds__(kPartBlock) void hdk_part_owner_fallback(PartArgs a) {
+  __shared__ PartTarget s_tg[HDK_HIP_MAX_TARGETS];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  if (*a.fallback != 1) {
+    return;
+  }
+  part_load_targets(a, p, s_tg);
+  __syncthreads();
+  const TableShape shape = table_shape(p);
+  const int tw = a.tw;
+  int64_t* table = a.kp.groupby_buf[0];
+  const uint32_t nsub = a.p1 * kPartXcds;
+  int32_t err = 0;
+  for (uint32_t sj = blockIdx.x; sj < a.nsrc * nsub; sj += gridDim.x) {
+    const uint32_t src = sj / nsub, j = sj - src * nsub;
+    const uint64_t n = min(static_cast<uint64_t>(a.src_fill[src][static_cast<size_t>(j) * a.src_fill_stride]), a.sub1);
+    const int64_t* in = a.src_slab[src] + static_cast<size_t>(j) * a.sub1 * tw;
+    for (uint64_t i = threadIdx.x; i < n; i += kPartBlock) {
+      if (!part_apply_global<K>(a, shape, table, s_tg, in + i * tw)) {
+        err = HDK_HIP_ERR_OUT_OF_SLOTS;
+      }
     }
-    const K key[2] = {static_cast<K>(tup[0]), static_cast<K>(tup[1])};
-    bool fresh;
-    const int64_t e = find_or_claim_from<K, true>(shape, table, a.entry_count, part_home<K>(a, tup), key, &fresh);
-    if (e < 0) {
-      err = HDK_HIP_ERR_OUT_OF_SLOTS;  // the table is full (the reference's get_group_value returns NULL)
-      continue;
-    }
-    part_apply_targets(s_tg, a.ntargets, reinterpret_cast<int8_t*>(table + static_cast<size_t>(e) * rq), tup);
   }
   if (err) {
     record_error(a.kp.error_code, err);

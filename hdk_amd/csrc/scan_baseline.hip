@@ -564,6 +564,13 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
   pa.owners = 0;  // from here on this is a one-table job: the owner's
   hipLaunchKernelGGL(hdk_part_collect_flags, dim3(1), dim3(64), 0, s, pa);
   launch_part_tail(plan, pa, props, s);
+  // armed like the one-GPU path's atomics kernel: only if level 2 found the inbox too skewed for fine slabs
+  const unsigned go = static_cast<unsigned>(props->num_cu) * 4;
+  if (plan->key_width == 4) {
+    hipLaunchKernelGGL(hdk_part_owner_fallback<int32_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  } else {
+    hipLaunchKernelGGL(hdk_part_owner_fallback<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
+  }
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
 }

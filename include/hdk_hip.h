@@ -57,7 +57,10 @@ extern "C" {
 #define HDK_HIP_ERR_RUNTIME 102 /* a HIP runtime call failed; see hdk_hip_last_error() */
 #define HDK_HIP_ERR_EXCHANGE_INCOMPLETE 103 /* device code of hdk_hip_aggregate_from_ranks: a rank's segment was flagged
                                                (a sub-slab overflowed: skewed keys; stale column statistics; or the
-                                               scatter was interrupted) -- redo the step with the table exchange */
+                                               scatter was interrupted), or the owner's spill list overflowed (its
+                                               table is all but full) -- redo the step with the table exchange.  A
+                                               heavy hitter that only overflows the OWNER's slabs is not an error: the
+                                               owner then applies its inbox with atomics (hdk_part_owner_fallback) */
 #define HDK_HIP_ERR_JOIN_SLOT_TAKEN (-1) /* one-to-one build hit a duplicate key (JoinHashImpl.h:55-66) */
 
 const char* hdk_hip_last_error(void);

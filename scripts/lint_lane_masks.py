@@ -10,7 +10,8 @@ the wrong side.  (baseline_table.h: TableShape documents the instance that was h
 Usage: lint_lane_masks.py [file.s] [kernel-name-substring ...]   -- without a .s file it
 cross-compiles the kernel sources to ISA (about
 two minutes, no GPU needed) and lists, per kernel, every uniform branch whose mask comes from a VALU
-compare, when the compare sits inside a loop that narrows EXEC and the branch comes after that loop.
+compare, when the compare sits in the own lines of a loop that narrows EXEC (not merely around such a loop) and
+the branch comes after that loop.
 """
 import os
 import re
@@ -29,7 +30,7 @@ def main():
     else:
         text = ""
         with tempfile.TemporaryDirectory() as tmp:
-            for src in ("scan_agg.hip", "reduce.hip", "join_build.hip", "init_groups.hip"):
+            for src in ("scan_agg.hip", "scan_baseline.hip", "scan_project.hip", "reduce.hip", "join_build.hip", "init_groups.hip"):
                 out = os.path.join(tmp, src + ".s")
                 subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-munsafe-fp-atomics",
                                        "-ffp-contract=off", "--cuda-device-only", "-S", src, "-o", out],
@@ -63,8 +64,18 @@ def main():
             start = min(labels[i2][0] for i2 in member)
             last = max(member)
             end = labels[last + 1][0] - 1 if last + 1 < len(labels) else len(lines)
-            if any("s_andn2_b64 exec, exec" in l for l in lines[start - 1:end]):
-                loops.append((start, end, lab))
+            loops.append((start, end, lab))
+        # a loop narrows EXEC trip by trip when the narrowing sits in its OWN lines: a block-uniform loop around a
+        # divergent inner loop runs its own lines under the EXEC it was entered with (the compare of a uniform value
+        # at the head of a tile loop is complete, whatever the row loops below it do)
+        narrowing = []
+        for start, end, lab in loops:
+            inner = [(s2, e2) for (s2, e2, l2) in loops if l2 != lab and start <= s2 and e2 <= end]
+            own = [l for n2, l in enumerate(lines[start - 1:end], start) if not any(s2 <= n2 <= e2 for s2, e2 in inner)]
+            if any("s_andn2_b64 exec, exec" in l for l in own):
+                narrowing.append((start, end, lab))
+        # innermost first: a compare belongs to the smallest loop around it
+        loops = sorted(narrowing, key=lambda t: t[1] - t[0])
         last_def, hits = {}, []
         for n, line in enumerate(lines, 1):
             d = re.match(r"\s+(v_cmp\w+_e64)\s+(s\[\d+:\d+\])", line)

@@ -317,6 +317,49 @@ def test_tuple_exchange_flags_what_it_cannot_carry(oracle, gpu_executor_factory)
     _check_rows(cp2, res.buffer, want2)
 
 
+@pytest.mark.parametrize("shape", ["narrow", "wide", "multi_target"])
+def test_tuple_exchange_owner_takes_a_heavy_hitter(oracle, gpu_executor_factory, shape):
+    """A key with 4 % of the rows of an 8-rank job: every sender's sub-slabs carry their share, but at the key's owner
+    the tuples of all eight ranks meet in ONE fine slab and overflow it and the overflow area (48 K tuples against
+    ~23 K of room).  The owner then applies its whole inbox with atomics (hdk_part_owner_fallback): the union of the
+    owners' tables is the oracle's result and no error word is set."""
+    rng = np.random.default_rng(79)
+    n = 1_200_000
+    base = rng.integers(0, 400_000, n, dtype=np.int64)
+    base[rng.random(n) < 0.04] = 7
+    v = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.05] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"k32": (base * 7 - 100_000).astype(np.int32), "k64": base * 3_000_000_019 - 2**40, "v": v,
+                          "d": rng.normal(size=n)}, fragment_size=150_000)
+    key, targets = {"narrow": ("k32", [Agg("sum", ColRef("v"), "s")]),
+                    "wide": ("k64", [Agg("min", ColRef("v"), "m")]),
+                    "multi_target": ("k64", [Agg("count", None, "c"), Agg("avg", ColRef("d"), "a"), Agg("max", ColRef("v"), "m")])}[shape]
+    q = QueryUnit("t", groupby=[ColRef(key)], force_baseline=True, baseline_entry_count=800_001,
+                  targets=[KeyRef(0, "key")] + targets)
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    tables, owner_entries, xs = _exchange_tables(cp, ex, st, 8)
+    errs = [int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) for x in xs]
+    assert not any(errs), errs
+    rows = []
+    for t in tables:
+        rows.extend(_rows(cp, t, owner_entries))
+        _assert_reference_placement(oracle, cp, t, owner_entries)
+    rows.sort(key=lambda r: (r[0] is None, r[0]))
+    w = _rows(cp, want)
+    assert len(rows) == len(w)
+    for a_, b_ in zip(rows, w):
+        for x_, y in zip(a_, b_):
+            if isinstance(y, float):
+                assert abs(x_ - y) <= 1e-6 * max(1e-300, abs(y)), (a_, b_)
+            else:
+                assert x_ == y, (a_, b_)
+    for x in xs:
+        x.step.free()
+
+
 def test_baseline_fast_kernel_shapes(oracle, gpu_executor_factory):
     """hdk_scan_agg_baseline_direct: 4- and 8-byte table keys, 16-byte and wider entries, int32 / double /
     nullable arguments, ragged fragment tails, a table that fills up -- against the oracle and against
@@ -720,15 +763,53 @@ def test_radix_partitioned_random_shapes(oracle, gpu_executor_factory, seed):
                 ex.execute(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
             assert ei.value.code == A.ERR_OUT_OF_SLOTS, what
             continue
-        step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
-        names = step.kernel_names()
-        res = step.run()
-        step.free()
-        try:
-            _check_rows(cp, res.buffer, want)
-            if res.row_count() < cp.plan.entry_count and not cp.plan.output_columnar:
-                _assert_reference_placement(oracle, cp, res.buffer)
-        except AssertionError as e:
-            raise AssertionError(f"{what} kernels {names}\n{e}") from e
+        # the default forms (8-byte tuples and the structure-of-arrays pass 3 where the shape and the column statistics
+        # allow), then the same launch with each of them switched off: 16 / 24-byte tuples, array-of-rows pass 3
+        for env in ({}, {"HDK_HIP_PART_WIDE": "1"}, {"HDK_HIP_PART_AOS": "1"}):
+            os.environ.update(env)
+            try:
+                step = ex.prepare(cp, flags=A.LAUNCH_FORCE_PARTITIONED)
+                names = step.kernel_names()
+                res = step.run()
+                step.free()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            try:
+                _check_rows(cp, res.buffer, want)
+                if res.row_count() < cp.plan.entry_count and not cp.plan.output_columnar:
+                    _assert_reference_placement(oracle, cp, res.buffer)
+            except AssertionError as e:
+                raise AssertionError(f"{what} env {env} kernels {names}\n{e}") from e
         ran += names.startswith("hdk_part_scatter")
+        # the same query as a multi-GPU tuple exchange, ranks emulated on this device: the union of the owners' tables is
+        # the oracle's result -- or the exchange says it is incomplete (skewed keys overflow an owner sub-slab)
+        world = int(rng.choice([2, 3, 5, 8]))
+        if len(st.get("t").frag_rows) >= 1:
+            try:
+                tables, owner_entries, xs = _exchange_tables(cp, ex, st, world)
+            except Exception as e:  # shape outside the exchange (too few entries per owner for a region, ...)
+                assert "status 100" in str(e) or "UNSUPPORTED" in str(e) or "outside" in str(e), (what, world, e)
+                continue
+            errs = [int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) for x in xs]
+            for x in xs:
+                x.step.free()
+            if any(e == A.ERR_OUT_OF_SLOTS for e in errs):
+                continue  # an owner's share of a table this full does not fit (load 0.9 and a hash-unlucky owner)
+            if any(e == A.ERR_EXCHANGE_INCOMPLETE for e in errs):
+                assert mode in ("hot", "zipf", "warm") or n < 100_000, (what, world, errs)
+                continue
+            assert not any(errs), (what, world, errs)
+            rows = []
+            for t in tables:
+                rows.extend(_rows(cp, t, owner_entries))
+            rows.sort(key=lambda r: tuple((x is None, x) for x in r[:cp.plan.key_count]))
+            w = _rows(cp, want)
+            assert len(rows) == len(w), (what, world)
+            for a_, b_ in zip(rows, w):
+                for x_, y in zip(a_, b_):
+                    if isinstance(y, float):
+                        assert x_ is not None and abs(x_ - y) <= 1e-6 * max(1e-300, abs(y)), (what, world, a_, b_)
+                    else:
+                        assert x_ == y, (what, world, a_, b_)
     assert ran >= 1 or seed not in (1, 2)

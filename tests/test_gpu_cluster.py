@@ -1,6 +1,8 @@
 """Join probes over key-range-clustered outer rows (hdk_amd/csrc/scan_cluster.h): the pre-pass permutes the outer
 columns, the plan's ordinary kernel runs over the permuted fragments.  Forced on small tables here
 (LAUNCH_CLUSTER_PROBES); integer results must equal the oracle's bit for bit -- aggregates do not depend on row order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -201,3 +203,70 @@ def test_sliced_join_survives_stale_statistics(oracle, gpu_executor_factory):
         assert_buffers_equal(cp, step.run().buffer, want)
         step.free()
         c.fragments[0][11] = saved
+
+
+_SOAK = os.environ.get("HDK_FUZZ_SEEDS", "")
+_SOAK_SEEDS = list(range(*map(int, _SOAK.split(":")))) if _SOAK else []
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", [1, 2] + _SOAK_SEEDS)
+def test_sliced_join_random_shapes(oracle, gpu_executor_factory, seed):
+    """Seeded random shapes through the sliced join: fact sizes from one batch to millions of rows in ragged fragments,
+    dimensions from 300 keys (64-key slices) to 2.4 M (9 K-key slices), dense or sparse key ranges, uniform / hot / sorted
+    / block-clustered foreign keys (overflow area; the order probe), x columns that travel in 8- or 16-byte tuples, NULL
+    keys / x / payloads, one to three random aggregates of the shape.  HDK_FUZZ_SEEDS adds seeds for soak runs."""
+    rng = np.random.default_rng(7000 + seed)
+    nf = int(rng.choice([5_000, 90_000, 700_000, 2_500_000]))
+    nd = int(rng.choice([300, 20_000, 400_000, 2_400_000]))
+    stride = int(rng.choice([1, 1, 3]))
+    off = int(rng.integers(-1000, 1000))
+    st = ArrowStorage()
+    dval = rng.integers(-10**6, 10**6, nd).astype(np.int64)
+    if rng.random() < 0.5:
+        dval[rng.random(nd) < 0.1] = A.NULL_BIGINT
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * stride + off, "dval": dval})
+    lo, hi = off, off + stride * (nd - 1) + 1
+    kind = str(rng.choice(["uniform", "hot", "sorted", "blocks"]))
+    if kind == "uniform":
+        fk = rng.integers(lo - 5, hi + 5, nf)
+    elif kind == "hot":
+        fk = np.where(rng.random(nf) < 0.6, off + stride * int(rng.integers(0, nd)), rng.integers(lo, hi, nf))
+    elif kind == "sorted":
+        fk = np.sort(rng.integers(lo, hi, nf))
+    else:  # runs of 3 000 rows inside a narrow key window: clustered without being sorted
+        starts = rng.integers(lo, max(hi - 500, lo + 1), nf // 3000 + 1)
+        fk = np.repeat(starts, 3000)[:nf] + rng.integers(0, 500, nf)
+    fk = fk.astype(np.int64)
+    fk[rng.random(nf) < 0.02] = A.NULL_BIGINT
+    xk = str(rng.choice(["int32", "int32_nulls", "wide"]))
+    if xk == "int32":
+        x = rng.integers(-2**31, 2**31, nf).astype(np.int64)
+    elif xk == "int32_nulls":
+        x = rng.integers(-2**31 + 1, 2**31, nf).astype(np.int64)
+        x[rng.random(nf) < 0.05] = A.NULL_BIGINT
+    else:
+        x = rng.integers(-2**45, 2**45, nf).astype(np.int64)
+        x[rng.random(nf) < 0.05] = A.NULL_BIGINT
+    st.import_numpy("fact", {"fk": fk, "x": x}, fragment_size=int(rng.integers(nf // 6 + 1, nf + 2)))
+    X, D = ColRef("x"), ColRef("dval", "dim")
+    pool = [Agg("sum", X + D, "s0"), Agg("sum", D + X, "s1"), Agg("count", None, "c"), Agg("sum", X, "sx"), Agg("min", X - D, "lo"),
+            Agg("max", D, "hi"), Agg("count", D, "cd"), Agg("avg", D, "a"), Agg("count", X, "cx"), Agg("max", X, "mx")]
+    ex = gpu_executor_factory(st)
+    for qi in range(3):
+        targets = [pool[0]] if (qi == 0 and rng.random() < 0.5) else [pool[int(i)] for i in rng.choice(len(pool), int(rng.integers(1, 4)), replace=False)]
+        q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        what = (seed, qi, nf, nd, stride, kind, xk, [t.name for t in targets])
+        assert err == 0, what
+        step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        names = step.kernel_names()
+        if os.environ.get("HDK_SOAK_LOG"):
+            with open(os.environ["HDK_SOAK_LOG"], "a") as f:
+                f.write(f"{what} {names.split(',')[0]}\n")
+        try:
+            assert_buffers_equal(cp, step.run().buffer, want)
+        except AssertionError as e:
+            raise AssertionError(f"{what} kernels {names}\n{e}") from e
+        finally:
+            step.free()
