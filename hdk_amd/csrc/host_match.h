@@ -140,6 +140,7 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);
 void project_describe(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, char* out, size_t out_len);
 int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
-                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, hipStream_t s);
+                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, const hdk_hip_device_properties* props,
+                       hipStream_t s);
 
 }  // namespace hdk

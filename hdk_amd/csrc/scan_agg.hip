@@ -1820,7 +1820,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   }
   if (shape.strategy == STRAT_PROJECT) {
     HDK_REQUIRE(params[HDK_KP_MAX_MATCHED] && params[HDK_KP_TOTAL_MATCHED], "MAX_MATCHED / TOTAL_MATCHED is NULL");
-    st = launch_project(plan, d_plan, kp, ko, shape, s);
+    st = launch_project(plan, d_plan, kp, ko, shape, props, s);
   } else {
     st = launch_baseline(plan, d_plan, kp, ko, shape, init_output, props, s);
   }

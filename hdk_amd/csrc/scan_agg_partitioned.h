@@ -432,8 +432,18 @@ __global__ __launch_bounds__(kPartBlock, (NARROW && LEVEL == 1) ? HDK_PART_L1_WA
     __syncthreads();
   };
 
-  if (LEVEL == 2 && __hip_atomic_load(a.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    return;
+  if (LEVEL == 2) {
+    // Block-uniform, through LDS: another block of THIS kernel may raise the flag (a fine slab and the overflow area
+    // full) between the reads of two waves.  A wave that returns on its own takes its share of the batch's steps with
+    // it -- wave 0 gone means no run starts and no total: the others then copy out with whatever LDS held (found by the
+    // round-3 soak as a 1-in-5 memory fault on a zipf-skewed two-key shape).
+    if (tid == 0) {
+      s_stop = __hip_atomic_load(a.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_stop) {
+      return;
+    }
   }
   if (LEVEL == 1) {
     const uint64_t nfrag = *a.kp.num_fragments;

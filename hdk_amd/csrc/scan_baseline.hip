@@ -451,6 +451,14 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   pa.src_slab[0] = pa.slab1;
   pa.src_fill[0] = pa.fill1;
   pa.src_fill_stride = kPartCursorStride;
+  if (getenv("HDK_HIP_PART_TRACE")) {
+    fprintf(stderr, "part: scratch %p +%zu | slab1 %p (%zu) fill1 %p (%zu) slab2 %p ovf %p spill_seg %p fill2 %p | p1 %u p2_log2 %u fine %u "
+            "cap1 %llu sub1 %llu cap2 %llu cap_ovf %llu cap_spill %llu tw %d slots %u rows %llu table %p\n",
+            scratch.p, up(b1) + up(bc1) + tail, (void*)pa.slab1, b1, (void*)pa.fill1, bc1, (void*)pa.slab2, (void*)pa.ovf,
+            (void*)pa.spill_seg, (void*)pa.fill2, pa.p1, pa.p2_log2, pa.fine_count, (unsigned long long)pa.cap1,
+            (unsigned long long)pa.sub1, (unsigned long long)pa.cap2, (unsigned long long)pa.cap_ovf,
+            (unsigned long long)pa.cap_spill, pa.tw, pa.slots, (unsigned long long)pa.total_rows, (void*)nullptr);
+  }
   launch_part_scatter<1>(pa, k32, dim3(g1), lds1, s);
   launch_part_tail(plan, pa, props, s);
   // armed fallback: runs only if the scatter passes found the data too skewed for slabs (or the statistics stale)

@@ -152,7 +152,12 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
   int64_t* s_stage = s_dyn;
   uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(kTile) * TW);
   const int tid = threadIdx.x;
-  if (__hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+  // (block-uniform, through LDS: another block of this kernel may raise the word between the reads of two waves)
+  if (tid == 0) {
+    s_stop = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_stop) {
     return;  // clustered input: probed in row order
   }
   const uint32_t xcd = static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (kSliceXcds - 1);
@@ -351,7 +356,13 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced(SliceArgs 
   const uint32_t ew = static_cast<uint32_t>(wpe);
   const uint32_t my_rep = tid & (rep - 1);
   int32_t* s_pay = reinterpret_cast<int32_t*>(lds + ew * rep);
-  const bool off = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  // (block-uniform, through LDS: another block of this kernel may raise the word between the reads of two waves)
+  __shared__ uint32_t s_off;
+  if (tid == 0) {
+    s_off = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool off = s_off != 0;
   // slabs beyond this grid (hdk_finalize folds the launch shape's count) hold identities
   for (uint32_t sidx = blockIdx.x + (off ? 0u : gridDim.x); sidx < a.num_slabs; sidx += gridDim.x) {
     for (uint32_t i = tid; i < ew; i += kSliceAggBlock) {

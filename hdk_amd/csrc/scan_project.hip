@@ -38,6 +38,11 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
       fa->pairs = 0;
     }
   }
+  for (int i = 0; i < fa->nquals; ++i) {
+    for (int t = 0; t < fa->ntargets; ++t) {
+      if (fa->q[i].col.buf_idx == fa->t[t].col.buf_idx) fa->keep_cached = 1;
+    }
+  }
   // columnar target columns: [int64 row positions][target columns, each aligned to 8]
   size_t off = (static_cast<size_t>(p->entry_count) * 8 + 7) & ~size_t(7);
   for (int t = 0; t < p->num_targets; ++t) {
@@ -46,6 +51,12 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
     off += static_cast<size_t>(p->entry_count) * p->targets[t].slot_width;
   }
   return true;
+}
+
+// The one-pass form needs a status word per batch of tiles, so the launch has to state its row count
+// (HDK_HIP_PROJECT_TWO_PASS=1: A/B measurements of the two-pass form).
+static bool project_one_pass(const hdk_hip_kernel_options* ko) {
+  return ko && ko->total_rows && !getenv("HDK_HIP_PROJECT_TWO_PASS");
 }
 
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
@@ -68,7 +79,8 @@ uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, c
 void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
   ProjFastArgs pf;
   if (!launch_forces_generic(ko) && match_project_fast(plan, &pf)) {
-    snprintf(out, out_len, "hdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct");
+    snprintf(out, out_len, "%shdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct",
+             project_one_pass(ko) ? "hdk_scan_project_stream," : "");
   } else {
     snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
                                  : plan->num_joins     ? "hdk_scan_project_join"
@@ -77,7 +89,8 @@ void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko
 }
 
 int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
-                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, hipStream_t s) {
+                       const hdk_hip_kernel_options* ko, const LaunchShape& shape, const hdk_hip_device_properties* props,
+                       hipStream_t s) {
   ProjArgs pa;
   pa.plan = d_plan;
   pa.kp = kp;
@@ -86,6 +99,37 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
   const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
   if (!generic && match_project_fast(plan, &pf)) {
     pf.kp = kp;
+    // ---- one pass (decoupled look-back over batches of tiles), the two passes armed behind it ----------------------
+    AsyncScratch status_mem(s);
+    bool streamed = false;
+    if (project_one_pass(ko)) {
+      // a status word per batch: the stated rows in full tiles, plus one ragged tile per fragment -- 64 K of them
+      // (the kernel counts the real tiles and hands the launch to the two passes if they do not fit)
+      uint64_t slack = 65536;
+      if (const char* e = getenv("HDK_HIP_PROJECT_STATUS_SLACK")) slack = strtoull(e, nullptr, 10);  // (tests)
+      const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + slack;
+      const uint64_t cap = tiles / kProjFastGroup + 1;
+      const size_t bytes = 16 + cap * sizeof(uint64_t);
+      if (hipMallocAsync(&status_mem.p, bytes, s) == hipSuccess) {
+        HDK_HIP_CHECK(hipMemsetAsync(status_mem.p, 0, bytes, s));
+        pf.ticket = static_cast<uint32_t*>(status_mem.p);
+        pf.status = reinterpret_cast<uint64_t*>(static_cast<int8_t*>(status_mem.p) + 16);
+        pf.status_cap = cap;
+        const void* k = pf.pairs ? reinterpret_cast<const void*>(hdk_scan_project_stream_pairs)
+                                 : reinterpret_cast<const void*>(hdk_scan_project_stream);
+        const uint32_t grid = resident_grid(k, kProjFastBlock, 0, props);
+        if (pf.pairs) {
+          hipLaunchKernelGGL(hdk_scan_project_stream_pairs, dim3(grid), dim3(kProjFastBlock), 0, s, pf);
+        } else {
+          hipLaunchKernelGGL(hdk_scan_project_stream, dim3(grid), dim3(kProjFastBlock), 0, s, pf);
+        }
+        pf.run_if = pf.ticket + 1;
+        streamed = true;
+      } else {
+        (void)hipGetLastError();
+        status_mem.p = nullptr;
+      }
+    }
     AsyncScratch counts_mem(s), mask_mem(s);  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
     HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
     uint32_t* counts = static_cast<uint32_t*>(counts_mem.p);
@@ -95,7 +139,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
     pf.sel_mask = nullptr;
     pf.sel_tiles = 0;
-    if (ko && ko->total_rows) {
+    if (ko && ko->total_rows && !streamed) {  // (armed behind the one-pass kernel the passes do without it)
       const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + 1024;
       if (hipMallocAsync(&mask_mem.p, tiles * kProjFastBlock, s) == hipSuccess) {
         pf.sel_mask = static_cast<uint8_t*>(mask_mem.p);
@@ -110,7 +154,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     } else {
       hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     }
-    hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched);
+    hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched, pf.run_if);
     if (pf.pairs) {
       hipLaunchKernelGGL(hdk_scan_project_direct_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     } else {

@@ -47,6 +47,13 @@ struct ProjFastArgs {
   uint8_t* sel_mask;                      // pass 1 -> pass 2: one byte (VR pass bits) per thread and tile, or nullptr
   uint64_t sel_tiles;                     // tiles the mask has room for; later tiles re-evaluate the filter in pass 2
   int32_t pairs;                          // every filter column is 8 bytes wide: the *_pairs kernels (rows dealt two at a time)
+  // one-pass form (hdk_scan_project_stream): one status word per batch of kProjFastGroup tiles, the batch ticket and the
+  // word that arms the two-pass kernels behind it
+  uint64_t* status;
+  uint64_t status_cap;       // batches the status array has room for
+  uint32_t* ticket;          // [0]: next batch; [1]: 1 = the input has more tiles than status words, take the two passes
+  const uint32_t* run_if;    // two-pass kernels: nullptr = always run; else only when *run_if == 1
+  int32_t keep_cached;       // a filter column is also a target: its lines are gathered again right after the filter
 };
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
@@ -138,6 +145,7 @@ HDK_DEV bool proj_fast_cmp(int cmp, bool fp, int64_t l, int64_t r) {
 // lane reads 16 bytes per load, lane after lane contiguous, no bounds tests, and the verdicts live in ONE register per
 // lane (bit r = slot r passes) -- a bool per row carried round the conjunct loop is kept by the compiler as a 0/1 byte
 // in a VGPR and converted back and forth every trip.
+template <bool NT = true>
 HDK_DEV uint32_t pf_filter_full_tile_pairs(const ProjFastArgs& a, const int8_t* const* cols, int64_t row0, int tid) {
   constexpr int VR = kProjFastVR;
   uint32_t m = (1u << VR) - 1u;
@@ -153,7 +161,8 @@ HDK_DEV uint32_t pf_filter_full_tile_pairs(const ProjFastArgs& a, const int8_t* 
 #pragma unroll
     for (int u = 0; u < VR / 2; ++u) {
       const uint32_t off = static_cast<uint32_t>(u * kProjFastBlock + tid) * 16u;
-      const pf_i64x2 x = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) pf_i64x2*>(base + off));
+      const __attribute__((address_space(1))) pf_i64x2* at = reinterpret_cast<const __attribute__((address_space(1))) pf_i64x2*>(base + off);
+      const pf_i64x2 x = NT ? __builtin_nontemporal_load(at) : *at;
       v[2 * u] = x.x;
       v[2 * u + 1] = x.y;
     }
@@ -185,6 +194,56 @@ HDK_DEV uint32_t pf_filter_full_tile_pairs(const ProjFastArgs& a, const int8_t* 
   return m;
 }
 
+// The filter over one tile in general: any column width, ragged tiles (rows past `nrows` fail), lane-striped or paired
+// rows.  Bit r of the result = slot r passes.
+template <int R>
+HDK_DEV uint32_t pf_filter_tile(const ProjFastArgs& a, const int8_t* const* cols, int64_t row0, int64_t nrows, int tid, bool nt) {
+  constexpr int VR = kProjFastVR;
+  bool pass[VR];
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
+  }
+  // decode + compare, all VR loads of a column in flight together
+  for (int qi = 0; qi < a.nquals; ++qi) {
+    const ProjFastQual q = a.q[qi];
+    const int8_t* qb = cols[q.col.buf_idx];
+    int64_t v[VR];
+    load_rows<VR, kProjFastBlock, R>(qb, q.col.width, q.col.kind, row0, tid, pass, nt, v);
+    const bool fpc = q.fp != 0;
+    const bool col_fp = q.col_fp != 0;
+    const bool nullable = q.nullable != 0;
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
+      pass[r] = pass[r] && !isnull;
+      if (fpc && !col_fp) {
+        v[r] = double_to_bits(static_cast<double>(v[r]));
+      }
+    }
+    // the comparison operator is wave-uniform: one switch per batch, the row loop inside each case
+#define HDK_PF_CMP(OP)                                                                                   \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                       \
+      pass[r] = pass[r] && (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs));      \
+    }
+    switch (q.cmp) {
+      case HDK_CMP_EQ: HDK_PF_CMP(==) break;
+      case HDK_CMP_NE: HDK_PF_CMP(!=) break;
+      case HDK_CMP_LT: HDK_PF_CMP(<) break;
+      case HDK_CMP_GT: HDK_PF_CMP(>) break;
+      case HDK_CMP_LE: HDK_PF_CMP(<=) break;
+      default: HDK_PF_CMP(>=) break;
+    }
+#undef HDK_PF_CMP
+  }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    bits |= (pass[r] ? 1u : 0u) << r;
+  }
+  return bits;
+}
+
 constexpr int kProjFastGroup = 4;  // writing pass: tiles handled per block-wide scan (one barrier per group, not per tile)
 
 template <int MODE, int R>  // MODE 0: count passing rows per block; 1: write them.  R: see pf_row
@@ -209,6 +268,9 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   uint32_t counted = 0;                                        // MODE 0: this thread's passing rows
   uint32_t running = MODE == 1 ? a.block_counts[blockIdx.x] : 0;  // MODE 1: next output row of the block
 
+  if (a.run_if && *a.run_if != 1) {
+    return;  // (armed behind the one-pass kernel, which took the launch)
+  }
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   __shared__ int32_t s_watch;
@@ -253,47 +315,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       } else if (MODE == 1 && masked) {
         bits = __builtin_nontemporal_load(mask_at);
       } else {
-        bool pass[VR];
-#pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          pass[r] = pf_row<kProjFastBlock, R>(row0, tid, r) < nrows;
-        }
-        // ---- filter: decode + compare, all VR loads of a column in flight together -----------------------
-        for (int qi = 0; qi < a.nquals; ++qi) {
-          const ProjFastQual q = a.q[qi];
-          const int8_t* qb = cols[q.col.buf_idx];
-          int64_t v[VR];
-          load_rows<VR, kProjFastBlock, R>(qb, q.col.width, q.col.kind, row0, tid, pass, MODE == 1, v);  // pass 1 leaves the lines cached
-          const bool fpc = q.fp != 0;
-          const bool col_fp = q.col_fp != 0;
-          const bool nullable = q.nullable != 0;
-#pragma unroll
-          for (int r = 0; r < VR; ++r) {
-            const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
-            pass[r] = pass[r] && !isnull;
-            if (fpc && !col_fp) {
-              v[r] = double_to_bits(static_cast<double>(v[r]));
-            }
-          }
-          // the comparison operator is wave-uniform: one switch per batch, the row loop inside each case
-#define HDK_PF_CMP(OP)                                                                                   \
-  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                       \
-      pass[r] = pass[r] && (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs));      \
-    }
-          switch (q.cmp) {
-            case HDK_CMP_EQ: HDK_PF_CMP(==) break;
-            case HDK_CMP_NE: HDK_PF_CMP(!=) break;
-            case HDK_CMP_LT: HDK_PF_CMP(<) break;
-            case HDK_CMP_GT: HDK_PF_CMP(>) break;
-            case HDK_CMP_LE: HDK_PF_CMP(<=) break;
-            default: HDK_PF_CMP(>=) break;
-          }
-#undef HDK_PF_CMP
-        }
-#pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          bits |= (pass[r] ? 1u : 0u) << r;
-        }
+        bits = pf_filter_tile<R>(a, cols, row0, nrows, tid, MODE == 1);  // pass 1 leaves the lines cached
         if (MODE == 0 && masked) {
           *mask_at = static_cast<uint8_t>(bits);
         }
@@ -426,10 +448,284 @@ extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_co
 extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct_pairs(ProjFastArgs a) {
   scan_project_direct_body<1, 2>(a);
 }
+// ---- one pass: filter -> dense output positions by decoupled look-back over batches -> write ------------------
+// The two passes above read the filter columns twice (or write and read a bitmask) and need a grid-wide step between
+// them.  Here a block takes a BATCH of kProjFastGroup consecutive tiles (a ticket, so that every earlier batch belongs
+// to a block that is already running), evaluates the filter, publishes the batch's count in its status word, looks
+// back over the status words of the batches before it until it meets one that already knows its prefix, publishes its
+// own prefix and writes.  Nothing waits for anything but counts, which depend on nothing: no chain.  Output rows come
+// out batch after batch, inside a batch wave by wave and lane by lane: deterministic, as with the two passes.
+// status word: [63:62] 0 = nothing yet, 1 = the batch's own count, 2 = the count of everything up to and including the
+// batch (= the output row after its last one); [61:0] the count.
+constexpr uint64_t kProjStatusCount = 1ull << 62, kProjStatusPrefix = 2ull << 62, kProjStatusValue = (1ull << 62) - 1;
+
+HDK_DEV uint64_t pf_look_back(const uint64_t* status, uint32_t batch, int lane) {
+  uint64_t excl = 0;
+  for (int64_t idx = static_cast<int64_t>(batch) - 1;; idx -= kWave) {
+    const int64_t i = idx - lane;
+    uint64_t st = kProjStatusPrefix;  // (before batch 0: nothing; batch 0's own prefix carries what TOTAL_MATCHED held)
+    if (i >= 0) {
+      for (;;) {
+        st = __hip_atomic_load(status + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st >> 62) {
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const uint64_t known = __ballot((st >> 62) == 2);
+    const int first = known ? __ffsll(static_cast<unsigned long long>(known)) - 1 : kWave;
+    uint64_t v = lane <= first ? (st & kProjStatusValue) : 0;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      v += __shfl_xor(v, d, kWave);
+    }
+    excl += v;
+    if (known) {
+      return excl;
+    }
+  }
+}
+
+template <int R>
+HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
+  constexpr int VR = kProjFastVR;
+  constexpr int G = kProjFastGroup;
+  constexpr int kWaves = kProjFastBlock / kWave;
+  constexpr int64_t kTileRows = static_cast<int64_t>(kProjFastBlock) * VR;
+  static_assert(kTileRows == 4096, "a strip entry is (tile of the batch) << 12 | row inside the tile");
+  __shared__ uint32_t s_wave_tot[2][kWaves];
+  __shared__ uint16_t s_rows[kWaves][kWave * kProjFastVR * G];
+  __shared__ uint32_t s_next;                                      // the block's next ticket
+  __shared__ uint64_t s_base;                                      // first output row of the batch
+  __shared__ int64_t s_g_row0[2][G];                               // batches that straddle fragments: row of each tile's
+  __shared__ const int8_t* s_g_tb[2][G][HDK_HIP_MAX_TARGETS];      // first slot, and its fragment's target columns
+  __shared__ int32_t s_watch;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const uint32_t max_matched = static_cast<uint32_t>(*a.kp.max_matched);
+  int64_t* buf = a.kp.groupby_buf[0];
+  const bool columnar = a.columnar != 0;
+  const bool keep = a.keep_cached != 0;
+  uint64_t total_tiles = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    total_tiles += static_cast<uint64_t>((a.kp.num_rows[f * ntab] + kTileRows - 1) / kTileRows);
+  }
+  const uint64_t nbatch = (total_tiles + G - 1) / G;
+  if (nbatch > a.status_cap) {  // more fragments (ragged tiles) than the status words allow for: the two passes take it
+    if (blockIdx.x == 0 && tid == 0) {
+      a.ticket[1] = 1;
+    }
+    return;
+  }
+  int32_t slots_err = 0;
+  uint32_t iter = 0;
+  // fragment cursor: tickets only grow, so it only moves forward
+  uint64_t cf = 0;
+  int64_t c_begin = 0, c_rows = 0, c_tiles = 0;
+  const int8_t* const* c_cols = nullptr;
+  if (nfrag) {
+    c_rows = a.kp.num_rows[0];
+    c_tiles = (c_rows + kTileRows - 1) / kTileRows;
+    c_cols = a.kp.col_buffers[0];
+  }
+  const Watch watch = watch_begin(a.kp);
+  if (tid == 0) {
+    s_next = atomicAdd(a.ticket, 1u);
+  }
+  __syncthreads();
+  uint32_t b = s_next;
+  __syncthreads();
+  while (b < nbatch) {
+    if (watch.flags) {
+      if (const int32_t w_ = watch_poll_block(watch, &s_watch)) {
+        if (tid == 0) {
+          record_error(a.kp.error_code, w_);
+          // nobody may wait for this batch: the result is void anyway
+          __hip_atomic_store(a.status + b, kProjStatusPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+    }
+    uint32_t next_ticket = 0;
+    if (tid == 0) {
+      next_ticket = atomicAdd(a.ticket, 1u);  // (in flight under the filter's loads)
+    }
+    const int par = static_cast<int>(iter & 1);
+    const int64_t t0 = static_cast<int64_t>(b) * G;
+    while (t0 >= c_begin + c_tiles) {
+      c_begin += c_tiles;
+      ++cf;
+      c_rows = a.kp.num_rows[cf * ntab];
+      c_tiles = (c_rows + kTileRows - 1) / kTileRows;
+      c_cols = a.kp.col_buffers[cf];
+    }
+    // the batch lies in one fragment (block-uniform): a strip entry is then the row's offset from the first tile's row 0
+    const bool same = t0 + G <= c_begin + c_tiles || static_cast<uint64_t>(c_begin + c_tiles) >= total_tiles;
+    const int64_t row00 = (t0 - c_begin) * kTileRows;
+    // ---- filter: verdict bits of this lane, bit g * VR + r = slot r of the batch's g-th tile passes --------------
+    uint32_t bits = 0;
+    {
+      uint64_t lf = cf;
+      int64_t l_begin = c_begin, l_rows = c_rows, l_tiles = c_tiles;
+      const int8_t* const* l_cols = c_cols;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int64_t tile = t0 + g;
+        if (static_cast<uint64_t>(tile) < total_tiles) {
+          while (tile >= l_begin + l_tiles) {
+            l_begin += l_tiles;
+            ++lf;
+            l_rows = a.kp.num_rows[lf * ntab];
+            l_tiles = (l_rows + kTileRows - 1) / kTileRows;
+            l_cols = a.kp.col_buffers[lf];
+          }
+          const int64_t row0 = (tile - l_begin) * kTileRows;
+          uint32_t m;
+          if (R == 2 && row0 + kTileRows <= l_rows) {
+            m = keep ? pf_filter_full_tile_pairs<false>(a, l_cols, row0, tid) : pf_filter_full_tile_pairs<true>(a, l_cols, row0, tid);
+          } else {
+            m = pf_filter_tile<R>(a, l_cols, row0, l_rows, tid, !keep);
+          }
+          bits |= m << (g * VR);
+          if (!same) {
+            if (tid == 0) {
+              s_g_row0[par][g] = row0;
+            }
+            if (tid < a.ntargets) {
+              s_g_tb[par][g][tid] = l_cols[a.t[tid].col.buf_idx];
+            }
+          }
+        }
+      }
+    }
+    // ---- dense positions inside the batch ----------------------------------------------------------------------
+    const uint32_t mine = __builtin_popcount(bits);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint32_t n = __shfl_up(incl, d, kWave);
+      if (lane >= d) {
+        incl += n;
+      }
+    }
+    if (lane == kWave - 1) {
+      s_wave_tot[par][wave] = incl;
+    }
+    if (tid == 0) {
+      s_next = next_ticket;
+    }
+    __syncthreads();
+    uint32_t before = 0, batch_total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const uint32_t t = s_wave_tot[par][w];
+      batch_total += t;
+      if (w < wave) {
+        before += t;
+      }
+    }
+    const uint32_t nb = s_next;
+    // ---- the batch's first output row: decoupled look-back, by wave 0 --------------------------------------------
+    if (wave == 0) {
+      uint64_t excl;
+      if (b == 0) {
+        excl = static_cast<uint32_t>(*a.kp.total_matched);  // this launch appends, like the claiming kernels
+      } else {
+        if (lane == 0) {
+          __hip_atomic_store(a.status + b, kProjStatusCount | batch_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl = pf_look_back(a.status, b, lane);
+      }
+      if (lane == 0) {
+        __hip_atomic_store(a.status + b, kProjStatusPrefix | (excl + batch_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base = excl;
+        if (b + 1 == nbatch) {
+          *a.kp.total_matched = static_cast<int32_t>(excl + batch_total);
+        }
+      }
+    }
+    __syncthreads();
+    const uint64_t base64 = s_base;
+    // ---- compact: the wave's passing rows, in output order, into its LDS strip (see the writing pass above) --------
+    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+    const uint64_t wave_base = base64 + before;  // first output row of this wave's rows
+    {
+      uint32_t j = incl - mine;
+      uint32_t left = bits;
+      while (left) {
+        const int bi = __ffs(left) - 1;
+        left &= left - 1;
+        s_rows[wave][j++] = static_cast<uint16_t>(((bi / VR) << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, bi % VR)));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto row_of = [&](uint32_t e) { return same ? row00 + e : s_g_row0[par][e >> 12] + (e & 4095u); };
+    // ---- project: row position, then each target column ---------------------------------------------------------
+    const size_t rq = a.row_size_quad;
+    for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+      const uint32_t j = j0 + lane;
+      if (j < wave_total) {
+        const int64_t row = row_of(s_rows[wave][j]);
+        const uint64_t pos = wave_base + j;
+        if (pos >= max_matched) {
+          slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
+        } else {
+          buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
+        }
+      }
+    }
+    for (int ti = 0; ti < a.ntargets; ++ti) {
+      const ProjFastTarget t = a.t[ti];
+      const int8_t* tb0 = c_cols[t.col.buf_idx];
+      int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
+      const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
+      for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        const uint64_t pos = wave_base + j;
+        if (j < wave_total && pos < max_matched) {
+          const uint32_t e = s_rows[wave][j];
+          const int8_t* tb = same ? tb0 : s_g_tb[par][e >> 12][ti];
+          const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row_of(e), true);
+          int8_t* dst = base + static_cast<size_t>(pos) * stride;
+          switch (t.slot_width) {
+            case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
+            case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v); break;
+            case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v); break;
+            default: *reinterpret_cast<int64_t*>(dst) = v; break;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next batch
+    ++iter;
+    b = nb;
+  }
+  if (slots_err) {
+    atomicCAS(a.kp.error_code, 0, slots_err);  // negative = ran out of slots (benign under a LIMIT)
+  }
+}
+
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_stream(ProjFastArgs a) {
+  scan_project_stream_body<1>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_stream_pairs(ProjFastArgs a) {
+  scan_project_stream_body<2>(a);
+}
+
 // per-block counts -> exclusive offsets (in place), starting at what TOTAL_MATCHED already holds (like the claiming
 // kernels of scan_project.h, which append with atomicAdd); the grand total is added to TOTAL_MATCHED
-extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint32_t* counts, uint32_t n, int32_t* total_matched) {
+extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint32_t* counts, uint32_t n, int32_t* total_matched,
+                                                                             const uint32_t* run_if) {
   __shared__ uint32_t s_part[1024];
+  if (run_if && *run_if != 1) {
+    return;
+  }
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t lo = tid * per;

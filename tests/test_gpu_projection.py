@@ -111,10 +111,13 @@ def test_direct_filter_project_kernel(oracle, gpu_executor_factory, columnar):
     assert len(got["a"]) == 5000 and all(x < 500 for x in got["a"])
 
 
-def test_selection_mask_and_its_fallbacks(oracle, gpu_executor_factory):
-    """The counting pass hands a selection bitmask to the writing pass when the launch states its row count.
-    Same rows with the mask, without it (total_rows = 0: the filter is evaluated twice) and with a mask that is
-    too short (tiles past its end re-evaluate) -- 5 M rows = 1221 tiles against the 1024 tiles of slack."""
+def test_one_pass_two_pass_and_their_fallbacks(oracle, gpu_executor_factory):
+    """A launch that states its row count takes the one-pass kernel (decoupled look-back over batches of tiles); if the
+    input turns out to have more tiles than status words, the kernel hands the launch to the two passes armed behind it.
+    Without a row count the two passes run alone: with a selection bitmask from the counting pass (HDK_HIP_PROJECT_TWO_PASS
+    forces them for a stated count), without it (total_rows = 0: the filter is evaluated twice), with a mask that is too
+    short (tiles past its end re-evaluate) -- 5 M rows = 1221 tiles against the 1024 tiles of slack.  Same rows always."""
+    import os
     rng = np.random.default_rng(33)
     n = 5_000_000
     a = rng.integers(0, 1000, n).astype(np.int64)
@@ -126,11 +129,19 @@ def test_selection_mask_and_its_fallbacks(oracle, gpu_executor_factory):
     cp, want, err, nrows = run_projection_oracle(oracle, st, q)
     assert err == 0 and nrows == int((a < 37).sum())
     ex = gpu_executor_factory(st)
-    for total_rows in (n, 0, 1):
-        step = ex.prepare(cp)
-        assert step.kernel_names().endswith("hdk_scan_project_direct")
-        step.ko.total_rows = total_rows
-        res = step.run()
-        step.free()
-        assert res.total_matched == nrows, total_rows
-        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), total_rows
+    for total_rows, env in ((n, {}), (0, {}), (1, {}), (1, {"HDK_HIP_PROJECT_STATUS_SLACK": "0"}),
+                            (n, {"HDK_HIP_PROJECT_STATUS_SLACK": "0"}), (n, {"HDK_HIP_PROJECT_TWO_PASS": "1"}),
+                            (1, {"HDK_HIP_PROJECT_TWO_PASS": "1"})):
+        os.environ.update(env)
+        try:
+            step = ex.prepare(cp)
+            assert step.kernel_names().endswith("hdk_scan_project_direct")
+            assert step.kernel_names().startswith("hdk_scan_project_stream") == ("HDK_HIP_PROJECT_TWO_PASS" not in env)
+            step.ko.total_rows = total_rows
+            res = step.run()
+            step.free()
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert res.total_matched == nrows, (total_rows, env)
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), (total_rows, env)
