@@ -2,6 +2,8 @@
 // specialised global-atomics kernel (scan_agg_baseline_fast.h) and the general one (scan_agg_global.h), with their
 // matchers.  A translation unit of its own (scan_agg.hip holds the API and the LDS strategies): the kernels of one
 // strategy family are compiled together and nothing else.
+#include <algorithm>
+#include <vector>
 #include "host_match.h"
 #include "scan_agg_baseline_fast.h"
 #include "scan_agg_global.h"
@@ -580,6 +582,22 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
     hipLaunchKernelGGL(hdk_part_owner_fallback<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   }
   HDK_HIP_CHECK(hipGetLastError());
+  if (getenv("HDK_HIP_PART_TRACE")) {  // debugging aid: where the owner's tuples are after the passes (synchronises)
+    HDK_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<uint32_t> c(bc2 / 4);
+    HDK_HIP_CHECK(hipMemcpy(c.data(), cur2, bc2, hipMemcpyDeviceToHost));
+    uint64_t in2 = 0, over2 = 0, segs = 0, maxfill = 0;
+    for (uint32_t f = 0; f < pa.fine_count; ++f) {
+      in2 += std::min<uint64_t>(c[f], pa.cap2);
+      over2 += c[f] > pa.cap2 ? c[f] - pa.cap2 : 0;
+      maxfill = std::max<uint64_t>(maxfill, c[f]);
+      segs += c[pa.fine_count + f];
+    }
+    fprintf(stderr, "owner: fine %u cap2 %llu | in fine slabs %llu (+%llu past cap, max cursor %llu) ovf %u/%llu seg-spill %llu list-spill %u/%llu fallback %u\n",
+            pa.fine_count, (unsigned long long)pa.cap2, (unsigned long long)in2, (unsigned long long)over2, (unsigned long long)maxfill,
+            c[2 * pa.fine_count], (unsigned long long)pa.cap_ovf, (unsigned long long)segs, c[2 * pa.fine_count + 1],
+            (unsigned long long)pa.cap_spill, c[2 * pa.fine_count + 2]);
+  }
   return HDK_HIP_OK;
 }
 

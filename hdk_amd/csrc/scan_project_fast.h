@@ -246,6 +246,62 @@ HDK_DEV uint32_t pf_filter_tile(const ProjFastArgs& a, const int8_t* const* cols
 
 constexpr int kProjFastGroup = 4;  // writing pass: tiles handled per block-wide scan (one barrier per group, not per tile)
 
+// ---- project the wave's passing rows: lane j takes the j-th entry of the wave's strip ------------------------------
+// U entries per lane and trip: the U gathers of a target column are all issued before the first store (a loop of one
+// gather -> wait -> store per trip ran at the latency of a gather: 16 trips x 3 columns per wave and batch at 50 %
+// selectivity).  row_of(e): the row of strip entry e; col_of(e, ti): target ti's column buffer for that row.
+constexpr int kProjFastU = 4;
+template <typename RowOf, typename ColOf>
+HDK_DEV void pf_project_rows(const ProjFastArgs& a, int64_t* buf, const uint16_t* strip, uint32_t wave_total, uint64_t wave_base,
+                             uint32_t max_matched, int lane, RowOf row_of, ColOf col_of, int32_t& slots_err) {
+  constexpr int U = kProjFastU;
+  const bool columnar = a.columnar != 0;
+  const size_t rq = a.row_size_quad;
+  for (uint32_t j0 = 0; j0 < wave_total; j0 += U * kWave) {
+    uint32_t e[U];
+    int64_t row[U];
+    uint64_t pos[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = j0 + u * kWave + lane;
+      ok[u] = j < wave_total;
+      e[u] = ok[u] ? strip[j] : 0;
+      row[u] = row_of(e[u]);
+      pos[u] = wave_base + j;
+      if (ok[u] && pos[u] >= max_matched) {
+        slots_err = -1 - static_cast<int32_t>(row[u] & 0x3fffffff);
+        ok[u] = false;
+      }
+      if (ok[u]) {
+        buf[columnar ? static_cast<size_t>(pos[u]) : static_cast<size_t>(pos[u]) * rq] = row[u];
+      }
+    }
+    for (int ti = 0; ti < a.ntargets; ++ti) {
+      const ProjFastTarget t = a.t[ti];
+      int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
+      const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
+      int64_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v[u] = ok[u] ? decode_col_g(col_of(e[u], ti), t.col.width, t.col.kind, row[u], true) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          int8_t* dst = base + static_cast<size_t>(pos[u]) * stride;
+          switch (t.slot_width) {
+            case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v[u]); break;
+            case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v[u]); break;
+            case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v[u]); break;
+            default: *reinterpret_cast<int64_t*>(dst) = v[u]; break;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, int R>  // MODE 0: count passing rows per block; 1: write them.  R: see pf_row
 HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   constexpr int VR = kProjFastVR;
@@ -375,40 +431,8 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       const int64_t group_stride_rows = static_cast<int64_t>(gridDim.x) * kTileRows;
       auto row_of = [&](uint32_t e) { return row0 + static_cast<int64_t>(e >> 12) * group_stride_rows + (e & 4095u); };
       // ---- project: row position, then each target column ---------------------------------------------
-      const size_t rq = a.row_size_quad;
-      for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
-        const uint32_t j = j0 + lane;
-        if (j < wave_total) {
-          const int64_t row = row_of(s_rows[wave][j]);
-          const uint32_t pos = wave_base + j;
-          if (pos >= max_matched) {
-            slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
-          } else {
-            buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
-          }
-        }
-      }
-      for (int ti = 0; ti < a.ntargets; ++ti) {
-        const ProjFastTarget t = a.t[ti];
-        const int8_t* tb = cols[t.col.buf_idx];
-        int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
-        const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
-        for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
-          const uint32_t j = j0 + lane;
-          const uint32_t pos = wave_base + j;
-          if (j < wave_total && pos < max_matched) {
-            const int64_t row = row_of(s_rows[wave][j]);
-            const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
-            int8_t* dst = base + static_cast<size_t>(pos) * stride;
-            switch (t.slot_width) {
-              case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
-              case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v); break;
-              case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v); break;
-              default: *reinterpret_cast<int64_t*>(dst) = v; break;
-            }
-          }
-        }
-      }
+      pf_project_rows(a, buf, s_rows[wave], wave_total, wave_base, max_matched, lane, row_of,
+                      [&](uint32_t, int ti) { return cols[a.t[ti].col.buf_idx]; }, slots_err);
       __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
       tile += static_cast<int64_t>(group - 1) * gridDim.x;
     }
@@ -667,41 +691,8 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     auto row_of = [&](uint32_t e) { return same ? row00 + e : s_g_row0[par][e >> 12] + (e & 4095u); };
     // ---- project: row position, then each target column ---------------------------------------------------------
-    const size_t rq = a.row_size_quad;
-    for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
-      const uint32_t j = j0 + lane;
-      if (j < wave_total) {
-        const int64_t row = row_of(s_rows[wave][j]);
-        const uint64_t pos = wave_base + j;
-        if (pos >= max_matched) {
-          slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
-        } else {
-          buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
-        }
-      }
-    }
-    for (int ti = 0; ti < a.ntargets; ++ti) {
-      const ProjFastTarget t = a.t[ti];
-      const int8_t* tb0 = c_cols[t.col.buf_idx];
-      int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
-      const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
-      for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
-        const uint32_t j = j0 + lane;
-        const uint64_t pos = wave_base + j;
-        if (j < wave_total && pos < max_matched) {
-          const uint32_t e = s_rows[wave][j];
-          const int8_t* tb = same ? tb0 : s_g_tb[par][e >> 12][ti];
-          const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row_of(e), true);
-          int8_t* dst = base + static_cast<size_t>(pos) * stride;
-          switch (t.slot_width) {
-            case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
-            case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v); break;
-            case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v); break;
-            default: *reinterpret_cast<int64_t*>(dst) = v; break;
-          }
-        }
-      }
-    }
+    pf_project_rows(a, buf, s_rows[wave], wave_total, wave_base, max_matched, lane, row_of,
+                    [&](uint32_t e, int ti) { return same ? c_cols[a.t[ti].col.buf_idx] : s_g_tb[par][e >> 12][ti]; }, slots_err);
     __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next batch
     ++iter;
     b = nb;
@@ -711,10 +702,13 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
   }
 }
 
-extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_stream(ProjFastArgs a) {
+#ifndef HDK_PROJ_STREAM_WAVES
+#define HDK_PROJ_STREAM_WAVES 0  // waves per SIMD the one-pass kernels are held to (0: the compiler's choice)
+#endif
+extern "C" __global__ __launch_bounds__(kProjFastBlock, HDK_PROJ_STREAM_WAVES) void hdk_scan_project_stream(ProjFastArgs a) {
   scan_project_stream_body<1>(a);
 }
-extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_stream_pairs(ProjFastArgs a) {
+extern "C" __global__ __launch_bounds__(kProjFastBlock, HDK_PROJ_STREAM_WAVES) void hdk_scan_project_stream_pairs(ProjFastArgs a) {
   scan_project_stream_body<2>(a);
 }
 

@@ -212,6 +212,8 @@ def merge_baseline_on_device(cp, recv, recv_counts: np.ndarray, device_id: int, 
             cnts.append(int(c))
         offs += baseline_table_quads(cp, int(c))
     d_err = torch.zeros(1, dtype=torch.int32, device=recv.device)
+    if not stream:  # the library's own stream is not ordered with torch's default stream, which has just filled d_err
+        torch.cuda.current_stream(recv.device).synchronize()
     if segs:
         that = (C.c_void_p * len(segs))(*segs)
         tc = (C.c_uint32 * len(segs))(*cnts)
@@ -293,19 +295,26 @@ class TupleExchange:
     def bytes_sent_per_rank(self) -> int:
         return (self.world - 1) * int(self.shape.segment_bytes)
 
-    def scatter(self, stream):
-        self.check(self.L.hdk_hip_scatter_to_owners(C.byref(self.step.plan), self.step._params, C.byref(self.ko),
-                                                    C.byref(self.shape), self.send.data_ptr(), self.dev, stream,
-                                                    self.ws_scatter.data_ptr(), self.ws_scatter.numel()))
+    def _on_stream(self, stream, fn):
+        # A NULL stream means "the library's own stream" to the C ABI, which is ordered neither with torch's default
+        # stream nor with the collective issued from it: a caller on the default stream gets a fenced side stream.
+        if stream:
+            return fn(stream)
+        return run_ordered(self.torch.device("cuda", self.dev), fn)
+
+    def scatter(self, stream=None):
+        self._on_stream(stream, lambda h: self.check(self.L.hdk_hip_scatter_to_owners(
+            C.byref(self.step.plan), self.step._params, C.byref(self.ko), C.byref(self.shape), self.send.data_ptr(),
+            self.dev, h, self.ws_scatter.data_ptr(), self.ws_scatter.numel())))
 
     def exchange(self, group=None):
         exchange_equal_segments(self.send, self.recv, self.world, group)
 
-    def aggregate(self, stream, recv=None):
+    def aggregate(self, stream=None, recv=None):
         r = self.recv if recv is None else recv
-        self.check(self.L.hdk_hip_aggregate_from_ranks(C.byref(self.step.plan), self.step._params, C.byref(self.ko),
-                                                       C.byref(self.shape), r.data_ptr(), self.dev, stream,
-                                                       self.ws_aggregate.data_ptr(), self.ws_aggregate.numel()))
+        self._on_stream(stream, lambda h: self.check(self.L.hdk_hip_aggregate_from_ranks(
+            C.byref(self.step.plan), self.step._params, C.byref(self.ko), C.byref(self.shape), r.data_ptr(), self.dev, h,
+            self.ws_aggregate.data_ptr(), self.ws_aggregate.numel())))
 
     def segment(self, buf, i):
         n = int(self.shape.segment_bytes)

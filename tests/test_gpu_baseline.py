@@ -191,6 +191,8 @@ def _exchange_tables(cp, ex, st, world, flags=0, rows_bound=None):
     frag_rows = st.get(cp.query.table).frag_rows
     shards = [D.shard_fragments(nfrag, world, r) for r in range(world)]
     bound = rows_bound or max(sum(frag_rows[f] for f in sh) for sh in shards)
+    # (the default stream's handle is 0, which the C ABI reads as "the library's own stream": TupleExchange then fences a
+    # side stream against the default stream, where the emulated all-to-all below -- plain device copies -- runs)
     h = torch.cuda.current_stream().cuda_stream
     xs, tables = [], []
     for r in range(world):
