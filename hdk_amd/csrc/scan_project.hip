@@ -53,10 +53,11 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
   return true;
 }
 
-// The one-pass form needs a status word per batch of tiles, so the launch has to state its row count
-// (HDK_HIP_PROJECT_TWO_PASS=1: A/B measurements of the two-pass form).
+// The one-pass form (HDK_HIP_PROJECT_ONE_PASS=1: measured slower than the two passes at 1 % and at 50 % selectivity,
+// DESIGN.md 3.2, and kept behind the switch) needs a status word per batch of tiles, so the launch has to state its row
+// count.
 static bool project_one_pass(const hdk_hip_kernel_options* ko) {
-  return ko && ko->total_rows && !getenv("HDK_HIP_PROJECT_TWO_PASS");
+  return ko && ko->total_rows && getenv("HDK_HIP_PROJECT_ONE_PASS");
 }
 
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
@@ -79,7 +80,7 @@ uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, c
 void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
   ProjFastArgs pf;
   if (!launch_forces_generic(ko) && match_project_fast(plan, &pf)) {
-    snprintf(out, out_len, "%shdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_direct",
+    snprintf(out, out_len, "%shdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_dense,hdk_scan_project_direct",
              project_one_pass(ko) ? "hdk_scan_project_stream," : "");
   } else {
     snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
@@ -131,9 +132,11 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
       }
     }
     AsyncScratch counts_mem(s), mask_mem(s);  // stream-ordered scratch: pass-1 counts / pass-2 offsets per block
-    HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, static_cast<size_t>(shape.grid) * sizeof(uint32_t), s));
+    HDK_HIP_CHECK(hipMallocAsync(&counts_mem.p, (static_cast<size_t>(shape.grid) + 1) * sizeof(uint32_t), s));
     uint32_t* counts = static_cast<uint32_t*>(counts_mem.p);
     pf.block_counts = counts;
+    pf.mode = counts + shape.grid;  // (0 until the offsets kernel decides: if it does not run, neither does a writing pass)
+    HDK_HIP_CHECK(hipMemsetAsync(pf.mode, 0, sizeof(uint32_t), s));
     // selection bitmask handed from the counting pass to the writing pass: rows/8 bytes when the caller
     // states the row count (plus room for one partial tile per fragment, up to 1024 fragments; tiles past
     // the end re-evaluate the filter).  No scratch, no mask: pass 2 then decodes the filter columns again.
@@ -154,10 +157,16 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     } else {
       hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     }
-    hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched, pf.run_if);
+    uint32_t force = 0;  // (HDK_HIP_PROJECT_WRITER=sparse|dense: A/B measurements)
+    if (const char* e = getenv("HDK_HIP_PROJECT_WRITER")) force = e[0] == 'd' ? 2u : e[0] == 's' ? 1u : 0u;
+    hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched, pf.run_if, kp,
+                       pf.mode, force);
+    // the two writing passes: the offsets kernel has picked one, the other returns at once
     if (pf.pairs) {
+      hipLaunchKernelGGL(hdk_scan_project_dense_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
       hipLaunchKernelGGL(hdk_scan_project_direct_pairs, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     } else {
+      hipLaunchKernelGGL(hdk_scan_project_dense, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
       hipLaunchKernelGGL(hdk_scan_project_direct, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     }
     HDK_HIP_CHECK(hipGetLastError());

@@ -53,6 +53,7 @@ struct ProjFastArgs {
   uint64_t status_cap;       // batches the status array has room for
   uint32_t* ticket;          // [0]: next batch; [1]: 1 = the input has more tiles than status words, take the two passes
   const uint32_t* run_if;    // two-pass kernels: nullptr = always run; else only when *run_if == 1
+  uint32_t* mode;            // written by hdk_scan_project_offsets: 1 = the sparse writing pass runs, 2 = the dense one
   int32_t keep_cached;       // a filter column is also a target: its lines are gathered again right after the filter
 };
 
@@ -70,10 +71,12 @@ HDK_DEV int64_t pf_row(int64_t tile_row0, int tid, int r) {
 typedef long long __attribute__((ext_vector_type(2))) pf_i64x2;
 
 // VR rows of one column: the decoder switch is wave-uniform and sits outside the row loop
-template <int VR, int BLOCK, int R>
+// PAIRS8: the rows are dealt in adjacent pairs AND the column is 8 bytes wide (always so for the filter columns of the
+// *_pairs kernels; the dense writing pass asks per target column)
+template <int VR, int BLOCK, int R, bool PAIRS8 = (R == 2)>
 HDK_DEV void load_rows(const int8_t* buf, int width, int kind, int64_t row0, int tid, const bool (&live)[VR], bool nt,
                        int64_t (&out)[VR]) {
-  if (R == 2) {  // 8-byte columns only (int64 / double bits): pairs of adjacent rows
+  if (PAIRS8) {  // 8-byte columns (int64 / double bits): pairs of adjacent rows
 #pragma unroll
     for (int r = 0; r < VR; r += 2) {
       out[r] = 0;
@@ -246,18 +249,53 @@ HDK_DEV uint32_t pf_filter_tile(const ProjFastArgs& a, const int8_t* const* cols
 
 constexpr int kProjFastGroup = 4;  // writing pass: tiles handled per block-wide scan (one barrier per group, not per tile)
 
-// ---- project the wave's passing rows: lane j takes the j-th entry of the wave's strip ------------------------------
-// U entries per lane and trip: the U gathers of a target column are all issued before the first store (a loop of one
-// gather -> wait -> store per trip ran at the latency of a gather: 16 trips x 3 columns per wave and batch at 50 %
-// selectivity).  row_of(e): the row of strip entry e; col_of(e, ti): target ti's column buffer for that row.
-constexpr int kProjFastU = 4;
-template <typename RowOf, typename ColOf>
-HDK_DEV void pf_project_rows(const ProjFastArgs& a, int64_t* buf, const uint16_t* strip, uint32_t wave_total, uint64_t wave_base,
-                             uint32_t max_matched, int lane, RowOf row_of, ColOf col_of, int32_t& slots_err) {
+// ---- writing a group of kProjFastGroup tiles -----------------------------------------------------------------------
+// Output order inside a group: tile after tile, inside a tile wave after wave, lane after lane, slot after slot.  So the
+// rows a WAVE passes from one tile land in one contiguous range of output rows, which is what lets a wave choose, tile by
+// tile, between two ways of getting them there:
+//   sparse -- few rows pass: the wave lists its passing rows in an LDS strip, lane j then gathers the j-th row from each
+//             target column and stores it (every gather and store has all its lanes busy; the target columns are read
+//             only where rows pass);
+//   dense  -- an eighth of the rows or more pass, so every 128-byte line of a target column is needed anyway: the wave
+//             reads its 8 slots per lane of the column with the coalesced loads of the filter pass, compacts the VALUES
+//             through LDS and stores them -- no row list, no gathers (at 50 % selectivity the gathers ran at 3.8 TB/s of
+//             in + out bytes; measured in DESIGN.md 3.2).
+constexpr int kProjFastG = kProjFastGroup;
+constexpr uint32_t kProjDenseMin = kWave * kProjFastVR / 8;  // passing rows of a wave and tile from which the dense form pays
+
+struct PfWavePos {
+  uint32_t lane_excl[kProjFastG];  // passing rows of the lower lanes of this wave, per tile
+  uint32_t wave_tot[kProjFastG];   // the wave's passing rows, per tile
+};
+
+// per-tile wave scans of the verdict bits (bit g * VR + r = slot r of tile g passes)
+HDK_DEV void pf_scan_tiles(uint32_t bits, int lane, PfWavePos& p) {
+#pragma unroll
+  for (int g = 0; g < kProjFastG; ++g) {
+    const uint32_t mine = __builtin_popcount((bits >> (g * kProjFastVR)) & ((1u << kProjFastVR) - 1u));
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint32_t n = __shfl_up(incl, d, kWave);
+      if (lane >= d) {
+        incl += n;
+      }
+    }
+    p.lane_excl[g] = incl - mine;
+    p.wave_tot[g] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), kWave - 1));  // (an SGPR)
+  }
+}
+
+// lane j takes the j-th entry of the wave's strip (entry: tile of the group << 12 | row inside the tile), U entries per
+// lane and trip with the type switches outside the entry loops: U gathers back to back, then U stores
+constexpr int kProjFastU = 2;
+template <typename RowOf, typename PosOf, typename ColOf>
+HDK_DEV void pf_project_rows(const ProjFastArgs& a, int64_t* buf, const uint16_t* strip, uint32_t count, uint32_t max_matched,
+                             int lane, RowOf row_of, PosOf pos_of, ColOf col_of, int32_t& slots_err) {
   constexpr int U = kProjFastU;
   const bool columnar = a.columnar != 0;
   const size_t rq = a.row_size_quad;
-  for (uint32_t j0 = 0; j0 < wave_total; j0 += U * kWave) {
+  for (uint32_t j0 = 0; j0 < count; j0 += U * kWave) {
     uint32_t e[U];
     int64_t row[U];
     uint64_t pos[U];
@@ -265,10 +303,10 @@ HDK_DEV void pf_project_rows(const ProjFastArgs& a, int64_t* buf, const uint16_t
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t j = j0 + u * kWave + lane;
-      ok[u] = j < wave_total;
+      ok[u] = j < count;
       e[u] = ok[u] ? strip[j] : 0;
       row[u] = row_of(e[u]);
-      pos[u] = wave_base + j;
+      pos[u] = pos_of(j, e[u]);
       if (ok[u] && pos[u] >= max_matched) {
         slots_err = -1 - static_cast<int32_t>(row[u] & 0x3fffffff);
         ok[u] = false;
@@ -282,34 +320,208 @@ HDK_DEV void pf_project_rows(const ProjFastArgs& a, int64_t* buf, const uint16_t
       int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
       const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
       int64_t v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        v[u] = ok[u] ? decode_col_g(col_of(e[u], ti), t.col.width, t.col.kind, row[u], true) : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          int8_t* dst = base + static_cast<size_t>(pos[u]) * stride;
-          switch (t.slot_width) {
-            case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v[u]); break;
-            case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v[u]); break;
-            case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v[u]); break;
-            default: *reinterpret_cast<int64_t*>(dst) = v[u]; break;
-          }
+#define HDK_PF_GATHER(T, CONV)                                          \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                       \
+    v[u] = 0;                                                           \
+    if (ok[u]) {                                                        \
+      const T x = gload<T>(col_of(e[u] >> 12, ti), row[u], true);       \
+      v[u] = CONV;                                                      \
+    }                                                                   \
+  }
+      if (t.col.kind == HDK_COL_DOUBLE) {
+        HDK_PF_GATHER(int64_t, x)
+      } else if (t.col.kind == HDK_COL_UNSIGNED) {
+        switch (t.col.width) {
+          case 1: HDK_PF_GATHER(uint8_t, static_cast<int64_t>(x)) break;
+          case 2: HDK_PF_GATHER(uint16_t, static_cast<int64_t>(x)) break;
+          case 4: HDK_PF_GATHER(uint32_t, static_cast<int64_t>(x)) break;
+          default: HDK_PF_GATHER(int64_t, x) break;
+        }
+      } else {  // (float columns are not in this kernel's shape: match_project_fast)
+        switch (t.col.width) {
+          case 1: HDK_PF_GATHER(int8_t, static_cast<int64_t>(x)) break;
+          case 2: HDK_PF_GATHER(int16_t, static_cast<int64_t>(x)) break;
+          case 4: HDK_PF_GATHER(int32_t, static_cast<int64_t>(x)) break;
+          default: HDK_PF_GATHER(int64_t, x) break;
         }
       }
+#undef HDK_PF_GATHER
+#define HDK_PF_PUT(T)                                                                                       \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                           \
+    if (ok[u]) {                                                                                            \
+      *reinterpret_cast<T*>(base + static_cast<size_t>(pos[u]) * stride) = static_cast<T>(v[u]);            \
+    }                                                                                                       \
+  }
+      switch (t.slot_width) {
+        case 1: HDK_PF_PUT(int8_t) break;
+        case 2: HDK_PF_PUT(int16_t) break;
+        case 4: HDK_PF_PUT(int32_t) break;
+        default: HDK_PF_PUT(int64_t) break;
+      }
+#undef HDK_PF_PUT
     }
   }
 }
 
-template <int MODE, int R>  // MODE 0: count passing rows per block; 1: write them.  R: see pf_row
+// the wave's passing rows of the tiles in the mask `tiles` into its strip, tile after tile; goff[g] = where tile g's entries start
+template <int R>
+HDK_DEV void pf_fill_strip(uint16_t* strip, uint32_t bits, int tid, const PfWavePos& p, uint32_t tiles,
+                           uint32_t (&goff)[kProjFastG], uint32_t* count) {
+  constexpr int VR = kProjFastVR;
+  uint32_t at = 0;
+#pragma unroll
+  for (int g = 0; g < kProjFastG; ++g) {
+    goff[g] = at;
+    if ((tiles >> g) & 1u) {
+      uint32_t j = at + p.lane_excl[g];
+      uint32_t left = (bits >> (g * VR)) & ((1u << VR) - 1u);
+      while (left) {
+        const int b = __ffs(left) - 1;
+        left &= left - 1;
+        strip[j++] = static_cast<uint16_t>((g << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, b)));
+      }
+      at += p.wave_tot[g];
+    }
+  }
+  *count = at;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One group: `bits` of this lane, the wave's positions, wave_base[g] = output row of the wave's first passing row of tile
+// g, trow0[g] = row (inside its fragment) of tile g's slot 0, full_mask bit g = tile g is a whole tile, col_of(g, ti) =
+// target ti's column buffer for tile g's fragment.  wave_lds: 4 KB of LDS of the wave's own.
+template <int R, typename ColOf>
+HDK_DEV void pf_write_group(const ProjFastArgs& a, int64_t* buf, int64_t* wave_lds, uint32_t bits, const PfWavePos& p,
+                            const uint64_t (&wave_base)[kProjFastG], const int64_t (&trow0)[kProjFastG], uint32_t full_mask,
+                            ColOf col_of, uint32_t max_matched, int tid, int lane, int32_t& slots_err) {
+  constexpr int VR = kProjFastVR;
+  constexpr int G = kProjFastG;
+  uint16_t* strip = reinterpret_cast<uint16_t*>(wave_lds);
+  uint32_t dense_mask = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    dense_mask |= ((full_mask >> g) & 1u) && p.wave_tot[g] >= kProjDenseMin ? 1u << g : 0u;
+  }
+  auto row_of = [&](uint32_t e) {
+    const uint32_t g = e >> 12;
+    return (g == 0 ? trow0[0] : g == 1 ? trow0[1] : g == 2 ? trow0[2] : trow0[3]) + (e & 4095u);
+  };
+  static_assert(G == 4, "the selects below spell out four tiles");
+  auto sel32 = [](const uint32_t (&x)[G], int g) { return g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : x[3]; };
+  auto sel64 = [](const uint64_t (&x)[G], int g) { return g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : x[3]; };
+  auto sel64s = [](const int64_t (&x)[G], int g) { return g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : x[3]; };
+  const bool columnar = a.columnar != 0;
+  const size_t rq = a.row_size_quad;
+  // ---- dense tiles, one after the other (g is wave-uniform: the per-tile values come out of their arrays by select, so
+  // that the loop need not be unrolled -- four copies of the body cost 60 registers) -------------------------------------
+  if (dense_mask) {
+    bool live[VR];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      live[r] = true;
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      if (!((dense_mask >> g) & 1u)) {
+        continue;
+      }
+      const uint32_t n = sel32(p.wave_tot, g);
+      const uint32_t m = (bits >> (g * VR)) & ((1u << VR) - 1u);
+      const uint32_t at0 = sel32(p.lane_excl, g);
+      const uint64_t out0 = sel64(wave_base, g);
+      const int64_t r0 = sel64s(trow0, g);
+      // the values of the lane's passing slots -> LDS at the lane's positions; then lane j stores the j-th value
+      auto compact = [&](const int64_t (&v)[VR]) {
+        uint32_t at = at0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if ((m >> r) & 1u) {
+            wave_lds[at++] = v[r];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      };
+      int64_t v[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        v[r] = r0 + pf_row<kProjFastBlock, R>(0, tid, r);
+      }
+      compact(v);
+      for (uint32_t j = lane; j < n; j += kWave) {
+        const int64_t row = wave_lds[j];
+        const uint64_t pos = out0 + j;
+        if (pos >= max_matched) {
+          slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
+        } else {
+          buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int ti = 0; ti < a.ntargets; ++ti) {
+        const ProjFastTarget t = a.t[ti];
+        int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
+        const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
+        if (R == 2 && t.col.width == 8 && t.col.kind != HDK_COL_FLOAT) {
+          load_rows<VR, kProjFastBlock, R, true>(col_of(g, ti), t.col.width, t.col.kind, r0, tid, live, true, v);
+        } else {
+          load_rows<VR, kProjFastBlock, R, false>(col_of(g, ti), t.col.width, t.col.kind, r0, tid, live, true, v);
+        }
+        compact(v);
+#define HDK_PF_PUT(T)                                                                                       \
+  for (uint32_t j = lane; j < n; j += kWave) {                                                              \
+    if (out0 + j < max_matched) {                                                                           \
+      *reinterpret_cast<T*>(base + static_cast<size_t>(out0 + j) * stride) = static_cast<T>(wave_lds[j]);   \
+    }                                                                                                       \
+  }
+        switch (t.slot_width) {
+          case 1: HDK_PF_PUT(int8_t) break;
+          case 2: HDK_PF_PUT(int16_t) break;
+          case 4: HDK_PF_PUT(int32_t) break;
+          default: HDK_PF_PUT(int64_t) break;
+        }
+#undef HDK_PF_PUT
+        __builtin_amdgcn_wave_barrier();  // the values are overwritten by the next column
+      }
+    }
+  }
+  // ---- the other tiles together: strip, gather, store ----------------------------------------------------------------
+  uint32_t sparse_mask = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    sparse_mask |= (!((dense_mask >> g) & 1u) && p.wave_tot[g] != 0) ? 1u << g : 0u;
+  }
+  if (sparse_mask) {
+    uint32_t goff[G], count;
+    pf_fill_strip<R>(strip, bits, tid, p, sparse_mask, goff, &count);
+    const uint64_t adj0 = wave_base[0] - goff[0], adj1 = wave_base[1] - goff[1], adj2 = wave_base[2] - goff[2],
+                   adj3 = wave_base[3] - goff[3];
+    pf_project_rows(a, buf, strip, count, max_matched, lane, row_of,
+                    [&](uint32_t j, uint32_t e) {
+                      const uint32_t g = e >> 12;
+                      return (g == 0 ? adj0 : g == 1 ? adj1 : g == 2 ? adj2 : adj3) + j;
+                    },
+                    col_of, slots_err);
+    __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
+  }
+}
+
+// MODE 0: count passing rows per block; 1: write them.  R: see pf_row.  DENSE (writing pass): positions tile after tile
+// and pf_write_group, for launches in which an eighth of the rows or more pass (decided on the device by
+// hdk_scan_project_offsets); else positions lane after lane over the whole group, one strip, gathers -- the order does
+// not matter to anyone, but the two forms cost each other registers (81 against 129) and a selective filter (1 %: 0.56 ms
+// per 256 M rows against 0.86) wants the occupancy.
+template <int MODE, int R, bool DENSE = false>
 HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   constexpr int VR = kProjFastVR;
   constexpr int G = kProjFastGroup;
   constexpr int kWaves = kProjFastBlock / kWave;
-  __shared__ uint32_t s_wave_tot[2][kWaves];
-  // MODE 1: per wave, the passing rows of the group in output order: (tile of the group) << 12 | row inside the tile
-  __shared__ uint16_t s_rows[MODE == 1 ? kWaves : 1][MODE == 1 ? kWave * kProjFastVR * G : 1];
+  __shared__ uint32_t s_wave_tot[2][G][kWaves];
+  // MODE 1: 4 KB per wave: the strip of its passing rows, or the values of one tile and column (pf_write_group)
+  __shared__ int64_t s_wave_lds[MODE == 1 ? kWaves : 1][MODE == 1 ? kWave * kProjFastVR : 1];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
@@ -324,8 +536,11 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
   uint32_t counted = 0;                                        // MODE 0: this thread's passing rows
   uint32_t running = MODE == 1 ? a.block_counts[blockIdx.x] : 0;  // MODE 1: next output row of the block
 
-  if (a.run_if && *a.run_if != 1) {
+  if (MODE == 0 && a.run_if && *a.run_if != 1) {
     return;  // (armed behind the one-pass kernel, which took the launch)
+  }
+  if (MODE == 1 && *a.mode != (DENSE ? 2u : 1u)) {
+    return;  // (the other writing pass has this launch, or the one-pass kernel had it)
   }
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
@@ -376,64 +591,137 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
           *mask_at = static_cast<uint8_t>(bits);
         }
       }
-      const uint32_t mine = __builtin_popcount(bits);
       if (MODE == 0) {
-        counted += mine;
+        counted += __builtin_popcount(bits);
         continue;
       }
-      // ---- selection vector -> dense output positions inside the block's range ------------------------
-      uint32_t incl = mine;
+      if (!DENSE) {
+        // ---- selection vector -> dense output positions inside the block's range, lane after lane ------------------
+        const uint32_t mine = __builtin_popcount(bits);
+        uint32_t incl = mine;
 #pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t n = __shfl_up(incl, d, kWave);
-        if (lane >= d) {
-          incl += n;
-        }
-      }
-      uint32_t out_pos = running + incl - mine;
-      uint32_t tile_total = 0;
-      {
-        const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one group ahead
-        if (lane == kWave - 1) {
-          s_wave_tot[par][wave] = incl;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          const uint32_t t = s_wave_tot[par][w];
-          tile_total += t;
-          if (w < wave) {
-            out_pos += t;
+        for (int d = 1; d < kWave; d <<= 1) {
+          const uint32_t n = __shfl_up(incl, d, kWave);
+          if (lane >= d) {
+            incl += n;
           }
         }
-        ++iter;
-      }
-      running += tile_total;
-      // ---- compact: the wave's passing rows, in output order, into its LDS strip ------------------------
-      // Lane j of the wave then handles the j-th passing row: every gather and store instruction has all its
-      // lanes busy and consecutive lanes write consecutive output rows (coalesced), instead of VR predicated
-      // load/store groups per lane in which a selective filter leaves 1 lane in 100 active.
-      const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
-      const uint32_t wave_base = out_pos - (incl - mine);  // first output row of this wave's rows
-      {
-        uint32_t j = incl - mine;
-        uint32_t left = bits;
-        while (left) {
-          const int b = __ffs(left) - 1;
-          left &= left - 1;
-          s_rows[wave][j++] = static_cast<uint16_t>(((b / VR) << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, b % VR)));
+        uint32_t out_pos = running + incl - mine;
+        uint32_t tile_total = 0;
+        {
+          const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one group ahead
+          if (lane == kWave - 1) {
+            s_wave_tot[par][0][wave] = incl;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int w = 0; w < kWaves; ++w) {
+            const uint32_t t = s_wave_tot[par][0][w];
+            tile_total += t;
+            if (w < wave) {
+              out_pos += t;
+            }
+          }
+          ++iter;
         }
+        running += tile_total;
+        // ---- compact: the wave's passing rows, in output order, into its LDS strip ----------------------------------
+        // Lane j of the wave then handles the j-th passing row: every gather and store instruction has all its
+        // lanes busy and consecutive lanes write consecutive output rows (coalesced), instead of VR predicated
+        // load/store groups per lane in which a selective filter leaves 1 lane in 100 active.
+        uint16_t* strip = reinterpret_cast<uint16_t*>(s_wave_lds[wave]);
+        const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+        const uint32_t wave_base = out_pos - (incl - mine);  // first output row of this wave's rows
+        {
+          uint32_t j = incl - mine;
+          uint32_t left = bits;
+          while (left) {
+            const int b = __ffs(left) - 1;
+            left &= left - 1;
+            strip[j++] = static_cast<uint16_t>(((b / VR) << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, b % VR)));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // row of a strip entry: the group's g-th tile is `g * gridDim.x` tiles further on
+        const int64_t group_stride_rows = static_cast<int64_t>(gridDim.x) * kTileRows;
+        auto row_of = [&](uint32_t e) { return row0 + static_cast<int64_t>(e >> 12) * group_stride_rows + (e & 4095u); };
+        // ---- project: row position, then each target column -----------------------------------------------------
+        const size_t rq = a.row_size_quad;
+        for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+          const uint32_t j = j0 + lane;
+          if (j < wave_total) {
+            const int64_t row = row_of(strip[j]);
+            const uint32_t pos = wave_base + j;
+            if (pos >= max_matched) {
+              slots_err = -1 - static_cast<int32_t>(row & 0x3fffffff);
+            } else {
+              buf[columnar ? static_cast<size_t>(pos) : static_cast<size_t>(pos) * rq] = row;
+            }
+          }
+        }
+        for (int ti = 0; ti < a.ntargets; ++ti) {
+          const ProjFastTarget t = a.t[ti];
+          const int8_t* tb = cols[t.col.buf_idx];
+          int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
+          const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
+          for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            const uint32_t pos = wave_base + j;
+            if (j < wave_total && pos < max_matched) {
+              const int64_t row = row_of(strip[j]);
+              const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
+              int8_t* dst = base + static_cast<size_t>(pos) * stride;
+              switch (t.slot_width) {
+                case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
+                case 2: *reinterpret_cast<int16_t*>(dst) = static_cast<int16_t>(v); break;
+                case 4: *reinterpret_cast<int32_t*>(dst) = static_cast<int32_t>(v); break;
+                default: *reinterpret_cast<int64_t*>(dst) = v; break;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
+      } else {
+        // ---- selection vector -> dense output positions inside the block's range (order: see pf_write_group) ------------
+        PfWavePos p;
+        pf_scan_tiles(bits, lane, p);
+        const int par = static_cast<int>(iter & 1);  // double buffer: a fast wave may already be one group ahead
+        if (lane < G) {
+          s_wave_tot[par][lane][wave] = lane == 0 ? p.wave_tot[0] : lane == 1 ? p.wave_tot[1] : lane == 2 ? p.wave_tot[2] : p.wave_tot[3];
+        }
+        __syncthreads();
+        ++iter;
+        uint64_t wave_base[G];
+        {
+          uint32_t at = running;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+              const uint32_t t = s_wave_tot[par][g][w];
+              total += t;
+              before += w < wave ? t : 0;
+            }
+            wave_base[g] = at + before;
+            at += total;
+          }
+          running = at;
+        }
+        // row 0 of the group's g-th tile: `g * gridDim.x` tiles further on in the same fragment
+        const int64_t group_stride_rows = static_cast<int64_t>(gridDim.x) * kTileRows;
+        int64_t trow0[G];
+        uint32_t full_mask = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          trow0[g] = row0 + g * group_stride_rows;
+          full_mask |= (g < group && trow0[g] + kTileRows <= nrows) ? 1u << g : 0u;
+        }
+        pf_write_group<R>(a, buf, s_wave_lds[wave], bits, p, wave_base, trow0, full_mask,
+                          [&](uint32_t, int ti) { return cols[a.t[ti].col.buf_idx]; }, max_matched, tid, lane, slots_err);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // row of a strip entry: the group's g-th tile is `g * gridDim.x` tiles further on
-      const int64_t group_stride_rows = static_cast<int64_t>(gridDim.x) * kTileRows;
-      auto row_of = [&](uint32_t e) { return row0 + static_cast<int64_t>(e >> 12) * group_stride_rows + (e & 4095u); };
-      // ---- project: row position, then each target column ---------------------------------------------
-      pf_project_rows(a, buf, s_rows[wave], wave_total, wave_base, max_matched, lane, row_of,
-                      [&](uint32_t, int ti) { return cols[a.t[ti].col.buf_idx]; }, slots_err);
-      __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
       tile += static_cast<int64_t>(group - 1) * gridDim.x;
     }
     frag_tile_begin += ntiles;
@@ -444,13 +732,13 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       counted += __shfl_down(counted, d, kWave);
     }
     if (lane == 0) {
-      s_wave_tot[0][wave] = counted;
+      s_wave_tot[0][0][wave] = counted;
     }
     __syncthreads();
     if (tid == 0) {
       uint32_t t = 0;
       for (int w = 0; w < kWaves; ++w) {
-        t += s_wave_tot[0][w];
+        t += s_wave_tot[0][0][w];
       }
       a.block_counts[blockIdx.x] = t;
     }
@@ -471,6 +759,16 @@ extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_co
 }
 extern "C" __global__ __launch_bounds__(kProjFastBlock) void hdk_scan_project_direct_pairs(ProjFastArgs a) {
   scan_project_direct_body<1, 2>(a);
+}
+// the writing pass for launches in which many rows pass (see scan_project_direct_body)
+#ifndef HDK_PROJ_DENSE_WAVES
+#define HDK_PROJ_DENSE_WAVES 0  // waves per SIMD the dense writing pass is held to (0: the compiler's choice)
+#endif
+extern "C" __global__ __launch_bounds__(kProjFastBlock, HDK_PROJ_DENSE_WAVES) void hdk_scan_project_dense(ProjFastArgs a) {
+  scan_project_direct_body<1, 1, true>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjFastBlock, HDK_PROJ_DENSE_WAVES) void hdk_scan_project_dense_pairs(ProjFastArgs a) {
+  scan_project_direct_body<1, 2, true>(a);
 }
 // ---- one pass: filter -> dense output positions by decoupled look-back over batches -> write ------------------
 // The two passes above read the filter columns twice (or write and read a bitmask) and need a grid-wide step between
@@ -518,8 +816,8 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
   constexpr int kWaves = kProjFastBlock / kWave;
   constexpr int64_t kTileRows = static_cast<int64_t>(kProjFastBlock) * VR;
   static_assert(kTileRows == 4096, "a strip entry is (tile of the batch) << 12 | row inside the tile");
-  __shared__ uint32_t s_wave_tot[2][kWaves];
-  __shared__ uint16_t s_rows[kWaves][kWave * kProjFastVR * G];
+  __shared__ uint32_t s_wave_tot[2][G][kWaves];
+  __shared__ int64_t s_wave_lds[kWaves][kWave * kProjFastVR];      // 4 KB per wave (pf_write_group)
   __shared__ uint32_t s_next;                                      // the block's next ticket
   __shared__ uint64_t s_base;                                      // first output row of the batch
   __shared__ int64_t s_g_row0[2][G];                               // batches that straddle fragments: row of each tile's
@@ -591,7 +889,7 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
     const bool same = t0 + G <= c_begin + c_tiles || static_cast<uint64_t>(c_begin + c_tiles) >= total_tiles;
     const int64_t row00 = (t0 - c_begin) * kTileRows;
     // ---- filter: verdict bits of this lane, bit g * VR + r = slot r of the batch's g-th tile passes --------------
-    uint32_t bits = 0;
+    uint32_t bits = 0, full_mask = 0;
     {
       uint64_t lf = cf;
       int64_t l_begin = c_begin, l_rows = c_rows, l_tiles = c_tiles;
@@ -608,6 +906,7 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
             l_cols = a.kp.col_buffers[lf];
           }
           const int64_t row0 = (tile - l_begin) * kTileRows;
+          full_mask |= row0 + kTileRows <= l_rows ? 1u << g : 0u;
           uint32_t m;
           if (R == 2 && row0 + kTileRows <= l_rows) {
             m = keep ? pf_filter_full_tile_pairs<false>(a, l_cols, row0, tid) : pf_filter_full_tile_pairs<true>(a, l_cols, row0, tid);
@@ -626,31 +925,29 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
         }
       }
     }
-    // ---- dense positions inside the batch ----------------------------------------------------------------------
-    const uint32_t mine = __builtin_popcount(bits);
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint32_t n = __shfl_up(incl, d, kWave);
-      if (lane >= d) {
-        incl += n;
-      }
-    }
-    if (lane == kWave - 1) {
-      s_wave_tot[par][wave] = incl;
+    // ---- dense positions inside the batch (order: see pf_write_group) ------------------------------------------------
+    PfWavePos p;
+    pf_scan_tiles(bits, lane, p);
+    if (lane < G) {
+      s_wave_tot[par][lane][wave] = lane == 0 ? p.wave_tot[0] : lane == 1 ? p.wave_tot[1] : lane == 2 ? p.wave_tot[2] : p.wave_tot[3];
     }
     if (tid == 0) {
       s_next = next_ticket;
     }
     __syncthreads();
-    uint32_t before = 0, batch_total = 0;
+    uint32_t before[G], tile_before[G], batch_total = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      const uint32_t t = s_wave_tot[par][w];
-      batch_total += t;
-      if (w < wave) {
-        before += t;
+    for (int g = 0; g < G; ++g) {
+      uint32_t bf = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t t = s_wave_tot[par][g][w];
+        total += t;
+        bf += w < wave ? t : 0;
       }
+      before[g] = bf;
+      tile_before[g] = batch_total;
+      batch_total += total;
     }
     const uint32_t nb = s_next;
     // ---- the batch's first output row: decoupled look-back, by wave 0 --------------------------------------------
@@ -674,26 +971,16 @@ HDK_DEV void scan_project_stream_body(const ProjFastArgs& a) {
     }
     __syncthreads();
     const uint64_t base64 = s_base;
-    // ---- compact: the wave's passing rows, in output order, into its LDS strip (see the writing pass above) --------
-    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
-    const uint64_t wave_base = base64 + before;  // first output row of this wave's rows
-    {
-      uint32_t j = incl - mine;
-      uint32_t left = bits;
-      while (left) {
-        const int bi = __ffs(left) - 1;
-        left &= left - 1;
-        s_rows[wave][j++] = static_cast<uint16_t>(((bi / VR) << 12) | static_cast<int>(pf_row<kProjFastBlock, R>(0, tid, bi % VR)));
-      }
+    uint64_t wave_base[G];
+    int64_t trow0[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      wave_base[g] = base64 + tile_before[g] + before[g];
+      trow0[g] = same ? row00 + g * kTileRows : s_g_row0[par][g];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    auto row_of = [&](uint32_t e) { return same ? row00 + e : s_g_row0[par][e >> 12] + (e & 4095u); };
-    // ---- project: row position, then each target column ---------------------------------------------------------
-    pf_project_rows(a, buf, s_rows[wave], wave_total, wave_base, max_matched, lane, row_of,
-                    [&](uint32_t e, int ti) { return same ? c_cols[a.t[ti].col.buf_idx] : s_g_tb[par][e >> 12][ti]; }, slots_err);
-    __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next batch
+    pf_write_group<R>(a, buf, s_wave_lds[wave], bits, p, wave_base, trow0, full_mask,
+                      [&](uint32_t g, int ti) { return same ? c_cols[a.t[ti].col.buf_idx] : s_g_tb[par][g][ti]; }, max_matched, tid,
+                      lane, slots_err);
     ++iter;
     b = nb;
   }
@@ -714,11 +1001,30 @@ extern "C" __global__ __launch_bounds__(kProjFastBlock, HDK_PROJ_STREAM_WAVES) v
 
 // per-block counts -> exclusive offsets (in place), starting at what TOTAL_MATCHED already holds (like the claiming
 // kernels of scan_project.h, which append with atomicAdd); the grand total is added to TOTAL_MATCHED
+// ... and picks the writing pass: `mode` = 2 (dense) when an eighth of the launch's rows or more pass, else 1 (`force`, if
+// not 0, decides instead: A/B measurements)
 extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint32_t* counts, uint32_t n, int32_t* total_matched,
-                                                                             const uint32_t* run_if) {
+                                                                             const uint32_t* run_if, KernParams kp, uint32_t* mode,
+                                                                             uint32_t force) {
   __shared__ uint32_t s_part[1024];
+  __shared__ unsigned long long s_rows_total;
   if (run_if && *run_if != 1) {
     return;
+  }
+  if (threadIdx.x == 0) {
+    s_rows_total = 0;
+  }
+  __syncthreads();
+  {
+    const uint64_t nfrag = *kp.num_fragments;
+    const uint32_t ntab = *kp.num_tables;
+    unsigned long long mine = 0;
+    for (uint64_t f = threadIdx.x; f < nfrag; f += 1024) {
+      mine += static_cast<unsigned long long>(kp.num_rows[f * ntab]);
+    }
+    if (mine) {
+      atomicAdd(&s_rows_total, mine);
+    }
   }
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (n + 1023) / 1024;
@@ -746,6 +1052,7 @@ extern "C" __global__ __launch_bounds__(1024) void hdk_scan_project_offsets(uint
   }
   if (tid == 1023) {
     atomicAdd(total_matched, static_cast<int32_t>(s_part[1023]));
+    *mode = force ? force : (static_cast<unsigned long long>(s_part[1023]) * 8ull >= s_rows_total ? 2u : 1u);
   }
 }
 

@@ -111,12 +111,14 @@ def test_direct_filter_project_kernel(oracle, gpu_executor_factory, columnar):
     assert len(got["a"]) == 5000 and all(x < 500 for x in got["a"])
 
 
-def test_one_pass_two_pass_and_their_fallbacks(oracle, gpu_executor_factory):
-    """A launch that states its row count takes the one-pass kernel (decoupled look-back over batches of tiles); if the
-    input turns out to have more tiles than status words, the kernel hands the launch to the two passes armed behind it.
-    Without a row count the two passes run alone: with a selection bitmask from the counting pass (HDK_HIP_PROJECT_TWO_PASS
-    forces them for a stated count), without it (total_rows = 0: the filter is evaluated twice), with a mask that is too
-    short (tiles past its end re-evaluate) -- 5 M rows = 1221 tiles against the 1024 tiles of slack.  Same rows always."""
+def test_two_pass_forms_one_pass_and_their_fallbacks(oracle, gpu_executor_factory):
+    """The two passes: the counting pass hands a selection bitmask to the writing pass when the launch states its row
+    count; without one (total_rows = 0) the filter is evaluated twice; a mask that is too short (5 M rows = 1221 tiles
+    against the 1024 tiles of slack) is re-evaluated past its end.  The writing pass is picked on the device from the
+    share of rows that pass (sparse: row list + gathers; dense: coalesced column reads + value compaction through LDS);
+    HDK_HIP_PROJECT_WRITER forces either.  HDK_HIP_PROJECT_ONE_PASS takes the one-pass kernel (decoupled look-back over
+    batches of tiles), which hands the launch to the two passes armed behind it when the input has more tiles than status
+    words.  Same rows always, at 3.7 % and at 60 % selectivity."""
     import os
     rng = np.random.default_rng(33)
     n = 5_000_000
@@ -124,24 +126,28 @@ def test_one_pass_two_pass_and_their_fallbacks(oracle, gpu_executor_factory):
     b = rng.integers(-500, 500, n).astype(np.int32)
     st = ArrowStorage()
     st.import_numpy("t", {"a": a, "b": b}, fragment_size=1_300_007)
-    q = QueryUnit("t", quals=[Cmp(ColRef("a"), "<", Lit(37))], output_columnar=True,
-                  targets=[Proj(ColRef("a"), "a"), Proj(ColRef("b"), "b")])
-    cp, want, err, nrows = run_projection_oracle(oracle, st, q)
-    assert err == 0 and nrows == int((a < 37).sum())
     ex = gpu_executor_factory(st)
-    for total_rows, env in ((n, {}), (0, {}), (1, {}), (1, {"HDK_HIP_PROJECT_STATUS_SLACK": "0"}),
-                            (n, {"HDK_HIP_PROJECT_STATUS_SLACK": "0"}), (n, {"HDK_HIP_PROJECT_TWO_PASS": "1"}),
-                            (1, {"HDK_HIP_PROJECT_TWO_PASS": "1"})):
-        os.environ.update(env)
-        try:
-            step = ex.prepare(cp)
-            assert step.kernel_names().endswith("hdk_scan_project_direct")
-            assert step.kernel_names().startswith("hdk_scan_project_stream") == ("HDK_HIP_PROJECT_TWO_PASS" not in env)
-            step.ko.total_rows = total_rows
-            res = step.run()
-            step.free()
-        finally:
-            for k in env:
-                del os.environ[k]
-        assert res.total_matched == nrows, (total_rows, env)
-        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), (total_rows, env)
+    for bound in (37, 600):
+        q = QueryUnit("t", quals=[Cmp(ColRef("a"), "<", Lit(bound))], output_columnar=True,
+                      targets=[Proj(ColRef("a"), "a"), Proj(ColRef("b"), "b")])
+        cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+        assert err == 0 and nrows == int((a < bound).sum())
+        want_rows = _sorted_rows(cp, want, nrows)
+        one = {"HDK_HIP_PROJECT_ONE_PASS": "1"}
+        for total_rows, env in ((n, {}), (0, {}), (1, {}), (n, {"HDK_HIP_PROJECT_WRITER": "sparse"}),
+                                (n, {"HDK_HIP_PROJECT_WRITER": "dense"}), (0, {"HDK_HIP_PROJECT_WRITER": "dense"}),
+                                (n, one), (1, one), (1, dict(one, HDK_HIP_PROJECT_STATUS_SLACK="0")),
+                                (n, dict(one, HDK_HIP_PROJECT_STATUS_SLACK="0"))):
+            os.environ.update(env)
+            try:
+                step = ex.prepare(cp)
+                assert step.kernel_names().endswith("hdk_scan_project_direct")
+                assert step.kernel_names().startswith("hdk_scan_project_stream") == ("HDK_HIP_PROJECT_ONE_PASS" in env)
+                step.ko.total_rows = total_rows
+                res = step.run()
+                step.free()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            assert res.total_matched == nrows, (bound, total_rows, env)
+            assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), want_rows), (bound, total_rows, env)
