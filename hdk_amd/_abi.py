@@ -40,6 +40,7 @@ ERR_OUT_OF_SLOTS = 3
 ERR_OVERFLOW_OR_UNDERFLOW = 7
 ERR_OUT_OF_TIME = 9
 ERR_INTERRUPTED = 10
+ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES = 15
 ERR_UNSUPPORTED = 100
 ERR_INVALID_ARG = 101
 ERR_RUNTIME = 102
@@ -56,7 +57,7 @@ JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY, JOIN_ONE_TO_ONE_FUSED, JOIN_KEYED_ONE_TO_ONE,
 JOIN_INNER, JOIN_LEFT = 0, 1
 JOIN_NULL_NONE, JOIN_NULL_NULLABLE, JOIN_NULL_BITWISE = 0, 1, 2
 Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH, Q_PROJECTION = 0, 1, 2, 3
-AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX, AGG_AVG, AGG_ID = 0, 1, 2, 3, 4, 5
+AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX, AGG_AVG, AGG_ID, AGG_SINGLE_VALUE = 0, 1, 2, 3, 4, 5, 6
 JC_SMALL_DATE, JC_SIGNED, JC_UNSIGNED, JC_DOUBLE = 0, 1, 2, 3
 (KP_COL_BUFFERS, KP_NUM_FRAGMENTS, KP_LITERALS, KP_NUM_ROWS, KP_FRAG_ROW_OFFSETS, KP_MAX_MATCHED,
  KP_TOTAL_MATCHED, KP_INIT_AGG_VALS, KP_GROUPBY_BUF, KP_ERROR_CODE, KP_NUM_TABLES,

@@ -68,6 +68,27 @@ struct SlotInit {
   int64_t v[kMaxSlots];
 };
 
+// reduceOneSlotSingleValue (QE/ResultSetReduction.cpp:1186-1230): by slot width, against the slot's init value; true =
+// two different values ("Multiple distinct values encountered")
+HDK_DEV bool reduce_single_value(const hdk_hip_target& tg, int8_t* this1, const int8_t* that1, int64_t init_val) {
+  if (tg.slot_width == 4) {
+    const int32_t l = *reinterpret_cast<const int32_t*>(this1), r = *reinterpret_cast<const int32_t*>(that1);
+    if (r == static_cast<int32_t>(init_val)) return false;
+    if (l == static_cast<int32_t>(init_val)) {
+      *reinterpret_cast<int32_t*>(this1) = r;
+      return false;
+    }
+    return l != r;
+  }
+  const int64_t l = *reinterpret_cast<const int64_t*>(this1), r = *reinterpret_cast<const int64_t*>(that1);
+  if (r == init_val) return false;
+  if (l == init_val) {
+    *reinterpret_cast<int64_t*>(this1) = r;
+    return false;
+  }
+  return l != r;
+}
+
 // reduceOneSlot with AGGREGATE_ONE_[NULLABLE_]VALUE / AGGREGATE_ONE_COUNT
 // (QE/ResultSetReduction.cpp:1026-1107,1234-1385)
 HDK_DEV void reduce_slot(const hdk_hip_target& tg, int8_t* this1, int8_t* this2, const int8_t* that1,
@@ -260,7 +281,8 @@ struct ThatList {
 
 // perfect hash / non-grouped: one thread per entry, partials in argument order
 __global__ __launch_bounds__(kRedBlock) void k_reduce_entrywise(const hdk_hip_plan* __restrict__ p, int64_t* this_buf,
-                                                                uint32_t entry_count, ThatList that, SlotInit init) {
+                                                                uint32_t entry_count, ThatList that, SlotInit init,
+                                                                int32_t* dev_error) {
   const uint32_t e = blockIdx.x * kRedBlock + threadIdx.x;
   if (e >= entry_count) {
     return;
@@ -292,7 +314,13 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_entrywise(const hdk_hip_pl
       int8_t *a1, *a2, *b1, *b2;
       slot_ptrs(p, this_buf, entry_count, e, t, s, &a1, &a2);
       slot_ptrs(p, const_cast<int64_t*>(tb), entry_count, e, t, s, &b1, &b2);
-      reduce_slot(p->targets[t], a1, a2, b1, b2, slot_init(init, s));
+      if (p->targets[t].agg == HDK_AGG_SINGLE_VALUE) {
+        if (reduce_single_value(p->targets[t], a1, b1, slot_init(init, s))) {
+          record_error(dev_error, HDK_HIP_ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES);
+        }
+      } else {
+        reduce_slot(p->targets[t], a1, a2, b1, b2, slot_init(init, s));
+      }
       s += p->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
     }
   }
@@ -348,6 +376,10 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_baseline(const hdk_hip_pla
           } else {
             *reinterpret_cast<int64_t*>(a2) = *reinterpret_cast<const int64_t*>(b2);
           }
+        }
+      } else if (tg.agg == HDK_AGG_SINGLE_VALUE) {
+        if (reduce_single_value(tg, a1, b1, slot_init(init, s))) {
+          record_error(dev_error, HDK_HIP_ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES);
         }
       } else {
         reduce_slot(tg, a1, a2, b1, b2, slot_init(init, s));
@@ -606,6 +638,9 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
         return HDK_HIP_ERR_INVALID_ARG;
       }
     }
+    for (int t = 0; t < plan->num_targets; ++t) {
+      HDK_REQUIRE(plan->targets[t].agg != HDK_AGG_SINGLE_VALUE || dev_error, "a SINGLE_VALUE target needs dev_error");
+    }
     for (int base = 0; base < num_that; base += kMaxThat) {
       ThatList tl;
       tl.n = num_that - base < kMaxThat ? num_that - base : kMaxThat;
@@ -613,7 +648,7 @@ extern "C" int32_t hdk_hip_reduce_buffers(const hdk_hip_plan* plan, int64_t* thi
         tl.buf[i] = i < tl.n ? that_bufs[base + i] : nullptr;
       }
       hipLaunchKernelGGL(k_reduce_entrywise, dim3((n + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, d_plan,
-                         this_buf, n, tl, init);
+                         this_buf, n, tl, init, dev_error);
     }
   } else {
     HDK_REQUIRE(dev_error, "dev_error is NULL");

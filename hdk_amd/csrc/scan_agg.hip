@@ -602,7 +602,11 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
   const int64_t row_bytes = static_cast<int64_t>(p->row_size_quad) * 8;
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
-    HDK_REQUIRE(tg.agg >= HDK_AGG_COUNT && tg.agg <= HDK_AGG_ID, "target %d: bad aggregate kind %d", t, tg.agg);
+    HDK_REQUIRE(tg.agg >= HDK_AGG_COUNT && tg.agg <= HDK_AGG_SINGLE_VALUE, "target %d: bad aggregate kind %d", t, tg.agg);
+    if (tg.agg == HDK_AGG_SINGLE_VALUE) {
+      HDK_REQUIRE(p->query_kind != HDK_Q_PROJECTION && tg.has_arg, "target %d: SINGLE_VALUE is an aggregate over an argument", t);
+      HDK_REQUIRE(tg.slot_width == 4 || tg.slot_width == 8, "target %d: SINGLE_VALUE slots are 4 or 8 bytes wide", t);
+    }
     HDK_REQUIRE(tg.has_arg == 0 || tg.has_arg == 1, "target %d: has_arg must be 0 or 1", t);
     HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
     HDK_REQUIRE(!exprs || tg.has_arg || tg.agg == HDK_AGG_COUNT || (tg.agg == HDK_AGG_ID && p->query_kind != HDK_Q_NON_GROUPED),
@@ -640,8 +644,9 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
     }
     HDK_REQUIRE(tg.arg_is_fp >= HDK_FP_SLOT_NONE && tg.arg_is_fp <= HDK_FP_SLOT_FLOAT, "target %d: arg_is_fp out of range", t);
     if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
-      HDK_REQUIRE(tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX || tg.agg == HDK_AGG_AVG,
-                  "target %d: a float accumulator belongs to SUM / MIN / MAX / AVG", t);
+      HDK_REQUIRE(tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX || tg.agg == HDK_AGG_AVG ||
+                      tg.agg == HDK_AGG_SINGLE_VALUE,
+                  "target %d: a float accumulator belongs to SUM / MIN / MAX / AVG / SINGLE_VALUE", t);
       HDK_REQUIRE(!exprs || (tg.has_arg && tg.arg.vclass == HDK_VC_FP), "target %d: a float accumulator needs a floating-point argument", t);
     } else if (tg.slot_width == 4 && tg.arg_is_fp && tg.agg != HDK_AGG_COUNT) {
       set_error("a 4-byte slot cannot hold a double: float arguments use arg_is_fp = HDK_FP_SLOT_FLOAT");
@@ -699,7 +704,11 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
   s.entry_count = p->query_kind == HDK_Q_NON_GROUPED ? 1u : p->entry_count;
   s.grid = (ko && ko->grid_dim_x) ? ko->grid_dim_x : static_cast<uint32_t>(props->grid_size);
   s.block = kBlock;
-  const bool force_global = ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS);
+  bool force_global = ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS);
+  for (int t = 0; t < p->num_targets; ++t) {
+    // SINGLE_VALUE lives on the final table only (checked_single_agg_id_shared): no per-block images to fold
+    force_global = force_global || p->targets[t].agg == HDK_AGG_SINGLE_VALUE;
+  }
   const uint64_t words = static_cast<uint64_t>(s.entry_count) * s.wpe;
   if (p->query_kind == HDK_Q_PROJECTION) {
     s.strategy = STRAT_PROJECT;

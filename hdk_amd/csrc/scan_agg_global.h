@@ -104,6 +104,51 @@ HDK_DEV void g_agg32(int agg, bool skip, int32_t nullv, int32_t* slot, int32_t v
   }
 }
 
+// checked_single_agg_id[_int32|_double|_float]_shared (QE/cuda_mapd_rt.cu:670-782): the slot moves from the NULL pattern
+// to the first value once; true = a different value is already there (ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES)
+HDK_DEV bool g_single64(int64_t* slot, int64_t vbits, int64_t nullbits) {
+  unsigned long long* us = reinterpret_cast<unsigned long long*>(slot);
+  unsigned long long old = static_cast<unsigned long long>(atomic_load_i64(slot));
+  for (;;) {
+    if (static_cast<int64_t>(old) != nullbits) {
+      return static_cast<int64_t>(old) != vbits;
+    }
+    const unsigned long long assumed = old;
+    old = atomicCAS(us, assumed, static_cast<unsigned long long>(vbits));
+    if (old == assumed) {
+      return false;
+    }
+  }
+}
+HDK_DEV bool g_single32(int32_t* slot, int32_t vbits, int32_t nullbits) {
+  int32_t old = atomic_load_i32(slot);
+  for (;;) {
+    if (old != nullbits) {
+      return old != vbits;
+    }
+    const int32_t assumed = old;
+    old = atomicCAS(slot, assumed, vbits);
+    if (old == assumed) {
+      return false;
+    }
+  }
+}
+// the NULL test is by value (`val == null_val`), the slot compare by bit pattern
+HDK_DEV bool g_single_value(const hdk_hip_target& tg, int8_t* slot, int64_t v) {
+  if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {
+    const float f = static_cast<float>(bits_to_double(v)), fn = static_cast<float>(bits_to_double(tg.null_val));
+    return f == fn ? false : g_single32(reinterpret_cast<int32_t*>(slot), __float_as_int(f), __float_as_int(fn));
+  }
+  if (tg.arg_is_fp) {
+    return bits_to_double(v) == bits_to_double(tg.null_val) ? false : g_single64(reinterpret_cast<int64_t*>(slot), v, tg.null_val);
+  }
+  if (v == tg.null_val) {
+    return false;
+  }
+  return tg.slot_width == 4 ? g_single32(reinterpret_cast<int32_t*>(slot), static_cast<int32_t>(v), static_cast<int32_t>(tg.null_val))
+                            : g_single64(reinterpret_cast<int64_t*>(slot), v, tg.null_val);
+}
+
 HDK_DEV void g_count(int8_t* slot, int width) {
   if (width == 4) {
     atomicAdd(reinterpret_cast<unsigned int*>(slot), 1u);
@@ -233,6 +278,12 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
               g_store_i32(reinterpret_cast<int32_t*>(s1), static_cast<int32_t>(v));
             } else {
               g_store_i64(reinterpret_cast<int64_t*>(s1), v);
+            }
+            continue;
+          }
+          if (tg.agg == HDK_AGG_SINGLE_VALUE) {
+            if (g_single_value(tg, s1, v)) {
+              err = HDK_HIP_ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES;
             }
             continue;
           }

@@ -64,6 +64,7 @@ static bool match_baseline_fast(const hdk_hip_plan* p, BaseFastArgs* fa) {
       continue;
     }
     if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;  // float accumulators: generic kernel
+    if (tg.agg == HDK_AGG_SINGLE_VALUE) return false;      // checked_single_agg_id: generic kernel (scan_agg_global.h)
     BaseFastTarget ft;
     ft.target = t;
     ft.buf_idx = -1;

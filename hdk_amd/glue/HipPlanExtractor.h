@@ -415,7 +415,8 @@ class PlanExtractor {
       case hdk::ir::AggType::kMin: d.agg = HDK_AGG_MIN; break;
       case hdk::ir::AggType::kMax: d.agg = HDK_AGG_MAX; break;
       case hdk::ir::AggType::kAvg: d.agg = HDK_AGG_AVG; break;
-      default: throw QueryMustRunOnCpu("aggregate outside COUNT / SUM / MIN / MAX / AVG");
+      case hdk::ir::AggType::kSingleValue: d.agg = HDK_AGG_SINGLE_VALUE; break;
+      default: throw QueryMustRunOnCpu("aggregate outside COUNT / SUM / MIN / MAX / AVG / SINGLE_VALUE");
     }
     const Expr* arg = IR::agg_arg(e);
     d.has_arg = arg != nullptr;
@@ -437,6 +438,12 @@ class PlanExtractor {
       d.null_val = INT64_MIN;  // (a 4-byte padded slot narrows it: make_plan knows the slot width)
     }
     if (d.agg == HDK_AGG_COUNT) d.arg_is_fp = at.is_fp() ? HDK_FP_SLOT_DOUBLE : HDK_FP_SLOT_NONE, d.null_val = d.arg.null_val;
+    if (d.agg == HDK_AGG_SINGLE_VALUE) {
+      // checked_single_agg_id: never a *_skip_val call, always handed the ARGUMENT type's NULL
+      // (QE/TargetExprBuilder.cpp:429-445,542-546)
+      d.skip_null = false;
+      d.null_val = at.is_fp() && at.size == 8 ? HDK_NULL_DOUBLE_BITS : inline_null(at);
+    }
     return d;
   }
 

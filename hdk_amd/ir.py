@@ -159,7 +159,7 @@ Cond = Union[Cmp, And, Or, Not]
 
 @dataclass(frozen=True)
 class Agg:
-    """Aggregate target: kind in count/sum/min/max/avg; arg None = COUNT(*)."""
+    """Aggregate target: kind in count/sum/min/max/avg/single_value; arg None = COUNT(*)."""
     kind: str
     arg: Optional[Expr] = None
     name: Optional[str] = None

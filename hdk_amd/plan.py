@@ -322,7 +322,8 @@ class CompiledPlan:
 
 _CMP = {"=": A.CMP_EQ, "==": A.CMP_EQ, "<>": A.CMP_NE, "!=": A.CMP_NE, "<": A.CMP_LT, ">": A.CMP_GT,
         "<=": A.CMP_LE, ">=": A.CMP_GE}
-_AGG = {"count": A.AGG_COUNT, "sum": A.AGG_SUM, "min": A.AGG_MIN, "max": A.AGG_MAX, "avg": A.AGG_AVG}
+_AGG = {"count": A.AGG_COUNT, "sum": A.AGG_SUM, "min": A.AGG_MIN, "max": A.AGG_MAX, "avg": A.AGG_AVG,
+        "single_value": A.AGG_SINGLE_VALUE}
 
 
 def _bits_to_double(v: int) -> float:
@@ -805,12 +806,19 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                 raise ValueError(f"{t.kind} needs an argument")
             # takes_float_argument (Shared/TargetInfo.h:170-179): SUM / MIN / MAX / AVG over a FLOAT argument
             # accumulate a float in the slot's low 4 bytes, whatever the padded slot width
-            float_acc = at is not None and at.is_fp and at.size == 4 and t.kind != "count"
+            float_acc = at is not None and at.is_fp and at.size == 4 and t.kind != "count"  # (SINGLE_VALUE included: :176)
             arg_nullable = at.nullable if at is not None else False
             # group-by: the declared nullability decides; non-grouped: always nullable and always
             # *_skip_val (OutputBufferInitialization.cpp:57-60, TargetExprBuilder.cpp:546-551)
             eff_nullable = True if kind == A.Q_NON_GROUPED else arg_nullable
             tg.skip_null = 1 if (t.arg is not None and eff_nullable) else 0
+            # SINGLE_VALUE: checked_single_agg_id takes the argument type's NULL whatever the nullability and is never a
+            # *_skip_val call (QE/TargetExprBuilder.cpp:429-445,542-546); its slot starts like MAX's
+            # (get_agg_initial_val, QE/OutputBufferInitialization.cpp:211-213)
+            single = t.kind == "single_value"
+            init_kind = "max" if single else ("sum" if t.kind == "avg" else t.kind)
+            if single:
+                tg.skip_null = 0
             tg.arg_is_fp = A.FP_SLOT_FLOAT if float_acc else (A.FP_SLOT_DOUBLE if (at is not None and at.is_fp) else 0)
             if t.kind == "count":
                 # agg_count[_skip_val]: skip value = the argument type's NULL (widened)
@@ -818,7 +826,7 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                 init_vals.append(0)
                 slot_widths.append(W)
             else:
-                if t.kind in ("min", "max"):
+                if t.kind in ("min", "max", "single_value"):
                     # domain-range-equivalent aggregates keep the ARGUMENT type's NULL
                     # (get_agg_initial_val on the arg type: inline_int_null_value(type) in an 8-byte slot)
                     nullv = at.null_as_int64_or_double_bits()
@@ -830,11 +838,11 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                     # the scan compares doubles (the decoder widens): null_val = the float sentinel widened; the
                     # slot starts at the 4-byte pattern, sign-extended (OutputBufferInitialization.cpp:52-65)
                     tg.null_val = A.to_i64(at.null_as_int64_or_double_bits())
-                    iv = _agg_init_val("sum" if t.kind == "avg" else t.kind, at, eff_nullable, 4)
+                    iv = _agg_init_val(init_kind, at, eff_nullable, 4)
                 elif eff_nullable:
                     iv = nullv
                 else:
-                    iv = _agg_init_val("sum" if t.kind == "avg" else t.kind, at, False, 8)
+                    iv = _agg_init_val(init_kind, at, False, 8)
                 init_vals.append(A.to_i64(iv))
                 slot_widths.append(W)
                 if t.kind == "avg":

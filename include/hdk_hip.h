@@ -292,9 +292,16 @@ enum hdk_hip_query_kind {
 
 enum hdk_hip_agg {
   HDK_AGG_COUNT = 0, HDK_AGG_SUM = 1, HDK_AGG_MIN = 2, HDK_AGG_MAX = 3, HDK_AGG_AVG = 4,
-  HDK_AGG_ID = 5 /* non-aggregate target, written with agg_id (QE/RuntimeFunctions.cpp:473-476).
+  HDK_AGG_ID = 5, /* non-aggregate target, written with agg_id (QE/RuntimeFunctions.cpp:473-476).
                     Group-by plans: a projected group-by key, `key_idx` names it and `arg` repeats its
                     expression.  Projection plans: any expression `arg`, key_idx = -1. */
+  HDK_AGG_SINGLE_VALUE = 6 /* SINGLE_VALUE(x) (hdk::ir::AggType::kSingleValue): the slot starts at the argument's NULL,
+                    the first non-NULL value is stored, a DIFFERENT non-NULL value ends the launch with
+                    HDK_HIP_ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES (checked_single_agg_id[_int32|_double|_float],
+                    QE/RuntimeFunctions.cpp:489-506,567-583,743-760; *_shared, QE/cuda_mapd_rt.cu:670-782; partial
+                    results: reduceOneSlotSingleValue, QE/ResultSetReduction.cpp:1186-1230).  `skip_null` = 1 and
+                    `null_val` = the slot's initial value; 4- or 8-byte slots.  Plans with such a target run on the
+                    global-atomics kernel (hdk_scan_agg_global). */
 };
 enum hdk_hip_fp_slot { HDK_FP_SLOT_NONE = 0, HDK_FP_SLOT_DOUBLE = 1, HDK_FP_SLOT_FLOAT = 2 };
 typedef struct hdk_hip_target {
@@ -551,6 +558,8 @@ int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf,
  * tables (hdk_hip_launch + hdk_hip_partition_baseline + hdk_hip_reduce_buffers), which has no such limit.
  * Plans outside the radix-partitioned shape (hdk_scan_agg_baseline_direct's: row-wise, 1-2 plain integer key columns,
  * plain-column arguments, `column cmp literal` filters) get HDK_HIP_ERR_UNSUPPORTED from shape_for.
+ * `stream` of the two calls must be the stream the all-to-all runs on, or be ordered with it by the caller: NULL means the
+ * manager's own stream, which is ordered neither with the legacy default stream nor with a communicator's.
  * ---------------------------------------------------------------------------------------- */
 typedef struct hdk_hip_exchange_shape {
   uint32_t num_owners;         /* G */

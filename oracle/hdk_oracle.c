@@ -1489,8 +1489,68 @@ static void small_min_max(int agg, int skip, int w, int8_t* slot, int64_t val, i
   }
 }
 
+/* checked_single_agg_id and its typed forms: QE/RuntimeFunctions.cpp:489-506 (int64), :567-583 (DEF_CHECKED_SINGLE_AGG_ID_INT,
+ * here n = 32), :743-760 (double: NULL test by value, slot compare by bit pattern), :799-816 (float).  0, or 15 =
+ * Executor::ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES. */
+int32_t orc_checked_single_agg_id(int64_t* agg, int64_t val, int64_t null_val) {
+  if (val == null_val) return 0;
+  if (*agg == val) return 0;
+  if (*agg == null_val) {
+    *agg = val;
+    return 0;
+  }
+  return 15;
+}
+int32_t orc_checked_single_agg_id_int32(int32_t* agg, int32_t val, int32_t null_val) {
+  if (val == null_val) return 0;
+  if (*agg == val) return 0;
+  if (*agg == null_val) {
+    *agg = val;
+    return 0;
+  }
+  return 15;
+}
+int32_t orc_checked_single_agg_id_double(int64_t* agg, double val, double null_val) {
+  if (val == null_val) return 0;
+  int64_t vbits, nbits;
+  memcpy(&vbits, &val, 8);
+  memcpy(&nbits, &null_val, 8);
+  if (*agg == vbits) return 0;
+  if (*agg == nbits) {
+    *agg = vbits;
+    return 0;
+  }
+  return 15;
+}
+int32_t orc_checked_single_agg_id_float(int32_t* agg, float val, float null_val) {
+  if (val == null_val) return 0;
+  int32_t vbits, nbits;
+  memcpy(&vbits, &val, 4);
+  memcpy(&nbits, &null_val, 4);
+  if (*agg == vbits) return 0;
+  if (*agg == nbits) {
+    *agg = vbits;
+    return 0;
+  }
+  return 15;
+}
+
 /* Apply one target's aggregate(s) to its slot(s): the call the JIT emits per target
  * (QE/TargetExprBuilder.cpp:341-460: name = agg_<kind>[_int32|_double|_float][_skip_val]). */
+static int32_t apply_target_single_value(const hdk_hip_target* tg, int8_t* slot1, int64_t val) {
+  const int64_t nullv = tg->null_val;
+  if (tg->arg_is_fp == HDK_FP_SLOT_FLOAT) {
+    return orc_checked_single_agg_id_float((int32_t*)slot1, (float)bits_to_double(val), (float)bits_to_double(nullv));
+  }
+  if (tg->arg_is_fp) {
+    return orc_checked_single_agg_id_double((int64_t*)slot1, bits_to_double(val), bits_to_double(nullv));
+  }
+  if (tg->slot_width == 4) {
+    return orc_checked_single_agg_id_int32((int32_t*)slot1, (int32_t)val, (int32_t)nullv);
+  }
+  return orc_checked_single_agg_id((int64_t*)slot1, val, nullv);
+}
+
 static void apply_target(const hdk_hip_target* tg, int8_t* slot1, int8_t* slot2, int64_t val) {
   const int skip = tg->skip_null;
   const int64_t nullv = tg->null_val;
@@ -1860,6 +1920,11 @@ static int32_t aggregate_row(orc_row_ctx* c, void* arg, int32_t* errp) {
       s1 = row_base + tg->slot_off;
       s2 = row_base + tg->slot2_off;
     }
+    if (tg->agg == HDK_AGG_SINGLE_VALUE) { /* the row function returns the call's code (QE/RowFuncBuilder.cpp) */
+      const int32_t e = apply_target_single_value(tg, s1, v);
+      if (e && !err) err = e;
+      continue;
+    }
     apply_target(tg, s1, s2, v);
   }
   if (err && !*errp) {
@@ -2023,6 +2088,27 @@ int32_t orc_is_empty_entry(const hdk_hip_plan* p, const int64_t* buf, uint32_t e
 
 /* reduceOneSlot: QE/ResultSetReduction.cpp:1234-1330 with AGGREGATE_ONE_* :1026-1107.
  * `init_val` is the slot's init value == skip value for nullable targets. */
+/* reduceOneSlotSingleValue (QE/ResultSetReduction.cpp:1186-1230): by slot width, against the slot's init value; the
+ * reference throws "Multiple distinct values encountered", here the code the device path reports */
+static int32_t reduce_single_value(const hdk_hip_target* tg, int8_t* this1, const int8_t* that1, int64_t init_val) {
+  if (tg->slot_width == 4) {
+    const int32_t l = *(const int32_t*)this1, r = *(const int32_t*)that1;
+    if (r == (int32_t)init_val) return 0;
+    if (l == (int32_t)init_val) {
+      *(int32_t*)this1 = r;
+      return 0;
+    }
+    return l != r ? 15 : 0;
+  }
+  const int64_t l = *(const int64_t*)this1, r = *(const int64_t*)that1;
+  if (r == init_val) return 0;
+  if (l == init_val) {
+    *(int64_t*)this1 = r;
+    return 0;
+  }
+  return l != r ? 15 : 0;
+}
+
 static void reduce_one_target(const hdk_hip_target* tg, int8_t* this1, int8_t* this2,
                               const int8_t* that1, const int8_t* that2, int64_t init_val) {
   if (tg->agg == HDK_AGG_ID) { /* non-agg projection: ResultSetReduction.cpp:1329-1385 */
@@ -2155,6 +2241,7 @@ static void slot_ptrs(const hdk_hip_plan* p, const int64_t* buf, uint32_t entry_
 
 int32_t orc_reduce(const hdk_hip_plan* p, int64_t* this_buf, uint32_t this_entry_count,
                    const int64_t* that_buf, uint32_t that_entry_count, const int64_t* init_vals) {
+  int32_t err = 0; /* SINGLE_VALUE conflicts: every entry is still reduced, the code is returned at the end */
   if (p->query_kind == HDK_Q_NON_GROUPED || p->query_kind == HDK_Q_PERFECT_HASH) {
     /* reduceOneEntryNoCollisions / reduceEntriesNoCollisionsColWise (:262-330, :353-449) */
     const uint32_t n = p->query_kind == HDK_Q_NON_GROUPED ? 1 : this_entry_count;
@@ -2178,11 +2265,16 @@ int32_t orc_reduce(const hdk_hip_plan* p, int64_t* this_buf, uint32_t this_entry
         int8_t *a1, *a2, *b1, *b2;
         slot_ptrs(p, this_buf, this_entry_count, e, t, &a1, &a2);
         slot_ptrs(p, that_buf, that_entry_count, e, t, &b1, &b2);
-        reduce_one_target(&p->targets[t], a1, a2, b1, b2, init_vals[iv]);
+        if (p->targets[t].agg == HDK_AGG_SINGLE_VALUE) {
+          const int32_t e1 = reduce_single_value(&p->targets[t], a1, b1, init_vals[iv]);
+          if (e1 && !err) err = e1;
+        } else {
+          reduce_one_target(&p->targets[t], a1, a2, b1, b2, init_vals[iv]);
+        }
         iv += p->targets[t].agg == HDK_AGG_AVG ? 2 : 1;
       }
     }
-    return 0;
+    return err;
   }
   /* baseline: re-insert every non-empty entry of `that` (reduceOneEntryBaseline :694-731) */
   for (uint32_t e = 0; e < that_entry_count; ++e) {
@@ -2263,13 +2355,16 @@ int32_t orc_reduce(const hdk_hip_plan* p, int64_t* this_buf, uint32_t this_entry
         if (tg->agg == HDK_AGG_AVG) {
           memcpy(a2, b2, (size_t)tg->slot2_width);
         }
+      } else if (tg->agg == HDK_AGG_SINGLE_VALUE) {
+        const int32_t e1 = reduce_single_value(tg, a1, b1, init_vals[iv]);
+        if (e1 && !err) err = e1;
       } else {
         reduce_one_target(tg, a1, a2, b1, b2, init_vals[iv]);
       }
       iv += tg->agg == HDK_AGG_AVG ? 2 : 1;
     }
   }
-  return 0;
+  return err;
 }
 
 /* ============================================================================================

@@ -83,6 +83,11 @@ uint64_t orc_agg_count_skip_val(uint64_t* agg, int64_t val, int64_t skip_val);
 uint32_t orc_agg_count_int32_skip_val(uint32_t* agg, int32_t val, int32_t skip_val);
 void orc_agg_max_skip_val(int64_t* agg, int64_t val, int64_t skip_val);
 void orc_agg_min_skip_val(int64_t* agg, int64_t val, int64_t skip_val);
+/* checked_single_agg_id[_int32|_double|_float] (QE/RuntimeFunctions.cpp:489-506,567-583,743-760,799-816): 0 or 15 */
+int32_t orc_checked_single_agg_id(int64_t* agg, int64_t val, int64_t null_val);
+int32_t orc_checked_single_agg_id_int32(int32_t* agg, int32_t val, int32_t null_val);
+int32_t orc_checked_single_agg_id_double(int64_t* agg, double val, double null_val);
+int32_t orc_checked_single_agg_id_float(int32_t* agg, float val, float null_val);
 void orc_agg_max_int32_skip_val(int32_t* agg, int32_t val, int32_t skip_val);
 void orc_agg_min_int32_skip_val(int32_t* agg, int32_t val, int32_t skip_val);
 uint64_t orc_agg_count_double(uint64_t* agg, double val);

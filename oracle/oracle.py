@@ -77,6 +77,10 @@ def lib():
         _sig(L, f"orc_agg_{n}_double_skip_val", None, v, C.c_double, C.c_double)
     _sig(L, "orc_agg_count", C.c_uint64, v, C.c_int64)
     _sig(L, "orc_agg_count_skip_val", C.c_uint64, v, C.c_int64, C.c_int64)
+    _sig(L, "orc_checked_single_agg_id", C.c_int32, v, C.c_int64, C.c_int64)
+    _sig(L, "orc_checked_single_agg_id_int32", C.c_int32, v, C.c_int32, C.c_int32)
+    _sig(L, "orc_checked_single_agg_id_double", C.c_int32, v, C.c_double, C.c_double)
+    _sig(L, "orc_checked_single_agg_id_float", C.c_int32, v, C.c_float, C.c_float)
     _sig(L, "orc_agg_count_int32", C.c_uint32, v, C.c_int32)
     _sig(L, "orc_agg_count_int32_skip_val", C.c_uint32, v, C.c_int32, C.c_int32)
     _sig(L, "orc_agg_count_double_skip_val", C.c_uint64, v, C.c_double, C.c_double)
@@ -156,6 +160,10 @@ def ref():
         _sig(R, f"agg_{n}_double_skip_val", None, v, C.c_double, C.c_double)
     _sig(R, "agg_count", C.c_uint64, v, C.c_int64)
     _sig(R, "agg_count_skip_val", C.c_uint64, v, C.c_int64, C.c_int64)
+    _sig(R, "checked_single_agg_id", C.c_int32, v, C.c_int64, C.c_int64)
+    _sig(R, "checked_single_agg_id_int32", C.c_int32, v, C.c_int32, C.c_int32)
+    _sig(R, "checked_single_agg_id_double", C.c_int32, v, C.c_double, C.c_double)
+    _sig(R, "checked_single_agg_id_float", C.c_int32, v, C.c_float, C.c_float)
     _sig(R, "agg_count_int32", C.c_uint32, v, C.c_int32)
     _sig(R, "agg_count_int32_skip_val", C.c_uint32, v, C.c_int32, C.c_int32)
     _sig(R, "agg_count_double_skip_val", C.c_uint64, v, C.c_double, C.c_double)

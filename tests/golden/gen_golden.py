@@ -128,6 +128,25 @@ def main():
         agg[f"{name}_double_skip_val_bits"] = int(acc.view(np.int64)[0])
     out["agg"] = {"int_vals": vals, "double_vals_bits": [int(np.float64(x).view(np.int64)) for x in dvals], "results": agg}
 
+    # ---- SINGLE_VALUE: checked_single_agg_id and its typed forms (return code and slot after every call) ------------
+    nullf = float(np.array([0x00800000], dtype=np.int32).view(np.float32)[0])
+    seqs = [[NULL64, 5, 5, NULL64, 5], [7, 8], [NULL64, NULL64], [3, NULL64, 3, 4, 3], [0, 0, NULL64, 1]]
+    single = []
+    for seq in seqs:
+        rec = {"seq": seq, "int64": [], "int32": [], "double": [], "float": []}
+        a64 = np.array([NULL64], dtype=np.int64)
+        a32 = np.array([-(2**31)], dtype=np.int32)
+        ad = np.array([nulld], dtype=np.float64).view(np.int64).copy()
+        af = np.array([nullf], dtype=np.float32).view(np.int32).copy()
+        for v in seq:
+            isnull = v == NULL64
+            rec["int64"].append([int(R.checked_single_agg_id(a64.ctypes.data, v, NULL64)), int(a64[0])])
+            rec["int32"].append([int(R.checked_single_agg_id_int32(a32.ctypes.data, -(2**31) if isnull else v, -(2**31))), int(a32[0])])
+            rec["double"].append([int(R.checked_single_agg_id_double(ad.ctypes.data, float(nulld) if isnull else v * 0.5, float(nulld))), int(ad[0])])
+            rec["float"].append([int(R.checked_single_agg_id_float(af.ctypes.data, nullf if isnull else v * 0.25, nullf)), int(af[0])])
+        single.append(rec)
+    out["single_value"] = single
+
     # ---- scalar helpers -------------------------------------------------------------------------------------
     sc = []
     for x in [0, 1, 49, 50, 51, -49, -50, -51, 12345, -12345, 2**40 + 3]:

@@ -109,6 +109,25 @@ def test_aggregates(oracle, golden):
         assert int(acc[0]) == res[f"{name}_double_skip_val_bits"]
 
 
+def test_single_value(oracle, golden):
+    """checked_single_agg_id[_int32|_double|_float] (QE/RuntimeFunctions.cpp:489-506,567-583,743-760,799-816): return
+    code and slot after every call of the reference's sequences."""
+    L = oracle.lib()
+    nulld = float(np.array([A.NULL_DOUBLE_BITS], dtype=np.int64).view(np.float64)[0])
+    nullf = float(np.array([0x00800000], dtype=np.int32).view(np.float32)[0])
+    for rec in golden["single_value"]:
+        a64 = np.array([NULL64], dtype=np.int64)
+        a32 = np.array([-(2**31)], dtype=np.int32)
+        ad = np.array([nulld], dtype=np.float64).view(np.int64).copy()
+        af = np.array([nullf], dtype=np.float32).view(np.int32).copy()
+        for i, v in enumerate(rec["seq"]):
+            isnull = v == NULL64
+            assert [L.orc_checked_single_agg_id(a64.ctypes.data, v, NULL64), int(a64[0])] == rec["int64"][i]
+            assert [L.orc_checked_single_agg_id_int32(a32.ctypes.data, -(2**31) if isnull else v, -(2**31)), int(a32[0])] == rec["int32"][i]
+            assert [L.orc_checked_single_agg_id_double(ad.ctypes.data, nulld if isnull else v * 0.5, nulld), int(ad[0])] == rec["double"][i]
+            assert [L.orc_checked_single_agg_id_float(af.ctypes.data, nullf if isnull else v * 0.25, nullf), int(af[0])] == rec["float"][i]
+
+
 def test_scalar_helpers(oracle, golden):
     L = oracle.lib()
     for s in golden["scalar"]:

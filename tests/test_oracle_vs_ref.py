@@ -104,6 +104,34 @@ def test_aggregates_random(oracle, ref):
         assert a[0] == b[0]
 
 
+def test_checked_single_agg_id_random(oracle, ref):
+    """SINGLE_VALUE: value sequences with few distinct values and NULLs, all four typed forms -- same return codes
+    (0 / 15 = ERR_SINGLE_VALUE_FOUND_MULTIPLE_VALUES) and the same slot after every call."""
+    L = oracle.lib()
+    rng = np.random.default_rng(21)
+    nulld = float(np.array([0x0010000000000000], dtype=np.int64).view(np.float64)[0])
+    nullf = float(np.array([0x00800000], dtype=np.int32).view(np.float32)[0])
+    for trial in range(300):
+        vals = rng.integers(-3, 3, int(rng.integers(1, 3)))
+        a, b = np.array([NULL64], dtype=np.int64), np.array([NULL64], dtype=np.int64)
+        a32, b32 = np.array([-(2**31)], dtype=np.int32), np.array([-(2**31)], dtype=np.int32)
+        ad, bd = np.array([nulld]).view(np.int64).copy(), np.array([nulld]).view(np.int64).copy()
+        af, bf = np.array([nullf], dtype=np.float32).view(np.int32).copy(), np.array([nullf], dtype=np.float32).view(np.int32).copy()
+        for _ in range(12):
+            isnull = rng.random() < 0.3
+            x = int(rng.choice(vals))
+            v = NULL64 if isnull else x
+            assert L.orc_checked_single_agg_id(a.ctypes.data, v, NULL64) == ref.checked_single_agg_id(b.ctypes.data, v, NULL64)
+            v32 = -(2**31) if isnull else x
+            assert L.orc_checked_single_agg_id_int32(a32.ctypes.data, v32, -(2**31)) == \
+                ref.checked_single_agg_id_int32(b32.ctypes.data, v32, -(2**31))
+            vd = nulld if isnull else x * 0.5
+            assert L.orc_checked_single_agg_id_double(ad.ctypes.data, vd, nulld) == ref.checked_single_agg_id_double(bd.ctypes.data, vd, nulld)
+            vf = nullf if isnull else x * 0.25
+            assert L.orc_checked_single_agg_id_float(af.ctypes.data, vf, nullf) == ref.checked_single_agg_id_float(bf.ctypes.data, vf, nullf)
+            assert a[0] == b[0] and a32[0] == b32[0] and ad[0] == bd[0] and af[0] == bf[0]
+
+
 def test_scalar_random(oracle, ref):
     L = oracle.lib()
     rng = np.random.default_rng(13)
