@@ -54,7 +54,7 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
 }
 
 // The one-pass form (HDK_HIP_PROJECT_ONE_PASS=1: measured slower than the two passes at 1 % and at 50 % selectivity,
-// DESIGN.md 3.2, and kept behind the switch) needs a status word per batch of tiles, so the launch has to state its row
+// DESIGN.md 3.6, and kept behind the switch) needs a status word per batch of tiles, so the launch has to state its row
 // count.
 static bool project_one_pass(const hdk_hip_kernel_options* ko) {
   return ko && ko->total_rows && getenv("HDK_HIP_PROJECT_ONE_PASS");

@@ -259,7 +259,7 @@ constexpr int kProjFastGroup = 4;  // writing pass: tiles handled per block-wide
 //   dense  -- an eighth of the rows or more pass, so every 128-byte line of a target column is needed anyway: the wave
 //             reads its 8 slots per lane of the column with the coalesced loads of the filter pass, compacts the VALUES
 //             through LDS and stores them -- no row list, no gathers (at 50 % selectivity the gathers ran at 3.8 TB/s of
-//             in + out bytes; measured in DESIGN.md 3.2).
+//             in + out bytes; measured in DESIGN.md 3.6).
 constexpr int kProjFastG = kProjFastGroup;
 constexpr uint32_t kProjDenseMin = kWave * kProjFastVR / 8;  // passing rows of a wave and tile from which the dense form pays
 

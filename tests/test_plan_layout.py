@@ -121,6 +121,27 @@ def test_min_max_keep_argument_null():
     assert cp.init_vals.tolist() == [0, A.NULL_INT, A.NULL_BIGINT]
 
 
+def test_single_value_layout():
+    # checked_single_agg_id is never a *_skip_val call and always takes the ARGUMENT type's NULL
+    # (QE/TargetExprBuilder.cpp:429-445,542-546); its slot starts like MAX's (get_agg_initial_val,
+    # QE/OutputBufferInitialization.cpp:211-250): the type's NULL when nullable, the integer minimum of the SLOT width
+    # when not -- which for a non-nullable INT32 argument in an 8-byte slot is not the NULL the function is handed
+    # (the reference's own quirk, restated as it is); non-grouped queries are always nullable (:57-60)
+    st = ArrowStorage()
+    st.import_arrow(pa.table({"k": pa.array([1, 1, 2], pa.int8()), "v": pa.array([3, None, 4], pa.int32()),
+                              "w": pa.array([5, 5, 6], pa.int32())}), "t")
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("single_value", ColRef("v")),
+                                                                        Agg("single_value", ColRef("w"))]))
+    t1, t2 = cp.plan.targets[1], cp.plan.targets[2]
+    assert t1.agg == t2.agg == A.AGG_SINGLE_VALUE and t1.skip_null == t2.skip_null == 0
+    assert t1.null_val == t2.null_val == A.NULL_INT
+    assert cp.plan.keyless == 0  # (get_keyless_info: default -> keyless = false, MemoryLayoutBuilder.cpp:398-400)
+    w_nullable = st.get("t").columns["w"].type.nullable
+    assert cp.init_vals.tolist() == [0, A.NULL_INT, A.NULL_INT if w_nullable else -(2**63)]
+    cp = compile_query(st, QueryUnit("t", targets=[Agg("single_value", ColRef("w"))]))
+    assert cp.plan.query_kind == A.Q_NON_GROUPED and cp.init_vals.tolist() == [A.NULL_INT]
+
+
 def test_unsupported_shapes_raise_query_must_run_on_cpu():
     st = ArrowStorage()
     st.import_numpy("t", {"a": np.arange(10, dtype=np.int64), "f": np.ones(10, dtype=np.float32), "d": np.ones(10)})
