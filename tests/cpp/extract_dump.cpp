@@ -161,6 +161,21 @@ int main(int argc, char** argv) {
       q.max_val_ = 299;
       dump("floats", run({{0, 4, HDK_COL_INT}, {0, 4, HDK_COL_FLOAT}, {0, 8, HDK_COL_DOUBLE}}, u, q));
     }
+    {  // SINGLE_VALUE: SELECT k, SINGLE_VALUE(f), SINGLE_VALUE(d), COUNT(*) GROUP BY k   (k INT, f FLOAT, d DOUBLE)
+      auto k = column(int_t(4, false), 0, 0), f = column(type_of(TypeDesc::Fp, 4, true), 0, 1), d = column(fp64(true), 0, 2);
+      hip_rt::UnitView<StandInIr> u;
+      u.groupby = {k.get()};
+      auto s1 = agg_expr(type_of(TypeDesc::Fp, 4, true), AggType::kSingleValue, f), s2 = agg_expr(fp64(true), AggType::kSingleValue, d),
+           c = agg_expr(int_t(4, false), AggType::kCount, nullptr);
+      u.targets = {k.get(), s1.get(), s2.get(), c.get()};
+      QmdStandIn q;
+      q.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+      q.group_col_widths_ = {8};
+      q.padded_slot_widths_ = {8, 8, 8, 8};
+      q.entry_count_ = 300;
+      q.max_val_ = 299;
+      dump("single", run({{0, 4, HDK_COL_INT}, {0, 4, HDK_COL_FLOAT}, {0, 8, HDK_COL_DOUBLE}}, u, q));
+    }
     // shapes the library does not cover must be refused, not mistranslated
     int refused = 0;
     auto expect_refusal = [&](const hip_rt::UnitView<StandInIr>& u) {

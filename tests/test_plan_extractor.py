@@ -62,6 +62,8 @@ def _queries():
         "projection": QueryUnit("t", quals=[Cmp(ColRef("val"), "<", Lit(100))], targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val") * 2, "v2")]),
         "floats": QueryUnit("g", groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("sum", ColRef("f"), "sf"), Agg("avg", ColRef("f"), "af"),
                                                                    Agg("min", ColRef("d"), "md"), Agg("count", ColRef("f"), "cf")]),
+        "single": QueryUnit("g", groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("single_value", ColRef("f"), "s1"),
+                                                                   Agg("single_value", ColRef("d"), "s2"), Agg("count", None, "c")]),
     }
 
 
@@ -99,7 +101,7 @@ def dumped(tmp_path_factory):
     return d
 
 
-@pytest.mark.parametrize("name", ["c2", "q4", "filters", "join", "c5", "projection", "floats"])
+@pytest.mark.parametrize("name", ["c2", "q4", "filters", "join", "c5", "projection", "floats", "single"])
 def test_extractor_matches_the_python_planner(dumped, name):
     st = _tables()
     want = compile_query(st, _queries()[name]).plan
