@@ -102,6 +102,28 @@ def test_planner_output_validates_and_corruptions_do_not():
     assert len(kinds) >= 6 and rejected > 2000
 
 
+def test_single_value_targets_validate_and_their_corruptions_do_not():
+    L = lib()
+    rng = np.random.default_rng(5)
+    st = make_tables(rng, 3000, 120)
+    cp = None
+    for name, tab in st.tables.items():
+        cols = [c for c, col in tab.columns.items() if col.type.kind == "int" and col.type.size == 8]
+        if len(cols) >= 2:
+            cp = compile_query(st, QueryUnit(name, groupby=[ColRef(cols[0])], force_baseline=True, baseline_entry_count=4099,
+                                            targets=[KeyRef(0, "k"), Agg("single_value", ColRef(cols[1]), "sv"), Agg("count", None, "c")]))
+            break
+    assert cp is not None
+    assert L.hdk_hip_validate_plan(C.byref(cp.plan), 0) == A.OK, L.hdk_hip_last_error()
+    sv = [t for t in range(cp.plan.num_targets) if cp.plan.targets[t].agg == A.AGG_SINGLE_VALUE][0]
+    for what, mutate in (("no argument", lambda q: setattr(q.targets[sv], "has_arg", 0)),
+                         ("2-byte slot", lambda q: setattr(q.targets[sv], "slot_width", 2)),
+                         ("aggregate kind past the last", lambda q: setattr(q.targets[sv], "agg", A.AGG_SINGLE_VALUE + 1))):
+        bad = A.Plan.from_buffer_copy(cp.plan)
+        mutate(bad)
+        assert L.hdk_hip_validate_plan(C.byref(bad), 0) in (A.ERR_INVALID_ARG, A.ERR_UNSUPPORTED), what
+
+
 def test_null_and_garbage_plans():
     L = lib()
     assert L.hdk_hip_validate_plan(None, 0) == A.ERR_INVALID_ARG
