@@ -153,17 +153,34 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         # splits -> hdk_hip_aggregate_from_ranks); skewed keys fall back to the exchange of partial tables
         bound = torch.tensor([w.local_rows], dtype=torch.int64, device="cuda")
         comm.all_reduce(bound, "max")
-        try:
-            step.free()
-            n_owner = D.owner_entry_count_for(cp.entry_count, world)
-            owner_t = torch.empty(D.baseline_table_quads(cp, n_owner), dtype=torch.int64, device="cuda")
-            step = w.ex.prepare(cp, w.frag_ids, flags=int(os.environ.get("HDK_BENCH_FLAGS", "0")), out_ptr=owner_t.data_ptr())
-            xch = D.TupleExchange(step, world, int(bound.item()), n_owner)
+        # (the shape only depends on the plan, the row bound and -- through the tuple width -- on the column statistics;
+        # the ranks settle the width among themselves inside TupleExchange, and the choice of the mode is made by ALL
+        # ranks together: a rank on its own in "tables" mode would issue other collectives than its peers)
+        step.free()
+        n_owner = D.owner_entry_count_for(cp.entry_count, world)
+        owner_t = torch.empty(D.baseline_table_quads(cp, n_owner), dtype=torch.int64, device="cuda")
+        step = w.ex.prepare(cp, w.frag_ids, flags=int(os.environ.get("HDK_BENCH_FLAGS", "0")), out_ptr=owner_t.data_ptr())
+        why = ""
+        if os.environ.get("HDK_BENCH_EXCHANGE", "tuples") == "tables":
+            why = "HDK_BENCH_EXCHANGE=tables"
+        else:
+            try:
+                C_probe = A.ExchangeShape()
+                ko_probe = A.KernelOptions.from_buffer_copy(step.ko)
+                ko_probe.total_rows = int(bound.item())
+                check(L.hdk_hip_exchange_shape_for(C.byref(step.plan), C.byref(ko_probe), world, n_owner, dev, C.byref(C_probe)))
+            except Exception as e:  # plan outside the radix-partitioned shape
+                why = str(e)
+        failed = torch.tensor([1 if why else 0], dtype=torch.int64, device="cuda")
+        comm.all_reduce(failed, "max")
+        if int(failed.item()) == 0:
+            xch = D.TupleExchange(step, world, int(bound.item()), n_owner)  # (collective: the ranks agree on the tuple width)
             owner["table"], owner["entries"] = owner_t, n_owner
             mode = "tuples"
-        except Exception as e:  # plan outside the radix-partitioned shape
+        else:
             if rank == 0:
-                print(f"# tuple exchange not available ({e}); exchanging partial tables", file=sys.stderr)
+                print(f"# tuple exchange not used ({why or 'another rank cannot'}); exchanging partial tables", file=sys.stderr)
+            step.free()
             step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS, out_ptr=out_t.data_ptr())
             mode = "tables"
 
@@ -568,11 +585,6 @@ def main():
                 "scan_kernel_ms": a["plan_resident"]["scan_kernel_ms"],
                 "host_enqueue_ms": a["plan_resident"]["host_enqueue_ms_per_step"],
                 "projected_rows_per_s_at_8_gpus": a["projected_rows_per_s_at_8_gpus_wire_excluded"]}
-        else:
-            line["multi_gpu_emulated"]["c2_rank0_of_8"] = {
-                "source": "profiles/r03_multi_gpu_floor_after.json (scripts/multi_gpu_floor.py --only a; or --multi-gpu-emulation full)",
-                "step_ms": 0.366, "scan_kernel_ms": 0.325, "host_enqueue_ms": 0.031, "rows": 128_000_000,
-                "projected_rows_per_s_at_8_gpus": 2.73e12, "measured_by_this_run": False}
     if comm.rank == 0:
         print(json.dumps(line))
     comm.close()

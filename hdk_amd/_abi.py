@@ -48,13 +48,13 @@ ERR_EXCHANGE_INCOMPLETE = 103
 
 # --- enums -----------------------------------------------------------------------------------
 VC_INT, VC_FP = 0, 1
-COL_INT, COL_UNSIGNED, COL_FLOAT, COL_DOUBLE = 0, 1, 2, 3
+COL_INT, COL_UNSIGNED, COL_FLOAT, COL_DOUBLE, COL_SMALL_DATE = 0, 1, 2, 3, 4
 LEAF_NONE, LEAF_COL, LEAF_INT, LEAF_FP = 0, 1, 2, 3
 (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_EXTRACT_YEAR, OP_SCALE_DOWN, OP_FLOOR_DIV,
  OP_CAST_INT_TO_FP, OP_CAST_FP_TO_INT) = range(1, 11)
 CMP_EQ, CMP_NE, CMP_LT, CMP_GT, CMP_LE, CMP_GE = range(1, 7)
 JOIN_ONE_TO_ONE, JOIN_ONE_TO_MANY, JOIN_ONE_TO_ONE_FUSED, JOIN_KEYED_ONE_TO_ONE, JOIN_KEYED_ONE_TO_MANY = 0, 1, 2, 3, 4
-JOIN_INNER, JOIN_LEFT = 0, 1
+JOIN_INNER, JOIN_LEFT, JOIN_SEMI, JOIN_ANTI = 0, 1, 2, 3
 JOIN_NULL_NONE, JOIN_NULL_NULLABLE, JOIN_NULL_BITWISE = 0, 1, 2
 Q_NON_GROUPED, Q_PERFECT_HASH, Q_BASELINE_HASH, Q_PROJECTION = 0, 1, 2, 3
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX, AGG_AVG, AGG_ID, AGG_SINGLE_VALUE = 0, 1, 2, 3, 4, 5, 6
@@ -67,6 +67,7 @@ LAUNCH_RECORD_EVENTS = 2
 LAUNCH_FORCE_GENERIC = 4
 LAUNCH_FORCE_SCALAR = 8
 LAUNCH_FORCE_PARTITIONED = 16
+LAUNCH_WIDE_TUPLES = 1024
 LAUNCH_PLAN_RESIDENT = 32
 LAUNCH_CHECK_INTERRUPT = 64
 LAUNCH_INIT_OUTPUT = 128

@@ -53,12 +53,20 @@ HDK_DEV void record_error(int32_t* error_code, int32_t err) {
 // ---------------------------------------------------------------------------------------------
 // decoders
 // ---------------------------------------------------------------------------------------------
+// the narrow NULL of a DATE-in-days column (FixedWidthSmallDate, QE/Codec.cpp:86-87)
+HDK_DEV int64_t small_date_null(int32_t width) { return width == 4 ? static_cast<int64_t>(INT32_MIN) : static_cast<int64_t>(INT16_MIN); }
+
 HDK_DEV int64_t decode_col(const int8_t* __restrict__ buf, int32_t width, int32_t kind, int64_t row) {
   switch (kind) {
     case HDK_COL_DOUBLE:
       return reinterpret_cast<const int64_t*>(buf)[row];
     case HDK_COL_FLOAT:
       return double_to_bits(static_cast<double>(reinterpret_cast<const float*>(buf)[row]));
+    case HDK_COL_SMALL_DATE: {  // fixed_width_small_date_decode (QE/DecodersImpl.h:151-159): days -> epoch seconds
+      const int64_t v = width == 4 ? static_cast<int64_t>(reinterpret_cast<const int32_t*>(buf)[row])
+                                   : static_cast<int64_t>(reinterpret_cast<const int16_t*>(buf)[row]);
+      return v == small_date_null(width) ? HDK_NULL_BIGINT : v * 86400;
+    }
     case HDK_COL_UNSIGNED:
       switch (width) {
         case 1:
@@ -105,6 +113,10 @@ HDK_DEV int64_t decode_col_g(const int8_t* buf, int32_t width, int32_t kind, int
       return gload<int64_t>(buf, row, nt);
     case HDK_COL_FLOAT:
       return double_to_bits(static_cast<double>(gload<float>(buf, row, nt)));
+    case HDK_COL_SMALL_DATE: {
+      const int64_t v = width == 4 ? static_cast<int64_t>(gload<int32_t>(buf, row, nt)) : static_cast<int64_t>(gload<int16_t>(buf, row, nt));
+      return v == small_date_null(width) ? HDK_NULL_BIGINT : v * 86400;
+    }
     case HDK_COL_UNSIGNED:
       switch (width) {
         case 1: return gload<uint8_t>(buf, row, nt);
@@ -611,8 +623,10 @@ HDK_DEV void for_each_row_match(RowCtx& c, const int64_t* join_hash_tables, int3
   }
   const hdk_hip_join& j0 = p->joins[0];
   const MatchSet m0 = matching_set(c, j0, join_hash_tables, nj, err);
-  const bool left0 = m0.n <= 0 && j0.type == HDK_JOIN_LEFT;
-  const int n0 = left0 ? 1 : m0.n;
+  // ANTI: the rest of the row runs when the probe found no slot (JoinLoop.cpp:258-262), with the inner row "not found"
+  const bool anti0 = j0.type == HDK_JOIN_ANTI;
+  const bool left0 = m0.n <= 0 && (j0.type == HDK_JOIN_LEFT || anti0);
+  const int n0 = left0 ? 1 : (anti0 ? 0 : m0.n);
   for (int i0 = 0; i0 < n0; ++i0) {
     c.join_row[0] = left0 ? -1 : (m0.ids ? static_cast<int64_t>(m0.ids[i0]) : m0.single);
     if (nj == 1) {
@@ -623,8 +637,9 @@ HDK_DEV void for_each_row_match(RowCtx& c, const int64_t* join_hash_tables, int3
     }
     const hdk_hip_join& j1 = p->joins[1];
     const MatchSet m1 = matching_set(c, j1, join_hash_tables, nj, err);
-    const bool left1 = m1.n <= 0 && j1.type == HDK_JOIN_LEFT;
-    const int n1 = left1 ? 1 : m1.n;
+    const bool anti1 = j1.type == HDK_JOIN_ANTI;
+    const bool left1 = m1.n <= 0 && (j1.type == HDK_JOIN_LEFT || anti1);
+    const int n1 = left1 ? 1 : (anti1 ? 0 : m1.n);
     for (int i1 = 0; i1 < n1; ++i1) {
       c.join_row[1] = left1 ? -1 : (m1.ids ? static_cast<int64_t>(m1.ids[i1]) : m1.single);
       if (quals_pass(c, 1, err)) {

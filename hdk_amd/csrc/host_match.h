@@ -26,8 +26,20 @@ inline bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* c
   if (e.nsteps != 0 || e.leaf0.kind != HDK_LEAF_COL) return false;
   const hdk_hip_col& c = p->cols[e.leaf0.col];
   if (c.table != 0) return false;
+  if (c.kind == HDK_COL_SMALL_DATE) return false;  // decoded (x 86400, narrow NULL) by the plan interpreters only
   *col = e.leaf0.col;
   return true;
+}
+
+// INNER, or SEMI: the same probe over a table whose fill let the first row of a key win
+inline bool join_type_inner_like(int32_t type) { return type == HDK_JOIN_INNER || type == HDK_JOIN_SEMI; }
+
+// some column of the plan is a DATE in days: none of the specialised kernels decodes it
+inline bool plan_reads_small_dates(const hdk_hip_plan* p) {
+  for (int i = 0; i < p->num_cols; ++i) {
+    if (p->cols[i].kind == HDK_COL_SMALL_DATE) return true;
+  }
+  return false;
 }
 
 // joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
@@ -38,7 +50,7 @@ inline bool needs_join_loops(const hdk_hip_plan* p) {
   }
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
-    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) {
+    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type)) {
       return true;
     }
   }

@@ -267,8 +267,10 @@ static int32_t one_to_one(int32_t* buff, int32_t invalid_slot_val, int32_t for_s
   }
   BuildArgs a;
   a.buff = buff;
+  // HashEntryInfo{max - min + 1 (+ 1 for the NULLs of a kBwEq join), bucket}.getNormalizedHashEntryCount()
+  // (PerfectJoinHashTable.cpp:45-85, HashJoinRuntime.h:46-55): the slots the caller allocated and initialised
   const int64_t range = ti.max_val - ti.min_val + 1 + (ti.uses_bw_eq ? 1 : 0);
-  a.hash_entry_count = bucket > 1 ? (range + bucket - 1) / bucket + 1 : range;
+  a.hash_entry_count = bucket > 1 ? (range + bucket - 1) / bucket : range;
   a.invalid_slot_val = invalid_slot_val;
   a.for_semi_join = for_semi_join;
   a.dev_err = dev_err_buff;

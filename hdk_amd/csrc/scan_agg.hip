@@ -492,7 +492,8 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
   for (int i = 0; exprs && i < p->num_cols; ++i) {
     const hdk_hip_col& c = p->cols[i];
     HDK_REQUIRE(c.width == 1 || c.width == 2 || c.width == 4 || c.width == 8, "column %d: width %d is not 1/2/4/8", i, c.width);
-    HDK_REQUIRE(c.kind >= HDK_COL_INT && c.kind <= HDK_COL_DOUBLE, "column %d: bad kind %d", i, c.kind);
+    HDK_REQUIRE(c.kind >= HDK_COL_INT && c.kind <= HDK_COL_SMALL_DATE, "column %d: bad kind %d", i, c.kind);
+    HDK_REQUIRE(c.kind != HDK_COL_SMALL_DATE || c.width == 2 || c.width == 4, "column %d: a DATE in days is 2 or 4 bytes wide", i);
     HDK_REQUIRE(c.kind != HDK_COL_FLOAT || c.width == 4, "column %d: a float column is 4 bytes wide", i);
     HDK_REQUIRE(c.kind != HDK_COL_DOUBLE || c.width == 8, "column %d: a double column is 8 bytes wide", i);
     HDK_REQUIRE(c.table >= -p->num_joins && c.table <= p->num_joins, "column %d: table %d out of range (%d joins)", i, c.table,
@@ -519,7 +520,11 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
   for (int j = 0; exprs && j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     HDK_REQUIRE(jn.kind >= HDK_JOIN_ONE_TO_ONE && jn.kind <= HDK_JOIN_KEYED_ONE_TO_MANY, "bad join kind");
-    HDK_REQUIRE(jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_LEFT, "bad join type");
+    HDK_REQUIRE(jn.type >= HDK_JOIN_INNER && jn.type <= HDK_JOIN_ANTI, "bad join type");
+    if (jn.type == HDK_JOIN_SEMI || jn.type == HDK_JOIN_ANTI) {  // first-row-wins fills exist for the one-to-one tables only
+      HDK_REQUIRE(jn.kind == HDK_JOIN_ONE_TO_ONE || jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED || jn.kind == HDK_JOIN_KEYED_ONE_TO_ONE,
+                  "join %d: a SEMI / ANTI join probes a one-to-one table", j);
+    }
     HDK_REQUIRE(jn.null_mode >= HDK_JOIN_NULL_NONE && jn.null_mode <= HDK_JOIN_NULL_BITWISE, "join %d: bad null_mode", j);
     HDK_REQUIRE(jn.table_idx >= 0 && jn.table_idx < p->num_joins, "join %d: table_idx %d out of range", j, jn.table_idx);
     HDK_REQUIRE(jn.bucket >= 0, "join %d: negative bucket", j);
@@ -529,6 +534,11 @@ static int32_t validate_plan_impl(const hdk_hip_plan* p, bool exprs) {
     }
     if (jn.kind <= HDK_JOIN_ONE_TO_ONE_FUSED) {
       HDK_REQUIRE(jn.max_key >= jn.min_key, "join %d: empty key range", j);
+      if (jn.null_mode == HDK_JOIN_NULL_BITWISE && jn.entry_count > 0 && jn.translated_null >= jn.min_key) {
+        // the slot a NULL key probes ([bucketized_]hash_join_idx_bitwise) must lie inside the table
+        const int64_t b = jn.bucket > 1 ? jn.bucket : 1;
+        HDK_REQUIRE((jn.translated_null - jn.min_key) / b < jn.entry_count, "join %d: translated NULL key outside the table", j);
+      }
     }
     if (jn.kind >= HDK_JOIN_KEYED_ONE_TO_ONE) {
       for (int k = 0; k + 1 < jn.key_component_count && k < HDK_HIP_MAX_JOIN_KEYS - 1; ++k) {
@@ -1008,7 +1018,7 @@ static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, J
   }
   if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
   const hdk_hip_join& jn = p->joins[0];
-  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || jn.fused_stride != 2 || jn.type != HDK_JOIN_INNER || jn.bucket > 1 ||
+  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || jn.fused_stride != 2 || !join_type_inner_like(jn.type) || jn.bucket > 1 ||
       jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.table_idx != 0) {
     return false;
   }
@@ -1088,7 +1098,8 @@ static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_opt
 // Taken by default for the hdk_join_agg_direct shape when the table is far larger than the caches and the column
 // statistics let payload and key offset travel in 32 bits; HDK_HIP_LAUNCH_CLUSTER_PROBES takes it whatever the sizes
 // (tests), HDK_HIP_LAUNCH_NO_CLUSTER_PROBES never.
-static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, const hdk_hip_kernel_options* ko, SliceArgs* sa) {
+static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, const hdk_hip_kernel_options* ko, uint32_t grid,
+                              SliceArgs* sa) {
   if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES)) return false;
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
   const hdk_hip_join& jn = p->joins[0];
@@ -1121,6 +1132,10 @@ static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, c
   sa->slice = slice;
   magic_u32(slice, &sa->slice_magic, &sa->slice_shift);
   sa->nbins = static_cast<uint32_t>((range + slice - 1) / slice);
+  // every block of the probe pass flushes into slab[blockIdx.x], and the workspace holds (and hdk_finalize folds) as many
+  // slabs as the launch shape's grid -- which the caller may have made small (KernelOptions::gridDimX): one block per
+  // slice at least, or the slices are not used
+  if (sa->nbins > grid) return false;
   // the NULL sentinels of x and of the payload, as the targets' leaves name them
   for (int t = 0; t < ja.ntargets; ++t) {
     for (const JdLeaf* l : {&ja.t[t].a, &ja.t[t].b}) {
@@ -1137,7 +1152,12 @@ static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, c
           xcol->max_val <= static_cast<int64_t>(INT32_MAX)) || getenv("HDK_HIP_SLICE_WIDE")) {
       sa->narrow = 0;
     }
-    if (!x_has_nulls) sa->x_null32 = 0;  // (no NULLs announced: INT32_MIN is an ordinary value; a NULL showing up anyway is caught as stale)
+    if (!x_has_nulls) {
+      // no NULLs announced: INT32_MIN is an ordinary value; a NULL showing up anyway (the leaf is nullable, x_null is set)
+      // is caught as stale by the scatter pass
+      sa->x_null_is_stale = sa->x_null32;
+      sa->x_null32 = 0;
+    }
     else if (sa->narrow && !sa->x_null32) sa->narrow = 0;  // NULLs possible but no sentinel known from the leaves
   } else {
     sa->x_null32 = 0;
@@ -1186,6 +1206,8 @@ static int32_t launch_sliced_kernels(SliceArgs& sa, const LaunchShape& shape, co
   const unsigned g_sc = resident_grid(reinterpret_cast<const void*>(hdk_join_scatter_slices<NARROW>), kSliceBlock, lds_sc, props);
   uint32_t members = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu) / sa.nbins;
   if (members < 1) members = 1;
+  if (sa.nbins * members > shape.grid) members = shape.grid / sa.nbins;  // slab[blockIdx.x] must exist (match_join_sliced: nbins <= grid)
+  if (members < 1) return HDK_HIP_OK;
   hipLaunchKernelGGL(hdk_join_order_probe, dim3(256), dim3(256), 0, s, sa);
   hipLaunchKernelGGL(hdk_join_scatter_slices<NARROW>, dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
   hipLaunchKernelGGL((hdk_join_agg_sliced<NARROW, FAST>), dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, sa);
@@ -1199,7 +1221,7 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
   AsyncScratch scratch(s);
   const hdk_hip_join& jn = plan->joins[0];
   SliceArgs sa;
-  if (match_join_sliced(plan, ja, ko, &sa)) {
+  if (match_join_sliced(plan, ja, ko, shape.grid, &sa)) {
     // key-range slices probed out of LDS; the row-order kernel below stays armed for what the slices cannot carry
     auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
     const size_t tw = sa.narrow ? 1 : 2;
@@ -1598,7 +1620,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     const bool direct = !generic && match_join_direct(plan, s, &jd);
     SliceArgs sl;
-    if (direct && match_join_sliced(plan, jd, ko, &sl)) {
+    if (direct && match_join_sliced(plan, jd, ko, s.grid, &sl)) {
       const int n = snprintf(out, out_len, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
@@ -1636,7 +1658,7 @@ static bool match_cluster_join(const hdk_hip_plan* p, const hdk_hip_kernel_optio
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_SCALAR | HDK_HIP_LAUNCH_FORCE_GENERIC)) return false;
   if (p->num_joins != 1 || p->query_kind == HDK_Q_PROJECTION || needs_join_loops(p)) return false;
   const hdk_hip_join& jn = p->joins[0];
-  if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || jn.type != HDK_JOIN_INNER) return false;
+  if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type)) return false;
   if (jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.bucket > 1) return false;  // (a NULL key that matches: not dropped)
   int kc;
   if (!plain_outer_col(p, jn.outer_key, &kc)) return false;

@@ -143,6 +143,9 @@ struct PartArgs {
   int32_t narrow;
   int32_t narrow_null;       // the argument column may hold NULLs: INT32_MIN stands for its in-band NULL
   int64_t narrow_arg_null;   // ... which the readers put back
+  int32_t narrow_null_is_stale;  // statistics say "no NULLs" but the argument's type is nullable: a value equal to the in-band
+                                 // NULL contradicts them (it fits 32 bits for a narrow column, so the range test cannot see it)
+  int32_t narrow_pad_;
   // level-2 input: the sub-slabs of `nsrc` level-1 outputs (single GPU: this launch's own; owner: one per rank)
   uint32_t nsrc;
   uint32_t src_fill_stride;              // uint32 words between the cursors of neighbouring sub-slabs
@@ -466,7 +469,8 @@ __global__ __launch_bounds__(kPartBlock, (NARROW && LEVEL == 1) ? HDK_PART_L1_WA
       const bool is_null = a.narrow_null && arg == a.narrow_arg_null;
       const int32_t v32 = is_null ? INT32_MIN : static_cast<int32_t>(arg);
       stale |= static_cast<int64_t>(static_cast<int32_t>(key)) != key ||
-               (!is_null && (static_cast<int64_t>(v32) != arg || (a.narrow_null && v32 == INT32_MIN)));
+               (!is_null && (static_cast<int64_t>(v32) != arg || (a.narrow_null && v32 == INT32_MIN))) ||
+               (a.narrow_null_is_stale && arg == a.narrow_arg_null);
       return static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(v32)) << 32) | static_cast<uint32_t>(key));
     };
     int64_t tile = blockIdx.x;
@@ -687,6 +691,10 @@ __global__ __launch_bounds__(kPartBlock, (NARROW && LEVEL == 1) ? HDK_PART_L1_WA
 // level 1 of a scatter to owners: the header of every owner segment -- tuples per (coarse slab, XCD) sub-slab, then the
 // flag word (0: complete; else the exchange cannot be used: a sub-slab overflowed, the statistics were stale, or the
 // launch was interrupted)
+// what a segment says about its own shape: the owner lays the inbox out with ITS shape, and column statistics (which
+// decide the tuple width) are per rank
+HDK_DEV uint32_t part_segment_tag(const PartArgs& a) { return static_cast<uint32_t>(a.tw * 8) | (a.p1 << 8); }
+
 __global__ void hdk_part_publish(PartArgs a) {
   const uint32_t o = blockIdx.x;
   uint32_t* header = reinterpret_cast<uint32_t*>(a.send + static_cast<uint64_t>(o) * a.seg_bytes);
@@ -697,6 +705,7 @@ __global__ void hdk_part_publish(PartArgs a) {
   }
   if (threadIdx.x == 0) {
     header[nsub] = *a.fallback;
+    header[nsub + 1] = part_segment_tag(a);
   }
 }
 
@@ -708,6 +717,7 @@ __global__ void hdk_part_collect_flags(PartArgs a) {
   uint32_t bad = 0;
   for (uint32_t r = threadIdx.x; r < a.nsrc; r += blockDim.x) {
     bad |= a.src_fill[r][nsub];
+    bad |= a.src_fill[r][nsub + 1] != part_segment_tag(a) ? 1u : 0u;  // a sender with another tuple width / geometry
   }
   if (bad) {
     atomicMax(a.fallback, 3u);

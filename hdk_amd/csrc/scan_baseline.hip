@@ -151,7 +151,8 @@ static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   return true;
 }
 
-static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
+static bool part_tuple_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
+  const bool keep_wide = (ko && (ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) || getenv("HDK_HIP_PART_WIDE");
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
   if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
@@ -189,7 +190,7 @@ static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
   }
   // narrow tuples (scan_agg_partitioned.h): one 4-byte table key, one integer argument column that the statistics
   // put inside 32 bits -- a nullable one gives up INT32_MIN for its in-band NULL
-  if (pa->nkeys == 1 && p->key_width == 4 && pa->nargs == 1 && pa->arg[0].kind == HDK_COL_INT && !getenv("HDK_HIP_PART_WIDE")) {
+  if (pa->nkeys == 1 && p->key_width == 4 && pa->nargs == 1 && pa->arg[0].kind == HDK_COL_INT && !keep_wide) {
     const hdk_hip_col* c = outer_col_of_buf(p, pa->arg[0].buf_idx);
     if (c && c->has_stats && c->min_val >= static_cast<int64_t>(INT32_MIN) + (c->has_nulls ? 1 : 0) &&
         c->max_val <= static_cast<int64_t>(INT32_MAX) && c->min_val <= c->max_val) {
@@ -200,6 +201,8 @@ static bool part_tuple_shape(const hdk_hip_plan* p, PartArgs* pa) {
         if (pa->tgt_arg[t]) {
           if (pa->narrow_null && !tg.arg.nullable) pa->narrow = 0;  // (statistics and type disagree: stay wide)
           pa->narrow_arg_null = tg.arg.null_val;
+          // "no NULLs" by the statistics, nullable by the type: a NULL showing up anyway must not be summed as a value
+          pa->narrow_null_is_stale = (!pa->narrow_null && tg.arg.nullable && tg.skip_null) ? 1 : 0;
         }
       }
       if (pa->narrow) pa->tw = 1;
@@ -281,7 +284,7 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
   if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
-  return part_tuple_shape(p, pa) && part_geometry(p, ko->total_rows, p->entry_count, 1, pa);
+  return part_tuple_shape(p, ko, pa) && part_geometry(p, ko->total_rows, p->entry_count, 1, pa);
 }
 
 constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
@@ -486,13 +489,13 @@ int32_t exchange_shape(const hdk_hip_plan* plan, const hdk_hip_kernel_options* k
                        uint32_t owner_entry_count, PartArgs* pa, hdk_hip_exchange_shape* out) {
   HDK_REQUIRE(num_owners >= 2 && num_owners <= kPartMaxSrc, "num_owners must be in [2, %d]", kPartMaxSrc);
   HDK_REQUIRE(ko && ko->total_rows, "hdk_hip_kernel_options::total_rows (the per-rank row bound) is required");
-  if (plan->query_kind != HDK_Q_BASELINE_HASH || !part_tuple_shape(plan, pa) ||
+  if (plan->query_kind != HDK_Q_BASELINE_HASH || !part_tuple_shape(plan, ko, pa) ||
       !part_geometry(plan, ko->total_rows, owner_entry_count, static_cast<uint32_t>(num_owners), pa)) {
     set_error("plan or table geometry outside the radix-partitioned group-by's shape");
     return HDK_HIP_ERR_UNSUPPORTED;
   }
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
-  pa->seg_header_bytes = up((static_cast<size_t>(pa->p1) * kPartXcds + 1) * sizeof(uint32_t));
+  pa->seg_header_bytes = up((static_cast<size_t>(pa->p1) * kPartXcds + 2) * sizeof(uint32_t));  // counts, flag, shape tag
   pa->seg_bytes = pa->seg_header_bytes + up(static_cast<size_t>(pa->p1) * pa->cap1 * pa->tw * 8);
   if (out) {
     memset(out, 0, sizeof(*out));

@@ -54,6 +54,8 @@ struct SliceArgs {
   uint32_t nbins;                     // slices in use (<= 256)
   int32_t narrow;                     // 8-byte tuples [x as int32 : key - min]; else 16-byte [key - min | x]
   int32_t x_null32;                   // narrow: INT32_MIN stands for x's in-band NULL
+  int32_t x_null_is_stale;            // narrow: the statistics announce no NULLs in x but its leaf is nullable -- a value equal
+                                      // to x_null contradicts them (and fits 32 bits when x is a narrow column's value)
   int64_t x_null;
   int64_t pay_null;                   // the payload column's in-band NULL
   int32_t pay_nullable;
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
         if (NARROW) {
           const bool is_null = a.x_null32 && x[r] == a.x_null;
           const int32_t x32 = is_null ? INT32_MIN : static_cast<int32_t>(x[r]);
-          stale |= live[r] && !is_null && (static_cast<int64_t>(x32) != x[r] || (a.x_null32 && x32 == INT32_MIN));
+          stale |= live[r] && ((!is_null && (static_cast<int64_t>(x32) != x[r] || (a.x_null32 && x32 == INT32_MIN))) ||
+                               (a.x_null_is_stale && x[r] == a.x_null));
           tup[r][0] = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(x32)) << 32) | d32);
         } else {
           tup[r][0] = static_cast<int64_t>(d);

@@ -126,6 +126,12 @@ HDK_DEV void load_rows_decoded(const VecCtx& c, const int8_t* __restrict__ buf, 
     HDK_LOAD_ROWS(int64_t, x)
   } else if (kind == HDK_COL_FLOAT) {
     HDK_LOAD_ROWS(float, double_to_bits(static_cast<double>(x)))
+  } else if (kind == HDK_COL_SMALL_DATE) {  // fixed_width_small_date_decode: days -> epoch seconds, narrow NULL -> NULL_BIGINT
+    if (width == 4) {
+      HDK_LOAD_ROWS(int32_t, x == INT32_MIN ? HDK_NULL_BIGINT : static_cast<int64_t>(x) * 86400)
+    } else {
+      HDK_LOAD_ROWS(int16_t, x == INT16_MIN ? HDK_NULL_BIGINT : static_cast<int64_t>(x) * 86400)
+    }
   } else if (kind == HDK_COL_UNSIGNED) {
     switch (width) {
       case 1: HDK_LOAD_ROWS(uint8_t, static_cast<int64_t>(x)) break;
@@ -388,7 +394,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
     const int32_t* __restrict__ table = (nj == 1 && jn.table_idx == 0)
                                             ? reinterpret_cast<const int32_t*>(join_hash_tables)
                                             : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
-    const bool inner = jn.type == HDK_JOIN_INNER;
+    const bool inner = jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_SEMI;  // (SEMI: INNER over a first-row-wins table)
     const bool fused = jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED;
     if (fused) {
       if (j == 0) {

@@ -267,7 +267,8 @@ class TupleExchange:
     `step` is the rank's PreparedStep whose output buffer (GROUPBY_BUF[0]) is the OWNER table of this rank
     (`owner_table_quads` words); `rows_bound` is the same upper bound on a rank's rows on every rank."""
 
-    def __init__(self, step, world_size: int, rows_bound: int, owner_entry_count: Optional[int] = None, flags: int = 0):
+    def __init__(self, step, world_size: int, rows_bound: int, owner_entry_count: Optional[int] = None, flags: int = 0,
+                 group=None):
         import torch
         from ._lib import check, lib
         self.torch, self.L, self.check = torch, lib(), check
@@ -280,12 +281,46 @@ class TupleExchange:
         self.shape = A.ExchangeShape()
         check(self.L.hdk_hip_exchange_shape_for(C.byref(step.plan), C.byref(self.ko), self.world, self.owner_entries,
                                                 self.dev, C.byref(self.shape)))
+        # The tuple width comes from THIS rank's column statistics (8-byte tuples when key and argument fit 32 bits);
+        # the all-to-all has equal splits and the owner lays its inbox out with its own shape, so the ranks must agree:
+        # the widest tuple any rank needs is taken by all (HDK_HIP_LAUNCH_WIDE_TUPLES), then the whole shape is compared.
+        self._agree_on_shape(step, group)
         device = torch.device("cuda", self.dev)
         n = self.world * int(self.shape.segment_bytes)
         self.send = torch.empty(n, dtype=torch.uint8, device=device)
         self.recv = torch.empty(n, dtype=torch.uint8, device=device)
         self.ws_scatter = torch.empty(int(self.shape.scatter_workspace_bytes), dtype=torch.uint8, device=device)
         self.ws_aggregate = torch.empty(int(self.shape.aggregate_workspace_bytes), dtype=torch.uint8, device=device)
+
+    def _agree_on_shape(self, step, group=None):
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return
+        torch = self.torch
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+        def fields():
+            sh = self.shape
+            return [int(sh.tuple_bytes), int(sh.segment_bytes), int(sh.segment_header_bytes), int(sh.coarse_per_owner),
+                    int(sh.regions_log2), int(sh.sub_slab_tuples), int(sh.owner_entry_count), int(sh.rows_bound)]
+
+        def spread(vals):
+            hi = torch.tensor(vals, dtype=torch.int64, device=dev)
+            lo = hi.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            return hi.cpu().tolist(), lo.cpu().tolist()
+
+        hi, lo = spread(fields())
+        if hi[0] != lo[0]:  # some rank cannot narrow: nobody does (every rank takes this branch: hi / lo are global)
+            if int(self.shape.tuple_bytes) < hi[0]:
+                self.ko.flags |= A.LAUNCH_WIDE_TUPLES
+                self.check(self.L.hdk_hip_exchange_shape_for(C.byref(step.plan), C.byref(self.ko), self.world,
+                                                             self.owner_entries, self.dev, C.byref(self.shape)))
+            hi, lo = spread(fields())
+        if hi != lo:
+            raise RuntimeError(f"ranks disagree on the exchange shape (max {hi} / min {lo}): the same plan, row bound and "
+                               "owner entry count are required on every rank")
 
     @property
     def owner_table_quads(self) -> int:

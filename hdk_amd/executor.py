@@ -215,7 +215,7 @@ class PreparedStep:
             if info["kind"] != A.JOIN_ONE_TO_ONE:
                 continue
             cols = [ci for ci, (tn, cn, slot) in enumerate(cp.input_cols) if slot == ji + 1]
-            entries = info["max"] - info["min"] + 1
+            entries = info["entry_count"]
             stride = 1 + len(cols)
             if len(cols) > 7 or entries * stride * 8 > max_bytes:
                 continue
@@ -390,8 +390,10 @@ class Executor:
             d_chunks = self.mgr.to_device(raw, self.device_id)
             keep.append(d_chunks)
             jcs.append(A.JoinColumn(d_chunks.ptr, raw.nbytes, inner.num_fragments, inner.num_rows, info["elem_szs"][k]))
+            # JoinColumnTypeInfo as PerfectJoinHashTableBuilder fills it (Builders/PerfectHashTableBuilder.h:100-106):
+            # {size, range min, range max, the column's own NULL, is_bitwise_eq, range max + 1, column kind}
             tis.append(A.JoinColumnTypeInfo(info["elem_szs"][k], info["mins"][k], info["maxs"][k], info["null_vals"][k],
-                                            0, A.JC_SIGNED, 0))
+                                            info["uses_bw_eq"], info["col_types"][k], info["translated_null_build"]))
         return jcs, tis, keep
 
     def _build_join_table(self, cp: CompiledPlan, ji: int) -> DeviceBuffer:
@@ -402,7 +404,7 @@ class Executor:
         like the reference's NeedsOneToManyHash."""
         info = cp.join_infos[ji]
         kind = info["kind"]
-        key = (info["inner_table"], tuple(info["inner_cols"]), kind)
+        key = (info["inner_table"], tuple(info["inner_cols"]), kind, info["uses_bw_eq"], info["for_semi_join"])
         if key in self._join_cache:
             return self._join_cache[key]
         L = lib()
@@ -410,20 +412,32 @@ class Executor:
         inner = self.storage.get(info["inner_table"])
         jcs, tis, keep = self._join_columns(inner, info)
         d_err = self.mgr.to_device(np.zeros(1, dtype=np.int32), dev)
+        semi = info["for_semi_join"]
         if kind in (A.JOIN_ONE_TO_ONE, A.JOIN_ONE_TO_MANY):
-            entries = info["max"] - info["min"] + 1
+            # HashEntryInfo{max - min + 1 (+ 1 for kBwEq), bucket_normalization}; the table has the NORMALISED count of
+            # slots (initHashTableOnGpu, Builders/PerfectHashTableBuilder.h:82-130)
+            hei = A.HashEntryInfo(info["hash_entry_count"], info["bucket"])
+            entries = info["entry_count"]
             if entries <= 0 or entries > 2**31 - 1:
                 raise QueryMustRunOnCpu("join key range too large for a perfect hash table (TooManyHashEntries)")
             if kind == A.JOIN_ONE_TO_ONE:
                 table = self.mgr.alloc(entries * 4, dev)
                 check(L.hdk_hip_init_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, dev, None))
-                check(L.hdk_hip_fill_hash_join_buff(table.ptr, A.JOIN_INVALID_SLOT, 0, d_err.ptr, jcs[0], tis[0], dev, None))
+                if info["bucketized"]:
+                    # (the reference always calls the bucketized fill for a one-to-one table, with bucket 1 for
+                    # everything but a DATE key; the plain entry point is that call with bucket 1)
+                    check(L.hdk_hip_fill_hash_join_buff_bucketized(table.ptr, A.JOIN_INVALID_SLOT, semi, d_err.ptr, jcs[0],
+                                                                   tis[0], info["bucket"], dev, None))
+                else:
+                    check(L.hdk_hip_fill_hash_join_buff(table.ptr, A.JOIN_INVALID_SLOT, semi, d_err.ptr, jcs[0], tis[0],
+                                                        dev, None))
             else:
                 n32 = 2 * entries + inner.num_rows
                 table = self.mgr.alloc(n32 * 4, dev)
                 check(L.hdk_hip_init_hash_join_buff(table.ptr, n32, A.JOIN_INVALID_SLOT, dev, None))
-                check(L.hdk_hip_fill_one_to_many_hash_table(table.ptr, A.HashEntryInfo(entries, 1), A.JOIN_INVALID_SLOT,
-                                                            jcs[0], tis[0], dev, None))
+                fill = L.hdk_hip_fill_one_to_many_hash_table_bucketized if info["bucketized"] else \
+                    L.hdk_hip_fill_one_to_many_hash_table
+                check(fill(table.ptr, hei, A.JOIN_INVALID_SLOT, jcs[0], tis[0], dev, None))
         else:
             kc, w, entries = len(info["inner_cols"]), info["key_width"], info["entry_count"]
             jc_arr = (A.JoinColumn * kc)(*jcs)
@@ -433,7 +447,7 @@ class Executor:
             table = self.mgr.alloc(dict_bytes + (0 if one else (2 * entries + inner.num_rows) * 4), dev)
             check(L.hdk_hip_init_baseline_hash_join_buff(table.ptr, entries, kc, w, 1 if one else 0,
                                                          A.JOIN_INVALID_SLOT, dev, None))
-            check(L.hdk_hip_fill_baseline_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, 0, kc, w,
+            check(L.hdk_hip_fill_baseline_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, semi, kc, w,
                                                          1 if one else 0, d_err.ptr, jc_arr, ti_arr, dev, None))
             if not one:
                 check(L.hdk_hip_fill_one_to_many_baseline_hash_table(table.ptr + dict_bytes, table.ptr, entries,

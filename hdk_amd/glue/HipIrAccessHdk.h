@@ -33,6 +33,7 @@ struct HdkIrAccess {
     else if (t->isDecimal()) d.cls = TypeDesc::Decimal, d.scale = t->as<hdk::ir::DecimalType>()->scale();
     else if (t->isFloatingPoint()) d.cls = TypeDesc::Fp;
     else if (t->isTimestamp()) d.cls = TypeDesc::Timestamp, d.seconds = t->as<hdk::ir::TimestampType>()->unit() == hdk::ir::TimeUnit::kSecond;
+    else if (t->isDate()) d.cls = TypeDesc::Date, d.seconds = t->as<hdk::ir::DateType>()->unit() != hdk::ir::TimeUnit::kDay;  // IR/Type.h:63,277
     else if (t->isBoolean()) d.cls = TypeDesc::Boolean;
     else if (t->isExtDictionary()) d.cls = TypeDesc::Integer;  // dictionary ids
     return d;

@@ -47,14 +47,16 @@ struct QueryMustRunOnCpu : std::runtime_error {  // (inside HDK: the class of QE
 enum class ExprKind { ColumnVar, Constant, BinOper, UOper, Extract, Agg, Other };
 
 struct TypeDesc {
-  enum Cls { Integer, Decimal, Fp, Timestamp, Boolean, Other };
+  enum Cls { Integer, Decimal, Fp, Timestamp, Boolean, Date, Other };
   Cls cls{Other};
   int size{8};          // bytes of the physical value (logical size; fixed-width encodings are the column's business)
   bool nullable{true};
   int scale{0};         // Decimal
-  bool seconds{true};   // Timestamp: unit is seconds (TIMESTAMP(0))
+  bool seconds{true};   // Timestamp: unit is seconds (TIMESTAMP(0)); Date: false = TimeUnit::kDay (a 2- / 4-byte day count
+                        // that fixed_width_small_date_decode turns into epoch seconds, QE/ColumnIR.cpp:46-49)
   bool is_fp() const { return cls == Fp; }
-  bool integer_like() const { return cls == Integer || cls == Decimal || cls == Timestamp || cls == Boolean; }
+  bool integer_like() const { return cls == Integer || cls == Decimal || cls == Timestamp || cls == Boolean || cls == Date; }
+  bool date_in_days() const { return cls == Date && !seconds; }
 };
 
 // in-band NULL of a value of this type, widened the way the decoders hand it to the kernels: integers sign-extended
@@ -70,6 +72,7 @@ inline int64_t inline_null(const TypeDesc& t) {
     }
     return HDK_NULL_DOUBLE_BITS;
   }
+  if (t.date_in_days()) return INT64_MIN;  // FixedWidthSmallDate: the narrow NULL is decoded to NULL_BIGINT (QE/Codec.cpp:86-102)
   switch (t.size) {
     case 1: return INT8_MIN;
     case 2: return INT16_MIN;
@@ -83,8 +86,8 @@ inline int64_t result_null(const TypeDesc& t) { return t.is_fp() ? HDK_NULL_DOUB
 struct JoinTableDesc {
   int32_t kind{HDK_JOIN_ONE_TO_ONE};  // hdk_hip_join_kind: getHashType() and the table class
   int64_t min_key{0}, max_key{0};     // col_range_ (perfect tables)
-  int64_t bucket{0};                  // bucket_normalization
-  int64_t entry_count{0};             // one-to-many / keyed tables
+  int64_t bucket{0};                  // bucket_normalization (HashEntryInfo; 86400 for a DATE key, PerfectJoinHashTable.cpp:81)
+  int64_t entry_count{0};             // slots: HashEntryInfo::getNormalizedHashEntryCount() (perfect) / entry count (keyed)
   int32_t key_component_width{8};     // keyed tables
 };
 
@@ -94,7 +97,9 @@ struct UnitView {  // the members of RelAlgExecutionUnit the hot path reads (QE/
   std::vector<const Expr*> quals;  // simple_quals followed by quals
   struct JoinLevel {
     std::vector<const Expr*> quals;  // JoinCondition::quals of the nesting level
-    bool left{false};                // JoinCondition::type == JoinType::LEFT
+    int32_t type{HDK_JOIN_INNER};    // JoinCondition::type as hdk_hip_join_type (JoinType::INNER / LEFT / SEMI / ANTI, sqldefs.h:33)
+    JoinLevel() = default;
+    JoinLevel(std::vector<const Expr*> q, int32_t t) : quals(std::move(q)), type(t) {}
   };
   std::vector<JoinLevel> joins;        // join_quals
   std::vector<const Expr*> groupby;    // groupby_exprs ({nullptr} for a non-grouped unit in HDK: pass an empty vector)
@@ -189,6 +194,7 @@ class PlanExtractor {
   int sql_width(const Expr* e) const {
     const TypeDesc t = IR::type(e);
     if (t.is_fp()) return 0;
+    if (t.cls == TypeDesc::Date) return 8;  // a decoded DATE is 8 bytes wide whatever its storage
     return IR::kind(e) == ExprKind::Constant ? literal_width(e) : t.size;
   }
 
@@ -227,6 +233,7 @@ class PlanExtractor {
           default: code = HDK_OP_MOD; break;
         }
         if (out.cls == TypeDesc::Decimal) throw QueryMustRunOnCpu("decimal arithmetic is outside the fixed kernel library");
+        if (IR::type(IR::left(e)).cls == TypeDesc::Date || IR::type(r).cls == TypeDesc::Date) throw QueryMustRunOnCpu("date arithmetic is outside the fixed kernel library");
         push(x, code, out, r, (code == HDK_OP_ADD || code == HDK_OP_SUB || code == HDK_OP_MUL) ? *width : 0);
         return;
       }
@@ -234,7 +241,8 @@ class PlanExtractor {
         if (IR::extract_field(e) != hdk::ir::DateExtractField::kYear) throw QueryMustRunOnCpu("only extract(year) is in the fixed kernel library");
         const Expr* from = IR::extract_from(e);
         const TypeDesc ft = IR::type(from);
-        if (ft.cls != TypeDesc::Timestamp || !ft.seconds) throw QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) argument");
+        // (a DATE reaches the operator in epoch seconds whatever its storage: fixed_width_small_date_decode)
+        if (!((ft.cls == TypeDesc::Timestamp && ft.seconds) || ft.cls == TypeDesc::Date)) throw QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) or DATE argument");
         flatten(from, x, width);
         push(x, HDK_OP_EXTRACT_YEAR, IR::type(e), nullptr, 0);
         *width = 8;
@@ -369,17 +377,23 @@ class PlanExtractor {
         jn.outer_key = outer;
         jn.null_val = outer.null_val;
         jn.null_mode = op == hdk::ir::OpType::kBwEq ? HDK_JOIN_NULL_BITWISE : (outer.nullable ? HDK_JOIN_NULL_NULLABLE : HDK_JOIN_NULL_NONE);
-        jn.translated_null = table.max_key + 1;  // hash_join_idx_bitwise's slot for NULL (PerfectJoinHashTable.cpp)
+        if (op == hdk::ir::OpType::kBwEq) {
+          if (keyed) throw QueryMustRunOnCpu("null-safe equality on a keyed join table");
+          // what getHashJoinArgs hands the _bitwise probe for a NULL key (PerfectJoinHashTable.cpp:803-810):
+          // col_range.getIntMax() / bucket_normalization + 1 for a DATE key, getIntMax() + 1 otherwise
+          jn.translated_null = table.bucket > 1 ? table.max_key / table.bucket + 1 : table.max_key + 1;
+        }
       } else {
         jn.extra_keys[component - 1] = outer;
       }
       ++component;
     }
     jn.kind = table.kind;
-    jn.type = level.left ? HDK_JOIN_LEFT : HDK_JOIN_INNER;
+    if (level.type < HDK_JOIN_INNER || level.type > HDK_JOIN_ANTI) throw QueryMustRunOnCpu("join type outside INNER / LEFT / SEMI / ANTI");
+    jn.type = level.type;
     jn.min_key = table.min_key;
     jn.max_key = table.max_key;
-    jn.bucket = table.bucket;
+    jn.bucket = table.bucket > 1 ? table.bucket : 0;
     jn.table_idx = j;
     jn.key_component_count = component;
     jn.key_component_width = table.key_component_width;
@@ -434,8 +448,14 @@ class PlanExtractor {
       const bool float_acc = at.size == 4 && d.agg != HDK_AGG_COUNT;
       d.arg_is_fp = float_acc ? HDK_FP_SLOT_FLOAT : HDK_FP_SLOT_DOUBLE;
       d.null_val = float_acc ? inline_null(at) : HDK_NULL_DOUBLE_BITS;
+    } else if (d.agg == HDK_AGG_MIN || d.agg == HDK_AGG_MAX) {
+      // domain-range-equivalent aggregates keep the ARGUMENT type's NULL: the slot starts at inline_int_null_value(arg
+      // type) sign-extended (get_agg_initial_val, QE/OutputBufferInitialization.cpp:190-258) and the skip value is the
+      // same number (QE/TargetExprBuilder.cpp:429-445); `at` is the type of the whole argument expression (BIGINT for
+      // anything computed)
+      d.null_val = inline_null(at);
     } else {
-      d.null_val = INT64_MIN;  // (a 4-byte padded slot narrows it: make_plan knows the slot width)
+      d.null_val = INT64_MIN;  // SUM / AVG over integers are BIGINT (a 4-byte padded slot narrows it: make_plan knows the slot width)
     }
     if (d.agg == HDK_AGG_COUNT) d.arg_is_fp = at.is_fp() ? HDK_FP_SLOT_DOUBLE : HDK_FP_SLOT_NONE, d.null_val = d.arg.null_val;
     if (d.agg == HDK_AGG_SINGLE_VALUE) {

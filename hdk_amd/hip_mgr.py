@@ -64,6 +64,16 @@ class HipMgr:
         check(self._lib.hdk_hip_mgr_copy_host_to_device_async(device_ptr, _host_ptr(host), num_bytes,
                                                               device_num))
 
+    def allocatePinnedHostMem(self, num_bytes) -> int:
+        """CudaMgr::allocatePinnedHostMem (CudaMgr/CudaMgr.h:120): page-locked host memory, the source an asynchronous
+        host-to-device copy needs to really be asynchronous."""
+        p = C.c_void_p()
+        check(self._lib.hdk_hip_mgr_allocate_pinned_host_mem(num_bytes, C.byref(p)))
+        return p.value
+
+    def freePinnedHostMem(self, host_ptr):
+        check(self._lib.hdk_hip_mgr_free_pinned_host_mem(host_ptr))
+
     def synchronizeStream(self, device_num):
         check(self._lib.hdk_hip_mgr_synchronize_stream(device_num))
 
@@ -132,6 +142,13 @@ class HipMgr:
         if arr.nbytes:
             self.copyHostToDevice(buf.ptr, arr, arr.nbytes, device_num)
         return buf
+
+    def pinned_array(self, shape, dtype):
+        """A numpy array over pinned host memory + the pointer to hand to freePinnedHostMem."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.allocatePinnedHostMem(max(n, 1))
+        arr = np.frombuffer((C.c_char * max(n, 1)).from_address(ptr), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        return arr, ptr
 
     def to_host(self, device_ptr, nbytes, device_num, dtype=np.int64) -> np.ndarray:
         out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)

@@ -22,11 +22,12 @@ class QueryMustRunOnCpu(Exception):
 @dataclass(frozen=True)
 class Type:
     """Subset of hdk::ir::Type (omniscidb/IR/Type.h): fixed-width, in-band-null columns."""
-    kind: str  # 'int' | 'fp' | 'decimal' | 'timestamp' | 'dict' | 'bool'
+    kind: str  # 'int' | 'fp' | 'decimal' | 'timestamp' | 'date' | 'dict' | 'bool'
     size: int  # bytes
     nullable: bool = True
     scale: int = 0  # decimal scale
-    unit: str = "s"  # timestamp unit
+    unit: str = "s"  # timestamp / date unit; a DATE in days (unit 'd', 2 or 4 bytes: Arrow date32, hdk::ir::DateType with
+    #                  TimeUnit::kDay) is read as epoch seconds by fixed_width_small_date_decode (QE/ColumnIR.cpp:46-49)
 
     @property
     def is_fp(self):
@@ -34,7 +35,16 @@ class Type:
 
     @property
     def is_integer_like(self):
-        return self.kind in ("int", "decimal", "timestamp", "dict", "bool")
+        return self.kind in ("int", "decimal", "timestamp", "date", "dict", "bool")
+
+    @property
+    def is_date_in_days(self):
+        return self.kind == "date" and self.unit == "d"
+
+    def logical(self) -> "Type":
+        """The type expressions see (hdk::ir::Type::canonicalize): a DATE in days is an 8-byte DATE in seconds once
+        decoded, with NULL_BIGINT for the column's narrow NULL (FixedWidthSmallDate, QE/Codec.cpp:86-102)."""
+        return Type("date", 8, self.nullable, 0, "s") if self.is_date_in_days else self
 
     def with_nullable(self, n):
         return Type(self.kind, self.size, n, self.scale, self.unit)
@@ -66,6 +76,9 @@ INT64 = int_type(8)
 INT32 = int_type(4)
 INT16 = int_type(2)
 INT8 = int_type(1)
+DATE32 = Type("date", 4, True, 0, "d")  # Arrow date32: days, 4 bytes (ArrowStorageUtils.cpp:899-914)
+DATE16 = Type("date", 2, True, 0, "d")
+DATE64 = Type("date", 8, True, 0, "s")  # a DATE held in seconds: plain integer decode, still bucketized by day
 FP64 = Type("fp", 8)
 FP32 = Type("fp", 4)
 
@@ -188,7 +201,10 @@ class JoinSpec:
     inner_table: str
     outer_key: Union[Expr, Sequence[Expr]]
     inner_col: Union[str, Sequence[str]]
-    type: str = "inner"  # inner | left
+    type: str = "inner"  # inner | left | semi | anti  (JoinType, Shared/sqldefs.h:33)
+    # outer_key IS NOT DISTINCT FROM inner_col (hdk::ir::OpType::kBwEq): NULL keys match NULL keys -- the build files
+    # them under a translated value and the probe is hash_join_idx_bitwise (PerfectJoinHashTable.cpp:798-816)
+    null_safe: bool = False
 
     @property
     def outer_keys(self) -> list:

@@ -100,8 +100,10 @@ class _Binder:
     def type_of(self, e: Expr) -> Type:
         if isinstance(e, ColRef):
             slot, _, col = self.resolve(e)
-            # a LEFT join without a match yields NULL for every column of the inner table
-            return col.type.with_nullable(True) if self._left_joined(slot) else col.type
+            # a LEFT join without a match yields NULL for every column of the inner table; a DATE in days is an 8-byte
+            # DATE in seconds once decoded (Type.logical)
+            lt = col.type.logical()
+            return lt.with_nullable(True) if self._left_joined(slot) else lt
         if isinstance(e, Lit):
             return Type("fp", 8, False) if isinstance(e.value, float) else Type("int", 8, False)
         if isinstance(e, BinOp):
@@ -109,6 +111,8 @@ class _Binder:
             nullable = lt.nullable or rt.nullable
             if lt.kind == "decimal" or rt.kind == "decimal":
                 raise QueryMustRunOnCpu("decimal arithmetic is outside the fixed kernel library")
+            if lt.kind == "date" or rt.kind == "date":
+                raise QueryMustRunOnCpu("date arithmetic is outside the fixed kernel library")
             if lt.is_fp or rt.is_fp:
                 if e.op == "%":
                     raise QueryMustRunOnCpu("fp modulo")
@@ -130,7 +134,8 @@ class _Binder:
                 return Range("invalid", has_nulls=has_nulls)
             if col.type.is_fp:
                 return Range("fp", st.min, st.max, 0, has_nulls)
-            return Range("int", st.min, st.max, 0, has_nulls)
+            # a DATE column's range carries the day bucket (getLeafColumnRange, QE/ExpressionRange.cpp:553-558)
+            return Range("int", st.min, st.max, 86400 if col.type.kind == "date" else 0, has_nulls)
         if isinstance(e, Lit):
             if isinstance(e.value, float):
                 return Range("fp", e.value, e.value)
@@ -217,8 +222,8 @@ def _flatten(b: _Binder, e: Expr):
     if isinstance(e, ExtractYear):
         l0, steps = _flatten(b, e.arg)
         at = b.type_of(e.arg)
-        if at.kind != "timestamp" or at.unit != "s":
-            raise QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) argument")
+        if at.kind not in ("timestamp", "date") or at.unit != "s":
+            raise QueryMustRunOnCpu("extract(year) needs a TIMESTAMP(0) or DATE argument")
         return l0, steps + [(A.OP_EXTRACT_YEAR, None, b.type_of(e))]
     if isinstance(e, Cast):
         l0, steps = _flatten(b, e.arg)
@@ -372,30 +377,43 @@ def _expr_refs_inner(b: "_Binder", e) -> bool:
     return False
 
 
-def _inner_keys_unique(inner: Table, cols: List[str]) -> bool:
-    """Would the one-to-one fill succeed (no duplicate non-NULL key)?  The reference finds out by
-    trying (fill_one_to_one_hashtable returns -1 -> NeedsOneToManyHash, PerfectHashTableBuilder.h:134-141);
-    the storage layer answers from the data so that the plan names the table kind up front."""
+def _inner_keys_unique(inner: Table, cols: List[str], nulls_match: bool = False, bucket: int = 1) -> bool:
+    """Would the one-to-one fill succeed (no two rows in one slot)?  The reference finds out by trying
+    (fill_one_to_one_hashtable returns -1 -> NeedsOneToManyHash, PerfectHashTableBuilder.h:134-141); the storage layer
+    answers from the data so that the plan names the table kind up front.  For a perfect table (one key column) the slots
+    are worked out exactly as the fill does (fill_hash_join_buff_impl, HashJoinRuntime.cpp:197-240): decoded element,
+    NULL rows dropped -- or, for a kBwEq join, filed under max + 1 --, slot = (elem - min) / bucket."""
     cache = inner.__dict__.setdefault("_unique_keys_cache", {})
-    key = tuple(cols)
+    key = tuple(cols) + (bool(nulls_match), int(bucket))
     if key not in cache:
         arrs = [np.concatenate(inner.columns[c].fragments) if inner.columns[c].fragments else np.zeros(0, np.int64)
                 for c in cols]
-        keep = np.ones(len(arrs[0]), dtype=bool)
-        for c, a in zip(cols, arrs):
-            keep &= a != inner.columns[c].type.null_value()
         if len(cols) == 1:
-            _, cnt = np.unique(arrs[0][keep], return_counts=True)
+            c0 = inner.columns[cols[0]]
+            st = c0.table_stats()
+            a0 = arrs[0].astype(np.int64)
+            isn = a0 == c0.type.null_value()
+            if c0.type.is_date_in_days:
+                a0 = a0 * 86400
+            if nulls_match:
+                a0 = np.where(isn, int(st.max) + 1, a0)
+            else:
+                a0 = a0[~isn]
+            slots = (a0 - int(st.min)) // max(int(bucket), 1)
+            _, cnt = np.unique(slots, return_counts=True)
         else:
+            keep = np.ones(len(arrs[0]), dtype=bool)
+            for c, a in zip(cols, arrs):
+                keep &= a != inner.columns[c].type.null_value()
             m = np.stack([a[keep].astype(np.int64) for a in arrs], axis=1)
             _, cnt = np.unique(m, axis=0, return_counts=True)
         cache[key] = int(cnt.max()) if cnt.size else 1  # largest matching set
     return cache[key] <= 1
 
 
-def _inner_max_matches(inner: Table, cols: List[str]) -> int:
-    _inner_keys_unique(inner, cols)
-    return inner.__dict__["_unique_keys_cache"][tuple(cols)]
+def _inner_max_matches(inner: Table, cols: List[str], nulls_match: bool = False, bucket: int = 1) -> int:
+    _inner_keys_unique(inner, cols, nulls_match, bucket)
+    return inner.__dict__["_unique_keys_cache"][tuple(cols) + (bool(nulls_match), int(bucket))]
 
 
 def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
@@ -418,6 +436,8 @@ def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
         st = icol.table_stats()
         if st.min is None:
             raise QueryMustRunOnCpu("empty join inner table")
+        if j.type not in ("inner", "left", "semi", "anti"):
+            raise QueryMustRunOnCpu(f"join type {j.type!r}")
         jn = p.joins[ji]
         jn.outer_key = make_expr(b, okeys[0])
         for k in range(1, len(okeys)):
@@ -428,14 +448,28 @@ def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
         if okt.is_fp:
             raise QueryMustRunOnCpu("join keys must be integers")
         jn.null_val = A.to_i64(okt.null_as_int64_or_double_bits())
-        jn.null_mode = A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE
-        jn.bucket = 0
-        jn.type = A.JOIN_INNER if j.type == "inner" else A.JOIN_LEFT
+        bw_eq = bool(j.null_safe)
+        # a DATE key is bucketized by day: bucket_normalization = the range's bucket (get_bucketized_hash_entry_info,
+        # QE/JoinHashTable/PerfectJoinHashTable.cpp:45-85; the bucket comes from getLeafColumnRange)
+        is_date = icol.type.kind == "date"
+        if is_date != (okt.kind == "date"):
+            raise QueryMustRunOnCpu("a DATE join key needs a DATE on both sides")
+        bucket = 86400 if is_date else 1
+        # key_col nullable or kBwEq: the probe gets the NULL (getHashJoinArgs, PerfectJoinHashTable.cpp:798-801) and is the
+        # _bitwise form for kBwEq, else _nullable for a nullable key (codegenSlot, :1018-1031)
+        jn.null_mode = A.JOIN_NULL_BITWISE if bw_eq else (A.JOIN_NULL_NULLABLE if okt.nullable else A.JOIN_NULL_NONE)
+        jn.bucket = bucket if is_date else 0
+        jn.type = {"inner": A.JOIN_INNER, "left": A.JOIN_LEFT, "semi": A.JOIN_SEMI, "anti": A.JOIN_ANTI}[j.type]
+        semi = j.type in ("semi", "anti")  # for_semi_anti_join: the fill lets the first row of a key win
         jn.table_idx = ji
-        range_entries = int(st.max) - int(st.min) + 1
+        # HashEntryInfo: hash_entry_count = max - min + 1 (+ 1 slot for the NULLs of a kBwEq join), normalised by the bucket
+        hash_entry_count = int(st.max) - int(st.min) + 1 + (1 if bw_eq else 0)
+        range_entries = -(-hash_entry_count // bucket)  # getNormalizedHashEntryCount (HashJoinRuntime.h:46-55)
         keyed = len(okeys) > 1 or range_entries > 2**31 - 1  # TooManyHashEntries -> keyed table
-        unique = _inner_keys_unique(inner, icols)
+        unique = semi or _inner_keys_unique(inner, icols, bw_eq and not keyed, 1 if keyed else bucket)
         if keyed:
+            if bw_eq or is_date:
+                raise QueryMustRunOnCpu("null-safe / DATE keys on a keyed join table are outside the fixed kernel library")
             jn.kind = A.JOIN_KEYED_ONE_TO_ONE if unique else A.JOIN_KEYED_ONE_TO_MANY
             # BaselineJoinHashTable::getKeyComponentWidth: 8 if any key column is 8 bytes wide
             jn.key_component_width = 8 if any(inner.columns[c].type.size == 8 for c in icols) or \
@@ -449,6 +483,21 @@ def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
             jn.key_component_count = 1
             jn.key_component_width = 8
             jn.entry_count = range_entries
+            if bw_eq:
+                if int(st.max) >= 2**63 - 1:
+                    raise QueryMustRunOnCpu("Cannot translate null value for kBW_EQ")  # PerfectJoinHashTable.cpp:165-168
+                # what the probe is handed for a NULL key (getHashJoinArgs, PerfectJoinHashTable.cpp:803-810): max + 1, and
+                # for a DATE key max / bucket + 1 -- while the BUILD files NULL rows under max + 1 in both cases
+                # (JoinColumnTypeInfo::translated_null_val, Builders/PerfectHashTableBuilder.h:100-106).  For a DATE key the
+                # two differ, and the probe's value normally fails its own `key >= min_key` test: NULLs then never match.
+                # Restated as it is; a translated value whose slot would fall outside the table is refused.
+                tr = int(st.max) + 1
+                if is_date:
+                    q_ = abs(int(st.max)) // bucket  # C++ integer division truncates toward zero
+                    tr = (q_ if int(st.max) >= 0 else -q_) + 1
+                if tr >= int(st.min) and (tr - int(st.min)) // bucket >= range_entries:
+                    raise QueryMustRunOnCpu("translated NULL key falls outside the join table")
+                jn.translated_null = tr
         join_infos.append({"inner_table": inner.name, "inner_col": icols[0], "inner_cols": list(icols),
                            "min": int(st.min), "max": int(st.max), "null_val": icol.type.null_value(),
                            "elem_sz": icol.type.size,
@@ -456,9 +505,16 @@ def _compile_joins_and_quals(b: "_Binder", q: QueryUnit, p: A.Plan):
                            "elem_szs": [inner.columns[c].type.size for c in icols],
                            "mins": [int(inner.columns[c].table_stats().min) for c in icols],
                            "maxs": [int(inner.columns[c].table_stats().max) for c in icols],
+                           "col_types": [A.JC_SMALL_DATE if inner.columns[c].type.is_date_in_days else A.JC_SIGNED
+                                         for c in icols],
                            "kind": int(jn.kind), "entry_count": int(jn.entry_count),
                            "key_width": int(jn.key_component_width), "num_elems": inner.num_rows,
-                           "max_matches": _inner_max_matches(inner, icols)})
+                           # the build's arguments (PerfectHashTableBuilder.h:87-130): HashEntryInfo, uses_bw_eq with its
+                           # translated NULL (always max + 1), the day bucket of a DATE key, first-row-wins fill
+                           "hash_entry_count": hash_entry_count, "bucket": bucket, "bucketized": bool(is_date),
+                           "uses_bw_eq": 1 if bw_eq else 0, "translated_null_build": int(st.max) + 1,
+                           "for_semi_join": 1 if semi else 0,
+                           "max_matches": 1 if semi else _inner_max_matches(inner, icols, bw_eq and not keyed, 1 if keyed else bucket)})
     # filter: a plain conjunction of comparisons keeps the per-conjunct staging; anything with OR / NOT becomes a
     # postfix program over the comparisons (hdk_hip_plan::filter_ops), evaluated at one stage
     leaves: List[Cmp] = []
@@ -522,16 +578,24 @@ def _fill_cols(storage: ArrowStorage, b: "_Binder", p: A.Plan):
         c.buf_idx = i
         c.table = slot
         c.width = ct.size
-        if ct.is_fp:
-            c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
-        else:
-            c.kind = A.COL_INT
-            # ChunkStats of the column (the reference's planner reads them through getExpressionRange,
-            # QE/ExpressionRange.cpp): lets multi-pass strategies move the column in fewer bytes than its width
-            st = storage.get(tn).columns[cn].table_stats()
-            if st.min is not None and st.max is not None and -(2**63) <= int(st.min) <= int(st.max) < 2**63:
-                c.has_stats, c.has_nulls = 1, 1 if st.has_nulls else 0
-                c.min_val, c.max_val = int(st.min), int(st.max)
+        _fill_col_kind(storage, tn, cn, ct, c)
+
+
+def _fill_col_kind(storage, tn, cn, ct, c):
+    if ct.is_fp:
+        c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
+    elif ct.is_date_in_days:
+        if ct.size not in (2, 4):
+            raise QueryMustRunOnCpu("a DATE in days is 2 or 4 bytes wide")
+        c.kind = A.COL_SMALL_DATE  # get_col_decoder -> FixedWidthSmallDate (QE/ColumnIR.cpp:46-49)
+    else:
+        c.kind = A.COL_INT
+        # ChunkStats of the column (the reference's planner reads them through getExpressionRange,
+        # QE/ExpressionRange.cpp): lets multi-pass strategies move the column in fewer bytes than its width
+        st = storage.get(tn).columns[cn].table_stats()
+        if st.min is not None and st.max is not None and -(2**63) <= int(st.min) <= int(st.max) < 2**63:
+            c.has_stats, c.has_nulls = 1, 1 if st.has_nulls else 0
+            c.min_val, c.max_val = int(st.min), int(st.max)
 
 
 def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
@@ -589,7 +653,7 @@ def compile_projection(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
         dic = b.resolve(src)[2].dictionary if isinstance(src, ColRef) else None
         name = t.name or (src.name if isinstance(src, ColRef) else f"expr_{ti}")
         rt = tt if w == tt.size else Type("fp" if tt.is_fp else "int", 8, tt.nullable)
-        if isinstance(src, ColRef) and tt.kind in ("decimal", "timestamp", "dict", "bool") and w == tt.size:
+        if isinstance(src, ColRef) and tt.kind in ("decimal", "timestamp", "date", "dict", "bool") and w == tt.size:
             rt = tt
         out_cols.append(OutCol(name, "proj", rt, ti, dictionary=dic,
                                scale=(tt.scale if tt.kind == "decimal" else 0)))
@@ -896,16 +960,7 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
         c.buf_idx = i
         c.table = slot
         c.width = ct.size
-        if ct.is_fp:
-            c.kind = A.COL_DOUBLE if ct.size == 8 else A.COL_FLOAT
-        else:
-            c.kind = A.COL_INT
-            # ChunkStats of the column (the reference's planner reads them through getExpressionRange,
-            # QE/ExpressionRange.cpp): lets multi-pass strategies move the column in fewer bytes than its width
-            st = storage.get(tn).columns[cn].table_stats()
-            if st.min is not None and st.max is not None and -(2**63) <= int(st.min) <= int(st.max) < 2**63:
-                c.has_stats, c.has_nulls = 1, 1 if st.has_nulls else 0
-                c.min_val, c.max_val = int(st.min), int(st.max)
+        _fill_col_kind(storage, tn, cn, ct, c)
     return CompiledPlan(plan=p, query=q, init_vals=np.array(init_vals, dtype=np.int64),
                         slot_widths=slot_widths, input_cols=list(b.cols),
                         inner_tables=[t.name for t in b.inner], join_infos=join_infos,

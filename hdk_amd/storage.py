@@ -85,6 +85,10 @@ def _stats(arr: np.ndarray, t: Type) -> ChunkStats:
         return ChunkStats(None, None, has_nulls)
     if t.is_fp:
         return ChunkStats(float(valid.min()), float(valid.max()), has_nulls)
+    if t.is_date_in_days:
+        # the statistics of a DATE-in-days chunk are kept in epoch seconds (DateDaysEncoder::updateStatsEncoded,
+        # omniscidb/DataMgr/DateDaysEncoder.h:94-120): what the expression ranges and the join tables are sized from
+        return ChunkStats(int(valid.min()) * 86400, int(valid.max()) * 86400, has_nulls)
     return ChunkStats(int(valid.min()), int(valid.max()), has_nulls)
 
 
@@ -128,9 +132,10 @@ def _arrow_to_fixed(col, field_type):
         ht = Type("timestamp", 8, True, unit=t.unit)
         arr = col.cast(pa.int64()).fill_null(ht.null_value())
     elif pa.types.is_date32(t):
-        # reference stores DATE as int64 seconds (ArrowStorageUtils.cpp date conversion)
-        ht = Type("timestamp", 8, True, unit="s")
-        arr = pc.multiply(col.cast(pa.int32()).cast(pa.int64()), 86400).fill_null(ht.null_value())
+        # date32 stays a 4-byte day count with an in-band NULL (ArrowStorageUtils.cpp:899-914: size 4 ->
+        # replaceNullValuesImpl<int32_t>); the scan reads it as epoch seconds (fixed_width_small_date_decode)
+        ht = Type("date", 4, True, unit="d")
+        arr = col.cast(pa.int32()).fill_null(ht.null_value())
     elif pa.types.is_decimal(t):
         if t.precision > 18:
             raise TypeError("decimal precision > 18 is not supported (HDK decimals are int64)")

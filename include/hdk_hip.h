@@ -157,7 +157,11 @@ enum hdk_hip_col_kind {
   HDK_COL_INT = 0,      /* fixed_width_int_decode: sign-extend 1/2/4/8 bytes */
   HDK_COL_UNSIGNED = 1, /* fixed_width_unsigned_decode (dictionary ids of 1/2 bytes) */
   HDK_COL_FLOAT = 2,    /* fixed_width_float_decode, widened to double */
-  HDK_COL_DOUBLE = 3    /* fixed_width_double_decode */
+  HDK_COL_DOUBLE = 3,   /* fixed_width_double_decode */
+  HDK_COL_SMALL_DATE = 4 /* fixed_width_small_date_decode (QE/DecodersImpl.h:151-159; chosen by get_col_decoder for a DATE
+                           stored in days, QE/ColumnIR.cpp:46-49): a 2- or 4-byte day count, read as epoch SECONDS
+                           (x 86400); the column's narrow NULL (INT16_MIN / INT32_MIN, QE/Codec.cpp:86-87) becomes
+                           NULL_BIGINT.  Read by the plan interpreters only (no specialised kernel takes such a column) */
 };
 
 typedef struct hdk_hip_col {
@@ -257,15 +261,30 @@ enum hdk_hip_join_kind {
   HDK_JOIN_KEYED_ONE_TO_ONE = 3,
   HDK_JOIN_KEYED_ONE_TO_MANY = 4
 };
-enum hdk_hip_join_type { HDK_JOIN_INNER = 0, HDK_JOIN_LEFT = 1 };
+enum hdk_hip_join_type {
+  HDK_JOIN_INNER = 0,
+  HDK_JOIN_LEFT = 1,
+  /* JoinType::SEMI / ANTI (Shared/sqldefs.h:33; JoinLoop::codegen, QE/LoopControlFlow/JoinLoop.cpp:254-262): the table
+   * is a one-to-one table filled with for_semi_join = 1 (first row of a key wins, duplicates are not an error:
+   * fill_hashtable_for_semi_join, JoinHashImpl.h:68-77).  SEMI runs the rest of the row when the probe finds a slot
+   * (exactly like INNER over that table: every outer row at most once), ANTI when it finds none (`slot_lookup_result
+   * < 0`); an ANTI join's inner columns are never read. */
+  HDK_JOIN_SEMI = 2,
+  HDK_JOIN_ANTI = 3
+};
 enum hdk_hip_join_null { HDK_JOIN_NULL_NONE = 0, HDK_JOIN_NULL_NULLABLE = 1, HDK_JOIN_NULL_BITWISE = 2 };
 typedef struct hdk_hip_join {
   hdk_hip_expr outer_key;
   int64_t min_key;
   int64_t max_key;
   int64_t null_val;
-  int64_t translated_null; /* hash_join_idx_bitwise */
-  int64_t bucket;          /* bucket_normalization; 0/1 => plain */
+  int64_t translated_null; /* [bucketized_]hash_join_idx_bitwise: the key a NULL probes with -- what getHashJoinArgs passes
+                              (QE/JoinHashTable/PerfectJoinHashTable.cpp:803-810): max_key + 1, or for a bucketized (DATE)
+                              key max_key / bucket + 1 */
+  int64_t bucket;          /* bucket_normalization (DATE keys: 86400, PerfectJoinHashTable.cpp:81); 0/1 => plain.  The
+                              table then has ceil((max - min + 1 [+ 1 when NULLs match]) / bucket) slots
+                              (HashEntryInfo::getNormalizedHashEntryCount, HashJoinRuntime.h:46-55) and `entry_count` of a
+                              one-to-many table is that number */
   int32_t kind;            /* hdk_hip_join_kind */
   int32_t type;            /* hdk_hip_join_type */
   int32_t null_mode;       /* hdk_hip_join_null */
@@ -428,6 +447,11 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
                                                   the batched interpreter as the consumer the pre-pass (32 B/row of traffic)
                                                   costs more than the locality returns (C3: 2.2 + 4.2 ms against 5.0 ms) */
 #define HDK_HIP_LAUNCH_NO_CLUSTER_PROBES 512u   /* overrides the flag above */
+#define HDK_HIP_LAUNCH_WIDE_TUPLES 1024u       /* multi-pass strategies: do NOT narrow tuples from the column statistics (8-byte
+                                                  tuples of the radix-partitioned group-by / the tuple exchange).  The
+                                                  statistics are per rank: ranks of one exchange must agree on the tuple
+                                                  width, so a rank whose columns would allow 8 bytes sets this when another
+                                                  rank's do not (hdk_amd/distributed.py: TupleExchange) */
 #define HDK_HIP_LAUNCH_FORCE_PARTITIONED 16u   /* take the radix-partitioned group-by whenever the plan shape
                                                   allows it, whatever the table size (testing) */
 #define HDK_HIP_LAUNCH_PLAN_RESIDENT 32u       /* the head of `workspace` already holds this plan (an earlier
@@ -569,7 +593,9 @@ typedef struct hdk_hip_exchange_shape {
   uint32_t regions_log2;       /* regions of the owner's table per coarse slab = 1 << this */
   uint32_t reserved_;
   uint64_t sub_slab_tuples;    /* capacity of one (coarse slab, XCD) sub-slab */
-  uint64_t segment_header_bytes;
+  uint64_t segment_header_bytes; /* header: uint32 tuples per (coarse slab, XCD) sub-slab, a flag word (0 = complete) and a
+                                    tag word (tuple bytes | coarse_per_owner << 8) that the owner checks against its own
+                                    shape: a sender that chose another tuple width makes the exchange INCOMPLETE */
   uint64_t segment_bytes;      /* one rank -> owner segment: header + coarse_per_owner x 8 sub-slabs; `send` and `recv`
                                   are num_owners segments each */
   uint64_t rows_bound;         /* ko->total_rows the shape was made for */

@@ -196,6 +196,13 @@ int64_t orc_fixed_width_unsigned_decode(const int8_t* byte_stream, int32_t byte_
   }
 }
 
+/* fixed_width_small_date_decode: QE/DecodersImpl.h:151-159 */
+int64_t orc_fixed_width_small_date_decode(const int8_t* byte_stream, int32_t byte_width, int32_t null_val,
+                                          int64_t ret_null_val, int64_t pos) {
+  const int64_t val = orc_fixed_width_int_decode(byte_stream, byte_width, pos);
+  return val == null_val ? ret_null_val : val * 86400;
+}
+
 float orc_fixed_width_float_decode(const int8_t* byte_stream, int64_t pos) {
   float v;
   memcpy(&v, &byte_stream[pos * sizeof(float)], sizeof(float));
@@ -764,6 +771,17 @@ int64_t orc_hash_join_idx_nullable(const int32_t* hash_buff, int64_t key, int64_
                                    int64_t max_key, int64_t null_val) {
   return key != null_val ? orc_hash_join_idx(hash_buff, key, min_key, max_key) : -1;
 }
+int64_t orc_bucketized_hash_join_idx_nullable(const int32_t* hash_buff, int64_t key, int64_t min_key, int64_t max_key,
+                                              int64_t null_val, int64_t bucket_normalization) { /* :312-323 */
+  return key != null_val ? orc_bucketized_hash_join_idx(hash_buff, key, min_key, max_key, bucket_normalization) : -1;
+}
+int64_t orc_bucketized_hash_join_idx_bitwise(const int32_t* hash_buff, int64_t key, int64_t min_key, int64_t max_key,
+                                             int64_t null_val, int64_t translated_val,
+                                             int64_t bucket_normalization) { /* :334-350 */
+  return key != null_val
+             ? orc_bucketized_hash_join_idx(hash_buff, key, min_key, max_key, bucket_normalization)
+             : orc_bucketized_hash_join_idx(hash_buff, translated_val, min_key, translated_val, bucket_normalization);
+}
 int64_t orc_hash_join_idx_bitwise(const int32_t* hash_buff, int64_t key, int64_t min_key,
                                   int64_t max_key, int64_t null_val, int64_t translated_val) {
   return key != null_val ? orc_hash_join_idx(hash_buff, key, min_key, max_key)
@@ -1103,6 +1121,16 @@ static int64_t keyed_slot_for_insert(int8_t* hash_buff, int64_t entry_count, con
 int orc_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
                                      size_t key_component_count, int32_t key_component_width,
                                      const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti) {
+  return orc_fill_baseline_hash_join_buff_semi(hash_buff, entry_count, invalid_slot_val, 0, key_component_count,
+                                               key_component_width, cols, ti);
+}
+
+/* for_semi_join: write_baseline_hash_slot_for_semi_join (HashJoinRuntime.cpp:480-507) -- the first row of a key
+ * keeps the slot, later rows of the key are not an error */
+int orc_fill_baseline_hash_join_buff_semi(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                          int32_t for_semi_join, size_t key_component_count,
+                                          int32_t key_component_width, const hdk_hip_join_column* cols,
+                                          const hdk_hip_join_column_type_info* ti) {
   const size_t entry_bytes = (key_component_count + 1) * (size_t)key_component_width;
   const size_t n = cols[0].num_elems;
   for (size_t row = 0; row < n; ++row) {
@@ -1113,10 +1141,16 @@ int orc_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int
     if (slot < 0) return -2;
     int8_t* val = hash_buff + (size_t)slot * entry_bytes + key_component_count * (size_t)key_component_width;
     if (key_component_width == 4) {
-      if (*(int32_t*)val != invalid_slot_val) return -1;
+      if (*(int32_t*)val != invalid_slot_val) {
+        if (for_semi_join) continue;
+        return -1;
+      }
       *(int32_t*)val = (int32_t)row;
     } else {
-      if (*(int64_t*)val != (int64_t)invalid_slot_val) return -1;
+      if (*(int64_t*)val != (int64_t)invalid_slot_val) {
+        if (for_semi_join) continue;
+        return -1;
+      }
       *(int64_t*)val = (int64_t)row;
     }
   }
@@ -1184,6 +1218,9 @@ static inline int64_t load_col(const orc_row_ctx* c, int32_t col_idx) {
   const int64_t row = col->table == 0 ? c->pos : c->join_row[col->table - 1];
   const int8_t* buf = c->cols[col->buf_idx];
   switch (col->kind) {
+    case HDK_COL_SMALL_DATE: /* FixedWidthSmallDate::codegenDecode, QE/Codec.cpp:86-102 */
+      return orc_fixed_width_small_date_decode(buf, col->width, col->width == 4 ? INT32_MIN : INT16_MIN, INT64_MIN,
+                                               row);
     case HDK_COL_UNSIGNED:
       return orc_fixed_width_unsigned_decode(buf, col->width, row);
     case HDK_COL_FLOAT:
@@ -1694,14 +1731,18 @@ static inline const void* join_table_ptr(const hdk_hip_plan* p, const hdk_hip_jo
                                                                           : join_hash_tables[jn->table_idx]);
 }
 
+/* PerfectJoinHashTable::codegenSlot picks the function by name: "bucketized_" for a DATE key, then "_bitwise" or
+ * "_nullable" (QE/JoinHashTable/PerfectJoinHashTable.cpp:1018-1031) */
 static int64_t perfect_probe(const hdk_hip_join* jn, const int32_t* table, int64_t key) {
   if (jn->bucket > 1) {
-    return (jn->null_mode == HDK_JOIN_NULL_NONE || key != jn->null_val)
-               ? orc_bucketized_hash_join_idx(table, key, jn->min_key, jn->max_key, jn->bucket)
-               : (jn->null_mode == HDK_JOIN_NULL_BITWISE
-                      ? orc_bucketized_hash_join_idx(table, jn->translated_null, jn->min_key,
-                                                     jn->translated_null, jn->bucket)
-                      : -1);
+    if (jn->null_mode == HDK_JOIN_NULL_BITWISE) {
+      return orc_bucketized_hash_join_idx_bitwise(table, key, jn->min_key, jn->max_key, jn->null_val,
+                                                  jn->translated_null, jn->bucket);
+    }
+    if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) {
+      return orc_bucketized_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val, jn->bucket);
+    }
+    return orc_bucketized_hash_join_idx(table, key, jn->min_key, jn->max_key, jn->bucket);
   }
   if (jn->null_mode == HDK_JOIN_NULL_NULLABLE) {
     return orc_hash_join_idx_nullable(table, key, jn->min_key, jn->max_key, jn->null_val);
@@ -1787,8 +1828,16 @@ static int32_t join_level(orc_row_ctx* c, const int64_t* join_hash_tables, int l
   const int32_t* ids;
   int64_t single;
   const int64_t n = matching_set(c, jn, join_hash_tables, &ids, &single, err);
+  if (jn->type == HDK_JOIN_ANTI) {
+    /* JoinLoop.cpp:258-262: the body runs when slot_lookup_result < 0 */
+    if (n > 0) {
+      return 0;
+    }
+    c->join_row[level] = -1;
+    return join_level(c, join_hash_tables, level + 1, body, arg, err);
+  }
   if (n <= 0) {
-    if (jn->type != HDK_JOIN_LEFT) {
+    if (jn->type != HDK_JOIN_LEFT) { /* INNER, SEMI (:254-257) */
       return 0;
     }
     c->join_row[level] = -1;

@@ -36,6 +36,8 @@ uint32_t orc_key_hash(const int64_t* key, uint32_t key_count, uint32_t key_byte_
 /* decoders: QE/DecodersImpl.h:30-150 */
 int64_t orc_fixed_width_int_decode(const int8_t* byte_stream, int32_t byte_width, int64_t pos);
 int64_t orc_fixed_width_unsigned_decode(const int8_t* byte_stream, int32_t byte_width, int64_t pos);
+int64_t orc_fixed_width_small_date_decode(const int8_t* byte_stream, int32_t byte_width, int32_t null_val,
+                                          int64_t ret_null_val, int64_t pos); /* QE/DecodersImpl.h:151-159 */
 float orc_fixed_width_float_decode(const int8_t* byte_stream, int64_t pos);
 double orc_fixed_width_double_decode(const int8_t* byte_stream, int64_t pos);
 
@@ -117,6 +119,10 @@ int64_t orc_bucketized_hash_join_idx(const int32_t* hash_buff, int64_t key, int6
                                      int64_t max_key, int64_t bucket_normalization);
 int64_t orc_hash_join_idx_nullable(const int32_t* hash_buff, int64_t key, int64_t min_key,
                                    int64_t max_key, int64_t null_val);
+int64_t orc_bucketized_hash_join_idx_nullable(const int32_t* hash_buff, int64_t key, int64_t min_key, int64_t max_key,
+                                              int64_t null_val, int64_t bucket_normalization);
+int64_t orc_bucketized_hash_join_idx_bitwise(const int32_t* hash_buff, int64_t key, int64_t min_key, int64_t max_key,
+                                             int64_t null_val, int64_t translated_val, int64_t bucket_normalization);
 int64_t orc_hash_join_idx_bitwise(const int32_t* hash_buff, int64_t key, int64_t min_key,
                                   int64_t max_key, int64_t null_val, int64_t translated_val);
 
@@ -147,6 +153,10 @@ void orc_init_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, si
 int orc_fill_baseline_hash_join_buff(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
                                      size_t key_component_count, int32_t key_component_width,
                                      const hdk_hip_join_column* cols, const hdk_hip_join_column_type_info* ti);
+int orc_fill_baseline_hash_join_buff_semi(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
+                                          int32_t for_semi_join, size_t key_component_count,
+                                          int32_t key_component_width, const hdk_hip_join_column* cols,
+                                          const hdk_hip_join_column_type_info* ti);
 int orc_fill_one_to_many_baseline_hash_table(int8_t* hash_buff, int64_t entry_count, int32_t invalid_slot_val,
                                              size_t key_component_count, int32_t key_component_width,
                                              const hdk_hip_join_column* cols,

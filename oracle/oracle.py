@@ -59,6 +59,7 @@ def lib():
     _sig(L, "orc_get_composite_key_index_64", C.c_int64, v, C.c_size_t, v, C.c_size_t)
     _sig(L, "orc_init_baseline_hash_join_buff", None, v, C.c_int64, C.c_size_t, C.c_int32, C.c_int32, C.c_int32)
     _sig(L, "orc_fill_baseline_hash_join_buff", C.c_int, v, C.c_int64, C.c_int32, C.c_size_t, C.c_int32, v, v)
+    _sig(L, "orc_fill_baseline_hash_join_buff_semi", C.c_int, v, C.c_int64, C.c_int32, C.c_int32, C.c_size_t, C.c_int32, v, v)
     _sig(L, "orc_fill_one_to_many_baseline_hash_table", C.c_int, v, C.c_int64, C.c_int32, C.c_size_t, C.c_int32, v, v)
     _sig(L, "orc_fixed_width_int_decode", C.c_int64, v, C.c_int32, C.c_int64)
     _sig(L, "orc_fixed_width_unsigned_decode", C.c_int64, v, C.c_int32, C.c_int64)
@@ -99,6 +100,10 @@ def lib():
     _sig(L, "orc_hash_join_idx_nullable", C.c_int64, v, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
     _sig(L, "orc_hash_join_idx_bitwise", C.c_int64, v, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
          C.c_int64)
+    _sig(L, "orc_bucketized_hash_join_idx_nullable", C.c_int64, v, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
+    _sig(L, "orc_bucketized_hash_join_idx_bitwise", C.c_int64, v, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+         C.c_int64, C.c_int64)
+    _sig(L, "orc_fixed_width_small_date_decode", C.c_int64, v, C.c_int32, C.c_int32, C.c_int64, C.c_int64)
     _sig(L, "orc_init_hash_join_buff", None, v, C.c_int64, C.c_int32)
     _sig(L, "orc_fill_hash_join_buff", C.c_int, v, C.c_int32, C.c_int32, v, C.c_size_t,
          C.POINTER(A.JoinColumnTypeInfo), C.c_int64)
@@ -192,6 +197,11 @@ def ref():
     _sig(R, "hash_join_idx_nullable", C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
     _sig(R, "hash_join_idx_bitwise", C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
          C.c_int64)
+    _sig(R, "bucketized_hash_join_idx_nullable", C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+         C.c_int64)
+    _sig(R, "bucketized_hash_join_idx_bitwise", C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+         C.c_int64, C.c_int64)
+    _sig(R, "fixed_width_small_date_decode", C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64)
     _sig(R, "translate_null_key_int64_t", C.c_int64, C.c_int64, C.c_int64, C.c_int64)
     _sig(R, "baseline_hash_join_idx_32", C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
     _sig(R, "baseline_hash_join_idx_64", C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)

@@ -9,7 +9,7 @@
 #   3. the C++ binding harness's host code (tests/cpp), compiled with the same flags (compile + link; it needs a
 #      device to run).
 # Usage: bash scripts/run_sanitizers.sh [pytest args]      exit status 0 = no report
-set -e
+set -e -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 ASAN_RT=$(gcc -print-file-name=libasan.so)
@@ -28,5 +28,6 @@ LD_PRELOAD="${CLANG_RT:-$ASAN_RT}" HDK_HIP_LIB=$ROOT/hdk_amd/libhdk_hip_asan.so 
   python -m pytest tests/test_abi.py tests/test_abi_negative.py tests/test_plan_layout.py -x -q -p no:cacheprovider
 echo "== 3. C++ binding harness, host code with the same flags (compile + link only)"
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -Wall -Werror -Wno-unused-parameter -I /root/reference/omniscidb -I include \
-  -I hdk_amd/glue -I tests/cpp tests/cpp/harness.cpp -L hdk_amd -lhdk_hip -Wl,-rpath,"$ROOT/hdk_amd" -o /tmp/harness_asan 2>&1 | tail -5 || true
+  -I hdk_amd/glue -I tests/cpp tests/cpp/harness.cpp -L hdk_amd -lhdk_hip -Wl,-rpath,"$ROOT/hdk_amd" -o /tmp/harness_asan 2>&1 | tail -20
+# (pipefail: a failed compile fails the script -- it used to read as a pass)
 echo "sanitizers: no report"

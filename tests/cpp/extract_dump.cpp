@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
            dval = column(bigint(false), 1, 2);
       auto on = bin_oper(type_of(TypeDesc::Boolean, 1, true), OpType::kEq, fk, dkey);
       hip_rt::UnitView<StandInIr> u;
-      u.joins.push_back({{on.get()}, false});
+      u.joins.push_back({{on.get()}, HDK_JOIN_INNER});
       auto add = bin_oper(bigint(true), OpType::kPlus, val, dval);
       auto sum = agg_expr(bigint(true), AggType::kSum, add), cnt = agg_expr(bigint(false), AggType::kCount, nullptr);
       u.targets = {sum.get(), cnt.get()};
@@ -175,6 +175,80 @@ int main(int argc, char** argv) {
       q.entry_count_ = 300;
       q.max_val_ = 299;
       dump("single", run({{0, 4, HDK_COL_INT}, {0, 4, HDK_COL_FLOAT}, {0, 8, HDK_COL_DOUBLE}}, u, q));
+    }
+    {  // DATE join, IS NOT DISTINCT FROM: SELECT COUNT(*), SUM(v) FROM fact JOIN ddup ON fact.day IS NOT DISTINCT FROM ddup.day
+       // (day: DATE in days, 4 bytes -> bucketized table: bucket 86400, range in epoch seconds; PerfectJoinHashTable.cpp:798-816)
+      auto date4 = type_of(TypeDesc::Date, 4, true);
+      date4.seconds = false;
+      auto fday = column(date4, 0, 0), dday = column(date4, 1, 2), v = column(bigint(true), 1, 1);
+      auto on = bin_oper(type_of(TypeDesc::Boolean, 1, true), OpType::kBwEq, fday, dday);
+      hip_rt::UnitView<StandInIr> u;
+      u.joins.push_back({{on.get()}, HDK_JOIN_INNER});
+      auto cnt = agg_expr(bigint(false), AggType::kCount, nullptr), sum = agg_expr(bigint(true), AggType::kSum, v);
+      u.targets = {cnt.get(), sum.get()};
+      QmdStandIn q;
+      q.query_desc_type_ = QueryDescriptionType::NonGroupedAggregate;
+      q.padded_slot_widths_ = {8, 8};
+      hip_rt::JoinTableDesc jt;
+      jt.kind = HDK_JOIN_ONE_TO_MANY;
+      jt.min_key = 18000LL * 86400;
+      jt.max_key = 18099LL * 86400;
+      jt.bucket = 86400;
+      jt.entry_count = 100;  // ceil((max - min + 1 + 1) / 86400)
+      dump("date_bw_eq", run({{0, 4, HDK_COL_SMALL_DATE}, {1, 8, HDK_COL_INT}, {1, 4, HDK_COL_SMALL_DATE}}, u, q, {jt}));
+    }
+    {  // integer IS NOT DISTINCT FROM under a LEFT join: SELECT COUNT(*), SUM(dval) FROM fact LEFT JOIN dim ON fk IS NOT DISTINCT FROM key
+      auto fk = column(bigint(true), 0, 0), dkey = column(bigint(true), 1, 2), dval = column(bigint(false), 1, 1);
+      auto on = bin_oper(type_of(TypeDesc::Boolean, 1, true), OpType::kBwEq, fk, dkey);
+      hip_rt::UnitView<StandInIr> u;
+      u.joins.push_back({{on.get()}, HDK_JOIN_LEFT});
+      // (a LEFT join makes every inner column nullable: the reference's planner rewrites the ColumnVar's type)
+      auto dval_n = column(bigint(true), 1, 1);
+      auto cnt = agg_expr(bigint(false), AggType::kCount, nullptr), sum = agg_expr(bigint(true), AggType::kSum, dval_n);
+      u.targets = {cnt.get(), sum.get()};
+      QmdStandIn q;
+      q.query_desc_type_ = QueryDescriptionType::NonGroupedAggregate;
+      q.padded_slot_widths_ = {8, 8};
+      hip_rt::JoinTableDesc jt;
+      jt.kind = HDK_JOIN_ONE_TO_ONE;
+      jt.min_key = 0;
+      jt.max_key = 999;
+      jt.entry_count = 1001;
+      dump("bw_eq_left", run({{0, 8, HDK_COL_INT}, {1, 8, HDK_COL_INT}, {1, 8, HDK_COL_INT}}, u, q, {jt}));
+    }
+    {  // SEMI join: SELECT COUNT(*), SUM(val) FROM fact WHERE EXISTS (SELECT 1 FROM dim WHERE key = fk)
+      auto fk = column(bigint(true), 0, 0), val = column(bigint(true), 0, 1), dkey = column(bigint(false), 1, 2);
+      auto on = bin_oper(type_of(TypeDesc::Boolean, 1, true), OpType::kEq, fk, dkey);
+      hip_rt::UnitView<StandInIr> u;
+      u.joins.push_back({{on.get()}, HDK_JOIN_SEMI});
+      auto cnt = agg_expr(bigint(false), AggType::kCount, nullptr), sum = agg_expr(bigint(true), AggType::kSum, val);
+      u.targets = {cnt.get(), sum.get()};
+      QmdStandIn q;
+      q.query_desc_type_ = QueryDescriptionType::NonGroupedAggregate;
+      q.padded_slot_widths_ = {8, 8};
+      hip_rt::JoinTableDesc jt;
+      jt.kind = HDK_JOIN_ONE_TO_ONE;
+      jt.min_key = 0;
+      jt.max_key = 999;
+      jt.entry_count = 1000;
+      dump("semi", run({{0, 8, HDK_COL_INT}, {0, 8, HDK_COL_INT}, {1, 8, HDK_COL_INT}}, u, q, {jt}));
+    }
+    {  // MIN / MAX over narrow nullable integers in 8-byte slots: the skip value is the ARGUMENT type's NULL
+       // SELECT k, MIN(s), MAX(i), MIN(i + 1), SUM(s) GROUP BY k      (k INT NOT NULL, s SMALLINT, i INT)
+      auto k = column(int_t(4, false), 0, 0), sc = column(int_t(2, true), 0, 1), ic = column(int_t(4, true), 0, 2);
+      hip_rt::UnitView<StandInIr> u;
+      u.groupby = {k.get()};
+      auto ip1 = bin_oper(bigint(true), OpType::kPlus, ic, int_literal(1));
+      auto mn = agg_expr(int_t(2, true), AggType::kMin, sc), mx = agg_expr(int_t(4, true), AggType::kMax, ic),
+           mn2 = agg_expr(bigint(true), AggType::kMin, ip1), sm = agg_expr(bigint(true), AggType::kSum, sc);
+      u.targets = {k.get(), mn.get(), mx.get(), mn2.get(), sm.get()};
+      QmdStandIn q;
+      q.query_desc_type_ = QueryDescriptionType::GroupByPerfectHash;
+      q.group_col_widths_ = {8};
+      q.padded_slot_widths_ = {8, 8, 8, 8, 8};
+      q.entry_count_ = 300;
+      q.max_val_ = 299;
+      dump("minmax_narrow", run({{0, 4, HDK_COL_INT}, {0, 2, HDK_COL_INT}, {0, 4, HDK_COL_INT}}, u, q));
     }
     // shapes the library does not cover must be refused, not mistranslated
     int refused = 0;

@@ -132,10 +132,22 @@ def make_tables_wide(rng, n, nd):
     dec = rng.integers(-300, 900, n, dtype=np.int64)
     dec[rng.random(n) < 0.03] = A.NULL_BIGINT
     cols.update({"f32": f32, "ts": ts, "dec": dec})
+    # a DATE in days on both sides (bucketized join tables) and a dimension key with NULL rows (IS NOT DISTINCT FROM)
+    from hdk_amd.ir import DATE32
+    day = (17000 + rng.integers(0, nd // 2 + 20, n)).astype(np.int32)
+    day[rng.random(n) < 0.03] = A.NULL_INT
+    cols["day"] = day
+    dday = (17010 + rng.integers(0, nd // 2, nd)).astype(np.int32)
+    dday[rng.random(nd) < 0.02] = A.NULL_INT
+    nkey = rng.permutation(nd).astype(np.int64)
+    nkey[rng.random(nd) < 0.01] = A.NULL_BIGINT
+    st.import_numpy("ddim", {"day": dday, "uday": (17010 + rng.permutation(nd)).astype(np.int32), "nkey": nkey,
+                             "x": rng.integers(-9, 9, nd).astype(np.int64)},
+                    fragment_size=int(rng.integers(nd // 3 + 1, nd + 1)), types={"day": DATE32, "uday": DATE32})
     # fragment shapes the base generator never draws: many fragments shorter than a tile, exactly one tile, one row more
     frag = int(rng.choice([frag, frag, n // 61 + 1, 2048, 8193]))
     st.import_numpy("fact", cols, fragment_size=frag,
-                    types={"ts": Type("timestamp", 8, unit="s"), "dec": Type("decimal", 8, scale=2)})
+                    types={"ts": Type("timestamp", 8, unit="s"), "dec": Type("decimal", 8, scale=2), "day": DATE32})
     return st
 
 
@@ -163,4 +175,20 @@ def random_query_wide(rng, projection=False):
     if groupby and not q.force_baseline and rng.random() < 0.4:
         j = int(rng.integers(0, len(groupby)))
         groupby[j] = ExtractYear(ColRef("ts")) if rng.random() < 0.5 else Cast(ColRef("dec"), INT32)
-    return replace(q, quals=quals, targets=targets, groupby=groupby, bigint_count=bool(rng.random() < 0.3))
+    joins = list(q.joins)
+    if not joins and rng.random() < 0.5:
+        # the join variants of SURVEY.md 8 a11 / a12 on a query that reads no inner column (so that SEMI's "first row of
+        # a key wins" stays invisible): bucketized DATE tables, IS NOT DISTINCT FROM, SEMI / ANTI
+        typ = str(rng.choice(["inner", "inner", "left", "semi", "anti"]))
+        v = int(rng.integers(0, 5))
+        if v == 0:
+            joins = [JoinSpec("ddim", ColRef("day"), "day", typ)]                                  # bucketized one-to-many
+        elif v == 1:
+            joins = [JoinSpec("ddim", ColRef("day"), "uday", typ)]                                 # bucketized one-to-one
+        elif v == 2:
+            joins = [JoinSpec("ddim", ColRef("fk"), "nkey", typ, null_safe=True)]                  # NULLs match NULLs
+        elif v == 3:
+            joins = [JoinSpec("ddim", ColRef("day"), "day", typ, null_safe=typ not in ("semi", "anti"))]
+        else:
+            joins = [JoinSpec("dim", [ColRef("fk2"), ColRef("k8")], ["a", "g"], "semi" if typ != "anti" else "anti")]  # keyed
+    return replace(q, quals=quals, targets=targets, groupby=groupby, joins=joins, bigint_count=bool(rng.random() < 0.3))

@@ -177,6 +177,28 @@ def main():
                    "bucketized_2": R.bucketized_hash_join_idx(table.ctypes.data, k, 10, 21, 2)})
     out["join_probe"] = {"table": table.tolist(), "min": 10, "max": 15, "cases": jp}
 
+    # ---- bucketized probes (DATE keys: bucket_normalization = 86400) and the small-date decoder -------------------
+    D = 86400
+    btable = np.array([4, -1, 2, 7, -1, 0, 11], dtype=np.int32)  # 5 day slots + the slot(s) a translated NULL lands in
+    mn, mx = 100 * D, 104 * D
+    bp = []
+    for k in (99 * D, 100 * D, 100 * D + 1, 102 * D, 104 * D, 104 * D + 5, 105 * D, NULL64):
+        bp.append({"key": k, "plain": R.bucketized_hash_join_idx(btable.ctypes.data, k, mn, mx, D),
+                   "nullable": R.bucketized_hash_join_idx_nullable(btable.ctypes.data, k, mn, mx, NULL64, D),
+                   # the two translated NULLs of the reference: what the probe passes (max / bucket + 1,
+                   # PerfectJoinHashTable.cpp:805-807) and what the build fills (max + 1, PerfectHashTableBuilder.h:100-106)
+                   "bitwise_probe_arg": R.bucketized_hash_join_idx_bitwise(btable.ctypes.data, k, mn, mx, NULL64, mx // D + 1, D)
+                   if mx // D + 1 >= mn else None,
+                   "bitwise_max_plus_1": R.bucketized_hash_join_idx_bitwise(btable.ctypes.data, k, mn, mx, NULL64, mx + 1, D)})
+    out["join_probe_bucketized"] = {"table": btable.tolist(), "min": mn, "max": mx, "bucket": D, "cases": bp}
+    days = np.array([0, 1, -1, 19000, -(2**31), 2**31 - 1, -25567], dtype=np.int32)
+    days16 = np.array([0, 1, -1, 19000, -(2**15), 2**15 - 1], dtype=np.int16)
+    out["small_date_decode"] = {
+        "w4": [{"v": int(v), "out": R.fixed_width_small_date_decode(days.ctypes.data, 4, -(2**31), NULL64, i)}
+               for i, v in enumerate(days)],
+        "w2": [{"v": int(v), "out": R.fixed_width_small_date_decode(days16.ctypes.data, 2, -(2**15), NULL64, i)}
+               for i, v in enumerate(days16)]}
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runtime_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

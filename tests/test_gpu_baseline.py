@@ -317,6 +317,22 @@ def test_tuple_exchange_flags_what_it_cannot_carry(oracle, gpu_executor_factory)
     assert errs.count(A.ERR_EXCHANGE_INCOMPLETE) >= 1, errs
     res = ex2.execute(cp2, flags=A.LAUNCH_FORCE_PARTITIONED)
     _check_rows(cp2, res.buffer, want2)
+    # stale statistics INSIDE the 32-bit range: has_nulls = 0 for an int32 column that holds one in-band NULL
+    # (INT32_MIN fits the narrow tuple, so only the explicit test sees it; round-3 advisor finding)
+    from hdk_amd.ir import INT32
+    v32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    st.import_numpy("t32", {"k": key, "v": v32}, fragment_size=50_000, types={"v": INT32})
+    c32 = st.get("t32").columns["v"]
+    c32.fragments[2][99] = A.NULL_INT
+    assert not any(s_.has_nulls for s_ in c32.stats)  # (computed at import, before the NULL went in)
+    q3 = QueryUnit("t32", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=131_071,
+                   targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s")])
+    ex3 = gpu_executor_factory(st)
+    cp3, want3, err3 = run_oracle(oracle, st, q3)
+    step3 = ex3.prepare(cp3, flags=A.LAUNCH_FORCE_PARTITIONED)
+    assert "hdk_part_scatter" in step3.kernel_names()
+    _check_rows(cp3, step3.run().buffer, want3)
+    step3.free()
 
 
 @pytest.mark.parametrize("shape", ["narrow", "wide", "multi_target"])

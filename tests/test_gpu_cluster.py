@@ -113,6 +113,27 @@ def test_direct_join_kernel_matches_the_oracle(oracle, gpu_executor_factory, key
             step.free()
 
 
+@pytest.mark.parametrize("grid", [1, 5, 64, 300])
+def test_sliced_join_with_a_small_caller_grid(oracle, gpu_executor_factory, grid):
+    """KernelOptions::gridDimX sizes the slab workspace and what hdk_finalize folds; every block of the sliced probe pass
+    flushes into slab[blockIdx.x].  With a grid smaller than the slices need (30 000 keys / 64 = 469 slices here) the
+    launch must fall back to row order, with a larger one the members per slice are clamped to it -- never a write past
+    the workspace, never a slab that is not folded (round-3 advisor finding)."""
+    st = _tables(400_000, 30_000, "uniform", 23)
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=_direct_targets()[0])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    ex.fuse_join_tables = True
+    step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES, grid=grid)
+    names = step.kernel_names()
+    # range 30 000 -> 64-key slices at least: 256 slices of 118 keys
+    assert names.startswith("hdk_join_agg_sliced" if False else ("hdk_join_order_probe" if grid >= 256 else "hdk_join_agg_direct")), names
+    for _ in range(2):
+        assert_buffers_equal(cp, step.run().buffer, want)
+    step.free()
+
+
 def test_direct_join_kernel_reports_overflow(oracle, gpu_executor_factory):
     from hdk_amd._lib import HdkHipError
     st = _tables(200_000, 5_000, "uniform", 3)

@@ -33,6 +33,41 @@ def test_hipmgr_contract(mgr):
     assert (mgr.to_host(d2.ptr, a.nbytes, 0) == -1).all()
     mgr.zeroDeviceMem(d2.ptr, a.nbytes, 0)
     assert (mgr.to_host(d2.ptr, a.nbytes, 0) == 0).all()
+    # pinned host memory (CudaMgr::allocatePinnedHostMem) as the source of an asynchronous upload
+    host, hptr = mgr.pinned_array((4096,), np.int64)
+    host[:] = np.arange(4096) * 3
+    d3 = mgr.alloc(host.nbytes, 0)
+    mgr.copyHostToDeviceAsync(d3.ptr, hptr, host.nbytes, 0)
+    mgr.synchronizeStream(0)
+    assert np.array_equal(mgr.to_host(d3.ptr, host.nbytes, 0), np.arange(4096) * 3)
+    del host
+    mgr.freePinnedHostMem(hptr)
+
+
+def test_measurement_helpers(mgr):
+    """hdk_hip_mgr_measure_hbm (what bench.py reports as roofline.peak_measured) and the HIP-event log of
+    HDK_HIP_LAUNCH_RECORD_EVENTS (hdk_hip_collect_scan_times: DeviceClock, QE/DeviceKernel.cpp:25-43)."""
+    from hdk_amd.executor import Executor
+    L = lib()
+    copy, read = C.c_double(0), C.c_double(0)
+    check(L.hdk_hip_mgr_measure_hbm(0, 256 << 20, 3, C.byref(copy), C.byref(read)))
+    assert 500 < copy.value < 9000 and 500 < read.value < 9000 and read.value > copy.value * 0.8
+    st = ArrowStorage()
+    rng = np.random.default_rng(0)
+    st.import_numpy("t", {"k": rng.integers(0, 64, 1 << 20), "v": rng.integers(-5, 5, 1 << 20)}, fragment_size=1 << 18)
+    ex = Executor(st, 0, mgr)
+    n = C.c_int32(0)
+    check(L.hdk_hip_collect_scan_times(0, None, 0, C.byref(n)))  # drain what earlier tests may have left
+    step = ex.prepare(QueryUnit("t", groupby=[ColRef("k")], targets=[KeyRef(0), Agg("sum", ColRef("v"))]),
+                      flags=A.LAUNCH_RECORD_EVENTS)
+    for _ in range(3):
+        step.run()
+    ms = (C.c_float * 8)()
+    check(L.hdk_hip_collect_scan_times(0, ms, 8, C.byref(n)))
+    assert n.value == 3 and all(0 < ms[i] < 50 for i in range(3))
+    check(L.hdk_hip_collect_scan_times(0, ms, 8, C.byref(n)))
+    assert n.value == 0  # collected once
+    step.free()
 
 
 @pytest.mark.parametrize("columnar", [False, True])

@@ -153,6 +153,33 @@ def test_join_probe(oracle, golden):
         assert L.orc_bucketized_hash_join_idx(table.ctypes.data, k, jp["min"], 21, 2) == c["bucketized_2"]
 
 
+def test_join_probe_bucketized(oracle, golden):
+    """bucketized_hash_join_idx[_nullable|_bitwise] (QE/GroupByRuntime.cpp:274-350) on a DATE-shaped key."""
+    L = oracle.lib()
+    jp = golden["join_probe_bucketized"]
+    t = np.array(jp["table"], dtype=np.int32)
+    mn, mx, D = jp["min"], jp["max"], jp["bucket"]
+    for c in jp["cases"]:
+        k = c["key"]
+        assert L.orc_bucketized_hash_join_idx(t.ctypes.data, k, mn, mx, D) == c["plain"]
+        assert L.orc_bucketized_hash_join_idx_nullable(t.ctypes.data, k, mn, mx, NULL64, D) == c["nullable"]
+        assert L.orc_bucketized_hash_join_idx_bitwise(t.ctypes.data, k, mn, mx, NULL64, mx + 1, D) == c["bitwise_max_plus_1"]
+        if c["bitwise_probe_arg"] is not None:
+            assert L.orc_bucketized_hash_join_idx_bitwise(t.ctypes.data, k, mn, mx, NULL64, mx // D + 1, D) == \
+                c["bitwise_probe_arg"]
+
+
+def test_small_date_decode(oracle, golden):
+    L = oracle.lib()
+    g = golden["small_date_decode"]
+    a4 = np.array([c["v"] for c in g["w4"]], dtype=np.int32)
+    a2 = np.array([c["v"] for c in g["w2"]], dtype=np.int16)
+    for i, c in enumerate(g["w4"]):
+        assert L.orc_fixed_width_small_date_decode(a4.ctypes.data, 4, -(2**31), NULL64, i) == c["out"]
+    for i, c in enumerate(g["w2"]):
+        assert L.orc_fixed_width_small_date_decode(a2.ctypes.data, 2, -(2**15), NULL64, i) == c["out"]
+
+
 # ---- QueryEngine/GroupByHashTest.cpp ports ------------------------------------------------------------
 def _groups_buffer(entry_count, key_qw_count, init_val=0):
     rsq = key_qw_count + 1

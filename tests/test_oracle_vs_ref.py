@@ -155,6 +155,50 @@ def test_join_probe_random(oracle, ref):
             ref.hash_join_idx_nullable(table.ctypes.data, k, 3, 42, 7)
 
 
+def test_join_probe_variants_random(oracle, ref):
+    """Every perfect-hash probe of QE/GroupByRuntime.cpp:274-366 -- plain, nullable, bitwise and the three bucketized
+    forms -- on random tables, ranges, buckets and NULL / translated-NULL values (the values PerfectJoinHashTable
+    passes, QE/JoinHashTable/PerfectJoinHashTable.cpp:798-816, and arbitrary ones)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(171)
+    for _ in range(300):
+        bucket = int(rng.choice([1, 2, 7, 86400]))
+        mn = int(rng.integers(-50, 50)) * bucket
+        slots = int(rng.integers(1, 60))
+        mx = mn + (slots - 1) * bucket + int(rng.integers(0, bucket))
+        table = rng.integers(-1, 1000, slots + 2).astype(np.int32)  # (+ the slot(s) a translated NULL may land in)
+        t = table.ctypes.data
+        null = int(rng.choice([NULL64, -(2**31), mn + bucket]))
+        trs = [mx + 1, mx // bucket + 1, int(rng.integers(mn, mx + 2 * bucket + 1))]
+        keys = [null, mn, mx, mn - 1, mx + 1] + [int(x) for x in rng.integers(mn - 3 * bucket, mx + 3 * bucket, 40)]
+        for k in keys:
+            assert L.orc_hash_join_idx(t, k, mn, mn + slots - 1) == ref.hash_join_idx(t, k, mn, mn + slots - 1)
+            assert L.orc_bucketized_hash_join_idx(t, k, mn, mx, bucket) == ref.bucketized_hash_join_idx(t, k, mn, mx, bucket)
+            assert L.orc_bucketized_hash_join_idx_nullable(t, k, mn, mx, null, bucket) == \
+                ref.bucketized_hash_join_idx_nullable(t, k, mn, mx, null, bucket)
+            for tr in trs:
+                # the reference reads slot (tr - mn) / bucket for a NULL key: keep it inside the table
+                if tr < mn or (tr - mn) // bucket >= table.size:
+                    continue
+                assert L.orc_bucketized_hash_join_idx_bitwise(t, k, mn, mx, null, tr, bucket) == \
+                    ref.bucketized_hash_join_idx_bitwise(t, k, mn, mx, null, tr, bucket)
+                if tr - mn < table.size:
+                    assert L.orc_hash_join_idx_bitwise(t, k, mn, mn + slots - 1, null, tr) == \
+                        ref.hash_join_idx_bitwise(t, k, mn, mn + slots - 1, null, tr)
+
+
+def test_small_date_decode_random(oracle, ref):
+    """fixed_width_small_date_decode (QE/DecodersImpl.h:151-159) as FixedWidthSmallDate calls it (QE/Codec.cpp:86-102)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    for w, null, dt in ((4, -(2**31), np.int32), (2, -(2**15), np.int16)):
+        raw = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, 64).astype(dt)
+        raw[::7] = null
+        for pos in range(64):
+            assert L.orc_fixed_width_small_date_decode(raw.ctypes.data, w, null, NULL64, pos) == \
+                ref.fixed_width_small_date_decode(raw.ctypes.data, w, null, NULL64, pos)
+
+
 @pytest.mark.parametrize("width,kc", [(8, 1), (8, 2), (4, 2), (4, 3)])
 def test_keyed_join_probe_vs_reference(oracle, ref, width, kc):
     """The oracle's keyed ("baseline") table build, probed by the REFERENCE's baseline_hash_join_idx_{32,64}

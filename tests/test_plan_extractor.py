@@ -42,6 +42,20 @@ def _tables():
     st.import_numpy("g", {"k": rng.integers(0, 300, n).astype(np.int32), "f": rng.random(n).astype(np.float32),
                           "d": rng.normal(size=n)},
                     types={"k": Type("int", 4, False), "f": Type("fp", 4, True), "d": Type("fp", 8, True)})
+    from hdk_amd.ir import DATE32
+    days = (18000 + np.arange(100)).astype(np.int32)
+    dday = np.concatenate([days, days[:50]])
+    dday[7] = -(2**31)
+    st.import_numpy("ddup", {"v": rng.integers(-9, 9, 150, dtype=np.int64), "day": dday}, types={"v": I64N, "day": DATE32})
+    fday = rng.integers(17990, 18110, n).astype(np.int32)
+    fday[::50] = -(2**31)
+    st.import_numpy("fdate", {"day": fday}, types={"day": DATE32})
+    dk = rng.permutation(1000).astype(np.int64)
+    dk[int(np.nonzero((dk != 0) & (dk != 999))[0][0])] = A.NULL_BIGINT  # one NULL row, the range stays [0, 999]
+    st.import_numpy("dimn", {"dval": rng.integers(0, 1000, 1000, dtype=np.int64), "key": dk}, types={"dval": I64, "key": I64N})
+    st.import_numpy("h", {"k": rng.integers(0, 300, n).astype(np.int32), "s": rng.integers(-99, 99, n).astype(np.int16),
+                          "i": rng.integers(-999, 999, n).astype(np.int32)},
+                    types={"k": Type("int", 4, False), "s": Type("int", 2, True), "i": Type("int", 4, True)})
     return st
 
 
@@ -62,6 +76,15 @@ def _queries():
         "projection": QueryUnit("t", quals=[Cmp(ColRef("val"), "<", Lit(100))], targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val") * 2, "v2")]),
         "floats": QueryUnit("g", groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("sum", ColRef("f"), "sf"), Agg("avg", ColRef("f"), "af"),
                                                                    Agg("min", ColRef("d"), "md"), Agg("count", ColRef("f"), "cf")]),
+        "date_bw_eq": QueryUnit("fdate", joins=[JoinSpec("ddup", ColRef("day"), "day", null_safe=True)],
+                                targets=[Agg("count", None, "c"), Agg("sum", ColRef("v", "ddup"), "s")], bigint_count=True),
+        "bw_eq_left": QueryUnit("fact", joins=[JoinSpec("dimn", ColRef("fk"), "key", "left", null_safe=True)],
+                                targets=[Agg("count", None, "c"), Agg("sum", ColRef("dval", "dimn"), "s")], bigint_count=True),
+        "semi": QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key", "semi")],
+                          targets=[Agg("count", None, "c"), Agg("sum", ColRef("val"), "s")], bigint_count=True),
+        "minmax_narrow": QueryUnit("h", groupby=[ColRef("k")],
+                                   targets=[KeyRef(0, "k"), Agg("min", ColRef("s"), "mn"), Agg("max", ColRef("i"), "mx"),
+                                            Agg("min", ColRef("i") + 1, "mn2"), Agg("sum", ColRef("s"), "sm")], bigint_count=True),
         "single": QueryUnit("g", groupby=[ColRef("k")], targets=[KeyRef(0, "k"), Agg("single_value", ColRef("f"), "s1"),
                                                                    Agg("single_value", ColRef("d"), "s2"), Agg("count", None, "c")]),
     }
@@ -77,7 +100,11 @@ def _expr_half(p):
            "quals": [_b(p.quals[i]) for i in range(p.num_quals)],
            "filter": (p.num_filter_ops, bytes(p.filter_ops[:p.num_filter_ops]), p.filter_after_joins if p.num_filter_ops else 0),
            "keys": [_b(p.keys[k]) for k in range(p.key_count)]}
-    out["joins"] = [(_b(j.outer_key), j.kind, j.type, j.null_mode, j.min_key, j.max_key, j.table_idx) for j in
+    # everything the probe is handed (getHashJoinArgs, PerfectJoinHashTable.cpp:786-824): key, range, NULL, the translated
+    # NULL of a _bitwise probe, bucket_normalization; plus the loop kind and the table's slot count
+    out["joins"] = [(_b(j.outer_key), j.kind, j.type, j.null_mode, j.null_val if j.null_mode else 0, j.min_key, j.max_key,
+                     j.bucket, j.translated_null if j.null_mode == A.JOIN_NULL_BITWISE else 0, j.table_idx,
+                     j.entry_count if j.kind != A.JOIN_ONE_TO_ONE or j.null_mode == A.JOIN_NULL_BITWISE else 0) for j in
                     [p.joins[i] for i in range(p.num_joins)]]
     tg = []
     for t in range(p.num_targets):
@@ -101,7 +128,8 @@ def dumped(tmp_path_factory):
     return d
 
 
-@pytest.mark.parametrize("name", ["c2", "q4", "filters", "join", "c5", "projection", "floats", "single"])
+@pytest.mark.parametrize("name", ["c2", "q4", "filters", "join", "c5", "projection", "floats", "single", "date_bw_eq", "bw_eq_left",
+                                  "semi", "minmax_narrow"])
 def test_extractor_matches_the_python_planner(dumped, name):
     st = _tables()
     want = compile_query(st, _queries()[name]).plan

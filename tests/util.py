@@ -41,22 +41,24 @@ def oracle_join_tables(O, storage, cp):
         inner = storage.get(info["inner_table"])
         kind = info["kind"]
         cols = info["inner_cols"]
+        semi = info["for_semi_join"]
         if kind in (A.JOIN_ONE_TO_ONE, A.JOIN_ONE_TO_MANY):
-            entries = info["max"] - info["min"] + 1
+            entries = info["entry_count"]  # the normalised slot count (HashEntryInfo::getNormalizedHashEntryCount)
             frs = inner.columns[cols[0]].fragments
             chunks = O.make_join_chunks(frs)
-            ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], 0, A.JC_SIGNED, 0)
+            ti = A.JoinColumnTypeInfo(info["elem_sz"], info["min"], info["max"], info["null_val"], info["uses_bw_eq"],
+                                      info["col_types"][0], info["translated_null_build"])
             if kind == A.JOIN_ONE_TO_ONE:
                 buff = np.empty(entries, dtype=np.int32)
                 L.orc_init_hash_join_buff(buff.ctypes.data, entries, -1)
-                rc = L.orc_fill_hash_join_buff(buff.ctypes.data, -1, 0, C.cast(chunks, C.c_void_p), len(frs),
-                                               C.byref(ti), 1)
+                rc = L.orc_fill_hash_join_buff(buff.ctypes.data, -1, semi, C.cast(chunks, C.c_void_p), len(frs),
+                                               C.byref(ti), info["bucket"])
                 assert rc == 0
             else:
                 buff = np.empty(2 * entries + inner.num_rows, dtype=np.int32)
                 L.orc_init_hash_join_buff(buff.ctypes.data, buff.size, -1)
                 L.orc_fill_one_to_many_hash_table(buff.ctypes.data, entries, -1, C.cast(chunks, C.c_void_p), len(frs),
-                                                  C.byref(ti), 1)
+                                                  C.byref(ti), info["bucket"])
             tables.append(buff)
             continue
         kc, w, entries = len(cols), info["key_width"], info["entry_count"]
@@ -70,11 +72,11 @@ def oracle_join_tables(O, storage, cp):
             jcs[k] = A.JoinColumn(C.cast(chunks, C.c_void_p).value, C.sizeof(chunks), len(frs), inner.num_rows,
                                   info["elem_szs"][k])
             tis[k] = A.JoinColumnTypeInfo(info["elem_szs"][k], info["mins"][k], info["maxs"][k], info["null_vals"][k],
-                                          0, A.JC_SIGNED, 0)
+                                          0, info["col_types"][k], 0)
         if kind == A.JOIN_KEYED_ONE_TO_ONE:
             buff = np.empty(entries * (kc + 1) * w, dtype=np.uint8)
             L.orc_init_baseline_hash_join_buff(buff.ctypes.data, entries, kc, w, 1, -1)
-            rc = L.orc_fill_baseline_hash_join_buff(buff.ctypes.data, entries, -1, kc, w, jcs, tis)
+            rc = L.orc_fill_baseline_hash_join_buff_semi(buff.ctypes.data, entries, -1, semi, kc, w, jcs, tis)
             assert rc == 0, rc
         else:
             buff = np.empty(entries * kc * w + (2 * entries + inner.num_rows) * 4, dtype=np.uint8)
