@@ -127,8 +127,9 @@ def test_sliced_join_with_a_small_caller_grid(oracle, gpu_executor_factory, grid
     ex.fuse_join_tables = True
     step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES, grid=grid)
     names = step.kernel_names()
-    # range 30 000 -> 64-key slices at least: 256 slices of 118 keys
-    assert names.startswith("hdk_join_agg_sliced" if False else ("hdk_join_order_probe" if grid >= 256 else "hdk_join_agg_direct")), names
+    # range 30 000 -> 256 slices of 118 keys: below 256 blocks the slices are not used (the row-order kernel reads
+    # clustered tuples instead), from 256 on they are, with the members per slice clamped to the grid
+    assert ("hdk_join_agg_sliced" in names) == (grid >= 256) and "hdk_join_agg_direct" in names, names
     for _ in range(2):
         assert_buffers_equal(cp, step.run().buffer, want)
     step.free()

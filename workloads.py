@@ -122,7 +122,7 @@ class Workload:
             table("dim", {"key": (I64, dim_key, (0, self.dim_rows - 1)),
                           "dval": (I64, uniform(0, 10**6, 8), (0, 10**6 - 1))}, [self.dim_rows], [0])
             # the planner decides one-to-one from the inner table's data (plan._inner_keys_unique): a permutation is unique
-            self.storage.get("dim").__dict__["_unique_keys_cache"] = {("key",): 1}
+            self.storage.get("dim").__dict__["_unique_keys_cache"] = {("key", False, 1): 1}  # (cols..., nulls_match, bucket)
             table("fact", {"fk": (I64, uniform(0, self.dim_rows, 2), (0, self.dim_rows - 1)), "val": val}, self.frag_rows,
                   self.frag_ids)
             self.query = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")],
