@@ -320,6 +320,25 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         mine = torch.tensor([want if want < 2**63 else want - 2**64], dtype=torch.int64, device="cuda")
         comm.all_reduce(mine)
         checks["sum_equals_torch_gather_sum"] = bool((int(final[0]) - int(mine.item())) % (1 << 64) == 0)
+    elif name == "c3g":
+        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
+        mine = torch.tensor([x if x < 2**63 else x - 2**64 for x in (v % (1 << 64) for v in ref["group_sums"])], dtype=torch.int64,
+                            device="cuda")
+        comm.all_reduce(mine)
+        want = [int(x) for x in mine.cpu().tolist()]
+        checks["groups"] = len(cols["g"])
+        checks["per_group_sums_equal_torch_index_add"] = bool(
+            sorted(cols["g"]) == list(range(64)) and all((s_ - want[g]) % (1 << 64) == 0 for g, s_ in zip(cols["g"], cols["s"])))
+    elif name == "c3m":
+        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        mine = torch.tensor([ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64, w.local_rows], dtype=torch.int64,
+                            device="cuda")
+        comm.all_reduce(mine)
+        mx = torch.tensor([ref["max_dval"]], dtype=torch.int64, device="cuda")
+        comm.all_reduce(mx, "max")
+        checks["sum_count_max_equal_torch"] = bool((int(final[0]) - int(mine[0].item())) % (1 << 64) == 0 and
+                                                   int(final[1]) == int(mine[1].item()) and int(final[2]) == int(mx.item()))
     else:
         final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
         cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
@@ -359,7 +378,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     achieved = w.local_rows * w.alg_bytes_per_row / (avg_scan_ms * 1e-3) / 1e9 if scan_ms else None
     traffic = None
     traffic_source = None
-    for rnd in ("r03", "r02"):  # counters are collected by separate rocprofv3 --pmc passes of this same command
+    for rnd in ("r04", "r03", "r02"):  # counters are collected by separate rocprofv3 --pmc passes of this same command
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
         if os.path.exists(pmc_path) and rows == CONFIGS[name][0] and world == 1:
             with open(pmc_path) as fpmc:
@@ -537,7 +556,7 @@ def main():
     del w
     extra = args.extra
     if extra == "auto":
-        extra = "c3,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
+        extra = "c3,c3g,c3m,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
     if extra == "none":
         extra = ""
     configs = []

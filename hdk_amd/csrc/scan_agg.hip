@@ -445,6 +445,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "scan_cluster.h"
 #include "scan_join_direct.h"
 #include "scan_join_sliced.h"
+#include "scan_join_sliced2.h"
 
 using namespace hdk;
 
@@ -680,6 +681,10 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
 static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
 static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, JoinDirectArgs* ja);
+// which of the join kernels takes a plan (one place: the launch, its description and its grid agree)
+enum JoinRoute { JOIN_ROUTE_NONE = 0, JOIN_ROUTE_DIRECT = 1, JOIN_ROUTE_SLICED2 = 2 };
+static JoinRoute route_join(const hdk_hip_plan* plan, const LaunchShape& shape, const hdk_hip_kernel_options* ko, JoinDirectArgs* ja,
+                            Slice2Args* ga);
 static bool join_direct_clusters(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko);
 // the counting form keeps 32-bit counters: half the bytes of the 8-byte words the shape was sized for
 static uint32_t keys_lds_bytes(const KeysArgs& ka, const LaunchShape& shape) {
@@ -976,14 +981,18 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
 
 
 // (same decisions as launch_scan_lds)
-static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, bool force_generic, bool force_scalar) {
+static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, const hdk_hip_kernel_options* ko, bool force_generic,
+                                    bool force_scalar) {
   FastArgs fa;
   int kw, vw;
   if (!force_generic && match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  JoinDirectArgs ja;
+  Slice2Args ga;
+  const JoinRoute route = force_generic ? JOIN_ROUTE_NONE : route_join(p, s, ko, &ja, &ga);
+  if (route == JOIN_ROUTE_DIRECT) return "hdk_join_agg_direct";
+  if (route == JOIN_ROUTE_SLICED2) return "hdk_scan_agg_vec_join";  // (armed behind the sliced passes)
   KeysArgs ka;
   if (!force_generic && match_keys(p, s, &ka)) return ka.nvals ? "hdk_scan_agg_keys_values" : "hdk_scan_agg_keys";
-  JoinDirectArgs ja;
-  if (!force_generic && match_join_direct(p, s, &ja)) return "hdk_join_agg_direct";
   if (needs_join_loops(p) || force_scalar) return "hdk_scan_agg_generic";
   return p->num_joins ? "hdk_scan_agg_vec_join" : "hdk_scan_agg_vec";
 }
@@ -1296,6 +1305,288 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
   return HDK_HIP_OK;  // (`scratch` is freed here, stream-ordered after the kernels above)
 }
 
+// ---- the general sliced join (scan_join_sliced2.h): join + perfect-hash GROUP BY on the joined column / + filters / any
+// list of integer aggregates over x and the payload, everything in 8-byte tuples ----------------------------------------
+// leaf of an aggregate argument: 0 = x (the one other 8-byte outer column), 1 = the payload, 2 = an integer literal
+static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int* xc) {
+  if (l.kind == HDK_LEAF_INT) return 2;
+  if (l.kind != HDK_LEAF_COL) return -1;
+  const hdk_hip_col& c = p->cols[l.col];
+  if (c.table == -1 && c.buf_idx == 1) return 1;
+  if (c.table != 0 || l.col == kc || c.width != 8 || c.kind != HDK_COL_INT) return -1;
+  if (*xc >= 0 && *xc != l.col) return -1;  // one value column travels in the tuple
+  *xc = l.col;
+  return 0;
+}
+
+static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, const hdk_hip_kernel_options* ko, Slice2Args* ga) {
+  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES) || getenv("HDK_HIP_NO_SLICED2")) return false;
+  if (shape.strategy != STRAT_LDS || p->num_joins != 1 || p->num_filter_ops || p->num_targets > HDK_HIP_MAX_TARGETS) return false;
+  if (p->query_kind != HDK_Q_NON_GROUPED && p->query_kind != HDK_Q_PERFECT_HASH) return false;
+  if (plan_reads_small_dates(p)) return false;
+  const bool forced = (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
+  const hdk_hip_join& jn = p->joins[0];
+  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || jn.fused_stride != 2 || !join_type_inner_like(jn.type) || jn.bucket > 1 ||
+      jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.table_idx != 0 || jn.max_key < jn.min_key) {
+    return false;
+  }
+  int kc;
+  if (!plain_outer_col(p, jn.outer_key, &kc) || p->cols[kc].width != 8 || p->cols[kc].kind != HDK_COL_INT) return false;
+  const uint64_t range = static_cast<uint64_t>(jn.max_key - jn.min_key) + 1;
+  if (range >= 0xFFFFFFFFull) return false;
+  if (!forced && (range * 16 < (32ull << 20) || ko->total_rows < (32ull << 20))) return false;
+  memset(ga, 0, sizeof(*ga));
+  SliceArgs& sa = ga->s;
+  const hdk_hip_col* pay = nullptr;
+  for (int i = 0; i < p->num_cols; ++i) {
+    const hdk_hip_col& c = p->cols[i];
+    if (c.table == -1 && c.buf_idx == 1) pay = &c;
+    else if (c.table != 0) return false;  // an inner column read through the row id, or a second payload word
+  }
+  // ---- targets ----------------------------------------------------------------------------------------------------------
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  if (wl.wpe != static_cast<int>(shape.wpe)) return false;
+  ga->wpe = wl.wpe;
+  for (int w = 0; w < wl.wpe; ++w) ga->wop[w] = wl.wop[w];
+  int xc = -1;
+  int nt = 0;
+  int64_t x_null = 0, p_null = 0;
+  bool x_nullable = false, p_nullable = false;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_ID) {
+      if (p->query_kind != HDK_Q_PERFECT_HASH || tg.key_idx != 0) return false;
+      continue;  // hdk_finalize rebuilds a projected key from the entry index
+    }
+    if (tg.agg == HDK_AGG_SINGLE_VALUE || tg.arg_is_fp || tg.slot_width != 8) return false;
+    if (tg.agg == HDK_AGG_AVG && tg.slot2_width != 8) return false;
+    if (!tg.has_arg) {
+      if (tg.agg != HDK_AGG_COUNT) return false;
+      continue;  // COUNT(*): the row count word
+    }
+    if (wl.vword[t] < 0 && wl.nword[t] < 0) continue;  // COUNT(not-null expression): the row count too
+    if (nt == kS2MaxTargets) return false;
+    S2Target& st = ga->t[nt++];
+    st.vword = wl.vword[t];
+    st.nword = wl.nword[t];
+    st.wop = wl.vword[t] >= 0 ? wl.wop[wl.vword[t]] : WOP_ADD_U64;
+    if (st.wop != WOP_ADD_U64 && st.wop != WOP_MIN_I64 && st.wop != WOP_MAX_I64) return false;
+    if (wl.nword[t] >= 0) ga->nword_mask |= 1u << wl.nword[t];
+    const hdk_hip_expr& e = tg.arg;
+    if (e.vclass != HDK_VC_INT || e.nsteps > 1) return false;
+    const int ka = s2_leaf_kind(p, e.leaf0, kc, &xc);
+    if (ka != 0 && ka != 1) return false;
+    bool nullable = e.leaf0.nullable != 0;
+    if (ka == 0 && e.leaf0.nullable) x_nullable = true, x_null = e.leaf0.null_val;
+    if (ka == 1 && e.leaf0.nullable) p_nullable = true, p_null = e.leaf0.null_val;
+    st.null_if_x = ka == 0 && e.leaf0.nullable;
+    st.null_if_p = ka == 1 && e.leaf0.nullable;
+    if (e.nsteps == 0) {
+      st.src = ka == 0 ? S2_X : S2_P;
+    } else {
+      const hdk_hip_step& sp = e.steps[0];
+      if ((sp.op != HDK_OP_ADD && sp.op != HDK_OP_SUB && sp.op != HDK_OP_MUL) || sp.out_class != HDK_VC_INT) return false;
+      if (sp.check_width != 0 && sp.check_width != 8) return false;  // (a 4-byte SQL type can overflow: the interpreter checks)
+      const int kb = s2_leaf_kind(p, sp.rhs, kc, &xc);
+      if (kb < 0) return false;
+      if (kb == 2) {
+        if (sp.rhs.ival <= -(int64_t(1) << 31) || sp.rhs.ival >= (int64_t(1) << 31)) return false;
+        st.src = ka == 0 ? S2_X_OP_LIT : S2_P_OP_LIT;
+        st.op = sp.op;
+        st.lit = sp.rhs.ival;
+      } else {
+        if (kb == ka) return false;  // x op x, payload op payload
+        nullable = nullable || sp.rhs.nullable;
+        if (kb == 0 && sp.rhs.nullable) x_nullable = true, x_null = sp.rhs.null_val, st.null_if_x = 1;
+        if (kb == 1 && sp.rhs.nullable) p_nullable = true, p_null = sp.rhs.null_val, st.null_if_p = 1;
+        if (sp.op == HDK_OP_ADD) st.src = S2_X_ADD_P;
+        else if (sp.op == HDK_OP_MUL) st.src = S2_X_MUL_P;
+        else st.src = ka == 0 ? S2_X_SUB_P : S2_P_SUB_X;
+      }
+    }
+    // a NULL argument is skipped (and counted) -- the only reading of a NULL the kernel has; a plan that would AGGREGATE
+    // the sentinel (nullable leaf, skip_null off) is the interpreter's
+    if (nullable && !tg.skip_null) return false;
+  }
+  ga->ntargets = nt;
+  // ---- filters: `outer column cmp literal` in pass 1, `payload cmp literal` in pass 2 ----------------------------------------
+  {
+    hdk_hip_plan outer_only;
+    memset(&outer_only, 0, sizeof(outer_only));
+    int nq = 0;
+    for (int i = 0; i < p->num_quals; ++i) {
+      const hdk_hip_qual& q = p->quals[i];
+      if (q.lhs.nsteps == 0 && q.lhs.leaf0.kind == HDK_LEAF_COL && p->cols[q.lhs.leaf0.col].table == -1 &&
+          p->cols[q.lhs.leaf0.col].buf_idx == 1) {
+        if (q.rhs.kind != HDK_LEAF_INT || ga->npq == kS2MaxPayQuals) return false;
+        if (q.lhs.leaf0.nullable) p_nullable = true, p_null = q.lhs.leaf0.null_val;
+        ga->pq[ga->npq].cmp = q.cmp;
+        ga->pq[ga->npq].rhs = q.rhs.ival;
+        ++ga->npq;
+      } else {
+        if (nq == kMaxPlainQuals) return false;
+        outer_only.quals[nq++] = q;
+      }
+    }
+    outer_only.num_quals = nq;
+    outer_only.num_filter_ops = 0;
+    outer_only.num_cols = p->num_cols;
+    memcpy(outer_only.cols, p->cols, sizeof(p->cols));
+    if (nq && !match_plain_quals(&outer_only, sa.q)) return false;
+    sa.nquals = nq;
+  }
+  // ---- group key: the payload, or payload / literal; perfect hash without a bucket ----------------------------------------------
+  ga->entry_count = shape.entry_count;
+  if (p->query_kind == HDK_Q_PERFECT_HASH) {
+    if (p->key_count != 1 || p->key_bucket[0] > 1) return false;
+    const hdk_hip_expr& ke = p->keys[0];
+    int dummy = -1;
+    if (ke.nsteps > 1 || s2_leaf_kind(p, ke.leaf0, kc, &dummy) != 1) return false;
+    if (ke.leaf0.nullable) p_nullable = true, p_null = ke.leaf0.null_val;
+    if (ke.nsteps == 1) {
+      const hdk_hip_step& sp = ke.steps[0];
+      if (sp.op != HDK_OP_DIV || sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT || sp.rhs.ival < 1 || sp.rhs.ival > INT32_MAX) return false;
+      ga->key_div = static_cast<int32_t>(sp.rhs.ival);
+      if (ga->key_div >= 2) magic_u32(static_cast<uint32_t>(ga->key_div), &ga->div_magic, &ga->div_shift);
+    }
+    ga->grouped = 1;
+    ga->key_min = p->key_min[0];
+    // eval_key: a NULL key takes the translated value when the layout has a slot for NULLs, else stays the NULL sentinel
+    const int64_t null_key = (p->key_has_nulls[0] && ke.nullable) ? p->key_null_translated[0] : ke.null_val;
+    ga->null_entry = static_cast<int64_t>(static_cast<uint64_t>(null_key) - static_cast<uint64_t>(p->key_min[0]));
+  }
+  // ---- the 8-byte tuple: payload and x inside 32 bits by the column statistics ------------------------------------------------------
+  if (pay && !(pay->has_stats && pay->min_val > static_cast<int64_t>(INT32_MIN) + 1 && pay->max_val <= static_cast<int64_t>(INT32_MAX))) return false;
+  sa.key_buf_idx = p->cols[kc].buf_idx;
+  sa.x_buf_idx = xc >= 0 ? p->cols[xc].buf_idx : -1;
+  sa.key_min = jn.min_key;
+  sa.key_range = range;
+  sa.key_nullable = jn.null_mode == HDK_JOIN_NULL_NULLABLE;
+  sa.key_null = jn.null_val;
+  sa.pay_null = p_null;
+  sa.pay_nullable = p_nullable;
+  sa.narrow = 1;
+  if (xc >= 0) {
+    const hdk_hip_col& xcol = p->cols[xc];
+    const bool x_has_nulls = !xcol.has_stats || xcol.has_nulls;
+    if (!(xcol.has_stats && xcol.min_val >= static_cast<int64_t>(INT32_MIN) + (x_has_nulls ? 1 : 0) && xcol.max_val <= static_cast<int64_t>(INT32_MAX))) return false;
+    sa.x_null = x_null;
+    sa.x_null32 = x_nullable ? 1 : 0;
+    if (!x_has_nulls) {
+      sa.x_null_is_stale = sa.x_null32;
+      sa.x_null32 = 0;
+    } else if (!x_nullable) {
+      return false;  // NULLs possible but no sentinel known from the leaves
+    }
+  }
+  // ---- geometry: <= 256 slices whose payloads fit LDS next to the group table ------------------------------------------------------
+  const uint64_t table_bytes1 = static_cast<uint64_t>(shape.entry_count) * wl.wpe * 8;
+  if (table_bytes1 > kS2MaxTableBytes) return false;
+  uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
+  if (slice < 64) slice = 64;
+  if (static_cast<uint64_t>(slice) * 4 + table_bytes1 > kS2LdsBytes) return false;  // (a second scatter level would be needed)
+  uint32_t rep = 1;
+  const uint32_t rep_max = ga->grouped ? 32 : 32;
+  while (rep < rep_max && static_cast<uint64_t>(slice) * 4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
+  ga->rep = rep;
+  sa.slice = slice;
+  magic_u32(slice, &sa.slice_magic, &sa.slice_shift);
+  sa.nbins = static_cast<uint32_t>((range + slice - 1) / slice);
+  if (sa.nbins > shape.grid) return false;  // one block (and one slab) per slice at least
+  const uint64_t rows = ko->total_rows;
+  const uint64_t nsub = static_cast<uint64_t>(sa.nbins) * kSliceXcds;
+  sa.sub = ((rows / nsub) * 17 / 16 + 4096 + 15) & ~15ull;
+  sa.cap_ovf = rows / 8 + 4096;
+  if (sa.sub > 0xFFFFFFF0ull || sa.cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors
+  return true;
+}
+
+static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, Slice2Args& ga,
+                                   const LaunchShape& shape, int64_t* slabs, const hdk_hip_device_properties* props, hipStream_t s,
+                                   bool* launched) {
+  *launched = false;
+  SliceArgs& sa = ga.s;
+  const void* kagg = ga.grouped ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<true>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<false>);
+  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(sa.slice) * 4;
+  if (lds_agg > 48 * 1024 && hipFuncSetAttribute(kagg, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_agg)) != hipSuccess) {
+    (void)hipGetLastError();
+    return HDK_HIP_OK;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kagg, kSliceAggBlock, lds_agg) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return HDK_HIP_OK;
+  }
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  const size_t nsub = static_cast<size_t>(sa.nbins) * kSliceXcds;
+  const size_t b_tuples = up((nsub * sa.sub + sa.cap_ovf) * 8);
+  const size_t b_fill = up((nsub * kSliceCursorStride + 8) * sizeof(uint32_t));
+  AsyncScratch scratch(s);
+  if (hipMallocAsync(&scratch.p, b_tuples + b_fill, s) != hipSuccess) {
+    (void)hipGetLastError();  // no scratch: the interpreter probes in row order
+    scratch.p = nullptr;
+    return HDK_HIP_OK;
+  }
+  int8_t* q = static_cast<int8_t*>(scratch.p);
+  sa.kp = kp;
+  sa.tuples = reinterpret_cast<int64_t*>(q);
+  sa.fill = reinterpret_cast<uint32_t*>(q + b_tuples);
+  sa.fill_ovf = sa.fill + nsub * kSliceCursorStride;
+  sa.mode = sa.fill_ovf + 1;
+  sa.probe = sa.mode + 1;
+  sa.num_slabs = shape.grid;
+  ga.slabs = slabs;
+  ga.error_code = kp.error_code;
+  HDK_HIP_CHECK(hipMemsetAsync(sa.fill, 0, b_fill, s));
+  constexpr int VR = 8;
+  const size_t lds_sc = static_cast<size_t>(kSliceBlock) * VR * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
+  const void* ksc = sa.nquals ? reinterpret_cast<const void*>(hdk_join_scatter_slices<true, true>)
+                              : reinterpret_cast<const void*>(hdk_join_scatter_slices<true, false>);
+  const unsigned g_sc = resident_grid(ksc, kSliceBlock, lds_sc, props);
+  uint32_t members = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu) / sa.nbins;
+  if (members < 1) members = 1;
+  if (sa.nbins * members > shape.grid) members = shape.grid / sa.nbins;
+  if (members < 1) return HDK_HIP_OK;
+  hipLaunchKernelGGL(hdk_join_order_probe, dim3(256), dim3(256), 0, s, sa);
+  if (sa.nquals) {
+    hipLaunchKernelGGL((hdk_join_scatter_slices<true, true>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
+  } else {
+    hipLaunchKernelGGL((hdk_join_scatter_slices<true, false>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
+  }
+  if (ga.grouped) {
+    hipLaunchKernelGGL(hdk_join_agg_sliced2<true>, dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+  } else {
+    hipLaunchKernelGGL(hdk_join_agg_sliced2<false>, dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+  }
+  // armed behind the passes: the batched interpreter over the plan's own columns, in row order -- clustered input, stale
+  // statistics, an overflow area that filled up
+  VecArgs v;
+  v.plan = d_plan;
+  v.kp = kp;
+  v.slabs = slabs;
+  v.entry_count = shape.entry_count;
+  v.rep = shape.rep;
+  v.run_if = sa.mode;
+  hipLaunchKernelGGL(hdk_scan_agg_vec_join, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+  HDK_HIP_CHECK(hipGetLastError());
+  *launched = true;
+  return HDK_HIP_OK;  // (`scratch` is freed here, stream-ordered after the kernels above)
+}
+
+static JoinRoute route_join(const hdk_hip_plan* plan, const LaunchShape& shape, const hdk_hip_kernel_options* ko, JoinDirectArgs* ja,
+                            Slice2Args* ga) {
+  const bool direct = match_join_direct(plan, shape, ja);
+  if (direct) {
+    SliceArgs sa;
+    if (match_join_sliced(plan, *ja, ko, shape.grid, &sa) && sa.fast && !getenv("HDK_HIP_SLICED2_ALWAYS")) {
+      return JOIN_ROUTE_DIRECT;  // BASELINE config 3 itself: SUM(x + payload), its compile-time form
+    }
+  }
+  if (match_join_sliced2(plan, shape, ko, ga)) return JOIN_ROUTE_SLICED2;
+  return direct ? JOIN_ROUTE_DIRECT : JOIN_ROUTE_NONE;
+}
+
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
                                const LaunchShape& shape, int64_t* slabs, hipStream_t s, bool force_generic,
                                bool force_scalar, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
@@ -1313,7 +1604,19 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     }
   }
   JoinDirectArgs ja;
-  if (!force_generic && match_join_direct(plan, shape, &ja)) {
+  Slice2Args ga;
+  const JoinRoute route = force_generic ? JOIN_ROUTE_NONE : route_join(plan, shape, ko, &ja, &ga);
+  if (route == JOIN_ROUTE_SLICED2) {
+    bool launched = false;
+    const int32_t st = launch_join_sliced2(plan, d_plan, kp, ga, shape, slabs, props, s, &launched);
+    if (st || launched) return st;
+    // (no scratch / no block this large: fall through to the kernels that probe in row order)
+    if (match_join_direct(plan, shape, &ja)) {
+      ja.kp = kp;
+      ja.slabs = slabs;
+      return launch_join_direct(plan, ja, ko, shape, props, s);
+    }
+  } else if (route == JOIN_ROUTE_DIRECT) {
     ja.kp = kp;
     ja.slabs = slabs;
     return launch_join_direct(plan, ja, ko, shape, props, s);
@@ -1334,6 +1637,7 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     v.slabs = slabs;
     v.entry_count = shape.entry_count;
     v.rep = shape.rep;
+    v.run_if = nullptr;
     if (plan->num_joins) {
       hipLaunchKernelGGL(hdk_scan_agg_vec_join, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
     } else {
@@ -1617,10 +1921,18 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   {
     ClusterArgs ca;
     JoinDirectArgs jd;
+    Slice2Args g2;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
-    const bool direct = !generic && match_join_direct(plan, s, &jd);
+    const JoinRoute route = generic ? JOIN_ROUTE_NONE : route_join(plan, s, ko, &jd, &g2);
+    const bool direct = route == JOIN_ROUTE_DIRECT;
     SliceArgs sl;
-    if (direct && match_join_sliced(plan, jd, ko, s.grid, &sl)) {
+    if (route == JOIN_ROUTE_SLICED2) {
+      const int n = snprintf(out, out_len, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,");
+      if (n > 0 && static_cast<size_t>(n) < out_len) {
+        out += n;
+        out_len -= static_cast<size_t>(n);
+      }
+    } else if (direct && match_join_sliced(plan, jd, ko, s.grid, &sl)) {
       const int n = snprintf(out, out_len, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
@@ -1632,7 +1944,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
         out += n;
         out_len -= static_cast<size_t>(n);
       }
-    } else if (!direct && match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
+    } else if (route == JOIN_ROUTE_NONE && match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
       const int n = snprintf(out, out_len, "hdk_cluster_by_key,hdk_cluster_params,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
@@ -1642,7 +1954,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   }
   if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize",
-             scan_kernel_name(plan, s, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
+             scan_kernel_name(plan, s, ko, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
                               ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)));
   } else if (s.strategy == STRAT_PROJECT) {
     project_describe(plan, ko, out, out_len);
@@ -1819,9 +2131,11 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   {
     ClusterArgs ca;
     JoinDirectArgs jd;
+    Slice2Args g2;
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
-    const bool direct = !generic && match_join_direct(plan, shape, &jd);  // (clusters its own input, as tuples)
-    if (!direct && match_cluster_join(plan, ko, &ca)) {
+    // (the direct and the sliced join kernels cluster their own input, as tuples)
+    const JoinRoute route = generic ? JOIN_ROUTE_NONE : route_join(plan, shape, ko, &jd, &g2);
+    if (route == JOIN_ROUTE_NONE && match_cluster_join(plan, ko, &ca)) {
       st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch.p);
       if (st) return st;
     }

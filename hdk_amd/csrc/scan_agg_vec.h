@@ -18,6 +18,7 @@ struct VecArgs {
   int64_t* slabs;
   uint32_t entry_count;
   uint32_t rep;
+  const uint32_t* run_if;  // nullptr: always run; else only when *run_if == 1 (armed behind the sliced join, scan_join_sliced2.h)
 };
 
 HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
@@ -55,6 +56,9 @@ template <bool J>
 HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
+  if (a.run_if && *a.run_if != 1) {
+    return;  // (the sliced passes did the job -- or the launch was interrupted: 2)
+  }
   const cplan_t p = to_const_as(a.plan);
   const int tid = threadIdx.x;
   if (tid == 0) {

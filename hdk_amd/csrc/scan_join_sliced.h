@@ -29,6 +29,7 @@
 // Reference behaviour replaced: the probe of the row function, hash_join_idx (QE/GroupByRuntime.cpp:298-366), in row
 // order (QE/IRCodegen.cpp:497-667); aggregates do not depend on row order, so the permutation is invisible.
 #pragma once
+#include "plain_quals.h"
 #include "scan_join_direct.h"
 
 namespace hdk {
@@ -72,6 +73,11 @@ struct SliceArgs {
   int32_t fast;
   int32_t fast_x_nullable, fast_p_nullable;
   int64_t fast_x_null, fast_p_null;
+  // filters `outer column cmp literal` (plain_quals.h), applied by pass 1 before the scatter: a row that fails is never a
+  // tuple (hdk_join_scatter_slices<NARROW, true>; the general sliced plans of scan_join_sliced2.h)
+  int32_t nquals;
+  int32_t pad_q_;
+  ProjFastQual q[kMaxPlainQuals];
 };
 
 // ---- pass 0: is the key column already clustered? ------------------------------------------------------------------
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void hdk_join_order_probe(SliceArgs a) {
 
 // ---- pass 1: rows -> tuples, scattered by slice -----------------------------------------------------------------------
 // dynamic LDS: [kTile][TW] staging | uint8 slice of every staging slot [kTile]
-template <bool NARROW>
+template <bool NARROW, bool Q = false>
 __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs a) {
   constexpr int VR = NARROW ? 8 : 4;
   constexpr int TW = NARROW ? 1 : 2;
@@ -227,6 +233,16 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
           k[r] = live[r] ? gload<int64_t>(kcol, row, true) : 0;
           x[r] = (live[r] && xcol) ? gload<int64_t>(xcol, row, true) : 0;
         }
+      }
+      if (Q) {  // the plan's filters on outer columns: three-valued, NULL fails (plain_quals_pass)
+        int64_t rown[VR];
+        const bool full = tile_row0 + kTile <= nrows;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          rown[r] = full ? tile_row0 + (static_cast<int64_t>(r >> 1) * kSliceBlock + tid) * 2 + (r & 1)
+                         : tile_row0 + static_cast<int64_t>(r) * kSliceBlock + tid;
+        }
+        plain_quals_pass<VR>(a.q, a.nquals, cols, rown, live, true);
       }
       // 1. slice + rank inside the slice.  A key outside [min, max] (a NULL among them) has no partner: the row is dropped
       uint32_t bin[VR], rank[VR];

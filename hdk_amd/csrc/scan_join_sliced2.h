@@ -1,0 +1,446 @@
+// scan_join_sliced2.h -- the sliced join (scan_join_sliced.h) for the star-schema shapes AROUND BASELINE config 3:
+//   SELECT [g(payload),] agg(f(x, payload)), ...  FROM outer JOIN inner ON outer.key = inner.key
+//   [WHERE outer_col cmp literal AND ... AND payload cmp literal ...]  [GROUP BY g(payload)]
+// i.e. the join followed by a perfect-hash GROUP BY on the joined column ("GROUP BY dim.dval % 64" --
+// here every key the reference's planner gives a perfect-hash layout: the payload itself or payload / literal), by
+// filters on either side, and by any list of up to four integer aggregates over x, the payload, x +-* payload or one of
+// them +-* a literal.  The reference runs all of this in ONE row function: join loop, filters, group lookup, agg_*
+// calls (QE/IRCodegen.cpp:497-667 inside QE/RowFuncBuilder.cpp:597-745); here it is the three passes of the sliced join
+//   pass 0  hdk_join_order_probe                 (scan_join_sliced.h, unchanged)
+//   pass 1  hdk_join_scatter_slices<true, Q>     the outer-column filters run BEFORE the scatter: fewer tuples
+//   pass 2  hdk_join_agg_sliced2<GROUPED>        below
+// with the batched interpreter (hdk_scan_agg_vec_join) armed behind them for whatever the 8-byte tuples cannot carry.
+//
+// Pass 2, per 1 024-thread block: the slice's int32 payloads in LDS next to a PRIVATE group table
+// (entry x word x replica, the layout of agg_common.h); per tuple one LDS probe, the payload filters, the group entry, and
+// one LDS atomic per aggregate word.  Everything about a tuple is 32 bits wide -- x and the payload fit by the column
+// statistics the 8-byte tuples rely on -- so NULL tests are 32-bit compares and no result can overflow or collide with a
+// 64-bit sentinel: the row function is ~40 vector instructions where the 64-bit general one of scan_join_direct.h (jd_eval)
+// needs 124.  What a target computes is looked up per tuple from wave-uniform (scalar) state: no per-query code.
+#pragma once
+#include "scan_join_sliced.h"
+
+namespace hdk {
+
+constexpr int kS2MaxTargets = 4;
+constexpr int kS2MaxPayQuals = 2;
+constexpr uint32_t kS2LdsBytes = 160 * 1024 - 1024;  // dynamic LDS of a pass-2 block (static: a few words)
+constexpr uint32_t kS2MaxTableBytes = 48 * 1024;
+
+enum S2Src : int32_t {
+  S2_NONE = 0,   // COUNT(*): the row count word
+  S2_X = 1,
+  S2_P = 2,
+  S2_X_ADD_P = 3,
+  S2_X_SUB_P = 4,
+  S2_P_SUB_X = 5,
+  S2_X_MUL_P = 6,
+  S2_X_OP_LIT = 7,  // x (+ - *) literal, `op`
+  S2_P_OP_LIT = 8
+};
+
+struct S2Target {
+  int32_t src;        // S2Src
+  int32_t op;         // HDK_OP_ADD / SUB / MUL for the *_OP_LIT forms
+  int64_t lit;
+  int32_t null_if_x;  // the argument is NULL when x is (a nullable x leaf is part of it)
+  int32_t null_if_p;
+  int32_t vword, nword;  // words of the entry, or -1
+  int32_t wop;        // WOP_ADD_U64 / WOP_MIN_I64 / WOP_MAX_I64
+  int32_t pad_;
+};
+
+struct S2PayQual {
+  int32_t cmp;        // hdk_hip_cmp
+  int32_t pad_;
+  int64_t rhs;
+};
+
+struct Slice2Args {
+  SliceArgs s;               // geometry, tuples, cursors, mode word, pass-1 filters
+  // group key: none (one entry), the payload, or payload / divisor; perfect hash: entry = key - key_min
+  int32_t grouped;
+  int32_t key_div;           // 0: the payload itself; else the literal divisor (1 .. 2^31 - 1)
+  uint32_t div_magic, div_shift;
+  int64_t key_min;
+  int64_t null_entry;        // entry of a NULL key (translated, or the NULL itself: then usually out of range)
+  uint32_t entry_count;
+  uint32_t rep;              // replicas of the LDS table (power of two)
+  int32_t wpe;
+  int32_t ntargets;
+  S2Target t[kS2MaxTargets];
+  int32_t wop[kMaxWordsPerEntry];
+  uint32_t nword_mask;
+  int32_t npq;
+  S2PayQual pq[kS2MaxPayQuals];
+  int64_t* slabs;
+  int32_t* error_code;
+};
+
+// signed 32-bit / positive invariant divisor, truncating like C (eval_expr's `a / b`)
+HDK_DEV int32_t s2_div(int32_t v, uint32_t d, uint32_t magic, uint32_t shift) {
+  if (d == 1u) {
+    return v;
+  }
+  const uint32_t n = static_cast<uint32_t>(v < 0 ? -v : v);
+  const uint32_t t = __umulhi(magic, n);
+  const uint32_t q = (((n - t) >> 1) + t) >> shift;
+  return v < 0 ? -static_cast<int32_t>(q) : static_cast<int32_t>(q);
+}
+
+// the argument of one target; 32-bit inputs, 64-bit result (|result| < 2^62: no overflow, no sentinel collision)
+HDK_DEV int64_t s2_value(const S2Target& tg, int32_t x, int32_t p) {
+  const int64_t X = x, P = p;
+  switch (tg.src) {
+    case S2_X: return X;
+    case S2_P: return P;
+    case S2_X_ADD_P: return X + P;
+    case S2_X_SUB_P: return X - P;
+    case S2_P_SUB_X: return P - X;
+    case S2_X_MUL_P: return X * P;
+    default: {
+      const int64_t a = tg.src == S2_X_OP_LIT ? X : P;
+      return tg.op == HDK_OP_ADD ? a + tg.lit : (tg.op == HDK_OP_SUB ? a - tg.lit : a * tg.lit);
+    }
+  }
+}
+
+// dynamic LDS: [entry_count x wpe x rep] aggregate words | int32 payload[slice]
+template <bool GROUPED>
+__global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Args g) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  const SliceArgs& a = g.s;
+  const int tid = threadIdx.x;
+  const int wpe = g.wpe;
+  const uint32_t rep = g.rep;
+  const uint32_t ew = g.entry_count * static_cast<uint32_t>(wpe);
+  const uint32_t my_rep = tid & (rep - 1);
+  int32_t* s_pay = reinterpret_cast<int32_t*>(lds + static_cast<size_t>(ew) * rep);
+  __shared__ uint32_t s_off;
+  if (tid == 0) {  // (block-uniform, through LDS: another block of this kernel may raise the word meanwhile)
+    s_off = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool off = s_off != 0;
+  // slabs beyond this grid (hdk_finalize folds the launch shape's count) hold identities
+  for (uint32_t sidx = blockIdx.x + (off ? 0u : gridDim.x); sidx < a.num_slabs; sidx += gridDim.x) {
+    for (uint32_t i = tid; i < ew; i += kSliceAggBlock) {
+      const uint32_t w = i % wpe;
+      g.slabs[static_cast<size_t>(sidx) * ew + i] = (g.nword_mask >> w) & 1u ? 0 : word_identity(g.wop[w]);
+    }
+  }
+  if (off) {
+    return;  // the armed interpreter writes the real slabs
+  }
+  for (uint32_t i = tid; i < ew * rep; i += kSliceAggBlock) {
+    lds[i] = word_identity(g.wop[(i / rep) % wpe]);
+  }
+  const int64_t* __restrict__ table = a.kp.join_hash_tables;  // fused: [row id | payload] per key
+  const uint32_t bin = blockIdx.x % a.nbins, member = blockIdx.x / a.nbins, members = gridDim.x / a.nbins;
+  const uint32_t first = bin * a.slice;
+  const uint32_t nkeys = static_cast<uint32_t>(min(static_cast<uint64_t>(a.slice), a.key_range - first));
+  bool bad = false;
+  for (uint32_t i = tid; i < nkeys; i += kSliceAggBlock) {
+    const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+        reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(first + i) * 16);
+    int32_t p32 = kSliceNoMatch;
+    if (e.x >= 0) {
+      if (a.pay_nullable && e.y == a.pay_null) {
+        p32 = kSliceNull;
+      } else {
+        p32 = static_cast<int32_t>(e.y);
+        bad |= static_cast<int64_t>(p32) != e.y || p32 == kSliceNoMatch || p32 == kSliceNull;
+      }
+    }
+    s_pay[i] = p32;
+  }
+  if (__any(bad) && (tid & (kWave - 1)) == 0) {
+    atomicMax(a.mode, 1u);  // a payload outside what the statistics announced: redone in row order
+  }
+  __syncthreads();
+  // non-grouped: per-lane accumulators, one LDS update per lane at the end
+  uint64_t r_rows = 0;
+  int64_t r_val[kS2MaxTargets];
+  uint64_t r_nulls[kS2MaxTargets];
+#pragma unroll
+  for (int t = 0; t < kS2MaxTargets; ++t) {
+    r_val[t] = (t < g.ntargets && g.t[t].vword >= 0) ? word_identity(g.t[t].wop) : 0;
+    r_nulls[t] = 0;
+  }
+  int32_t err = 0;
+  const int nt = g.ntargets;
+  const int npq = g.npq;
+  const bool x_null32 = a.x_null32 != 0;
+  // K joined rows at a time: everything that is the same for every row of the launch -- which comparison a filter makes,
+  // what a target computes, how its word combines -- is decided ONCE per batch by scalar code, the K rows then run through
+  // straight vector code.  (One row at a time the scalar dispatch was the bottleneck: ~70 scalar instructions per tuple.)
+  constexpr int K = 4;
+  // ok[k]: slot k holds a tuple with a partner; x32 / p32 its outer value and payload (kSliceNull: the column's NULL)
+  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p32)[K], bool (&ok)[K]) {
+    bool pnull[K], xnull[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pnull[k] = p32[k] == kSliceNull;
+      xnull[k] = x_null32 && x32[k] == INT32_MIN;
+    }
+    // filters on the joined column: a NULL fails every comparison (DEF_CMP_NULLABLE)
+    for (int q = 0; q < npq; ++q) {
+      const int64_t rhs = g.pq[q].rhs;
+#define HDK_S2_CMP(OP)                                                                \
+  _Pragma("unroll") for (int k = 0; k < K; ++k) {                                     \
+    ok[k] = ok[k] && !pnull[k] && (static_cast<int64_t>(p32[k]) OP rhs);              \
+  }
+      switch (g.pq[q].cmp) {
+        case HDK_CMP_EQ: HDK_S2_CMP(==) break;
+        case HDK_CMP_NE: HDK_S2_CMP(!=) break;
+        case HDK_CMP_LT: HDK_S2_CMP(<) break;
+        case HDK_CMP_GT: HDK_S2_CMP(>) break;
+        case HDK_CMP_LE: HDK_S2_CMP(<=) break;
+        default: HDK_S2_CMP(>=) break;
+      }
+#undef HDK_S2_CMP
+    }
+    uint32_t base[K];
+    if (GROUPED) {
+      const uint32_t kd = static_cast<uint32_t>(g.key_div);
+      const uint32_t stride = static_cast<uint32_t>(wpe) * rep;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int64_t entry = pnull[k] ? g.null_entry
+                                       : static_cast<int64_t>(kd ? s2_div(p32[k], kd, g.div_magic, g.div_shift) : p32[k]) - g.key_min;
+        if (ok[k] && static_cast<uint64_t>(entry) >= g.entry_count) {
+          err = HDK_HIP_ERR_OUT_OF_SLOTS;  // key outside the range the layout was sized for
+          ok[k] = false;
+        }
+        base[k] = (ok[k] ? static_cast<uint32_t>(entry) : 0u) * stride + my_rep;
+        if (ok[k]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[k]), 1ull);  // row count
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        base[k] = my_rep;
+        r_rows += ok[k] ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kS2MaxTargets; ++t) {
+      if (t < nt && g.t[t].src != S2_NONE) {
+        const S2Target& tg = g.t[t];
+        const bool nx = tg.null_if_x != 0, np = tg.null_if_p != 0;
+        const int64_t lit = tg.lit;
+        int64_t v[K];
+#define HDK_S2_VAL(EXPR)                                  \
+  _Pragma("unroll") for (int k = 0; k < K; ++k) {         \
+    const int64_t X = x32[k], P = p32[k];                 \
+    (void)X;                                              \
+    (void)P;                                              \
+    v[k] = (EXPR);                                        \
+  }
+        switch (tg.src) {
+          case S2_X: HDK_S2_VAL(X) break;
+          case S2_P: HDK_S2_VAL(P) break;
+          case S2_X_ADD_P: HDK_S2_VAL(X + P) break;
+          case S2_X_SUB_P: HDK_S2_VAL(X - P) break;
+          case S2_P_SUB_X: HDK_S2_VAL(P - X) break;
+          case S2_X_MUL_P: HDK_S2_VAL(X * P) break;
+          case S2_X_OP_LIT:
+            if (tg.op == HDK_OP_ADD) { HDK_S2_VAL(X + lit) } else if (tg.op == HDK_OP_SUB) { HDK_S2_VAL(X - lit) } else { HDK_S2_VAL(X * lit) }
+            break;
+          default:
+            if (tg.op == HDK_OP_ADD) { HDK_S2_VAL(P + lit) } else if (tg.op == HDK_OP_SUB) { HDK_S2_VAL(P - lit) } else { HDK_S2_VAL(P * lit) }
+            break;
+        }
+#undef HDK_S2_VAL
+        bool isn[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          isn[k] = (nx && xnull[k]) || (np && pnull[k]);
+        }
+        const int32_t wop = tg.wop;
+        if (GROUPED) {
+          const uint32_t voff = static_cast<uint32_t>(tg.vword) * rep, noff = static_cast<uint32_t>(tg.nword) * rep;
+          if (tg.nword >= 0) {  // counts NULLs; the flush turns it into the non-null count
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              if (ok[k] && isn[k]) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[k] + noff), 1ull);
+              }
+            }
+          }
+          if (tg.vword >= 0) {
+            if (wop == WOP_ADD_U64) {
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                if (ok[k] && !isn[k]) atomicAdd(reinterpret_cast<unsigned long long*>(lds + base[k] + voff), static_cast<unsigned long long>(v[k]));
+              }
+            } else if (wop == WOP_MIN_I64) {
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                if (ok[k] && !isn[k]) atomicMin(reinterpret_cast<long long*>(lds + base[k] + voff), static_cast<long long>(v[k]));
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                if (ok[k] && !isn[k]) atomicMax(reinterpret_cast<long long*>(lds + base[k] + voff), static_cast<long long>(v[k]));
+              }
+            }
+          }
+        } else {
+          int64_t acc = r_val[t];
+          uint64_t nulls = r_nulls[t];
+          const bool has_v = tg.vword >= 0;
+          if (wop == WOP_ADD_U64) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const bool use = ok[k] && !isn[k] && has_v;
+              acc = static_cast<int64_t>(static_cast<uint64_t>(acc) + (use ? static_cast<uint64_t>(v[k]) : 0ull));
+              nulls += (ok[k] && isn[k]) ? 1u : 0u;
+            }
+          } else if (wop == WOP_MIN_I64) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const bool use = ok[k] && !isn[k] && has_v;
+              acc = (use && v[k] < acc) ? v[k] : acc;
+              nulls += (ok[k] && isn[k]) ? 1u : 0u;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const bool use = ok[k] && !isn[k] && has_v;
+              acc = (use && v[k] > acc) ? v[k] : acc;
+              nulls += (ok[k] && isn[k]) ? 1u : 0u;
+            }
+          }
+          r_val[t] = acc;
+          r_nulls[t] = nulls;
+        }
+      }
+    }
+  };
+  // K tuples of this slice: probe the payloads in LDS, then the batch
+  auto tuples = [&](const int64_t (&w)[K], const bool (&live)[K]) {
+    int32_t x32[K], p32[K];
+    bool ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t local = static_cast<uint32_t>(w[k]) - first;
+      const bool in = live[k] && local < nkeys;
+      p32[k] = in ? s_pay[local] : kSliceNoMatch;
+      x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w[k]) >> 32);
+      ok[k] = p32[k] != kSliceNoMatch;  // (INNER join: no partner, no row)
+    }
+    batch(x32, p32, ok);
+  };
+  // the slice's eight sub-slabs: 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
+#pragma unroll 1
+  for (int xq = 0; xq < kSliceXcds; ++xq) {
+    const size_t sidx = static_cast<size_t>(bin) * kSliceXcds + xq;
+    const uint64_t n = min(static_cast<uint64_t>(a.fill[sidx * kSliceCursorStride]), a.sub);
+    const uint64_t npairs = (n + 1) / 2;
+    const int8_t* in = reinterpret_cast<const int8_t*>(a.tuples + sidx * a.sub);
+    const uint64_t stride = static_cast<uint64_t>(members) * kSliceAggBlock;
+    bf_i64x2 n0, n1;
+    n0.x = n0.y = n1.x = n1.y = 0;
+    uint64_t pw = static_cast<uint64_t>(member) * kSliceAggBlock + tid;
+    if (pw < npairs) {
+      n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw), true);
+    }
+    if (pw + stride < npairs) {
+      n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + stride), true);
+    }
+#pragma unroll 1
+    for (; pw < npairs; pw += 2 * stride) {
+      const bf_i64x2 c0 = n0, c1 = n1;
+      if (pw + 2 * stride < npairs) {
+        n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 2 * stride), true);
+      }
+      if (pw + 3 * stride < npairs) {
+        n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 3 * stride), true);
+      }
+      const int64_t w[K] = {c0.x, c0.y, c1.x, c1.y};
+      const bool live[K] = {true, 2 * pw + 1 < n, pw + stride < npairs, pw + stride < npairs && 2 * (pw + stride) + 1 < n};
+      tuples(w, live);
+    }
+  }
+  // the overflow area (tuples of any slice, skewed keys): probed against the table in memory by all blocks together --
+  // a block's group table is private, so any block can take any tuple
+  {
+    const uint64_t n = min(static_cast<uint64_t>(*a.fill_ovf), a.cap_ovf);
+    const int64_t* in = a.tuples + static_cast<size_t>(a.nbins) * kSliceXcds * a.sub;
+    bool bad2 = false;
+    const uint64_t step = static_cast<uint64_t>(gridDim.x) * kSliceAggBlock;
+#pragma unroll 1
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSliceAggBlock + tid; i < n; i += K * step) {
+      int32_t x32[K], p32[K];
+      bool ok[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint64_t ik = i + static_cast<uint64_t>(k) * step;
+        const bool live = ik < n;
+        const int64_t w = live ? in[ik] : 0;
+        bf_i64x2 e;
+        e.x = -1;
+        e.y = 0;
+        if (live) {
+          e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+              reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(static_cast<uint32_t>(w)) * 16);
+        }
+        ok[k] = e.x >= 0;
+        x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w) >> 32);
+        p32[k] = static_cast<int32_t>(e.y);
+        if (ok[k]) {
+          if (a.pay_nullable && e.y == a.pay_null) {
+            p32[k] = kSliceNull;
+          } else {
+            bad2 |= static_cast<int64_t>(p32[k]) != e.y || p32[k] == kSliceNoMatch || p32[k] == kSliceNull;
+          }
+        }
+      }
+      batch(x32, p32, ok);
+    }
+    if (__any(bad2) && (tid & (kWave - 1)) == 0) {
+      atomicMax(a.mode, 1u);
+    }
+  }
+  if (err) {
+    record_error(g.error_code, err);
+  }
+  if (!GROUPED && r_rows) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(lds + my_rep), static_cast<unsigned long long>(r_rows));
+#pragma unroll
+    for (int t = 0; t < kS2MaxTargets; ++t) {
+      if (t < nt && g.t[t].src != S2_NONE) {
+        if (g.t[t].vword >= 0) {
+          vec_lds_op(g.t[t].wop, lds + static_cast<uint32_t>(g.t[t].vword) * rep + my_rep, r_val[t]);
+        }
+        if (g.t[t].nword >= 0 && r_nulls[t]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(lds + static_cast<uint32_t>(g.t[t].nword) * rep + my_rep),
+                    static_cast<unsigned long long>(r_nulls[t]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int64_t* slab = g.slabs + static_cast<size_t>(blockIdx.x) * ew;
+  for (uint32_t i = tid; i < ew; i += kSliceAggBlock) {
+    const uint32_t w = i % wpe;
+    const int32_t op = g.wop[w];
+    int64_t v = lds[i * rep];
+    for (uint32_t r = 1; r < rep; ++r) {
+      v = word_combine(op, v, lds[i * rep + r]);
+    }
+    if ((g.nword_mask >> w) & 1u) {  // NULL count -> non-null count = rows of the entry - NULLs
+      const uint32_t w0 = (i / wpe) * wpe;
+      int64_t rows = 0;
+      for (uint32_t r = 0; r < rep; ++r) {
+        rows += lds[w0 * rep + r];
+      }
+      v = rows - v;
+    }
+    slab[i] = v;
+  }
+}
+
+}  // namespace hdk

@@ -129,7 +129,7 @@ def test_sliced_join_with_a_small_caller_grid(oracle, gpu_executor_factory, grid
     names = step.kernel_names()
     # range 30 000 -> 256 slices of 118 keys: below 256 blocks the slices are not used (the row-order kernel reads
     # clustered tuples instead), from 256 on they are, with the members per slice clamped to the grid
-    assert ("hdk_join_agg_sliced" in names) == (grid >= 256) and "hdk_join_agg_direct" in names, names
+    assert ("hdk_join_agg_sliced" in names) == (grid >= 256) and ("hdk_join_agg_direct" in names or "hdk_scan_agg_vec_join" in names), names
     for _ in range(2):
         assert_buffers_equal(cp, step.run().buffer, want)
     step.free()
@@ -225,6 +225,94 @@ def test_sliced_join_survives_stale_statistics(oracle, gpu_executor_factory):
         assert_buffers_equal(cp, step.run().buffer, want)
         step.free()
         c.fragments[0][11] = saved
+
+
+def _sliced2_queries():
+    """the star-schema shapes around BASELINE config 3 (scan_join_sliced2.h): join + perfect-hash GROUP BY on the joined
+    column, filters on either side, lists of integer aggregates over x and the payload"""
+    X, P = ColRef("x"), ColRef("dval", "dim")
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    return [
+        # SURVEY 8d's variant of C3: GROUP BY a function of the joined column
+        QueryUnit("fact", joins=j, groupby=[P / 15625], targets=[KeyRef(0, "g"), Agg("sum", X, "s")]),
+        QueryUnit("fact", joins=j, groupby=[P / 31250], targets=[KeyRef(0, "g"), Agg("sum", X + P, "s"), Agg("count", None, "c"),
+                                                                  Agg("max", P, "mx"), Agg("min", X, "mn")]),
+        # filters: outer column (pass 1: before the scatter) and joined column (pass 2)
+        QueryUnit("fact", joins=j, quals=[Cmp(X, ">", Lit(-10**9)), Cmp(P, "<", Lit(500_000))], groupby=[P / 100_000],
+                  targets=[KeyRef(0, "g"), Agg("avg", X, "a"), Agg("count", P, "cp")]),
+        QueryUnit("fact", joins=j, quals=[Cmp(ColRef("fk"), "<", Lit(10**9)), Cmp(X, "<=", Lit(0)), Cmp(P, "<>", Lit(17))],
+                  targets=[Agg("sum", X, "s"), Agg("count", None, "c"), Agg("max", P, "mx")]),
+        # non-grouped lists the compile-time form of C3 does not cover
+        QueryUnit("fact", joins=j, targets=[Agg("sum", X, "s"), Agg("count", None, "c"), Agg("max", P, "mx")]),
+        QueryUnit("fact", joins=j, targets=[Agg("sum", X * P, "p"), Agg("min", X - P, "lo"), Agg("max", P - X, "hi"), Agg("count", X, "cx")]),
+        QueryUnit("fact", joins=j, targets=[Agg("sum", P * 3, "p3"), Agg("min", X + 7, "x7"), Agg("avg", P, "ap")]),
+    ]
+
+
+@pytest.mark.parametrize("key_kind", ["uniform", "hot", "sorted"])
+@pytest.mark.parametrize("x_kind,pay_nulls", [("int32", False), ("int32_nulls", True)])
+def test_sliced2_matches_the_oracle(oracle, gpu_executor_factory, key_kind, x_kind, pay_nulls):
+    """hdk_join_agg_sliced2: every shape against the oracle -- keys without a partner, NULL keys, NULL x, NULL payloads
+    (a NULL group key takes the translated slot), hot keys (the overflow area), sorted keys (the order probe hands the
+    launch to the armed interpreter); a second run of the prepared step gives the same buffer."""
+    st = _sliced_tables(500_000, 30_000, 41, x_kind, key_kind, pay_nulls)
+    seen = 0
+    for q in _sliced2_queries():
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, q
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        names = step.kernel_names()
+        assert names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_vec_join"), (q, names)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+        # and the same plan on the interpreters
+        assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+        seen += 1
+    assert seen == 7
+
+
+def test_sliced2_survives_stale_statistics_and_reports_errors(oracle, gpu_executor_factory):
+    """an x outside the announced 32 bits -> the armed interpreter redoes the launch; a payload outside them that also
+    leaves the group-key range, or a key range that no longer covers the data -> ERR_OUT_OF_SLOTS, as on the interpreter.
+    (The oracle is not asked about out-of-range keys: like the reference's get_group_value_fast it would write outside
+    the buffer.)"""
+    from hdk_amd._lib import HdkHipError
+    from hdk_amd.storage import ChunkStats
+    st = _sliced_tables(400_000, 30_000, 43, "int32")
+    q = _sliced2_queries()[1]
+    c = st.get("fact").columns["x"]
+    saved = c.fragments[0][11]
+    c.fragments[0][11] = 2**40 + 3  # the statistics (computed at import) still say +-2^31
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+    assert "hdk_join_agg_sliced2" in step.kernel_names()
+    assert_buffers_equal(cp, step.run().buffer, want)
+    step.free()
+    c.fragments[0][11] = saved
+    # a stale payload: outside 32 bits AND outside the group-key range the layout was sized for
+    d = st.get("dim").columns["dval"]
+    saved = d.fragments[0][11]
+    d.fragments[0][11] = 2**40 + 3
+    for flags in (A.LAUNCH_CLUSTER_PROBES, A.LAUNCH_FORCE_GENERIC):
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(ex.compile(q), flags=flags)
+        with pytest.raises(HdkHipError) as ei:
+            step.run()
+        assert ei.value.code == A.ERR_OUT_OF_SLOTS
+        step.free()
+    d.fragments[0][11] = saved
+    # a key range that no longer covers the data, inside 32 bits: the sliced kernel itself reports it
+    d.stats = [ChunkStats(-10**6, 10**5, False) for _ in d.stats]
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(ex.compile(_sliced2_queries()[0]), flags=A.LAUNCH_CLUSTER_PROBES)
+    assert "hdk_join_agg_sliced2" in step.kernel_names()
+    with pytest.raises(HdkHipError) as ei:
+        step.run()
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS
+    step.free()
 
 
 _SOAK = os.environ.get("HDK_FUZZ_SEEDS", "")

@@ -140,6 +140,43 @@ def test_c3_join_probe_at_baseline_size(mgr, oracle):
     _oracle_sample(w, oracle)
 
 
+def test_c3g_join_then_group_by_at_baseline_size(mgr, oracle):
+    """C3g (SURVEY.md 8d's variant of C3): 1 B-row fact JOIN 10 M-row dim GROUP BY dim.dval / 15625 -> 64 groups, SUM(fact.val):
+    per-group sums = torch index_add over the gathered dimension column; the sliced passes and the interpreter agree."""
+    import torch
+    from hdk_amd.executor import ExecutionResult
+    w = _workload("c3g", mgr)
+    cp = w.compiled
+    out = torch.empty(max(cp.buffer_quads, 1), dtype=torch.int64, device="cuda")
+    names = _run_into(w, out)
+    assert names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_vec_join"), names
+    ref = w.reference_checks()
+    first = out.cpu().numpy().copy()
+    cols = ExecutionResult(cp, first, cp.entry_count).to_columns()
+    assert sorted(cols["g"]) == list(range(64))
+    for g, s_ in zip(cols["g"], cols["s"]):
+        assert (s_ - ref["group_sums"][g]) % (1 << 64) == 0, g
+    assert _run_into(w, out, flags=A.LAUNCH_FORCE_GENERIC).startswith("hdk_scan_agg_vec_join")
+    assert np.array_equal(out.cpu().numpy(), first)
+    _run_into(w, out)
+    assert np.array_equal(out.cpu().numpy(), first)  # idempotent
+    _oracle_sample(w, oracle)
+
+
+def test_c3m_other_target_list_at_baseline_size(mgr, oracle):
+    """C3 with SUM(val), COUNT(*), MAX(dval): not the compile-time form of the headline query, same sliced passes."""
+    import torch
+    w = _workload("c3m", mgr)
+    cp = w.compiled
+    out = torch.empty(max(cp.buffer_quads, 1), dtype=torch.int64, device="cuda")
+    names = _run_into(w, out)
+    assert names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2"), names
+    ref = w.reference_checks()
+    got = out.cpu().numpy()
+    assert int(got[0]) % (1 << 64) == ref["sum_val"] and int(got[1]) == w.rows and int(got[2]) == ref["max_dval"]
+    _oracle_sample(w, oracle)
+
+
 def test_c2_at_baseline_size(mgr, oracle):
     import torch
     from hdk_amd.executor import ExecutionResult

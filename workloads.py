@@ -3,6 +3,8 @@
 
   c2   1 B rows, 64 keys:  SELECT key, SUM(val) ... GROUP BY key                   (headline; perfect hash)
   c3   1 B-row fact JOIN 10 M-row dim on int64 key:  SELECT SUM(fact.val + dim.dval)
+  c3g  the same join, then GROUP BY dim.dval / 15625 (64 groups on the joined column), SUM(fact.val)
+  c3m  the same join with another target list: SUM(fact.val), COUNT(*), MAX(dim.dval)
   c5   1 B rows, 100 M keys:  SELECT key, SUM(val) ... GROUP BY key                (open addressing, 200 M entries)
   c5s  the shard one GPU of eight sees in C5: 125 M rows drawn from the 100 M-key domain (200 M entries)
   q1..q4  taxi Q1-Q4 (Benchmarks/taxi/taxi_reduced_bench.cpp:51-89) over a 1 B-row table with the sample's domains
@@ -43,6 +45,9 @@ CONFIGS = {
     # name: (default rows, algorithmic bytes per row, description)
     "c2": (1_000_000_000, 16, "C2: SELECT key, SUM(val) GROUP BY key; int64, 64 uniform keys"),
     "c3": (1_000_000_000, 16, "C3: SELECT SUM(fact.val + dim.dval) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key"),
+    "c3g": (1_000_000_000, 16, "C3g: SELECT dim.dval / 15625, SUM(fact.val) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key GROUP BY 1 "
+                               "(SURVEY.md 8d's star-schema variant of C3: 64 groups on the joined column)"),
+    "c3m": (1_000_000_000, 16, "C3m: SELECT SUM(fact.val), COUNT(*), MAX(dim.dval) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key"),
     "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
     "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
     "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
@@ -112,7 +117,7 @@ class Workload:
                   self.frag_ids)
             self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
-        elif name == "c3":
+        elif name in ("c3", "c3g", "c3m"):
             self.dim_rows = int(dim_rows)
 
             def dim_key(f, n):
@@ -125,8 +130,13 @@ class Workload:
             self.storage.get("dim").__dict__["_unique_keys_cache"] = {("key", False, 1): 1}  # (cols..., nulls_match, bucket)
             table("fact", {"fk": (I64, uniform(0, self.dim_rows, 2), (0, self.dim_rows - 1)), "val": val}, self.frag_rows,
                   self.frag_ids)
-            self.query = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")],
-                                   targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"), "s")])
+            j = [JoinSpec("dim", ColRef("fk"), "key")]
+            dval = ColRef("dval", "dim")
+            self.query = {
+                "c3": QueryUnit("fact", joins=j, targets=[Agg("sum", ColRef("val") + dval, "s")]),
+                "c3g": QueryUnit("fact", joins=j, groupby=[dval / 15625], targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s")]),
+                "c3m": QueryUnit("fact", joins=j, targets=[Agg("sum", ColRef("val"), "s"), Agg("count", None, "c"), Agg("max", dval, "mx")]),
+            }[name]
         else:  # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types, the sample's value domains)
             table("trips", {
                 "cab_type": (Type("dict", 4), uniform(0, 2, 3, torch.int32), (0, 1)),
@@ -189,16 +199,34 @@ class Workload:
             for f in self.frag_ids:
                 total = (total + int(self.cols[self.val_col][f].sum().item())) % (1 << 64)
             out["sum_val"] = total
-        elif self.name == "c3":
+        elif self.name in ("c3", "c3g", "c3m"):
             key = self.cols[("dim", "key")][0]
             dval = self.cols[("dim", "dval")][0]
             by_key = torch.empty_like(dval)
             by_key[key] = dval  # dval of the dim row whose key is k
             total = 0
+            sums = torch.zeros(64, dtype=torch.int64, device=self.dev)
+            counts = torch.zeros(64, dtype=torch.int64, device=self.dev)
+            sum_val, mx = 0, -(1 << 63)
             for f in self.frag_ids:
                 fk, v = self.cols[("fact", "fk")][f], self.cols[("fact", "val")][f]
-                total = (total + int((v + by_key[fk]).sum().item())) % (1 << 64)
+                d = by_key[fk]
+                if self.name == "c3":
+                    total = (total + int((v + d).sum().item())) % (1 << 64)
+                elif self.name == "c3g":
+                    g = torch.div(d, 15625, rounding_mode="trunc")
+                    sums.index_add_(0, g, v)
+                    counts += torch.bincount(g, minlength=64)
+                else:
+                    sum_val = (sum_val + int(v.sum().item())) % (1 << 64)
+                    mx = max(mx, int(d.max().item()))
+                del d
             out["sum_val_plus_dval"] = total
+            if self.name == "c3g":
+                out["group_sums"] = [int(x) for x in sums.cpu().tolist()]
+                out["group_counts"] = [int(x) for x in counts.cpu().tolist()]
+            if self.name == "c3m":
+                out["sum_val"], out["max_dval"] = sum_val, mx
         else:
             kcol = "cab_type" if self.name == "q1" else "passenger_count"
             counts = None
