@@ -1480,21 +1480,52 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
       return false;  // NULLs possible but no sentinel known from the leaves
     }
   }
-  // ---- geometry: <= 256 slices whose payloads fit LDS next to the group table ------------------------------------------------------
+  // ---- geometry: slices whose payloads fit LDS next to the group table; <= 256 of them: one scatter level, else two ------------
   const uint64_t table_bytes1 = static_cast<uint64_t>(shape.entry_count) * wl.wpe * 8;
   if (table_bytes1 > kS2MaxTableBytes) return false;
+  const uint64_t rows = ko->total_rows;
   uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
   if (slice < 64) slice = 64;
-  if (static_cast<uint64_t>(slice) * 4 + table_bytes1 > kS2LdsBytes) return false;  // (a second scatter level would be needed)
-  uint32_t rep = 1;
-  const uint32_t rep_max = ga->grouped ? 32 : 32;
-  while (rep < rep_max && static_cast<uint64_t>(slice) * 4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
-  ga->rep = rep;
-  sa.slice = slice;
-  magic_u32(slice, &sa.slice_magic, &sa.slice_shift);
-  sa.nbins = static_cast<uint32_t>((range + slice - 1) / slice);
-  if (sa.nbins > shape.grid) return false;  // one block (and one slab) per slice at least
-  const uint64_t rows = ko->total_rows;
+  const bool one_level = static_cast<uint64_t>(slice) * 4 + table_bytes1 <= kS2LdsBytes && !getenv("HDK_HIP_SLICE_TWO_LEVELS");
+  auto pick_rep = [&](uint32_t keys) {
+    uint32_t rep = 1;
+    while (rep < 32 && static_cast<uint64_t>(keys) * 4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
+    return rep;
+  };
+  if (one_level) {
+    ga->rep = pick_rep(slice);
+    sa.slice = slice;
+    magic_u32(slice, &sa.slice_magic, &sa.slice_shift);
+    sa.nbins = static_cast<uint32_t>((range + slice - 1) / slice);
+    ga->fslice = slice;
+    ga->nslices = sa.nbins;
+    ga->nsl_par = sa.nbins;
+    if (sa.nbins > shape.grid) return false;  // one block (and one slab) per slice at least
+  } else {
+    // fine slices of <= 32 K keys (128 KB of LDS; less when the group table is big), `fpc` of them per coarse bin
+    uint64_t fs = (kS2LdsBytes - table_bytes1) / 4;
+    if (fs > 32768) fs = 32768;
+    fs &= ~static_cast<uint64_t>(63);
+    if (fs < 1024) return false;
+    if (const char* e = getenv("HDK_HIP_SLICE_FINE_KEYS")) fs = static_cast<uint64_t>(atoi(e)) & ~63ull;  // (tests: small tables, two levels)
+    if (fs < 64) fs = 64;
+    const uint64_t nslices = (range + fs - 1) / fs;
+    const uint64_t fpc = (nslices + kSliceMaxBins - 1) / kSliceMaxBins;
+    if (fpc > static_cast<uint64_t>(kSliceMaxBins) || fpc * fs > 0xFFFFFFFFull) return false;
+    const uint64_t coarse = fpc * fs;
+    ga->two_level = 1;
+    ga->fpc = static_cast<uint32_t>(fpc);
+    ga->fslice = static_cast<uint32_t>(fs);
+    magic_u32(ga->fslice, &ga->fmagic, &ga->fshift);
+    sa.slice = static_cast<uint32_t>(coarse);
+    magic_u32(sa.slice, &sa.slice_magic, &sa.slice_shift);
+    sa.nbins = static_cast<uint32_t>((range + coarse - 1) / coarse);
+    ga->nslices = sa.nbins * ga->fpc;  // (the last coarse bin's slices past the key range stay empty)
+    ga->rep = pick_rep(ga->fslice);
+    ga->cap2 = ((rows / ((range + fs - 1) / fs)) * 17 / 16 + 2048 + 15) & ~15ull;
+    if (ga->cap2 > 0xFFFFFFF0ull) return false;
+    ga->nsl_par = ga->nslices < shape.grid ? ga->nslices : shape.grid;  // (launch_join_sliced2 lowers it to what is resident)
+  }
   const uint64_t nsub = static_cast<uint64_t>(sa.nbins) * kSliceXcds;
   sa.sub = ((rows / nsub) * 17 / 16 + 4096 + 15) & ~15ull;
   sa.cap_ovf = rows / 8 + 4096;
@@ -1508,7 +1539,7 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   *launched = false;
   SliceArgs& sa = ga.s;
   const void* kagg = ga.grouped ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<true>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<false>);
-  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(sa.slice) * 4;
+  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(ga.fslice) * 4;
   if (lds_agg > 48 * 1024 && hipFuncSetAttribute(kagg, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_agg)) != hipSuccess) {
     (void)hipGetLastError();
     return HDK_HIP_OK;
@@ -1521,9 +1552,12 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
   const size_t nsub = static_cast<size_t>(sa.nbins) * kSliceXcds;
   const size_t b_tuples = up((nsub * sa.sub + sa.cap_ovf) * 8);
-  const size_t b_fill = up((nsub * kSliceCursorStride + 8) * sizeof(uint32_t));
+  const size_t b_tuples2 = ga.two_level ? up(static_cast<size_t>(ga.nslices) * ga.cap2 * 8) : 0;
+  const size_t n_fill1 = nsub * kSliceCursorStride + 8;
+  const size_t n_fill2 = ga.two_level ? static_cast<size_t>(ga.nslices) * kSliceCursorStride : 0;
+  const size_t b_fill = up((n_fill1 + n_fill2) * sizeof(uint32_t));
   AsyncScratch scratch(s);
-  if (hipMallocAsync(&scratch.p, b_tuples + b_fill, s) != hipSuccess) {
+  if (hipMallocAsync(&scratch.p, b_tuples + b_tuples2 + b_fill, s) != hipSuccess) {
     (void)hipGetLastError();  // no scratch: the interpreter probes in row order
     scratch.p = nullptr;
     return HDK_HIP_OK;
@@ -1531,10 +1565,12 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   int8_t* q = static_cast<int8_t*>(scratch.p);
   sa.kp = kp;
   sa.tuples = reinterpret_cast<int64_t*>(q);
-  sa.fill = reinterpret_cast<uint32_t*>(q + b_tuples);
+  ga.tuples2 = reinterpret_cast<int64_t*>(q + b_tuples);
+  sa.fill = reinterpret_cast<uint32_t*>(q + b_tuples + b_tuples2);
   sa.fill_ovf = sa.fill + nsub * kSliceCursorStride;
   sa.mode = sa.fill_ovf + 1;
   sa.probe = sa.mode + 1;
+  ga.fill2 = sa.fill + n_fill1;
   sa.num_slabs = shape.grid;
   ga.slabs = slabs;
   ga.error_code = kp.error_code;
@@ -1544,20 +1580,35 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   const void* ksc = sa.nquals ? reinterpret_cast<const void*>(hdk_join_scatter_slices<true, true>)
                               : reinterpret_cast<const void*>(hdk_join_scatter_slices<true, false>);
   const unsigned g_sc = resident_grid(ksc, kSliceBlock, lds_sc, props);
-  uint32_t members = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu) / sa.nbins;
-  if (members < 1) members = 1;
-  if (sa.nbins * members > shape.grid) members = shape.grid / sa.nbins;
-  if (members < 1) return HDK_HIP_OK;
+  const uint32_t resident = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
+  uint32_t members = 1;
+  if (ga.two_level) {  // persistent blocks, each walking slices b, b + nsl_par, ...
+    if (ga.nsl_par > resident) ga.nsl_par = resident;
+    if (ga.nsl_par > shape.grid) ga.nsl_par = shape.grid;
+  } else {
+    members = resident / sa.nbins;
+    if (members < 1) members = 1;
+    if (sa.nbins * members > shape.grid) members = shape.grid / sa.nbins;
+  }
+  if (members < 1 || ga.nsl_par < 1) return HDK_HIP_OK;
   hipLaunchKernelGGL(hdk_join_order_probe, dim3(256), dim3(256), 0, s, sa);
   if (sa.nquals) {
     hipLaunchKernelGGL((hdk_join_scatter_slices<true, true>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
   } else {
     hipLaunchKernelGGL((hdk_join_scatter_slices<true, false>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
   }
+  if (ga.two_level) {
+    const size_t lds_l2 = static_cast<size_t>(kSliceBlock) * VR * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
+    const uint32_t ncx = (sa.nbins + kSliceXcds - 1) / kSliceXcds;
+    const uint32_t res2 = resident_grid(reinterpret_cast<const void*>(hdk_join_scatter_level2), kSliceBlock, lds_l2, props);
+    uint32_t m2 = res2 / (ncx * kSliceXcds);
+    if (m2 < 1) m2 = 1;
+    hipLaunchKernelGGL(hdk_join_scatter_level2, dim3(ncx * kSliceXcds * m2), dim3(kSliceBlock), lds_l2, s, ga);
+  }
   if (ga.grouped) {
-    hipLaunchKernelGGL(hdk_join_agg_sliced2<true>, dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    hipLaunchKernelGGL(hdk_join_agg_sliced2<true>, dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
   } else {
-    hipLaunchKernelGGL(hdk_join_agg_sliced2<false>, dim3(sa.nbins * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    hipLaunchKernelGGL(hdk_join_agg_sliced2<false>, dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
   }
   // armed behind the passes: the batched interpreter over the plan's own columns, in row order -- clustered input, stale
   // statistics, an overflow area that filled up
@@ -1927,7 +1978,8 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     const bool direct = route == JOIN_ROUTE_DIRECT;
     SliceArgs sl;
     if (route == JOIN_ROUTE_SLICED2) {
-      const int n = snprintf(out, out_len, "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,");
+      const int n = snprintf(out, out_len, g2.two_level ? "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_scatter_level2,hdk_join_agg_sliced2,"
+                                                        : "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
         out_len -= static_cast<size_t>(n);

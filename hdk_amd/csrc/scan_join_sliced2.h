@@ -8,6 +8,7 @@
 // calls (QE/IRCodegen.cpp:497-667 inside QE/RowFuncBuilder.cpp:597-745); here it is the three passes of the sliced join
 //   pass 0  hdk_join_order_probe                 (scan_join_sliced.h, unchanged)
 //   pass 1  hdk_join_scatter_slices<true, Q>     the outer-column filters run BEFORE the scatter: fewer tuples
+//   pass 1b hdk_join_scatter_level2              (key ranges beyond 256 slices: see below)
 //   pass 2  hdk_join_agg_sliced2<GROUPED>        below
 // with the batched interpreter (hdk_scan_agg_vec_join) armed behind them for whatever the 8-byte tuples cannot carry.
 //
@@ -17,6 +18,14 @@
 // statistics the 8-byte tuples rely on -- so NULL tests are 32-bit compares and no result can overflow or collide with a
 // 64-bit sentinel: the row function is ~40 vector instructions where the 64-bit general one of scan_join_direct.h (jd_eval)
 // needs 124.  What a target computes is looked up per tuple from wave-uniform (scalar) state: no per-query code.
+//
+// TWO SCATTER LEVELS (round 4: no more cliff at 256 x 39 936 = 10.2 M keys).  A block can stage 256 write targets in LDS, so
+// a key range of more than 256 LDS-sized slices is cut twice, like the open-addressing group-by (scan_agg_partitioned.h):
+// pass 1 scatters into <= 256 COARSE bins of `fpc` slices each (the same kernel: a coarse bin is its "slice"), pass 1b
+// reads one coarse bin and scatters it into its <= 256 fine slices (all blocks of a coarse bin on one XCD, so that partial
+// lines meet in one L2), pass 2 walks the fine slices, one block at a time per slice, reloading its LDS payloads per
+// slice and keeping its group table across slices.  256 x 256 slices x 32 K keys cover every 32-bit key range; the
+// second level costs 16 more bytes per row (read + write of the 8-byte tuples).
 #pragma once
 #include "scan_join_sliced.h"
 
@@ -75,6 +84,17 @@ struct Slice2Args {
   S2PayQual pq[kS2MaxPayQuals];
   int64_t* slabs;
   int32_t* error_code;
+  // two scatter levels: s.slice / s.nbins describe the COARSE bins; fine slice f of coarse bin c is slice c * fpc + f
+  int32_t two_level;
+  uint32_t fpc;              // fine slices per coarse bin (<= 256)
+  uint32_t fslice;           // keys per fine slice (one level: = s.slice)
+  uint32_t fmagic, fshift;   // (key offset inside the coarse bin) / fslice
+  uint32_t nslices;          // fine slices in all (one level: = s.nbins)
+  uint64_t cap2;             // tuples a fine slab holds (multiple of 16)
+  int64_t* tuples2;          // [nslices][cap2]
+  uint32_t* fill2;           // [nslices] x kSliceCursorStride
+  uint32_t nsl_par;          // pass 2: slices worked on at a time (blocks = nsl_par x members)
+  uint32_t pad2_;
 };
 
 // signed 32-bit / positive invariant divisor, truncating like C (eval_expr's `a / b`)
@@ -102,6 +122,172 @@ HDK_DEV int64_t s2_value(const S2Target& tg, int32_t x, int32_t p) {
       const int64_t a = tg.src == S2_X_OP_LIT ? X : P;
       return tg.op == HDK_OP_ADD ? a + tg.lit : (tg.op == HDK_OP_SUB ? a - tg.lit : a * tg.lit);
     }
+  }
+}
+
+// ---- pass 1b: one coarse bin -> its fine slices ------------------------------------------------------------------------
+// Blocks b with b % 8 == c % 8 work on coarse bin c (all of a bin's writers behind ONE L2: the partial 128-byte lines at
+// the ends of their runs merge there before they reach memory; affinity for speed only, any placement is correct); the
+// bin's eight per-XCD sub-slabs are walked as one sequence of tiles.  Per tile: LDS histogram by fine slice, one cursor
+// claim per slice, staging ordered by slice, copy-out -- the machinery of pass 1.  A tuple that does not fit its fine slab
+// goes to the shared overflow area (probed against the table in memory by pass 2).
+// dynamic LDS: int64 staging[kTile] | uint8 fine slice of every staging slot [kTile]
+__global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Args g) {
+  constexpr int VR = 8;
+  constexpr int kTile = kSliceBlock * VR;
+  const SliceArgs& a = g.s;
+  __shared__ uint32_t s_cnt[kSliceMaxBins];
+  __shared__ uint4 s_run[kSliceMaxBins];  // .x start in the staging area, .y tuples that fit the fine slab, .z slab position, .w overflow position
+  __shared__ uint32_t s_total, s_stop;
+  extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
+  int64_t* s_stage = s_dyn;
+  uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + kTile);
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_stop = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = tid; i < kSliceMaxBins; i += kSliceBlock) {
+    s_cnt[i] = 0;
+  }
+  __syncthreads();
+  if (s_stop) {
+    return;  // clustered input / stale statistics / interrupted: nothing to refine
+  }
+  // block -> (coarse bin, member): bins c = x + 8 j live on XCD x
+  const uint32_t ncx = (a.nbins + kSliceXcds - 1) / kSliceXcds;  // coarse bins per XCD (padded)
+  const uint32_t xcd = blockIdx.x % kSliceXcds, qq = blockIdx.x / kSliceXcds;
+  const uint32_t c = xcd + kSliceXcds * (qq % ncx), member = qq / ncx, members = gridDim.x / (kSliceXcds * ncx);
+  if (c >= a.nbins || member >= members) {
+    return;
+  }
+  const uint32_t cfirst = c * a.slice;  // key offset of the coarse bin's first key
+  const Watch watch = watch_begin(a.kp);
+  int64_t tile = member;
+  int64_t part_tile_begin = 0;
+#pragma unroll 1
+  for (int xq = 0; xq < kSliceXcds; ++xq) {
+    const size_t sidx = static_cast<size_t>(c) * kSliceXcds + xq;
+    const int64_t n = static_cast<int64_t>(min(static_cast<uint64_t>(a.fill[sidx * kSliceCursorStride]), a.sub));
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    const int8_t* in = reinterpret_cast<const int8_t*>(a.tuples + sidx * a.sub);
+#pragma unroll 1
+    for (; tile < part_tile_begin + ntiles; tile += members) {
+      if (tid == 0) {  // block-uniform exit (the batch below has barriers)
+        uint32_t stop = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (watch.flags) {
+          if (const int32_t w_ = watch_poll(watch)) {
+            record_error(a.kp.error_code, w_);
+            atomicMax(a.mode, 2u);
+            stop = 2;
+          }
+        }
+        s_stop = stop;
+      }
+      __syncthreads();
+      if (s_stop) {
+        return;
+      }
+      const int64_t t0 = (tile - part_tile_begin) * kTile;
+      int64_t w[VR];
+      bool live[VR];
+      if (t0 + kTile <= n) {  // full tile: tuples dealt in adjacent pairs, 16-byte non-temporal loads (sub-slabs are 16-byte aligned)
+#pragma unroll
+        for (int u = 0; u < VR / 2; ++u) {
+          const bf_i64x2 ww = gload<bf_i64x2>(in, (t0 >> 1) + static_cast<int64_t>(u) * kSliceBlock + tid, true);
+          w[2 * u] = ww.x;
+          w[2 * u + 1] = ww.y;
+          live[2 * u] = true;
+          live[2 * u + 1] = true;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const int64_t i = t0 + static_cast<int64_t>(r) * kSliceBlock + tid;
+          live[r] = i < n;
+          w[r] = live[r] ? gload<int64_t>(in, i, true) : 0;
+        }
+      }
+      uint32_t bin[VR], rank[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const uint32_t d = static_cast<uint32_t>(w[r]) - cfirst;  // offset inside the coarse bin (< s.slice)
+        const uint32_t t = __umulhi(g.fmagic, d);
+        bin[r] = live[r] ? ((((d - t) >> 1) + t) >> g.fshift) : 0u;
+        if (bin[r] >= g.fpc) {
+          bin[r] = g.fpc - 1;  // (cannot happen for a tuple pass 1 put into this bin)
+        }
+        rank[r] = 0;
+        if (live[r]) {
+          rank[r] = atomicAdd(&s_cnt[bin[r]], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid < kSliceMaxBins) {
+        const uint32_t nn = s_cnt[tid];
+        uint32_t base = 0, nfit = 0, obase = 0;
+        if (nn) {
+          base = atomicAdd(g.fill2 + (static_cast<size_t>(c) * g.fpc + tid) * kSliceCursorStride, nn);
+          nfit = static_cast<uint64_t>(base) >= g.cap2 ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(nn), g.cap2 - base));
+          if (nfit < nn) {
+            obase = atomicAdd(a.fill_ovf, nn - nfit);
+            if (static_cast<uint64_t>(obase) + (nn - nfit) > a.cap_ovf) {
+              atomicMax(a.mode, 1u);  // too skewed for slabs: the interpreter takes over
+            }
+          }
+        }
+        s_run[tid].y = nfit;
+        s_run[tid].z = base;
+        s_run[tid].w = obase;
+      }
+      if (tid < kWave) {  // exclusive scan of the counts: where each slice's run starts in the staging area
+        uint32_t carry = 0;
+        for (int c0 = 0; c0 < kSliceMaxBins; c0 += kWave) {
+          const uint32_t nn = s_cnt[c0 + tid];
+          uint32_t incl = nn;
+#pragma unroll
+          for (int dd = 1; dd < kWave; dd <<= 1) {
+            const uint32_t v = __shfl_up(incl, dd, kWave);
+            if (tid >= dd) {
+              incl += v;
+            }
+          }
+          s_run[c0 + tid].x = carry + incl - nn;
+          carry += __shfl(incl, kWave - 1, kWave);
+        }
+        if (tid == 0) {
+          s_total = carry;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        if (live[r]) {
+          const uint32_t si = s_run[bin[r]].x + rank[r];
+          s_binof[si] = static_cast<uint8_t>(bin[r]);
+          s_stage[si] = w[r];
+        }
+      }
+      if (tid < kSliceMaxBins) {
+        s_cnt[tid] = 0;
+      }
+      __syncthreads();
+      const uint32_t total = s_total;
+      for (uint32_t i = tid; i < total; i += kSliceBlock) {
+        const uint32_t b = s_binof[i];
+        const uint4 run = s_run[b];
+        const uint32_t r = i - run.x;
+        if (r < run.y) {
+          g.tuples2[(static_cast<uint64_t>(c) * g.fpc + b) * g.cap2 + run.z + r] = s_stage[i];
+        } else {
+          const uint64_t o = static_cast<uint64_t>(run.w) + (r - run.y);
+          if (o < a.cap_ovf) {  // (else mode is 1: the launch is redone in row order)
+            a.tuples[static_cast<uint64_t>(a.nbins) * kSliceXcds * a.sub + o] = s_stage[i];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    part_tile_begin += ntiles;
   }
 }
 
@@ -136,28 +322,8 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     lds[i] = word_identity(g.wop[(i / rep) % wpe]);
   }
   const int64_t* __restrict__ table = a.kp.join_hash_tables;  // fused: [row id | payload] per key
-  const uint32_t bin = blockIdx.x % a.nbins, member = blockIdx.x / a.nbins, members = gridDim.x / a.nbins;
-  const uint32_t first = bin * a.slice;
-  const uint32_t nkeys = static_cast<uint32_t>(min(static_cast<uint64_t>(a.slice), a.key_range - first));
-  bool bad = false;
-  for (uint32_t i = tid; i < nkeys; i += kSliceAggBlock) {
-    const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
-        reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(first + i) * 16);
-    int32_t p32 = kSliceNoMatch;
-    if (e.x >= 0) {
-      if (a.pay_nullable && e.y == a.pay_null) {
-        p32 = kSliceNull;
-      } else {
-        p32 = static_cast<int32_t>(e.y);
-        bad |= static_cast<int64_t>(p32) != e.y || p32 == kSliceNoMatch || p32 == kSliceNull;
-      }
-    }
-    s_pay[i] = p32;
-  }
-  if (__any(bad) && (tid & (kWave - 1)) == 0) {
-    atomicMax(a.mode, 1u);  // a payload outside what the statistics announced: redone in row order
-  }
-  __syncthreads();
+  const uint32_t member = blockIdx.x / g.nsl_par, members = gridDim.x / g.nsl_par;
+  uint32_t first = 0, nkeys = 0;  // the slice at hand: key offsets [first, first + nkeys)
   // non-grouped: per-lane accumulators, one LDS update per lane at the end
   uint64_t r_rows = 0;
   int64_t r_val[kS2MaxTargets];
@@ -333,35 +499,75 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     }
     batch(x32, p32, ok);
   };
-  // the slice's eight sub-slabs: 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
+  // the block's slices (one level: exactly one; two levels: slice, slice + nsl_par, ...), each: payloads into LDS, then its
+  // tuples -- 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
 #pragma unroll 1
-  for (int xq = 0; xq < kSliceXcds; ++xq) {
-    const size_t sidx = static_cast<size_t>(bin) * kSliceXcds + xq;
-    const uint64_t n = min(static_cast<uint64_t>(a.fill[sidx * kSliceCursorStride]), a.sub);
-    const uint64_t npairs = (n + 1) / 2;
-    const int8_t* in = reinterpret_cast<const int8_t*>(a.tuples + sidx * a.sub);
-    const uint64_t stride = static_cast<uint64_t>(members) * kSliceAggBlock;
-    bf_i64x2 n0, n1;
-    n0.x = n0.y = n1.x = n1.y = 0;
-    uint64_t pw = static_cast<uint64_t>(member) * kSliceAggBlock + tid;
-    if (pw < npairs) {
-      n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw), true);
+  for (uint32_t sl = blockIdx.x % g.nsl_par; sl < g.nslices; sl += g.nsl_par) {
+    uint32_t coarse = sl, fine = 0;
+    if (g.two_level) {
+      coarse = sl / g.fpc;
+      fine = sl - coarse * g.fpc;
     }
-    if (pw + stride < npairs) {
-      n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + stride), true);
+    first = coarse * a.slice + fine * g.fslice;
+    const uint64_t coarse_end = min(static_cast<uint64_t>(coarse + 1) * a.slice, a.key_range);
+    nkeys = first < coarse_end ? static_cast<uint32_t>(min(static_cast<uint64_t>(g.fslice), coarse_end - first)) : 0u;
+    __syncthreads();  // (the previous slice's probes are done)
+    bool bad = false;
+    for (uint32_t i = tid; i < nkeys; i += kSliceAggBlock) {
+      const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
+          reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(first + i) * 16);
+      int32_t p32 = kSliceNoMatch;
+      if (e.x >= 0) {
+        if (a.pay_nullable && e.y == a.pay_null) {
+          p32 = kSliceNull;
+        } else {
+          p32 = static_cast<int32_t>(e.y);
+          bad |= static_cast<int64_t>(p32) != e.y || p32 == kSliceNoMatch || p32 == kSliceNull;
+        }
+      }
+      s_pay[i] = p32;
     }
+    if (__any(bad) && (tid & (kWave - 1)) == 0) {
+      atomicMax(a.mode, 1u);  // a payload outside what the statistics announced: redone in row order
+    }
+    __syncthreads();
+    const int nparts = g.two_level ? 1 : kSliceXcds;  // one level: the slice's eight per-XCD sub-slabs
 #pragma unroll 1
-    for (; pw < npairs; pw += 2 * stride) {
-      const bf_i64x2 c0 = n0, c1 = n1;
-      if (pw + 2 * stride < npairs) {
-        n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 2 * stride), true);
+    for (int xq = 0; xq < nparts; ++xq) {
+      uint64_t n;
+      const int8_t* in;
+      if (g.two_level) {
+        n = min(static_cast<uint64_t>(g.fill2[static_cast<size_t>(sl) * kSliceCursorStride]), g.cap2);
+        in = reinterpret_cast<const int8_t*>(g.tuples2 + static_cast<size_t>(sl) * g.cap2);
+      } else {
+        const size_t sidx = static_cast<size_t>(sl) * kSliceXcds + xq;
+        n = min(static_cast<uint64_t>(a.fill[sidx * kSliceCursorStride]), a.sub);
+        in = reinterpret_cast<const int8_t*>(a.tuples + sidx * a.sub);
       }
-      if (pw + 3 * stride < npairs) {
-        n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 3 * stride), true);
+      const uint64_t npairs = (n + 1) / 2;
+      const uint64_t stride = static_cast<uint64_t>(members) * kSliceAggBlock;
+      bf_i64x2 n0, n1;
+      n0.x = n0.y = n1.x = n1.y = 0;
+      uint64_t pw = static_cast<uint64_t>(member) * kSliceAggBlock + tid;
+      if (pw < npairs) {
+        n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw), true);
       }
-      const int64_t w[K] = {c0.x, c0.y, c1.x, c1.y};
-      const bool live[K] = {true, 2 * pw + 1 < n, pw + stride < npairs, pw + stride < npairs && 2 * (pw + stride) + 1 < n};
-      tuples(w, live);
+      if (pw + stride < npairs) {
+        n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + stride), true);
+      }
+#pragma unroll 1
+      for (; pw < npairs; pw += 2 * stride) {
+        const bf_i64x2 c0 = n0, c1 = n1;
+        if (pw + 2 * stride < npairs) {
+          n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 2 * stride), true);
+        }
+        if (pw + 3 * stride < npairs) {
+          n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 3 * stride), true);
+        }
+        const int64_t w[K] = {c0.x, c0.y, c1.x, c1.y};
+        const bool live[K] = {true, 2 * pw + 1 < n, pw + stride < npairs, pw + stride < npairs && 2 * (pw + stride) + 1 < n};
+        tuples(w, live);
+      }
     }
   }
   // the overflow area (tuples of any slice, skewed keys): probed against the table in memory by all blocks together --

@@ -273,6 +273,32 @@ def test_sliced2_matches_the_oracle(oracle, gpu_executor_factory, key_kind, x_ki
     assert seen == 7
 
 
+@pytest.mark.parametrize("key_kind", ["uniform", "hot", "sorted"])
+def test_sliced2_two_scatter_levels(oracle, gpu_executor_factory, key_kind, monkeypatch):
+    """Key ranges beyond 256 LDS-sized slices take a second scatter level (hdk_join_scatter_level2): forced here on a
+    90 K-key range with 128-key fine slices (704 slices in 235 coarse bins of 3), every sliced2 shape against the oracle."""
+    monkeypatch.setenv("HDK_HIP_SLICE_TWO_LEVELS", "1")
+    monkeypatch.setenv("HDK_HIP_SLICE_FINE_KEYS", "128")
+    st = _sliced_tables(600_000, 30_000, 47, "int32_nulls", key_kind, True)
+    for q in _sliced2_queries():
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, q
+        step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        assert step.kernel_names().startswith(
+            "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_scatter_level2,hdk_join_agg_sliced2,hdk_scan_agg_vec_join"), step.kernel_names()
+        assert_buffers_equal(cp, step.run().buffer, want)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+    # the headline form SUM(x + payload) too: beyond 10.2 M keys it takes this path
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=[Agg("sum", ColRef("x") + ColRef("dval", "dim"), "s")])
+    cp, want, err = run_oracle(oracle, st, q)
+    monkeypatch.setenv("HDK_HIP_SLICED2_ALWAYS", "1")
+    step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+    assert "hdk_join_scatter_level2" in step.kernel_names()
+    assert_buffers_equal(cp, step.run().buffer, want)
+    step.free()
+
+
 def test_sliced2_survives_stale_statistics_and_reports_errors(oracle, gpu_executor_factory):
     """an x outside the announced 32 bits -> the armed interpreter redoes the launch; a payload outside them that also
     leaves the group-key range, or a key range that no longer covers the data -> ERR_OUT_OF_SLOTS, as on the interpreter.

@@ -61,7 +61,7 @@ class Workload:
     """Tables resident on `device`, the query, and what the checks need."""
 
     def __init__(self, name, rows, device, mgr, frag_ids=None, fragment_size=FRAGMENT_ROWS, dim_rows=10_000_000,
-                 key_domain=100_000_000, seed_offset=0, generators=None):
+                 key_domain=100_000_000, seed_offset=0, generators=None, dim_key_stride=1):
         import torch
         from hdk_amd.executor import Executor
         from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
@@ -119,16 +119,20 @@ class Workload:
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
         elif name in ("c3", "c3g", "c3m"):
             self.dim_rows = int(dim_rows)
+            self.dim_key_stride = stride = int(dim_key_stride)  # > 1: a SPARSE dimension (keys k * stride: the table's range is stride x its rows)
 
             def dim_key(f, n):
                 g = torch.Generator(device=self.dev)
                 g.manual_seed(SEED + 7)
-                return torch.randperm(n, dtype=torch.int64, device=self.dev, generator=g)
-            table("dim", {"key": (I64, dim_key, (0, self.dim_rows - 1)),
+                return torch.randperm(n, dtype=torch.int64, device=self.dev, generator=g) * stride
+
+            def fact_fk(f, n):
+                return uniform(0, self.dim_rows, 2)(f, n) * stride
+            table("dim", {"key": (I64, dim_key, (0, (self.dim_rows - 1) * stride)),
                           "dval": (I64, uniform(0, 10**6, 8), (0, 10**6 - 1))}, [self.dim_rows], [0])
             # the planner decides one-to-one from the inner table's data (plan._inner_keys_unique): a permutation is unique
             self.storage.get("dim").__dict__["_unique_keys_cache"] = {("key", False, 1): 1}  # (cols..., nulls_match, bucket)
-            table("fact", {"fk": (I64, uniform(0, self.dim_rows, 2), (0, self.dim_rows - 1)), "val": val}, self.frag_rows,
+            table("fact", {"fk": (I64, fact_fk, (0, (self.dim_rows - 1) * stride)), "val": val}, self.frag_rows,
                   self.frag_ids)
             j = [JoinSpec("dim", ColRef("fk"), "key")]
             dval = ColRef("dval", "dim")
@@ -202,15 +206,16 @@ class Workload:
         elif self.name in ("c3", "c3g", "c3m"):
             key = self.cols[("dim", "key")][0]
             dval = self.cols[("dim", "dval")][0]
+            st_ = getattr(self, "dim_key_stride", 1)
             by_key = torch.empty_like(dval)
-            by_key[key] = dval  # dval of the dim row whose key is k
+            by_key[key // st_] = dval  # dval of the dim row whose key is k * stride
             total = 0
             sums = torch.zeros(64, dtype=torch.int64, device=self.dev)
             counts = torch.zeros(64, dtype=torch.int64, device=self.dev)
             sum_val, mx = 0, -(1 << 63)
             for f in self.frag_ids:
                 fk, v = self.cols[("fact", "fk")][f], self.cols[("fact", "val")][f]
-                d = by_key[fk]
+                d = by_key[fk // st_]
                 if self.name == "c3":
                     total = (total + int((v + d).sum().item())) % (1 << 64)
                 elif self.name == "c3g":
