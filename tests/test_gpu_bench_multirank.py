@@ -1,0 +1,72 @@
+"""bench.py's N > 1 control flow on the box the driver has: two ranks on ONE GPU, launched exactly as the driver launches
+them (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), collectives staged through the host
+(HDK_BENCH_BACKEND=gloo: the gather + fold of perfect-hash tables, the tuple exchange of the open-addressing group-by and
+its forced fallback, the exchange of partial tables).  Every `checks` entry of the printed line must hold.  The nccl
+branch differs in the transport only (Comm.all_gather / all_reduce / the all-to-all calls)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(config, rows, extra_env=None, scaling="strong", ranks=2):
+    env = dict(os.environ, HDK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
+           "--config", config, "--rows", str(rows), "--scaling", scaling, "--extra", "none", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def _all_checks_hold(line):
+    assert line["checks"], line
+    for k, v in line["checks"].items():
+        assert v is not False, (k, line["checks"])
+
+
+def test_c2_two_ranks_gather_and_fold():
+    line = _run("c2", 64_000_000)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert "all-gather" in line["config"]["parallelism"] and line["config"]["fragments_per_gpu"] == 1
+    _all_checks_hold(line)
+    assert line["checks"]["groups"] == 64 and line["checks"]["oracle_bit_exact_on_sample"] is True
+
+
+def test_q3_two_ranks_weak_scaling():
+    line = _run("q3", 48_000_000, scaling="weak")
+    assert line["scaling"] == "weak" and line["config"]["rows_per_gpu"] == 48_000_000
+    _all_checks_hold(line)
+
+
+def test_c5_two_ranks_tuple_exchange():
+    line = _run("c5", 64_000_000)
+    assert "tuples scattered to owner segments" in line["config"]["parallelism"], line["config"]
+    ex = line["exchange"]
+    assert ex["tuple_bytes"] == 8 and all(ex["ms"][k] > 0 for k in ("scatter", "all_to_all", "aggregate"))
+    assert ex["bytes_sent_over_xgmi_per_gpu"] > 0
+    _all_checks_hold(line)
+    assert line["checks"]["sum_of_sums"] is True and line["checks"]["idempotent"] is True
+
+
+def test_c5_two_ranks_forced_table_exchange():
+    line = _run("c5", 64_000_000, {"HDK_BENCH_EXCHANGE": "tables"})
+    assert "owner partition of the partial table" in line["config"]["parallelism"], line["config"]
+    assert line["merge"]["ms"] > 0 and line["merge"]["bytes_sent_over_xgmi_per_gpu"] > 0
+    _all_checks_hold(line)
