@@ -161,8 +161,14 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         owner_t = torch.empty(D.baseline_table_quads(cp, n_owner), dtype=torch.int64, device="cuda")
         step = w.ex.prepare(cp, w.frag_ids, flags=int(os.environ.get("HDK_BENCH_FLAGS", "0")), out_ptr=owner_t.data_ptr())
         why = ""
-        if os.environ.get("HDK_BENCH_EXCHANGE", "tuples") == "tables":
-            why = "HDK_BENCH_EXCHANGE=tables"
+        # tuples or pre-aggregated tables: HDK_BENCH_EXCHANGE=tuples|tables forces one; "auto" (default) asks the cost model
+        # (measured compute rates + an assumed link rate, hdk_amd/distributed.py: the same answer on every rank)
+        pick = os.environ.get("HDK_BENCH_EXCHANGE", "auto")
+        owner["model"] = D.choose_open_addressing_exchange(world, int(bound.item()), getattr(w, "key_domain", cp.entry_count // 2))
+        if pick == "auto":
+            pick = owner["model"]["mode"]
+        if pick == "tables":
+            why = "cost model / HDK_BENCH_EXCHANGE: tables"
         else:
             try:
                 C_probe = A.ExchangeShape()
@@ -419,6 +425,8 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     if mode == "tables" and merge_ms:
         out["merge"] = {"ms": float(np.mean(merge_ms)), "bytes_sent_over_xgmi_per_gpu": owner.get("sent_bytes"),
                         "what": "owner partition + all_to_all_single + owner re-insert, HIP events on the step's stream"}
+    if owner.get("model"):
+        out["exchange_model"] = owner["model"]
     if mode == "tuples":
         out["exchange"] = {"ms": xch_ms, "bytes_sent_over_xgmi_per_gpu": xch.bytes_sent_per_rank,
                            "tuple_bytes": int(xch.shape.tuple_bytes), "owner_entries": xch.owner_entries,

@@ -247,6 +247,43 @@ def owner_entry_count_for(entry_count: int, world_size: int) -> int:
     return max(-(-int(entry_count) // int(world_size)), 1024)
 
 
+def choose_open_addressing_exchange(world_size: int, rows_per_rank: int, key_domain: int, tuple_bytes: int = 8,
+                                    entry_bytes: int = 16, link_gbps: float = 64.0, rates: Optional[dict] = None) -> dict:
+    """Tuples or pre-aggregated tables for a multi-GPU open-addressing group-by?  A model, not a measurement of the wire:
+    every piece of COMPUTE is a rate measured on one MI355X (profiles/r03_multi_gpu_floor_after.json,
+    profiles/r03_c5_tuple_exchange_emulated.json), the wire is `link_gbps` per direction and GPU pair (xGMI is point to
+    point: a rank's bytes for owner o cross ONE link; the figure is an ASSUMPTION -- the microarch guide lists ~153 GB/s per
+    link peak, RCCL all-to-all reaches a fraction of it; no multi-GPU box was available to measure it).
+
+    tuples: every row travels once as `tuple_bytes`; a rank sends rows x (G-1)/G of them, (G-1) links in parallel.
+    tables: a rank first aggregates its rows into a table of its own, then ships its DISTINCT groups:
+            d = K (1 - exp(-rows / K)) entries of `entry_bytes` -- fewer bytes than tuples while a rank sees its keys
+            several times (1 B rows / 100 M keys: 5 rows per group and rank at G = 2, 2.7 at G = 4, 1.75 at G = 8), but it
+            pays a local aggregation, the owner partition of the table and a re-insert at the owner.
+    Returns {"mode", "tuples_ms", "tables_ms", "tuples_wire_bytes", "tables_wire_bytes", ...}."""
+    import math
+    G = int(world_size)
+    r = {"scatter_rows_per_ms": 128e6 / 0.72,          # hdk_hip_scatter_to_owners: 128 M rows in 0.72 ms
+         "aggregate_tuples_per_ms": 128e6 / 1.09,      # hdk_hip_aggregate_from_ranks: 8 x 16 M tuples in 1.04-1.14 ms
+         "local_groupby_rows_per_ms": 125e6 / 1.98,    # one local table (C5 shard shape)
+         "partition_entries_per_ms": 200e6 / 7.4,      # hdk_hip_partition_baseline over a 200 M-entry table
+         "reinsert_entries_per_ms": 71e6 / 4.3}        # hdk_hip_reduce_buffers re-insert at the owner
+    r.update(rates or {})
+    rows, K = float(rows_per_rank), float(key_domain)
+    distinct = K * (1.0 - math.exp(-rows / K)) if K > 0 else rows
+    frac = (G - 1) / G
+    link_bytes_per_ms = link_gbps * 1e6
+    t_bytes = rows * frac * tuple_bytes
+    e_bytes = distinct * frac * entry_bytes
+    links = max(G - 1, 1)
+    tuples_ms = rows / r["scatter_rows_per_ms"] + t_bytes / links / link_bytes_per_ms + rows / r["aggregate_tuples_per_ms"]
+    tables_ms = (rows / r["local_groupby_rows_per_ms"] + 2 * distinct / r["partition_entries_per_ms"] +
+                 e_bytes / links / link_bytes_per_ms + distinct / r["reinsert_entries_per_ms"])
+    return {"mode": "tuples" if tuples_ms <= tables_ms else "tables", "tuples_ms": tuples_ms, "tables_ms": tables_ms,
+            "tuples_wire_bytes": t_bytes, "tables_wire_bytes": e_bytes, "distinct_groups_per_rank": distinct,
+            "rows_per_group_and_rank": rows / distinct if distinct else 0.0, "link_gbps_assumed": link_gbps}
+
+
 def exchange_equal_segments(send, recv, world_size: int, group=None):
     """The one collective of the tuple exchange: `send` and `recv` are `world_size` segments of equal size; segment o of
     rank r's `send` lands as segment r of rank o's `recv`.  Sizes are static (hdk_hip_exchange_shape::segment_bytes):

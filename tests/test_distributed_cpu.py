@@ -222,3 +222,20 @@ def test_tuple_exchange_routes_equal_segments_gloo():
     """The collective of the tuple exchange at world size 2 and 4: segment o of rank r arrives as segment r of rank o."""
     _spawn(_segments_worker, 2, 39500 + (os.getpid() % 2000))
     _spawn(_segments_worker, 4, 41500 + (os.getpid() % 2000))
+
+
+def test_exchange_cost_model_counts_bytes_the_right_way():
+    """1 B rows over 100 M keys: a rank of TWO holds 500 M rows = 5 rows per group, so pre-aggregated entries are fewer
+    bytes than tuples at G = 2 and 4 and about as many at G = 8 (round-3 verdict: DESIGN.md had this backwards); what the
+    model picks also prices the local aggregation, the owner partition and the re-insert."""
+    from hdk_amd.distributed import choose_open_addressing_exchange as model
+    m2, m4, m8 = (model(g, 1_000_000_000 // g, 100_000_000) for g in (2, 4, 8))
+    assert 4.9 < m2["rows_per_group_and_rank"] < 5.1 and 2.6 < m4["rows_per_group_and_rank"] < 2.8 and 1.7 < m8["rows_per_group_and_rank"] < 1.8
+    assert m2["tables_wire_bytes"] < 0.5 * m2["tuples_wire_bytes"]
+    assert m4["tables_wire_bytes"] < m4["tuples_wire_bytes"]
+    assert m8["tables_wire_bytes"] > m8["tuples_wire_bytes"]
+    assert m2["mode"] == "tables" and m8["mode"] == "tuples"
+    # a faster wire moves the break-even: with nothing to pay for bytes the tuple exchange's cheaper compute wins everywhere
+    assert model(2, 500_000_000, 100_000_000, link_gbps=1e6)["mode"] == "tuples"
+    # few keys: a table exchange ships almost nothing
+    assert model(8, 125_000_000, 1000)["tables_wire_bytes"] < 1e6

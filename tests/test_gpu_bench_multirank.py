@@ -56,13 +56,14 @@ def test_q3_two_ranks_weak_scaling():
 
 
 def test_c5_two_ranks_tuple_exchange():
-    line = _run("c5", 64_000_000)
+    line = _run("c5", 64_000_000, {"HDK_BENCH_EXCHANGE": "tuples"})
     assert "tuples scattered to owner segments" in line["config"]["parallelism"], line["config"]
     ex = line["exchange"]
     assert ex["tuple_bytes"] == 8 and all(ex["ms"][k] > 0 for k in ("scatter", "all_to_all", "aggregate"))
     assert ex["bytes_sent_over_xgmi_per_gpu"] > 0
     _all_checks_hold(line)
     assert line["checks"]["sum_of_sums"] is True and line["checks"]["idempotent"] is True
+    assert line["exchange_model"]["mode"] in ("tuples", "tables") and line["exchange_model"]["link_gbps_assumed"] == 64.0
 
 
 def test_c5_two_ranks_forced_table_exchange():

@@ -113,6 +113,7 @@ class Workload:
             self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
         elif name in ("c5", "c5s"):
+            self.key_domain = int(key_domain)
             table("t", {"key": (I64, uniform(0, key_domain, 0), (0, key_domain - 1)), "val": val}, self.frag_rows,
                   self.frag_ids)
             self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
