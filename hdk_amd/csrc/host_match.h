@@ -126,6 +126,10 @@ int32_t launch_head(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT]
 // HIP events around a launch's dominant kernels (HDK_HIP_LAUNCH_RECORD_EVENTS): begin returns the pair to record
 int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
 
+// ---- scan_fast.hip: the streaming kernel hdk_scan_agg_direct (scan_agg_fast.h), key width kw, value width vw ---------
+struct FastArgs;
+int32_t launch_fast_direct(int kw, int vw, const FastArgs& fa, const LaunchShape& shape, hipStream_t s);
+
 // ---- scan_baseline.hip: GroupByBaselineHash plans and perfect-hash tables too big for LDS (STRAT_GLOBAL) ----------
 // persistent grid of the kernel that will run (x 4: random atomics make block run times uneven)
 uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props);

@@ -757,7 +757,9 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     const uint32_t cu = static_cast<uint32_t>(props->num_cu);
     const bool static_ops = fa.nops == 1 || ((fa.nops == 2 || fa.nops == 3) && fa.op_kind[0] == FOP_ADD_ONE &&
                                              (fa.op_kind[1] == FOP_ADD_U64 || fa.op_kind[1] == FOP_ADD_F64));
-    if (fa.nquals) {
+    if (fa.nxq || fa.vform) {
+      s.grid = 3u * cu;  // X mode (24-32 B/row over three or four streamed columns): c2x at 256 M rows 768 blocks 0.960 ms, 1024 1.054, 1280 1.079, 1536 1.035
+    } else if (fa.nquals) {
       s.grid = 4u * cu;  // filtered: the filter-column gathers want more waves (C2 + WHERE: 1.09 vs 1.14 ms at 2 per CU)
     } else if (kw == 0 || kw + vw >= 16) {
       s.grid = 2u * cu;
@@ -849,6 +851,7 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   int vcol = -1;
   int vw = 0;
   bool need_real_rowcount = false, need_real_nn = false;
+  const hdk_hip_expr* vexpr = nullptr;  // every aggregate argument is this one expression: column a, a op column b, a op literal
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     if (tg.agg == HDK_AGG_ID) {
@@ -860,9 +863,11 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
       need_real_rowcount = true;
       continue;
     }
-    int c;
-    if (!plain_outer_col(p, tg.arg, &c)) return false;
-    if (vcol >= 0 && c != vcol) return false;
+    const hdk_hip_expr& e = tg.arg;
+    if (vexpr && memcmp(vexpr, &e, sizeof(e)) != 0) return false;
+    vexpr = &e;
+    if (e.nsteps > 1 || e.leaf0.kind != HDK_LEAF_COL || p->cols[e.leaf0.col].table != 0) return false;
+    const int c = e.leaf0.col;
     vcol = c;
     const hdk_hip_col& col = p->cols[c];
     const bool fp = col.kind == HDK_COL_DOUBLE;
@@ -876,6 +881,36 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     fa->val_null = tg.arg.null_val;
     fa->val_nullable = nullable;
     fa->val_is_fp = fp;
+    if (e.nsteps == 1) {
+      // a op b / a op literal over 8-byte integer columns (the Q instantiations: fast_value_expr)
+      const hdk_hip_step& sp = e.steps[0];
+      if (fp || col.width != 8 || tg.arg_is_fp || sp.out_class != HDK_VC_INT) return false;
+      if (sp.op != HDK_OP_ADD && sp.op != HDK_OP_SUB && sp.op != HDK_OP_MUL) return false;
+      // a NULL operand gives the step's NULL, which must be what the target skips (eval_target_arg: arg.null_val, and the
+      // slot's own sentinel for a value that collides with it)
+      if (tg.skip_null && (e.null_val != sp.null_out || tg.null_val != sp.null_out)) return false;
+      if (!tg.skip_null && (e.leaf0.nullable || sp.rhs.nullable)) return false;
+      fa->a_nullable = e.leaf0.nullable;
+      fa->a_null = e.leaf0.null_val;
+      fa->vop = sp.op;
+      fa->v_check_width = sp.check_width;
+      fa->v_null_out = sp.null_out;
+      if (sp.rhs.kind == HDK_LEAF_INT) {
+        fa->vform = 2;
+        fa->v_lit = sp.rhs.ival;
+      } else if (sp.rhs.kind == HDK_LEAF_COL) {
+        const hdk_hip_col& bc = p->cols[sp.rhs.col];
+        if (bc.table != 0 || bc.kind != HDK_COL_INT || bc.width != 8 || sp.rhs.col == c) return false;
+        fa->vform = 1;
+        fa->x_buf_idx[0] = bc.buf_idx;  // extra streamed column 0
+        fa->nx = 1;
+        fa->b_src = 1;
+        fa->b_nullable = sp.rhs.nullable;
+        fa->b_null = sp.rhs.null_val;
+      } else {
+        return false;
+      }
+    }
     const bool counts_rows = tg.agg == HDK_AGG_COUNT || tg.agg == HDK_AGG_AVG;
     if (counts_rows && target_has_nn_word(tg)) need_real_nn = true;
     if (counts_rows && !target_has_nn_word(tg)) need_real_rowcount = true;
@@ -921,64 +956,62 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   }
   if (nops > kFastMaxOps) return false;
   fa->nops = nops;
-  if (p->num_quals) {
-    // filtered plans: only the instantiations launch_direct_kw has (grouped, 8-byte value column)
-    if (kw == 0 || vw != 8 || !match_plain_quals(p, fa->q)) return false;
-    fa->nquals = p->num_quals;
+  if (p->num_quals || fa->vform) {
+    // filtered plans / expression arguments: only the instantiations scan_fast.hip has (grouped, 8-byte value column)
+    if (kw == 0 || vw != 8 || p->num_filter_ops) return false;
+    // X mode: every filter operand is the value column, the (8-byte) key column, one of <= 2 other 8-byte integer columns
+    // -- streamed with 16-byte loads beside the value column -- or an integer literal
+    FastArgs x = *fa;
+    // (filters against literals only, no expression: the gathered form -- any column width, and measured faster for that
+    // shape: C2 + WHERE c < 0 at 256 M rows 0.98 ms against 1.10 ms with c streamed)
+    bool needs_x = fa->vform != 0;
+    for (int i = 0; i < p->num_quals; ++i) needs_x = needs_x || p->quals[i].rhs.kind == HDK_LEAF_COL;
+    bool xmode = needs_x && !fa->val_is_fp && !getenv("HDK_HIP_FAST_NO_XMODE");
+    auto src_of = [&](int col) -> int {
+      const hdk_hip_col& cc = p->cols[col];
+      if (cc.table != 0 || cc.kind != HDK_COL_INT || cc.width != 8) return -1;
+      if (cc.buf_idx == x.val_buf_idx) return 0;
+      if (kw == 8 && cc.buf_idx == x.key_buf_idx) return 3;
+      for (int i = 0; i < x.nx; ++i) {
+        if (x.x_buf_idx[i] == cc.buf_idx) return 1 + i;
+      }
+      if (x.nx == 2) return -1;
+      x.x_buf_idx[x.nx] = cc.buf_idx;
+      return 1 + x.nx++;
+    };
+    for (int i = 0; xmode && i < p->num_quals; ++i) {
+      const hdk_hip_qual& q = p->quals[i];
+      FastArgs::XQual& xq = x.xq[i];
+      if (i >= kMaxPlainQuals || q.lhs.nsteps || q.lhs.leaf0.kind != HDK_LEAF_COL) { xmode = false; break; }
+      xq.lhs_src = src_of(q.lhs.leaf0.col);
+      xq.lhs_nullable = q.lhs.leaf0.nullable;
+      xq.lhs_null = q.lhs.leaf0.null_val;
+      xq.cmp = q.cmp;
+      if (q.rhs.kind == HDK_LEAF_INT) {
+        xq.rhs_src = 4;
+        xq.lit = q.rhs.ival;
+      } else if (q.rhs.kind == HDK_LEAF_COL) {
+        xq.rhs_src = src_of(q.rhs.col);
+        xq.rhs_nullable = q.rhs.nullable;
+        xq.rhs_null = q.rhs.null_val;
+      } else {
+        xq.rhs_src = -1;
+      }
+      if (xq.lhs_src < 0 || xq.rhs_src < 0) xmode = false;
+    }
+    if (xmode) {
+      x.nxq = p->num_quals;
+      *fa = x;
+    } else {
+      // gathered `column cmp literal` filters (any column width, fp literals): the Q instantiations; no expression argument
+      if (fa->vform || !match_plain_quals(p, fa->q)) return false;
+      fa->nquals = p->num_quals;
+    }
   }
   *kw_out = kw;
   *vw_out = vw;
   return true;
 }
-
-template <int KW, int VW, int FIXED, bool Q = false>
-static int32_t launch_direct(const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
-  constexpr int U = (KW != 0 && VW != 0) ? 4 : 8;
-  hipLaunchKernelGGL((hdk_scan_agg_direct<KW, VW, U, FIXED, Q>), dim3(shape.grid), dim3(kFastBlock), shape.lds_bytes,
-                     s, fa);
-  HDK_HIP_CHECK(hipGetLastError());
-  return HDK_HIP_OK;
-}
-
-// compile-time op list for the single-op shapes (C2: one ds_add_u64 per row; Q1: one +1 per row)
-template <int KW>
-static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& shape, hipStream_t s) {
-  const int only = fa.nops == 1 ? fa.op_kind[0] : -1;
-  if (fa.nquals) {  // filtered: KW != 0 and VW == 8 (match_fast); three op-list forms
-    if (KW == 0) return HDK_HIP_ERR_UNSUPPORTED;
-    constexpr int KQ = KW ? KW : 8;
-    if (only == FOP_ADD_U64) return launch_direct<KQ, 8, FOP_ADD_U64, true>(fa, shape, s);
-    if (fa.nops == 3 && fa.op_kind[0] == FOP_ADD_ONE && fa.op_word[0] == 0 && fa.op_kind[1] == FOP_ADD_U64 &&
-        fa.op_kind[2] == FOP_ADD_ONE_IF_NULL) {
-      return launch_direct<KQ, 8, 100, true>(fa, shape, s);
-    }
-    return launch_direct<KQ, 8, -1, true>(fa, shape, s);
-  }
-  switch (vw) {
-    case 0:
-      if (KW != 0 && only == FOP_ADD_ONE) return launch_direct<KW, 0, FOP_ADD_ONE>(fa, shape, s);
-      return launch_direct<KW, 0, -1>(fa, shape, s);
-    case 4:
-      return launch_direct<KW, 4, -1>(fa, shape, s);
-    default: {
-      if (only == FOP_ADD_U64) return launch_direct<KW, 8, FOP_ADD_U64>(fa, shape, s);
-      if (only == FOP_ADD_F64) return launch_direct<KW, 8, FOP_ADD_F64>(fa, shape, s);
-      // "row count, sum[, NULL count]" (one AVG, or SUM + COUNT of the same column): compile-time list
-      const bool sum_list = (fa.nops == 2 || fa.nops == 3) && fa.op_kind[0] == FOP_ADD_ONE && fa.op_word[0] == 0 &&
-                            (fa.op_kind[1] == FOP_ADD_U64 || fa.op_kind[1] == FOP_ADD_F64) &&
-                            (fa.nops == 2 || fa.op_kind[2] == FOP_ADD_ONE_IF_NULL);
-      if (sum_list && KW != 0) {
-        const bool fp = fa.op_kind[1] == FOP_ADD_F64;
-        if (fa.nops == 3) {
-          return fp ? launch_direct<KW, 8, 101>(fa, shape, s) : launch_direct<KW, 8, 100>(fa, shape, s);
-        }
-        return fp ? launch_direct<KW, 8, 103>(fa, shape, s) : launch_direct<KW, 8, 102>(fa, shape, s);
-      }
-      return launch_direct<KW, 8, -1>(fa, shape, s);
-    }
-  }
-}
-
 
 // (same decisions as launch_scan_lds)
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, const hdk_hip_kernel_options* ko, bool force_generic,
@@ -1646,13 +1679,7 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   if (!force_generic && match_fast(plan, shape, &fa, &kw, &vw)) {
     fa.kp = kp;
     fa.slabs = slabs;
-    switch (kw) {
-      case 0: return launch_direct_kw<0>(vw, fa, shape, s);
-      case 1: return launch_direct_kw<1>(vw, fa, shape, s);
-      case 2: return launch_direct_kw<2>(vw, fa, shape, s);
-      case 4: return launch_direct_kw<4>(vw, fa, shape, s);
-      default: return launch_direct_kw<8>(vw, fa, shape, s);
-    }
+    return launch_fast_direct(kw, vw, fa, shape, s);  // (scan_fast.hip: the instantiations live in their own translation unit)
   }
   JoinDirectArgs ja;
   Slice2Args ga;

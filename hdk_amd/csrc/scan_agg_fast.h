@@ -61,7 +61,79 @@ struct FastArgs {
   uint32_t nword_mask;  // (counting mode) bit w: word w holds a NULL count
   int32_t nquals;       // plain filters `outer column cmp literal` (Q instantiations only)
   ProjFastQual q[kMaxPlainQuals];
+  // ---- X instantiations (round 4): up to two EXTRA 8-byte integer columns streamed like the value column (16-byte loads,
+  // issued with the tile's other loads), so that
+  //   * the aggregate argument may be an expression over the value column a:  a op e  or  a op literal, op in + - *, with the
+  //     reference's NULL propagation and overflow check (DEF_ARITH_NULLABLE, QE/ArithmeticIR.cpp:277-520);
+  //   * filters may compare any two of {a, the extra columns, the key column (8-byte keys)} or one of them with a literal
+  //     (DEF_CMP_NULLABLE: a NULL on either side fails the conjunct).
+  // Operands are named by source: 0 = a, 1 / 2 = extra column 0 / 1, 3 = the key column, 4 = a literal.
+  int32_t nx;               // extra streamed columns
+  int32_t x_buf_idx[2];
+  int32_t nxq;              // filters in operand form (nquals is 0 then)
+  struct XQual {
+    int32_t lhs_src, rhs_src;
+    int32_t cmp;            // hdk_hip_cmp
+    int32_t lhs_nullable, rhs_nullable;
+    int32_t pad_;
+    int64_t lhs_null, rhs_null, lit;
+  } xq[kMaxPlainQuals];
+  int32_t vform;            // 0: the value column itself; 1: a op extra column b_src; 2: a op literal
+  int32_t vop;              // HDK_OP_ADD / SUB / MUL
+  int32_t v_check_width;
+  int32_t b_src;            // 1 / 2
+  int32_t a_nullable, b_nullable;
+  int64_t a_null, b_null;
+  int64_t v_lit;
+  int64_t v_null_out;       // NULL of the expression's result (= val_null: what the row body skips)
 };
+
+// operand of an X-mode filter / expression
+HDK_DEV int64_t fast_x_src(int32_t src, int64_t a, int64_t e0, int64_t e1, int64_t key, int64_t lit) {
+  return src == 0 ? a : (src == 1 ? e0 : (src == 2 ? e1 : (src == 3 ? key : lit)));
+}
+
+// the X-mode filters of one row: true when every conjunct is TRUE
+HDK_DEV bool fast_x_pass(const FastArgs& a, int64_t va, int64_t e0, int64_t e1, int64_t key) {
+  bool pass = true;
+  const int n = a.nxq;
+  for (int q = 0; q < n; ++q) {
+    const FastArgs::XQual& xq = a.xq[q];
+    const int64_t l = fast_x_src(xq.lhs_src, va, e0, e1, key, 0);
+    const int64_t r = fast_x_src(xq.rhs_src, va, e0, e1, key, xq.lit);
+    const bool isnull = (xq.lhs_nullable && l == xq.lhs_null) || (xq.rhs_nullable && r == xq.rhs_null);
+    bool c;
+    switch (xq.cmp) {
+      case HDK_CMP_EQ: c = l == r; break;
+      case HDK_CMP_NE: c = l != r; break;
+      case HDK_CMP_LT: c = l < r; break;
+      case HDK_CMP_GT: c = l > r; break;
+      case HDK_CMP_LE: c = l <= r; break;
+      default: c = l >= r; break;
+    }
+    pass = pass && c && !isnull;
+  }
+  return pass;
+}
+
+// the X-mode aggregate argument of one row (eval_expr's one integer step)
+HDK_DEV int64_t fast_x_value(const FastArgs& a, int64_t va, int64_t e0, int64_t e1, int32_t& err) {
+  if (!a.vform) {
+    return va;
+  }
+  const int64_t b = a.vform == 1 ? (a.b_src == 1 ? e0 : e1) : a.v_lit;
+  if ((a.a_nullable && va == a.a_null) || (a.vform == 1 && a.b_nullable && b == a.b_null)) {
+    return a.v_null_out;
+  }
+  int64_t r;
+  const bool ovf = a.vop == HDK_OP_ADD ? checked_arith(HDK_OP_ADD, va, b, a.v_check_width, &r)
+                                       : (a.vop == HDK_OP_SUB ? checked_arith(HDK_OP_SUB, va, b, a.v_check_width, &r)
+                                                              : checked_arith(HDK_OP_MUL, va, b, a.v_check_width, &r));
+  if (ovf) {
+    err = HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW;
+  }
+  return r;
+}
 
 // column buffers are plain hipMalloc'ed global memory: say so, or the pointers loaded from
 // COL_BUFFERS are generic and every access becomes a flat_load
@@ -247,8 +319,12 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
 // R = rows per lane per step (16 B of the widest column); U = steps per tile.
 // Q: the plan has plain filters (plain_quals.h); rows that fail them are skipped before the LDS update.  A
 // separate instantiation so that the unfiltered kernels (C1/C2) stay exactly as they were.
-template <int KW, int VW, int U, int FIXED, bool Q = false>
+// XM > 0: X mode with XM - 1 extra 8-byte columns streamed beside the value column (filters between columns, expression
+// arguments); Q is false then (the gathered `column cmp literal` filters are the other way to filter).
+template <int KW, int VW, int U, int FIXED, bool Q = false, int XM = 0>
 __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
+  constexpr bool XMODE = XM > 0;
+  constexpr int X = XM > 0 ? XM - 1 : 0;
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ unsigned long long s_masks[2];
   constexpr int WMAX = (KW > VW ? KW : VW) == 0 ? 8 : (KW > VW ? KW : VW);
@@ -297,6 +373,8 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
     const int8_t* const* cols = a.kp.col_buffers[f];
     const gcol_t kcol = KW ? (gcol_t)cols[a.key_buf_idx] : nullptr;
     const gcol_t vcol = VW ? (gcol_t)cols[a.val_buf_idx] : nullptr;
+    const gcol_t xcol0 = X > 0 ? (gcol_t)cols[a.x_buf_idx[0]] : nullptr;
+    const gcol_t xcol1 = X > 1 ? (gcol_t)cols[a.x_buf_idx[1]] : nullptr;
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
@@ -305,11 +383,14 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
         // loads before applying this one -- a second register set -- measured 2-3 % slower: 6.6 against 6.75 TB/s.)
         uint32_t kr[U][KREGS];
         uint32_t vr[U][VREGS];
+        uint32_t xr0[X > 0 ? U : 1][4], xr1[X > 1 ? U : 1][4];  // (X mode: VW == 8, R == 2: 16 bytes per lane and step)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t r = row0 + (static_cast<int64_t>(u) * kFastBlock + tid) * R;
           if (KW) load_bytes<(KB > 0 ? KB : 4), true>(kcol + r * KW, kr[u]);
           if (VW) load_bytes<(VB > 0 ? VB : 4), true>(vcol + r * VW, vr[u]);
+          if constexpr (X > 0) load_bytes<16, true>(xcol0 + r * 8, xr0[u]);
+          if constexpr (X > 1) load_bytes<16, true>(xcol1 + r * 8, xr1[u]);
         }
         bool pass[U * R];
 #pragma unroll
@@ -332,7 +413,15 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
 #pragma unroll
           for (int i = 0; i < R; ++i) {
             const int64_t key = KW ? extract_elem<(KW ? KW : 8)>(kr[u], i) : 0;
-            const int64_t val = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
+            int64_t val = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
+            if constexpr (XMODE) {
+              const int64_t e0 = X > 0 ? extract_elem<8>(xr0[X > 0 ? u : 0], i) : 0;
+              const int64_t e1 = X > 1 ? extract_elem<8>(xr1[X > 1 ? u : 0], i) : 0;
+              if (!fast_x_pass(a, val, e0, e1, key)) {
+                continue;
+              }
+              val = fast_x_value(a, val, e0, e1, err);
+            }
             if (!Q || pass[u * R + i]) {
               fast_row<KW, FIXED, MASK>(a, ops, lds, my_rep, estride, key, val, VW != 0, touched, nonnull, err);
             }
@@ -350,7 +439,15 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
             }
           }
           const int64_t key = KW ? load_elem<(KW ? KW : 8)>(kcol, r) : 0;
-          const int64_t val = VW ? load_elem<(VW ? VW : 8)>(vcol, r) : 0;
+          int64_t val = VW ? load_elem<(VW ? VW : 8)>(vcol, r) : 0;
+          if constexpr (XMODE) {
+            const int64_t e0 = X > 0 ? load_elem<8>(xcol0, r) : 0;
+            const int64_t e1 = X > 1 ? load_elem<8>(xcol1, r) : 0;
+            if (!fast_x_pass(a, val, e0, e1, key)) {
+              continue;
+            }
+            val = fast_x_value(a, val, e0, e1, err);
+          }
           fast_row<KW, FIXED, MASK>(a, ops, lds, my_rep, estride, key, val, VW != 0, touched, nonnull, err);
         }
       }

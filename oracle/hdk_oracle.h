@@ -222,6 +222,10 @@ double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals,
                          int64_t* out);
 int32_t orc_max_threads(void);
 
+/* placement-aware helpers of the CPU baseline (bench.py) */
+int32_t orc_allowed_cpu_count(void);
+double orc_host_stream_read_gbps(int32_t num_threads, size_t bytes_per_thread, int32_t reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,7 @@ def timed(step, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=256_000_000)
-    ap.add_argument("--only", default="c1,c2,c2n,c2f,c3,c3g,q1,q2,q3,q4,c5,p1,p50,pj")
+    ap.add_argument("--only", default="c1,c2,c2n,c2f,c2x,c2cc,c3,c3g,q1,q2,q3,q4,c5,p1,p50,pj")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
@@ -57,13 +57,13 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c3", "c3g", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c3", "c3g", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
@@ -90,6 +90,10 @@ def main():
         # C2 with a filter that half of the rows pass (filter column = a third 8-byte column: 24 B/row)
         "c2f": (QueryUnit("t", quals=[Cmp(ColRef("valn"), "<", Lit(0))], groupby=[ColRef("key")],
                           targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 24),
+        # the streaming kernel's wider menu (round 4): an expression argument over two columns; a column-column filter
+        "c2x": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val") * ColRef("hk"))]), 24),
+        "c2cc": (QueryUnit("t", quals=[Cmp(ColRef("val"), "<", ColRef("hk"))], groupby=[ColRef("key")],
+                           targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 24),
         "c3": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")],
                          targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"))]), 16),
         "c3g": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") / 15625],

@@ -34,6 +34,7 @@
 
 #include "HipKernel.h"
 #include "HipMgr.h"
+#include "HipArena.h"
 #include "HipPlanBuilder.h"
 #include "HipPlanExtractor.h"
 #include "HipRuntimeOnDevice.h"
@@ -55,31 +56,40 @@ int64_t gen_val(uint64_t i) {
   return static_cast<int64_t>(mix(i + (1ull << 40)) % 2000001) - 1000000;
 }
 
-// what HDK reaches through Executor::getDataMgr(): the device manager and the per-kernel allocator
+// what HDK reaches through Executor::getDataMgr(): the device manager and -- through a BufferProvider
+// (BufferProvider/BufferProvider.h:23-64; here the standalone arena with the same method set, glue/HipArena.h) -- the
+// per-kernel allocator and the copies
 struct DeviceServices : hip_rt::HipWorkspaceAllocator {
-  explicit DeviceServices(hip_mgr::HipMgr* m) : mgr(m) {}
+  explicit DeviceServices(hip_mgr::HipMgr* m) : mgr(m), arena(m) {}
   ~DeviceServices() override {
-    for (int8_t* p : owned) mgr->freeDeviceMem(p);
+    for (auto* b : owned) arena.free(b);
   }
   int8_t* alloc(size_t num_bytes) override {
-    int8_t* p = mgr->allocateDeviceMem(num_bytes ? num_bytes : 8, kDevice);
-    owned.push_back(p);
-    return p;
+    auto* b = arena.alloc(hip_mgr::ARENA_GPU_LEVEL, kDevice, num_bytes);
+    owned.push_back(b);
+    return b->getMemoryPtr();
   }
   template <class T>
   int8_t* upload(const std::vector<T>& host) {
     int8_t* d = alloc(host.size() * sizeof(T));
-    mgr->copyHostToDevice(d, reinterpret_cast<const int8_t*>(host.data()), host.size() * sizeof(T), kDevice);
+    const size_t bytes = host.size() * sizeof(T);
+    if (bytes <= (64u << 10)) {  // the small parameter arrays: staged through the arena's pinned bounce buffer
+      arena.copyToDeviceAsyncIfPossible(d, reinterpret_cast<const int8_t*>(host.data()), bytes, kDevice);
+      arena.synchronizeStream(kDevice);
+    } else {
+      arena.copyToDevice(d, reinterpret_cast<const int8_t*>(host.data()), bytes, kDevice);
+    }
     return d;
   }
   template <class T>
   std::vector<T> download(const int8_t* dev, size_t n) {
     std::vector<T> host(n);
-    mgr->copyDeviceToHost(reinterpret_cast<int8_t*>(host.data()), dev, n * sizeof(T), kDevice);
+    arena.copyFromDevice(reinterpret_cast<int8_t*>(host.data()), dev, n * sizeof(T), kDevice);
     return host;
   }
   hip_mgr::HipMgr* mgr;
-  std::vector<int8_t*> owned;
+  hip_mgr::HipArena arena;
+  std::vector<hip_mgr::HipArena::Buffer*> owned;
   uint64_t rows_in_step{0};  // QueryExecutionContext knows the fragments of the step
 };
 DeviceServices* g_services = nullptr;

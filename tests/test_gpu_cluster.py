@@ -63,8 +63,11 @@ def test_clustered_probes_match_the_oracle(oracle, gpu_executor_factory, key_kin
             # the C3 shape over a fused table has a kernel of its own that reads clustered TUPLES; everything else runs the
             # batched interpreter over the permuted columns
             # (and for tables whose key-range slices fit LDS, a path of its own: scan_join_sliced.h)
+            # (round 4: join + GROUP BY on the joined column / filters / other target lists over a fused table: the general
+            # sliced kernel, scan_join_sliced2.h, with the batched interpreter armed behind it)
             assert names.startswith("hdk_cluster_by_key,hdk_cluster_params,hdk_scan_agg_vec_join") or \
-                names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,hdk_join_agg_direct"), names
+                names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,hdk_join_agg_direct") or \
+                names.startswith("hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_vec_join"), names
             assert_buffers_equal(cp, step.run().buffer, want)
             # a second run of the same prepared step: the scratch of the first is gone, the result is not
             assert_buffers_equal(cp, step.run().buffer, want)

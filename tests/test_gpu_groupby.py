@@ -195,7 +195,7 @@ def test_mid_size_tables_stay_in_lds(oracle, gpu_executor_factory):
                           "k9": rng.integers(0, 9000, n).astype(np.int32), "v": v}, fragment_size=130_000)
     cases = [("k5", [KeyRef(0), Agg("count")], "hdk_scan_agg_direct"),                        # 5000 x 1 word
              ("k2", [KeyRef(0), Agg("sum", ColRef("v")), Agg("count")], "hdk_scan_agg_direct"),  # 2400 x 3 words
-             ("k2", [KeyRef(0), Agg("min", ColRef("v") * 2)], "hdk_scan_agg_vec"),            # expression -> batched kernel
+             ("k2", [KeyRef(0), Agg("min", ColRef("v") / 2)], "hdk_scan_agg_vec"),            # an expression outside the streaming kernel's menu -> batched kernel
              ("k9", [KeyRef(0), Agg("count")], "hdk_scan_agg_global")]                          # 9000 words: too big
     for key, targets, kernel in cases:
         q = QueryUnit("t", groupby=[ColRef(key)], targets=targets)
@@ -363,3 +363,55 @@ def test_transformed_keys_kernel_with_value_aggregates(oracle, gpu_executor_fact
             raise AssertionError(f"case {i}: {q}\n{e}") from e
         ran += 1
     assert ran >= 12, ran
+
+
+def test_direct_kernel_expression_arguments_and_column_filters(oracle, gpu_executor_factory):
+    """The streaming kernel's wider menu (round 4): aggregate arguments `a op b` / `a op literal` over two plain 8-byte
+    columns and filters `column cmp column` stay on hdk_scan_agg_direct (they used to fall to the batched interpreter at a
+    third of the rate).  NULLs on either operand, NULL keys, every key width, ragged fragments; an overflow is reported
+    with the reference's error code on every kernel family."""
+    from hdk_amd._lib import HdkHipError
+    rng = np.random.default_rng(61)
+    n = 300_007
+    a = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    b = rng.integers(-1000, 1000, n, dtype=np.int64)
+    c32 = rng.integers(-50, 50, n).astype(np.int32)
+    a[rng.random(n) < 0.03] = A.NULL_BIGINT
+    b[rng.random(n) < 0.03] = A.NULL_BIGINT
+    k64 = rng.integers(0, 64, n, dtype=np.int64)
+    k16 = rng.integers(-3, 40, n).astype(np.int16)
+    k16[rng.random(n) < 0.02] = A.NULL_SMALLINT
+    st = ArrowStorage()
+    st.import_numpy("t", {"k64": k64, "k16": k16, "a": a, "b": b, "c32": c32, "c64": c32.astype(np.int64)}, fragment_size=77_777)
+    ex = gpu_executor_factory(st)
+    A_, B_ = ColRef("a"), ColRef("b")
+    queries = [
+        QueryUnit("t", groupby=[ColRef("k64")], targets=[KeyRef(0, "k"), Agg("sum", A_ * B_, "s")]),
+        QueryUnit("t", groupby=[ColRef("k16")], targets=[KeyRef(0, "k"), Agg("sum", A_ + B_, "s"), Agg("count", A_ + B_, "c")]),
+        QueryUnit("t", groupby=[ColRef("k64")], targets=[KeyRef(0, "k"), Agg("avg", A_ - 7, "av"), Agg("min", A_ - 7, "mn"), Agg("max", A_ - 7, "mx")]),
+        QueryUnit("t", groupby=[ColRef("k64")], quals=[Cmp(A_, "<", B_)], targets=[KeyRef(0, "k"), Agg("sum", A_, "s")]),
+        QueryUnit("t", groupby=[ColRef("k16")], quals=[Cmp(B_, ">=", ColRef("c64")), Cmp(A_, ">", Lit(-10**9))],
+                  targets=[KeyRef(0, "k"), Agg("sum", A_ * 3, "s"), Agg("count", None, "c")]),
+        QueryUnit("t", groupby=[ColRef("k64")], quals=[Cmp(ColRef("k64"), "<>", ColRef("c64")), Cmp(B_, "<", Lit(900))],
+                  targets=[KeyRef(0, "k"), Agg("max", A_ - B_, "m")]),
+        # a 4-byte column in a column-column filter is outside the streamed form: the batched interpreter takes the plan
+        QueryUnit("t", groupby=[ColRef("k16")], quals=[Cmp(B_, ">=", ColRef("c32"))], targets=[KeyRef(0, "k"), Agg("sum", A_ * 3, "s")]),
+    ]
+    for qi, q in enumerate(queries):
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, q
+        step = ex.prepare(cp)
+        assert step.kernel_names().startswith("hdk_scan_agg_direct" if qi < 6 else "hdk_scan_agg_vec"), (q, step.kernel_names())
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+        for flags in (A.LAUNCH_FORCE_GENERIC, A.LAUNCH_FORCE_SCALAR):
+            assert_buffers_equal(cp, ex.execute(cp, flags=flags).buffer, want)
+    # overflow of a BIGINT product: ERR_OVERFLOW_OR_UNDERFLOW (7) from the streaming kernel too
+    st.get("t").columns["a"].fragments[1][5] = 2**62
+    st.get("t").columns["b"].fragments[1][5] = 4
+    cp, want, err = run_oracle(oracle, st, queries[0])
+    assert err == A.ERR_OVERFLOW_OR_UNDERFLOW
+    for flags in (0, A.LAUNCH_FORCE_GENERIC):
+        with pytest.raises(HdkHipError) as ei:
+            gpu_executor_factory(st).execute(cp, flags=flags)
+        assert ei.value.code == A.ERR_OVERFLOW_OR_UNDERFLOW
