@@ -120,7 +120,8 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     nfrag_total = len(__import__("workloads").fragment_rows(rows))
     frag_ids = D.shard_fragments(nfrag_total, world, rank) if (strong and world > 1) else None
     t_gen = time.perf_counter()
-    w = Workload(name, rows, dev, mgr, frag_ids=frag_ids, seed_offset=0 if strong else rank * 100_003,
+    kw = {"dim_rows": int(args.dim_rows)} if (args.dim_rows and name.startswith("c3")) else {}
+    w = Workload(name, rows, dev, mgr, frag_ids=frag_ids, seed_offset=0 if strong else rank * 100_003, **kw,
                  generators=c2_numpy_generator(torch, torch.device("cuda", dev), 0 if strong else rank * nfrag_total)
                  if name == "c2" else None)
     torch.cuda.synchronize()
@@ -557,6 +558,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--rows", type=int, default=0, help="rows of the table (default: the config's BASELINE size)")
+    ap.add_argument("--dim-rows", type=int, default=0, help="c3*: rows of the dimension table (default 10 M, BASELINE's)")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--extra", default="auto", help="other configs to report under 'configs' (auto: all at N=1, none otherwise)")
     ap.add_argument("--cpu-sample-frags", type=int, default=0, help="fragments the CPU baseline runs on (0 = all)")

@@ -14,10 +14,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ARGS = {"c3big": "--config c3 --dim-rows 100000000"}  # name -> bench arguments when they are not just --config <name>
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
-ALG = {"c2": (16, 1_000_000_000), "c3": (16, 1_000_000_000), "c5": (16, 1_000_000_000), "c5s": (16, 125_000_000),
+ALG = {"c2": (16, 1_000_000_000), "c3": (16, 1_000_000_000), "c3g": (16, 1_000_000_000), "c3m": (16, 1_000_000_000),
+       "c3big": (16, 1_000_000_000), "c5": (16, 1_000_000_000), "c5s": (16, 125_000_000),
        "q1": (4, 1_000_000_000), "q2": (10, 1_000_000_000), "q3": (10, 1_000_000_000), "q4": (18, 1_000_000_000)}
 
 
@@ -60,9 +62,10 @@ def main():
             kernels[short(k)] = {"dispatches": calls, "FETCH_SIZE_KB": round(f_kb), "WRITE_SIZE_KB": round(w_kb),
                                  "read_bytes": round(rd), "written_bytes": round(wb)}
             traffic += (rd + wb) * calls / n_main
-        out = {"what": f"bench.py --config {name} (BASELINE size: {rows} rows on one GPU), averages per dispatch",
-               "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --config {name} --steps 5 --warmup 2 "
-                          "--no-cpu-baseline --no-oracle-sample --extra none   (one counter per pass)",
+        cfg = ARGS.get(name, f"--config {name}")
+        out = {"what": f"bench.py {cfg} (BASELINE size: {rows} rows on one GPU), averages per dispatch",
+               "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py {cfg} --steps 5 --warmup 2 "
+                          "--no-cpu-baseline --no-oracle-sample --no-multi-gpu-emulation --extra none   (one counter per pass)",
                "correction": "gfx950: read bytes = 2 x 1024 x FETCH_SIZE (128-byte requests tallied as 64); written bytes = 1024 x WRITE_SIZE",
                "rows": rows, "algorithmic_bytes_per_row": bpr, "algorithmic_bytes": bpr * rows, "kernels": kernels,
                "traffic_bytes_per_launch": round(traffic), "traffic_bytes_per_row": round(traffic / rows, 2),

@@ -120,6 +120,7 @@ class Workload:
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
         elif name in ("c3", "c3g", "c3m"):
             self.dim_rows = int(dim_rows)
+            self.description = self.description.replace("dim(10 M rows)", f"dim({self.dim_rows / 1e6:g} M rows)")
             self.dim_key_stride = stride = int(dim_key_stride)  # > 1: a SPARSE dimension (keys k * stride: the table's range is stride x its rows)
 
             def dim_key(f, n):
