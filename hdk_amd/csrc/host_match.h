@@ -22,6 +22,20 @@ inline uint32_t resident_grid(const void* kernel, int block, size_t lds_bytes, c
   return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
 }
 
+// grid of a radix-scatter pass: resident blocks, held to `per_cu_default` per CU when that is not 0
+// (HDK_HIP_SCATTER_BLOCKS_PER_CU overrides; 0 = all resident blocks).  The join's level 1 with three 512-thread blocks on a
+// CU is 6-12 % slower than with two (scripts/microbench/scatter_runs.hip: 1.38 / 1.21 ms per 256 M rows, fewer bytes
+// written: 2.57 against 2.67 GB -- fewer half-written lines in flight per L2); the group-by's level 1 does not care.
+inline uint32_t scatter_grid(const void* kernel, int block, size_t lds_bytes, const hdk_hip_device_properties* props,
+                             uint32_t per_cu_default = 0) {
+  uint32_t g = resident_grid(kernel, block, lds_bytes, props);
+  uint32_t per_cu = per_cu_default;
+  if (const char* e = getenv("HDK_HIP_SCATTER_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(atoi(e));
+  const uint32_t cap = per_cu * static_cast<uint32_t>(props->num_cu);
+  if (cap >= 1 && cap < g) g = cap;
+  return g;
+}
+
 inline bool plain_outer_col(const hdk_hip_plan* p, const hdk_hip_expr& e, int* col) {
   if (e.nsteps != 0 || e.leaf0.kind != HDK_LEAF_COL) return false;
   const hdk_hip_col& c = p->cols[e.leaf0.col];

@@ -691,10 +691,14 @@ static uint32_t keys_lds_bytes(const KeysArgs& ka, const LaunchShape& shape) {
   return ka.nvals ? shape.lds_bytes : shape.lds_bytes / 2;
 }
 // counting / value form, rows dealt 2 (some 8-byte column is read) or 4 at a time
-static const void* keys_kernel(const KeysArgs& ka) {
+static const void* keys_kernel(const KeysArgs& ka, uint32_t block = kKeysBlock) {
   int wmax = 1;
   for (int k = 0; k < ka.nkeys; ++k) wmax = ka.key[k].width > wmax ? ka.key[k].width : wmax;
   for (int v = 0; v < ka.nvals; ++v) wmax = ka.val[v].width > wmax ? ka.val[v].width : wmax;
+  if (ka.nvals && block == kKeysWideBlock) {
+    return wmax == 8 ? reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 2, kKeysWideBlock>)
+                     : reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 4, kKeysWideBlock>);
+  }
   if (ka.nvals) {
     return wmax == 8 ? reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 2>)
                      : reinterpret_cast<const void*>(hdk_scan_agg_keys<true, 4>);
@@ -782,9 +786,14 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     size_t lds_for_occupancy = s.lds_bytes;
     KeysArgs ka;
     if (s.strategy == STRAT_LDS && !generic && match_keys(p, s, &ka)) {
-      k = keys_kernel(ka);
-      block = kKeysBlock;
       lds_for_occupancy = keys_lds_bytes(ka, s);
+      block = kKeysBlock;
+      // value form with a table that leaves room for fewer than four blocks per CU: twice the threads per table
+      if (ka.nvals && (160u * 1024u) / (lds_for_occupancy + 1024u) < 4 && !getenv("HDK_HIP_KEYS_NO_WIDE_BLOCK")) {
+        block = kKeysWideBlock;
+      }
+      s.block = static_cast<uint32_t>(block);
+      k = keys_kernel(ka, s.block);
     } else if (s.strategy == STRAT_LDS) {
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
                  : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_agg_vec_join)
@@ -848,7 +857,6 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
       if (fa->key_translate_null && fa->key_null_translated != static_cast<int32_t>(fa->key_null_translated)) return false;
     }
   }
-  int vcol = -1;
   int vw = 0;
   bool need_real_rowcount = false, need_real_nn = false;
   const hdk_hip_expr* vexpr = nullptr;  // every aggregate argument is this one expression: column a, a op column b, a op literal
@@ -868,7 +876,7 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     vexpr = &e;
     if (e.nsteps > 1 || e.leaf0.kind != HDK_LEAF_COL || p->cols[e.leaf0.col].table != 0) return false;
     const int c = e.leaf0.col;
-    vcol = c;
+
     const hdk_hip_col& col = p->cols[c];
     const bool fp = col.kind == HDK_COL_DOUBLE;
     if (col.kind != HDK_COL_INT && !fp) return false;
@@ -1245,7 +1253,7 @@ static int32_t launch_sliced_kernels(SliceArgs& sa, const LaunchShape& shape, co
   constexpr int VR = NARROW ? 8 : 4;
   constexpr int TW = NARROW ? 1 : 2;
   const size_t lds_sc = static_cast<size_t>(kSliceBlock) * VR * TW * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
-  const unsigned g_sc = resident_grid(reinterpret_cast<const void*>(hdk_join_scatter_slices<NARROW>), kSliceBlock, lds_sc, props);
+  const unsigned g_sc = scatter_grid(reinterpret_cast<const void*>(hdk_join_scatter_slices<NARROW>), kSliceBlock, lds_sc, props, 2);
   uint32_t members = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu) / sa.nbins;
   if (members < 1) members = 1;
   if (sa.nbins * members > shape.grid) members = shape.grid / sa.nbins;  // slab[blockIdx.x] must exist (match_join_sliced: nbins <= grid)
@@ -1612,7 +1620,7 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   const size_t lds_sc = static_cast<size_t>(kSliceBlock) * VR * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
   const void* ksc = sa.nquals ? reinterpret_cast<const void*>(hdk_join_scatter_slices<true, true>)
                               : reinterpret_cast<const void*>(hdk_join_scatter_slices<true, false>);
-  const unsigned g_sc = resident_grid(ksc, kSliceBlock, lds_sc, props);
+  const unsigned g_sc = scatter_grid(ksc, kSliceBlock, lds_sc, props, 2);
   const uint32_t resident = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
   uint32_t members = 1;
   if (ga.two_level) {  // persistent blocks, each walking slices b, b + nsl_par, ...
@@ -1704,7 +1712,8 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     ka.kp = kp;
     ka.slabs = slabs;
     void* kargs[] = {&ka};
-    HDK_HIP_CHECK(hipLaunchKernel(keys_kernel(ka), dim3(shape.grid), dim3(kKeysBlock), kargs, keys_lds_bytes(ka, shape), s));
+    const uint32_t kblock = shape.block == kKeysWideBlock ? kKeysWideBlock : kKeysBlock;
+    HDK_HIP_CHECK(hipLaunchKernel(keys_kernel(ka, kblock), dim3(shape.grid), dim3(kblock), kargs, keys_lds_bytes(ka, shape), s));
     HDK_HIP_CHECK(hipGetLastError());
     return HDK_HIP_OK;
   }

@@ -22,6 +22,10 @@
 namespace hdk {
 
 constexpr int kKeysBlock = 256;
+// The value form with a table too large to replicate (Q4's 2 499 entries x 3 words = 60 KB) fits two blocks on a CU:
+// with 256 threads that is two waves per SIMD, too few to cover the loads.  Same kernel with 512 threads per block:
+// two blocks = four waves per SIMD sharing the same two tables.
+constexpr int kKeysWideBlock = 512;
 constexpr int kKeysMaxVals = 2;
 constexpr int kKeysMaxOps = 8;
 constexpr int kKeysVR = 8;   // rows per lane and tile (taxi Q3/Q4 at 256 M rows: 4 -> 0.79/1.23 ms, 8 -> 0.60/1.00, 12 -> 0.66/1.02)
@@ -95,7 +99,7 @@ struct KeysArgs {
 typedef const __attribute__((address_space(1))) int8_t* keys_gptr;
 
 // VR values of a column for this lane in a full tile: dst[u * R + i] = row  row0 + (u * kKeysBlock + tid) * R + i
-template <typename T, int R, typename D>
+template <typename T, int R, int BS, typename D>
 HDK_DEV void keys_load(const int8_t* buf, int64_t row0, int tid, D* dst) {
   constexpr int VR = kKeysVR;
   typedef T vec_t __attribute__((ext_vector_type(R)));
@@ -106,7 +110,7 @@ HDK_DEV void keys_load(const int8_t* buf, int64_t row0, int tid, D* dst) {
   const keys_gptr base = reinterpret_cast<keys_gptr>((static_cast<uint64_t>(b_hi) << 32) | b_lo);
 #pragma unroll
   for (int u = 0; u < VR / R; ++u) {
-    const uint32_t off = static_cast<uint32_t>(u * kKeysBlock + tid) * static_cast<uint32_t>(R * sizeof(T));
+    const uint32_t off = static_cast<uint32_t>(u * BS + tid) * static_cast<uint32_t>(R * sizeof(T));
     const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) vec_t*>(base + off));
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -166,7 +170,7 @@ HDK_DEV void keys_row(const KeysArgs& a, int64_t* lds, const int8_t* const* cols
   }
 }
 
-#define HDK_KEYS_LOAD(DST, T) keys_load<T, R>(buf, row0, tid, DST);
+#define HDK_KEYS_LOAD(DST, T) keys_load<T, R, BS>(buf, row0, tid, DST);
 
 // One FULL tile of kKeysBlock * VR rows starting at row `row0` of a fragment.  Returns a per-lane bit mask of the rows
 // (bit r = the r-th row of this lane) that took no part in the tile's LDS updates and are the caller's to evaluate
@@ -181,7 +185,7 @@ HDK_DEV void keys_row(const KeysArgs& a, int64_t* lds, const int8_t* const* cols
 constexpr uint32_t kKeysPoison = 8192;  // > kLdsMaxTableWords >= entry_count >= every cardinality; 3 x 8192 x 7680 < 2^31
 constexpr uint32_t kKeysFiltered = 0x80000000u;
 
-template <bool VALS, int R>
+template <bool VALS, int R, int BS>
 HDK_DEV uint32_t keys_tile(const KeysArgs& a, int64_t* lds, const int8_t* const* cols, int64_t row0, int tid,
                            uint32_t my_rep, uint32_t wpe, int32_t& err) {
   constexpr int VR = kKeysVR;
@@ -196,7 +200,7 @@ HDK_DEV uint32_t keys_tile(const KeysArgs& a, int64_t* lds, const int8_t* const*
     bool pass[VR];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
-      row[r] = row0 + static_cast<int64_t>((r / R) * kKeysBlock + tid) * R + (r % R);
+      row[r] = row0 + static_cast<int64_t>((r / R) * BS + tid) * R + (r % R);
       pass[r] = true;
     }
     plain_quals_pass<VR>(a.q, a.nquals, cols, row, pass, true);
@@ -415,7 +419,7 @@ HDK_DEV uint32_t keys_tile(const KeysArgs& a, int64_t* lds, const int8_t* const*
 HDK_DEV void keys_fold_counts(const KeysArgs& a, int64_t* lds, int64_t* slab, int tid, bool first) {
   uint32_t* cnt = reinterpret_cast<uint32_t*>(lds);
   const uint32_t rep = a.rep;
-  for (uint32_t i = tid; i < a.entry_count; i += kKeysBlock) {
+  for (uint32_t i = tid; i < a.entry_count; i += blockDim.x) {
     int64_t acc = first ? 0 : slab[i];
     for (uint32_t r = 0; r < rep; ++r) {
       acc += cnt[i * rep + r];
@@ -425,9 +429,9 @@ HDK_DEV void keys_fold_counts(const KeysArgs& a, int64_t* lds, int64_t* slab, in
   }
 }
 
-template <bool VALS, int R>
+template <bool VALS, int R, int BS = kKeysBlock>
 // waves per SIMD the register budget is held to: the tile body needs 81 / 87 VGPRs (counting / value form)
-__global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(KeysArgs a) {
+__global__ __launch_bounds__(BS, VALS ? 5 : 6) void hdk_scan_agg_keys(KeysArgs a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   constexpr int VR = kKeysVR;
   const int tid = threadIdx.x;
@@ -435,11 +439,11 @@ __global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(Ke
   const uint32_t wpe = VALS ? static_cast<uint32_t>(a.wpe) : 1u;  // counting form: one word (the row count) per entry
   const uint32_t total_words = a.entry_count * wpe * rep;
   if (VALS) {
-    for (uint32_t i = tid; i < total_words; i += kKeysBlock) {
+    for (uint32_t i = tid; i < total_words; i += BS) {
       lds[i] = word_identity(a.wop[(i >> a.rep_shift) % wpe]);
     }
   } else {
-    for (uint32_t i = tid; i < total_words; i += kKeysBlock) {
+    for (uint32_t i = tid; i < total_words; i += BS) {
       reinterpret_cast<uint32_t*>(lds)[i] = 0;
     }
   }
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(Ke
   const uint32_t my_rep = tid & (rep - 1);
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
-  constexpr int64_t kTileRows = static_cast<int64_t>(kKeysBlock) * VR;
+  constexpr int64_t kTileRows = static_cast<int64_t>(BS) * VR;
   int32_t err = 0;
   int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * a.entry_count * wpe;
   // counting form: a 32-bit counter can take 2^32 - 1 rows; the block folds its counters into the slab well before.
@@ -468,14 +472,14 @@ __global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(Ke
       HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       if (row0 + kTileRows <= nrows) {
-        uint32_t slow = keys_tile<VALS, R>(a, lds, cols, row0, tid, my_rep, wpe, err);
+        uint32_t slow = keys_tile<VALS, R, BS>(a, lds, cols, row0, tid, my_rep, wpe, err);
         while (slow) {  // rare: rows outside the 32-bit ranges of the transforms
           const int r = __ffs(slow) - 1;
           slow &= slow - 1;
-          keys_row<VALS>(a, lds, cols, row0 + static_cast<int64_t>((r / R) * kKeysBlock + tid) * R + (r % R), my_rep, wpe, err);
+          keys_row<VALS>(a, lds, cols, row0 + static_cast<int64_t>((r / R) * BS + tid) * R + (r % R), my_rep, wpe, err);
         }
       } else {
-        for (int64_t rr = row0 + tid; rr < nrows; rr += kKeysBlock) {  // the ragged last tile of the fragment
+        for (int64_t rr = row0 + tid; rr < nrows; rr += BS) {  // the ragged last tile of the fragment
           keys_row<VALS>(a, lds, cols, rr, my_rep, wpe, err);
         }
       }
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(kKeysBlock, VALS ? 5 : 6) void hdk_scan_agg_keys(Ke
     return;
   }
   const uint32_t ew = a.entry_count * wpe;
-  for (uint32_t i = tid; i < ew; i += kKeysBlock) {
+  for (uint32_t i = tid; i < ew; i += BS) {
     const uint32_t w = i % wpe;
     const int32_t op = a.wop[w];
     int64_t acc = lds[i * rep];

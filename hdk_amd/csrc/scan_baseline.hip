@@ -430,7 +430,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   const uint32_t gmask = (1u << pa.g_log2) - 1;
   const size_t lds1 = part_scatter_lds_bytes(pa.p1, gmask, pa.tw, pa.narrow != 0);
   // pass-1 grid: what is resident, at most one block per batch
-  unsigned g1 = resident_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
+  unsigned g1 = scatter_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
   const uint64_t tile = static_cast<uint64_t>(part_tile(pa.narrow != 0));
   const uint64_t tiles = (pa.total_rows + tile - 1) / tile;
   if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);
@@ -544,7 +544,7 @@ int32_t launch_scatter_to_owners(const hdk_hip_plan* plan, const hdk_hip_plan* d
   pa.fill_ovf = pa.fallback + 1;  // (never used: a scatter to owners has no overflow area)
   HDK_HIP_CHECK(hipMemsetAsync(pa.fill1, 0, bc, s));
   const size_t lds1 = part_scatter_lds_bytes(pa.owners * pa.p1, 0, pa.tw, pa.narrow != 0);
-  unsigned g1 = resident_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
+  unsigned g1 = scatter_grid(part_scatter_kernel<1>(pa, k32), kPartBlock, lds1, props);
   const uint64_t tile = static_cast<uint64_t>(part_tile(pa.narrow != 0));
   const uint64_t tiles = (pa.total_rows + tile - 1) / tile;
   if (tiles < g1) g1 = static_cast<unsigned>(tiles ? tiles : 1);

@@ -365,6 +365,44 @@ def test_transformed_keys_kernel_with_value_aggregates(oracle, gpu_executor_fact
     assert ran >= 12, ran
 
 
+def test_keys_value_form_with_a_table_too_large_to_replicate(oracle, gpu_executor_factory, monkeypatch):
+    """Taxi Q4 with a measure (three transformed keys, ~2 000 entries x 3-4 words): the LDS table leaves room for two or
+    three blocks per CU, so the value form runs with 512 threads per block (scan_agg_keys.h: kKeysWideBlock).  Both block
+    sizes against the oracle, ragged fragments, NULL keys and NULL measures, a small grid."""
+    from hdk_amd.ir import Type
+    rng = np.random.default_rng(4242)
+    n = 400_013
+    ts = rng.integers(1230768000, 1451606400, n, dtype=np.int64)
+    ts[rng.random(n) < 0.01] = A.NULL_BIGINT
+    pc = rng.integers(0, 7, n).astype(np.int16)
+    pc[rng.random(n) < 0.02] = A.NULL_SMALLINT
+    dist = rng.integers(0, 2700, n, dtype=np.int64)  # 8 x 8 x 28 = 1 792 entries x 3 or 4 words: 42-56 KB of LDS
+    amt = rng.integers(0, 20000, n, dtype=np.int64)
+    amt[rng.random(n) < 0.03] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("trips", {"pc": pc, "ts": ts, "dist": dist, "amt": amt}, fragment_size=55_555,
+                    types={"ts": Type("timestamp", 8, unit="s"), "dist": Type("decimal", 8, scale=2), "amt": Type("decimal", 8, scale=2)})
+    for targets in ([Agg("count", None, "c"), Agg("sum", ColRef("amt"), "s")],
+                    [Agg("avg", ColRef("amt"), "a")], [Agg("max", ColRef("amt"), "m"), Agg("count", None, "c")]):
+        q = QueryUnit("trips", groupby=[ColRef("pc"), ExtractYear(ColRef("ts")), Cast(ColRef("dist"), INT32)],
+                      targets=[KeyRef(0), KeyRef(1), KeyRef(2)] + targets)
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0
+        assert cp.entry_count * 3 * 8 > 40 * 1024, cp.entry_count  # fewer than four blocks of it fit a CU's 160 KB
+        ex = gpu_executor_factory(st)
+        step = ex.prepare(cp)
+        assert step.kernel_names().split(",")[0] == "hdk_scan_agg_keys_values"
+        step.free()
+        for no_wide in ("", "1"):
+            if no_wide:
+                monkeypatch.setenv("HDK_HIP_KEYS_NO_WIDE_BLOCK", "1")
+            else:
+                monkeypatch.delenv("HDK_HIP_KEYS_NO_WIDE_BLOCK", raising=False)
+            for grid in (0, 5):
+                assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, grid=grid).buffer, want)
+    monkeypatch.delenv("HDK_HIP_KEYS_NO_WIDE_BLOCK", raising=False)
+
+
 def test_direct_kernel_expression_arguments_and_column_filters(oracle, gpu_executor_factory):
     """The streaming kernel's wider menu (round 4): aggregate arguments `a op b` / `a op literal` over two plain 8-byte
     columns and filters `column cmp column` stay on hdk_scan_agg_direct (they used to fall to the batched interpreter at a
