@@ -82,6 +82,9 @@ SIGNATURES = {
     "hdk_hip_fill_one_to_many_baseline_hash_table": (i32, [v, v, i64, i32, sz, i32, C.POINTER(A.JoinColumn),
                                                            C.POINTER(A.JoinColumnTypeInfo), i32, v]),
     "hdk_hip_build_fused_join_table": (i32, [v, i64, C.POINTER(v), C.POINTER(i32), C.POINTER(i32), i32, v, i32, v]),
+    "hdk_hip_join_build_scratch_bytes": (sz, [i64, i64, i32]),
+    "hdk_hip_fill_hash_join_buff_fused": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i64, C.POINTER(v),
+                                                C.POINTER(i32), C.POINTER(i32), i32, v, v, sz, i32, v]),
     "hdk_hip_init_hash_join_buff": (i32, [v, i64, i32, i32, v]),
     "hdk_hip_fill_hash_join_buff": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo, i32, v]),
     "hdk_hip_fill_hash_join_buff_bucketized": (i32, [v, i32, i32, v, A.JoinColumn, A.JoinColumnTypeInfo,

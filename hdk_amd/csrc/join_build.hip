@@ -67,10 +67,14 @@ struct BuildArgs {
   size_t num_chunks;
   hdk_hip_join_column_type_info ti;
   int64_t bucket;  // <= 1: plain
+  const uint32_t* run_if;  // nullptr: always; else only when *run_if != 0 (armed behind the partitioned build, join_build_part.h)
 };
 
 template <int MODE>
 __global__ __launch_bounds__(kJoinBlock) void k_join_build(BuildArgs a) {
+  if (a.run_if && *a.run_if == 0) {
+    return;
+  }
   const size_t stride = static_cast<size_t>(gridDim.x) * kJoinBlock;
   const size_t start = static_cast<size_t>(blockIdx.x) * kJoinBlock + threadIdx.x;
   const int elem_sz = static_cast<int>(a.ti.elem_sz);
@@ -253,6 +257,12 @@ static int32_t check_join_args(const hdk_hip_join_column& jc, const hdk_hip_join
   return HDK_HIP_OK;
 }
 
+static int64_t pb_min_rows();
+static int32_t one_to_one_partitioned(int32_t* buff, int32_t invalid_slot_val, int32_t* dev_err_buff, const hdk_hip_join_column& jc,
+                                      const hdk_hip_join_column_type_info& ti, int64_t bucket, const int8_t* const* pcols,
+                                      const int32_t* widths, const int32_t* kinds, int np, int64_t* fused, void* scratch,
+                                      size_t scratch_bytes, int32_t device_id, hipStream_t s, bool* done);
+
 static int32_t one_to_one(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join, int32_t* dev_err_buff,
                           const hdk_hip_join_column& jc, const hdk_hip_join_column_type_info& ti,
                           int64_t bucket, int32_t device_id, void* stream) {
@@ -264,6 +274,12 @@ static int32_t one_to_one(int32_t* buff, int32_t invalid_slot_val, int32_t for_s
   if (st) return st;
   if (jc.num_elems == 0) {
     return HDK_HIP_OK;
+  }
+  if (!for_semi_join && pb_min_rows() > 0 && static_cast<int64_t>(jc.num_elems) >= pb_min_rows()) {
+    bool done = false;
+    st = one_to_one_partitioned(buff, invalid_slot_val, dev_err_buff, jc, ti, bucket, nullptr, nullptr, nullptr, 0, nullptr,
+                                nullptr, 0, device_id, s, &done);
+    if (st || done) return st;
   }
   BuildArgs a;
   a.buff = buff;
@@ -278,6 +294,7 @@ static int32_t one_to_one(int32_t* buff, int32_t invalid_slot_val, int32_t for_s
   a.num_chunks = jc.num_chunks;
   a.ti = ti;
   a.bucket = bucket;
+  a.run_if = nullptr;
   hipLaunchKernelGGL(k_join_build<BUILD_ONE_TO_ONE>, dim3(grid_for(jc.num_elems, device_id)), dim3(kJoinBlock),
                      0, s, a);
   HDK_HIP_CHECK(hipGetLastError());
@@ -306,6 +323,7 @@ static int32_t one_to_many(int32_t* buff, int64_t hash_entry_count, int32_t inva
   a.num_chunks = jc.num_chunks;
   a.ti = ti;
   a.bucket = bucket;
+  a.run_if = nullptr;
   const unsigned g = grid_for(jc.num_elems, device_id);
   const unsigned ge = grid_for(static_cast<size_t>(hash_entry_count), device_id);
   if (jc.num_elems) {
@@ -533,9 +551,13 @@ struct FusedArgs {
   int32_t kinds[kMaxFusedCols];
   int32_t ncols;
   int64_t* out;
+  const uint32_t* run_if;  // as BuildArgs::run_if
 };
 
 __global__ __launch_bounds__(kJoinBlock) void k_build_fused(FusedArgs a) {
+  if (a.run_if && *a.run_if == 0) {
+    return;
+  }
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kJoinBlock;
   const int64_t es = 1 + a.ncols;
   for (int64_t slot = static_cast<int64_t>(blockIdx.x) * kJoinBlock + threadIdx.x; slot < a.entry_count; slot += stride) {
@@ -546,6 +568,165 @@ __global__ __launch_bounds__(kJoinBlock) void k_build_fused(FusedArgs a) {
       o[1 + c] = rid >= 0 ? decode_col(a.cols[c], a.widths[c], a.kinds[c], rid) : 0;
     }
   }
+}
+
+}  // namespace hdk
+
+#include "join_build_part.h"
+
+namespace hdk {
+
+// ---- the partitioned one-to-one build (join_build_part.h): geometry, scratch layout, launches ---------------------------
+struct PbLayout {
+  size_t off_fill1, off_fill2, off_t1, off_t2, cursor_bytes, total;
+};
+
+static size_t pb_up(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+
+// false: this table is not one for the partitioned build (no rows, more row ids or slots than 32 bits address)
+static bool pb_geometry(PbArgs* a, PbLayout* l, int64_t rows, int64_t entries, int np) {
+  if (rows <= 0 || entries <= 0 || rows > INT32_MAX || entries > INT32_MAX || np < 0 || np > kPbMaxPayload) return false;
+  const int tw = 1 + np;
+  a->np = np;
+  a->hash_entry_count = entries;
+  a->slice_log2 = np ? kPbSliceLog2Fused : kPbSliceLog2;
+  a->nslices = static_cast<uint32_t>((entries + (1ll << a->slice_log2) - 1) >> a->slice_log2);
+  uint32_t fpc_log2 = 0;
+  while (((a->nslices + (1u << fpc_log2) - 1) >> fpc_log2) > static_cast<uint32_t>(kPbMaxBins)) ++fpc_log2;
+  if (const char* e = getenv("HDK_HIP_BUILD_TWO_LEVELS")) {  // tests: two levels on small tables
+    const uint32_t want = static_cast<uint32_t>(atoi(e));
+    if (want > fpc_log2 && want <= 8) fpc_log2 = want;
+  }
+  if (fpc_log2 > 8) return false;
+  a->fpc_log2 = fpc_log2;
+  a->two_level = fpc_log2 ? 1u : 0u;
+  a->nb1 = (a->nslices + (1u << fpc_log2) - 1) >> fpc_log2;
+  const uint64_t nsub = static_cast<uint64_t>(a->nb1) * kPbXcds;
+  a->cap1 = ((static_cast<uint64_t>(rows) / nsub) * 5 / 4 + 4096 + 15) & ~15ull;
+  a->cap2 = 1ull << a->slice_log2;
+  if (a->cap1 > 0xFFFFFFF0ull) return false;
+  l->off_fill1 = 256;  // [0]: the flag word
+  l->off_fill2 = l->off_fill1 + pb_up(nsub * kPbCursorStride * 4);
+  l->cursor_bytes = l->off_fill2 + (a->two_level ? pb_up(static_cast<size_t>(a->nslices) * kPbCursor2Stride * 4) : 0);
+  l->off_t1 = l->cursor_bytes;
+  l->off_t2 = l->off_t1 + pb_up(nsub * a->cap1 * tw * 8);
+  l->total = l->off_t2 + (a->two_level ? pb_up(static_cast<size_t>(a->nslices) * a->cap2 * tw * 8) : 0);
+  return true;
+}
+
+template <int TW>
+static int32_t pb_launch(const PbArgs& a, const hdk_hip_device_properties* props, hipStream_t s) {
+  constexpr int VR = TW == 1 ? 8 : (TW == 2 ? 4 : 2);
+  const size_t lds_sc = PbStage<TW, VR>::lds_bytes();
+  const unsigned cu = static_cast<unsigned>(props->num_cu);
+  hipLaunchKernelGGL((k_pb_scatter<TW, VR>), dim3(2 * cu), dim3(kPbBlock), lds_sc, s, a);
+  if (a.two_level) {
+    unsigned g2 = a.nb1 * kPbXcds;
+    if (g2 > 3 * cu) g2 = 3 * cu;
+    hipLaunchKernelGGL((k_pb_scatter2<TW, VR>), dim3(g2), dim3(kPbBlock), lds_sc, s, a);
+  }
+  const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * (4 + 8 * (TW - 1));
+  HDK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_build<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds_b)));
+  const int bblock = TW == 1 ? kPbBuildBlock : kPbBuildBlockFused;
+  unsigned per_cu = static_cast<unsigned>((160u * 1024u) / (lds_b + 1024));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu * bblock > 2048u) per_cu = 2048u / bblock;
+  unsigned gb = per_cu * cu;
+  if (gb > a.nslices) gb = a.nslices;
+  hipLaunchKernelGGL((k_pb_build<TW>), dim3(gb), dim3(bblock), lds_b, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
+// rows from which the transparent entry points partition (HDK_HIP_BUILD_PARTITION_MIN_ROWS; 0 = never)
+static int64_t pb_min_rows() {
+  if (const char* e = getenv("HDK_HIP_BUILD_PARTITION_MIN_ROWS")) return atoll(e);
+  return 2000000;
+}
+
+// The whole build on `s`: partitioned passes, then the atomic kernels armed on the overflow flag.  `buff` must have been
+// initialised (hdk_hip_init_hash_join_buff), as for the atomic build.  scratch == nullptr: from the stream's pool.
+static int32_t one_to_one_partitioned(int32_t* buff, int32_t invalid_slot_val, int32_t* dev_err_buff, const hdk_hip_join_column& jc,
+                                      const hdk_hip_join_column_type_info& ti, int64_t bucket, const int8_t* const* pcols,
+                                      const int32_t* widths, const int32_t* kinds, int np, int64_t* fused, void* scratch,
+                                      size_t scratch_bytes, int32_t device_id, hipStream_t s, bool* done) {
+  *done = false;
+  PbArgs a;
+  memset(&a, 0, sizeof(a));
+  PbLayout l;
+  const int64_t range = ti.max_val - ti.min_val + 1 + (ti.uses_bw_eq ? 1 : 0);
+  const int64_t entries = bucket > 1 ? (range + bucket - 1) / bucket : range;
+  if (!pb_geometry(&a, &l, static_cast<int64_t>(jc.num_elems), entries, fused ? np : 0)) return HDK_HIP_OK;
+  AsyncScratch own(s);
+  int8_t* base = static_cast<int8_t*>(scratch);
+  if (!base) {
+    if (hipMallocAsync(&own.p, l.total, s) != hipSuccess) {
+      (void)hipGetLastError();
+      return HDK_HIP_OK;  // no room for the tuples: the atomic build needs none
+    }
+    base = static_cast<int8_t*>(own.p);
+  } else {
+    HDK_REQUIRE(scratch_bytes >= l.total, "scratch too small: %zu bytes, hdk_hip_join_build_scratch_bytes says %zu", scratch_bytes, l.total);
+  }
+  HDK_HIP_CHECK(hipMemsetAsync(base, 0, l.cursor_bytes, s));
+  a.chunks = reinterpret_cast<const hdk_hip_join_chunk*>(jc.col_chunks_buff);
+  a.num_chunks = jc.num_chunks;
+  a.ti = ti;
+  a.bucket = bucket;
+  a.invalid_slot_val = invalid_slot_val;
+  a.dev_err = dev_err_buff;
+  for (int c = 0; c < a.np; ++c) {
+    a.pcols[c] = pcols[c];
+    a.pwidths[c] = widths[c];
+    a.pkinds[c] = kinds[c];
+  }
+  a.flag = reinterpret_cast<uint32_t*>(base);
+  a.fill1 = reinterpret_cast<uint32_t*>(base + l.off_fill1);
+  a.fill2 = reinterpret_cast<uint32_t*>(base + l.off_fill2);
+  a.tuples1 = reinterpret_cast<int64_t*>(base + l.off_t1);
+  a.tuples2 = reinterpret_cast<int64_t*>(base + l.off_t2);
+  a.buff = buff;
+  a.fused = fused;
+  const hdk_hip_device_properties* props = device_props(device_id);
+  int32_t st;
+  switch (1 + a.np) {
+    case 1: st = pb_launch<1>(a, props, s); break;
+    case 2: st = pb_launch<2>(a, props, s); break;
+    case 3: st = pb_launch<3>(a, props, s); break;
+    default: st = pb_launch<4>(a, props, s); break;
+  }
+  if (st) return st;
+  // armed: a key distribution that overflowed a sub-slab is built with atomics (the table is still as initialised)
+  BuildArgs b;
+  b.buff = buff;
+  b.hash_entry_count = entries;
+  b.invalid_slot_val = invalid_slot_val;
+  b.for_semi_join = 0;
+  b.dev_err = dev_err_buff;
+  b.chunks = a.chunks;
+  b.num_chunks = a.num_chunks;
+  b.ti = ti;
+  b.bucket = bucket;
+  b.run_if = a.flag;
+  hipLaunchKernelGGL(k_join_build<BUILD_ONE_TO_ONE>, dim3(grid_for(jc.num_elems, device_id)), dim3(kJoinBlock), 0, s, b);
+  if (fused) {
+    FusedArgs f;
+    f.table = buff;
+    f.entry_count = entries;
+    f.ncols = np;
+    f.out = fused;
+    f.run_if = a.flag;
+    for (int c = 0; c < kMaxFusedCols; ++c) {
+      f.cols[c] = c < np ? pcols[c] : nullptr;
+      f.widths[c] = c < np ? widths[c] : 0;
+      f.kinds[c] = c < np ? kinds[c] : 0;
+    }
+    hipLaunchKernelGGL(k_build_fused, dim3(grid_for(static_cast<size_t>(entries), device_id)), dim3(kJoinBlock), 0, s, f);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  *done = true;
+  return HDK_HIP_OK;
 }
 
 }  // namespace hdk
@@ -570,6 +751,7 @@ extern "C" int32_t hdk_hip_build_fused_join_table(const int32_t* table, int64_t 
   a.entry_count = entry_count;
   a.ncols = ncols;
   a.out = out;
+  a.run_if = nullptr;
   for (int c = 0; c < kMaxFusedCols; ++c) {
     a.cols[c] = c < ncols ? inner_cols[c] : nullptr;
     a.widths[c] = c < ncols ? widths[c] : 0;
@@ -742,4 +924,42 @@ extern "C" int32_t hdk_hip_fill_one_to_many_baseline_hash_table(int32_t* buff, c
   }
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
+}
+
+extern "C" size_t hdk_hip_join_build_scratch_bytes(int64_t num_rows, int64_t entry_count, int32_t ncols) {
+  PbArgs a;
+  PbLayout l;
+  if (!pb_geometry(&a, &l, num_rows, entry_count, ncols)) return 0;
+  return l.total;
+}
+
+extern "C" int32_t hdk_hip_fill_hash_join_buff_fused(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join,
+                                                     int32_t* dev_err_buff, hdk_hip_join_column join_column,
+                                                     hdk_hip_join_column_type_info type_info, int64_t bucket_normalization,
+                                                     const int8_t* const* inner_cols, const int32_t* widths,
+                                                     const int32_t* kinds, int32_t ncols, int64_t* fused_out, void* scratch,
+                                                     size_t scratch_bytes, int32_t device_id, void* stream) {
+  HDK_REQUIRE(buff && dev_err_buff && fused_out, "NULL buffer");
+  HDK_REQUIRE(bucket_normalization > 0, "bucket_normalization must be positive");
+  HDK_REQUIRE(ncols >= 0 && ncols <= kMaxFusedCols, "0..%d payload columns", kMaxFusedCols);
+  HDK_REQUIRE(ncols == 0 || (inner_cols && widths && kinds), "NULL column description");
+  int32_t st = check_join_args(join_column, type_info);
+  if (st) return st;
+  hipStream_t s;
+  st = device_enter(device_id, stream, &s);
+  if (st) return st;
+  const int64_t range = type_info.max_val - type_info.min_val + 1 + (type_info.uses_bw_eq ? 1 : 0);
+  const int64_t entries = bucket_normalization > 1 ? (range + bucket_normalization - 1) / bucket_normalization : range;
+  if (join_column.num_elems && !for_semi_join && ncols <= kPbMaxPayload && pb_min_rows() > 0 &&
+      static_cast<int64_t>(join_column.num_elems) >= pb_min_rows()) {
+    bool done = false;
+    st = one_to_one_partitioned(buff, invalid_slot_val, dev_err_buff, join_column, type_info, bucket_normalization, inner_cols,
+                                widths, kinds, ncols, fused_out, scratch, scratch_bytes, device_id, s, &done);
+    if (st || done) return st;
+  }
+  // small, semi-join or wide tables: the table with atomics, then the fused form derived from it
+  st = one_to_one(buff, invalid_slot_val, for_semi_join, dev_err_buff, join_column, type_info, bucket_normalization, device_id,
+                  stream);
+  if (st) return st;
+  return hdk_hip_build_fused_join_table(buff, entries, inner_cols, widths, kinds, ncols, fused_out, device_id, stream);
 }

@@ -106,11 +106,17 @@ class PreparedStep:
         ntab = 1 + len(cp.inner_tables)
 
         # ---- join hash tables (built once per device, cached) ----------------------------
-        self.join_tables = [ex._build_join_table(cp, ji) for ji in range(len(cp.inner_tables))]
         # the launch uses a private copy of the plan: fusing join tables rewrites column descriptors
         self.plan = A.Plan.from_buffer_copy(cp.plan)
-        if self.join_tables and ex.fuse_join_tables and not (flags & (A.LAUNCH_FORCE_SCALAR |
-                                                                        A.LAUNCH_FORCE_GLOBAL_ATOMICS)):
+        fuse = bool(cp.inner_tables) and ex.fuse_join_tables and \
+            not (flags & (A.LAUNCH_FORCE_SCALAR | A.LAUNCH_FORCE_GLOBAL_ATOMICS)) and \
+            bool({"hdk_scan_agg_vec_join", "hdk_scan_project_join"} & set(self.kernel_names().split(",")))
+        # (a table that will be fused is built together with its fused form: one sweep over the inner rows)
+        self.join_tables = []
+        for ji in range(len(cp.inner_tables)):
+            spec = self._fuse_spec(ji) if fuse else None
+            self.join_tables.append(ex._build_join_table(cp, ji, ((spec[0], self), spec[1], spec[2]) if spec else None))
+        if fuse:
             self._fuse_join_tables()
         p = self.plan
 
@@ -204,32 +210,47 @@ class PreparedStep:
         check(self.L.hdk_hip_describe_launch(C.byref(self.plan), C.byref(self.ko), self.dev, out, 256))
         return out.value.decode()
 
-    def _fuse_join_tables(self, max_bytes=2 << 30):
+    def _fuse_spec(self, ji, max_bytes=2 << 30):
+        """What the fused form of join ji's table holds: (cache key, plan columns read through the join, stride), or
+        None when the table stays as it is (not one-to-one, more than seven columns, too large)."""
+        cp = self.cp
+        info = cp.join_infos[ji]
+        if info["kind"] != A.JOIN_ONE_TO_ONE:
+            return None
+        cols = [ci for ci, (tn, cn, slot) in enumerate(cp.input_cols) if slot == ji + 1]
+        stride = 1 + len(cols)
+        if len(cols) > 7 or info["entry_count"] * stride * 8 > max_bytes:
+            return None
+        key = (info["inner_table"], info["inner_col"], tuple(cp.input_cols[ci][1] for ci in cols), info["uses_bw_eq"],
+               info["for_semi_join"])
+        return key, cols, stride
+
+    def _payload_arrays(self, ji, cols):
+        cp, p = self.cp, self.plan
+        inner = self.ex.storage.get(cp.join_infos[ji]["inner_table"])
+        ptrs = (C.c_void_p * max(len(cols), 1))()
+        widths = (C.c_int32 * max(len(cols), 1))()
+        kinds = (C.c_int32 * max(len(cols), 1))()
+        for k, ci in enumerate(cols):
+            ptrs[k] = self.ex.cache.linearized(inner, cp.input_cols[ci][1]).ptr
+            widths[k] = cp.plan.cols[ci].width
+            kinds[k] = cp.plan.cols[ci].kind
+        return ptrs, widths, kinds
+
+    def _fuse_join_tables(self):
         """Replace each one-to-one join table by the fused [row id | payload ...] form when the batched
         interpreter (or the projection kernel) will run the plan: one gather per probing row instead of
         slot -> row id -> inner column (HDK_JOIN_ONE_TO_ONE_FUSED, include/hdk_hip.h)."""
-        if not ({"hdk_scan_agg_vec_join", "hdk_scan_project_join"} & set(self.kernel_names().split(","))):
-            return
-        cp, p, storage = self.cp, self.plan, self.ex.storage
+        cp, p = self.cp, self.plan
         for ji, info in enumerate(cp.join_infos):
-            if info["kind"] != A.JOIN_ONE_TO_ONE:
+            spec = self._fuse_spec(ji)
+            if spec is None:
                 continue
-            cols = [ci for ci, (tn, cn, slot) in enumerate(cp.input_cols) if slot == ji + 1]
+            key, cols, stride = spec
             entries = info["entry_count"]
-            stride = 1 + len(cols)
-            if len(cols) > 7 or entries * stride * 8 > max_bytes:
-                continue
-            key = (info["inner_table"], info["inner_col"], tuple(cp.input_cols[ci][1] for ci in cols))
             fused = self.ex._fused_cache.get(key)
-            if fused is None:
-                inner = storage.get(info["inner_table"])
-                ptrs = (C.c_void_p * max(len(cols), 1))()
-                widths = (C.c_int32 * max(len(cols), 1))()
-                kinds = (C.c_int32 * max(len(cols), 1))()
-                for k, ci in enumerate(cols):
-                    ptrs[k] = self.ex.cache.linearized(inner, cp.input_cols[ci][1]).ptr
-                    widths[k] = p.cols[ci].width
-                    kinds[k] = p.cols[ci].kind
+            if fused is None:  # (the plain table came out of the cache: derive the fused form from it)
+                ptrs, widths, kinds = self._payload_arrays(ji, cols)
                 fused = self.mgr.alloc(entries * stride * 8, self.dev)
                 check(self.L.hdk_hip_build_fused_join_table(self.join_tables[ji].ptr, entries, ptrs, widths, kinds,
                                                             len(cols), fused.ptr, self.dev, None))
@@ -396,7 +417,7 @@ class Executor:
                                             info["uses_bw_eq"], info["col_types"][k], info["translated_null_build"]))
         return jcs, tis, keep
 
-    def _build_join_table(self, cp: CompiledPlan, ji: int) -> DeviceBuffer:
+    def _build_join_table(self, cp: CompiledPlan, ji: int, fuse_spec=None) -> DeviceBuffer:
         """HashJoin::getInstance / PerfectJoinHashTable::reify / BaselineJoinHashTable::reify for one
         device (QE/JoinHashTable/HashJoin.cpp:258-330): the table kind the plan names -- perfect or
         keyed, one-to-one or one-to-many -- built with the *_on_device entry points.  The plan chose
@@ -413,6 +434,7 @@ class Executor:
         jcs, tis, keep = self._join_columns(inner, info)
         d_err = self.mgr.to_device(np.zeros(1, dtype=np.int32), dev)
         semi = info["for_semi_join"]
+        fused_key = None
         if kind in (A.JOIN_ONE_TO_ONE, A.JOIN_ONE_TO_MANY):
             # HashEntryInfo{max - min + 1 (+ 1 for kBwEq), bucket_normalization}; the table has the NORMALISED count of
             # slots (initHashTableOnGpu, Builders/PerfectHashTableBuilder.h:82-130)
@@ -423,7 +445,23 @@ class Executor:
             if kind == A.JOIN_ONE_TO_ONE:
                 table = self.mgr.alloc(entries * 4, dev)
                 check(L.hdk_hip_init_hash_join_buff(table.ptr, entries, A.JOIN_INVALID_SLOT, dev, None))
-                if info["bucketized"]:
+                if fuse_spec is not None and fuse_spec[0][0] not in self._fused_cache:
+                    # the table and its fused form in one sweep (hdk_hip_fill_hash_join_buff_fused: partitioned from a
+                    # few million rows on, no gather through the row id)
+                    (fkey, step), cols, stride = fuse_spec
+                    ptrs, widths, kinds = step._payload_arrays(ji, cols)
+                    fused = self.mgr.alloc(entries * stride * 8, dev)
+                    sb = L.hdk_hip_join_build_scratch_bytes(inner.num_rows, entries, len(cols))
+                    scratch = self.mgr.alloc(sb, dev) if sb else None
+                    check(L.hdk_hip_fill_hash_join_buff_fused(table.ptr, A.JOIN_INVALID_SLOT, semi, d_err.ptr, jcs[0], tis[0],
+                                                              max(info["bucket"], 1), ptrs, widths, kinds, len(cols), fused.ptr,
+                                                              scratch.ptr if scratch else None, sb, dev, None))
+                    self.mgr.synchronizeStream(dev)
+                    if scratch:
+                        scratch.free()
+                    self._fused_cache[fkey] = fused
+                    fused_key = fkey
+                elif info["bucketized"]:
                     # (the reference always calls the bucketized fill for a one-to-one table, with bucket 1 for
                     # everything but a DATE key; the plain entry point is that call with bucket 1)
                     check(L.hdk_hip_fill_hash_join_buff_bucketized(table.ptr, A.JOIN_INVALID_SLOT, semi, d_err.ptr, jcs[0],
@@ -459,6 +497,8 @@ class Executor:
             d.free()
         if err != 0:
             table.free()
+            if fused_key is not None:
+                self._fused_cache.pop(fused_key).free()
             raise QueryMustRunOnCpu(f"join table build failed with code {err} (-1: duplicate key in a one-to-one "
                                     "table, PerfectHashTableBuilder.h:134-141 NeedsOneToManyHash; -2: stale metadata)")
         self._join_cache[key] = table

@@ -717,6 +717,23 @@ int32_t hdk_hip_build_fused_join_table(const int32_t* table, int64_t entry_count
                                        const int32_t* widths, const int32_t* kinds, int32_t ncols, int64_t* out,
                                        int32_t device_id, void* stream);
 
+/* A one-to-one table AND its fused form in one sweep over the inner rows (MI355X addition; the table is what
+ * fill_hash_join_buff_on_device_bucketized leaves, QE/JoinHashTable/Runtime/HashJoinRuntimeGpu.cu:57-75, the fused form
+ * what hdk_hip_build_fused_join_table derives from it).  From a few million rows on, and unless the table is built for a
+ * semi join, the rows are PARTITIONED by slot range (one or two radix levels) and each 32 768-slot slice is built in LDS
+ * and written front to back, payloads travelling with the rows: no random atomics (1e8 of them cost 4.4 ms), no gather
+ * through the row id (2.9 ms per 1e8 slots).  hdk_hip_fill_hash_join_buff[_bucketized] take the same route for the table
+ * alone.  A taken slot is -1 and a key outside [min, max] -2 in *dev_err_buff, as there; `buff` must have been initialised
+ * (hdk_hip_init_hash_join_buff).  `scratch`: hdk_hip_join_build_scratch_bytes(rows, slots, ncols) bytes of device memory
+ * (0: this table is not partitioned, none needed), or NULL -- the library then takes it from the stream's memory pool
+ * (hipMallocAsync).  HDK_HIP_BUILD_PARTITION_MIN_ROWS overrides the threshold (0 = never partition). */
+size_t hdk_hip_join_build_scratch_bytes(int64_t num_rows, int64_t entry_count, int32_t ncols);
+int32_t hdk_hip_fill_hash_join_buff_fused(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join, int32_t* dev_err_buff,
+                                          hdk_hip_join_column join_column, hdk_hip_join_column_type_info type_info,
+                                          int64_t bucket_normalization, const int8_t* const* inner_cols, const int32_t* widths,
+                                          const int32_t* kinds, int32_t ncols, int64_t* fused_out, void* scratch,
+                                          size_t scratch_bytes, int32_t device_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,128 @@ def test_join_build_kats_and_random(mgr, oracle):
             assert sorted(gi[gp[k]:gp[k] + gc[k]]) == sorted(wi[gp[k]:gp[k] + gc[k]])
 
 
+def _fill_one_to_one(mgr, oracle, arrays, ti, bucket=1, payload=None, two_levels=None, monkeypatch=None):
+    """Device table (and fused table) against orc_fill_hash_join_buff + a by-hand fused form.  Returns (err, rc)."""
+    L, O = lib(), oracle
+    esz = arrays[0].dtype.itemsize
+    jc, keep = _device_join_column(mgr, arrays, esz)
+    rng_ = ti.max_val - ti.min_val + 1 + (1 if ti.uses_bw_eq else 0)
+    n = (rng_ + bucket - 1) // bucket if bucket > 1 else rng_
+    table = mgr.alloc(n * 4, 0)
+    d_err = mgr.to_device(np.zeros(1, dtype=np.int32), 0)
+    check(L.hdk_hip_init_hash_join_buff(table.ptr, n, -1, 0, None))
+    fused = None
+    if payload is None:
+        check(L.hdk_hip_fill_hash_join_buff_bucketized(table.ptr, -1, 0, d_err.ptr, jc, ti, bucket, 0, None))
+    else:
+        nc = len(payload)
+        dcols = [mgr.to_device(c, 0) for c in payload]
+        ptrs = (C.c_void_p * nc)(*[d.ptr for d in dcols])
+        widths = (C.c_int32 * nc)(*[c.dtype.itemsize for c in payload])
+        kinds = (C.c_int32 * nc)(*[A.COL_DOUBLE if c.dtype == np.float64 else A.COL_INT for c in payload])
+        fused = mgr.alloc(n * (1 + nc) * 8, 0)
+        rows = sum(a.size for a in arrays)
+        sb = L.hdk_hip_join_build_scratch_bytes(rows, n, nc)
+        scratch = mgr.alloc(max(sb, 8), 0) if nc != 2 else None  # two payload columns: the library's own scratch
+        check(L.hdk_hip_fill_hash_join_buff_fused(table.ptr, -1, 0, d_err.ptr, jc, ti, bucket, ptrs, widths, kinds, nc, fused.ptr,
+                                                  scratch.ptr if scratch else None, sb if scratch else 0, 0, None))
+    mgr.synchronizeStream(0)
+    err = int(mgr.to_host(d_err.ptr, 4, 0, np.int32)[0])
+    want = np.empty(n, dtype=np.int32)
+    O.lib().orc_init_hash_join_buff(want.ctypes.data, n, -1)
+    chunks = O.make_join_chunks(arrays)
+    rc = O.lib().orc_fill_hash_join_buff(want.ctypes.data, -1, 0, C.cast(chunks, C.c_void_p), len(arrays), C.byref(ti), bucket)
+    if rc == 0 and err == 0:
+        got = mgr.to_host(table.ptr, n * 4, 0, np.int32)
+        assert np.array_equal(got, want)
+        if payload is not None:
+            gf = mgr.to_host(fused.ptr, n * (1 + len(payload)) * 8, 0, np.int64).reshape(n, 1 + len(payload))
+            assert np.array_equal(gf[:, 0], want.astype(np.int64))
+            ok = want >= 0
+            for c, col in enumerate(payload):
+                w = np.zeros(n, dtype=np.int64)
+                w[ok] = col[want[ok]].view(np.int64) if col.dtype == np.float64 else col[want[ok]].astype(np.int64)
+                assert np.array_equal(gf[:, 1 + c], w), c
+    return err, rc
+
+
+def test_partitioned_join_build(mgr, oracle, monkeypatch):
+    """The one-to-one build by slot-range partitions (join_build_part.h) against orc_fill_hash_join_buff
+    (HashJoinRuntime.cpp:197-293): forced on small inputs; one slice, several slices, two scatter levels; chunked key
+    columns of every width; NULL keys skipped, or filed under the translated NULL of a kBwEq join; DATE buckets; sparse
+    ranges; duplicates (-1) and keys outside the statistics (-2); a key distribution that overflows a sub-slab (the armed
+    atomic kernels build the table); the fused form with one to three payload columns from the caller's or the library's
+    scratch, and with four through the gather."""
+    monkeypatch.setenv("HDK_HIP_BUILD_PARTITION_MIN_ROWS", "1")
+    L = lib()
+    rng = np.random.default_rng(77)
+
+    def ti_of(allk, esz, nullv, bw=0, ctype=None, bucket=1, lo=None, hi=None):
+        live = allk[allk != nullv]
+        lo = int(live.min()) if lo is None else lo
+        hi = int(live.max()) if hi is None else hi
+        tr = (hi // bucket + 1) if (bw and bucket > 1) else hi + 1
+        return A.JoinColumnTypeInfo(esz, lo, hi, nullv, bw, A.JC_SIGNED if ctype is None else ctype, tr if bw else 0)
+
+    for two in (None, "1", "3"):
+        if two:
+            monkeypatch.setenv("HDK_HIP_BUILD_TWO_LEVELS", two)
+        else:
+            monkeypatch.delenv("HDK_HIP_BUILD_TWO_LEVELS", raising=False)
+        # a permutation in three chunks, 100 K keys (4 slices), int64
+        perm = rng.permutation(100_000).astype(np.int64) + 17
+        arrays = [np.ascontiguousarray(perm[i::3]) for i in range(3)]
+        assert _fill_one_to_one(mgr, oracle, arrays, ti_of(perm, 8, A.NULL_BIGINT)) == (0, 0)
+        # sparse: 30 K keys over a range of 300 K, int32, NULLs skipped
+        k32 = (rng.permutation(30_000) * 10 - 5000).astype(np.int32)
+        k32[rng.random(k32.size) < 0.02] = A.NULL_INT
+        assert _fill_one_to_one(mgr, oracle, [k32[:11_111], k32[11_111:]], ti_of(k32, 4, A.NULL_INT)) == (0, 0)
+        # int16 keys, one NULL row filed under max + 1 (kBwEq)
+        k16 = rng.permutation(3_000).astype(np.int16)
+        k16[5] = A.NULL_SMALLINT
+        assert _fill_one_to_one(mgr, oracle, [k16], ti_of(k16, 2, A.NULL_SMALLINT, bw=1)) == (0, 0)
+        # DATE in seconds, bucket 86400
+        days = rng.permutation(40_000).astype(np.int64)[:25_000]
+        secs = days * 86400
+        assert _fill_one_to_one(mgr, oracle, [secs], ti_of(secs, 8, A.NULL_BIGINT, bucket=86400), bucket=86400) == (0, 0)
+        # duplicates: -1 on both sides
+        dup = rng.integers(0, 50_000, 60_000).astype(np.int64)
+        err, rc = _fill_one_to_one(mgr, oracle, [dup], ti_of(dup, 8, A.NULL_BIGINT))
+        assert err == -1 and rc != 0
+        # fused forms
+        pay = [rng.integers(-2**40, 2**40, perm.size, dtype=np.int64), rng.integers(-100, 100, perm.size).astype(np.int32),
+               rng.normal(size=perm.size), rng.integers(0, 9, perm.size).astype(np.int16)]
+        for nc in (1, 2, 3, 4):
+            assert _fill_one_to_one(mgr, oracle, arrays, ti_of(perm, 8, A.NULL_BIGINT), payload=pay[:nc]) == (0, 0), nc
+    monkeypatch.delenv("HDK_HIP_BUILD_TWO_LEVELS", raising=False)
+    # stale statistics: a key above max
+    st_k = np.arange(5_000, dtype=np.int64)
+    jc, keep = _device_join_column(mgr, [st_k], 8)
+    ti = A.JoinColumnTypeInfo(8, 0, 3_999, A.NULL_BIGINT, 0, A.JC_SIGNED, 0)
+    table = mgr.alloc(4_000 * 4, 0)
+    d_err = mgr.to_device(np.zeros(1, dtype=np.int32), 0)
+    check(L.hdk_hip_init_hash_join_buff(table.ptr, 4_000, -1, 0, None))
+    check(L.hdk_hip_fill_hash_join_buff(table.ptr, -1, 0, d_err.ptr, jc, ti, 0, None))
+    mgr.synchronizeStream(0)
+    assert int(mgr.to_host(d_err.ptr, 4, 0, np.int32)[0]) == -2
+    assert np.array_equal(mgr.to_host(table.ptr, 16_000, 0, np.int32), np.arange(4_000, dtype=np.int32))
+    # nearly every row in the first of eight level-1 bins (8 slices each): its sub-slabs overflow, the armed atomic kernels
+    # build the table
+    monkeypatch.setenv("HDK_HIP_BUILD_TWO_LEVELS", "3")
+    skew = rng.permutation(8 * 32768)[:200_000].astype(np.int64)
+    skew = np.concatenate([skew, np.array([64 * 32768 - 1], dtype=np.int64)])
+    pay = [rng.integers(0, 1000, skew.size, dtype=np.int64)]
+    assert _fill_one_to_one(mgr, oracle, [skew], ti_of(skew, 8, A.NULL_BIGINT), payload=pay) == (0, 0)
+    assert _fill_one_to_one(mgr, oracle, [skew], ti_of(skew, 8, A.NULL_BIGINT)) == (0, 0)
+    # (with payloads a slice has 4 096 slots: 100 K rows in the first of sixteen 131 K-slot bins overflow its sub-slabs)
+    monkeypatch.setenv("HDK_HIP_BUILD_TWO_LEVELS", "5")
+    skew = np.concatenate([rng.permutation(32 * 4096)[:100_000].astype(np.int64), np.array([64 * 32768 - 1], dtype=np.int64)])
+    pay = [rng.integers(0, 1000, skew.size, dtype=np.int64), rng.integers(0, 1000, skew.size).astype(np.int32)]
+    assert _fill_one_to_one(mgr, oracle, [skew], ti_of(skew, 8, A.NULL_BIGINT), payload=pay) == (0, 0)
+    monkeypatch.delenv("HDK_HIP_BUILD_TWO_LEVELS", raising=False)
+    assert L.hdk_hip_join_build_scratch_bytes(0, 100, 1) == 0 and L.hdk_hip_join_build_scratch_bytes(10**6, 10**6, 9) == 0
+
+
 def test_device_reduce_perfect_hash(mgr, oracle):
     """hdk_hip_reduce_buffers == the oracle's ResultSetReduction restatement, partials in order."""
     rng = np.random.default_rng(21)
