@@ -335,7 +335,7 @@ __global__ __launch_bounds__(TW == 1 ? kPbBuildBlock : kPbBuildBlockFused) void 
     for (uint32_t i = tid; i < nslots; i += nthr) {
       const int32_t rid = s_rid[i];
       a.buff[base + i] = rid;
-      if (NP > 0 && a.fused) {  // HDK_JOIN_ONE_TO_ONE_FUSED: [row id | payload words], empty slots carry zeros
+      if (a.fused) {  // HDK_JOIN_ONE_TO_ONE_FUSED: [row id | payload words], empty slots carry zeros
         int64_t* o = a.fused + (static_cast<int64_t>(base) + i) * TW;
         o[0] = rid;
 #pragma unroll

@@ -187,9 +187,9 @@ def _fill_one_to_one(mgr, oracle, arrays, ti, bucket=1, payload=None, two_levels
     else:
         nc = len(payload)
         dcols = [mgr.to_device(c, 0) for c in payload]
-        ptrs = (C.c_void_p * nc)(*[d.ptr for d in dcols])
-        widths = (C.c_int32 * nc)(*[c.dtype.itemsize for c in payload])
-        kinds = (C.c_int32 * nc)(*[A.COL_DOUBLE if c.dtype == np.float64 else A.COL_INT for c in payload])
+        ptrs = (C.c_void_p * max(nc, 1))(*[d.ptr for d in dcols])
+        widths = (C.c_int32 * max(nc, 1))(*[c.dtype.itemsize for c in payload])
+        kinds = (C.c_int32 * max(nc, 1))(*[A.COL_DOUBLE if c.dtype == np.float64 else A.COL_INT for c in payload])
         fused = mgr.alloc(n * (1 + nc) * 8, 0)
         rows = sum(a.size for a in arrays)
         sb = L.hdk_hip_join_build_scratch_bytes(rows, n, nc)
@@ -262,7 +262,7 @@ def test_partitioned_join_build(mgr, oracle, monkeypatch):
         # fused forms
         pay = [rng.integers(-2**40, 2**40, perm.size, dtype=np.int64), rng.integers(-100, 100, perm.size).astype(np.int32),
                rng.normal(size=perm.size), rng.integers(0, 9, perm.size).astype(np.int16)]
-        for nc in (1, 2, 3, 4):
+        for nc in (0, 1, 2, 3, 4):  # (0: a join none of whose inner columns is read still gets [row id] entries)
             assert _fill_one_to_one(mgr, oracle, arrays, ti_of(perm, 8, A.NULL_BIGINT), payload=pay[:nc]) == (0, 0), nc
     monkeypatch.delenv("HDK_HIP_BUILD_TWO_LEVELS", raising=False)
     # stale statistics: a key above max
