@@ -292,6 +292,13 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Arg
 }
 
 // dynamic LDS: [entry_count x wpe x rep] aggregate words | int32 payload[slice]
+#ifndef HDK_S2_K_GROUPED
+#define HDK_S2_K_GROUPED 8  // joined rows per batch (4 or 8) of the grouped / the non-grouped form: 8 amortises the scalar dispatch (c3g 7.83 -> 7.6 ms, c3m 7.7 -> 7.6)
+#endif
+#ifndef HDK_S2_K_PLAIN
+#define HDK_S2_K_PLAIN 8
+#endif
+
 template <bool GROUPED>
 __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Args g) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   // K joined rows at a time: everything that is the same for every row of the launch -- which comparison a filter makes,
   // what a target computes, how its word combines -- is decided ONCE per batch by scalar code, the K rows then run through
   // straight vector code.  (One row at a time the scalar dispatch was the bottleneck: ~70 scalar instructions per tuple.)
-  constexpr int K = 4;
+  constexpr int K = GROUPED ? HDK_S2_K_GROUPED : HDK_S2_K_PLAIN;
   // ok[k]: slot k holds a tuple with a partner; x32 / p32 its outer value and payload (kSliceNull: the column's NULL)
   auto batch = [&](const int32_t (&x32)[K], const int32_t (&p32)[K], bool (&ok)[K]) {
     bool pnull[K], xnull[K];
@@ -546,26 +553,30 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
       }
       const uint64_t npairs = (n + 1) / 2;
       const uint64_t stride = static_cast<uint64_t>(members) * kSliceAggBlock;
-      bf_i64x2 n0, n1;
-      n0.x = n0.y = n1.x = n1.y = 0;
+      constexpr int W = K / 2;  // 16-byte words per trip
+      bf_i64x2 nx[W];
       uint64_t pw = static_cast<uint64_t>(member) * kSliceAggBlock + tid;
-      if (pw < npairs) {
-        n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw), true);
-      }
-      if (pw + stride < npairs) {
-        n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + stride), true);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        nx[j].x = nx[j].y = 0;
+        if (pw + j * stride < npairs) {
+          nx[j] = gload<bf_i64x2>(in, static_cast<int64_t>(pw + j * stride), true);
+        }
       }
 #pragma unroll 1
-      for (; pw < npairs; pw += 2 * stride) {
-        const bf_i64x2 c0 = n0, c1 = n1;
-        if (pw + 2 * stride < npairs) {
-          n0 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 2 * stride), true);
+      for (; pw < npairs; pw += W * stride) {
+        int64_t w[K];
+        bool live[K];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          w[2 * j] = nx[j].x;
+          w[2 * j + 1] = nx[j].y;
+          live[2 * j] = pw + j * stride < npairs;
+          live[2 * j + 1] = live[2 * j] && 2 * (pw + j * stride) + 1 < n;
+          if (pw + (W + j) * stride < npairs) {
+            nx[j] = gload<bf_i64x2>(in, static_cast<int64_t>(pw + (W + j) * stride), true);
+          }
         }
-        if (pw + 3 * stride < npairs) {
-          n1 = gload<bf_i64x2>(in, static_cast<int64_t>(pw + 3 * stride), true);
-        }
-        const int64_t w[K] = {c0.x, c0.y, c1.x, c1.y};
-        const bool live[K] = {true, 2 * pw + 1 < n, pw + stride < npairs, pw + stride < npairs && 2 * (pw + stride) + 1 < n};
         tuples(w, live);
       }
     }
