@@ -53,7 +53,14 @@ class Comm:
         self.backend = os.environ.get("HDK_BENCH_BACKEND", "nccl")
         self.dev = self.local_rank if self.backend == "nccl" else self.local_rank % torch.cuda.device_count()
         torch.cuda.set_device(self.dev)
-        if self.world > 1:
+        # HDK_BENCH_SINGLE_RANK_COLLECTIVES=1: a ONE-rank job still initialises the process group and runs the N > 1 step
+        # (all-gather + fold, tuple exchange + all-to-all) -- the only way to drive the RCCL branch on a one-GPU box
+        self.multi = self.world > 1 or os.environ.get("HDK_BENCH_SINGLE_RANK_COLLECTIVES") == "1"
+        if self.multi:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev))
             else:
@@ -69,7 +76,7 @@ class Comm:
             dst.copy_(self.torch.cat(parts))
 
     def all_reduce(self, t, op="sum"):
-        if self.world == 1:
+        if not self.multi:
             return t
         o = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
         if self.backend == "nccl":
@@ -81,12 +88,12 @@ class Comm:
         return t
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def close(self):
-        if self.world > 1:
+        if self.multi:
             self.dist.destroy_process_group()
 
 
@@ -115,6 +122,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     from workloads import CONFIGS, Workload
     L = lib()
     world, rank, dev = comm.world, comm.rank, comm.dev
+    multi = comm.multi  # (world > 1, or one rank told to run the N > 1 step)
     rows = int(args.rows) if (args.rows and primary) else CONFIGS[name][0]
     strong = args.scaling == "strong"
     nfrag_total = len(__import__("workloads").fragment_rows(rows))
@@ -137,19 +145,19 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     out_t = torch.empty(quads, dtype=torch.int64, device="cuda")
     step = w.ex.prepare(cp, w.frag_ids, grid=args.grid if primary else 0, flags=A.LAUNCH_RECORD_EVENTS | int(os.environ.get("HDK_BENCH_FLAGS", "0")),
                         out_ptr=out_t.data_ptr())
-    gathered = torch.empty(world * quads, dtype=torch.int64, device="cuda") if (world > 1 and not baseline) else None
+    gathered = torch.empty(world * quads, dtype=torch.int64, device="cuda") if (multi and not baseline) else None
     d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
     init_vals = np.ascontiguousarray(cp.init_vals, dtype=np.int64)
     merge_ms, owner = [], {}
     # ---- N > 1 ----------------------------------------------------------------------------------------------------
     xch, xch_ev, mode = None, [], "single"
-    if world > 1 and not baseline:
+    if multi and not baseline:
         mode = "gather+fold"
         # (hoisted out of the step: the argument arrays of the fold; the plan stays resident in the workspace after
         # the first launch, so a step uploads nothing)
         that = (C.c_void_p * (world - 1))(*[gathered.data_ptr() + i * quads * 8 for i in range(1, world)])
         counts = (C.c_uint32 * (world - 1))(*([cp.entry_count] * (world - 1)))
-    if world > 1 and baseline:
+    if multi and baseline:
         # open addressing: TUPLES go to their owner rank (hdk_hip_scatter_to_owners -> one all-to-all with equal
         # splits -> hdk_hip_aggregate_from_ranks); skewed keys fall back to the exchange of partial tables
         bound = torch.tensor([w.local_rows], dtype=torch.int64, device="cuda")
@@ -209,7 +217,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
             xch_ev.append(ev)
             return
         step.enqueue(stream)  # output-buffer initialisation + launch (fused for the open-addressing tables)
-        if world == 1:
+        if not multi:
             return
         if mode == "gather+fold":
             # ResultSetReduction over the per-GPU partial tables: all-gather (1.5 KB each for C2) + device fold
@@ -266,7 +274,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     for _ in range(steps):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         comm.dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -290,8 +298,8 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     ref = w.reference_checks()
     if name in ("c2", "c5", "c5s"):
         if baseline:
-            tbl = owner["table"] if world > 1 else out_t
-            n_e = owner["entries"] if world > 1 else cp.entry_count
+            tbl = owner["table"] if multi else out_t
+            n_e = owner["entries"] if multi else cp.entry_count
             k, s = _baseline_groups(torch, cp, tbl, n_e)
             mine = torch.tensor([int(s.sum().item()), int(k.numel()), ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64,
                                  w.local_rows], dtype=torch.int64, device="cuda")
@@ -299,16 +307,16 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
             got_sum, groups, want_sum, all_rows = (int(x) for x in mine.cpu().tolist())
             checks["sum_of_sums"] = bool((got_sum - want_sum) % (1 << 64) == 0)
             checks["groups"] = groups
-            if world == 1:
+            if not multi:
                 checks["groups_equal_distinct_keys"] = bool(groups == w.distinct_keys())
             first = (k.clone(), s.clone())
             one_step()
             torch.cuda.synchronize()
-            tbl = owner["table"] if world > 1 else out_t
+            tbl = owner["table"] if multi else out_t
             k2, s2 = _baseline_groups(torch, cp, tbl, n_e)
             checks["idempotent"] = bool(torch.equal(first[0], k2) and torch.equal(first[1], s2))
         else:
-            final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+            final = (gathered[:quads] if multi else out_t).cpu().numpy()
             cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
             mine = torch.tensor([ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64, w.local_rows],
                                 dtype=torch.int64, device="cuda")
@@ -318,17 +326,17 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
             checks["groups"] = len(cols["key"])
             one_step()
             torch.cuda.synchronize()
-            again = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+            again = (gathered[:quads] if multi else out_t).cpu().numpy()
             checks["idempotent"] = bool(np.array_equal(again, final))
         checks["row_count"] = bool(all_rows == (rows if strong else rows * world))
     elif name == "c3":
-        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        final = (gathered[:quads] if multi else out_t).cpu().numpy()
         want = ref["sum_val_plus_dval"]
         mine = torch.tensor([want if want < 2**63 else want - 2**64], dtype=torch.int64, device="cuda")
         comm.all_reduce(mine)
         checks["sum_equals_torch_gather_sum"] = bool((int(final[0]) - int(mine.item())) % (1 << 64) == 0)
     elif name == "c3g":
-        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        final = (gathered[:quads] if multi else out_t).cpu().numpy()
         cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
         mine = torch.tensor([x if x < 2**63 else x - 2**64 for x in (v % (1 << 64) for v in ref["group_sums"])], dtype=torch.int64,
                             device="cuda")
@@ -338,7 +346,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         checks["per_group_sums_equal_torch_index_add"] = bool(
             sorted(cols["g"]) == list(range(64)) and all((s_ - want[g]) % (1 << 64) == 0 for g, s_ in zip(cols["g"], cols["s"])))
     elif name == "c3m":
-        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        final = (gathered[:quads] if multi else out_t).cpu().numpy()
         mine = torch.tensor([ref["sum_val"] if ref["sum_val"] < 2**63 else ref["sum_val"] - 2**64, w.local_rows], dtype=torch.int64,
                             device="cuda")
         comm.all_reduce(mine)
@@ -347,7 +355,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         checks["sum_count_max_equal_torch"] = bool((int(final[0]) - int(mine[0].item())) % (1 << 64) == 0 and
                                                    int(final[1]) == int(mine[1].item()) and int(final[2]) == int(mx.item()))
     else:
-        final = (gathered[:quads] if world > 1 else out_t).cpu().numpy()
+        final = (gathered[:quads] if multi else out_t).cpu().numpy()
         cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
         mine = torch.tensor(ref["key_counts"] + [w.local_rows], dtype=torch.int64, device="cuda")
         comm.all_reduce(mine)

@@ -71,3 +71,37 @@ def test_c5_two_ranks_forced_table_exchange():
     assert "owner partition of the partial table" in line["config"]["parallelism"], line["config"]
     assert line["merge"]["ms"] > 0 and line["merge"]["bytes_sent_over_xgmi_per_gpu"] > 0
     _all_checks_hold(line)
+
+
+def _run_rccl_single_rank(config, rows, extra_env=None):
+    """ONE rank, backend nccl (= RCCL), the N > 1 step forced (HDK_BENCH_SINGLE_RANK_COLLECTIVES): process-group init with
+    a device id, all-gather / all-reduce / all-to-all / barrier on RCCL next to the library's launches on the explicit
+    stream -- everything of the RCCL branch that one GPU can run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HDK_BENCH_SINGLE_RANK_COLLECTIVES="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("HDK_BENCH_BACKEND", None)
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", config,
+           "--rows", str(rows), "--extra", "none", "--no-cpu-baseline", "--no-multi-gpu-emulation"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_branch_with_one_rank_gather_and_fold():
+    line = _run_rccl_single_rank("c2", 64_000_000)
+    assert line["n_gpus"] == 1 and "all-gather" in line["config"]["parallelism"], line["config"]
+    _all_checks_hold(line)
+    assert line["checks"]["groups"] == 64
+
+
+def test_rccl_branch_with_one_rank_table_exchange():
+    """(The tuple exchange needs two owners -- hdk_hip_exchange_shape_for refuses one -- so a single rank asked for it takes
+    the agreed fallback: the owner partition of its partial table, RCCL all-to-all with unequal splits, owner re-insert.)"""
+    for pick in ("tuples", "tables"):
+        line = _run_rccl_single_rank("c5", 32_000_000, {"HDK_BENCH_EXCHANGE": pick})
+        assert "owner partition of the partial table" in line["config"]["parallelism"], line["config"]
+        assert line["merge"]["ms"] > 0
+        _all_checks_hold(line)
