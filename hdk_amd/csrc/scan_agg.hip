@@ -1349,11 +1349,14 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
 // ---- the general sliced join (scan_join_sliced2.h): join + perfect-hash GROUP BY on the joined column / + filters / any
 // list of integer aggregates over x and the payload, everything in 8-byte tuples ----------------------------------------
 // leaf of an aggregate argument: 0 = x (the one other 8-byte outer column), 1 = the payload, 2 = an integer literal
-static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int* xc) {
+static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int* xc, int* pidx = nullptr) {
   if (l.kind == HDK_LEAF_INT) return 2;
   if (l.kind != HDK_LEAF_COL) return -1;
   const hdk_hip_col& c = p->cols[l.col];
-  if (c.table == -1 && c.buf_idx == 1) return 1;
+  if (c.table == -1 && (c.buf_idx == 1 || c.buf_idx == 2)) {
+    if (pidx) *pidx = c.buf_idx - 1;
+    return 1;
+  }
   if (c.table != 0 || l.col == kc || c.width != 8 || c.kind != HDK_COL_INT) return -1;
   if (*xc >= 0 && *xc != l.col) return -1;  // one value column travels in the tuple
   *xc = l.col;
@@ -1367,7 +1370,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   if (plan_reads_small_dates(p)) return false;
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_CLUSTER_PROBES) != 0;
   const hdk_hip_join& jn = p->joins[0];
-  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || jn.fused_stride != 2 || !join_type_inner_like(jn.type) || jn.bucket > 1 ||
+  if (jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED || (jn.fused_stride != 2 && jn.fused_stride != 3) || !join_type_inner_like(jn.type) || jn.bucket > 1 ||
       jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.table_idx != 0 || jn.max_key < jn.min_key) {
     return false;
   }
@@ -1378,12 +1381,14 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   if (!forced && (range * 16 < (32ull << 20) || ko->total_rows < (32ull << 20))) return false;
   memset(ga, 0, sizeof(*ga));
   SliceArgs& sa = ga->s;
-  const hdk_hip_col* pay = nullptr;
+  const int npay = jn.fused_stride - 1;
+  const hdk_hip_col* pay[2] = {nullptr, nullptr};
   for (int i = 0; i < p->num_cols; ++i) {
     const hdk_hip_col& c = p->cols[i];
-    if (c.table == -1 && c.buf_idx == 1) pay = &c;
-    else if (c.table != 0) return false;  // an inner column read through the row id, or a second payload word
+    if (c.table == -1 && c.buf_idx >= 1 && c.buf_idx <= npay) pay[c.buf_idx - 1] = &c;
+    else if (c.table != 0) return false;  // an inner column read through the row id, or a third payload word
   }
+  ga->npay = npay;
   // ---- targets ----------------------------------------------------------------------------------------------------------
   WordLayout wl;
   make_word_layout(p, &wl);
@@ -1392,8 +1397,8 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   for (int w = 0; w < wl.wpe; ++w) ga->wop[w] = wl.wop[w];
   int xc = -1;
   int nt = 0;
-  int64_t x_null = 0, p_null = 0;
-  bool x_nullable = false, p_nullable = false;
+  int64_t x_null = 0, p_null[2] = {0, 0};
+  bool x_nullable = false, p_nullable[2] = {false, false};
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     if (tg.agg == HDK_AGG_ID) {
@@ -1416,11 +1421,13 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     if (wl.nword[t] >= 0) ga->nword_mask |= 1u << wl.nword[t];
     const hdk_hip_expr& e = tg.arg;
     if (e.vclass != HDK_VC_INT || e.nsteps > 1) return false;
-    const int ka = s2_leaf_kind(p, e.leaf0, kc, &xc);
+    int pi = 0;
+    const int ka = s2_leaf_kind(p, e.leaf0, kc, &xc, &pi);
     if (ka != 0 && ka != 1) return false;
     bool nullable = e.leaf0.nullable != 0;
     if (ka == 0 && e.leaf0.nullable) x_nullable = true, x_null = e.leaf0.null_val;
-    if (ka == 1 && e.leaf0.nullable) p_nullable = true, p_null = e.leaf0.null_val;
+    if (ka == 1 && e.leaf0.nullable) p_nullable[pi] = true, p_null[pi] = e.leaf0.null_val;
+    if (ka == 1) st.pidx = pi;
     st.null_if_x = ka == 0 && e.leaf0.nullable;
     st.null_if_p = ka == 1 && e.leaf0.nullable;
     if (e.nsteps == 0) {
@@ -1429,7 +1436,8 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
       const hdk_hip_step& sp = e.steps[0];
       if ((sp.op != HDK_OP_ADD && sp.op != HDK_OP_SUB && sp.op != HDK_OP_MUL) || sp.out_class != HDK_VC_INT) return false;
       if (sp.check_width != 0 && sp.check_width != 8) return false;  // (a 4-byte SQL type can overflow: the interpreter checks)
-      const int kb = s2_leaf_kind(p, sp.rhs, kc, &xc);
+      int pj = 0;
+      const int kb = s2_leaf_kind(p, sp.rhs, kc, &xc, &pj);
       if (kb < 0) return false;
       if (kb == 2) {
         if (sp.rhs.ival <= -(int64_t(1) << 31) || sp.rhs.ival >= (int64_t(1) << 31)) return false;
@@ -1440,7 +1448,8 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
         if (kb == ka) return false;  // x op x, payload op payload
         nullable = nullable || sp.rhs.nullable;
         if (kb == 0 && sp.rhs.nullable) x_nullable = true, x_null = sp.rhs.null_val, st.null_if_x = 1;
-        if (kb == 1 && sp.rhs.nullable) p_nullable = true, p_null = sp.rhs.null_val, st.null_if_p = 1;
+        if (kb == 1) st.pidx = pj;
+        if (kb == 1 && sp.rhs.nullable) p_nullable[pj] = true, p_null[pj] = sp.rhs.null_val, st.null_if_p = 1;
         if (sp.op == HDK_OP_ADD) st.src = S2_X_ADD_P;
         else if (sp.op == HDK_OP_MUL) st.src = S2_X_MUL_P;
         else st.src = ka == 0 ? S2_X_SUB_P : S2_P_SUB_X;
@@ -1459,9 +1468,11 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     for (int i = 0; i < p->num_quals; ++i) {
       const hdk_hip_qual& q = p->quals[i];
       if (q.lhs.nsteps == 0 && q.lhs.leaf0.kind == HDK_LEAF_COL && p->cols[q.lhs.leaf0.col].table == -1 &&
-          p->cols[q.lhs.leaf0.col].buf_idx == 1) {
+          p->cols[q.lhs.leaf0.col].buf_idx >= 1 && p->cols[q.lhs.leaf0.col].buf_idx <= npay) {
         if (q.rhs.kind != HDK_LEAF_INT || ga->npq == kS2MaxPayQuals) return false;
-        if (q.lhs.leaf0.nullable) p_nullable = true, p_null = q.lhs.leaf0.null_val;
+        const int qi = p->cols[q.lhs.leaf0.col].buf_idx - 1;
+        if (q.lhs.leaf0.nullable) p_nullable[qi] = true, p_null[qi] = q.lhs.leaf0.null_val;
+        ga->pq[ga->npq].pidx = qi;
         ga->pq[ga->npq].cmp = q.cmp;
         ga->pq[ga->npq].rhs = q.rhs.ival;
         ++ga->npq;
@@ -1482,9 +1493,10 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   if (p->query_kind == HDK_Q_PERFECT_HASH) {
     if (p->key_count != 1 || p->key_bucket[0] > 1) return false;
     const hdk_hip_expr& ke = p->keys[0];
-    int dummy = -1;
-    if (ke.nsteps > 1 || s2_leaf_kind(p, ke.leaf0, kc, &dummy) != 1) return false;
-    if (ke.leaf0.nullable) p_nullable = true, p_null = ke.leaf0.null_val;
+    int dummy = -1, ki = 0;
+    if (ke.nsteps > 1 || s2_leaf_kind(p, ke.leaf0, kc, &dummy, &ki) != 1) return false;
+    ga->key_pidx = ki;
+    if (ke.leaf0.nullable) p_nullable[ki] = true, p_null[ki] = ke.leaf0.null_val;
     if (ke.nsteps == 1) {
       const hdk_hip_step& sp = ke.steps[0];
       if (sp.op != HDK_OP_DIV || sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT || sp.rhs.ival < 1 || sp.rhs.ival > INT32_MAX) return false;
@@ -1498,15 +1510,19 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     ga->null_entry = static_cast<int64_t>(static_cast<uint64_t>(null_key) - static_cast<uint64_t>(p->key_min[0]));
   }
   // ---- the 8-byte tuple: payload and x inside 32 bits by the column statistics ------------------------------------------------------
-  if (pay && !(pay->has_stats && pay->min_val > static_cast<int64_t>(INT32_MIN) + 1 && pay->max_val <= static_cast<int64_t>(INT32_MAX))) return false;
+  for (int j = 0; j < npay; ++j) {
+    if (pay[j] && !(pay[j]->has_stats && pay[j]->min_val > static_cast<int64_t>(INT32_MIN) + 1 && pay[j]->max_val <= static_cast<int64_t>(INT32_MAX))) return false;
+  }
   sa.key_buf_idx = p->cols[kc].buf_idx;
   sa.x_buf_idx = xc >= 0 ? p->cols[xc].buf_idx : -1;
   sa.key_min = jn.min_key;
   sa.key_range = range;
   sa.key_nullable = jn.null_mode == HDK_JOIN_NULL_NULLABLE;
   sa.key_null = jn.null_val;
-  sa.pay_null = p_null;
-  sa.pay_nullable = p_nullable;
+  sa.pay_null = p_null[0];
+  sa.pay_nullable = p_nullable[0];
+  ga->pay_null1 = p_null[1];
+  ga->pay_nullable1 = p_nullable[1];
   sa.narrow = 1;
   if (xc >= 0) {
     const hdk_hip_col& xcol = p->cols[xc];
@@ -1527,10 +1543,11 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   const uint64_t rows = ko->total_rows;
   uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
   if (slice < 64) slice = 64;
-  const bool one_level = static_cast<uint64_t>(slice) * 4 + table_bytes1 <= kS2LdsBytes && !getenv("HDK_HIP_SLICE_TWO_LEVELS");
+  const uint64_t kb4 = 4ull * npay;  // LDS bytes per key of a slice
+  const bool one_level = static_cast<uint64_t>(slice) * kb4 + table_bytes1 <= kS2LdsBytes && !getenv("HDK_HIP_SLICE_TWO_LEVELS");
   auto pick_rep = [&](uint32_t keys) {
     uint32_t rep = 1;
-    while (rep < 32 && static_cast<uint64_t>(keys) * 4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
+    while (rep < 32 && static_cast<uint64_t>(keys) * kb4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
     return rep;
   };
   if (one_level) {
@@ -1544,7 +1561,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     if (sa.nbins > shape.grid) return false;  // one block (and one slab) per slice at least
   } else {
     // fine slices of <= 32 K keys (128 KB of LDS; less when the group table is big), `fpc` of them per coarse bin
-    uint64_t fs = (kS2LdsBytes - table_bytes1) / 4;
+    uint64_t fs = (kS2LdsBytes - table_bytes1) / kb4;
     if (fs > 32768) fs = 32768;
     fs &= ~static_cast<uint64_t>(63);
     if (fs < 1024) return false;
@@ -1579,8 +1596,10 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
                                    bool* launched) {
   *launched = false;
   SliceArgs& sa = ga.s;
-  const void* kagg = ga.grouped ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<true>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<false>);
-  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(ga.fslice) * 4;
+  const bool two_pay = ga.npay == 2;
+  const void* kagg = ga.grouped ? (two_pay ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<true, 2>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<true, 1>))
+                                : (two_pay ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<false, 2>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<false, 1>));
+  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(ga.fslice) * 4 * (two_pay ? 2 : 1);
   if (lds_agg > 48 * 1024 && hipFuncSetAttribute(kagg, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_agg)) != hipSuccess) {
     (void)hipGetLastError();
     return HDK_HIP_OK;
@@ -1647,9 +1666,17 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
     hipLaunchKernelGGL(hdk_join_scatter_level2, dim3(ncx * kSliceXcds * m2), dim3(kSliceBlock), lds_l2, s, ga);
   }
   if (ga.grouped) {
-    hipLaunchKernelGGL(hdk_join_agg_sliced2<true>, dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    if (two_pay) {
+      hipLaunchKernelGGL((hdk_join_agg_sliced2<true, 2>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    } else {
+      hipLaunchKernelGGL((hdk_join_agg_sliced2<true, 1>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    }
   } else {
-    hipLaunchKernelGGL(hdk_join_agg_sliced2<false>, dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    if (two_pay) {
+      hipLaunchKernelGGL((hdk_join_agg_sliced2<false, 2>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    } else {
+      hipLaunchKernelGGL((hdk_join_agg_sliced2<false, 1>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
+    }
   }
   // armed behind the passes: the batched interpreter over the plan's own columns, in row order -- clustered input, stale
   // statistics, an overflow area that filled up

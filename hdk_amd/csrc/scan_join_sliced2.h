@@ -56,12 +56,12 @@ struct S2Target {
   int32_t null_if_p;
   int32_t vword, nword;  // words of the entry, or -1
   int32_t wop;        // WOP_ADD_U64 / WOP_MIN_I64 / WOP_MAX_I64
-  int32_t pad_;
+  int32_t pidx;       // which payload word "P" is (0 or 1)
 };
 
 struct S2PayQual {
   int32_t cmp;        // hdk_hip_cmp
-  int32_t pad_;
+  int32_t pidx;       // payload word compared
   int64_t rhs;
 };
 
@@ -94,7 +94,12 @@ struct Slice2Args {
   int64_t* tuples2;          // [nslices][cap2]
   uint32_t* fill2;           // [nslices] x kSliceCursorStride
   uint32_t nsl_par;          // pass 2: slices worked on at a time (blocks = nsl_par x members)
-  uint32_t pad2_;
+  // payload words of the fused entry ([row id | p0 | p1]): one or two int32 arrays per slice in LDS
+  int32_t npay;              // 1 or 2 (0 reads as 1: a join without payload columns keeps one dummy array)
+  int32_t key_pidx;          // payload word the group key is computed from
+  int32_t pay_nullable1;     // NULL rule of payload word 1 (word 0: s.pay_nullable / s.pay_null)
+  int32_t pad3_;
+  int64_t pay_null1;
 };
 
 // signed 32-bit / positive invariant divisor, truncating like C (eval_expr's `a / b`)
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Arg
 #define HDK_S2_K_PLAIN 8
 #endif
 
-template <bool GROUPED>
+template <bool GROUPED, int NPAY>
 __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Args g) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   const SliceArgs& a = g.s;
@@ -309,6 +314,8 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   const uint32_t ew = g.entry_count * static_cast<uint32_t>(wpe);
   const uint32_t my_rep = tid & (rep - 1);
   int32_t* s_pay = reinterpret_cast<int32_t*>(lds + static_cast<size_t>(ew) * rep);
+  int32_t* s_pay1 = s_pay + g.fslice;  // (NPAY == 2)
+  const uint32_t fstride = 1u + static_cast<uint32_t>(NPAY);  // quads of a fused entry
   __shared__ uint32_t s_off;
   if (tid == 0) {  // (block-uniform, through LDS: another block of this kernel may raise the word meanwhile)
     s_off = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -349,16 +356,28 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   // straight vector code.  (One row at a time the scalar dispatch was the bottleneck: ~70 scalar instructions per tuple.)
   constexpr int K = GROUPED ? HDK_S2_K_GROUPED : HDK_S2_K_PLAIN;
   // ok[k]: slot k holds a tuple with a partner; x32 / p32 its outer value and payload (kSliceNull: the column's NULL)
-  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p32)[K], bool (&ok)[K]) {
-    bool pnull[K], xnull[K];
+  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p0)[K], const int32_t (&p1)[K], bool (&ok)[K]) {
+    bool pn0[K], pn1[K], xnull[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      pnull[k] = p32[k] == kSliceNull;
+      pn0[k] = p0[k] == kSliceNull;
+      pn1[k] = NPAY == 2 && p1[k] == kSliceNull;
       xnull[k] = x_null32 && x32[k] == INT32_MIN;
     }
+    // the payload word a filter / the key / a target reads (wave-uniform choice; NPAY == 1: word 0)
+    auto pick = [&](int pidx, int32_t (&pp)[K], bool (&pn)[K]) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        pp[k] = (NPAY == 2 && pidx) ? p1[k] : p0[k];
+        pn[k] = (NPAY == 2 && pidx) ? pn1[k] : pn0[k];
+      }
+    };
     // filters on the joined column: a NULL fails every comparison (DEF_CMP_NULLABLE)
     for (int q = 0; q < npq; ++q) {
       const int64_t rhs = g.pq[q].rhs;
+      int32_t p32[K];
+      bool pnull[K];
+      pick(g.pq[q].pidx, p32, pnull);
 #define HDK_S2_CMP(OP)                                                                \
   _Pragma("unroll") for (int k = 0; k < K; ++k) {                                     \
     ok[k] = ok[k] && !pnull[k] && (static_cast<int64_t>(p32[k]) OP rhs);              \
@@ -377,6 +396,9 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     if (GROUPED) {
       const uint32_t kd = static_cast<uint32_t>(g.key_div);
       const uint32_t stride = static_cast<uint32_t>(wpe) * rep;
+      int32_t p32[K];
+      bool pnull[K];
+      pick(g.key_pidx, p32, pnull);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int64_t entry = pnull[k] ? g.null_entry
@@ -404,6 +426,9 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
         const bool nx = tg.null_if_x != 0, np = tg.null_if_p != 0;
         const int64_t lit = tg.lit;
         int64_t v[K];
+        int32_t p32[K];
+        bool pnull[K];
+        pick(tg.pidx, p32, pnull);
 #define HDK_S2_VAL(EXPR)                                  \
   _Pragma("unroll") for (int k = 0; k < K; ++k) {         \
     const int64_t X = x32[k], P = p32[k];                 \
@@ -494,17 +519,18 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   };
   // K tuples of this slice: probe the payloads in LDS, then the batch
   auto tuples = [&](const int64_t (&w)[K], const bool (&live)[K]) {
-    int32_t x32[K], p32[K];
+    int32_t x32[K], p0[K], p1[K];
     bool ok[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t local = static_cast<uint32_t>(w[k]) - first;
       const bool in = live[k] && local < nkeys;
-      p32[k] = in ? s_pay[local] : kSliceNoMatch;
+      p0[k] = in ? s_pay[local] : kSliceNoMatch;
+      p1[k] = (NPAY == 2 && in) ? s_pay1[local] : 0;
       x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w[k]) >> 32);
-      ok[k] = p32[k] != kSliceNoMatch;  // (INNER join: no partner, no row)
+      ok[k] = p0[k] != kSliceNoMatch;  // (INNER join: no partner, no row)
     }
-    batch(x32, p32, ok);
+    batch(x32, p0, p1, ok);
   };
   // the block's slices (one level: exactly one; two levels: slice, slice + nsl_par, ...), each: payloads into LDS, then its
   // tuples -- 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
@@ -521,18 +547,31 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     __syncthreads();  // (the previous slice's probes are done)
     bool bad = false;
     for (uint32_t i = tid; i < nkeys; i += kSliceAggBlock) {
-      const bf_i64x2 e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
-          reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(first + i) * 16);
-      int32_t p32 = kSliceNoMatch;
-      if (e.x >= 0) {
-        if (a.pay_nullable && e.y == a.pay_null) {
+      const int64_t* e = table + static_cast<uint64_t>(first + i) * fstride;
+      const int64_t rid = __builtin_nontemporal_load(e);
+      int32_t p32 = kSliceNoMatch, q32 = 0;
+      if (rid >= 0) {
+        const int64_t y = __builtin_nontemporal_load(e + 1);
+        if (a.pay_nullable && y == a.pay_null) {
           p32 = kSliceNull;
         } else {
-          p32 = static_cast<int32_t>(e.y);
-          bad |= static_cast<int64_t>(p32) != e.y || p32 == kSliceNoMatch || p32 == kSliceNull;
+          p32 = static_cast<int32_t>(y);
+          bad |= static_cast<int64_t>(p32) != y || p32 == kSliceNoMatch || p32 == kSliceNull;
+        }
+        if (NPAY == 2) {
+          const int64_t z = __builtin_nontemporal_load(e + 2);
+          if (g.pay_nullable1 && z == g.pay_null1) {
+            q32 = kSliceNull;
+          } else {
+            q32 = static_cast<int32_t>(z);
+            bad |= static_cast<int64_t>(q32) != z || q32 == kSliceNull;
+          }
         }
       }
       s_pay[i] = p32;
+      if (NPAY == 2) {
+        s_pay1[i] = q32;
+      }
     }
     if (__any(bad) && (tid & (kWave - 1)) == 0) {
       atomicMax(a.mode, 1u);  // a payload outside what the statistics announced: redone in row order
@@ -590,32 +629,42 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     const uint64_t step = static_cast<uint64_t>(gridDim.x) * kSliceAggBlock;
 #pragma unroll 1
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSliceAggBlock + tid; i < n; i += K * step) {
-      int32_t x32[K], p32[K];
+      int32_t x32[K], p0[K], p1[K];
       bool ok[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const uint64_t ik = i + static_cast<uint64_t>(k) * step;
         const bool live = ik < n;
         const int64_t w = live ? in[ik] : 0;
-        bf_i64x2 e;
-        e.x = -1;
-        e.y = 0;
+        int64_t rid = -1, y = 0, z = 0;
         if (live) {
-          e = *reinterpret_cast<const __attribute__((address_space(1))) bf_i64x2*>(
-              reinterpret_cast<uintptr_t>(table) + static_cast<uint64_t>(static_cast<uint32_t>(w)) * 16);
+          const int64_t* e = table + static_cast<uint64_t>(static_cast<uint32_t>(w)) * fstride;
+          rid = e[0];
+          y = e[1];
+          if (NPAY == 2) {
+            z = e[2];
+          }
         }
-        ok[k] = e.x >= 0;
+        ok[k] = rid >= 0;
         x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w) >> 32);
-        p32[k] = static_cast<int32_t>(e.y);
+        p0[k] = static_cast<int32_t>(y);
+        p1[k] = static_cast<int32_t>(z);
         if (ok[k]) {
-          if (a.pay_nullable && e.y == a.pay_null) {
-            p32[k] = kSliceNull;
+          if (a.pay_nullable && y == a.pay_null) {
+            p0[k] = kSliceNull;
           } else {
-            bad2 |= static_cast<int64_t>(p32[k]) != e.y || p32[k] == kSliceNoMatch || p32[k] == kSliceNull;
+            bad2 |= static_cast<int64_t>(p0[k]) != y || p0[k] == kSliceNoMatch || p0[k] == kSliceNull;
+          }
+          if (NPAY == 2) {
+            if (g.pay_nullable1 && z == g.pay_null1) {
+              p1[k] = kSliceNull;
+            } else {
+              bad2 |= static_cast<int64_t>(p1[k]) != z || p1[k] == kSliceNull;
+            }
           }
         }
       }
-      batch(x32, p32, ok);
+      batch(x32, p0, p1, ok);
     }
     if (__any(bad2) && (tid & (kWave - 1)) == 0) {
       atomicMax(a.mode, 1u);

@@ -165,7 +165,10 @@ def _sliced_tables(nf, nd, seed, x_kind, key_kind="uniform", pay_nulls=False):
     dval = rng.integers(-10**6, 10**6, nd).astype(np.int64)
     if pay_nulls:
         dval[rng.random(nd) < 0.1] = A.NULL_BIGINT
-    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * 3 - 77, "dval": dval})  # every third key only
+    attr = rng.integers(0, 48, nd).astype(np.int32)  # a second inner column: queries that read both get [row id | p0 | p1] entries
+    if pay_nulls:
+        attr[rng.random(nd) < 0.05] = A.NULL_INT
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * 3 - 77, "dval": dval, "attr": attr})  # every third key only
     lo, hi = -77, 3 * nd - 77
     if key_kind == "uniform":
         fk = rng.integers(lo - 20, hi + 20, nf).astype(np.int64)
@@ -302,6 +305,40 @@ def test_sliced2_two_scatter_levels(oracle, gpu_executor_factory, key_kind, monk
     step.free()
 
 
+def _sliced2_two_payload_queries():
+    """filter on one inner column, group by / aggregate another: the fused entries carry two payload words"""
+    X, P, Q = ColRef("x"), ColRef("dval", "dim"), ColRef("attr", "dim")
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    return [
+        QueryUnit("fact", joins=j, quals=[Cmp(P, "<", Lit(250_000))], groupby=[Q], targets=[KeyRef(0, "g"), Agg("sum", X, "s"), Agg("count", None, "c")]),
+        QueryUnit("fact", joins=j, quals=[Cmp(Q, "=", Lit(7))], targets=[Agg("sum", X + P, "s"), Agg("count", None, "c")]),
+        QueryUnit("fact", joins=j, quals=[Cmp(Q, ">=", Lit(10)), Cmp(X, ">", Lit(-10**9))], groupby=[P / 50_000],
+                  targets=[KeyRef(0, "g"), Agg("max", Q, "mq"), Agg("min", X - Q, "lo"), Agg("avg", P, "ap")]),
+        QueryUnit("fact", joins=j, groupby=[Q / 4], targets=[KeyRef(0, "g"), Agg("sum", P * 2, "p2"), Agg("count", Q, "cq"), Agg("sum", X * Q, "xq")]),
+    ]
+
+
+@pytest.mark.parametrize("key_kind,two_levels", [("uniform", False), ("hot", False), ("uniform", True), ("sorted", True)])
+def test_sliced2_two_payload_words(oracle, gpu_executor_factory, key_kind, two_levels, monkeypatch):
+    """hdk_join_agg_sliced2<*, 2>: plans that read TWO columns of the inner table (filter on one, group by / aggregate the
+    other) stay on the sliced path: two int32 arrays per slice in LDS, entries of three words.  NULLs in both columns, keys
+    without a partner, a hot key (overflow area probed in memory), one and two scatter levels."""
+    if two_levels:
+        monkeypatch.setenv("HDK_HIP_SLICE_TWO_LEVELS", "1")
+        monkeypatch.setenv("HDK_HIP_SLICE_FINE_KEYS", "192")
+    st = _sliced_tables(500_000, 30_000, 53, "int32_nulls", key_kind, True)
+    for q in _sliced2_two_payload_queries():
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, q
+        step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        names = step.kernel_names()
+        assert "hdk_join_agg_sliced2" in names and (("hdk_join_scatter_level2" in names) == two_levels), (q, names)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+        assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+
+
 def test_sliced2_survives_stale_statistics_and_reports_errors(oracle, gpu_executor_factory):
     """an x outside the announced 32 bits -> the armed interpreter redoes the launch; a payload outside them that also
     leaves the group-key range, or a key range that no longer covers the data -> ERR_OUT_OF_SLOTS, as on the interpreter.
@@ -364,7 +401,10 @@ def test_sliced_join_random_shapes(oracle, gpu_executor_factory, seed):
     dval = rng.integers(-10**6, 10**6, nd).astype(np.int64)
     if rng.random() < 0.5:
         dval[rng.random(nd) < 0.1] = A.NULL_BIGINT
-    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * stride + off, "dval": dval})
+    attr = rng.integers(0, 40, nd).astype(np.int32)
+    if rng.random() < 0.5:
+        attr[rng.random(nd) < 0.05] = A.NULL_INT
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * stride + off, "dval": dval, "attr": attr})
     lo, hi = off, off + stride * (nd - 1) + 1
     kind = str(rng.choice(["uniform", "hot", "sorted", "blocks"]))
     if kind == "uniform":
@@ -391,10 +431,19 @@ def test_sliced_join_random_shapes(oracle, gpu_executor_factory, seed):
     X, D = ColRef("x"), ColRef("dval", "dim")
     pool = [Agg("sum", X + D, "s0"), Agg("sum", D + X, "s1"), Agg("count", None, "c"), Agg("sum", X, "sx"), Agg("min", X - D, "lo"),
             Agg("max", D, "hi"), Agg("count", D, "cd"), Agg("avg", D, "a"), Agg("count", X, "cx"), Agg("max", X, "mx")]
+    At = ColRef("attr", "dim")
+    pool2 = pool[2:] + [Agg("max", At, "ma"), Agg("sum", X * At, "xa"), Agg("count", At, "ca"), Agg("sum", At + 3, "a3")]
     ex = gpu_executor_factory(st)
-    for qi in range(3):
+    for qi in range(5):
         targets = [pool[0]] if (qi == 0 and rng.random() < 0.5) else [pool[int(i)] for i in rng.choice(len(pool), int(rng.integers(1, 4)), replace=False)]
         q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=targets)
+        if qi >= 3:  # the general sliced form: filters on either side, GROUP BY a joined column, one or two payload words
+            gb = [None, D / int(rng.choice([50_000, 125_000])), At, At / 3][int(rng.integers(0, 4))]
+            quals = [c for c in (Cmp(D, "<", Lit(int(rng.integers(-500_000, 900_000)))), Cmp(At, ">=", Lit(int(rng.integers(0, 30)))),
+                                 Cmp(X, ">", Lit(int(rng.integers(-2**31, 0))))) if rng.random() < 0.4]
+            targets = [pool2[int(i)] for i in rng.choice(len(pool2), int(rng.integers(1, 4)), replace=False)]
+            q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=quals, groupby=[gb] if gb is not None else [],
+                          targets=([KeyRef(0, "g")] if gb is not None else []) + targets)
         cp, want, err = run_oracle(oracle, st, q)
         what = (seed, qi, nf, nd, stride, kind, xk, [t.name for t in targets])
         assert err == 0, what
