@@ -408,7 +408,9 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
     const int64_t fstride = jn.fused_stride;
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
-      // dead slots probe with their (clamped, valid) row too: harmless, keeps the loads unconditional
+      // the loads stay unconditional, but a row the outer filters already rejected probes SLOT 0 (one cached line
+      // for all of them) instead of fetching its own 128-byte line from memory: with a 5 % filter in front of the join
+      // (bench_configs pj) the probes, not the scan, were the whole cost
       int64_t slot;
       int64_t idx;
       if (fused) {
@@ -424,7 +426,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
           maxk = jn.translated_null;
         }
         in_range = in_range && k >= jn.min_key && k <= maxk;
-        slot = in_range ? (jn.bucket > 1 ? (k - jn.min_key) / jn.bucket : (k - jn.min_key)) : 0;
+        slot = (in_range && pass[r]) ? (jn.bucket > 1 ? (k - jn.min_key) / jn.bucket : (k - jn.min_key)) : 0;
         // one line fetch per probe: the row id and the first payload word come in together (a later,
         // separate payload gather would find the line evicted again -- 16 waves x 512 probes in flight
         // per CU dwarf the L1)
@@ -447,7 +449,7 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
         }
         idx = in_range ? rid : -1;
       } else {
-        idx = probe_join_g(jn, table, key[r], &slot);
+        idx = probe_join_g(jn, table, pass[r] ? key[r] : jn.min_key, &slot);
       }
       if (inner) {
         pass[r] = pass[r] && idx >= 0;
