@@ -9,14 +9,42 @@ namespace hdk {
 
 // the shape hdk_scan_project_direct takes (scan_project_fast.h)
 static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
-  if (p->query_kind != HDK_Q_PROJECTION || p->num_joins || p->num_quals > kProjFastMaxQuals) return false;
+  if (p->query_kind != HDK_Q_PROJECTION || p->num_joins > 1 || p->num_quals > kProjFastMaxQuals) return false;
   memset(fa, 0, sizeof(*fa));
-  if (!match_plain_quals(p, fa->q)) return false;
+  if (!match_plain_quals(p, fa->q)) return false;  // (filters on outer columns only: a filter on a joined column is the interpreter's)
   fa->nquals = p->num_quals;
+  if (p->num_joins) {
+    // one inner-like join on a one-to-one perfect-hash table, probed with a plain integer column of the outer table
+    const hdk_hip_join& jn = p->joins[0];
+    int kc;
+    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type) || jn.table_idx != 0 ||
+        p->num_filter_ops || getenv("HDK_HIP_PROJECT_NO_FAST_JOIN")) {
+      return false;
+    }
+    if (!plain_outer_col(p, jn.outer_key, &kc) || (p->cols[kc].kind != HDK_COL_INT && p->cols[kc].kind != HDK_COL_UNSIGNED)) return false;
+    fa->join = 1;
+    fa->jn = jn;
+    fa->jkey.buf_idx = p->cols[kc].buf_idx;
+    fa->jkey.width = p->cols[kc].width;
+    fa->jkey.kind = p->cols[kc].kind;
+  }
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     int c;
-    if (tg.agg != HDK_AGG_ID || !plain_outer_col(p, tg.arg, &c)) return false;
+    if (tg.agg != HDK_AGG_ID) return false;
+    if (!plain_outer_col(p, tg.arg, &c)) {
+      // a column of the joined row: payload word of the fused entry, or the inner column at the row id
+      if (!fa->join || tg.arg.nsteps != 0 || tg.arg.leaf0.kind != HDK_LEAF_COL) return false;
+      c = tg.arg.leaf0.col;
+      const hdk_hip_col& jc = p->cols[c];
+      if (jc.table == -1 && fa->jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED && jc.buf_idx >= 1 && jc.buf_idx < fa->jn.fused_stride) {
+        fa->t[t].src = PF_SRC_PAYLOAD;
+      } else if (jc.table == 1 && fa->jn.kind == HDK_JOIN_ONE_TO_ONE && jc.kind != HDK_COL_SMALL_DATE) {
+        fa->t[t].src = PF_SRC_INNER;
+      } else {
+        return false;
+      }
+    }
     const hdk_hip_col& col = p->cols[c];
     if (col.kind == HDK_COL_FLOAT) return false;
     fa->t[t].col.buf_idx = col.buf_idx;
@@ -40,7 +68,7 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
   }
   for (int i = 0; i < fa->nquals; ++i) {
     for (int t = 0; t < fa->ntargets; ++t) {
-      if (fa->q[i].col.buf_idx == fa->t[t].col.buf_idx) fa->keep_cached = 1;
+      if (fa->t[t].src == PF_SRC_OUTER && fa->q[i].col.buf_idx == fa->t[t].col.buf_idx) fa->keep_cached = 1;
     }
   }
   // columnar target columns: [int64 row positions][target columns, each aligned to 8]
@@ -56,8 +84,8 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
 // The one-pass form (HDK_HIP_PROJECT_ONE_PASS=1: measured slower than the two passes at 1 % and at 50 % selectivity,
 // DESIGN.md 3.6, and kept behind the switch) needs a status word per batch of tiles, so the launch has to state its row
 // count.
-static bool project_one_pass(const hdk_hip_kernel_options* ko) {
-  return ko && ko->total_rows && getenv("HDK_HIP_PROJECT_ONE_PASS");
+static bool project_one_pass(const hdk_hip_kernel_options* ko, const ProjFastArgs* pf = nullptr) {
+  return ko && ko->total_rows && getenv("HDK_HIP_PROJECT_ONE_PASS") && !(pf && pf->join);
 }
 
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
@@ -81,7 +109,7 @@ void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko
   ProjFastArgs pf;
   if (!launch_forces_generic(ko) && match_project_fast(plan, &pf)) {
     snprintf(out, out_len, "%shdk_scan_project_count,hdk_scan_project_offsets,hdk_scan_project_dense,hdk_scan_project_direct",
-             project_one_pass(ko) ? "hdk_scan_project_stream," : "");
+             project_one_pass(ko, &pf) ? "hdk_scan_project_stream," : "");
   } else {
     snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
                                  : plan->num_joins     ? "hdk_scan_project_join"
@@ -103,7 +131,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     // ---- one pass (decoupled look-back over batches of tiles), the two passes armed behind it ----------------------
     AsyncScratch status_mem(s);
     bool streamed = false;
-    if (project_one_pass(ko)) {
+    if (project_one_pass(ko, &pf)) {
       // a status word per batch: the stated rows in full tiles, plus one ragged tile per fragment -- 64 K of them
       // (the kernel counts the real tiles and hands the launch to the two passes if they do not fit)
       uint64_t slack = 65536;
@@ -159,6 +187,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     }
     uint32_t force = 0;  // (HDK_HIP_PROJECT_WRITER=sparse|dense: A/B measurements)
     if (const char* e = getenv("HDK_HIP_PROJECT_WRITER")) force = e[0] == 'd' ? 2u : e[0] == 's' ? 1u : 0u;
+    if (pf.join) force = 1u;  // joined columns are gathered row by row: the sparse writing pass
     hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched, pf.run_if, kp,
                        pf.mode, force);
     // the two writing passes: the offsets kernel has picked one, the other returns at once

@@ -28,10 +28,17 @@ constexpr int kProjFastBlock = 512;
 constexpr int kProjFastVR = 8;
 constexpr int kProjFastMaxQuals = kMaxPlainQuals;
 
+enum ProjFastSrc : int32_t {
+  PF_SRC_OUTER = 0,    // a column of the outer table at the row
+  PF_SRC_PAYLOAD = 1,  // payload word `col.buf_idx` of the joined row's fused entry (HDK_JOIN_ONE_TO_ONE_FUSED)
+  PF_SRC_INNER = 2     // a column of the inner table at the joined row id (the reference's table layout)
+};
 struct ProjFastTarget {
   ProjFastCol col;
   int32_t slot_width;
   int32_t slot_off;  // row-wise: byte offset inside the row
+  int32_t src;       // ProjFastSrc
+  int32_t pad_;
 };
 struct ProjFastArgs {
   KernParams kp;
@@ -55,7 +62,42 @@ struct ProjFastArgs {
   const uint32_t* run_if;    // two-pass kernels: nullptr = always run; else only when *run_if == 1
   uint32_t* mode;            // written by hdk_scan_project_offsets: 1 = the sparse writing pass runs, 2 = the dense one
   int32_t keep_cached;       // a filter column is also a target: its lines are gathered again right after the filter
+  // ONE inner-like join on a one-to-one perfect-hash table (plain or fused): the counting pass probes the rows that
+  // passed the filters -- only those -- and a row without a partner loses its verdict bit; the (sparse) writing pass
+  // probes again for the joined columns it projects.  [bucketized_]hash_join_idx[_nullable|_bitwise]
+  // (QE/GroupByRuntime.cpp:274-366) through JoinLoop's Singleton form (QE/IRCodegen.cpp:497-667).
+  int32_t join;
+  ProjFastCol jkey;          // the outer key column
+  hdk_hip_join jn;
 };
+
+// the joined row of outer row `row`: its row id (-1: no partner) and the slot of its entry
+HDK_DEV int64_t pf_join_probe(const ProjFastArgs& a, const int8_t* const* cols, const int64_t* join_hash_tables, int64_t row,
+                              int64_t* slot_out) {
+  const int64_t key = decode_col_g(cols[a.jkey.buf_idx], a.jkey.width, a.jkey.kind, row, false);
+  int64_t k = key;
+  int64_t maxk = a.jn.max_key;
+  *slot_out = 0;
+  if (a.jn.null_mode != HDK_JOIN_NULL_NONE && key == a.jn.null_val) {
+    if (a.jn.null_mode == HDK_JOIN_NULL_NULLABLE) {
+      return -1;
+    }
+    k = a.jn.translated_null;
+    maxk = a.jn.translated_null;
+  }
+  if (k < a.jn.min_key || k > maxk) {
+    return -1;
+  }
+  int64_t off = k - a.jn.min_key;
+  if (a.jn.bucket > 1) {
+    off /= a.jn.bucket;
+  }
+  *slot_out = off;
+  if (a.jn.kind == HDK_JOIN_ONE_TO_ONE_FUSED) {
+    return gload<int64_t>(reinterpret_cast<const int8_t*>(join_hash_tables), off * a.jn.fused_stride, false);
+  }
+  return gload<int32_t>(reinterpret_cast<const int8_t*>(join_hash_tables), off, false);
+}
 
 // Row of batch slot r.  R = 1: lane-striped (slot r of lane t = tile row r*BLOCK + t).  R = 2: slots 2k
 // and 2k+1 are ADJACENT rows of an 8-byte column, one 16-byte load per lane.  Measured on this kernel the
@@ -66,6 +108,21 @@ template <int BLOCK, int R>
 HDK_DEV int64_t pf_row(int64_t tile_row0, int tid, int r) {
   return R == 1 ? tile_row0 + static_cast<int64_t>(r) * BLOCK + tid
                 : tile_row0 + (static_cast<int64_t>(r >> 1) * BLOCK + tid) * 2 + (r & 1);
+}
+
+// verdict bits after the join: a passing row without a partner fails (INNER / SEMI)
+template <int R>
+HDK_DEV uint32_t pf_join_filter(const ProjFastArgs& a, const int8_t* const* cols, int64_t row0, int tid, uint32_t bits) {
+  uint32_t left = bits;
+  while (left) {
+    const int b = __ffs(left) - 1;
+    left &= left - 1;
+    int64_t slot;
+    if (pf_join_probe(a, cols, a.kp.join_hash_tables, pf_row<kProjFastBlock, R>(row0, tid, b), &slot) < 0) {
+      bits &= ~(1u << b);
+    }
+  }
+  return bits;
 }
 
 typedef long long __attribute__((ext_vector_type(2))) pf_i64x2;
@@ -564,7 +621,10 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
       const bool masked = a.sel_mask != nullptr && static_cast<uint64_t>(tile) < a.sel_tiles;  // block-uniform
       uint8_t* mask_at = a.sel_mask + static_cast<size_t>(tile) * kProjFastBlock + tid;
       if (MODE == 0 && R == 2 && row0 + kTileRows <= nrows) {  // the counting pass over a full tile: straight line
-        const uint32_t m = pf_filter_full_tile_pairs(a, cols, row0, tid);
+        uint32_t m = pf_filter_full_tile_pairs(a, cols, row0, tid);
+        if (a.join) {
+          m = pf_join_filter<R>(a, cols, row0, tid, m);
+        }
         if (masked) {
           *mask_at = static_cast<uint8_t>(m);
         }
@@ -587,6 +647,9 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
         bits = __builtin_nontemporal_load(mask_at);
       } else {
         bits = pf_filter_tile<R>(a, cols, row0, nrows, tid, MODE == 1);  // pass 1 leaves the lines cached
+        if (a.join) {
+          bits = pf_join_filter<R>(a, cols, row0, tid, bits);
+        }
         if (MODE == 0 && masked) {
           *mask_at = static_cast<uint8_t>(bits);
         }
@@ -663,7 +726,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
         }
         for (int ti = 0; ti < a.ntargets; ++ti) {
           const ProjFastTarget t = a.t[ti];
-          const int8_t* tb = cols[t.col.buf_idx];
+          const int8_t* tb = t.src == PF_SRC_PAYLOAD ? nullptr : cols[t.col.buf_idx];
           int8_t* base = columnar ? reinterpret_cast<int8_t*>(buf) + a.col_off[ti] : reinterpret_cast<int8_t*>(buf) + t.slot_off;
           const size_t stride = columnar ? static_cast<size_t>(t.slot_width) : rq * 8;
           for (uint32_t j0 = 0; j0 < wave_total; j0 += kWave) {
@@ -671,7 +734,16 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
             const uint32_t pos = wave_base + j;
             if (j < wave_total && pos < max_matched) {
               const int64_t row = row_of(strip[j]);
-              const int64_t v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
+              int64_t v;
+              if (t.src == PF_SRC_OUTER) {
+                v = decode_col_g(tb, t.col.width, t.col.kind, row, true);
+              } else {  // a column of the joined row (every row of the strip has a partner: the counting pass saw to it)
+                int64_t slot;
+                const int64_t rid = pf_join_probe(a, cols, a.kp.join_hash_tables, row, &slot);
+                v = t.src == PF_SRC_PAYLOAD
+                        ? gload<int64_t>(reinterpret_cast<const int8_t*>(a.kp.join_hash_tables), slot * a.jn.fused_stride + t.col.buf_idx, false)
+                        : decode_col_g(tb, t.col.width, t.col.kind, rid < 0 ? 0 : rid, false);
+              }
               int8_t* dst = base + static_cast<size_t>(pos) * stride;
               switch (t.slot_width) {
                 case 1: *reinterpret_cast<int8_t*>(dst) = static_cast<int8_t>(v); break;
