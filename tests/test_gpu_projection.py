@@ -151,3 +151,63 @@ def test_two_pass_forms_one_pass_and_their_fallbacks(oracle, gpu_executor_factor
                     del os.environ[k]
             assert res.total_matched == nrows, (bound, total_rows, env)
             assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), want_rows), (bound, total_rows, env)
+
+
+@pytest.mark.parametrize("columnar,fused", [(False, True), (True, True), (True, False)])
+def test_direct_filter_project_through_a_join(oracle, gpu_executor_factory, columnar, fused, monkeypatch):
+    """The two-pass kernels take ONE inner one-to-one join too (scan_project_fast.h: pf_join_probe): the counting pass
+    probes the rows that passed the filters, a row without a partner loses its verdict bit, the sparse writing pass
+    gathers the joined columns -- from the fused entries or, with the reference's table, through the row id.  NULL keys,
+    keys without a partner, 2-byte unsigned-looking keys, 1 % / 60 % / 100 % selectivity, ragged fragments, a LIMIT; the
+    batched interpreter (HDK_HIP_PROJECT_NO_FAST_JOIN) gives the same set of rows; LEFT joins and filters on a joined column stay
+    with the interpreters."""
+    rng = np.random.default_rng(31)
+    nd, nf = 40_000, 600_011
+    st = ArrowStorage()
+    w = rng.integers(-50, 50, nd).astype(np.int32)
+    w[rng.random(nd) < 0.05] = A.NULL_INT
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64) * 2 + 5, "w": w, "z": rng.integers(-2**40, 2**40, nd)})
+    fk = rng.integers(0, 2 * nd + 20, nf).astype(np.int64)
+    fk[rng.random(nf) < 0.03] = A.NULL_BIGINT
+    st.import_numpy("fact", {"fk": fk, "v": rng.integers(0, 1000, nf).astype(np.int64), "s": rng.integers(0, 100, nf).astype(np.int16)},
+                    fragment_size=170_001)
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    for sel in (990, 400, 0):
+        q = QueryUnit("fact", joins=j, quals=[Cmp(ColRef("v"), ">=", Lit(sel)), Cmp(ColRef("s"), "<", Lit(95))], output_columnar=columnar,
+                      targets=[Proj(ColRef("v"), "v"), Proj(ColRef("w", "dim"), "w"), Proj(ColRef("s"), "s"), Proj(ColRef("z", "dim"), "z")])
+        cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+        assert err == 0 and nrows > 0
+        ex = gpu_executor_factory(st)
+        ex.fuse_join_tables = fused
+        step = ex.prepare(cp)
+        assert step.kernel_names().startswith("hdk_scan_project_count,hdk_scan_project_offsets"), step.kernel_names()
+        res = step.run()
+        step.free()
+        assert res.total_matched == nrows
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
+        monkeypatch.setenv("HDK_HIP_PROJECT_NO_FAST_JOIN", "1")
+        ex2 = gpu_executor_factory(st)
+        ex2.fuse_join_tables = fused
+        step = ex2.prepare(cp)
+        assert step.kernel_names() == "hdk_scan_project_join"
+        res2 = step.run()
+        step.free()
+        monkeypatch.delenv("HDK_HIP_PROJECT_NO_FAST_JOIN")
+        assert np.array_equal(_sorted_rows(cp, res2.buffer, nrows), _sorted_rows(cp, want, nrows))
+    # LIMIT
+    q = QueryUnit("fact", joins=j, quals=[Cmp(ColRef("v"), ">=", Lit(100))], output_columnar=columnar, scan_limit=777,
+                  targets=[Proj(ColRef("v"), "v"), Proj(ColRef("w", "dim"), "w")])
+    cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+    res = gpu_executor_factory(st).execute(cp)
+    assert err < 0 and res.error_code < 0 and res.total_matched == nrows and res.row_count() == 777
+    # not this kernel's: LEFT join, a filter on the joined column
+    for q in (QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key", type="left")], quals=[Cmp(ColRef("v"), ">=", Lit(900))],
+                        targets=[Proj(ColRef("v"), "v"), Proj(ColRef("w", "dim"), "w")]),
+              QueryUnit("fact", joins=j, quals=[Cmp(ColRef("w", "dim"), ">", Lit(0))], targets=[Proj(ColRef("v"), "v")])):
+        cp, want, err, nrows = run_projection_oracle(oracle, st, q)
+        step = gpu_executor_factory(st).prepare(cp)
+        assert "hdk_scan_project_count" not in step.kernel_names(), step.kernel_names()
+        res = step.run()
+        step.free()
+        assert res.total_matched == nrows
+        assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
