@@ -64,9 +64,18 @@ inline bool needs_join_loops(const hdk_hip_plan* p) {
   }
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
-    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type)) {
+    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED && jn.kind != HDK_JOIN_KEYED_ONE_TO_ONE) ||
+        !join_type_inner_like(jn.type)) {
       return true;
     }
+  }
+  return false;
+}
+
+// some join of a plan the batched interpreters take probes a keyed one-to-one table: their *_keyed kernels
+inline bool plan_has_keyed_join(const hdk_hip_plan* p) {
+  for (int j = 0; j < p->num_joins; ++j) {
+    if (p->joins[j].kind == HDK_JOIN_KEYED_ONE_TO_ONE) return true;
   }
   return false;
 }

@@ -52,7 +52,7 @@ HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
   }
 }
 
-template <bool J>
+template <bool J, bool KEYED = false>
 HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
@@ -81,7 +81,7 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
   const int nt = p->num_targets;
 
-  VecCtxT<J> c;
+  VecCtxT<J, KEYED> c;
   vec_ctx_init(c, p, tid, kVecBlock);
   int32_t err = 0;
 
@@ -180,6 +180,11 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs
 }
 extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_join(VecArgs a) {
   scan_agg_vec_body<true>(a);
+}
+// ... and plans in which some inner-like join probes a KEYED one-to-one table (composite or wide keys): the probe is a
+// hash and a short linear walk per row; a kernel of its own so that its registers are not the perfect-hash plans' problem
+extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_keyed(VecArgs a) {
+  scan_agg_vec_body<true, true>(a);
 }
 
 }  // namespace hdk

@@ -35,7 +35,7 @@ HDK_DEV void store_slot(int8_t* p, int width, int64_t v) {
   }
 }
 
-template <bool J, int BLOCK>
+template <bool J, int BLOCK, bool KEYED = false>
 HDK_DEV void scan_project_body(const ProjArgs& a) {
   __shared__ uint64_t s_col_off[HDK_HIP_MAX_TARGETS];
   __shared__ uint32_t s_wave_tot[2][BLOCK / kWave];
@@ -57,7 +57,7 @@ HDK_DEV void scan_project_body(const ProjArgs& a) {
   constexpr int64_t kTileRows = static_cast<int64_t>(BLOCK) * VR;
   int64_t* buf = a.kp.groupby_buf[0];
 
-  VecCtxT<J> c;
+  VecCtxT<J, KEYED> c;
   vec_ctx_init(c, p, tid, BLOCK);
   int32_t err = 0;
   int32_t slots_err = 0;
@@ -194,6 +194,9 @@ extern "C" __global__ __launch_bounds__(kProjBlockPlain) void hdk_scan_project(P
 }
 extern "C" __global__ __launch_bounds__(kProjBlockJoin) void hdk_scan_project_join(ProjArgs a) {
   scan_project_body<true, kProjBlockJoin>(a);
+}
+extern "C" __global__ __launch_bounds__(kProjBlockJoin) void hdk_scan_project_keyed(ProjArgs a) {  // (vec_eval.h: keyed_probe_one)
+  scan_project_body<true, kProjBlockJoin, true>(a);
 }
 
 // General form: any join the library accepts (one-to-many and keyed tables, LEFT joins), one row at

@@ -98,7 +98,8 @@ uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, c
     block = kProjFastBlock;
   } else {
     k = scalar ? reinterpret_cast<const void*>(hdk_scan_project_scalar)
-               : (p->num_joins ? reinterpret_cast<const void*>(hdk_scan_project_join)
+               : (p->num_joins ? (plan_has_keyed_join(p) ? reinterpret_cast<const void*>(hdk_scan_project_keyed)
+                                                         : reinterpret_cast<const void*>(hdk_scan_project_join))
                                : reinterpret_cast<const void*>(hdk_scan_project));
     block = scalar ? kProjBlock : (p->num_joins ? kProjBlockJoin : kProjBlockPlain);
   }
@@ -112,7 +113,7 @@ void project_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko
              project_one_pass(ko, &pf) ? "hdk_scan_project_stream," : "");
   } else {
     snprintf(out, out_len, "%s", needs_join_loops(plan) ? "hdk_scan_project_scalar"
-                                 : plan->num_joins     ? "hdk_scan_project_join"
+                                 : plan->num_joins     ? (plan_has_keyed_join(plan) ? "hdk_scan_project_keyed" : "hdk_scan_project_join")
                                                        : "hdk_scan_project");
   }
 }
@@ -201,6 +202,8 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
     HDK_HIP_CHECK(hipGetLastError());
   } else if (needs_join_loops(plan) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR))) {
     hipLaunchKernelGGL(hdk_scan_project_scalar, dim3(shape.grid), dim3(kProjBlock), 0, s, pa);
+  } else if (plan->num_joins && plan_has_keyed_join(plan)) {
+    hipLaunchKernelGGL(hdk_scan_project_keyed, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);
   } else if (plan->num_joins) {
     hipLaunchKernelGGL(hdk_scan_project_join, dim3(shape.grid), dim3(kProjBlockJoin), 0, s, pa);
   } else {

@@ -57,21 +57,31 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "c3f", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "c3f", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
         key, val, valn = key[:n_t], val[:n_t], valn[:n_t]
-    st.import_numpy("t", {"key": key, "val": val, "valn": valn, "fk": rng.integers(0, nd, len(key), dtype=np.int64),
-                          "hk": rng.integers(0, max(n // 10, 1000), len(key), dtype=np.int64)}, fragment_size=frag)
+    fk = rng.integers(0, nd, len(key), dtype=np.int64)
+    tcols = {"key": key, "val": val, "valn": valn, "fk": fk, "hk": rng.integers(0, max(n // 10, 1000), len(key), dtype=np.int64)}
+    if only & {"c3d", "c3k"}:  # plain key columns for the parity-path joins (no arithmetic in front of the probe)
+        tcols.update({"fk10": fk // 10, "k1": key * 15, "k2": fk // 10000})
+    st.import_numpy("t", tcols, fragment_size=frag)
     st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64),
                             "attr": rng.integers(0, 64, nd).astype(np.int64)}, fragment_size=frag)
+    if only & {"c3d", "c3k"}:
+        # parity-path joins: a dimension with two rows per key (one-to-many table) and one with a two-column key (keyed table)
+        nd2 = max(nd // 10, 1000)
+        st.import_numpy("dim2", {"key": np.concatenate([rng.permutation(nd2), rng.permutation(nd2)]).astype(np.int64),
+                                 "dval": rng.integers(0, 10**6, 2 * nd2).astype(np.int64)}, fragment_size=frag)
+        st.import_numpy("dimk", {"k1": (np.arange(nd2) % 1000).astype(np.int64), "k2": (np.arange(nd2) // 1000).astype(np.int64),
+                                 "dval": rng.integers(0, 10**6, nd2).astype(np.int64)}, fragment_size=frag)
     # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types)
     nt = n if need_trips else 1000
     st.import_numpy("trips", {"cab_type": rng.integers(0, 2, nt).astype(np.int32),
@@ -98,6 +108,10 @@ def main():
                          targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim"))]), 16),
         "c3g": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") / 15625],
                           targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
+        "c3d": (QueryUnit("t", joins=[JoinSpec("dim2", ColRef("fk10"), "key")],
+                          targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim2")), Agg("count")]), 16),
+        "c3k": (QueryUnit("t", joins=[JoinSpec("dimk", [ColRef("k1"), ColRef("k2")], ["k1", "k2"])],
+                          targets=[Agg("sum", ColRef("val") + ColRef("dval", "dimk")), Agg("count")]), 24),
         # star schema: filter on one dimension column, group by another (two payload words in the sliced join)
         "c3f": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
                           groupby=[ColRef("attr", "dim")], targets=[KeyRef(0), Agg("sum", ColRef("val")), Agg("count")]), 16),
