@@ -64,8 +64,9 @@ inline bool needs_join_loops(const hdk_hip_plan* p) {
   }
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
-    if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED && jn.kind != HDK_JOIN_KEYED_ONE_TO_ONE) ||
-        !join_type_inner_like(jn.type)) {
+    // at most one partner per row: INNER / SEMI drop the row without one, LEFT keeps it with NULL inner columns, ANTI keeps
+    // only those -- no loop (the batched interpreters, vec_eval.h: rows_pass_v); matching sets need the loop nest
+    if (jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED && jn.kind != HDK_JOIN_KEYED_ONE_TO_ONE) {
       return true;
     }
   }

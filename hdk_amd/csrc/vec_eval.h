@@ -57,6 +57,7 @@ struct VecCtxT {
   int32_t jref1[VR];
   int64_t jpay0[VR];          // payload word 1 of a fused entry: arrives with the row id in one 16-B gather
   int64_t jpay1[VR];
+  uint32_t jmiss0, jmiss1;    // bit r: slot r found no partner at join 0 / 1 of a LEFT (or ANTI) join: its inner columns read as NULL
   const int64_t* fused0;      // fused tables (HDK_JOIN_ONE_TO_ONE_FUSED) or nullptr
   const int64_t* fused1;
   int32_t fstride0;
@@ -84,6 +85,8 @@ HDK_DEV void vec_ctx_init(VecCtx& c, cplan_t p, int tid, int blk) {
     c.jpay0[r] = 0;
     c.jpay1[r] = 0;
   }
+  c.jmiss0 = 0;
+  c.jmiss1 = 0;
   c.fused0 = nullptr;
   c.fused1 = nullptr;
   c.fstride0 = 0;
@@ -152,7 +155,7 @@ HDK_DEV void load_rows_decoded(const VecCtx& c, const int8_t* __restrict__ buf, 
 }
 
 template <class VecCtx>
-HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
+HDK_DEV void load_leaf_raw_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
   if (l.kind == HDK_LEAF_COL) {
     const int32_t ci = l.col;
     const int width = c.plan->cols[ci].width;
@@ -192,6 +195,24 @@ HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       out[r] = v;
+    }
+  }
+}
+
+// A column of an inner table whose row found no partner (LEFT join): NULL, as load_leaf reads join_row == -1
+// (codegenOuterJoinNullPlaceholder, QE/ColumnIR.cpp).
+template <class VecCtx>
+HDK_DEV void load_leaf_v(const VecCtx& c, cleaf_t l, int64_t (&out)[VR]) {
+  load_leaf_raw_v(c, l, out);
+  if (VecCtx::kJoins && l.kind == HDK_LEAF_COL) {
+    const int table = c.plan->cols[l.col].table;
+    const uint32_t miss = (table == 1 || table == -1) ? c.jmiss0 : ((table == 2 || table == -2) ? c.jmiss1 : 0u);
+    if (__any(miss != 0)) {
+      const int64_t nullv = l.null_val;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        out[r] = (miss >> r) & 1u ? nullv : out[r];
+      }
     }
   }
 }
@@ -463,8 +484,14 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
     }
   }
   const int nj = VecCtx::kJoins ? p->num_joins : 0;
+  if (VecCtx::kJoins) {
+    c.jmiss0 = 0;
+    c.jmiss1 = 0;
+  }
   for (int j = 0; j < nj; ++j) {
     cjoin_t jn = p->joins[j];
+    const bool anti = jn.type == HDK_JOIN_ANTI;  // the row goes on when the probe finds NO partner (JoinLoop.cpp:258-262)
+    uint32_t miss = 0;
     int64_t key[VR];
     eval_expr_v(c, jn.outer_key, key, pass, err);
     const int32_t* __restrict__ table = (nj == 1 && jn.table_idx == 0)
@@ -495,13 +522,23 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
         }
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-          pass[r] = pass[r] && idx[r] >= 0;  // (inner-like: needs_join_loops sends LEFT joins to the row-at-a-time kernels)
+          if (inner) {
+            pass[r] = pass[r] && idx[r] >= 0;
+          } else {
+            pass[r] = pass[r] && !(anti && idx[r] >= 0);
+            miss |= idx[r] < 0 ? 1u << r : 0u;
+          }
           const int32_t ref = idx[r] < 0 ? 0 : static_cast<int32_t>(idx[r]);
           if (j == 0) {
             c.jref0[r] = ref;
           } else {
             c.jref1[r] = ref;
           }
+        }
+        if (j == 0) {
+          c.jmiss0 = miss;
+        } else {
+          c.jmiss1 = miss;
         }
         continue;
       }
@@ -564,6 +601,9 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
       }
       if (inner) {
         pass[r] = pass[r] && idx >= 0;
+      } else {  // LEFT: the row stays, its inner columns are NULL; ANTI: only such rows stay
+        pass[r] = pass[r] && !(anti && idx >= 0);
+        miss |= idx < 0 ? 1u << r : 0u;
       }
       const int32_t ref = fused ? static_cast<int32_t>(slot) : (idx < 0 ? 0 : static_cast<int32_t>(idx));
       if (j == 0) {
@@ -571,6 +611,11 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
       } else {
         c.jref1[r] = ref;
       }
+    }
+    if (j == 0) {
+      c.jmiss0 = miss;
+    } else {
+      c.jmiss1 = miss;
     }
   }
   if (VecCtx::kJoins) {  // filters that read joined columns

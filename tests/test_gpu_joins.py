@@ -28,8 +28,11 @@ def test_aggregates_over_general_joins(oracle, gpu_executor_factory, case):
         cp, want, err = run_oracle(oracle, st, q)
         assert err == 0, name
         step = ex.prepare(cp)
-        # (matching sets and LEFT joins: the row-at-a-time interpreter; an inner join on a keyed one-to-one table: the batched one)
-        assert step.kernel_names().startswith(("hdk_scan_agg_generic", "hdk_scan_agg_vec_keyed")), (name, step.kernel_names())
+        # (matching sets: the row-at-a-time interpreter; at most one partner per row -- one-to-one tables, perfect or keyed,
+        # INNER / LEFT / SEMI / ANTI: the batched ones)
+        names = step.kernel_names()
+        one_to_one = all(i["kind"] in (A.JOIN_ONE_TO_ONE, A.JOIN_KEYED_ONE_TO_ONE) for i in cp.join_infos)
+        assert names.startswith(("hdk_scan_agg_vec_join", "hdk_scan_agg_vec_keyed") if one_to_one else "hdk_scan_agg_generic"), (name, names)
         res = step.run()
         assert_buffers_equal(cp, res.buffer, want)
         step.free()
@@ -44,7 +47,8 @@ def test_projections_over_general_joins(oracle, gpu_executor_factory, case):
         cp, want, err, nrows = run_projection_oracle(oracle, st, q)
         assert err == 0 and nrows > 0, name
         step = ex.prepare(cp)
-        assert step.kernel_names() == "hdk_scan_project_scalar", name
+        one_to_one = all(i["kind"] in (A.JOIN_ONE_TO_ONE, A.JOIN_KEYED_ONE_TO_ONE) for i in cp.join_infos)
+        assert (step.kernel_names() == "hdk_scan_project_scalar") == (not one_to_one), (name, step.kernel_names())
         res = step.run()
         assert res.total_matched == nrows, name
         assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows)), name
