@@ -91,6 +91,22 @@ inline void fill_hash_join_buff_on_device_bucketized(int32_t* buff, const int32_
                                                device_id, nullptr));
 }
 
+// The table AND its fused form ([row id | payload words], HDK_JOIN_ONE_TO_ONE_FUSED) in one sweep over the inner rows: what
+// PerfectJoinHashTableBuilder::initOneToOneHashTableOnGpu (Builders/PerfectHashTableBuilder.h:82-141) calls in place of
+// fill_hash_join_buff_on_device_bucketized when the plan's kernels read the fused table.  `scratch` comes from the
+// BufferProvider (hdk_hip_join_build_scratch_bytes(rows, slots, ncols) bytes; 0 = none needed) or is NULL (stream pool).
+template <class RefJoinColumn, class RefTypeInfo>
+inline void fill_hash_join_buff_fused_on_device(int32_t* buff, const int32_t invalid_slot_val, const bool for_semi_join,
+                                                int* dev_err_buff, const RefJoinColumn& join_column,
+                                                const RefTypeInfo& type_info, const int64_t bucket_normalization,
+                                                const int8_t* const* inner_cols, const int32_t* widths, const int32_t* kinds,
+                                                const int32_t ncols, int64_t* fused_out, int8_t* scratch,
+                                                const size_t scratch_bytes, const int device_id) {
+  check(hdk_hip_fill_hash_join_buff_fused(buff, invalid_slot_val, for_semi_join, dev_err_buff, to_abi_column(join_column),
+                                          to_abi(type_info), bucket_normalization, inner_cols, widths, kinds, ncols, fused_out,
+                                          scratch, scratch_bytes, device_id, nullptr));
+}
+
 template <class RefHashEntryInfo, class RefJoinColumn, class RefTypeInfo>
 inline void fill_one_to_many_hash_table_on_device(int32_t* buff, const RefHashEntryInfo& hash_entry_info,
                                                   const int32_t invalid_slot_val, const RefJoinColumn& join_column,

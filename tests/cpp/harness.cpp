@@ -253,6 +253,26 @@ int run_join(hip_mgr::HipMgr& mgr) {
   mgr.synchronizeStream(kDevice);
   const int32_t build_err = dev.download<int32_t>(d_build_err, 1)[0];
   std::printf("join build_error %d\n", build_err);
+  {
+    // the same table together with its fused form [row id | dval] in one sweep over the inner rows
+    // (HipRuntimeOnDevice.h: fill_hash_join_buff_fused_on_device)
+    int32_t* table2 = reinterpret_cast<int32_t*>(dev.alloc(kDimRows * sizeof(int32_t)));
+    int64_t* fused = reinterpret_cast<int64_t*>(dev.alloc(kDimRows * 2 * sizeof(int64_t)));
+    hip_rt::init_hash_join_buff_on_device(table2, kDimRows, -1, kDevice);
+    const int8_t* inner_cols[1] = {d_dval};
+    const int32_t widths[1] = {8}, kinds[1] = {HDK_COL_INT};
+    hip_rt::fill_hash_join_buff_fused_on_device(table2, -1, false, reinterpret_cast<int*>(d_build_err), join_column, type_info, 1,
+                                                inner_cols, widths, kinds, 1, fused, nullptr, 0, kDevice);
+    mgr.synchronizeStream(kDevice);
+    const auto t1 = dev.download<int32_t>(reinterpret_cast<int8_t*>(hash_table), kDimRows);
+    const auto t2 = dev.download<int32_t>(reinterpret_cast<int8_t*>(table2), kDimRows);
+    const auto fz = dev.download<int64_t>(reinterpret_cast<int8_t*>(fused), kDimRows * 2);
+    bool ok = dev.download<int32_t>(d_build_err, 1)[0] == 0;
+    for (size_t i = 0; i < kDimRows; ++i) {
+      ok = ok && t1[i] == t2[i] && fz[2 * i] == t1[i] && fz[2 * i + 1] == (t1[i] >= 0 ? dval[static_cast<size_t>(t1[i])] : 0);
+    }
+    std::printf("join fused_build %d\n", ok ? 1 : 0);
+  }
 
   std::vector<std::vector<int8_t*>> col_buffers;
   std::vector<int64_t> num_rows;

@@ -45,6 +45,7 @@ def expected_lines():
         add = fval[match] + dval_by_key[fk[match]]
         add = add[fval[match] != NULL]
         out.append("join build_error 0")
+        out.append("join fused_build 1")
         out.append("join error_code 0")
         out.append(f"join sum {int(add.sum())} count {int(match.sum())}")
         out.append("interrupt error_code 10")
