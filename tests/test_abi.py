@@ -82,3 +82,20 @@ def test_plan_validation_errors_without_a_gpu():
     rc, msg = broken(lambda p: setattr(p, "query_kind", A.Q_PERFECT_HASH))  # not a baseline plan any more
     assert rc == A.ERR_INVALID_ARG
     assert L.hdk_hip_baseline_table_quads(None, 10, C.byref(q)) == A.ERR_INVALID_ARG
+
+
+def test_join_build_scratch_geometry_is_host_only():
+    """hdk_hip_join_build_scratch_bytes (the partitioned one-to-one build, join_build_part.h) is plain host arithmetic: 0 for
+    tables the build does not partition, 8 / 16 / 24 / 32 bytes per row and scatter level otherwise, a second level from
+    256 slices on (32 768 slots a slice for the table alone, 4 096 with payload columns)."""
+    from hdk_amd._lib import lib
+    L = lib()
+    f = L.hdk_hip_join_build_scratch_bytes
+    assert f(0, 100, 0) == 0 and f(100, 0, 0) == 0 and f(10**6, 10**6, 4) == 0 and f(2**31, 10**6, 0) == 0
+    one = f(4_000_000, 4_000_000, 0)         # 123 slices: one level, 8-byte tuples
+    assert 4_000_000 * 8 <= one <= 4_000_000 * 8 * 1.25 + (123 * 8 * 4096 + 4096) * 8 + 2**20
+    two = f(100_000_000, 100_000_000, 0)     # 3 052 slices: level-1 sub-slabs + 32 768-tuple slabs per slice
+    assert two > 100_000_000 * 8 * 2 and two < 100_000_000 * 8 * 2.5
+    fused = f(100_000_000, 100_000_000, 1)   # 16-byte tuples
+    assert 1.9 * two < fused < 2.2 * two
+    assert f(5_000_000, 50_000_000, 0) > f(5_000_000, 5_000_000, 0)  # a sparse range: more slices, hence more slabs
