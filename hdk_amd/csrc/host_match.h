@@ -59,9 +59,7 @@ inline bool plan_reads_small_dates(const hdk_hip_plan* p) {
 // joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
 // LEFT joins (the batched interpreter handles inner one-to-one probes)
 inline bool needs_join_loops(const hdk_hip_plan* p) {
-  if (p->num_filter_ops) {
-    return true;  // OR / NOT over the conjuncts: evaluated by the row-at-a-time interpreter (filter_program_pass)
-  }
+  // (OR / NOT filter programs run in the batched interpreters too: vec_eval.h, filter_program_pass_v)
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];
     // at most one partner per row: INNER / SEMI drop the row without one, LEFT keeps it with NULL inner columns, ANTI keeps

@@ -2086,7 +2086,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
 static bool match_cluster_join(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, ClusterArgs* ca) {
   if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES)) return false;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_SCALAR | HDK_HIP_LAUNCH_FORCE_GENERIC)) return false;
-  if (p->num_joins != 1 || p->query_kind == HDK_Q_PROJECTION || needs_join_loops(p)) return false;
+  if (p->num_joins != 1 || p->query_kind == HDK_Q_PROJECTION || needs_join_loops(p) || p->num_filter_ops) return false;
   const hdk_hip_join& jn = p->joins[0];
   if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type)) return false;
   if (jn.null_mode == HDK_JOIN_NULL_BITWISE || jn.bucket > 1) return false;  // (a NULL key that matches: not dropped)

@@ -358,10 +358,10 @@ HDK_DEV void eval_expr_v(const VecCtx& c, cexpr_t e, int64_t (&acc)[VR], const b
 
 // pass[r] &= (conjunct is TRUE)
 template <class VecCtx>
-HDK_DEV void eval_qual_v(const VecCtx& c, cqual_t q, bool (&pass)[VR], int32_t& err) {
+HDK_DEV void eval_qual3_v(const VecCtx& c, cqual_t q, const bool (&live)[VR], bool (&tv)[VR], bool (&nv)[VR], int32_t& err) {
   int64_t lhs[VR];
   int64_t rhs[VR];
-  eval_expr_v(c, q.lhs, lhs, pass, err);
+  eval_expr_v(c, q.lhs, lhs, live, err);
   load_leaf_v(c, q.rhs, rhs);
   const bool lhs_fp = q.lhs.vclass == HDK_VC_FP;
   const bool rhs_fp = leaf_is_fp_c(c.plan, q.rhs);
@@ -394,7 +394,79 @@ HDK_DEV void eval_qual_v(const VecCtx& c, cqual_t q, bool (&pass)[VR], int32_t& 
         default: t = a >= b; break;
       }
     }
-    pass[r] = pass[r] && !isnull && t;
+    tv[r] = !isnull && t;  // TRUE; a NULL operand makes the comparison NULL (DEF_CMP_NULLABLE)
+    nv[r] = isnull;
+  }
+}
+
+// one conjunct: the row stays when the comparison is TRUE
+template <class VecCtx>
+HDK_DEV void eval_qual_v(const VecCtx& c, cqual_t q, bool (&pass)[VR], int32_t& err) {
+  bool tv[VR], nv[VR];
+  eval_qual3_v(c, q, pass, tv, nv, err);
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    pass[r] = pass[r] && tv[r];
+  }
+}
+
+// The filter as a postfix program over the comparisons (hdk_hip_plan::filter_ops: OR / NOT trees) with the reference's
+// three-valued logical_and / logical_or / logical_not (QE/RuntimeFunctions.cpp:357-384) -- filter_program_pass
+// (device_common.h) for the VR rows of a batch: per row two bit masks hold the value stack (bit i of t: entry i is TRUE; of
+// n: NULL), the stack pointer and the operator are wave-uniform.
+template <class VecCtx>
+HDK_DEV void filter_program_pass_v(const VecCtx& c, bool (&pass)[VR], int32_t& err) {
+  cplan_t p = c.plan;
+  uint32_t t[VR], n[VR];
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    t[r] = 0;
+    n[r] = 0;
+  }
+  int sp = 0;
+  const int nops = p->num_filter_ops;
+  for (int i = 0; i < nops; ++i) {
+    const uint32_t op = p->filter_ops[i];
+    if (op < HDK_F_AND) {
+      bool tv[VR], nv[VR];
+      eval_qual3_v(c, p->quals[op], pass, tv, nv, err);
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        t[r] = (t[r] & ~(1u << sp)) | (static_cast<uint32_t>(tv[r]) << sp);
+        n[r] = (n[r] & ~(1u << sp)) | (static_cast<uint32_t>(nv[r]) << sp);
+      }
+      ++sp;
+    } else if (op == HDK_F_NOT) {
+      const uint32_t m = 1u << (sp - 1);
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        t[r] = (t[r] & ~m) | (~(t[r] | n[r]) & m);  // NULL stays NULL, TRUE <-> FALSE
+      }
+    } else {
+      const bool is_and = op == HDK_F_AND;
+      const uint32_t m = 1u << (sp - 2);
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const uint32_t ta = (t[r] >> (sp - 2)) & 1u, tb = (t[r] >> (sp - 1)) & 1u;
+        const uint32_t na = (n[r] >> (sp - 2)) & 1u, nb = (n[r] >> (sp - 1)) & 1u;
+        uint32_t tr, nr;
+        if (is_and) {
+          const uint32_t fa = (ta | na) ^ 1u, fb = (tb | nb) ^ 1u;  // FALSE operands
+          tr = ta & tb;
+          nr = (tr | fa | fb) ^ 1u;
+        } else {
+          tr = ta | tb;
+          nr = (tr ^ 1u) & (na | nb);
+        }
+        t[r] = (t[r] & ~m) | (tr << (sp - 2));
+        n[r] = (n[r] & ~m) | (nr << (sp - 2));
+      }
+      sp -= 1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    pass[r] = pass[r] && sp == 1 && (t[r] & 1u);
   }
 }
 
@@ -478,9 +550,16 @@ template <class VecCtx>
 HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass)[VR], int32_t& err) {
   cplan_t p = c.plan;
   const int nq = p->num_quals;
-  for (int q = 0; q < nq; ++q) {
-    if (!VecCtx::kJoins || !p->quals[q].after_joins) {
-      eval_qual_v(c, p->quals[q], pass, err);
+  const bool program = p->num_filter_ops != 0;  // OR / NOT: one program, before the joins or (it reads a joined column) after
+  if (program) {
+    if (!VecCtx::kJoins || !p->filter_after_joins) {
+      filter_program_pass_v(c, pass, err);
+    }
+  } else {
+    for (int q = 0; q < nq; ++q) {
+      if (!VecCtx::kJoins || !p->quals[q].after_joins) {
+        eval_qual_v(c, p->quals[q], pass, err);
+      }
     }
   }
   const int nj = VecCtx::kJoins ? p->num_joins : 0;
@@ -619,9 +698,15 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
     }
   }
   if (VecCtx::kJoins) {  // filters that read joined columns
-    for (int q = 0; q < nq; ++q) {
-      if (p->quals[q].after_joins) {
-        eval_qual_v(c, p->quals[q], pass, err);
+    if (program) {
+      if (p->filter_after_joins) {
+        filter_program_pass_v(c, pass, err);
+      }
+    } else {
+      for (int q = 0; q < nq; ++q) {
+        if (p->quals[q].after_joins) {
+          eval_qual_v(c, p->quals[q], pass, err);
+        }
       }
     }
   }
