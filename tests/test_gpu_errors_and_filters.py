@@ -51,16 +51,25 @@ def test_or_not_filters_match_the_oracle(oracle, gpu_executor_factory):
         for q in queries:
             cp, want, err = run_oracle(oracle, st, q)
             assert err == 0 and cp.plan.num_filter_ops > 0
-            res = gpu_executor_factory(st).execute(cp)
+            step = gpu_executor_factory(st).prepare(cp)
+            if cp.plan.query_kind != A.Q_BASELINE_HASH:  # the program runs in the batched interpreter (filter_program_pass_v)
+                assert step.kernel_names().startswith("hdk_scan_agg_vec"), step.kernel_names()
+            res = step.run()
+            step.free()
             if cp.plan.query_kind == A.Q_BASELINE_HASH:
                 _check_rows(cp, res.buffer, want)
             else:
                 assert_buffers_equal(cp, res.buffer, want)
+                # and row at a time (filter_program_pass)
+                assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_SCALAR).buffer, want)
         from test_gpu_projection import _sorted_rows
         from test_projection import run_projection_oracle
         qp = QueryUnit("t", quals=quals, targets=[Proj(ColRef("k"), "k"), Proj(ColRef("b"), "b")], output_columnar=True)
         cp, want, err, nrows = run_projection_oracle(oracle, st, qp)
-        res = gpu_executor_factory(st).execute(cp)
+        step = gpu_executor_factory(st).prepare(cp)
+        assert step.kernel_names() == "hdk_scan_project", step.kernel_names()
+        res = step.run()
+        step.free()
         assert err == 0 and res.total_matched == nrows
         assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
 
