@@ -14,18 +14,14 @@
 // atomic kernel keeps that case).  Sub-slab capacities come from the row count; a key distribution that overflows one
 // raises a flag, the slice pass leaves the table alone, and the atomic kernels -- armed behind it -- do the work.
 #pragma once
+#include "part_scatter_batch.h"
 
 namespace hdk {
 
-constexpr int kPbBlock = 512;             // scatter passes
 constexpr int kPbBuildBlock = 1024;       // slice pass of the table alone: one block per CU
 constexpr int kPbBuildBlockFused = 512;   // ... with payloads: up to three blocks per CU
 constexpr int kPbSliceLog2 = 15;          // the table alone: 32 768 slots per slice, 128 KB of row ids in LDS
 constexpr int kPbSliceLog2Fused = 12;     // with payloads: 4 096 slots per slice, row id + payload words in LDS (48 / 80 / 112 KB)
-constexpr int kPbMaxBins = 256;
-constexpr int kPbXcds = 8;
-constexpr uint32_t kPbCursorStride = 32;  // level-1 cursors: one per 128-byte line
-constexpr uint32_t kPbCursor2Stride = 8;  // level-2 cursors
 constexpr int kPbMaxPayload = 3;
 
 struct PbArgs {
@@ -55,86 +51,6 @@ struct PbArgs {
   int32_t* buff;
   int64_t* fused;            // nullptr: the table only
 };
-
-// A batch of a block's tuples -> runs ordered by bin in LDS -> consecutive positions behind each bin's cursor.
-// dynamic LDS: [kTile][TW] staging | uint8 bin of every staging slot
-template <int TW, int VR>
-struct PbStage {
-  static constexpr int kTile = kPbBlock * VR;
-  static constexpr size_t lds_bytes() { return static_cast<size_t>(kTile) * TW * 8 + kTile + 16; }
-};
-
-// dest(bin, n) -> claims n positions of bin's slab and returns {first position, positions that exist}
-template <int TW, int VR, typename Claim, typename Addr>
-HDK_DEV void pb_scatter_batch(const int64_t (&tup)[VR][TW], const uint32_t (&bin)[VR], const bool (&live)[VR], uint32_t* s_cnt,
-                              uint4* s_run, uint32_t* s_total, int64_t* s_stage, uint8_t* s_binof, int64_t* out, Claim claim,
-                              Addr addr) {
-  const int tid = threadIdx.x;
-  uint32_t rank[VR];
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    rank[r] = live[r] ? atomicAdd(&s_cnt[bin[r]], 1u) : 0u;
-  }
-  __syncthreads();
-  if (tid < kPbMaxBins) {
-    const uint32_t n = s_cnt[tid];
-    uint32_t base = 0, nfit = 0;
-    if (n) {
-      claim(static_cast<uint32_t>(tid), n, &base, &nfit);
-    }
-    s_run[tid].y = nfit;
-    s_run[tid].z = base;
-  }
-  if (tid < kWave) {  // exclusive scan of the counts
-    uint32_t carry = 0;
-    for (int c0 = 0; c0 < kPbMaxBins; c0 += kWave) {
-      const uint32_t n = s_cnt[c0 + tid];
-      uint32_t incl = n;
-#pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d, kWave);
-        if (tid >= d) {
-          incl += v;
-        }
-      }
-      s_run[c0 + tid].x = carry + incl - n;
-      carry += __shfl(incl, kWave - 1, kWave);
-    }
-    if (tid == 0) {
-      *s_total = carry;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < VR; ++r) {
-    if (live[r]) {
-      const uint32_t si = s_run[bin[r]].x + rank[r];
-      s_binof[si] = static_cast<uint8_t>(bin[r]);
-#pragma unroll
-      for (int w = 0; w < TW; ++w) {
-        s_stage[static_cast<size_t>(si) * TW + w] = tup[r][w];
-      }
-    }
-  }
-  if (tid < kPbMaxBins) {
-    s_cnt[tid] = 0;
-  }
-  __syncthreads();
-  const uint32_t total = *s_total;
-  for (uint32_t i = tid; i < total; i += kPbBlock) {
-    const uint32_t b = s_binof[i];
-    const uint4 run = s_run[b];
-    const uint32_t r = i - run.x;
-    if (r < run.y) {
-      int64_t* o = out + addr(b, static_cast<uint64_t>(run.z) + r) * TW;
-#pragma unroll
-      for (int w = 0; w < TW; ++w) {
-        o[w] = s_stage[static_cast<size_t>(i) * TW + w];
-      }
-    }
-  }
-  __syncthreads();
-}
 
 // ---- level 1: inner rows -> tuples, scattered by slot range -----------------------------------------------------------
 template <int TW, int VR>

@@ -20,6 +20,7 @@ struct GlobalArgs {
   KernParams kp;
   uint32_t entry_count;
   uint32_t rows_per_tile;
+  const uint32_t* run_if;  // nullptr: always; else only when *run_if != 0 (armed behind the partitioned perfect-hash passes)
 };
 
 HDK_DEV void g_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -161,6 +162,9 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
   __shared__ uint64_t s_col_off[2 * HDK_HIP_MAX_TARGETS];  // columnar slot-column offsets
   const hdk_hip_plan* __restrict__ p = a.plan;
   const int tid = threadIdx.x;
+  if (a.run_if && *a.run_if == 0) {
+    return;
+  }
   const bool columnar = p->output_columnar;
   if (columnar && tid < 2 * HDK_HIP_MAX_TARGETS) {
     s_col_off[tid] = columnar_slot_off(p, a.entry_count, tid);

@@ -1,0 +1,293 @@
+// scan_agg_perfect_part.h -- perfect-hash GROUP BY whose table does not fit LDS, by ENTRY-RANGE PARTITIONS.
+//
+// A GroupByPerfectHash layout with more than kLdsMaxTableWords words (some ten thousand groups up to the planner's
+// switch to open addressing at 2^30 / ((keys + targets) x 8) entries, QE/MemoryLayoutBuilder.cpp:176-179) used to go to
+// hdk_scan_agg_global: one or two memory-side atomics per row, 1.1e10 rows/s whatever the table size -- seven times
+// slower than the OPEN-ADDRESSING group-by of the same keys (scan_agg_partitioned.h), although the perfect layout is the
+// easier one: entry = key - min, no hash, no probe sequence.  Same remedy, simpler passes:
+//   pass A  k_pp_scatter     rows -> filters -> tuples [entry | argument words], scattered by entry range (<= 256 bins)
+//   pass A2 k_pp_scatter2    (more than 256 slices) one block per (bin, XCD) sub-slab, by slice
+//   pass B  k_pp_aggregate   one block per slice of 2^k entries: the slice's rows of the (initialised) table into LDS, the
+//                            tuples applied there (the agg_* of part_apply_targets on LDS rows), the rows written back
+// The reference's row function for this layout: get_group_value_fast[_keyless] + agg_* (QE/RowFuncBuilder.cpp:597-745,
+// QE/GroupByRuntime.cpp:202-246).  A key distribution that overflows a slab (capacities come from the row count: a hot key)
+// raises a flag; pass B then leaves the table alone and hdk_scan_agg_global, armed behind it, does the launch.
+#pragma once
+#include "part_scatter_batch.h"  // pb_scatter_batch: the run-staging scatter
+#include "scan_agg_partitioned.h"  // PartTarget, part_apply_targets
+#include "plain_quals.h"
+
+namespace hdk {
+
+constexpr int kPpMaxArgs = 2;
+constexpr int kPpMaxKeySlots = 4;  // projected-key slots of a row (HDK_AGG_ID targets)
+constexpr uint32_t kPpLdsBytes = 60 * 1024;
+
+struct PpArgs {
+  KernParams kp;
+  // the key: a plain integer column of the outer table
+  ProjFastCol key;
+  int32_t key_nullable;
+  int32_t null_has_entry;    // a NULL key has a slot (translated) -- else it is out of range like any other stranger
+  int64_t key_null;
+  int64_t key_min;
+  int64_t null_entry;
+  uint32_t entry_count;
+  uint32_t row_bytes;
+  int32_t nargs;
+  int32_t nquals;
+  ProjFastCol arg[kPpMaxArgs];
+  ProjFastQual q[kMaxPlainQuals];
+  int32_t ntargets;          // aggregate targets (PartTarget); projected keys apart
+  int32_t nkeyslots;
+  PartTarget tg[HDK_HIP_MAX_TARGETS];
+  int32_t keyslot_off[kPpMaxKeySlots];
+  int32_t keyslot_width[kPpMaxKeySlots];
+  int32_t keyslot_translated[kPpMaxKeySlots];  // 1: the layout's own key slot (holds the TRANSLATED key, as get_group_value_fast stores it); 0: a projected key (agg_id of the key expression: a NULL stays NULL)
+  // geometry
+  uint32_t slice_log2;       // entries per slice = 1 << slice_log2 (their rows fit kPpLdsBytes)
+  uint32_t nslices;
+  uint32_t fpc_log2;         // slices per level-1 bin = 1 << fpc_log2 (0: one level)
+  uint32_t nb1;
+  uint32_t two_level;
+  // packed: ONE integer argument inside 32 bits by the column statistics travels in the entry's word -- [argument : entry],
+  // 8 bytes a tuple instead of 16 (its NULL as INT32_MIN; a value the statistics did not announce raises the flag)
+  uint32_t packed;
+  int64_t packed_null;       // the argument column's in-band NULL
+  int32_t packed_nullable;
+  int32_t pad_;
+  uint64_t cap1, cap2;
+  int64_t* tuples1;          // [nb1][kPbXcds][cap1][TW]
+  int64_t* tuples2;          // [nslices][cap2][TW]
+  uint32_t* fill1;
+  uint32_t* fill2;
+  uint32_t* flag;            // 0: partitions; != 0: the armed global-atomics kernel takes the launch
+};
+
+// ---- pass A -------------------------------------------------------------------------------------------------------------
+template <int TW, int VR>
+__global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
+  constexpr int kTile = kPbBlock * VR;
+  __shared__ uint32_t s_cnt[kPbMaxBins];
+  __shared__ uint4 s_run[kPbMaxBins];
+  __shared__ uint32_t s_total;
+  extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
+  int64_t* s_stage = s_dyn;
+  uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(kTile) * TW);
+  const int tid = threadIdx.x;
+  const uint32_t xcd = static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (kPbXcds - 1);
+  for (int i = tid; i < kPbMaxBins; i += kPbBlock) {
+    s_cnt[i] = 0;
+  }
+  __syncthreads();
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const uint32_t bin_shift = a.slice_log2 + a.fpc_log2;
+  bool stranger = false, stale = false;
+  int64_t tile = blockIdx.x;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t nrows = a.kp.num_rows[f * ntab];
+    const int64_t ntiles = (nrows + kTile - 1) / kTile;
+    const int8_t* const* cols = a.kp.col_buffers[f];
+    for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
+      const int64_t row0 = (tile - frag_tile_begin) * kTile;
+      int64_t row[VR];
+      bool live[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        row[r] = row0 + static_cast<int64_t>(r) * kPbBlock + tid;
+        live[r] = row[r] < nrows;
+        row[r] = live[r] ? row[r] : 0;
+      }
+      if (a.nquals) {
+        plain_quals_pass<VR>(a.q, a.nquals, cols, row, live, true);
+      }
+      int64_t tup[VR][TW];
+      uint32_t bin[VR];
+      const int8_t* kb = cols[a.key.buf_idx];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const int64_t k = decode_col_g(kb, a.key.width, a.key.kind, row[r], true);
+        int64_t entry;
+        if (a.key_nullable && k == a.key_null) {
+          entry = a.null_has_entry ? a.null_entry : -1;
+        } else {
+          entry = static_cast<int64_t>(static_cast<uint64_t>(k) - static_cast<uint64_t>(a.key_min));
+        }
+        if (live[r] && static_cast<uint64_t>(entry) >= a.entry_count) {
+          stranger = true;  // a key outside the range the layout was sized for (get_group_value_fast would write past the buffer)
+          live[r] = false;
+        }
+        const uint32_t e32 = live[r] ? static_cast<uint32_t>(entry) : 0u;
+        bin[r] = e32 >> bin_shift;
+        tup[r][0] = static_cast<int64_t>(e32);
+#pragma unroll
+        for (int w = 1; w < TW; ++w) {
+          tup[r][w] = live[r] ? decode_col_g(cols[a.arg[w - 1].buf_idx], a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true) : 0;
+        }
+        if (TW == 1 && a.packed) {
+          const int64_t x = live[r] ? decode_col_g(cols[a.arg[0].buf_idx], a.arg[0].width, a.arg[0].kind, row[r], true) : 0;
+          const bool is_null = a.packed_nullable && x == a.packed_null;
+          const int32_t x32 = is_null ? INT32_MIN : static_cast<int32_t>(x);
+          stale |= live[r] && !is_null && (static_cast<int64_t>(x32) != x || x32 == INT32_MIN);
+          tup[r][0] = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(x32)) << 32) | e32);
+        }
+      }
+      pb_scatter_batch<TW, VR>(
+          tup, bin, live, s_cnt, s_run, &s_total, s_stage, s_binof, a.tuples1,
+          [&](uint32_t b, uint32_t n, uint32_t* base, uint32_t* nfit) {
+            *base = atomicAdd(a.fill1 + (static_cast<size_t>(b) * kPbXcds + xcd) * kPbCursorStride, n);
+            *nfit = static_cast<uint64_t>(*base) >= a.cap1 ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(n), a.cap1 - *base));
+            if (*nfit < n) {
+              atomicMax(a.flag, 1u);  // a hot entry range: the global-atomics kernel takes the launch
+            }
+          },
+          [&](uint32_t b, uint64_t pos) { return (static_cast<uint64_t>(b) * kPbXcds + xcd) * a.cap1 + pos; });
+    }
+    frag_tile_begin += ntiles;
+  }
+  if (__any(stranger) && (threadIdx.x & (kWave - 1)) == 0) {
+    record_error(a.kp.error_code, HDK_HIP_ERR_OUT_OF_SLOTS);
+  }
+  if (__any(stale) && (threadIdx.x & (kWave - 1)) == 0) {
+    atomicMax(a.flag, 1u);  // a value outside what the statistics announced: the global-atomics kernel reads the columns
+  }
+}
+
+// ---- pass A2 ------------------------------------------------------------------------------------------------------------
+template <int TW, int VR>
+__global__ __launch_bounds__(kPbBlock) void k_pp_scatter2(PpArgs a) {
+  constexpr int kTile = kPbBlock * VR;
+  __shared__ uint32_t s_cnt[kPbMaxBins];
+  __shared__ uint4 s_run[kPbMaxBins];
+  __shared__ uint32_t s_total, s_stop;
+  extern __shared__ __attribute__((aligned(16))) int64_t s_dyn[];
+  int64_t* s_stage = s_dyn;
+  uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn + static_cast<size_t>(kTile) * TW);
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_stop = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = tid; i < kPbMaxBins; i += kPbBlock) {
+    s_cnt[i] = 0;
+  }
+  __syncthreads();
+  if (s_stop) {
+    return;
+  }
+  const uint32_t fmask = (1u << a.fpc_log2) - 1u;
+  for (uint32_t sub = blockIdx.x; sub < a.nb1 * kPbXcds; sub += gridDim.x) {
+    const uint32_t b1 = sub / kPbXcds;
+    const uint64_t n = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(sub) * kPbCursorStride]), a.cap1);
+    const int64_t* src = a.tuples1 + static_cast<uint64_t>(sub) * a.cap1 * TW;
+    for (uint64_t t0 = 0; t0 < n; t0 += kTile) {
+      int64_t tup[VR][TW];
+      uint32_t bin[VR];
+      bool live[VR];
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const uint64_t i = t0 + static_cast<uint64_t>(r) * kPbBlock + tid;
+        live[r] = i < n;
+#pragma unroll
+        for (int w = 0; w < TW; ++w) {
+          tup[r][w] = live[r] ? __builtin_nontemporal_load(src + i * TW + w) : 0;
+        }
+        bin[r] = (static_cast<uint32_t>(tup[r][0]) >> a.slice_log2) & fmask;
+      }
+      pb_scatter_batch<TW, VR>(
+          tup, bin, live, s_cnt, s_run, &s_total, s_stage, s_binof, a.tuples2,
+          [&](uint32_t f, uint32_t cnt, uint32_t* base, uint32_t* nfit) {
+            const uint32_t slice = (b1 << a.fpc_log2) + f;
+            *base = atomicAdd(a.fill2 + static_cast<size_t>(slice) * kPbCursor2Stride, cnt);
+            *nfit = static_cast<uint64_t>(*base) >= a.cap2 ? 0u : static_cast<uint32_t>(min(static_cast<uint64_t>(cnt), a.cap2 - *base));
+            if (*nfit < cnt) {
+              atomicMax(a.flag, 1u);
+            }
+          },
+          [&](uint32_t f, uint64_t pos) { return static_cast<uint64_t>((b1 << a.fpc_log2) + f) * a.cap2 + pos; });
+    }
+  }
+}
+
+// ---- pass B -------------------------------------------------------------------------------------------------------------
+// dynamic LDS: the slice's rows
+template <int TW>
+__global__ __launch_bounds__(kPbBlock) void k_pp_aggregate(PpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t s_rows[];
+  __shared__ PartTarget s_tg[HDK_HIP_MAX_TARGETS];
+  __shared__ uint32_t s_stop;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) {
+    s_stop = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < static_cast<uint32_t>(a.ntargets)) {
+    s_tg[tid] = a.tg[tid];
+  }
+  __syncthreads();
+  if (s_stop) {
+    return;  // (hdk_scan_agg_global, armed behind this kernel, aggregates the launch)
+  }
+  const uint32_t slots = 1u << a.slice_log2;
+  const uint32_t rq = a.row_bytes / 8;
+  int64_t* table = a.kp.groupby_buf[0];
+  for (uint32_t s = blockIdx.x; s < a.nslices; s += gridDim.x) {
+    const uint32_t e0 = s << a.slice_log2;
+    const uint32_t n_e = min(slots, a.entry_count - e0);
+    const uint32_t nq = n_e * rq;
+    int64_t* rows = table + static_cast<size_t>(e0) * rq;
+    for (uint32_t i = tid; i < nq; i += kPbBlock) {
+      s_rows[i] = rows[i];
+    }
+    __syncthreads();
+    const int nsrc = a.two_level ? 1 : kPbXcds;
+    for (int x = 0; x < nsrc; ++x) {
+      const int64_t* src;
+      uint64_t n;
+      if (a.two_level) {
+        src = a.tuples2 + static_cast<uint64_t>(s) * a.cap2 * TW;
+        n = min(static_cast<uint64_t>(a.fill2[static_cast<size_t>(s) * kPbCursor2Stride]), a.cap2);
+      } else {
+        const uint64_t sub = static_cast<uint64_t>(s) * kPbXcds + x;
+        src = a.tuples1 + sub * a.cap1 * TW;
+        n = min(static_cast<uint64_t>(a.fill1[sub * kPbCursorStride]), a.cap1);
+      }
+      for (uint64_t i = tid; i < n; i += kPbBlock) {
+        int64_t t[3];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          t[w] = w < TW ? __builtin_nontemporal_load(src + i * TW + w) : 0;
+        }
+        const uint32_t entry = static_cast<uint32_t>(t[0]);
+        if (TW == 1 && a.packed) {
+          const int32_t x32 = static_cast<int32_t>(static_cast<uint64_t>(t[0]) >> 32);
+          t[1] = (a.packed_nullable && x32 == INT32_MIN) ? a.packed_null : static_cast<int64_t>(x32);
+        }
+        const uint32_t local = entry - e0;
+        if (local < n_e) {
+          int8_t* rowb = reinterpret_cast<int8_t*>(s_rows + static_cast<size_t>(local) * rq);
+          if (a.nkeyslots) {  // agg_id: every row of a group stores the same key
+            const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min) + entry);
+            const int64_t projected = (a.null_has_entry && static_cast<int64_t>(entry) == a.null_entry) ? a.key_null : stored;
+            for (int ks = 0; ks < a.nkeyslots; ++ks) {
+              const int64_t key = a.keyslot_translated[ks] ? stored : projected;
+              if (a.keyslot_width[ks] == 4) {
+                *reinterpret_cast<int32_t*>(rowb + a.keyslot_off[ks]) = static_cast<int32_t>(key);
+              } else {
+                *reinterpret_cast<int64_t*>(rowb + a.keyslot_off[ks]) = key;
+              }
+            }
+          }
+          part_apply_targets(s_tg, a.ntargets, rowb, t);
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nq; i += kPbBlock) {
+      rows[i] = s_rows[i];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace hdk

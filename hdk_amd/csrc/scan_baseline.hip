@@ -8,6 +8,7 @@
 #include "scan_agg_baseline_fast.h"
 #include "scan_agg_global.h"
 #include "scan_agg_partitioned.h"
+#include "scan_agg_perfect_part.h"
 
 namespace hdk {
 
@@ -606,9 +607,10 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
 }
 
 static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan,
-                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic) {
+                                  const KernParams& kp, const LaunchShape& shape, hipStream_t s, bool force_generic,
+                                  const uint32_t* run_if = nullptr) {
   BaseFastArgs fa;
-  if (!force_generic && match_baseline_fast(plan, &fa)) {
+  if (!run_if && !force_generic && match_baseline_fast(plan, &fa)) {
     fa.plan = d_plan;
     fa.kp = kp;
     fa.entry_count = shape.entry_count;
@@ -621,6 +623,7 @@ static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* 
   a.kp = kp;
   a.entry_count = shape.entry_count;
   a.rows_per_tile = kGlobalBlock * 4;
+  a.run_if = run_if;
   hipLaunchKernelGGL(hdk_scan_agg_global, dim3(shape.grid), dim3(kGlobalBlock), 0, s, a);
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
@@ -642,11 +645,17 @@ uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, 
   return resident_grid(k, block, 0, props) * 4;
 }
 
+struct PpLayout;
+static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PpArgs* a, PpLayout* l);
+static bool perfect_partitioned_takes(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko);
+
 void baseline_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
   BaseFastArgs fa;
   PartArgs part;
   if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
     snprintf(out, out_len, "hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate,hdk_part_overflow,hdk_scan_agg_baseline_direct");
+  } else if (perfect_partitioned_takes(plan, ko)) {
+    snprintf(out, out_len, "hdk_pp_scatter,hdk_pp_scatter2,hdk_pp_aggregate,hdk_scan_agg_global");
   } else {
     snprintf(out, out_len, "%s", !launch_forces_generic(ko) && match_baseline_fast(plan, &fa) ? "hdk_scan_agg_baseline_direct"
                                                                                                : "hdk_scan_agg_global");
@@ -659,6 +668,195 @@ static int32_t init_row_wise_output(const hdk_hip_plan* plan, const KernParams& 
   const uint32_t key_count = plan->keyless ? 0u : static_cast<uint32_t>(plan->key_count);
   return launch_init_row_wise_indirect(kp.groupby_buf, kp.init_agg_vals, plan->entry_count, key_count,
                                        static_cast<uint32_t>(plan->key_width), plan->row_size_quad, plan->keyless, props, s);
+}
+
+
+// ---- perfect-hash tables beyond LDS: entry-range partitions (scan_agg_perfect_part.h) ---------------------------------------
+struct PpLayout {
+  size_t off_fill1, off_fill2, off_t1, off_t2, cursor_bytes, total;
+  int tw;
+};
+
+static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PpArgs* a, PpLayout* l) {
+  if (!ko || getenv("HDK_HIP_NO_PERFECT_PARTITIONS")) return false;
+  const bool forced = getenv("HDK_HIP_PERFECT_PARTITIONS_ALWAYS") != nullptr;  // (tests: small inputs)
+  if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR |
+                   HDK_HIP_LAUNCH_CHECK_INTERRUPT)) {
+    return false;
+  }
+  if (ko->watchdog_ms || ko->total_rows == 0 || (!forced && ko->total_rows < (16ull << 20))) return false;
+  if (p->query_kind != HDK_Q_PERFECT_HASH || p->key_count != 1 || p->output_columnar || p->num_joins || p->key_bucket[0] > 1) return false;
+  if (p->entry_count < 2 || static_cast<uint64_t>(p->entry_count) >= 0x7FFFFFFFull) return false;
+  memset(a, 0, sizeof(*a));
+  int kc;
+  if (!plain_outer_col(p, p->keys[0], &kc) || (p->cols[kc].kind != HDK_COL_INT && p->cols[kc].kind != HDK_COL_UNSIGNED)) return false;
+  if (!match_plain_quals(p, a->q)) return false;
+  a->nquals = p->num_quals;
+  a->key.buf_idx = p->cols[kc].buf_idx;
+  a->key.width = p->cols[kc].width;
+  a->key.kind = p->cols[kc].kind;
+  a->key_nullable = p->keys[0].nullable;
+  a->key_null = p->keys[0].null_val;
+  a->key_min = p->key_min[0];
+  a->null_has_entry = p->key_has_nulls[0] && p->keys[0].nullable;
+  a->null_entry = static_cast<int64_t>(static_cast<uint64_t>(p->key_null_translated[0]) - static_cast<uint64_t>(p->key_min[0]));
+  a->entry_count = p->entry_count;
+  a->row_bytes = static_cast<uint32_t>(p->row_size_quad) * 8;
+  if (a->row_bytes == 0 || a->row_bytes > 256) return false;
+  if (!p->keyless) {  // the layout's key slot: quad 0 of the row (get_group_value_fast)
+    a->keyslot_off[0] = 0;
+    a->keyslot_width[0] = 8;
+    a->keyslot_translated[0] = 1;
+    a->nkeyslots = 1;
+  }
+  int arg_col[kPpMaxArgs] = {-1, -1};
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_ID) {
+      if (tg.key_idx != 0) return false;
+      if (tg.slot_width == 0) continue;
+      if (a->nkeyslots == kPpMaxKeySlots || (tg.slot_width != 4 && tg.slot_width != 8)) return false;
+      a->keyslot_off[a->nkeyslots] = tg.slot_off;
+      a->keyslot_width[a->nkeyslots] = tg.slot_width;
+      ++a->nkeyslots;
+      continue;
+    }
+    if (tg.agg == HDK_AGG_SINGLE_VALUE || tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;
+    if ((tg.slot_width != 4 && tg.slot_width != 8) || (tg.agg == HDK_AGG_AVG && tg.slot2_width != 4 && tg.slot2_width != 8)) return false;
+    PartTarget d;
+    memset(&d, 0, sizeof(d));
+    d.agg = tg.agg;
+    d.has_arg = tg.has_arg;
+    d.skip_null = tg.skip_null;
+    d.arg_is_fp = tg.arg_is_fp;
+    d.slot_width = tg.slot_width;
+    d.slot2_width = tg.slot2_width;
+    d.slot_off = tg.slot_off;
+    d.slot2_off = tg.slot2_off;
+    d.null_val = tg.null_val;
+    d.arg_null_val = tg.arg.null_val;
+    d.arg_nullable = tg.arg.nullable;
+    if (tg.has_arg) {
+      int c;
+      if (!plain_outer_col(p, tg.arg, &c)) return false;
+      const hdk_hip_col& col = p->cols[c];
+      int w = -1;
+      for (int i = 0; i < a->nargs; ++i) {
+        if (arg_col[i] == c) w = i;
+      }
+      if (w < 0) {
+        if (a->nargs == kPpMaxArgs) return false;
+        w = a->nargs++;
+        arg_col[w] = c;
+        a->arg[w].buf_idx = col.buf_idx;
+        a->arg[w].width = col.width;
+        a->arg[w].kind = col.kind;
+      }
+      d.arg_word = 1 + w;
+      d.arg_fp = col.kind == HDK_COL_FLOAT || col.kind == HDK_COL_DOUBLE;
+    }
+    a->tg[a->ntargets++] = d;
+  }
+  // ---- geometry --------------------------------------------------------------------------------------------------------------
+  uint32_t slice_log2 = 0;
+  while ((2ull << slice_log2) * a->row_bytes <= kPpLdsBytes) ++slice_log2;
+  if (const char* e = getenv("HDK_HIP_PERFECT_SLICE_LOG2")) slice_log2 = static_cast<uint32_t>(atoi(e));  // (tests)
+  if (slice_log2 < 4 || slice_log2 > 20) return false;
+  a->slice_log2 = slice_log2;
+  a->nslices = static_cast<uint32_t>((static_cast<uint64_t>(a->entry_count) + (1ull << slice_log2) - 1) >> slice_log2);
+  uint32_t fpc_log2 = 0;
+  while (((a->nslices + (1u << fpc_log2) - 1) >> fpc_log2) > static_cast<uint32_t>(kPbMaxBins)) ++fpc_log2;
+  if (fpc_log2 > 8) return false;
+  a->fpc_log2 = fpc_log2;
+  a->two_level = fpc_log2 ? 1u : 0u;
+  a->nb1 = (a->nslices + (1u << fpc_log2) - 1) >> fpc_log2;
+  const uint64_t rows = ko->total_rows;
+  const uint64_t nsub = static_cast<uint64_t>(a->nb1) * kPbXcds;
+  a->cap1 = ((rows / nsub) * 5 / 4 + 4096 + 15) & ~15ull;
+  a->cap2 = ((rows / a->nslices) * 5 / 4 + 1024 + 15) & ~15ull;
+  if (a->cap1 > 0xFFFFFFF0ull || a->cap2 > 0xFFFFFFF0ull) return false;
+  auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  l->tw = 1 + a->nargs;
+  if (a->nargs == 1 && arg_col[0] >= 0 && !(ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) {
+    const hdk_hip_col& c = p->cols[arg_col[0]];
+    // (nullable: some target skips this column's NULLs with the column's own sentinel -- the leaf of any of them says so)
+    int64_t nullv = 0;
+    bool nullable = false;
+    for (int t = 0; t < p->num_targets; ++t) {
+      const hdk_hip_target& tg = p->targets[t];
+      if (tg.agg != HDK_AGG_ID && tg.has_arg && tg.arg.leaf0.nullable) nullable = true, nullv = tg.arg.leaf0.null_val;
+    }
+    if (c.kind == HDK_COL_INT && c.has_stats && c.min_val > static_cast<int64_t>(INT32_MIN) && c.max_val <= static_cast<int64_t>(INT32_MAX) &&
+        (nullable || !c.has_nulls)) {
+      a->packed = 1;
+      a->packed_nullable = nullable ? 1 : 0;
+      a->packed_null = nullv;
+      l->tw = 1;
+    }
+  }
+  l->off_fill1 = 256;
+  l->off_fill2 = l->off_fill1 + up(nsub * kPbCursorStride * 4);
+  l->cursor_bytes = l->off_fill2 + (a->two_level ? up(static_cast<size_t>(a->nslices) * kPbCursor2Stride * 4) : 0);
+  l->off_t1 = l->cursor_bytes;
+  l->off_t2 = l->off_t1 + up(nsub * a->cap1 * l->tw * 8);
+  l->total = l->off_t2 + (a->two_level ? up(static_cast<size_t>(a->nslices) * a->cap2 * l->tw * 8) : 0);
+  return true;
+}
+
+static bool perfect_partitioned_takes(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
+  PpArgs a;
+  PpLayout l;
+  return match_perfect_partitioned(p, ko, &a, &l);
+}
+
+template <int TW>
+static void pp_launch(const PpArgs& a, const hdk_hip_device_properties* props, hipStream_t s) {
+  constexpr int VR = TW == 1 ? 8 : (TW == 2 ? 4 : 2);
+  const size_t lds_sc = PbStage<TW, VR>::lds_bytes();
+  const unsigned cu = static_cast<unsigned>(props->num_cu);
+  hipLaunchKernelGGL((k_pp_scatter<TW, VR>), dim3(2 * cu), dim3(kPbBlock), lds_sc, s, a);
+  if (a.two_level) {
+    unsigned g2 = a.nb1 * kPbXcds;
+    if (g2 > 3 * cu) g2 = 3 * cu;
+    hipLaunchKernelGGL((k_pp_scatter2<TW, VR>), dim3(g2), dim3(kPbBlock), lds_sc, s, a);
+  }
+  const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * a.row_bytes;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pp_aggregate<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds_b));
+  unsigned gb = 2 * cu;
+  if (gb > a.nslices) gb = a.nslices;
+  hipLaunchKernelGGL((k_pp_aggregate<TW>), dim3(gb), dim3(kPbBlock), lds_b, s, a);
+}
+
+// true: the passes (and the armed global-atomics kernel) are on the stream
+static int32_t launch_perfect_partitioned(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, PpArgs& a,
+                                          const PpLayout& l, const LaunchShape& shape, const hdk_hip_device_properties* props,
+                                          hipStream_t s, bool* launched) {
+  *launched = false;
+  AsyncScratch scratch(s);
+  if (hipMallocAsync(&scratch.p, l.total, s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return HDK_HIP_OK;  // no room for the tuples: global atomics
+  }
+  int8_t* base = static_cast<int8_t*>(scratch.p);
+  HDK_HIP_CHECK(hipMemsetAsync(base, 0, l.cursor_bytes, s));
+  a.kp = kp;
+  a.flag = reinterpret_cast<uint32_t*>(base);
+  a.fill1 = reinterpret_cast<uint32_t*>(base + l.off_fill1);
+  a.fill2 = reinterpret_cast<uint32_t*>(base + l.off_fill2);
+  a.tuples1 = reinterpret_cast<int64_t*>(base + l.off_t1);
+  a.tuples2 = reinterpret_cast<int64_t*>(base + l.off_t2);
+  switch (l.tw) {
+    case 1: pp_launch<1>(a, props, s); break;
+    case 2: pp_launch<2>(a, props, s); break;
+    default: pp_launch<3>(a, props, s); break;
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  const int32_t st = launch_scan_global(plan, d_plan, kp, shape, s, true, a.flag);  // armed: only when a slab overflowed
+  if (st) return st;
+  *launched = true;
+  return HDK_HIP_OK;
 }
 
 int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
@@ -680,6 +878,13 @@ int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, co
   if (init_output) {
     const int32_t st = init_row_wise_output(plan, kp, props, s);
     if (st) return st;
+  }
+  PpArgs pp;
+  PpLayout pl;
+  if (match_perfect_partitioned(plan, ko, &pp, &pl)) {
+    bool launched = false;
+    const int32_t st = launch_perfect_partitioned(plan, d_plan, kp, pp, pl, shape, props, s, &launched);
+    if (st || launched) return st;
   }
   return launch_scan_global(plan, d_plan, kp, shape, s, launch_forces_generic(ko));
 }

@@ -57,13 +57,13 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
@@ -112,6 +112,8 @@ def main():
                           targets=[Agg("sum", ColRef("val") + ColRef("dval", "dim2")), Agg("count")]), 16),
         "c3k": (QueryUnit("t", joins=[JoinSpec("dimk", [ColRef("k1"), ColRef("k2")], ["k1", "k2"])],
                           targets=[Agg("sum", ColRef("val") + ColRef("dval", "dimk")), Agg("count")]), 24),
+        # a perfect-hash GROUP BY whose table does not fit LDS (rows / 10 groups): the global-atomics strategy
+        "c2m": (QueryUnit("t", groupby=[ColRef("hk")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
         # an OR in the filter: the postfix filter program, in the batched interpreter since round 4
         "c2or": (QueryUnit("t", quals=[Or(Cmp(ColRef("val"), "<", Lit(0)), Cmp(ColRef("key"), "=", Lit(3)))], groupby=[ColRef("key")],
                            targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
