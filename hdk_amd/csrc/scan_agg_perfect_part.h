@@ -106,9 +106,37 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
       int64_t tup[VR][TW];
       uint32_t bin[VR];
       const int8_t* kb = cols[a.key.buf_idx];
+      // all loads of the batch first (the decoder's width switch is wave-uniform: one branch per column, the row loop inside --
+      // with the switch inside the row loop the loads went out one at a time and the pass ran at half the copy rate)
+      int64_t kv[VR], xv[VR];
+      if (a.key.width == 8) {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          kv[r] = gload<int64_t>(kb, row[r], true);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          kv[r] = decode_col_g(kb, a.key.width, a.key.kind, row[r], true);
+        }
+      }
+      if (TW == 1 && a.packed) {
+        const int8_t* xb = cols[a.arg[0].buf_idx];
+        if (a.arg[0].width == 8) {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            xv[r] = gload<int64_t>(xb, row[r], true);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            xv[r] = decode_col_g(xb, a.arg[0].width, a.arg[0].kind, row[r], true);
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const int64_t k = decode_col_g(kb, a.key.width, a.key.kind, row[r], true);
+        const int64_t k = kv[r];
         int64_t entry;
         if (a.key_nullable && k == a.key_null) {
           entry = a.null_has_entry ? a.null_entry : -1;
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
           tup[r][w] = live[r] ? decode_col_g(cols[a.arg[w - 1].buf_idx], a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true) : 0;
         }
         if (TW == 1 && a.packed) {
-          const int64_t x = live[r] ? decode_col_g(cols[a.arg[0].buf_idx], a.arg[0].width, a.arg[0].kind, row[r], true) : 0;
+          const int64_t x = xv[r];
           const bool is_null = a.packed_nullable && x == a.packed_null;
           const int32_t x32 = is_null ? INT32_MIN : static_cast<int32_t>(x);
           stale |= live[r] && !is_null && (static_cast<int64_t>(x32) != x || x32 == INT32_MIN);
@@ -252,33 +280,45 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_aggregate(PpArgs a) {
         src = a.tuples1 + sub * a.cap1 * TW;
         n = min(static_cast<uint64_t>(a.fill1[sub * kPbCursorStride]), a.cap1);
       }
-      for (uint64_t i = tid; i < n; i += kPbBlock) {
-        int64_t t[3];
+      constexpr int U = 4;  // tuples in flight per lane
+      for (uint64_t i0 = tid; i0 < n; i0 += static_cast<uint64_t>(U) * kPbBlock) {
+        int64_t tt[U][3];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          t[w] = w < TW ? __builtin_nontemporal_load(src + i * TW + w) : 0;
+        for (int u = 0; u < U; ++u) {
+          const uint64_t i = i0 + static_cast<uint64_t>(u) * kPbBlock;
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            tt[u][w] = (w < TW && i < n) ? __builtin_nontemporal_load(src + i * TW + w) : 0;
+          }
         }
-        const uint32_t entry = static_cast<uint32_t>(t[0]);
-        if (TW == 1 && a.packed) {
-          const int32_t x32 = static_cast<int32_t>(static_cast<uint64_t>(t[0]) >> 32);
-          t[1] = (a.packed_nullable && x32 == INT32_MIN) ? a.packed_null : static_cast<int64_t>(x32);
-        }
-        const uint32_t local = entry - e0;
-        if (local < n_e) {
-          int8_t* rowb = reinterpret_cast<int8_t*>(s_rows + static_cast<size_t>(local) * rq);
-          if (a.nkeyslots) {  // agg_id: every row of a group stores the same key
-            const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min) + entry);
-            const int64_t projected = (a.null_has_entry && static_cast<int64_t>(entry) == a.null_entry) ? a.key_null : stored;
-            for (int ks = 0; ks < a.nkeyslots; ++ks) {
-              const int64_t key = a.keyslot_translated[ks] ? stored : projected;
-              if (a.keyslot_width[ks] == 4) {
-                *reinterpret_cast<int32_t*>(rowb + a.keyslot_off[ks]) = static_cast<int32_t>(key);
-              } else {
-                *reinterpret_cast<int64_t*>(rowb + a.keyslot_off[ks]) = key;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i0 + static_cast<uint64_t>(u) * kPbBlock >= n) {
+            break;
+          }
+          int64_t* t = tt[u];
+          const uint32_t entry = static_cast<uint32_t>(t[0]);
+          if (TW == 1 && a.packed) {
+            const int32_t x32 = static_cast<int32_t>(static_cast<uint64_t>(t[0]) >> 32);
+            t[1] = (a.packed_nullable && x32 == INT32_MIN) ? a.packed_null : static_cast<int64_t>(x32);
+          }
+          const uint32_t local = entry - e0;
+          if (local < n_e) {
+            int8_t* rowb = reinterpret_cast<int8_t*>(s_rows + static_cast<size_t>(local) * rq);
+            if (a.nkeyslots) {  // agg_id: every row of a group stores the same key
+              const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min) + entry);
+              const int64_t projected = (a.null_has_entry && static_cast<int64_t>(entry) == a.null_entry) ? a.key_null : stored;
+              for (int ks = 0; ks < a.nkeyslots; ++ks) {
+                const int64_t key = a.keyslot_translated[ks] ? stored : projected;
+                if (a.keyslot_width[ks] == 4) {
+                  *reinterpret_cast<int32_t*>(rowb + a.keyslot_off[ks]) = static_cast<int32_t>(key);
+                } else {
+                  *reinterpret_cast<int64_t*>(rowb + a.keyslot_off[ks]) = key;
+                }
               }
             }
+            part_apply_targets(s_tg, a.ntargets, rowb, t);
           }
-          part_apply_targets(s_tg, a.ntargets, rowb, t);
         }
       }
     }

@@ -814,7 +814,9 @@ static void pp_launch(const PpArgs& a, const hdk_hip_device_properties* props, h
   constexpr int VR = TW == 1 ? 8 : (TW == 2 ? 4 : 2);
   const size_t lds_sc = PbStage<TW, VR>::lds_bytes();
   const unsigned cu = static_cast<unsigned>(props->num_cu);
-  hipLaunchKernelGGL((k_pp_scatter<TW, VR>), dim3(2 * cu), dim3(kPbBlock), lds_sc, s, a);
+  unsigned per_cu = 2;
+  if (const char* e = getenv("HDK_HIP_PP_BLOCKS_PER_CU")) per_cu = static_cast<unsigned>(atoi(e)) ? static_cast<unsigned>(atoi(e)) : 2u;
+  hipLaunchKernelGGL((k_pp_scatter<TW, VR>), dim3(per_cu * cu), dim3(kPbBlock), lds_sc, s, a);
   if (a.two_level) {
     unsigned g2 = a.nb1 * kPbXcds;
     if (g2 > 3 * cu) g2 = 3 * cu;
