@@ -79,11 +79,27 @@ __global__ __launch_bounds__(kPbBlock) void k_pb_scatter(PbArgs a) {
       int64_t tup[VR][TW];
       uint32_t bin[VR];
       bool live[VR];
+      // all key loads of the batch first (an 8-byte signed key -- the usual dimension key -- without the decoder's switches
+      // between the loads)
+      int64_t ev[VR];
+      if (elem_sz == 8 && a.ti.column_type == HDK_JC_SIGNED) {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
+          ev[r] = i < ch.num_elems ? __builtin_nontemporal_load(reinterpret_cast<const int64_t*>(ch.col_buff) + i) : 0;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
+          ev[r] = i < ch.num_elems ? join_elem(ch.col_buff, i, elem_sz, a.ti.column_type) : 0;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
         const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
         live[r] = i < ch.num_elems;
-        int64_t elem = live[r] ? join_elem(ch.col_buff, i, elem_sz, a.ti.column_type) : 0;
+        int64_t elem = ev[r];
         if (live[r] && elem == a.ti.null_val) {
           if (a.ti.uses_bw_eq) {
             elem = a.ti.translated_null_val;
