@@ -1,6 +1,6 @@
 // scan_agg_perfect_part.h -- perfect-hash GROUP BY whose table does not fit LDS, by ENTRY-RANGE PARTITIONS.
 //
-// A GroupByPerfectHash layout with more than kLdsMaxTableWords words (some ten thousand groups up to the planner's
+// (One to three plain key columns: perfect_key_hash.)  A GroupByPerfectHash layout with more than kLdsMaxTableWords words (some ten thousand groups up to the planner's
 // switch to open addressing at 2^30 / ((keys + targets) x 8) entries, QE/MemoryLayoutBuilder.cpp:176-179) used to go to
 // hdk_scan_agg_global: one or two memory-side atomics per row, 1.1e10 rows/s whatever the table size -- seven times
 // slower than the OPEN-ADDRESSING group-by of the same keys (scan_agg_partitioned.h), although the perfect layout is the
@@ -20,18 +20,24 @@
 namespace hdk {
 
 constexpr int kPpMaxArgs = 2;
-constexpr int kPpMaxKeySlots = 4;  // projected-key slots of a row (HDK_AGG_ID targets)
+constexpr int kPpMaxKeys = 3;
+constexpr int kPpMaxKeySlots = 8;  // projected-key slots of a row (HDK_AGG_ID targets)
 constexpr uint32_t kPpLdsBytes = 60 * 1024;
 
 struct PpArgs {
   KernParams kp;
-  // the key: a plain integer column of the outer table
-  ProjFastCol key;
-  int32_t key_nullable;
-  int32_t null_has_entry;    // a NULL key has a slot (translated) -- else it is out of range like any other stranger
-  int64_t key_null;
-  int64_t key_min;
-  int64_t null_entry;
+  // the keys: one to three plain integer columns of the outer table; entry = sum((key_k - min_k) * stride_k), perfect_key_hash
+  // (QE/RowFuncBuilder.cpp:748-801)
+  int32_t nkeys;
+  int32_t pad0_;
+  ProjFastCol key[kPpMaxKeys];
+  int32_t key_nullable[kPpMaxKeys];
+  int32_t null_has_entry[kPpMaxKeys];  // a NULL key has a slot (translated) -- else it is out of range like any other stranger
+  int64_t key_null[kPpMaxKeys];
+  int64_t key_min[kPpMaxKeys];
+  int64_t key_translated[kPpMaxKeys];  // what a NULL key is stored / hashed as
+  uint32_t key_card[kPpMaxKeys];
+  uint32_t key_stride[kPpMaxKeys];
   uint32_t entry_count;
   uint32_t row_bytes;
   int32_t nargs;
@@ -43,6 +49,7 @@ struct PpArgs {
   PartTarget tg[HDK_HIP_MAX_TARGETS];
   int32_t keyslot_off[kPpMaxKeySlots];
   int32_t keyslot_width[kPpMaxKeySlots];
+  int32_t keyslot_key[kPpMaxKeySlots];         // which key the slot holds
   int32_t keyslot_translated[kPpMaxKeySlots];  // 1: the layout's own key slot (holds the TRANSLATED key, as get_group_value_fast stores it); 0: a projected key (agg_id of the key expression: a NULL stays NULL)
   // geometry
   uint32_t slice_log2;       // entries per slice = 1 << slice_log2 (their rows fit kPpLdsBytes)
@@ -105,19 +112,24 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
       }
       int64_t tup[VR][TW];
       uint32_t bin[VR];
-      const int8_t* kb = cols[a.key.buf_idx];
       // all loads of the batch first (the decoder's width switch is wave-uniform: one branch per column, the row loop inside --
       // with the switch inside the row loop the loads went out one at a time and the pass ran at half the copy rate)
-      int64_t kv[VR], xv[VR];
-      if (a.key.width == 8) {
+      int64_t kv[kPpMaxKeys][VR], xv[VR];
 #pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          kv[r] = gload<int64_t>(kb, row[r], true);
-        }
-      } else {
+      for (int ki = 0; ki < kPpMaxKeys; ++ki) {
+        if (ki < a.nkeys) {
+          const int8_t* kb = cols[a.key[ki].buf_idx];
+          if (a.key[ki].width == 8) {
 #pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          kv[r] = decode_col_g(kb, a.key.width, a.key.kind, row[r], true);
+            for (int r = 0; r < VR; ++r) {
+              kv[ki][r] = gload<int64_t>(kb, row[r], true);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+              kv[ki][r] = decode_col_g(kb, a.key[ki].width, a.key[ki].kind, row[r], true);
+            }
+          }
         }
       }
       if (TW == 1 && a.packed) {
@@ -136,14 +148,22 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const int64_t k = kv[r];
-        int64_t entry;
-        if (a.key_nullable && k == a.key_null) {
-          entry = a.null_has_entry ? a.null_entry : -1;
-        } else {
-          entry = static_cast<int64_t>(static_cast<uint64_t>(k) - static_cast<uint64_t>(a.key_min));
+        uint64_t entry = 0;
+        bool inside = true;
+#pragma unroll
+        for (int ki = 0; ki < kPpMaxKeys; ++ki) {
+          if (ki < a.nkeys) {
+            int64_t k = kv[ki][r];
+            if (a.key_nullable[ki] && k == a.key_null[ki]) {
+              inside = inside && a.null_has_entry[ki];
+              k = a.key_translated[ki];
+            }
+            const uint64_t term = static_cast<uint64_t>(k) - static_cast<uint64_t>(a.key_min[ki]);
+            inside = inside && term < a.key_card[ki];
+            entry += term * a.key_stride[ki];
+          }
         }
-        if (live[r] && static_cast<uint64_t>(entry) >= a.entry_count) {
+        if (live[r] && !(inside && entry < a.entry_count)) {
           stranger = true;  // a key outside the range the layout was sized for (get_group_value_fast would write past the buffer)
           live[r] = false;
         }
@@ -305,11 +325,12 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_aggregate(PpArgs a) {
           const uint32_t local = entry - e0;
           if (local < n_e) {
             int8_t* rowb = reinterpret_cast<int8_t*>(s_rows + static_cast<size_t>(local) * rq);
-            if (a.nkeyslots) {  // agg_id: every row of a group stores the same key
-              const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min) + entry);
-              const int64_t projected = (a.null_has_entry && static_cast<int64_t>(entry) == a.null_entry) ? a.key_null : stored;
+            if (a.nkeyslots) {  // agg_id / the layout's key slots: every row of a group stores the same keys
               for (int ks = 0; ks < a.nkeyslots; ++ks) {
-                const int64_t key = a.keyslot_translated[ks] ? stored : projected;
+                const int ki = a.keyslot_key[ks];
+                const uint32_t term = (entry / a.key_stride[ki]) % a.key_card[ki];
+                const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min[ki]) + term);
+                const int64_t key = (!a.keyslot_translated[ks] && a.null_has_entry[ki] && stored == a.key_translated[ki]) ? a.key_null[ki] : stored;
                 if (a.keyslot_width[ks] == 4) {
                   *reinterpret_cast<int32_t*>(rowb + a.keyslot_off[ks]) = static_cast<int32_t>(key);
                 } else {

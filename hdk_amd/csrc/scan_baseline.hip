@@ -685,39 +685,57 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
     return false;
   }
   if (ko->watchdog_ms || ko->total_rows == 0 || (!forced && ko->total_rows < (16ull << 20))) return false;
-  if (p->query_kind != HDK_Q_PERFECT_HASH || p->key_count != 1 || p->output_columnar || p->num_joins || p->key_bucket[0] > 1) return false;
+  if (p->query_kind != HDK_Q_PERFECT_HASH || p->key_count < 1 || p->key_count > kPpMaxKeys || p->output_columnar || p->num_joins) return false;
   if (p->entry_count < 2 || static_cast<uint64_t>(p->entry_count) >= 0x7FFFFFFFull) return false;
   memset(a, 0, sizeof(*a));
-  int kc;
-  if (!plain_outer_col(p, p->keys[0], &kc) || (p->cols[kc].kind != HDK_COL_INT && p->cols[kc].kind != HDK_COL_UNSIGNED)) return false;
   if (!match_plain_quals(p, a->q)) return false;
   a->nquals = p->num_quals;
-  a->key.buf_idx = p->cols[kc].buf_idx;
-  a->key.width = p->cols[kc].width;
-  a->key.kind = p->cols[kc].kind;
-  a->key_nullable = p->keys[0].nullable;
-  a->key_null = p->keys[0].null_val;
-  a->key_min = p->key_min[0];
-  a->null_has_entry = p->key_has_nulls[0] && p->keys[0].nullable;
-  a->null_entry = static_cast<int64_t>(static_cast<uint64_t>(p->key_null_translated[0]) - static_cast<uint64_t>(p->key_min[0]));
+  a->nkeys = p->key_count;
+  uint64_t stride = 1;
+  for (int k = 0; k < p->key_count; ++k) {
+    int kc;
+    if (p->key_bucket[k] > 1 || !plain_outer_col(p, p->keys[k], &kc) ||
+        (p->cols[kc].kind != HDK_COL_INT && p->cols[kc].kind != HDK_COL_UNSIGNED)) {
+      return false;
+    }
+    // (one key: the entry count is its cardinality; several: getBucketedCardinality per key, perfect_key_hash's strides)
+    const uint64_t card = p->key_count == 1 ? static_cast<uint64_t>(p->entry_count) : static_cast<uint64_t>(p->key_card[k]);
+    if (card == 0 || card > 0x7FFFFFFFull || stride > 0x7FFFFFFFull) return false;
+    a->key[k].buf_idx = p->cols[kc].buf_idx;
+    a->key[k].width = p->cols[kc].width;
+    a->key[k].kind = p->cols[kc].kind;
+    a->key_nullable[k] = p->keys[k].nullable;
+    a->key_null[k] = p->keys[k].null_val;
+    a->key_min[k] = p->key_min[k];
+    a->null_has_entry[k] = p->key_has_nulls[k] && p->keys[k].nullable;
+    a->key_translated[k] = p->key_null_translated[k];
+    a->key_card[k] = static_cast<uint32_t>(card);
+    a->key_stride[k] = static_cast<uint32_t>(stride);
+    stride *= card;
+  }
   a->entry_count = p->entry_count;
   a->row_bytes = static_cast<uint32_t>(p->row_size_quad) * 8;
   if (a->row_bytes == 0 || a->row_bytes > 256) return false;
-  if (!p->keyless) {  // the layout's key slot: quad 0 of the row (get_group_value_fast)
-    a->keyslot_off[0] = 0;
-    a->keyslot_width[0] = 8;
-    a->keyslot_translated[0] = 1;
-    a->nkeyslots = 1;
+  if (!p->keyless) {  // the layout's key slots: quads 0 .. keys - 1 of the row (get_group_value_fast / perfect_key_hash rows)
+    for (int k = 0; k < p->key_count; ++k) {
+      a->keyslot_off[a->nkeyslots] = 8 * k;
+      a->keyslot_width[a->nkeyslots] = 8;
+      a->keyslot_key[a->nkeyslots] = k;
+      a->keyslot_translated[a->nkeyslots] = 1;
+      ++a->nkeyslots;
+    }
   }
   int arg_col[kPpMaxArgs] = {-1, -1};
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     if (tg.agg == HDK_AGG_ID) {
-      if (tg.key_idx != 0) return false;
+      if (tg.key_idx < 0 || tg.key_idx >= p->key_count) return false;
       if (tg.slot_width == 0) continue;
       if (a->nkeyslots == kPpMaxKeySlots || (tg.slot_width != 4 && tg.slot_width != 8)) return false;
       a->keyslot_off[a->nkeyslots] = tg.slot_off;
       a->keyslot_width[a->nkeyslots] = tg.slot_width;
+      a->keyslot_key[a->nkeyslots] = tg.key_idx;
+      a->keyslot_translated[a->nkeyslots] = 0;
       ++a->nkeyslots;
       continue;
     }
