@@ -621,9 +621,14 @@ static int32_t pb_launch(const PbArgs& a, const hdk_hip_device_properties* props
   const unsigned cu = static_cast<unsigned>(props->num_cu);
   hipLaunchKernelGGL((k_pb_scatter<TW, VR>), dim3(2 * cu), dim3(kPbBlock), lds_sc, s, a);
   if (a.two_level) {
-    unsigned g2 = a.nb1 * kPbXcds;
-    if (g2 > 3 * cu) g2 = 3 * cu;
-    hipLaunchKernelGGL((k_pb_scatter2<TW, VR>), dim3(g2), dim3(kPbBlock), lds_sc, s, a);
+    // level 2: `members2` blocks per level-1 bin, a bin's blocks congruent modulo 8 (one XCD); about three resident blocks per CU
+    PbArgs a2 = a;
+    const unsigned bins8 = (a.nb1 + kPbXcds - 1) / kPbXcds;
+    unsigned m2 = (3 * cu) / (bins8 * kPbXcds);
+    if (m2 < 1) m2 = 1;
+    if (m2 > 16) m2 = 16;
+    a2.members2 = m2;
+    hipLaunchKernelGGL((k_pb_scatter2<TW, VR>), dim3(bins8 * kPbXcds * m2), dim3(kPbBlock), lds_sc, s, a2);
   }
   const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * (4 + 8 * (TW - 1));
   HDK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_build<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -41,6 +41,8 @@ struct PbArgs {
   uint32_t fpc_log2;         // fine slices per level-1 bin = 1 << fpc_log2 (0: one level)
   uint32_t nb1;              // level-1 bins
   uint32_t two_level;
+  uint32_t members2;         // level 2: blocks per level-1 bin
+  uint32_t pad1_;
   uint64_t cap1;             // tuples of a (bin, XCD) sub-slab
   uint64_t cap2;             // tuples of a slice (level 2): its slot count -- more means a duplicate
   int64_t* tuples1;          // [nb1][kPbXcds][cap1][TW]
@@ -165,11 +167,23 @@ __global__ __launch_bounds__(kPbBlock) void k_pb_scatter2(PbArgs a) {
   }
   const uint32_t fmask = (1u << a.fpc_log2) - 1u;
   bool dup = false;
-  for (uint32_t sub = blockIdx.x; sub < a.nb1 * kPbXcds; sub += gridDim.x) {
-    const uint32_t b1 = sub / kPbXcds;
+  // Blocks b with b % 8 == c % 8 work on level-1 bin c, `members` of them per bin (block ids are dealt to the XCDs round
+  // robin: all writers of a slice's slab then sit behind ONE L2 and the partial lines at the ends of their runs merge there;
+  // an affinity for speed, any placement is correct).  The bin's eight sub-slabs are one sequence of tiles, dealt to the
+  // members in turn.
+  const uint32_t members = a.members2;
+  const uint32_t lane8 = blockIdx.x % kPbXcds, idx8 = blockIdx.x / kPbXcds;
+  const uint32_t member = idx8 % members;
+  for (uint32_t b1 = lane8 + kPbXcds * (idx8 / members); b1 < a.nb1; b1 += kPbXcds * (gridDim.x / (kPbXcds * members))) {
+   uint32_t turn = 0;
+   for (uint32_t x8 = 0; x8 < kPbXcds; ++x8) {
+    const uint32_t sub = b1 * kPbXcds + x8;
     const uint64_t n = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(sub) * kPbCursorStride]), a.cap1);
     const int64_t* src = a.tuples1 + static_cast<uint64_t>(sub) * a.cap1 * TW;
-    for (uint64_t t0 = 0; t0 < n; t0 += kTile) {
+    for (uint64_t t0 = 0; t0 < n; t0 += kTile, ++turn) {
+      if (turn % members != member) {
+        continue;
+      }
       int64_t tup[VR][TW];
       uint32_t bin[VR];
       bool live[VR];
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pb_scatter2(PbArgs a) {
           },
           [&](uint32_t f, uint64_t pos) { return static_cast<uint64_t>((b1 << a.fpc_log2) + f) * a.cap2 + pos; });
     }
+   }
   }
   if (__any(dup) && (threadIdx.x & (kWave - 1)) == 0) {
     atomicMin(a.dev_err, -1);

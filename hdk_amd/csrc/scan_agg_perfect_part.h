@@ -57,6 +57,8 @@ struct PpArgs {
   uint32_t fpc_log2;         // slices per level-1 bin = 1 << fpc_log2 (0: one level)
   uint32_t nb1;
   uint32_t two_level;
+  uint32_t members2;         // level 2: blocks per level-1 bin
+  uint32_t pad1_;
   // packed: ONE integer argument inside 32 bits by the column statistics travels in the entry's word -- [argument : entry],
   // 8 bytes a tuple instead of 16 (its NULL as INT32_MIN; a value the statistics did not announce raises the flag)
   uint32_t packed;
@@ -72,7 +74,8 @@ struct PpArgs {
 };
 
 // ---- pass A -------------------------------------------------------------------------------------------------------------
-template <int TW, int VR>
+// NK: key columns the code is compiled for (1: the single-key form -- entry = key - min, no strides; kPpMaxKeys: any number)
+template <int TW, int VR, int NK>
 __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
   constexpr int kTile = kPbBlock * VR;
   __shared__ uint32_t s_cnt[kPbMaxBins];
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
       uint32_t bin[VR];
       // all loads of the batch first (the decoder's width switch is wave-uniform: one branch per column, the row loop inside --
       // with the switch inside the row loop the loads went out one at a time and the pass ran at half the copy rate)
-      int64_t kv[kPpMaxKeys][VR], xv[VR];
+      int64_t kv[NK][VR], xv[VR];
 #pragma unroll
-      for (int ki = 0; ki < kPpMaxKeys; ++ki) {
+      for (int ki = 0; ki < NK; ++ki) {
         if (ki < a.nkeys) {
           const int8_t* kb = cols[a.key[ki].buf_idx];
           if (a.key[ki].width == 8) {
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
         uint64_t entry = 0;
         bool inside = true;
 #pragma unroll
-        for (int ki = 0; ki < kPpMaxKeys; ++ki) {
+        for (int ki = 0; ki < NK; ++ki) {
           if (ki < a.nkeys) {
             int64_t k = kv[ki][r];
             if (a.key_nullable[ki] && k == a.key_null[ki]) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
             }
             const uint64_t term = static_cast<uint64_t>(k) - static_cast<uint64_t>(a.key_min[ki]);
             inside = inside && term < a.key_card[ki];
-            entry += term * a.key_stride[ki];
+            entry += NK == 1 ? term : term * a.key_stride[ki];
           }
         }
         if (live[r] && !(inside && entry < a.entry_count)) {
@@ -225,11 +228,23 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter2(PpArgs a) {
     return;
   }
   const uint32_t fmask = (1u << a.fpc_log2) - 1u;
-  for (uint32_t sub = blockIdx.x; sub < a.nb1 * kPbXcds; sub += gridDim.x) {
-    const uint32_t b1 = sub / kPbXcds;
+  // Blocks b with b % 8 == c % 8 work on level-1 bin c, `members` of them per bin (block ids are dealt to the XCDs round
+  // robin: all writers of a slice's slab then sit behind ONE L2 and the partial lines at the ends of their runs merge there;
+  // an affinity for speed, any placement is correct).  The bin's eight sub-slabs are one sequence of tiles, dealt to the
+  // members in turn.
+  const uint32_t members = a.members2;
+  const uint32_t lane8 = blockIdx.x % kPbXcds, idx8 = blockIdx.x / kPbXcds;
+  const uint32_t member = idx8 % members;
+  for (uint32_t b1 = lane8 + kPbXcds * (idx8 / members); b1 < a.nb1; b1 += kPbXcds * (gridDim.x / (kPbXcds * members))) {
+   uint32_t turn = 0;
+   for (uint32_t x8 = 0; x8 < kPbXcds; ++x8) {
+    const uint32_t sub = b1 * kPbXcds + x8;
     const uint64_t n = min(static_cast<uint64_t>(a.fill1[static_cast<size_t>(sub) * kPbCursorStride]), a.cap1);
     const int64_t* src = a.tuples1 + static_cast<uint64_t>(sub) * a.cap1 * TW;
-    for (uint64_t t0 = 0; t0 < n; t0 += kTile) {
+    for (uint64_t t0 = 0; t0 < n; t0 += kTile, ++turn) {
+      if (turn % members != member) {
+        continue;
+      }
       int64_t tup[VR][TW];
       uint32_t bin[VR];
       bool live[VR];
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter2(PpArgs a) {
           },
           [&](uint32_t f, uint64_t pos) { return static_cast<uint64_t>((b1 << a.fpc_log2) + f) * a.cap2 + pos; });
     }
+   }
   }
 }
 
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_aggregate(PpArgs a) {
             if (a.nkeyslots) {  // agg_id / the layout's key slots: every row of a group stores the same keys
               for (int ks = 0; ks < a.nkeyslots; ++ks) {
                 const int ki = a.keyslot_key[ks];
-                const uint32_t term = (entry / a.key_stride[ki]) % a.key_card[ki];
+                const uint32_t term = a.nkeys == 1 ? entry : (entry / a.key_stride[ki]) % a.key_card[ki];
                 const int64_t stored = static_cast<int64_t>(static_cast<uint64_t>(a.key_min[ki]) + term);
                 const int64_t key = (!a.keyslot_translated[ks] && a.null_has_entry[ki] && stored == a.key_translated[ki]) ? a.key_null[ki] : stored;
                 if (a.keyslot_width[ks] == 4) {

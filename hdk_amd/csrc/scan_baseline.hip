@@ -834,11 +834,20 @@ static void pp_launch(const PpArgs& a, const hdk_hip_device_properties* props, h
   const unsigned cu = static_cast<unsigned>(props->num_cu);
   unsigned per_cu = 2;
   if (const char* e = getenv("HDK_HIP_PP_BLOCKS_PER_CU")) per_cu = static_cast<unsigned>(atoi(e)) ? static_cast<unsigned>(atoi(e)) : 2u;
-  hipLaunchKernelGGL((k_pp_scatter<TW, VR>), dim3(per_cu * cu), dim3(kPbBlock), lds_sc, s, a);
+  if (a.nkeys == 1) {
+    hipLaunchKernelGGL((k_pp_scatter<TW, VR, 1>), dim3(per_cu * cu), dim3(kPbBlock), lds_sc, s, a);
+  } else {
+    hipLaunchKernelGGL((k_pp_scatter<TW, VR, kPpMaxKeys>), dim3(per_cu * cu), dim3(kPbBlock), lds_sc, s, a);
+  }
   if (a.two_level) {
-    unsigned g2 = a.nb1 * kPbXcds;
-    if (g2 > 3 * cu) g2 = 3 * cu;
-    hipLaunchKernelGGL((k_pp_scatter2<TW, VR>), dim3(g2), dim3(kPbBlock), lds_sc, s, a);
+    // level 2: `members2` blocks per level-1 bin, a bin's blocks congruent modulo 8 (one XCD); about three resident blocks per CU
+    PpArgs a2 = a;
+    const unsigned bins8 = (a.nb1 + kPbXcds - 1) / kPbXcds;
+    unsigned m2 = (3 * cu) / (bins8 * kPbXcds);
+    if (m2 < 1) m2 = 1;
+    if (m2 > 16) m2 = 16;
+    a2.members2 = m2;
+    hipLaunchKernelGGL((k_pp_scatter2<TW, VR>), dim3(bins8 * kPbXcds * m2), dim3(kPbBlock), lds_sc, s, a2);
   }
   const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * a.row_bytes;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pp_aggregate<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
