@@ -58,7 +58,17 @@ inline bool plan_reads_small_dates(const hdk_hip_plan* p) {
 
 // joins only the row-at-a-time interpreter walks: matching sets with more than one row, keyed tables,
 // LEFT joins (the batched interpreter handles inner one-to-one probes)
+// an aggregate plan whose ONE join probes a one-to-many perfect-hash table: the batched interpreter replays the batch once
+// per match (hdk_scan_agg_vec_many; vec_eval.h: vec_round_v).  Projections claim output rows per tile and stay row at a time.
+inline bool plan_is_single_matching_set_join(const hdk_hip_plan* p) {
+  return p->num_joins == 1 && p->joins[0].kind == HDK_JOIN_ONE_TO_MANY && p->query_kind != HDK_Q_PROJECTION &&
+         !getenv("HDK_HIP_NO_BATCHED_MATCHING_SETS");
+}
+
 inline bool needs_join_loops(const hdk_hip_plan* p) {
+  if (plan_is_single_matching_set_join(p)) {
+    return false;
+  }
   // (OR / NOT filter programs run in the batched interpreters too: vec_eval.h, filter_program_pass_v)
   for (int j = 0; j < p->num_joins; ++j) {
     const hdk_hip_join& jn = p->joins[j];

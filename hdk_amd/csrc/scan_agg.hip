@@ -796,8 +796,9 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
       k = keys_kernel(ka, s.block);
     } else if (s.strategy == STRAT_LDS) {
       k = scalar ? reinterpret_cast<const void*>(hdk_scan_agg_generic)
-                 : (p->num_joins ? (plan_has_keyed_join(p) ? reinterpret_cast<const void*>(hdk_scan_agg_vec_keyed)
-                                                           : reinterpret_cast<const void*>(hdk_scan_agg_vec_join))
+                 : (p->num_joins ? (plan_is_single_matching_set_join(p) ? reinterpret_cast<const void*>(hdk_scan_agg_vec_many)
+                                    : plan_has_keyed_join(p)            ? reinterpret_cast<const void*>(hdk_scan_agg_vec_keyed)
+                                                                        : reinterpret_cast<const void*>(hdk_scan_agg_vec_join))
                                  : reinterpret_cast<const void*>(hdk_scan_agg_vec));
       block = scalar ? kBlock : kVecBlock;
     } else if (s.strategy == STRAT_PROJECT) {
@@ -1036,7 +1037,10 @@ static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s,
   KeysArgs ka;
   if (!force_generic && match_keys(p, s, &ka)) return ka.nvals ? "hdk_scan_agg_keys_values" : "hdk_scan_agg_keys";
   if (needs_join_loops(p) || force_scalar) return "hdk_scan_agg_generic";
-  return p->num_joins ? (plan_has_keyed_join(p) ? "hdk_scan_agg_vec_keyed" : "hdk_scan_agg_vec_join") : "hdk_scan_agg_vec";
+  return p->num_joins ? (plan_is_single_matching_set_join(p) ? "hdk_scan_agg_vec_many"
+                         : plan_has_keyed_join(p)            ? "hdk_scan_agg_vec_keyed"
+                                                             : "hdk_scan_agg_vec_join")
+                      : "hdk_scan_agg_vec";
 }
 
 // ---- hdk_join_agg_direct (scan_join_direct.h): the matcher ------------------------------------------------------------
@@ -1753,7 +1757,9 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     v.entry_count = shape.entry_count;
     v.rep = shape.rep;
     v.run_if = nullptr;
-    if (plan->num_joins && plan_has_keyed_join(plan)) {
+    if (plan_is_single_matching_set_join(plan)) {
+      hipLaunchKernelGGL(hdk_scan_agg_vec_many, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
+    } else if (plan->num_joins && plan_has_keyed_join(plan)) {
       hipLaunchKernelGGL(hdk_scan_agg_vec_keyed, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
     } else if (plan->num_joins) {
       hipLaunchKernelGGL(hdk_scan_agg_vec_join, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);

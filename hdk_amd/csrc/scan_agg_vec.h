@@ -52,7 +52,7 @@ HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
   }
 }
 
-template <bool J, bool KEYED = false>
+template <bool J, bool KEYED = false, bool MANY = false>
 HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
@@ -81,7 +81,7 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   const bool grouped = p->query_kind != HDK_Q_NON_GROUPED;
   const int nt = p->num_targets;
 
-  VecCtxT<J, KEYED> c;
+  VecCtxT<J, KEYED, MANY> c;
   vec_ctx_init(c, p, tid, kVecBlock);
   int32_t err = 0;
 
@@ -95,9 +95,11 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       HDK_WATCH_TILE(watch, err, tile)
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
-      bool pass[VR];
-      vec_ctx_tile(c, row0, nrows, pass);  // dead slots re-read a valid row; their results are dropped
-      rows_pass_v(c, a.kp.join_hash_tables, pass, err);
+      bool pass0[VR];
+      vec_ctx_tile(c, row0, nrows, pass0);  // dead slots re-read a valid row; their results are dropped
+      rows_pass_v(c, a.kp.join_hash_tables, pass0, err);
+      // group entry + aggregate updates of the batch's rows that are still in
+      auto aggregate = [&](bool (&pass)[VR]) {
       int64_t entry[VR];
       if (grouped) {
         perfect_hash_entry_v(c, entry, pass, err);
@@ -146,6 +148,19 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
           }
         }
       }
+          };
+      if constexpr (MANY) {
+        // a matching-set join: the batch once per match (round i: every row's i-th partner), vec_eval.h: vec_round_v
+        for (int round = 0;; ++round) {
+          bool live[VR];
+          if (!vec_round_v(c, round, pass0, live, err)) {
+            break;
+          }
+          aggregate(live);
+        }
+      } else {
+        aggregate(pass0);
+      }
     }
     frag_tile_begin += ntiles;
   }
@@ -185,6 +200,10 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_join(Ve
 // hash and a short linear walk per row; a kernel of its own so that its registers are not the perfect-hash plans' problem
 extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_keyed(VecArgs a) {
   scan_agg_vec_body<true, true>(a);
+}
+// ... and plans whose ONE join probes a one-to-many perfect-hash table: the batch is replayed once per match
+extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_many(VecArgs a) {
+  scan_agg_vec_body<true, false, true>(a);
 }
 
 }  // namespace hdk

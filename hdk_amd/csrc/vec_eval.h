@@ -43,10 +43,17 @@ HDK_DEV cplan_t to_const_as(const hdk_hip_plan* p) {
 }
 typedef long long __attribute__((ext_vector_type(2))) i64x2;
 
-template <bool J, bool KEYED = false>
+template <bool J, bool KEYED = false, bool MANY = false>
 struct VecCtxT {
   static constexpr bool kJoins = J;  // false: the plan has no joins; all probe state compiles away
   static constexpr bool kKeyed = KEYED;  // some join probes a keyed ("baseline") one-to-one table: a kernel of its own
+  // MANY: the plan's ONE join probes a one-to-many perfect-hash table (matching sets, HashJoin::codegenMatchingSet,
+  // QE/JoinHashTable/HashJoin.cpp:149-197): the batch is replayed once per match -- round i takes every row's i-th
+  // partner (vec_round_v, called by the kernel body); the filters on joined columns run per round
+  static constexpr bool kMany = MANY;
+  int32_t mpos[MANY ? VR : 1];  // the row's matching set: first position in the table's row-id area, number of partners
+  int32_t mcnt[MANY ? VR : 1];
+  const int32_t* mids;          // the table's row-id area
   cplan_t plan;
   const int8_t* const* cols;  // col_buffers[frag]
   int64_t row0;               // first row of the tile; slot r of lane `tid` is row0 + r*blk + tid
@@ -87,6 +94,7 @@ HDK_DEV void vec_ctx_init(VecCtx& c, cplan_t p, int tid, int blk) {
   }
   c.jmiss0 = 0;
   c.jmiss1 = 0;
+  c.mids = nullptr;
   c.fused0 = nullptr;
   c.fused1 = nullptr;
   c.fstride0 = 0;
@@ -577,6 +585,27 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
                                             ? reinterpret_cast<const int32_t*>(join_hash_tables)
                                             : reinterpret_cast<const int32_t*>(join_hash_tables[jn.table_idx]);
     const bool inner = jn.type == HDK_JOIN_INNER || jn.type == HDK_JOIN_SEMI;  // (SEMI: INNER over a first-row-wins table)
+    if constexpr (VecCtx::kMany) {
+      // [first position | count | row ids] (fill_one_to_many_hash_table): two probes of the slot, no row id yet
+      const int64_t ec = jn.entry_count;
+      c.mids = table + 2 * ec;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        int64_t slot;
+        const int64_t pos = probe_join_g(jn, table, pass[r] ? key[r] : jn.min_key, &slot);
+        int32_t n = 0;
+        if (pos >= 0) {
+          n = gload<int32_t>(reinterpret_cast<const int8_t*>(table), ec + slot, false);
+        }
+        c.mpos[r] = pos < 0 ? 0 : static_cast<int32_t>(pos);
+        c.mcnt[r] = pass[r] ? n : 0;
+        if (inner) {
+          pass[r] = pass[r] && n > 0;
+        }  // (LEFT: a row without partners takes ONE round with its inner columns NULL; ANTI: only such rows go on)
+        c.jref0[r] = 0;
+      }
+      return;  // the rounds (and the filters on joined columns) are the caller's: vec_round_v
+    }
     if constexpr (VecCtx::kKeyed) {
       if (jn.kind == HDK_JOIN_KEYED_ONE_TO_ONE) {
         // composite / wide keys: the key expressions for the batch, then one probe per live row (a rejected row
@@ -710,6 +739,49 @@ HDK_DEV void rows_pass_v(VecCtx& c, const int64_t* join_hash_tables, bool (&pass
       }
     }
   }
+}
+
+// Round `round` of a batch whose join is a matching-set join (VecCtx::kMany; rows_pass_v has run): live[r] = row r takes part
+// in this round -- it has a `round`-th partner, or it is a LEFT / ANTI row without any taking its single round -- and the
+// join's row references / miss mask are set for it; then the filters on joined columns.  Returns whether any row of the wave
+// is still in (JoinLoop's Set form, QE/IRCodegen.cpp:497-667: the loop body once per match).
+template <class VecCtx>
+HDK_DEV bool vec_round_v(VecCtx& c, int round, const bool (&pass)[VR], bool (&live)[VR], int32_t& err) {
+  cplan_t p = c.plan;
+  cjoin_t jn = p->joins[0];
+  const bool left = jn.type == HDK_JOIN_LEFT, anti = jn.type == HDK_JOIN_ANTI;
+  uint32_t miss = 0;
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    const int32_t n = c.mcnt[r];
+    const bool lone = (left || anti) && n == 0 && round == 0;  // no partner: one round, inner columns NULL
+    live[r] = pass[r] && ((!anti && round < n) || lone);
+    miss |= lone ? 1u << r : 0u;
+    int32_t rid = 0;
+    if (live[r] && !lone) {
+      rid = gload<int32_t>(reinterpret_cast<const int8_t*>(c.mids), static_cast<int64_t>(c.mpos[r]) + round, false);
+    }
+    c.jref0[r] = rid;
+    any = any || live[r];
+  }
+  c.jmiss0 = miss;
+  if (!__any(any)) {
+    return false;
+  }
+  if (p->num_filter_ops) {
+    if (p->filter_after_joins) {
+      filter_program_pass_v(c, live, err);
+    }
+  } else {
+    const int nq = p->num_quals;
+    for (int q = 0; q < nq; ++q) {
+      if (p->quals[q].after_joins) {
+        eval_qual_v(c, p->quals[q], live, err);
+      }
+    }
+  }
+  return true;
 }
 
 // group key #k for the batch (perfect hash: NULL translated)

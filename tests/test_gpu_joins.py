@@ -32,7 +32,9 @@ def test_aggregates_over_general_joins(oracle, gpu_executor_factory, case):
         # INNER / LEFT / SEMI / ANTI: the batched ones)
         names = step.kernel_names()
         one_to_one = all(i["kind"] in (A.JOIN_ONE_TO_ONE, A.JOIN_KEYED_ONE_TO_ONE) for i in cp.join_infos)
-        assert names.startswith(("hdk_scan_agg_vec_join", "hdk_scan_agg_vec_keyed") if one_to_one else "hdk_scan_agg_generic"), (name, names)
+        many = len(cp.join_infos) == 1 and cp.join_infos[0]["kind"] == A.JOIN_ONE_TO_MANY  # replayed per match in the batched kernel
+        want_k = ("hdk_scan_agg_vec_join", "hdk_scan_agg_vec_keyed") if one_to_one else ("hdk_scan_agg_vec_many" if many else "hdk_scan_agg_generic")
+        assert names.startswith(want_k), (name, names)
         res = step.run()
         assert_buffers_equal(cp, res.buffer, want)
         step.free()
