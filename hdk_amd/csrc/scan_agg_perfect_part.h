@@ -43,6 +43,16 @@ struct PpArgs {
   int32_t nargs;
   int32_t nquals;
   ProjFastCol arg[kPpMaxArgs];
+  // an argument may be ONE integer step over plain columns: a op b / a op literal (eval_expr's checked + - *), computed by
+  // the scatter pass; the tuple carries the value (NULL operands give the step's NULL, which the target skips)
+  struct ArgExpr {
+    int32_t form;            // 0: the column itself; 1: a op column b; 2: a op literal
+    int32_t op;              // HDK_OP_ADD / SUB / MUL
+    int32_t check_width;
+    int32_t a_nullable, b_nullable, pad_;
+    ProjFastCol b;
+    int64_t a_null, b_null, lit, null_out;
+  } ax[kPpMaxArgs];
   ProjFastQual q[kMaxPlainQuals];
   int32_t ntargets;          // aggregate targets (PartTarget); projected keys apart
   int32_t nkeyslots;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
   const uint32_t bin_shift = a.slice_log2 + a.fpc_log2;
-  bool stranger = false, stale = false;
+  bool stranger = false, stale = false, overflow = false;
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
@@ -175,7 +185,22 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
         tup[r][0] = static_cast<int64_t>(e32);
 #pragma unroll
         for (int w = 1; w < TW; ++w) {
-          tup[r][w] = live[r] ? decode_col_g(cols[a.arg[w - 1].buf_idx], a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true) : 0;
+          int64_t va = live[r] ? decode_col_g(cols[a.arg[w - 1].buf_idx], a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true) : 0;
+          const PpArgs::ArgExpr& ex = a.ax[w - 1];
+          if (ex.form) {
+            const int64_t vb = ex.form == 1 ? (live[r] ? decode_col_g(cols[ex.b.buf_idx], ex.b.width, ex.b.kind, row[r], true) : 0) : ex.lit;
+            if ((ex.a_nullable && va == ex.a_null) || (ex.form == 1 && ex.b_nullable && vb == ex.b_null)) {
+              va = ex.null_out;
+            } else {
+              int64_t res;
+              const bool ovf = ex.op == HDK_OP_ADD ? checked_arith(HDK_OP_ADD, va, vb, ex.check_width, &res)
+                                                   : (ex.op == HDK_OP_SUB ? checked_arith(HDK_OP_SUB, va, vb, ex.check_width, &res)
+                                                                          : checked_arith(HDK_OP_MUL, va, vb, ex.check_width, &res));
+              overflow |= live[r] && ovf;
+              va = res;
+            }
+          }
+          tup[r][w] = va;
         }
         if (TW == 1 && a.packed) {
           const int64_t x = xv[r];
@@ -203,6 +228,9 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
   }
   if (__any(stale) && (threadIdx.x & (kWave - 1)) == 0) {
     atomicMax(a.flag, 1u);  // a value outside what the statistics announced: the global-atomics kernel reads the columns
+  }
+  if (__any(overflow) && (threadIdx.x & (kWave - 1)) == 0) {
+    record_error(a.kp.error_code, HDK_HIP_ERR_OVERFLOW_OR_UNDERFLOW);
   }
 }
 

@@ -726,6 +726,7 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
     }
   }
   int arg_col[kPpMaxArgs] = {-1, -1};
+  bool any_expr = false;
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     if (tg.agg == HDK_AGG_ID) {
@@ -755,17 +756,48 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
     d.arg_null_val = tg.arg.null_val;
     d.arg_nullable = tg.arg.nullable;
     if (tg.has_arg) {
-      int c;
-      if (!plain_outer_col(p, tg.arg, &c)) return false;
+      // a plain column, or one checked integer step over plain columns: a op b / a op literal
+      const hdk_hip_expr& e = tg.arg;
+      if (e.nsteps > 1 || e.leaf0.kind != HDK_LEAF_COL || p->cols[e.leaf0.col].table != 0 || p->cols[e.leaf0.col].kind == HDK_COL_SMALL_DATE) return false;
+      const int c = e.leaf0.col;
       const hdk_hip_col& col = p->cols[c];
+      PpArgs::ArgExpr ex;
+      memset(&ex, 0, sizeof(ex));
+      if (e.nsteps == 1) {
+        const hdk_hip_step& sp = e.steps[0];
+        if (col.kind != HDK_COL_INT || tg.arg_is_fp || sp.out_class != HDK_VC_INT) return false;
+        if (sp.op != HDK_OP_ADD && sp.op != HDK_OP_SUB && sp.op != HDK_OP_MUL) return false;
+        if (tg.skip_null && (e.null_val != sp.null_out || tg.null_val != sp.null_out)) return false;
+        if (!tg.skip_null && (e.leaf0.nullable || sp.rhs.nullable)) return false;
+        ex.op = sp.op;
+        ex.check_width = sp.check_width;
+        ex.a_nullable = e.leaf0.nullable;
+        ex.a_null = e.leaf0.null_val;
+        ex.null_out = sp.null_out;
+        if (sp.rhs.kind == HDK_LEAF_INT) {
+          ex.form = 2;
+          ex.lit = sp.rhs.ival;
+        } else if (sp.rhs.kind == HDK_LEAF_COL && p->cols[sp.rhs.col].table == 0 && p->cols[sp.rhs.col].kind == HDK_COL_INT) {
+          ex.form = 1;
+          ex.b.buf_idx = p->cols[sp.rhs.col].buf_idx;
+          ex.b.width = p->cols[sp.rhs.col].width;
+          ex.b.kind = p->cols[sp.rhs.col].kind;
+          ex.b_nullable = sp.rhs.nullable;
+          ex.b_null = sp.rhs.null_val;
+        } else {
+          return false;
+        }
+      }
       int w = -1;
       for (int i = 0; i < a->nargs; ++i) {
-        if (arg_col[i] == c) w = i;
+        if (arg_col[i] == c && memcmp(&a->ax[i], &ex, sizeof(ex)) == 0) w = i;
       }
       if (w < 0) {
         if (a->nargs == kPpMaxArgs) return false;
         w = a->nargs++;
         arg_col[w] = c;
+        a->ax[w] = ex;
+        any_expr = any_expr || ex.form != 0;
         a->arg[w].buf_idx = col.buf_idx;
         a->arg[w].width = col.width;
         a->arg[w].kind = col.kind;
@@ -795,7 +827,7 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
   if (a->cap1 > 0xFFFFFFF0ull || a->cap2 > 0xFFFFFFF0ull) return false;
   auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   l->tw = 1 + a->nargs;
-  if (a->nargs == 1 && arg_col[0] >= 0 && !(ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) {
+  if (a->nargs == 1 && arg_col[0] >= 0 && !any_expr && !(ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) {
     const hdk_hip_col& c = p->cols[arg_col[0]];
     // (nullable: some target skips this column's NULLs with the column's own sentinel -- the leaf of any of them says so)
     int64_t nullv = 0;
