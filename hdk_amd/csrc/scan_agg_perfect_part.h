@@ -159,6 +159,35 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
           }
         }
       }
+      // argument columns (and the second operand of an expression argument): the same, loads first
+      int64_t av[TW > 1 ? TW - 1 : 1][VR], bv[TW > 1 ? TW - 1 : 1][VR];
+#pragma unroll
+      for (int w = 1; w < TW; ++w) {
+        const int8_t* ab = cols[a.arg[w - 1].buf_idx];
+        if (a.arg[w - 1].width == 8 && a.arg[w - 1].kind != HDK_COL_FLOAT) {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            av[w - 1][r] = gload<int64_t>(ab, row[r], true);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            av[w - 1][r] = decode_col_g(ab, a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true);
+          }
+        }
+        if (a.ax[w - 1].form == 1) {
+          const int8_t* bb = cols[a.ax[w - 1].b.buf_idx];
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            bv[w - 1][r] = decode_col_g(bb, a.ax[w - 1].b.width, a.ax[w - 1].b.kind, row[r], true);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            bv[w - 1][r] = 0;
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
         uint64_t entry = 0;
@@ -185,10 +214,10 @@ __global__ __launch_bounds__(kPbBlock) void k_pp_scatter(PpArgs a) {
         tup[r][0] = static_cast<int64_t>(e32);
 #pragma unroll
         for (int w = 1; w < TW; ++w) {
-          int64_t va = live[r] ? decode_col_g(cols[a.arg[w - 1].buf_idx], a.arg[w - 1].width, a.arg[w - 1].kind, row[r], true) : 0;
+          int64_t va = av[w - 1][r];
           const PpArgs::ArgExpr& ex = a.ax[w - 1];
           if (ex.form) {
-            const int64_t vb = ex.form == 1 ? (live[r] ? decode_col_g(cols[ex.b.buf_idx], ex.b.width, ex.b.kind, row[r], true) : 0) : ex.lit;
+            const int64_t vb = ex.form == 1 ? bv[w - 1][r] : ex.lit;
             if ((ex.a_nullable && va == ex.a_null) || (ex.form == 1 && ex.b_nullable && vb == ex.b_null)) {
               va = ex.null_out;
             } else {
