@@ -97,6 +97,25 @@ __global__ __launch_bounds__(kPbBlock) void k_pb_scatter(PbArgs a) {
           ev[r] = i < ch.num_elems ? join_elem(ch.col_buff, i, elem_sz, a.ti.column_type) : 0;
         }
       }
+      // payload words: the same, all loads of a column first (8-byte integer / double columns without the decoder)
+      int64_t pv[TW > 1 ? TW - 1 : 1][VR];
+#pragma unroll
+      for (int w = 1; w < TW; ++w) {
+        const int8_t* pb = a.pcols[w - 1];
+        if (a.pwidths[w - 1] == 8 && a.pkinds[w - 1] != HDK_COL_FLOAT) {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
+            pv[w - 1][r] = i < ch.num_elems ? __builtin_nontemporal_load(reinterpret_cast<const int64_t*>(pb) + index_base + i) : 0;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
+            pv[w - 1][r] = i < ch.num_elems ? decode_col(pb, a.pwidths[w - 1], a.pkinds[w - 1], static_cast<int64_t>(index_base + i)) : 0;
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
         const size_t i = tile * kTile + static_cast<size_t>(r) * kPbBlock + tid;
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(kPbBlock) void k_pb_scatter(PbArgs a) {
         tup[r][0] = static_cast<int64_t>((static_cast<uint64_t>(rid) << 32) | slot32);
 #pragma unroll
         for (int w = 1; w < TW; ++w) {
-          tup[r][w] = live[r] ? decode_col(a.pcols[w - 1], a.pwidths[w - 1], a.pkinds[w - 1], static_cast<int64_t>(index_base + i)) : 0;
+          tup[r][w] = live[r] ? pv[w - 1][r] : 0;
         }
       }
       pb_scatter_batch<TW, VR>(
