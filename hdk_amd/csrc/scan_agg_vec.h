@@ -198,7 +198,7 @@ extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_join(Ve
 }
 // ... and plans in which some inner-like join probes a KEYED one-to-one table (composite or wide keys): the probe is a
 // hash and a short linear walk per row; a kernel of its own so that its registers are not the perfect-hash plans' problem
-extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_keyed(VecArgs a) {
+extern "C" __global__ __launch_bounds__(kVecBlock, 2) void hdk_scan_agg_vec_keyed(VecArgs a) {  // (two waves per SIMD: 256 registers; unbounded it took 296 and ran one)
   scan_agg_vec_body<true, true>(a);
 }
 // ... and plans whose ONE join probes a one-to-many perfect-hash table: the batch is replayed once per match
