@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Arg
 
 // dynamic LDS: [entry_count x wpe x rep] aggregate words | int32 payload[slice]
 #ifndef HDK_S2_K_GROUPED
-#define HDK_S2_K_GROUPED 8  // joined rows per batch (4 or 8) of the grouped / the non-grouped form: 8 amortises the scalar dispatch (c3g 7.83 -> 7.6 ms, c3m 7.7 -> 7.6)
+#define HDK_S2_K_GROUPED 6  // joined rows per batch of the grouped / the non-grouped form: the scalar dispatch amortised over six rows; eight spill at the 128 registers a 1 024-thread block leaves (two payload words: 164 bytes per lane, c3f 3.47 ms against 3.04)
 #endif
 #ifndef HDK_S2_K_PLAIN
 #define HDK_S2_K_PLAIN 6  // (8 spills 52-112 bytes per lane at the 128 registers a 1 024-thread block leaves; 6 does not and measures the same or better)
