@@ -647,7 +647,7 @@ HDK_DEV void scan_project_direct_body(const ProjFastArgs& a) {
         bits = __builtin_nontemporal_load(mask_at);
       } else {
         bits = pf_filter_tile<R>(a, cols, row0, nrows, tid, MODE == 1);  // pass 1 leaves the lines cached
-        if (a.join) {
+        if (!DENSE && a.join) {  // (a join plan never takes the dense writing pass: its registers stay what they were)
           bits = pf_join_filter<R>(a, cols, row0, tid, bits);
         }
         if (MODE == 0 && masked) {
