@@ -193,7 +193,10 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
 extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs a) {
   scan_agg_vec_body<false>(a);
 }
-extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_join(VecArgs a) {
+#ifndef HDK_VEC_JOIN_WAVES
+#define HDK_VEC_JOIN_WAVES 2
+#endif
+extern "C" __global__ __launch_bounds__(kVecBlock, HDK_VEC_JOIN_WAVES) void hdk_scan_agg_vec_join(VecArgs a) {
   scan_agg_vec_body<true>(a);
 }
 // ... and plans in which some inner-like join probes a KEYED one-to-one table (composite or wide keys): the probe is a
