@@ -190,7 +190,10 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
 // Two instantiations: plans without joins carry no probe state (fewer VGPRs, more waves for the
 // compute-bound taxi Q3/Q4 shapes); plans with joins trade occupancy for 16-byte probe gathers --
 // a random gather is bound by line fetches from HBM, not by occupancy (scripts/microbench/gather.hip).
-extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec(VecArgs a) {
+#ifndef HDK_VEC_WAVES
+#define HDK_VEC_WAVES 3  // (151 registers: three waves per SIMD as it is)
+#endif
+extern "C" __global__ __launch_bounds__(kVecBlock, HDK_VEC_WAVES) void hdk_scan_agg_vec(VecArgs a) {
   scan_agg_vec_body<false>(a);
 }
 #ifndef HDK_VEC_JOIN_WAVES
