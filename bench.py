@@ -45,8 +45,8 @@ class Comm:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus and self.world > 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if self.world != args.gpus:  # (main() has already started the ranks itself when no launcher did)
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: refusing to print a line for another job size")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -280,6 +280,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     elapsed = float(comm.all_reduce(tt, "max").item())
+    ranks_seen = int(comm.all_reduce(torch.ones(1, dtype=torch.int64, device="cuda")).item())  # ranks that really ran
 
     ms_buf = (C.c_float * max(steps, 1))()
     check(L.hdk_hip_collect_scan_times(dev, ms_buf, steps, C.byref(n_ev)))
@@ -406,6 +407,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         "value": value,
         "unit": "rows/s",
         "n_gpus": world,
+        "ranks_seen_by_collective": ranks_seen,
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
@@ -558,6 +560,22 @@ def cpu_baseline(w, args):
             "variants": variants}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU through torch.distributed.run, as a child."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -577,6 +595,15 @@ def main():
                          "exchange; full: plus C2's shard; none)")
     ap.add_argument("--no-multi-gpu-emulation", dest="multi_gpu_emulation", action="store_const", const="none")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # No launcher: start the N ranks ourselves, as a CHILD process -- this parent has not touched HIP (nothing above
+        # imports torch) and never replaces itself.  Rank 0's JSON line is the child's stdout, relayed as it comes.
+        sys.exit(launch_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to print a line for another job size")
 
     comm = Comm(args)
     from hdk_amd._lib import check, lib

@@ -55,7 +55,7 @@
 //            redoes the launch from the columns, the answer is right whatever the metadata said.
 //
 // Multi-GPU (no reference counterpart -- the reference merges per-device tables on the host,
-// QE/Execute.cpp:1224-1336): with `owners` > 1 the keys are split by owner = mulhi32(key_hash, owners) and every
+// QE/Execute.cpp:1224-1336): with `owners` != 0 the keys are split by owner = mulhi32(key_hash, owners) and every
 // owner holds an open-addressing table of its own (`entry_count` is then the OWNER's).  Level 1 scatters a rank's
 // tuples into bins (owner, coarse slab of the owner's table), straight into the send buffer: one segment per owner,
 // [header: tuples per (coarse slab, XCD) | the sub-slabs], every segment the same size whatever the data -- the
@@ -152,7 +152,7 @@ struct PartArgs {
   const int64_t* src_slab[kPartMaxSrc];  // [p1][kPartXcds][sub1][tw]
   const uint32_t* src_fill[kPartMaxSrc]; // [p1][kPartXcds] x src_fill_stride
   // multi-GPU tuple exchange: level 1 writes owner segments
-  uint32_t owners;           // > 1: bins of level 1 are (owner, coarse slab of the owner's table)
+  uint32_t owners;           // != 0: bins of level 1 are (owner, coarse slab of the owner's table)
   int8_t* send;              // [owners] segments of seg_bytes: [header | p1 x kPartXcds sub-slabs of sub1 tuples]
   uint64_t seg_bytes;
   uint64_t seg_header_bytes; // header: uint32 tuples[p1 * kPartXcds], then uint32 flag (0 = complete)
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kPartBlock, (NARROW && LEVEL == 1) ? HDK_PART_L1_WA
   constexpr int tw = TW;  // tuple words, compile time: the tuples of a batch live in registers
   static_assert(!NARROW || (TW == 1 && sizeof(K) == 4), "narrow tuples: one word, 4-byte key");
   const int tid = threadIdx.x;
-  const bool dist = LEVEL == 1 && a.owners > 1;
+  const bool dist = LEVEL == 1 && a.owners != 0;
   const uint32_t nbins = LEVEL == 1 ? (dist ? a.owners * a.p1 : a.p1) : (1u << a.p2_log2);
   const uint32_t gmask = (1u << a.g_log2) - 1;
   const uint32_t cap_stage = part_stage_tuples(nbins, gmask, kTile);

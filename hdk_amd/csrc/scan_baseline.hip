@@ -216,11 +216,13 @@ static bool part_tuple_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options
   return true;
 }
 
-// ---- geometry of the passes for a table of `entry_count` entries (the plan's, or an owner's when `owners` > 1) ------
+// ---- geometry of the passes for a table of `entry_count` entries: the plan's (`owners` == 0, a one-GPU job), or an
+// owner's in a tuple exchange among `owners` >= 1 ranks (one owner: a rank exchanging with itself, the shape RCCL tests
+// on a one-GPU box run) ----------------------------------------------------------------------------------------------
 static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_count, uint32_t owners, PartArgs* pa) {
   if (entry_count < 128) return false;
   pa->entry_count = entry_count;
-  pa->owners = owners > 1 ? owners : 0;
+  pa->owners = owners;
   magic_u32(entry_count, &pa->mod_magic, &pa->mod_shift);
   // regions: as many entries as fit the LDS image
   pa->slots = pa->soa ? kPartSoaSlots : kPartLdsBytes / (p->row_size_quad * 8);
@@ -229,7 +231,7 @@ static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_c
   const uint64_t pf = (static_cast<uint64_t>(entry_count) + pa->slots - 1) / pa->slots;
   // two scatter levels of <= 256 bins each, as even as powers of two allow (longer runs per bin and batch); level 1
   // also separates the owners
-  const uint64_t g = owners > 1 ? owners : 1;
+  const uint64_t g = owners ? owners : 1;
   uint32_t p2_log2 = (pow2_ceil_log2(pf * g) + 1) / 2;
   if (p2_log2 > pow2_ceil_log2(pf)) p2_log2 = pow2_ceil_log2(pf);
   while (((pf + (1ull << p2_log2) - 1) >> p2_log2) * g > static_cast<uint64_t>(kPartMaxBins)) ++p2_log2;
@@ -244,7 +246,7 @@ static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_c
   // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
   // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements (wide tuples on one GPU only).
   pa->g_log2 = 0;
-  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = (pa->p1 < 2 || owners > 1 || pa->narrow) ? 0 : atoi(e);
+  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = (pa->p1 < 2 || owners || pa->narrow) ? 0 : atoi(e);
   if (pa->g_log2) {
     int found = 0;
     for (int64_t k = 1; k < 4096 && found < 2; ++k) {
@@ -275,7 +277,7 @@ static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_c
   pa->cap_ovf = rows / 16 + 4096;
   pa->sub1 = ((pa->cap1 / kPartXcds + kPartXcds * 256) + 15) & ~15ull;  // per-XCD share of a coarse slab, with slack, whole lines for every tuple width
   pa->cap1 = pa->sub1 * kPartXcds;
-  pa->cap_spill = owners > 1 ? rows / 16 + 4096 : static_cast<uint64_t>(pa->p1) * pa->cap1;  // one GPU: slab 1, reused
+  pa->cap_spill = owners ? rows / 16 + 4096 : static_cast<uint64_t>(pa->p1) * pa->cap1;  // one GPU: slab 1, reused
   if (pa->cap1 > 0xFFFFFFF0ull || pa->cap2 > 0xFFFF0000ull || pa->cap_ovf > 0xFFFFFFF0ull) return false;  // 32-bit cursors (and 32-bit tuple indices with look-ahead in pass 3)
   return true;
 }
@@ -285,7 +287,7 @@ static bool match_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_option
   const bool forced = (ko->flags & HDK_HIP_LAUNCH_FORCE_PARTITIONED) != 0;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)) return false;
   if (!forced && (p->entry_count < (2u << 20) || ko->total_rows < (8ull << 20))) return false;
-  return part_tuple_shape(p, ko, pa) && part_geometry(p, ko->total_rows, p->entry_count, 1, pa);
+  return part_tuple_shape(p, ko, pa) && part_geometry(p, ko->total_rows, p->entry_count, 0, pa);
 }
 
 constexpr int32_t kPartitionedNoScratch = -1000;  // internal: scratch for the slabs could not be allocated
@@ -488,7 +490,7 @@ static size_t exchange_cursor_bytes(const PartArgs& pa) {
 
 int32_t exchange_shape(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, int32_t num_owners,
                        uint32_t owner_entry_count, PartArgs* pa, hdk_hip_exchange_shape* out) {
-  HDK_REQUIRE(num_owners >= 2 && num_owners <= kPartMaxSrc, "num_owners must be in [2, %d]", kPartMaxSrc);
+  HDK_REQUIRE(num_owners >= 1 && num_owners <= kPartMaxSrc, "num_owners must be in [1, %d]", kPartMaxSrc);
   HDK_REQUIRE(ko && ko->total_rows, "hdk_hip_kernel_options::total_rows (the per-rank row bound) is required");
   if (plan->query_kind != HDK_Q_BASELINE_HASH || !part_tuple_shape(plan, ko, pa) ||
       !part_geometry(plan, ko->total_rows, owner_entry_count, static_cast<uint32_t>(num_owners), pa)) {

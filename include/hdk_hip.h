@@ -586,7 +586,8 @@ int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf,
  * manager's own stream, which is ordered neither with the legacy default stream nor with a communicator's.
  * ---------------------------------------------------------------------------------------- */
 typedef struct hdk_hip_exchange_shape {
-  uint32_t num_owners;         /* G */
+  uint32_t num_owners;         /* G, 1 ... 32 (one owner: a rank exchanging with itself -- every kernel and the collective run,
+                                  which is how a one-GPU box exercises the RCCL all-to-all) */
   uint32_t owner_entry_count;  /* entries of every owner's table */
   uint32_t tuple_bytes;        /* 8, 16 or 24 */
   uint32_t coarse_per_owner;   /* level-1 bins per owner (G x this <= 256) */

@@ -98,10 +98,48 @@ def test_rccl_branch_with_one_rank_gather_and_fold():
 
 
 def test_rccl_branch_with_one_rank_table_exchange():
-    """(The tuple exchange needs two owners -- hdk_hip_exchange_shape_for refuses one -- so a single rank asked for it takes
-    the agreed fallback: the owner partition of its partial table, RCCL all-to-all with unequal splits, owner re-insert.)"""
-    for pick in ("tuples", "tables"):
-        line = _run_rccl_single_rank("c5", 32_000_000, {"HDK_BENCH_EXCHANGE": pick})
-        assert "owner partition of the partial table" in line["config"]["parallelism"], line["config"]
-        assert line["merge"]["ms"] > 0
-        _all_checks_hold(line)
+    """The owner partition of the rank's partial table, RCCL all-to-all with unequal splits, owner re-insert."""
+    line = _run_rccl_single_rank("c5", 32_000_000, {"HDK_BENCH_EXCHANGE": "tables"})
+    assert "owner partition of the partial table" in line["config"]["parallelism"], line["config"]
+    assert line["merge"]["ms"] > 0
+    _all_checks_hold(line)
+
+
+def test_rccl_branch_with_one_rank_tuple_exchange():
+    """One rank, one owner: scatter to the (single) owner segment, the EQUAL-split all-to-all on RCCL, owner aggregation --
+    the tuple exchange's collective on the real transport, as far as one GPU allows."""
+    line = _run_rccl_single_rank("c5", 32_000_000, {"HDK_BENCH_EXCHANGE": "tuples"})
+    assert "tuples scattered to owner segments" in line["config"]["parallelism"], line["config"]
+    ex = line["exchange"]
+    assert ex["tuple_bytes"] == 8 and all(ex["ms"][k] > 0 for k in ("scatter", "all_to_all", "aggregate"))
+    _all_checks_hold(line)
+    assert line["checks"]["sum_of_sums"] is True and line["checks"]["idempotent"] is True
+    assert line["checks"]["groups_equal_distinct_keys"] is not False
+
+
+def test_plain_python_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses at N = 1): bench.py starts the two ranks itself
+    as a child torch.distributed.run and the line says n_gpus 2, confirmed by an all-reduce of ones."""
+    env = dict(os.environ, HDK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2",
+           "--rows", "64000000", "--extra", "none", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen_by_collective"] == 2
+    _all_checks_hold(line)
+
+
+def test_world_size_mismatch_is_refused():
+    """A launcher environment for another job size: no line, non-zero exit (never a 1-GPU number under --gpus 2)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rows", "32000000",
+           "--extra", "none", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-1000:]
+    assert "WORLD_SIZE" in r.stderr
