@@ -439,6 +439,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include <string.h>
 
 #include "host_match.h"
+#include "scan_bh_host.h"
 #include "scan_agg_fast.h"
 #include "scan_agg_vec.h"
 #include "scan_agg_keys.h"
@@ -2212,7 +2213,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
   for (int j = 0; j < plan->num_joins; ++j) {
     if (plan->joins[j].kind == HDK_JOIN_ONE_TO_ONE_FUSED) {
       HDK_REQUIRE(plan->joins[j].fused_stride >= 1, "fused join table needs fused_stride >= 1");
-      if (shape.strategy == STRAT_GLOBAL || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) ||
+      if ((shape.strategy == STRAT_GLOBAL && !bh_lds_kernel_name(plan, ko)) || (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) ||
           needs_join_loops(plan)) {
         set_error("fused join tables are only read by the batched interpreter kernels");
         return HDK_HIP_ERR_UNSUPPORTED;

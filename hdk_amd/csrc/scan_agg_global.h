@@ -158,6 +158,8 @@ HDK_DEV void g_count(int8_t* slot, int width) {
   }
 }
 
+// (the atomics above are shared with scan_bh.h; the kernel itself belongs to ONE translation unit, scan_baseline.hip)
+#ifdef HDK_SCAN_AGG_GLOBAL_KERNEL
 extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(GlobalArgs a) {
   __shared__ uint64_t s_col_off[2 * HDK_HIP_MAX_TARGETS];  // columnar slot-column offsets
   const hdk_hip_plan* __restrict__ p = a.plan;
@@ -320,5 +322,7 @@ extern "C" __global__ __launch_bounds__(kGlobalBlock) void hdk_scan_agg_global(G
     record_error(a.kp.error_code, err);
   }
 }
+
+#endif  // HDK_SCAN_AGG_GLOBAL_KERNEL
 
 }  // namespace hdk

@@ -7,6 +7,7 @@
 #include "watch.h"
 #include "agg_common.h"
 #include "vec_eval.h"
+#include "scan_bh_decl.h"
 
 namespace hdk {
 
@@ -19,6 +20,10 @@ struct VecArgs {
   uint32_t entry_count;
   uint32_t rep;
   const uint32_t* run_if;  // nullptr: always run; else only when *run_if == 1 (armed behind the sliced join, scan_join_sliced2.h)
+  // BH instantiations (scan_bh.hip): the group table is an open-addressing table in LDS (scan_bh.h); `entry_count` is the
+  // output table's, `rep` the replicas, `slabs` unused
+  uint32_t bh_cap_log2;
+  uint32_t bh_pad_;
 };
 
 HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
@@ -52,10 +57,12 @@ HDK_DEV void vec_lds_op(int32_t wop, int64_t* wp, int64_t v) {
   }
 }
 
-template <bool J, bool KEYED = false, bool MANY = false>
+template <bool J, bool KEYED = false, bool MANY = false, bool BH = false>
 HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ WordLayout wl;
+  __shared__ uint64_t s_col_off[BH ? 2 * HDK_HIP_MAX_TARGETS : 1];
+  __shared__ BhLdsLayout s_ll;  // (BH only; an unused LDS object costs nothing)
   if (a.run_if && *a.run_if != 1) {
     return;  // (the sliced passes did the job -- or the launch was interrupted: 2)
   }
@@ -63,14 +70,22 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     make_word_layout(a.plan, &wl);
+    if constexpr (BH) {
+      bh_layout_identity(wl, &s_ll);
+    }
   }
   __syncthreads();
-  const int wpe = wl.wpe;
+  // (BH: an entry is its wpe words and then the key word)
+  const int wpe = BH ? wl.wpe + 1 : wl.wpe;
   const uint32_t rep = a.rep;
   const uint32_t ew = a.entry_count * wpe;
   const uint32_t total_words = ew * rep;
-  for (uint32_t i = tid; i < total_words; i += kVecBlock) {
-    lds[i] = word_identity(wl.wop[(i / rep) % wpe]);
+  if constexpr (BH) {
+    bh_lds_init(lds, s_ll, a.bh_cap_log2, rep, tid, kVecBlock);
+  } else {
+    for (uint32_t i = tid; i < total_words; i += kVecBlock) {
+      lds[i] = word_identity(wl.wop[(i / rep) % wpe]);
+    }
   }
   __syncthreads();
 
@@ -101,7 +116,38 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
       // group entry + aggregate updates of the batch's rows that are still in
       auto aggregate = [&](bool (&pass)[VR]) {
       int64_t entry[VR];
-      if (grouped) {
+      if constexpr (BH) {
+        // key word of the batch's rows -> entry of the lane's replica (found or claimed)
+        int64_t kw[VR];
+        eval_key_v(c, 0, kw, pass, err);
+        if (p->key_count == 2) {  // two 4-byte keys share the key word, as they share the table's first quad
+          int64_t k1[VR];
+          eval_key_v(c, 1, k1, pass, err);
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            kw[r] = static_cast<int64_t>((static_cast<uint64_t>(k1[r]) << 32) | static_cast<uint32_t>(kw[r]));
+          }
+        } else if (p->key_width == 4) {
+#pragma unroll
+          for (int r = 0; r < VR; ++r) {
+            kw[r] = static_cast<int32_t>(kw[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          entry[r] = 0;
+          if (pass[r]) {
+            const int32_t e = bh_lds_find_or_claim(lds + my_rep, kw[r], a.bh_cap_log2, static_cast<uint32_t>(wpe) * rep,
+                                                   static_cast<uint32_t>(wl.wpe) * rep);
+            if (e < 0) {
+              err = HDK_HIP_ERR_OUT_OF_SLOTS;  // more groups than the plan's table holds
+              pass[r] = false;
+            } else {
+              entry[r] = e;
+            }
+          }
+        }
+      } else if (grouped) {
         perfect_hash_entry_v(c, entry, pass, err);
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
@@ -164,6 +210,18 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
     }
     frag_tile_begin += ntiles;
   }
+  if constexpr (BH) {
+    BhGeom g;
+    g.out_entry_count = a.entry_count;
+    g.cap_log2 = a.bh_cap_log2;
+    g.rep = rep;
+    g.lds_bytes = 0;
+    bh_flush_block<kVecBlock>(a.plan, wl, s_ll, lds, g, a.kp.groupby_buf, s_col_off, tid, err);
+    if (err) {
+      record_error(a.kp.error_code, err);
+    }
+    return;
+  }
   if (err) {
     record_error(a.kp.error_code, err);
   }
@@ -187,6 +245,7 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
   }
 }
 
+#ifndef HDK_VEC_BODY_ONLY  // (scan_bh.hip instantiates the body with BH = true under its own kernel names)
 // Two instantiations: plans without joins carry no probe state (fewer VGPRs, more waves for the
 // compute-bound taxi Q3/Q4 shapes); plans with joins trade occupancy for 16-byte probe gathers --
 // a random gather is bound by line fetches from HBM, not by occupancy (scripts/microbench/gather.hip).
@@ -211,5 +270,7 @@ extern "C" __global__ __launch_bounds__(kVecBlock, 2) void hdk_scan_agg_vec_keye
 extern "C" __global__ __launch_bounds__(kVecBlock) void hdk_scan_agg_vec_many(VecArgs a) {
   scan_agg_vec_body<true, false, true>(a);
 }
+
+#endif  // HDK_VEC_BODY_ONLY
 
 }  // namespace hdk

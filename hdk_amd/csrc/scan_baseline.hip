@@ -4,7 +4,9 @@
 // strategy family are compiled together and nothing else.
 #include <algorithm>
 #include <vector>
+#define HDK_SCAN_AGG_GLOBAL_KERNEL
 #include "host_match.h"
+#include "scan_bh_host.h"
 #include "scan_agg_baseline_fast.h"
 #include "scan_agg_global.h"
 #include "scan_agg_partitioned.h"
@@ -654,7 +656,9 @@ static bool perfect_partitioned_takes(const hdk_hip_plan* p, const hdk_hip_kerne
 void baseline_describe(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko, char* out, size_t out_len) {
   BaseFastArgs fa;
   PartArgs part;
-  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
+  if (const char* bh = bh_lds_kernel_name(plan, ko)) {  // a small table: open addressing in LDS (scan_bh.hip)
+    snprintf(out, out_len, "%s", bh);
+  } else if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
     snprintf(out, out_len, "hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate,hdk_part_overflow,hdk_scan_agg_baseline_direct");
   } else if (perfect_partitioned_takes(plan, ko)) {
     snprintf(out, out_len, "hdk_pp_scatter,hdk_pp_scatter2,hdk_pp_aggregate,hdk_scan_agg_global");
@@ -926,7 +930,7 @@ int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, co
                         const hdk_hip_kernel_options* ko, const LaunchShape& shape, bool init_output,
                         const hdk_hip_device_properties* props, hipStream_t s) {
   PartArgs part;
-  if (!(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
+  if (!bh_lds_kernel_name(plan, ko) && !(ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS)) && match_partitioned(plan, ko, &part)) {
     part.init_output = init_output;
     int32_t st = launch_scan_partitioned(plan, d_plan, kp, part, shape, props, s);
     if (st == kPartitionedNoScratch) {
@@ -941,6 +945,11 @@ int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, co
   if (init_output) {
     const int32_t st = init_row_wise_output(plan, kp, props, s);
     if (st) return st;
+  }
+  {
+    bool launched = false;
+    const int32_t st = launch_bh_lds(plan, d_plan, kp, ko, props, s, &launched);
+    if (st || launched) return st;
   }
   PpArgs pp;
   PpLayout pl;

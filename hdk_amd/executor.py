@@ -110,7 +110,8 @@ class PreparedStep:
         self.plan = A.Plan.from_buffer_copy(cp.plan)
         fuse = bool(cp.inner_tables) and ex.fuse_join_tables and \
             not (flags & (A.LAUNCH_FORCE_SCALAR | A.LAUNCH_FORCE_GLOBAL_ATOMICS)) and \
-            bool({"hdk_scan_agg_vec_join", "hdk_scan_project_join", "hdk_scan_agg_vec_keyed", "hdk_scan_project_keyed"} &
+            bool({"hdk_scan_agg_vec_join", "hdk_scan_project_join", "hdk_scan_agg_vec_keyed", "hdk_scan_project_keyed",
+                  "hdk_scan_agg_bh_vec_join"} &
                  set(self.kernel_names().split(",")))
         # (a table that will be fused is built together with its fused form: one sweep over the inner rows)
         self.join_tables = []

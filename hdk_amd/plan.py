@@ -24,6 +24,7 @@ from .storage import ArrowStorage, Table
 
 BASELINE_THRESHOLD = 1_000_000  # Config.exec.group_by.baseline_threshold (Shared/Config.h:51)
 DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS = 16384  # Shared/Config.h:42
+BIG_GROUP_THRESHOLD = 16384  # Config.exec.group_by.big_group_threshold (Shared/Config.h:43)
 MAX_BUFFER_SIZE = 1 << 30  # MemoryLayoutBuilder.cpp:176
 
 
@@ -175,6 +176,26 @@ class _Binder:
                 return Range("int", math.floor(a.lo), math.ceil(a.hi), 0, a.has_nulls)
             return a
         return Range("invalid")
+
+
+def _ndv_bound(b: "_Binder", e: Expr, rows: int) -> int:
+    """Upper bound on the distinct values of a group-by expression from the column statistics (+ 1 for NULL)."""
+    if isinstance(e, Cast):
+        return _ndv_bound(b, e.arg, rows)
+    if isinstance(e, BinOp) and e.op == "%" and isinstance(e.rhs, Lit) and isinstance(e.rhs.value, int) and e.rhs.value:
+        m = abs(int(e.rhs.value))
+        a = b.range_of(e.lhs)
+        signed = a.kind != "int" or a.lo < 0
+        return min((2 * m - 1) if signed else m, _ndv_bound(b, e.lhs, rows)) + (1 if a.kind != "int" or a.has_nulls else 0)
+    if isinstance(e, BinOp) and e.op in "+-*" and (isinstance(e.rhs, Lit) or isinstance(e.lhs, Lit)):
+        return _ndv_bound(b, e.lhs if isinstance(e.rhs, Lit) else e.rhs, rows)
+    r = b.range_of(e)
+    if r.kind == "int":
+        c = int(r.hi) - int(r.lo)
+        if r.bucket:
+            c //= r.bucket
+        return min(c + 1 + (1 if r.has_nulls else 0), rows)
+    return rows
 
 
 # ---------------------------------------------------------------------------------------------
@@ -693,8 +714,10 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
     key_ranges = [b.range_of(k) for k in q.groupby]
     p.key_count = nkeys
     for ki, k in enumerate(q.groupby):
-        if key_types[ki].is_fp:
-            raise QueryMustRunOnCpu("floating-point group-by keys are outside the fixed kernel library")
+        # (a floating-point key is its bit pattern from here on: groupByColumnCodegen bit-casts the double to the 8-byte
+        # key word, QE/IRCodegen.cpp:1219-1221; its range is not an integer range, so the layout is GroupByBaselineHash)
+        if key_types[ki].is_fp and key_types[ki].size != 8:
+            raise QueryMustRunOnCpu("4-byte floating-point group-by keys are outside the fixed kernel library")
         p.keys[ki] = make_expr(b, k)
 
     def card(r: Range) -> int:  # ColRangeInfo::getBucketedCardinality
@@ -741,7 +764,21 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
                     prod *= card(r)
                 if prod is not None:
                     est = min(est, prod)
-                entry_count = max(2 * est, DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS)
+                    entry_count = max(2 * est, DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS)
+                else:
+                    # keys without an integer range (cast(x as double), x % m: QE/ExpressionRange.cpp:391-419).  The reference
+                    # takes the default guess for small inputs and runs its NDV estimator query otherwise
+                    # (groups_approx_upper_bound <= big_group_threshold, RelAlgExecutor.cpp:1533-1557); the stand-in for that
+                    # query is a bound on the distinct values from the column statistics (callers with a real estimate pass
+                    # baseline_entry_count)
+                    upper = max([b.outer.num_rows] + [t.num_rows for t in b.inner])
+                    if upper <= BIG_GROUP_THRESHOLD:
+                        entry_count = DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS
+                    else:
+                        ndv = 1
+                        for k in q.groupby:
+                            ndv *= _ndv_bound(b, k, est)
+                        entry_count = 2 * max(min(ndv, est), 1)
         if entry_count >= 2**31:
             raise QueryMustRunOnCpu("group-by buffer entry count does not fit int32")
     p.query_kind = kind

@@ -158,6 +158,12 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) 
             kt = cp.key_types[oc.key_idx]
             nullv = kt.null_value()
             col = []
+            if kt.is_fp:  # the key word holds the double's bits (groupByColumnCodegen's bit-cast, QE/IRCodegen.cpp:1219-1221)
+                fv = np.ascontiguousarray(vals, dtype=np.int64).view(np.float64)
+                for v, f in zip(vals.tolist(), fv.tolist()):
+                    col.append(None if (kt.nullable and v == A.NULL_DOUBLE_BITS) else f)
+                res[oc.name] = col
+                continue
             for v in vals.tolist():
                 if kt.nullable and v == nullv:
                     col.append(None)

@@ -8,7 +8,7 @@
 // chunk: between the write of a tuple line and its read lie at most the chunk's input + 2 x its tuples
 // (MI355X_MICROARCH.md, Infinity Cache residency rule: table + every byte moved between two uses <= ~256 MiB).
 //
-// Usage: mall_pingpong [rows = 512 Mi] ; under rocprofv3 --kernel-trace --pmc FETCH_SIZE (and WRITE_SIZE) the per-kernel
+// Usage: mall_pingpong [rows = 512 Mi] [shape 0 stream | 1 scatter] [policy 0 nt/pl | 1 nt/nt | 2 pl/pl] [chunk MiB, 0 = one pass]; under rocprofv3 --kernel-trace --pmc FETCH_SIZE (and WRITE_SIZE) the per-kernel
 // counters tell whether the chunked B is served without HBM fetches (FETCH_SIZE counts Infinity-Cache hits too according
 // to the guide, so TIME is the verdict; the counters are reported for completeness).
 #include <hip/hip_runtime.h>
@@ -242,6 +242,13 @@ int main(int argc, char** argv) {
            static_cast<long long>(nchunks), best, best / in_gib, n * 32.0 / best / 1e6);
     fflush(stdout);
   };
+  if (argc > 4) {  // one configuration only (for rocprofv3 --kernel-trace --stats: per-kernel times of exactly this variant)
+    const int scatter = atoi(argv[2]), pol = atoi(argv[3]);
+    const int64_t mib = atoll(argv[4]);
+    const int64_t rows = mib ? (mib << 20) / 16 / kTile * kTile : n;
+    run(scatter, pol != 2, rows < n ? rows : n, 3, pol == 1);
+    return 0;
+  }
   // A or B alone over everything (the HBM-rate baseline of each kernel): chunk = n with the other kernel's time subtracted is
   // not needed -- the monolithic row IS A + B at HBM rates.
   for (int scatter = 0; scatter < 2; ++scatter) {

@@ -1,0 +1,223 @@
+"""GPU parity for the open-addressing group-by kept in LDS (hdk_amd/csrc/scan_bh.h): GroupByBaselineHash plans whose table
+is small -- the reference's BaselineHash benchmark shape (cast(x as double) key, five aggregates), keys without an
+expression range (x % m, also behind a join), few-group tables of every layout.  Compared with the oracle as {key ->
+slots}; every group must sit on the reference's probe sequence, and the global-atomics kernels (the reference's own
+scheme, HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS) must give the identical result."""
+import os
+
+import numpy as np
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd.ir import Agg, Cast, Cmp, ColRef, FP64, JoinSpec, KeyRef, Lit, Or, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+from test_gpu_baseline import _assert_reference_placement, _check_rows, _rows
+from util import run_oracle
+
+pytestmark = pytest.mark.gpu
+
+BH_KERNELS = ("hdk_scan_agg_bh_vec", "hdk_scan_agg_bh_direct")
+
+
+def _bh_table(n, seed, nulls=True):
+    rng = np.random.default_rng(seed)
+    cols = {"x10": rng.integers(1, 11, n).astype(np.int32), "x100": rng.integers(1, 101, n).astype(np.int32),
+            "x1k": rng.integers(1, 1001, n).astype(np.int32), "y10": rng.integers(1, 11, n).astype(np.int32),
+            "k64": rng.integers(0, 300, n, dtype=np.int64) * 3_000_000_019 - 2**40,
+            "v": rng.integers(-2**31, 2**31, n, dtype=np.int64), "d": rng.normal(size=n),
+            "f": rng.normal(size=n).astype(np.float32), "k2": rng.integers(0, 3, n).astype(np.int32),
+            "k32": (rng.integers(0, 90, n) * 7 - 100).astype(np.int32)}
+    if nulls:
+        cols["y10"][rng.random(n) < 0.03] = A.NULL_INT
+        cols["x10"][rng.random(n) < 0.01] = A.NULL_INT
+        cols["v"][rng.random(n) < 0.05] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("t", cols, fragment_size=n // 3 + 1)
+    return st
+
+
+def _bh_query(xcol, **kw):
+    y = ColRef("y10")
+    return QueryUnit("t", groupby=[Cast(ColRef(xcol), FP64)],
+                     targets=[KeyRef(0, "key0"), Agg("count", y, "c"), Agg("sum", y, "s"), Agg("max", y, "mx"), Agg("min", y, "mn"),
+                              Agg("avg", y, "a")], **kw)
+
+
+def _run_and_check(oracle, ex, st, q, expect_kernel=BH_KERNELS, placement=True):
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.query_kind == A.Q_BASELINE_HASH
+    step = ex.prepare(cp)
+    names = step.kernel_names()
+    assert any(names.startswith(k) for k in expect_kernel), names
+    res = step.run()
+    _check_rows(cp, res.buffer, want)
+    if placement and not cp.plan.output_columnar and res.row_count() < cp.entry_count:
+        _assert_reference_placement(oracle, cp, res.buffer)
+    # a second launch into the same buffer accumulates like a second run of the row function would
+    step.launch()
+    twice = step.fetch()
+    step.free()
+    assert len(_rows(cp, twice.buffer)) == len(_rows(cp, want))
+    c1, c2 = res.to_columns(), twice.to_columns()
+    if "c" in c1:
+        assert sorted(2 * x for x in c1["c"]) == sorted(c2["c"])
+    # the reference's own scheme gives the identical groups
+    ref = ex.execute(cp, flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS)
+    _check_rows(cp, res.buffer, ref.buffer)
+    return cp, res
+
+
+@pytest.mark.parametrize("xcol,groups", [("x10", 11), ("x100", 100), ("x1k", 1000)])
+def test_reference_baseline_hash_benchmark_shape(oracle, gpu_executor_factory, xcol, groups):
+    """BH001-003: cast(x as double) key, count / sum / max / min / avg of one int column (with NULLs)."""
+    st = _bh_table(700_000, 11)
+    ex = gpu_executor_factory(st)
+    expect = BH_KERNELS if groups <= 100 else BH_KERNELS + ("hdk_scan_agg_global", "hdk_scan_agg_baseline_direct", "hdk_bh_")
+    cp, res = _run_and_check(oracle, ex, st, _bh_query(xcol), expect_kernel=expect)
+    assert res.row_count() == groups
+    keys = res.to_columns()["key0"]
+    assert all(k is None or (isinstance(k, float) and k == int(k)) for k in keys)
+
+
+@pytest.mark.parametrize("columnar", [False, True])
+def test_few_groups_every_slot_kind(oracle, gpu_executor_factory, columnar):
+    st = _bh_table(500_000, 12)
+    ex = gpu_executor_factory(st)
+    q = QueryUnit("t", groupby=[ColRef("k64")], force_baseline=True, baseline_entry_count=401, output_columnar=columnar,
+                  targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c"), Agg("count", ColRef("v"), "cv"),
+                           Agg("min", ColRef("d"), "mn"), Agg("max", ColRef("v"), "mx"), Agg("avg", ColRef("f"), "af"),
+                           Agg("sum", ColRef("f"), "sf")])
+    _run_and_check(oracle, ex, st, q)
+
+
+def test_two_int32_keys_share_the_key_word(oracle, gpu_executor_factory):
+    st = _bh_table(300_000, 13)
+    ex = gpu_executor_factory(st)
+    q = QueryUnit("t", groupby=[ColRef("k32"), ColRef("k2")], force_baseline=True, baseline_entry_count=601,
+                  targets=[KeyRef(0, "a"), KeyRef(1, "b"), Agg("sum", ColRef("y10"), "s"), Agg("count", None, "c")])
+    cp, res = _run_and_check(oracle, ex, st, q)
+    assert cp.plan.key_width == 4 and cp.plan.key_count == 2
+
+
+def test_compact_count_slots(oracle, gpu_executor_factory):
+    """COUNT(*) alone by a 4-byte key: 4-byte slots (pick_target_compact_width)."""
+    st = _bh_table(300_000, 14)
+    ex = gpu_executor_factory(st)
+    q = QueryUnit("t", groupby=[ColRef("k32")], force_baseline=True, baseline_entry_count=257,
+                  targets=[KeyRef(0, "a"), Agg("count", None, "c")])
+    cp, res = _run_and_check(oracle, ex, st, q)
+    assert cp.plan.targets[1].slot_width == 4
+
+
+def test_filters_and_expression_keys(oracle, gpu_executor_factory):
+    st = _bh_table(400_000, 15)
+    ex = gpu_executor_factory(st)
+    for quals in ([Cmp(ColRef("y10"), "<=", Lit(7))], [Or(Cmp(ColRef("v"), "<", Lit(0)), Cmp(ColRef("x10"), "=", Lit(3)))]):
+        q = QueryUnit("t", groupby=[ColRef("x100") % 37], quals=quals,
+                      targets=[KeyRef(0, "g"), Agg("sum", ColRef("v"), "s"), Agg("avg", ColRef("d"), "a"), Agg("count", None, "c")])
+        cp, res = _run_and_check(oracle, ex, st, q)
+        assert cp.entry_count == 2 * 37
+
+
+def test_modulo_key_behind_a_join(oracle, gpu_executor_factory):
+    """SURVEY 8(d)'s C3 variant as written: fact JOIN dim, GROUP BY dim.dval % 64, SUM(fact.val)."""
+    rng = np.random.default_rng(16)
+    nd, n = 20_000, 600_000
+    st = ArrowStorage()
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64)})
+    st.import_numpy("fact", {"fk": rng.integers(0, nd + 50, n).astype(np.int64), "val": rng.integers(-2**31, 2**31, n).astype(np.int64)},
+                    fragment_size=190_000)
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") % 64],
+                  targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s"), Agg("count", None, "c")])
+    ex = gpu_executor_factory(st)
+    for fuse in (True, False):
+        ex.fuse_join_tables = fuse
+        cp, res = _run_and_check(oracle, ex, st, q, expect_kernel=("hdk_scan_agg_bh_vec_join", "hdk_join_"))
+        assert res.row_count() == 64
+
+
+def test_more_groups_than_entries_is_out_of_slots(oracle, gpu_executor_factory):
+    from hdk_amd._lib import HdkHipError
+    st = _bh_table(100_000, 17)
+    q = QueryUnit("t", groupby=[ColRef("x1k")], force_baseline=True, baseline_entry_count=300,
+                  targets=[KeyRef(0), Agg("sum", ColRef("v"))])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == A.ERR_OUT_OF_SLOTS
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(cp)
+    assert step.kernel_names().startswith(BH_KERNELS), step.kernel_names()
+    step.free()
+    with pytest.raises(HdkHipError) as ei:
+        ex.execute(cp)
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS
+
+
+_SOAK = os.environ.get("HDK_FUZZ_SEEDS", "")
+_SOAK_SEEDS = list(range(*map(int, _SOAK.split(":")))) if _SOAK else []
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", [1, 2, 3] + _SOAK_SEEDS)
+def test_small_open_addressing_tables_random_shapes(oracle, gpu_executor_factory, seed):
+    """Seeded random plans with small open-addressing tables: 1-2 keys of either width, plain / double-cast / modulo keys,
+    1-4 aggregates over int64 / int32 / double / float columns with NULLs, optional filters, skewed keys, load factors
+    up to more groups than entries (ERR_OUT_OF_SLOTS on both sides), ragged fragments, row-wise and columnar."""
+    from hdk_amd._lib import HdkHipError
+    rng = np.random.default_rng(7700 + seed)
+    n = int(rng.choice([900, 40_000, 350_000, 1_500_000]))
+    ndv = int(rng.choice([3, 40, 300, 900]))
+    base = rng.integers(0, ndv, n, dtype=np.int64)
+    if rng.random() < 0.4:
+        base[rng.random(n) < 0.5] = 1
+    cols = {"k64": base * 3_000_000_019 - 2**40, "k32": (base * 7 - 1000).astype(np.int32), "k2": rng.integers(0, 3, n).astype(np.int32),
+            "v": rng.integers(-2**31, 2**31, n, dtype=np.int64), "i32": rng.integers(-1000, 1000, n).astype(np.int32),
+            "d": rng.normal(size=n), "f": rng.normal(size=n).astype(np.float32)}
+    cols["v"][rng.random(n) < 0.05] = A.NULL_BIGINT
+    cols["i32"][rng.random(n) < 0.05] = A.NULL_INT
+    cols["k32"][rng.random(n) < 0.01] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", cols, fragment_size=int(rng.integers(n // 5 + 1, n + 2)))
+    ex = gpu_executor_factory(st)
+    for qi in range(5):
+        form = str(rng.choice(["k64", "k32", "k32+k2", "double", "mod"]))
+        if form == "double":
+            groupby, groups = [Cast(ColRef("k32"), FP64)], ndv + 1
+        elif form == "mod":
+            m = int(rng.integers(2, 50))
+            groupby, groups = [ColRef("i32") % m], 2 * m
+        elif form == "k32+k2":
+            groupby, groups = [ColRef("k32"), ColRef("k2")], 3 * (ndv + 1)
+        else:
+            groupby, groups = [ColRef(form)], ndv + 1
+        load = float(rng.choice([0.3, 0.5, 0.9, 1.4]))
+        entries = max(int(groups / load) | 1, 5)
+        targets = [KeyRef(i, f"k{i}") for i in range(len(groupby))]
+        for ti in range(int(rng.integers(1, 5))):
+            kind = str(rng.choice(["sum", "count", "min", "max", "avg"]))
+            arg = None if (kind == "count" and rng.random() < 0.5) else ColRef(str(rng.choice(["v", "i32", "d", "f"])))
+            targets.append(Agg(kind, arg, f"t{ti}"))
+        quals = [Cmp(ColRef("i32"), "<=", Lit(int(rng.integers(-200, 900))))] if rng.random() < 0.4 else []
+        columnar = bool(rng.random() < 0.25) and len(groupby) == 1
+        q = QueryUnit("t", groupby=groupby, quals=quals, force_baseline=True, baseline_entry_count=entries, targets=targets,
+                      output_columnar=columnar)
+        cp, want, err = run_oracle(oracle, st, q)
+        what = (seed, qi, n, ndv, form, entries, columnar, q)
+        if err:
+            assert err == A.ERR_OUT_OF_SLOTS, what
+            with pytest.raises(HdkHipError) as ei:
+                ex.execute(cp)
+            assert ei.value.code == A.ERR_OUT_OF_SLOTS, what
+            continue
+        step = ex.prepare(cp)
+        names = step.kernel_names()
+        res = step.run()
+        step.free()
+        try:
+            if entries <= 300:  # (<= 512 LDS entries of at most 14 words: always within the 64 KiB the kernels take)
+                assert names.startswith(BH_KERNELS), names
+            _check_rows(cp, res.buffer, want, float32_atol=2e-3)
+            if res.row_count() < cp.entry_count and not columnar:
+                _assert_reference_placement(oracle, cp, res.buffer)
+        except AssertionError as e:
+            raise AssertionError(f"{what}: {e}") from e
