@@ -20,11 +20,16 @@ struct PbStage {
   static constexpr size_t lds_bytes() { return static_cast<size_t>(kTile) * TW * 8 + kTile + 16; }
 };
 
-// dest(bin, n) -> claims n positions of bin's slab and returns {first position, positions that exist}
-template <int TW, int VR, typename Claim, typename Addr>
+struct PbNoDrop {
+  HDK_DEV void operator()(const int64_t*) const {}
+};
+
+// dest(bin, n) -> claims n positions of bin's slab and returns {first position, positions that exist}; drop(tuple): called
+// for every tuple that found no position (its slab is full)
+template <int TW, int VR, typename Claim, typename Addr, typename Drop = PbNoDrop>
 HDK_DEV void pb_scatter_batch(const int64_t (&tup)[VR][TW], const uint32_t (&bin)[VR], const bool (&live)[VR], uint32_t* s_cnt,
                               uint4* s_run, uint32_t* s_total, int64_t* s_stage, uint8_t* s_binof, int64_t* out, Claim claim,
-                              Addr addr) {
+                              Addr addr, Drop drop = Drop()) {
   const int tid = threadIdx.x;
   uint32_t rank[VR];
 #pragma unroll
@@ -87,6 +92,8 @@ HDK_DEV void pb_scatter_batch(const int64_t (&tup)[VR][TW], const uint32_t (&bin
       for (int w = 0; w < TW; ++w) {
         o[w] = s_stage[static_cast<size_t>(i) * TW + w];
       }
+    } else {
+      drop(s_stage + static_cast<size_t>(i) * TW);
     }
   }
   __syncthreads();

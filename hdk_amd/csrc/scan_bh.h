@@ -108,13 +108,13 @@ HDK_DEV void bh_lds_init(int64_t* lds, const BhLdsLayout& ll, uint32_t cap_log2,
   }
 }
 
-// One group's block partial folded into the output table: the key goes through the reference's probe sequence, the words
+// One group's partial folded into the output table: the key goes through the reference's probe sequence, the words
 // through agg_*_shared's atomics with the partial in place of a row's value (hdk_finalize's apply_* with atomics).
-// ew: the group's LDS words, word w of the layout (agg_common.h) at ew[ll.lmap[w] * wstride] (word 0 = rows of the group;
-// NULL-count words hold the NULL rows, as the scan counts them).
-HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const WordLayout& wl, const BhLdsLayout& ll, int64_t* buf,
-                           uint32_t entry_count, const uint64_t* col_off, int64_t keyword, const int64_t* ew, uint32_t wstride,
-                           int32_t& err) {
+// word(w): word w of the layout (agg_common.h): word 0 = rows of the group, value words the partial sum / min / max,
+// NULL-count words the NULL rows (as the scans count them).
+template <class WordFn>
+HDK_DEV void bh_fold_group_fn(const hdk_hip_plan* p, const TableShape shape, const WordLayout& wl, int64_t* buf, uint32_t entry_count,
+                              const uint64_t* col_off, int64_t keyword, WordFn word, int32_t& err) {
   int64_t entry;
   bool fresh = false;
   int64_t kv[2] = {keyword, 0};
@@ -133,7 +133,7 @@ HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const 
   }
   const bool columnar = p->output_columnar;
   int8_t* rowb = reinterpret_cast<int8_t*>(buf + static_cast<size_t>(entry) * p->row_size_quad);
-  const int64_t rowcount = ew[static_cast<uint32_t>(ll.lmap[0]) * wstride];
+  const int64_t rowcount = word(0);
   const int nt = p->num_targets;
   int slot_idx = 0;
   for (int t = 0; t < nt; ++t) {
@@ -152,7 +152,7 @@ HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const 
     slot_idx += tg.agg == HDK_AGG_AVG ? 2 : 1;
     const int vw = wl.vword[t];
     const int nw = wl.nword[t];
-    const int64_t nn = nw >= 0 ? rowcount - ew[static_cast<uint32_t>(ll.lmap[nw]) * wstride] : rowcount;
+    const int64_t nn = nw >= 0 ? rowcount - word(nw) : rowcount;
     if (tg.agg == HDK_AGG_ID) {
       if (tg.slot_width && fresh) {  // (a row-wise baseline table keeps no slot for a projected key)
         const int64_t k = kv[tg.key_idx ? 1 : 0];
@@ -181,7 +181,7 @@ HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const 
     if (vw < 0 || (tg.skip_null && nn == 0)) {
       continue;  // nothing but NULLs: the slot keeps its value
     }
-    const int64_t partial = ew[static_cast<uint32_t>(ll.lmap[vw]) * wstride];
+    const int64_t partial = word(vw);
     if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) {  // float accumulator in the slot's low 4 bytes; the block partial is a double
       g_aggf32(tg.agg, tg.skip_null, float_slot_null(tg), reinterpret_cast<int32_t*>(s1), static_cast<float>(bits_to_double(partial)));
     } else if (tg.slot_width == 4) {
@@ -190,6 +190,14 @@ HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const 
       g_agg64(tg.agg, tg.arg_is_fp != 0, tg.skip_null, tg.null_val, reinterpret_cast<int64_t*>(s1), partial);
     }
   }
+}
+
+// ew: the group's LDS words, word w of the layout at ew[ll.lmap[w] * wstride]
+HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const WordLayout& wl, const BhLdsLayout& ll, int64_t* buf,
+                           uint32_t entry_count, const uint64_t* col_off, int64_t keyword, const int64_t* ew, uint32_t wstride,
+                           int32_t& err) {
+  bh_fold_group_fn(p, shape, wl, buf, entry_count, col_off, keyword,
+                   [&](int w) -> int64_t { return ew[static_cast<uint32_t>(ll.lmap[w]) * wstride]; }, err);
 }
 
 // End of a block's scan: merge replicas 1.. into replica 0, then fold replica 0's groups into the output table.

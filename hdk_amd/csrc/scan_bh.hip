@@ -189,6 +189,7 @@ static const void* bh_kernel(const hdk_hip_plan* p) {
 }
 
 const char* bh_lds_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
+  if (const char* pk = bh_packed_kernel_name(p, ko)) return pk;
   BhGeom g;
   BhFastArgs fa;
   int kw, vw, block;
@@ -200,6 +201,10 @@ const char* bh_lds_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_optio
 int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
                       const hdk_hip_device_properties* props, hipStream_t s, bool* launched) {
   *launched = false;
+  {
+    const int32_t st = launch_bh_packed(plan, d_plan, kp, ko, props, s, launched);
+    if (st || *launched) return st;
+  }
   {
     BhFastArgs fa;
     int kw, vw, block;

@@ -11,4 +11,9 @@ const char* bh_lds_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_optio
 int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
                       const hdk_hip_device_properties* props, hipStream_t s, bool* launched);
 
+// scan_bh_packed.hip: the packed form (scan_bh_packed.h), tried first
+const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko);
+int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                         const hdk_hip_device_properties* props, hipStream_t s, bool* launched);
+
 }  // namespace hdk

@@ -1,0 +1,267 @@
+// scan_bh_packed.hip -- instantiations, matcher and launcher of the packed on-chip open-addressing group-by
+// (scan_bh_packed.h): the reference's BaselineHash benchmark shape at three LDS operations a row.
+#include <string.h>
+
+#include "host_match.h"
+#include "scan_bh_packed.h"
+#include "scan_bh_host.h"
+
+namespace hdk {
+
+constexpr uint32_t kBhPackedReplicatedBytes = 32u << 10;  // replicas while the table is tiny
+constexpr uint32_t kBhPackedMaxBytes256 = 52u << 10;      // one replica, 256-thread blocks (three on a CU)
+constexpr uint32_t kBhPackedMaxBytes512 = 100u << 10;     // one replica, one 512-thread block per CU
+// |argument| below this keeps a block's flush interval at 2^20 rows or more (|sum| < 2^39)
+constexpr int64_t kBhPackedMaxAbsVal = (1ll << 19) - 1;
+
+static bool bh_packed_off() {
+  static const bool off = getenv("HDK_HIP_NO_BH_PACKED") != nullptr || getenv("HDK_HIP_NO_BH_LDS") != nullptr;  // (A/B measurements; read once)
+  return off;
+}
+
+// the part of the match that does not depend on the table's size: columns, statistics, the word kinds
+static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, int* kw_out, int* vw_out) {
+  if (bh_packed_off() || p->query_kind != HDK_Q_BASELINE_HASH) return false;
+  if (ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_PARTITIONED))) return false;
+  if (launch_forces_generic(ko)) return false;
+  if (p->num_joins || p->key_count != 1 || (p->key_width != 4 && p->key_width != 8)) return false;
+  memset(a, 0, sizeof(*a));
+  if (!match_plain_quals(p, a->q)) return false;
+  a->nquals = p->num_quals;
+  const hdk_hip_expr& ke = p->keys[0];
+  if (ke.leaf0.kind != HDK_LEAF_COL) return false;
+  const hdk_hip_col& kc = p->cols[ke.leaf0.col];
+  if (kc.table != 0 || kc.kind != HDK_COL_INT || (kc.width != 4 && kc.width != 8)) return false;
+  if (ke.nsteps == 1) {
+    const hdk_hip_step& sp = ke.steps[0];
+    if (sp.op != HDK_OP_CAST_INT_TO_FP || p->key_width != 8) return false;
+    a->key_form = 1;
+    a->key_null_out = sp.null_out;
+  } else if (ke.nsteps != 0) {
+    return false;
+  }
+  a->key_nullable = ke.leaf0.nullable;
+  a->key_null = ke.leaf0.null_val;
+  a->key_buf_idx = kc.buf_idx;
+  a->key_width = kc.width;
+  a->key_min = INT32_MIN;
+  a->key_max = INT32_MAX;
+  if (kc.width == 8) {  // an 8-byte key column rides as 32 bits when the statistics say it fits (strangers take the exact path)
+    if (!kc.has_stats || kc.min_val < INT32_MIN || kc.max_val > INT32_MAX) return false;
+    a->key_min = static_cast<int32_t>(kc.min_val);
+    a->key_max = static_cast<int32_t>(kc.max_val);
+  }
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  for (int w = 0; w < kMaxWordsPerEntry; ++w) a->wkind[w] = BHW_ROWS;
+  bool have_val = false;
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg == HDK_AGG_SINGLE_VALUE) return false;
+    if (tg.agg == HDK_AGG_ID) {
+      if (tg.key_idx != 0 || (tg.slot_width != 0 && tg.slot_width != 4 && tg.slot_width != 8)) return false;
+      continue;
+    }
+    if (tg.slot_width != 4 && tg.slot_width != 8) return false;
+    if (tg.agg == HDK_AGG_AVG && tg.slot2_width != 4 && tg.slot2_width != 8) return false;
+    if (!tg.has_arg) {
+      if (tg.agg != HDK_AGG_COUNT) return false;
+      continue;
+    }
+    int c;
+    if (!plain_outer_col(p, tg.arg, &c)) return false;
+    const hdk_hip_col& col = p->cols[c];
+    if (col.kind != HDK_COL_INT || (col.width != 4 && col.width != 8) || tg.arg_is_fp) return false;
+    if (!col.has_stats || col.min_val < -kBhPackedMaxAbsVal || col.max_val > kBhPackedMaxAbsVal) return false;
+    const int nullable = tg.skip_null && tg.arg.nullable;
+    if (have_val && (a->val_buf_idx != col.buf_idx || a->val_nullable != nullable)) return false;
+    have_val = true;
+    a->val_buf_idx = col.buf_idx;
+    a->val_width = col.width;
+    a->val_nullable = nullable;
+    a->val_null = tg.arg.null_val;
+    a->val_min = static_cast<int32_t>(col.min_val);
+    a->val_max = static_cast<int32_t>(col.max_val);
+    if (wl.vword[t] >= 0) {
+      a->wkind[wl.vword[t]] = tg.agg == HDK_AGG_MIN ? BHW_MIN : (tg.agg == HDK_AGG_MAX ? BHW_MAX : BHW_SUM);
+      a->want_minmax = a->want_minmax || tg.agg == HDK_AGG_MIN || tg.agg == HDK_AGG_MAX;
+    }
+    if (wl.nword[t] >= 0) a->wkind[wl.nword[t]] = BHW_NULLS;
+  }
+  a->has_val = have_val;
+  // rows a block may put into one entry before it folds its table: rows < 2^23, |sum| < 2^39
+  const int64_t amax = have_val ? std::max<int64_t>(std::max<int64_t>(-static_cast<int64_t>(a->val_min), a->val_max), 1) : 1;
+  const int64_t by_sum = ((1ll << 39) - 1) / amax;
+  a->flush_rows = static_cast<uint32_t>(std::min<int64_t>(by_sum, 1ll << 23));
+  a->out_entry_count = p->entry_count;
+  *kw_out = kc.width;
+  *vw_out = have_val ? a->val_width : 0;
+  return true;
+}
+
+// LDS arrays of `cap` entries, `rep` replicas
+static void bh_packed_geometry(BhPackedArgs* a, uint32_t cap_log2, uint32_t rep) {
+  const uint32_t cap = (1u << cap_log2) + 4;  // (+ the dummy entry, padded to a bucket)
+  a->cap_log2 = cap_log2;
+  a->rep = rep;
+  a->off_mm = cap;
+  a->off_packed = 3 * cap;
+  a->off_nulls = 5 * cap;
+  uint32_t words = 6 * cap;
+  // replica r starts 4 r banks further on: lanes that read the same bucket of different replicas do not collide
+  if (rep > 1) {
+    while (words % 64 != 4) words += 4;
+  }
+  a->rep_words = words;
+}
+
+static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, int* kw, int* vw, int* block,
+                            uint32_t* lds_bytes) {
+  if (!match_bh_packed_shape(p, ko, a, kw, vw)) return false;
+  const uint32_t cap_log2 = std::max<uint32_t>(pow2_ceil_log2(p->entry_count < 4 ? 4 : p->entry_count), 2);
+  const uint64_t one = 24ull * ((1ull << cap_log2) + 4);
+  if (one > kBhPackedMaxBytes512) return false;
+  uint32_t rep = 32;
+  while (rep > 1 && (one + 16) * rep > kBhPackedReplicatedBytes) rep >>= 1;
+  bh_packed_geometry(a, cap_log2, rep);
+  *lds_bytes = a->rep_words * 4 * rep;
+  *block = one > kBhPackedMaxBytes256 ? 512 : 256;
+  return true;
+}
+
+template <int KW, int VW, int BLOCK>
+static const void* bh_packed_kernel_of() {
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, 4, BLOCK>);
+}
+template <int BLOCK>
+static const void* bh_packed_kernel(int kw, int vw) {
+  if (kw == 4) return vw == 0 ? bh_packed_kernel_of<4, 0, BLOCK>() : (vw == 4 ? bh_packed_kernel_of<4, 4, BLOCK>() : bh_packed_kernel_of<4, 8, BLOCK>());
+  return vw == 0 ? bh_packed_kernel_of<8, 0, BLOCK>() : (vw == 4 ? bh_packed_kernel_of<8, 4, BLOCK>() : bh_packed_kernel_of<8, 8, BLOCK>());
+}
+
+// ---- tables beyond LDS (to 1 M entries): 256 bins by the key's hash, a bin's groups in the LDS of one block ----------------
+constexpr uint32_t kBhBinsLog2 = 8;
+constexpr int kBhScatterVR = 8;
+struct BhPartLayout {
+  size_t cursor_bytes, total;
+  uint32_t lds_bytes;
+};
+static bool match_bh_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, BhPartLayout* l) {
+  static const bool off = getenv("HDK_HIP_NO_BH_PARTITIONS") != nullptr;  // (A/B measurements; read once)
+  static const bool always = getenv("HDK_HIP_BH_PARTITIONS_ALWAYS") != nullptr;  // (tests: small inputs and tables)
+  if (off || !ko || ko->total_rows == 0) return false;
+  if (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT) {
+    // (fine: the table is initialised by the init kernel before the passes, launch_baseline)
+  }
+  int kw, vw;
+  if (!match_bh_packed_shape(p, ko, a, &kw, &vw)) return false;
+  if (!always && (ko->total_rows < (4ull << 20) || p->entry_count > (1u << 20))) return false;
+  if (ko->total_rows >= (1ull << 40)) return false;
+  // a bin sees 1 / 256 of the groups: room for 2.5 x the bin's share of the table's entries (every entry in use and an
+  // uneven hash still fit; what does not goes through the exact path), between 64 and 4096 tags
+  const uint64_t share = (static_cast<uint64_t>(p->entry_count) + 255) / 256;
+  uint32_t cap_log2 = pow2_ceil_log2(share * 5 / 2 + 1);
+  if (cap_log2 < 6) cap_log2 = 6;
+  if (cap_log2 > 12) cap_log2 = 12;
+  bh_packed_geometry(a, cap_log2, 1);
+  a->bins_log2 = kBhBinsLog2;
+  l->lds_bytes = a->rep_words * 4;
+  a->cap = ((ko->total_rows / (256 * kPbXcds)) * 5 / 4 + 2048 + 1) & ~1ull;
+  l->cursor_bytes = static_cast<size_t>(256) * kPbXcds * kPbCursorStride * sizeof(uint32_t);
+  l->total = l->cursor_bytes + static_cast<size_t>(256) * kPbXcds * a->cap * 8;
+  return true;
+}
+
+const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
+  BhPackedArgs a;
+  int kw, vw, block;
+  uint32_t lds;
+  if (match_bh_packed(p, ko, &a, &kw, &vw, &block, &lds)) return "hdk_scan_agg_bh_packed,hdk_bh_fold_slabs";
+  BhPartLayout l;
+  if (match_bh_partitioned(p, ko, &a, &l)) return "hdk_bh_scatter,hdk_bh_aggregate";
+  return nullptr;
+}
+
+static int32_t launch_bh_partitioned(const hdk_hip_plan* d_plan, const KernParams& kp, BhPackedArgs& a, const BhPartLayout& l,
+                                     const hdk_hip_device_properties* props, hipStream_t s, bool* launched) {
+  AsyncScratch scratch(s);
+  if (hipMallocAsync(&scratch.p, l.total, s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return HDK_HIP_OK;  // no room for the tuples: the other strategies
+  }
+  int8_t* base = static_cast<int8_t*>(scratch.p);
+  HDK_HIP_CHECK(hipMemsetAsync(base, 0, l.cursor_bytes, s));
+  a.plan = d_plan;
+  a.kp = kp;
+  a.fill = reinterpret_cast<uint32_t*>(base);
+  a.tuples = reinterpret_cast<int64_t*>(base + l.cursor_bytes);
+  const size_t lds_sc = PbStage<1, kBhScatterVR>::lds_bytes();
+  const unsigned g1 = scatter_grid(reinterpret_cast<const void*>(hdk_bh_scatter<kBhScatterVR>), kPbBlock, lds_sc, props, 2);
+  hipLaunchKernelGGL((hdk_bh_scatter<kBhScatterVR>), dim3(g1), dim3(kPbBlock), lds_sc, s, a);
+  const void* ak = reinterpret_cast<const void*>(hdk_bh_aggregate);
+  if (l.lds_bytes > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l.lds_bytes)));
+  }
+  hipLaunchKernelGGL(hdk_bh_aggregate, dim3(256), dim3(kBhAggThreads), l.lds_bytes, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  *launched = true;
+  return HDK_HIP_OK;
+}
+
+int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                         const hdk_hip_device_properties* props, hipStream_t s, bool* launched) {
+  *launched = false;
+  BhPackedArgs a;
+  int kw, vw, block;
+  uint32_t lds;
+  if (!match_bh_packed(plan, ko, &a, &kw, &vw, &block, &lds)) {
+    BhPartLayout l;
+    if (match_bh_partitioned(plan, ko, &a, &l)) return launch_bh_partitioned(d_plan, kp, a, l, props, s, launched);
+    return HDK_HIP_OK;
+  }
+  a.plan = d_plan;
+  a.kp = kp;
+  const void* k = block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw);
+  if (lds > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  }
+  uint32_t grid = resident_grid(k, block, lds, props);
+  const uint32_t cu = static_cast<uint32_t>(props->num_cu);
+  static const int per_cu_env = getenv("HDK_HIP_BH_BLOCKS_PER_CU") ? atoi(getenv("HDK_HIP_BH_BLOCKS_PER_CU")) : 0;  // (measurements)
+  const uint32_t want = (per_cu_env > 0 ? static_cast<uint32_t>(per_cu_env) : (block == 512 ? 1u : 4u)) * cu;
+  if (grid > want) grid = want;
+  if (ko && ko->grid_dim_x) grid = ko->grid_dim_x;
+  // Two-level fold: the blocks leave their tables in scratch slabs, a second kernel merges them in LDS and folds every group
+  // into the output table `fold_groups` times -- folding from every scan block is (blocks x groups) contended memory-side
+  // atomics: 0.3 ms for 10 groups, 3.6 ms for 1000 (profiles/r05_bh_fold.txt).  HDK_HIP_BH_DIRECT_FOLD=1: the one-level form.
+  static const bool direct_fold = getenv("HDK_HIP_BH_DIRECT_FOLD") != nullptr;
+  AsyncScratch scratch(s);
+  const size_t slab_bytes = static_cast<size_t>(6) * ((static_cast<size_t>(1) << a.cap_log2) + 4) * 4;
+  if (!direct_fold && hipMallocAsync(&scratch.p, slab_bytes * grid, s) == hipSuccess) {
+    a.slabs = static_cast<uint32_t*>(scratch.p);
+    a.num_slabs = grid;
+    const uint32_t cap = 1u << a.cap_log2;
+    a.fold_slices = cap >= 256 ? cap / 128 : 1;  // bucket ranges of 32 buckets
+    a.fold_groups = a.fold_slices >= 32 ? 2 : (a.fold_slices >= 8 ? 4 : 8);
+    if (a.fold_groups > grid) a.fold_groups = grid;
+  } else {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+  }
+  void* kargs[] = {&a};
+  HDK_HIP_CHECK(hipLaunchKernel(k, dim3(grid), dim3(block), kargs, lds, s));
+  if (a.slabs) {
+    const size_t fold_lds = (static_cast<size_t>(9) << a.cap_log2) * 4;
+    const void* fk = reinterpret_cast<const void*>(hdk_bh_fold_slabs);
+    if (fold_lds > (48u << 10)) {
+      HDK_HIP_CHECK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fold_lds)));
+    }
+    hipLaunchKernelGGL(hdk_bh_fold_slabs, dim3(a.fold_slices * a.fold_groups), dim3(kBhFoldBlock), fold_lds, s, a);
+  }
+  HDK_HIP_CHECK(hipGetLastError());
+  *launched = true;
+  return HDK_HIP_OK;
+}
+
+}  // namespace hdk

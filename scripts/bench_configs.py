@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=256_000_000)
     ap.add_argument("--only", default="c1,c2,c2n,c2f,c2x,c2cc,c3,c3g,c3f,q1,q2,q3,q4,c5,p1,p50,pj")
+    ap.add_argument("--launch-env", default="", help="KEY=VAL,... set while the steps are prepared and run (A/B switches of the library)")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
@@ -49,7 +50,7 @@ def main():
 
     from hdk_amd import _abi as A
     from hdk_amd.executor import Executor
-    from hdk_amd.ir import Agg, Cast, Cmp, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, Lit, Or, Proj, QueryUnit, Type
+    from hdk_amd.ir import Agg, Cast, Cmp, ColRef, ExtractYear, FP64, INT32, JoinSpec, KeyRef, Lit, Or, Proj, QueryUnit, Type
     from hdk_amd.storage import ArrowStorage
 
     n = args.rows
@@ -57,13 +58,13 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
@@ -91,8 +92,19 @@ def main():
                               "total_amount": rng.integers(0, 20000, nt, dtype=np.int64)}, fragment_size=frag,
                     types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
                            "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
+    # the reference's synthetic benchmark table (Benchmarks/synthetic_benchmark/create_table.py:118-130): INT columns, uniform
+    need_syn = bool(only & {"bh1", "bh2", "bh3", "bh4", "bh5", "bh1n"})
+    ns = n if need_syn else 1000
+    syn = {f"x{nm}": rng.integers(1, hi + 1, ns).astype(np.int32) for nm, hi in (("10", 10), ("100", 100), ("1k", 1000), ("10k", 10_000), ("100k", 100_000))}
+    syn["y10"] = rng.integers(1, 11, ns).astype(np.int32)
+    st.import_numpy("syn", syn, fragment_size=frag)
     ex = Executor(st, 0)
     ex.fuse_join_tables = not args.no_fuse
+
+    def bh(xcol):  # queries/BaselineHash/BH001-005.sql
+        y = ColRef("y10")
+        return QueryUnit("syn", groupby=[Cast(ColRef(xcol), FP64)],
+                         targets=[KeyRef(0, "key0"), Agg("count", y), Agg("sum", y), Agg("max", y), Agg("min", y), Agg("avg", y)])
     Q = {
         "c1": (QueryUnit("t", targets=[Agg("sum", ColRef("val"))]), 8),
         "c2": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
@@ -144,9 +156,16 @@ def main():
                           targets=[Proj(ColRef("key"), "key"), Proj(ColRef("val"), "val")]), 16 + 12),
         "pj": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("val"), "<", Lit(-2**31 + 2**32 // 20))],
                          output_columnar=True, targets=[Proj(ColRef("val"), "val"), Proj(ColRef("dval", "dim"), "dval")]), 16 + 1.2),
+        # the reference's BaselineHash benchmark queries: 10 ... 100 K groups behind a double key; 8 bytes per row
+        "bh1": (bh("x10"), 8), "bh2": (bh("x100"), 8), "bh3": (bh("x1k"), 8), "bh4": (bh("x10k"), 8), "bh5": (bh("x100k"), 8),
+        # SURVEY 8(d)'s C3 variant as written: no expression range for a modulo, so an open-addressing table of 128 entries
+        "c3gm": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") % 64],
+                           targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
         "c5": (QueryUnit("t", groupby=[ColRef("hk")], force_baseline=True,
                          targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
     }
+    for kv in [x for x in args.launch_env.split(",") if x]:
+        os.environ[kv.split("=")[0]] = kv.split("=", 1)[1]
     for name, (q, bpr) in Q.items():
         if name not in only:
             continue

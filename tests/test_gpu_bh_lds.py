@@ -17,7 +17,7 @@ from util import run_oracle
 
 pytestmark = pytest.mark.gpu
 
-BH_KERNELS = ("hdk_scan_agg_bh_vec", "hdk_scan_agg_bh_direct")
+BH_KERNELS = ("hdk_scan_agg_bh_vec", "hdk_scan_agg_bh_direct", "hdk_scan_agg_bh_packed")
 
 
 def _bh_table(n, seed, nulls=True):
@@ -221,3 +221,82 @@ def test_small_open_addressing_tables_random_shapes(oracle, gpu_executor_factory
                 _assert_reference_placement(oracle, cp, res.buffer)
         except AssertionError as e:
             raise AssertionError(f"{what}: {e}") from e
+
+
+# ---- tables beyond LDS: the 256-bin passes (hdk_bh_scatter + hdk_bh_aggregate) ---------------------------------------------
+def _mid_table(n, groups, seed, hot=0.0):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(1, groups + 1, n).astype(np.int32)
+    if hot:
+        x[rng.random(n) < hot] = 7
+    y = rng.integers(1, 11, n).astype(np.int32)
+    y[rng.random(n) < 0.02] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", {"x": x, "y10": y, "x64": x.astype(np.int64) * 3 - 100, "w": rng.integers(-5000, 5000, n).astype(np.int64)},
+                    fragment_size=n // 3 + 7)
+    return st
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("groups,hot", [(9_000, 0.0), (60_000, 0.0), (9_000, 0.6)])
+def test_mid_sized_tables_by_hash_bins(oracle, gpu_executor_factory, groups, hot):
+    """BH004 / BH005's size class: 10 K - 100 K groups behind a double key.  A hot key overflows its bin's slab: those rows
+    take the reference's own scheme inside the scatter pass."""
+    st = _mid_table(4_400_000, groups, 21, hot)
+    ex = gpu_executor_factory(st)
+    q = _bh_query("x")
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.entry_count == 2 * groups
+    step = ex.prepare(cp)
+    assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    _assert_reference_placement(oracle, cp, res.buffer)
+    _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).buffer, want)
+
+
+@pytest.mark.timeout(900)
+def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_executor_factory):
+    """8-byte key and argument columns that fit 32 bits by their statistics, a filter, and -- second run -- statistics that
+    do NOT hold (narrowed by hand in the launch's plan copy): the rows outside them take the exact path, same result."""
+    st = _mid_table(4_300_000, 30_000, 22)
+    ex = gpu_executor_factory(st)
+    w = ColRef("w")
+    q = QueryUnit("t", groupby=[ColRef("x64")], quals=[Cmp(ColRef("y10"), "<=", Lit(8))], force_baseline=True, baseline_entry_count=70_001,
+                  targets=[KeyRef(0, "k"), Agg("sum", w, "s"), Agg("min", w, "mn"), Agg("max", w, "mx"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    for stale in (False, True):
+        step = ex.prepare(cp)
+        assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+        if stale:
+            for ci in range(step.plan.num_cols):
+                c = step.plan.cols[ci]
+                if c.has_stats and c.width == 8:
+                    c.min_val, c.max_val = c.min_val // 2, c.max_val // 2
+        res = step.run()
+        step.free()
+        _check_rows(cp, res.buffer, want)
+        _assert_reference_placement(oracle, cp, res.buffer)
+
+
+def test_small_table_with_stale_statistics(oracle, gpu_executor_factory):
+    """The one-pass packed kernel with statistics that do not hold: rows outside them bypass the packed sum."""
+    st = _mid_table(900_000, 300, 23)
+    ex = gpu_executor_factory(st)
+    w = ColRef("w")
+    q = QueryUnit("t", groupby=[ColRef("x64")], force_baseline=True, baseline_entry_count=701,
+                  targets=[KeyRef(0, "k"), Agg("sum", w, "s"), Agg("min", w, "mn"), Agg("max", w, "mx"), Agg("avg", w, "a")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    step = ex.prepare(cp)
+    assert step.kernel_names().startswith("hdk_scan_agg_bh_packed"), step.kernel_names()
+    for ci in range(step.plan.num_cols):
+        c = step.plan.cols[ci]
+        if c.has_stats and c.width == 8:
+            c.min_val, c.max_val = c.min_val // 2, c.max_val // 2
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    _assert_reference_placement(oracle, cp, res.buffer)
