@@ -216,7 +216,9 @@ HDK_DEV void scan_agg_vec_body(const VecArgs& a) {
     g.cap_log2 = a.bh_cap_log2;
     g.rep = rep;
     g.lds_bytes = 0;
-    bh_flush_block<kVecBlock>(a.plan, wl, s_ll, lds, g, a.kp.groupby_buf, s_col_off, tid, err);
+    // (a.slabs: the two-level fold -- this block's table goes to its slab, hdk_bh_fold_words folds the slabs)
+    int64_t* slab = a.slabs ? a.slabs + (static_cast<size_t>(blockIdx.x) * (static_cast<uint32_t>(wl.wpe) + 1) << a.bh_cap_log2) : nullptr;
+    bh_flush_block<kVecBlock>(a.plan, wl, s_ll, lds, g, a.kp.groupby_buf, s_col_off, tid, err, slab);
     if (err) {
       record_error(a.kp.error_code, err);
     }

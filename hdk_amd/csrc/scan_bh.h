@@ -200,11 +200,12 @@ HDK_DEV void bh_fold_group(const hdk_hip_plan* p, const TableShape shape, const 
                    [&](int w) -> int64_t { return ew[static_cast<uint32_t>(ll.lmap[w]) * wstride]; }, err);
 }
 
-// End of a block's scan: merge replicas 1.. into replica 0, then fold replica 0's groups into the output table.
+// End of a block's scan: merge replicas 1.. into replica 0, then either fold replica 0's groups into the output table, or
+// (slab != nullptr) leave replica 0 -- cap x (nlw + 1) words, entry-major -- in the block's slab for hdk_bh_fold_words.
 // s_col_off: [2 * HDK_HIP_MAX_TARGETS] LDS words for the columnar slot offsets (filled here).
 template <int BLOCK>
 HDK_DEV void bh_flush_block(const hdk_hip_plan* p, const WordLayout& wl, const BhLdsLayout& ll, int64_t* lds, const BhGeom& g,
-                            int64_t* const* groupby_buf, uint64_t* s_col_off, int tid, int32_t& err) {
+                            int64_t* const* groupby_buf, uint64_t* s_col_off, int tid, int32_t& err, int64_t* slab) {
   const uint32_t W = static_cast<uint32_t>(ll.nlw) + 1;
   const uint32_t rep = g.rep;
   const uint32_t cap = 1u << g.cap_log2;
@@ -237,6 +238,13 @@ HDK_DEV void bh_flush_block(const hdk_hip_plan* p, const WordLayout& wl, const B
     }
     __syncthreads();
   }
+  if (slab) {
+    const uint32_t n = cap * W;
+    for (uint32_t i = tid; i < n; i += BLOCK) {
+      slab[i] = lds[i * rep];
+    }
+    return;
+  }
   // ---- replica 0 into the output table ------------------------------------------------------------------------------
   const TableShape shape = table_shape(p);
   int64_t* buf = groupby_buf[0];
@@ -246,6 +254,71 @@ HDK_DEV void bh_flush_block(const hdk_hip_plan* p, const WordLayout& wl, const B
       continue;
     }
     bh_fold_group(p, shape, wl, ll, buf, g.out_entry_count, s_col_off, key, lds + e * estride, rep, err);
+  }
+}
+
+// ---- the fold of the scan blocks' slabs (two-level fold) ------------------------------------------------------------------
+// Folding from every scan block costs (blocks x groups) contended memory-side atomics: 0.3 ms for 10 groups, 3.6 ms for
+// 1000 (measured with the packed form, profiles/r05_bh_configs.txt).  Instead the blocks leave their tables in slabs and block
+// (slice, group) of this kernel merges entry range `slice` of slabs group, group + fold_groups, ... in LDS (same hash, same
+// positions as the scan: a key sits in the same range of every slab, give or take a probe over the range's end), then
+// folds each group of its table into the output table.
+struct BhFoldArgs {
+  const hdk_hip_plan* plan;
+  KernParams kp;
+  BhGeom g;          // rep is 1 here
+  BhLdsLayout ll;
+  const int64_t* slabs;
+  uint32_t num_slabs;
+  uint32_t fold_slices;  // power of two, <= cap
+  uint32_t fold_groups;
+  uint32_t pad_;
+};
+constexpr int kBhFoldWordsBlock = 256;
+HDK_DEV void bh_fold_words_body(const BhFoldArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) int64_t lds[];
+  __shared__ WordLayout wl;
+  __shared__ BhLdsLayout s_ll;
+  __shared__ uint64_t s_col_off[2 * HDK_HIP_MAX_TARGETS];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    make_word_layout(a.plan, &wl);
+    s_ll = a.ll;
+  }
+  __syncthreads();
+  bh_lds_init(lds, s_ll, a.g.cap_log2, 1, tid, kBhFoldWordsBlock);
+  __syncthreads();
+  const uint32_t W = static_cast<uint32_t>(s_ll.nlw) + 1;
+  const uint32_t cap = 1u << a.g.cap_log2;
+  const uint32_t per_slice = cap / a.fold_slices;
+  const uint32_t slice = blockIdx.x % a.fold_slices, group = blockIdx.x / a.fold_slices;
+  int32_t err = 0;
+  for (uint32_t sl = group; sl < a.num_slabs; sl += a.fold_groups) {
+    const int64_t* slab = a.slabs + static_cast<size_t>(sl) * cap * W;
+    for (uint32_t i = tid; i < per_slice; i += kBhFoldWordsBlock) {
+      const uint32_t e = slice * per_slice + i;
+      const int64_t key = slab[e * W + s_ll.nlw];
+      if (key == kBhEmpty) {
+        continue;
+      }
+      const int32_t e0 = bh_lds_find_or_claim(lds, key, a.g.cap_log2, W, static_cast<uint32_t>(s_ll.nlw));
+      if (e0 < 0) {
+        err = HDK_HIP_ERR_OUT_OF_SLOTS;
+        continue;
+      }
+      for (int w = 0; w < s_ll.nlw; ++w) {
+        const int64_t v = slab[e * W + w];
+        if (v != word_identity(s_ll.lwop[w])) {
+          bh_lds_word_op(s_ll.lwop[w], lds + static_cast<uint32_t>(e0) * W + w, v);
+        }
+      }
+    }
+  }
+  BhGeom g = a.g;
+  g.rep = 1;
+  bh_flush_block<kBhFoldWordsBlock>(a.plan, wl, s_ll, lds, g, a.kp.groupby_buf, s_col_off, tid, err, nullptr);
+  if (err) {
+    record_error(a.kp.error_code, err);
   }
 }
 

@@ -24,6 +24,45 @@ extern "C" __global__ __launch_bounds__(kVecBlock, 2) void hdk_scan_agg_bh_vec_j
   scan_agg_vec_body<true, false, false, true>(a);
 }
 
+extern "C" __global__ __launch_bounds__(kBhFoldWordsBlock) void hdk_bh_fold_words(BhFoldArgs a) { bh_fold_words_body(a); }
+
+// Two-level fold of a scan's per-block tables (scan_bh.h): scratch slabs + the fold kernel's geometry; false: the blocks fold
+// into the output table themselves (tiny grids, no scratch, HDK_HIP_BH_DIRECT_FOLD=1)
+static bool bh_two_level_fold(AsyncScratch& scratch, const BhGeom& g, const BhLdsLayout& ll, uint32_t grid, hipStream_t s, BhFoldArgs* fa) {
+  static const bool direct_fold = getenv("HDK_HIP_BH_DIRECT_FOLD") != nullptr;  // (A/B measurements; read once)
+  const uint32_t cap = 1u << g.cap_log2;
+  const size_t slab_words = static_cast<size_t>(cap) * (static_cast<uint32_t>(ll.nlw) + 1);
+  // worth it once the one-level fold would mean more than a few thousand contended group folds
+  if (direct_fold || static_cast<uint64_t>(grid) * cap < 4096) return false;
+  if (hipMallocAsync(&scratch.p, slab_words * 8 * grid, s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return false;
+  }
+  memset(fa, 0, sizeof(*fa));
+  fa->g = g;
+  fa->g.rep = 1;
+  fa->ll = ll;
+  fa->slabs = static_cast<const int64_t*>(scratch.p);
+  fa->num_slabs = grid;
+  fa->fold_slices = cap >= 256 ? cap / 128 : 1;
+  fa->fold_groups = fa->fold_slices >= 32 ? 2 : (fa->fold_slices >= 8 ? 4 : 8);
+  if (fa->fold_groups > grid) fa->fold_groups = grid;
+  return true;
+}
+static int32_t launch_bh_fold_words(BhFoldArgs& fa, const hdk_hip_plan* d_plan, const KernParams& kp, hipStream_t s) {
+  fa.plan = d_plan;
+  fa.kp = kp;
+  const size_t lds = (static_cast<size_t>(fa.ll.nlw) + 1) * 8 << fa.g.cap_log2;
+  if (lds > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hdk_bh_fold_words), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+  }
+  hipLaunchKernelGGL(hdk_bh_fold_words, dim3(fa.fold_slices * fa.fold_groups), dim3(kBhFoldWordsBlock), lds, s, fa);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
 // LDS for the table: up to 32 KiB keeps three or four interpreter blocks on a CU; an unreplicated table may take 64 KiB
 // (two blocks) -- beyond that the plan goes to the partitioned or the global-atomics kernels
 constexpr uint32_t kBhLdsReplicatedBytes = 32u << 10;
@@ -223,9 +262,17 @@ int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, cons
       const uint32_t want = (per_cu_env > 0 ? static_cast<uint32_t>(per_cu_env) : (block == 512 ? 1u : 4u)) * cu;
       if (grid > want) grid = want;
       if (ko && ko->grid_dim_x) grid = ko->grid_dim_x;
+      AsyncScratch scratch(s);
+      BhFoldArgs fold;
+      const bool two_level = bh_two_level_fold(scratch, fa.g, fa.ll, grid, s, &fold);
+      fa.slabs = two_level ? static_cast<int64_t*>(scratch.p) : nullptr;
       void* kargs[] = {&fa};
       HDK_HIP_CHECK(hipLaunchKernel(k, dim3(grid), dim3(block), kargs, fa.g.lds_bytes, s));
       HDK_HIP_CHECK(hipGetLastError());
+      if (two_level) {
+        const int32_t st = launch_bh_fold_words(fold, d_plan, kp, s);
+        if (st) return st;
+      }
       *launched = true;
       return HDK_HIP_OK;
     }
@@ -246,9 +293,25 @@ int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, cons
   v.rep = g.rep;
   v.run_if = nullptr;
   v.bh_cap_log2 = g.cap_log2;
+  AsyncScratch scratch(s);
+  BhFoldArgs fold;
+  WordLayout wl;
+  make_word_layout(plan, &wl);
+  BhLdsLayout ll;
+  ll.nlw = wl.wpe;
+  for (int w = 0; w < kMaxWordsPerEntry; ++w) {
+    ll.lwop[w] = w < wl.wpe ? wl.wop[w] : 0;
+    ll.lmap[w] = w;
+  }
+  const bool two_level = bh_two_level_fold(scratch, g, ll, grid, s, &fold);
+  v.slabs = two_level ? static_cast<int64_t*>(scratch.p) : nullptr;
   void* kargs[] = {&v};
   HDK_HIP_CHECK(hipLaunchKernel(k, dim3(grid), dim3(kVecBlock), kargs, g.lds_bytes, s));
   HDK_HIP_CHECK(hipGetLastError());
+  if (two_level) {
+    const int32_t st = launch_bh_fold_words(fold, d_plan, kp, s);
+    if (st) return st;
+  }
   *launched = true;
   return HDK_HIP_OK;
 }

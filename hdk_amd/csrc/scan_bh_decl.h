@@ -27,6 +27,6 @@ HDK_DEV int32_t bh_lds_find_or_claim(int64_t* lds, int64_t key, uint32_t cap_log
 HDK_DEV void bh_layout_identity(const WordLayout& wl, BhLdsLayout* ll);
 template <int BLOCK>
 HDK_DEV void bh_flush_block(const hdk_hip_plan* p, const WordLayout& wl, const BhLdsLayout& ll, int64_t* lds, const BhGeom& g,
-                            int64_t* const* groupby_buf, uint64_t* s_col_off, int tid, int32_t& err);
+                            int64_t* const* groupby_buf, uint64_t* s_col_off, int tid, int32_t& err, int64_t* slab);
 
 }  // namespace hdk

@@ -31,6 +31,7 @@ struct BhFastArgs {
   int32_t lw_nulls, lw_sum, lw_min, lw_max;  // LDS word of each update of the argument, -1: none (LDS word 0 = rows)
   int32_t nquals;
   int32_t pad_;
+  int64_t* slabs;  // two-level fold (scan_bh.h: hdk_bh_fold_words): block b leaves its table in slab b; nullptr: folds itself
   ProjFastQual q[kMaxPlainQuals];
 };
 
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_direct(BhFastArgs a) {
     }
     frag_tile_begin += ntiles;
   }
-  bh_flush_block<BLOCK>(a.plan, wl, s_ll, lds, a.g, a.kp.groupby_buf, s_col_off, tid, err);
+  int64_t* slab = a.slabs ? a.slabs + (static_cast<size_t>(blockIdx.x) * (static_cast<uint32_t>(a.ll.nlw) + 1) << a.g.cap_log2) : nullptr;
+  bh_flush_block<BLOCK>(a.plan, wl, s_ll, lds, a.g, a.kp.groupby_buf, s_col_off, tid, err, slab);
   if (err) {
     record_error(a.kp.error_code, err);
   }

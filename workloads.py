@@ -48,6 +48,16 @@ CONFIGS = {
     "c3g": (1_000_000_000, 16, "C3g: SELECT dim.dval / 15625, SUM(fact.val) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key GROUP BY 1 "
                                "(SURVEY.md 8d's star-schema variant of C3: 64 groups on the joined column)"),
     "c3m": (1_000_000_000, 16, "C3m: SELECT SUM(fact.val), COUNT(*), MAX(dim.dval) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key"),
+    "c3gm": (1_000_000_000, 16, "C3gm: SELECT dim.dval % 64, SUM(fact.val) FROM fact JOIN dim(10 M rows) ON fact.fk = dim.key GROUP BY 1 "
+                                "(SURVEY.md 8d's variant of C3 as written: a modulo has no expression range, so the 128-entry table is "
+                                "GroupByBaselineHash)"),
+    # the reference's own benchmark for small open-addressing tables (Benchmarks/synthetic_benchmark/queries/BaselineHash/
+    # BH001-005.sql over create_table.py's INT columns): cast(x AS double) key, five aggregates of one column; 8 bytes per row
+    "bh1": (1_000_000_000, 8, "BH001: SELECT cast(x10 AS double), count(y10), sum(y10), max(y10), min(y10), avg(y10) GROUP BY 1; 10 groups"),
+    "bh2": (1_000_000_000, 8, "BH002: the same by cast(x100 AS double); 100 groups"),
+    "bh3": (1_000_000_000, 8, "BH003: the same by cast(x1k AS double); 1 K groups"),
+    "bh4": (1_000_000_000, 8, "BH004: the same by cast(x10k AS double); 10 K groups"),
+    "bh5": (1_000_000_000, 8, "BH005: the same by cast(x100k AS double); 100 K groups"),
     "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
     "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
     "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
@@ -64,7 +74,7 @@ class Workload:
                  key_domain=100_000_000, seed_offset=0, generators=None, dim_key_stride=1):
         import torch
         from hdk_amd.executor import Executor
-        from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, INT32, JoinSpec, KeyRef, QueryUnit, Type
+        from hdk_amd.ir import Agg, Cast, ColRef, ExtractYear, FP64, INT32, JoinSpec, KeyRef, QueryUnit, Type
         from hdk_amd.storage import ArrowStorage, ChunkStats, Column, Table
         if name not in CONFIGS:
             raise ValueError(f"unknown config {name}; one of {sorted(CONFIGS)}")
@@ -118,7 +128,18 @@ class Workload:
                   self.frag_ids)
             self.query = QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0, "key"), Agg("sum", ColRef("val"), "s")])
             self.key_col, self.val_col = ("t", "key"), ("t", "val")
-        elif name in ("c3", "c3g", "c3m"):
+        elif name in ("bh1", "bh2", "bh3", "bh4", "bh5"):
+            self.bh_groups = {"bh1": 10, "bh2": 100, "bh3": 1000, "bh4": 10_000, "bh5": 100_000}[name]
+            I32 = Type("int", 4, True)
+            g = self.bh_groups
+            table("syn", {"x": (I32, uniform(1, g + 1, 11, torch.int32), (1, g)), "y10": (I32, uniform(1, 11, 12, torch.int32), (1, 10))},
+                  self.frag_rows, self.frag_ids)
+            y = ColRef("y10")
+            self.query = QueryUnit("syn", groupby=[Cast(ColRef("x"), FP64)],
+                                   targets=[KeyRef(0, "key0"), Agg("count", y, "c"), Agg("sum", y, "s"), Agg("max", y, "mx"),
+                                            Agg("min", y, "mn"), Agg("avg", y, "a")])
+            self.key_col, self.val_col = ("syn", "x"), ("syn", "y10")
+        elif name in ("c3", "c3g", "c3gm", "c3m"):
             self.dim_rows = int(dim_rows)
             self.description = self.description.replace("dim(10 M rows)", f"dim({self.dim_rows / 1e6:g} M rows)")
             self.dim_key_stride = stride = int(dim_key_stride)  # > 1: a SPARSE dimension (keys k * stride: the table's range is stride x its rows)
@@ -141,6 +162,7 @@ class Workload:
             self.query = {
                 "c3": QueryUnit("fact", joins=j, targets=[Agg("sum", ColRef("val") + dval, "s")]),
                 "c3g": QueryUnit("fact", joins=j, groupby=[dval / 15625], targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s")]),
+                "c3gm": QueryUnit("fact", joins=j, groupby=[dval % 64], targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s")]),
                 "c3m": QueryUnit("fact", joins=j, targets=[Agg("sum", ColRef("val"), "s"), Agg("count", None, "c"), Agg("max", dval, "mx")]),
             }[name]
         else:  # taxi-shaped table (taxi_reduced_bench.cpp:13-24 column types, the sample's value domains)
@@ -205,7 +227,22 @@ class Workload:
             for f in self.frag_ids:
                 total = (total + int(self.cols[self.val_col][f].sum().item())) % (1 << 64)
             out["sum_val"] = total
-        elif self.name in ("c3", "c3g", "c3m"):
+        elif self.name.startswith("bh"):
+            g = self.bh_groups
+            cnt = torch.zeros(g + 1, dtype=torch.int64, device=self.dev)
+            sm = torch.zeros(g + 1, dtype=torch.int64, device=self.dev)
+            mx = torch.full((g + 1,), -(1 << 62), dtype=torch.int64, device=self.dev)
+            mn = torch.full((g + 1,), 1 << 62, dtype=torch.int64, device=self.dev)
+            for f in self.frag_ids:
+                x = self.cols[("syn", "x")][f].to(torch.int64)
+                y = self.cols[("syn", "y10")][f].to(torch.int64)
+                cnt += torch.bincount(x, minlength=g + 1)
+                sm.index_add_(0, x, y)
+                mx = torch.maximum(mx, torch.zeros_like(mx).scatter_reduce_(0, x, y, "amax", include_self=False))
+                mn = torch.minimum(mn, torch.full_like(mn, 1 << 62).scatter_reduce_(0, x, y, "amin", include_self=True))
+                del x, y
+            out["bh"] = {"count": cnt.cpu().tolist(), "sum": sm.cpu().tolist(), "max": mx.cpu().tolist(), "min": mn.cpu().tolist()}
+        elif self.name in ("c3", "c3g", "c3gm", "c3m"):
             key = self.cols[("dim", "key")][0]
             dval = self.cols[("dim", "dval")][0]
             st_ = getattr(self, "dim_key_stride", 1)
@@ -220,8 +257,8 @@ class Workload:
                 d = by_key[fk // st_]
                 if self.name == "c3":
                     total = (total + int((v + d).sum().item())) % (1 << 64)
-                elif self.name == "c3g":
-                    g = torch.div(d, 15625, rounding_mode="trunc")
+                elif self.name in ("c3g", "c3gm"):
+                    g = torch.div(d, 15625, rounding_mode="trunc") if self.name == "c3g" else d % 64
                     sums.index_add_(0, g, v)
                     counts += torch.bincount(g, minlength=64)
                 else:
@@ -229,7 +266,7 @@ class Workload:
                     mx = max(mx, int(d.max().item()))
                 del d
             out["sum_val_plus_dval"] = total
-            if self.name == "c3g":
+            if self.name in ("c3g", "c3gm"):
                 out["group_sums"] = [int(x) for x in sums.cpu().tolist()]
                 out["group_counts"] = [int(x) for x in counts.cpu().tolist()]
             if self.name == "c3m":
