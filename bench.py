@@ -463,6 +463,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
                            "what": "HIP events on the step's stream around hdk_hip_scatter_to_owners, all_to_all_single and "
                                    "hdk_hip_aggregate_from_ranks"}
     step.free()
+    w.resident_out = None if (multi or baseline) else out_t  # (the end-to-end run compares its buffer with this one)
     return out, w
 
 
@@ -481,6 +482,128 @@ def _baseline_groups(torch, cp, table, entry_count):
     k, s = keys[live], rows[:, sq][live]
     order = torch.argsort(k)
     return k[order], s[order]
+
+
+def end_to_end(w, mgr, comm, resident_out, steps=3):
+    """C2 with the columns in HOST memory (the reference's cold path: Executor::fetchChunks -> copyHostToDevice[Async],
+    QE/Execute.cpp:2965-3068, DataMgr/GpuMgr.h:29-40): every fragment's chunks sit in pinned host memory
+    (allocatePinnedHostMem) and travel through GpuMgr::copyHostToDeviceAsync on the manager's stream into one of two staging
+    sets while the launch over the previous fragment runs on a second stream; per-fragment launches accumulate into ONE
+    output buffer (repeated launches = repeated row-function calls), which must equal the resident run's.  Reports the H->D
+    rate, rows/s and how much of the scan time the copies hide."""
+    import torch
+    from hdk_amd import _abi as A
+    from hdk_amd.executor import Executor
+    from hdk_amd.storage import ArrowStorage, ChunkStats, Column, Table
+    from workloads import TensorChunk
+    dev = comm.dev
+    tdev = torch.device("cuda", dev)
+    t_setup = time.perf_counter()
+    frag_rows = [w.frag_rows[f] for f in w.frag_ids]
+    big = max(frag_rows)
+    names = ["key", "val"]
+    # host side: one pinned array per column holding all fragments back to back
+    offs = np.concatenate([[0], np.cumsum(frag_rows)]).astype(np.int64)
+    host, host_ptrs = {}, []
+    for c in names:
+        arr, ptr = mgr.pinned_array((int(offs[-1]),), np.int64)
+        host_ptrs.append(ptr)
+        ht = torch.from_numpy(arr)
+        for i, f in enumerate(w.frag_ids):
+            ht[offs[i]:offs[i + 1]].copy_(w.cols[("t", c)][f])  # (D -> H once, untimed)
+        host[c] = arr
+    torch.cuda.synchronize()
+    # device side: two staging sets; a two-fragment (+ ragged tail) view of them as a table the executor can prepare steps on
+    stage = [{c: torch.empty(big, dtype=torch.int64, device=tdev) for c in names} for _ in range(2)]
+    tails = sorted({r for r in frag_rows if r != big})
+    st = ArrowStorage()
+    vrows = [big, big] + tails
+    ex = Executor(st, dev, mgr)
+    cols = []
+    outer = w.storage.get("t")
+    for c in names:
+        stats = outer.columns[c].stats[0]
+        cols.append(Column(c, outer.columns[c].type, [None] * len(vrows), [ChunkStats(stats.min, stats.max, stats.has_nulls)] * len(vrows)))
+        for vi, r in enumerate(vrows):
+            src = stage[vi][c] if vi < 2 else None
+            if src is not None:
+                ex.cache.put(("t", c, vi), TensorChunk(src))
+    st.add_table(Table("t", cols, vrows))
+    # (a ragged tail fragment reads the head of whichever staging set its parity selects: one view per (tail size, set))
+    cp = ex.compile(w.query)
+    out_t = torch.empty(max(cp.buffer_quads, 1), dtype=torch.int64, device=tdev)
+    step_of = {}
+    for b in range(2):
+        step_of[(big, b)] = ex.prepare(cp, [b], out_ptr=out_t.data_ptr())
+    for ti, r in enumerate(tails):
+        for b in range(2):
+            for c in names:
+                ex.cache.put(("t", c, 2 + ti), TensorChunk(stage[b][c][:r]))
+            step_of[(r, b)] = ex.prepare(cp, [2 + ti], out_ptr=out_t.data_ptr())
+    copy_s = torch.cuda.ExternalStream(mgr.getStream(dev), device=tdev)
+    comp_s = torch.cuda.Stream(device=tdev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    t_setup = time.perf_counter() - t_setup
+
+    def run(copies=True, launches=True):
+        for e in done:
+            e.record(comp_s)
+        step_of[(big, 0)].init_output(comp_s.cuda_stream)
+        for i in range(len(frag_rows)):
+            b, r = i % 2, frag_rows[i]
+            if copies:
+                copy_s.wait_event(done[b])
+                for c in names:
+                    mgr.copyHostToDeviceAsync(stage[b][c].data_ptr(), host[c][offs[i]:offs[i + 1]], r * 8, dev)
+                ready[b].record(copy_s)
+                comp_s.wait_event(ready[b])
+            if launches:
+                step_of[(r, b)].launch(comp_s.cuda_stream)
+                done[b].record(comp_s)
+        torch.cuda.synchronize()
+
+    def timed(**kw):
+        run(**kw)  # warm
+        best = None
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            run(**kw)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
+    t_pipe = timed()
+    same = bool(torch.equal(out_t[:resident_out.numel()], resident_out))
+    t_copy = timed(launches=False)
+    t_scan = timed(copies=False)  # (launch per fragment over whatever the staging sets hold)
+    total_bytes = int(offs[-1]) * 16
+    out = {"what": "C2 from pinned host memory: copyHostToDeviceAsync of fragment f + 1 (manager stream) beside the launch over "
+                   "fragment f (second stream), two staging sets, launches accumulate into one buffer; best of %d" % steps,
+           "rows_per_s": int(offs[-1]) / t_pipe, "ms_per_step": t_pipe * 1e3, "h2d_GBps": total_bytes / t_pipe / 1e9,
+           "copy_only_ms": t_copy * 1e3, "copy_only_GBps": total_bytes / t_copy / 1e9, "scan_only_ms": t_scan * 1e3,
+           "overlap_fraction": max(0.0, min(1.0, (t_copy + t_scan - t_pipe) / t_scan)) if t_scan > 0 else None,
+           "same_result_as_resident_run": same, "pinned_host_GB": total_bytes / 1e9, "setup_s": t_setup,
+           "link": _pcie_link(dev)}
+    for s_ in step_of.values():
+        s_.free()
+    del stage, out_t
+    for ptr in host_ptrs:
+        mgr.freePinnedHostMem(ptr)
+    return out
+
+
+def _pcie_link(dev):
+    """The GPU's host link as sysfs states it (speed x width), for the H->D figure."""
+    try:
+        import glob
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.exists(os.path.join(d, "current_link_speed")) and os.path.exists(os.path.join(d, "mem_info_vram_total")):
+                with open(os.path.join(d, "current_link_speed")) as f1, open(os.path.join(d, "current_link_width")) as f2:
+                    return f"{f1.read().strip()} x{f2.read().strip()}"
+    except OSError:
+        pass
+    return None
 
 
 def cpu_baseline(w, args):
@@ -609,6 +732,7 @@ def main():
     ap.add_argument("--cpu-sample-frags", type=int, default=0, help="fragments the CPU baseline runs on (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-sample", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-resident (H->D inclusive) run of C2")
     ap.add_argument("--multi-gpu-emulation", choices=["c5", "full", "none"], default="c5",
                     help="N = 1 default run: also measure one rank's step of an 8-GPU job on this device (c5: the tuple "
                          "exchange; full: plus C2's shard; none)")
@@ -636,6 +760,8 @@ def main():
                                              "what": "16 B/lane streaming read / copy (read + written bytes) of 4 GiB, best of 3"}
         if line["roofline"]["achieved"]:
             line["roofline"]["frac_of_measured_read"] = line["roofline"]["achieved"] / read_gbps.value
+    if comm.rank == 0 and comm.world == 1 and not args.no_end_to_end and args.config == "c2" and w.resident_out is not None:
+        line["end_to_end"] = end_to_end(w, mgr, comm, w.resident_out)
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline and args.config == "c2":
         line["cpu_baseline"] = cpu_baseline(w, args)
     else:

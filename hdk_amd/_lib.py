@@ -36,6 +36,7 @@ v, i32, u32, i64, sz, i8 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_siz
 SIGNATURES = {
     "hdk_hip_last_error": (C.c_char_p, []),
     "hdk_hip_version": (i32, []),
+    "hdk_hip_reload_switches": (None, []),
     "hdk_hip_mgr_get_device_count": (i32, [C.POINTER(i32)]),
     "hdk_hip_mgr_set_context": (i32, [i32]),
     "hdk_hip_set_interrupt": (i32, [i32, i32]),
@@ -152,6 +153,20 @@ def _load():
         f.argtypes = args
     _lib = L
     return L
+
+
+_switch_env = None
+
+
+def sync_switches():
+    """The library reads its HDK_HIP_* switches once per process (csrc/switches.h).  Tests and A/B scripts change them
+    between launches: when this process's HDK_HIP_* environment differs from what the library last read, ask for a re-read.
+    Called where a launch is prepared, not per launch."""
+    global _switch_env
+    now = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("HDK_HIP_")))
+    if now != _switch_env:
+        lib().hdk_hip_reload_switches()
+        _switch_env = now
 
 
 def check(status: int):

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "host_common.h"
+#include "switches.h"
 #include "launch_common.h"
 #include "plain_quals.h"
 
@@ -30,7 +31,7 @@ inline uint32_t scatter_grid(const void* kernel, int block, size_t lds_bytes, co
                              uint32_t per_cu_default = 0) {
   uint32_t g = resident_grid(kernel, block, lds_bytes, props);
   uint32_t per_cu = per_cu_default;
-  if (const char* e = getenv("HDK_HIP_SCATTER_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(atoi(e));
+  if (const char* e = hdk_sw(SW_SCATTER_BLOCKS_PER_CU)) per_cu = static_cast<uint32_t>(atoi(e));
   const uint32_t cap = per_cu * static_cast<uint32_t>(props->num_cu);
   if (cap >= 1 && cap < g) g = cap;
   return g;
@@ -62,7 +63,7 @@ inline bool plan_reads_small_dates(const hdk_hip_plan* p) {
 // per match (hdk_scan_agg_vec_many; vec_eval.h: vec_round_v).  Projections claim output rows per tile and stay row at a time.
 inline bool plan_is_single_matching_set_join(const hdk_hip_plan* p) {
   return p->num_joins == 1 && p->joins[0].kind == HDK_JOIN_ONE_TO_MANY && p->query_kind != HDK_Q_PROJECTION &&
-         !getenv("HDK_HIP_NO_BATCHED_MATCHING_SETS");
+         !hdk_sw(SW_NO_BATCHED_MATCHING_SETS);
 }
 
 inline bool needs_join_loops(const hdk_hip_plan* p) {

@@ -13,6 +13,7 @@
 #include <cstring>
 #include "device_common.h"
 #include "host_common.h"
+#include "switches.h"
 
 namespace hdk {
 
@@ -586,6 +587,10 @@ static size_t pb_up(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 // false: this table is not one for the partitioned build (no rows, more row ids or slots than 32 bits address)
 static bool pb_geometry(PbArgs* a, PbLayout* l, int64_t rows, int64_t entries, int np) {
   if (rows <= 0 || entries <= 0 || rows > INT32_MAX || entries > INT32_MAX || np < 0 || np > kPbMaxPayload) return false;
+  // A SPARSE table (a dimension of 3 M rows over a key range of 2^31) is not for this build: the build pass rewrites every
+  // slot and level 2 keeps 8 bytes of scratch per slot -- gigabytes moved and allocated where the atomic build does one CAS
+  // per row.  Dense enough = at most 16 slots per row.
+  if (entries / 16 > rows) return false;
   const int tw = 1 + np;
   a->np = np;
   a->hash_entry_count = entries;
@@ -593,7 +598,7 @@ static bool pb_geometry(PbArgs* a, PbLayout* l, int64_t rows, int64_t entries, i
   a->nslices = static_cast<uint32_t>((entries + (1ll << a->slice_log2) - 1) >> a->slice_log2);
   uint32_t fpc_log2 = 0;
   while (((a->nslices + (1u << fpc_log2) - 1) >> fpc_log2) > static_cast<uint32_t>(kPbMaxBins)) ++fpc_log2;
-  if (const char* e = getenv("HDK_HIP_BUILD_TWO_LEVELS")) {  // tests: two levels on small tables
+  if (const char* e = hdk_sw(SW_BUILD_TWO_LEVELS)) {  // tests: two levels on small tables
     const uint32_t want = static_cast<uint32_t>(atoi(e));
     if (want > fpc_log2 && want <= 8) fpc_log2 = want;
   }
@@ -611,6 +616,7 @@ static bool pb_geometry(PbArgs* a, PbLayout* l, int64_t rows, int64_t entries, i
   l->off_t1 = l->cursor_bytes;
   l->off_t2 = l->off_t1 + pb_up(nsub * a->cap1 * tw * 8);
   l->total = l->off_t2 + (a->two_level ? pb_up(static_cast<size_t>(a->nslices) * a->cap2 * tw * 8) : 0);
+  if (l->total > (static_cast<size_t>(16) << 30)) return false;  // (never starve the stream pool: the atomic build needs no scratch)
   return true;
 }
 
@@ -646,7 +652,7 @@ static int32_t pb_launch(const PbArgs& a, const hdk_hip_device_properties* props
 
 // rows from which the transparent entry points partition (HDK_HIP_BUILD_PARTITION_MIN_ROWS; 0 = never)
 static int64_t pb_min_rows() {
-  if (const char* e = getenv("HDK_HIP_BUILD_PARTITION_MIN_ROWS")) return atoll(e);
+  if (const char* e = hdk_sw(SW_BUILD_PARTITION_MIN_ROWS)) return atoll(e);
   return 2000000;
 }
 

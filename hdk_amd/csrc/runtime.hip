@@ -10,6 +10,46 @@
 #include <string.h>
 
 #include "host_common.h"
+#include "switches.h"
+
+// ---- the HDK_HIP_* switches (switches.h): read once, re-read on request ---------------------------------------------------
+namespace hdk {
+namespace {
+constexpr int kSwitchLen = 64;
+const char* const kSwitchNames[SW_COUNT] = {
+#define HDK_SW_NAME(name) "HDK_HIP_" #name,
+    HDK_SWITCH_LIST(HDK_SW_NAME)
+#undef HDK_SW_NAME
+};
+struct SwitchTable {
+  bool set[SW_COUNT];
+  char val[SW_COUNT][kSwitchLen];
+};
+SwitchTable g_switches;
+std::once_flag g_switches_once;
+void read_switches() {
+  for (int i = 0; i < SW_COUNT; ++i) {
+    const char* e = getenv(kSwitchNames[i]);
+    g_switches.set[i] = e != nullptr;
+    if (e) {
+      strncpy(g_switches.val[i], e, kSwitchLen - 1);
+      g_switches.val[i][kSwitchLen - 1] = 0;
+    } else {
+      g_switches.val[i][0] = 0;
+    }
+  }
+}
+}  // namespace
+const char* hdk_sw(SwitchId id) {
+  std::call_once(g_switches_once, read_switches);
+  return g_switches.set[id] ? g_switches.val[id] : nullptr;
+}
+}  // namespace hdk
+
+extern "C" void hdk_hip_reload_switches(void) {
+  std::call_once(hdk::g_switches_once, hdk::read_switches);
+  hdk::read_switches();
+}
 
 namespace hdk {
 
@@ -55,7 +95,7 @@ static void init_device(int32_t d) {
   hipMemPool_t pool = nullptr;
   if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool) {
     uint64_t keep = static_cast<uint64_t>(hp.totalGlobalMem) / 4;
-    if (const char* e = getenv("HDK_HIP_POOL_KEEP_MB")) {
+    if (const char* e = hdk_sw(SW_POOL_KEEP_MB)) {
       keep = static_cast<uint64_t>(strtoull(e, nullptr, 10)) << 20;
     }
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);

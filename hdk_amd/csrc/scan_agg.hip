@@ -790,7 +790,7 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
       lds_for_occupancy = keys_lds_bytes(ka, s);
       block = kKeysBlock;
       // value form with a table that leaves room for fewer than four blocks per CU: twice the threads per table
-      if (ka.nvals && (160u * 1024u) / (lds_for_occupancy + 1024u) < 4 && !getenv("HDK_HIP_KEYS_NO_WIDE_BLOCK")) {
+      if (ka.nvals && (160u * 1024u) / (lds_for_occupancy + 1024u) < 4 && !hdk_sw(SW_KEYS_NO_WIDE_BLOCK)) {
         block = kKeysWideBlock;
       }
       s.block = static_cast<uint32_t>(block);
@@ -977,7 +977,7 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     // shape: C2 + WHERE c < 0 at 256 M rows 0.98 ms against 1.10 ms with c streamed)
     bool needs_x = fa->vform != 0;
     for (int i = 0; i < p->num_quals; ++i) needs_x = needs_x || p->quals[i].rhs.kind == HDK_LEAF_COL;
-    bool xmode = needs_x && !fa->val_is_fp && !getenv("HDK_HIP_FAST_NO_XMODE");
+    bool xmode = needs_x && !fa->val_is_fp && !hdk_sw(SW_FAST_NO_XMODE);
     auto src_of = [&](int col) -> int {
       const hdk_hip_col& cc = p->cols[col];
       if (cc.table != 0 || cc.kind != HDK_COL_INT || cc.width != 8) return -1;
@@ -1205,7 +1205,7 @@ static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, c
   if (ja.x_buf_idx >= 0) {
     const bool x_has_nulls = !xcol || !xcol->has_stats || xcol->has_nulls;
     if (!(xcol && xcol->has_stats && xcol->min_val >= static_cast<int64_t>(INT32_MIN) + (x_has_nulls ? 1 : 0) &&
-          xcol->max_val <= static_cast<int64_t>(INT32_MAX)) || getenv("HDK_HIP_SLICE_WIDE")) {
+          xcol->max_val <= static_cast<int64_t>(INT32_MAX)) || hdk_sw(SW_SLICE_WIDE)) {
       sa->narrow = 0;
     }
     if (!x_has_nulls) {
@@ -1220,7 +1220,7 @@ static bool match_join_sliced(const hdk_hip_plan* p, const JoinDirectArgs& ja, c
   }
   // the FAST form of the probe pass: ONE target, SUM(x + payload) in either order, into an ADD word
   if (ja.ntargets == 1 && ja.t[0].has_arg && ja.t[0].nsteps == 1 && ja.t[0].op == HDK_OP_ADD && ja.t[0].vword >= 0 &&
-      ja.t[0].wop == WOP_ADD_U64 && !getenv("HDK_HIP_SLICE_GENERAL")) {
+      ja.t[0].wop == WOP_ADD_U64 && !hdk_sw(SW_SLICE_GENERAL)) {
     const JdLeaf &la = ja.t[0].a, &lb = ja.t[0].b;
     const JdLeaf* lx = la.kind == JD_X ? &la : (lb.kind == JD_X ? &lb : nullptr);
     const JdLeaf* lp = la.kind == JD_PAYLOAD ? &la : (lb.kind == JD_PAYLOAD ? &lb : nullptr);
@@ -1370,7 +1370,7 @@ static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, in
 }
 
 static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, const hdk_hip_kernel_options* ko, Slice2Args* ga) {
-  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES) || getenv("HDK_HIP_NO_SLICED2")) return false;
+  if (!ko || ko->total_rows == 0 || (ko->flags & HDK_HIP_LAUNCH_NO_CLUSTER_PROBES) || hdk_sw(SW_NO_SLICED2)) return false;
   if (shape.strategy != STRAT_LDS || p->num_joins != 1 || p->num_filter_ops || p->num_targets > HDK_HIP_MAX_TARGETS) return false;
   if (p->query_kind != HDK_Q_NON_GROUPED && p->query_kind != HDK_Q_PERFECT_HASH) return false;
   if (plan_reads_small_dates(p)) return false;
@@ -1550,7 +1550,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
   if (slice < 64) slice = 64;
   const uint64_t kb4 = 4ull * npay;  // LDS bytes per key of a slice
-  const bool one_level = static_cast<uint64_t>(slice) * kb4 + table_bytes1 <= kS2LdsBytes && !getenv("HDK_HIP_SLICE_TWO_LEVELS");
+  const bool one_level = static_cast<uint64_t>(slice) * kb4 + table_bytes1 <= kS2LdsBytes && !hdk_sw(SW_SLICE_TWO_LEVELS);
   auto pick_rep = [&](uint32_t keys) {
     uint32_t rep = 1;
     while (rep < 32 && static_cast<uint64_t>(keys) * kb4 + table_bytes1 * (rep * 2) <= kS2LdsBytes && table_bytes1 * (rep * 2) <= 16 * 1024) rep *= 2;
@@ -1571,7 +1571,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     if (fs > 32768) fs = 32768;
     fs &= ~static_cast<uint64_t>(63);
     if (fs < 1024) return false;
-    if (const char* e = getenv("HDK_HIP_SLICE_FINE_KEYS")) fs = static_cast<uint64_t>(atoi(e)) & ~63ull;  // (tests: small tables, two levels)
+    if (const char* e = hdk_sw(SW_SLICE_FINE_KEYS)) fs = static_cast<uint64_t>(atoi(e)) & ~63ull;  // (tests: small tables, two levels)
     if (fs < 64) fs = 64;
     const uint64_t nslices = (range + fs - 1) / fs;
     const uint64_t fpc = (nslices + kSliceMaxBins - 1) / kSliceMaxBins;
@@ -1704,7 +1704,7 @@ static JoinRoute route_join(const hdk_hip_plan* plan, const LaunchShape& shape, 
   const bool direct = match_join_direct(plan, shape, ja);
   if (direct) {
     SliceArgs sa;
-    if (match_join_sliced(plan, *ja, ko, shape.grid, &sa) && sa.fast && !getenv("HDK_HIP_SLICED2_ALWAYS")) {
+    if (match_join_sliced(plan, *ja, ko, shape.grid, &sa) && sa.fast && !hdk_sw(SW_SLICED2_ALWAYS)) {
       return JOIN_ROUTE_DIRECT;  // BASELINE config 3 itself: SUM(x + payload), its compile-time form
     }
   }

@@ -155,7 +155,7 @@ static bool part_simple_shape(const hdk_hip_plan* p, PartArgs* pa) {
 }
 
 static bool part_tuple_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PartArgs* pa) {
-  const bool keep_wide = (ko && (ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) || getenv("HDK_HIP_PART_WIDE");
+  const bool keep_wide = (ko && (ko->flags & HDK_HIP_LAUNCH_WIDE_TUPLES)) || hdk_sw(SW_PART_WIDE);
   BaseFastArgs bf;
   if (!match_baseline_fast(p, &bf)) return false;
   if (p->row_size_quad == 0 || p->row_size_quad > 16 || p->entry_count < 128) return false;
@@ -214,7 +214,7 @@ static bool part_tuple_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options
   // pass 3 with a structure-of-arrays image (hdk_part_aggregate_soa): one 4-byte key, SUM over one integer column
   const bool simple = part_simple_shape(p, pa);
   pa->soa = simple && p->key_width == 4 && pa->simple_agg == HDK_AGG_SUM && pa->simple_has_arg && (pa->narrow || pa->tw == 2) &&
-            !getenv("HDK_HIP_PART_AOS");
+            !hdk_sw(SW_PART_AOS);
   return true;
 }
 
@@ -248,7 +248,7 @@ static bool part_geometry(const hdk_hip_plan* p, uint64_t rows, uint32_t entry_c
   // per CU: 4.9 + 3.1 + 2.4 ms against 2.6 + 2.7 + 2.0 ms for runs as they come.  Runs as they come is the default;
   // HDK_HIP_PART_G_LOG2=3 turns the padding on for measurements (wide tuples on one GPU only).
   pa->g_log2 = 0;
-  if (const char* e = getenv("HDK_HIP_PART_G_LOG2")) pa->g_log2 = (pa->p1 < 2 || owners || pa->narrow) ? 0 : atoi(e);
+  if (const char* e = hdk_sw(SW_PART_G_LOG2)) pa->g_log2 = (pa->p1 < 2 || owners || pa->narrow) ? 0 : atoi(e);
   if (pa->g_log2) {
     int found = 0;
     for (int64_t k = 1; k < 4096 && found < 2; ++k) {
@@ -340,7 +340,7 @@ static void launch_part_tail(const hdk_hip_plan* plan, PartArgs& pa, const hdk_h
   // pass 2: kPartG2X blocks per coarse slab, all of them on one XCD (block id % 8 picks the slab inside a set of eight)
   const unsigned g2 = ((pa.p1 + kPartXcds - 1) / kPartXcds) * kPartXcds * kPartG2X;
   const size_t table_bytes = static_cast<size_t>(pa.slots) * plan->row_size_quad * 8;
-  const bool simple = pa.simple_agg >= 0 && !getenv("HDK_HIP_PART_GENERAL");  // (part_simple_shape; env: A/B measurements)
+  const bool simple = pa.simple_agg >= 0 && !hdk_sw(SW_PART_GENERAL);  // (part_simple_shape; env: A/B measurements)
   const bool sum2 = simple && (pa.narrow || pa.tw == 2) && pa.simple_agg == HDK_AGG_SUM;
   launch_part_scatter<2>(pa, k32, dim3(g2), lds2, s);
   const dim3 ga(pa.fine_count), ba(kPartAggBlock);
@@ -462,7 +462,7 @@ static int32_t launch_scan_partitioned(const hdk_hip_plan* plan, const hdk_hip_p
   pa.src_slab[0] = pa.slab1;
   pa.src_fill[0] = pa.fill1;
   pa.src_fill_stride = kPartCursorStride;
-  if (getenv("HDK_HIP_PART_TRACE")) {
+  if (hdk_sw(SW_PART_TRACE)) {
     fprintf(stderr, "part: scratch %p +%zu | slab1 %p (%zu) fill1 %p (%zu) slab2 %p ovf %p spill_seg %p fill2 %p | p1 %u p2_log2 %u fine %u "
             "cap1 %llu sub1 %llu cap2 %llu cap_ovf %llu cap_spill %llu tw %d slots %u rows %llu table %p\n",
             scratch.p, up(b1) + up(bc1) + tail, (void*)pa.slab1, b1, (void*)pa.fill1, bc1, (void*)pa.slab2, (void*)pa.ovf,
@@ -591,7 +591,7 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
     hipLaunchKernelGGL(hdk_part_owner_fallback<int64_t>, dim3(go), dim3(kPartBlock), 0, s, pa);
   }
   HDK_HIP_CHECK(hipGetLastError());
-  if (getenv("HDK_HIP_PART_TRACE")) {  // debugging aid: where the owner's tuples are after the passes (synchronises)
+  if (hdk_sw(SW_PART_TRACE)) {  // debugging aid: where the owner's tuples are after the passes (synchronises)
     HDK_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<uint32_t> c(bc2 / 4);
     HDK_HIP_CHECK(hipMemcpy(c.data(), cur2, bc2, hipMemcpyDeviceToHost));
@@ -684,8 +684,8 @@ struct PpLayout {
 };
 
 static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, PpArgs* a, PpLayout* l) {
-  if (!ko || getenv("HDK_HIP_NO_PERFECT_PARTITIONS")) return false;
-  const bool forced = getenv("HDK_HIP_PERFECT_PARTITIONS_ALWAYS") != nullptr;  // (tests: small inputs)
+  if (!ko || hdk_sw(SW_NO_PERFECT_PARTITIONS)) return false;
+  const bool forced = hdk_sw(SW_PERFECT_PARTITIONS_ALWAYS) != nullptr;  // (tests: small inputs)
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR |
                    HDK_HIP_LAUNCH_CHECK_INTERRUPT)) {
     return false;
@@ -816,7 +816,7 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
   // ---- geometry --------------------------------------------------------------------------------------------------------------
   uint32_t slice_log2 = 0;
   while ((2ull << slice_log2) * a->row_bytes <= kPpLdsBytes) ++slice_log2;
-  if (const char* e = getenv("HDK_HIP_PERFECT_SLICE_LOG2")) slice_log2 = static_cast<uint32_t>(atoi(e));  // (tests)
+  if (const char* e = hdk_sw(SW_PERFECT_SLICE_LOG2)) slice_log2 = static_cast<uint32_t>(atoi(e));  // (tests)
   if (slice_log2 < 4 || slice_log2 > 20) return false;
   a->slice_log2 = slice_log2;
   a->nslices = static_cast<uint32_t>((static_cast<uint64_t>(a->entry_count) + (1ull << slice_log2) - 1) >> slice_log2);
@@ -871,7 +871,7 @@ static void pp_launch(const PpArgs& a, const hdk_hip_device_properties* props, h
   const size_t lds_sc = PbStage<TW, VR>::lds_bytes();
   const unsigned cu = static_cast<unsigned>(props->num_cu);
   unsigned per_cu = 2;
-  if (const char* e = getenv("HDK_HIP_PP_BLOCKS_PER_CU")) per_cu = static_cast<unsigned>(atoi(e)) ? static_cast<unsigned>(atoi(e)) : 2u;
+  if (const char* e = hdk_sw(SW_PP_BLOCKS_PER_CU)) per_cu = static_cast<unsigned>(atoi(e)) ? static_cast<unsigned>(atoi(e)) : 2u;
   if (a.nkeys == 1) {
     hipLaunchKernelGGL((k_pp_scatter<TW, VR, 1>), dim3(per_cu * cu), dim3(kPbBlock), lds_sc, s, a);
   } else {

@@ -29,7 +29,7 @@ extern "C" __global__ __launch_bounds__(kBhFoldWordsBlock) void hdk_bh_fold_word
 // Two-level fold of a scan's per-block tables (scan_bh.h): scratch slabs + the fold kernel's geometry; false: the blocks fold
 // into the output table themselves (tiny grids, no scratch, HDK_HIP_BH_DIRECT_FOLD=1)
 static bool bh_two_level_fold(AsyncScratch& scratch, const BhGeom& g, const BhLdsLayout& ll, uint32_t grid, hipStream_t s, BhFoldArgs* fa) {
-  static const bool direct_fold = getenv("HDK_HIP_BH_DIRECT_FOLD") != nullptr;  // (A/B measurements; read once)
+  const bool direct_fold = hdk_sw(SW_BH_DIRECT_FOLD) != nullptr;  // (A/B measurements)
   const uint32_t cap = 1u << g.cap_log2;
   const size_t slab_words = static_cast<size_t>(cap) * (static_cast<uint32_t>(ll.nlw) + 1);
   // worth it once the one-level fold would mean more than a few thousand contended group folds
@@ -69,7 +69,7 @@ constexpr uint32_t kBhLdsReplicatedBytes = 32u << 10;
 constexpr uint32_t kBhLdsMaxBytes = 64u << 10;
 
 static bool bh_switch_off() {
-  static const bool off = getenv("HDK_HIP_NO_BH_LDS") != nullptr;  // (A/B measurements; read once)
+  const bool off = hdk_sw(SW_NO_BH_LDS) != nullptr;  // (A/B measurements)
   return off;
 }
 
@@ -112,7 +112,7 @@ bool match_bh_lds(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhGeo
 constexpr uint32_t kBhFastLdsMaxBytes = 144u << 10;
 
 static bool match_bh_fast(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhFastArgs* fa, int* kw_out, int* vw_out, int* block_out) {
-  static const bool off = getenv("HDK_HIP_NO_BH_DIRECT") != nullptr;  // (A/B measurements; read once)
+  const bool off = hdk_sw(SW_NO_BH_DIRECT) != nullptr;  // (A/B measurements)
   if (off || p->query_kind != HDK_Q_BASELINE_HASH || bh_switch_off()) return false;
   if (ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_PARTITIONED))) return false;
   if (launch_forces_generic(ko)) return false;
@@ -258,7 +258,7 @@ int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, cons
       // narrow rows carry more LDS atomics per byte; one 512-thread block per CU when the table needs the LDS
       uint32_t grid = resident_grid(k, block, fa.g.lds_bytes, props);
       const uint32_t cu = static_cast<uint32_t>(props->num_cu);
-      static const int per_cu_env = getenv("HDK_HIP_BH_BLOCKS_PER_CU") ? atoi(getenv("HDK_HIP_BH_BLOCKS_PER_CU")) : 0;  // (measurements)
+      const int per_cu_env = hdk_sw(SW_BH_BLOCKS_PER_CU) ? atoi(hdk_sw(SW_BH_BLOCKS_PER_CU)) : 0;  // (measurements)
       const uint32_t want = (per_cu_env > 0 ? static_cast<uint32_t>(per_cu_env) : (block == 512 ? 1u : 4u)) * cu;
       if (grid > want) grid = want;
       if (ko && ko->grid_dim_x) grid = ko->grid_dim_x;

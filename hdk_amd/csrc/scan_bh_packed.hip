@@ -15,7 +15,7 @@ constexpr uint32_t kBhPackedMaxBytes512 = 100u << 10;     // one replica, one 51
 constexpr int64_t kBhPackedMaxAbsVal = (1ll << 19) - 1;
 
 static bool bh_packed_off() {
-  static const bool off = getenv("HDK_HIP_NO_BH_PACKED") != nullptr || getenv("HDK_HIP_NO_BH_LDS") != nullptr;  // (A/B measurements; read once)
+  const bool off = hdk_sw(SW_NO_BH_PACKED) != nullptr || hdk_sw(SW_NO_BH_LDS) != nullptr;  // (A/B measurements)
   return off;
 }
 
@@ -147,8 +147,8 @@ struct BhPartLayout {
   uint32_t lds_bytes;
 };
 static bool match_bh_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, BhPartLayout* l) {
-  static const bool off = getenv("HDK_HIP_NO_BH_PARTITIONS") != nullptr;  // (A/B measurements; read once)
-  static const bool always = getenv("HDK_HIP_BH_PARTITIONS_ALWAYS") != nullptr;  // (tests: small inputs and tables)
+  const bool off = hdk_sw(SW_NO_BH_PARTITIONS) != nullptr;  // (A/B measurements)
+  const bool always = hdk_sw(SW_BH_PARTITIONS_ALWAYS) != nullptr;  // (tests: small inputs and tables)
   if (off || !ko || ko->total_rows == 0) return false;
   if (ko->flags & HDK_HIP_LAUNCH_INIT_OUTPUT) {
     // (fine: the table is initialised by the init kernel before the passes, launch_baseline)
@@ -228,14 +228,14 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   }
   uint32_t grid = resident_grid(k, block, lds, props);
   const uint32_t cu = static_cast<uint32_t>(props->num_cu);
-  static const int per_cu_env = getenv("HDK_HIP_BH_BLOCKS_PER_CU") ? atoi(getenv("HDK_HIP_BH_BLOCKS_PER_CU")) : 0;  // (measurements)
+  const int per_cu_env = hdk_sw(SW_BH_BLOCKS_PER_CU) ? atoi(hdk_sw(SW_BH_BLOCKS_PER_CU)) : 0;  // (measurements)
   const uint32_t want = (per_cu_env > 0 ? static_cast<uint32_t>(per_cu_env) : (block == 512 ? 1u : 4u)) * cu;
   if (grid > want) grid = want;
   if (ko && ko->grid_dim_x) grid = ko->grid_dim_x;
   // Two-level fold: the blocks leave their tables in scratch slabs, a second kernel merges them in LDS and folds every group
   // into the output table `fold_groups` times -- folding from every scan block is (blocks x groups) contended memory-side
   // atomics: 0.3 ms for 10 groups, 3.6 ms for 1000 (profiles/r05_bh_fold.txt).  HDK_HIP_BH_DIRECT_FOLD=1: the one-level form.
-  static const bool direct_fold = getenv("HDK_HIP_BH_DIRECT_FOLD") != nullptr;
+  const bool direct_fold = hdk_sw(SW_BH_DIRECT_FOLD) != nullptr;
   AsyncScratch scratch(s);
   const size_t slab_bytes = static_cast<size_t>(6) * ((static_cast<size_t>(1) << a.cap_log2) + 4) * 4;
   if (!direct_fold && hipMallocAsync(&scratch.p, slab_bytes * grid, s) == hipSuccess) {

@@ -18,7 +18,7 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
     const hdk_hip_join& jn = p->joins[0];
     int kc;
     if ((jn.kind != HDK_JOIN_ONE_TO_ONE && jn.kind != HDK_JOIN_ONE_TO_ONE_FUSED) || !join_type_inner_like(jn.type) || jn.table_idx != 0 ||
-        p->num_filter_ops || getenv("HDK_HIP_PROJECT_NO_FAST_JOIN")) {
+        p->num_filter_ops || hdk_sw(SW_PROJECT_NO_FAST_JOIN)) {
       return false;
     }
     if (!plain_outer_col(p, jn.outer_key, &kc) || (p->cols[kc].kind != HDK_COL_INT && p->cols[kc].kind != HDK_COL_UNSIGNED)) return false;
@@ -85,7 +85,7 @@ static bool match_project_fast(const hdk_hip_plan* p, ProjFastArgs* fa) {
 // DESIGN.md 3.6, and kept behind the switch) needs a status word per batch of tiles, so the launch has to state its row
 // count.
 static bool project_one_pass(const hdk_hip_kernel_options* ko, const ProjFastArgs* pf = nullptr) {
-  return ko && ko->total_rows && getenv("HDK_HIP_PROJECT_ONE_PASS") && !(pf && pf->join);
+  return ko && ko->total_rows && hdk_sw(SW_PROJECT_ONE_PASS) && !(pf && pf->join);
 }
 
 uint32_t project_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
@@ -136,7 +136,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
       // a status word per batch: the stated rows in full tiles, plus one ragged tile per fragment -- 64 K of them
       // (the kernel counts the real tiles and hands the launch to the two passes if they do not fit)
       uint64_t slack = 65536;
-      if (const char* e = getenv("HDK_HIP_PROJECT_STATUS_SLACK")) slack = strtoull(e, nullptr, 10);  // (tests)
+      if (const char* e = hdk_sw(SW_PROJECT_STATUS_SLACK)) slack = strtoull(e, nullptr, 10);  // (tests)
       const uint64_t tiles = ko->total_rows / (static_cast<uint64_t>(kProjFastBlock) * kProjFastVR) + slack;
       const uint64_t cap = tiles / kProjFastGroup + 1;
       const size_t bytes = 16 + cap * sizeof(uint64_t);
@@ -187,7 +187,7 @@ int32_t launch_project(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, con
       hipLaunchKernelGGL(hdk_scan_project_count, dim3(shape.grid), dim3(kProjFastBlock), 0, s, pf);
     }
     uint32_t force = 0;  // (HDK_HIP_PROJECT_WRITER=sparse|dense: A/B measurements)
-    if (const char* e = getenv("HDK_HIP_PROJECT_WRITER")) force = e[0] == 'd' ? 2u : e[0] == 's' ? 1u : 0u;
+    if (const char* e = hdk_sw(SW_PROJECT_WRITER)) force = e[0] == 'd' ? 2u : e[0] == 's' ? 1u : 0u;
     if (pf.join) force = 1u;  // joined columns are gathered row by row: the sparse writing pass
     hipLaunchKernelGGL(hdk_scan_project_offsets, dim3(1), dim3(1024), 0, s, counts, shape.grid, kp.total_matched, pf.run_if, kp,
                        pf.mode, force);

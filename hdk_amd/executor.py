@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _abi as A
 from . import result_set
-from ._lib import HdkHipError, check, lib
+from ._lib import HdkHipError, check, lib, sync_switches
 from .hip_mgr import DeviceBuffer, HipMgr
 from .ir import QueryMustRunOnCpu, QueryUnit
 from .plan import CompiledPlan, columnar_init_vals, compact_init_vals, compile_query, eff_key_count
@@ -95,6 +95,7 @@ class PreparedStep:
         self.ex, self.cp, self.frag_ids = ex, cp, list(frag_ids)
         self.mgr, self.dev = ex.mgr, ex.device_id
         self.L = lib()
+        sync_switches()  # (a test or an A/B script may have changed HDK_HIP_* since the library read them)
         self.keep: List[DeviceBuffer] = []
         self._graph = None
         p = cp.plan
@@ -208,6 +209,7 @@ class PreparedStep:
         return b
 
     def kernel_names(self) -> str:
+        sync_switches()
         out = C.create_string_buffer(256)
         check(self.L.hdk_hip_describe_launch(C.byref(self.plan), C.byref(self.ko), self.dev, out, 256))
         return out.value.decode()

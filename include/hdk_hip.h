@@ -559,6 +559,15 @@ int32_t hdk_hip_partition_baseline(const hdk_hip_plan* plan, const int64_t* buf,
                                    int64_t* const* seg_bufs, int32_t device_id, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Environment switches (MI355X addition; no reference counterpart: the reference's knobs are Config fields,
+ * Shared/Config.h).  libhdk_hip.so reads its HDK_HIP_* variables (tests and A/B measurements, none needed
+ * in production) ONCE per process, at the first launch that asks for one -- never per launch, so a host that calls
+ * setenv() while queries run races with nothing.  A caller that changes them on purpose (the test harness) asks for a
+ * re-read; not to be called while another thread is inside a launch.
+ * ---------------------------------------------------------------------------------------- */
+void hdk_hip_reload_switches(void);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU open-addressing group-by by TUPLE exchange (MI355X addition; replaces, for plans of the
  * radix-partitioned shape, per-device tables + host merge: Executor::reduceMultiDeviceResultSets,
  * QE/Execute.cpp:1224-1336, reduceOneEntryBaseline, QE/ResultSetReduction.cpp:694-731).  Keys are split by owner =
@@ -658,7 +667,11 @@ typedef struct hdk_hip_hash_entry_info { /* HashEntryInfo */
 int32_t hdk_hip_init_hash_join_buff(int32_t* buff, int64_t entry_count, int32_t invalid_slot_val,
                                     int32_t device_id, void* stream);
 /* fill_hash_join_buff_on_device[_bucketized] (HashJoinRuntime.h:158-171): one-to-one; on a duplicate
- * key `*dev_err_buff` becomes -1 (the caller then rebuilds one-to-many, PerfectHashTableBuilder.h:134-141). */
+ * key `*dev_err_buff` becomes -1 (the caller then rebuilds one-to-many, PerfectHashTableBuilder.h:134-141).
+ * ONE call fills ONE table: from 2 M rows on (and a table of at most 16 slots per row) the fill goes through slot-range
+ * partitions whose build pass writes EVERY slot of `buff` (the claimed row id, or `invalid_slot_val`), so entries of an
+ * earlier call into the same buffer do not survive -- the reference's callers (PerfectHashTableBuilder::initOneToOneHashTable
+ * OnGpu) hand the whole JoinColumn to one call as well. */
 int32_t hdk_hip_fill_hash_join_buff(int32_t* buff, int32_t invalid_slot_val, int32_t for_semi_join,
                                     int32_t* dev_err_buff, hdk_hip_join_column join_column,
                                     hdk_hip_join_column_type_info type_info, int32_t device_id,

@@ -93,7 +93,7 @@ def main():
                     types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
                            "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
     # the reference's synthetic benchmark table (Benchmarks/synthetic_benchmark/create_table.py:118-130): INT columns, uniform
-    need_syn = bool(only & {"bh1", "bh2", "bh3", "bh4", "bh5", "bh1n"})
+    need_syn = bool(only & {"bh1", "bh2", "bh3", "bh4", "bh5", "ph1", "ph2", "ph3"})
     ns = n if need_syn else 1000
     syn = {f"x{nm}": rng.integers(1, hi + 1, ns).astype(np.int32) for nm, hi in (("10", 10), ("100", 100), ("1k", 1000), ("10k", 10_000), ("100k", 100_000))}
     syn["y10"] = rng.integers(1, 11, ns).astype(np.int32)
@@ -157,6 +157,10 @@ def main():
         "pj": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("val"), "<", Lit(-2**31 + 2**32 // 20))],
                          output_columnar=True, targets=[Proj(ColRef("val"), "val"), Proj(ColRef("dval", "dim"), "dval")]), 16 + 1.2),
         # the reference's BaselineHash benchmark queries: 10 ... 100 K groups behind a double key; 8 bytes per row
+        # the same aggregates by the integer column itself: the perfect-hash twin of BH001-003 (what the dense route would run)
+        "ph1": (QueryUnit("syn", groupby=[ColRef("x10")], targets=[KeyRef(0, "k"), Agg("count", ColRef("y10")), Agg("sum", ColRef("y10")), Agg("max", ColRef("y10")), Agg("min", ColRef("y10")), Agg("avg", ColRef("y10"))]), 8),
+        "ph2": (QueryUnit("syn", groupby=[ColRef("x100")], targets=[KeyRef(0, "k"), Agg("count", ColRef("y10")), Agg("sum", ColRef("y10")), Agg("max", ColRef("y10")), Agg("min", ColRef("y10")), Agg("avg", ColRef("y10"))]), 8),
+        "ph3": (QueryUnit("syn", groupby=[ColRef("x1k")], targets=[KeyRef(0, "k"), Agg("count", ColRef("y10")), Agg("sum", ColRef("y10")), Agg("max", ColRef("y10")), Agg("min", ColRef("y10")), Agg("avg", ColRef("y10"))]), 8),
         "bh1": (bh("x10"), 8), "bh2": (bh("x100"), 8), "bh3": (bh("x1k"), 8), "bh4": (bh("x10k"), 8), "bh5": (bh("x100k"), 8),
         # SURVEY 8(d)'s C3 variant as written: no expression range for a modulo, so an open-addressing table of 128 entries
         "c3gm": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") % 64],

@@ -231,3 +231,138 @@ def test_keyed_join_probe_vs_reference(oracle, ref, width, kc):
         key = rng.integers(3000, 9000, kc).astype(dt)
         r = ref_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries)
         assert r < 0 and orc_probe(buff.ctypes.data, key.ctypes.data, kc * width, entries) == r
+
+
+def _probe_through_ref(ref, table_ptr, key, mn, mx, null, tr, bucket, bw_eq, nullable):
+    """The probe PerfectJoinHashTable::codegenSlot picks for a table (QE/JoinHashTable/PerfectJoinHashTable.cpp:798-816)."""
+    if bucket > 1:
+        if bw_eq:
+            return ref.bucketized_hash_join_idx_bitwise(table_ptr, key, mn, mx, null, tr, bucket)
+        if nullable:
+            return ref.bucketized_hash_join_idx_nullable(table_ptr, key, mn, mx, null, bucket)
+        return ref.bucketized_hash_join_idx(table_ptr, key, mn, mx, bucket)
+    if bw_eq:
+        return ref.hash_join_idx_bitwise(table_ptr, key, mn, mx, null, tr)
+    if nullable:
+        return ref.hash_join_idx_nullable(table_ptr, key, mn, mx, null)
+    return ref.hash_join_idx(table_ptr, key, mn, mx)
+
+
+@pytest.mark.parametrize("bucket", [1, 86400])
+@pytest.mark.parametrize("bw_eq", [0, 1])
+@pytest.mark.parametrize("semi", [0, 1])
+def test_one_to_one_tables_built_by_the_oracle_probed_by_the_reference(oracle, ref, bucket, bw_eq, semi):
+    """The BUILD half of the join oracle (orc_fill_hash_join_buff: HashJoinRuntime.cpp:197-293 cannot be compiled here --
+    Logger / TBB) pinned through the reference's own PROBES: for random inner columns (NULLs, DATE buckets, duplicates for
+    a semi join, three chunks) every inner key, probed through the function codegenSlot would pick, must come back with a
+    row that holds that key; the NULL key hits exactly when the join is IS NOT DISTINCT FROM; strangers miss."""
+    import ctypes as C
+    from hdk_amd import _abi as A
+    L = oracle.lib()
+    rng = np.random.default_rng(1000 + bucket % 7 + 10 * bw_eq + 100 * semi)
+    for trial in range(12):
+        n = int(rng.integers(5, 400))
+        days = rng.permutation(3 * n)[:n].astype(np.int64) - n
+        if bucket > 1 and bw_eq:
+            # The reference files a NULL of a bucketized kBwEq table under translated_null = max / bucket + 1 -- DAYS -- while
+            # min is in seconds (PerfectJoinHashTable.cpp:806-811, get_bucketized_hash_slot): slot (tr - min) / bucket, which
+            # is the slot of day 0 whenever min < 0 <= max, and outside the table otherwise.  Keep to the first case with day 0
+            # itself unused, where the behaviour is defined.
+            days = days[days != 0]
+            days = np.concatenate([days, np.array([-2, 3], dtype=np.int64)])
+            days = np.unique(days) if not semi else days
+            rng.shuffle(days)
+            n = days.size
+        if semi:
+            days[rng.integers(0, n, n // 4)] = days[0]  # duplicates: the first row of a key wins
+        keys = days * bucket + (rng.integers(0, bucket, n) if bucket > 1 else 0)
+        if bucket > 1 and not semi:
+            keys = days * bucket + int(rng.integers(0, bucket))  # (one row per day: two rows of a day collide)
+        if bucket > 1 and bw_eq:
+            keys = days * bucket  # (midnights: the NULL's slot is then exactly day 0's, see above)
+        null = NULL64
+        has_null = trial % 2 == 0
+        if has_null:
+            keys[rng.integers(0, n, 2)] = null
+        live = keys[keys != null]
+        mn, mx = int(live.min()), int(live.max())
+        tr = (mx // bucket + 1) if bucket > 1 else mx + 1  # translated NULL of a kBwEq join (HashJoin.cpp: getTranslatedNullVal)
+        entries = (mx - mn) // bucket + 1 + (1 if bw_eq else 0) if bucket > 1 else mx - mn + 1 + (1 if bw_eq else 0)
+        table = np.empty(entries + 2, dtype=np.int32)
+        L.orc_init_hash_join_buff(table.ctypes.data, table.size, -1)
+        parts = [keys[: n // 3], keys[n // 3: 2 * n // 3], keys[2 * n // 3:]]
+        chunks = oracle.make_join_chunks(parts)
+        ti = A.JoinColumnTypeInfo(8, mn, mx, null, bw_eq, A.JC_SIGNED, tr if bw_eq else 0)
+        rc = L.orc_fill_hash_join_buff(table.ctypes.data, -1, semi, C.cast(chunks, C.c_void_p), 3, C.byref(ti), bucket)
+        null_rows = np.flatnonzero(keys == null)
+        if not semi and bw_eq and null_rows.size > 1:
+            assert rc != 0  # two NULL rows collide in the translated slot of a one-to-one table
+            continue
+        assert rc == 0, (trial, rc)
+        t = table.ctypes.data
+        for i in range(n):
+            k = int(keys[i])
+            if k == null:
+                continue
+            got = _probe_through_ref(ref, t, k, mn, mx, null, tr, bucket, bw_eq, True)
+            assert got >= 0 and (int(keys[got]) - mn) // bucket == (k - mn) // bucket, (trial, i, got)
+            if semi:  # first row of the key (in chunk order) wins
+                assert got == int(np.flatnonzero((keys - mn) // bucket == (k - mn) // bucket)[0])
+            else:
+                assert got == i
+        got_null = _probe_through_ref(ref, t, null, mn, mx, null, tr, bucket, bw_eq, True)
+        if bw_eq and null_rows.size:
+            assert got_null == int(null_rows[0])
+        else:
+            assert got_null == -1
+        present = set(((live - mn) // bucket).tolist())
+        for k in [mn - 1, mx + bucket, mn - 5 * bucket] + [int(x) for x in rng.integers(mn, mx + 1, 60)]:
+            if bucket > 1 and bw_eq and mn <= k <= mx and (k - mn) // bucket == (tr - mn) // bucket:
+                continue  # (day 0's slot holds the NULL row: see above)
+            got = _probe_through_ref(ref, t, k, mn, mx, null, tr, bucket, bw_eq, True)
+            if k < mn or k > mx:
+                assert got == -1, (trial, k, got)
+            elif (k - mn) // bucket not in present:
+                assert got == -1, (trial, k, got)
+
+
+@pytest.mark.parametrize("bucket", [1, 86400])
+def test_one_to_many_table_built_by_the_oracle_decoded_like_the_reference_test(oracle, ref, bucket):
+    """orc_fill_one_to_many_hash_table's [offsets | counts | row ids] (HashJoinRuntime.cpp:589-853), decoded the way
+    Tests/JoinHashTableTest.cpp:207-260 decodes a table and probed through the reference's hash_join_idx on the offset and
+    the count sub-buffers (HashJoin::codegenMatchingSet, QE/JoinHashTable/HashJoin.cpp:149-197): every key's matching set
+    is exactly the rows that hold it."""
+    import ctypes as C
+    from hdk_amd import _abi as A
+    L = oracle.lib()
+    rng = np.random.default_rng(2000 + bucket % 5)
+    for trial in range(10):
+        n = int(rng.integers(10, 500))
+        days = rng.integers(-20, 40, n).astype(np.int64)
+        keys = days * bucket + (rng.integers(0, bucket, n) if bucket > 1 else 0)
+        null = NULL64
+        if trial % 2:
+            keys[rng.integers(0, n, 3)] = null
+        live = keys[keys != null]
+        mn, mx = int(live.min()), int(live.max())
+        entries = (mx - mn) // bucket + 1
+        buff = np.empty(2 * entries + n, dtype=np.int32)
+        L.orc_init_hash_join_buff(buff.ctypes.data, buff.size, -1)  # (PerfectHashTableBuilder::initOneToManyHashTable: the whole buffer)
+        parts = [keys[: n // 2], keys[n // 2:]]
+        chunks = oracle.make_join_chunks(parts)
+        ti = A.JoinColumnTypeInfo(8, mn, mx, null, 0, A.JC_SIGNED, 0)
+        L.orc_fill_one_to_many_hash_table(buff.ctypes.data, entries, -1, C.cast(chunks, C.c_void_p), 2, C.byref(ti), bucket)
+        offs, counts, ids = buff[:entries], buff[entries:2 * entries], buff[2 * entries:]
+        slot_of = (keys - mn) // bucket
+        for s in range(entries):
+            want = np.flatnonzero((keys != null) & (slot_of == s))
+            if want.size == 0:
+                assert offs[s] == -1 and counts[s] in (0, -1)
+                continue
+            got = np.sort(ids[offs[s]: offs[s] + counts[s]])
+            assert np.array_equal(got, want), (trial, s)
+            k = int(keys[want[0]])
+            # the probes of the matching set: offsets buffer, then the counts buffer behind it
+            probe = (lambda p: ref.bucketized_hash_join_idx(p, k, mn, mx, bucket)) if bucket > 1 else (lambda p: ref.hash_join_idx(p, k, mn, mx))
+            assert probe(buff.ctypes.data) == offs[s] and probe(buff.ctypes.data + entries * 4) == counts[s]
+        assert int(counts[counts > 0].sum()) == int((keys != null).sum())

@@ -146,7 +146,10 @@ def test_unsupported_shapes_raise_query_must_run_on_cpu():
     st = ArrowStorage()
     st.import_numpy("t", {"a": np.arange(10, dtype=np.int64), "f": np.ones(10, dtype=np.float32), "d": np.ones(10)})
     with pytest.raises(QueryMustRunOnCpu):
-        compile_query(st, QueryUnit("t", groupby=[ColRef("d")], targets=[Agg("count")]))  # fp group key
+        compile_query(st, QueryUnit("t", groupby=[ColRef("f")], targets=[Agg("count")]))  # 4-byte fp group key
+    # (a double key is its bit pattern in an open-addressing table since round 5: groupByColumnCodegen, QE/IRCodegen.cpp:1219-1221)
+    cp = compile_query(st, QueryUnit("t", groupby=[ColRef("d")], targets=[Agg("count")]))
+    assert cp.plan.query_kind == A.Q_BASELINE_HASH and cp.plan.key_width == 8
     deep = BinOp("+", ColRef("a"), BinOp("*", ColRef("a"), Lit(2)))
     with pytest.raises(QueryMustRunOnCpu):
         compile_query(st, QueryUnit("t", targets=[Agg("sum", deep)]))  # right operand must be a leaf
