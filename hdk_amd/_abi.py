@@ -68,6 +68,7 @@ LAUNCH_FORCE_GENERIC = 4
 LAUNCH_FORCE_SCALAR = 8
 LAUNCH_FORCE_PARTITIONED = 16
 LAUNCH_WIDE_TUPLES = 1024
+LAUNCH_ACCUMULATE = 2048
 LAUNCH_PLAN_RESIDENT = 32
 LAUNCH_CHECK_INTERRUPT = 64
 LAUNCH_INIT_OUTPUT = 128

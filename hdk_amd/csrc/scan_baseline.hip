@@ -568,7 +568,8 @@ int32_t launch_aggregate_from_ranks(const hdk_hip_plan* plan, const hdk_hip_plan
   if (st) return st;
   pa.plan = d_plan;
   pa.kp = kp;
-  pa.init_output = 1;  // pass 3 writes every region of the owner's table
+  // pass 3 writes every region of the owner's table -- or merges into the table an earlier chunk left (ACCUMULATE)
+  pa.init_output = (ko && (ko->flags & HDK_HIP_LAUNCH_ACCUMULATE)) ? 0 : 1;
   size_t bc2 = 0;
   uint32_t* cur2 = nullptr;
   part_carve_tail(pa, scratch, true, &bc2, &cur2);

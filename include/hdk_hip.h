@@ -447,6 +447,11 @@ typedef struct hdk_hip_kernel_options { /* KernelOptions, QE/DeviceKernel.h:33-4
                                                   the batched interpreter as the consumer the pre-pass (32 B/row of traffic)
                                                   costs more than the locality returns (C3: 2.2 + 4.2 ms against 5.0 ms) */
 #define HDK_HIP_LAUNCH_NO_CLUSTER_PROBES 512u   /* overrides the flag above */
+#define HDK_HIP_LAUNCH_ACCUMULATE 2048u         /* hdk_hip_aggregate_from_ranks: GROUPBY_BUF[0] already holds an owner table (an
+                                                  earlier CHUNK of the same exchange put it there): merge this call's tuples
+                                                  into it instead of writing the table completely -- what lets a rank's rows be
+                                                  exchanged in chunks, scatter of chunk k + 1 beside the all-to-all of chunk k
+                                                  beside the aggregation of chunk k - 1 */
 #define HDK_HIP_LAUNCH_WIDE_TUPLES 1024u       /* multi-pass strategies: do NOT narrow tuples from the column statistics (8-byte
                                                   tuples of the radix-partitioned group-by / the tuple exchange).  The
                                                   statistics are per rank: ranks of one exchange must agree on the tuple

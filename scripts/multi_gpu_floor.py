@@ -263,12 +263,98 @@ def part_c(args, mgr, quiet=False):
     return res
 
 
+def part_d(args, mgr, quiet=False, link_gbps=64.0, nchunks=4):
+    """The exchange PIPELINE of one rank of an 8-GPU C5 job, emulated on one device (VERDICT r4 task 6): the rank's rows in
+    `nchunks` chunks, scatter(k + 1) / wire(k) / aggregate(k - 1) on three streams (hdk_amd.distributed.ChunkedTupleExchange).
+    The wire of chunk k is a device copy of its segments plus a spin of segment_bytes / `link_gbps` -- the modelled time of
+    one all-to-all over point-to-point xGMI links, every owner's segment on its own link; the owner's inbox is the rank's own
+    segment for owner 0 eight times over (the tuple count of the real inbox, the rank's own keys).  Reports the serial step
+    (stage after stage, as bench.py's N > 1 step runs today) beside the overlapped one and max(compute, wire)."""
+    import torch
+    from hdk_amd import distributed as D
+    from workloads import Workload, fragment_rows
+    world, dev, rows = args.world, 0, 1_000_000_000
+    frs = fragment_rows(rows)
+    mine = D.shard_fragments(len(frs), world, 0)
+    w = Workload("c5", rows, dev, mgr, frag_ids=mine)
+    cp = w.compiled
+    chunks = [mine[i * len(mine) // nchunks:(i + 1) * len(mine) // nchunks] for i in range(nchunks)]
+    chunks = [c for c in chunks if c]
+    bounds = [max(sum(frs[f] for f in D.shard_fragments(len(frs), world, r)[i * len(mine) // nchunks:(i + 1) * len(mine) // nchunks])
+                  for r in range(world)) for i in range(len(chunks))]
+    probe = w.ex.prepare(cp, chunks[0])
+    x0 = D.TupleExchange(probe, world, bounds[0])
+    table = torch.empty(x0.owner_table_quads, dtype=torch.int64, device="cuda")
+    probe.free()
+    steps = [w.ex.prepare(cp, c, out_ptr=table.data_ptr()) for c in chunks]
+    pipe = D.ChunkedTupleExchange(steps, world, bounds)
+    # cycles of torch.cuda._sleep per millisecond
+    ts = torch.cuda.current_stream()
+    torch.cuda._sleep(1_000_000)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ts)
+    torch.cuda._sleep(20_000_000)
+    e1.record(ts)
+    torch.cuda.synchronize()
+    cyc_per_ms = 20_000_000 / e0.elapsed_time(e1)
+    wire_ms = [int(c.shape.segment_bytes) / (link_gbps * 1e9) * 1e3 for c in pipe.chunks]
+
+    def wire(k, c, stream):
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(int(wire_ms[k] * cyc_per_ms))
+            for r in range(world):
+                c.segment(c.recv, r).copy_(c.segment(c.send, 0), non_blocking=True)
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None or dt < best else best
+        return best
+
+    cur = torch.cuda.current_stream()
+    overlapped = wall(lambda: pipe.run(wire, after=cur), args.steps)
+    errs = pipe.error_codes()
+
+    def serial():
+        h = cur.cuda_stream
+        for k, c in enumerate(pipe.chunks):
+            c.scatter(h)
+        for k, c in enumerate(pipe.chunks):
+            wire(k, c, cur)
+        for k, c in enumerate(pipe.chunks):
+            c.aggregate(h, accumulate=k > 0)
+
+    serial_ms = wall(serial, args.steps)
+    h = cur.cuda_stream
+    scatter_ms = wall(lambda: [c.scatter(h) for c in pipe.chunks], args.steps)
+    agg_ms = wall(lambda: [c.aggregate(h, accumulate=k > 0) for k, c in enumerate(pipe.chunks)], args.steps)
+    res = {"chunks": len(chunks), "link_gbps_assumed": link_gbps, "rows_per_rank": w.local_rows,
+           "scatter_ms": scatter_ms, "aggregate_ms": agg_ms, "compute_ms": scatter_ms + agg_ms, "wire_ms_modelled": sum(wire_ms),
+           "step_ms_serial": serial_ms, "step_ms_overlapped": overlapped,
+           "overlapped_over_max_of_compute_and_wire": overlapped / max(scatter_ms + agg_ms, sum(wire_ms)),
+           "chunk_error_codes": errs,
+           "projected_rows_per_s_at_%d_gpus" % world: rows / (overlapped * 1e-3)}
+    if not quiet:
+        print(json.dumps({"c5_exchange_pipeline": res}), flush=True)
+    for s_ in steps:
+        s_.free()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="a,b")
     ap.add_argument("--configs", default="c2,q1,q2,q3,q4")
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--chunks", type=int, default=4, help="part D: chunks of the exchange pipeline")
     ap.add_argument("--one-rank", action="store_true", help="part B: run rank 0 only and use its segment 8 times")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -284,6 +370,8 @@ def main():
         out["c5_table_exchange_merge"] = part_b(args, mgr)
     if "c" in args.only:
         out["c5_tuple_exchange"] = part_c(args, mgr)
+    if "d" in args.only:
+        out["c5_exchange_pipeline"] = part_d(args, mgr, nchunks=args.chunks)
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)

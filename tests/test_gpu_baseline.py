@@ -279,6 +279,116 @@ def test_multi_gpu_tuple_exchange_emulated(oracle, gpu_executor_factory, shape, 
     assert per_owner.min() > 0.8 * per_owner.mean()  # mulhi(hash, G) spreads the keys evenly
 
 
+def _chunks_of(frags, k):
+    k = max(1, min(k, len(frags)))
+    return [frags[i * len(frags) // k:(i + 1) * len(frags) // k] for i in range(k)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("target,world,nchunks", [("sum", 8, 3), ("multi", 4, 2), ("sum", 2, 4)])
+def test_multi_gpu_tuple_exchange_in_chunks(oracle, gpu_executor_factory, target, world, nchunks):
+    """The exchange of a rank's rows in K chunks (HDK_HIP_LAUNCH_ACCUMULATE: chunk 0 writes the owner's table, chunks 1.. merge
+    into it), ranks emulated one after another: the union of the owners' tables is the oracle's result, owners disjoint,
+    the reference's placement in every owner's table."""
+    import torch
+    from hdk_amd import distributed as D
+    rng = np.random.default_rng(79)
+    n = 900_000
+    st = ArrowStorage()
+    v = rng.integers(-2**31 + 1, 2**31, n, dtype=np.int64)
+    v[rng.random(n) < 0.03] = A.NULL_BIGINT
+    st.import_numpy("t", {"k": rng.integers(0, 40_000, n, dtype=np.int64) * 7 - 50_000, "v": v, "f": rng.normal(size=n)},
+                    fragment_size=25_000)
+    targets = [Agg("sum", ColRef("v"), "s")] if target == "sum" else [Agg("sum", ColRef("v"), "s"), Agg("count", None, "c"),
+                                                                       Agg("min", ColRef("v"), "mn"), Agg("avg", ColRef("f"), "af")]
+    q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=131_071, targets=[KeyRef(0, "key")] + targets)
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    frag_rows = st.get("t").frag_rows
+    shards = [D.shard_fragments(len(frag_rows), world, r) for r in range(world)]
+    chunked = [_chunks_of(sh, nchunks) for sh in shards]
+    bounds = [max(sum(frag_rows[f] for f in chunked[r][k]) for r in range(world)) for k in range(nchunks)]
+    h = torch.cuda.current_stream().cuda_stream
+    xs, tables, keep = [], [], []
+    for r in range(world):
+        probe = ex.prepare(cp, frag_ids=chunked[r][0])
+        x0 = D.TupleExchange(probe, world, bounds[0])
+        table = torch.empty(x0.owner_table_quads, dtype=torch.int64, device="cuda")
+        probe.free()
+        row = []
+        for k in range(nchunks):
+            step = ex.prepare(cp, frag_ids=chunked[r][k], out_ptr=table.data_ptr())
+            x = D.TupleExchange(step, world, bounds[k])
+            x.scatter(h)
+            row.append(x)
+        xs.append(row)
+        tables.append(table)
+    torch.cuda.synchronize()
+    all_rows = []
+    for o in range(world):
+        for k in range(nchunks):
+            x = xs[o][k]
+            for r in range(world):
+                x.segment(x.recv, r).copy_(xs[r][k].segment(xs[r][k].send, o))
+            x.aggregate(h, accumulate=k > 0)
+        torch.cuda.synchronize()
+        for x in xs[o]:
+            assert int(x.step.mgr.to_host(x.step.d_err.ptr, 4, 0, np.int32)[0]) == 0
+        t = tables[o].cpu().numpy()
+        ne = xs[o][0].owner_entries
+        all_rows.extend(_rows(cp, t, ne))
+        _assert_reference_placement(oracle, cp, t, ne)
+    keys = [r[0] for r in all_rows]
+    assert len(keys) == len(set(keys))
+    g, w = sorted(all_rows, key=lambda r: r[0]), _rows(cp, want)
+    assert len(g) == len(w)
+    for a, b in zip(g, w):
+        for x_, y in zip(a, b):
+            if isinstance(y, float):
+                assert abs(x_ - y) <= 1e-6 * max(1e-300, abs(y)), (a, b)
+            else:
+                assert x_ == y, (a, b)
+
+
+def test_chunked_exchange_pipeline_on_three_streams(oracle, gpu_executor_factory):
+    """ChunkedTupleExchange.run: scatter / wire / aggregate of consecutive chunks on three streams, one rank exchanging with
+    itself (the wire is a device copy on the wire stream): the owner's table is the oracle's result."""
+    import torch
+    from hdk_amd import distributed as D
+    rng = np.random.default_rng(80)
+    n = 700_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": rng.integers(0, 30_000, n, dtype=np.int64) * 5, "v": rng.integers(-10**6, 10**6, n, dtype=np.int64)},
+                    fragment_size=50_000)
+    q = QueryUnit("t", groupby=[ColRef("k")], force_baseline=True, baseline_entry_count=99_991,
+                  targets=[KeyRef(0, "key"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    ex = gpu_executor_factory(st)
+    frags = list(range(len(st.get("t").frag_rows)))
+    chunks = _chunks_of(frags, 4)
+    bounds = [sum(st.get("t").frag_rows[f] for f in c) for c in chunks]
+    probe = ex.prepare(cp, frag_ids=chunks[0])
+    x0 = D.TupleExchange(probe, 1, bounds[0], owner_entry_count=cp.entry_count)
+    table = torch.empty(x0.owner_table_quads, dtype=torch.int64, device="cuda")
+    probe.free()
+    steps = [ex.prepare(cp, frag_ids=c, out_ptr=table.data_ptr()) for c in chunks]
+    pipe = D.ChunkedTupleExchange(steps, 1, bounds, owner_entry_count=cp.entry_count)
+
+    def wire(k, c, stream):
+        with torch.cuda.stream(stream):
+            c.recv.copy_(c.send, non_blocking=True)
+
+    for _ in range(2):  # (a second step over the same buffers: chunk 0 rewrites the table)
+        pipe.run(wire, after=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert pipe.error_codes() == [0] * len(steps)
+    t = table.cpu().numpy()
+    _check_rows(cp, t, want)
+    _assert_reference_placement(oracle, cp, t)
+
+
 def test_tuple_exchange_flags_what_it_cannot_carry(oracle, gpu_executor_factory):
     """Skew (one key owning most rows overflows its owner sub-slab) and stale column statistics (a value outside the
     announced range) leave HDK_HIP_ERR_EXCHANGE_INCOMPLETE in the owner's error word -- never a wrong table; the
