@@ -1044,6 +1044,18 @@ static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s,
                       : "hdk_scan_agg_vec";
 }
 
+// A GroupByPerfectHash plan of the packed on-chip kernels' shape (scan_bh_packed.h: one plain key column, every aggregate over
+// one integer column inside its statistics) that would otherwise run on the batched interpreter or -- its table beyond LDS --
+// on the perfect-partitioned / global-atomics kernels: the reference's PerfectHashSingleCol benchmark queries (PHS001-005:
+// count, sum, max, min, avg by x10 ... x100k) are this shape; the interpreter ran them at 7 % of the HBM roofline, and 1 000
+// groups fell to global atomics (1.5 s per 256 M rows, profiles/r05_bh_configs.txt).
+static bool perfect_goes_packed(const hdk_hip_plan* p, const LaunchShape& s, const hdk_hip_kernel_options* ko) {
+  if (p->query_kind != HDK_Q_PERFECT_HASH || !bh_packed_kernel_name(p, ko)) return false;
+  if (s.strategy == STRAT_GLOBAL) return true;
+  if (s.strategy != STRAT_LDS) return false;
+  return strcmp(scan_kernel_name(p, s, ko, false, false), "hdk_scan_agg_vec") == 0;
+}
+
 // ---- hdk_join_agg_direct (scan_join_direct.h): the matcher ------------------------------------------------------------
 static bool jd_leaf_from(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int xc, JdLeaf* out) {
   out->nullable = l.nullable;
@@ -2077,7 +2089,9 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
       }
     }
   }
-  if (s.strategy == STRAT_LDS) {
+  if (perfect_goes_packed(plan, s, ko)) {
+    snprintf(out, out_len, "%s", bh_packed_kernel_name(plan, ko));
+  } else if (s.strategy == STRAT_LDS) {
     snprintf(out, out_len, "%s,hdk_finalize",
              scan_kernel_name(plan, s, ko, ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR)),
                               ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)));
@@ -2263,6 +2277,21 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     if (route == JOIN_ROUTE_NONE && match_cluster_join(plan, ko, &ca)) {
       st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch.p);
       if (st) return st;
+    }
+  }
+  if (perfect_goes_packed(plan, shape, ko)) {
+    if (init_output) {
+      st = init_row_wise_output(plan, params, device_id, s);
+      if (st) return st;
+    }
+    bool launched = false;
+    st = launch_bh_packed(plan, d_plan, kp, ko, props, s, &launched);
+    if (st) return st;
+    if (launched) {
+      if (timed) {
+        HDK_HIP_CHECK(hipEventRecord(e1, s));
+      }
+      return HDK_HIP_OK;
     }
   }
   if (shape.strategy == STRAT_LDS) {

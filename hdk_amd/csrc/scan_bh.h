@@ -118,7 +118,26 @@ HDK_DEV void bh_fold_group_fn(const hdk_hip_plan* p, const TableShape shape, con
   int64_t entry;
   bool fresh = false;
   int64_t kv[2] = {keyword, 0};
-  if (p->key_width == 4) {
+  if (p->query_kind == HDK_Q_PERFECT_HASH) {
+    // a GroupByPerfectHash table fed from the same LDS tables (one key column, no bucket): get_group_value_fast[_keyless]
+    // (QE/GroupByRuntime.cpp:198-246) -- entry = key - min with a NULL key under its translated value, the key stored when
+    // the layout keeps one; `keyword` is the key column's value
+    int64_t k = keyword;
+    if (p->key_has_nulls[0] && p->keys[0].nullable && k == p->keys[0].null_val) {
+      k = p->key_null_translated[0];
+    }
+    const uint64_t e = static_cast<uint64_t>(k - p->key_min[0]);
+    if (e >= entry_count) {
+      err = HDK_HIP_ERR_OUT_OF_SLOTS;  // a key outside the range the layout was sized for
+      return;
+    }
+    entry = static_cast<int64_t>(e);
+    fresh = true;  // (a projected key is stored by every writer: the same value)
+    if (!p->keyless) {
+      int64_t* kp = p->output_columnar ? buf + e : buf + e * p->row_size_quad;
+      g_store_i64(kp, k);
+    }
+  } else if (p->key_width == 4) {
     const int32_t key[HDK_HIP_MAX_KEYS] = {static_cast<int32_t>(keyword), static_cast<int32_t>(static_cast<uint64_t>(keyword) >> 32), 0, 0};
     kv[0] = key[0];
     kv[1] = key[1];

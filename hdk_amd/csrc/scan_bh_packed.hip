@@ -21,7 +21,11 @@ static bool bh_packed_off() {
 
 // the part of the match that does not depend on the table's size: columns, statistics, the word kinds
 static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, int* kw_out, int* vw_out) {
-  if (bh_packed_off() || p->query_kind != HDK_Q_BASELINE_HASH) return false;
+  // GroupByBaselineHash, or a GroupByPerfectHash layout of the same shape (one plain key column, no bucket): the LDS side is
+  // the same, the fold addresses the table by key - min instead of the probe sequence (scan_bh.h: bh_fold_group_fn)
+  const bool perfect = p->query_kind == HDK_Q_PERFECT_HASH;
+  if (bh_packed_off() || (p->query_kind != HDK_Q_BASELINE_HASH && !perfect)) return false;
+  if (perfect && (p->key_count != 1 || p->key_bucket[0] > 1 || p->keys[0].nsteps != 0)) return false;
   if (ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_PARTITIONED))) return false;
   if (launch_forces_generic(ko)) return false;
   if (p->num_joins || p->key_count != 1 || (p->key_width != 4 && p->key_width != 8)) return false;
@@ -118,7 +122,10 @@ static void bh_packed_geometry(BhPackedArgs* a, uint32_t cap_log2, uint32_t rep)
 static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhPackedArgs* a, int* kw, int* vw, int* block,
                             uint32_t* lds_bytes) {
   if (!match_bh_packed_shape(p, ko, a, kw, vw)) return false;
-  const uint32_t cap_log2 = std::max<uint32_t>(pow2_ceil_log2(p->entry_count < 4 ? 4 : p->entry_count), 2);
+  uint32_t cap_log2 = std::max<uint32_t>(pow2_ceil_log2(p->entry_count < 4 ? 4 : p->entry_count), 2);
+  // (a perfect-hash layout has one entry per possible key: every one may be in use, and tags at a load of 1 probe for ever --
+  // twice the entries where LDS allows; an open-addressing table is sized at twice its groups already)
+  if (p->query_kind == HDK_Q_PERFECT_HASH && 24ull * ((2ull << cap_log2) + 4) <= kBhPackedMaxBytes512) ++cap_log2;
   const uint64_t one = 24ull * ((1ull << cap_log2) + 4);
   if (one > kBhPackedMaxBytes512) return false;
   uint32_t rep = 32;

@@ -300,3 +300,53 @@ def test_small_table_with_stale_statistics(oracle, gpu_executor_factory):
     step.free()
     _check_rows(cp, res.buffer, want)
     _assert_reference_placement(oracle, cp, res.buffer)
+
+
+# ---- GroupByPerfectHash plans of the same shape through the same kernels (the reference's PerfectHashSingleCol queries) -------
+def _phs_query(xcol, table="t", **kw):
+    y = ColRef("y10")
+    return QueryUnit(table, groupby=[ColRef(xcol)],
+                     targets=[KeyRef(0, "k"), Agg("count", y, "c"), Agg("sum", y, "s"), Agg("max", y, "mx"), Agg("min", y, "mn"),
+                              Agg("avg", y, "a")], **kw)
+
+
+@pytest.mark.parametrize("xcol", ["x10", "x100", "x1k"])
+@pytest.mark.parametrize("columnar", [False, True])
+def test_perfect_hash_benchmark_shape_on_the_packed_kernel(oracle, gpu_executor_factory, xcol, columnar):
+    """PHS001-003: count / sum / max / min / avg of one int column by an int key with a perfect-hash layout (NULL keys and
+    NULL arguments present): the buffer must equal the oracle's bit for bit -- entries, stored keys, untouched slots."""
+    from util import assert_buffers_equal
+    st = _bh_table(600_000, 31)
+    ex = gpu_executor_factory(st)
+    q = _phs_query(xcol, output_columnar=columnar)
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.query_kind == A.Q_PERFECT_HASH
+    step = ex.prepare(cp)
+    assert step.kernel_names().startswith("hdk_scan_agg_bh_packed"), step.kernel_names()
+    res = step.run()
+    assert_buffers_equal(cp, res.buffer, want)
+    step.launch()  # a second launch accumulates
+    twice = step.fetch()
+    step.free()
+    c1, c2 = res.to_columns(), twice.to_columns()
+    assert [2 * x for x in c1["c"]] == c2["c"] and c1["k"] == c2["k"]
+    # the interpreter and the global-atomics kernels give the identical buffer
+    assert_buffers_equal(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+    assert_buffers_equal(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).buffer, want)
+
+
+@pytest.mark.timeout(900)
+def test_perfect_hash_table_beyond_lds_by_hash_bins(oracle, gpu_executor_factory):
+    """PHS004's size class: 9 000 groups -- the table does not fit LDS, the rows go through the 256-bin passes and the fold
+    addresses the perfect-hash table by key - min."""
+    from util import assert_buffers_equal
+    st = _mid_table(4_400_000, 9_000, 32)
+    ex = gpu_executor_factory(st)
+    q = _phs_query("x")
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.query_kind == A.Q_PERFECT_HASH
+    step = ex.prepare(cp)
+    assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+    res = step.run()
+    step.free()
+    assert_buffers_equal(cp, res.buffer, want)
