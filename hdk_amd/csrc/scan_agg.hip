@@ -1517,8 +1517,12 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     if (ke.leaf0.nullable) p_nullable[ki] = true, p_null[ki] = ke.leaf0.null_val;
     if (ke.nsteps == 1) {
       const hdk_hip_step& sp = ke.steps[0];
-      if (sp.op != HDK_OP_DIV || sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT || sp.rhs.ival < 1 || sp.rhs.ival > INT32_MAX) return false;
+      if ((sp.op != HDK_OP_DIV && sp.op != HDK_OP_MOD) || sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT || sp.rhs.ival < 1 ||
+          sp.rhs.ival > INT32_MAX) {
+        return false;
+      }
       ga->key_div = static_cast<int32_t>(sp.rhs.ival);
+      ga->key_mod = sp.op == HDK_OP_MOD;
       if (ga->key_div >= 2) magic_u32(static_cast<uint32_t>(ga->key_div), &ga->div_magic, &ga->div_shift);
     }
     ga->grouped = 1;
@@ -1609,9 +1613,17 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   return true;
 }
 
+// `bh`: the launch belongs to a GroupByBaselineHash plan run through an internal dense table (launch_baseline_sliced_join):
+// armed behind the passes is the open-addressing interpreter of that plan, and the slabs are folded into the open-addressing
+// table by hdk_bh_fold_dense instead of hdk_finalize.
+struct BhBehindSliced {
+  const hdk_hip_plan* plan;  // the baseline-hash plan (host)
+  const hdk_hip_kernel_options* ko;
+  BhDenseFold fold;
+};
 static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, Slice2Args& ga,
                                    const LaunchShape& shape, int64_t* slabs, const hdk_hip_device_properties* props, hipStream_t s,
-                                   bool* launched) {
+                                   bool* launched, BhBehindSliced* bh = nullptr) {
   *launched = false;
   SliceArgs& sa = ga.s;
   const bool two_pay = ga.npay == 2;
@@ -1698,6 +1710,16 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   }
   // armed behind the passes: the batched interpreter over the plan's own columns, in row order -- clustered input, stale
   // statistics, an overflow area that filled up
+  if (bh) {
+    int32_t st = launch_bh_vec_armed(bh->plan, d_plan, kp, bh->ko, props, s, sa.mode);
+    if (st) return st;
+    bh->fold.slabs = slabs;
+    bh->fold.num_slabs = shape.grid;
+    st = launch_bh_fold_dense(bh->fold, d_plan, kp, s);
+    if (st) return st;
+    *launched = true;
+    return HDK_HIP_OK;
+  }
   VecArgs v;
   v.plan = d_plan;
   v.kp = kp;
@@ -1705,6 +1727,8 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   v.entry_count = shape.entry_count;
   v.rep = shape.rep;
   v.run_if = sa.mode;
+  v.bh_cap_log2 = 0;
+  v.bh_pad_ = 0;
   hipLaunchKernelGGL(hdk_scan_agg_vec_join, dim3(shape.grid), dim3(kVecBlock), shape.lds_bytes, s, v);
   HDK_HIP_CHECK(hipGetLastError());
   *launched = true;
@@ -1722,6 +1746,78 @@ static JoinRoute route_join(const hdk_hip_plan* plan, const LaunchShape& shape, 
   }
   if (match_join_sliced2(plan, shape, ko, ga)) return JOIN_ROUTE_SLICED2;
   return direct ? JOIN_ROUTE_DIRECT : JOIN_ROUTE_NONE;
+}
+
+// ---- GroupByBaselineHash behind the sliced join (`GROUP BY dim.dval % 64`) -----------------------------------------
+// The reference's planner has no range for a modulo (QE/ExpressionRange.cpp:391-419), so the OUTPUT is an open-addressing
+// table -- but the kernel can bound the key itself: payload % m lies in (-m, m).  The plan runs as an INTERNAL perfect-hash
+// plan over that range (the same scatter and LDS passes as C3g, a dense private group table beside every slice); the slabs
+// are folded into the open-addressing table through the reference's probe sequence (scan_bh.hip: hdk_bh_fold_dense).
+static bool baseline_sliced_join_plan(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props,
+                                      hdk_hip_plan* inner, LaunchShape* shape, Slice2Args* ga, BhDenseFold* fold) {
+  if (p->query_kind != HDK_Q_BASELINE_HASH || p->num_joins != 1 || p->key_count != 1 || p->key_width != 8 || p->output_columnar) return false;
+  if (!ko || (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_PARTITIONED)) || launch_forces_generic(ko)) return false;
+  if (!bh_lds_kernel_name(p, ko)) return false;  // (the armed fallback is the open-addressing interpreter)
+  const hdk_hip_expr& ke = p->keys[0];
+  if (ke.nsteps != 1 || ke.leaf0.kind != HDK_LEAF_COL) return false;
+  const hdk_hip_step& sp = ke.steps[0];
+  if (sp.op != HDK_OP_MOD || sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT || sp.rhs.ival < 1 || sp.rhs.ival > 4096) return false;
+  const hdk_hip_col& kc = p->cols[ke.leaf0.col];
+  const int64_t m = sp.rhs.ival;
+  const bool nonneg = kc.has_stats && kc.min_val >= 0;
+  const int64_t lo = nonneg ? 0 : -(m - 1), hi = m - 1;
+  const bool has_null = ke.nullable != 0;
+  *inner = *p;
+  inner->query_kind = HDK_Q_PERFECT_HASH;
+  inner->keyless = 0;
+  inner->idx_target_as_key = -1;
+  inner->key_min[0] = lo;
+  inner->key_bucket[0] = 0;
+  inner->key_card[0] = static_cast<uint32_t>(hi - lo + 1 + (has_null ? 1 : 0));
+  inner->key_has_nulls[0] = has_null ? 1 : 0;
+  inner->key_null_translated[0] = hi + 1;
+  inner->entry_count = static_cast<uint32_t>(hi - lo + 1 + (has_null ? 1 : 0));
+  *shape = choose_shape(inner, ko, props);
+  if (shape->strategy != STRAT_LDS || !match_join_sliced2(inner, *shape, ko, ga)) return false;
+  memset(fold, 0, sizeof(*fold));
+  fold->entries = inner->entry_count;
+  fold->out_entry_count = p->entry_count;
+  fold->wpe = ga->wpe;
+  for (int w = 0; w < ga->wpe; ++w) fold->wop[w] = ga->wop[w];
+  fold->nword_mask = ga->nword_mask;
+  fold->key_lo = lo;
+  fold->null_entry = has_null ? static_cast<uint32_t>(hi + 1 - lo) : 0xFFFFFFFFu;
+  fold->null_key = ke.null_val;
+  return true;
+}
+
+const char* baseline_sliced_join_names(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {
+  hdk_hip_plan inner;
+  LaunchShape shape;
+  Slice2Args ga;
+  BhDenseFold fold;
+  if (!baseline_sliced_join_plan(p, ko, props, &inner, &shape, &ga, &fold)) return nullptr;
+  return ga.two_level ? "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_scatter_level2,hdk_join_agg_sliced2,hdk_scan_agg_bh_vec_join,hdk_bh_fold_dense"
+                      : "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_bh_vec_join,hdk_bh_fold_dense";
+}
+
+int32_t launch_baseline_sliced_join(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                                    const hdk_hip_device_properties* props, hipStream_t s, bool* launched) {
+  *launched = false;
+  hdk_hip_plan inner;
+  LaunchShape shape;
+  Slice2Args ga;
+  BhBehindSliced bh;
+  if (!baseline_sliced_join_plan(plan, ko, props, &inner, &shape, &ga, &bh.fold)) return HDK_HIP_OK;
+  bh.plan = plan;
+  bh.ko = ko;
+  AsyncScratch slabs(s);
+  if (hipMallocAsync(&slabs.p, static_cast<size_t>(shape.grid) * shape.slab_words * 8, s) != hipSuccess) {
+    (void)hipGetLastError();
+    slabs.p = nullptr;
+    return HDK_HIP_OK;
+  }
+  return launch_join_sliced2(&inner, d_plan, kp, ga, shape, static_cast<int64_t*>(slabs.p), props, s, launched, &bh);
 }
 
 static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
@@ -2081,7 +2177,8 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
         out += n;
         out_len -= static_cast<size_t>(n);
       }
-    } else if (route == JOIN_ROUTE_NONE && match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
+    } else if (route == JOIN_ROUTE_NONE && !baseline_sliced_join_names(plan, ko, props) &&
+               match_cluster_join(plan, ko, &ca)) {  // the pre-pass that clusters the outer rows by join-key range
       const int n = snprintf(out, out_len, "hdk_cluster_by_key,hdk_cluster_params,");
       if (n > 0 && static_cast<size_t>(n) < out_len) {
         out += n;
@@ -2098,7 +2195,11 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   } else if (s.strategy == STRAT_PROJECT) {
     project_describe(plan, ko, out, out_len);
   } else {
-    baseline_describe(plan, ko, out, out_len);
+    if (const char* sj = baseline_sliced_join_names(plan, ko, props)) {  // a bounded key behind a large join table
+      snprintf(out, out_len, "%s", sj);
+    } else {
+      baseline_describe(plan, ko, out, out_len);
+    }
   }
   return HDK_HIP_OK;
 }
@@ -2274,7 +2375,8 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
     // (the direct and the sliced join kernels cluster their own input, as tuples)
     const JoinRoute route = generic ? JOIN_ROUTE_NONE : route_join(plan, shape, ko, &jd, &g2);
-    if (route == JOIN_ROUTE_NONE && match_cluster_join(plan, ko, &ca)) {
+    // (a baseline-hash plan behind the sliced join clusters its own input, as tuples: launch_baseline_sliced_join)
+    if (route == JOIN_ROUTE_NONE && !baseline_sliced_join_names(plan, ko, props) && match_cluster_join(plan, ko, &ca)) {
       st = launch_cluster_join(ca, &kp, props, s, &cluster_scratch.p);
       if (st) return st;
     }

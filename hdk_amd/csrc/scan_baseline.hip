@@ -949,7 +949,9 @@ int32_t launch_baseline(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, co
   }
   {
     bool launched = false;
-    const int32_t st = launch_bh_lds(plan, d_plan, kp, ko, props, s, &launched);
+    int32_t st = launch_baseline_sliced_join(plan, d_plan, kp, ko, props, s, &launched);
+    if (st || launched) return st;
+    st = launch_bh_lds(plan, d_plan, kp, ko, props, s, &launched);
     if (st || launched) return st;
   }
   PpArgs pp;

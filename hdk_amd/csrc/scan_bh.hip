@@ -63,6 +63,71 @@ static int32_t launch_bh_fold_words(BhFoldArgs& fa, const hdk_hip_plan* d_plan, 
   return HDK_HIP_OK;
 }
 
+// ---- dense internal tables folded into the open-addressing table (scan_bh_host.h: BhDenseFold) -------------------------------
+struct BhDenseFoldArgs {
+  const hdk_hip_plan* plan;
+  KernParams kp;
+  BhDenseFold f;
+};
+// one wave per internal entry: lanes fold the slabs' words (a fixed shuffle tree: deterministic), lane 0 finds or claims the
+// group's entry on the reference's probe sequence and adds the partial in
+extern "C" __global__ __launch_bounds__(256) void hdk_bh_fold_dense(BhDenseFoldArgs a) {
+  __shared__ WordLayout wl;
+  __shared__ uint64_t s_col_off[2 * HDK_HIP_MAX_TARGETS];
+  __shared__ int64_t s_words[4][kMaxWordsPerEntry];
+  if (threadIdx.x == 0) {
+    make_word_layout(a.plan, &wl);
+  }
+  if (threadIdx.x < 2 * HDK_HIP_MAX_TARGETS) {
+    s_col_off[threadIdx.x] = a.plan->output_columnar ? columnar_slot_off(a.plan, a.f.out_entry_count, threadIdx.x) : 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t entry = blockIdx.x * 4 + wave;
+  if (entry >= a.f.entries) {
+    return;
+  }
+  const int wpe = a.f.wpe;
+  const size_t ew = static_cast<size_t>(a.f.entries) * wpe;
+  int64_t* words = s_words[wave];
+  for (int w = 0; w < wpe; ++w) {
+    const int32_t op = a.f.wop[w];
+    int64_t acc = word_identity(op);
+    for (uint32_t b = lane; b < a.f.num_slabs; b += 64) {
+      acc = word_combine(op, acc, a.f.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      const int lo = __shfl_down(static_cast<int>(static_cast<uint32_t>(acc)), d, 64);
+      const int hi = __shfl_down(static_cast<int>(static_cast<uint64_t>(acc) >> 32), d, 64);
+      acc = word_combine(op, acc, static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+    }
+    if (lane == 0) {
+      words[w] = acc;
+    }
+  }
+  if (lane != 0 || words[0] == 0) {
+    return;  // (no row of this group: nothing to claim)
+  }
+  const int64_t rows = words[0];
+  int32_t err = 0;
+  const int64_t key = entry == a.f.null_entry ? a.f.null_key : a.f.key_lo + static_cast<int64_t>(entry);
+  bh_fold_group_fn(a.plan, table_shape(a.plan), wl, a.kp.groupby_buf[0], a.f.out_entry_count, s_col_off, key,
+                   [&](int w) -> int64_t { return ((a.f.nword_mask >> w) & 1u) ? rows - words[w] : words[w]; }, err);
+  if (err) {
+    record_error(a.kp.error_code, err);
+  }
+}
+
+int32_t launch_bh_fold_dense(const BhDenseFold& fold, const hdk_hip_plan* d_plan, const KernParams& kp, hipStream_t s) {
+  BhDenseFoldArgs a;
+  a.plan = d_plan;
+  a.kp = kp;
+  a.f = fold;
+  hipLaunchKernelGGL(hdk_bh_fold_dense, dim3((fold.entries + 3) / 4), dim3(256), 0, s, a);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
 // LDS for the table: up to 32 KiB keeps three or four interpreter blocks on a CU; an unreplicated table may take 64 KiB
 // (two blocks) -- beyond that the plan goes to the partitioned or the global-atomics kernels
 constexpr uint32_t kBhLdsReplicatedBytes = 32u << 10;
@@ -235,6 +300,31 @@ const char* bh_lds_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_optio
   if (match_bh_fast(p, ko, &fa, &kw, &vw, &block)) return "hdk_scan_agg_bh_direct";
   if (!match_bh_lds(p, ko, &g)) return nullptr;
   return p->num_joins ? "hdk_scan_agg_bh_vec_join" : "hdk_scan_agg_bh_vec";
+}
+
+int32_t launch_bh_vec_armed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                            const hdk_hip_device_properties* props, hipStream_t s, const uint32_t* run_if) {
+  BhGeom g;
+  if (!match_bh_lds(plan, ko, &g)) {
+    set_error("the open-addressing interpreter does not take this plan");
+    return HDK_HIP_ERR_UNSUPPORTED;
+  }
+  const void* k = bh_kernel(plan);
+  if (g.lds_bytes > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(g.lds_bytes)));
+  }
+  VecArgs v;
+  memset(&v, 0, sizeof(v));
+  v.plan = d_plan;
+  v.kp = kp;
+  v.entry_count = g.out_entry_count;
+  v.rep = g.rep;
+  v.run_if = run_if;
+  v.bh_cap_log2 = g.cap_log2;
+  void* kargs[] = {&v};
+  HDK_HIP_CHECK(hipLaunchKernel(k, dim3(resident_grid(k, kVecBlock, g.lds_bytes, props)), dim3(kVecBlock), kargs, g.lds_bytes, s));
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
 }
 
 int32_t launch_bh_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,

@@ -70,6 +70,8 @@ struct Slice2Args {
   // group key: none (one entry), the payload, or payload / divisor; perfect hash: entry = key - key_min
   int32_t grouped;
   int32_t key_div;           // 0: the payload itself; else the literal divisor (1 .. 2^31 - 1)
+  int32_t key_mod;           // 1: the key is payload % key_div (C's truncating remainder: the sign of the payload), not the quotient
+  int32_t pad_mod_;
   uint32_t div_magic, div_shift;
   int64_t key_min;
   int64_t null_entry;        // entry of a NULL key (translated, or the NULL itself: then usually out of range)
@@ -401,8 +403,9 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
       pick(g.key_pidx, p32, pnull);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int64_t entry = pnull[k] ? g.null_entry
-                                       : static_cast<int64_t>(kd ? s2_div(p32[k], kd, g.div_magic, g.div_shift) : p32[k]) - g.key_min;
+        const int32_t quot = kd ? s2_div(p32[k], kd, g.div_magic, g.div_shift) : p32[k];
+        const int32_t keyv = g.key_mod ? p32[k] - quot * static_cast<int32_t>(kd) : quot;
+        const int64_t entry = pnull[k] ? g.null_entry : static_cast<int64_t>(keyv) - g.key_min;
         if (ok[k] && static_cast<uint64_t>(entry) >= g.entry_count) {
           err = HDK_HIP_ERR_OUT_OF_SLOTS;  // key outside the range the layout was sized for
           ok[k] = false;

@@ -14,12 +14,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ARGS = {"c3big": "--config c3 --dim-rows 100000000"}  # name -> bench arguments when they are not just --config <name>
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 ALG = {"c2": (16, 1_000_000_000), "c3": (16, 1_000_000_000), "c3g": (16, 1_000_000_000), "c3m": (16, 1_000_000_000),
        "c3big": (16, 1_000_000_000), "c5": (16, 1_000_000_000), "c5s": (16, 125_000_000),
+       "c3gm": (16, 1_000_000_000), "bh1": (8, 1_000_000_000), "bh3": (8, 1_000_000_000), "bh5": (8, 1_000_000_000),
        "q1": (4, 1_000_000_000), "q2": (10, 1_000_000_000), "q3": (10, 1_000_000_000), "q4": (18, 1_000_000_000)}
 
 

@@ -350,3 +350,32 @@ def test_perfect_hash_table_beyond_lds_by_hash_bins(oracle, gpu_executor_factory
     res = step.run()
     step.free()
     assert_buffers_equal(cp, res.buffer, want)
+
+
+@pytest.mark.parametrize("signed,nulls", [(False, False), (True, True)])
+def test_modulo_key_behind_the_sliced_join(oracle, gpu_executor_factory, signed, nulls):
+    """C3gm on the sliced LDS path (forced on a small table: HDK_HIP_LAUNCH_CLUSTER_PROBES): an internal dense group table
+    over the key's own range (-m, m), folded into the open-addressing table by hdk_bh_fold_dense; negative payloads (C's
+    truncating remainder) and NULL payloads included."""
+    rng = np.random.default_rng(41 + signed)
+    nd, n = 30_000, 700_000
+    dval = rng.integers(-10**6 if signed else 0, 10**6, nd).astype(np.int64)
+    if nulls:
+        dval[rng.random(nd) < 0.02] = A.NULL_BIGINT
+    st = ArrowStorage()
+    st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": dval})
+    st.import_numpy("fact", {"fk": rng.integers(0, nd + 30, n).astype(np.int64), "val": rng.integers(-2**31, 2**31, n).astype(np.int64)},
+                    fragment_size=230_000)
+    q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], groupby=[ColRef("dval", "dim") % 64],
+                  targets=[KeyRef(0, "g"), Agg("sum", ColRef("val"), "s"), Agg("count", None, "c")])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.query_kind == A.Q_BASELINE_HASH
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+    names = step.kernel_names()
+    assert names.startswith("hdk_join_order_probe,hdk_join_scatter_slices") and names.endswith("hdk_bh_fold_dense"), names
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    _assert_reference_placement(oracle, cp, res.buffer)
+    assert res.row_count() == (127 if signed else 64) + (1 if nulls else 0)
