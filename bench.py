@@ -445,7 +445,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
                                     "gather+fold": "all-gather of the partial tables + device fold", "single": "one GPU"}[mode])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": kernels if baseline else kernels.split(",")[0], "avg_kernel_ms": avg_scan_ms,
+                     "kernel": dominant_kernel(kernels), "kernels": kernels, "avg_kernel_ms": avg_scan_ms,
                      "alg_bytes_per_row": w.alg_bytes_per_row,
                      "note": "per GPU: this rank's rows x algorithmic bytes / mean HIP-event time of the scan launch "
                              "(all of its passes)"},
@@ -465,6 +465,21 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
     step.free()
     w.resident_out = None if (multi or baseline) else out_t  # (the end-to-end run compares its buffer with this one)
     return out, w
+
+
+# The pass of a multi-kernel launch that takes the most time, by the rocprofv3 kernel statistics of this same command
+# (profiles/r05_bench_default_kernel_stats.csv): the scatter pass of every radix strategy (C3 5.4 of 6.8 ms, C5 level 1 5.4 of
+# 12.3 ms, the 256-bin pass 4.7 of 6.7 ms); single-pass launches name their scan kernel.  `roofline.frac` is computed from the
+# HIP-event time of ALL passes either way.
+_DOMINANT = ("hdk_join_scatter_slices", "hdk_part_scatter", "hdk_bh_scatter", "hdk_pp_scatter")
+
+
+def dominant_kernel(names):
+    ks = names.split(",")
+    for d in _DOMINANT:
+        if d in ks:
+            return d
+    return ks[0]
 
 
 def _baseline_groups(torch, cp, table, entry_count):

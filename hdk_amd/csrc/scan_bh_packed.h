@@ -219,35 +219,40 @@ HDK_DEV uint32_t bh_bucket_of(const BhHot& h, int32_t key) {
 // cases sit behind wave-uniform tests: a key that is not in its bucket (probe loop, one inlined copy), a row that improves
 // MIN / MAX, a NULL argument.  Returns the mask of rows for the caller's exact path: the tag value itself as a key,
 // statistics that do not hold for the row, a full table when FULL_IS_ERROR is false.
-template <int NR, bool FULL_IS_ERROR>
+template <int NR, bool FULL_IS_ERROR, bool ALLOK = false>
 HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&key)[NR], const int32_t (&val)[NR], const bool (&ok_in)[NR],
                                 const bool (&null_in)[NR], int32_t& err) {
+  // (ALLOK: every row takes part -- full, unfiltered tiles: `ok_in` is not read.  Predicates are combined with & and |, never
+  // && and ||, and folded into VGPR bit masks row by row: the short-circuit forms became branches around two compares, and four
+  // rows of live lane masks pushed scalar registers into spill lanes inside the row loop.)
   uint32_t e[NR];
   uint32_t bucket[NR];
   uint4 t[NR];
-  bool ok[NR];
-  uint32_t slow = 0, miss = 0;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    ok[j] = ok_in[j];
-    const bool stranger = static_cast<uint32_t>(key[j]) == kBhTagEmpty ||
-                          (h.has_val && !null_in[j] && (val[j] < h.val_min || val[j] > h.val_max));
-    if (ok[j] && stranger) {
-      slow |= 1u << j;
-    }
-    ok[j] = ok[j] && !stranger;
     bucket[j] = bh_bucket_of(h, key[j]);
     t[j] = *reinterpret_cast<const uint4*>(rp + bucket[j] * 4);
   }
+  const uint32_t span = static_cast<uint32_t>(h.val_max) - static_cast<uint32_t>(h.val_min);
+  const bool has_val = h.has_val != 0;
+  uint32_t slow = 0, miss = 0, nulls = 0;
+  uint32_t e_add[NR];  // where the row's packed increment goes: its entry, or the dummy
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
+    const uint32_t bit = 1u << j;
     const uint32_t k = static_cast<uint32_t>(key[j]);
-    const uint32_t s = t[j].x == k ? 0u : (t[j].y == k ? 1u : (t[j].z == k ? 2u : 3u));
-    const bool hit = t[j].x == k || t[j].y == k || t[j].z == k || t[j].w == k;
-    e[j] = ok[j] ? bucket[j] * 4 + s : h.cap;
-    if (ok[j] && !hit) {
-      miss |= 1u << j;
-    }
+    const bool okj = ALLOK ? true : ok_in[j];
+    const bool nullj = null_in[j];
+    // strangers: the tag value itself as a key; an argument (not NULL) outside the statistics the packed sum was sized for
+    const bool outside = has_val & !nullj & ((static_cast<uint32_t>(val[j]) - static_cast<uint32_t>(h.val_min)) > span);
+    const bool stranger = (k == kBhTagEmpty) | outside;
+    const bool in = okj & !stranger;
+    slow |= (okj & stranger) ? bit : 0u;
+    const bool h0 = t[j].x == k, h1 = t[j].y == k, h2 = t[j].z == k, h3 = t[j].w == k;
+    const uint32_t s = h0 ? 0u : (h1 ? 1u : (h2 ? 2u : 3u));
+    e[j] = in ? bucket[j] * 4 + s : h.cap;
+    miss |= (in & !(h0 | h1 | h2 | h3)) ? bit : 0u;
+    nulls |= (in & nullj) ? bit : 0u;
   }
   // strangers to their bucket (a group's first rows, keys pushed out of a full bucket): the lane's pending rows one after
   // another through ONE inlined probe loop
@@ -269,6 +274,7 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
         } else {
           slow |= 1u << j;
         }
+        nulls &= ~(1u << j);
       }
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
@@ -277,38 +283,35 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
     }
   }
   unsigned long long* packed = reinterpret_cast<unsigned long long*>(rp + h.off_packed);
-  if (!h.has_val) {
+  if (!has_val) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      atomicAdd(packed + e[j], e[j] != h.cap ? 1ull << kBhSumBits : 0ull);
+      atomicAdd(packed + e[j], 1ull << kBhSumBits);  // (rows that do not take part count into the dummy entry)
     }
     return slow;
   }
-  bool addv[NR];
-  uint32_t nulls = 0, better = 0;
-  uint64_t mm[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    addv[j] = e[j] != h.cap && !null_in[j];
-    if (e[j] != h.cap && null_in[j]) {
-      nulls |= 1u << j;
-    }
-    if (h.want_minmax) {
-      mm[j] = reinterpret_cast<const uint64_t*>(rp + h.off_mm)[e[j]];
-    }
+    e_add[j] = (nulls >> j) & 1u ? h.cap : e[j];  // a NULL argument is counted apart (below), not added
   }
   if (h.want_minmax) {
+    uint64_t mm[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      if (addv[j] && (val[j] < static_cast<int32_t>(static_cast<uint32_t>(mm[j])) || val[j] > static_cast<int32_t>(static_cast<uint32_t>(mm[j] >> 32)))) {
-        better |= 1u << j;
-      }
+      mm[j] = reinterpret_cast<const uint64_t*>(rp + h.off_mm)[e_add[j]];
+    }
+    uint32_t better = 0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      // (a row that goes to the dummy entry may "improve" the dummy's pair once: harmless)
+      const bool b = (val[j] < static_cast<int32_t>(static_cast<uint32_t>(mm[j]))) | (val[j] > static_cast<int32_t>(static_cast<uint32_t>(mm[j] >> 32)));
+      better |= b ? 1u << j : 0u;
     }
     if (__builtin_amdgcn_ballot_w64(better != 0)) {  // (after a group's first rows: never)
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         if (better & (1u << j)) {
-          int32_t* mmw = reinterpret_cast<int32_t*>(rp + h.off_mm) + 2 * e[j];
+          int32_t* mmw = reinterpret_cast<int32_t*>(rp + h.off_mm) + 2 * e_add[j];
           atomicMin(mmw, val[j]);
           atomicMax(mmw + 1, val[j]);
         }
@@ -317,8 +320,8 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
   }
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    const unsigned long long inc = (1ull << kBhSumBits) + static_cast<unsigned long long>(static_cast<long long>(val[j]));
-    atomicAdd(packed + (addv[j] ? e[j] : h.cap), addv[j] ? inc : 0ull);
+    // (the dummy entry swallows the increments of the rows that do not take part: no select on the operand)
+    atomicAdd(packed + e_add[j], (1ull << kBhSumBits) + static_cast<unsigned long long>(static_cast<long long>(val[j])));
   }
   if (__builtin_amdgcn_ballot_w64(nulls != 0)) {
 #pragma unroll
@@ -388,8 +391,11 @@ HDK_DEV void bh_packed_flush(const BhPackedArgs& a, const BhExactCtx* cx, uint32
 
 // ---- the one-pass kernel: the table fits LDS -------------------------------------------------------------------------
 // KW / VW: byte width of the key / argument column (VW 0: COUNT(*) only); U steps of 16 bytes per lane and tile
+#ifndef HDK_BH_PACKED_WAVES
+#define HDK_BH_PACKED_WAVES 0  // > 0: hold the kernel to that many waves per SIMD (A/B builds: make variant DEFS=-DHDK_BH_PACKED_WAVES=4)
+#endif
 template <int KW, int VW, int U, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed(BhPackedArgs a) {
+__global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 256 / BLOCK : 1) void hdk_scan_agg_bh_packed(BhPackedArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   __shared__ BhExactCtx s_cx;
   constexpr int WMAX = KW > VW ? KW : VW;
@@ -470,9 +476,11 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed(BhPackedArgs a) 
         uint32_t slow = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          isnull[i] = VW && a.val_nullable && v64[i] == a.val_null;
           key[i] = static_cast<int32_t>(k64[i]);
           val[i] = static_cast<int32_t>(v64[i]);
+          // (a 4-byte column's NULL test in 32 bits: the widened compare was a sign extension and two compares per row)
+          isnull[i] = VW == 4 ? (a.val_nullable != 0) & (val[i] == static_cast<int32_t>(a.val_null))
+                              : (VW != 0) & (a.val_nullable != 0) & (v64[i] == a.val_null);
           // 8-byte columns ride as their low 32 bits: what does not fit (a key outside the statistics or NULL, an argument
           // outside them) takes the exact path
           bool wide = false;
@@ -487,7 +495,11 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed(BhPackedArgs a) 
             ok[i] = false;
           }
         }
-        slow |= bh_packed_rows<R, true>(hot, rp, key, val, ok, isnull, err);
+        if (KW != 8 && VW != 8 && full && !filtered) {  // (8-byte columns: `ok` also carries the rows that do not fit 32 bits)
+          slow |= bh_packed_rows<R, true, true>(hot, rp, key, val, ok, isnull, err);
+        } else {
+          slow |= bh_packed_rows<R, true>(hot, rp, key, val, ok, isnull, err);
+        }
         // rows for the reference's own scheme (rare): one call site, the lane's pending rows one after another
         while (__builtin_amdgcn_ballot_w64(slow != 0)) {
           if (slow) {

@@ -138,7 +138,10 @@ static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options*
 
 template <int KW, int VW, int BLOCK>
 static const void* bh_packed_kernel_of() {
-  return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, 4, BLOCK>);
+#ifndef HDK_BH_PACKED_U
+#define HDK_BH_PACKED_U 4  // 16-byte steps per lane and tile (A/B builds at 256 M rows: 2 -> bh3 0.86 ms, 4 -> 0.79, 8 -> 0.87)
+#endif
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, HDK_BH_PACKED_U, BLOCK>);
 }
 template <int BLOCK>
 static const void* bh_packed_kernel(int kw, int vw) {

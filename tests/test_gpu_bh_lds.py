@@ -216,7 +216,8 @@ def test_small_open_addressing_tables_random_shapes(oracle, gpu_executor_factory
         try:
             if entries <= 300:  # (<= 512 LDS entries of at most 14 words: always within the 64 KiB the kernels take)
                 assert names.startswith(BH_KERNELS), names
-            _check_rows(cp, res.buffer, want, float32_atol=2e-3)
+            # (a float SUM is added row by row in float by the reference: its rounding noise grows like sqrt(rows of a group))
+            _check_rows(cp, res.buffer, want, float32_atol=2e-3 * max(1.0, (n / 40_000) ** 0.5))
             if res.row_count() < cp.entry_count and not columnar:
                 _assert_reference_placement(oracle, cp, res.buffer)
         except AssertionError as e:
