@@ -1367,12 +1367,17 @@ static int32_t launch_join_direct(const hdk_hip_plan* plan, JoinDirectArgs ja, c
 // ---- the general sliced join (scan_join_sliced2.h): join + perfect-hash GROUP BY on the joined column / + filters / any
 // list of integer aggregates over x and the payload, everything in 8-byte tuples ----------------------------------------
 // leaf of an aggregate argument: 0 = x (the one other 8-byte outer column), 1 = the payload, 2 = an integer literal
-static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int* xc, int* pidx = nullptr) {
+// (`yc`: the outer column that rides in the tuple's spare bits, if any -- it reads like a third payload word, pidx 2)
+static int s2_leaf_kind(const hdk_hip_plan* p, const hdk_hip_leaf& l, int kc, int* xc, int* pidx = nullptr, int yc = -1) {
   if (l.kind == HDK_LEAF_INT) return 2;
   if (l.kind != HDK_LEAF_COL) return -1;
   const hdk_hip_col& c = p->cols[l.col];
   if (c.table == -1 && (c.buf_idx == 1 || c.buf_idx == 2)) {
     if (pidx) *pidx = c.buf_idx - 1;
+    return 1;
+  }
+  if (l.col == yc) {  // (match_join_sliced2 checked it: an integer column of the outer table, 8 or 4 bytes wide)
+    if (pidx) *pidx = 2;
     return 1;
   }
   if (c.table != 0 || l.col == kc || c.width != 8 || c.kind != HDK_COL_INT) return -1;
@@ -1407,6 +1412,50 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     else if (c.table != 0) return false;  // an inner column read through the row id, or a third payload word
   }
   ga->npay = npay;
+  // ---- a second outer column: y, in the bits of the tuple's low word the key offset leaves free ------------------------------
+  // Which one: the group key's column when that is an outer column (GROUP BY fact.g ... WHERE dim.d < c); else, when the
+  // aggregates read two outer columns, the one with the narrower statistics.  It must fit: codes 1 .. max - min + 1.
+  uint32_t key_bits = 1;
+  while (key_bits < 32 && (1ull << key_bits) < range) ++key_bits;
+  auto y_fits = [&](int ci) {
+    const hdk_hip_col& c = p->cols[ci];
+    if (c.table != 0 || ci == kc || (c.width != 8 && c.width != 4) || c.kind != HDK_COL_INT || !c.has_stats || c.max_val < c.min_val) return false;
+    if (c.min_val <= static_cast<int64_t>(INT32_MIN) + 2 || c.max_val > static_cast<int64_t>(INT32_MAX)) return false;
+    return static_cast<uint64_t>(c.max_val - c.min_val) + 2 <= (1ull << (32 - key_bits));
+  };
+  int yc = -1;
+  if (!hdk_sw(SW_S2_NO_Y)) {
+    if (p->query_kind == HDK_Q_PERFECT_HASH && p->key_count == 1 && p->keys[0].leaf0.kind == HDK_LEAF_COL &&
+        p->cols[p->keys[0].leaf0.col].table == 0) {
+      yc = p->keys[0].leaf0.col;
+      if (!y_fits(yc)) return false;
+    } else {
+      int oc[2] = {-1, -1}, noc = 0;
+      auto note = [&](const hdk_hip_leaf& l) {
+        if (l.kind != HDK_LEAF_COL || p->cols[l.col].table != 0 || l.col == kc) return true;
+        for (int i = 0; i < noc; ++i) {
+          if (oc[i] == l.col) return true;
+        }
+        if (noc == 2) return false;
+        oc[noc++] = l.col;
+        return true;
+      };
+      for (int t = 0; t < p->num_targets; ++t) {
+        const hdk_hip_target& tg = p->targets[t];
+        if (tg.agg == HDK_AGG_ID || !tg.has_arg) continue;
+        if (!note(tg.arg.leaf0) || (tg.arg.nsteps >= 1 && !note(tg.arg.steps[0].rhs))) return false;
+      }
+      if (noc == 2) {
+        const bool f0 = y_fits(oc[0]), f1 = y_fits(oc[1]);
+        if (!f0 && !f1) return false;
+        if (f0 && f1) {
+          yc = (p->cols[oc[0]].max_val - p->cols[oc[0]].min_val) <= (p->cols[oc[1]].max_val - p->cols[oc[1]].min_val) ? oc[0] : oc[1];
+        } else {
+          yc = f0 ? oc[0] : oc[1];
+        }
+      }
+    }
+  }
   // ---- targets ----------------------------------------------------------------------------------------------------------
   WordLayout wl;
   make_word_layout(p, &wl);
@@ -1415,8 +1464,8 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   for (int w = 0; w < wl.wpe; ++w) ga->wop[w] = wl.wop[w];
   int xc = -1;
   int nt = 0;
-  int64_t x_null = 0, p_null[2] = {0, 0};
-  bool x_nullable = false, p_nullable[2] = {false, false};
+  int64_t x_null = 0, p_null[3] = {0, 0, 0};  // ([2]: y)
+  bool x_nullable = false, p_nullable[3] = {false, false, false};
   for (int t = 0; t < p->num_targets; ++t) {
     const hdk_hip_target& tg = p->targets[t];
     if (tg.agg == HDK_AGG_ID) {
@@ -1440,7 +1489,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     const hdk_hip_expr& e = tg.arg;
     if (e.vclass != HDK_VC_INT || e.nsteps > 1) return false;
     int pi = 0;
-    const int ka = s2_leaf_kind(p, e.leaf0, kc, &xc, &pi);
+    const int ka = s2_leaf_kind(p, e.leaf0, kc, &xc, &pi, yc);
     if (ka != 0 && ka != 1) return false;
     bool nullable = e.leaf0.nullable != 0;
     if (ka == 0 && e.leaf0.nullable) x_nullable = true, x_null = e.leaf0.null_val;
@@ -1455,7 +1504,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
       if ((sp.op != HDK_OP_ADD && sp.op != HDK_OP_SUB && sp.op != HDK_OP_MUL) || sp.out_class != HDK_VC_INT) return false;
       if (sp.check_width != 0 && sp.check_width != 8) return false;  // (a 4-byte SQL type can overflow: the interpreter checks)
       int pj = 0;
-      const int kb = s2_leaf_kind(p, sp.rhs, kc, &xc, &pj);
+      const int kb = s2_leaf_kind(p, sp.rhs, kc, &xc, &pj, yc);
       if (kb < 0) return false;
       if (kb == 2) {
         if (sp.rhs.ival <= -(int64_t(1) << 31) || sp.rhs.ival >= (int64_t(1) << 31)) return false;
@@ -1512,7 +1561,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
     if (p->key_count != 1 || p->key_bucket[0] > 1) return false;
     const hdk_hip_expr& ke = p->keys[0];
     int dummy = -1, ki = 0;
-    if (ke.nsteps > 1 || s2_leaf_kind(p, ke.leaf0, kc, &dummy, &ki) != 1) return false;
+    if (ke.nsteps > 1 || s2_leaf_kind(p, ke.leaf0, kc, &dummy, &ki, yc) != 1) return false;
     ga->key_pidx = ki;
     if (ke.leaf0.nullable) p_nullable[ki] = true, p_null[ki] = ke.leaf0.null_val;
     if (ke.nsteps == 1) {
@@ -1546,6 +1595,32 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   ga->pay_null1 = p_null[1];
   ga->pay_nullable1 = p_nullable[1];
   sa.narrow = 1;
+  if (yc >= 0) {
+    const hdk_hip_col& ycol = p->cols[yc];
+    if (ycol.has_nulls && !p_nullable[2]) return false;  // NULLs possible but no sentinel known from the leaves
+    sa.y_buf_idx = ycol.buf_idx;
+    sa.y_width = ycol.width;
+    sa.y_shift = key_bits;
+    sa.y_min = ycol.min_val;
+    sa.y_codes = static_cast<uint32_t>(ycol.max_val - ycol.min_val) + 2;
+    sa.y_nullable = p_nullable[2];
+    sa.y_null = p_null[2];
+  }
+  // two payload words in one LDS word when their statistics leave room (codes: word 0 two reserved, word 1 one)
+  if (npay == 2 && pay[0] && pay[1] && !hdk_sw(SW_S2_NO_PACKED_PAIR)) {
+    const uint64_t n0 = static_cast<uint64_t>(pay[0]->max_val - pay[0]->min_val) + 3, n1 = static_cast<uint64_t>(pay[1]->max_val - pay[1]->min_val) + 2;
+    uint32_t b0 = 1, b1 = 1;
+    while (b0 < 32 && (1ull << b0) < n0) ++b0;
+    while (b1 < 32 && (1ull << b1) < n1) ++b1;
+    if (pay[0]->max_val >= pay[0]->min_val && pay[1]->max_val >= pay[1]->min_val && b0 + b1 <= 32) {
+      ga->packed = 1;
+      ga->pk_bits0 = b0;
+      ga->pk_codes0 = static_cast<uint32_t>(n0);  // codes in all (b0 <= 31: at most 2^31)
+      ga->pk_codes1 = static_cast<uint32_t>(n1);
+      ga->pk_min0 = pay[0]->min_val;
+      ga->pk_min1 = pay[1]->min_val;
+    }
+  }
   if (xc >= 0) {
     const hdk_hip_col& xcol = p->cols[xc];
     const bool x_has_nulls = !xcol.has_stats || xcol.has_nulls;
@@ -1565,7 +1640,7 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
   const uint64_t rows = ko->total_rows;
   uint32_t slice = static_cast<uint32_t>((range + kSliceMaxBins - 1) / kSliceMaxBins);
   if (slice < 64) slice = 64;
-  const uint64_t kb4 = 4ull * npay;  // LDS bytes per key of a slice
+  const uint64_t kb4 = 4ull * (ga->packed ? 1 : npay);  // LDS bytes per key of a slice
   const bool one_level = static_cast<uint64_t>(slice) * kb4 + table_bytes1 <= kS2LdsBytes && !hdk_sw(SW_SLICE_TWO_LEVELS);
   auto pick_rep = [&](uint32_t keys) {
     uint32_t rep = 1;
@@ -1616,6 +1691,24 @@ static bool match_join_sliced2(const hdk_hip_plan* p, const LaunchShape& shape, 
 // `bh`: the launch belongs to a GroupByBaselineHash plan run through an internal dense table (launch_baseline_sliced_join):
 // armed behind the passes is the open-addressing interpreter of that plan, and the slabs are folded into the open-addressing
 // table by hdk_bh_fold_dense instead of hdk_finalize.
+typedef void (*S2Kernel)(Slice2Args);
+template <bool GROUPED, bool HASY>
+static S2Kernel s2_agg_kernel_npay(int npay_form) {
+  return npay_form == 3 ? hdk_join_agg_sliced2<GROUPED, 3, HASY> : (npay_form == 2 ? hdk_join_agg_sliced2<GROUPED, 2, HASY> : hdk_join_agg_sliced2<GROUPED, 1, HASY>);
+}
+static S2Kernel s2_agg_kernel(const Slice2Args& ga) {
+  const int form = ga.packed ? 3 : (ga.npay == 2 ? 2 : 1);
+  const bool y = ga.s.y_shift != 0;
+  return ga.grouped ? (y ? s2_agg_kernel_npay<true, true>(form) : s2_agg_kernel_npay<true, false>(form))
+                    : (y ? s2_agg_kernel_npay<false, true>(form) : s2_agg_kernel_npay<false, false>(form));
+}
+typedef void (*S2Scatter)(SliceArgs);
+static S2Scatter s2_scatter_kernel(const SliceArgs& sa) {
+  if (sa.y_shift && sa.y_width == 4) return sa.nquals ? hdk_join_scatter_slices<true, true, 4> : hdk_join_scatter_slices<true, false, 4>;
+  if (sa.y_shift) return sa.nquals ? hdk_join_scatter_slices<true, true, 8> : hdk_join_scatter_slices<true, false, 8>;
+  return sa.nquals ? hdk_join_scatter_slices<true, true, 0> : hdk_join_scatter_slices<true, false, 0>;
+}
+
 struct BhBehindSliced {
   const hdk_hip_plan* plan;  // the baseline-hash plan (host)
   const hdk_hip_kernel_options* ko;
@@ -1626,10 +1719,9 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
                                    bool* launched, BhBehindSliced* bh = nullptr) {
   *launched = false;
   SliceArgs& sa = ga.s;
-  const bool two_pay = ga.npay == 2;
-  const void* kagg = ga.grouped ? (two_pay ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<true, 2>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<true, 1>))
-                                : (two_pay ? reinterpret_cast<const void*>(hdk_join_agg_sliced2<false, 2>) : reinterpret_cast<const void*>(hdk_join_agg_sliced2<false, 1>));
-  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(ga.fslice) * 4 * (two_pay ? 2 : 1);
+  const S2Kernel kagg_fn = s2_agg_kernel(ga);
+  const void* kagg = reinterpret_cast<const void*>(kagg_fn);
+  const size_t lds_agg = static_cast<size_t>(ga.entry_count) * ga.wpe * ga.rep * 8 + static_cast<size_t>(ga.fslice) * 4 * ((ga.npay == 2 && !ga.packed) ? 2 : 1);
   if (lds_agg > 48 * 1024 && hipFuncSetAttribute(kagg, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_agg)) != hipSuccess) {
     (void)hipGetLastError();
     return HDK_HIP_OK;
@@ -1667,9 +1759,8 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   HDK_HIP_CHECK(hipMemsetAsync(sa.fill, 0, b_fill, s));
   constexpr int VR = 8;
   const size_t lds_sc = static_cast<size_t>(kSliceBlock) * VR * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
-  const void* ksc = sa.nquals ? reinterpret_cast<const void*>(hdk_join_scatter_slices<true, true>)
-                              : reinterpret_cast<const void*>(hdk_join_scatter_slices<true, false>);
-  const unsigned g_sc = scatter_grid(ksc, kSliceBlock, lds_sc, props, 2);
+  const S2Scatter ksc_fn = s2_scatter_kernel(sa);
+  const unsigned g_sc = scatter_grid(reinterpret_cast<const void*>(ksc_fn), kSliceBlock, lds_sc, props, 2);
   const uint32_t resident = static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(props->num_cu);
   uint32_t members = 1;
   if (ga.two_level) {  // persistent blocks, each walking slices b, b + nsl_par, ...
@@ -1682,11 +1773,7 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
   }
   if (members < 1 || ga.nsl_par < 1) return HDK_HIP_OK;
   hipLaunchKernelGGL(hdk_join_order_probe, dim3(256), dim3(256), 0, s, sa);
-  if (sa.nquals) {
-    hipLaunchKernelGGL((hdk_join_scatter_slices<true, true>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
-  } else {
-    hipLaunchKernelGGL((hdk_join_scatter_slices<true, false>), dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
-  }
+  hipLaunchKernelGGL(ksc_fn, dim3(g_sc), dim3(kSliceBlock), lds_sc, s, sa);
   if (ga.two_level) {
     const size_t lds_l2 = static_cast<size_t>(kSliceBlock) * VR * 8 + static_cast<size_t>(kSliceBlock) * VR + 16;
     const uint32_t ncx = (sa.nbins + kSliceXcds - 1) / kSliceXcds;
@@ -1695,19 +1782,7 @@ static int32_t launch_join_sliced2(const hdk_hip_plan* plan, const hdk_hip_plan*
     if (m2 < 1) m2 = 1;
     hipLaunchKernelGGL(hdk_join_scatter_level2, dim3(ncx * kSliceXcds * m2), dim3(kSliceBlock), lds_l2, s, ga);
   }
-  if (ga.grouped) {
-    if (two_pay) {
-      hipLaunchKernelGGL((hdk_join_agg_sliced2<true, 2>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
-    } else {
-      hipLaunchKernelGGL((hdk_join_agg_sliced2<true, 1>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
-    }
-  } else {
-    if (two_pay) {
-      hipLaunchKernelGGL((hdk_join_agg_sliced2<false, 2>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
-    } else {
-      hipLaunchKernelGGL((hdk_join_agg_sliced2<false, 1>), dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
-    }
-  }
+  hipLaunchKernelGGL(kagg_fn, dim3(ga.nsl_par * members), dim3(kSliceAggBlock), lds_agg, s, ga);
   // armed behind the passes: the batched interpreter over the plan's own columns, in row order -- clustered input, stale
   // statistics, an overflow area that filled up
   if (bh) {

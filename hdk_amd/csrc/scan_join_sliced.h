@@ -78,7 +78,22 @@ struct SliceArgs {
   int32_t nquals;
   int32_t pad_q_;
   ProjFastQual q[kMaxPlainQuals];
+  // a SECOND outer column y riding in the tuple's low word above the key offset (scan_join_sliced2.h: a group key or a
+  // measure of the outer table): [x : code(y) << y_shift | key - min], code = y - y_min + 1, 0 = NULL; the key range fits
+  // y_shift bits and the column statistics put every code below 2^(32 - y_shift).  y_shift == 0: no such column
+  int32_t y_buf_idx;
+  int32_t y_nullable;
+  uint32_t y_shift;
+  int32_t y_width;                    // 8 or 4 bytes
+  int32_t pad_y_;
+  uint32_t y_codes;                   // codes in use: 1 .. y_codes - 1 (a value outside them contradicts the statistics)
+  int64_t y_min, y_null;
 };
+
+// the key offset of a narrow tuple's low word (all of it when no second outer column rides along)
+HDK_DEV uint32_t slice_key_of(const SliceArgs& a, uint32_t lo) {
+  return a.y_shift ? lo & ((1u << a.y_shift) - 1u) : lo;
+}
 
 // ---- pass 0: is the key column already clustered? ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hdk_join_order_probe(SliceArgs a) {
@@ -148,8 +163,12 @@ __global__ __launch_bounds__(256) void hdk_join_order_probe(SliceArgs a) {
 
 // ---- pass 1: rows -> tuples, scattered by slice -----------------------------------------------------------------------
 // dynamic LDS: [kTile][TW] staging | uint8 slice of every staging slot [kTile]
-template <bool NARROW, bool Q = false>
+// YW: byte width of the second outer column (8 or 4; 0: none)
+template <bool NARROW, bool Q = false, int YW = 0>
 __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs a) {
+  static_assert(NARROW || YW == 0, "the second outer column rides in 8-byte tuples");
+  constexpr bool Y = YW != 0;
+  typedef int __attribute__((ext_vector_type(2))) i32x2;
   constexpr int VR = NARROW ? 8 : 4;
   constexpr int TW = NARROW ? 1 : 2;
   constexpr int kTile = kSliceBlock * VR;
@@ -185,6 +204,7 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
     const int8_t* const* cols = a.kp.col_buffers[f];
     const int8_t* kcol = cols[a.key_buf_idx];
     const int8_t* xcol = a.x_buf_idx >= 0 ? cols[a.x_buf_idx] : nullptr;
+    const int8_t* ycol = Y ? cols[a.y_buf_idx] : nullptr;
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       if (tid == 0) {  // block-uniform exit (the batch below has barriers)
         uint32_t stop = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,7 +223,16 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
       }
       const int64_t tile_row0 = (tile - frag_tile_begin) * kTile;
       int64_t k[VR], x[VR];
+      uint32_t ycode[VR];  // (Y) the second outer column, already as its code shifted above the key offset
       bool live[VR];
+      auto y_code = [&](int64_t y) -> uint32_t {
+        if (a.y_nullable && y == a.y_null) {
+          return 0u;
+        }
+        const uint64_t c = static_cast<uint64_t>(y) - static_cast<uint64_t>(a.y_min) + 1u;
+        stale |= c - 1u >= static_cast<uint64_t>(a.y_codes - 1u);  // (a row dropped later may raise it too: only slower, never wrong)
+        return static_cast<uint32_t>(c) << a.y_shift;
+      };
       if (tile_row0 + kTile <= nrows) {
         // full tile: rows dealt in adjacent pairs, one 16-byte non-temporal load per lane, pair and column
 #pragma unroll
@@ -220,6 +249,15 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
           }
           x[2 * u] = xx.x;
           x[2 * u + 1] = xx.y;
+          if (YW == 8) {
+            const bf_i64x2 yy = gload<bf_i64x2>(ycol, p, true);
+            ycode[2 * u] = y_code(yy.x);
+            ycode[2 * u + 1] = y_code(yy.y);
+          } else if (YW == 4) {
+            const i32x2 yy = gload<i32x2>(ycol, p, true);
+            ycode[2 * u] = y_code(yy.x);
+            ycode[2 * u + 1] = y_code(yy.y);
+          }
         }
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
@@ -232,6 +270,9 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
           live[r] = row < nrows;
           k[r] = live[r] ? gload<int64_t>(kcol, row, true) : 0;
           x[r] = (live[r] && xcol) ? gload<int64_t>(xcol, row, true) : 0;
+          if (Y) {
+            ycode[r] = !live[r] ? 0u : y_code(YW == 4 ? static_cast<int64_t>(gload<int32_t>(ycol, row, true)) : gload<int64_t>(ycol, row, true));
+          }
         }
       }
       if (Q) {  // the plan's filters on outer columns: three-valued, NULL fails (plain_quals_pass)
@@ -259,7 +300,7 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_slices(SliceArgs
           const int32_t x32 = is_null ? INT32_MIN : static_cast<int32_t>(x[r]);
           stale |= live[r] && ((!is_null && (static_cast<int64_t>(x32) != x[r] || (a.x_null32 && x32 == INT32_MIN))) ||
                                (a.x_null_is_stale && x[r] == a.x_null));
-          tup[r][0] = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(x32)) << 32) | d32);
+          tup[r][0] = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(x32)) << 32) | (Y ? d32 | ycode[r] : d32));
         } else {
           tup[r][0] = static_cast<int64_t>(d);
           tup[r][TW - 1] = x[r];

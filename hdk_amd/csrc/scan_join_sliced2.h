@@ -12,6 +12,16 @@
 //   pass 2  hdk_join_agg_sliced2<GROUPED>        below
 // with the batched interpreter (hdk_scan_agg_vec_join) armed behind them for whatever the 8-byte tuples cannot carry.
 //
+// Round 5 -- still 8 bytes per tuple:
+//   * a SECOND OUTER COLUMN y (GROUP BY fact.g ... WHERE dim.d < c; SUM(fact.a), SUM(fact.b)): the key offset needs
+//     ceil(log2(key range)) bits of the tuple's low word, y's code (y - min + 1 by its statistics, 0 = NULL) takes the
+//     rest -- 8 bits beside a 10 M-key dimension, enough for any group key whose table fits LDS.  y reads like a third
+//     payload word (pidx 2) in filters-free positions: the group key (y, y / lit, y % lit) or an aggregate argument (y,
+//     x op y, y op lit).  An 8- or 4-byte integer column.  A value outside the statistics arms the interpreter.
+//   * TWO PAYLOAD WORDS PACKED into one LDS word when their statistics fit 32 bits together (NPAY = 3): a slice keeps
+//     39 936 keys, so the star shape "filter on dim.a, group by dim.b" keeps ONE scatter level up to 10.2 M keys
+//     (c3f at 256 M rows: 3.27 -> 2.36 ms).
+//
 // Pass 2, per 1 024-thread block: the slice's int32 payloads in LDS next to a PRIVATE group table
 // (entry x word x replica, the layout of agg_common.h); per tuple one LDS probe, the payload filters, the group entry, and
 // one LDS atomic per aggregate word.  Everything about a tuple is 32 bits wide -- x and the payload fit by the column
@@ -98,10 +108,15 @@ struct Slice2Args {
   uint32_t nsl_par;          // pass 2: slices worked on at a time (blocks = nsl_par x members)
   // payload words of the fused entry ([row id | p0 | p1]): one or two int32 arrays per slice in LDS
   int32_t npay;              // 1 or 2 (0 reads as 1: a join without payload columns keeps one dummy array)
-  int32_t key_pidx;          // payload word the group key is computed from
+  int32_t key_pidx;          // what the group key is computed from: payload word 0 / 1, or 2: the outer column y of the tuple
   int32_t pay_nullable1;     // NULL rule of payload word 1 (word 0: s.pay_nullable / s.pay_null)
-  int32_t pad3_;
+  // two payload words PACKED into one LDS word when their statistics leave room (a slice holds twice the keys: star joins
+  // that filter on one dimension column and group by another keep ONE scatter level up to 10 M keys):
+  //   word = c0 | c1 << pk_bits0;  c0: 0 no partner, 1 NULL, else p0 - pk_min0 + 2;  c1: 0 NULL, else p1 - pk_min1 + 1
+  int32_t packed;
   int64_t pay_null1;
+  uint32_t pk_bits0, pk_codes0, pk_codes1, pad_pk_;
+  int64_t pk_min0, pk_min1;
 };
 
 // signed 32-bit / positive invariant divisor, truncating like C (eval_expr's `a / b`)
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Arg
       uint32_t bin[VR], rank[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        const uint32_t d = static_cast<uint32_t>(w[r]) - cfirst;  // offset inside the coarse bin (< s.slice)
+        const uint32_t d = slice_key_of(a, static_cast<uint32_t>(w[r])) - cfirst;  // offset inside the coarse bin (< s.slice)
         const uint32_t t = __umulhi(g.fmagic, d);
         bin[r] = live[r] ? ((((d - t) >> 1) + t) >> g.fshift) : 0u;
         if (bin[r] >= g.fpc) {
@@ -306,8 +321,13 @@ __global__ __launch_bounds__(kSliceBlock) void hdk_join_scatter_level2(Slice2Arg
 #define HDK_S2_K_PLAIN 6  // (8 spills 52-112 bytes per lane at the 128 registers a 1 024-thread block leaves; 6 does not and measures the same or better)
 #endif
 
-template <bool GROUPED, int NPAY>
+// NPAY: payload words per key in LDS -- 1, 2, or 3: two words packed into one (Slice2Args::packed); HASY: the tuples carry a
+// second outer column above the key offset (SliceArgs::y_shift)
+template <bool GROUPED, int NPAY, bool HASY>
 __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Args g) {
+  constexpr bool PACKED = NPAY == 3;
+  constexpr bool TWO = NPAY >= 2;      // the row function sees two payload words
+  constexpr int NW = TWO ? 2 : 1;      // payload quads of a fused entry
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   const SliceArgs& a = g.s;
   const int tid = threadIdx.x;
@@ -317,7 +337,11 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   const uint32_t my_rep = tid & (rep - 1);
   int32_t* s_pay = reinterpret_cast<int32_t*>(lds + static_cast<size_t>(ew) * rep);
   int32_t* s_pay1 = s_pay + g.fslice;  // (NPAY == 2)
-  const uint32_t fstride = 1u + static_cast<uint32_t>(NPAY);  // quads of a fused entry
+  const uint32_t fstride = 1u + static_cast<uint32_t>(NW);  // quads of a fused entry
+  const uint32_t kmask = HASY ? (1u << a.y_shift) - 1u : ~0u;
+  const int32_t y_bias = static_cast<int32_t>(a.y_min - 1);  // y = code + y_bias (code 0: NULL)
+  const uint32_t pk_mask0 = PACKED ? (1u << g.pk_bits0) - 1u : 0u;
+  const int32_t pk_bias0 = static_cast<int32_t>(g.pk_min0 - 2), pk_bias1 = static_cast<int32_t>(g.pk_min1 - 1);
   __shared__ uint32_t s_off;
   if (tid == 0) {  // (block-uniform, through LDS: another block of this kernel may raise the word meanwhile)
     s_off = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -358,20 +382,22 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   // straight vector code.  (One row at a time the scalar dispatch was the bottleneck: ~70 scalar instructions per tuple.)
   constexpr int K = GROUPED ? HDK_S2_K_GROUPED : HDK_S2_K_PLAIN;
   // ok[k]: slot k holds a tuple with a partner; x32 / p32 its outer value and payload (kSliceNull: the column's NULL)
-  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p0)[K], const int32_t (&p1)[K], bool (&ok)[K]) {
-    bool pn0[K], pn1[K], xnull[K];
+  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p0)[K], const int32_t (&p1)[K], const int32_t (&y32)[K], bool (&ok)[K]) {
+    bool pn0[K], pn1[K], yn[K], xnull[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       pn0[k] = p0[k] == kSliceNull;
-      pn1[k] = NPAY == 2 && p1[k] == kSliceNull;
+      pn1[k] = TWO && p1[k] == kSliceNull;
+      yn[k] = HASY && y32[k] == kSliceNull;
       xnull[k] = x_null32 && x32[k] == INT32_MIN;
     }
-    // the payload word a filter / the key / a target reads (wave-uniform choice; NPAY == 1: word 0)
+    // the word a filter / the key / a target reads: payload word 0 / 1, or 2: the tuple's y (wave-uniform choice)
     auto pick = [&](int pidx, int32_t (&pp)[K], bool (&pn)[K]) {
+      const bool is_y = HASY && pidx == 2, is_1 = TWO && pidx == 1;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        pp[k] = (NPAY == 2 && pidx) ? p1[k] : p0[k];
-        pn[k] = (NPAY == 2 && pidx) ? pn1[k] : pn0[k];
+        pp[k] = is_y ? y32[k] : (is_1 ? p1[k] : p0[k]);
+        pn[k] = is_y ? yn[k] : (is_1 ? pn1[k] : pn0[k]);
       }
     };
     // filters on the joined column: a NULL fails every comparison (DEF_CMP_NULLABLE)
@@ -522,18 +548,28 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   };
   // K tuples of this slice: probe the payloads in LDS, then the batch
   auto tuples = [&](const int64_t (&w)[K], const bool (&live)[K]) {
-    int32_t x32[K], p0[K], p1[K];
+    int32_t x32[K], p0[K], p1[K], y32[K];
     bool ok[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t local = static_cast<uint32_t>(w[k]) - first;
+      const uint32_t lo = static_cast<uint32_t>(w[k]);
+      const uint32_t local = (lo & kmask) - first;
       const bool in = live[k] && local < nkeys;
-      p0[k] = in ? s_pay[local] : kSliceNoMatch;
-      p1[k] = (NPAY == 2 && in) ? s_pay1[local] : 0;
+      if (PACKED) {
+        const uint32_t pw = in ? static_cast<uint32_t>(s_pay[local]) : 0u;
+        const uint32_t c0 = pw & pk_mask0, c1 = pw >> g.pk_bits0;
+        p0[k] = c0 == 0 ? kSliceNoMatch : (c0 == 1 ? kSliceNull : static_cast<int32_t>(c0) + pk_bias0);
+        p1[k] = c1 == 0 ? kSliceNull : static_cast<int32_t>(c1) + pk_bias1;
+      } else {
+        p0[k] = in ? s_pay[local] : kSliceNoMatch;
+        p1[k] = (TWO && in) ? s_pay1[local] : 0;
+      }
+      const uint32_t yc = HASY ? lo >> a.y_shift : 0u;
+      y32[k] = yc == 0 ? kSliceNull : static_cast<int32_t>(yc) + y_bias;
       x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w[k]) >> 32);
       ok[k] = p0[k] != kSliceNoMatch;  // (INNER join: no partner, no row)
     }
-    batch(x32, p0, p1, ok);
+    batch(x32, p0, p1, y32, ok);
   };
   // the block's slices (one level: exactly one; two levels: slice, slice + nsl_par, ...), each: payloads into LDS, then its
   // tuples -- 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
@@ -553,7 +589,25 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
       const int64_t* e = table + static_cast<uint64_t>(first + i) * fstride;
       const int64_t rid = __builtin_nontemporal_load(e);
       int32_t p32 = kSliceNoMatch, q32 = 0;
-      if (rid >= 0) {
+      if (PACKED) {
+        uint32_t c0 = 0, c1 = 0;
+        if (rid >= 0) {
+          const int64_t y = __builtin_nontemporal_load(e + 1);
+          const int64_t z = __builtin_nontemporal_load(e + 2);
+          c0 = 1;
+          if (!(a.pay_nullable && y == a.pay_null)) {
+            const uint64_t d0 = static_cast<uint64_t>(y) - static_cast<uint64_t>(g.pk_min0);
+            bad |= d0 >= g.pk_codes0 - 2u;  // a payload outside its statistics
+            c0 = static_cast<uint32_t>(d0) + 2u;
+          }
+          if (!(g.pay_nullable1 && z == g.pay_null1)) {
+            const uint64_t d1 = static_cast<uint64_t>(z) - static_cast<uint64_t>(g.pk_min1);
+            bad |= d1 >= g.pk_codes1 - 1u;
+            c1 = static_cast<uint32_t>(d1) + 1u;
+          }
+        }
+        p32 = static_cast<int32_t>(c0 | (c1 << g.pk_bits0));
+      } else if (rid >= 0) {
         const int64_t y = __builtin_nontemporal_load(e + 1);
         if (a.pay_nullable && y == a.pay_null) {
           p32 = kSliceNull;
@@ -632,7 +686,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     const uint64_t step = static_cast<uint64_t>(gridDim.x) * kSliceAggBlock;
 #pragma unroll 1
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSliceAggBlock + tid; i < n; i += K * step) {
-      int32_t x32[K], p0[K], p1[K];
+      int32_t x32[K], p0[K], p1[K], y32[K];
       bool ok[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -641,13 +695,15 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
         const int64_t w = live ? in[ik] : 0;
         int64_t rid = -1, y = 0, z = 0;
         if (live) {
-          const int64_t* e = table + static_cast<uint64_t>(static_cast<uint32_t>(w)) * fstride;
+          const int64_t* e = table + static_cast<uint64_t>(static_cast<uint32_t>(w) & kmask) * fstride;
           rid = e[0];
           y = e[1];
-          if (NPAY == 2) {
+          if (TWO) {
             z = e[2];
           }
         }
+        const uint32_t yc = HASY ? static_cast<uint32_t>(w) >> a.y_shift : 0u;
+        y32[k] = yc == 0 ? kSliceNull : static_cast<int32_t>(yc) + y_bias;
         ok[k] = rid >= 0;
         x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w) >> 32);
         p0[k] = static_cast<int32_t>(y);
@@ -658,7 +714,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
           } else {
             bad2 |= static_cast<int64_t>(p0[k]) != y || p0[k] == kSliceNoMatch || p0[k] == kSliceNull;
           }
-          if (NPAY == 2) {
+          if (TWO) {
             if (g.pay_nullable1 && z == g.pay_null1) {
               p1[k] = kSliceNull;
             } else {
@@ -667,7 +723,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
           }
         }
       }
-      batch(x32, p0, p1, ok);
+      batch(x32, p0, p1, y32, ok);
     }
     if (__any(bad2) && (tid & (kWave - 1)) == 0) {
       atomicMax(a.mode, 1u);

@@ -34,6 +34,8 @@ namespace hdk {
   X(PROJECT_ONE_PASS)               \
   X(PROJECT_STATUS_SLACK)           \
   X(PROJECT_WRITER)                 \
+  X(S2_NO_PACKED_PAIR)              \
+  X(S2_NO_Y)                        \
   X(SCATTER_BLOCKS_PER_CU)          \
   X(SLICED2_ALWAYS)                 \
   X(SLICE_FINE_KEYS)                \

@@ -58,13 +58,13 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "c3d", "c3k", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
@@ -73,6 +73,8 @@ def main():
     tcols = {"key": key, "val": val, "valn": valn, "fk": fk, "hk": rng.integers(0, max(n // 10, 1000), len(key), dtype=np.int64)}
     if only & {"c3d", "c3k"}:  # plain key columns for the parity-path joins (no arithmetic in front of the probe)
         tcols.update({"fk10": fk // 10, "k1": key * 15, "k2": fk // 10000})
+    if only & {"c3x"}:
+        tcols["g32"] = key.astype(np.int32)  # a fact-side group key as an INT column
     st.import_numpy("t", tcols, fragment_size=frag)
     st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64),
                             "attr": rng.integers(0, 64, nd).astype(np.int64)}, fragment_size=frag)
@@ -132,6 +134,14 @@ def main():
         # star schema: filter on one dimension column, group by another (two payload words in the sliced join)
         "c3f": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
                           groupby=[ColRef("attr", "dim")], targets=[KeyRef(0), Agg("sum", ColRef("val")), Agg("count")]), 16),
+        # group by a column of the FACT table under the join, filter on the dimension (round 5: the second outer column rides in
+        # the 8-byte tuple's spare bits); two fact measures
+        "c3x": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
+                          groupby=[ColRef("g32")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 20),
+        "c3x8": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
+                           groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 24),
+        "c3x2": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
+                           targets=[Agg("sum", ColRef("val")), Agg("sum", ColRef("key")), Agg("count")]), 24),
         "q1": (QueryUnit("trips", groupby=[ColRef("cab_type")], targets=[KeyRef(0), Agg("count")]), 4),
         "q2": (QueryUnit("trips", groupby=[ColRef("passenger_count")],
                          targets=[KeyRef(0), Agg("avg", ColRef("total_amount"))]), 10),

@@ -185,7 +185,12 @@ def _sliced_tables(nf, nd, seed, x_kind, key_kind="uniform", pay_nulls=False):
     else:
         x = rng.integers(-2**45, 2**45, nf).astype(np.int64)
         x[rng.random(nf) < 0.05] = A.NULL_BIGINT
-    st.import_numpy("fact", {"fk": fk, "x": x}, fragment_size=nf // 4 + 5)
+    # a second outer column with a narrow range (a group key / a second measure of the fact table: rides in the tuple's spare bits)
+    g = rng.integers(-3, 60, nf).astype(np.int64)
+    if x_kind != "int32":
+        g[rng.random(nf) < 0.03] = A.NULL_BIGINT
+    g32 = np.where(g == A.NULL_BIGINT, A.NULL_INT, g).astype(np.int32)  # (the same as an INT column)
+    st.import_numpy("fact", {"fk": fk, "x": x, "g": g, "g32": g32}, fragment_size=nf // 4 + 5)
     return st
 
 
@@ -318,11 +323,15 @@ def _sliced2_two_payload_queries():
     ]
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("key_kind,two_levels", [("uniform", False), ("hot", False), ("uniform", True), ("sorted", True)])
-def test_sliced2_two_payload_words(oracle, gpu_executor_factory, key_kind, two_levels, monkeypatch):
-    """hdk_join_agg_sliced2<*, 2>: plans that read TWO columns of the inner table (filter on one, group by / aggregate the
-    other) stay on the sliced path: two int32 arrays per slice in LDS, entries of three words.  NULLs in both columns, keys
-    without a partner, a hot key (overflow area probed in memory), one and two scatter levels."""
+def test_sliced2_two_payload_words(oracle, gpu_executor_factory, key_kind, two_levels, packed, monkeypatch):
+    """hdk_join_agg_sliced2<*, 2 | 3>: plans that read TWO columns of the inner table (filter on one, group by / aggregate the
+    other) stay on the sliced path: entries of three words; per slice in LDS two int32 arrays, or ONE array of packed codes
+    when the two columns' statistics fit 32 bits together (here: 21 + 6 bits).  NULLs in both columns, keys without a partner,
+    a hot key (overflow area probed in memory), one and two scatter levels."""
+    if not packed:
+        monkeypatch.setenv("HDK_HIP_S2_NO_PACKED_PAIR", "1")
     if two_levels:
         monkeypatch.setenv("HDK_HIP_SLICE_TWO_LEVELS", "1")
         monkeypatch.setenv("HDK_HIP_SLICE_FINE_KEYS", "192")
@@ -337,6 +346,98 @@ def test_sliced2_two_payload_words(oracle, gpu_executor_factory, key_kind, two_l
         assert_buffers_equal(cp, step.run().buffer, want)
         step.free()
         assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+
+
+def _sliced2_outer_pair_queries():
+    """a second column of the OUTER table under the join: the group key (GROUP BY fact.g ... WHERE dim.d < c) or a second
+    measure; it rides in the bits of the 8-byte tuple the key offset leaves free"""
+    X, G, P, Q = ColRef("x"), ColRef("g"), ColRef("dval", "dim"), ColRef("attr", "dim")
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    return [
+        QueryUnit("fact", joins=j, quals=[Cmp(P, "<", Lit(250_000))], groupby=[G], targets=[KeyRef(0, "g"), Agg("sum", X, "s")]),
+        QueryUnit("fact", joins=j, groupby=[G / 3], targets=[KeyRef(0, "g"), Agg("sum", X + P, "s"), Agg("count", G, "cg"), Agg("max", G, "mg"),
+                                                              Agg("count", None, "c")]),
+        QueryUnit("fact", joins=j, quals=[Cmp(P, ">=", Lit(-400_000)), Cmp(X, "<", Lit(10**9))],
+                  targets=[Agg("sum", X, "sx"), Agg("sum", G, "sg"), Agg("min", G, "mn"), Agg("avg", X * G, "a")]),
+        QueryUnit("fact", joins=j, quals=[Cmp(P, "<", Lit(600_000))], groupby=[Q], targets=[KeyRef(0, "q"), Agg("sum", X, "sx"), Agg("sum", G + 5, "sg")]),
+        QueryUnit("fact", joins=j, groupby=[G], targets=[KeyRef(0, "g"), Agg("count", None, "c"), Agg("min", P, "lo"), Agg("max", G, "hi")]),
+        # the same column as a 4-byte INT
+        QueryUnit("fact", joins=j, quals=[Cmp(P, "<", Lit(100_000))], groupby=[ColRef("g32")],
+                  targets=[KeyRef(0, "g"), Agg("sum", X, "s"), Agg("count", ColRef("g32"), "c")]),
+    ]
+
+
+@pytest.mark.parametrize("key_kind,x_kind,two_levels", [("uniform", "int32", False), ("hot", "int32_nulls", False), ("uniform", "int32_nulls", True),
+                                                        ("sorted", "int32", True)])
+def test_sliced2_second_outer_column(oracle, gpu_executor_factory, key_kind, x_kind, two_levels, monkeypatch):
+    """GROUP BY an outer column / two outer measures under the sliced join: the second column's code sits above the key
+    offset in the tuple (scan_join_sliced.h: SliceArgs::y_shift).  NULL group keys and NULL measures, keys without a partner,
+    a hot key, one and two scatter levels; the interpreters give the same buffer."""
+    if two_levels:
+        monkeypatch.setenv("HDK_HIP_SLICE_TWO_LEVELS", "1")
+        monkeypatch.setenv("HDK_HIP_SLICE_FINE_KEYS", "192")
+    st = _sliced_tables(500_000, 30_000, 59, x_kind, key_kind, x_kind != "int32")
+    for q in _sliced2_outer_pair_queries():
+        cp, want, err = run_oracle(oracle, st, q)
+        assert err == 0, q
+        step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        names = step.kernel_names()
+        assert "hdk_join_agg_sliced2" in names and (("hdk_join_scatter_level2" in names) == two_levels), (q, names)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+        assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+
+
+def test_sliced2_second_outer_column_limits(oracle, gpu_executor_factory, monkeypatch):
+    """What does not fit the spare bits stays off the sliced path (and still equals the oracle): a second outer column whose
+    range needs more bits than the key offset leaves; three outer columns.  A value outside the announced statistics of the
+    riding column hands the launch to the armed interpreter."""
+    st = _sliced_tables(300_000, 30_000, 61, "int32")
+    rng = np.random.default_rng(5)
+    f = st.get("fact")
+    n = 300_000
+    st2 = ArrowStorage()
+    st2.import_numpy("dim", {k: np.concatenate(c.fragments) for k, c in st.get("dim").columns.items()})
+    cols = {k: np.concatenate(c.fragments) for k, c in f.columns.items()}
+    cols["wide"] = rng.integers(0, 2**20, n).astype(np.int64)  # 20 bits + 17 bits of key offset: does not fit
+    cols["h"] = rng.integers(0, 9, n).astype(np.int64)
+    st2.import_numpy("fact", cols, fragment_size=n // 3 + 1)
+    X, G, W, H, P = ColRef("x"), ColRef("g"), ColRef("wide"), ColRef("h"), ColRef("dval", "dim")
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    for q, sliced in [(QueryUnit("fact", joins=j, targets=[Agg("sum", X, "a"), Agg("sum", W, "b")]), False),
+                      (QueryUnit("fact", joins=j, targets=[Agg("sum", X, "a"), Agg("sum", G, "b"), Agg("sum", H, "c")]), False),
+                      (QueryUnit("fact", joins=j, targets=[Agg("sum", W, "a"), Agg("sum", H + P, "b")]), False),  # (y op payload: not a form)
+                      (QueryUnit("fact", joins=j, targets=[Agg("sum", W * H, "a"), Agg("max", P, "b"), Agg("min", H, "c")]), True)]:
+        cp, want, err = run_oracle(oracle, st2, q)
+        assert err == 0
+        step = gpu_executor_factory(st2).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+        assert ("hdk_join_agg_sliced2" in step.kernel_names()) == sliced, (q, step.kernel_names())
+        assert_buffers_equal(cp, step.run().buffer, want)
+        step.free()
+    # stale statistics of the riding column
+    q = _sliced2_outer_pair_queries()[4]
+    c = st.get("fact").columns["g"]
+    dim_keys = set(np.concatenate(st.get("dim").columns["key"].fragments).tolist())
+    at = next(i for i, k in enumerate(st.get("fact").columns["fk"].fragments[0].tolist()) if k in dim_keys)  # a row with a partner
+    saved = c.fragments[0][at]
+    c.fragments[0][at] = 4000  # the statistics (computed at import) still say -3 .. 59; the layout has no entry for it either
+    from hdk_amd._lib import HdkHipError
+    ex = gpu_executor_factory(st)
+    step = ex.prepare(ex.compile(q), flags=A.LAUNCH_CLUSTER_PROBES)
+    assert "hdk_join_agg_sliced2" in step.kernel_names()
+    with pytest.raises(HdkHipError) as ei:
+        step.run()
+    assert ei.value.code == A.ERR_OUT_OF_SLOTS
+    step.free()
+    q = _sliced2_outer_pair_queries()[2]  # as a measure: no layout to leave, the sum must simply be right
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    step = gpu_executor_factory(st).prepare(cp, flags=A.LAUNCH_CLUSTER_PROBES)
+    assert "hdk_join_agg_sliced2" in step.kernel_names()
+    assert_buffers_equal(cp, step.run().buffer, want)
+    step.free()
+    c.fragments[0][at] = saved
 
 
 def test_sliced2_survives_stale_statistics_and_reports_errors(oracle, gpu_executor_factory):
@@ -427,21 +528,27 @@ def test_sliced_join_random_shapes(oracle, gpu_executor_factory, seed):
     else:
         x = rng.integers(-2**45, 2**45, nf).astype(np.int64)
         x[rng.random(nf) < 0.05] = A.NULL_BIGINT
-    st.import_numpy("fact", {"fk": fk, "x": x}, fragment_size=int(rng.integers(nf // 6 + 1, nf + 2)))
-    X, D = ColRef("x"), ColRef("dval", "dim")
+    frag = int(rng.integers(nf // 6 + 1, nf + 2))
+    gcol = rng.integers(0, int(rng.choice([4, 50, 3000])), nf).astype(np.int64) - 7  # a second outer column (rides in the tuple when it fits)
+    if rng.random() < 0.5:
+        gcol[rng.random(nf) < 0.04] = A.NULL_BIGINT
+    st.import_numpy("fact", {"fk": fk, "x": x, "g": gcol}, fragment_size=frag)
+    X, D, G = ColRef("x"), ColRef("dval", "dim"), ColRef("g")
     pool = [Agg("sum", X + D, "s0"), Agg("sum", D + X, "s1"), Agg("count", None, "c"), Agg("sum", X, "sx"), Agg("min", X - D, "lo"),
             Agg("max", D, "hi"), Agg("count", D, "cd"), Agg("avg", D, "a"), Agg("count", X, "cx"), Agg("max", X, "mx")]
     At = ColRef("attr", "dim")
     pool2 = pool[2:] + [Agg("max", At, "ma"), Agg("sum", X * At, "xa"), Agg("count", At, "ca"), Agg("sum", At + 3, "a3")]
+    pool3 = pool2 + [Agg("sum", G, "sg"), Agg("min", G, "ng"), Agg("count", G, "cg"), Agg("sum", X + G, "xg")]
     ex = gpu_executor_factory(st)
     for qi in range(5):
         targets = [pool[0]] if (qi == 0 and rng.random() < 0.5) else [pool[int(i)] for i in rng.choice(len(pool), int(rng.integers(1, 4)), replace=False)]
         q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], targets=targets)
         if qi >= 3:  # the general sliced form: filters on either side, GROUP BY a joined column, one or two payload words
-            gb = [None, D / int(rng.choice([50_000, 125_000])), At, At / 3][int(rng.integers(0, 4))]
+            gb = [None, D / int(rng.choice([50_000, 125_000])), At, At / 3, G, G / 5][int(rng.integers(0, 6))]
             quals = [c for c in (Cmp(D, "<", Lit(int(rng.integers(-500_000, 900_000)))), Cmp(At, ">=", Lit(int(rng.integers(0, 30)))),
                                  Cmp(X, ">", Lit(int(rng.integers(-2**31, 0))))) if rng.random() < 0.4]
-            targets = [pool2[int(i)] for i in rng.choice(len(pool2), int(rng.integers(1, 4)), replace=False)]
+            pl = pool3 if rng.random() < 0.5 else pool2
+            targets = [pl[int(i)] for i in rng.choice(len(pl), int(rng.integers(1, 4)), replace=False)]
             q = QueryUnit("fact", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=quals, groupby=[gb] if gb is not None else [],
                           targets=([KeyRef(0, "g")] if gb is not None else []) + targets)
         cp, want, err = run_oracle(oracle, st, q)
