@@ -58,6 +58,9 @@ struct BhPackedArgs {
   int32_t val_min, val_max;  // statistics of the argument: what the packed sum was sized for
   int32_t key_min, key_max;  // statistics of the key column when it is 8 bytes wide (values outside take the exact path)
   int32_t want_minmax;
+  // dense: the key column's statistics [dense_min, dense_min + dense_n) fit the table: entry = key - dense_min (NULL: dense_n)
+  int32_t dense, dense_min;
+  uint32_t dense_n, pad_dense_;
   uint32_t flush_rows;     // a block folds its table into the output and starts over before it has seen this many rows: the
                            // bound the packed fields were sized for (rows < 2^24, |sum| < 2^39 per entry)
   int32_t nquals;
@@ -70,7 +73,14 @@ struct BhPackedArgs {
   uint32_t num_slabs;
   uint32_t fold_slices;    // bucket ranges (power of two, <= buckets)
   uint32_t fold_groups;    // slab groups: fold block (slice, group) takes slabs group, group + fold_groups, ...
-  uint32_t pad2_;
+  // three-level fold (many slabs): stage 1 merges the slabs of a (slice, group) in LDS and writes its groups as a LIST
+  // lists[(slice * fold_groups + group) * list_cap ...] of five 64-bit words [tag, max:min, rows, sum, nulls], their number in
+  // list_counts[]; stage 2, ONE block per slice, merges the slice's lists and folds every group into the output table once --
+  // no two blocks meet on an entry of the output.  0: the one-kernel form (every (slice, group) block folds into the output)
+  int32_t fold_stage;
+  uint32_t list_cap;
+  uint64_t* lists;
+  uint32_t* list_counts;
   // pass A / B
   int64_t* tuples;         // [bins][kPbXcds][cap]
   uint32_t* fill;          // [bins][kPbXcds] x kPbCursorStride
@@ -191,6 +201,8 @@ struct BhHot {
   uint32_t off_mm, off_packed, off_nulls;
   int32_t val_min, val_max;
   int32_t has_val, want_minmax, one_bucket;
+  int32_t dense_min, key_null32, key_nullable;    // (dense tables)
+  uint32_t dense_n;
 };
 HDK_DEV BhHot bh_hot(const BhPackedArgs& a) {
   BhHot h;
@@ -206,6 +218,10 @@ HDK_DEV BhHot bh_hot(const BhPackedArgs& a) {
   h.has_val = a.has_val;
   h.want_minmax = a.want_minmax;
   h.one_bucket = a.cap_log2 <= 2;
+  h.dense_min = a.dense_min;
+  h.dense_n = a.dense_n;
+  h.key_nullable = a.key_nullable && a.key_width == 4;  // (an 8-byte column's NULL does not fit 32 bits: the caller's exact path)
+  h.key_null32 = static_cast<int32_t>(a.key_null);
   return h;
 }
 HDK_DEV uint32_t bh_bucket_of(const BhHot& h, int32_t key) {
@@ -219,6 +235,9 @@ HDK_DEV uint32_t bh_bucket_of(const BhHot& h, int32_t key) {
 // cases sit behind wave-uniform tests: a key that is not in its bucket (probe loop, one inlined copy), a row that improves
 // MIN / MAX, a NULL argument.  Returns the mask of rows for the caller's exact path: the tag value itself as a key,
 // statistics that do not hold for the row, a full table when FULL_IS_ERROR is false.
+template <int NR>
+HDK_DEV void bh_rows_update(const BhHot& h, uint32_t* rp, const uint32_t (&e)[NR], uint32_t nulls, const int32_t (&val)[NR]);
+
 template <int NR, bool FULL_IS_ERROR, bool ALLOK = false>
 HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&key)[NR], const int32_t (&val)[NR], const bool (&ok_in)[NR],
                                 const bool (&null_in)[NR], int32_t& err) {
@@ -236,7 +255,6 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
   const uint32_t span = static_cast<uint32_t>(h.val_max) - static_cast<uint32_t>(h.val_min);
   const bool has_val = h.has_val != 0;
   uint32_t slow = 0, miss = 0, nulls = 0;
-  uint32_t e_add[NR];  // where the row's packed increment goes: its entry, or the dummy
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const uint32_t bit = 1u << j;
@@ -282,14 +300,23 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
       }
     }
   }
+  bh_rows_update<NR>(h, rp, e, nulls, val);
+  return slow;
+}
+
+// the updates of NR rows whose entries are known: e[j] = the row's entry, or the dummy (h.cap) when it does not take part;
+// `nulls`: rows whose argument is NULL
+template <int NR>
+HDK_DEV void bh_rows_update(const BhHot& h, uint32_t* rp, const uint32_t (&e)[NR], uint32_t nulls, const int32_t (&val)[NR]) {
   unsigned long long* packed = reinterpret_cast<unsigned long long*>(rp + h.off_packed);
-  if (!has_val) {
+  if (!h.has_val) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       atomicAdd(packed + e[j], 1ull << kBhSumBits);  // (rows that do not take part count into the dummy entry)
     }
-    return slow;
+    return;
   }
+  uint32_t e_add[NR];  // where the row's packed increment goes: its entry, or the dummy
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     e_add[j] = (nulls >> j) & 1u ? h.cap : e[j];  // a NULL argument is counted apart (below), not added
@@ -331,6 +358,34 @@ HDK_DEV uint32_t bh_packed_rows(const BhHot& h, uint32_t* rp, const int32_t (&ke
       }
     }
   }
+}
+
+// DENSE tables: the key column's statistics span no more values than the table has entries, so a row's entry is
+// key - dense_min (the NULL key: entry dense_n) -- no tags, no probe; the tags are written once, when the block hands its
+// table on (bh_dense_finish), so that the folds see what they see from the tag form.  A key outside the statistics takes
+// the exact path.
+template <int NR, bool ALLOK>
+HDK_DEV uint32_t bh_dense_rows(const BhHot& h, uint32_t* rp, const int32_t (&key)[NR], const int32_t (&val)[NR], const bool (&ok_in)[NR],
+                               const bool (&null_in)[NR]) {
+  const uint32_t span = static_cast<uint32_t>(h.val_max) - static_cast<uint32_t>(h.val_min);
+  const bool has_val = h.has_val != 0, key_nullable = h.key_nullable != 0;
+  uint32_t e[NR];
+  uint32_t slow = 0, nulls = 0;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const uint32_t bit = 1u << j;
+    const bool okj = ALLOK ? true : ok_in[j];
+    const bool nullj = null_in[j];
+    const uint32_t d = static_cast<uint32_t>(key[j]) - static_cast<uint32_t>(h.dense_min);
+    const bool knull = key_nullable & (key[j] == h.key_null32);
+    const bool kin = (d < h.dense_n) | knull;
+    const bool outside = has_val & !nullj & ((static_cast<uint32_t>(val[j]) - static_cast<uint32_t>(h.val_min)) > span);
+    const bool in = okj & kin & !outside;
+    slow |= (okj & !(kin & !outside)) ? bit : 0u;
+    e[j] = in ? (knull ? h.dense_n : d) : h.cap;
+    nulls |= (in & nullj) ? bit : 0u;
+  }
+  bh_rows_update<NR>(h, rp, e, nulls, val);
   return slow;
 }
 
@@ -370,6 +425,35 @@ HDK_DEV void bh_packed_merge_replicas(const BhPackedArgs& a, uint32_t* lds, int 
   }
 }
 
+// Dense tables at the end of a block (or of its flush interval): replicas 1.. into replica 0 entry by entry, then replica
+// 0's tags -- the key of every entry that saw a row.
+template <int BLOCK>
+HDK_DEV void bh_dense_finish(const BhPackedArgs& a, uint32_t* lds, int tid) {
+  const uint32_t cap = 1u << a.cap_log2;
+  __syncthreads();
+  for (uint32_t ei = tid; ei < cap; ei += BLOCK) {
+    uint64_t pk = reinterpret_cast<const uint64_t*>(lds + a.off_packed)[ei];
+    uint32_t nl = lds[a.off_nulls + ei];
+    const uint64_t mm0 = reinterpret_cast<const uint64_t*>(lds + a.off_mm)[ei];
+    int32_t mn = static_cast<int32_t>(static_cast<uint32_t>(mm0)), mx = static_cast<int32_t>(static_cast<uint32_t>(mm0 >> 32));
+    for (uint32_t r = 1; r < a.rep; ++r) {
+      const uint32_t* rb = lds + r * a.rep_words;
+      pk += reinterpret_cast<const uint64_t*>(rb + a.off_packed)[ei];
+      nl += rb[a.off_nulls + ei];
+      const uint64_t mm = reinterpret_cast<const uint64_t*>(rb + a.off_mm)[ei];
+      mn = min(mn, static_cast<int32_t>(static_cast<uint32_t>(mm)));
+      mx = max(mx, static_cast<int32_t>(static_cast<uint32_t>(mm >> 32)));
+    }
+    reinterpret_cast<uint64_t*>(lds + a.off_packed)[ei] = pk;
+    lds[a.off_nulls + ei] = nl;
+    reinterpret_cast<uint64_t*>(lds + a.off_mm)[ei] = (static_cast<uint64_t>(static_cast<uint32_t>(mx)) << 32) | static_cast<uint32_t>(mn);
+    const bool live = (pk | nl) != 0;  // (rows >= 1 makes the packed word positive: |sum| < 2^39)
+    const uint32_t key = ei < a.dense_n ? ei + static_cast<uint32_t>(a.dense_min) : static_cast<uint32_t>(static_cast<int32_t>(a.key_null));
+    lds[ei] = (live && ei <= a.dense_n) ? key : kBhTagEmpty;
+  }
+  __syncthreads();
+}
+
 // End of a block (or of its flush interval): replicas merged, replica 0's groups into the output table.
 template <int BLOCK>
 HDK_DEV void bh_packed_flush(const BhPackedArgs& a, const BhExactCtx* cx, uint32_t* lds, int tid, int32_t& err) {
@@ -391,11 +475,67 @@ HDK_DEV void bh_packed_flush(const BhPackedArgs& a, const BhExactCtx* cx, uint32
 
 // ---- the one-pass kernel: the table fits LDS -------------------------------------------------------------------------
 // KW / VW: byte width of the key / argument column (VW 0: COUNT(*) only); U steps of 16 bytes per lane and tile
+#ifndef HDK_BH_STEP_FENCE
+#define HDK_BH_STEP_FENCE 1
+#endif
 #ifndef HDK_BH_PACKED_WAVES
 #define HDK_BH_PACKED_WAVES 0  // > 0: hold the kernel to that many waves per SIMD (A/B builds: make variant DEFS=-DHDK_BH_PACKED_WAVES=4)
 #endif
-template <int KW, int VW, int U, int BLOCK>
-__global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 256 / BLOCK : 1) void hdk_scan_agg_bh_packed(BhPackedArgs a) {
+// One step of a tile: the R rows in a lane's 16-byte registers through the row body.  ALLOK: every row takes part (a full tile
+// of an unfiltered plan over 4-byte columns) -- the hot form computes no row bounds and no per-row flags at all.  Returns the
+// rows for the exact path.
+template <int KW, int VW, int R, bool DENSE, bool ALLOK>
+HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t* rp, const uint32_t* kr, const uint32_t* vr, bool full,
+                              int64_t rbase, int64_t row0, int64_t nrows, const int8_t* const* cols, int32_t& err) {
+  int32_t key[R], val[R];
+  bool ok[R], isnull[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    ok[i] = ALLOK || full || rbase + i < nrows;
+  }
+  if (!ALLOK && a.nquals != 0) {
+    int64_t rows[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      rows[i] = ok[i] ? rbase + i : row0;
+    }
+    plain_quals_pass<R>(a.q, a.nquals, cols, rows, ok, true);
+  }
+  uint32_t slow = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int64_t k64 = extract_elem<KW>(kr, i);
+    const int64_t v64 = VW ? extract_elem<(VW ? VW : 8)>(vr, i) : 0;
+    key[i] = static_cast<int32_t>(k64);
+    val[i] = static_cast<int32_t>(v64);
+    // (a 4-byte column's NULL test in 32 bits: the widened compare was a sign extension and two compares per row)
+    isnull[i] = VW == 4 ? (a.val_nullable != 0) & (val[i] == static_cast<int32_t>(a.val_null))
+                        : (VW != 0) & (a.val_nullable != 0) & (v64 == a.val_null);
+    // 8-byte columns ride as their low 32 bits: what does not fit (a key outside the statistics or NULL, an argument
+    // outside them) takes the exact path
+    bool wide = false;
+    if (KW == 8) {
+      wide = (a.key_nullable && k64 == a.key_null) || k64 < a.key_min || k64 > a.key_max;
+    }
+    if (VW == 8) {
+      wide = wide || (!isnull[i] && (v64 < a.val_min || v64 > a.val_max));
+    }
+    if (!ALLOK && ok[i] && wide) {
+      slow |= 1u << i;
+      ok[i] = false;
+    }
+  }
+  slow |= DENSE ? bh_dense_rows<R, ALLOK>(hot, rp, key, val, ok, isnull) : bh_packed_rows<R, true, ALLOK>(hot, rp, key, val, ok, isnull, err);
+  return slow;
+}
+
+// PLAIN: an unfiltered plan over 4-byte columns -- every row of a full tile takes part, so the kernel holds ONLY the hot form of
+// the steps (and a row-at-a-time loop for the ragged tail of a fragment).  The general form -- row bounds, filters, 8-byte
+// columns whose strangers bypass the table -- needs 178 vector registers with four steps in flight (two waves on a SIMD) and
+// held the hot form to that when both sat in one kernel; on its own the hot form takes 122.
+template <int KW, int VW, int U, int BLOCK, bool DENSE, bool PLAIN>
+HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
+  static_assert(!PLAIN || (KW == 4 && (VW == 4 || VW == 0)), "the plain form reads 4-byte columns");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   __shared__ BhExactCtx s_cx;
   constexpr int WMAX = KW > VW ? KW : VW;
@@ -429,6 +569,9 @@ __global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       HDK_WATCH_TILE(watch, err, tile)
       if (rows_since_flush + static_cast<uint32_t>(kTileRows) > a.flush_rows) {  // (block-uniform: every thread walks the same tiles)
+        if (DENSE) {
+          bh_dense_finish<BLOCK>(a, lds32, tid);
+        }
         bh_packed_flush<BLOCK>(a, &s_cx, lds32, tid, err);
         __syncthreads();
         bh_packed_lds_init(lds32, a, tid, BLOCK);
@@ -438,6 +581,25 @@ __global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 
       rows_since_flush += static_cast<uint32_t>(kTileRows);
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       const bool full = row0 + kTileRows <= nrows;
+      if (PLAIN && !full) {  // the ragged tail of a fragment, a row per lane and trip
+        for (int64_t r = row0 + tid; r < nrows; r += BLOCK) {
+          const uint32_t k1[1] = {static_cast<uint32_t>(load_elem<KW>(kcol, r))};
+          const uint32_t v1[1] = {VW ? static_cast<uint32_t>(load_elem<(VW ? VW : 4)>(vcol, r)) : 0u};
+          uint32_t slow1 = bh_tile_step<KW, VW, 1, DENSE, false>(a, hot, rp, k1, v1, true, r, r, nrows, cols, err);
+          while (__builtin_amdgcn_ballot_w64(slow1 != 0)) {
+            if (slow1) {
+              slow1 = 0;
+              const int64_t kj = static_cast<int32_t>(k1[0]), vj = static_cast<int32_t>(v1[0]);
+              const bool nj = (VW != 0) & (a.val_nullable != 0) & (vj == a.val_null);
+              const bool knull = a.key_nullable && kj == a.key_null;
+              const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
+              const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, nj);
+              err = xe ? xe : err;
+            }
+          }
+        }
+        continue;
+      }
       uint32_t kr[U][KREGS];
       uint32_t vr[U][VREGS];
       if (full) {
@@ -447,81 +609,78 @@ __global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 
           load_bytes<KB, true>(kcol + r * KW, kr[u]);
           if (VW) load_bytes<(VB > 0 ? VB : 4), true>(vcol + r * VW, vr[u]);
         }
-      }
+      } else {  // ragged tail of a fragment: element loads into the same registers
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int32_t key[R], val[R];
-        bool ok[R], isnull[R];
-        int64_t k64[R], v64[R];
-        const int64_t rbase = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          ok[i] = full || rbase + i < nrows;
-          if (full) {
-            k64[i] = extract_elem<KW>(kr[u], i);
-            v64[i] = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
-          } else {  // ragged tail of a fragment: element loads
-            k64[i] = ok[i] ? load_elem<KW>(kcol, rbase + i) : 0;
-            v64[i] = (VW && ok[i]) ? load_elem<(VW ? VW : 8)>(vcol, rbase + i) : 0;
-          }
-        }
-        if (filtered) {
-          int64_t rows[R];
+        for (int u = 0; u < U; ++u) {
+          const int64_t rbase = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
 #pragma unroll
           for (int i = 0; i < R; ++i) {
-            rows[i] = ok[i] ? rbase + i : row0;
-          }
-          plain_quals_pass<R>(a.q, a.nquals, cols, rows, ok, true);
-        }
-        uint32_t slow = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          key[i] = static_cast<int32_t>(k64[i]);
-          val[i] = static_cast<int32_t>(v64[i]);
-          // (a 4-byte column's NULL test in 32 bits: the widened compare was a sign extension and two compares per row)
-          isnull[i] = VW == 4 ? (a.val_nullable != 0) & (val[i] == static_cast<int32_t>(a.val_null))
-                              : (VW != 0) & (a.val_nullable != 0) & (v64[i] == a.val_null);
-          // 8-byte columns ride as their low 32 bits: what does not fit (a key outside the statistics or NULL, an argument
-          // outside them) takes the exact path
-          bool wide = false;
-          if (KW == 8) {
-            wide = (a.key_nullable && k64[i] == a.key_null) || k64[i] < a.key_min || k64[i] > a.key_max;
-          }
-          if (VW == 8) {
-            wide = wide || (!isnull[i] && (v64[i] < a.val_min || v64[i] > a.val_max));
-          }
-          if (ok[i] && wide) {
-            slow |= 1u << i;
-            ok[i] = false;
-          }
-        }
-        if (KW != 8 && VW != 8 && full && !filtered) {  // (8-byte columns: `ok` also carries the rows that do not fit 32 bits)
-          slow |= bh_packed_rows<R, true, true>(hot, rp, key, val, ok, isnull, err);
-        } else {
-          slow |= bh_packed_rows<R, true>(hot, rp, key, val, ok, isnull, err);
-        }
-        // rows for the reference's own scheme (rare): one call site, the lane's pending rows one after another
-        while (__builtin_amdgcn_ballot_w64(slow != 0)) {
-          if (slow) {
-            const int j = __ffs(slow) - 1;
-            slow &= slow - 1;
-            int64_t kj = k64[0], vj = v64[0];
-            bool nj = isnull[0];
-#pragma unroll
-            for (int i = 1; i < R; ++i) {
-              kj = i == j ? k64[i] : kj;
-              vj = i == j ? v64[i] : vj;
-              nj = i == j ? isnull[i] : nj;
+            const bool in = rbase + i < nrows;
+            const int64_t k = in ? load_elem<KW>(kcol, rbase + i) : 0;
+            const int64_t v = (VW && in) ? load_elem<(VW ? VW : 8)>(vcol, rbase + i) : 0;
+            if (KW == 8) {
+              kr[u][2 * i] = static_cast<uint32_t>(k);
+              kr[u][(2 * i + 1) % KREGS] = static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32);
+            } else {
+              kr[u][i % KREGS] = static_cast<uint32_t>(k);
             }
-            const bool knull = a.key_nullable && kj == a.key_null;
-            const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
-            const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, nj);
-            err = xe ? xe : err;
+            if (VW == 8) {
+              vr[u][(2 * i) % VREGS] = static_cast<uint32_t>(v);
+              vr[u][(2 * i + 1) % VREGS] = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
+            } else if (VW == 4) {
+              vr[u][i % VREGS] = static_cast<uint32_t>(v);
+            }
           }
+        }
+      }
+      uint32_t slow_all = 0;  // bit u * R + i: row i of step u goes through the reference's own scheme (below, after the steps)
+      if (PLAIN) {
+        // every row takes part -- no row bounds, no filters, no 8-byte columns (whose strangers `ok` carries)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          slow_all |= bh_tile_step<KW, VW, R, DENSE, true>(a, hot, rp, kr[u], vr[u], true, 0, 0, 0, cols, err) << (u * R);
+#if HDK_BH_STEP_FENCE
+          __builtin_amdgcn_sched_barrier(0);  // (steps interleaved by the scheduler: 178 registers, two waves on a SIMD)
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t rbase = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
+          slow_all |= bh_tile_step<KW, VW, R, DENSE, false>(a, hot, rp, kr[u], vr[u], full, rbase, row0, nrows, cols, err) << (u * R);
+        }
+      }
+      // rows for the reference's own scheme (rare): ONE call site behind the tile's steps -- the callee's registers come on
+      // top of what is live at the call, and here that is the tile's column registers and nothing else.  The lane's pending
+      // rows one after another.
+      while (__builtin_amdgcn_ballot_w64(slow_all != 0)) {
+        if (slow_all) {
+          const int b = __ffs(slow_all) - 1;
+          slow_all &= slow_all - 1;
+          int64_t kj = 0, vj = 0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              const bool me = b == u * R + i;
+              const int64_t k64 = extract_elem<KW>(kr[u], i);
+              const int64_t v64 = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
+              kj = me ? k64 : kj;
+              vj = me ? v64 : vj;
+            }
+          }
+          const bool nj = (VW != 0) & (a.val_nullable != 0) & (vj == a.val_null);
+          const bool knull = a.key_nullable && kj == a.key_null;
+          const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
+          const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, nj);
+          err = xe ? xe : err;
         }
       }
     }
     frag_tile_begin += ntiles;
+  }
+  if (DENSE) {
+    bh_dense_finish<BLOCK>(a, lds32, tid);  // (the tag-keyed merge below then finds replicas 1.. without tags: nothing to do)
   }
   if (a.slabs) {
     // the block's table to its slab; hdk_bh_fold_slabs folds the slabs into the output table
@@ -537,6 +696,25 @@ __global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 
   if (err) {
     record_error(a.kp.error_code, err);
   }
+}
+
+template <int KW, int VW, int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 256 / BLOCK : 1) void hdk_scan_agg_bh_packed(BhPackedArgs a) {
+  bh_packed_kernel_body<KW, VW, U, BLOCK, false, false>(a);
+}
+// the dense form (entry = key - min by the key column's statistics; 256-thread blocks only: such tables are small)
+template <int KW, int VW, int U>
+__global__ __launch_bounds__(kBhPackedBlock, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES : 1) void hdk_scan_agg_bh_dense(BhPackedArgs a) {
+  bh_packed_kernel_body<KW, VW, U, kBhPackedBlock, true, false>(a);
+}
+// the plain forms (unfiltered, 4-byte key and argument columns): the reference's benchmark shapes
+template <int VW, int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed_plain(BhPackedArgs a) {
+  bh_packed_kernel_body<4, VW, U, BLOCK, false, true>(a);
+}
+template <int VW, int U>
+__global__ __launch_bounds__(kBhPackedBlock) void hdk_scan_agg_bh_dense_plain(BhPackedArgs a) {
+  bh_packed_kernel_body<4, VW, U, kBhPackedBlock, true, true>(a);
 }
 
 // ---- the fold of the scan blocks' slabs -----------------------------------------------------------------------------------
@@ -572,34 +750,93 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
   const uint32_t per_slice = cap / a.fold_slices;  // entries of a slice (a multiple of 4, or the whole table)
   const uint32_t e_begin = slice * per_slice;
   const uint32_t words = bh_slab_words(a);
-  for (uint32_t sl = group; sl < a.num_slabs; sl += a.fold_groups) {
-    const uint32_t* slab = a.slabs + static_cast<size_t>(sl) * words;
-    for (uint32_t i = tid; i < per_slice; i += kBhFoldBlock) {
-      const uint32_t ei = e_begin + i;
-      const uint32_t tag = slab[ei];
+  // (slab, entry) pairs of this block's slabs group, group + fold_groups, ... side by side: every trip of a thread is an
+  // independent load -- one slab after the other (a few entries each, 128 dependent trips) the kernel took 100 - 240 us, as long
+  // as a third of the scan it follows
+  auto merge = [&](int32_t key, const BhPartial& b) {
+    const uint32_t bucket = a.cap_log2 > 2 ? ((bh_tag_hash(key) << a.bins_log2) >> (bshift + a.bins_log2)) & bmask : 0u;
+    const int32_t e0 = bh_tag_probe(tags, key, bucket, bmask);
+    if (e0 < 0) {
+      err = HDK_HIP_ERR_OUT_OF_SLOTS;
+      return;
+    }
+    atomicAdd(rows + e0, static_cast<unsigned long long>(b.rows));
+    atomicAdd(sum + e0, static_cast<unsigned long long>(b.sum));
+    if (b.nulls) atomicAdd(nulls + e0, static_cast<unsigned long long>(b.nulls));
+    int32_t* mmw = reinterpret_cast<int32_t*>(mm) + 2 * e0;
+    atomicMin(mmw, static_cast<int32_t>(b.mn));
+    atomicMax(mmw + 1, static_cast<int32_t>(b.mx));
+  };
+  if (a.fold_stage == 2) {  // (grid = fold_slices: `group` is 0) the lists stage 1 left for this slice, side by side
+    const uint32_t lc_log2 = 31 - __clz(a.list_cap);  // (a power of two, as cap and the slices are)
+    const uint32_t total2 = a.fold_groups << lc_log2;
+    constexpr int kLists = 4;
+    for (uint32_t i0 = tid; i0 < total2; i0 += kBhFoldBlock * kLists) {
+      uint64_t w[kLists][5];
+      bool live[kLists];
+#pragma unroll
+      for (int j = 0; j < kLists; ++j) {
+        const uint32_t idx = i0 + j * kBhFoldBlock;
+        const uint32_t li = slice * a.fold_groups + (idx >> lc_log2), i = idx & (a.list_cap - 1);
+        live[j] = idx < total2 && i < a.list_counts[li];
+        const uint64_t* e = a.lists + (static_cast<size_t>(li) * a.list_cap + i) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          w[j][k] = live[j] ? e[k] : 0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kLists; ++j) {
+        if (live[j]) {
+          BhPartial b;
+          b.mn = static_cast<int32_t>(static_cast<uint32_t>(w[j][1]));
+          b.mx = static_cast<int32_t>(static_cast<uint32_t>(w[j][1] >> 32));
+          b.rows = static_cast<int64_t>(w[j][2]);
+          b.sum = static_cast<int64_t>(w[j][3]);
+          b.nulls = static_cast<int64_t>(w[j][4]);
+          merge(static_cast<int32_t>(static_cast<uint32_t>(w[j][0])), b);
+        }
+      }
+    }
+  }
+  const uint32_t nmine = (a.fold_stage != 2 && group < a.num_slabs) ? (a.num_slabs - group + a.fold_groups - 1) / a.fold_groups : 0u;
+  const uint32_t ps_log2 = 31 - __clz(per_slice);  // (a power of two: cap and fold_slices are)
+  const uint32_t total = nmine << ps_log2;
+  constexpr int kInFlight = 4;
+  for (uint32_t i0 = tid; i0 < total; i0 += kBhFoldBlock * kInFlight) {
+    uint32_t tagv[kInFlight], eiv[kInFlight];
+    const uint32_t* slabv[kInFlight];
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) {
+      const uint32_t idx = i0 + j * kBhFoldBlock;
+      const bool in = idx < total;
+      const uint32_t sl = group + (idx >> ps_log2) * a.fold_groups;
+      eiv[j] = e_begin + (idx & (per_slice - 1));
+      slabv[j] = a.slabs + static_cast<size_t>(in ? sl : group) * words;
+      tagv[j] = in ? slabv[j][eiv[j]] : kBhTagEmpty;
+    }
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) {
+      const uint32_t tag = tagv[j], ei = eiv[j];
+      const uint32_t* slab = slabv[j];
       if (tag == kBhTagEmpty) {
         continue;
       }
       const BhPartial b = bh_decode(reinterpret_cast<const uint64_t*>(slab + a.off_packed)[ei], slab[a.off_nulls + ei],
                                     reinterpret_cast<const uint64_t*>(slab + a.off_mm)[ei]);
-      const int32_t key = static_cast<int32_t>(tag);
-      const uint32_t bucket = a.cap_log2 > 2 ? ((bh_tag_hash(key) << a.bins_log2) >> (bshift + a.bins_log2)) & bmask : 0u;
-      const int32_t e0 = bh_tag_probe(tags, key, bucket, bmask);
-      if (e0 < 0) {
-        err = HDK_HIP_ERR_OUT_OF_SLOTS;
-        continue;
-      }
-      atomicAdd(rows + e0, static_cast<unsigned long long>(b.rows));
-      atomicAdd(sum + e0, static_cast<unsigned long long>(b.sum));
-      if (b.nulls) atomicAdd(nulls + e0, static_cast<unsigned long long>(b.nulls));
-      int32_t* mmw = reinterpret_cast<int32_t*>(mm) + 2 * e0;
-      atomicMin(mmw, static_cast<int32_t>(b.mn));
-      atomicMax(mmw + 1, static_cast<int32_t>(b.mx));
+      merge(static_cast<int32_t>(tag), b);
     }
   }
   __syncthreads();
   const TableShape shape = table_shape(a.plan);
   int64_t* buf = a.kp.groupby_buf[0];
+  __shared__ uint32_t s_list_n;
+  if (tid == 0) {
+    s_list_n = 0;
+  }
+  __syncthreads();
+  const uint32_t li = slice * a.fold_groups + group;
+  uint64_t* list = a.fold_stage == 1 ? a.lists + static_cast<size_t>(li) * a.list_cap * 5 : nullptr;
   for (uint32_t ei = tid; ei < cap; ei += kBhFoldBlock) {
     const uint32_t tag = tags[ei];
     if (tag == kBhTagEmpty) {
@@ -611,8 +848,25 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
     b.nulls = static_cast<int64_t>(nulls[ei]);
     b.mn = static_cast<int32_t>(static_cast<uint32_t>(mm[ei]));
     b.mx = static_cast<int32_t>(static_cast<uint32_t>(mm[ei] >> 32));
+    if (a.fold_stage == 1) {
+      const uint32_t pos = atomicAdd(&s_list_n, 1u);
+      if (pos < a.list_cap) {  // (else: more keys than a slice's share met here -- probing crossed slice borders; folded right away)
+        list[pos * 5] = tag;
+        list[pos * 5 + 1] = mm[ei];
+        list[pos * 5 + 2] = static_cast<uint64_t>(b.rows);
+        list[pos * 5 + 3] = static_cast<uint64_t>(b.sum);
+        list[pos * 5 + 4] = static_cast<uint64_t>(b.nulls);
+        continue;
+      }
+    }
     bh_fold_group_fn(a.plan, shape, s_cx.wl, buf, a.out_entry_count, s_cx.col_off, bh_key_word(a, static_cast<int32_t>(tag)),
                      [&](int w) -> int64_t { return bh_partial_word(b, s_cx.wkind[w]); }, err);
+  }
+  if (a.fold_stage == 1) {
+    __syncthreads();
+    if (tid == 0) {
+      a.list_counts[li] = s_list_n;
+    }
   }
   if (err) {
     record_error(a.kp.error_code, err);

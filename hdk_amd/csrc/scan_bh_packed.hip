@@ -50,6 +50,12 @@ static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_op
   a->key_width = kc.width;
   a->key_min = INT32_MIN;
   a->key_max = INT32_MAX;
+  // the key column's statistics, for the dense form (match_bh_packed decides)
+  if (kc.has_stats && kc.max_val >= kc.min_val && kc.min_val > INT32_MIN && kc.max_val < INT32_MAX &&
+      static_cast<uint64_t>(kc.max_val - kc.min_val) < (1u << 20)) {
+    a->dense_min = static_cast<int32_t>(kc.min_val);
+    a->dense_n = static_cast<uint32_t>(kc.max_val - kc.min_val) + 1;
+  }
   if (kc.width == 8) {  // an 8-byte key column rides as 32 bits when the statistics say it fits (strangers take the exact path)
     if (!kc.has_stats || kc.min_val < INT32_MIN || kc.max_val > INT32_MAX) return false;
     a->key_min = static_cast<int32_t>(kc.min_val);
@@ -128,11 +134,21 @@ static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   if (p->query_kind == HDK_Q_PERFECT_HASH && 24ull * ((2ull << cap_log2) + 4) <= kBhPackedMaxBytes512) ++cap_log2;
   const uint64_t one = 24ull * ((1ull << cap_log2) + 4);
   if (one > kBhPackedMaxBytes512) return false;
+  // dense: one entry per value of the key column's statistics (+ the NULL key's) when that costs at most twice the tags' LDS
+  // and fits a 256-thread block's share -- no tags to read, no probe (bh_dense_rows)
+  if (a->dense_n && !hdk_sw(SW_NO_BH_DENSE)) {
+    const uint32_t dlog2 = std::max<uint32_t>(pow2_ceil_log2(a->dense_n + 1), 2);
+    if (dlog2 <= cap_log2 + 1 && 24ull * ((1ull << dlog2) + 4) <= kBhPackedMaxBytes256) {
+      a->dense = 1;
+      cap_log2 = dlog2;
+    }
+  }
+  const uint64_t bytes = 24ull * ((1ull << cap_log2) + 4);
   uint32_t rep = 32;
-  while (rep > 1 && (one + 16) * rep > kBhPackedReplicatedBytes) rep >>= 1;
+  while (rep > 1 && (bytes + 16) * rep > kBhPackedReplicatedBytes) rep >>= 1;
   bh_packed_geometry(a, cap_log2, rep);
   *lds_bytes = a->rep_words * 4 * rep;
-  *block = one > kBhPackedMaxBytes256 ? 512 : 256;
+  *block = bytes > kBhPackedMaxBytes256 ? 512 : 256;
   return true;
 }
 
@@ -142,6 +158,28 @@ static const void* bh_packed_kernel_of() {
 #define HDK_BH_PACKED_U 4  // 16-byte steps per lane and tile (A/B builds at 256 M rows: 2 -> bh3 0.86 ms, 4 -> 0.79, 8 -> 0.87)
 #endif
   return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, HDK_BH_PACKED_U, BLOCK>);
+}
+template <int KW, int VW>
+static const void* bh_dense_kernel_of() {
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense<KW, VW, HDK_BH_PACKED_U>);
+}
+static const void* bh_dense_kernel(int kw, int vw) {
+  if (kw == 4) return vw == 0 ? bh_dense_kernel_of<4, 0>() : (vw == 4 ? bh_dense_kernel_of<4, 4>() : bh_dense_kernel_of<4, 8>());
+  return vw == 0 ? bh_dense_kernel_of<8, 0>() : (vw == 4 ? bh_dense_kernel_of<8, 4>() : bh_dense_kernel_of<8, 8>());
+}
+// unfiltered plans over 4-byte columns: the kernels that hold only the hot form of the steps
+static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return kw == 4 && (vw == 4 || vw == 0) && a.nquals == 0; }
+static const void* bh_plain_kernel(bool dense, int vw, int block) {
+  if (dense) {
+    return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<4, HDK_BH_PACKED_U>)
+                   : reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<0, HDK_BH_PACKED_U>);
+  }
+  if (block == 512) {
+    return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<4, HDK_BH_PACKED_U, 512>)
+                   : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<0, HDK_BH_PACKED_U, 512>);
+  }
+  return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<4, HDK_BH_PACKED_U, 256>)
+                 : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<0, HDK_BH_PACKED_U, 256>);
 }
 template <int BLOCK>
 static const void* bh_packed_kernel(int kw, int vw) {
@@ -186,7 +224,10 @@ const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_op
   BhPackedArgs a;
   int kw, vw, block;
   uint32_t lds;
-  if (match_bh_packed(p, ko, &a, &kw, &vw, &block, &lds)) return "hdk_scan_agg_bh_packed,hdk_bh_fold_slabs";
+  if (match_bh_packed(p, ko, &a, &kw, &vw, &block, &lds)) {
+    if (bh_plain(a, kw, vw)) return a.dense ? "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed_plain,hdk_bh_fold_slabs";
+    return a.dense ? "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed,hdk_bh_fold_slabs";
+  }
   BhPartLayout l;
   if (match_bh_partitioned(p, ko, &a, &l)) return "hdk_bh_scatter,hdk_bh_aggregate";
   return nullptr;
@@ -232,7 +273,8 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   }
   a.plan = d_plan;
   a.kp = kp;
-  const void* k = block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw);
+  const void* k = bh_plain(a, kw, vw) ? bh_plain_kernel(a.dense != 0, vw, block)
+                                      : (a.dense ? bh_dense_kernel(kw, vw) : (block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw)));
   if (lds > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   }
@@ -248,12 +290,31 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   const bool direct_fold = hdk_sw(SW_BH_DIRECT_FOLD) != nullptr;
   AsyncScratch scratch(s);
   const size_t slab_bytes = static_cast<size_t>(6) * ((static_cast<size_t>(1) << a.cap_log2) + 4) * 4;
-  if (!direct_fold && hipMallocAsync(&scratch.p, slab_bytes * grid, s) == hipSuccess) {
+  const uint32_t cap = 1u << a.cap_log2;
+  // bucket ranges of 8 buckets (measured at 1 024 slabs: ranges of 32 buckets left stage 2 with 8 blocks for 1 000 groups and
+  // ONE for 100 -- 100 us either way; with these both stages take a trip or two per thread)
+  const uint32_t slices = cap >= 64 ? cap / 32 : 1;
+  // three levels when there are many slabs (hdk_bh_fold_slabs: fold_stage): about 256 stage-1 blocks, lists of twice a
+  // slice's entries (probing may carry a key over a slice border)
+  const bool staged = grid >= 64 && !hdk_sw(SW_BH_FOLD_GROUPS);
+  const uint32_t groups1 = std::min<uint32_t>(std::max<uint32_t>(256u / slices, 2u), grid);
+  const uint32_t list_cap = std::min<uint32_t>(cap, 2 * (cap / slices));
+  const size_t list_bytes = staged ? static_cast<size_t>(slices) * groups1 * list_cap * 40 : 0;
+  const size_t count_bytes = staged ? static_cast<size_t>(slices) * groups1 * 4 : 0;
+  const size_t slabs_total = (slab_bytes * grid + 255) & ~static_cast<size_t>(255);
+  if (!direct_fold && hipMallocAsync(&scratch.p, slabs_total + list_bytes + count_bytes, s) == hipSuccess) {
     a.slabs = static_cast<uint32_t*>(scratch.p);
     a.num_slabs = grid;
-    const uint32_t cap = 1u << a.cap_log2;
-    a.fold_slices = cap >= 256 ? cap / 128 : 1;  // bucket ranges of 32 buckets
-    a.fold_groups = a.fold_slices >= 32 ? 2 : (a.fold_slices >= 8 ? 4 : 8);
+    a.fold_slices = slices;
+    if (staged) {
+      a.lists = reinterpret_cast<uint64_t*>(static_cast<int8_t*>(scratch.p) + slabs_total);
+      a.list_counts = reinterpret_cast<uint32_t*>(static_cast<int8_t*>(scratch.p) + slabs_total + list_bytes);
+      a.list_cap = list_cap;
+    }
+    // about 256 fold blocks: every (slice, group) folds its groups into the output table once -- `fold_groups` contended updates
+    // per entry instead of one per scan block
+    a.fold_groups = staged ? groups1 : 8;
+    if (const char* e = hdk_sw(SW_BH_FOLD_GROUPS)) a.fold_groups = std::max(1, atoi(e));  // (measurements: the one-kernel fold)
     if (a.fold_groups > grid) a.fold_groups = grid;
   } else {
     (void)hipGetLastError();
@@ -267,7 +328,14 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
     if (fold_lds > (48u << 10)) {
       HDK_HIP_CHECK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fold_lds)));
     }
-    hipLaunchKernelGGL(hdk_bh_fold_slabs, dim3(a.fold_slices * a.fold_groups), dim3(kBhFoldBlock), fold_lds, s, a);
+    if (a.lists) {
+      a.fold_stage = 1;
+      hipLaunchKernelGGL(hdk_bh_fold_slabs, dim3(a.fold_slices * a.fold_groups), dim3(kBhFoldBlock), fold_lds, s, a);
+      a.fold_stage = 2;
+      hipLaunchKernelGGL(hdk_bh_fold_slabs, dim3(a.fold_slices), dim3(kBhFoldBlock), fold_lds, s, a);
+    } else {
+      hipLaunchKernelGGL(hdk_bh_fold_slabs, dim3(a.fold_slices * a.fold_groups), dim3(kBhFoldBlock), fold_lds, s, a);
+    }
   }
   HDK_HIP_CHECK(hipGetLastError());
   *launched = true;

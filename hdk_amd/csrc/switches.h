@@ -9,12 +9,14 @@ namespace hdk {
 #define HDK_SWITCH_LIST(X)          \
   X(BH_BLOCKS_PER_CU)               \
   X(BH_DIRECT_FOLD)                 \
+  X(BH_FOLD_GROUPS)                 \
   X(BH_PARTITIONS_ALWAYS)           \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(FAST_NO_XMODE)                  \
   X(KEYS_NO_WIDE_BLOCK)             \
   X(NO_BATCHED_MATCHING_SETS)       \
+  X(NO_BH_DENSE)                    \
   X(NO_BH_DIRECT)                   \
   X(NO_BH_LDS)                      \
   X(NO_BH_PACKED)                   \

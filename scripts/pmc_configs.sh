@@ -3,7 +3,7 @@
 # usage: scripts/pmc_configs.sh "<configs>" "<counters...>" <tag>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/pmc_$3 -o pmc --output-format csv -- python3 scripts/bench_configs.py --rows 128000000 --only $1 > gpurun_out/pmc_$3.log 2>&1
+rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/pmc_$3 -o pmc --output-format csv -- python3 scripts/bench_configs.py --rows ${ROWS:-128000000} --only $1 > gpurun_out/pmc_$3.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_$3/**/*counter_collection.csv", recursive=True)

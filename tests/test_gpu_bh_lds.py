@@ -17,7 +17,15 @@ from util import run_oracle
 
 pytestmark = pytest.mark.gpu
 
-BH_KERNELS = ("hdk_scan_agg_bh_vec", "hdk_scan_agg_bh_direct", "hdk_scan_agg_bh_packed")
+BH_KERNELS = ("hdk_scan_agg_bh_vec", "hdk_scan_agg_bh_direct", "hdk_scan_agg_bh_packed", "hdk_scan_agg_bh_dense")
+
+
+def _one_pass_kernel(dense, monkeypatch):
+    """the one-pass packed kernel in its two forms: entries by key - min (the key column's statistics are narrow: all of
+    these tests' tables) or, with the switch, by 32-bit tags as for sparse keys"""
+    if not dense:
+        monkeypatch.setenv("HDK_HIP_NO_BH_DENSE", "1")
+    return "hdk_scan_agg_bh_dense" if dense else "hdk_scan_agg_bh_packed"
 
 
 def _bh_table(n, seed, nulls=True):
@@ -68,13 +76,14 @@ def _run_and_check(oracle, ex, st, q, expect_kernel=BH_KERNELS, placement=True):
     return cp, res
 
 
+@pytest.mark.parametrize("dense", [True, False])
 @pytest.mark.parametrize("xcol,groups", [("x10", 11), ("x100", 100), ("x1k", 1000)])
-def test_reference_baseline_hash_benchmark_shape(oracle, gpu_executor_factory, xcol, groups):
-    """BH001-003: cast(x as double) key, count / sum / max / min / avg of one int column (with NULLs)."""
+def test_reference_baseline_hash_benchmark_shape(oracle, gpu_executor_factory, xcol, groups, dense, monkeypatch):
+    """BH001-003: cast(x as double) key, count / sum / max / min / avg of one int column (with NULLs; x10 has NULL keys)."""
+    kernel = _one_pass_kernel(dense, monkeypatch)
     st = _bh_table(700_000, 11)
     ex = gpu_executor_factory(st)
-    expect = BH_KERNELS if groups <= 100 else BH_KERNELS + ("hdk_scan_agg_global", "hdk_scan_agg_baseline_direct", "hdk_bh_")
-    cp, res = _run_and_check(oracle, ex, st, _bh_query(xcol), expect_kernel=expect)
+    cp, res = _run_and_check(oracle, ex, st, _bh_query(xcol), expect_kernel=(kernel,))
     assert res.row_count() == groups
     keys = res.to_columns()["key0"]
     assert all(k is None or (isinstance(k, float) and k == int(k)) for k in keys)
@@ -282,8 +291,11 @@ def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_
         _assert_reference_placement(oracle, cp, res.buffer)
 
 
-def test_small_table_with_stale_statistics(oracle, gpu_executor_factory):
-    """The one-pass packed kernel with statistics that do not hold: rows outside them bypass the packed sum."""
+@pytest.mark.parametrize("dense", [True, False])
+def test_small_table_with_stale_statistics(oracle, gpu_executor_factory, dense, monkeypatch):
+    """The one-pass packed kernel with statistics that do not hold: rows outside them bypass the packed sum (and, in the dense
+    form, keys outside them the table)."""
+    kernel = _one_pass_kernel(dense, monkeypatch)
     st = _mid_table(900_000, 300, 23)
     ex = gpu_executor_factory(st)
     w = ColRef("w")
@@ -292,7 +304,7 @@ def test_small_table_with_stale_statistics(oracle, gpu_executor_factory):
     cp, want, err = run_oracle(oracle, st, q)
     assert err == 0
     step = ex.prepare(cp)
-    assert step.kernel_names().startswith("hdk_scan_agg_bh_packed"), step.kernel_names()
+    assert step.kernel_names().startswith(kernel), step.kernel_names()
     for ci in range(step.plan.num_cols):
         c = step.plan.cols[ci]
         if c.has_stats and c.width == 8:
@@ -311,9 +323,10 @@ def _phs_query(xcol, table="t", **kw):
                               Agg("avg", y, "a")], **kw)
 
 
+@pytest.mark.parametrize("dense", [True, False])
 @pytest.mark.parametrize("xcol", ["x10", "x100", "x1k"])
 @pytest.mark.parametrize("columnar", [False, True])
-def test_perfect_hash_benchmark_shape_on_the_packed_kernel(oracle, gpu_executor_factory, xcol, columnar):
+def test_perfect_hash_benchmark_shape_on_the_packed_kernel(oracle, gpu_executor_factory, xcol, columnar, dense, monkeypatch):
     """PHS001-003: count / sum / max / min / avg of one int column by an int key with a perfect-hash layout (NULL keys and
     NULL arguments present): the buffer must equal the oracle's bit for bit -- entries, stored keys, untouched slots."""
     from util import assert_buffers_equal
@@ -322,8 +335,9 @@ def test_perfect_hash_benchmark_shape_on_the_packed_kernel(oracle, gpu_executor_
     q = _phs_query(xcol, output_columnar=columnar)
     cp, want, err = run_oracle(oracle, st, q)
     assert err == 0 and cp.plan.query_kind == A.Q_PERFECT_HASH
+    kernel = _one_pass_kernel(dense, monkeypatch)
     step = ex.prepare(cp)
-    assert step.kernel_names().startswith("hdk_scan_agg_bh_packed"), step.kernel_names()
+    assert step.kernel_names().startswith(kernel), step.kernel_names()
     res = step.run()
     assert_buffers_equal(cp, res.buffer, want)
     step.launch()  # a second launch accumulates
