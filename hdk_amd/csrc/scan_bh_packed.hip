@@ -4,6 +4,7 @@
 
 #include "host_match.h"
 #include "scan_bh_packed.h"
+#include "scan_bh_dense_part.h"
 #include "scan_bh_host.h"
 
 namespace hdk {
@@ -220,6 +221,83 @@ static bool match_bh_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_opt
   return true;
 }
 
+// ---- dense keys beyond LDS: 256 bins by key range, 4-byte tuples (scan_bh_dense_part.h) ---------------------------------------
+struct BhDensePartLayout {
+  size_t cursor_bytes, total;
+  uint32_t lds_bytes;
+  int kw, vw;
+};
+static bool match_bh_dense_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhDensePartArgs* g, BhDensePartLayout* l) {
+  const bool always = hdk_sw(SW_BH_PARTITIONS_ALWAYS) != nullptr;  // (tests: small inputs and tables)
+  if (hdk_sw(SW_NO_BH_PARTITIONS) || hdk_sw(SW_NO_BH_DENSE_PARTITIONS) || !ko || ko->total_rows == 0) return false;
+  memset(g, 0, sizeof(*g));
+  BhPackedArgs& a = g->p;
+  if (!match_bh_packed_shape(p, ko, &a, &l->kw, &l->vw)) return false;
+  if (!a.dense_n) return false;
+  if (!always && ko->total_rows < (4ull << 20)) return false;
+  if (ko->total_rows >= (1ull << 40)) return false;
+  g->n_entries = a.dense_n + ((a.key_nullable && a.key_width == 4) ? 1u : 0u);
+  g->width = (g->n_entries + 255) / 256;
+  if (g->width < 2) g->width = 2;
+  g->nbins = (g->n_entries + g->width - 1) / g->width;
+  g->w = pow2_ceil_log2(g->width);
+  if (g->w < 1) g->w = 1;
+  if (g->w > 11) return false;  // (a bin's table: 2 048 entries of 24 bytes)
+  magic_u32(g->width, &g->wmagic, &g->wshift);
+  // the argument's code next to the offset inside the bin
+  uint32_t vbits = 0;
+  if (a.has_val) {
+    const uint64_t codes = static_cast<uint64_t>(static_cast<int64_t>(a.val_max) - a.val_min) + 2;
+    vbits = pow2_ceil_log2(codes);
+    g->val_codes = static_cast<uint32_t>(codes);
+  }
+  if (g->w + vbits > 32) return false;
+  // pass B's LDS: the bin's table, replicated while that stays below 48 KB
+  uint32_t reps = 16;
+  while (reps > 1 && (24ull * ((1ull << g->w) + 4) + 16) * reps > (48u << 10)) reps >>= 1;
+  bh_packed_geometry(&a, g->w, reps);
+  l->lds_bytes = a.rep_words * 4 * reps;
+  g->cap4 = ((ko->total_rows / (static_cast<uint64_t>(g->nbins) * kPbXcds)) * 5 / 4 + 4096 + 3) & ~3ull;
+  if (g->cap4 > 0xFFFFFFF0ull) return false;
+  l->cursor_bytes = static_cast<size_t>(g->nbins) * kPbXcds * kPbCursorStride * sizeof(uint32_t);
+  l->total = l->cursor_bytes + static_cast<size_t>(g->nbins) * kPbXcds * g->cap4 * 4;
+  return true;
+}
+
+template <int KW>
+static const void* bh_dscatter_kernel_kw(int vw) {
+  return vw == 0 ? reinterpret_cast<const void*>(hdk_bh_dscatter<KW, 0>)
+                 : (vw == 4 ? reinterpret_cast<const void*>(hdk_bh_dscatter<KW, 4>) : reinterpret_cast<const void*>(hdk_bh_dscatter<KW, 8>));
+}
+
+static int32_t launch_bh_dense_part(const hdk_hip_plan* d_plan, const KernParams& kp, BhDensePartArgs& g, const BhDensePartLayout& l,
+                                    const hdk_hip_device_properties* props, hipStream_t s, bool* launched) {
+  AsyncScratch scratch(s);
+  if (hipMallocAsync(&scratch.p, l.total, s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return HDK_HIP_OK;  // no room for the tuples: the other strategies
+  }
+  int8_t* base = static_cast<int8_t*>(scratch.p);
+  HDK_HIP_CHECK(hipMemsetAsync(base, 0, l.cursor_bytes, s));
+  g.p.plan = d_plan;
+  g.p.kp = kp;
+  g.fill = reinterpret_cast<uint32_t*>(base);
+  g.tuples4 = reinterpret_cast<uint32_t*>(base + l.cursor_bytes);
+  const void* sk = l.kw == 4 ? bh_dscatter_kernel_kw<4>(l.vw) : bh_dscatter_kernel_kw<8>(l.vw);
+  const unsigned g1 = scatter_grid(sk, kPbBlock, kBhDpScatterLds, props, 2);
+  void* kargs[] = {&g};
+  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), kargs, kBhDpScatterLds, s));
+  const void* ak = reinterpret_cast<const void*>(hdk_bh_daggregate);
+  if (l.lds_bytes > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l.lds_bytes)));
+  }
+  hipLaunchKernelGGL(hdk_bh_daggregate, dim3(g.nbins), dim3(kBhDpAggThreads), l.lds_bytes, s, g);
+  HDK_HIP_CHECK(hipGetLastError());
+  *launched = true;
+  return HDK_HIP_OK;
+}
+
 const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
   BhPackedArgs a;
   int kw, vw, block;
@@ -228,6 +306,9 @@ const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_op
     if (bh_plain(a, kw, vw)) return a.dense ? "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed_plain,hdk_bh_fold_slabs";
     return a.dense ? "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed,hdk_bh_fold_slabs";
   }
+  BhDensePartArgs dg;
+  BhDensePartLayout dl;
+  if (match_bh_dense_part(p, ko, &dg, &dl)) return "hdk_bh_dscatter,hdk_bh_daggregate";
   BhPartLayout l;
   if (match_bh_partitioned(p, ko, &a, &l)) return "hdk_bh_scatter,hdk_bh_aggregate";
   return nullptr;
@@ -267,6 +348,9 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   int kw, vw, block;
   uint32_t lds;
   if (!match_bh_packed(plan, ko, &a, &kw, &vw, &block, &lds)) {
+    BhDensePartArgs dg;
+    BhDensePartLayout dl;
+    if (match_bh_dense_part(plan, ko, &dg, &dl)) return launch_bh_dense_part(d_plan, kp, dg, dl, props, s, launched);
     BhPartLayout l;
     if (match_bh_partitioned(plan, ko, &a, &l)) return launch_bh_partitioned(d_plan, kp, a, l, props, s, launched);
     return HDK_HIP_OK;

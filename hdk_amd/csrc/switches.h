@@ -17,6 +17,7 @@ namespace hdk {
   X(KEYS_NO_WIDE_BLOCK)             \
   X(NO_BATCHED_MATCHING_SETS)       \
   X(NO_BH_DENSE)                    \
+  X(NO_BH_DENSE_PARTITIONS)         \
   X(NO_BH_DIRECT)                   \
   X(NO_BH_LDS)                      \
   X(NO_BH_PACKED)                   \

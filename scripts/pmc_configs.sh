@@ -18,6 +18,6 @@ else:
         if (r["Dispatch_Id"]) not in seen:
             seen.add(r["Dispatch_Id"]); calls[k] += 1
     for k in acc:
-        if "scan" in k:
+        if any(w in k for w in "${KFILTER:-scan}".split(",")):
             print(k, "calls", calls[k], {c: round(v / calls[k]) for c, v in acc[k].items()})
 PY

@@ -241,24 +241,36 @@ def _mid_table(n, groups, seed, hot=0.0):
         x[rng.random(n) < hot] = 7
     y = rng.integers(1, 11, n).astype(np.int32)
     y[rng.random(n) < 0.02] = A.NULL_INT
+    x64 = x.astype(np.int64) * 3 - 100
+    x[rng.random(n) < 0.002] = A.NULL_INT  # NULL keys: a group of their own
     st = ArrowStorage()
-    st.import_numpy("t", {"x": x, "y10": y, "x64": x.astype(np.int64) * 3 - 100, "w": rng.integers(-5000, 5000, n).astype(np.int64)},
+    st.import_numpy("t", {"x": x, "y10": y, "x64": x64, "w": rng.integers(-5000, 5000, n).astype(np.int64)},
                     fragment_size=n // 3 + 7)
     return st
 
 
+def _two_pass_kernels(bins, monkeypatch):
+    """tables beyond LDS: 256 bins by key RANGE with 4-byte tuples when the key column's statistics are dense enough (all of
+    these tests' tables), or -- with the switch -- by the key's hash with 8-byte tuples, as for sparse keys"""
+    if bins == "hash":
+        monkeypatch.setenv("HDK_HIP_NO_BH_DENSE_PARTITIONS", "1")
+    return "hdk_bh_dscatter,hdk_bh_daggregate" if bins == "range" else "hdk_bh_scatter,hdk_bh_aggregate"
+
+
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("bins", ["range", "hash"])
 @pytest.mark.parametrize("groups,hot", [(9_000, 0.0), (60_000, 0.0), (9_000, 0.6)])
-def test_mid_sized_tables_by_hash_bins(oracle, gpu_executor_factory, groups, hot):
+def test_mid_sized_tables_by_hash_bins(oracle, gpu_executor_factory, groups, hot, bins, monkeypatch):
     """BH004 / BH005's size class: 10 K - 100 K groups behind a double key.  A hot key overflows its bin's slab: those rows
     take the reference's own scheme inside the scatter pass."""
     st = _mid_table(4_400_000, groups, 21, hot)
     ex = gpu_executor_factory(st)
     q = _bh_query("x")
     cp, want, err = run_oracle(oracle, st, q)
-    assert err == 0 and cp.entry_count == 2 * groups
+    assert err == 0 and cp.entry_count in (2 * groups, 2 * groups + 2)
+    kernels = _two_pass_kernels(bins, monkeypatch)
     step = ex.prepare(cp)
-    assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+    assert step.kernel_names() == kernels, step.kernel_names()
     res = step.run()
     step.free()
     _check_rows(cp, res.buffer, want)
@@ -267,7 +279,8 @@ def test_mid_sized_tables_by_hash_bins(oracle, gpu_executor_factory, groups, hot
 
 
 @pytest.mark.timeout(900)
-def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_executor_factory):
+@pytest.mark.parametrize("bins", ["range", "hash"])
+def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_executor_factory, bins, monkeypatch):
     """8-byte key and argument columns that fit 32 bits by their statistics, a filter, and -- second run -- statistics that
     do NOT hold (narrowed by hand in the launch's plan copy): the rows outside them take the exact path, same result."""
     st = _mid_table(4_300_000, 30_000, 22)
@@ -277,9 +290,10 @@ def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_
                   targets=[KeyRef(0, "k"), Agg("sum", w, "s"), Agg("min", w, "mn"), Agg("max", w, "mx"), Agg("count", None, "c")])
     cp, want, err = run_oracle(oracle, st, q)
     assert err == 0
+    kernels = _two_pass_kernels(bins, monkeypatch)
     for stale in (False, True):
         step = ex.prepare(cp)
-        assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+        assert step.kernel_names() == kernels, step.kernel_names()
         if stale:
             for ci in range(step.plan.num_cols):
                 c = step.plan.cols[ci]
@@ -351,7 +365,8 @@ def test_perfect_hash_benchmark_shape_on_the_packed_kernel(oracle, gpu_executor_
 
 
 @pytest.mark.timeout(900)
-def test_perfect_hash_table_beyond_lds_by_hash_bins(oracle, gpu_executor_factory):
+@pytest.mark.parametrize("bins", ["range", "hash"])
+def test_perfect_hash_table_beyond_lds_by_hash_bins(oracle, gpu_executor_factory, bins, monkeypatch):
     """PHS004's size class: 9 000 groups -- the table does not fit LDS, the rows go through the 256-bin passes and the fold
     addresses the perfect-hash table by key - min."""
     from util import assert_buffers_equal
@@ -360,8 +375,9 @@ def test_perfect_hash_table_beyond_lds_by_hash_bins(oracle, gpu_executor_factory
     q = _phs_query("x")
     cp, want, err = run_oracle(oracle, st, q)
     assert err == 0 and cp.plan.query_kind == A.Q_PERFECT_HASH
+    kernels = _two_pass_kernels(bins, monkeypatch)
     step = ex.prepare(cp)
-    assert step.kernel_names() == "hdk_bh_scatter,hdk_bh_aggregate", step.kernel_names()
+    assert step.kernel_names() == kernels, step.kernel_names()
     res = step.run()
     step.free()
     assert_buffers_equal(cp, res.buffer, want)
