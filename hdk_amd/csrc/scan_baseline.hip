@@ -817,7 +817,10 @@ static bool match_perfect_partitioned(const hdk_hip_plan* p, const hdk_hip_kerne
   // ---- geometry --------------------------------------------------------------------------------------------------------------
   uint32_t slice_log2 = 0;
   while ((2ull << slice_log2) * a->row_bytes <= kPpLdsBytes) ++slice_log2;
-  if (const char* e = hdk_sw(SW_PERFECT_SLICE_LOG2)) slice_log2 = static_cast<uint32_t>(atoi(e));  // (tests)
+  if (const char* e = hdk_sw(SW_PERFECT_SLICE_LOG2)) {  // (tests: smaller slices; never more than LDS holds)
+    const uint32_t want = static_cast<uint32_t>(atoi(e));
+    if (want < slice_log2) slice_log2 = want;
+  }
   if (slice_log2 < 4 || slice_log2 > 20) return false;
   a->slice_log2 = slice_log2;
   a->nslices = static_cast<uint32_t>((static_cast<uint64_t>(a->entry_count) + (1ull << slice_log2) - 1) >> slice_log2);
@@ -888,9 +891,7 @@ static void pp_launch(const PpArgs& a, const hdk_hip_device_properties* props, h
     a2.members2 = m2;
     hipLaunchKernelGGL((k_pp_scatter2<TW, VR>), dim3(bins8 * kPbXcds * m2), dim3(kPbBlock), lds_sc, s, a2);
   }
-  const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * a.row_bytes;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pp_aggregate<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds_b));
+  const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * a.row_bytes;  // (granted: launch_perfect_partitioned asked)
   unsigned gb = 2 * cu;
   if (gb > a.nslices) gb = a.nslices;
   hipLaunchKernelGGL((k_pp_aggregate<TW>), dim3(gb), dim3(kPbBlock), lds_b, s, a);
@@ -901,6 +902,16 @@ static int32_t launch_perfect_partitioned(const hdk_hip_plan* plan, const hdk_hi
                                           const PpLayout& l, const LaunchShape& shape, const hdk_hip_device_properties* props,
                                           hipStream_t s, bool* launched) {
   *launched = false;
+  // the aggregate pass's LDS first: a device that does not grant it runs the plan on global atomics, not into a launch error
+  {
+    const size_t lds_b = (static_cast<size_t>(1) << a.slice_log2) * a.row_bytes;
+    const void* ak = l.tw == 1 ? reinterpret_cast<const void*>(k_pp_aggregate<1>)
+                               : (l.tw == 2 ? reinterpret_cast<const void*>(k_pp_aggregate<2>) : reinterpret_cast<const void*>(k_pp_aggregate<3>));
+    if (hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)) != hipSuccess) {
+      (void)hipGetLastError();
+      return HDK_HIP_OK;
+    }
+  }
   AsyncScratch scratch(s);
   if (hipMallocAsync(&scratch.p, l.total, s) != hipSuccess) {
     (void)hipGetLastError();

@@ -382,7 +382,10 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
   // straight vector code.  (One row at a time the scalar dispatch was the bottleneck: ~70 scalar instructions per tuple.)
   constexpr int K = GROUPED ? HDK_S2_K_GROUPED : HDK_S2_K_PLAIN;
   // ok[k]: slot k holds a tuple with a partner; x32 / p32 its outer value and payload (kSliceNull: the column's NULL)
-  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p0)[K], const int32_t (&p1)[K], const int32_t (&y32)[K], bool (&ok)[K]) {
+  // (with_quals: the filters on the joined columns are still to be applied -- tuples of the overflow area; a slice's tuples find
+  // them applied to the payloads in LDS: a key whose payloads fail reads as a key without a partner)
+  auto batch = [&](const int32_t (&x32)[K], const int32_t (&p0)[K], const int32_t (&p1)[K], const int32_t (&y32)[K], bool (&ok)[K],
+                   const bool with_quals) {
     bool pn0[K], pn1[K], yn[K], xnull[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
       }
     };
     // filters on the joined column: a NULL fails every comparison (DEF_CMP_NULLABLE)
-    for (int q = 0; q < npq; ++q) {
+    for (int q = 0; q < (with_quals ? npq : 0); ++q) {
       const int64_t rhs = g.pq[q].rhs;
       int32_t p32[K];
       bool pnull[K];
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
       x32[k] = static_cast<int32_t>(static_cast<uint64_t>(w[k]) >> 32);
       ok[k] = p0[k] != kSliceNoMatch;  // (INNER join: no partner, no row)
     }
-    batch(x32, p0, p1, y32, ok);
+    batch(x32, p0, p1, y32, ok, false);
   };
   // the block's slices (one level: exactly one; two levels: slice, slice + nsl_par, ...), each: payloads into LDS, then its
   // tuples -- 16-byte words w, w + stride, ...; two words (four tuples) per trip, the next two in flight
@@ -585,6 +588,27 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
     nkeys = first < coarse_end ? static_cast<uint32_t>(min(static_cast<uint64_t>(g.fslice), coarse_end - first)) : 0u;
     __syncthreads();  // (the previous slice's probes are done)
     bool bad = false;
+    // the filters on the joined columns, once per KEY (10 M) instead of once per tuple (1 B): INNER join + WHERE on the inner
+    // side = filter the inner side first; a NULL fails every comparison (DEF_CMP_NULLABLE)
+    auto pay_pass = [&](int64_t y, bool ynull, int64_t z, bool znull) {
+      bool pass = true;
+      for (int q = 0; q < npq; ++q) {
+        const bool second = TWO && g.pq[q].pidx == 1;
+        const int64_t v = second ? z : y, rhs = g.pq[q].rhs;
+        const bool vnull = second ? znull : ynull;
+        bool c;
+        switch (g.pq[q].cmp) {
+          case HDK_CMP_EQ: c = v == rhs; break;
+          case HDK_CMP_NE: c = v != rhs; break;
+          case HDK_CMP_LT: c = v < rhs; break;
+          case HDK_CMP_GT: c = v > rhs; break;
+          case HDK_CMP_LE: c = v <= rhs; break;
+          default: c = v >= rhs; break;
+        }
+        pass = pass && !vnull && c;
+      }
+      return pass;
+    };
     for (uint32_t i = tid; i < nkeys; i += kSliceAggBlock) {
       const int64_t* e = table + static_cast<uint64_t>(first + i) * fstride;
       const int64_t rid = __builtin_nontemporal_load(e);
@@ -595,6 +619,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
           const int64_t y = __builtin_nontemporal_load(e + 1);
           const int64_t z = __builtin_nontemporal_load(e + 2);
           c0 = 1;
+          const bool yn = a.pay_nullable && y == a.pay_null, zn = g.pay_nullable1 && z == g.pay_null1;
           if (!(a.pay_nullable && y == a.pay_null)) {
             const uint64_t d0 = static_cast<uint64_t>(y) - static_cast<uint64_t>(g.pk_min0);
             bad |= d0 >= g.pk_codes0 - 2u;  // a payload outside its statistics
@@ -605,24 +630,35 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
             bad |= d1 >= g.pk_codes1 - 1u;
             c1 = static_cast<uint32_t>(d1) + 1u;
           }
+          if (npq && !pay_pass(y, yn, z, zn)) {
+            c0 = 0;
+            c1 = 0;
+          }
         }
         p32 = static_cast<int32_t>(c0 | (c1 << g.pk_bits0));
       } else if (rid >= 0) {
         const int64_t y = __builtin_nontemporal_load(e + 1);
-        if (a.pay_nullable && y == a.pay_null) {
+        const bool yn = a.pay_nullable && y == a.pay_null;
+        if (yn) {
           p32 = kSliceNull;
         } else {
           p32 = static_cast<int32_t>(y);
           bad |= static_cast<int64_t>(p32) != y || p32 == kSliceNoMatch || p32 == kSliceNull;
         }
+        int64_t z = 0;
+        bool zn = false;
         if (NPAY == 2) {
-          const int64_t z = __builtin_nontemporal_load(e + 2);
-          if (g.pay_nullable1 && z == g.pay_null1) {
+          z = __builtin_nontemporal_load(e + 2);
+          zn = g.pay_nullable1 && z == g.pay_null1;
+          if (zn) {
             q32 = kSliceNull;
           } else {
             q32 = static_cast<int32_t>(z);
             bad |= static_cast<int64_t>(q32) != z || q32 == kSliceNull;
           }
+        }
+        if (npq && !pay_pass(y, yn, z, zn)) {
+          p32 = kSliceNoMatch;
         }
       }
       s_pay[i] = p32;
@@ -723,7 +759,7 @@ __global__ __launch_bounds__(kSliceAggBlock) void hdk_join_agg_sliced2(Slice2Arg
           }
         }
       }
-      batch(x32, p0, p1, y32, ok);
+      batch(x32, p0, p1, y32, ok, true);
     }
     if (__any(bad2) && (tid & (kWave - 1)) == 0) {
       atomicMax(a.mode, 1u);

@@ -45,7 +45,9 @@ class HipArena {
   HipArena& operator=(const HipArena&) = delete;
   ~HipArena() {
     for (auto& kv : live_) release(kv.second.get());
-    if (bounce_) (void)hdk_hip_mgr_free_pinned_host_mem(bounce_);
+    for (auto& kv : bounce_) {
+      if (kv.second) (void)hdk_hip_mgr_free_pinned_host_mem(kv.second);
+    }
   }
 
   // allocator APIs (GpuAllocator)
@@ -88,11 +90,20 @@ class HipArena {
       mgr_->copyHostToDevice(device_ptr, host_ptr, num_bytes, device_id);
       return;
     }
-    std::lock_guard<std::mutex> lk(mu_);
-    if (!bounce_) check(hdk_hip_mgr_allocate_pinned_host_mem(bounce_bytes_, &bounce_));
-    mgr_->synchronizeStream(device_id);  // the previous user of the bounce buffer is done
-    std::memcpy(bounce_, host_ptr, num_bytes);
-    mgr_->copyHostToDeviceAsync(device_ptr, bounce_, num_bytes, device_id);
+    // ONE bounce buffer PER DEVICE: the copy it last carried ran on that device's stream, so waiting for that stream is
+    // waiting for the right copy (a buffer shared by all devices would be overwritten under a copy still in flight to
+    // another device).  The map is guarded; the wait and the memcpy are not done under the lock of another device's buffer.
+    int8_t* bounce = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      int8_t*& slot = bounce_[device_id];
+      if (!slot) check(hdk_hip_mgr_allocate_pinned_host_mem(bounce_bytes_, &slot));
+      bounce = slot;
+    }
+    std::lock_guard<std::mutex> dev_lk(bounce_mu_[static_cast<size_t>(device_id) % kBounceLocks]);
+    mgr_->synchronizeStream(device_id);  // the previous user of THIS device's bounce buffer is done
+    std::memcpy(bounce, host_ptr, num_bytes);
+    mgr_->copyHostToDeviceAsync(device_ptr, bounce, num_bytes, device_id);
   }
   void synchronizeStream(const int device_id) const { mgr_->synchronizeStream(device_id); }
   void copyFromDevice(int8_t* host_ptr, const int8_t* device_ptr, const size_t num_bytes, const int device_id) const {
@@ -124,7 +135,9 @@ class HipArena {
   }
   HipMgr* mgr_;
   size_t bounce_bytes_;
-  int8_t* bounce_{nullptr};
+  static constexpr size_t kBounceLocks = 16;
+  std::unordered_map<int, int8_t*> bounce_;   // device id -> its pinned bounce buffer (under mu_)
+  std::mutex bounce_mu_[kBounceLocks];        // one user at a time per device's buffer
   mutable std::mutex mu_;
   std::unordered_map<Buffer*, std::unique_ptr<Buffer>> live_;
 };

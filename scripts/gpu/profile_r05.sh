@@ -17,6 +17,7 @@ run_pmc() {  # name, tag, counters, bench args...
   rm -rf $O/pmc_${name}_$tag
 }
 run_stats bench_default
+run_stats bench_no_e2e --no-end-to-end
 Q="--steps 5 --warmup 2 --no-cpu-baseline --no-oracle-sample --no-multi-gpu-emulation --no-end-to-end --extra none"
 for c in ${CONFIGS:-c2 c3 c3g c3gm c3m bh1 bh3 bh5 c5 c5s q1 q2 q3 q4}; do
   run_pmc $c fetch "FETCH_SIZE" --config $c $Q
@@ -24,7 +25,7 @@ for c in ${CONFIGS:-c2 c3 c3g c3gm c3m bh1 bh3 bh5 c5 c5s q1 q2 q3 q4}; do
 done
 # the Infinity-Cache experiment (scripts/microbench/mall_pingpong.hip): per-kernel times of one pass over everything against
 # 512 MiB chunks, streamed and scattered tuples
-for cfg in "0 0 0" "0 0 512" "1 0 0" "1 0 512"; do
+for cfg in ${MALL_CFGS:-"0 0 0" "0 0 512" "1 0 0" "1 0 512"}; do
   set -- $cfg
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_mall -o mall --output-format csv -- scripts/microbench/mall_pingpong 536870912 $1 $2 $3 > $O/mall_$1_$3.txt 2>&1
   find $O/prof_mall -name "*kernel_stats.csv" -exec cp {} $O/mall_$1_$3_kernel_stats.csv \;
