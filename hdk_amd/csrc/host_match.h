@@ -90,9 +90,12 @@ inline bool plan_has_keyed_join(const hdk_hip_plan* p) {
   return false;
 }
 
-// filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape
-inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
-  if (p->num_quals > kMaxPlainQuals || p->num_filter_ops) return false;
+// filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape.
+// allow_program: the caller's kernel evaluates its filters through plain_quals_pass and nothing else, so an AND / OR / NOT
+// program over such leaves (hdk_hip_plan::filter_ops) is fine too: it rides in out[0]
+inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out, bool allow_program = false) {
+  if (p->num_quals > kMaxPlainQuals) return false;
+  if (p->num_filter_ops && (!allow_program || p->num_filter_ops > kMaxPlainProg || p->num_joins || p->num_quals == 0)) return false;
   for (int i = 0; i < p->num_quals; ++i) {
     const hdk_hip_qual& q = p->quals[i];
     int c;
@@ -115,6 +118,11 @@ inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out) {
     } else {
       fq.rhs = q.rhs.ival;
     }
+    fq.nprog = 0;
+  }
+  if (p->num_filter_ops) {
+    out[0].nprog = p->num_filter_ops;
+    for (int i = 0; i < p->num_filter_ops; ++i) out[0].prog[i] = p->filter_ops[i];
   }
   return true;
 }

@@ -2,6 +2,10 @@
 // `outer column <cmp> literal` with the reference's three-valued semantics (DEF_CMP_NULLABLE,
 // QE/RuntimeFunctions.cpp:83-117: a NULL operand fails the conjunct), evaluated for VR rows per lane
 // with every wave-uniform decision (decoder, operator, fp/int) outside the row loops.
+// Round 5: the same leaves under a postfix AND / OR / NOT program (hdk_hip_plan::filter_ops; logical_and / logical_or /
+// logical_not, QE/RuntimeFunctions.cpp:357-384) -- `WHERE a < 0 OR k = 3` no longer sends a plan to the interpreter.  Every
+// leaf is evaluated for every live row into two bit masks per lane (bit r: TRUE / NULL for row r), the program combines
+// masks: no per-row control flow, a stack of three values in registers (at most kMaxPlainQuals leaves).
 #pragma once
 #include "device_common.h"
 
@@ -23,7 +27,11 @@ struct ProjFastQual {
   int64_t rhs;       // literal: int64, or double bits when the comparison is fp
   int32_t fp;        // compare as double (column or literal is fp)
   int32_t col_fp;    // the column holds fp values
+  // the filter's postfix program, carried by quals[0] (nprog == 0: the plain conjunction of all leaves)
+  int32_t nprog;
+  uint8_t prog[12];
 };
+constexpr int kMaxPlainProg = 12;
 
 // VR rows (explicit row numbers, only where live) of one column
 template <int VR>
@@ -59,10 +67,98 @@ HDK_DEV void plain_load_rows(const int8_t* buf, int width, int kind, const int64
 #undef HDK_PQ_ROWS
 }
 
+// pass[r] &= the program over the leaves is TRUE for row[r]
+template <int VR>
+HDK_DEV void plain_quals_program(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
+                                 bool (&pass)[VR], bool nt) {
+  constexpr int NW = (VR + 31) / 32;  // mask words per value: one bit per row
+  uint32_t lt[kMaxPlainQuals][NW], ln[kMaxPlainQuals][NW];  // leaf qi: bit r = TRUE / NULL for row r
+#pragma unroll
+  for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      lt[qi][w] = 0;
+      ln[qi][w] = 0;
+    }
+    if (qi < nquals) {
+      const ProjFastQual q = quals[qi];
+      int64_t v[VR];
+      plain_load_rows<VR>(cols[q.col.buf_idx], q.col.width, q.col.kind, row, pass, nt, v);
+      const bool fpc = q.fp != 0, col_fp = q.col_fp != 0, nullable = q.nullable != 0;
+#pragma unroll
+      for (int r = 0; r < VR; ++r) {
+        const bool isnull = nullable && (col_fp ? bits_to_double(v[r]) == bits_to_double(q.null_val) : v[r] == q.null_val);
+        ln[qi][r / 32] |= isnull ? 1u << (r % 32) : 0u;
+        if (fpc && !col_fp) {
+          v[r] = double_to_bits(static_cast<double>(v[r]));
+        }
+      }
+#define HDK_PQ_BITS(OP)                                                                                                     \
+  _Pragma("unroll") for (int r = 0; r < VR; ++r) {                                                                          \
+    lt[qi][r / 32] |= (fpc ? (bits_to_double(v[r]) OP bits_to_double(q.rhs)) : (v[r] OP q.rhs)) ? 1u << (r % 32) : 0u;       \
+  }
+      switch (q.cmp) {
+        case HDK_CMP_EQ: HDK_PQ_BITS(==) break;
+        case HDK_CMP_NE: HDK_PQ_BITS(!=) break;
+        case HDK_CMP_LT: HDK_PQ_BITS(<) break;
+        case HDK_CMP_GT: HDK_PQ_BITS(>) break;
+        case HDK_CMP_LE: HDK_PQ_BITS(<=) break;
+        default: HDK_PQ_BITS(>=) break;
+      }
+#undef HDK_PQ_BITS
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        lt[qi][w] &= ~ln[qi][w];  // (a NULL operand: the comparison is NULL, not TRUE)
+      }
+    }
+  }
+  // the value stack: a = top, b, c below it (wave-uniform program, per-lane masks)
+  uint32_t at[NW], an[NW], bt[NW], bn[NW], ct[NW], cn[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    at[w] = an[w] = bt[w] = bn[w] = ct[w] = cn[w] = 0;
+  }
+  const int nprog = quals[0].nprog;
+  for (int i = 0; i < nprog; ++i) {
+    const uint32_t op = quals[0].prog[i];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      if (op < HDK_F_AND) {
+        ct[w] = bt[w]; cn[w] = bn[w];
+        bt[w] = at[w]; bn[w] = an[w];
+        at[w] = op == 0 ? lt[0][w] : (op == 1 ? lt[1][w] : lt[2][w]);
+        an[w] = op == 0 ? ln[0][w] : (op == 1 ? ln[1][w] : ln[2][w]);
+      } else if (op == HDK_F_NOT) {
+        at[w] = ~(at[w] | an[w]);  // NULL stays NULL, TRUE <-> FALSE
+      } else {
+        uint32_t rt, rn;
+        if (op == HDK_F_AND) {
+          const uint32_t fa = ~(at[w] | an[w]), fb = ~(bt[w] | bn[w]);  // FALSE operands
+          rt = at[w] & bt[w];
+          rn = ~(rt | fa | fb);
+        } else {
+          rt = at[w] | bt[w];
+          rn = ~rt & (an[w] | bn[w]);
+        }
+        at[w] = rt; an[w] = rn;
+        bt[w] = ct[w]; bn[w] = cn[w];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < VR; ++r) {
+    pass[r] = pass[r] && ((at[r / 32] >> (r % 32)) & 1u);
+  }
+}
+
 // pass[r] &= every conjunct is TRUE for row[r]
 template <int VR>
 HDK_DEV void plain_quals_pass(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
                               bool (&pass)[VR], bool nt) {
+  if (nquals > 0 && quals[0].nprog != 0) {  // (wave-uniform)
+    plain_quals_program<VR>(quals, nquals, cols, row, pass, nt);
+    return;
+  }
   for (int qi = 0; qi < nquals; ++qi) {
     const ProjFastQual q = quals[qi];
     int64_t v[VR];

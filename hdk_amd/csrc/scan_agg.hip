@@ -969,7 +969,7 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   fa->nops = nops;
   if (p->num_quals || fa->vform) {
     // filtered plans / expression arguments: only the instantiations scan_fast.hip has (grouped, 8-byte value column)
-    if (kw == 0 || vw != 8 || p->num_filter_ops) return false;
+    if (kw == 0 || vw != 8) return false;
     // X mode: every filter operand is the value column, the (8-byte) key column, one of <= 2 other 8-byte integer columns
     // -- streamed with 16-byte loads beside the value column -- or an integer literal
     FastArgs x = *fa;
@@ -977,7 +977,11 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     // shape: C2 + WHERE c < 0 at 256 M rows 0.98 ms against 1.10 ms with c streamed)
     bool needs_x = fa->vform != 0;
     for (int i = 0; i < p->num_quals; ++i) needs_x = needs_x || p->quals[i].rhs.kind == HDK_LEAF_COL;
-    bool xmode = needs_x && !fa->val_is_fp && !hdk_sw(SW_FAST_NO_XMODE);
+    // an AND / OR / NOT program: in X mode when every operand is a column the kernel streams anyway (the value and the key
+    // column: `WHERE val < 0 OR key = 3` reads nothing extra), else over gathered `column cmp literal` leaves
+    const bool program = p->num_filter_ops != 0;
+    if (program && (p->num_filter_ops > kMaxPlainProg || p->num_quals > kMaxPlainQuals)) return false;
+    bool xmode = (needs_x || program) && !fa->val_is_fp && !hdk_sw(SW_FAST_NO_XMODE);
     auto src_of = [&](int col) -> int {
       const hdk_hip_col& cc = p->cols[col];
       if (cc.table != 0 || cc.kind != HDK_COL_INT || cc.width != 8) return -1;
@@ -1010,12 +1014,19 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
       }
       if (xq.lhs_src < 0 || xq.rhs_src < 0) xmode = false;
     }
+    if (xmode && program && x.nx != 0) xmode = false;  // (the program's X kernel streams no extra column; a third column just
+                                                       //  for a literal compare is cheaper gathered anyway)
+    if (program && needs_x && !xmode) return false;
     if (xmode) {
       x.nxq = p->num_quals;
+      if (program) {
+        x.nxprog = p->num_filter_ops;
+        for (int i = 0; i < p->num_filter_ops; ++i) x.xprog[i] = p->filter_ops[i];
+      }
       *fa = x;
     } else {
       // gathered `column cmp literal` filters (any column width, fp literals): the Q instantiations; no expression argument
-      if (fa->vform || !match_plain_quals(p, fa->q)) return false;
+      if (fa->vform || !match_plain_quals(p, fa->q, true)) return false;
       fa->nquals = p->num_quals;
     }
   }
@@ -2037,7 +2048,7 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
   if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_PERFECT_HASH || p->num_joins) return false;
   if (p->key_count < 1 || p->key_count > kKeysMax) return false;
   if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
-  if (!match_plain_quals(p, ka->q)) return false;
+  if (!match_plain_quals(p, ka->q, true)) return false;
   ka->wpe = shape.wpe;
   ka->nvals = 0;
   ka->nops = 0;

@@ -78,6 +78,8 @@ struct FastArgs {
     int32_t pad_;
     int64_t lhs_null, rhs_null, lit;
   } xq[kMaxPlainQuals];
+  int32_t nxprog;           // > 0: the filters are the leaves of this postfix AND / OR / NOT program (hdk_hip_plan::filter_ops)
+  uint8_t xprog[kMaxPlainProg];
   int32_t vform;            // 0: the value column itself; 1: a op extra column b_src; 2: a op literal
   int32_t vop;              // HDK_OP_ADD / SUB / MUL
   int32_t v_check_width;
@@ -93,7 +95,65 @@ HDK_DEV int64_t fast_x_src(int32_t src, int64_t a, int64_t e0, int64_t e1, int64
   return src == 0 ? a : (src == 1 ? e0 : (src == 2 ? e1 : (src == 3 ? key : lit)));
 }
 
-// the X-mode filters of one row: true when every conjunct is TRUE
+// X-mode filters under an AND / OR / NOT program (FastArgs::xprog), for the N rows of a lane's tile at once: every leaf into
+// two bit masks (bit j: TRUE / NULL for row j), the program once over masks -- three-valued logical_and / logical_or /
+// logical_not (QE/RuntimeFunctions.cpp:357-384), a stack of three values.  (Row by row the wave-uniform program loop ran once
+// per row: `WHERE val < 0 OR key = 3` took 2.8 ms per 256 M rows, twice the gathered form.)  Returns the rows that pass.
+template <int N>
+HDK_DEV uint32_t fast_x_program(const FastArgs& a, const int64_t (&va)[N], const int64_t (&e0)[N], const int64_t (&e1)[N],
+                                const int64_t (&key)[N]) {
+  static_assert(N <= 32, "one bit per row");
+  uint32_t lt[kMaxPlainQuals], ln[kMaxPlainQuals];
+#pragma unroll
+  for (int q = 0; q < kMaxPlainQuals; ++q) {
+    lt[q] = 0;
+    ln[q] = 0;
+    if (q < a.nxq) {
+      const FastArgs::XQual xq = a.xq[q];
+      uint32_t t = 0, n = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int64_t l = fast_x_src(xq.lhs_src, va[j], e0[j], e1[j], key[j], 0);
+        const int64_t r = fast_x_src(xq.rhs_src, va[j], e0[j], e1[j], key[j], xq.lit);
+        const bool isnull = (xq.lhs_nullable && l == xq.lhs_null) || (xq.rhs_nullable && r == xq.rhs_null);
+        const bool c = xq.cmp == HDK_CMP_EQ ? l == r
+                     : (xq.cmp == HDK_CMP_NE ? l != r
+                     : (xq.cmp == HDK_CMP_LT ? l < r : (xq.cmp == HDK_CMP_GT ? l > r : (xq.cmp == HDK_CMP_LE ? l <= r : l >= r))));
+        t |= c ? 1u << j : 0u;
+        n |= isnull ? 1u << j : 0u;
+      }
+      lt[q] = t & ~n;
+      ln[q] = n;
+    }
+  }
+  uint32_t at = 0, an = 0, bt = 0, bn = 0, ct = 0, cn = 0;
+  for (int i = 0; i < a.nxprog; ++i) {
+    const uint32_t op = a.xprog[i];
+    if (op < HDK_F_AND) {
+      ct = bt; cn = bn;
+      bt = at; bn = an;
+      at = op == 0 ? lt[0] : (op == 1 ? lt[1] : lt[2]);
+      an = op == 0 ? ln[0] : (op == 1 ? ln[1] : ln[2]);
+    } else if (op == HDK_F_NOT) {
+      at = ~(at | an);
+    } else {
+      uint32_t rt, rn;
+      if (op == HDK_F_AND) {
+        const uint32_t fa = ~(at | an), fb = ~(bt | bn);
+        rt = at & bt;
+        rn = ~(rt | fa | fb);
+      } else {
+        rt = at | bt;
+        rn = ~rt & (an | bn);
+      }
+      at = rt; an = rn;
+      bt = ct; bn = cn;
+    }
+  }
+  return at;
+}
+
+// the X-mode filters of one row: true when every conjunct is TRUE (programs: fast_x_program)
 HDK_DEV bool fast_x_pass(const FastArgs& a, int64_t va, int64_t e0, int64_t e1, int64_t key) {
   bool pass = true;
   const int n = a.nxq;
@@ -324,7 +384,9 @@ HDK_DEV void fast_row(const FastArgs& a, const OpList& ops, int64_t* lds, uint32
 template <int KW, int VW, int U, int FIXED, bool Q = false, int XM = 0>
 __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
   constexpr bool XMODE = XM > 0;
-  constexpr int X = XM > 0 ? XM - 1 : 0;
+  constexpr bool XPROG = XM == 4;  // X mode, no extra column, the filters under an AND / OR / NOT program (its own instantiation:
+                                   // with the program behind a run-time test the other X kernels grew by 10 registers, c2cc + 11 %)
+  constexpr int X = (XM > 0 && XM < 4) ? XM - 1 : 0;
   extern __shared__ __attribute__((aligned(16))) int64_t lds[];
   __shared__ unsigned long long s_masks[2];
   constexpr int WMAX = (KW > VW ? KW : VW) == 0 ? 8 : (KW > VW ? KW : VW);
@@ -408,6 +470,24 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
           }
           plain_quals_pass<U * R>(a.q, a.nquals, cols, rows, pass, true);
         }
+        uint32_t xmask = ~0u;  // (X mode under a filter program: the tile's rows that pass)
+        if constexpr (XPROG) {
+          static_assert(U * R <= 32, "one bit per row");
+          {
+            int64_t va[U * R], ea0[U * R], ea1[U * R], ka[U * R];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+              for (int i = 0; i < R; ++i) {
+                ka[u * R + i] = KW ? extract_elem<(KW ? KW : 8)>(kr[u], i) : 0;
+                va[u * R + i] = VW ? extract_elem<(VW ? VW : 8)>(vr[u], i) : 0;
+                ea0[u * R + i] = X > 0 ? extract_elem<8>(xr0[X > 0 ? u : 0], i) : 0;
+                ea1[u * R + i] = X > 1 ? extract_elem<8>(xr1[X > 1 ? u : 0], i) : 0;
+              }
+            }
+            xmask = fast_x_program<U * R>(a, va, ea0, ea1, ka);
+          }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -417,7 +497,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
             if constexpr (XMODE) {
               const int64_t e0 = X > 0 ? extract_elem<8>(xr0[X > 0 ? u : 0], i) : 0;
               const int64_t e1 = X > 1 ? extract_elem<8>(xr1[X > 1 ? u : 0], i) : 0;
-              if (!fast_x_pass(a, val, e0, e1, key)) {
+              if (XPROG ? !((xmask >> ((u * R + i) & 31)) & 1u) : !fast_x_pass(a, val, e0, e1, key)) {
                 continue;
               }
               val = fast_x_value(a, val, e0, e1, err);
@@ -443,7 +523,14 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
           if constexpr (XMODE) {
             const int64_t e0 = X > 0 ? load_elem<8>(xcol0, r) : 0;
             const int64_t e1 = X > 1 ? load_elem<8>(xcol1, r) : 0;
-            if (!fast_x_pass(a, val, e0, e1, key)) {
+            bool xp;
+            if (XPROG) {
+              const int64_t v1[1] = {val}, e01[1] = {e0}, e11[1] = {e1}, k1[1] = {key};
+              xp = (fast_x_program<1>(a, v1, e01, e11, k1) & 1u) != 0;
+            } else {
+              xp = fast_x_pass(a, val, e0, e1, key);
+            }
+            if (!xp) {
               continue;
             }
             val = fast_x_value(a, val, e0, e1, err);

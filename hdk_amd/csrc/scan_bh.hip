@@ -183,7 +183,7 @@ static bool match_bh_fast(const hdk_hip_plan* p, const hdk_hip_kernel_options* k
   if (launch_forces_generic(ko)) return false;
   if (p->num_joins || p->key_count != 1 || (p->key_width != 4 && p->key_width != 8)) return false;
   memset(fa, 0, sizeof(*fa));
-  if (!match_plain_quals(p, fa->q)) return false;
+  if (!match_plain_quals(p, fa->q, true)) return false;
   fa->nquals = p->num_quals;
   // the key: a plain integer column, or cast(such a column AS double)
   const hdk_hip_expr& ke = p->keys[0];

@@ -31,7 +31,7 @@ static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_op
   if (launch_forces_generic(ko)) return false;
   if (p->num_joins || p->key_count != 1 || (p->key_width != 4 && p->key_width != 8)) return false;
   memset(a, 0, sizeof(*a));
-  if (!match_plain_quals(p, a->q)) return false;
+  if (!match_plain_quals(p, a->q, true)) return false;
   a->nquals = p->num_quals;
   const hdk_hip_expr& ke = p->keys[0];
   if (ke.leaf0.kind != HDK_LEAF_COL) return false;

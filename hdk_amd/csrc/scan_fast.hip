@@ -35,6 +35,7 @@ static int32_t launch_direct_kw(int vw, const FastArgs& fa, const LaunchShape& s
   if (fa.nxq || fa.vform) {  // X mode: KW != 0 and VW == 8 (match_fast)
     if (KW == 0) return HDK_HIP_ERR_UNSUPPORTED;
     constexpr int KX = KW ? KW : 8;
+    if (fa.nxprog) return launch_direct_x<KX, 4>(fa, shape, s);  // (match_scan_fast: a program only without extra columns)
     return fa.nx == 2 ? launch_direct_x<KX, 3>(fa, shape, s) : (fa.nx == 1 ? launch_direct_x<KX, 2>(fa, shape, s) : launch_direct_x<KX, 1>(fa, shape, s));
   }
   if (fa.nquals) {  // filtered: KW != 0 and VW == 8 (match_fast); three op-list forms

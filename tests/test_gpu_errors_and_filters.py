@@ -39,6 +39,7 @@ def test_or_not_filters_match_the_oracle(oracle, gpu_executor_factory):
         [Not(Or(Cmp(A_, "<", Lit(0)), Cmp(B_, ">", Lit(5))))],
         [Or(And(Cmp(A_, ">=", Lit(-5)), Cmp(A_, "<=", Lit(5))), Not(Cmp(D_, "<", Lit(0.25)))), Cmp(B_, "<>", Lit(3))],
     ]
+    seen_kernels = set()
     for quals in filters:
         # perfect hash, open addressing, non-grouped, projection
         queries = [
@@ -52,10 +53,16 @@ def test_or_not_filters_match_the_oracle(oracle, gpu_executor_factory):
             cp, want, err = run_oracle(oracle, st, q)
             assert err == 0 and cp.plan.num_filter_ops > 0
             step = gpu_executor_factory(st).prepare(cp)
-            if cp.plan.query_kind != A.Q_BASELINE_HASH:  # the program runs in the batched interpreter (filter_program_pass_v)
-                assert step.kernel_names().startswith("hdk_scan_agg_vec"), step.kernel_names()
+            if cp.plan.query_kind != A.Q_BASELINE_HASH:
+                # up to three `column cmp literal` leaves: the specialised kernels run the program themselves (plain_quals.h,
+                # round 5); more leaves: the batched interpreter (filter_program_pass_v)
+                names = step.kernel_names()
+                assert names.startswith(("hdk_scan_agg_vec", "hdk_scan_agg_keys", "hdk_scan_agg_direct")), names
+                seen_kernels.add(names.split(",")[0])
             res = step.run()
             step.free()
+            if cp.plan.query_kind != A.Q_BASELINE_HASH:  # and through the batched interpreter whatever the pick was
+                assert_buffers_equal(cp, gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
             if cp.plan.query_kind == A.Q_BASELINE_HASH:
                 _check_rows(cp, res.buffer, want)
             else:
@@ -72,6 +79,61 @@ def test_or_not_filters_match_the_oracle(oracle, gpu_executor_factory):
         step.free()
         assert err == 0 and res.total_matched == nrows
         assert np.array_equal(_sorted_rows(cp, res.buffer, nrows), _sorted_rows(cp, want, nrows))
+
+
+def test_or_filters_on_the_streaming_kernels(oracle, gpu_executor_factory):
+    """`WHERE val < 0 OR key = 3` (c2or of scripts/bench_configs.py) and its relatives on the kernels that took only
+    conjunctions until round 5: the streaming kernel (one key, one argument), the keys kernel, the on-chip open-addressing
+    kernels.  NULLs in every filter column: three-valued OR / AND / NOT (a NULL leaf under OR passes when the other side is
+    TRUE, NOT NULL is NULL)."""
+    from hdk_amd.ir import Cast
+    rng = np.random.default_rng(77)
+    n = 700_000
+    key = rng.integers(0, 64, n, dtype=np.int64)
+    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    val[rng.random(n) < 0.05] = A.NULL_BIGINT
+    c = rng.integers(-50, 50, n).astype(np.int32)
+    c[rng.random(n) < 0.1] = A.NULL_INT
+    f = rng.normal(size=n)
+    f[rng.random(n) < 0.1] = np.frombuffer(np.uint64(A.NULL_DOUBLE_BITS).tobytes(), dtype=np.float64)[0]
+    x = rng.integers(1, 20, n).astype(np.int32)
+    y = rng.integers(1, 11, n).astype(np.int32)
+    y[rng.random(n) < 0.05] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": key, "val": val, "c": c, "f": f, "x": x, "y": y}, fragment_size=n // 3 + 11)
+    K, V, C, F = ColRef("key"), ColRef("val"), ColRef("c"), ColRef("f")
+    programs = [
+        [Or(Cmp(V, "<", Lit(0)), Cmp(K, "=", Lit(3)))],
+        [Not(Or(Cmp(C, "<", Lit(0)), Cmp(F, ">", Lit(0.5))))],
+        [Or(And(Cmp(C, ">=", Lit(-5)), Cmp(C, "<=", Lit(5))), Not(Cmp(F, "<", Lit(0.25))))],
+        [And(Or(Cmp(C, "<", Lit(10)), Cmp(V, ">", Lit(0))), Cmp(K, "<>", Lit(7)))],
+    ]
+    from test_gpu_baseline import _check_rows
+    from hdk_amd.ir import FP64
+    for quals in programs:
+        shapes = [
+            (QueryUnit("t", quals=quals, groupby=[K], targets=[KeyRef(0, "k"), Agg("sum", V, "s")]), "hdk_scan_agg_direct"),
+            (QueryUnit("t", quals=quals, groupby=[K, ColRef("x")], targets=[KeyRef(0, "k"), KeyRef(1, "x"), Agg("count", None, "n")]), "hdk_scan_agg_keys"),
+            (QueryUnit("t", quals=quals, groupby=[Cast(ColRef("x"), FP64)],
+                       targets=[KeyRef(0, "k"), Agg("count", ColRef("y"), "n"), Agg("sum", ColRef("y"), "s"), Agg("min", ColRef("y"), "mn")]),
+             "hdk_scan_agg_bh_"),
+        ]
+        for q, kernel in shapes:
+            cp, want, err = run_oracle(oracle, st, q)
+            assert err == 0 and cp.plan.num_filter_ops > 0
+            step = gpu_executor_factory(st).prepare(cp)
+            assert step.kernel_names().startswith(kernel), (q, step.kernel_names())
+            res = step.run()
+            step.free()
+            if cp.plan.query_kind == A.Q_BASELINE_HASH:
+                _check_rows(cp, res.buffer, want)
+            else:
+                assert_buffers_equal(cp, res.buffer, want)
+            other = gpu_executor_factory(st).execute(cp, flags=A.LAUNCH_FORCE_GENERIC)
+            if cp.plan.query_kind == A.Q_BASELINE_HASH:
+                _check_rows(cp, other.buffer, want)
+            else:
+                assert_buffers_equal(cp, other.buffer, want)
 
 
 def _expect_error(oracle, gpu_executor_factory, st, q, code):
