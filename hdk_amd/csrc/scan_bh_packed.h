@@ -484,7 +484,7 @@ HDK_DEV void bh_packed_flush(const BhPackedArgs& a, const BhExactCtx* cx, uint32
 // One step of a tile: the R rows in a lane's 16-byte registers through the row body.  ALLOK: every row takes part (a full tile
 // of an unfiltered plan over 4-byte columns) -- the hot form computes no row bounds and no per-row flags at all.  Returns the
 // rows for the exact path.
-template <int KW, int VW, int R, bool DENSE, bool ALLOK>
+template <int KW, int VW, int R, bool DENSE, bool ALLOK, bool NOQ = false>
 HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t* rp, const uint32_t* kr, const uint32_t* vr, bool full,
                               int64_t rbase, int64_t row0, int64_t nrows, const int8_t* const* cols, int32_t& err) {
   int32_t key[R], val[R];
@@ -493,7 +493,7 @@ HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t*
   for (int i = 0; i < R; ++i) {
     ok[i] = ALLOK || full || rbase + i < nrows;
   }
-  if (!ALLOK && a.nquals != 0) {
+  if (!ALLOK && !NOQ && a.nquals != 0) {  // (NOQ: a plain kernel -- the plan has no filters: none compiled in)
     int64_t rows[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -529,13 +529,15 @@ HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t*
   return slow;
 }
 
-// PLAIN: an unfiltered plan over 4-byte columns -- every row of a full tile takes part, so the kernel holds ONLY the hot form of
-// the steps (and a row-at-a-time loop for the ragged tail of a fragment).  The general form -- row bounds, filters, 8-byte
+// PLAIN: an unfiltered plan -- every row of a full tile takes part, so the kernel holds ONLY the hot form of the steps (and a
+// row-at-a-time loop for the ragged tail of a fragment); over 4-byte columns that form has no per-row flags at all.  The general form -- row bounds, filters, 8-byte
 // columns whose strangers bypass the table -- needs 178 vector registers with four steps in flight (two waves on a SIMD) and
 // held the hot form to that when both sat in one kernel; on its own the hot form takes 122.
 template <int KW, int VW, int U, int BLOCK, bool DENSE, bool PLAIN>
 HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
-  static_assert(!PLAIN || (KW == 4 && (VW == 4 || VW == 0)), "the plain form reads 4-byte columns");
+  // (8-byte columns in a plain kernel: their strangers -- values outside 32 bits or the statistics -- still go through `ok`,
+  // but there are no row bounds and no filters in the step: HOT32 below is the all-rows-take-part form)
+  constexpr bool HOT32 = KW != 8 && VW != 8;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   __shared__ BhExactCtx s_cx;
   constexpr int WMAX = KW > VW ? KW : VW;
@@ -583,13 +585,14 @@ HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
       const bool full = row0 + kTileRows <= nrows;
       if (PLAIN && !full) {  // the ragged tail of a fragment, a row per lane and trip
         for (int64_t r = row0 + tid; r < nrows; r += BLOCK) {
-          const uint32_t k1[1] = {static_cast<uint32_t>(load_elem<KW>(kcol, r))};
-          const uint32_t v1[1] = {VW ? static_cast<uint32_t>(load_elem<(VW ? VW : 4)>(vcol, r)) : 0u};
-          uint32_t slow1 = bh_tile_step<KW, VW, 1, DENSE, false>(a, hot, rp, k1, v1, true, r, r, nrows, cols, err);
+          const int64_t kj = load_elem<KW>(kcol, r);
+          const int64_t vj = VW ? load_elem<(VW ? VW : 4)>(vcol, r) : 0;
+          const uint32_t k1[2] = {static_cast<uint32_t>(kj), static_cast<uint32_t>(static_cast<uint64_t>(kj) >> 32)};
+          const uint32_t v1[2] = {static_cast<uint32_t>(vj), static_cast<uint32_t>(static_cast<uint64_t>(vj) >> 32)};
+          uint32_t slow1 = bh_tile_step<KW, VW, 1, DENSE, false, true>(a, hot, rp, k1, v1, true, r, r, nrows, cols, err);
           while (__builtin_amdgcn_ballot_w64(slow1 != 0)) {
             if (slow1) {
               slow1 = 0;
-              const int64_t kj = static_cast<int32_t>(k1[0]), vj = static_cast<int32_t>(v1[0]);
               const bool nj = (VW != 0) & (a.val_nullable != 0) & (vj == a.val_null);
               const bool knull = a.key_nullable && kj == a.key_null;
               const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
@@ -638,7 +641,7 @@ HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
         // every row takes part -- no row bounds, no filters, no 8-byte columns (whose strangers `ok` carries)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          slow_all |= bh_tile_step<KW, VW, R, DENSE, true>(a, hot, rp, kr[u], vr[u], true, 0, 0, 0, cols, err) << (u * R);
+          slow_all |= bh_tile_step<KW, VW, R, DENSE, HOT32, true>(a, hot, rp, kr[u], vr[u], true, 0, 0, 0, cols, err) << (u * R);
 #if HDK_BH_STEP_FENCE
           __builtin_amdgcn_sched_barrier(0);  // (steps interleaved by the scheduler: 178 registers, two waves on a SIMD)
 #endif
@@ -707,14 +710,14 @@ template <int KW, int VW, int U>
 __global__ __launch_bounds__(kBhPackedBlock, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES : 1) void hdk_scan_agg_bh_dense(BhPackedArgs a) {
   bh_packed_kernel_body<KW, VW, U, kBhPackedBlock, true, false>(a);
 }
-// the plain forms (unfiltered, 4-byte key and argument columns): the reference's benchmark shapes
-template <int VW, int U, int BLOCK>
+// the plain forms (unfiltered plans: the reference's benchmark shapes)
+template <int KW, int VW, int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed_plain(BhPackedArgs a) {
-  bh_packed_kernel_body<4, VW, U, BLOCK, false, true>(a);
+  bh_packed_kernel_body<KW, VW, U, BLOCK, false, true>(a);
 }
-template <int VW, int U>
+template <int KW, int VW, int U>
 __global__ __launch_bounds__(kBhPackedBlock) void hdk_scan_agg_bh_dense_plain(BhPackedArgs a) {
-  bh_packed_kernel_body<4, VW, U, kBhPackedBlock, true, true>(a);
+  bh_packed_kernel_body<KW, VW, U, kBhPackedBlock, true, true>(a);
 }
 
 // ---- the fold of the scan blocks' slabs -----------------------------------------------------------------------------------

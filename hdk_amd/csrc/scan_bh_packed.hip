@@ -168,19 +168,17 @@ static const void* bh_dense_kernel(int kw, int vw) {
   if (kw == 4) return vw == 0 ? bh_dense_kernel_of<4, 0>() : (vw == 4 ? bh_dense_kernel_of<4, 4>() : bh_dense_kernel_of<4, 8>());
   return vw == 0 ? bh_dense_kernel_of<8, 0>() : (vw == 4 ? bh_dense_kernel_of<8, 4>() : bh_dense_kernel_of<8, 8>());
 }
-// unfiltered plans over 4-byte columns: the kernels that hold only the hot form of the steps
-static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return kw == 4 && (vw == 4 || vw == 0) && a.nquals == 0; }
-static const void* bh_plain_kernel(bool dense, int vw, int block) {
-  if (dense) {
-    return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<4, HDK_BH_PACKED_U>)
-                   : reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<0, HDK_BH_PACKED_U>);
-  }
-  if (block == 512) {
-    return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<4, HDK_BH_PACKED_U, 512>)
-                   : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<0, HDK_BH_PACKED_U, 512>);
-  }
-  return vw == 4 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<4, HDK_BH_PACKED_U, 256>)
-                 : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<0, HDK_BH_PACKED_U, 256>);
+// unfiltered plans: the kernels that hold only the hot form of the steps (every column width)
+static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return a.nquals == 0 && !hdk_sw(SW_NO_BH_PLAIN); }
+template <int KW, int VW>
+static const void* bh_plain_kernel_of(bool dense, int block) {
+  if (dense) return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<KW, VW, HDK_BH_PACKED_U>);
+  return block == 512 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<KW, VW, HDK_BH_PACKED_U, 512>)
+                      : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<KW, VW, HDK_BH_PACKED_U, 256>);
+}
+static const void* bh_plain_kernel(bool dense, int kw, int vw, int block) {
+  if (kw == 4) return vw == 0 ? bh_plain_kernel_of<4, 0>(dense, block) : (vw == 4 ? bh_plain_kernel_of<4, 4>(dense, block) : bh_plain_kernel_of<4, 8>(dense, block));
+  return vw == 0 ? bh_plain_kernel_of<8, 0>(dense, block) : (vw == 4 ? bh_plain_kernel_of<8, 4>(dense, block) : bh_plain_kernel_of<8, 8>(dense, block));
 }
 template <int BLOCK>
 static const void* bh_packed_kernel(int kw, int vw) {
@@ -357,7 +355,7 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   }
   a.plan = d_plan;
   a.kp = kp;
-  const void* k = bh_plain(a, kw, vw) ? bh_plain_kernel(a.dense != 0, vw, block)
+  const void* k = bh_plain(a, kw, vw) ? bh_plain_kernel(a.dense != 0, kw, vw, block)
                                       : (a.dense ? bh_dense_kernel(kw, vw) : (block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw)));
   if (lds > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -22,6 +22,7 @@ namespace hdk {
   X(NO_BH_LDS)                      \
   X(NO_BH_PACKED)                   \
   X(NO_BH_PARTITIONS)               \
+  X(NO_BH_PLAIN)                    \
   X(NO_PERFECT_PARTITIONS)          \
   X(NO_SLICED2)                     \
   X(PART_AOS)                       \

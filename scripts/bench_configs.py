@@ -58,13 +58,13 @@ def main():
     st = ArrowStorage()
     frag = 32_000_000
     print(f"# generating {n} rows ...", file=sys.stderr)
-    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
+    n_t0 = n if (only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "ph64", "bh64", "bh64f", "c3d", "c3k", "p1", "p50", "pj", "c5"}) else 1000
     key = rng.integers(0, 64, n_t0, dtype=np.int64)
     val = rng.integers(-2**31, 2**31, n_t0, dtype=np.int64)
     valn = val.copy()
     valn[rng.random(n_t0) < 0.01] = A.NULL_BIGINT
     nd = args.dim_rows
-    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "c3d", "c3k", "p1", "p50", "pj", "c5"})
+    need_t = bool(only & {"c1", "c2", "c2n", "c2f", "c2x", "c2cc", "c2or", "c2m", "c3", "c3g", "c3gm", "c3f", "c3x", "c3x8", "c3x2", "ph64", "bh64", "bh64f", "c3d", "c3k", "p1", "p50", "pj", "c5"})
     need_trips = bool(only & {"q1", "q2", "q3", "q4", "q3v", "q3m", "q4v"})
     if not need_t:
         n_t = 1000
@@ -75,6 +75,8 @@ def main():
         tcols.update({"fk10": fk // 10, "k1": key * 15, "k2": fk // 10000})
     if only & {"c3x"}:
         tcols["g32"] = key.astype(np.int32)  # a fact-side group key as an INT column
+    if only & {"ph64", "bh64", "bh64f"}:
+        tcols["y64"] = rng.integers(1, 11, len(key), dtype=np.int64)  # the BaselineHash benchmark's measure as a BIGINT column
     st.import_numpy("t", tcols, fragment_size=frag)
     st.import_numpy("dim", {"key": rng.permutation(nd).astype(np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64),
                             "attr": rng.integers(0, 64, nd).astype(np.int64)}, fragment_size=frag)
@@ -142,6 +144,12 @@ def main():
                            groupby=[ColRef("key")], targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 24),
         "c3x2": (QueryUnit("t", joins=[JoinSpec("dim", ColRef("fk"), "key")], quals=[Cmp(ColRef("dval", "dim"), "<", Lit(500_000))],
                            targets=[Agg("sum", ColRef("val")), Agg("sum", ColRef("key")), Agg("count")]), 24),
+        # the benchmark's five aggregates over BIGINT columns (the general step form of the on-chip kernels): perfect hash on the
+        # key, open addressing behind a cast, and the latter with a filter
+        "ph64": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0)] + [Agg(k, ColRef("y64")) for k in ("count", "sum", "max", "min", "avg")]), 16),
+        "bh64": (QueryUnit("t", groupby=[Cast(ColRef("key"), FP64)], targets=[KeyRef(0)] + [Agg(k, ColRef("y64")) for k in ("count", "sum", "max", "min", "avg")]), 16),
+        "bh64f": (QueryUnit("t", groupby=[Cast(ColRef("key"), FP64)], quals=[Cmp(ColRef("y64"), "<=", Lit(7))],
+                            targets=[KeyRef(0)] + [Agg(k, ColRef("y64")) for k in ("count", "sum", "max", "min", "avg")]), 16),
         "q1": (QueryUnit("trips", groupby=[ColRef("cab_type")], targets=[KeyRef(0), Agg("count")]), 4),
         "q2": (QueryUnit("trips", groupby=[ColRef("passenger_count")],
                          targets=[KeyRef(0), Agg("avg", ColRef("total_amount"))]), 10),
