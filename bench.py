@@ -471,7 +471,7 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
 # (profiles/r05_bench_default_kernel_stats.csv): the scatter pass of every radix strategy (C3 5.4 of 6.8 ms, C5 level 1 5.4 of
 # 12.3 ms, the 256-bin pass 4.7 of 6.7 ms); single-pass launches name their scan kernel.  `roofline.frac` is computed from the
 # HIP-event time of ALL passes either way.
-_DOMINANT = ("hdk_join_scatter_slices", "hdk_part_scatter", "hdk_bh_scatter", "hdk_pp_scatter")
+_DOMINANT = ("hdk_join_scatter_slices", "hdk_part_scatter", "hdk_bh_dscatter", "hdk_bh_scatter", "hdk_pp_scatter")
 
 
 def dominant_kernel(names):

@@ -158,11 +158,14 @@ static const void* bh_packed_kernel_of() {
 #ifndef HDK_BH_PACKED_U
 #define HDK_BH_PACKED_U 4  // 16-byte steps per lane and tile (A/B builds at 256 M rows: 2 -> bh3 0.86 ms, 4 -> 0.79, 8 -> 0.87)
 #endif
-  return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, HDK_BH_PACKED_U, BLOCK>);
+#ifndef HDK_BH_GENERAL_U
+#define HDK_BH_GENERAL_U 2  // the general (filtered) kernels: two steps per tile (measured at 256 M rows, filtered BH001 on 4- / 8-byte columns: four steps 1.31 / 1.55 ms, two 1.15 / 1.34, one 1.11 / 1.36)
+#endif
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_packed<KW, VW, HDK_BH_GENERAL_U, BLOCK>);
 }
 template <int KW, int VW>
 static const void* bh_dense_kernel_of() {
-  return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense<KW, VW, HDK_BH_PACKED_U>);
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense<KW, VW, HDK_BH_GENERAL_U>);
 }
 static const void* bh_dense_kernel(int kw, int vw) {
   if (kw == 4) return vw == 0 ? bh_dense_kernel_of<4, 0>() : (vw == 4 ? bh_dense_kernel_of<4, 4>() : bh_dense_kernel_of<4, 8>());
