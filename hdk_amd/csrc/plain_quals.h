@@ -151,11 +151,14 @@ HDK_DEV void plain_quals_program(const ProjFastQual* quals, int nquals, const in
   }
 }
 
-// pass[r] &= every conjunct is TRUE for row[r]
-template <int VR>
+// pass[r] &= every conjunct is TRUE for row[r].  PROG: the kernel's matcher accepts AND / OR / NOT programs
+// (match_plain_quals(..., allow_program = true)) -- only those kernels carry the program's code: compiled into the radix
+// scatters too it cost them registers and a resident block (C5 12.5 -> 15.1 ms per 1 B rows, the perfect-hash partitions 4.1 ->
+// 4.9 ms per 256 M) although no plan of theirs has one
+template <int VR, bool PROG = false>
 HDK_DEV void plain_quals_pass(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
                               bool (&pass)[VR], bool nt) {
-  if (nquals > 0 && quals[0].nprog != 0) {  // (wave-uniform)
+  if (PROG && nquals > 0 && quals[0].nprog != 0) {  // (wave-uniform)
     plain_quals_program<VR>(quals, nquals, cols, row, pass, nt);
     return;
   }

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
               rows[u * R + i] = row0 + (static_cast<int64_t>(u) * kFastBlock + tid) * R + i;
             }
           }
-          plain_quals_pass<U * R>(a.q, a.nquals, cols, rows, pass, true);
+          plain_quals_pass<U * R, true>(a.q, a.nquals, cols, rows, pass, true);
         }
         uint32_t xmask = ~0u;  // (X mode under a filter program: the tile's rows that pass)
         if constexpr (XPROG) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kFastBlock) void hdk_scan_agg_direct(FastArgs a) {
           if (Q) {
             const int64_t rows1[1] = {r};
             bool pass1[1] = {true};
-            plain_quals_pass<1>(a.q, a.nquals, cols, rows1, pass1, true);
+            plain_quals_pass<1, true>(a.q, a.nquals, cols, rows1, pass1, true);
             if (!pass1[0]) {
               continue;
             }

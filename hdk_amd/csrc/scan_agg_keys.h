@@ -126,7 +126,7 @@ HDK_DEV void keys_row(const KeysArgs& a, int64_t* lds, const int8_t* const* cols
   if (a.nquals) {
     const int64_t rows1[1] = {rr};
     bool pass1[1] = {true};
-    plain_quals_pass<1>(a.q, a.nquals, cols, rows1, pass1, true);
+    plain_quals_pass<1, true>(a.q, a.nquals, cols, rows1, pass1, true);
     if (!pass1[0]) {
       return;
     }
@@ -203,7 +203,7 @@ HDK_DEV uint32_t keys_tile(const KeysArgs& a, int64_t* lds, const int8_t* const*
       row[r] = row0 + static_cast<int64_t>((r / R) * BS + tid) * R + (r % R);
       pass[r] = true;
     }
-    plain_quals_pass<VR>(a.q, a.nquals, cols, row, pass, true);
+    plain_quals_pass<VR, true>(a.q, a.nquals, cols, row, pass, true);
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       entry[r] = pass[r] ? 0u : kKeysFiltered;

@@ -33,12 +33,11 @@ constexpr int kBhDpAggThreads = 1024;
 #endif
 
 struct BhDensePartArgs {
-  BhPackedArgs p;          // columns, statistics, word kinds, the LDS geometry of pass B (cap_log2 = w, one replica)
+  BhPackedArgs p;          // columns, statistics, word kinds, the LDS geometry of pass B (cap_log2 = w; replicas while the table is small)
   uint32_t w;              // bits of a tuple's offset inside its bin (2^w >= width)
   uint32_t width;          // entries of a bin
   uint32_t wmagic, wshift; // entry / width
   uint32_t nbins;          // bins in use (<= 256)
-  uint32_t val_codes;      // codes of the argument: 1 .. val_codes - 1
   uint32_t n_entries;      // dense_n (+ 1: the NULL key's entry)
   uint64_t cap4;           // tuples of a (bin, XCD) sub-slab (multiple of 4)
   uint32_t* tuples4;       // [nbins][kPbXcds][cap4]
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(kPbBlock, HDK_BH_DP_WAVES) void hdk_bh_dscatter(BhD
           for (int i = 0; i < R; ++i) {
             rows[i] = ok[i] ? rbase + i : row0;
           }
-          plain_quals_pass<R>(a.q, a.nquals, cols, rows, ok, true);
+          plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) {

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_direct(BhFastArgs a) {
               rows[u * R + i] = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R + i;
             }
           }
-          plain_quals_pass<U * R>(a.q, a.nquals, cols, rows, pass, true);
+          plain_quals_pass<U * R, true>(a.q, a.nquals, cols, rows, pass, true);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_direct(BhFastArgs a) {
           if (filtered) {
             const int64_t rows1[1] = {r};
             bool pass1[1] = {true};
-            plain_quals_pass<1>(a.q, a.nquals, cols, rows1, pass1, true);
+            plain_quals_pass<1, true>(a.q, a.nquals, cols, rows1, pass1, true);
             if (!pass1[0]) {
               continue;
             }

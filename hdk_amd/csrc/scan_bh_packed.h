@@ -13,6 +13,12 @@
 //   * keys are 32-bit tags (the key column's value, before any cast), four to a 16-byte bucket: one ds_read_b128 finds
 //     the entry of all but a few per cent of the rows (linear probing over buckets for the rest);
 // three LDS operations a row, two of them plain reads that broadcast when lanes share a group.
+// Second half of the round: DENSE tables -- when the key column's statistics span no more values than the
+// table has room for, a row's entry is key - min and there are no tags at all (bh_dense_rows; the tags are written once, when a
+// block hands its table on); PLAIN kernels -- an unfiltered plan's kernel holds only the hot form of a tile's steps (the
+// general form, the exact-path call and the filter code each cost the hot form registers and waves when they shared its
+// kernel); a THREE-LEVEL fold of the blocks' tables (hdk_bh_fold_slabs: slabs -> lists -> output table, every group folded
+// into the output once).
 // Shape: one group key = an integer column whose values fit 32 bits, as it is or cast to double; every aggregate over ONE
 // integer column inside 32 bits with statistics (or COUNT(*) alone); filters `column cmp literal`.
 //
@@ -499,7 +505,7 @@ HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t*
     for (int i = 0; i < R; ++i) {
       rows[i] = ok[i] ? rbase + i : row0;
     }
-    plain_quals_pass<R>(a.q, a.nquals, cols, rows, ok, true);
+    plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
   }
   uint32_t slow = 0;
 #pragma unroll
@@ -878,7 +884,9 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
 
 // ---- tables beyond LDS: pass A, rows -> filters -> tuples [argument : key] -> 256 bins by the key's hash ------------------
 // (the argument's NULL travels as INT32_MIN: no value inside the statistics the packed sum accepts is that small)
-template <int VR>
+// (PROG: the plan's filters are an AND / OR / NOT program -- its own instantiation: the program's code costs the pass a resident
+// block, 1.23 -> 1.8 ms per 256 M rows, whether a plan has one or not)
+template <int VR, bool PROG = false>
 __global__ __launch_bounds__(kPbBlock) void hdk_bh_scatter(BhPackedArgs a) {
   constexpr int kTile = kPbBlock * VR;
   __shared__ uint32_t s_cnt[kPbMaxBins];
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bh_scatter(BhPackedArgs a) {
         row[r] = live[r] ? row[r] : 0;
       }
       if (a.nquals) {
-        plain_quals_pass<VR>(a.q, a.nquals, cols, row, live, true);
+        plain_quals_pass<VR, PROG>(a.q, a.nquals, cols, row, live, true);
       }
       int64_t k64[VR], v64[VR];
       if (a.key_width == 8) {

@@ -250,7 +250,6 @@ static bool match_bh_dense_part(const hdk_hip_plan* p, const hdk_hip_kernel_opti
   if (a.has_val) {
     const uint64_t codes = static_cast<uint64_t>(static_cast<int64_t>(a.val_max) - a.val_min) + 2;
     vbits = pow2_ceil_log2(codes);
-    g->val_codes = static_cast<uint32_t>(codes);
   }
   if (g->w + vbits > 32) return false;
   // pass B's LDS: the bin's table, replicated while that stays below 48 KB
@@ -330,8 +329,12 @@ static int32_t launch_bh_partitioned(const hdk_hip_plan* d_plan, const KernParam
   a.fill = reinterpret_cast<uint32_t*>(base);
   a.tuples = reinterpret_cast<int64_t*>(base + l.cursor_bytes);
   const size_t lds_sc = PbStage<1, kBhScatterVR>::lds_bytes();
-  const unsigned g1 = scatter_grid(reinterpret_cast<const void*>(hdk_bh_scatter<kBhScatterVR>), kPbBlock, lds_sc, props, 2);
-  hipLaunchKernelGGL((hdk_bh_scatter<kBhScatterVR>), dim3(g1), dim3(kPbBlock), lds_sc, s, a);
+  const bool prog = a.nquals > 0 && a.q[0].nprog != 0;
+  const void* sk = prog ? reinterpret_cast<const void*>(hdk_bh_scatter<kBhScatterVR, true>)
+                        : reinterpret_cast<const void*>(hdk_bh_scatter<kBhScatterVR, false>);
+  const unsigned g1 = scatter_grid(sk, kPbBlock, lds_sc, props, 2);
+  void* sargs[] = {&a};
+  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), sargs, lds_sc, s));
   const void* ak = reinterpret_cast<const void*>(hdk_bh_aggregate);
   if (l.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l.lds_bytes)));

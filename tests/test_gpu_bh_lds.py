@@ -280,6 +280,27 @@ def test_mid_sized_tables_by_hash_bins(oracle, gpu_executor_factory, groups, hot
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("bins", ["range", "hash"])
+def test_mid_sized_table_under_an_or_filter(oracle, gpu_executor_factory, bins, monkeypatch):
+    """`WHERE y10 <= 3 OR w < 0` in front of the two-pass forms: the scatter passes run the AND / OR / NOT program themselves
+    (plain_quals.h; the hash-bin scatter in its own instantiation).  NULLs in y10: a NULL leaf under OR passes when the other
+    side is TRUE."""
+    st = _mid_table(4_300_000, 20_000, 24)
+    ex = gpu_executor_factory(st)
+    q = _bh_query("x", quals=[Or(Cmp(ColRef("y10"), "<=", Lit(3)), Cmp(ColRef("w"), "<", Lit(0)))])
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cp.plan.num_filter_ops > 0
+    kernels = _two_pass_kernels(bins, monkeypatch)
+    step = ex.prepare(cp)
+    assert step.kernel_names() == kernels, step.kernel_names()
+    res = step.run()
+    step.free()
+    _check_rows(cp, res.buffer, want)
+    _assert_reference_placement(oracle, cp, res.buffer)
+    _check_rows(cp, ex.execute(cp, flags=A.LAUNCH_FORCE_GENERIC).buffer, want)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("bins", ["range", "hash"])
 def test_mid_sized_table_int64_columns_filters_and_stale_statistics(oracle, gpu_executor_factory, bins, monkeypatch):
     """8-byte key and argument columns that fit 32 bits by their statistics, a filter, and -- second run -- statistics that
     do NOT hold (narrowed by hand in the launch's plan copy): the rows outside them take the exact path, same result."""
