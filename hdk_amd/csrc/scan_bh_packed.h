@@ -481,9 +481,6 @@ HDK_DEV void bh_packed_flush(const BhPackedArgs& a, const BhExactCtx* cx, uint32
 
 // ---- the one-pass kernel: the table fits LDS -------------------------------------------------------------------------
 // KW / VW: byte width of the key / argument column (VW 0: COUNT(*) only); U steps of 16 bytes per lane and tile
-#ifndef HDK_BH_STEP_FENCE
-#define HDK_BH_STEP_FENCE 1
-#endif
 #ifndef HDK_BH_PACKED_WAVES
 #define HDK_BH_PACKED_WAVES 0  // > 0: hold the kernel to that many waves per SIMD (A/B builds: make variant DEFS=-DHDK_BH_PACKED_WAVES=4)
 #endif
@@ -648,9 +645,6 @@ HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           slow_all |= bh_tile_step<KW, VW, R, DENSE, HOT32, true>(a, hot, rp, kr[u], vr[u], true, 0, 0, 0, cols, err) << (u * R);
-#if HDK_BH_STEP_FENCE
-          __builtin_amdgcn_sched_barrier(0);  // (steps interleaved by the scheduler: 178 registers, two waves on a SIMD)
-#endif
         }
       } else {
 #pragma unroll
