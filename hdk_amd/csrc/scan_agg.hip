@@ -2048,7 +2048,7 @@ static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs
   if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_PERFECT_HASH || p->num_joins) return false;
   if (p->key_count < 1 || p->key_count > kKeysMax) return false;
   if (shape.rep == 0 || (shape.rep & (shape.rep - 1))) return false;
-  if (!match_plain_quals(p, ka->q, true)) return false;
+  if (!match_plain_quals(p, ka->q)) return false;  // (no filter programs here: scan_agg_keys.h, HDK_KEYS_PROG)
   ka->wpe = shape.wpe;
   ka->nvals = 0;
   ka->nops = 0;

@@ -19,6 +19,13 @@
 #include "plain_quals.h"
 #include "scan_agg_fast.h"  // FastOpKind, fast_lds_op: the per-row LDS update list of the value form
 
+// AND / OR / NOT filter programs (plain_quals.h) are NOT compiled into this kernel: measured in one call at 256 M rows, their
+// code costs the unfiltered taxi queries 3-4 % (Q3 0.445 -> 0.431 ms, Q4 0.79 -> 0.77, Q3 + AVG 0.83 -> 0.80 without it);
+// such plans stay with the batched interpreter (A/B: -DHDK_KEYS_PROG=true and allow_program in match_keys)
+#ifndef HDK_KEYS_PROG
+#define HDK_KEYS_PROG false
+#endif
+
 namespace hdk {
 
 constexpr int kKeysBlock = 256;
@@ -126,7 +133,7 @@ HDK_DEV void keys_row(const KeysArgs& a, int64_t* lds, const int8_t* const* cols
   if (a.nquals) {
     const int64_t rows1[1] = {rr};
     bool pass1[1] = {true};
-    plain_quals_pass<1, true>(a.q, a.nquals, cols, rows1, pass1, true);
+    plain_quals_pass<1, HDK_KEYS_PROG>(a.q, a.nquals, cols, rows1, pass1, true);
     if (!pass1[0]) {
       return;
     }
@@ -203,7 +210,7 @@ HDK_DEV uint32_t keys_tile(const KeysArgs& a, int64_t* lds, const int8_t* const*
       row[r] = row0 + static_cast<int64_t>((r / R) * BS + tid) * R + (r % R);
       pass[r] = true;
     }
-    plain_quals_pass<VR, true>(a.q, a.nquals, cols, row, pass, true);
+    plain_quals_pass<VR, HDK_KEYS_PROG>(a.q, a.nquals, cols, row, pass, true);
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       entry[r] = pass[r] ? 0u : kKeysFiltered;
