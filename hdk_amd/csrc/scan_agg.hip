@@ -2233,7 +2233,22 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
   HDK_REQUIRE(out && out_len, "out is NULL");
   const int32_t st = validate_plan(plan);
   if (st) return st;
-  const hdk_hip_device_properties* props = device_props(device_id);
+  // (HDK_HIP_DEVICE_ASSUMED_MI355X: the answer for an MI355X without touching a device -- kernel routing is host arithmetic
+  // over the plan, the options and these few numbers, and the CPU test-suite pins it: tests/test_kernel_routing_cpu.py)
+  static const hdk_hip_device_properties assumed = [] {
+    hdk_hip_device_properties p;
+    memset(&p, 0, sizeof(p));
+    p.global_mem = 288ull << 30;
+    p.num_cu = 256;
+    p.max_threads_per_block = 1024;
+    p.wavefront_size = 64;
+    p.grid_size = 4 * 256;
+    p.shared_mem_per_block = 64 << 10;
+    p.has_shared_memory_atomics = p.can_load_async = p.has_fp64 = 1;
+    strncpy(p.arch_name, "gfx950 (assumed)", sizeof(p.arch_name) - 1);
+    return p;
+  }();
+  const hdk_hip_device_properties* props = device_id == HDK_HIP_DEVICE_ASSUMED_MI355X ? &assumed : device_props(device_id);
   if (!props) return HDK_HIP_ERR_RUNTIME;
   const LaunchShape s = choose_shape(plan, ko, props);
   {

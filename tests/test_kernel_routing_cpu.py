@@ -1,0 +1,107 @@
+"""Which kernels a plan takes -- pinned on a CPU-only box.
+
+Kernel routing (the `match_*` functions of hdk_amd/csrc) is host arithmetic over the plan, the kernel options and a few
+device numbers; `hdk_hip_describe_launch` answers it for an assumed MI355X (`HDK_HIP_DEVICE_ASSUMED_MI355X`) without touching a
+device.  The GPU suite asserts the same names on the device (and `test_gpu_abi_negative.py` that the assumed numbers are the
+device's); here the driver's per-round CPU run sees a routing regression -- a benchmark shape falling back to an
+interpreter or to global atomics -- without waiting for a GPU.  Tables are small (the statistics and NDV bounds are what
+routing reads); `total_rows` is passed as the BASELINE size.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd._lib import lib, sync_switches
+from hdk_amd.ir import Agg, Cast, Cmp, ColRef, FP64, KeyRef, Lit, Or, QueryUnit
+from hdk_amd.plan import compile_query
+from hdk_amd.storage import ArrowStorage
+
+ASSUMED_MI355X = -355  # include/hdk_hip.h: HDK_HIP_DEVICE_ASSUMED_MI355X
+BIG = 1_000_000_000
+
+
+def _names(cp, total_rows=BIG, flags=0):
+    sync_switches()
+    ko = A.KernelOptions(0, 0, 0, flags, total_rows, 0, 0)
+    out = C.create_string_buffer(256)
+    st = lib().hdk_hip_describe_launch(C.byref(cp.plan), C.byref(ko), ASSUMED_MI355X, out, 256)
+    assert st == 0, lib().hdk_hip_last_error()
+    return out.value.decode()
+
+
+@pytest.fixture(scope="module")
+def storage():
+    rng = np.random.default_rng(3)
+    n = 300_000
+    st = ArrowStorage()
+    y = rng.integers(1, 11, n).astype(np.int32)
+    y[rng.random(n) < 0.02] = A.NULL_INT
+    st.import_numpy("syn", {"x10": rng.integers(1, 11, n).astype(np.int32), "x1k": rng.integers(1, 1001, n).astype(np.int32),
+                            "x100k": rng.integers(1, 100_001, n).astype(np.int32), "y10": y,
+                            "sparse": (rng.integers(0, 90_000, n) * 7919).astype(np.int32), "d": rng.normal(size=n)},
+                    fragment_size=n // 3 + 1)
+    st.import_numpy("t", {"key": rng.integers(0, 64, n, dtype=np.int64), "val": rng.integers(-2**31, 2**31, n, dtype=np.int64),
+                          "c": rng.integers(-50, 50, n).astype(np.int32), "k2": rng.integers(0, 7, n).astype(np.int16),
+                          "wide": rng.integers(0, 2**40, n, dtype=np.int64)}, fragment_size=n // 3 + 1)
+    return st
+
+
+def _bh(xcol, **kw):
+    y = ColRef("y10")
+    return QueryUnit("syn", groupby=[Cast(ColRef(xcol), FP64)],
+                     targets=[KeyRef(0, "k")] + [Agg(k, y) for k in ("count", "sum", "max", "min", "avg")], **kw)
+
+
+def test_headline_and_its_neighbours(storage):
+    K, V, C_ = ColRef("key"), ColRef("val"), ColRef("c")
+    c2 = QueryUnit("t", groupby=[K], targets=[KeyRef(0), Agg("sum", V)])
+    assert _names(compile_query(storage, c2)) == "hdk_scan_agg_direct,hdk_finalize"
+    c1 = QueryUnit("t", targets=[Agg("sum", V)])
+    assert _names(compile_query(storage, c1)) == "hdk_scan_agg_direct,hdk_finalize"
+    for quals in ([Cmp(C_, "<", Lit(0))], [Or(Cmp(V, "<", Lit(0)), Cmp(K, "=", Lit(3)))], [Or(Cmp(C_, "<", Lit(0)), Cmp(V, ">", Lit(5)))]):
+        q = QueryUnit("t", quals=quals, groupby=[K], targets=[KeyRef(0), Agg("sum", V)])
+        assert _names(compile_query(storage, q)) == "hdk_scan_agg_direct,hdk_finalize", quals
+    two_keys = QueryUnit("t", groupby=[K, ColRef("k2")], targets=[KeyRef(0), KeyRef(1), Agg("count", None)])
+    assert _names(compile_query(storage, two_keys)) == "hdk_scan_agg_keys,hdk_finalize"
+    # (the keys kernel carries no filter-program code: the interpreter)
+    two_keys_or = QueryUnit("t", quals=[Or(Cmp(C_, "<", Lit(0)), Cmp(V, ">", Lit(5)))], groupby=[K, ColRef("k2")],
+                            targets=[KeyRef(0), KeyRef(1), Agg("count", None)])
+    assert _names(compile_query(storage, two_keys_or)).startswith("hdk_scan_agg_vec")
+
+
+def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
+    """BH001 / BH003 / BH005 (bench.py lines) and what their switches select."""
+    one_pass = "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs"
+    assert _names(compile_query(storage, _bh("x10"))) == one_pass
+    assert _names(compile_query(storage, _bh("x1k"))) == one_pass
+    assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"
+    # filtered: the general kernels; an fp argument: the word form; an expression key: the interpreter with an LDS table
+    assert _names(compile_query(storage, _bh("x10", quals=[Cmp(ColRef("y10"), "<=", Lit(7))]))) == "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs"
+    fp_arg = QueryUnit("syn", groupby=[Cast(ColRef("x10"), FP64)], targets=[KeyRef(0), Agg("sum", ColRef("d"))])
+    assert _names(compile_query(storage, fp_arg)).startswith("hdk_scan_agg_bh_direct")
+    expr_key = QueryUnit("syn", groupby=[ColRef("x1k") % 37], targets=[KeyRef(0), Agg("sum", ColRef("y10"))])
+    assert _names(compile_query(storage, expr_key)).startswith("hdk_scan_agg_bh_vec")
+    # sparse keys: tags on chip, hash bins beyond
+    sparse = QueryUnit("syn", groupby=[ColRef("sparse")], force_baseline=True, baseline_entry_count=180_001,
+                       targets=[KeyRef(0), Agg("sum", ColRef("y10")), Agg("count", None)])
+    assert _names(compile_query(storage, sparse)) == "hdk_bh_scatter,hdk_bh_aggregate"
+    # the reference's own scheme when asked for
+    assert _names(compile_query(storage, _bh("x10")), flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).startswith("hdk_scan_agg_global")
+    monkeypatch.setenv("HDK_HIP_NO_BH_DENSE", "1")
+    assert _names(compile_query(storage, _bh("x10"))) == "hdk_scan_agg_bh_packed_plain,hdk_bh_fold_slabs"
+    monkeypatch.setenv("HDK_HIP_NO_BH_DENSE_PARTITIONS", "1")
+    assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_scatter,hdk_bh_aggregate"
+    monkeypatch.setenv("HDK_HIP_NO_BH_LDS", "1")
+    assert _names(compile_query(storage, _bh("x10"))).startswith("hdk_scan_agg_global")
+
+
+def test_huge_open_addressing_table_takes_the_radix_passes(storage):
+    """C5's shape: 8-byte key, a table of 200 M entries, 1 B rows."""
+    q = QueryUnit("t", groupby=[ColRef("wide")], force_baseline=True, baseline_entry_count=200_000_000,
+                  targets=[KeyRef(0), Agg("sum", ColRef("val"))])
+    names = _names(compile_query(storage, q))
+    assert names.startswith("hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate"), names
+    # a small input of the same plan: the direct global-atomics kernel
+    assert _names(compile_query(storage, q), total_rows=100_000).startswith("hdk_scan_agg_baseline_direct")
