@@ -2243,7 +2243,7 @@ extern "C" int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_h
     p.max_threads_per_block = 1024;
     p.wavefront_size = 64;
     p.grid_size = 4 * 256;
-    p.shared_mem_per_block = 64 << 10;
+    p.shared_mem_per_block = 160 << 10;  // (what hipDeviceProp_t::sharedMemPerBlock reports on the MI355X)
     p.has_shared_memory_atomics = p.can_load_async = p.has_fp64 = 1;
     strncpy(p.arch_name, "gfx950 (assumed)", sizeof(p.arch_name) - 1);
     return p;

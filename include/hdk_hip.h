@@ -518,7 +518,7 @@ int32_t hdk_hip_graph_destroy(void* graph_exec);
  * receives how many there were. */
 int32_t hdk_hip_collect_scan_times(int32_t device_id, float* ms_out, int32_t capacity, int32_t* count);
 /* Names of the device kernels a launch of `plan` dispatches (for profiling), comma separated.
- * device_id HDK_HIP_DEVICE_ASSUMED_MI355X: answered for an MI355X (256 CUs, 64 KB of static LDS per block) without touching
+ * device_id HDK_HIP_DEVICE_ASSUMED_MI355X: answered for an MI355X (256 CUs, 160 KB of LDS per block) without touching
  * a device -- routing is host arithmetic, and a CPU-only test-suite can pin it. */
 #define HDK_HIP_DEVICE_ASSUMED_MI355X (-355)
 int32_t hdk_hip_describe_launch(const hdk_hip_plan* plan, const hdk_hip_kernel_options* ko,

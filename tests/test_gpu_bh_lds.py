@@ -225,8 +225,10 @@ def test_small_open_addressing_tables_random_shapes(oracle, gpu_executor_factory
         try:
             if entries <= 300:  # (<= 512 LDS entries of at most 14 words: always within the 64 KiB the kernels take)
                 assert names.startswith(BH_KERNELS), names
-            # (a float SUM is added row by row in float by the reference: its rounding noise grows like sqrt(rows of a group))
-            _check_rows(cp, res.buffer, want, float32_atol=2e-3 * max(1.0, (n / 40_000) ** 0.5))
+            # (a float SUM is added row by row in float by the reference: with zero-mean values the partial sums wander like
+            # sqrt(k) and every addition rounds at their magnitude, so the noise of a group's sum grows LINEARLY with its rows --
+            # eps32 x rows / 2.8: 0.016 for the 750 K rows of seed 3154's hot key, where 0.028 was seen)
+            _check_rows(cp, res.buffer, want, float32_atol=2e-3 * max(1.0, n / 40_000))
             if res.row_count() < cp.entry_count and not columnar:
                 _assert_reference_placement(oracle, cp, res.buffer)
         except AssertionError as e:

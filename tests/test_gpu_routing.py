@@ -28,7 +28,7 @@ def test_assumed_device_is_this_device(storage, gpu_executor_factory):
     ex = gpu_executor_factory(storage)
     props = ex.mgr.getDeviceProperties(0)
     assert (props.num_cu, props.wavefront_size, props.max_threads_per_block, props.grid_size) == (256, 64, 1024, 1024)
-    assert props.shared_mem_per_block == 64 << 10
+    assert props.shared_mem_per_block == 160 << 10
     K, V, C_ = ColRef("key"), ColRef("val"), ColRef("c")
     queries = [
         QueryUnit("t", groupby=[K], targets=[KeyRef(0), Agg("sum", V)]),
