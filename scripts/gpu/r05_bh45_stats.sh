@@ -1,6 +1,6 @@
 # per-kernel times of the two-pass group-by (bh4 / bh5, 256 M rows): range bins with 4-byte tuples vs hash bins with 8-byte tuples
 mkdir -p gpurun_out/r05; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for form in range; do
+for form in range hash; do
   [ $form = hash ] && export HDK_HIP_NO_BH_DENSE_PARTITIONS=1
   for c in bh4 bh5; do
     rm -rf gpurun_out/r05/bh_stats
