@@ -105,3 +105,59 @@ def test_huge_open_addressing_table_takes_the_radix_passes(storage):
     assert names.startswith("hdk_part_scatter,hdk_part_scatter,hdk_part_aggregate"), names
     # a small input of the same plan: the direct global-atomics kernel
     assert _names(compile_query(storage, q), total_rows=100_000).startswith("hdk_scan_agg_baseline_direct")
+
+
+def _fused(cp):
+    """The plan as the executor launches it when a one-to-one join table is used in its fused [row id | payloads] form
+    (hdk_amd/executor.py: _fuse_join_tables -- the plan-side half of it; no table is built here)."""
+    plan = A.Plan.from_buffer_copy(cp.plan)
+    cols = [ci for ci, (_t, _c, slot) in enumerate(cp.input_cols) if slot == 1]
+    for k, ci in enumerate(cols):
+        plan.cols[ci].kind = A.COL_DOUBLE if plan.cols[ci].kind in (A.COL_FLOAT, A.COL_DOUBLE) else A.COL_INT
+        plan.cols[ci].width = 8
+        plan.cols[ci].table = -1
+        plan.cols[ci].buf_idx = 1 + k
+    plan.joins[0].kind = A.JOIN_ONE_TO_ONE_FUSED
+    plan.joins[0].fused_stride = 1 + len(cols)
+
+    class _Cp:
+        pass
+    out = _Cp()
+    out.plan = plan
+    return out
+
+
+def test_star_schema_shapes_take_the_sliced_join():
+    """C3 and the shapes around it (bench.py's c3 / c3g / c3gm / c3m; bench_configs' c3f / c3x) against a 10 M-key dimension:
+    key-range slices in LDS, ONE scatter level -- also for two dimension columns (packed into one LDS word) and for a group key
+    from the fact table (in the tuple's spare bits)."""
+    from hdk_amd.ir import JoinSpec
+    rng = np.random.default_rng(4)
+    nd, n = 10_000_000, 200_000
+    st = ArrowStorage()
+    st.import_numpy("dim", {"key": np.arange(nd, dtype=np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64),
+                            "attr": rng.integers(0, 64, nd).astype(np.int64)})
+    st.import_numpy("fact", {"fk": rng.integers(0, nd, n, dtype=np.int64), "val": rng.integers(-2**31, 2**31, n, dtype=np.int64),
+                             "g": rng.integers(0, 64, n, dtype=np.int64), "g32": rng.integers(0, 64, n).astype(np.int32)},
+                    fragment_size=n // 2 + 1)
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    V, D, At = ColRef("val"), ColRef("dval", "dim"), ColRef("attr", "dim")
+    one_level = "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_vec_join,hdk_finalize"
+    shapes = {
+        "c3": (QueryUnit("fact", joins=j, targets=[Agg("sum", V + D)]),
+               "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced,hdk_join_agg_direct,hdk_finalize"),
+        "c3g": (QueryUnit("fact", joins=j, groupby=[D / 15625], targets=[KeyRef(0), Agg("sum", V)]), one_level),
+        "c3m": (QueryUnit("fact", joins=j, targets=[Agg("sum", V), Agg("count", None), Agg("max", D)]), one_level),
+        "c3gm": (QueryUnit("fact", joins=j, groupby=[D % 64], targets=[KeyRef(0), Agg("sum", V)]),
+                 "hdk_join_order_probe,hdk_join_scatter_slices,hdk_join_agg_sliced2,hdk_scan_agg_bh_vec_join,hdk_bh_fold_dense"),
+        "c3f": (QueryUnit("fact", joins=j, quals=[Cmp(D, "<", Lit(500_000))], groupby=[At], targets=[KeyRef(0), Agg("sum", V), Agg("count", None)]),
+                one_level),
+        "c3x": (QueryUnit("fact", joins=j, quals=[Cmp(D, "<", Lit(500_000))], groupby=[ColRef("g32")], targets=[KeyRef(0), Agg("sum", V)]), one_level),
+        "c3x2": (QueryUnit("fact", joins=j, quals=[Cmp(D, "<", Lit(500_000))], targets=[Agg("sum", V), Agg("sum", ColRef("g")), Agg("count", None)]),
+                 one_level),
+    }
+    for name, (q, want) in shapes.items():
+        cp = compile_query(st, q)
+        assert _names(_fused(cp)) == want, (name, _names(_fused(cp)))
+    # a small fact table: nothing to slice for -- row order (the interpreter / the direct kernel)
+    assert "hdk_join_scatter_slices" not in _names(_fused(compile_query(st, shapes["c3g"][0])), total_rows=1_000_000)
