@@ -45,3 +45,26 @@ def test_assumed_device_is_this_device(storage, gpu_executor_factory):
         cp = compile_query(storage, q)
         for rows in (R.BIG, 100_000):
             assert _names_on(cp, 0, rows) == _names_on(cp, R.ASSUMED_MI355X, rows), (q, rows)
+
+
+def test_assumed_device_routes_the_star_schema_shapes_like_this_device():
+    from hdk_amd.ir import JoinSpec
+    from hdk_amd.storage import ArrowStorage
+    import numpy as np
+    rng = np.random.default_rng(4)
+    nd, n = 10_000_000, 200_000
+    st = ArrowStorage()
+    st.import_numpy("dim", {"key": np.arange(nd, dtype=np.int64), "dval": rng.integers(0, 10**6, nd).astype(np.int64),
+                            "attr": rng.integers(0, 64, nd).astype(np.int64)})
+    st.import_numpy("fact", {"fk": rng.integers(0, nd, n, dtype=np.int64), "val": rng.integers(-2**31, 2**31, n, dtype=np.int64),
+                             "g32": rng.integers(0, 64, n).astype(np.int32)}, fragment_size=n // 2 + 1)
+    j = [JoinSpec("dim", ColRef("fk"), "key")]
+    V, D, At = ColRef("val"), ColRef("dval", "dim"), ColRef("attr", "dim")
+    for q in (QueryUnit("fact", joins=j, targets=[Agg("sum", V + D)]),
+              QueryUnit("fact", joins=j, groupby=[D / 15625], targets=[KeyRef(0), Agg("sum", V)]),
+              QueryUnit("fact", joins=j, groupby=[D % 64], targets=[KeyRef(0), Agg("sum", V)]),
+              QueryUnit("fact", joins=j, quals=[Cmp(D, "<", Lit(500_000))], groupby=[At], targets=[KeyRef(0), Agg("sum", V)]),
+              QueryUnit("fact", joins=j, quals=[Cmp(D, "<", Lit(500_000))], groupby=[ColRef("g32")], targets=[KeyRef(0), Agg("sum", V)])):
+        cp = R._fused(compile_query(st, q))
+        for rows in (R.BIG, 1_000_000):
+            assert _names_on(cp, 0, rows) == _names_on(cp, R.ASSUMED_MI355X, rows), (q, rows)
