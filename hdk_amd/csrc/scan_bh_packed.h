@@ -55,7 +55,8 @@ struct BhPackedArgs {
   uint32_t bins_log2;      // pass A / B: bins by the top hash bits (0: the one-pass kernel)
   int32_t key_buf_idx, val_buf_idx;
   int32_t key_width, val_width;  // bytes of the columns
-  int32_t key_form;        // 0: the column's value is the key; 1: cast(integer AS double)
+  int32_t key_form;        // 0: the column's value is the key; 1: cast(integer AS double); 2: column % key_mod (general kernels,
+                           // dense tables only: the kernel bounds the key where the planner has no range -- (-m, m))
   int32_t key_nullable;
   int64_t key_null;        // the key column's in-band NULL (widened)
   int64_t key_null_out;    // key_form 1: the cast's NULL (NULL_DOUBLE bits)
@@ -67,6 +68,8 @@ struct BhPackedArgs {
   // dense: the key column's statistics [dense_min, dense_min + dense_n) fit the table: entry = key - dense_min (NULL: dense_n)
   int32_t dense, dense_min;
   uint32_t dense_n, pad_dense_;
+  int32_t key_mod;         // key_form 2: the literal divisor m (1 .. 2^15), with its magic for the unsigned quotient
+  uint32_t mod_magic, mod_shift, pad_mod_;
   uint32_t flush_rows;     // a block folds its table into the output and starts over before it has seen this many rows: the
                            // bound the packed fields were sized for (rows < 2^24, |sum| < 2^39 per entry)
   int32_t nquals;
@@ -113,10 +116,36 @@ HDK_DEV BhPartial bh_decode(uint64_t packed, uint32_t nulls, uint64_t mm) {
 
 HDK_DEV uint32_t bh_tag_hash(int32_t key) { return static_cast<uint32_t>(key) * 0x9E3779B1u; }
 
+// v % m for a positive invariant m, truncating like C (the sign of v): eval_expr's `a % b` (host_match.h: magic_u32)
+HDK_DEV int32_t bh_mod(int32_t v, uint32_t m, uint32_t magic, uint32_t shift) {
+  if (m == 1u) {
+    return 0;
+  }
+  const uint32_t n = static_cast<uint32_t>(v < 0 ? -v : v);
+  const uint32_t t = __umulhi(magic, n);
+  const uint32_t q = (((n - t) >> 1) + t) >> shift;
+  const int32_t r = static_cast<int32_t>(n - q * m);
+  return v < 0 ? -r : r;
+}
+// the key word of the output table for a raw column value that goes through the exact path
+HDK_DEV int64_t bh_exact_key_word(const BhPackedArgs& a, int64_t kj) {
+  const bool knull = a.key_nullable && kj == a.key_null;
+  if (a.key_form == 1) {
+    return knull ? a.key_null_out : double_to_bits(static_cast<double>(kj));
+  }
+  if (a.key_form == 2) {
+    return knull ? a.key_null_out : kj % static_cast<int64_t>(a.key_mod);
+  }
+  return kj;
+}
+
 // the 64-bit key word of the output table for a key column value
 HDK_DEV int64_t bh_key_word(const BhPackedArgs& a, int32_t key) {
   if (a.key_form == 1) {
     return (a.key_nullable && static_cast<int64_t>(key) == a.key_null) ? a.key_null_out : double_to_bits(static_cast<double>(key));
+  }
+  if (a.key_form == 2) {  // (the table holds the remainder already; the column's NULL stands for the expression's)
+    return (a.key_nullable && static_cast<int64_t>(key) == a.key_null) ? a.key_null_out : static_cast<int64_t>(key);
   }
   return static_cast<int64_t>(key);
 }
@@ -510,6 +539,11 @@ HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t*
     const int64_t k64 = extract_elem<KW>(kr, i);
     const int64_t v64 = VW ? extract_elem<(VW ? VW : 8)>(vr, i) : 0;
     key[i] = static_cast<int32_t>(k64);
+    if (!NOQ && a.key_form == 2) {  // (general kernels only) the key is column % m; a NULL stays the column's NULL
+      const bool knull = (a.key_nullable != 0) & (key[i] == static_cast<int32_t>(a.key_null));
+      const int32_t r = bh_mod(key[i], static_cast<uint32_t>(a.key_mod), a.mod_magic, a.mod_shift);
+      key[i] = knull ? key[i] : r;
+    }
     val[i] = static_cast<int32_t>(v64);
     // (a 4-byte column's NULL test in 32 bits: the widened compare was a sign extension and two compares per row)
     isnull[i] = VW == 4 ? (a.val_nullable != 0) & (val[i] == static_cast<int32_t>(a.val_null))
@@ -597,8 +631,7 @@ HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
             if (slow1) {
               slow1 = 0;
               const bool nj = (VW != 0) & (a.val_nullable != 0) & (vj == a.val_null);
-              const bool knull = a.key_nullable && kj == a.key_null;
-              const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
+              const int64_t kword = bh_exact_key_word(a, kj);
               const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, nj);
               err = xe ? xe : err;
             }
@@ -673,8 +706,7 @@ HDK_DEV void bh_packed_kernel_body(const BhPackedArgs& a) {
             }
           }
           const bool nj = (VW != 0) & (a.val_nullable != 0) & (vj == a.val_null);
-          const bool knull = a.key_nullable && kj == a.key_null;
-          const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
+          const int64_t kword = bh_exact_key_word(a, kj);
           const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, nj);
           err = xe ? xe : err;
         }
@@ -979,9 +1011,8 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bh_scatter(BhPackedArgs a) {
             kj = i == j ? k64[i] : kj;
             vj = i == j ? v64[i] : vj;
           }
-          const bool knull = a.key_nullable && kj == a.key_null;
           const bool vnull = a.has_val && a.val_nullable && vj == a.val_null;
-          const int64_t kword = a.key_form == 1 ? (knull ? a.key_null_out : double_to_bits(static_cast<double>(kj))) : kj;
+          const int64_t kword = bh_exact_key_word(a, kj);
           const int32_t xe = bh_exact_row(a.plan, out_buf, a.out_entry_count, &s_cx, kword, vj, vnull);
           err = xe ? xe : err;
         }

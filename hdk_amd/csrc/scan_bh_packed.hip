@@ -39,9 +39,20 @@ static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_op
   if (kc.table != 0 || kc.kind != HDK_COL_INT || (kc.width != 4 && kc.width != 8)) return false;
   if (ke.nsteps == 1) {
     const hdk_hip_step& sp = ke.steps[0];
-    if (sp.op != HDK_OP_CAST_INT_TO_FP || p->key_width != 8) return false;
-    a->key_form = 1;
-    a->key_null_out = sp.null_out;
+    if (sp.op == HDK_OP_CAST_INT_TO_FP && p->key_width == 8) {
+      a->key_form = 1;
+      a->key_null_out = sp.null_out;
+    } else if (sp.op == HDK_OP_MOD && sp.out_class == HDK_VC_INT && sp.rhs.kind == HDK_LEAF_INT && sp.rhs.ival >= 1 &&
+               sp.rhs.ival <= (1 << 15) && p->query_kind == HDK_Q_BASELINE_HASH && !hdk_sw(SW_NO_BH_MOD_KEYS)) {
+      // column % m: no expression range for the planner (QE/ExpressionRange.cpp:391-419: a baseline-hash layout), but the
+      // kernel knows the key lies in (-m, m) -- a dense table over that range (match_bh_packed; the general kernels)
+      a->key_form = 2;
+      a->key_mod = static_cast<int32_t>(sp.rhs.ival);
+      if (a->key_mod >= 2) magic_u32(static_cast<uint32_t>(a->key_mod), &a->mod_magic, &a->mod_shift);
+      a->key_null_out = ke.null_val;
+    } else {
+      return false;
+    }
   } else if (ke.nsteps != 0) {
     return false;
   }
@@ -56,6 +67,11 @@ static bool match_bh_packed_shape(const hdk_hip_plan* p, const hdk_hip_kernel_op
       static_cast<uint64_t>(kc.max_val - kc.min_val) < (1u << 20)) {
     a->dense_min = static_cast<int32_t>(kc.min_val);
     a->dense_n = static_cast<uint32_t>(kc.max_val - kc.min_val) + 1;
+  }
+  if (a->key_form == 2) {  // the remainder's own range, whatever the column's: [0, m) when the statistics say >= 0, else (-m, m)
+    const bool nonneg = kc.has_stats && kc.min_val >= 0;
+    a->dense_min = nonneg ? 0 : -(a->key_mod - 1);
+    a->dense_n = static_cast<uint32_t>(nonneg ? a->key_mod : 2 * a->key_mod - 1);
   }
   if (kc.width == 8) {  // an 8-byte key column rides as 32 bits when the statistics say it fits (strangers take the exact path)
     if (!kc.has_stats || kc.min_val < INT32_MIN || kc.max_val > INT32_MAX) return false;
@@ -134,7 +150,6 @@ static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   // twice the entries where LDS allows; an open-addressing table is sized at twice its groups already)
   if (p->query_kind == HDK_Q_PERFECT_HASH && 24ull * ((2ull << cap_log2) + 4) <= kBhPackedMaxBytes512) ++cap_log2;
   const uint64_t one = 24ull * ((1ull << cap_log2) + 4);
-  if (one > kBhPackedMaxBytes512) return false;
   // dense: one entry per value of the key column's statistics (+ the NULL key's) when that costs at most twice the tags' LDS
   // and fits a 256-thread block's share -- no tags to read, no probe (bh_dense_rows)
   if (a->dense_n && !hdk_sw(SW_NO_BH_DENSE)) {
@@ -144,6 +159,10 @@ static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options*
       cap_log2 = dlog2;
     }
   }
+  if (a->key_form == 2 && !a->dense) return false;  // (modulo keys: only as a dense table over the remainder's range)
+  // (tags: the LDS table must hold as many entries as the output table; a dense table only its keys' range -- the 16 384-entry
+  // default guess of a small input does not keep a 64-key plan off the chip)
+  if (!a->dense && one > kBhPackedMaxBytes512) return false;
   const uint64_t bytes = 24ull * ((1ull << cap_log2) + 4);
   uint32_t rep = 32;
   while (rep > 1 && (bytes + 16) * rep > kBhPackedReplicatedBytes) rep >>= 1;
@@ -172,7 +191,7 @@ static const void* bh_dense_kernel(int kw, int vw) {
   return vw == 0 ? bh_dense_kernel_of<8, 0>() : (vw == 4 ? bh_dense_kernel_of<8, 4>() : bh_dense_kernel_of<8, 8>());
 }
 // unfiltered plans: the kernels that hold only the hot form of the steps (every column width)
-static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return a.nquals == 0 && !hdk_sw(SW_NO_BH_PLAIN); }
+static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return a.nquals == 0 && a.key_form != 2 && !hdk_sw(SW_NO_BH_PLAIN); }
 template <int KW, int VW>
 static const void* bh_plain_kernel_of(bool dense, int block) {
   if (dense) return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<KW, VW, HDK_BH_PACKED_U>);
@@ -204,7 +223,7 @@ static bool match_bh_partitioned(const hdk_hip_plan* p, const hdk_hip_kernel_opt
     // (fine: the table is initialised by the init kernel before the passes, launch_baseline)
   }
   int kw, vw;
-  if (!match_bh_packed_shape(p, ko, a, &kw, &vw)) return false;
+  if (!match_bh_packed_shape(p, ko, a, &kw, &vw) || a->key_form == 2) return false;
   if (!always && (ko->total_rows < (4ull << 20) || p->entry_count > (1u << 20))) return false;
   if (ko->total_rows >= (1ull << 40)) return false;
   // a bin sees 1 / 256 of the groups: room for 2.5 x the bin's share of the table's entries (every entry in use and an
@@ -233,7 +252,7 @@ static bool match_bh_dense_part(const hdk_hip_plan* p, const hdk_hip_kernel_opti
   if (hdk_sw(SW_NO_BH_PARTITIONS) || hdk_sw(SW_NO_BH_DENSE_PARTITIONS) || !ko || ko->total_rows == 0) return false;
   memset(g, 0, sizeof(*g));
   BhPackedArgs& a = g->p;
-  if (!match_bh_packed_shape(p, ko, &a, &l->kw, &l->vw)) return false;
+  if (!match_bh_packed_shape(p, ko, &a, &l->kw, &l->vw) || a.key_form == 2) return false;
   if (!a.dense_n) return false;
   if (!always && ko->total_rows < (4ull << 20)) return false;
   if (ko->total_rows >= (1ull << 40)) return false;

@@ -20,6 +20,7 @@ namespace hdk {
   X(NO_BH_DENSE_PARTITIONS)         \
   X(NO_BH_DIRECT)                   \
   X(NO_BH_LDS)                      \
+  X(NO_BH_MOD_KEYS)                 \
   X(NO_BH_PACKED)                   \
   X(NO_BH_PARTITIONS)               \
   X(NO_BH_PLAIN)                    \

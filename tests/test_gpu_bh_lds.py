@@ -129,6 +129,35 @@ def test_filters_and_expression_keys(oracle, gpu_executor_factory):
         assert cp.entry_count == 2 * 37
 
 
+@pytest.mark.parametrize("xcol,m,signed", [("x1k", 37, False), ("k32", 11, True), ("x10", 7, False), ("k64s", 64, True)])
+def test_modulo_key_on_the_dense_kernel(oracle, gpu_executor_factory, xcol, m, signed, monkeypatch):
+    """`GROUP BY col % m` with the benchmark's aggregates: the planner has no range for a modulo (an open-addressing layout of
+    2 x NDV-bound entries, or the 16 384-entry default guess), the kernel does -- (-m, m), or [0, m) when the statistics say the
+    column is not negative -- and runs the plan on a dense LDS table over it (hdk_scan_agg_bh_dense, key_form 2).  Negative
+    values (C's truncating remainder), NULL keys (x10: the NULL group), an 8-byte column inside 32 bits, a filter in front; the
+    interpreter and the reference's own scheme give the same groups."""
+    st = _bh_table(500_000, 41)
+    t = st.get("t")
+    # an 8-byte signed key column inside 32 bits
+    import numpy as _np
+    k64s = _np.concatenate(t.columns["k32"].fragments).astype(_np.int64) * 3 - 50
+    st2 = ArrowStorage()
+    cols = {k: _np.concatenate(c.fragments) for k, c in t.columns.items()}
+    cols["k64s"] = k64s
+    st2.import_numpy("t", cols, fragment_size=500_000 // 3 + 1)
+    ex = gpu_executor_factory(st2)
+    y = ColRef("y10")
+    for quals in ([], [Cmp(ColRef("y10"), "<=", Lit(7))]):
+        q = QueryUnit("t", groupby=[ColRef(xcol) % m], quals=quals,
+                      targets=[KeyRef(0, "g"), Agg("count", y, "c"), Agg("sum", y, "s"), Agg("max", y, "mx"), Agg("min", y, "mn"), Agg("avg", y, "a")])
+        cp, res = _run_and_check(oracle, ex, st2, q, expect_kernel=("hdk_scan_agg_bh_dense,",))
+        groups = res.row_count()
+        assert groups <= (2 * m - 1 if signed else m) + 1
+    monkeypatch.setenv("HDK_HIP_NO_BH_MOD_KEYS", "1")
+    q = QueryUnit("t", groupby=[ColRef(xcol) % m], targets=[KeyRef(0, "g"), Agg("count", y, "c"), Agg("sum", y, "s")])
+    _run_and_check(oracle, ex, st2, q, expect_kernel=("hdk_scan_agg_bh_vec",))
+
+
 def test_modulo_key_behind_a_join(oracle, gpu_executor_factory):
     """SURVEY 8(d)'s C3 variant as written: fact JOIN dim, GROUP BY dim.dval % 64, SUM(fact.val)."""
     rng = np.random.default_rng(16)

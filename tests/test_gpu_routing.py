@@ -36,6 +36,7 @@ def test_assumed_device_is_this_device(storage, gpu_executor_factory):
         QueryUnit("t", groupby=[K, ColRef("k2")], targets=[KeyRef(0), KeyRef(1), Agg("count", None)]),
         R._bh("x10"), R._bh("x1k"), R._bh("x100k"), R._bh("x10", quals=[Cmp(ColRef("y10"), "<=", Lit(7))]),
         QueryUnit("syn", groupby=[ColRef("x1k") % 37], targets=[KeyRef(0), Agg("sum", ColRef("y10"))]),
+        QueryUnit("syn", groupby=[ColRef("x1k") % 37], targets=[KeyRef(0), Agg("sum", ColRef("d"))]),
         QueryUnit("syn", groupby=[ColRef("sparse")], force_baseline=True, baseline_entry_count=180_001,
                   targets=[KeyRef(0), Agg("sum", ColRef("y10")), Agg("count", None)]),
         QueryUnit("t", groupby=[ColRef("wide")], force_baseline=True, baseline_entry_count=200_000_000,

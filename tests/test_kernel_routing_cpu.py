@@ -77,12 +77,15 @@ def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     assert _names(compile_query(storage, _bh("x10"))) == one_pass
     assert _names(compile_query(storage, _bh("x1k"))) == one_pass
     assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"
-    # filtered: the general kernels; an fp argument: the word form; an expression key: the interpreter with an LDS table
+    # filtered: the general kernels; an fp argument: the word form; a modulo key: a dense table over (-m, m) in the general
+    # kernels when the aggregates are the packed shape, else the interpreter with an LDS table
     assert _names(compile_query(storage, _bh("x10", quals=[Cmp(ColRef("y10"), "<=", Lit(7))]))) == "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs"
     fp_arg = QueryUnit("syn", groupby=[Cast(ColRef("x10"), FP64)], targets=[KeyRef(0), Agg("sum", ColRef("d"))])
     assert _names(compile_query(storage, fp_arg)).startswith("hdk_scan_agg_bh_direct")
     expr_key = QueryUnit("syn", groupby=[ColRef("x1k") % 37], targets=[KeyRef(0), Agg("sum", ColRef("y10"))])
-    assert _names(compile_query(storage, expr_key)).startswith("hdk_scan_agg_bh_vec")
+    assert _names(compile_query(storage, expr_key)) == "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs"
+    expr_key_fp = QueryUnit("syn", groupby=[ColRef("x1k") % 37], targets=[KeyRef(0), Agg("sum", ColRef("d"))])
+    assert _names(compile_query(storage, expr_key_fp)).startswith("hdk_scan_agg_bh_vec")
     # sparse keys: tags on chip, hash bins beyond
     sparse = QueryUnit("syn", groupby=[ColRef("sparse")], force_baseline=True, baseline_entry_count=180_001,
                        targets=[KeyRef(0), Agg("sum", ColRef("y10")), Agg("count", None)])
