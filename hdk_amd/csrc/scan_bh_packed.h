@@ -531,7 +531,37 @@ HDK_DEV uint32_t bh_tile_step(const BhPackedArgs& a, const BhHot& hot, uint32_t*
     for (int i = 0; i < R; ++i) {
       rows[i] = ok[i] ? rbase + i : row0;
     }
-    plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
+    if (a.q[0].nprog != 0) {
+      plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
+    } else {
+      // a conjunction: a conjunct on the key or the argument column (WHERE measure > 0, WHERE key < c) reads the registers the
+      // tile already holds instead of gathering the column a second time (the filtered BH001: 1.17 -> see DESIGN.md 3.4c)
+      for (int qi = 0; qi < a.nquals; ++qi) {
+        const ProjFastQual q = a.q[qi];
+        const bool plain_int = q.col.kind == HDK_COL_INT && !q.fp;
+        const bool on_val = VW != 0 && plain_int && q.col.buf_idx == a.val_buf_idx && q.col.width == VW;
+        const bool on_key = plain_int && q.col.buf_idx == a.key_buf_idx && q.col.width == KW;
+        if (on_val || on_key) {
+          const bool nullable = q.nullable != 0;
+#define HDK_BH_REGQ(OP)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                            \
+    const int64_t v = on_val ? (VW ? extract_elem<(VW ? VW : 8)>(vr, i) : 0) : extract_elem<KW>(kr, i);        \
+    ok[i] = ok[i] & !(nullable & (v == q.null_val)) & (v OP q.rhs);                                          \
+  }
+          switch (q.cmp) {
+            case HDK_CMP_EQ: HDK_BH_REGQ(==) break;
+            case HDK_CMP_NE: HDK_BH_REGQ(!=) break;
+            case HDK_CMP_LT: HDK_BH_REGQ(<) break;
+            case HDK_CMP_GT: HDK_BH_REGQ(>) break;
+            case HDK_CMP_LE: HDK_BH_REGQ(<=) break;
+            default: HDK_BH_REGQ(>=) break;
+          }
+#undef HDK_BH_REGQ
+        } else {
+          plain_quals_pass<R, false>(&a.q[qi], 1, cols, rows, ok, true);
+        }
+      }
+    }
   }
   uint32_t slow = 0;
 #pragma unroll
