@@ -767,19 +767,19 @@ template <int KW, int VW, int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 256 / BLOCK : 1) void hdk_scan_agg_bh_packed(BhPackedArgs a) {
   bh_packed_kernel_body<KW, VW, U, BLOCK, false, false>(a);
 }
-// the dense form (entry = key - min by the key column's statistics; 256-thread blocks only: such tables are small)
-template <int KW, int VW, int U>
-__global__ __launch_bounds__(kBhPackedBlock, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES : 1) void hdk_scan_agg_bh_dense(BhPackedArgs a) {
-  bh_packed_kernel_body<KW, VW, U, kBhPackedBlock, true, false>(a);
+// the dense form (entry = key - min by the key column's statistics); 512-thread blocks, one per CU, for tables of 2 K - 4 K entries
+template <int KW, int VW, int U, int BLOCK = kBhPackedBlock>
+__global__ __launch_bounds__(BLOCK, HDK_BH_PACKED_WAVES ? HDK_BH_PACKED_WAVES * 256 / BLOCK : 1) void hdk_scan_agg_bh_dense(BhPackedArgs a) {
+  bh_packed_kernel_body<KW, VW, U, BLOCK, true, false>(a);
 }
 // the plain forms (unfiltered plans: the reference's benchmark shapes)
 template <int KW, int VW, int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_packed_plain(BhPackedArgs a) {
   bh_packed_kernel_body<KW, VW, U, BLOCK, false, true>(a);
 }
-template <int KW, int VW, int U>
-__global__ __launch_bounds__(kBhPackedBlock) void hdk_scan_agg_bh_dense_plain(BhPackedArgs a) {
-  bh_packed_kernel_body<KW, VW, U, kBhPackedBlock, true, true>(a);
+template <int KW, int VW, int U, int BLOCK = kBhPackedBlock>
+__global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bh_dense_plain(BhPackedArgs a) {
+  bh_packed_kernel_body<KW, VW, U, BLOCK, true, true>(a);
 }
 
 // ---- the fold of the scan blocks' slabs -----------------------------------------------------------------------------------

@@ -154,7 +154,9 @@ static bool match_bh_packed(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   // and fits a 256-thread block's share -- no tags to read, no probe (bh_dense_rows)
   if (a->dense_n && !hdk_sw(SW_NO_BH_DENSE)) {
     const uint32_t dlog2 = std::max<uint32_t>(pow2_ceil_log2(a->dense_n + 1), 2);
-    if (dlog2 <= cap_log2 + 1 && 24ull * ((1ull << dlog2) + 4) <= kBhPackedMaxBytes256) {
+    // (to 52 KB with 256-thread blocks; to 100 KB -- 4 096 entries -- with one 512-thread block per CU: slower per row, but one
+    // pass where the alternative is two)
+    if (dlog2 <= cap_log2 + 1 && 24ull * ((1ull << dlog2) + 4) <= kBhPackedMaxBytes512) {
       a->dense = 1;
       cap_log2 = dlog2;
     }
@@ -186,7 +188,15 @@ template <int KW, int VW>
 static const void* bh_dense_kernel_of() {
   return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense<KW, VW, HDK_BH_GENERAL_U>);
 }
-static const void* bh_dense_kernel(int kw, int vw) {
+template <int KW, int VW>
+static const void* bh_dense_kernel512_of() {
+  return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense<KW, VW, HDK_BH_GENERAL_U, 512>);
+}
+static const void* bh_dense_kernel(int kw, int vw, int block) {
+  if (block == 512) {
+    if (kw == 4) return vw == 0 ? bh_dense_kernel512_of<4, 0>() : (vw == 4 ? bh_dense_kernel512_of<4, 4>() : bh_dense_kernel512_of<4, 8>());
+    return vw == 0 ? bh_dense_kernel512_of<8, 0>() : (vw == 4 ? bh_dense_kernel512_of<8, 4>() : bh_dense_kernel512_of<8, 8>());
+  }
   if (kw == 4) return vw == 0 ? bh_dense_kernel_of<4, 0>() : (vw == 4 ? bh_dense_kernel_of<4, 4>() : bh_dense_kernel_of<4, 8>());
   return vw == 0 ? bh_dense_kernel_of<8, 0>() : (vw == 4 ? bh_dense_kernel_of<8, 4>() : bh_dense_kernel_of<8, 8>());
 }
@@ -194,7 +204,10 @@ static const void* bh_dense_kernel(int kw, int vw) {
 static bool bh_plain(const BhPackedArgs& a, int kw, int vw) { return a.nquals == 0 && a.key_form != 2 && !hdk_sw(SW_NO_BH_PLAIN); }
 template <int KW, int VW>
 static const void* bh_plain_kernel_of(bool dense, int block) {
-  if (dense) return reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<KW, VW, HDK_BH_PACKED_U>);
+  if (dense) {
+    return block == 512 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<KW, VW, HDK_BH_PACKED_U, 512>)
+                        : reinterpret_cast<const void*>(hdk_scan_agg_bh_dense_plain<KW, VW, HDK_BH_PACKED_U, 256>);
+  }
   return block == 512 ? reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<KW, VW, HDK_BH_PACKED_U, 512>)
                       : reinterpret_cast<const void*>(hdk_scan_agg_bh_packed_plain<KW, VW, HDK_BH_PACKED_U, 256>);
 }
@@ -381,7 +394,7 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   a.plan = d_plan;
   a.kp = kp;
   const void* k = bh_plain(a, kw, vw) ? bh_plain_kernel(a.dense != 0, kw, vw, block)
-                                      : (a.dense ? bh_dense_kernel(kw, vw) : (block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw)));
+                                      : (a.dense ? bh_dense_kernel(kw, vw, block) : (block == 512 ? bh_packed_kernel<512>(kw, vw) : bh_packed_kernel<256>(kw, vw)));
   if (lds > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   }

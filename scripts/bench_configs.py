@@ -97,9 +97,12 @@ def main():
                     types={"cab_type": Type("dict", 4), "pickup_datetime": Type("timestamp", 8, unit="s"),
                            "trip_distance": Type("decimal", 8, scale=2), "total_amount": Type("decimal", 8, scale=2)})
     # the reference's synthetic benchmark table (Benchmarks/synthetic_benchmark/create_table.py:118-130): INT columns, uniform
-    need_syn = bool(only & {"bh1", "bh1f", "bhm", "bh2", "bh3", "bh4", "bh5", "ph1", "ph2", "ph3"})
+    need_syn = bool(only & {"bh1", "bh1f", "bhm", "bh2k", "bh4k", "bh2", "bh3", "bh4", "bh5", "ph1", "ph2", "ph3"})
     ns = n if need_syn else 1000
     syn = {f"x{nm}": rng.integers(1, hi + 1, ns).astype(np.int32) for nm, hi in (("10", 10), ("100", 100), ("1k", 1000), ("10k", 10_000), ("100k", 100_000))}
+    if only & {"bh2k", "bh4k"}:  # between the 256-thread dense tables (2 K entries) and the two-pass forms
+        syn["x2k"] = rng.integers(1, 2001, ns).astype(np.int32)
+        syn["x4k"] = rng.integers(1, 4001, ns).astype(np.int32)
     syn["y10"] = rng.integers(1, 11, ns).astype(np.int32)
     st.import_numpy("syn", syn, fragment_size=frag)
     ex = Executor(st, 0)
@@ -149,6 +152,8 @@ def main():
         "bh1f": (QueryUnit("syn", groupby=[Cast(ColRef("x10"), FP64)], quals=[Cmp(ColRef("y10"), "<=", Lit(7))],
                            targets=[KeyRef(0, "key0")] + [Agg(k, ColRef("y10")) for k in ("count", "sum", "max", "min", "avg")]), 8),
         # a key without an expression range (x % m: GroupByBaselineHash) in front of the benchmark's aggregates
+        "bh2k": (bh("x2k"), 8),
+        "bh4k": (bh("x4k"), 8),
         "bhm": (QueryUnit("syn", groupby=[ColRef("x1k") % 37],
                           targets=[KeyRef(0, "key0")] + [Agg(k, ColRef("y10")) for k in ("count", "sum", "max", "min", "avg")]), 8),
         "ph64": (QueryUnit("t", groupby=[ColRef("key")], targets=[KeyRef(0)] + [Agg(k, ColRef("y64")) for k in ("count", "sum", "max", "min", "avg")]), 16),

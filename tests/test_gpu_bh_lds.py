@@ -158,6 +158,23 @@ def test_modulo_key_on_the_dense_kernel(oracle, gpu_executor_factory, xcol, m, s
     _run_and_check(oracle, ex, st2, q, expect_kernel=("hdk_scan_agg_bh_vec",))
 
 
+@pytest.mark.parametrize("groups", [1_500, 3_000, 4_000])
+def test_dense_tables_of_a_few_thousand_groups_stay_on_chip(oracle, gpu_executor_factory, groups):
+    """1.5 K groups: 256-thread blocks; 3 K and 4 K (2 x entries beyond what tags could hold on chip): ONE 512-thread block
+    per CU with a dense table of up to 4 096 entries -- still one pass."""
+    rng = np.random.default_rng(groups)
+    n = 1_200_000
+    x = rng.integers(1, groups + 1, n).astype(np.int32)
+    x[rng.random(n) < 0.002] = A.NULL_INT
+    y = rng.integers(1, 11, n).astype(np.int32)
+    y[rng.random(n) < 0.02] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", {"x": x, "y10": y}, fragment_size=n // 3 + 5)
+    ex = gpu_executor_factory(st)
+    cp, res = _run_and_check(oracle, ex, st, _bh_query("x"), expect_kernel=("hdk_scan_agg_bh_dense_plain,",))
+    assert res.row_count() == groups + 1
+
+
 def test_modulo_key_behind_a_join(oracle, gpu_executor_factory):
     """SURVEY 8(d)'s C3 variant as written: fact JOIN dim, GROUP BY dim.dval % 64, SUM(fact.val)."""
     rng = np.random.default_rng(16)
