@@ -39,7 +39,7 @@ def storage():
     y = rng.integers(1, 11, n).astype(np.int32)
     y[rng.random(n) < 0.02] = A.NULL_INT
     st.import_numpy("syn", {"x10": rng.integers(1, 11, n).astype(np.int32), "x1k": rng.integers(1, 1001, n).astype(np.int32),
-                            "x100k": rng.integers(1, 100_001, n).astype(np.int32), "y10": y,
+                            "x100k": rng.integers(1, 100_001, n).astype(np.int32), "x4k": rng.integers(1, 4001, n).astype(np.int32), "y10": y,
                             "sparse": (rng.integers(0, 90_000, n) * 7919).astype(np.int32), "d": rng.normal(size=n)},
                     fragment_size=n // 3 + 1)
     st.import_numpy("t", {"key": rng.integers(0, 64, n, dtype=np.int64), "val": rng.integers(-2**31, 2**31, n, dtype=np.int64),
@@ -76,6 +76,7 @@ def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     one_pass = "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs"
     assert _names(compile_query(storage, _bh("x10"))) == one_pass
     assert _names(compile_query(storage, _bh("x1k"))) == one_pass
+    assert _names(compile_query(storage, _bh("x4k"))) == one_pass  # (4 096 dense entries under one 512-thread block per CU)
     assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"
     # filtered: the general kernels; an fp argument: the word form; a modulo key: a dense table over (-m, m) in the general
     # kernels when the aggregates are the packed shape, else the interpreter with an LDS table
@@ -94,6 +95,7 @@ def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     assert _names(compile_query(storage, _bh("x10")), flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).startswith("hdk_scan_agg_global")
     monkeypatch.setenv("HDK_HIP_NO_BH_DENSE", "1")
     assert _names(compile_query(storage, _bh("x10"))) == "hdk_scan_agg_bh_packed_plain,hdk_bh_fold_slabs"
+    assert _names(compile_query(storage, _bh("x4k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"  # (tags would need 8 K entries)
     monkeypatch.setenv("HDK_HIP_NO_BH_DENSE_PARTITIONS", "1")
     assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_scatter,hdk_bh_aggregate"
     monkeypatch.setenv("HDK_HIP_NO_BH_LDS", "1")
