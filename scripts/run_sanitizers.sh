@@ -4,7 +4,7 @@
 # pool, so device code is not covered:
 #   1. the oracle (oracle/libhdk_oracle_asan.so) under the whole CPU test-suite;
 #   2. the HOST half of libhdk_hip.so (plan validation, matchers, shape / workspace arithmetic, the C ABI's argument
-#      checks) -- built with -fsanitize=address,undefined for the host pass only (-fno-gpu-sanitize) as
+#      checks; the kernel-routing matchers through tests/test_kernel_routing_cpu.py) -- built with -fsanitize=address,undefined for the host pass only (-fno-gpu-sanitize) as
 #      hdk_amd/libhdk_hip_asan.so -- under the ABI tests that need no device;
 #   3. the C++ binding harness's host code (tests/cpp), compiled with the same flags (compile + link; it needs a
 #      device to run).
@@ -25,7 +25,7 @@ make -C hdk_amd/csrc variant NAME=asan DEFS="-O1 -g -fno-omit-frame-pointer -fsa
   LDEXTRA="-fsanitize=address,undefined -fno-gpu-sanitize" -j4 > /tmp/asan_build.log 2>&1 || { tail -20 /tmp/asan_build.log; exit 1; }
 CLANG_RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so 2>/dev/null || true)
 LD_PRELOAD="${CLANG_RT:-$ASAN_RT}" HDK_HIP_LIB=$ROOT/hdk_amd/libhdk_hip_asan.so \
-  python -m pytest tests/test_abi.py tests/test_abi_negative.py tests/test_plan_layout.py -x -q -p no:cacheprovider
+  python -m pytest tests/test_abi.py tests/test_abi_negative.py tests/test_plan_layout.py tests/test_kernel_routing_cpu.py -x -q -p no:cacheprovider
 echo "== 3. C++ binding harness, host code with the same flags (compile + link only)"
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -Wall -Werror -Wno-unused-parameter -I /root/reference/omniscidb -I include \
   -I hdk_amd/glue -I tests/cpp tests/cpp/harness.cpp -L hdk_amd -lhdk_hip -Wl,-rpath,"$ROOT/hdk_amd" -o /tmp/harness_asan 2>&1 | tail -20
