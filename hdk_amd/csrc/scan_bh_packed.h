@@ -793,15 +793,25 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   __shared__ BhExactCtx s_cx;
   const int tid = threadIdx.x;
-  const uint32_t cap = 1u << a.cap_log2;
+  const uint32_t scan_cap = 1u << a.cap_log2;  // entries of a scan block's table (the slabs)
+  // this block's own table: in the staged forms a block meets the keys of ONE slice (<= list_cap, a few more when probing
+  // carried keys over a slice border) -- a table of 4 x list_cap entries instead of the scan's capacity (4 096 entries took
+  // 144 initialising stores and 16 emit trips per thread for 64 keys); what it cannot hold is folded into the output at once
+  uint32_t cap_log2 = a.cap_log2;
+  if (a.fold_stage != 0) {
+    const uint32_t want = 33 - __clz(a.list_cap * 2 - 1);  // log2(4 x list_cap) for a power of two
+    cap_log2 = min(cap_log2, max(want, 6u));
+  }
+  const uint32_t cap = 1u << cap_log2;
   const uint32_t bmask = (cap >> 2) - 1;
-  const uint32_t bshift = 32 - a.bins_log2 - (a.cap_log2 - 2);
   uint32_t* tags = lds32;
   uint64_t* mm = reinterpret_cast<uint64_t*>(lds32 + cap);
   unsigned long long* rows = reinterpret_cast<unsigned long long*>(lds32 + 3 * cap);
   unsigned long long* sum = reinterpret_cast<unsigned long long*>(lds32 + 5 * cap);
   unsigned long long* nulls = reinterpret_cast<unsigned long long*>(lds32 + 7 * cap);
   bh_exact_ctx_init(&s_cx, a, tid);
+  const TableShape shape = table_shape(a.plan);
+  int64_t* buf = a.kp.groupby_buf[0];
   for (uint32_t i = tid; i < cap; i += kBhFoldBlock) {
     tags[i] = kBhTagEmpty;
     mm[i] = (static_cast<uint64_t>(static_cast<uint32_t>(INT32_MIN)) << 32) | static_cast<uint32_t>(INT32_MAX);
@@ -812,17 +822,19 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
   __syncthreads();
   int32_t err = 0;
   const uint32_t slice = blockIdx.x % a.fold_slices, group = blockIdx.x / a.fold_slices;
-  const uint32_t per_slice = cap / a.fold_slices;  // entries of a slice (a multiple of 4, or the whole table)
+  const uint32_t per_slice = scan_cap / a.fold_slices;  // entries of a slice (a multiple of 4, or the whole table)
   const uint32_t e_begin = slice * per_slice;
   const uint32_t words = bh_slab_words(a);
   // (slab, entry) pairs of this block's slabs group, group + fold_groups, ... side by side: every trip of a thread is an
   // independent load -- one slab after the other (a few entries each, 128 dependent trips) the kernel took 100 - 240 us, as long
   // as a third of the scan it follows
   auto merge = [&](int32_t key, const BhPartial& b) {
-    const uint32_t bucket = a.cap_log2 > 2 ? ((bh_tag_hash(key) << a.bins_log2) >> (bshift + a.bins_log2)) & bmask : 0u;
+    // (the one-pass kernel's slabs: no bins; the bucket by the top hash bits of THIS table's size)
+    const uint32_t bucket = cap_log2 > 2 ? (bh_tag_hash(key) >> (32 - (cap_log2 - 2))) & bmask : 0u;
     const int32_t e0 = bh_tag_probe(tags, key, bucket, bmask);
-    if (e0 < 0) {
-      err = HDK_HIP_ERR_OUT_OF_SLOTS;
+    if (e0 < 0) {  // this block's table is full: the partial goes into the output table as it is
+      bh_fold_group_fn(a.plan, shape, s_cx.wl, buf, a.out_entry_count, s_cx.col_off, bh_key_word(a, key),
+                       [&](int w) -> int64_t { return bh_partial_word(b, s_cx.wkind[w]); }, err);
       return;
     }
     atomicAdd(rows + e0, static_cast<unsigned long long>(b.rows));
@@ -893,8 +905,6 @@ __global__ __launch_bounds__(kBhFoldBlock) void hdk_bh_fold_slabs(BhPackedArgs a
     }
   }
   __syncthreads();
-  const TableShape shape = table_shape(a.plan);
-  int64_t* buf = a.kp.groupby_buf[0];
   __shared__ uint32_t s_list_n;
   if (tid == 0) {
     s_list_n = 0;
