@@ -93,9 +93,29 @@ inline bool plan_has_keyed_join(const hdk_hip_plan* p) {
 // filters of the form `outer column cmp literal` (plain_quals.h); false when any conjunct has another shape.
 // allow_program: the caller's kernel evaluates its filters through plain_quals_pass and nothing else, so an AND / OR / NOT
 // program over such leaves (hdk_hip_plan::filter_ops) is fine too: it rides in out[0]
+// deepest value stack a postfix filter program needs (hdk_hip_plan::filter_ops): the streaming kernels' evaluators
+// (plain_quals.h: plain_quals_program; scan_agg_fast.h: fast_x_program) keep kPlainProgStack values in registers, so a
+// program that nests deeper -- `(a AND b) OR ((a AND c) OR (b AND c))` pushes four -- must go to the interpreter
+// (vec_eval.h keeps 16).  plan.py deduplicates leaves, so three quals can need any depth.
+constexpr int kPlainProgStack = 3;
+inline int filter_program_depth(const hdk_hip_plan* p) {
+  int depth = 0, deepest = 0;
+  for (int i = 0; i < p->num_filter_ops; ++i) {
+    const uint32_t op = p->filter_ops[i];
+    if (op < HDK_F_AND) {
+      ++depth;
+    } else if (op != HDK_F_NOT) {
+      --depth;
+    }
+    if (depth > deepest) deepest = depth;
+  }
+  return deepest;
+}
+
 inline bool match_plain_quals(const hdk_hip_plan* p, ProjFastQual* out, bool allow_program = false) {
   if (p->num_quals > kMaxPlainQuals) return false;
-  if (p->num_filter_ops && (!allow_program || p->num_filter_ops > kMaxPlainProg || p->num_joins || p->num_quals == 0)) return false;
+  if (p->num_filter_ops && (!allow_program || p->num_filter_ops > kMaxPlainProg || p->num_joins || p->num_quals == 0 ||
+                            filter_program_depth(p) > kPlainProgStack)) return false;
   for (int i = 0; i < p->num_quals; ++i) {
     const hdk_hip_qual& q = p->quals[i];
     int c;
@@ -170,6 +190,10 @@ int32_t scan_events_begin(int32_t device_id, hipStream_t s, hipEvent_t* e0, hipE
 // ---- scan_fast.hip: the streaming kernel hdk_scan_agg_direct (scan_agg_fast.h), key width kw, value width vw ---------
 struct FastArgs;
 int32_t launch_fast_direct(int kw, int vw, const FastArgs& fa, const LaunchShape& shape, hipStream_t s);
+
+// ---- scan_cols.hip: non-grouped aggregates over several plain columns (scan_agg_cols.h: hdk_scan_agg_cols) -----------
+struct ColsArgs;
+int32_t launch_cols(const ColsArgs& ca, const LaunchShape& shape, hipStream_t s);
 
 // ---- scan_baseline.hip: GroupByBaselineHash plans and perfect-hash tables too big for LDS (STRAT_GLOBAL) ----------
 // persistent grid of the kernel that will run (x 4: random atomics make block run times uneven)

@@ -441,6 +441,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 #include "host_match.h"
 #include "scan_bh_host.h"
 #include "scan_agg_fast.h"
+#include "scan_agg_cols.h"
 #include "scan_agg_vec.h"
 #include "scan_agg_keys.h"
 #include "scan_cluster.h"
@@ -680,6 +681,7 @@ int32_t validate_plan_layout(const hdk_hip_plan* p) { return validate_plan_impl(
 struct FastArgs;
 static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs* fa, int* kw_out, int* vw_out);
 static bool match_keys(const hdk_hip_plan* p, const LaunchShape& shape, KeysArgs* ka);
+static bool match_cols(const hdk_hip_plan* p, const LaunchShape& shape, ColsArgs* ca);
 static bool match_keys_values(const hdk_hip_plan* p, KeysArgs* ka);
 static bool match_join_direct(const hdk_hip_plan* p, const LaunchShape& shape, JoinDirectArgs* ja);
 // which of the join kernels takes a plan (one place: the launch, its description and its grid agree)
@@ -779,6 +781,11 @@ LaunchShape choose_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko
     if (lds_limited >= cu && s.grid > lds_limited) {
       s.grid = lds_limited;  // a large unreplicated table: fewer blocks fit per CU, keep them all resident
     }
+  } else if (ColsArgs cols_args; !(ko && ko->grid_dim_x) && !(ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR))) &&
+             match_cols(p, s, &cols_args)) {
+    // one column streamed at a time, kColsU x 16 bytes in flight per lane: two 256-thread blocks per CU carry 64 KB per CU
+    const char* per_cu = hdk_sw(SW_COLS_BLOCKS_PER_CU);  // (A/B measurements)
+    s.grid = (per_cu && atoi(per_cu) > 0 ? static_cast<uint32_t>(atoi(per_cu)) : kColsBlocksPerCu) * static_cast<uint32_t>(props->num_cu);
   } else if (!(ko && ko->grid_dim_x)) {
     const bool scalar = (ko && (ko->flags & HDK_HIP_LAUNCH_FORCE_SCALAR)) || needs_join_loops(p);
     const bool generic = ko && (ko->flags & (HDK_HIP_LAUNCH_FORCE_GENERIC | HDK_HIP_LAUNCH_FORCE_SCALAR));
@@ -980,7 +987,8 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
     // an AND / OR / NOT program: in X mode when every operand is a column the kernel streams anyway (the value and the key
     // column: `WHERE val < 0 OR key = 3` reads nothing extra), else over gathered `column cmp literal` leaves
     const bool program = p->num_filter_ops != 0;
-    if (program && (p->num_filter_ops > kMaxPlainProg || p->num_quals > kMaxPlainQuals)) return false;
+    if (program && (p->num_filter_ops > kMaxPlainProg || p->num_quals > kMaxPlainQuals ||
+                    filter_program_depth(p) > kPlainProgStack)) return false;
     bool xmode = (needs_x || program) && !fa->val_is_fp && !hdk_sw(SW_FAST_NO_XMODE);
     auto src_of = [&](int col) -> int {
       const hdk_hip_col& cc = p->cols[col];
@@ -1035,12 +1043,72 @@ static bool match_fast(const hdk_hip_plan* p, const LaunchShape& shape, FastArgs
   return true;
 }
 
+// ---- column-by-column matcher: plan -> ColsArgs (scan_agg_cols.h) --------------------------------------------------------
+// Non-grouped, unfiltered, no join; every target COUNT(*) or an aggregate of a plain outer column (integer or double), at most
+// kColsMaxCols distinct columns: NonGroupedAgg/NGA01-05.sql.  (One column with every argument alike is match_fast's.)
+static bool match_cols(const hdk_hip_plan* p, const LaunchShape& shape, ColsArgs* ca) {
+  if (shape.strategy != STRAT_LDS || p->query_kind != HDK_Q_NON_GROUPED || p->num_joins || p->num_quals || p->num_filter_ops) return false;
+  if (hdk_sw(SW_NO_COLS_KERNEL)) return false;
+  memset(ca, 0, sizeof(*ca));
+  WordLayout wl;
+  make_word_layout(p, &wl);
+  ca->wpe = wl.wpe;
+  for (int w = 0; w < kMaxWordsPerEntry; ++w) {
+    ca->wcol[w] = -1;
+    ca->wkind[w] = w == 0 ? CW_ROWS : CW_UNUSED;
+  }
+  for (int t = 0; t < p->num_targets; ++t) {
+    const hdk_hip_target& tg = p->targets[t];
+    if (tg.agg != HDK_AGG_COUNT && tg.agg != HDK_AGG_SUM && tg.agg != HDK_AGG_MIN && tg.agg != HDK_AGG_MAX && tg.agg != HDK_AGG_AVG) return false;
+    if (!tg.has_arg) {
+      if (tg.agg != HDK_AGG_COUNT) return false;
+      continue;
+    }
+    int c;
+    if (!plain_outer_col(p, tg.arg, &c)) return false;
+    const hdk_hip_col& col = p->cols[c];
+    const bool fp = col.kind == HDK_COL_DOUBLE;
+    if (col.kind != HDK_COL_INT && !fp) return false;
+    if (fp ? col.width != 8 : (col.width != 1 && col.width != 2 && col.width != 4 && col.width != 8)) return false;
+    if (tg.agg != HDK_AGG_COUNT && (tg.arg_is_fp != 0) != fp) return false;  // (no int -> fp promotion, no float accumulators)
+    if (tg.arg_is_fp == HDK_FP_SLOT_FLOAT) return false;
+    const int nullable = tg.skip_null && tg.arg.nullable;
+    int ci = -1;
+    for (int i = 0; i < ca->ncols; ++i) {
+      if (ca->col[i].buf_idx == col.buf_idx) ci = i;
+    }
+    if (ci < 0) {
+      if (ca->ncols == kColsMaxCols) return false;
+      ci = ca->ncols++;
+      ca->col[ci].buf_idx = col.buf_idx;
+      ca->col[ci].width = col.width;
+      ca->col[ci].fp = fp;
+      ca->col[ci].nullable = nullable;
+      ca->col[ci].null_val = tg.arg.null_val;
+    } else if (ca->col[ci].nullable != nullable || (nullable && ca->col[ci].null_val != tg.arg.null_val) || ca->col[ci].width != col.width ||
+               ca->col[ci].fp != static_cast<int32_t>(fp)) {
+      return false;
+    }
+    if (wl.vword[t] >= 0) {
+      ca->wcol[wl.vword[t]] = ci;
+      ca->wkind[wl.vword[t]] = (tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_AVG) ? CW_SUM : (tg.agg == HDK_AGG_MIN ? CW_MIN : CW_MAX);
+    }
+    if (wl.nword[t] >= 0) {
+      ca->wcol[wl.nword[t]] = ci;
+      ca->wkind[wl.nword[t]] = CW_NN;
+    }
+  }
+  return ca->ncols > 0;
+}
+
 // (same decisions as launch_scan_lds)
 static const char* scan_kernel_name(const hdk_hip_plan* p, const LaunchShape& s, const hdk_hip_kernel_options* ko, bool force_generic,
                                     bool force_scalar) {
   FastArgs fa;
   int kw, vw;
   if (!force_generic && match_fast(p, s, &fa, &kw, &vw)) return "hdk_scan_agg_direct";
+  ColsArgs ca;
+  if (!force_generic && match_cols(p, s, &ca)) return "hdk_scan_agg_cols";
   JoinDirectArgs ja;
   Slice2Args ga;
   const JoinRoute route = force_generic ? JOIN_ROUTE_NONE : route_join(p, s, ko, &ja, &ga);
@@ -1915,6 +1983,12 @@ static int32_t launch_scan_lds(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
     fa.kp = kp;
     fa.slabs = slabs;
     return launch_fast_direct(kw, vw, fa, shape, s);  // (scan_fast.hip: the instantiations live in their own translation unit)
+  }
+  ColsArgs ca;
+  if (!force_generic && match_cols(plan, shape, &ca)) {
+    ca.kp = kp;
+    ca.slabs = slabs;
+    return launch_cols(ca, shape, s);  // (scan_cols.hip)
   }
   JoinDirectArgs ja;
   Slice2Args ga;

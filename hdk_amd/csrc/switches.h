@@ -13,6 +13,7 @@ namespace hdk {
   X(BH_PARTITIONS_ALWAYS)           \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
+  X(COLS_BLOCKS_PER_CU)             \
   X(FAST_NO_XMODE)                  \
   X(KEYS_NO_WIDE_BLOCK)             \
   X(NO_BATCHED_MATCHING_SETS)       \
@@ -24,6 +25,7 @@ namespace hdk {
   X(NO_BH_PACKED)                   \
   X(NO_BH_PARTITIONS)               \
   X(NO_BH_PLAIN)                    \
+  X(NO_COLS_KERNEL)                 \
   X(NO_PERFECT_PARTITIONS)          \
   X(NO_SLICED2)                     \
   X(PART_AOS)                       \

@@ -426,6 +426,7 @@ class ChunkedTupleExchange:
         self.ev_scattered = [torch.cuda.Event() for _ in self.chunks]
         self.ev_arrived = [torch.cuda.Event() for _ in self.chunks]
         self.ev_done = torch.cuda.Event()
+        self._ran = False  # (a step has been enqueued: the next one is ordered after its ev_done)
 
     @property
     def owner_entries(self):
@@ -438,8 +439,19 @@ class ChunkedTupleExchange:
     def run(self, wire, after=None):
         """One step.  wire(k, chunk, stream): moves chunk k's `send` segments into the peers' `recv` on `stream` (a torch
         stream: issue the collective under `with torch.cuda.stream(stream)`).  `after`: a torch stream the step starts after
-        and that is made to wait for the step's end (the caller's timeline)."""
+        and that is made to wait for the step's end (the caller's timeline).  Consecutive run() calls are ordered among
+        themselves (each starts when the previous one's last aggregate has finished); reading the owner's table is the
+        caller's to order: wait for `ev_done` or pass `after`."""
         torch = self.torch
+        # Step n + 1 starts after step n has ENDED on all three streams, whatever the caller does: scatter(chunk 0) rewrites
+        # chunk 0's `send` while the previous step's all-to-all may still read it, the wire rewrites `recv` and chunk 0's
+        # non-accumulating aggregate rewrites the owner's table under the previous step's last aggregates (round 5's advisor
+        # finding: only `after=` callers that synchronised every step were safe).  ev_done is recorded on the aggregate
+        # stream, which by then has waited for every wire and hence every scatter of that step.
+        if self._ran:
+            for s_ in (self.s_scatter, self.s_wire, self.s_agg):
+                s_.wait_event(self.ev_done)
+        self._ran = True
         if after is not None:
             start = torch.cuda.Event()
             start.record(after)

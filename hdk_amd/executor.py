@@ -13,6 +13,7 @@ All compute goes through the C ABI; there is no CPU execution path in this packa
 (`device_type="CPU"` raises).
 """
 import ctypes as C
+import dataclasses
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -22,7 +23,7 @@ from . import result_set
 from ._lib import HdkHipError, check, lib, sync_switches
 from .hip_mgr import DeviceBuffer, HipMgr
 from .ir import QueryMustRunOnCpu, QueryUnit
-from .plan import CompiledPlan, columnar_init_vals, compact_init_vals, compile_query, eff_key_count
+from .plan import DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS, CompiledPlan, columnar_init_vals, compact_init_vals, compile_query, eff_key_count
 from .storage import ArrowStorage
 
 
@@ -524,8 +525,21 @@ class Executor:
     def execute(self, q: QueryUnit, device_type: str = "GPU", frag_ids=None, **kw) -> ExecutionResult:
         if device_type != "GPU":
             raise QueryMustRunOnCpu("hdk_amd ships the GPU path only; run device_type='CPU' on HDK itself")
-        step = self.prepare(q, frag_ids, **kw)
-        try:
-            return step.run()
-        finally:
-            step.free()
+        # A QueryUnit whose open-addressing table the PLANNER sized (no baseline_entry_count): running out of slots means
+        # the estimate was wrong (stale statistics, a key from an inner column) -- RelAlgExecutor::handleOutOfMemoryRetry
+        # (QE/RelAlgExecutor.cpp:1713-1747) re-runs with a doubled max_groups_buffer_entry_guess, at most twice more, and
+        # so does this.  A CompiledPlan or a caller-pinned entry count reports ERR_OUT_OF_SLOTS as before.
+        retries_left = 2 if (isinstance(q, QueryUnit) and not q.baseline_entry_count) else 0
+        guess = 0
+        while True:
+            step = self.prepare(q, frag_ids, **kw)
+            try:
+                return step.run()
+            except HdkHipError as e:
+                if e.code != A.ERR_OUT_OF_SLOTS or step.cp.plan.query_kind != A.Q_BASELINE_HASH or retries_left == 0:
+                    raise
+                retries_left -= 1
+                guess = max(2 * max(guess, int(step.cp.entry_count)), DEFAULT_MAX_GROUPS_BUFFER_ENTRY_GUESS)
+                q = dataclasses.replace(q, baseline_entry_count=guess)
+            finally:
+                step.free()

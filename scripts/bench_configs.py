@@ -105,6 +105,29 @@ def main():
         syn["x4k"] = rng.integers(1, 4001, ns).astype(np.int32)
     syn["y10"] = rng.integers(1, 11, ns).astype(np.int32)
     st.import_numpy("syn", syn, fragment_size=frag)
+    # the same table for the suite's other families (tests/syn_queries.py: NonGroupedAgg, MultiStep, PerfectHashMultiCol), with
+    # only the columns the asked-for configs read
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import syn_queries as SQ
+    SYN2 = {f"nga{i}": (SQ.nga(i, "syn2"), 24) for i in range(1, 6)}
+    SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2", FP64), 12) for i in range(1, 5)})
+    SYN2.update({f"msphs{i}": (SQ.msphs(i, "syn2"), 12) for i in range(1, 5)})
+    SYN2.update({f"phm{i}": (SQ.phm(i, "syn2"), 12) for i in range(1, 7)})
+    want2 = [k for k in SYN2 if k in only]
+    cols2 = set()
+    for k in want2:
+        q2 = SYN2[k][0]
+        for e in list(q2.groupby) + [t.arg for t in q2.targets if getattr(t, "arg", None) is not None]:
+            stack = [e]
+            while stack:
+                x = stack.pop()
+                if isinstance(x, ColRef):
+                    cols2.add(x.name)
+                for attr in ("arg", "lhs", "rhs", "left", "right"):
+                    if hasattr(x, attr) and getattr(x, attr) is not None and not isinstance(getattr(x, attr), (int, float, str)):
+                        stack.append(getattr(x, attr))
+    if want2:
+        st.import_numpy("syn2", SQ.syn_table(rng, n, sorted(cols2)), fragment_size=frag)
     ex = Executor(st, 0)
     ex.fuse_join_tables = not args.no_fuse
 
@@ -196,6 +219,7 @@ def main():
         "c5": (QueryUnit("t", groupby=[ColRef("hk")], force_baseline=True,
                          targets=[KeyRef(0), Agg("sum", ColRef("val"))]), 16),
     }
+    Q.update({k: SYN2[k] for k in want2})
     for kv in [x for x in args.launch_env.split(",") if x]:
         os.environ[kv.split("=")[0]] = kv.split("=", 1)[1]
     for name, (q, bpr) in Q.items():

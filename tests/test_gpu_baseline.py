@@ -3,6 +3,8 @@ shape) and perfect-hash tables forced off LDS.  Slot positions of a baseline tab
 insertion order, so buffers are compared as {key -> slots} after decoding; keys/ints bit-exact."""
 import os
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,42 @@ def test_baseline_table_full_reports_out_of_slots(oracle, gpu_executor_factory):
     with pytest.raises(HdkHipError) as ei:
         gpu_executor_factory(st).execute(cp)
     assert ei.value.code == A.ERR_OUT_OF_SLOTS
+
+
+def test_planner_sized_table_is_retried_with_a_doubled_guess(oracle, gpu_executor_factory):
+    """Statistics narrower than the data (round 5's advisor finding): cast(x as double) has no integer range, so the table is
+    sized 2 x the NDV bound the statistics give (plan.py) -- here [1, 5] for a column holding 5 000 values.  The launch runs out
+    of slots; Executor.execute re-runs with the reference's doubled max_groups_buffer_entry_guess
+    (QE/RelAlgExecutor.cpp:1731-1747) instead of failing.  A caller-pinned entry count still reports ERR_OUT_OF_SLOTS (above)."""
+    from hdk_amd.ir import Cast, FP64
+    from hdk_amd.storage import ChunkStats
+    rng = np.random.default_rng(41)
+    n = 60_000
+    st = ArrowStorage()
+    st.import_numpy("t", {"x": rng.integers(1, 5_001, n).astype(np.int32), "v": rng.integers(-100, 100, n, dtype=np.int64)},
+                    fragment_size=20_000)
+    q = QueryUnit("t", groupby=[Cast(ColRef("x"), FP64)], targets=[KeyRef(0, "k"), Agg("sum", ColRef("v"), "s"), Agg("count", None, "c")])
+    _, want, err = run_oracle(oracle, st, dataclasses.replace(q, baseline_entry_count=16_384))
+    assert err == 0
+    col = st.get("t").columns["x"]
+    col.stats = [ChunkStats(1, 5, False) for _ in col.stats]
+    ex = gpu_executor_factory(st)
+    from hdk_amd import plan as P
+    old = P.BIG_GROUP_THRESHOLD
+    P.BIG_GROUP_THRESHOLD = 1_000  # (so that 60 K rows count as a big input and the NDV bound is what sizes the table)
+    try:
+        first = ex.compile(q)
+        assert first.entry_count < 100, first.entry_count
+        res = ex.execute(q)
+    finally:
+        P.BIG_GROUP_THRESHOLD = old
+    assert res.error_code == 0 and res.entry_count == 16_384
+    got = res.to_columns()
+    wcp = ex.compile(dataclasses.replace(q, baseline_entry_count=16_384))
+    from hdk_amd.executor import ExecutionResult
+    wantc = ExecutionResult(wcp, want, 16_384).to_columns()
+    assert sorted(zip(got["k"], got["s"], got["c"])) == sorted(zip(wantc["k"], wantc["s"], wantc["c"]))
+    assert len(got["k"]) == len(np.unique(np.concatenate(col.fragments)))
 
 
 def test_perfect_hash_via_global_atomics(oracle, gpu_executor_factory):
@@ -383,6 +421,15 @@ def test_chunked_exchange_pipeline_on_three_streams(oracle, gpu_executor_factory
     for _ in range(2):  # (a second step over the same buffers: chunk 0 rewrites the table)
         pipe.run(wire, after=torch.cuda.current_stream())
     torch.cuda.synchronize()
+    assert pipe.error_codes() == [0] * len(steps)
+    t = table.cpu().numpy()
+    _check_rows(cp, t, want)
+    _assert_reference_placement(oracle, cp, t)
+    # ... and back to back with NO `after` and no synchronisation between steps: run() orders step n + 1 after step n's
+    # ev_done itself (send / recv / the owner's table are reused by every step)
+    for _ in range(6):
+        pipe.run(wire)
+    pipe.ev_done.synchronize()
     assert pipe.error_codes() == [0] * len(steps)
     t = table.cpu().numpy()
     _check_rows(cp, t, want)

@@ -32,7 +32,21 @@ def _run(config, rows, extra_env=None, scaling="strong", ranks=2):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
-    return json.loads(lines[0])
+    return _headline(r.stdout, lines[0])
+
+
+def _headline(stdout, text):
+    """The driver's contract for the line: the LAST stdout line, compact, with the roofline object in it."""
+    assert stdout.rstrip("\n").splitlines()[-1] == text
+    assert len(text) < 4096, len(text)
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "checks", "detail"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert os.path.exists(os.path.join(ROOT, line["detail"]))
+    return line
 
 
 def _all_checks_hold(line):
@@ -87,7 +101,7 @@ def _run_rccl_single_rank(config, rows, extra_env=None):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    return _headline(r.stdout, lines[0])
 
 
 def test_rccl_branch_with_one_rank_gather_and_fold():
@@ -129,7 +143,7 @@ def test_plain_python_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    line = json.loads(lines[0])
+    line = _headline(r.stdout, lines[0])
     assert line["n_gpus"] == 2 and line["ranks_seen_by_collective"] == 2
     _all_checks_hold(line)
 
@@ -143,3 +157,23 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-1000:]
     assert "WORLD_SIZE" in r.stderr
+
+
+def test_default_command_prints_a_parsable_headline():
+    """`python bench.py` exactly as the driver runs it at N = 1 (BASELINE size, every secondary config, CPU baseline, end-to-end
+    leg, emulations): the last stdout line is the compact headline with `roofline` and `cpu_baseline` filled in."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HDK_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = _headline(r.stdout, r.stdout.rstrip("\n").splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["rows"] == 1_000_000_000 and line["dtype"] == "int64"
+    assert 0.5 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["traffic"]
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["unit"] == "rows/s"
+    _all_checks_hold(line)
+    assert len(line["configs"]) >= 13 and all(ok for _, _, ok in line["configs"].values()), line["configs"]
+    with open(os.path.join(ROOT, line["detail"])) as f:
+        full = json.load(f)
+    assert full["value"] == line["value"] and len(full["configs"]) == len(line["configs"])

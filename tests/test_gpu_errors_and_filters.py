@@ -137,6 +137,47 @@ def test_or_filters_on_the_streaming_kernels(oracle, gpu_executor_factory):
                 assert_buffers_equal(cp, other.buffer, want)
 
 
+def test_filter_program_deeper_than_the_streaming_stack(oracle, gpu_executor_factory):
+    """`(a AND b) OR ((a AND c) OR (b AND c))`: three leaves (plan.py deduplicates them), eleven ops, a value stack of FOUR --
+    one more than the streaming kernels' evaluators keep in registers (plain_quals.h, scan_agg_fast.h).  The matchers must
+    hand it to the interpreter (host_match.h: filter_program_depth); the result equals the oracle's either way."""
+    from hdk_amd.ir import Cast, FP64
+    from test_gpu_baseline import _check_rows
+    rng = np.random.default_rng(78)
+    n = 400_000
+    c = rng.integers(-50, 50, n).astype(np.int32)
+    c[rng.random(n) < 0.1] = A.NULL_INT
+    val = rng.integers(-2**31, 2**31, n, dtype=np.int64)
+    val[rng.random(n) < 0.05] = A.NULL_BIGINT
+    y = rng.integers(1, 11, n).astype(np.int32)
+    y[rng.random(n) < 0.05] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", {"key": rng.integers(0, 64, n, dtype=np.int64), "val": val, "c": c, "x": rng.integers(1, 20, n).astype(np.int32),
+                          "y": y}, fragment_size=n // 3 + 7)
+    K, V, C_ = ColRef("key"), ColRef("val"), ColRef("c")
+    a, b, cc = Cmp(C_, "<", Lit(10)), Cmp(V, ">", Lit(0)), Cmp(K, "<>", Lit(7))
+    deep = [Or(And(a, b), Or(And(a, cc), And(b, cc)))]
+    left = [Or(Or(And(a, b), And(a, cc)), And(b, cc))]  # (the same predicate, left-nested: depth 3, stays on the streaming kernels)
+    for quals, streaming in ((deep, False), (left, True)):
+        shapes = [
+            (QueryUnit("t", quals=quals, groupby=[K], targets=[KeyRef(0, "k"), Agg("sum", V, "s")]), "hdk_scan_agg_direct"),
+            (QueryUnit("t", quals=quals, groupby=[Cast(ColRef("x"), FP64)],
+                       targets=[KeyRef(0, "k"), Agg("count", ColRef("y"), "n"), Agg("sum", ColRef("y"), "s")]), "hdk_scan_agg_bh_dense"),
+        ]
+        for q, kernel in shapes:
+            cp, want, err = run_oracle(oracle, st, q)
+            assert err == 0 and cp.plan.num_quals == 3 and cp.plan.num_filter_ops == 11
+            step = gpu_executor_factory(st).prepare(cp)
+            names = step.kernel_names()
+            assert names.startswith(kernel) == streaming and ("_vec" in names) != streaming, (quals, names)
+            res = step.run()
+            step.free()
+            if cp.plan.query_kind == A.Q_BASELINE_HASH:
+                _check_rows(cp, res.buffer, want)
+            else:
+                assert_buffers_equal(cp, res.buffer, want)
+
+
 def _expect_error(oracle, gpu_executor_factory, st, q, code):
     cp, want, err = run_oracle(oracle, st, q)
     assert err == code, err

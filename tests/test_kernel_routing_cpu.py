@@ -71,6 +71,27 @@ def test_headline_and_its_neighbours(storage):
     assert _names(compile_query(storage, two_keys_or)).startswith("hdk_scan_agg_vec")
 
 
+def test_filter_program_deeper_than_three_goes_to_the_interpreter(storage):
+    """Round 5's advisor finding: the streaming evaluators keep a three-value stack; `(a AND b) OR ((a AND c) OR (b AND c))`
+    needs four (three deduplicated leaves, eleven ops).  It must route to the interpreter; its left-nested form stays."""
+    from hdk_amd.ir import And
+    K, V, C_ = ColRef("key"), ColRef("val"), ColRef("c")
+    a, b, c = Cmp(C_, "<", Lit(10)), Cmp(V, ">", Lit(0)), Cmp(K, "<>", Lit(7))
+    deep = [Or(And(a, b), Or(And(a, c), And(b, c)))]
+    left = [Or(Or(And(a, b), And(a, c)), And(b, c))]
+    for quals, streaming in ((deep, False), (left, True)):
+        q = QueryUnit("t", quals=quals, groupby=[K], targets=[KeyRef(0), Agg("sum", V)])
+        cp = compile_query(storage, q)
+        assert cp.plan.num_quals == 3 and cp.plan.num_filter_ops == 11
+        assert (_names(cp) == "hdk_scan_agg_direct,hdk_finalize") == streaming, (quals, _names(cp))
+        assert _names(cp).startswith("hdk_scan_agg_vec") != streaming
+        y = ColRef("y10")
+        ya, yb, yc = Cmp(y, "<=", Lit(7)), Cmp(ColRef("x10"), ">", Lit(2)), Cmp(ColRef("x1k"), "<>", Lit(5))
+        yq = [Or(And(ya, yb), Or(And(ya, yc), And(yb, yc)))] if not streaming else [Or(Or(And(ya, yb), And(ya, yc)), And(yb, yc))]
+        names = _names(compile_query(storage, _bh("x10", quals=yq)))
+        assert names.startswith("hdk_scan_agg_bh_dense,") == streaming and ("_vec" in names) != streaming, names
+
+
 def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     """BH001 / BH003 / BH005 (bench.py lines) and what their switches select."""
     one_pass = "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs"
@@ -166,3 +187,16 @@ def test_star_schema_shapes_take_the_sliced_join():
         assert _names(_fused(cp)) == want, (name, _names(_fused(cp)))
     # a small fact table: nothing to slice for -- row order (the interpreter / the direct kernel)
     assert "hdk_join_scatter_slices" not in _names(_fused(compile_query(st, shapes["c3g"][0])), total_rows=1_000_000)
+
+
+def test_non_grouped_benchmark_queries_stream_column_by_column():
+    """NonGroupedAgg/NGA01-05.sql (six aggregates over six INT columns) used to run on the batched interpreter: now the
+    column-by-column streaming kernel (scan_agg_cols.h); a filter (rows tie the columns together) keeps the interpreter."""
+    from syn_queries import NGA_COLS, nga, syn_table
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(np.random.default_rng(5), 50_000, NGA_COLS, null_frac=0.02), fragment_size=20_000)
+    for i in range(1, 6):
+        assert _names(compile_query(st, nga(i))) == "hdk_scan_agg_cols,hdk_finalize", i
+        assert _names(compile_query(st, nga(i)), flags=A.LAUNCH_FORCE_GENERIC) == "hdk_scan_agg_vec,hdk_finalize"
+    filtered = QueryUnit("syn", quals=[Cmp(ColRef("x10"), ">", Lit(3))], targets=[Agg("sum", ColRef("x100")), Agg("sum", ColRef("y100"))])
+    assert _names(compile_query(st, filtered)) == "hdk_scan_agg_vec,hdk_finalize"
