@@ -188,6 +188,7 @@ struct FinalizeArgs {
   int64_t** groupby_buf;  // GROUPBY_BUF
   uint32_t num_slabs;
   uint32_t entry_count;
+  const uint32_t* skip_if;  // nullptr, or: do nothing when *skip_if != 0 (slabs of a strategy whose statistics did not hold)
 };
 
 HDK_DEV int64_t shfl_down_i64(int64_t v, int delta) {
@@ -288,6 +289,9 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
   __shared__ WordLayout wl;
   __shared__ int64_t s_words[kBlock / kWave][kMaxWordsPerEntry];
   const hdk_hip_plan* __restrict__ p = a.plan;
+  if (a.skip_if && *a.skip_if) {
+    return;
+  }
   if (threadIdx.x == 0) {
     make_word_layout(p, &wl);
   }
@@ -440,6 +444,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
 
 #include "host_match.h"
 #include "scan_bh_host.h"
+#include "scan_bhm_host.h"
 #include "scan_agg_fast.h"
 #include "scan_agg_cols.h"
 #include "scan_agg_vec.h"
@@ -2472,6 +2477,21 @@ static int32_t launch_cluster_join(ClusterArgs ca, KernParams* kp, const hdk_hip
   return HDK_HIP_OK;
 }
 
+int32_t hdk::launch_finalize_slabs(const hdk_hip_plan* d_plan, const int64_t* slabs, int64_t** groupby_buf, uint32_t num_slabs,
+                                   uint32_t entry_count, const uint32_t* skip_if, hipStream_t s) {
+  FinalizeArgs fa;
+  fa.plan = d_plan;
+  fa.slabs = slabs;
+  fa.groupby_buf = groupby_buf;
+  fa.num_slabs = num_slabs;
+  fa.entry_count = entry_count;
+  fa.skip_if = skip_if;
+  const unsigned fblocks = (entry_count + (kBlock / kWave) - 1) / (kBlock / kWave);
+  hipLaunchKernelGGL(hdk_finalize, dim3(fblocks), dim3(kBlock), 0, s, fa);
+  HDK_HIP_CHECK(hipGetLastError());
+  return HDK_HIP_OK;
+}
+
 // HDK_HIP_LAUNCH_INIT_OUTPUT for the strategies that do not fuse it: the init kernel, on the launch stream
 static int32_t init_row_wise_output(const hdk_hip_plan* plan, int8_t* const params[HDK_KP_COUNT], int32_t device_id,
                                     hipStream_t s) {
@@ -2584,6 +2604,7 @@ extern "C" int32_t hdk_hip_launch(const hdk_hip_plan* plan, int8_t* const params
       HDK_HIP_CHECK(hipEventRecord(e1, s));
     }
     FinalizeArgs fa;
+    fa.skip_if = nullptr;
     fa.plan = d_plan;
     fa.slabs = slabs;
     fa.groupby_buf = kp.groupby_buf;

@@ -7,6 +7,7 @@
 #define HDK_SCAN_AGG_GLOBAL_KERNEL
 #include "host_match.h"
 #include "scan_bh_host.h"
+#include "scan_bhm_host.h"
 #include "scan_agg_baseline_fast.h"
 #include "scan_agg_global.h"
 #include "scan_agg_partitioned.h"
@@ -632,6 +633,17 @@ static int32_t launch_scan_global(const hdk_hip_plan* plan, const hdk_hip_plan* 
   hipLaunchKernelGGL(hdk_scan_agg_global, dim3(shape.grid), dim3(kGlobalBlock), 0, s, a);
   HDK_HIP_CHECK(hipGetLastError());
   return HDK_HIP_OK;
+}
+
+int32_t launch_scan_global_armed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp,
+                                 const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props, hipStream_t s,
+                                 const uint32_t* run_if) {
+  LaunchShape shape;
+  memset(&shape, 0, sizeof(shape));
+  shape.strategy = STRAT_GLOBAL;
+  shape.entry_count = plan->entry_count;
+  shape.grid = baseline_grid(plan, ko, props);
+  return launch_scan_global(plan, d_plan, kp, shape, s, true, run_if);
 }
 
 uint32_t baseline_grid(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, const hdk_hip_device_properties* props) {

@@ -6,6 +6,7 @@
 #include "scan_bh_packed.h"
 #include "scan_bh_dense_part.h"
 #include "scan_bh_host.h"
+#include "scan_bhm_host.h"
 
 namespace hdk {
 
@@ -343,7 +344,7 @@ const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_op
   if (match_bh_dense_part(p, ko, &dg, &dl)) return "hdk_bh_dscatter,hdk_bh_daggregate";
   BhPartLayout l;
   if (match_bh_partitioned(p, ko, &a, &l)) return "hdk_bh_scatter,hdk_bh_aggregate";
-  return nullptr;
+  return bhm_kernel_name(p, ko);  // several argument columns / key columns: scan_bhm.hip
 }
 
 static int32_t launch_bh_partitioned(const hdk_hip_plan* d_plan, const KernParams& kp, BhPackedArgs& a, const BhPartLayout& l,
@@ -389,7 +390,7 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
     if (match_bh_dense_part(plan, ko, &dg, &dl)) return launch_bh_dense_part(d_plan, kp, dg, dl, props, s, launched);
     BhPartLayout l;
     if (match_bh_partitioned(plan, ko, &a, &l)) return launch_bh_partitioned(d_plan, kp, a, l, props, s, launched);
-    return HDK_HIP_OK;
+    return launch_bhm(plan, d_plan, kp, ko, props, s, launched);
   }
   a.plan = d_plan;
   a.kp = kp;

@@ -11,6 +11,7 @@ namespace hdk {
   X(BH_DIRECT_FOLD)                 \
   X(BH_FOLD_GROUPS)                 \
   X(BH_PARTITIONS_ALWAYS)           \
+  X(BHM_BLOCKS_PER_CU)              \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(COLS_BLOCKS_PER_CU)             \
@@ -25,6 +26,7 @@ namespace hdk {
   X(NO_BH_PACKED)                   \
   X(NO_BH_PARTITIONS)               \
   X(NO_BH_PLAIN)                    \
+  X(NO_BHM)                         \
   X(NO_COLS_KERNEL)                 \
   X(NO_PERFECT_PARTITIONS)          \
   X(NO_SLICED2)                     \

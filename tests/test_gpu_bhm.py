@@ -1,0 +1,148 @@
+"""The multi-argument / multi-key on-chip group-by (hdk_scan_agg_bhm, hdk_amd/csrc/scan_bhm.h) against the oracle: the
+reference's MultiStep (MSBS001, MSPHS001) and PerfectHashMultiCol (PHM001, PHM002) benchmark shapes and their edge cases --
+NULL keys and arguments, statistics that do not hold (the armed fallback), ragged fragments, row-wise and columnar tables,
+few groups (replicated LDS tables) and thousands (one 1024-thread block per CU).  Integers bit-exact; placement of an
+open-addressing table asserted through the reference's probe sequence."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from hdk_amd import _abi as A
+from hdk_amd.ir import Agg, Cast, ColRef, FP64, KeyRef, QueryUnit
+from hdk_amd.storage import ArrowStorage
+
+from syn_queries import msbs, msphs, phm, syn_table
+from test_gpu_baseline import _assert_reference_placement, _check_rows
+from util import assert_buffers_equal, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+BHM = "hdk_scan_agg_bhm"
+
+
+def _run(oracle, make, st, q, kernel=BHM):
+    cp, want, err = run_oracle(oracle, st, q)
+    assert err == 0
+    step = make(st).prepare(cp)
+    assert step.kernel_names().split(",")[0] == kernel, step.kernel_names()
+    res = step.run()
+    step.free()
+    if cp.plan.query_kind == A.Q_BASELINE_HASH:
+        _check_rows(cp, res.buffer, want)
+        if not cp.plan.output_columnar:
+            _assert_reference_placement(oracle, cp, res.buffer)
+    else:
+        assert_buffers_equal(cp, res.buffer, want)
+    other = make(st).execute(cp, flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS)  # the reference's own scheme gives the same groups
+    if cp.plan.query_kind == A.Q_BASELINE_HASH:
+        _check_rows(cp, other.buffer, want)
+    else:
+        assert_buffers_equal(cp, other.buffer, want)
+    return cp, res
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.04])
+def test_multistep_and_multicol_benchmark_shapes(oracle, gpu_executor_factory, null_frac):
+    rng = np.random.default_rng(21)
+    n = 900_007
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(rng, n, ("x10", "y10", "z10", "x100", "x1k"), null_frac=null_frac), fragment_size=300_011)
+    for q in (msbs(1, key_type=FP64), msphs(1), phm(1), phm(2)):
+        cp, res = _run(oracle, gpu_executor_factory, st, q)
+        step = gpu_executor_factory(st).prepare(cp)
+        names = step.kernel_names()
+        step.free()
+        assert names.endswith("hdk_bhm_fold" if cp.plan.query_kind == A.Q_BASELINE_HASH else "hdk_finalize"), names
+    # columnar output tables
+    for q in (msphs(1), phm(2), msbs(1, key_type=FP64)):
+        _run(oracle, gpu_executor_factory, st, dataclasses.replace(q, output_columnar=True))
+
+
+def test_few_groups_replicated_tables_and_every_aggregate(oracle, gpu_executor_factory):
+    """Ten groups (sixteen LDS replicas), MIN and MAX and AVG and COUNT of three columns, `column - literal` and
+    `column * literal` arguments, negative values."""
+    rng = np.random.default_rng(22)
+    n = 500_003
+    a = rng.integers(-500, 500, n).astype(np.int32)
+    a[rng.random(n) < 0.05] = A.NULL_INT
+    b = rng.integers(0, 70_000, n).astype(np.int32)
+    c = rng.integers(-3, 4, n).astype(np.int32)
+    c[rng.random(n) < 0.5] = A.NULL_INT
+    k = rng.integers(-4, 6, n).astype(np.int32)
+    k[rng.random(n) < 0.02] = A.NULL_INT
+    st = ArrowStorage()
+    st.import_numpy("t", {"k": k, "a": a, "b": b, "c": c}, fragment_size=170_001)
+    A_, B_, C_ = ColRef("a"), ColRef("b"), ColRef("c")
+    # (HDK_HIP_MAX_TARGETS = 8 per plan)
+    t1 = [KeyRef(0, "k"), Agg("count", None, "n"), Agg("min", A_, "mna"), Agg("max", A_, "mxa"), Agg("avg", A_, "ava"),
+          Agg("sum", A_ * 3, "s3a"), Agg("count", C_, "cc"), Agg("max", B_ - 7, "mxb")]
+    t2 = [KeyRef(0, "k"), Agg("min", C_, "mnc"), Agg("sum", B_, "sb"), Agg("avg", C_, "avc"), Agg("min", B_, "mnb"), Agg("max", C_, "mxc")]
+    for groupby in ([ColRef("k")], [Cast(ColRef("k"), FP64)]):
+        for targets in (t1, t2):
+            _run(oracle, gpu_executor_factory, st, QueryUnit("t", groupby=groupby, targets=targets))
+
+
+def test_three_key_columns_and_three_argument_columns(oracle, gpu_executor_factory):
+    rng = np.random.default_rng(23)
+    n = 400_009
+    st = ArrowStorage()
+    cols = {"k0": rng.integers(1, 8, n).astype(np.int32), "k1": rng.integers(-3, 4, n).astype(np.int32),
+            "k2": rng.integers(100, 120, n).astype(np.int32), "a": rng.integers(0, 1000, n).astype(np.int32),
+            "b": rng.integers(-50, 50, n).astype(np.int32), "c": rng.integers(1, 5, n).astype(np.int32)}
+    cols["k1"][rng.random(n) < 0.03] = A.NULL_INT
+    cols["b"][rng.random(n) < 0.1] = A.NULL_INT
+    st.import_numpy("t", cols, fragment_size=150_000)
+    q = QueryUnit("t", groupby=[ColRef("k0"), ColRef("k1"), ColRef("k2")],
+                  targets=[KeyRef(0, "k0"), KeyRef(1, "k1"), KeyRef(2, "k2"), Agg("sum", ColRef("a"), "sa"), Agg("max", ColRef("a"), "mxa"),
+                           Agg("avg", ColRef("b"), "avb"), Agg("min", ColRef("b") + 1, "mnb"), Agg("count", ColRef("c"), "cc")])
+    _run(oracle, gpu_executor_factory, st, q)
+
+
+def test_statistics_that_do_not_hold_take_the_armed_fallback(oracle, gpu_executor_factory):
+    """An argument outside its announced range, a NULL where the statistics announce none, a key outside the table's range:
+    the on-chip kernel raises its flag, its folds skip, and the global-atomics kernel armed behind them redoes the launch --
+    the result is the oracle's either way (never a wrong result from stale metadata)."""
+    rng = np.random.default_rng(24)
+    n = 300_000
+    base = syn_table(rng, n, ("x10", "x100", "x1k"))
+    for what in ("argument", "null", "key"):
+        cols = {c: v.copy() for c, v in base.items()}
+        st = ArrowStorage()
+        st.import_numpy("syn", cols, fragment_size=100_000)
+        t = st.get("syn")
+        if what == "argument":
+            t.columns["x100"].fragments[1][777] = 100_000  # statistics say [1, 100]
+        elif what == "null":
+            t.columns["x10"].fragments[2][5] = A.NULL_INT  # has_nulls = False
+        for q in (msphs(1), msbs(1, key_type=FP64)):
+            if what == "key":
+                if q.groupby[0] == ColRef("x1k"):
+                    continue  # (a perfect-hash key outside its range is OUT_OF_SLOTS by contract)
+                t.columns["x1k"].fragments[0][3] = 1234  # an open-addressing key outside the dense range: still a valid group
+            cp, want, err = run_oracle(oracle, st, q)
+            assert err == 0
+            step = gpu_executor_factory(st).prepare(cp)
+            assert step.kernel_names().startswith(BHM)
+            res = step.run()
+            step.free()
+            if cp.plan.query_kind == A.Q_BASELINE_HASH:
+                _check_rows(cp, res.buffer, want)
+            else:
+                assert_buffers_equal(cp, res.buffer, want)
+
+
+def test_routing_limits(oracle, gpu_executor_factory):
+    """What stays with the other kernels: one plain argument column (the packed kernels), tables beyond LDS."""
+    rng = np.random.default_rng(25)
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(rng, 200_000, ("x10", "y10", "x100", "x1k", "x100k")), fragment_size=100_000)
+    y = ColRef("y10")
+    one_arg = QueryUnit("syn", groupby=[Cast(ColRef("x1k"), FP64)], targets=[KeyRef(0, "k")] + [Agg(kd, y) for kd in ("count", "sum", "max", "min", "avg")])
+    ex = gpu_executor_factory(st)
+    s1 = ex.prepare(ex.compile(one_arg))
+    assert s1.kernel_names().startswith("hdk_scan_agg_bh_dense")
+    s1.free()
+    s2 = ex.prepare(ex.compile(msphs(3)))
+    assert not s2.kernel_names().startswith(BHM)
+    s2.free()

@@ -200,3 +200,28 @@ def test_non_grouped_benchmark_queries_stream_column_by_column():
         assert _names(compile_query(st, nga(i)), flags=A.LAUNCH_FORCE_GENERIC) == "hdk_scan_agg_vec,hdk_finalize"
     filtered = QueryUnit("syn", quals=[Cmp(ColRef("x10"), ">", Lit(3))], targets=[Agg("sum", ColRef("x100")), Agg("sum", ColRef("y100"))])
     assert _names(compile_query(st, filtered)) == "hdk_scan_agg_vec,hdk_finalize"
+
+
+def test_multistep_and_multicol_benchmark_shapes_stay_on_chip():
+    """MultiStep/MSBS001, MSPHS001 (six aggregates over two columns and an expression, 1 000 groups) and
+    PerfectHashMultiCol/PHM001-002 (two key columns) used to fall to global atomics, the interpreter or the perfect-partitioned
+    passes: now the multi-argument on-chip kernel (scan_bhm.h).  Its switch gives the old routes back."""
+    from syn_queries import msbs, msphs, phm, syn_table
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(np.random.default_rng(6), 60_000, ("x10", "y10", "z10", "x100", "x1k")), fragment_size=20_000)
+    for q, fold in ((msbs(1, key_type=FP64), "hdk_bhm_fold"), (msphs(1), "hdk_finalize"), (phm(1), "hdk_finalize"), (phm(2), "hdk_finalize")):
+        names = _names(compile_query(st, q))
+        assert names == f"hdk_scan_agg_bhm,{fold}", (q.groupby, names)
+        assert "global" not in names and "hdk_pp_" not in names and "_vec" not in names
+    assert _names(compile_query(st, msphs(1)), flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).startswith("hdk_scan_agg_global")
+    # unknown row bound: the packed fields cannot be sized -- the general routes
+    assert "bhm" not in _names(compile_query(st, msphs(1)), total_rows=0)
+
+
+def test_multistep_switch_gives_the_old_routes_back(monkeypatch):
+    from syn_queries import msphs, phm, syn_table
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(np.random.default_rng(6), 60_000, ("x10", "y10", "z10", "x100", "x1k")), fragment_size=20_000)
+    monkeypatch.setenv("HDK_HIP_NO_BHM", "1")
+    assert _names(compile_query(st, msphs(1))).startswith("hdk_scan_agg_global")
+    assert _names(compile_query(st, phm(1))).startswith("hdk_scan_agg_vec")
