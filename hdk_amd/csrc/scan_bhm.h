@@ -18,7 +18,11 @@
 //     row reads the word (ds_read_b64), compares all fields at once ((cur | guards) - candidates keeps every guard bit iff no
 //     field improves) and only then -- after a group's first rows, never -- runs a compare-and-swap loop;
 //   * arguments may be `column op literal` (+ - *), several arguments may read the same column: it is streamed once.
-// MSBS001's six aggregates are two ds_add_u64 and one ds_read_b64 a row, 24 bytes of LDS per group.
+// MSBS001's six aggregates are two ds_add_u64 and one ds_read_b32 a row, 20 bytes of LDS per group.
+// Two forms of the same row body: SHAPES the suite uses (which argument has a packed word, a MAX / MIN field, an `op literal`
+// step; no NULLs announced; all fields inside 32 bits) are compile-time constants of their own instantiations (BhmStatic: the
+// per-row code has no branch and no select left); every other shape runs the same body with the descriptors read at run time
+// (BhmDynamic: uniform branches, slower, any combination).
 // At the end a block decodes its table into a slab of the generic partial-aggregate words (agg_common.h); a GroupByPerfectHash
 // plan's slabs are folded by hdk_finalize (the internal index IS the plan's), an open-addressing plan's by hdk_bhm_fold
 // (find_or_claim on the reference's probe sequence, once per group).
@@ -35,10 +39,8 @@ namespace hdk {
 
 constexpr int kBhmMaxKeys = 3;
 constexpr int kBhmMaxSrc = 3;     // streamed argument columns
-constexpr int kBhmMaxDer = 2;     // arguments derived from one column (the column itself, column op literal)
-constexpr int kBhmMaxPacked = kBhmMaxSrc * kBhmMaxDer;
-constexpr int kBhmMaxFields = 2 * kBhmMaxSrc * kBhmMaxDer;
-constexpr int kBhmMaxMm = 2;      // 64-bit MIN / MAX words per entry
+constexpr int kBhmMaxDer = 4;     // arguments in all: a column itself, or `column op literal`
+constexpr int kBhmMaxFields = 2 * kBhmMaxDer;
 constexpr int kBhmSumBits = 40;
 
 enum BhmWordKind : int32_t { BMW_ROWS = 0, BMW_SUM = 1, BMW_NN = 2, BMW_MIN = 3, BMW_MAX = 4 };
@@ -54,35 +56,40 @@ struct BhmKey {
   uint32_t pad_;
 };
 
+// a MIN / MAX field of the entry's 64-bit word (two 32-bit halves; a field lies inside one of them)
+struct BhmField {
+  uint32_t shift;       // inside its half
+  uint32_t mask_lo;     // the code's bits (without the guard bit), unshifted, when the field is in the low half, else 0
+  uint32_t mask_hi;     // ... in the high half
+  int32_t bias;         // MAX: code = v - bias (bias = smallest value - 1);  MIN: code = bias - v (bias = largest value + 1)
+};
+
 struct BhmDer {
-  int32_t op;         // 0: the column's value; HDK_OP_ADD / HDK_OP_SUB / HDK_OP_MUL with `lit`
-  int32_t lit;
-  int32_t packed;     // index of its [rows : sum] word, or -1
-  int32_t mx_word, mn_word;  // which MIN / MAX word holds its MAX / MIN field, or -1
-  uint32_t mx_shift, mn_shift;
-  int32_t mx_bias;    // MAX code = v - mx_bias + 1 (mx_bias = the smallest value the statistics allow)
-  int32_t mn_bias;    // MIN code = mn_bias - v + 1 (mn_bias = the largest)
-  uint32_t mx_mask, mn_mask;  // the field without its guard bit, unshifted
-  uint32_t pad_;
+  int32_t src;          // argument column it reads
+  int32_t mul, add;     // value = column * mul + add (the column itself: 1, 0)
+  int32_t packed;       // index of its [non-NULL rows : sum] word, or -1
+  int32_t has_mx, has_mn;
+  BhmField mx, mn;
 };
 
 struct BhmSrc {
   int32_t buf_idx;
-  int32_t nullable;   // the column's in-band NULL is announced by the statistics and skipped by every target
+  int32_t nullable;     // the column's in-band NULL is announced by the statistics and skipped by every target
   int32_t null32;
-  int32_t raw_min;    // statistics of the column: raw - raw_min <= raw_span
+  int32_t raw_min;      // statistics of the column: raw - raw_min <= raw_span
   uint32_t raw_span;
-  int32_t nder;
-  BhmDer der[kBhmMaxDer];
+  uint32_t pad_;
 };
 
 // one word of the slab a block writes at the end (agg_common.h's layout)
 struct BhmSlabWord {
-  int32_t kind;       // BhmWordKind
-  int32_t packed;     // BMW_SUM / BMW_NN / BMW_ROWS: the packed word (ROWS: -1 = the 32-bit row counter)
-  int32_t mm_word;    // BMW_MIN / BMW_MAX (and BMW_NN of an argument without a packed word: non-NULL iff its field is not 0)
+  int32_t kind;         // BhmWordKind
+  int32_t packed;       // BMW_SUM / BMW_NN / BMW_ROWS: the packed word (ROWS: -1 = the 32-bit row counter)
+  int32_t in_mm;        // BMW_MIN / BMW_MAX (and BMW_NN of an argument without a packed word: non-NULL iff its field is not 0)
+  int32_t half;
   uint32_t shift, mask;
   int32_t bias;
+  int32_t pad_;
 };
 
 struct BhmArgs {
@@ -98,43 +105,109 @@ struct BhmArgs {
   uint32_t off_rows;
   uint32_t lds_bytes;
   uint32_t max_rows_per_block;  // what the packed fields were sized for
-  int32_t nkeys, nsrc;
-  int32_t npacked, nmm;
+  int32_t nkeys, nsrc, nder;
+  int32_t npacked;
+  int32_t mm_bytes;        // 0: no MIN / MAX; 4: all fields inside 32 bits; 8
   int32_t rows_packed;     // packed word whose count is the row count, or -1: the 32-bit counters
   int32_t wpe;
+  int32_t any_nullable;    // some key or argument column has a NULL to look for
   BhmKey key[kBhmMaxKeys];
   BhmSrc src[kBhmMaxSrc];
-  uint64_t guards[kBhmMaxMm];    // guard bits of the fields of each MIN / MAX word
-  int32_t nfields[kBhmMaxMm];
-  uint32_t fshift[kBhmMaxMm][kBhmMaxFields];
-  uint32_t fmask[kBhmMaxMm][kBhmMaxFields];
+  BhmDer der[kBhmMaxDer];
+  uint32_t guard_lo, guard_hi;   // guard bits of the fields
+  int32_t nfields;
+  int32_t pad_;
+  uint32_t fshift[kBhmMaxFields], fmask[kBhmMaxFields], fhalf[kBhmMaxFields];
   BhmSlabWord sw[kMaxWordsPerEntry];
   // open-addressing plans: the key word of internal entry i (hdk_bhm_fold)
   int32_t key_form;        // 0: the key column's value; 1: cast(integer AS double)
-  int32_t pad_;
+  int32_t pad2_;
   int64_t key_null_word;   // key word of the NULL key's entry
 };
 
-HDK_DEV int32_t bhm_apply(int32_t op, int32_t raw, int32_t lit) {
-  return op == 0 ? raw : (op == HDK_OP_ADD ? raw + lit : (op == HDK_OP_SUB ? raw - lit : raw * lit));
+// ---- the shape of a plan's arguments, as compile-time constants or read from the descriptors ------------------------------
+// code of argument i: bits 0-1 the column, bit 2 a packed word, bit 3 a MAX field, bit 4 a MIN field, bits 5-6 the step
+// (0 none, 1 + literal (also -), 2 * literal); 0xFF: no such argument
+constexpr uint32_t kBhmNone = 0xFF;
+constexpr uint32_t bhm_code(int src, bool packed, bool mx, bool mn, int step) {
+  return static_cast<uint32_t>(src) | (packed ? 4u : 0u) | (mx ? 8u : 0u) | (mn ? 16u : 0u) | (static_cast<uint32_t>(step) << 5);
 }
+template <uint32_t D0, uint32_t D1 = kBhmNone, uint32_t D2 = kBhmNone, uint32_t D3 = kBhmNone>
+struct BhmStatic {
+  static constexpr bool kStatic = true;
+  static constexpr uint32_t code(int i) { return i == 0 ? D0 : (i == 1 ? D1 : (i == 2 ? D2 : D3)); }
+  HDK_DEV static bool used(const BhmArgs&, int i) { return code(i) != kBhmNone; }
+  HDK_DEV static int src(const BhmArgs&, int i) { return static_cast<int>(code(i) & 3u); }
+  HDK_DEV static bool packed(const BhmArgs&, int i) { return (code(i) & 4u) != 0; }
+  HDK_DEV static bool mx(const BhmArgs&, int i) { return (code(i) & 8u) != 0; }
+  HDK_DEV static bool mn(const BhmArgs&, int i) { return (code(i) & 16u) != 0; }
+  HDK_DEV static int step(const BhmArgs&, int i) { return static_cast<int>((code(i) >> 5) & 3u); }
+  HDK_DEV static bool nulls(const BhmArgs&) { return false; }
+  HDK_DEV static int mm_bytes(const BhmArgs&) { return ((D0 | (D1 == kBhmNone ? 0 : D1) | (D2 == kBhmNone ? 0 : D2) | (D3 == kBhmNone ? 0 : D3)) & 24u) ? 4 : 0; }
+};
+struct BhmDynamic {
+  static constexpr bool kStatic = false;
+  HDK_DEV static bool used(const BhmArgs& a, int i) { return i < a.nder; }
+  HDK_DEV static int src(const BhmArgs& a, int i) { return a.der[i].src; }
+  HDK_DEV static bool packed(const BhmArgs& a, int i) { return a.der[i].packed >= 0; }
+  HDK_DEV static bool mx(const BhmArgs& a, int i) { return a.der[i].has_mx != 0; }
+  HDK_DEV static bool mn(const BhmArgs& a, int i) { return a.der[i].has_mn != 0; }
+  HDK_DEV static int step(const BhmArgs& a, int i) { return a.der[i].mul != 1 ? 2 : (a.der[i].add != 0 ? 1 : 0); }
+  HDK_DEV static bool nulls(const BhmArgs& a) { return a.any_nullable != 0; }
+  HDK_DEV static int mm_bytes(const BhmArgs& a) { return a.mm_bytes; }
+};
 
-// per-field maximum of two MIN / MAX words (the rare path: a row improves some field)
-HDK_DEV uint64_t bhm_merge_fields(const BhmArgs& a, int w, uint64_t cur, uint64_t cand) {
-  uint64_t out = 0;
-  for (int f = 0; f < a.nfields[w]; ++f) {
-    const uint64_t m = static_cast<uint64_t>(a.fmask[w][f]) << a.fshift[w][f];
-    const uint64_t x = cur & m, y = cand & m;
-    out |= x > y ? x : y;
+// a row improves some MIN / MAX field (after a group's first rows: never): compare-and-swap until every field of the word is at
+// least the row's.  ONE inlined copy per row body (the caller walks its pending rows through it one after another).
+HDK_DEV void bhm_mm_improve(const BhmArgs& ar, uint32_t* word, uint32_t cand_lo, uint32_t cand_hi, int32_t mm_bytes) {
+  const BhmArgs* a = &ar;
+  const int nf = a->nfields;
+  if (mm_bytes == 4) {
+    uint32_t old = *word;
+    while (true) {
+      uint32_t merged = 0;
+      for (int f = 0; f < nf; ++f) {
+        const uint32_t m = a->fmask[f] << a->fshift[f];
+        const uint32_t x = old & m, y = cand_lo & m;
+        merged |= x > y ? x : y;
+      }
+      if (merged == old) {
+        return;
+      }
+      const uint32_t seen = atomicCAS(word, old, merged);
+      if (seen == old) {
+        return;
+      }
+      old = seen;
+    }
   }
-  return out;
+  unsigned long long* w64 = reinterpret_cast<unsigned long long*>(word);
+  unsigned long long old = *w64;
+  const unsigned long long cand = (static_cast<unsigned long long>(cand_hi) << 32) | cand_lo;
+  while (true) {
+    unsigned long long merged = 0;
+    for (int f = 0; f < nf; ++f) {
+      const unsigned long long m = static_cast<unsigned long long>(a->fmask[f]) << (a->fshift[f] + 32u * a->fhalf[f]);
+      const unsigned long long x = old & m, y = cand & m;
+      merged |= x > y ? x : y;
+    }
+    if (merged == old) {
+      return;
+    }
+    const unsigned long long seen = atomicCAS(w64, old, merged);
+    if (seen == old) {
+      return;
+    }
+    old = seen;
+  }
 }
 
 // NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s.  `stale` collects "the statistics do
 // not hold" (the caller raises the launch's flag).
-template <int NK, int NS, int NR>
+template <class C, int NK, int NS, int NR>
 HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR], const int32_t (&x)[NS][NR], uint32_t& stale) {
   const uint32_t dummy = a.entries;
+  const bool nulls = C::nulls(a);
   uint32_t e[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -144,104 +217,137 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
     for (int kk = 0; kk < NK; ++kk) {
       const BhmKey& key = a.key[kk];
       const int32_t kv = k[kk][j];
-      const bool isnull = (key.nullable != 0) & (kv == key.null32);
       uint32_t d = static_cast<uint32_t>(kv) - static_cast<uint32_t>(key.min);
-      bad = bad | (!isnull & (d >= key.n));
-      d = isnull ? key.null_d : d;
-      idx += __umul24(d, key.stride);
+      if (nulls) {
+        const bool isnull = (key.nullable != 0) & (kv == key.null32);
+        bad = bad | (!isnull & (d >= key.n));
+        d = isnull ? key.null_d : d;
+      } else {
+        bad = bad | (d >= key.n);
+      }
+      idx += NK == 1 ? d : __umul24(d, key.stride);
     }
     stale |= bad ? 1u : 0u;
     e[j] = bad ? dummy : idx;
   }
-  uint64_t cand0[NR], cand1[NR];
-#pragma unroll
-  for (int j = 0; j < NR; ++j) {
-    cand0[j] = 0;
-    cand1[j] = 0;
-  }
+  // the argument columns against their statistics; live: not NULL (and inside them)
+  bool live[NS][NR];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const BhmSrc& src = a.src[s];
-    bool live[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int32_t raw = x[s][j];
-      const bool isnull = (src.nullable != 0) & (raw == src.null32);
-      const bool out = !isnull & ((static_cast<uint32_t>(raw) - static_cast<uint32_t>(src.raw_min)) > src.raw_span);
-      stale |= out ? 1u : 0u;
-      live[j] = !isnull & !out;
+      const bool out = (static_cast<uint32_t>(raw) - static_cast<uint32_t>(src.raw_min)) > src.raw_span;
+      if (nulls) {
+        const bool isnull = (src.nullable != 0) & (raw == src.null32);
+        stale |= (out & !isnull) ? 1u : 0u;
+        live[s][j] = !isnull & !out;
+      } else {
+        stale |= out ? 1u : 0u;
+        live[s][j] = true;  // (a row outside the statistics raises the flag: what it adds is thrown away with the launch)
+      }
     }
+  }
+  uint32_t cand_lo[NR], cand_hi[NR];
 #pragma unroll
-    for (int i = 0; i < kBhmMaxDer; ++i) {
-      if (i < src.nder) {
-        const BhmDer& der = src.der[i];
-        if (der.packed >= 0) {
-          unsigned long long* pk = reinterpret_cast<unsigned long long*>(rp) + static_cast<uint32_t>(der.packed) * a.e1;
+  for (int j = 0; j < NR; ++j) {
+    cand_lo[j] = 0;
+    cand_hi[j] = 0;
+  }
+  const int mmb = C::mm_bytes(a);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            const int32_t v = bhm_apply(der.op, x[s][j], der.lit);
-            // (a NULL argument is not counted and not added: its increment goes to the dummy entry)
-            atomicAdd(pk + (live[j] ? e[j] : dummy),
-                      (1ull << kBhmSumBits) + static_cast<unsigned long long>(static_cast<long long>(v)));
-          }
+  for (int i = 0; i < kBhmMaxDer; ++i) {
+    if (C::used(a, i)) {
+      const BhmDer& der = a.der[i];
+      const int s = C::src(a, i);
+      int32_t v[NR];
+      bool lv[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        int32_t raw = x[0][j];
+        lv[j] = live[0][j];
+        if (NS > 1 && s == 1) {
+          raw = x[NS > 1 ? 1 : 0][j];
+          lv[j] = live[NS > 1 ? 1 : 0][j];
         }
-        if (der.mx_word >= 0) {
-#pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            const int32_t v = bhm_apply(der.op, x[s][j], der.lit);
-            const uint64_t c = live[j] ? static_cast<uint64_t>(static_cast<uint32_t>(v - der.mx_bias + 1) & der.mx_mask) << der.mx_shift : 0ull;
-            cand0[j] |= der.mx_word == 0 ? c : 0ull;
-            cand1[j] |= der.mx_word == 1 ? c : 0ull;
-          }
+        if (NS > 2 && s == 2) {
+          raw = x[NS > 2 ? 2 : 0][j];
+          lv[j] = live[NS > 2 ? 2 : 0][j];
         }
-        if (der.mn_word >= 0) {
+        const int st = C::step(a, i);
+        v[j] = st == 0 ? raw : (st == 1 ? raw + der.add : __mul24(raw, der.mul) + der.add);
+      }
+      if (C::packed(a, i)) {
+        unsigned long long* pk = reinterpret_cast<unsigned long long*>(rp) + static_cast<uint32_t>(der.packed) * a.e1;
 #pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            const int32_t v = bhm_apply(der.op, x[s][j], der.lit);
-            const uint64_t c = live[j] ? static_cast<uint64_t>(static_cast<uint32_t>(der.mn_bias - v + 1) & der.mn_mask) << der.mn_shift : 0ull;
-            cand0[j] |= der.mn_word == 0 ? c : 0ull;
-            cand1[j] |= der.mn_word == 1 ? c : 0ull;
-          }
+        for (int j = 0; j < NR; ++j) {
+          // (a NULL argument is not counted and not added: its increment goes to the dummy entry)
+          const uint32_t ej = nulls ? (lv[j] ? e[j] : dummy) : e[j];
+          atomicAdd(pk + ej, (1ull << kBhmSumBits) + static_cast<unsigned long long>(static_cast<long long>(v[j])));
+        }
+      }
+      if (C::mx(a, i)) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const uint32_t code = static_cast<uint32_t>(v[j] - der.mx.bias);
+          const uint32_t c = nulls ? (lv[j] ? code : 0u) : code;
+          cand_lo[j] |= (c & der.mx.mask_lo) << der.mx.shift;
+          if (mmb == 8) cand_hi[j] |= (c & der.mx.mask_hi) << der.mx.shift;
+        }
+      }
+      if (C::mn(a, i)) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const uint32_t code = static_cast<uint32_t>(der.mn.bias - v[j]);
+          const uint32_t c = nulls ? (lv[j] ? code : 0u) : code;
+          cand_lo[j] |= (c & der.mn.mask_lo) << der.mn.shift;
+          if (mmb == 8) cand_hi[j] |= (c & der.mn.mask_hi) << der.mn.shift;
         }
       }
     }
   }
   // MIN / MAX: look before touching
-#pragma unroll
-  for (int w = 0; w < kBhmMaxMm; ++w) {
-    if (w < a.nmm) {
-      unsigned long long* mm = reinterpret_cast<unsigned long long*>(rp + a.off_mm) + static_cast<uint32_t>(w) * a.e1;
-      const uint64_t H = a.guards[w];
-      uint64_t cur[NR];
+  if (mmb != 0) {
+    uint32_t better = 0;
+    if (mmb == 4) {
+      uint32_t* mm = reinterpret_cast<uint32_t*>(rp + a.off_mm);
+      const uint32_t H = a.guard_lo;
+      uint32_t cur[NR];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         cur[j] = mm[e[j]];
       }
-      uint32_t better = 0;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const uint64_t cd = w == 0 ? cand0[j] : cand1[j];
-        better |= ((((cur[j] | H) - cd) & H) != H) ? 1u << j : 0u;
+        better |= ((((cur[j] | H) - cand_lo[j]) & H) != H) ? 1u << j : 0u;
       }
-      if (__builtin_amdgcn_ballot_w64(better != 0)) {  // (after a group's first rows: never)
+    } else {
+      const uint2* mm = reinterpret_cast<const uint2*>(rp + a.off_mm);
+      const uint32_t Hl = a.guard_lo, Hh = a.guard_hi;
+      uint2 cur[NR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          if (better & (1u << j)) {
-            const uint64_t cd = w == 0 ? cand0[j] : cand1[j];
-            unsigned long long old = cur[j];
-            while (true) {
-              const unsigned long long merged = bhm_merge_fields(a, w, old, cd);
-              if (merged == old) {
-                break;
-              }
-              const unsigned long long seen = atomicCAS(mm + e[j], old, merged);
-              if (seen == old) {
-                break;
-              }
-              old = seen;
-            }
-          }
+      for (int j = 0; j < NR; ++j) {
+        cur[j] = mm[e[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const bool b = ((((cur[j].x | Hl) - cand_lo[j]) & Hl) != Hl) | ((((cur[j].y | Hh) - cand_hi[j]) & Hh) != Hh);
+        better |= b ? 1u << j : 0u;
+      }
+    }
+    while (__builtin_amdgcn_ballot_w64(better != 0)) {
+      if (better) {
+        const int j = __ffs(better) - 1;
+        better &= better - 1;
+        uint32_t ej = e[0], cl = cand_lo[0], ch = cand_hi[0];
+#pragma unroll
+        for (int i = 1; i < NR; ++i) {
+          ej = i == j ? e[i] : ej;
+          cl = i == j ? cand_lo[i] : cl;
+          ch = i == j ? cand_hi[i] : ch;
         }
+        bhm_mm_improve(a, reinterpret_cast<uint32_t*>(rp + a.off_mm + static_cast<size_t>(ej) * static_cast<uint32_t>(mmb)), cl, ch, mmb);
       }
     }
   }
@@ -254,35 +360,87 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
   }
 }
 
-// word w of the slab for entry `ei`: the replicas' partials decoded and combined
-HDK_DEV int64_t bhm_slab_word(const BhmArgs& a, const uint8_t* lds8, const BhmSlabWord& sw, uint32_t ei) {
-  int64_t acc = (sw.kind == BMW_MIN) ? INT64_MAX : ((sw.kind == BMW_MAX) ? INT64_MIN : 0);
+// entry `ei` of the block's table as slab words (agg_common.h): the replicas' partials decoded and combined
+HDK_DEV void bhm_slab_entry(const BhmArgs& a, const uint8_t* lds8, uint32_t ei, int64_t* out) {
+  // the raw LDS words of the entry, summed / merged over the replicas
+  int64_t psum[kBhmMaxDer], pcnt[kBhmMaxDer];
+#pragma unroll
+  for (int pi = 0; pi < kBhmMaxDer; ++pi) {
+    psum[pi] = 0;
+    pcnt[pi] = 0;
+  }
+  uint32_t mm_lo = 0, mm_hi = 0;
+  int64_t rows = 0;
   for (uint32_t r = 0; r < a.rep; ++r) {
     const uint8_t* rp = lds8 + static_cast<size_t>(r) * a.rep_bytes;
-    if (sw.kind == BMW_ROWS && sw.packed < 0) {
-      acc += reinterpret_cast<const uint32_t*>(rp + a.off_rows)[ei];
-    } else if (sw.kind == BMW_ROWS || sw.kind == BMW_SUM || (sw.kind == BMW_NN && sw.packed >= 0)) {
-      const uint64_t pk = reinterpret_cast<const uint64_t*>(rp)[static_cast<uint32_t>(sw.packed) * a.e1 + ei];
-      const int64_t sum = static_cast<int64_t>(pk << (64 - kBhmSumBits)) >> (64 - kBhmSumBits);
-      const int64_t cnt = static_cast<int64_t>((pk - static_cast<uint64_t>(sum)) >> kBhmSumBits);
-      acc += sw.kind == BMW_SUM ? sum : cnt;
-    } else {
-      const uint64_t mm = reinterpret_cast<const uint64_t*>(rp + a.off_mm)[static_cast<uint32_t>(sw.mm_word) * a.e1 + ei];
-      const uint32_t code = static_cast<uint32_t>(mm >> sw.shift) & sw.mask;
-      if (sw.kind == BMW_NN) {
-        acc += code ? 1 : 0;  // (only "none / some" is read from the count of a MIN / MAX-only argument)
-      } else if (code) {
-        const int64_t v = sw.kind == BMW_MAX ? static_cast<int64_t>(sw.bias) + (code - 1) : static_cast<int64_t>(sw.bias) - (code - 1);
-        acc = sw.kind == BMW_MAX ? (v > acc ? v : acc) : (v < acc ? v : acc);
+#pragma unroll
+    for (int pi = 0; pi < kBhmMaxDer; ++pi) {
+      if (pi < a.npacked) {
+        const uint64_t pk = reinterpret_cast<const uint64_t*>(rp)[static_cast<uint32_t>(pi) * a.e1 + ei];
+        const int64_t sum = static_cast<int64_t>(pk << (64 - kBhmSumBits)) >> (64 - kBhmSumBits);
+        psum[pi] += sum;
+        pcnt[pi] += static_cast<int64_t>((pk - static_cast<uint64_t>(sum)) >> kBhmSumBits);
       }
     }
+    if (a.mm_bytes == 4) {
+      const uint32_t w = reinterpret_cast<const uint32_t*>(rp + a.off_mm)[ei];
+      // per-field maximum over the replicas
+      for (int f = 0; f < a.nfields; ++f) {
+        const uint32_t m = a.fmask[f] << a.fshift[f];
+        mm_lo = (mm_lo & ~m) | ((w & m) > (mm_lo & m) ? (w & m) : (mm_lo & m));
+      }
+    } else if (a.mm_bytes == 8) {
+      const uint32_t wl = reinterpret_cast<const uint32_t*>(rp + a.off_mm)[2 * ei], wh = reinterpret_cast<const uint32_t*>(rp + a.off_mm)[2 * ei + 1];
+      for (int f = 0; f < a.nfields; ++f) {
+        const uint32_t m = a.fmask[f] << a.fshift[f];
+        if (a.fhalf[f] == 0) {
+          mm_lo = (mm_lo & ~m) | ((wl & m) > (mm_lo & m) ? (wl & m) : (mm_lo & m));
+        } else {
+          mm_hi = (mm_hi & ~m) | ((wh & m) > (mm_hi & m) ? (wh & m) : (mm_hi & m));
+        }
+      }
+    }
+    if (a.rows_packed < 0) {
+      rows += reinterpret_cast<const uint32_t*>(rp + a.off_rows)[ei];
+    }
   }
-  return acc;
+  for (int w = 0; w < a.wpe; ++w) {
+    const BhmSlabWord sw = a.sw[w];
+    int64_t v;
+    if (sw.kind == BMW_ROWS && sw.packed < 0) {
+      v = rows;
+    } else if (sw.kind == BMW_ROWS || sw.kind == BMW_SUM || (sw.kind == BMW_NN && sw.packed >= 0)) {
+      int64_t sm = psum[0], ct = pcnt[0];
+#pragma unroll
+      for (int pi = 1; pi < kBhmMaxDer; ++pi) {
+        sm = sw.packed == pi ? psum[pi] : sm;
+        ct = sw.packed == pi ? pcnt[pi] : ct;
+      }
+      v = sw.kind == BMW_SUM ? sm : ct;
+    } else {
+      const uint32_t code = ((sw.half ? mm_hi : mm_lo) >> sw.shift) & sw.mask;
+      if (sw.kind == BMW_NN) {
+        v = code ? 1 : 0;  // (only "none / some" is read from the count of a MIN / MAX-only argument)
+      } else if (sw.kind == BMW_MAX) {
+        v = code ? static_cast<int64_t>(sw.bias) + code : INT64_MIN;
+      } else {
+        v = code ? static_cast<int64_t>(sw.bias) - code : INT64_MAX;
+      }
+    }
+    out[w] = v;
+  }
 }
 
-// NK key columns, NS argument columns, all 4 bytes wide; U steps of 16 bytes per lane, column and tile
-template <int NK, int NS, int BLOCK, int U>
+// C: the arguments' shape (BhmStatic<...> or BhmDynamic); NK key columns, NS argument columns, all 4 bytes wide; U steps of
+// 16 bytes per lane, column and tile
+#ifndef HDK_BHM_PREFETCH
+#define HDK_BHM_PREFETCH 0  // 1: issue the NEXT full tile's loads before this tile's rows go through the table.  Measured WORSE
+                            // (256 M rows, msbs1 / msphs1 at three blocks per CU: 0.69 / 0.63 ms against 0.63 / 0.60 -- the second
+                            // register set costs more waves than the overlap returns)
+#endif
+template <class C, int NK, int NS, int BLOCK, int U>
 __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
+  constexpr bool PREFETCH = HDK_BHM_PREFETCH != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
   constexpr int R = 4;
   const int tid = threadIdx.x;
@@ -317,23 +475,36 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
     for (int s = 0; s < NS; ++s) {
       xcol[s] = (gcol_t)cols[a.src[s].buf_idx];
     }
+    // (PREFETCH: full tiles double-buffered -- see HDK_BHM_PREFETCH)
+    uint32_t kr[U][NK][4], xr[U][NS][4];
+    bool have = false;  // kr / xr hold this tile already
+    auto load_tile = [&](int64_t row0, uint32_t (&kd)[U][NK][4], uint32_t (&xd)[U][NS][4]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          load_bytes<16, true>(kcol[kk] + r * 4, kd[u][kk]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          load_bytes<16, true>(xcol[s] + r * 4, xd[u][s]);
+        }
+      }
+    };
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       HDK_WATCH_TILE(watch, err, tile)
       rows_seen += static_cast<uint32_t>(kTileRows);
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       if (row0 + kTileRows <= nrows) {
-        uint32_t kr[U][NK][4], xr[U][NS][4];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int64_t r = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
-#pragma unroll
-          for (int kk = 0; kk < NK; ++kk) {
-            load_bytes<16, true>(kcol[kk] + r * 4, kr[u][kk]);
-          }
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            load_bytes<16, true>(xcol[s] + r * 4, xr[u][s]);
-          }
+        if (!have) {
+          load_tile(row0, kr, xr);
+        }
+        uint32_t kn[U][NK][4], xn[U][NS][4];
+        const int64_t next0 = row0 + static_cast<int64_t>(gridDim.x) * kTileRows;
+        const bool next_full = PREFETCH && next0 + kTileRows <= nrows;
+        if (next_full) {
+          load_tile(next0, kn, xn);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -349,9 +520,27 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
               xv[s][i] = static_cast<int32_t>(xr[u][s][i]);
             }
           }
-          bhm_rows<NK, NS, R>(a, rp, kv, xv, stale);
+          bhm_rows<C, NK, NS, R>(a, rp, kv, xv, stale);
+        }
+        have = next_full;
+        if (next_full) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+              for (int kk = 0; kk < NK; ++kk) {
+                kr[u][kk][i] = kn[u][kk][i];
+              }
+#pragma unroll
+              for (int s = 0; s < NS; ++s) {
+                xr[u][s][i] = xn[u][s][i];
+              }
+            }
+          }
         }
       } else {
+        have = false;
         // the ragged tail of a fragment, a row per lane and trip
         for (int64_t r = row0 + tid; r < nrows; r += BLOCK) {
           int32_t kv[NK][1], xv[NS][1];
@@ -363,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
           for (int s = 0; s < NS; ++s) {
             xv[s][0] = static_cast<int32_t>(load_elem<4>(xcol[s], r));
           }
-          bhm_rows<NK, NS, 1>(a, rp, kv, xv, stale);
+          bhm_rows<C, NK, NS, 1>(a, rp, kv, xv, stale);
         }
       }
     }
@@ -378,11 +567,51 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
   }
   __syncthreads();
   int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * a.entries * a.wpe;
-  const uint32_t total = a.entries * static_cast<uint32_t>(a.wpe);
-  for (uint32_t i = tid; i < total; i += BLOCK) {
-    const uint32_t ei = i / static_cast<uint32_t>(a.wpe), w = i % static_cast<uint32_t>(a.wpe);
-    slab[i] = bhm_slab_word(a, lds8, a.sw[w], ei);
+  for (uint32_t ei = tid; ei < a.entries; ei += BLOCK) {
+    bhm_slab_entry(a, lds8, ei, slab + static_cast<size_t>(ei) * a.wpe);
   }
+}
+
+// ---- slabs [num_slabs][words] -> [groups][words]: output slab g combines the input slabs g, g + groups, ... -------------------------
+// Thread per word, coalesced over the slab; what makes the folds cheap (a wave per entry over `groups` slabs instead of over
+// hundreds, each of whose words sits in a different memory line: 77-97 us for 512 slabs of 1 000 groups, against ~20 us here).
+struct BhmReduceArgs {
+  const int64_t* in;
+  int64_t* out;
+  const uint32_t* flag;
+  uint32_t num_slabs, groups, words;
+  int32_t wpe;
+  int32_t wop[kMaxWordsPerEntry];
+};
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void hdk_bhm_reduce_slabs(BhmReduceArgs a) {
+  if (*a.flag) {
+    return;
+  }
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  if (i >= a.words) {
+    return;
+  }
+  const int32_t op = a.wop[i % static_cast<uint32_t>(a.wpe)];
+  int64_t acc = word_identity(op);
+  constexpr int kInFlight = 8;
+  uint32_t b = g;
+  for (; b + (kInFlight - 1) * a.groups < a.num_slabs; b += kInFlight * a.groups) {
+    int64_t v[kInFlight];
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) {
+      v[j] = a.in[static_cast<size_t>(b + j * a.groups) * a.words + i];
+    }
+#pragma unroll
+    for (int j = 0; j < kInFlight; ++j) {
+      acc = word_combine(op, acc, v[j]);
+    }
+  }
+  for (; b < a.num_slabs; b += a.groups) {
+    acc = word_combine(op, acc, a.in[static_cast<size_t>(b) * a.words + i]);
+  }
+  a.out[static_cast<size_t>(g) * a.words + i] = acc;
 }
 
 // ---- the fold of an open-addressing plan's slabs: one wave per internal entry ---------------------------------------------------

@@ -13,7 +13,10 @@ constexpr uint32_t kBhmMaxLdsBytes = 144u << 10;        // one 1024-thread block
 constexpr uint32_t kBhmSmallLdsBytes = 40u << 10;       // up to here: 256-thread blocks, four on a CU
 constexpr uint32_t kBhmReplicatedBytes = 32u << 10;     // replicas while the table is tiny
 constexpr int64_t kBhmMaxAbsVal = (1ll << 19) - 1;      // |argument| below this keeps a block's row budget at 2^20 or more
-constexpr int kBhmU = 2;                                // 16-byte steps per lane, column and tile
+#ifndef HDK_BHM_U
+#define HDK_BHM_U 2  // (A/B builds: -DHDK_BHM_U=4)
+#endif
+constexpr int kBhmU = HDK_BHM_U;                        // 16-byte steps per lane, column and tile
 
 static bool bhm_off() { return hdk_sw(SW_NO_BHM) != nullptr || hdk_sw(SW_NO_BH_LDS) != nullptr; }
 
@@ -88,7 +91,8 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
       if (n > (1u << 20) || n > 4ull * p->entry_count + 64) return false;
       key.min = static_cast<int32_t>(kc.min_val);
       key.n = static_cast<uint32_t>(n);
-      key.nullable = ke.leaf0.nullable != 0;
+      // (a NULL key only when the statistics announce one: else it lies outside them like any other stranger -- the flag)
+      key.nullable = ke.leaf0.nullable != 0 && kc.has_nulls != 0;
       key.null_d = static_cast<uint32_t>(n);
       key.stride = 1;
       entries = n + (key.nullable ? 1 : 0);
@@ -108,11 +112,11 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
   struct DerInfo {
     int64_t rmin, rmax;
     bool want_packed, want_max, want_min;
-  } info[kBhmMaxSrc][kBhmMaxDer];
+  } info[kBhmMaxDer];
   memset(info, 0, sizeof(info));
-  int word_src[kMaxWordsPerEntry], word_der[kMaxWordsPerEntry], word_kind[kMaxWordsPerEntry];
+  int word_der[kMaxWordsPerEntry], word_kind[kMaxWordsPerEntry];
   for (int w = 0; w < kMaxWordsPerEntry; ++w) {
-    word_src[w] = word_der[w] = -1;
+    word_der[w] = -1;
     word_kind[w] = BMW_ROWS;
   }
   int64_t amax = 1;
@@ -134,8 +138,7 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
     const hdk_hip_col& col = p->cols[e.leaf0.col];
     if (col.table != 0 || col.kind != HDK_COL_INT || col.width != 4 || !col.has_stats || col.max_val < col.min_val) return false;
     if (col.min_val < -kBhmMaxAbsVal || col.max_val > kBhmMaxAbsVal) return false;
-    int32_t op = 0;
-    int64_t lit = 0, rmin = col.min_val, rmax = col.max_val;
+    int64_t mul = 1, add = 0, rmin = col.min_val, rmax = col.max_val;
     if (e.nsteps == 1) {
       const hdk_hip_step& sp = e.steps[0];
       if (sp.out_class != HDK_VC_INT || sp.rhs.kind != HDK_LEAF_INT) return false;
@@ -144,23 +147,25 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
       // a NULL operand gives the step's NULL, which must be what the target skips (as match_fast)
       if (tg.skip_null && (e.null_val != sp.null_out || tg.null_val != sp.null_out)) return false;
       if (!tg.skip_null && e.leaf0.nullable) return false;
-      op = sp.op;
-      lit = sp.rhs.ival;
-      const int64_t c0 = op == HDK_OP_ADD ? rmin + lit : (op == HDK_OP_SUB ? rmin - lit : rmin * lit);
-      const int64_t c1 = op == HDK_OP_ADD ? rmax + lit : (op == HDK_OP_SUB ? rmax - lit : rmax * lit);
+      if (sp.op == HDK_OP_MUL) {
+        mul = sp.rhs.ival;
+      } else {
+        add = sp.op == HDK_OP_ADD ? sp.rhs.ival : -sp.rhs.ival;
+      }
+      const int64_t c0 = rmin * mul + add, c1 = rmax * mul + add;
       rmin = std::min(c0, c1);
       rmax = std::max(c0, c1);
       // (the result's range fits the operation's type: the checked arithmetic of QE/ArithmeticIR.cpp:277-520 cannot fire)
       const int cw = sp.check_width ? sp.check_width : 8;
       const int64_t tmax = cw >= 8 ? INT64_MAX : (1ll << (8 * cw - 1)) - 1;
       if (rmin < -tmax || rmax > tmax) return false;
-    } else if (!tg.skip_null && e.leaf0.nullable && col.has_nulls) {
-      return false;  // (a NULL aggregated as a value: the sentinel is far outside the packed fields)
+      if (mul == 1 && add == 0) return false;  // (x + 0: leave the oddities to the interpreter)
     }
     if (rmin < -kBhmMaxAbsVal || rmax > kBhmMaxAbsVal) return false;
-    // the column's NULL: skipped when the statistics announce NULLs; else it would be outside them (the flag)
-    const int nullable = (tg.skip_null && e.leaf0.nullable && col.has_nulls) ? 1 : 0;
+    // the column's NULL: skipped when the statistics announce NULLs; else it would be outside them (the flag).  A NULL
+    // aggregated as a value (no skip) is far outside the packed fields: not this kernel's
     if (!tg.skip_null && col.has_nulls && e.leaf0.nullable) return false;
+    const int nullable = (tg.skip_null && e.leaf0.nullable && col.has_nulls) ? 1 : 0;
     int s = -1;
     for (int i = 0; i < a->nsrc; ++i) {
       if (a->src[i].buf_idx == col.buf_idx) s = i;
@@ -177,92 +182,104 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
     } else if (a->src[s].nullable != nullable) {
       return false;
     }
-    BhmSrc& src = a->src[s];
     int d = -1;
-    for (int i = 0; i < src.nder; ++i) {
-      if (src.der[i].op == op && src.der[i].lit == static_cast<int32_t>(lit)) d = i;
+    for (int i = 0; i < a->nder; ++i) {
+      if (a->der[i].src == s && a->der[i].mul == static_cast<int32_t>(mul) && a->der[i].add == static_cast<int32_t>(add)) d = i;
     }
     if (d < 0) {
-      if (src.nder == kBhmMaxDer) return false;
-      d = src.nder++;
-      src.der[d].op = op;
-      src.der[d].lit = static_cast<int32_t>(lit);
-      src.der[d].packed = src.der[d].mx_word = src.der[d].mn_word = -1;
-      info[s][d].rmin = rmin;
-      info[s][d].rmax = rmax;
+      if (a->nder == kBhmMaxDer) return false;
+      d = a->nder++;
+      a->der[d].src = s;
+      a->der[d].mul = static_cast<int32_t>(mul);
+      a->der[d].add = static_cast<int32_t>(add);
+      a->der[d].packed = -1;
+      info[d].rmin = rmin;
+      info[d].rmax = rmax;
     }
     amax = std::max<int64_t>(amax, std::max<int64_t>(-rmin, rmax));
-    if (tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_AVG || tg.agg == HDK_AGG_COUNT) info[s][d].want_packed = true;
-    if (tg.agg == HDK_AGG_MAX) info[s][d].want_max = true;
-    if (tg.agg == HDK_AGG_MIN) info[s][d].want_min = true;
+    if (tg.agg == HDK_AGG_SUM || tg.agg == HDK_AGG_AVG || tg.agg == HDK_AGG_COUNT) info[d].want_packed = true;
+    if (tg.agg == HDK_AGG_MAX) info[d].want_max = true;
+    if (tg.agg == HDK_AGG_MIN) info[d].want_min = true;
     if (wl.vword[t] >= 0) {
-      word_src[wl.vword[t]] = s;
       word_der[wl.vword[t]] = d;
       word_kind[wl.vword[t]] = tg.agg == HDK_AGG_MIN ? BMW_MIN : (tg.agg == HDK_AGG_MAX ? BMW_MAX : BMW_SUM);
     }
     if (wl.nword[t] >= 0) {
-      word_src[wl.nword[t]] = s;
       word_der[wl.nword[t]] = d;
       word_kind[wl.nword[t]] = BMW_NN;
       g->nword_mask |= 1u << wl.nword[t];
     }
   }
   if (a->nsrc == 0) return false;  // (COUNT(*) alone: the keys kernel / the one-argument packed kernels)
-  if (a->nkeys == 1 && a->nsrc == 1 && a->src[0].nder == 1 && a->src[0].der[0].op == 0) return false;  // scan_bh_packed.h's own shape
-  // ---- LDS words: packed [rows : sum] words, MIN / MAX fields -------------------------------------------------------------
+  if (a->nkeys == 1 && a->nder == 1 && a->der[0].mul == 1 && a->der[0].add == 0) return false;  // scan_bh_packed.h's own shape
+  for (int k = 0; k < a->nkeys; ++k) a->any_nullable |= a->key[k].nullable;
+  for (int s = 0; s < a->nsrc; ++s) a->any_nullable |= a->src[s].nullable;
+  // ---- LDS words: packed [rows : sum] words, MIN / MAX fields in the halves of one 64-bit word ---------------------------------
   a->rows_packed = -1;
-  uint32_t bitpos[kBhmMaxMm] = {0, 0};
-  auto place_field = [&](uint32_t codebits, int32_t* word, uint32_t* shift, uint32_t* mask) -> bool {
+  uint32_t bitpos[2] = {0, 0};
+  int fhalf_of[kBhmMaxDer][2];
+  auto place_field = [&](uint32_t codebits, BhmField* fd, int* half_out) -> bool {
     const uint32_t need = codebits + 1;  // + the guard bit
-    for (int w = 0; w < kBhmMaxMm; ++w) {
-      if (bitpos[w] + need <= 64 && a->nfields[w] < kBhmMaxFields) {
-        *word = w;
-        *shift = bitpos[w];
-        *mask = static_cast<uint32_t>((1ull << codebits) - 1);
-        a->fshift[w][a->nfields[w]] = bitpos[w];
-        a->fmask[w][a->nfields[w]] = *mask;
-        a->nfields[w]++;
-        a->guards[w] |= 1ull << (bitpos[w] + codebits);
-        bitpos[w] += need;
-        a->nmm = std::max(a->nmm, w + 1);
+    for (int h = 0; h < 2; ++h) {
+      if (bitpos[h] + need <= 32 && a->nfields < kBhmMaxFields) {
+        const uint32_t mask = static_cast<uint32_t>((1ull << codebits) - 1);
+        fd->shift = bitpos[h];
+        fd->mask_lo = h == 0 ? mask : 0u;
+        fd->mask_hi = h == 1 ? mask : 0u;
+        a->fshift[a->nfields] = bitpos[h];
+        a->fmask[a->nfields] = mask;
+        a->fhalf[a->nfields] = static_cast<uint32_t>(h);
+        a->nfields++;
+        (h == 0 ? a->guard_lo : a->guard_hi) |= 1u << (bitpos[h] + codebits);
+        bitpos[h] += need;
+        *half_out = h;
         return true;
       }
     }
     return false;
   };
-  for (int s = 0; s < a->nsrc; ++s) {
-    for (int d = 0; d < a->src[s].nder; ++d) {
-      BhmDer& der = a->src[s].der[d];
-      const DerInfo& di = info[s][d];
-      if (di.want_packed) {
-        der.packed = a->npacked++;
-        if (!a->src[s].nullable && a->rows_packed < 0) a->rows_packed = der.packed;
-      }
-      const uint32_t codebits = bits_for(static_cast<uint64_t>(di.rmax - di.rmin) + 2);
-      if (codebits > 31) return false;
-      if (di.want_max) {
-        der.mx_bias = static_cast<int32_t>(di.rmin);
-        if (!place_field(codebits, &der.mx_word, &der.mx_shift, &der.mx_mask)) return false;
-      }
-      if (di.want_min) {
-        der.mn_bias = static_cast<int32_t>(di.rmax);
-        if (!place_field(codebits, &der.mn_word, &der.mn_shift, &der.mn_mask)) return false;
-      }
+  for (int d = 0; d < a->nder; ++d) {
+    BhmDer& der = a->der[d];
+    const DerInfo& di = info[d];
+    if (di.want_packed) {
+      der.packed = a->npacked++;
+      if (!a->src[der.src].nullable && a->rows_packed < 0) a->rows_packed = der.packed;
+    }
+    const uint32_t codebits = bits_for(static_cast<uint64_t>(di.rmax - di.rmin) + 2);
+    if (codebits > 30) return false;
+    fhalf_of[d][0] = fhalf_of[d][1] = 0;
+    if (di.want_max) {
+      der.has_mx = 1;
+      der.mx.bias = static_cast<int32_t>(di.rmin - 1);
+      if (!place_field(codebits, &der.mx, &fhalf_of[d][0])) return false;
+    }
+    if (di.want_min) {
+      der.has_mn = 1;
+      der.mn.bias = static_cast<int32_t>(di.rmax + 1);
+      if (!place_field(codebits, &der.mn, &fhalf_of[d][1])) return false;
     }
   }
+  a->mm_bytes = a->nfields == 0 ? 0 : (bitpos[1] == 0 ? 4 : 8);
   // the slab words
   for (int w = 0; w < wl.wpe; ++w) {
     BhmSlabWord& sw = a->sw[w];
     sw.kind = word_kind[w];
     sw.packed = -1;
-    sw.mm_word = -1;
-    if (w == 0 || word_src[w] < 0) {
+    if (w == 0 || word_der[w] < 0) {
       sw.kind = BMW_ROWS;
       sw.packed = a->rows_packed;
       continue;
     }
-    const BhmSrc& src = a->src[word_src[w]];
-    const BhmDer& der = src.der[word_der[w]];
+    const BhmDer& der = a->der[word_der[w]];
+    const BhmSrc& src = a->src[der.src];
+    auto from_field = [&](bool mx) {
+      const BhmField& fd = mx ? der.mx : der.mn;
+      sw.in_mm = 1;
+      sw.half = fhalf_of[word_der[w]][mx ? 0 : 1];
+      sw.shift = fd.shift;
+      sw.mask = fd.mask_lo | fd.mask_hi;
+      sw.bias = fd.bias;
+    };
     if (sw.kind == BMW_SUM) {
       sw.packed = der.packed;
     } else if (sw.kind == BMW_NN) {
@@ -272,30 +289,19 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
       } else if (der.packed >= 0) {
         sw.packed = der.packed;
       } else {  // MIN / MAX only: "some non-NULL row" is all its count says
-        const bool mx = der.mx_word >= 0;
-        sw.mm_word = mx ? der.mx_word : der.mn_word;
-        sw.shift = mx ? der.mx_shift : der.mn_shift;
-        sw.mask = mx ? der.mx_mask : der.mn_mask;
+        from_field(der.has_mx != 0);
       }
-    } else if (sw.kind == BMW_MAX) {
-      sw.mm_word = der.mx_word;
-      sw.shift = der.mx_shift;
-      sw.mask = der.mx_mask;
-      sw.bias = der.mx_bias;
     } else {
-      sw.mm_word = der.mn_word;
-      sw.shift = der.mn_shift;
-      sw.mask = der.mn_mask;
-      sw.bias = der.mn_bias;
+      from_field(sw.kind == BMW_MAX);
     }
   }
   // ---- geometry -----------------------------------------------------------------------------------------------------------
   a->e1 = (a->entries + 1 + 1) & ~1u;
-  const uint32_t per_entry = 8u * static_cast<uint32_t>(a->npacked) + 8u * static_cast<uint32_t>(a->nmm) + (a->rows_packed < 0 ? 4u : 0u);
+  const uint32_t per_entry = 8u * static_cast<uint32_t>(a->npacked) + static_cast<uint32_t>(a->mm_bytes) + (a->rows_packed < 0 ? 4u : 0u);
   const uint64_t one = static_cast<uint64_t>(a->e1) * per_entry;
   if (one > kBhmMaxLdsBytes) return false;
   a->off_mm = 8u * static_cast<uint32_t>(a->npacked) * a->e1;
-  a->off_rows = a->off_mm + 8u * static_cast<uint32_t>(a->nmm) * a->e1;
+  a->off_rows = a->off_mm + static_cast<uint32_t>(a->mm_bytes) * a->e1;
   uint32_t rep_bytes = (static_cast<uint32_t>(one) + 15u) & ~15u;
   uint32_t rep = 16;
   while (rep > 1 && static_cast<uint64_t>(rep_bytes + 16) * rep > kBhmReplicatedBytes) rep >>= 1;
@@ -308,31 +314,78 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
   g->nk = a->nkeys;
   g->ns = a->nsrc;
   g->block = a->lds_bytes > kBhmSmallLdsBytes ? 1024 : 256;
-  g->grid_per_cu = g->block == 1024 ? 1 : 4;
+  // (256-thread blocks: three on a CU measured best -- msbs1 / msphs1 / phm2 at 256 M rows: 1 -> 1.06 / 1.04 / 0.79 ms, 2 -> 0.66 /
+  // 0.63 / 0.60, 3 -> 0.63 / 0.60 / 0.60, 4 -> 0.74 / 0.72 / 0.71, 8 -> 0.94 / 0.93 / 0.89: more waves add LDS contention and slabs)
+  g->grid_per_cu = g->block == 1024 ? 1 : 3;
   // rows a block may put into one entry: rows < 2^23, |sum| < 2^39
   const int64_t by_sum = ((1ll << 39) - 1) / amax;
   a->max_rows_per_block = static_cast<uint32_t>(std::min<int64_t>(by_sum, 1ll << 23));
   return true;
 }
 
-template <int NK, int NS>
-static const void* bhm_kernel_ns(int block) {
-  return block == 1024 ? reinterpret_cast<const void*>(hdk_scan_agg_bhm<NK, NS, 1024, kBhmU>)
-                       : reinterpret_cast<const void*>(hdk_scan_agg_bhm<NK, NS, 256, kBhmU>);
+// ---- the instantiations ---------------------------------------------------------------------------------------------------------
+template <class C, int NK, int NS>
+static const void* bhm_kernel_of(int block) {
+  return block == 1024 ? reinterpret_cast<const void*>(hdk_scan_agg_bhm<C, NK, NS, 1024, kBhmU>)
+                       : reinterpret_cast<const void*>(hdk_scan_agg_bhm<C, NK, NS, 256, kBhmU>);
 }
 template <int NK>
-static const void* bhm_kernel_nk(int ns, int block) {
-  return ns == 1 ? bhm_kernel_ns<NK, 1>(block) : (ns == 2 ? bhm_kernel_ns<NK, 2>(block) : bhm_kernel_ns<NK, 3>(block));
+static const void* bhm_dynamic_nk(int ns, int block) {
+  return ns == 1 ? bhm_kernel_of<BhmDynamic, NK, 1>(block) : (ns == 2 ? bhm_kernel_of<BhmDynamic, NK, 2>(block) : bhm_kernel_of<BhmDynamic, NK, 3>(block));
 }
-static const void* bhm_kernel(const BhmGeom& g) {
-  return g.nk == 1 ? bhm_kernel_nk<1>(g.ns, g.block) : (g.nk == 2 ? bhm_kernel_nk<2>(g.ns, g.block) : bhm_kernel_nk<3>(g.ns, g.block));
+// the shapes with compile-time argument lists (BhmStatic): what the reference's benchmark suite and its neighbours ask for.
+// Arguments are numbered in the order the targets name them, columns likewise.
+struct BhmStaticShape {
+  int nk, ns;
+  uint32_t code[kBhmMaxDer];
+  const void* (*kernel)(int block);
+};
+#define HDK_BHM_SHAPE(NK, NS, D0, D1, D2, D3) \
+  { NK, NS, {D0, D1, D2, D3}, [](int block) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3>, NK, NS>(block); } }
+constexpr uint32_t kN = kBhmNone;
+static const BhmStaticShape kBhmShapes[] = {
+    // MultiStep/MSBS001-005, MSPHS001-...: max(x100) + sum(x100), max(x10), max(x10 + 1) + sum(x10 + 1)
+    HDK_BHM_SHAPE(1, 2, bhm_code(0, true, true, false, 0), bhm_code(1, false, true, false, 0), bhm_code(1, true, true, false, 1), kN),
+    // PerfectHashMultiCol/PHM001-006: count / sum / max / min / avg of one column by two keys (and by three)
+    HDK_BHM_SHAPE(2, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
+    HDK_BHM_SHAPE(3, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
+    // sums (counts, averages) of two columns: MultiStep/MSBS006-007, MSPHM's SUM(x10), SUM(y10) by one key and by two
+    HDK_BHM_SHAPE(1, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN),
+    HDK_BHM_SHAPE(2, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN),
+    // sum of one column by two keys; sum of `column + literal` by one
+    HDK_BHM_SHAPE(2, 1, bhm_code(0, true, false, false, 0), kN, kN, kN),
+    HDK_BHM_SHAPE(1, 1, bhm_code(0, true, false, false, 1), kN, kN, kN),
+};
+#undef HDK_BHM_SHAPE
+
+static uint32_t bhm_code_of(const BhmArgs& a, int i) {
+  if (i >= a.nder) return kBhmNone;
+  const BhmDer& d = a.der[i];
+  if (d.mul != 1 && d.add != 0) return 0xFE;  // (column * literal + literal: never produced by the matcher)
+  return bhm_code(d.src, d.packed >= 0, d.has_mx != 0, d.has_mn != 0, d.mul != 1 ? 2 : (d.add != 0 ? 1 : 0));
+}
+
+// compile-time shape when there is one (no NULLs to look for, every field inside 32 bits), else the run-time form
+static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_static) {
+  *is_static = false;
+  if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
+    for (const BhmStaticShape& sh : kBhmShapes) {
+      bool same = sh.nk == g.nk && sh.ns == g.ns;
+      for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
+      if (same) {
+        *is_static = true;
+        return sh.kernel(g.block);
+      }
+    }
+  }
+  return g.nk == 1 ? bhm_dynamic_nk<1>(g.ns, g.block) : (g.nk == 2 ? bhm_dynamic_nk<2>(g.ns, g.block) : bhm_dynamic_nk<3>(g.ns, g.block));
 }
 
 const char* bhm_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
   BhmArgs a;
   BhmGeom g;
   if (!match_bhm(p, ko, &a, &g)) return nullptr;
-  return g.perfect ? "hdk_scan_agg_bhm,hdk_finalize" : "hdk_scan_agg_bhm,hdk_bhm_fold";
+  return g.perfect ? "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_finalize" : "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_bhm_fold";
 }
 
 int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
@@ -341,7 +394,8 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
   BhmArgs a;
   BhmGeom g;
   if (!match_bhm(plan, ko, &a, &g)) return HDK_HIP_OK;
-  const void* k = bhm_kernel(g);
+  bool is_static;
+  const void* k = bhm_kernel(a, g, &is_static);
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
   }
@@ -355,9 +409,13 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
   const uint64_t need = (2 * ko->total_rows + budget - 1) / budget;
   if (need > grid) grid = static_cast<uint32_t>(std::min<uint64_t>(need, 1u << 16));
   if (ko->grid_dim_x) grid = ko->grid_dim_x;
-  const size_t slab_bytes = static_cast<size_t>(grid) * a.entries * a.wpe * 8;
+  // the blocks' slabs, and -- when there are many -- the few slabs they are reduced to before the fold
+  const uint32_t words = a.entries * static_cast<uint32_t>(a.wpe);
+  const uint32_t red_groups = grid > 16 ? 4u : 0u;
+  const size_t slab_bytes = (static_cast<size_t>(grid) * words * 8 + 255) & ~static_cast<size_t>(255);
+  const size_t red_bytes = static_cast<size_t>(red_groups) * words * 8;
   AsyncScratch scratch(s);
-  if (hipMallocAsync(&scratch.p, 256 + slab_bytes, s) != hipSuccess) {
+  if (hipMallocAsync(&scratch.p, 256 + slab_bytes + red_bytes, s) != hipSuccess) {
     (void)hipGetLastError();
     scratch.p = nullptr;
     return HDK_HIP_OK;  // no room for the slabs: the other strategies
@@ -369,18 +427,36 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
   a.slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(scratch.p) + 256);
   void* kargs[] = {&a};
   HDK_HIP_CHECK(hipLaunchKernel(k, dim3(grid), dim3(g.block), kargs, a.lds_bytes, s));
+  const int64_t* fold_slabs = a.slabs;
+  uint32_t fold_count = grid;
+  if (red_groups) {
+    BhmReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.in = a.slabs;
+    r.out = reinterpret_cast<int64_t*>(static_cast<int8_t*>(scratch.p) + 256 + slab_bytes);
+    r.flag = a.flag;
+    r.num_slabs = grid;
+    r.groups = red_groups;
+    r.words = words;
+    r.wpe = a.wpe;
+    for (int w = 0; w < a.wpe; ++w) r.wop[w] = g.wop[w];
+    hipLaunchKernelGGL(hdk_bhm_reduce_slabs<0>, dim3((words + 255) / 256, red_groups), dim3(256), 0, s, r);
+    HDK_HIP_CHECK(hipGetLastError());
+    fold_slabs = r.out;
+    fold_count = red_groups;
+  }
   int32_t st;
   if (g.perfect) {
-    st = launch_finalize_slabs(d_plan, a.slabs, kp.groupby_buf, grid, plan->entry_count, a.flag, s);
+    st = launch_finalize_slabs(d_plan, fold_slabs, kp.groupby_buf, fold_count, plan->entry_count, a.flag, s);
     if (st) return st;
   } else {
     BhmFoldArgs f;
     memset(&f, 0, sizeof(f));
     f.plan = d_plan;
     f.kp = kp;
-    f.slabs = a.slabs;
+    f.slabs = fold_slabs;
     f.flag = a.flag;
-    f.num_slabs = grid;
+    f.num_slabs = fold_count;
     f.entries = a.entries;
     f.out_entry_count = plan->entry_count;
     f.wpe = a.wpe;

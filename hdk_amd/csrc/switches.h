@@ -12,6 +12,7 @@ namespace hdk {
   X(BH_FOLD_GROUPS)                 \
   X(BH_PARTITIONS_ALWAYS)           \
   X(BHM_BLOCKS_PER_CU)              \
+  X(BHM_DYNAMIC)                    \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(COLS_BLOCKS_PER_CU)             \

@@ -10,7 +10,9 @@ from hdk_amd import _abi as A
 from hdk_amd.ir import Agg, Cast, ColRef, FP32, FP64, KeyRef, QueryUnit
 
 SYN_COLUMNS = {"x10": 10, "y10": 10, "z10": 10, "x100": 100, "y100": 100, "z100": 100, "x1k": 1000, "x10k": 10_000, "x100k": 100_000,
-               "x1m": 1_000_000}
+               "x1m": 1_000_000,
+               # (not in create_table.py: group counts between the suite's decades, for the tables that just fit / just miss LDS)
+               "x2k": 2000, "x4k": 4000, "x6k": 6000}
 
 
 def syn_table(rng, n, columns=None, null_frac=0.0):
@@ -43,7 +45,7 @@ def _ms_targets():
             Agg("sum", x100, "s100"), Agg("sum", x10 + 1, "s10p")]
 
 
-MS_KEYS = {1: "x1k", 2: "x10k", 3: "x100k", 4: "x1m"}
+MS_KEYS = {1: "x1k", 2: "x10k", 3: "x100k", 4: "x1m", "2k": "x2k", "4k": "x4k", "6k": "x6k"}
 
 
 def msbs(i, table="syn", key_type=FP32):

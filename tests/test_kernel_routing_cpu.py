@@ -211,7 +211,7 @@ def test_multistep_and_multicol_benchmark_shapes_stay_on_chip():
     st.import_numpy("syn", syn_table(np.random.default_rng(6), 60_000, ("x10", "y10", "z10", "x100", "x1k")), fragment_size=20_000)
     for q, fold in ((msbs(1, key_type=FP64), "hdk_bhm_fold"), (msphs(1), "hdk_finalize"), (phm(1), "hdk_finalize"), (phm(2), "hdk_finalize")):
         names = _names(compile_query(st, q))
-        assert names == f"hdk_scan_agg_bhm,{fold}", (q.groupby, names)
+        assert names == f"hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,{fold}", (q.groupby, names)
         assert "global" not in names and "hdk_pp_" not in names and "_vec" not in names
     assert _names(compile_query(st, msphs(1)), flags=A.LAUNCH_FORCE_GLOBAL_ATOMICS).startswith("hdk_scan_agg_global")
     # unknown row bound: the packed fields cannot be sized -- the general routes
