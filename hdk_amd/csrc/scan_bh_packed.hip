@@ -339,12 +339,14 @@ const char* bh_packed_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_op
     if (bh_plain(a, kw, vw)) return a.dense ? "hdk_scan_agg_bh_dense_plain,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed_plain,hdk_bh_fold_slabs";
     return a.dense ? "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs" : "hdk_scan_agg_bh_packed,hdk_bh_fold_slabs";
   }
+  // several argument or key columns, and one-argument tables that fit LDS at 12 bytes an entry but not at 24: scan_bhm.hip
+  if (const char* m = bhm_kernel_name(p, ko)) return m;
   BhDensePartArgs dg;
   BhDensePartLayout dl;
   if (match_bh_dense_part(p, ko, &dg, &dl)) return "hdk_bh_dscatter,hdk_bh_daggregate";
   BhPartLayout l;
   if (match_bh_partitioned(p, ko, &a, &l)) return "hdk_bh_scatter,hdk_bh_aggregate";
-  return bhm_kernel_name(p, ko);  // several argument columns / key columns: scan_bhm.hip
+  return nullptr;
 }
 
 static int32_t launch_bh_partitioned(const hdk_hip_plan* d_plan, const KernParams& kp, BhPackedArgs& a, const BhPartLayout& l,
@@ -385,12 +387,14 @@ int32_t launch_bh_packed(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, c
   int kw, vw, block;
   uint32_t lds;
   if (!match_bh_packed(plan, ko, &a, &kw, &vw, &block, &lds)) {
+    int32_t st = launch_bhm(plan, d_plan, kp, ko, props, s, launched);
+    if (st || *launched) return st;
     BhDensePartArgs dg;
     BhDensePartLayout dl;
     if (match_bh_dense_part(plan, ko, &dg, &dl)) return launch_bh_dense_part(d_plan, kp, dg, dl, props, s, launched);
     BhPartLayout l;
     if (match_bh_partitioned(plan, ko, &a, &l)) return launch_bh_partitioned(d_plan, kp, a, l, props, s, launched);
-    return launch_bhm(plan, d_plan, kp, ko, props, s, launched);
+    return HDK_HIP_OK;
   }
   a.plan = d_plan;
   a.kp = kp;

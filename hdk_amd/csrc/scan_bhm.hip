@@ -18,7 +18,8 @@ constexpr int64_t kBhmMaxAbsVal = (1ll << 19) - 1;      // |argument| below this
 #endif
 constexpr int kBhmU = HDK_BHM_U;                        // 16-byte steps per lane, column and tile
 
-static bool bhm_off() { return hdk_sw(SW_NO_BHM) != nullptr || hdk_sw(SW_NO_BH_LDS) != nullptr; }
+// (A/B switches; every table here is dense: HDK_HIP_NO_BH_DENSE turns it off with the one-argument dense forms)
+static bool bhm_off() { return hdk_sw(SW_NO_BHM) != nullptr || hdk_sw(SW_NO_BH_LDS) != nullptr || hdk_sw(SW_NO_BH_DENSE) != nullptr; }
 
 static uint32_t bits_for(uint64_t codes) {  // bits that hold the values 0 .. codes - 1
   uint32_t b = 1;
@@ -211,7 +212,8 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
     }
   }
   if (a->nsrc == 0) return false;  // (COUNT(*) alone: the keys kernel / the one-argument packed kernels)
-  if (a->nkeys == 1 && a->nder == 1 && a->der[0].mul == 1 && a->der[0].add == 0) return false;  // scan_bh_packed.h's own shape
+  // (one key, one plain argument is scan_bh_packed.h's own shape: its one-pass kernels are asked first, launch_bh_packed; what
+  // they cannot hold -- 24 bytes an entry, 4 096 entries -- may still fit here at 12: BH004 / PHS004's 10 000 groups in ONE pass)
   for (int k = 0; k < a->nkeys; ++k) a->any_nullable |= a->key[k].nullable;
   for (int s = 0; s < a->nsrc; ++s) a->any_nullable |= a->src[s].nullable;
   // ---- LDS words: packed [rows : sum] words, MIN / MAX fields in the halves of one 64-bit word ---------------------------------
@@ -346,7 +348,9 @@ constexpr uint32_t kN = kBhmNone;
 static const BhmStaticShape kBhmShapes[] = {
     // MultiStep/MSBS001-005, MSPHS001-...: max(x100) + sum(x100), max(x10), max(x10 + 1) + sum(x10 + 1)
     HDK_BHM_SHAPE(1, 2, bhm_code(0, true, true, false, 0), bhm_code(1, false, true, false, 0), bhm_code(1, true, true, false, 1), kN),
-    // PerfectHashMultiCol/PHM001-006: count / sum / max / min / avg of one column by two keys (and by three)
+    // PerfectHashMultiCol/PHM001-006: count / sum / max / min / avg of one column by two keys (and by three); by one key:
+    // BaselineHash/BH004, PerfectHashSingleCol/PHS004 (10 000 groups: 12 bytes an entry fit one CU's LDS)
+    HDK_BHM_SHAPE(1, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
     HDK_BHM_SHAPE(2, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
     HDK_BHM_SHAPE(3, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
     // sums (counts, averages) of two columns: MultiStep/MSBS006-007, MSPHM's SUM(x10), SUM(y10) by one key and by two

@@ -300,6 +300,9 @@ def _mid_table(n, groups, seed, hot=0.0):
 def _two_pass_kernels(bins, monkeypatch):
     """tables beyond LDS: 256 bins by key RANGE with 4-byte tuples when the key column's statistics are dense enough (all of
     these tests' tables), or -- with the switch -- by the key's hash with 8-byte tuples, as for sparse keys"""
+    # (round 6: tables up to ~12 000 groups fit LDS at the multi-argument kernel's 12 bytes an entry and run in ONE pass,
+    # tests/test_gpu_bhm.py; these tests are about the two-pass forms, which still take what is larger)
+    monkeypatch.setenv("HDK_HIP_NO_BHM", "1")
     if bins == "hash":
         monkeypatch.setenv("HDK_HIP_NO_BH_DENSE_PARTITIONS", "1")
     return "hdk_bh_dscatter,hdk_bh_daggregate" if bins == "range" else "hdk_bh_scatter,hdk_bh_aggregate"

@@ -146,3 +146,14 @@ def test_routing_limits(oracle, gpu_executor_factory):
     s2 = ex.prepare(ex.compile(msphs(3)))
     assert not s2.kernel_names().startswith(BHM)
     s2.free()
+
+
+@pytest.mark.parametrize("groups,hot", [(9_000, 0.0), (8_000, 0.7)])
+def test_bh004_size_class_in_one_pass(oracle, gpu_executor_factory, groups, hot):
+    """BaselineHash/BH004 and PerfectHashSingleCol/PHS004 (10 000 groups, five aggregates of one column): 24 bytes an entry
+    do not fit a CU's LDS (the packed kernels took two passes: 0.19 of the roofline), 12 bytes do -- one pass, also with a hot
+    key (70 % of the rows in one group: nothing overflows, the packed fields are sized for a block's rows)."""
+    from test_gpu_bh_lds import _bh_query, _mid_table, _phs_query
+    st = _mid_table(3_300_000, groups, 27, hot)
+    for q in (_bh_query("x"), _phs_query("x")):
+        cp, res = _run(oracle, gpu_executor_factory, st, q)

@@ -99,6 +99,14 @@ def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     assert _names(compile_query(storage, _bh("x1k"))) == one_pass
     assert _names(compile_query(storage, _bh("x4k"))) == one_pass  # (4 096 dense entries under one 512-thread block per CU)
     assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"
+    # BH004's 10 000 groups: 24 bytes an entry do not fit a CU's LDS, the multi-argument kernel's 12 do -- ONE pass (round 6)
+    st10k = ArrowStorage()
+    rng10k = np.random.default_rng(4)
+    st10k.import_numpy("syn", {"x10k": rng10k.integers(1, 10_001, 50_000).astype(np.int32), "y10": rng10k.integers(1, 11, 50_000).astype(np.int32)},
+                       fragment_size=20_000)
+    assert _names(compile_query(st10k, _bh("x10k"))) == "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_bhm_fold"
+    ph10k = QueryUnit("syn", groupby=[ColRef("x10k")], targets=[KeyRef(0, "k")] + [Agg(k, ColRef("y10")) for k in ("count", "sum", "max", "min", "avg")])
+    assert _names(compile_query(st10k, ph10k)) == "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_finalize"
     # filtered: the general kernels; an fp argument: the word form; a modulo key: a dense table over (-m, m) in the general
     # kernels when the aggregates are the packed shape, else the interpreter with an LDS table
     assert _names(compile_query(storage, _bh("x10", quals=[Cmp(ColRef("y10"), "<=", Lit(7))]))) == "hdk_scan_agg_bh_dense,hdk_bh_fold_slabs"
