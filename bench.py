@@ -336,6 +336,16 @@ def run_config(name, args, comm, mgr, steps, warmup, primary):
         mine = torch.tensor([want if want < 2**63 else want - 2**64], dtype=torch.int64, device="cuda")
         comm.all_reduce(mine)
         checks["sum_equals_torch_gather_sum"] = bool((int(final[0]) - int(mine.item())) % (1 << 64) == 0)
+    elif name in __import__("workloads").SYN_SUITE:
+        # the suite's NonGroupedAgg / MultiStep / PerfectHashMultiCol shapes: every group and target against torch.bincount /
+        # index_add_ / scatter_reduce_ over the same columns (workloads.Workload.check_syn)
+        final = out_t.cpu().numpy()
+        cols = ExecutionResult(cp, final, cp.entry_count).to_columns()
+        checks["groups"] = len(next(iter(cols.values())))
+        checks["every_group_and_target_equals_torch"] = bool(w.check_syn(cols, ref["syn"]))
+        one_step()
+        torch.cuda.synchronize()
+        checks["idempotent"] = bool(w.check_syn(ExecutionResult(cp, out_t.cpu().numpy(), cp.entry_count).to_columns(), ref["syn"]))
     elif name.startswith("bh"):
         # the reference's BaselineHash benchmark shape: every group's count / sum / max / min (and avg = sum / count) against
         # torch.bincount / index_add_ / scatter_reduce_ over the same columns
@@ -819,7 +829,7 @@ def main():
     del w
     extra = args.extra
     if extra == "auto":
-        extra = "c3,c3g,c3gm,c3m,bh1,bh3,bh5,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
+        extra = "c3,c3g,c3gm,c3m,bh1,bh3,bh4,bh5,nga2,msbs1,msphs1,phm2,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
     if extra == "none":
         extra = ""
     configs = []

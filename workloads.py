@@ -58,6 +58,14 @@ CONFIGS = {
     "bh3": (1_000_000_000, 8, "BH003: the same by cast(x1k AS double); 1 K groups"),
     "bh4": (1_000_000_000, 8, "BH004: the same by cast(x10k AS double); 10 K groups"),
     "bh5": (1_000_000_000, 8, "BH005: the same by cast(x100k AS double); 100 K groups"),
+    # the same suite's other families (tests/syn_queries.py holds the queries): NonGroupedAgg, MultiStep, PerfectHashMultiCol
+    "nga2": (1_000_000_000, 24, "NGA02: SELECT SUM(x10), SUM(y10), SUM(z10), SUM(x100), SUM(y100), SUM(z100); six INT columns, no key"),
+    "nga5": (1_000_000_000, 24, "NGA05: SELECT AVG(x10), AVG(y10), AVG(z10), AVG(x100), AVG(y100), AVG(z100)"),
+    "msbs1": (1_000_000_000, 12, "MSBS001: SELECT cast(x1k AS double), count(*), max(x100), max(x10), max(x10 + 1), sum(x100), sum(x10 + 1) "
+                                 "GROUP BY 1; 1 K groups, open addressing (the query's post-aggregate arithmetic is above the hot path)"),
+    "msphs1": (1_000_000_000, 12, "MSPHS001: the same by x1k itself; 1 K groups, perfect hash"),
+    "phm2": (1_000_000_000, 12, "PHM002: SELECT x100, y10, count(z10), sum(z10), max(z10), min(z10), avg(z10) GROUP BY 1, 2; 1 K groups, "
+                                "two-column perfect hash"),
     "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
     "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
     "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
@@ -65,6 +73,33 @@ CONFIGS = {
     "q3": (1_000_000_000, 10, "taxi Q3: SELECT passenger_count, extract(year from pickup_datetime), COUNT(*) GROUP BY 1, 2"),
     "q4": (1_000_000_000, 18, "taxi Q4: SELECT passenger_count, extract(year ...), cast(trip_distance as int), COUNT(*) GROUP BY 1, 2, 3"),
 }
+
+
+# name -> query (built from tests/syn_queries.py: the reference's synthetic benchmark suite beyond BaselineHash)
+SYN_SUITE = {
+    "nga2": lambda SQ: SQ.nga(2),
+    "nga5": lambda SQ: SQ.nga(5),
+    "msbs1": lambda SQ: SQ.msbs(1, key_type=__import__("hdk_amd.ir", fromlist=["FP64"]).FP64),
+    "msphs1": lambda SQ: SQ.msphs(1),
+    "phm2": lambda SQ: SQ.phm(2),
+}
+
+
+def _expr_columns(e, out):
+    from hdk_amd.ir import ColRef
+    if isinstance(e, ColRef):
+        out.add(e.name)
+    for attr in ("arg", "lhs", "rhs"):
+        x = getattr(e, attr, None)
+        if x is not None and not isinstance(x, (int, float, str)):
+            _expr_columns(x, out)
+
+
+def _query_columns(q):
+    out = set()
+    for e in list(q.groupby) + [t.arg for t in q.targets if getattr(t, "arg", None) is not None]:
+        _expr_columns(e, out)
+    return out
 
 
 class Workload:
@@ -139,6 +174,17 @@ class Workload:
                                    targets=[KeyRef(0, "key0"), Agg("count", y, "c"), Agg("sum", y, "s"), Agg("max", y, "mx"),
                                             Agg("min", y, "mn"), Agg("avg", y, "a")])
             self.key_col, self.val_col = ("syn", "x"), ("syn", "y10")
+        elif name in SYN_SUITE:
+            import os
+            import sys
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import syn_queries as SQ
+            self.query = SYN_SUITE[name](SQ)
+            I32 = Type("int", 4, True)
+            names = sorted(_query_columns(self.query))
+            table("syn", {c: (I32, uniform(1, SQ.SYN_COLUMNS[c] + 1, 20 + sorted(SQ.SYN_COLUMNS).index(c), torch.int32), (1, SQ.SYN_COLUMNS[c]))
+                          for c in names}, self.frag_rows, self.frag_ids)
+            self.syn_hi = {c: SQ.SYN_COLUMNS[c] for c in names}
         elif name in ("c3", "c3g", "c3gm", "c3m"):
             self.dim_rows = int(dim_rows)
             self.description = self.description.replace("dim(10 M rows)", f"dim({self.dim_rows / 1e6:g} M rows)")
@@ -227,6 +273,8 @@ class Workload:
             for f in self.frag_ids:
                 total = (total + int(self.cols[self.val_col][f].sum().item())) % (1 << 64)
             out["sum_val"] = total
+        elif self.name in SYN_SUITE:
+            out["syn"] = self._syn_reference()
         elif self.name.startswith("bh"):
             g = self.bh_groups
             cnt = torch.zeros(g + 1, dtype=torch.int64, device=self.dev)
@@ -285,6 +333,97 @@ class Workload:
                                     self.cols[("trips", "total_amount")][f])
                 out["key_sums"] = [int(x) for x in sums.cpu().tolist()]
         return out
+
+    # ---- the suite's other families: every group and target from plain torch ops over the same tensors ---------------------------
+    def _syn_eval(self, e, f):
+        """int64 tensor of expression `e` (a column, column + / - / * literal, cast(column AS ...)) over fragment f."""
+        from hdk_amd.ir import BinOp, Cast, ColRef, Lit
+        torch = self.torch
+        if isinstance(e, ColRef):
+            return self.cols[("syn", e.name)][f].to(torch.int64)
+        if isinstance(e, Cast):
+            return self._syn_eval(e.arg, f)
+        if isinstance(e, BinOp) and isinstance(e.rhs, Lit):
+            a = self._syn_eval(e.lhs, f)
+            return {"+": a + int(e.rhs.value), "-": a - int(e.rhs.value), "*": a * int(e.rhs.value)}[e.op]
+        raise ValueError(f"not a suite expression: {e}")
+
+    def _syn_reference(self):
+        """{'dims': [...], 'targets': {name: list by dense group id}} -- bincount / index_add_ / scatter_reduce_ per fragment."""
+        from hdk_amd.ir import Agg
+        torch = self.torch
+        q = self.query
+        dims = []
+        for k in q.groupby:
+            cs = set()
+            _expr_columns(k, cs)
+            dims.append(self.syn_hi[cs.pop()])
+        G = 1
+        for d in dims:
+            G *= d
+        aggs = [t for t in q.targets if isinstance(t, Agg)]
+        cnt = torch.zeros(G, dtype=torch.int64, device=self.dev)
+        acc = {}
+        for t in aggs:
+            if t.arg is not None:
+                init = {"max": -(1 << 62), "min": 1 << 62}.get(t.kind, 0)
+                acc[t.name] = torch.full((G,), init, dtype=torch.int64, device=self.dev)
+        for f in self.frag_ids:
+            gid = None
+            stride = 1
+            for k, d in zip(q.groupby, dims):
+                term = (self._syn_eval(k, f) - 1) * stride
+                gid = term if gid is None else gid + term
+                stride *= d
+            if gid is None:
+                gid = torch.zeros(self.frag_rows[f], dtype=torch.int64, device=self.dev)
+            cnt += torch.bincount(gid, minlength=G)
+            for t in aggs:
+                if t.arg is None:
+                    continue
+                v = self._syn_eval(t.arg, f)
+                if t.kind in ("sum", "avg"):
+                    acc[t.name].index_add_(0, gid, v)
+                elif t.kind == "max":
+                    acc[t.name] = torch.maximum(acc[t.name], torch.full_like(acc[t.name], -(1 << 62)).scatter_reduce_(0, gid, v, "amax", include_self=True))
+                elif t.kind == "min":
+                    acc[t.name] = torch.minimum(acc[t.name], torch.full_like(acc[t.name], 1 << 62).scatter_reduce_(0, gid, v, "amin", include_self=True))
+                del v
+            del gid
+        return {"dims": dims, "count": cnt.cpu().tolist(), "targets": {n: a.cpu().tolist() for n, a in acc.items()}}
+
+    def check_syn(self, cols, ref):
+        """The launch's result columns (ExecutionResult.to_columns) against _syn_reference(): every group, every target; AVG
+        within 1e-6 relative (a double quotient), everything else exact."""
+        from hdk_amd.ir import Agg, KeyRef
+        q = self.query
+        dims, cnt = ref["dims"], ref["count"]
+        keys = [t for t in q.targets if isinstance(t, KeyRef)]
+        aggs = [t for t in q.targets if isinstance(t, Agg)]
+        nrows = len(cols[aggs[0].name])
+        if nrows != sum(1 for c in cnt if c):
+            return False
+        for i in range(nrows):
+            gid, stride = 0, 1
+            for t, d in zip(sorted(keys, key=lambda t: t.idx), dims):
+                kv = cols[t.name][i]
+                if kv is None or kv != int(kv):
+                    return False
+                gid += (int(kv) - 1) * stride
+                stride *= d
+            n = cnt[gid]
+            for t in aggs:
+                got = cols[t.name][i]
+                if t.kind == "count":
+                    ok = got == n
+                elif t.kind == "avg":
+                    want = ref["targets"][t.name][gid] / n
+                    ok = got is not None and abs(got - want) <= 1e-6 * max(abs(want), 1e-300)
+                else:
+                    ok = got == ref["targets"][t.name][gid]
+                if not ok:
+                    return False
+        return True
 
     def distinct_keys(self):
         """Number of distinct group keys over the local rows (c2 / c5): torch.unique on the concatenated key column."""
