@@ -1,6 +1,7 @@
 """Expected output of tests/cpp/harness.cpp, computed with numpy from the harness's data definition (a splitmix64
 finaliser of the row number), independent of every line of device code.
-    python tests/golden/gen_cpp_harness_golden.py > tests/golden/cpp_harness_output.txt"""
+    python tests/golden/gen_cpp_harness_golden.py > tests/golden/cpp_harness_output.txt
+    python tests/golden/gen_cpp_harness_golden.py multi_device > tests/golden/cpp_multi_device_output.txt"""
 import numpy as np
 
 NULL = np.iinfo(np.int64).min
@@ -96,5 +97,16 @@ def expected_lines():
     return out
 
 
+def multi_device_lines():
+    """Expected output of tests/cpp/multi_device.cpp: the c2 and c5 steps' data spread over the devices of a node and merged
+    over RCCL -- the same groups whatever the number of devices."""
+    out = []
+    for ln in expected_lines():
+        if ln.startswith("c2 ") or ln.startswith("c5 "):
+            out.append("mg_" + ln)
+    return out
+
+
 if __name__ == "__main__":
-    print("\n".join(expected_lines()))
+    import sys
+    print("\n".join(multi_device_lines() if sys.argv[1:] == ["multi_device"] else expected_lines()))

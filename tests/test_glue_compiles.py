@@ -103,3 +103,15 @@ def test_cpp_harness_golden_is_what_the_generator_prints():
     spec.loader.exec_module(mod)
     want = open(os.path.join(ROOT, "tests", "golden", "cpp_harness_output.txt")).read().strip().split("\n")
     assert mod.expected_lines() == want
+    want_mg = open(os.path.join(ROOT, "tests", "golden", "cpp_multi_device_output.txt")).read().strip().split("\n")
+    assert mod.multi_device_lines() == want_mg
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists("/opt/rocm/include/rccl/rccl.h")), reason="reference tree / RCCL headers not present")
+def test_multi_device_merge_host_compiles_against_rccl():
+    """hdk_amd/glue/HipReduce.h (ncclCommInitAll, ncclAllGather, grouped ncclSend / ncclRecv around the C ABI's reduce and
+    tuple-exchange calls) and its harness compile against the image's rccl.h -- and link, so that every symbol it names
+    exists in librccl / libamdhip64 / libhdk_hip (running it needs a GPU: tests/test_gpu_cpp_harness.py)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "--no-print-directory",
+                           os.path.join(ROOT, "tests", "cpp", "_build", "multi_device")])
+    assert os.access(os.path.join(ROOT, "tests", "cpp", "_build", "multi_device"), os.X_OK)

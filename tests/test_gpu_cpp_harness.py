@@ -30,3 +30,22 @@ def test_cpp_harness_matches_the_golden():
     err = r.stderr
     assert "c2: hdk_scan_agg_direct" in err and "q3: hdk_scan_agg_keys" in err, err
     assert "c5: hdk_part_scatter" in err and "projection: hdk_scan_project" in err and "floats: hdk_scan_agg_keys_values" in err, err
+
+
+@pytest.mark.gpu
+def test_cpp_multi_device_merge_matches_the_golden():
+    """tests/cpp/multi_device.cpp: hdk_amd/glue/HipReduce.h -- ONE process, ncclCommInitAll over every device HipMgr reports,
+    a host thread per device: ncclAllGather + hdk_hip_reduce_buffers for the perfect-hash partials, hdk_hip_scatter_to_owners
+    -> grouped ncclSend / ncclRecv -> hdk_hip_aggregate_from_ranks for the open-addressing group-by.  The result does not
+    depend on the number of devices (one here: a rank exchanging with itself, every kernel and both collectives run)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "multi_device")
+    if os.path.isdir("/root/reference/omniscidb"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "--no-print-directory"])
+    assert os.path.exists(exe), "tests/cpp/_build/multi_device is missing: run __graft_entry__.build() in the build container"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    want = [w for w in open(os.path.join(ROOT, "tests", "golden", "cpp_multi_device_output.txt")).read().split("\n") if w]
+    got = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("mg_")]  # (RCCL may print a banner of its own)
+    assert got == want, r.stderr[-3000:]
+    assert "multi_device: " in r.stderr and "owner(s)" in r.stderr
