@@ -285,42 +285,10 @@ HDK_DEV void apply_value(const hdk_hip_target& tg, int8_t* slot, int64_t partial
   }
 }
 
-extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a) {
-  __shared__ WordLayout wl;
-  __shared__ int64_t s_words[kBlock / kWave][kMaxWordsPerEntry];
-  const hdk_hip_plan* __restrict__ p = a.plan;
-  if (a.skip_if && *a.skip_if) {
-    return;
-  }
-  if (threadIdx.x == 0) {
-    make_word_layout(p, &wl);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t entry = blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
-  if (entry >= a.entry_count) {
-    return;
-  }
-  const int wpe = wl.wpe;
-  const size_t ew = static_cast<size_t>(a.entry_count) * wpe;
-  // fold slabs: lane l takes slabs l, l+64, ...; then a fixed shuffle tree (deterministic order)
-  int64_t* words = s_words[threadIdx.x / kWave];  // written and read by lane 0 only
-  for (int w = 0; w < wpe; ++w) {
-    const int32_t op = wl.wop[w];
-    int64_t acc = word_identity(op);
-    for (uint32_t b = lane; b < a.num_slabs; b += kWave) {
-      acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
-    }
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-      acc = word_combine(op, acc, shfl_down_i64(acc, d));
-    }
-    if (lane == 0) {
-      words[w] = acc;
-    }
-  }
-  if (lane != 0) {
-    return;
-  }
+// One entry's folded partial words into the output buffer: the exact agg_*[_skip_val] semantics (QE/RuntimeFunctions.cpp:
+// 387-875), so that repeated launches accumulate like repeated row-function calls.  words[w * ws]: word w of the layout.
+HDK_DEV void finalize_apply(const hdk_hip_plan* __restrict__ p, const WordLayout& wl, const FinalizeArgs& a, uint32_t entry,
+                            const int64_t* words, int ws) {
   const int64_t rowcount = words[0];
   if (rowcount == 0) {
     return;
@@ -394,7 +362,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
     }
     const int vw = wl.vword[t];
     const int nw = wl.nword[t];
-    const int64_t nn = nw >= 0 ? words[nw] : rowcount;
+    const int64_t nn = nw >= 0 ? words[nw * ws] : rowcount;
     switch (tg.agg) {
       case HDK_AGG_COUNT:
         apply_count(s1, tg.slot_width, nn);
@@ -420,14 +388,85 @@ extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a
       }
       case HDK_AGG_AVG:
         apply_count(s2, tg.slot2_width, nn);
-        apply_value(tg, s1, words[vw], nn, rowcount);
+        apply_value(tg, s1, words[vw * ws], nn, rowcount);
         break;
       default:
-        apply_value(tg, s1, words[vw], nn, rowcount);
+        apply_value(tg, s1, words[vw * ws], nn, rowcount);
         break;
     }
     slot_idx += tg.agg == HDK_AGG_AVG ? 2 : 1;
   }
+}
+
+
+extern "C" __global__ __launch_bounds__(kBlock) void hdk_finalize(FinalizeArgs a) {
+  __shared__ WordLayout wl;
+  __shared__ int64_t s_words[kBlock / kWave][kMaxWordsPerEntry];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  if (a.skip_if && *a.skip_if) {
+    return;
+  }
+  if (threadIdx.x == 0) {
+    make_word_layout(p, &wl);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t entry = blockIdx.x * (kBlock / kWave) + (threadIdx.x / kWave);
+  if (entry >= a.entry_count) {
+    return;
+  }
+  const int wpe = wl.wpe;
+  const size_t ew = static_cast<size_t>(a.entry_count) * wpe;
+  // fold slabs: lane l takes slabs l, l+64, ...; then a fixed shuffle tree (deterministic order)
+  int64_t* words = s_words[threadIdx.x / kWave];  // written and read by lane 0 only
+  for (int w = 0; w < wpe; ++w) {
+    const int32_t op = wl.wop[w];
+    int64_t acc = word_identity(op);
+    for (uint32_t b = lane; b < a.num_slabs; b += kWave) {
+      acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      acc = word_combine(op, acc, shfl_down_i64(acc, d));
+    }
+    if (lane == 0) {
+      words[w] = acc;
+    }
+  }
+  if (lane != 0) {
+    return;
+  }
+  finalize_apply(p, wl, a, entry, words, 1);
+}
+
+// Few slabs, many entries (the two-pass group-bys leave 8 slabs of a 100 K-entry table: a WAVE per entry took 343 us for it):
+// a THREAD per entry folds the slabs' words itself.
+constexpr int kFinalizeFlatBlock = 256;
+extern "C" __global__ __launch_bounds__(kFinalizeFlatBlock) void hdk_finalize_flat(FinalizeArgs a) {
+  __shared__ WordLayout wl;
+  __shared__ int64_t s_words[kMaxWordsPerEntry][kFinalizeFlatBlock];
+  const hdk_hip_plan* __restrict__ p = a.plan;
+  if (a.skip_if && *a.skip_if) {
+    return;
+  }
+  if (threadIdx.x == 0) {
+    make_word_layout(p, &wl);
+  }
+  __syncthreads();
+  const uint32_t entry = blockIdx.x * kFinalizeFlatBlock + threadIdx.x;
+  if (entry >= a.entry_count) {
+    return;
+  }
+  const int wpe = wl.wpe;
+  const size_t ew = static_cast<size_t>(a.entry_count) * wpe;
+  for (int w = 0; w < wpe; ++w) {
+    const int32_t op = wl.wop[w];
+    int64_t acc = word_identity(op);
+    for (uint32_t b = 0; b < a.num_slabs; ++b) {
+      acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+    }
+    s_words[w][threadIdx.x] = acc;
+  }
+  finalize_apply(p, wl, a, entry, &s_words[0][threadIdx.x], kFinalizeFlatBlock);
 }
 
 }  // namespace hdk
@@ -2486,6 +2525,11 @@ int32_t hdk::launch_finalize_slabs(const hdk_hip_plan* d_plan, const int64_t* sl
   fa.num_slabs = num_slabs;
   fa.entry_count = entry_count;
   fa.skip_if = skip_if;
+  if (num_slabs <= 16 && entry_count >= 2048) {  // few slabs of a large table: a thread per entry
+    hipLaunchKernelGGL(hdk_finalize_flat, dim3((entry_count + kFinalizeFlatBlock - 1) / kFinalizeFlatBlock), dim3(kFinalizeFlatBlock), 0, s, fa);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
+  }
   const unsigned fblocks = (entry_count + (kBlock / kWave) - 1) / (kBlock / kWave);
   hipLaunchKernelGGL(hdk_finalize, dim3(fblocks), dim3(kBlock), 0, s, fa);
   HDK_HIP_CHECK(hipGetLastError());

@@ -204,11 +204,9 @@ HDK_DEV void bhm_mm_improve(const BhmArgs& ar, uint32_t* word, uint32_t cand_lo,
 
 // NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s.  `stale` collects "the statistics do
 // not hold" (the caller raises the launch's flag).
-template <class C, int NK, int NS, int NR>
-HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR], const int32_t (&x)[NS][NR], uint32_t& stale) {
-  const uint32_t dummy = a.entries;
-  const bool nulls = C::nulls(a);
-  uint32_t e[NR];
+// the dense entry of NR rows from their key columns (dummy = the entry behind the table for a key outside the statistics)
+template <int NK, int NR>
+HDK_DEV void bhm_key_entries(const BhmArgs& a, bool nulls, uint32_t dummy, const int32_t (&k)[NK][NR], uint32_t (&e)[NR], uint32_t& stale) {
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     uint32_t idx = 0;
@@ -230,8 +228,11 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
     stale |= bad ? 1u : 0u;
     e[j] = bad ? dummy : idx;
   }
-  // the argument columns against their statistics; live: not NULL (and inside them)
-  bool live[NS][NR];
+}
+
+// the argument columns against their statistics; live: not NULL (and inside them)
+template <int NS, int NR>
+HDK_DEV void bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[NS][NR], bool (&live)[NS][NR], uint32_t& stale) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const BhmSrc& src = a.src[s];
@@ -249,6 +250,25 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
       }
     }
   }
+}
+
+template <class C, int NS, int NR>
+HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]);
+
+template <class C, int NK, int NS, int NR>
+HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR], const int32_t (&x)[NS][NR], uint32_t& stale) {
+  const bool nulls = C::nulls(a);
+  uint32_t e[NR];
+  bhm_key_entries<NK, NR>(a, nulls, a.entries, k, e, stale);
+  bool live[NS][NR];
+  bhm_src_live<NS, NR>(a, nulls, x, live, stale);
+  bhm_update<C, NS, NR>(a, rp, a.entries, e, x, live);
+}
+
+// the LDS updates of NR rows whose entries are known (e[j]; `dummy` for rows that do not take part)
+template <class C, int NS, int NR>
+HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]) {
+  const bool nulls = C::nulls(a);
   uint32_t cand_lo[NR], cand_hi[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -634,11 +654,11 @@ struct BhmFoldArgs {
   int64_t key_null_word;
 };
 
-template <int DUMMY = 0>
+template <int FLAT = 0>
 __global__ __launch_bounds__(256) void hdk_bhm_fold(BhmFoldArgs a) {
   __shared__ WordLayout wl;
   __shared__ uint64_t s_col_off[2 * HDK_HIP_MAX_TARGETS];
-  __shared__ int64_t s_words[4][kMaxWordsPerEntry];
+  __shared__ int64_t s_words[FLAT ? kMaxWordsPerEntry : 4][FLAT ? 256 : kMaxWordsPerEntry];
   if (*a.flag) {
     return;  // the statistics did not hold: the slabs are not to be trusted (the armed fallback redoes the launch)
   }
@@ -649,33 +669,59 @@ __global__ __launch_bounds__(256) void hdk_bhm_fold(BhmFoldArgs a) {
     s_col_off[threadIdx.x] = a.plan->output_columnar ? columnar_slot_off(a.plan, a.out_entry_count, threadIdx.x) : 0;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t entry = blockIdx.x * 4 + wave;
-  if (entry >= a.entries) {
-    return;
-  }
   const int wpe = a.wpe;
   const size_t ew = static_cast<size_t>(a.entries) * wpe;
-  int64_t* words = s_words[wave];
-  for (int w = 0; w < wpe; ++w) {
-    const int32_t op = a.wop[w];
-    int64_t acc = word_identity(op);
-    for (uint32_t b = lane; b < a.num_slabs; b += 64) {
-      acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+  uint32_t entry;
+  const int64_t* words;
+  int ws;
+  if (FLAT) {
+    // few slabs of a large table (the two-pass form's eight): a THREAD per internal entry
+    entry = blockIdx.x * 256 + threadIdx.x;
+    if (entry >= a.entries) {
+      return;
     }
-    for (int d = 32; d > 0; d >>= 1) {
-      const int lo = __shfl_down(static_cast<int>(static_cast<uint32_t>(acc)), d, 64);
-      const int hi = __shfl_down(static_cast<int>(static_cast<uint64_t>(acc) >> 32), d, 64);
-      acc = word_combine(op, acc, static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+    for (int w = 0; w < wpe; ++w) {
+      const int32_t op = a.wop[w];
+      int64_t acc = word_identity(op);
+      for (uint32_t b = 0; b < a.num_slabs; ++b) {
+        acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+      }
+      s_words[FLAT ? w : 0][FLAT ? threadIdx.x : 0] = acc;
     }
-    if (lane == 0) {
-      words[w] = acc;
+    words = &s_words[0][FLAT ? threadIdx.x : 0];
+    ws = 256;
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    entry = blockIdx.x * 4 + wave;
+    if (entry >= a.entries) {
+      return;
     }
-  }
-  if (lane != 0 || words[0] == 0) {
-    return;  // (no row of this group: nothing to claim)
+    int64_t* wv = s_words[FLAT ? 0 : wave];
+    for (int w = 0; w < wpe; ++w) {
+      const int32_t op = a.wop[w];
+      int64_t acc = word_identity(op);
+      for (uint32_t b = lane; b < a.num_slabs; b += 64) {
+        acc = word_combine(op, acc, a.slabs[b * ew + static_cast<size_t>(entry) * wpe + w]);
+      }
+      for (int d = 32; d > 0; d >>= 1) {
+        const int lo = __shfl_down(static_cast<int>(static_cast<uint32_t>(acc)), d, 64);
+        const int hi = __shfl_down(static_cast<int>(static_cast<uint64_t>(acc) >> 32), d, 64);
+        acc = word_combine(op, acc, static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+      }
+      if (lane == 0) {
+        wv[w] = acc;
+      }
+    }
+    if (lane != 0) {
+      return;
+    }
+    words = wv;
+    ws = 1;
   }
   const int64_t rows = words[0];
+  if (rows == 0) {
+    return;  // (no row of this group: nothing to claim)
+  }
   int32_t err = 0;
   int64_t key;
   if (entry == a.null_entry) {
@@ -685,7 +731,7 @@ __global__ __launch_bounds__(256) void hdk_bhm_fold(BhmFoldArgs a) {
     key = a.key_form == 1 ? double_to_bits(static_cast<double>(kv)) : kv;
   }
   bh_fold_group_fn(a.plan, table_shape(a.plan), wl, a.kp.groupby_buf[0], a.out_entry_count, s_col_off, key,
-                   [&](int w) -> int64_t { return ((a.nword_mask >> w) & 1u) ? rows - words[w] : words[w]; }, err);
+                   [&](int w) -> int64_t { return ((a.nword_mask >> w) & 1u) ? rows - words[w * ws] : words[w * ws]; }, err);
   if (err) {
     record_error(a.kp.error_code, err);
   }

@@ -5,6 +5,7 @@
 
 #include "host_match.h"
 #include "scan_bhm.h"
+#include "scan_bhm_part.h"
 #include "scan_bhm_host.h"
 
 namespace hdk {
@@ -37,7 +38,8 @@ struct BhmGeom {
   int32_t wop[kMaxWordsPerEntry];
 };
 
-static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhmArgs* a, BhmGeom* g) {
+// the part of the match that does not depend on where the table lives: keys, arguments, LDS words per entry
+static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhmArgs* a, BhmGeom* g, uint32_t* per_entry_out, int64_t* amax_out) {
   const bool perfect = p->query_kind == HDK_Q_PERFECT_HASH;
   if (bhm_off() || (!perfect && p->query_kind != HDK_Q_BASELINE_HASH)) return false;
   if (!ko || ko->total_rows == 0 || ko->total_rows >= (1ull << 40)) return false;
@@ -297,13 +299,28 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
       from_field(sw.kind == BMW_MAX);
     }
   }
-  // ---- geometry -----------------------------------------------------------------------------------------------------------
+  *per_entry_out = 8u * static_cast<uint32_t>(a->npacked) + static_cast<uint32_t>(a->mm_bytes) + (a->rows_packed < 0 ? 4u : 0u);
+  *amax_out = amax;
+  g->nk = a->nkeys;
+  g->ns = a->nsrc;
+  return true;
+}
+
+// byte offsets of a replica's arrays for a table of a->entries entries
+static uint64_t bhm_lds_layout(BhmArgs* a, uint32_t per_entry) {
   a->e1 = (a->entries + 1 + 1) & ~1u;
-  const uint32_t per_entry = 8u * static_cast<uint32_t>(a->npacked) + static_cast<uint32_t>(a->mm_bytes) + (a->rows_packed < 0 ? 4u : 0u);
-  const uint64_t one = static_cast<uint64_t>(a->e1) * per_entry;
-  if (one > kBhmMaxLdsBytes) return false;
   a->off_mm = 8u * static_cast<uint32_t>(a->npacked) * a->e1;
   a->off_rows = a->off_mm + static_cast<uint32_t>(a->mm_bytes) * a->e1;
+  return static_cast<uint64_t>(a->e1) * per_entry;
+}
+
+// ONE pass: the whole dense table in a block's LDS
+static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhmArgs* a, BhmGeom* g) {
+  uint32_t per_entry;
+  int64_t amax;
+  if (!match_bhm_shape(p, ko, a, g, &per_entry, &amax)) return false;
+  const uint64_t one = bhm_lds_layout(a, per_entry);
+  if (one > kBhmMaxLdsBytes) return false;
   uint32_t rep_bytes = (static_cast<uint32_t>(one) + 15u) & ~15u;
   uint32_t rep = 16;
   while (rep > 1 && static_cast<uint64_t>(rep_bytes + 16) * rep > kBhmReplicatedBytes) rep >>= 1;
@@ -313,8 +330,6 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
   a->rep = rep;
   a->rep_bytes = rep_bytes;
   a->lds_bytes = rep_bytes * rep;
-  g->nk = a->nkeys;
-  g->ns = a->nsrc;
   g->block = a->lds_bytes > kBhmSmallLdsBytes ? 1024 : 256;
   // (256-thread blocks: three on a CU measured best -- msbs1 / msphs1 / phm2 at 256 M rows: 1 -> 1.06 / 1.04 / 0.79 ms, 2 -> 0.66 /
   // 0.63 / 0.60, 3 -> 0.63 / 0.60 / 0.60, 4 -> 0.74 / 0.72 / 0.71, 8 -> 0.94 / 0.93 / 0.89: more waves add LDS contention and slabs)
@@ -322,6 +337,63 @@ static bool match_bhm(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, B
   // rows a block may put into one entry: rows < 2^23, |sum| < 2^39
   const int64_t by_sum = ((1ll << 39) - 1) / amax;
   a->max_rows_per_block = static_cast<uint32_t>(std::min<int64_t>(by_sum, 1ll << 23));
+  return true;
+}
+
+// TWO passes (scan_bhm_part.h): bins of 2^w entries, 4-byte tuples
+constexpr uint32_t kBhmPartLdsBytes = 50u << 10;   // a bin's table in pass B: 4 096 entries of 12 bytes (three 256-thread blocks on a CU)
+struct BhmPartLayout {
+  size_t cursor_bytes, tuple_bytes, slab_bytes, total;
+};
+static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko, BhmPartArgs* pg, BhmGeom* g, BhmPartLayout* l) {
+  if (hdk_sw(SW_NO_BHM_PARTITIONS) || hdk_sw(SW_NO_BH_PARTITIONS)) return false;
+  memset(pg, 0, sizeof(*pg));
+  BhmArgs* a = &pg->b;
+  uint32_t per_entry;
+  int64_t amax;
+  if (!match_bhm_shape(p, ko, a, g, &per_entry, &amax)) return false;
+  const bool always = hdk_sw(SW_BH_PARTITIONS_ALWAYS) != nullptr;  // (tests: small inputs and tables)
+  if (!always && ko->total_rows < (4ull << 20)) return false;
+  const uint32_t total = a->entries;
+  // the largest bin that fits pass B's LDS, but at least 64 bins while the table has that many groups of 16 (pass B runs
+  // 8 blocks per bin: parallelism) -- and never more than 256 bins
+  uint32_t w = 4;
+  while (w < 14 && (static_cast<uint64_t>((2u << w) + 2) * per_entry) <= kBhmPartLdsBytes) ++w;
+  uint32_t min_bins = 128;  // (256 M rows, msbs2 / msphs3 / phm4 / bh5: 8 bins 3.12 / 1.71 / 1.47 / 1.35 ms, 32: 1.56 / 1.71 / 1.47 / 1.35, 64: 1.41 / 1.54 /
+                            // 1.37 / 1.21, 128: 1.32 / 1.48 / 1.33 / 1.20: pass B wants blocks)
+  if (const char* e = hdk_sw(SW_BHM_PART_MIN_BINS)) min_bins = static_cast<uint32_t>(std::max(1, atoi(e)));  // (measurements)
+  while (w > 4 && ((total + (1u << w) - 1) >> w) < min_bins) --w;
+  while (((total + (1u << w) - 1) >> w) > kPbMaxBins) ++w;
+  if (static_cast<uint64_t>((1u << w) + 2) * per_entry > kBhmPartLdsBytes) return false;  // too many groups for 256 bins
+  pg->w = w;
+  pg->nbins = (total + (1u << w) - 1) >> w;
+  pg->total_entries = total;
+  // the tuple: [entry inside the bin | code of every argument column]
+  uint32_t pos = w;
+  for (int s = 0; s < a->nsrc; ++s) {
+    const uint32_t cb = bits_for(static_cast<uint64_t>(a->src[s].raw_span) + 2);
+    if (pos + cb > 32) return false;
+    pg->cshift[s] = pos;
+    pg->cmask[s] = static_cast<uint32_t>((1ull << cb) - 1);
+    pos += cb;
+  }
+  // pass B's table: one bin, one replica
+  a->entries = 1u << w;
+  const uint64_t one = bhm_lds_layout(a, per_entry);
+  a->rep = 1;
+  a->rep_bytes = (static_cast<uint32_t>(one) + 15u) & ~15u;
+  a->lds_bytes = a->rep_bytes;
+  a->max_rows_per_block = 0xFFFFFFFFu;  // (pass B checks its own bound: a sub-slab's capacity)
+  // twice a sub-slab's even share of the rows (a hot key overflows it: the flag, the armed fallback)
+  pg->cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 3) & ~3ull;
+  const int64_t by_sum = ((1ll << 39) - 1) / amax;
+  if (pg->cap > 0xFFFFFFF0ull || static_cast<int64_t>(pg->cap) > std::min<int64_t>(by_sum, 1ll << 23)) return false;
+  l->cursor_bytes = static_cast<size_t>(pg->nbins) * kPbXcds * kPbCursorStride * sizeof(uint32_t);
+  // (after pass B the tuples are spent and their space takes the ONE slab the eight are reduced to: at least that much)
+  l->tuple_bytes = std::max(static_cast<size_t>(pg->nbins) * kPbXcds * pg->cap * 4, static_cast<size_t>(total) * a->wpe * 8);
+  l->slab_bytes = static_cast<size_t>(kPbXcds) * total * a->wpe * 8;
+  if (l->slab_bytes > (1ull << 30)) return false;  // (PHM005's 1 M entries: 700 MB of slabs, written and read once)
+  l->total = 256 + l->cursor_bytes + l->tuple_bytes + l->slab_bytes;
   return true;
 }
 
@@ -341,9 +413,13 @@ struct BhmStaticShape {
   int nk, ns;
   uint32_t code[kBhmMaxDer];
   const void* (*kernel)(int block);
+  const void* (*aggregate)();  // pass B of the two-pass form (the keys are folded into the tuple: NK does not matter)
 };
-#define HDK_BHM_SHAPE(NK, NS, D0, D1, D2, D3) \
-  { NK, NS, {D0, D1, D2, D3}, [](int block) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3>, NK, NS>(block); } }
+#define HDK_BHM_SHAPE(NK, NS, D0, D1, D2, D3)                                                                            \
+  {                                                                                                                      \
+    NK, NS, {D0, D1, D2, D3}, [](int block) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3>, NK, NS>(block); }, \
+        []() -> const void* { return reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS>); }   \
+  }
 constexpr uint32_t kN = kBhmNone;
 static const BhmStaticShape kBhmShapes[] = {
     // MultiStep/MSBS001-005, MSPHS001-...: max(x100) + sum(x100), max(x10), max(x10 + 1) + sum(x10 + 1)
@@ -361,6 +437,15 @@ static const BhmStaticShape kBhmShapes[] = {
     HDK_BHM_SHAPE(1, 1, bhm_code(0, true, false, false, 1), kN, kN, kN),
 };
 #undef HDK_BHM_SHAPE
+
+template <int NK>
+static const void* bhm_scatter_nk(int ns) {
+  return ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 1>)
+                 : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 2>) : reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 3>));
+}
+static const void* bhm_scatter_kernel(const BhmGeom& g) {
+  return g.nk == 1 ? bhm_scatter_nk<1>(g.ns) : (g.nk == 2 ? bhm_scatter_nk<2>(g.ns) : bhm_scatter_nk<3>(g.ns));
+}
 
 static uint32_t bhm_code_of(const BhmArgs& a, int i) {
   if (i >= a.nder) return kBhmNone;
@@ -385,11 +470,116 @@ static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_stati
   return g.nk == 1 ? bhm_dynamic_nk<1>(g.ns, g.block) : (g.nk == 2 ? bhm_dynamic_nk<2>(g.ns, g.block) : bhm_dynamic_nk<3>(g.ns, g.block));
 }
 
+static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g) {
+  if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
+    for (const BhmStaticShape& sh : kBhmShapes) {
+      bool same = sh.ns == g.ns;  // (any NK: pass B sees entries, not keys)
+      for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
+      if (same) return sh.aggregate();
+    }
+  }
+  return g.ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 1>)
+                   : (g.ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 2>)
+                                : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 3>));
+}
+
 const char* bhm_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
   BhmArgs a;
   BhmGeom g;
-  if (!match_bhm(p, ko, &a, &g)) return nullptr;
+  if (!match_bhm(p, ko, &a, &g)) {
+    BhmPartArgs pg;
+    BhmPartLayout l;
+    if (match_bhm_part(p, ko, &pg, &g, &l)) {
+      return g.perfect ? "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_finalize"
+                       : "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_bhm_fold";
+    }
+    return nullptr;
+  }
   return g.perfect ? "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_finalize" : "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_bhm_fold";
+}
+
+// the fold of `fold_count` slabs of the dense table (internal entry i = key_lo + i ...) into the plan's output, and the armed fallback
+static int32_t launch_bhm_folds(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                                const hdk_hip_device_properties* props, hipStream_t s, const BhmArgs& a, const BhmGeom& g, uint32_t entries,
+                                const int64_t* fold_slabs, uint32_t fold_count) {
+  int32_t st;
+  if (g.perfect) {
+    st = launch_finalize_slabs(d_plan, fold_slabs, kp.groupby_buf, fold_count, plan->entry_count, a.flag, s);
+    if (st) return st;
+  } else {
+    BhmFoldArgs f;
+    memset(&f, 0, sizeof(f));
+    f.plan = d_plan;
+    f.kp = kp;
+    f.slabs = fold_slabs;
+    f.flag = a.flag;
+    f.num_slabs = fold_count;
+    f.entries = entries;
+    f.out_entry_count = plan->entry_count;
+    f.wpe = a.wpe;
+    for (int w = 0; w < a.wpe; ++w) f.wop[w] = g.wop[w];
+    f.nword_mask = g.nword_mask;
+    f.key_form = a.key_form;
+    f.key_lo = g.key_lo;
+    f.null_entry = g.null_entry;
+    f.key_null_word = a.key_null_word;
+    if (fold_count <= 16 && entries >= 2048) {  // few slabs of a large table: a thread per entry
+      hipLaunchKernelGGL(hdk_bhm_fold<1>, dim3((entries + 255) / 256), dim3(256), 0, s, f);
+    } else {
+      hipLaunchKernelGGL(hdk_bhm_fold<0>, dim3((entries + 3) / 4), dim3(256), 0, s, f);
+    }
+    HDK_HIP_CHECK(hipGetLastError());
+  }
+  // armed: runs only when the flag says the statistics did not hold (the folds skipped then)
+  return launch_scan_global_armed(plan, d_plan, kp, ko, props, s, a.flag);
+}
+
+static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
+                               const hdk_hip_device_properties* props, hipStream_t s, BhmPartArgs& pg, const BhmGeom& g, const BhmPartLayout& l,
+                               bool* launched) {
+  AsyncScratch scratch(s);
+  if (hipMallocAsync(&scratch.p, l.total, s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch.p = nullptr;
+    return HDK_HIP_OK;  // no room for the tuples: the other strategies
+  }
+  int8_t* base = static_cast<int8_t*>(scratch.p);
+  HDK_HIP_CHECK(hipMemsetAsync(base, 0, 256 + l.cursor_bytes, s));
+  BhmArgs& a = pg.b;
+  a.plan = d_plan;
+  a.kp = kp;
+  a.flag = reinterpret_cast<uint32_t*>(base);
+  pg.fill = reinterpret_cast<uint32_t*>(base + 256);
+  pg.tuples = reinterpret_cast<uint32_t*>(base + 256 + l.cursor_bytes);
+  a.slabs = reinterpret_cast<int64_t*>(base + 256 + l.cursor_bytes + l.tuple_bytes);
+  const void* sk = bhm_scatter_kernel(g);
+  HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kBhmScatterLds)));
+  const unsigned g1 = scatter_grid(sk, kPbBlock, kBhmScatterLds, props, 2);
+  void* kargs[] = {&pg};
+  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), kargs, kBhmScatterLds, s));
+  const void* ak = bhm_aggregate_kernel(a, g);
+  if (a.lds_bytes > (48u << 10)) {
+    HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
+  }
+  HDK_HIP_CHECK(hipLaunchKernel(ak, dim3(pg.nbins * kPbXcds), dim3(kBhmAggBlock), kargs, a.lds_bytes, s));
+  // the eight slabs -> one (a thread per word, coalesced), then the fold with a thread per entry: folding the eight directly
+  // took 110 - 135 us for 100 K entries (88 strided words per thread)
+  BhmReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.in = a.slabs;
+  r.out = reinterpret_cast<int64_t*>(base + 256 + l.cursor_bytes);  // (the tuples are spent: their space takes the one slab)
+  r.flag = a.flag;
+  r.num_slabs = kPbXcds;
+  r.groups = 1;
+  r.words = pg.total_entries * static_cast<uint32_t>(a.wpe);
+  r.wpe = a.wpe;
+  for (int w = 0; w < a.wpe; ++w) r.wop[w] = g.wop[w];
+  hipLaunchKernelGGL(hdk_bhm_reduce_slabs<0>, dim3((r.words + 255) / 256, 1), dim3(256), 0, s, r);
+  HDK_HIP_CHECK(hipGetLastError());
+  const int32_t st = launch_bhm_folds(plan, d_plan, kp, ko, props, s, a, g, pg.total_entries, r.out, 1);
+  if (st) return st;
+  *launched = true;
+  return HDK_HIP_OK;
 }
 
 int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const KernParams& kp, const hdk_hip_kernel_options* ko,
@@ -397,7 +587,12 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
   *launched = false;
   BhmArgs a;
   BhmGeom g;
-  if (!match_bhm(plan, ko, &a, &g)) return HDK_HIP_OK;
+  if (!match_bhm(plan, ko, &a, &g)) {
+    BhmPartArgs pg;
+    BhmPartLayout l;
+    if (match_bhm_part(plan, ko, &pg, &g, &l)) return launch_bhm_part(plan, d_plan, kp, ko, props, s, pg, g, l, launched);
+    return HDK_HIP_OK;
+  }
   bool is_static;
   const void* k = bhm_kernel(a, g, &is_static);
   if (a.lds_bytes > (48u << 10)) {
@@ -449,32 +644,7 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
     fold_slabs = r.out;
     fold_count = red_groups;
   }
-  int32_t st;
-  if (g.perfect) {
-    st = launch_finalize_slabs(d_plan, fold_slabs, kp.groupby_buf, fold_count, plan->entry_count, a.flag, s);
-    if (st) return st;
-  } else {
-    BhmFoldArgs f;
-    memset(&f, 0, sizeof(f));
-    f.plan = d_plan;
-    f.kp = kp;
-    f.slabs = fold_slabs;
-    f.flag = a.flag;
-    f.num_slabs = fold_count;
-    f.entries = a.entries;
-    f.out_entry_count = plan->entry_count;
-    f.wpe = a.wpe;
-    for (int w = 0; w < a.wpe; ++w) f.wop[w] = g.wop[w];
-    f.nword_mask = g.nword_mask;
-    f.key_form = a.key_form;
-    f.key_lo = g.key_lo;
-    f.null_entry = g.null_entry;
-    f.key_null_word = a.key_null_word;
-    hipLaunchKernelGGL(hdk_bhm_fold<0>, dim3((a.entries + 3) / 4), dim3(256), 0, s, f);
-    HDK_HIP_CHECK(hipGetLastError());
-  }
-  // armed: runs only when the flag says the statistics did not hold (the folds skipped then)
-  st = launch_scan_global_armed(plan, d_plan, kp, ko, props, s, a.flag);
+  const int32_t st = launch_bhm_folds(plan, d_plan, kp, ko, props, s, a, g, a.entries, fold_slabs, fold_count);
   if (st) return st;
   *launched = true;
   return HDK_HIP_OK;

@@ -13,6 +13,7 @@ namespace hdk {
   X(BH_PARTITIONS_ALWAYS)           \
   X(BHM_BLOCKS_PER_CU)              \
   X(BHM_DYNAMIC)                    \
+  X(BHM_PART_MIN_BINS)              \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(COLS_BLOCKS_PER_CU)             \
@@ -28,6 +29,7 @@ namespace hdk {
   X(NO_BH_PARTITIONS)               \
   X(NO_BH_PLAIN)                    \
   X(NO_BHM)                         \
+  X(NO_BHM_PARTITIONS)              \
   X(NO_COLS_KERNEL)                 \
   X(NO_PERFECT_PARTITIONS)          \
   X(NO_SLICED2)                     \

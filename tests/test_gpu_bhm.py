@@ -157,3 +157,45 @@ def test_bh004_size_class_in_one_pass(oracle, gpu_executor_factory, groups, hot)
     st = _mid_table(3_300_000, groups, 27, hot)
     for q in (_bh_query("x"), _phs_query("x")):
         cp, res = _run(oracle, gpu_executor_factory, st, q)
+
+
+# ---- tables beyond a CU's LDS: the two-pass form (scan_bhm_part.h) ---------------------------------------------------------------
+PART = "hdk_bhm_scatter"
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.03])
+def test_two_pass_form_for_tables_beyond_lds(oracle, gpu_executor_factory, monkeypatch, null_frac):
+    """MSBS002 / MSPHS002 / PHM003-004's size class (10 K - 100 K groups): 4-byte tuples [entry in the bin | argument codes] by
+    key range, a bin's table in LDS, eight slabs folded like the one-pass kernel's.  Ragged fragments, NULLs, both layouts."""
+    monkeypatch.setenv("HDK_HIP_BH_PARTITIONS_ALWAYS", "1")  # (the row count here is far below where the passes pay)
+    rng = np.random.default_rng(31)
+    n = 1_200_011
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(rng, n, ("x10", "y10", "z10", "x100", "x1k", "x10k", "x100k"), null_frac=null_frac), fragment_size=400_003)
+    for q in (msbs(2, key_type=FP64), msphs(2), msphs(3), msbs(3, key_type=FP64), phm(4)):
+        cp, res = _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+    _run(oracle, gpu_executor_factory, st, dataclasses.replace(msphs(2), output_columnar=True), kernel=PART)
+    # five aggregates of one column by 100 K groups (BH005 / PHS005's shape)
+    y = ColRef("y10")
+    for groupby in ([Cast(ColRef("x100k"), FP64)], [ColRef("x100k")]):
+        q = QueryUnit("syn", groupby=groupby, targets=[KeyRef(0, "k")] + [Agg(kd, y, kd) for kd in ("count", "sum", "max", "min", "avg")])
+        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+
+
+def test_two_pass_form_falls_back_on_a_hot_key_and_on_stale_statistics(oracle, gpu_executor_factory, monkeypatch):
+    """70 % of the rows in one group overflow that bin's sub-slabs (sized for twice the even share); an argument outside its
+    statistics: either way the flag is raised, the folds skip and the armed global-atomics kernel gives the oracle's result."""
+    monkeypatch.setenv("HDK_HIP_BH_PARTITIONS_ALWAYS", "1")
+    rng = np.random.default_rng(32)
+    n = 900_000
+    cols = syn_table(rng, n, ("x10", "x100", "x10k"))
+    cols["x10k"][rng.random(n) < 0.7] = 4242
+    st = ArrowStorage()
+    st.import_numpy("syn", cols, fragment_size=300_000)
+    for q in (msphs(2), msbs(2, key_type=FP64)):
+        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+    st2 = ArrowStorage()
+    cols2 = syn_table(rng, n, ("x10", "x100", "x10k"))
+    st2.import_numpy("syn", cols2, fragment_size=300_000)
+    st2.get("syn").columns["x100"].fragments[1][99] = 7_000  # statistics say [1, 100]
+    _run(oracle, gpu_executor_factory, st2, msphs(2), kernel=PART)

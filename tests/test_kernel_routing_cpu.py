@@ -98,7 +98,12 @@ def test_reference_baseline_hash_benchmark_shapes(storage, monkeypatch):
     assert _names(compile_query(storage, _bh("x10"))) == one_pass
     assert _names(compile_query(storage, _bh("x1k"))) == one_pass
     assert _names(compile_query(storage, _bh("x4k"))) == one_pass  # (4 096 dense entries under one 512-thread block per CU)
+    # (round 6: BH005's 100 K groups on the multi-argument kernels' two-pass form -- leaner scatter, 12-byte entries: 1.14 ms per
+    # 256 M rows against hdk_bh_dscatter's 1.38; its switch gives round 5's passes back)
+    assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_bhm_fold"
+    monkeypatch.setenv("HDK_HIP_NO_BHM_PARTITIONS", "1")
     assert _names(compile_query(storage, _bh("x100k"))) == "hdk_bh_dscatter,hdk_bh_daggregate"
+    monkeypatch.delenv("HDK_HIP_NO_BHM_PARTITIONS")
     # BH004's 10 000 groups: 24 bytes an entry do not fit a CU's LDS, the multi-argument kernel's 12 do -- ONE pass (round 6)
     st10k = ArrowStorage()
     rng10k = np.random.default_rng(4)
@@ -233,3 +238,19 @@ def test_multistep_switch_gives_the_old_routes_back(monkeypatch):
     monkeypatch.setenv("HDK_HIP_NO_BHM", "1")
     assert _names(compile_query(st, msphs(1))).startswith("hdk_scan_agg_global")
     assert _names(compile_query(st, phm(1))).startswith("hdk_scan_agg_vec")
+
+
+def test_multistep_shapes_beyond_lds_take_the_range_bin_passes():
+    """MSBS002-003, MSPHS002-003 (10 K / 100 K groups), PHM003-005 (10 K - 1 M entries): no global atomics, no hdk_pp_* passes
+    (round 5's routes) -- 4-byte tuples by key range, scan_bhm_part.h."""
+    from syn_queries import msbs, msphs, phm, syn_table
+    st = ArrowStorage()
+    st.import_numpy("syn", syn_table(np.random.default_rng(7), 60_000, ("x10", "y10", "z10", "x100", "x1k", "x10k", "x100k")), fragment_size=20_000)
+    for q, fold in ((msbs(2, key_type=FP64), "hdk_bhm_fold"), (msbs(3, key_type=FP64), "hdk_bhm_fold"), (msphs(2), "hdk_finalize"), (msphs(3), "hdk_finalize"),
+                    (phm(4), "hdk_finalize"), (phm(5), "hdk_finalize")):
+        names = _names(compile_query(st, q))
+        assert names == f"hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,{fold}", (q.groupby, names)
+    # (PHM003's 10 000 entries of 12 bytes fit one CU's LDS: one pass)
+    assert _names(compile_query(st, phm(3))) == "hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,hdk_finalize"
+    # small inputs: the passes do not pay (the global-atomics kernel); HDK_HIP_NO_BHM_PARTITIONS: round 5's routes
+    assert "bhm" not in _names(compile_query(st, msphs(2)), total_rows=1_000_000)
