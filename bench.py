@@ -720,6 +720,21 @@ def cpu_baseline(w, args):
                                "bit_exact_vs_interpreter": bool(np.array_equal(out, want)), "timing": "best of 5, scan + reduction"}
         except (ValueError, MemoryError) as e:
             variants[label] = {"error": str(e)}
+    # ONE thread over one 8 M-row piece: what the row loop costs per row when nothing else competes for memory -- the number
+    # that explains the gap to the streaming-read figure below (a dependent read-modify-write per row, not a stream)
+    single = None
+    try:
+        n1 = min(8_000_000, rows[0])
+        sec1, _ = O.c2_jit_shaped([frags[0][0][:n1]], [frags[0][1][:n1]], cp.plan, init_buf, 1, first_touch=True, reps=5)
+        mhz = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("cpu MHz"):
+                    mhz = max(mhz or 0.0, float(ln.split(":")[1]))
+        single = {"rows_per_s": n1 / sec1, "ns_per_row": sec1 / n1 * 1e9, "host_GBps": n1 * w.alg_bytes_per_row / sec1 / 1e9,
+                  "cycles_per_row_at_max_cpu_MHz": (sec1 / n1 * mhz * 1e6) if mhz else None, "max_cpu_MHz_seen": mhz}
+    except (ValueError, MemoryError, OSError) as e:
+        single = {"error": str(e)}
     # the host: sockets / NUMA nodes, and what a pinned kernel-per-thread READ of two 8-byte columns reaches (the access
     # shape of the row loop without its dependent read-modify-write) -- the figure the baseline is held against.  The same
     # 8 GiB in all, whatever the thread count (a footprint that grows with the threads measured the host's page placement,
@@ -734,13 +749,24 @@ def cpu_baseline(w, args):
         host["model"] = next((ln.split(":", 1)[1].strip() for ln in lines if ln.startswith("model name")), None)
     except OSError:
         pass
-    stream = {}
-    for t_stream in sorted({max(allowed // 8, 1), max(allowed // 4, 1), max(allowed // 2, 1), allowed}):
-        stream[str(t_stream)] = float(O.lib().orc_host_stream_read_gbps(t_stream, (4 << 30) // t_stream, 3))
+    # (round 6) threads placed one per PHYSICAL core first, round robin over the NUMA nodes, SMT siblings last; pages first touched
+    # by their reader after the pin; all threads timed between two barriers of one parallel region; the same 8 GiB in all
+    stream, per_node = {}, {}
+    cores = max(int(O.lib().orc_physical_core_count()), 1)
+    pn = (C.c_double * 8)()
+    for t_stream in sorted({max(cores // 4, 1), max(cores // 2, 1), cores, allowed}):
+        stream[str(t_stream)] = float(O.lib().orc_host_stream_read_gbps_placed(t_stream, (4 << 30) // t_stream, 3, pn, 8))
+        per_node[str(t_stream)] = [round(x, 1) for x in list(pn)[:max(host["numa_nodes"] or 1, 1)]]
     best_t = max(stream, key=lambda k: stream[k])
+    host["physical_cores"] = cores
     host["stream_read_GBps_by_threads"] = stream
+    host["stream_read_GBps_by_threads_per_numa_node"] = per_node
     host["stream_read_GBps"] = stream[best_t]
     host["stream_threads"] = int(best_t)
+    ks = sorted(stream, key=int)
+    host["stream_figures_sane"] = all(min(stream[a], stream[b]) * 2 >= max(stream[a], stream[b]) or stream[b] >= stream[a] for a, b in zip(ks, ks[1:]))
+    host["numa_placement"] = ("threads placed one per physical core first, round robin over the NUMA nodes, SMT siblings last "
+                              "(oracle/hdk_oracle.c: placement_order); every thread first-touches its own pages after the pin")
     for v in variants.values():
         if "host_GBps" in v and host["stream_read_GBps"] > 0:
             v["frac_of_host_stream_read"] = v["host_GBps"] / host["stream_read_GBps"]
@@ -759,7 +785,81 @@ def cpu_baseline(w, args):
             "reported_variant": next(k for k, v in variants.items() if v is best),
             "fastest_variant": next(k for k, v in variants.items() if v is fastest),
             "host": host,
+            "single_thread": single,
+            "host_stream_read_GBps": host.get("stream_read_GBps"),
+            "frac_of_host_stream_read": best.get("frac_of_host_stream_read"),
+            "why_below_the_stream_figure": (
+                "the JIT-shaped loop is get_group_value_fast + agg_sum per row: load key -> row address -> load slot -> add -> store, a "
+                "store-to-load chain through the group table with a compare on the key slot, not a streaming read; "
+                + (f"one thread alone retires a row in {single['ns_per_row']:.2f} ns = {single['host_GBps']:.1f} GB/s"
+                   + (f" ({single['cycles_per_row_at_max_cpu_MHz']:.1f} cycles at {single['max_cpu_MHz_seen']:.0f} MHz)" if single.get("cycles_per_row_at_max_cpu_MHz") else "")
+                   + f"; {best['threads']} threads reach {best['rows_per_s'] / single['rows_per_s']:.1f} x that"
+                   if single and "ns_per_row" in single else "single-thread figure unavailable")),
             "variants": variants}
+
+
+def measure_traffic_live(config, rows_arg):
+    """roofline.traffic measured by THIS run: two child passes of this same script under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE, then WRITE_SIZE -- one counter per pass, kernel trace only, as MI355X_MICROARCH.md's HBM section prescribes),
+    summed over the kernels of one launch.  gfx950: bytes read = 2 x 1024 x FETCH_SIZE (a 128-byte request is tallied as 64),
+    bytes written = 1024 x WRITE_SIZE.  The children run before this process touches the GPU; None when rocprofv3 is not there,
+    a pass fails, or this process is itself being profiled (no nested profilers)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES"):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    steps = 3
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hdk_pmc_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "x", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", "1", "--extra", "none",
+                   "--no-cpu-baseline", "--no-oracle-sample", "--no-multi-gpu-emulation", "--no-end-to-end", "--no-live-traffic"]
+            if rows_arg:
+                cmd += ["--rows", str(rows_arg)]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                print(f"# live traffic: the {ctr} pass failed (rc {r.returncode}); using the committed profile", file=sys.stderr)
+                return None
+            acc, calls = {}, {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    k = row["Kernel_Name"]
+                    if "hdk" not in k or "k_cal" in k or row["Counter_Name"] != ctr:
+                        continue
+                    acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
+                    calls.setdefault(k, set()).add(row["Dispatch_Id"])
+            per[ctr] = {k: (acc[k] / len(calls[k]), len(calls[k])) for k in acc}
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            print(f"# live traffic: {e}; using the committed profile", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fe, wr = per["FETCH_SIZE"], per["WRITE_SIZE"]
+    if not fe:
+        return None
+    # the launch's kernels: dispatched as often as the one that reads most (warm-up + steps + the checks' extra step) -- one-off
+    # work (a join-table build) is dispatched fewer times and is not part of a step
+    main_k = max(fe, key=lambda k: fe[k][0] * fe[k][1])
+    n_main = fe[main_k][1]
+    traffic, kernels = 0.0, {}
+    for k, (kb, n) in fe.items():
+        if n < n_main:
+            continue
+        rd, wb = 2 * 1024 * kb, 1024 * wr.get(k, (0.0, 0))[0]
+        traffic += (rd + wb) * n / n_main
+        kernels[k.replace("void ", "").replace("hdk::", "").split("(")[0]] = {"read_bytes": round(rd), "written_bytes": round(wb), "dispatches": n}
+    return {"bytes_per_launch": round(traffic), "kernels": kernels,
+            "source": "measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes (one counter per pass)"}
 
 
 def launch_ranks(n):
@@ -793,6 +893,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-sample", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-resident (H->D inclusive) run of C2")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child passes (N = 1 default run); use the committed profile")
     ap.add_argument("--multi-gpu-emulation", choices=["c5", "full", "none"], default="c5",
                     help="N = 1 default run: also measure one rank's step of an 8-GPU job on this device (c5: the tuple "
                          "exchange; full: plus C2's shard; none)")
@@ -808,11 +910,20 @@ def main():
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to print a line for another job size")
 
+    live = None
+    if (args.gpus == 1 and not args.no_live_traffic and "RANK" not in os.environ and args.extra == "auto" and args.config == "c2"
+            and not os.environ.get("HDK_BENCH_SINGLE_RANK_COLLECTIVES")):
+        live = measure_traffic_live(args.config, args.rows)  # (children: before this process touches the GPU)
+
     comm = Comm(args)
     from hdk_amd._lib import check, lib
     from hdk_amd.hip_mgr import HipMgr
     mgr = HipMgr()
     line, w = run_config(args.config, args, comm, mgr, args.steps, args.warmup, primary=True)
+    if comm.rank == 0 and live:
+        line["roofline"]["traffic"] = live["bytes_per_launch"]
+        line["roofline"]["traffic_source"] = live["source"]
+        line["roofline"]["traffic_kernels"] = live["kernels"]
     if comm.rank == 0:
         copy_gbps, read_gbps = C.c_double(0), C.c_double(0)
         check(lib().hdk_hip_mgr_measure_hbm(comm.dev, 4 << 30, 3, C.byref(copy_gbps), C.byref(read_gbps)))
@@ -896,7 +1007,7 @@ def main():
 HEADLINE_MAX_BYTES = 4096
 _ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_kernel_ms",
                   "median_kernel_ms", "alg_bytes_per_row", "peak_measured", "frac_of_measured_read")
-_CPU_KEYS = ("value", "unit", "cores", "host_cores", "kind", "sample", "reported_variant", "frac_of_host_stream_read")
+_CPU_KEYS = ("value", "unit", "cores", "host_cores", "kind", "sample", "reported_variant", "frac_of_host_stream_read", "host_stream_read_GBps")
 _E2E_KEYS = ("rows_per_s", "h2d_GBps", "overlap_fraction", "same_result_as_resident_run", "link")
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks_seen_by_collective", "steps", "warmup", "ms_per_step", "higher_is_better",
              "scaling", "vs_baseline", "dtype", "data", "config")

@@ -18,6 +18,8 @@
 #include <time.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <stdio.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -2601,6 +2603,164 @@ double orc_host_stream_read_gbps(int32_t num_threads, size_t bytes_per_thread, i
   return 2.0 * (double)n * 8.0 * (double)num_threads / best / 1e9;
 }
 
+/* ---- the host's streaming-read figure, placed on purpose (round 6) -----------------------------------------------------
+ * orc_host_stream_read_gbps above spreads its threads by CPU NUMBER; on a two-socket EPYC whose numbers run socket 0 cores,
+ * socket 1 cores, then their SMT siblings, 128 threads landed two to a core on half the cores and the figure fell 10 x from
+ * its 64-thread value (profiles/r05_bench_default.json: 733 / 1 002 / 100 / 44 GB/s at 32 / 64 / 128 / 256 threads) -- placement,
+ * not DRAM.  Here thread t gets the t-th entry of a list that holds ONE CPU per physical core first (its lowest-numbered
+ * sibling), dealt round robin over the NUMA nodes, and only then the siblings; every thread maps and first-touches its own
+ * pages after it is pinned; all threads are timed inside ONE parallel region between two barriers (no fork / join in the
+ * figure).  per_node[i] (i < max_nodes): GB/s of the threads on node i.  Returns the total, or a negative number. */
+static int read_first_int(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int v = -1;
+  if (fscanf(f, "%d", &v) != 1) v = -1;
+  fclose(f);
+  return v;
+}
+static int cpu_numa_node(int cpu) {
+  char path[128];
+  for (int node = 0; node < 64; ++node) {
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/node%d", cpu, node);
+    if (access(path, F_OK) == 0) return node;
+  }
+  return 0;
+}
+/* allowed CPUs, one per physical core first (round robin over the nodes), then the SMT siblings; *ncores = the first part */
+static int placement_order(int* out, int cap, int* ncores) {
+  int cpus[CPU_SETSIZE];
+  const int n = allowed_cpus(cpus, CPU_SETSIZE);
+  int prim[CPU_SETSIZE], sec[CPU_SETSIZE], np_ = 0, ns = 0;
+  char path[128];
+  for (int i = 0; i < n; ++i) {
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpus[i]);
+    const int first = read_first_int(path);
+    if (first < 0 || first == cpus[i]) prim[np_++] = cpus[i]; else sec[ns++] = cpus[i];
+  }
+  int k = 0;
+  for (int part = 0; part < 2; ++part) {
+    const int* src = part == 0 ? prim : sec;
+    const int cnt = part == 0 ? np_ : ns;
+    int taken[CPU_SETSIZE];
+    memset(taken, 0, sizeof(int) * (size_t)(cnt > 0 ? cnt : 1));
+    int left = cnt;
+    while (left > 0 && k < cap) {
+      for (int node = 0; node < 64 && left > 0 && k < cap; ++node) { /* one CPU of every node per round */
+        for (int i = 0; i < cnt; ++i) {
+          if (!taken[i] && cpu_numa_node(src[i]) == node) {
+            taken[i] = 1;
+            out[k++] = src[i];
+            --left;
+            break;
+          }
+        }
+      }
+    }
+    if (part == 0) *ncores = k;
+  }
+  return k;
+}
+
+int32_t orc_physical_core_count(void) {
+  int order[CPU_SETSIZE], ncores = 0;
+  (void)placement_order(order, CPU_SETSIZE, &ncores);
+  return ncores;
+}
+
+double orc_host_stream_read_gbps_placed(int32_t num_threads, size_t bytes_per_thread, int32_t reps, double* per_node, int32_t max_nodes) {
+  int order[CPU_SETSIZE], ncores = 0;
+  const int ncpus = placement_order(order, CPU_SETSIZE, &ncores);
+  if (num_threads < 1) num_threads = 1;
+  if (ncpus <= 0) return -1.0;
+  if (num_threads > ncpus) num_threads = ncpus;
+  const size_t n = bytes_per_thread / 8;
+  double* secs = (double*)calloc((size_t)num_threads, sizeof(double));
+  int* node_of = (int*)calloc((size_t)num_threads, sizeof(int));
+  int64_t* sink = (int64_t*)calloc((size_t)num_threads, sizeof(int64_t));
+  if (!secs || !node_of || !sink) return -1.0;
+  int bad = 0;
+  if (reps < 1) reps = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(num_threads)
+#endif
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    const int cpu = order[t % ncpus];
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    (void)sched_setaffinity(0, sizeof(one), &one);
+    node_of[t] = cpu_numa_node(cpu);
+    int64_t* x = (int64_t*)map_pages(n * 8);
+    int64_t* y = (int64_t*)map_pages(n * 8);
+    if (!x || !y) {
+      bad = 1;
+    } else {
+      for (size_t i = 0; i < n; ++i) { /* first touch by the reader, after the pin */
+        x[i] = (int64_t)i;
+        y[i] = (int64_t)(i ^ 5);
+      }
+    }
+    double best = -1.0;
+    for (int r = 0; r < reps + 1; ++r) { /* (the first trip is a warm-up) */
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+      struct timespec t0, t1;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      int64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if (x && y) {
+        for (size_t i = 0; i + 4 <= n; i += 4) {
+          s0 += x[i] + y[i];
+          s1 += x[i + 1] + y[i + 1];
+          s2 += x[i + 2] + y[i + 2];
+          s3 += x[i + 3] + y[i + 3];
+        }
+      }
+      sink[t] += s0 + s1 + s2 + s3;
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+      clock_gettime(CLOCK_MONOTONIC, &t1); /* (after the barrier: every thread's figure is the slowest thread's) */
+      const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      if (r > 0 && (best < 0 || sec < best)) best = sec;
+    }
+    secs[t] = best;
+    if (x) munmap(x, n ? n * 8 : 4096);
+    if (y) munmap(y, n ? n * 8 : 4096);
+  }
+  int cpus_all[CPU_SETSIZE];
+  const int nall = allowed_cpus(cpus_all, CPU_SETSIZE);
+  { /* back to the allowed set */
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    for (int i = 0; i < ncpus; ++i) CPU_SET(order[i], &all);
+    (void)sched_setaffinity(0, sizeof(all), &all);
+    (void)nall;
+  }
+  double worst = 0.0;
+  for (int t = 0; t < num_threads; ++t) worst = secs[t] > worst ? secs[t] : worst;
+  for (int i = 0; per_node && i < max_nodes; ++i) per_node[i] = 0.0;
+  if (!bad && worst > 0 && per_node) {
+    for (int t = 0; t < num_threads; ++t) {
+      if (node_of[t] < max_nodes) per_node[node_of[t]] += 2.0 * (double)n * 8.0 / worst / 1e9;
+    }
+  }
+  int64_t keep = 0;
+  for (int t = 0; t < num_threads; ++t) keep += sink[t];
+  free(secs);
+  free(node_of);
+  free(sink);
+  if (bad || worst <= 0) return -1.0;
+  (void)keep;
+  return 2.0 * (double)n * 8.0 * (double)num_threads / worst / 1e9;
+}
+
 /* ---- CPU baseline, JIT-shaped (bench.py `cpu_baseline.variants.jit_shaped`; never part of the product) -------------
  * What HDK's LLVM backend emits for `SELECT key, SUM(val) FROM t GROUP BY key` over a perfect-hash, row-wise layout,
  * written out by hand: the row function is the decoders (fixed_width_int_decode, QE/DecodersImpl.h:30-61) feeding
@@ -2634,7 +2794,16 @@ double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals,
   if (first_touch) { /* threads spread over the allowed CPUs and pinned: the pages they touch below stay local to them */
 #ifdef _OPENMP
 #pragma omp parallel num_threads(num_threads)
-    pin_spread(omp_get_thread_num(), omp_get_num_threads(), cpus, ncpus);
+    { /* one thread per physical core first, round robin over the NUMA nodes, SMT siblings last (placement_order) */
+      int order[CPU_SETSIZE], ncores_ = 0;
+      const int no = placement_order(order, CPU_SETSIZE, &ncores_);
+      if (no > 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(order[omp_get_thread_num() % no], &one);
+        (void)sched_setaffinity(0, sizeof(one), &one);
+      }
+    }
 #endif
   }
   /* same static fragment -> thread map for the copy and for the scans */

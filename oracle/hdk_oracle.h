@@ -225,6 +225,9 @@ int32_t orc_max_threads(void);
 /* placement-aware helpers of the CPU baseline (bench.py) */
 int32_t orc_allowed_cpu_count(void);
 double orc_host_stream_read_gbps(int32_t num_threads, size_t bytes_per_thread, int32_t reps);
+/* the same figure with the threads placed one per physical core first, round robin over the NUMA nodes (hdk_oracle.c) */
+double orc_host_stream_read_gbps_placed(int32_t num_threads, size_t bytes_per_thread, int32_t reps, double* per_node, int32_t max_nodes);
+int32_t orc_physical_core_count(void);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ def lib():
     _sig(L, "orc_fixed_width_small_date_decode", C.c_int64, v, C.c_int32, C.c_int32, C.c_int64, C.c_int64)
     _sig(L, "orc_allowed_cpu_count", C.c_int32)
     _sig(L, "orc_host_stream_read_gbps", C.c_double, C.c_int32, C.c_size_t, C.c_int32)
+    _sig(L, "orc_host_stream_read_gbps_placed", C.c_double, C.c_int32, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.c_int32)
+    _sig(L, "orc_physical_core_count", C.c_int32)
     _sig(L, "orc_init_hash_join_buff", None, v, C.c_int64, C.c_int32)
     _sig(L, "orc_fill_hash_join_buff", C.c_int, v, C.c_int32, C.c_int32, v, C.c_size_t,
          C.POINTER(A.JoinColumnTypeInfo), C.c_int64)

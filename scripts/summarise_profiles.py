@@ -18,10 +18,10 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ARGS = {"c3big": "--config c3 --dim-rows 100000000"}  # name -> bench arguments when they are not just --config <name>
 SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
-ALG = {"c2": (16, 1_000_000_000), "c3": (16, 1_000_000_000), "c3g": (16, 1_000_000_000), "c3m": (16, 1_000_000_000),
-       "c3big": (16, 1_000_000_000), "c5": (16, 1_000_000_000), "c5s": (16, 125_000_000),
-       "c3gm": (16, 1_000_000_000), "bh1": (8, 1_000_000_000), "bh3": (8, 1_000_000_000), "bh5": (8, 1_000_000_000),
-       "q1": (4, 1_000_000_000), "q2": (10, 1_000_000_000), "q3": (10, 1_000_000_000), "q4": (18, 1_000_000_000)}
+sys.path.insert(0, ROOT)
+from workloads import CONFIGS  # noqa: E402  (name -> (rows, algorithmic bytes per row, description))
+ALG = {name: (bpr, rows) for name, (rows, bpr, _d) in CONFIGS.items()}
+ALG["c3big"] = (16, 1_000_000_000)
 
 
 def counters(path):
@@ -46,6 +46,9 @@ def main():
     line = [l for l in open(os.path.join(SRC, "bench_default_bench.json")) if l.startswith("{")][-1]
     with open(os.path.join(DST, f"{RND}_bench_default.json"), "w") as f:
         f.write(line)
+    for extra in ("bench_no_e2e_kernel_stats.csv", "bench_detail.json"):  # (round 6: the headline's side file travels with it)
+        if os.path.exists(os.path.join(SRC, extra)):
+            shutil.copy(os.path.join(SRC, extra), os.path.join(DST, f"{RND}_{extra}"))
     for name, (bpr, rows) in ALG.items():
         if not os.path.exists(os.path.join(SRC, f"{name}_fetch_counters.csv")):
             continue
