@@ -2446,7 +2446,12 @@ int32_t orc_run_plan_parallel(const hdk_hip_plan* plan, const int8_t* const* con
   if (num_threads < 1) {
     num_threads = 1;
   }
-  int64_t* partials = (int64_t*)malloc(num_fragments * buffer_quads * sizeof(int64_t));
+  /* every kernel's private buffer on cache lines of its own (HDK allocates one ResultSet buffer per kernel; buffers laid end to
+   * end in one malloc share their border lines, and two threads' read-modify-writes on one line cost a cross-core transfer
+   * each: round 6 found the JIT-shaped leg 10 x slower for it) */
+  const size_t pstride = (buffer_quads + 31) & ~(size_t)31; /* quads: multiples of 256 bytes */
+  int64_t* partials = NULL;
+  if (posix_memalign((void**)&partials, 256, (num_fragments ? num_fragments : 1) * pstride * sizeof(int64_t)) != 0) partials = NULL;
   if (!partials) {
     return HDK_HIP_ERR_RUNTIME;
   }
@@ -2455,7 +2460,7 @@ int32_t orc_run_plan_parallel(const hdk_hip_plan* plan, const int8_t* const* con
 #pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
 #endif
   for (int64_t f = 0; f < (int64_t)num_fragments; ++f) { /* one ExecutionKernel per fragment */
-    int64_t* mine = partials + (size_t)f * buffer_quads;
+    int64_t* mine = partials + (size_t)f * pstride;
     memcpy(mine, init_buffer, buffer_quads * sizeof(int64_t));
     const int32_t e = orc_run_plan_range(plan, col_buffers, (uint64_t)f, (uint64_t)f + 1, num_rows,
                                          num_tables, join_hash_tables, mine);
@@ -2470,7 +2475,7 @@ int32_t orc_run_plan_parallel(const hdk_hip_plan* plan, const int8_t* const* con
   }
   memcpy(out, init_buffer, buffer_quads * sizeof(int64_t));
   for (uint64_t f = 0; f < num_fragments && !err; ++f) { /* reduceMultiDeviceResultSets */
-    const int32_t e = orc_reduce(plan, out, plan->entry_count, partials + (size_t)f * buffer_quads,
+    const int32_t e = orc_reduce(plan, out, plan->entry_count, partials + (size_t)f * pstride,
                                  plan->entry_count, init_vals);
     if (e) {
       err = e;
@@ -2627,35 +2632,69 @@ static int cpu_numa_node(int cpu) {
   }
   return 0;
 }
-/* allowed CPUs, one per physical core first (round robin over the nodes), then the SMT siblings; *ncores = the first part */
+/* allowed CPUs, one per physical core first (round robin over the nodes), then the SMT siblings; *ncores = the first part.
+ * Reads sysfs once per CPU (callers hold the result: never inside a parallel region). */
 static int placement_order(int* out, int cap, int* ncores) {
   int cpus[CPU_SETSIZE];
   const int n = allowed_cpus(cpus, CPU_SETSIZE);
-  int prim[CPU_SETSIZE], sec[CPU_SETSIZE], np_ = 0, ns = 0;
+  static int prim[CPU_SETSIZE], sec[CPU_SETSIZE], pnode[CPU_SETSIZE], snode[CPU_SETSIZE];
+  int np_ = 0, ns = 0, max_node = 0;
   char path[128];
   for (int i = 0; i < n; ++i) {
     snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpus[i]);
     const int first = read_first_int(path);
-    if (first < 0 || first == cpus[i]) prim[np_++] = cpus[i]; else sec[ns++] = cpus[i];
+    /* the round-robin unit is the L3 domain (a CCD: its link to the memory controllers caps what its cores can stream), numbered so
+     * that consecutive domains alternate between the NUMA nodes: domain key = (rank of the L3 inside its node) * 64 + node */
+    const int numa = cpu_numa_node(cpus[i]);
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpus[i]);
+    const int l3 = read_first_int(path);
+    static int l3_first[CPU_SETSIZE], l3_node[CPU_SETSIZE], l3_rank[CPU_SETSIZE], nl3;
+    if (i == 0) nl3 = 0;
+    int di = -1;
+    for (int q = 0; q < nl3; ++q) {
+      if (l3_first[q] == (l3 < 0 ? cpus[i] : l3)) di = q;
+    }
+    if (di < 0) {
+      di = nl3++;
+      l3_first[di] = l3 < 0 ? cpus[i] : l3;
+      l3_node[di] = numa;
+      int r = 0;
+      for (int q = 0; q < di; ++q) r += l3_node[q] == numa;
+      l3_rank[di] = r;
+    }
+    const int node = (l3_rank[di] % 64) * 64 + (numa % 64); /* ("node" below = this domain key) */
+    max_node = node > max_node ? node : max_node;
+    if (first < 0 || first == cpus[i]) {
+      pnode[np_] = node;
+      prim[np_++] = cpus[i];
+    } else {
+      snode[ns] = node;
+      sec[ns++] = cpus[i];
+    }
   }
   int k = 0;
   for (int part = 0; part < 2; ++part) {
     const int* src = part == 0 ? prim : sec;
+    const int* nodes = part == 0 ? pnode : snode;
     const int cnt = part == 0 ? np_ : ns;
-    int taken[CPU_SETSIZE];
-    memset(taken, 0, sizeof(int) * (size_t)(cnt > 0 ? cnt : 1));
+    static int next[4096];  /* per domain key: where its next untaken CPU is searched from */
+    for (int i = 0; i < 4096; ++i) next[i] = 0;
     int left = cnt;
     while (left > 0 && k < cap) {
-      for (int node = 0; node < 64 && left > 0 && k < cap; ++node) { /* one CPU of every node per round */
-        for (int i = 0; i < cnt; ++i) {
-          if (!taken[i] && cpu_numa_node(src[i]) == node) {
-            taken[i] = 1;
-            out[k++] = src[i];
-            --left;
-            break;
-          }
+      int took = 0;
+      for (int node = 0; node <= max_node && node < 4096 && left > 0 && k < cap; ++node) { /* one CPU of every L3 domain per round */
+        int i = next[node];
+        while (i < cnt && nodes[i] != node) ++i;
+        if (i < cnt) {
+          out[k++] = src[i];
+          --left;
+          ++took;
+          next[node] = i + 1;
+        } else {
+          next[node] = cnt;
         }
       }
+      if (!took) break;
     }
     if (part == 0) *ncores = k;
   }
@@ -2668,6 +2707,7 @@ int32_t orc_physical_core_count(void) {
   return ncores;
 }
 
+enum { kStreamPasses = 6 };
 double orc_host_stream_read_gbps_placed(int32_t num_threads, size_t bytes_per_thread, int32_t reps, double* per_node, int32_t max_nodes) {
   int order[CPU_SETSIZE], ncores = 0;
   const int ncpus = placement_order(order, CPU_SETSIZE, &ncores);
@@ -2714,20 +2754,22 @@ double orc_host_stream_read_gbps_placed(int32_t num_threads, size_t bytes_per_th
       struct timespec t0, t1;
       clock_gettime(CLOCK_MONOTONIC, &t0);
       int64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      if (x && y) {
+      for (int pass = 0; pass < kStreamPasses && x && y; ++pass) { /* (several passes per timed trip: a barrier of 256 threads
+                                                                      costs milliseconds, one pass over 8 GiB about as much) */
         for (size_t i = 0; i + 4 <= n; i += 4) {
           s0 += x[i] + y[i];
           s1 += x[i + 1] + y[i + 1];
           s2 += x[i + 2] + y[i + 2];
           s3 += x[i + 3] + y[i + 3];
         }
+        __asm__ volatile("" : "+r"(s0), "+r"(s1), "+r"(s2), "+r"(s3) : : "memory");
       }
       sink[t] += s0 + s1 + s2 + s3;
 #ifdef _OPENMP
 #pragma omp barrier
 #endif
       clock_gettime(CLOCK_MONOTONIC, &t1); /* (after the barrier: every thread's figure is the slowest thread's) */
-      const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      const double sec = ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec)) / kStreamPasses;
       if (r > 0 && (best < 0 || sec < best)) best = sec;
     }
     secs[t] = best;
@@ -2786,23 +2828,26 @@ double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals,
   if (reps < 1) reps = 1;
   int64_t** lk = (int64_t**)calloc(num_fragments, sizeof(int64_t*));
   int64_t** lv = (int64_t**)calloc(num_fragments, sizeof(int64_t*));
-  int64_t* partials = (int64_t*)malloc(num_fragments * quads * sizeof(int64_t));
+  /* (private buffers on their own cache lines: see orc_run_plan_parallel) */
+  const size_t pstride = (quads + 31) & ~(size_t)31;
+  int64_t* partials = NULL;
+  if (posix_memalign((void**)&partials, 256, (num_fragments ? num_fragments : 1) * pstride * sizeof(int64_t)) != 0) partials = NULL;
   if (!lk || !lv || !partials) return -1.0;
   int bad = 0;
   int cpus[CPU_SETSIZE];
   const int ncpus = allowed_cpus(cpus, CPU_SETSIZE);
-  if (first_touch) { /* threads spread over the allowed CPUs and pinned: the pages they touch below stay local to them */
+  static int place[CPU_SETSIZE];
+  int place_cores = 0;
+  const int place_n = first_touch ? placement_order(place, CPU_SETSIZE, &place_cores) : 0; /* (sysfs: once, outside the region) */
+  (void)place_cores;
+  if (first_touch) { /* threads placed and pinned: the pages they touch below stay local to them */
 #ifdef _OPENMP
 #pragma omp parallel num_threads(num_threads)
-    { /* one thread per physical core first, round robin over the NUMA nodes, SMT siblings last (placement_order) */
-      int order[CPU_SETSIZE], ncores_ = 0;
-      const int no = placement_order(order, CPU_SETSIZE, &ncores_);
-      if (no > 0) {
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(order[omp_get_thread_num() % no], &one);
-        (void)sched_setaffinity(0, sizeof(one), &one);
-      }
+    if (place_n > 0) { /* one thread per physical core first, round robin over the NUMA nodes, SMT siblings last */
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(place[omp_get_thread_num() % place_n], &one);
+      (void)sched_setaffinity(0, sizeof(one), &one);
     }
 #endif
   }
@@ -2834,7 +2879,7 @@ double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals,
 #pragma omp parallel for schedule(static, 1) num_threads(num_threads)
 #endif
     for (int64_t f = 0; f < (int64_t)num_fragments; ++f) {
-      int64_t* restrict buf = partials + (size_t)f * quads;
+      int64_t* restrict buf = partials + (size_t)f * pstride;
       memcpy(buf, init_buffer, quads * sizeof(int64_t));
       const int64_t* restrict k = lk[f];
       const int64_t* restrict v = lv[f];
@@ -2860,7 +2905,7 @@ double orc_c2_jit_shaped(const int64_t* const* keys, const int64_t* const* vals,
     }
     memcpy(out, init_buffer, quads * sizeof(int64_t));
     for (uint64_t f = 0; f < num_fragments; ++f) { /* reduceOneSlot over the partials, in fragment order */
-      const int64_t* p = partials + (size_t)f * quads;
+      const int64_t* p = partials + (size_t)f * pstride;
       for (uint32_t e = 0; e < entry_count; ++e) {
         /* isEmptyEntry (RS/ResultSetStorage.cpp:439-547): the key, or -- keyless -- the slot idx_target_as_key names
          * still at its init value (`keyless` = that quad + 1) */
