@@ -124,7 +124,25 @@ class PlanExtractor {
     }
     filters(unit.quals);
     for (const Expr* k : unit.groupby) {
-      wu_.keys.push_back(expr(k));
+      hdk_hip_expr kx = expr(k);
+      // A FLOAT group key is widened to double before it becomes the key word (CgenState::castToTypeIn(group_key, 64),
+      // QE/IRCodegen.cpp:1219-1221), its NULL the FLOAT sentinel widened.  A FLOAT column travels as a double already;
+      // cast(<integer> AS FLOAT) is taken only while the argument COLUMN's statistics lie inside +-2^24, where the step library's
+      // conversion to double gives the same value (MultiStep/MSBS001-005's cast(x1k AS float)); hdk_amd/plan.py has the same rule.
+      const TypeDesc kt = IR::type(k);
+      if (kt.is_fp() && kt.size == 4) {
+        if (kx.nsteps == 0 && kx.leaf0.kind == HDK_LEAF_COL) {
+          // (a FLOAT column: nothing to do)
+        } else if (kx.nsteps == 1 && kx.steps[0].op == HDK_OP_CAST_INT_TO_FP && kx.leaf0.kind == HDK_LEAF_COL &&
+                   wu_.cols[static_cast<size_t>(kx.leaf0.col)].has_stats && wu_.cols[static_cast<size_t>(kx.leaf0.col)].min_val >= -(1ll << 24) &&
+                   wu_.cols[static_cast<size_t>(kx.leaf0.col)].max_val <= (1ll << 24)) {
+          kx.steps[0].null_out = inline_null(kt);
+          kx.null_val = inline_null(kt);
+        } else {
+          throw QueryMustRunOnCpu("4-byte floating-point group-by key outside the fixed kernel library (computed, or a cast whose argument may exceed 2^24)");
+        }
+      }
+      wu_.keys.push_back(kx);
     }
     if (wu_.keys.size() > HDK_HIP_MAX_KEYS || unit.targets.empty() || unit.targets.size() > HDK_HIP_MAX_TARGETS) {
       throw QueryMustRunOnCpu("keys / targets outside the fixed kernel library");

@@ -716,9 +716,27 @@ def compile_query(storage: ArrowStorage, q: QueryUnit) -> CompiledPlan:
     for ki, k in enumerate(q.groupby):
         # (a floating-point key is its bit pattern from here on: groupByColumnCodegen bit-casts the double to the 8-byte
         # key word, QE/IRCodegen.cpp:1219-1221; its range is not an integer range, so the layout is GroupByBaselineHash)
+        # A FLOAT key is widened to double before it becomes the key word (CgenState::castToTypeIn(group_key, 64) in
+        # groupByColumnCodegen, QE/IRCodegen.cpp:1219-1221; read back as static_cast<float>(double), RS/ResultSetIteration.cpp
+        # makeTargetValue, case 8), its NULL the FLOAT sentinel widened.  A FLOAT column is carried as a double already
+        # (fixed_width_float_decode).  cast(<integer> AS FLOAT): the step library has the conversion to double only, which is the
+        # same value exactly when the argument's statistics lie inside +-2^24 (MultiStep/MSBS001-005: cast(x1k AS float)) --
+        # wider arguments would need the rounding to float and stay out.
         if key_types[ki].is_fp and key_types[ki].size != 8:
-            raise QueryMustRunOnCpu("4-byte floating-point group-by keys are outside the fixed kernel library")
+            if isinstance(k, Cast) and b.type_of(k.arg).is_integer_like:
+                ar = b.range_of(k.arg)
+                if ar.kind != "int" or int(ar.lo) < -(1 << 24) or int(ar.hi) > (1 << 24):
+                    raise QueryMustRunOnCpu("cast(<integer> AS FLOAT) group-by key whose argument may exceed 2^24 (the rounding to float "
+                                            "is outside the fixed kernel library)")
+            elif not isinstance(k, ColRef):
+                raise QueryMustRunOnCpu("4-byte floating-point group-by key expressions are outside the fixed kernel library")
         p.keys[ki] = make_expr(b, k)
+        if key_types[ki].is_fp and key_types[ki].size == 4 and p.keys[ki].nsteps:
+            # the cast's NULL is the FLOAT sentinel, and the key word holds it widened to double (computed doubles carry
+            # NULL_DOUBLE otherwise: _result_null)
+            fnull = A.to_i64(key_types[ki].null_as_int64_or_double_bits())
+            p.keys[ki].steps[p.keys[ki].nsteps - 1].null_out = fnull
+            p.keys[ki].null_val = fnull
 
     def card(r: Range) -> int:  # ColRangeInfo::getBucketedCardinality
         c = int(r.hi) - int(r.lo)

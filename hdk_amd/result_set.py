@@ -160,8 +160,12 @@ def to_columns(cp: CompiledPlan, buf: np.ndarray, entry_count=None, nrows=None) 
             col = []
             if kt.is_fp:  # the key word holds the double's bits (groupByColumnCodegen's bit-cast, QE/IRCodegen.cpp:1219-1221)
                 fv = np.ascontiguousarray(vals, dtype=np.int64).view(np.float64)
+                # (a FLOAT key sits in the word widened to double, its NULL the widened FLOAT sentinel: makeTargetValue's case 8)
+                null_bits = kt.null_as_int64_or_double_bits()
+                if kt.size == 4:
+                    fv = fv.astype(np.float32).astype(np.float64)
                 for v, f in zip(vals.tolist(), fv.tolist()):
-                    col.append(None if (kt.nullable and v == A.NULL_DOUBLE_BITS) else f)
+                    col.append(None if (kt.nullable and v == null_bits) else f)
                 res[oc.name] = col
                 continue
             for v in vals.tolist():

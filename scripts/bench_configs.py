@@ -110,10 +110,10 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import syn_queries as SQ
     SYN2 = {f"nga{i}": (SQ.nga(i, "syn2"), 24) for i in range(1, 6)}
-    SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2", FP64), 12) for i in range(1, 5)})
+    SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2"), 12) for i in range(1, 5)})  # (cast(x AS float) keys, as written)
     SYN2.update({f"msphs{i}": (SQ.msphs(i, "syn2"), 12) for i in range(1, 5)})
     SYN2.update({f"msphs{i}": (SQ.msphs(i, "syn2"), 12) for i in ("2k", "4k", "6k")})
-    SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2", FP64), 12) for i in ("2k", "4k", "6k")})
+    SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2"), 12) for i in ("2k", "4k", "6k")})
     SYN2.update({f"phm{i}": (SQ.phm(i, "syn2"), 12) for i in range(1, 7)})
     want2 = [k for k in SYN2 if k in only]
     cols2 = set()

@@ -29,5 +29,8 @@ LD_PRELOAD="${CLANG_RT:-$ASAN_RT}" HDK_HIP_LIB=$ROOT/hdk_amd/libhdk_hip_asan.so 
 echo "== 3. C++ binding harness, host code with the same flags (compile + link only)"
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -Wall -Werror -Wno-unused-parameter -I /root/reference/omniscidb -I include \
   -I hdk_amd/glue -I tests/cpp tests/cpp/harness.cpp -L hdk_amd -lhdk_hip -Wl,-rpath,"$ROOT/hdk_amd" -o /tmp/harness_asan 2>&1 | tail -20
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -Wall -Werror -Wno-unused-parameter -D__HIP_PLATFORM_AMD__ -I /root/reference/omniscidb -I include \
+  -I hdk_amd/glue -I tests/cpp -I /opt/rocm/include tests/cpp/multi_device.cpp -L hdk_amd -lhdk_hip -L /opt/rocm/lib -lrccl -lamdhip64 -lpthread \
+  -Wl,-rpath,"$ROOT/hdk_amd" -Wl,-rpath,/opt/rocm/lib -o /tmp/multi_device_asan 2>&1 | tail -20
 # (pipefail: a failed compile fails the script -- it used to read as a pass)
 echo "sanitizers: no report"

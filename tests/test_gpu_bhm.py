@@ -48,7 +48,7 @@ def test_multistep_and_multicol_benchmark_shapes(oracle, gpu_executor_factory, n
     n = 900_007
     st = ArrowStorage()
     st.import_numpy("syn", syn_table(rng, n, ("x10", "y10", "z10", "x100", "x1k"), null_frac=null_frac), fragment_size=300_011)
-    for q in (msbs(1, key_type=FP64), msphs(1), phm(1), phm(2)):
+    for q in (msbs(1), msbs(1, key_type=FP64), msphs(1), phm(1), phm(2)):  # (MSBS as written: cast(x1k AS float); and its double twin)
         cp, res = _run(oracle, gpu_executor_factory, st, q)
         step = gpu_executor_factory(st).prepare(cp)
         names = step.kernel_names()
@@ -172,7 +172,7 @@ def test_two_pass_form_for_tables_beyond_lds(oracle, gpu_executor_factory, monke
     n = 1_200_011
     st = ArrowStorage()
     st.import_numpy("syn", syn_table(rng, n, ("x10", "y10", "z10", "x100", "x1k", "x10k", "x100k"), null_frac=null_frac), fragment_size=400_003)
-    for q in (msbs(2, key_type=FP64), msphs(2), msphs(3), msbs(3, key_type=FP64), phm(4)):
+    for q in (msbs(2), msphs(2), msphs(3), msbs(3, key_type=FP64), phm(4)):
         cp, res = _run(oracle, gpu_executor_factory, st, q, kernel=PART)
     _run(oracle, gpu_executor_factory, st, dataclasses.replace(msphs(2), output_columnar=True), kernel=PART)
     # five aggregates of one column by 100 K groups (BH005 / PHS005's shape)
@@ -199,3 +199,38 @@ def test_two_pass_form_falls_back_on_a_hot_key_and_on_stale_statistics(oracle, g
     st2.import_numpy("syn", cols2, fragment_size=300_000)
     st2.get("syn").columns["x100"].fragments[1][99] = 7_000  # statistics say [1, 100]
     _run(oracle, gpu_executor_factory, st2, msphs(2), kernel=PART)
+
+
+def test_float_group_keys(oracle, gpu_executor_factory):
+    """FLOAT group keys (round 6): cast(<integer> AS FLOAT) as MSBS001-005 write it, and a plain FLOAT column.  The key word is the
+    value widened to double, the NULL key the FLOAT sentinel widened (castToTypeIn(group_key, 64), QE/IRCodegen.cpp:1219-1221);
+    the result column reads back as floats with None for the NULL group, and every group equals numpy's."""
+    from hdk_amd.ir import FP32
+    rng = np.random.default_rng(41)
+    n = 300_000
+    cols = syn_table(rng, n, ("x10", "x100", "x1k"), null_frac=0.02)
+    f = rng.integers(-20, 20, n).astype(np.float32) * np.float32(0.5)
+    f[rng.random(n) < 0.03] = np.frombuffer(np.uint32(A.NULL_FLOAT_BITS).tobytes(), dtype=np.float32)[0]
+    cols["f"] = f
+    st = ArrowStorage()
+    st.import_numpy("syn", cols, fragment_size=100_000)
+    cp, res = _run(oracle, gpu_executor_factory, st, msbs(1))
+    out = res.to_columns()
+    x = cols["x1k"]
+    assert sum(1 for k in out["k"] if k is None) == 1 and len(out["k"]) == len(np.unique(x[x != A.NULL_INT])) + 1
+    i = out["k"].index(7.0)
+    m = x == 7
+    x100 = cols["x100"][m]
+    assert out["c"][i] == int(m.sum()) and out["s100"][i] == int(x100[x100 != A.NULL_INT].astype(np.int64).sum())
+    inull = out["k"].index(None)
+    assert out["c"][inull] == int((x == A.NULL_INT).sum())
+    # a FLOAT column as the key: the general open-addressing kernels (its values are not a dense integer range)
+    q = QueryUnit("syn", groupby=[ColRef("f")], targets=[KeyRef(0, "k"), Agg("count", None, "c"), Agg("sum", ColRef("x10"), "s")])
+    cpf, want, err = run_oracle(oracle, st, q)
+    assert err == 0 and cpf.key_types[0] == FP32.with_nullable(True) or cpf.key_types[0].size == 4
+    resf = gpu_executor_factory(st).execute(cpf)
+    _check_rows(cpf, resf.buffer, want)
+    outf = resf.to_columns()
+    live = f[f != np.frombuffer(np.uint32(A.NULL_FLOAT_BITS).tobytes(), dtype=np.float32)[0]]
+    assert sorted(k for k in outf["k"] if k is not None) == sorted(float(v) for v in np.unique(live))
+    assert sum(1 for k in outf["k"] if k is None) == 1

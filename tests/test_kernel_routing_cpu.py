@@ -222,7 +222,8 @@ def test_multistep_and_multicol_benchmark_shapes_stay_on_chip():
     from syn_queries import msbs, msphs, phm, syn_table
     st = ArrowStorage()
     st.import_numpy("syn", syn_table(np.random.default_rng(6), 60_000, ("x10", "y10", "z10", "x100", "x1k")), fragment_size=20_000)
-    for q, fold in ((msbs(1, key_type=FP64), "hdk_bhm_fold"), (msphs(1), "hdk_finalize"), (phm(1), "hdk_finalize"), (phm(2), "hdk_finalize")):
+    for q, fold in ((msbs(1), "hdk_bhm_fold"), (msbs(1, key_type=FP64), "hdk_bhm_fold"), (msphs(1), "hdk_finalize"), (phm(1), "hdk_finalize"),
+                    (phm(2), "hdk_finalize")):
         names = _names(compile_query(st, q))
         assert names == f"hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,{fold}", (q.groupby, names)
         assert "global" not in names and "hdk_pp_" not in names and "_vec" not in names
@@ -246,7 +247,7 @@ def test_multistep_shapes_beyond_lds_take_the_range_bin_passes():
     from syn_queries import msbs, msphs, phm, syn_table
     st = ArrowStorage()
     st.import_numpy("syn", syn_table(np.random.default_rng(7), 60_000, ("x10", "y10", "z10", "x100", "x1k", "x10k", "x100k")), fragment_size=20_000)
-    for q, fold in ((msbs(2, key_type=FP64), "hdk_bhm_fold"), (msbs(3, key_type=FP64), "hdk_bhm_fold"), (msphs(2), "hdk_finalize"), (msphs(3), "hdk_finalize"),
+    for q, fold in ((msbs(2), "hdk_bhm_fold"), (msbs(3, key_type=FP64), "hdk_bhm_fold"), (msphs(2), "hdk_finalize"), (msphs(3), "hdk_finalize"),
                     (phm(4), "hdk_finalize"), (phm(5), "hdk_finalize")):
         names = _names(compile_query(st, q))
         assert names == f"hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,{fold}", (q.groupby, names)

@@ -61,7 +61,7 @@ CONFIGS = {
     # the same suite's other families (tests/syn_queries.py holds the queries): NonGroupedAgg, MultiStep, PerfectHashMultiCol
     "nga2": (1_000_000_000, 24, "NGA02: SELECT SUM(x10), SUM(y10), SUM(z10), SUM(x100), SUM(y100), SUM(z100); six INT columns, no key"),
     "nga5": (1_000_000_000, 24, "NGA05: SELECT AVG(x10), AVG(y10), AVG(z10), AVG(x100), AVG(y100), AVG(z100)"),
-    "msbs1": (1_000_000_000, 12, "MSBS001: SELECT cast(x1k AS double), count(*), max(x100), max(x10), max(x10 + 1), sum(x100), sum(x10 + 1) "
+    "msbs1": (1_000_000_000, 12, "MSBS001: SELECT cast(x1k AS float), count(*), max(x100), max(x10), max(x10 + 1), sum(x100), sum(x10 + 1) "
                                  "GROUP BY 1; 1 K groups, open addressing (the query's post-aggregate arithmetic is above the hot path)"),
     "msphs1": (1_000_000_000, 12, "MSPHS001: the same by x1k itself; 1 K groups, perfect hash"),
     "phm2": (1_000_000_000, 12, "PHM002: SELECT x100, y10, count(z10), sum(z10), max(z10), min(z10), avg(z10) GROUP BY 1, 2; 1 K groups, "
@@ -79,7 +79,7 @@ CONFIGS = {
 SYN_SUITE = {
     "nga2": lambda SQ: SQ.nga(2),
     "nga5": lambda SQ: SQ.nga(5),
-    "msbs1": lambda SQ: SQ.msbs(1, key_type=__import__("hdk_amd.ir", fromlist=["FP64"]).FP64),
+    "msbs1": lambda SQ: SQ.msbs(1),  # (cast(x1k AS float), as the suite writes it)
     "msphs1": lambda SQ: SQ.msphs(1),
     "phm2": lambda SQ: SQ.phm(2),
 }
