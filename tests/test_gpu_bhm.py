@@ -234,3 +234,76 @@ def test_float_group_keys(oracle, gpu_executor_factory):
     live = f[f != np.frombuffer(np.uint32(A.NULL_FLOAT_BITS).tobytes(), dtype=np.float32)[0]]
     assert sorted(k for k in outf["k"] if k is not None) == sorted(float(v) for v in np.unique(live))
     assert sum(1 for k in outf["k"] if k is None) == 1
+
+
+def _random_case(rng):
+    """A random table of INT columns (random ranges, some with NULLs), a random group-by over 1-3 of them (perfect hash, or one key
+    cast to double / float: open addressing) and 1-6 aggregates over up to three columns, plain or `column op literal`."""
+    from hdk_amd.ir import FP32
+    n = int(rng.integers(50_000, 400_000))
+    ncols = 6
+    cols, spans = {}, {}
+    for c in range(ncols):
+        lo = int(rng.integers(-50, 50))
+        span = int(rng.choice([3, 10, 40, 100, 1000, 5000, 40_000]))
+        v = rng.integers(lo, lo + span, n).astype(np.int32)
+        if rng.random() < 0.4:
+            v[rng.random(n) < rng.choice([0.001, 0.05, 0.5])] = A.NULL_INT
+        cols[f"c{c}"] = v
+        spans[f"c{c}"] = span
+    names = list(cols)
+    rng.shuffle(names)
+    form = rng.choice(["perfect", "double", "float"])
+    nkeys = int(rng.integers(1, 4)) if form == "perfect" else 1
+    keys = names[:nkeys]
+    while form == "perfect" and nkeys > 1 and np.prod([spans[k] + 2 for k in keys]) > 300_000:  # (the planner's multi-column limit is 1e6)
+        nkeys -= 1
+        keys = names[:nkeys]
+    args = names[nkeys:nkeys + int(rng.integers(1, 4))]
+    groupby = [ColRef(k) for k in keys] if form == "perfect" else [Cast(ColRef(keys[0]), FP64 if form == "double" else FP32)]
+    targets = [KeyRef(i, f"k{i}") for i in range(nkeys)]
+    if rng.random() < 0.6:
+        targets.append(Agg("count", None, "n"))
+    for i in range(int(rng.integers(1, 8 - len(targets) + 1))):
+        a = ColRef(str(rng.choice(args)))
+        r = rng.random()
+        expr = a if r < 0.6 else (a + int(rng.integers(1, 9)) if r < 0.75 else (a - int(rng.integers(1, 9)) if r < 0.9 else a * int(rng.integers(2, 5))))
+        targets.append(Agg(str(rng.choice(["count", "sum", "min", "max", "avg"])), expr, f"t{i}"))
+    st = ArrowStorage()
+    st.import_numpy("t", cols, fragment_size=int(rng.integers(n // 5 + 1, n + 1)))
+    return st, QueryUnit("t", groupby=groupby, targets=targets, output_columnar=bool(rng.random() < 0.25))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["default", "dynamic", "two_pass"])
+def test_random_multi_argument_group_bys(oracle, gpu_executor_factory, monkeypatch, mode):
+    """Differential test over random shapes of the multi-argument group-by's domain, on the compile-time shapes where they apply,
+    on the run-time descriptor form alone (HDK_HIP_BHM_DYNAMIC) and with the two-pass form forced for every table beyond LDS
+    (HDK_HIP_BH_PARTITIONS_ALWAYS): whatever kernel the launch takes, the groups are the oracle's.  HDK_FUZZ_SEEDS=a:b widens it."""
+    import os
+    from hdk_amd.ir import QueryMustRunOnCpu
+    if mode == "dynamic":
+        monkeypatch.setenv("HDK_HIP_BHM_DYNAMIC", "1")
+    if mode == "two_pass":
+        monkeypatch.setenv("HDK_HIP_BH_PARTITIONS_ALWAYS", "1")
+    lo, hi = (int(x) for x in os.environ.get("HDK_FUZZ_SEEDS", "0:14").split(":"))
+    took = 0
+    for seed in range(lo, hi):
+        rng = np.random.default_rng(9000 + seed)
+        st, q = _random_case(rng)
+        try:
+            cp, want, err = run_oracle(oracle, st, q)
+        except QueryMustRunOnCpu:
+            continue
+        if err != 0:
+            continue
+        step = gpu_executor_factory(st).prepare(cp)
+        names = step.kernel_names()
+        res = step.run()
+        step.free()
+        took += "bhm" in names
+        if cp.plan.query_kind == A.Q_BASELINE_HASH:
+            _check_rows(cp, res.buffer, want)
+        else:
+            assert_buffers_equal(cp, res.buffer, want)
+    assert took >= (hi - lo) // 3, took  # (the generator aims at this kernel family: most cases must land on it)
