@@ -380,9 +380,19 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   // pass B's table: one bin, one replica
   a->entries = 1u << w;
   const uint64_t one = bhm_lds_layout(a, per_entry);
-  a->rep = 1;
-  a->rep_bytes = (static_cast<uint32_t>(one) + 15u) & ~15u;
-  a->lds_bytes = a->rep_bytes;
+  // ONE replica: replicas of a small bin's table (HDK_HIP_BHM_PART_REPLICAS = 2 / 4 / 8) measured no better -- bh5 1.14 / 1.15 / 1.21 /
+  // 1.20 ms, msbs2 1.32 / 1.31 / 1.29 / 1.31, phm4 1.27 / 1.29 / 1.35 / 1.34 per 256 M rows: same-address conflicts are not what
+  // bounds pass B (its LDS operations per row are)
+  uint32_t prep_bytes = (static_cast<uint32_t>(one) + 15u) & ~15u;
+  uint32_t prep = 1;
+  if (const char* e = hdk_sw(SW_BHM_PART_REPLICAS)) prep = static_cast<uint32_t>(std::max(1, atoi(e)));  // (measurements; a power of two)
+  while (prep > 1 && static_cast<uint64_t>(prep_bytes + 16) * prep > kBhmReplicatedBytes) prep >>= 1;
+  if (prep > 1) {
+    while (prep_bytes % 256 != 16) prep_bytes += 16;
+  }
+  a->rep = prep;
+  a->rep_bytes = prep_bytes;
+  a->lds_bytes = prep_bytes * prep;
   a->max_rows_per_block = 0xFFFFFFFFu;  // (pass B checks its own bound: a sub-slab's capacity)
   // twice a sub-slab's even share of the rows (a hot key overflows it: the flag, the armed fallback)
   pg->cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 3) & ~3ull;

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
     }
   }
   __syncthreads();
+  uint8_t* rp = lds8 + static_cast<size_t>(tid & (a.rep - 1)) * a.rep_bytes;
   const uint32_t bin = blockIdx.x / kPbXcds, x = blockIdx.x % kPbXcds;
   const size_t sub = static_cast<size_t>(bin) * kPbXcds + x;
   const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(g.fill[sub * kPbCursorStride]), g.cap));
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
           lv[s][j] = nulls ? (in & (code != 0)) : true;
         }
       }
-      bhm_update<C, NS, R>(a, lds8, dummy, e, xv, lv);
+      bhm_update<C, NS, R>(a, rp, dummy, e, xv, lv);
     }
   }
   __syncthreads();

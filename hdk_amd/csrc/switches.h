@@ -14,6 +14,7 @@ namespace hdk {
   X(BHM_BLOCKS_PER_CU)              \
   X(BHM_DYNAMIC)                    \
   X(BHM_PART_MIN_BINS)              \
+  X(BHM_PART_REPLICAS)              \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(COLS_BLOCKS_PER_CU)             \
