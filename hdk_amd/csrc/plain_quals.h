@@ -67,10 +67,11 @@ HDK_DEV void plain_load_rows(const int8_t* buf, int width, int kind, const int64
 #undef HDK_PQ_ROWS
 }
 
-// pass[r] &= the program over the leaves is TRUE for row[r]
-template <int VR>
-HDK_DEV void plain_quals_program(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
-                                 bool (&pass)[VR], bool nt) {
+// pass[r] &= the program over the leaves is TRUE for row r.  load(qi, q, live, v): leaf qi's column values of the VR rows,
+// int64-widened (double bits for an fp column) -- from memory by row number (plain_load_rows), or from registers a kernel
+// already holds (scan_bhm.h: the filter columns ride in the tile's batch of 16-byte loads).
+template <int VR, class LoadFn>
+HDK_DEV void plain_quals_program_with(const ProjFastQual* quals, int nquals, LoadFn load, bool (&pass)[VR]) {
   constexpr int NW = (VR + 31) / 32;  // mask words per value: one bit per row
   uint32_t lt[kMaxPlainQuals][NW], ln[kMaxPlainQuals][NW];  // leaf qi: bit r = TRUE / NULL for row r
 #pragma unroll
@@ -83,7 +84,7 @@ HDK_DEV void plain_quals_program(const ProjFastQual* quals, int nquals, const in
     if (qi < nquals) {
       const ProjFastQual q = quals[qi];
       int64_t v[VR];
-      plain_load_rows<VR>(cols[q.col.buf_idx], q.col.width, q.col.kind, row, pass, nt, v);
+      load(qi, q, pass, v);
       const bool fpc = q.fp != 0, col_fp = q.col_fp != 0, nullable = q.nullable != 0;
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
@@ -155,17 +156,16 @@ HDK_DEV void plain_quals_program(const ProjFastQual* quals, int nquals, const in
 // (match_plain_quals(..., allow_program = true)) -- only those kernels carry the program's code: compiled into the radix
 // scatters too it cost them registers and a resident block (C5 12.5 -> 15.1 ms per 1 B rows, the perfect-hash partitions 4.1 ->
 // 4.9 ms per 256 M) although no plan of theirs has one
-template <int VR, bool PROG = false>
-HDK_DEV void plain_quals_pass(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
-                              bool (&pass)[VR], bool nt) {
+template <int VR, bool PROG, class LoadFn>
+HDK_DEV void plain_quals_pass_with(const ProjFastQual* quals, int nquals, LoadFn load, bool (&pass)[VR]) {
   if (PROG && nquals > 0 && quals[0].nprog != 0) {  // (wave-uniform)
-    plain_quals_program<VR>(quals, nquals, cols, row, pass, nt);
+    plain_quals_program_with<VR>(quals, nquals, load, pass);
     return;
   }
   for (int qi = 0; qi < nquals; ++qi) {
     const ProjFastQual q = quals[qi];
     int64_t v[VR];
-    plain_load_rows<VR>(cols[q.col.buf_idx], q.col.width, q.col.kind, row, pass, nt, v);
+    load(qi, q, pass, v);
     const bool fpc = q.fp != 0;
     const bool col_fp = q.col_fp != 0;
     const bool nullable = q.nullable != 0;
@@ -191,6 +191,18 @@ HDK_DEV void plain_quals_pass(const ProjFastQual* quals, int nquals, const int8_
     }
 #undef HDK_PQ_CMP
   }
+}
+
+// the leaves' columns read from memory by row number
+template <int VR, bool PROG = false>
+HDK_DEV void plain_quals_pass(const ProjFastQual* quals, int nquals, const int8_t* const* cols, const int64_t (&row)[VR],
+                              bool (&pass)[VR], bool nt) {
+  plain_quals_pass_with<VR, PROG>(
+      quals, nquals,
+      [&](int, const ProjFastQual& q, const bool (&live)[VR], int64_t (&v)[VR]) {
+        plain_load_rows<VR>(cols[q.col.buf_idx], q.col.width, q.col.kind, row, live, nt, v);
+      },
+      pass);
 }
 
 }  // namespace hdk

@@ -32,6 +32,7 @@
 #pragma once
 #include "watch.h"
 #include "agg_common.h"
+#include "plain_quals.h"
 #include "scan_agg_fast.h"
 #include "scan_bh.h"
 
@@ -121,8 +122,13 @@ struct BhmArgs {
   BhmSlabWord sw[kMaxWordsPerEntry];
   // open-addressing plans: the key word of internal entry i (hdk_bhm_fold)
   int32_t key_form;        // 0: the key column's value; 1: cast(integer AS double)
-  int32_t pad2_;
+  int32_t col_width;       // bytes of every streamed column: 4, or 8 (BIGINT columns inside 32 bits by their statistics; their
+                           // in-band NULL is mapped to INT32_MIN: key / src `null32` say INT32_MIN then)
   int64_t key_null_word;   // key word of the NULL key's entry
+  // plain filters `column cmp literal` / AND-OR-NOT programs over them (plain_quals.h): the kernels' Q instantiations
+  int32_t nquals;
+  int32_t qvec;            // every filter column is an integer column of the streamed width: loaded 16 bytes a lane with the tile
+  ProjFastQual q[kMaxPlainQuals];
 };
 
 // ---- the shape of a plan's arguments, as compile-time constants or read from the descriptors ------------------------------
@@ -204,9 +210,27 @@ HDK_DEV void bhm_mm_improve(const BhmArgs& ar, uint32_t* word, uint32_t cand_lo,
 
 // NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s.  `stale` collects "the statistics do
 // not hold" (the caller raises the launch's flag).
-// the dense entry of NR rows from their key columns (dummy = the entry behind the table for a key outside the statistics)
+// One element of a streamed column as the 32-bit value the row body works on.  W == 8: a BIGINT column whose statistics lie
+// inside 32 bits -- the in-band NULL (INT64_MIN) becomes INT32_MIN (what the descriptors' null32 says for such columns); a value
+// that does not fit 32 bits, or is INT32_MIN itself, sets `wide` (the statistics do not hold for it).
+template <int W>
+HDK_DEV int32_t bhm_narrow(const uint32_t* regs, int i, bool& wide) {
+  if (W == 4) {
+    wide = false;
+    return static_cast<int32_t>(regs[i]);
+  }
+  const int64_t v = extract_elem<8>(regs, i);
+  const int32_t lo = static_cast<int32_t>(v);
+  const bool isnull = v == INT64_MIN;
+  wide = !isnull & ((v != static_cast<int64_t>(lo)) | (lo == INT32_MIN));
+  return isnull ? INT32_MIN : lo;
+}
+
+// the dense entry of NR rows from their key columns (dummy = the entry behind the table for a key outside the statistics);
+// returns the rows whose key lies outside them
 template <int NK, int NR>
-HDK_DEV void bhm_key_entries(const BhmArgs& a, bool nulls, uint32_t dummy, const int32_t (&k)[NK][NR], uint32_t (&e)[NR], uint32_t& stale) {
+HDK_DEV uint32_t bhm_key_entries(const BhmArgs& a, bool nulls, uint32_t dummy, const int32_t (&k)[NK][NR], uint32_t (&e)[NR]) {
+  uint32_t badm = 0;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     uint32_t idx = 0;
@@ -225,14 +249,16 @@ HDK_DEV void bhm_key_entries(const BhmArgs& a, bool nulls, uint32_t dummy, const
       }
       idx += NK == 1 ? d : __umul24(d, key.stride);
     }
-    stale |= bad ? 1u : 0u;
+    badm |= bad ? 1u << j : 0u;
     e[j] = bad ? dummy : idx;
   }
+  return badm;
 }
 
-// the argument columns against their statistics; live: not NULL (and inside them)
+// the argument columns against their statistics; live: not NULL (and inside them); returns the rows with a value outside them
 template <int NS, int NR>
-HDK_DEV void bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[NS][NR], bool (&live)[NS][NR], uint32_t& stale) {
+HDK_DEV uint32_t bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[NS][NR], bool (&live)[NS][NR]) {
+  uint32_t badm = 0;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const BhmSrc& src = a.src[s];
@@ -242,33 +268,45 @@ HDK_DEV void bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[NS][N
       const bool out = (static_cast<uint32_t>(raw) - static_cast<uint32_t>(src.raw_min)) > src.raw_span;
       if (nulls) {
         const bool isnull = (src.nullable != 0) & (raw == src.null32);
-        stale |= (out & !isnull) ? 1u : 0u;
+        badm |= (out & !isnull) ? 1u << j : 0u;
         live[s][j] = !isnull & !out;
       } else {
-        stale |= out ? 1u : 0u;
+        badm |= out ? 1u << j : 0u;
         live[s][j] = true;  // (a row outside the statistics raises the flag: what it adds is thrown away with the launch)
       }
     }
   }
+  return badm;
 }
 
-template <class C, int NS, int NR>
+template <class C, int NS, int NR, bool Q = false>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]);
 
-template <class C, int NK, int NS, int NR>
-HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR], const int32_t (&x)[NS][NR], uint32_t& stale) {
+// NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s; okm: rows that take part (a ragged tile's
+// end, filters); `stale` collects "the statistics do not hold" for rows that take part (the caller raises the launch's flag).
+template <class C, int NK, int NS, int NR, bool Q = false>
+HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR], const int32_t (&x)[NS][NR], uint32_t okm, uint32_t widem,
+                      uint32_t& stale) {
   const bool nulls = C::nulls(a);
   uint32_t e[NR];
-  bhm_key_entries<NK, NR>(a, nulls, a.entries, k, e, stale);
+  uint32_t badm = bhm_key_entries<NK, NR>(a, nulls, a.entries, k, e) | widem;
   bool live[NS][NR];
-  bhm_src_live<NS, NR>(a, nulls, x, live, stale);
-  bhm_update<C, NS, NR>(a, rp, a.entries, e, x, live);
+  badm |= bhm_src_live<NS, NR>(a, nulls, x, live);
+  stale |= badm & okm;
+  if (!C::kStatic || Q) {  // (a compile-time shape without a filter: every row takes part -- a bad one raises `stale`)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      e[j] = ((okm & ~badm) >> j) & 1u ? e[j] : a.entries;
+    }
+  }
+  bhm_update<C, NS, NR, Q>(a, rp, a.entries, e, x, live);
 }
 
 // the LDS updates of NR rows whose entries are known (e[j]; `dummy` for rows that do not take part)
-template <class C, int NS, int NR>
+template <class C, int NS, int NR, bool Q>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]) {
   const bool nulls = C::nulls(a);
+  constexpr bool skips = !C::kStatic || Q;  // rows that take no part exist
   uint32_t cand_lo[NR], cand_hi[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -302,9 +340,12 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
         unsigned long long* pk = reinterpret_cast<unsigned long long*>(rp) + static_cast<uint32_t>(der.packed) * a.e1;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          // (a NULL argument is not counted and not added: its increment goes to the dummy entry)
+          // (a NULL argument is not counted and not added; nor is a row the filter dropped: many lanes adding to the one
+          // dummy entry would serialise -- 30 % of the rows dropped: 5.2 ms per 1 B rows with the adds, X without)
           const uint32_t ej = nulls ? (lv[j] ? e[j] : dummy) : e[j];
-          atomicAdd(pk + ej, (1ull << kBhmSumBits) + static_cast<unsigned long long>(static_cast<long long>(v[j])));
+          if (!skips || ej != dummy) {
+            atomicAdd(pk + ej, (1ull << kBhmSumBits) + static_cast<unsigned long long>(static_cast<long long>(v[j])));
+          }
         }
       }
       if (C::mx(a, i)) {
@@ -375,7 +416,9 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
     uint32_t* rows = reinterpret_cast<uint32_t*>(rp + a.off_rows);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      atomicAdd(rows + e[j], 1u);
+      if (!skips || e[j] != dummy) {
+        atomicAdd(rows + e[j], 1u);
+      }
     }
   }
 }
@@ -453,16 +496,13 @@ HDK_DEV void bhm_slab_entry(const BhmArgs& a, const uint8_t* lds8, uint32_t ei, 
 
 // C: the arguments' shape (BhmStatic<...> or BhmDynamic); NK key columns, NS argument columns, all 4 bytes wide; U steps of
 // 16 bytes per lane, column and tile
-#ifndef HDK_BHM_PREFETCH
-#define HDK_BHM_PREFETCH 0  // 1: issue the NEXT full tile's loads before this tile's rows go through the table.  Measured WORSE
-                            // (256 M rows, msbs1 / msphs1 at three blocks per CU: 0.69 / 0.63 ms against 0.63 / 0.60 -- the second
-                            // register set costs more waves than the overlap returns)
-#endif
-template <class C, int NK, int NS, int BLOCK, int U>
+// (round-6 note: issuing the NEXT full tile's loads before this tile's rows go through the table -- a second register set --
+// measured WORSE: msbs1 / msphs1 at three blocks per CU 0.69 / 0.63 ms against 0.63 / 0.60 per 256 M rows; not kept)
+// W: bytes of every streamed column (4, or 8: BIGINT columns inside 32 bits); U steps of 16 bytes per lane, column and tile
+template <class C, int NK, int NS, int BLOCK, int U, int W = 4, bool Q = false>
 __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
-  constexpr bool PREFETCH = HDK_BHM_PREFETCH != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
-  constexpr int R = 4;
+  constexpr int R = 16 / W;
   const int tid = threadIdx.x;
   {
     uint4* z = reinterpret_cast<uint4*>(lds8);
@@ -480,6 +520,8 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
   uint32_t stale = 0;
   uint32_t rows_seen = 0;
   const Watch watch = watch_begin(a.kp);
+  constexpr bool filtered = Q;  // (the matcher picks the Q kernels for plans with a filter, and only for them)
+  const bool qvec = Q && a.qvec != 0;
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   for (uint64_t f = 0; f < nfrag; ++f) {
@@ -495,84 +537,110 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
     for (int s = 0; s < NS; ++s) {
       xcol[s] = (gcol_t)cols[a.src[s].buf_idx];
     }
-    // (PREFETCH: full tiles double-buffered -- see HDK_BHM_PREFETCH)
-    uint32_t kr[U][NK][4], xr[U][NS][4];
-    bool have = false;  // kr / xr hold this tile already
-    auto load_tile = [&](int64_t row0, uint32_t (&kd)[U][NK][4], uint32_t (&xd)[U][NS][4]) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t r = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-          load_bytes<16, true>(kcol[kk] + r * 4, kd[u][kk]);
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          load_bytes<16, true>(xcol[s] + r * 4, xd[u][s]);
-        }
-      }
-    };
     for (; tile < frag_tile_begin + ntiles; tile += gridDim.x) {
       HDK_WATCH_TILE(watch, err, tile)
       rows_seen += static_cast<uint32_t>(kTileRows);
       const int64_t row0 = (tile - frag_tile_begin) * kTileRows;
       if (row0 + kTileRows <= nrows) {
-        if (!have) {
-          load_tile(row0, kr, xr);
-        }
-        uint32_t kn[U][NK][4], xn[U][NS][4];
-        const int64_t next0 = row0 + static_cast<int64_t>(gridDim.x) * kTileRows;
-        const bool next_full = PREFETCH && next0 + kTileRows <= nrows;
-        if (next_full) {
-          load_tile(next0, kn, xn);
+        uint32_t kr[U][NK][4], xr[U][NS][4], qr[Q ? U : 1][kMaxPlainQuals][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t r = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R;
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            load_bytes<16, true>(kcol[kk] + r * W, kr[u][kk]);
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            load_bytes<16, true>(xcol[s] + r * W, xr[u][s]);
+          }
+          // the filter's columns in the same batch (integers of the streamed width: BhmArgs::qvec): read by row number after
+          // the batch has landed, their latency stood alone -- 5.2 ms per 1 B rows for MSPHS001 WHERE x10 < 8, X this way
+#pragma unroll
+          for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+            if (Q && qvec && qi < a.nquals) {
+              load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);
+            }
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int32_t kv[NK][R], xv[NS][R];
+          uint32_t widem = 0, okm = (1u << R) - 1u;
 #pragma unroll
           for (int i = 0; i < R; ++i) {
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
-              kv[kk][i] = static_cast<int32_t>(kr[u][kk][i]);
+              bool wide;
+              kv[kk][i] = bhm_narrow<W>(kr[u][kk], i, wide);
+              widem |= wide ? 1u << i : 0u;
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-              xv[s][i] = static_cast<int32_t>(xr[u][s][i]);
+              bool wide;
+              xv[s][i] = bhm_narrow<W>(xr[u][s], i, wide);
+              widem |= wide ? 1u << i : 0u;
             }
           }
-          bhm_rows<C, NK, NS, R>(a, rp, kv, xv, stale);
-        }
-        have = next_full;
-        if (next_full) {
+          if (filtered) {
+            int64_t rows[R];
+            bool ok[R];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
+            for (int i = 0; i < R; ++i) {
+              rows[i] = row0 + (static_cast<int64_t>(u) * BLOCK + tid) * R + i;
+              ok[i] = true;
+            }
+            if (qvec) {
+              plain_quals_pass_with<R, true>(
+                  a.q, a.nquals,
+                  [&](int qi, const ProjFastQual&, const bool (&)[R], int64_t (&v)[R]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < R; ++i) {
+                      // (qi is wave-uniform: a select over the three register sets' values, not an indexed array -- that would live in scratch)
+                      const int64_t v0 = extract_elem<W>(qr[Q ? u : 0][0], i), v1 = extract_elem<W>(qr[Q ? u : 0][1], i), v2 = extract_elem<W>(qr[Q ? u : 0][2], i);
+                      v[i] = qi == 0 ? v0 : (qi == 1 ? v1 : v2);
+                    }
+                  },
+                  ok);
+            } else {
+              plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
+            }
+            okm = 0;
 #pragma unroll
-              for (int kk = 0; kk < NK; ++kk) {
-                kr[u][kk][i] = kn[u][kk][i];
-              }
-#pragma unroll
-              for (int s = 0; s < NS; ++s) {
-                xr[u][s][i] = xn[u][s][i];
-              }
+            for (int i = 0; i < R; ++i) {
+              okm |= ok[i] ? 1u << i : 0u;
             }
           }
+          bhm_rows<C, NK, NS, R, Q>(a, rp, kv, xv, okm, widem, stale);
         }
       } else {
-        have = false;
         // the ragged tail of a fragment, a row per lane and trip
         for (int64_t r = row0 + tid; r < nrows; r += BLOCK) {
           int32_t kv[NK][1], xv[NS][1];
+          uint32_t widem = 0, okm = 1u;
 #pragma unroll
           for (int kk = 0; kk < NK; ++kk) {
-            kv[kk][0] = static_cast<int32_t>(load_elem<4>(kcol[kk], r));
+            const int64_t v = load_elem<W>(kcol[kk], r);
+            const uint32_t two[2] = {static_cast<uint32_t>(v), static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32)};
+            bool wide;
+            kv[kk][0] = bhm_narrow<W>(two, 0, wide);
+            widem |= wide ? 1u : 0u;
           }
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            xv[s][0] = static_cast<int32_t>(load_elem<4>(xcol[s], r));
+            const int64_t v = load_elem<W>(xcol[s], r);
+            const uint32_t two[2] = {static_cast<uint32_t>(v), static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32)};
+            bool wide;
+            xv[s][0] = bhm_narrow<W>(two, 0, wide);
+            widem |= wide ? 1u : 0u;
           }
-          bhm_rows<C, NK, NS, 1>(a, rp, kv, xv, stale);
+          if (filtered) {
+            const int64_t rows1[1] = {r};
+            bool ok1[1] = {true};
+            plain_quals_pass<1, true>(a.q, a.nquals, cols, rows1, ok1, true);
+            okm = ok1[0] ? 1u : 0u;
+          }
+          bhm_rows<C, NK, NS, 1, Q>(a, rp, kv, xv, okm, widem, stale);
         }
       }
     }

@@ -7,6 +7,7 @@
 #include "scan_bhm.h"
 #include "scan_bhm_part.h"
 #include "scan_bhm_host.h"
+#include "scan_bhm_shapes.h"
 
 namespace hdk {
 
@@ -14,11 +15,6 @@ constexpr uint32_t kBhmMaxLdsBytes = 144u << 10;        // one 1024-thread block
 constexpr uint32_t kBhmSmallLdsBytes = 40u << 10;       // up to here: 256-thread blocks, four on a CU
 constexpr uint32_t kBhmReplicatedBytes = 32u << 10;     // replicas while the table is tiny
 constexpr int64_t kBhmMaxAbsVal = (1ll << 19) - 1;      // |argument| below this keeps a block's row budget at 2^20 or more
-#ifndef HDK_BHM_U
-#define HDK_BHM_U 2  // (A/B builds: -DHDK_BHM_U=4)
-#endif
-constexpr int kBhmU = HDK_BHM_U;                        // 16-byte steps per lane, column and tile
-
 // (A/B switches; every table here is dense: HDK_HIP_NO_BH_DENSE turns it off with the one-argument dense forms)
 static bool bhm_off() { return hdk_sw(SW_NO_BHM) != nullptr || hdk_sw(SW_NO_BH_LDS) != nullptr || hdk_sw(SW_NO_BH_DENSE) != nullptr; }
 
@@ -29,7 +25,7 @@ static uint32_t bits_for(uint64_t codes) {  // bits that hold the values 0 .. co
 }
 
 struct BhmGeom {
-  int nk, ns, block;
+  int nk, ns, block, width;
   uint32_t grid_per_cu;
   bool perfect;
   int64_t key_lo;
@@ -45,9 +41,15 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   if (!ko || ko->total_rows == 0 || ko->total_rows >= (1ull << 40)) return false;
   if (ko->flags & (HDK_HIP_LAUNCH_FORCE_GLOBAL_ATOMICS | HDK_HIP_LAUNCH_FORCE_PARTITIONED)) return false;
   if (launch_forces_generic(ko)) return false;
-  if (p->num_joins || p->num_quals || p->num_filter_ops) return false;
+  if (p->num_joins) return false;
   if (p->key_count < 1 || p->key_count > kBhmMaxKeys) return false;
   memset(a, 0, sizeof(*a));
+  // plain filters `outer column cmp literal`, alone or under an AND / OR / NOT program (plain_quals.h): the run-time form
+  if (p->num_quals || p->num_filter_ops) {
+    if (!match_plain_quals(p, a->q, true)) return false;
+    a->nquals = p->num_quals;
+  }
+  int width = 0;  // of every streamed column: 4, or 8 (BIGINT inside 32 bits)
   memset(g, 0, sizeof(*g));
   g->perfect = perfect;
   g->null_entry = 0xFFFFFFFFu;
@@ -57,10 +59,13 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
     const hdk_hip_expr& ke = p->keys[k];
     if (ke.leaf0.kind != HDK_LEAF_COL) return false;
     const hdk_hip_col& kc = p->cols[ke.leaf0.col];
-    if (kc.table != 0 || kc.kind != HDK_COL_INT || kc.width != 4) return false;
+    if (kc.table != 0 || kc.kind != HDK_COL_INT || (kc.width != 4 && kc.width != 8)) return false;
+    if (width && width != kc.width) return false;  // (one width for all streamed columns)
+    width = kc.width;
+    if (kc.width == 8 && (!kc.has_stats || kc.min_val <= INT32_MIN || kc.max_val > INT32_MAX)) return false;
     BhmKey& key = a->key[k];
     key.buf_idx = kc.buf_idx;
-    key.null32 = static_cast<int32_t>(ke.leaf0.null_val);
+    key.null32 = kc.width == 8 ? INT32_MIN : static_cast<int32_t>(ke.leaf0.null_val);  // (bhm_narrow maps a BIGINT NULL there)
     if (perfect) {
       // the plan's own index: (key - min) * stride, a NULL under its translated value (perfect_key_hash)
       if (ke.nsteps != 0 || p->key_bucket[k] > 1) return false;
@@ -139,7 +144,7 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
     const hdk_hip_expr& e = tg.arg;
     if (e.nsteps > 1 || e.leaf0.kind != HDK_LEAF_COL || tg.arg_is_fp || e.vclass != HDK_VC_INT) return false;
     const hdk_hip_col& col = p->cols[e.leaf0.col];
-    if (col.table != 0 || col.kind != HDK_COL_INT || col.width != 4 || !col.has_stats || col.max_val < col.min_val) return false;
+    if (col.table != 0 || col.kind != HDK_COL_INT || col.width != width || !col.has_stats || col.max_val < col.min_val) return false;
     if (col.min_val < -kBhmMaxAbsVal || col.max_val > kBhmMaxAbsVal) return false;
     int64_t mul = 1, add = 0, rmin = col.min_val, rmax = col.max_val;
     if (e.nsteps == 1) {
@@ -179,7 +184,7 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
       BhmSrc& src = a->src[s];
       src.buf_idx = col.buf_idx;
       src.nullable = nullable;
-      src.null32 = static_cast<int32_t>(e.leaf0.null_val);
+      src.null32 = col.width == 8 ? INT32_MIN : static_cast<int32_t>(e.leaf0.null_val);
       src.raw_min = static_cast<int32_t>(col.min_val);
       src.raw_span = static_cast<uint32_t>(col.max_val - col.min_val);
     } else if (a->src[s].nullable != nullable) {
@@ -214,6 +219,13 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
     }
   }
   if (a->nsrc == 0) return false;  // (COUNT(*) alone: the keys kernel / the one-argument packed kernels)
+  a->col_width = width;
+  g->width = width;
+  a->qvec = a->nquals > 0;
+  for (int qi = 0; qi < a->nquals; ++qi) {
+    const ProjFastCol& c = a->q[qi].col;
+    a->qvec = a->qvec && c.kind == HDK_COL_INT && c.width == width;
+  }
   // (one key, one plain argument is scan_bh_packed.h's own shape: its one-pass kernels are asked first, launch_bh_packed; what
   // they cannot hold -- 24 bytes an entry, 4 096 entries -- may still fit here at 12: BH004 / PHS004's 10 000 groups in ONE pass)
   for (int k = 0; k < a->nkeys; ++k) a->any_nullable |= a->key[k].nullable;
@@ -407,54 +419,29 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   return true;
 }
 
-// ---- the instantiations ---------------------------------------------------------------------------------------------------------
-template <class C, int NK, int NS>
-static const void* bhm_kernel_of(int block) {
-  return block == 1024 ? reinterpret_cast<const void*>(hdk_scan_agg_bhm<C, NK, NS, 1024, kBhmU>)
-                       : reinterpret_cast<const void*>(hdk_scan_agg_bhm<C, NK, NS, 256, kBhmU>);
-}
-template <int NK>
-static const void* bhm_dynamic_nk(int ns, int block) {
-  return ns == 1 ? bhm_kernel_of<BhmDynamic, NK, 1>(block) : (ns == 2 ? bhm_kernel_of<BhmDynamic, NK, 2>(block) : bhm_kernel_of<BhmDynamic, NK, 3>(block));
-}
-// the shapes with compile-time argument lists (BhmStatic): what the reference's benchmark suite and its neighbours ask for.
-// Arguments are numbered in the order the targets name them, columns likewise.
+// ---- the instantiations (scan_bhm_shapes.h: the list; this file holds <4-byte columns, no filter> and pass B) ------------------
+HDK_BHM_DEFINE_KERNELS(4, false)
+
 struct BhmStaticShape {
   int nk, ns;
   uint32_t code[kBhmMaxDer];
-  const void* (*kernel)(int block);
-  const void* (*aggregate)();  // pass B of the two-pass form (the keys are folded into the tuple: NK does not matter)
+  const void* (*aggregate)();  // pass B of the two-pass form (the keys are folded into the tuple: NK, W, the filter do not matter)
 };
-#define HDK_BHM_SHAPE(NK, NS, D0, D1, D2, D3)                                                                            \
-  {                                                                                                                      \
-    NK, NS, {D0, D1, D2, D3}, [](int block) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3>, NK, NS>(block); }, \
-        []() -> const void* { return reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS>); }   \
-  }
-constexpr uint32_t kN = kBhmNone;
-static const BhmStaticShape kBhmShapes[] = {
-    // MultiStep/MSBS001-005, MSPHS001-...: max(x100) + sum(x100), max(x10), max(x10 + 1) + sum(x10 + 1)
-    HDK_BHM_SHAPE(1, 2, bhm_code(0, true, true, false, 0), bhm_code(1, false, true, false, 0), bhm_code(1, true, true, false, 1), kN),
-    // PerfectHashMultiCol/PHM001-006: count / sum / max / min / avg of one column by two keys (and by three); by one key:
-    // BaselineHash/BH004, PerfectHashSingleCol/PHS004 (10 000 groups: 12 bytes an entry fit one CU's LDS)
-    HDK_BHM_SHAPE(1, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
-    HDK_BHM_SHAPE(2, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
-    HDK_BHM_SHAPE(3, 1, bhm_code(0, true, true, true, 0), kN, kN, kN),
-    // sums (counts, averages) of two columns: MultiStep/MSBS006-007, MSPHM's SUM(x10), SUM(y10) by one key and by two
-    HDK_BHM_SHAPE(1, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN),
-    HDK_BHM_SHAPE(2, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN),
-    // sum of one column by two keys; sum of `column + literal` by one
-    HDK_BHM_SHAPE(2, 1, bhm_code(0, true, false, false, 0), kN, kN, kN),
-    HDK_BHM_SHAPE(1, 1, bhm_code(0, true, false, false, 1), kN, kN, kN),
-};
-#undef HDK_BHM_SHAPE
+#define HDK_BHM_SHAPE_ROW(NK, NS, D0, D1, D2, D3) \
+  {NK, NS, {D0, D1, D2, D3}, []() -> const void* { return reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS>); }},
+static const BhmStaticShape kBhmShapes[] = {HDK_BHM_SHAPES(HDK_BHM_SHAPE_ROW)};
+#undef HDK_BHM_SHAPE_ROW
+constexpr int kBhmNumShapes = static_cast<int>(sizeof(kBhmShapes) / sizeof(kBhmShapes[0]));
 
-template <int NK>
-static const void* bhm_scatter_nk(int ns) {
-  return ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 1>)
-                 : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 2>) : reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 3>));
+// the (column width, filtered) quarter a plan belongs to
+template <class F4, class F4Q, class F8, class F8Q>
+static const void* bhm_by_quarter(const BhmArgs& a, const BhmGeom& g, F4 f4, F4Q f4q, F8 f8, F8Q f8q) {
+  return g.width == 8 ? (a.nquals ? f8q() : f8()) : (a.nquals ? f4q() : f4());
 }
-static const void* bhm_scatter_kernel(const BhmGeom& g) {
-  return g.nk == 1 ? bhm_scatter_nk<1>(g.ns) : (g.nk == 2 ? bhm_scatter_nk<2>(g.ns) : bhm_scatter_nk<3>(g.ns));
+static const void* bhm_scatter_kernel(const BhmArgs& a, const BhmGeom& g) {
+  return bhm_by_quarter(
+      a, g, [&] { return BhmKernels<4, false>::scatter(g.nk, g.ns); }, [&] { return BhmKernels<4, true>::scatter(g.nk, g.ns); },
+      [&] { return BhmKernels<8, false>::scatter(g.nk, g.ns); }, [&] { return BhmKernels<8, true>::scatter(g.nk, g.ns); });
 }
 
 static uint32_t bhm_code_of(const BhmArgs& a, int i) {
@@ -468,16 +455,21 @@ static uint32_t bhm_code_of(const BhmArgs& a, int i) {
 static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_static) {
   *is_static = false;
   if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
-    for (const BhmStaticShape& sh : kBhmShapes) {
+    for (int si = 0; si < kBhmNumShapes; ++si) {
+      const BhmStaticShape& sh = kBhmShapes[si];
       bool same = sh.nk == g.nk && sh.ns == g.ns;
       for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
       if (same) {
         *is_static = true;
-        return sh.kernel(g.block);
+        return bhm_by_quarter(
+            a, g, [&] { return BhmKernels<4, false>::fixed(si, g.block); }, [&] { return BhmKernels<4, true>::fixed(si, g.block); },
+            [&] { return BhmKernels<8, false>::fixed(si, g.block); }, [&] { return BhmKernels<8, true>::fixed(si, g.block); });
       }
     }
   }
-  return g.nk == 1 ? bhm_dynamic_nk<1>(g.ns, g.block) : (g.nk == 2 ? bhm_dynamic_nk<2>(g.ns, g.block) : bhm_dynamic_nk<3>(g.ns, g.block));
+  return bhm_by_quarter(
+      a, g, [&] { return BhmKernels<4, false>::dynamic(g.nk, g.ns, g.block); }, [&] { return BhmKernels<4, true>::dynamic(g.nk, g.ns, g.block); },
+      [&] { return BhmKernels<8, false>::dynamic(g.nk, g.ns, g.block); }, [&] { return BhmKernels<8, true>::dynamic(g.nk, g.ns, g.block); });
 }
 
 static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g) {
@@ -562,11 +554,12 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   pg.fill = reinterpret_cast<uint32_t*>(base + 256);
   pg.tuples = reinterpret_cast<uint32_t*>(base + 256 + l.cursor_bytes);
   a.slabs = reinterpret_cast<int64_t*>(base + 256 + l.cursor_bytes + l.tuple_bytes);
-  const void* sk = bhm_scatter_kernel(g);
-  HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kBhmScatterLds)));
-  const unsigned g1 = scatter_grid(sk, kPbBlock, kBhmScatterLds, props, 2);
+  const void* sk = bhm_scatter_kernel(a, g);
+  const size_t scatter_lds = bhm_scatter_lds(g.width);
+  HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatter_lds)));
+  const unsigned g1 = scatter_grid(sk, kPbBlock, scatter_lds, props, 2);
   void* kargs[] = {&pg};
-  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), kargs, kBhmScatterLds, s));
+  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), kargs, scatter_lds, s));
   const void* ak = bhm_aggregate_kernel(a, g);
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));

@@ -23,9 +23,9 @@
 
 namespace hdk {
 
-constexpr int kBhmPartVR = 16;                      // rows per lane and batch of pass A
-constexpr int kBhmPartTile = kPbBlock * kBhmPartVR;  // 8 192 rows
-constexpr size_t kBhmScatterLds = static_cast<size_t>(kBhmPartTile) * 4 + kBhmPartTile + 16;  // uint32 staging | uint8 bin of every slot
+// rows per lane and batch of pass A: 16 over 4-byte columns (8 192 rows a batch), 8 over 8-byte ones (their loads take twice the registers)
+constexpr int bhm_part_vr(int w) { return w == 8 ? 8 : 16; }
+constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kPbBlock) * bhm_part_vr(w) * 5 + 16; }  // uint32 staging | uint8 bin of every slot
 constexpr int kBhmAggBlock = 256;
 
 struct BhmPartArgs {
@@ -42,10 +42,11 @@ struct BhmPartArgs {
 };
 
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------
-template <int NK, int NS>
+template <int NK, int NS, int W = 4, bool Q = false>
 __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
-  constexpr int VR = kBhmPartVR;
-  constexpr int R = 4, U = VR / R;
+  constexpr int VR = bhm_part_vr(W);
+  constexpr int kBhmPartTile = kPbBlock * VR;
+  constexpr int R = 16 / W, U = VR / R;
   const BhmArgs& a = g.b;
   __shared__ uint32_t s_cnt[kPbMaxBins];
   __shared__ uint4 s_run[kPbMaxBins];
@@ -95,18 +96,25 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
       const bool full = row0 + kBhmPartTile <= nrows;
       uint32_t tup[VR], bin[VR];
       bool live[VR];
-      uint32_t kr[U][NK][4], xr[U][NS][4];
+      uint32_t kr[U][NK][4], xr[U][NS][4], qr[Q ? U : 1][kMaxPlainQuals][4];
+      const bool qvec = Q && full && a.qvec != 0;  // the filter's columns with the batch (scan_bhm.h); a ragged tile: by row number
       if (full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t r = row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R;
 #pragma unroll
           for (int kk = 0; kk < NK; ++kk) {
-            load_bytes<16, true>(kcol[kk] + r * 4, kr[u][kk]);
+            load_bytes<16, true>(kcol[kk] + r * W, kr[u][kk]);
           }
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            load_bytes<16, true>(xcol[s] + r * 4, xr[u][s]);
+            load_bytes<16, true>(xcol[s] + r * W, xr[u][s]);
+          }
+#pragma unroll
+          for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+            if (Q && qvec && qi < a.nquals) {
+              load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);
+            }
           }
         }
       } else {
@@ -118,45 +126,90 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
             const bool in = r < nrows;
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
-              kr[u][kk][i] = in ? static_cast<uint32_t>(load_elem<4>(kcol[kk], r)) : 0u;
+              const int64_t v = in ? load_elem<W>(kcol[kk], r) : 0;
+              if (W == 8) {
+                kr[u][kk][(2 * i) % 4] = static_cast<uint32_t>(v);
+                kr[u][kk][(2 * i + 1) % 4] = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
+              } else {
+                kr[u][kk][i % 4] = static_cast<uint32_t>(v);
+              }
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-              xr[u][s][i] = in ? static_cast<uint32_t>(load_elem<4>(xcol[s], r)) : 0u;
+              const int64_t v = in ? load_elem<W>(xcol[s], r) : 0;
+              if (W == 8) {
+                xr[u][s][(2 * i) % 4] = static_cast<uint32_t>(v);
+                xr[u][s][(2 * i + 1) % 4] = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
+              } else {
+                xr[u][s][i % 4] = static_cast<uint32_t>(v);
+              }
             }
           }
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        int32_t kv[NK][R];
+        int32_t kv[NK][R], xv[NS][R];
+        uint32_t widem = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
 #pragma unroll
           for (int kk = 0; kk < NK; ++kk) {
-            kv[kk][i] = static_cast<int32_t>(kr[u][kk][i]);
+            bool wide;
+            kv[kk][i] = bhm_narrow<W>(kr[u][kk], i, wide);
+            widem |= wide ? 1u << i : 0u;
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            bool wide;
+            xv[s][i] = bhm_narrow<W>(xr[u][s], i, wide);
+            widem |= wide ? 1u << i : 0u;
+          }
+        }
+        bool ok[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          ok[i] = full || row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i < nrows;
+        }
+        if (Q) {  // plain filters: rows that fail are not scattered
+          int64_t rows[R];
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            rows[i] = ok[i] ? row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i : row0;
+          }
+          if (qvec) {
+            plain_quals_pass_with<R, true>(
+                a.q, a.nquals,
+                [&](int qi, const ProjFastQual&, const bool (&)[R], int64_t (&v)[R]) {
+#pragma unroll
+                  for (int i = 0; i < R; ++i) {
+                    const int64_t v0 = extract_elem<W>(qr[Q ? u : 0][0], i), v1 = extract_elem<W>(qr[Q ? u : 0][1], i), v2 = extract_elem<W>(qr[Q ? u : 0][2], i);
+                    v[i] = qi == 0 ? v0 : (qi == 1 ? v1 : v2);
+                  }
+                },
+                ok);
+          } else {
+            plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
           }
         }
         uint32_t e[R];
-        uint32_t st_rows = 0;  // (rows past a ragged tile's end are not strangers)
-        bhm_key_entries<NK, R>(a, nulls, 0xFFFFFFFFu, kv, e, st_rows);
+        const uint32_t kbad = bhm_key_entries<NK, R>(a, nulls, 0xFFFFFFFFu, kv, e) | widem;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const int r = u * R + i;
-          const bool in = full || row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i < nrows;
-          bool bad = e[i] == 0xFFFFFFFFu;
+          bool bad = ((kbad >> i) & 1u) != 0;
           uint32_t t = e[i] & wmask;
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
             const BhmSrc& src = a.src[s];
-            const int32_t raw = static_cast<int32_t>(xr[u][s][i]);
+            const int32_t raw = xv[s][i];
             const uint32_t d = static_cast<uint32_t>(raw) - static_cast<uint32_t>(src.raw_min);
             const bool isnull = nulls & (src.nullable != 0) & (raw == src.null32);
             bad = bad | (!isnull & (d > src.raw_span));
             t |= (isnull ? 0u : d + 1u) << g.cshift[s];
           }
-          stale |= (in & bad) ? 1u : 0u;
-          live[r] = in & !bad;
+          stale |= (ok[i] & bad) ? 1u : 0u;
+          live[r] = ok[i] & !bad;
           bin[r] = live[r] ? e[i] >> g.w : 0u;
           tup[r] = t;
         }

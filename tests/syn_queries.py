@@ -67,3 +67,10 @@ def phm(i, table="syn"):
     return QueryUnit(table, groupby=[ColRef(PHM_KEYS[i]), ColRef("y10")],
                      targets=[KeyRef(0, "k0"), KeyRef(1, "k1"), Agg("count", z, "c"), Agg("sum", z, "s"), Agg("max", z, "mx"),
                               Agg("min", z, "mn"), Agg("avg", z, "a")])
+
+
+def filtered(q, column, op, literal):
+    """`q` WHERE column <op> literal"""
+    import dataclasses
+    from hdk_amd.ir import Cmp, Lit
+    return dataclasses.replace(q, quals=list(q.quals) + [Cmp(ColRef(column), op, Lit(literal))])

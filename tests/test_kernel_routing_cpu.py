@@ -232,6 +232,43 @@ def test_multistep_and_multicol_benchmark_shapes_stay_on_chip():
     assert "bhm" not in _names(compile_query(st, msphs(1)), total_rows=0)
 
 
+def test_bigint_columns_and_filters_stay_on_chip():
+    """The same shapes over 8-byte columns whose statistics fit 32 bits (Arrow int64 tables), and behind plain filters / AND-OR-NOT
+    programs: still the multi-argument on-chip kernel (one pass and two), not global atomics or the interpreter.  An 8-byte
+    column whose statistics do NOT fit 32 bits, and a mix of widths, keep the general routes."""
+    from syn_queries import msbs, msphs, phm, syn_table
+    import dataclasses
+    from hdk_amd.ir import Not
+    rng = np.random.default_rng(8)
+    names_ = ("x10", "y10", "z10", "x100", "x1k", "x10k")
+    narrow = syn_table(rng, 60_000, names_)
+    wide = {k: v.astype(np.int64) for k, v in narrow.items()}
+    st4, st8 = ArrowStorage(), ArrowStorage()
+    st4.import_numpy("syn", narrow, fragment_size=20_000)
+    st8.import_numpy("syn", wide, fragment_size=20_000)
+    X10, X100 = ColRef("x10"), ColRef("x100")
+    quals = [Or(Cmp(X10, "<", Lit(4)), Not(Cmp(X100, ">", Lit(50))))]
+    for st in (st4, st8):
+        for q, fold in ((msbs(1, key_type=FP64), "hdk_bhm_fold"), (msphs(1), "hdk_finalize"), (phm(2), "hdk_finalize")):
+            for qq in (q, dataclasses.replace(q, quals=[Cmp(X10, "<", Lit(7))]), dataclasses.replace(q, quals=quals)):
+                if st is st4 and not qq.quals:
+                    continue  # (the test above)
+                names = _names(compile_query(st, qq))
+                assert names == f"hdk_scan_agg_bhm,hdk_bhm_reduce_slabs,{fold}", (qq.groupby, qq.quals, names)
+        names = _names(compile_query(st, dataclasses.replace(msphs(2), quals=quals)))
+        assert names == "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_finalize", names
+    big = dict(wide)
+    big["x10"] = big["x10"] + (1 << 40)
+    st = ArrowStorage()
+    st.import_numpy("syn", big, fragment_size=20_000)
+    assert "bhm" not in _names(compile_query(st, msphs(1)))
+    mixed = dict(wide)
+    mixed["x10"] = narrow["x10"]
+    st = ArrowStorage()
+    st.import_numpy("syn", mixed, fragment_size=20_000)
+    assert "bhm" not in _names(compile_query(st, msphs(1)))
+
+
 def test_multistep_switch_gives_the_old_routes_back(monkeypatch):
     from syn_queries import msphs, phm, syn_table
     st = ArrowStorage()

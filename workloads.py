@@ -66,6 +66,8 @@ CONFIGS = {
     "msphs1": (1_000_000_000, 12, "MSPHS001: the same by x1k itself; 1 K groups, perfect hash"),
     "phm2": (1_000_000_000, 12, "PHM002: SELECT x100, y10, count(z10), sum(z10), max(z10), min(z10), avg(z10) GROUP BY 1, 2; 1 K groups, "
                                 "two-column perfect hash"),
+    "msphs1w": (1_000_000_000, 24, "MSPHS001 over BIGINT columns (an Arrow table of int64): the same kernel, narrowing in registers"),
+    "msphs1f": (1_000_000_000, 12, "MSPHS001 WHERE x10 < 8 (about 70 % of the rows pass; the filter column is one of the arguments)"),
     "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
     "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
     "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
@@ -82,7 +84,10 @@ SYN_SUITE = {
     "msbs1": lambda SQ: SQ.msbs(1),  # (cast(x1k AS float), as the suite writes it)
     "msphs1": lambda SQ: SQ.msphs(1),
     "phm2": lambda SQ: SQ.phm(2),
+    "msphs1w": lambda SQ: SQ.msphs(1),
+    "msphs1f": lambda SQ: SQ.filtered(SQ.msphs(1), "x10", "<", 8),
 }
+SYN_WIDE = ("msphs1w",)  # 8-byte columns
 
 
 def _expr_columns(e, out):
@@ -97,7 +102,7 @@ def _expr_columns(e, out):
 
 def _query_columns(q):
     out = set()
-    for e in list(q.groupby) + [t.arg for t in q.targets if getattr(t, "arg", None) is not None]:
+    for e in list(q.groupby) + [t.arg for t in q.targets if getattr(t, "arg", None) is not None] + [c.lhs for c in q.quals]:
         _expr_columns(e, out)
     return out
 
@@ -180,9 +185,9 @@ class Workload:
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
             import syn_queries as SQ
             self.query = SYN_SUITE[name](SQ)
-            I32 = Type("int", 4, True)
+            ctype, tdtype = (Type("int", 8, True), torch.int64) if name in SYN_WIDE else (Type("int", 4, True), torch.int32)
             names = sorted(_query_columns(self.query))
-            table("syn", {c: (I32, uniform(1, SQ.SYN_COLUMNS[c] + 1, 20 + sorted(SQ.SYN_COLUMNS).index(c), torch.int32), (1, SQ.SYN_COLUMNS[c]))
+            table("syn", {c: (ctype, uniform(1, SQ.SYN_COLUMNS[c] + 1, 20 + sorted(SQ.SYN_COLUMNS).index(c), tdtype), (1, SQ.SYN_COLUMNS[c]))
                           for c in names}, self.frag_rows, self.frag_ids)
             self.syn_hi = {c: SQ.SYN_COLUMNS[c] for c in names}
         elif name in ("c3", "c3g", "c3gm", "c3m"):
@@ -377,11 +382,20 @@ class Workload:
                 stride *= d
             if gid is None:
                 gid = torch.zeros(self.frag_rows[f], dtype=torch.int64, device=self.dev)
+            keep = None  # the suite's filters: a conjunction of `column cmp literal` over columns without NULLs
+            for c in q.quals:
+                a, b = self._syn_eval(c.lhs, f), int(c.rhs.value)
+                m = {"<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b, "=": a == b, "<>": a != b}[c.op]
+                keep = m if keep is None else keep & m
+            if keep is not None:
+                gid = gid[keep]
             cnt += torch.bincount(gid, minlength=G)
             for t in aggs:
                 if t.arg is None:
                     continue
                 v = self._syn_eval(t.arg, f)
+                if keep is not None:
+                    v = v[keep]
                 if t.kind in ("sum", "avg"):
                     acc[t.name].index_add_(0, gid, v)
                 elif t.kind == "max":
