@@ -389,6 +389,7 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
     pg->cmask[s] = static_cast<uint32_t>((1ull << cb) - 1);
     pos += cb;
   }
+  pg->tw = (pos <= 16 && !hdk_sw(SW_BHM_WIDE_TUPLES)) ? 2 : 4;
   // pass B's table: one bin, one replica
   a->entries = 1u << w;
   const uint64_t one = bhm_lds_layout(a, per_entry);
@@ -407,12 +408,13 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   a->lds_bytes = prep_bytes * prep;
   a->max_rows_per_block = 0xFFFFFFFFu;  // (pass B checks its own bound: a sub-slab's capacity)
   // twice a sub-slab's even share of the rows (a hot key overflows it: the flag, the armed fallback)
-  pg->cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 3) & ~3ull;
+  pg->cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 7) & ~7ull;
   const int64_t by_sum = ((1ll << 39) - 1) / amax;
   if (pg->cap > 0xFFFFFFF0ull || static_cast<int64_t>(pg->cap) > std::min<int64_t>(by_sum, 1ll << 23)) return false;
   l->cursor_bytes = static_cast<size_t>(pg->nbins) * kPbXcds * kPbCursorStride * sizeof(uint32_t);
   // (after pass B the tuples are spent and their space takes the ONE slab the eight are reduced to: at least that much)
-  l->tuple_bytes = std::max(static_cast<size_t>(pg->nbins) * kPbXcds * pg->cap * 4, static_cast<size_t>(total) * a->wpe * 8);
+  // (+ one batch of slack: a clamped claim of the last sub-slab, scan_bhm_part.h)
+  l->tuple_bytes = std::max((static_cast<size_t>(pg->nbins) * kPbXcds * pg->cap + kBhmPartBlock * 16) * pg->tw, static_cast<size_t>(total) * a->wpe * 8);
   l->slab_bytes = static_cast<size_t>(kPbXcds) * total * a->wpe * 8;
   if (l->slab_bytes > (1ull << 30)) return false;  // (PHM005's 1 M entries: 700 MB of slabs, written and read once)
   l->total = 256 + l->cursor_bytes + l->tuple_bytes + l->slab_bytes;
@@ -425,10 +427,13 @@ HDK_BHM_DEFINE_KERNELS(4, false)
 struct BhmStaticShape {
   int nk, ns;
   uint32_t code[kBhmMaxDer];
-  const void* (*aggregate)();  // pass B of the two-pass form (the keys are folded into the tuple: NK, W, the filter do not matter)
+  const void* (*aggregate)(int tw);  // pass B of the two-pass form (the keys are folded into the tuple: NK, W, the filter do not matter)
 };
-#define HDK_BHM_SHAPE_ROW(NK, NS, D0, D1, D2, D3) \
-  {NK, NS, {D0, D1, D2, D3}, []() -> const void* { return reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS>); }},
+#define HDK_BHM_SHAPE_ROW(NK, NS, D0, D1, D2, D3)                                                                            \
+  {NK, NS, {D0, D1, D2, D3}, [](int tw) -> const void* {                                                                     \
+     return tw == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS, 2>)                     \
+                    : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS, 4>);                    \
+   }},
 static const BhmStaticShape kBhmShapes[] = {HDK_BHM_SHAPES(HDK_BHM_SHAPE_ROW)};
 #undef HDK_BHM_SHAPE_ROW
 constexpr int kBhmNumShapes = static_cast<int>(sizeof(kBhmShapes) / sizeof(kBhmShapes[0]));
@@ -472,17 +477,21 @@ static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_stati
       [&] { return BhmKernels<8, false>::dynamic(g.nk, g.ns, g.block); }, [&] { return BhmKernels<8, true>::dynamic(g.nk, g.ns, g.block); });
 }
 
-static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g) {
+template <int TW>
+static const void* bhm_aggregate_dynamic(int ns) {
+  return ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 1, TW>)
+                 : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 2, TW>)
+                            : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 3, TW>));
+}
+static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g, int tw) {
   if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
     for (const BhmStaticShape& sh : kBhmShapes) {
       bool same = sh.ns == g.ns;  // (any NK: pass B sees entries, not keys)
       for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
-      if (same) return sh.aggregate();
+      if (same) return sh.aggregate(tw);
     }
   }
-  return g.ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 1>)
-                   : (g.ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 2>)
-                                : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 3>));
+  return tw == 2 ? bhm_aggregate_dynamic<2>(g.ns) : bhm_aggregate_dynamic<4>(g.ns);
 }
 
 const char* bhm_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options* ko) {
@@ -557,10 +566,10 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   const void* sk = bhm_scatter_kernel(a, g);
   const size_t scatter_lds = bhm_scatter_lds(g.width);
   HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatter_lds)));
-  const unsigned g1 = scatter_grid(sk, kPbBlock, scatter_lds, props, 2);
+  const unsigned g1 = scatter_grid(sk, kBhmPartBlock, scatter_lds, props, 1024 / kBhmPartBlock);
   void* kargs[] = {&pg};
-  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kPbBlock), kargs, scatter_lds, s));
-  const void* ak = bhm_aggregate_kernel(a, g);
+  HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kBhmPartBlock), kargs, scatter_lds, s));
+  const void* ak = bhm_aggregate_kernel(a, g, static_cast<int>(pg.tw));
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
   }

@@ -2,7 +2,7 @@
 //
 // A dense table of 10 K - 500 K groups (MultiStep/MSBS002-003, MSPHS002-003, PerfectHashMultiCol/PHM003-005, BaselineHash/
 // BH005) is cut into bins of 2^w consecutive entries, each small enough for one block's LDS:
-//   pass A  hdk_bhm_scatter     every row becomes ONE 4-byte tuple
+//   pass A  hdk_bhm_scatter     every row becomes ONE 4-byte tuple (2-byte when entry and codes fit 16 bits: BH005's 9 + 4)
 //                                   [entry inside the bin : w | code of argument column 0 | code of column 1 | ...]
 //                               (code = value - min + 1 by the column's statistics, 0 = NULL: x100 takes 7 bits, x10 four) and
 //                               goes behind its bin's cursor -- batches of 8 192 rows per block, staged in LDS ordered by bin, so
@@ -23,9 +23,13 @@
 
 namespace hdk {
 
+#ifndef HDK_BHM_PART_BLOCK
+#define HDK_BHM_PART_BLOCK 512
+#endif
+constexpr int kBhmPartBlock = HDK_BHM_PART_BLOCK;  // pass A's block (A/B builds: -DHDK_BHM_PART_BLOCK=256)
 // rows per lane and batch of pass A: 16 over 4-byte columns (8 192 rows a batch), 8 over 8-byte ones (their loads take twice the registers)
 constexpr int bhm_part_vr(int w) { return w == 8 ? 8 : 16; }
-constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kPbBlock) * bhm_part_vr(w) * 5 + 16; }  // uint32 staging | uint8 bin of every slot
+constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kBhmPartBlock) * bhm_part_vr(w) * 5 + 16; }  // uint32 staging | uint8 bin of every slot
 constexpr int kBhmAggBlock = 256;
 
 struct BhmPartArgs {
@@ -33,41 +37,161 @@ struct BhmPartArgs {
   uint32_t w;              // bits of a tuple's entry inside its bin
   uint32_t nbins;          // <= 256
   uint32_t total_entries;  // the dense table
-  uint32_t pad_;
+  uint32_t tw;             // bytes of a tuple: 2 when entry and codes fit 16 bits (BH005 / PHS005: 9 + 4), else 4
   uint32_t cshift[kBhmMaxSrc];  // position of argument column s's code in the tuple
   uint32_t cmask[kBhmMaxSrc];
-  uint64_t cap;            // tuples of a (bin, XCD) sub-slab (a multiple of 4)
-  uint32_t* tuples;        // [nbins][kPbXcds][cap]
-  uint32_t* fill;          // [nbins][kPbXcds] x kPbCursorStride
+  uint64_t cap;            // tuples of a (bin, XCD) sub-slab (a multiple of 8: sub-slabs start 16-byte aligned)
+  uint32_t* tuples;        // [kPbXcds][nbins][cap] tuples of `tw` bytes (+ one batch of slack behind the last)
+  uint32_t* fill;          // [kPbXcds][nbins] x kPbCursorStride
 };
 
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------
+// R = 16 / W consecutive rows of one lane (one 16-byte step of every streamed column) -> their tuples and bins.  FULL: the
+// tile lies inside the fragment (every row exists).
+// No row is tested against its statistics here: distances from the minimum are CLAMPED for everything that addresses memory
+// (the bin, the entry) and their per-lane MAXIMA are carried through the kernel (kover, sover) and compared once at its end --
+// a row outside the statistics is scattered somewhere harmless and the launch is redone by the armed fallback.  With a compare
+// and a select per row and column the compiler held sixteen rows' lane masks in scalar registers and spilled them (258
+// v_readlane / v_writelane, 24 instructions per row for the tuple alone; pass A is bound by instruction issue).
+template <int NK, int NS, int W, bool Q, bool FULL, bool NULLS>
+HDK_DEV void bhm_part_rows(const BhmPartArgs& g, const int8_t* const* cols, const uint32_t (&kr)[NK][4], const uint32_t (&xr)[NS][4],
+                           const uint32_t (&qr)[kMaxPlainQuals][4], bool qvec, int64_t first_row, int64_t nrows, uint32_t* tup,
+                           uint32_t* bin4, uint32_t (&kover)[NK], uint32_t (&sover)[NS], uint32_t& stale) {
+  constexpr int R = 16 / W;
+  const BhmArgs& a = g.b;
+  const uint32_t wmask = (1u << g.w) - 1u;
+  int32_t kv[NK][R], xv[NS][R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      bool wide;
+      kv[kk][i] = bhm_narrow<W>(kr[kk], i, wide);
+      if (W == 8) stale |= wide ? 1u : 0u;  // (of a row that does not take part, too: redone needlessly, never wrongly)
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bool wide;
+      xv[s][i] = bhm_narrow<W>(xr[s], i, wide);
+      if (W == 8) stale |= wide ? 1u : 0u;
+    }
+  }
+  bool ok[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    ok[i] = FULL || first_row + i < nrows;
+  }
+  if (Q) {  // plain filters: rows that fail are not scattered
+    if (qvec) {
+      plain_quals_pass_with<R, true>(
+          a.q, a.nquals,
+          [&](int qi, const ProjFastQual&, const bool (&)[R], int64_t (&v)[R]) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              // (qi is wave-uniform: a select over the three register sets' values, not an indexed array -- that would live in scratch)
+              const int64_t v0 = extract_elem<W>(qr[0], i), v1 = extract_elem<W>(qr[1], i), v2 = extract_elem<W>(qr[2], i);
+              v[i] = qi == 0 ? v0 : (qi == 1 ? v1 : v2);
+            }
+          },
+          ok);
+    } else {
+      int64_t rows[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        rows[i] = ok[i] ? first_row + i : 0;  // (only rows that are `ok` are read)
+      }
+      plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    uint32_t idx = 0;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const BhmKey& key = a.key[kk];
+      uint32_t d = static_cast<uint32_t>(kv[kk][i]) - static_cast<uint32_t>(key.min);
+      const bool isnull = NULLS && (key.nullable != 0) & (kv[kk][i] == key.null32);
+      uint32_t seen = d;
+      if (NULLS) {
+        seen = isnull ? 0u : seen;
+      }
+      if (!FULL || Q) {
+        seen = ok[i] ? seen : 0u;
+      }
+      kover[kk] = max(kover[kk], seen);
+      d = min(d, key.n - 1u);
+      if (NULLS) {
+        d = isnull ? key.null_d : d;  // (the NULL key's term: a translated value inside the range, or the entry behind it)
+      }
+      idx += NK == 1 ? d : __umul24(d, key.stride);
+    }
+    uint32_t t = idx & wmask;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const BhmSrc& src = a.src[s];
+      uint32_t d = static_cast<uint32_t>(xv[s][i]) - static_cast<uint32_t>(src.raw_min);
+      uint32_t code = d + 1u;
+      if (NULLS) {
+        const bool isnull = (src.nullable != 0) & (xv[s][i] == src.null32);
+        d = isnull ? 0u : d;
+        code = isnull ? 0u : code;
+      }
+      if (!FULL || Q) {
+        d = ok[i] ? d : 0u;
+      }
+      sover[s] = max(sover[s], d);
+      t |= code << g.cshift[s];
+    }
+    bin4[i] = (idx >> g.w) << 2;
+    if (!FULL || Q) {
+      bin4[i] = ok[i] ? bin4[i] : 4u * kPbMaxBins;
+    }
+    tup[i] = t;
+  }
+}
+
 template <int NK, int NS, int W = 4, bool Q = false>
-__global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
+__global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void hdk_bhm_scatter(BhmPartArgs g) {
   constexpr int VR = bhm_part_vr(W);
-  constexpr int kBhmPartTile = kPbBlock * VR;
+  constexpr int kBhmPartTile = kBhmPartBlock * VR;
   constexpr int R = 16 / W, U = VR / R;
   const BhmArgs& a = g.b;
-  __shared__ uint32_t s_cnt[kPbMaxBins];
-  __shared__ uint4 s_run[kPbMaxBins];
-  __shared__ uint32_t s_total;
+  // a batch's bins: rows per bin, where a bin's run starts in the staging area, and what turns a staging position into the
+  // tuple's place behind the bin's cursor.  Entry kPbMaxBins: the DEAD bin (rows that are not scattered: a ragged tile's end,
+  // rows outside the statistics, rows a filter dropped) -- staged behind all live runs and never copied out, so that the row
+  // loops carry no `if (live)` (the compiler kept 16 lane masks in scalar registers and spilled them: 258 v_readlane /
+  // v_writelane and 111 branches in a kernel that is bound by instruction issue)
+  __shared__ uint32_t s_cnt[kPbMaxBins + 1];
+  __shared__ uint32_t s_x[kPbMaxBins + 1];
+  __shared__ uint32_t s_delta[kPbMaxBins];
   __shared__ int32_t s_watch;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn32[];
   uint32_t* s_stage = s_dyn32;
   uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn32 + kBhmPartTile);
   const int tid = threadIdx.x;
   const uint32_t xcd = static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (kPbXcds - 1);
-  for (int i = tid; i < kPbMaxBins; i += kPbBlock) {
+  for (int i = tid; i <= kPbMaxBins; i += kBhmPartBlock) {
     s_cnt[i] = 0;
   }
+  // this block's tuples go to its XCD's part of the slab: [xcd][bin][cap] -- positions inside it fit 32 bits
+  uint8_t* const xcd_tuples = reinterpret_cast<uint8_t*>(g.tuples) + static_cast<size_t>(xcd) * g.nbins * g.cap * g.tw;
   __syncthreads();
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
   int32_t err = 0;
   uint32_t stale = 0;
+  uint32_t kover[NK], sover[NS];  // per lane: the largest distance from a column's minimum seen so far (bhm_part_rows)
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    kover[kk] = 0;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    sover[s] = 0;
+  }
   const Watch watch = watch_begin(a.kp);
   const bool nulls = a.any_nullable != 0;
-  const uint32_t wmask = (1u << g.w) - 1u;
+  const bool narrow = g.tw == 2;  // (wave-uniform: 2-byte tuples)
   int64_t tile = blockIdx.x;
   int64_t frag_tile_begin = 0;
   bool stop = false;
@@ -94,35 +218,35 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
       }
       const int64_t row0 = (tile - frag_tile_begin) * kBhmPartTile;
       const bool full = row0 + kBhmPartTile <= nrows;
-      uint32_t tup[VR], bin[VR];
-      bool live[VR];
+      uint32_t tup[VR], bin4[VR];  // bin4: byte offset of the row's bin in s_cnt / s_x (the dead bin: 4 * kPbMaxBins)
+      // (issuing the NEXT tile's loads here, before the batch's LDS work, measured worse: 2.43 -> 2.49 ms per 1 B rows for BH005,
+      // 1.31 -> 1.47 ms per 256 M for MSBS002 -- the second register set spills)
       uint32_t kr[U][NK][4], xr[U][NS][4], qr[Q ? U : 1][kMaxPlainQuals][4];
       const bool qvec = Q && full && a.qvec != 0;  // the filter's columns with the batch (scan_bhm.h); a ragged tile: by row number
+      // a full tile's columns: 16 bytes per lane, step and column
+#define HDK_BHM_PART_LOAD(ROW0)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                    \
+    const int64_t r = (ROW0) + (static_cast<int64_t>(u) * kBhmPartBlock + tid) * R;                       \
+    _Pragma("unroll") for (int kk = 0; kk < NK; ++kk) {                                              \
+      load_bytes<16, true>(kcol[kk] + r * W, kr[u][kk]);                                             \
+    }                                                                                                \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                 \
+      load_bytes<16, true>(xcol[s] + r * W, xr[u][s]);                                               \
+    }                                                                                                \
+    _Pragma("unroll") for (int qi = 0; qi < kMaxPlainQuals; ++qi) {                                  \
+      if (Q && a.qvec != 0 && qi < a.nquals) {                                                       \
+        load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);          \
+      }                                                                                              \
+    }                                                                                                \
+  }
       if (full) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int64_t r = row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R;
-#pragma unroll
-          for (int kk = 0; kk < NK; ++kk) {
-            load_bytes<16, true>(kcol[kk] + r * W, kr[u][kk]);
-          }
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            load_bytes<16, true>(xcol[s] + r * W, xr[u][s]);
-          }
-#pragma unroll
-          for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
-            if (Q && qvec && qi < a.nquals) {
-              load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);
-            }
-          }
-        }
+        HDK_BHM_PART_LOAD(row0)
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
           for (int i = 0; i < R; ++i) {
-            const int64_t r = row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i;
+            const int64_t r = row0 + (static_cast<int64_t>(u) * kBhmPartBlock + tid) * R + i;
             const bool in = r < nrows;
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
@@ -147,97 +271,44 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
           }
         }
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int32_t kv[NK][R], xv[NS][R];
-        uint32_t widem = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-#pragma unroll
-          for (int kk = 0; kk < NK; ++kk) {
-            bool wide;
-            kv[kk][i] = bhm_narrow<W>(kr[u][kk], i, wide);
-            widem |= wide ? 1u << i : 0u;
-          }
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            bool wide;
-            xv[s][i] = bhm_narrow<W>(xr[u][s], i, wide);
-            widem |= wide ? 1u << i : 0u;
-          }
+      // rows -> tuples (bhm_part_rows); the full tile's instantiations know every row is there, the ones for plans without an
+      // announced NULL carry no NULL code (wave-uniform branches around whole instantiations, nothing per row)
+#define HDK_BHM_PART_ROWS(FULL_, NULLS_)                                                                                          \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                                \
+    bhm_part_rows<NK, NS, W, Q, FULL_, NULLS_>(g, cols, kr[u], xr[u], qr[Q ? u : 0], qvec,                                       \
+                                               row0 + (static_cast<int64_t>(u) * kBhmPartBlock + tid) * (16 / W), nrows, &tup[u * (16 / W)], \
+                                               &bin4[u * (16 / W)], kover, sover, stale);                                        \
+  }
+      if (full) {
+        if (nulls) {
+          HDK_BHM_PART_ROWS(true, true)
+        } else {
+          HDK_BHM_PART_ROWS(true, false)
         }
-        bool ok[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          ok[i] = full || row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i < nrows;
-        }
-        if (Q) {  // plain filters: rows that fail are not scattered
-          int64_t rows[R];
-#pragma unroll
-          for (int i = 0; i < R; ++i) {
-            rows[i] = ok[i] ? row0 + (static_cast<int64_t>(u) * kPbBlock + tid) * R + i : row0;
-          }
-          if (qvec) {
-            plain_quals_pass_with<R, true>(
-                a.q, a.nquals,
-                [&](int qi, const ProjFastQual&, const bool (&)[R], int64_t (&v)[R]) {
-#pragma unroll
-                  for (int i = 0; i < R; ++i) {
-                    const int64_t v0 = extract_elem<W>(qr[Q ? u : 0][0], i), v1 = extract_elem<W>(qr[Q ? u : 0][1], i), v2 = extract_elem<W>(qr[Q ? u : 0][2], i);
-                    v[i] = qi == 0 ? v0 : (qi == 1 ? v1 : v2);
-                  }
-                },
-                ok);
-          } else {
-            plain_quals_pass<R, true>(a.q, a.nquals, cols, rows, ok, true);
-          }
-        }
-        uint32_t e[R];
-        const uint32_t kbad = bhm_key_entries<NK, R>(a, nulls, 0xFFFFFFFFu, kv, e) | widem;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          const int r = u * R + i;
-          bool bad = ((kbad >> i) & 1u) != 0;
-          uint32_t t = e[i] & wmask;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const BhmSrc& src = a.src[s];
-            const int32_t raw = xv[s][i];
-            const uint32_t d = static_cast<uint32_t>(raw) - static_cast<uint32_t>(src.raw_min);
-            const bool isnull = nulls & (src.nullable != 0) & (raw == src.null32);
-            bad = bad | (!isnull & (d > src.raw_span));
-            t |= (isnull ? 0u : d + 1u) << g.cshift[s];
-          }
-          stale |= (ok[i] & bad) ? 1u : 0u;
-          live[r] = ok[i] & !bad;
-          bin[r] = live[r] ? e[i] >> g.w : 0u;
-          tup[r] = t;
-        }
+      } else if (nulls) {
+        HDK_BHM_PART_ROWS(false, true)
+      } else {
+        HDK_BHM_PART_ROWS(false, false)
       }
+#undef HDK_BHM_PART_ROWS
+#undef HDK_BHM_PART_LOAD
       // the batch: LDS histogram by bin, one cursor claim per bin and XCD, staging ordered by bin, copy-out in runs
       uint32_t rank[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
-        rank[r] = live[r] ? atomicAdd(&s_cnt[bin[r]], 1u) : 0u;
+        // (behind a filter many rows are dead: their adds would meet on one address)
+        rank[r] = (!Q || bin4[r] != 4u * kPbMaxBins) ? atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(s_cnt) + bin4[r]), 1u) : 0u;
       }
       __syncthreads();
+      // one cursor claim per bin: issued here, its answer is looked at after the staging writes
+      uint32_t claim_n = 0, claim_base = 0;
       if (tid < kPbMaxBins) {
-        const uint32_t n = s_cnt[tid];
-        uint32_t base = 0, nfit = 0;
-        if (n) {
-          base = atomicAdd(g.fill + (static_cast<size_t>(tid) * kPbXcds + xcd) * kPbCursorStride, n);
-          const uint64_t room = base < g.cap ? g.cap - base : 0;
-          nfit = n < room ? n : static_cast<uint32_t>(room);
-          if (nfit < n) {
-            stale = 1;  // the sub-slab is full (a hot key): the launch is redone by the armed fallback
-          }
+        claim_n = s_cnt[tid];
+        if (claim_n) {
+          claim_base = atomicAdd(g.fill + (static_cast<size_t>(xcd) * g.nbins + tid) * kPbCursorStride, claim_n);
         }
-        const uint64_t at = (static_cast<uint64_t>(tid) * kPbXcds + xcd) * g.cap + base;
-        s_run[tid].y = nfit;
-        s_run[tid].z = static_cast<uint32_t>(at);
-        s_run[tid].w = static_cast<uint32_t>(at >> 32);
       }
-      if (tid < kWave) {  // exclusive scan of the counts
+      if (tid < kWave) {  // exclusive scan of the live bins' counts; the dead run starts where they end
         uint32_t carry = 0;
         for (int c0 = 0; c0 < kPbMaxBins; c0 += kWave) {
           const uint32_t n = s_cnt[c0 + tid];
@@ -249,38 +320,71 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
               incl += v;
             }
           }
-          s_run[c0 + tid].x = carry + incl - n;
+          s_x[c0 + tid] = carry + incl - n;
           carry += __shfl(incl, kWave - 1, kWave);
         }
         if (tid == 0) {
-          s_total = carry;
+          s_x[kPbMaxBins] = carry;
         }
       }
       __syncthreads();
+      if (narrow) {  // (a uniform branch around the loops, not inside them)
 #pragma unroll
-      for (int r = 0; r < VR; ++r) {
-        if (live[r]) {
-          const uint32_t si = s_run[bin[r]].x + rank[r];
-          s_binof[si] = static_cast<uint8_t>(bin[r]);
-          s_stage[si] = tup[r];
+        for (int r = 0; r < VR; ++r) {
+          if (!Q || bin4[r] != 4u * kPbMaxBins) {
+            const uint32_t si = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_x) + bin4[r]) + rank[r];
+            s_binof[si] = static_cast<uint8_t>(bin4[r] >> 2);  // (the dead run's are never read)
+            reinterpret_cast<uint16_t*>(s_stage)[si] = static_cast<uint16_t>(tup[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+          if (!Q || bin4[r] != 4u * kPbMaxBins) {
+            const uint32_t si = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_x) + bin4[r]) + rank[r];
+            s_binof[si] = static_cast<uint8_t>(bin4[r] >> 2);
+            s_stage[si] = tup[r];
+          }
         }
       }
       if (tid < kPbMaxBins) {
+        // a claim that does not fit its sub-slab (a hot key) raises the flag -- the launch is redone by the armed fallback -- and
+        // is clamped to the sub-slab's end: its tuples spill over the next sub-slab's first ones (or the slack behind the last)
+        uint32_t base = claim_base;
+        if (claim_n && static_cast<uint64_t>(claim_base) + claim_n > g.cap) {
+          stale = 1;
+          base = static_cast<uint32_t>(min(static_cast<uint64_t>(claim_base), g.cap));
+        }
+        s_delta[tid] = static_cast<uint32_t>(static_cast<uint64_t>(tid) * g.cap) + base - s_x[tid];
         s_cnt[tid] = 0;
       }
+      if (tid == 0) {
+        s_cnt[kPbMaxBins] = 0;
+      }
       __syncthreads();
-      const uint32_t total = s_total;
-      for (uint32_t i = tid; i < total; i += kPbBlock) {
-        const uint32_t b = s_binof[i];
-        const uint4 run = s_run[b];
-        const uint32_t r = i - run.x;
-        if (r < run.y) {
-          g.tuples[((static_cast<uint64_t>(run.w) << 32) | run.z) + r] = s_stage[i];
+      const uint32_t total = s_x[kPbMaxBins];
+      if (narrow) {
+        for (uint32_t i = tid; i < total; i += kBhmPartBlock) {
+          const uint32_t at = s_delta[s_binof[i]] + i;
+          reinterpret_cast<uint16_t*>(xcd_tuples)[at] = reinterpret_cast<const uint16_t*>(s_stage)[i];
+        }
+      } else {
+        for (uint32_t i = tid; i < total; i += kBhmPartBlock) {
+          const uint32_t at = s_delta[s_binof[i]] + i;
+          reinterpret_cast<uint32_t*>(xcd_tuples)[at] = s_stage[i];
         }
       }
       __syncthreads();
     }
     frag_tile_begin += ntiles;
+  }
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    stale |= kover[kk] >= a.key[kk].n ? 1u : 0u;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    stale |= sover[s] > a.src[s].raw_span ? 1u : 0u;
   }
   if (stale) {
     atomicOr(a.flag, 1u);
@@ -291,7 +395,7 @@ __global__ __launch_bounds__(kPbBlock) void hdk_bhm_scatter(BhmPartArgs g) {
 }
 
 // ---- pass B: one block per (bin, XCD sub-slab) -----------------------------------------------------------------------------------
-template <class C, int NS>
+template <class C, int NS, int TW = 4>
 __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g) {
   const BhmArgs& a = g.b;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
@@ -309,49 +413,67 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   __syncthreads();
   uint8_t* rp = lds8 + static_cast<size_t>(tid & (a.rep - 1)) * a.rep_bytes;
   const uint32_t bin = blockIdx.x / kPbXcds, x = blockIdx.x % kPbXcds;
-  const size_t sub = static_cast<size_t>(bin) * kPbXcds + x;
+  const size_t sub = static_cast<size_t>(x) * g.nbins + bin;  // ([xcd][bin][cap])
   const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(g.fill[sub * kPbCursorStride]), g.cap));
-  const uint32_t* t = g.tuples + sub * g.cap;
+  const uint8_t* t = reinterpret_cast<const uint8_t*>(g.tuples) + sub * g.cap * TW;
   const uint32_t wmask = (1u << g.w) - 1u;
   const uint32_t dummy = a.entries;  // (= 2^w: the entry behind the bin's table)
   const bool nulls = C::nulls(a);
-  constexpr int R = 4, U = 4;
-  constexpr uint32_t kStep = kBhmAggBlock * R * U;
+  constexpr int TPV = 16 / TW;  // tuples of a 16-byte load: 4, or 8 two-byte ones
+  constexpr int U = 16 / TPV;   // loads per lane and step: 16 tuples either way
+  constexpr int R = 4;          // rows of one bhm_update
+  constexpr uint32_t kStep = kBhmAggBlock * TPV * U;
   typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
   for (uint32_t base = 0; base < n; base += kStep) {
     const bool full = base + kStep <= n;
     u32x4_t tv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * R;
-      if (full || i + R <= n) {  // (sub-slabs start 16-byte aligned: cap is a multiple of 4)
-        tv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(t + i));
+      const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * TPV;
+      if (full || i + TPV <= n) {  // (sub-slabs start 16-byte aligned: cap is a multiple of 8)
+        tv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(t + static_cast<size_t>(i) * TW));
       } else {
-        tv[u].x = i < n ? t[i] : 0;
-        tv[u].y = i + 1 < n ? t[i + 1] : 0;
-        tv[u].z = i + 2 < n ? t[i + 2] : 0;
-        tv[u].w = 0;
+        uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < TPV; ++j) {
+          if (i + j < n) {
+            if (TW == 2) {
+              wd[j / 2] |= static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(t)[i + j]) << (16 * (j & 1));
+            } else {
+              wd[j % 4] = reinterpret_cast<const uint32_t*>(t)[i + j];
+            }
+          }
+        }
+        tv[u].x = wd[0];
+        tv[u].y = wd[1];
+        tv[u].z = wd[2];
+        tv[u].w = wd[3];
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * R;
-      const uint32_t tw[R] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
-      uint32_t e[R];
-      int32_t xv[NS][R];
-      bool lv[NS][R];
+      const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * TPV;
+      const uint32_t wd[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const bool in = full | (i + j < n);
-        e[j] = in ? tw[j] & wmask : dummy;
+      for (int h = 0; h < TPV / R; ++h) {
+        uint32_t e[R];
+        int32_t xv[NS][R];
+        bool lv[NS][R];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const uint32_t code = (tw[j] >> g.cshift[s]) & g.cmask[s];
-          xv[s][j] = static_cast<int32_t>(code) + (a.src[s].raw_min - 1);
-          lv[s][j] = nulls ? (in & (code != 0)) : true;
+        for (int j = 0; j < R; ++j) {
+          const int jj = h * R + j;
+          const uint32_t tup = TW == 2 ? (wd[jj / 2] >> (16 * (jj & 1))) & 0xFFFFu : wd[jj % 4];
+          const bool in = full | (i + jj < n);
+          e[j] = in ? tup & wmask : dummy;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const uint32_t code = (tup >> g.cshift[s]) & g.cmask[s];
+            xv[s][j] = static_cast<int32_t>(code) + (a.src[s].raw_min - 1);
+            lv[s][j] = nulls ? (in & (code != 0)) : true;
+          }
         }
+        bhm_update<C, NS, R>(a, rp, dummy, e, xv, lv);
       }
-      bhm_update<C, NS, R>(a, rp, dummy, e, xv, lv);
     }
   }
   __syncthreads();

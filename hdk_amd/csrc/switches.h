@@ -15,6 +15,7 @@ namespace hdk {
   X(BHM_DYNAMIC)                    \
   X(BHM_PART_MIN_BINS)              \
   X(BHM_PART_REPLICAS)              \
+  X(BHM_WIDE_TUPLES)                \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \
   X(COLS_BLOCKS_PER_CU)             \

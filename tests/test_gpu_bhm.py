@@ -175,11 +175,15 @@ def test_two_pass_form_for_tables_beyond_lds(oracle, gpu_executor_factory, monke
     for q in (msbs(2), msphs(2), msphs(3), msbs(3, key_type=FP64), phm(4)):
         cp, res = _run(oracle, gpu_executor_factory, st, q, kernel=PART)
     _run(oracle, gpu_executor_factory, st, dataclasses.replace(msphs(2), output_columnar=True), kernel=PART)
-    # five aggregates of one column by 100 K groups (BH005 / PHS005's shape)
+    # five aggregates of one column by 100 K groups (BH005 / PHS005's shape): entry-in-bin + code fit 16 bits -- 2-byte tuples;
+    # HDK_HIP_BHM_WIDE_TUPLES keeps them at 4 bytes
     y = ColRef("y10")
-    for groupby in ([Cast(ColRef("x100k"), FP64)], [ColRef("x100k")]):
-        q = QueryUnit("syn", groupby=groupby, targets=[KeyRef(0, "k")] + [Agg(kd, y, kd) for kd in ("count", "sum", "max", "min", "avg")])
-        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+    for wide in ("", "1"):
+        monkeypatch.setenv("HDK_HIP_BHM_WIDE_TUPLES", wide) if wide else monkeypatch.delenv("HDK_HIP_BHM_WIDE_TUPLES", raising=False)
+        for groupby in ([Cast(ColRef("x100k"), FP64)], [ColRef("x100k")]):
+            q = QueryUnit("syn", groupby=groupby, targets=[KeyRef(0, "k")] + [Agg(kd, y, kd) for kd in ("count", "sum", "max", "min", "avg")])
+            _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+            _run(oracle, gpu_executor_factory, st, dataclasses.replace(q, targets=q.targets[:3]), kernel=PART)
 
 
 def test_two_pass_form_falls_back_on_a_hot_key_and_on_stale_statistics(oracle, gpu_executor_factory, monkeypatch):
