@@ -138,9 +138,10 @@ constexpr uint32_t kBhmNone = 0xFF;
 constexpr uint32_t bhm_code(int src, bool packed, bool mx, bool mn, int step) {
   return static_cast<uint32_t>(src) | (packed ? 4u : 0u) | (mx ? 8u : 0u) | (mn ? 16u : 0u) | (static_cast<uint32_t>(step) << 5);
 }
-template <uint32_t D0, uint32_t D1 = kBhmNone, uint32_t D2 = kBhmNone, uint32_t D3 = kBhmNone>
+// NULLS: some key or argument column announces NULLs (a NULL argument is skipped by its targets, a NULL key has its own entry)
+template <uint32_t D0, uint32_t D1 = kBhmNone, uint32_t D2 = kBhmNone, uint32_t D3 = kBhmNone, bool NULLS = false>
 struct BhmStatic {
-  static constexpr bool kStatic = true;
+  static constexpr bool kSkips = NULLS;  // rows / arguments that take no part exist
   static constexpr uint32_t code(int i) { return i == 0 ? D0 : (i == 1 ? D1 : (i == 2 ? D2 : D3)); }
   HDK_DEV static bool used(const BhmArgs&, int i) { return code(i) != kBhmNone; }
   HDK_DEV static int src(const BhmArgs&, int i) { return static_cast<int>(code(i) & 3u); }
@@ -148,11 +149,11 @@ struct BhmStatic {
   HDK_DEV static bool mx(const BhmArgs&, int i) { return (code(i) & 8u) != 0; }
   HDK_DEV static bool mn(const BhmArgs&, int i) { return (code(i) & 16u) != 0; }
   HDK_DEV static int step(const BhmArgs&, int i) { return static_cast<int>((code(i) >> 5) & 3u); }
-  HDK_DEV static bool nulls(const BhmArgs&) { return false; }
+  HDK_DEV static bool nulls(const BhmArgs&) { return NULLS; }
   HDK_DEV static int mm_bytes(const BhmArgs&) { return ((D0 | (D1 == kBhmNone ? 0 : D1) | (D2 == kBhmNone ? 0 : D2) | (D3 == kBhmNone ? 0 : D3)) & 24u) ? 4 : 0; }
 };
 struct BhmDynamic {
-  static constexpr bool kStatic = false;
+  static constexpr bool kSkips = true;
   HDK_DEV static bool used(const BhmArgs& a, int i) { return i < a.nder; }
   HDK_DEV static int src(const BhmArgs& a, int i) { return a.der[i].src; }
   HDK_DEV static bool packed(const BhmArgs& a, int i) { return a.der[i].packed >= 0; }
@@ -293,7 +294,7 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
   bool live[NS][NR];
   badm |= bhm_src_live<NS, NR>(a, nulls, x, live);
   stale |= badm & okm;
-  if (!C::kStatic || Q) {  // (a compile-time shape without a filter: every row takes part -- a bad one raises `stale`)
+  if (C::kSkips || Q) {  // (a compile-time shape without NULLs or a filter: every row takes part -- a bad one raises `stale`)
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       e[j] = ((okm & ~badm) >> j) & 1u ? e[j] : a.entries;
@@ -306,7 +307,7 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
 template <class C, int NS, int NR, bool Q>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]) {
   const bool nulls = C::nulls(a);
-  constexpr bool skips = !C::kStatic || Q;  // rows that take no part exist
+  constexpr bool skips = C::kSkips || Q;  // rows that take no part exist
   uint32_t cand_lo[NR], cand_hi[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -657,6 +658,14 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
   int64_t* slab = a.slabs + static_cast<size_t>(blockIdx.x) * a.entries * a.wpe;
   for (uint32_t ei = tid; ei < a.entries; ei += BLOCK) {
     bhm_slab_entry(a, lds8, ei, slab + static_cast<size_t>(ei) * a.wpe);
+  }
+}
+
+// (tests, HDK_HIP_BHM_FLAG_IS_ERROR: instead of arming the fallback)
+template <int DUMMY = 0>
+__global__ void hdk_bhm_flag_is_error(const uint32_t* flag, int32_t* error_code) {
+  if (*flag) {
+    record_error(error_code, HDK_HIP_ERR_OUT_OF_SLOTS);
   }
 }
 

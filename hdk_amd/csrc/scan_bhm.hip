@@ -407,14 +407,24 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   a->rep_bytes = prep_bytes;
   a->lds_bytes = prep_bytes * prep;
   a->max_rows_per_block = 0xFFFFFFFFu;  // (pass B checks its own bound: a sub-slab's capacity)
-  // twice a sub-slab's even share of the rows (a hot key overflows it: the flag, the armed fallback)
-  pg->cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 7) & ~7ull;
+  // the sub-slabs are sized on the device from a sample of the keys (hdk_bhm_part_sample / _layout): twice what the sample
+  // promises a bin.  The allocation has room for a quarter more rows than the launch's bound says there are.
   const int64_t by_sum = ((1ll << 39) - 1) / amax;
-  if (pg->cap > 0xFFFFFFF0ull || static_cast<int64_t>(pg->cap) > std::min<int64_t>(by_sum, 1ll << 23)) return false;
-  l->cursor_bytes = static_cast<size_t>(pg->nbins) * kPbXcds * kPbCursorStride * sizeof(uint32_t);
+  pg->cap_limit = static_cast<uint64_t>(std::min<int64_t>(by_sum, 1ll << 23));
+  const uint64_t even_cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 7) & ~7ull;
+  if (even_cap > pg->cap_limit) return false;
+  pg->total_rows = ko->total_rows;
+  pg->region_max = ((ko->total_rows / kPbXcds) * 5 / 2 + static_cast<uint64_t>(pg->nbins) * 4104 + 7) & ~7ull;
+  if (pg->region_max > 0xFFFFFFF0ull) return false;
+  // about 2 000 tiles of 1 024 rows are looked at (every tile of a small input, every 128th at most)
+  pg->sample_stride = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(ko->total_rows / (256ull * (16 / g->width)) / 2048, 1), 128));
+  if (const char* e = hdk_sw(SW_BHM_PART_SAMPLE_STRIDE)) pg->sample_stride = static_cast<uint32_t>(std::max(1, atoi(e)));  // (tests)
+  l->cursor_bytes = static_cast<size_t>(pg->nbins) * kPbXcds * kPbCursorStride * sizeof(uint32_t) + kBlWords * sizeof(uint32_t);
+  l->cursor_bytes = (l->cursor_bytes + 255) & ~static_cast<size_t>(255);
   // (after pass B the tuples are spent and their space takes the ONE slab the eight are reduced to: at least that much)
   // (+ one batch of slack: a clamped claim of the last sub-slab, scan_bhm_part.h)
-  l->tuple_bytes = std::max((static_cast<size_t>(pg->nbins) * kPbXcds * pg->cap + kBhmPartBlock * 16) * pg->tw, static_cast<size_t>(total) * a->wpe * 8);
+  l->tuple_bytes = std::max((static_cast<size_t>(kPbXcds) * pg->region_max + kBhmPartBlock * 16) * pg->tw, static_cast<size_t>(total) * a->wpe * 8);
+  l->tuple_bytes = (l->tuple_bytes + 255) & ~static_cast<size_t>(255);
   l->slab_bytes = static_cast<size_t>(kPbXcds) * total * a->wpe * 8;
   if (l->slab_bytes > (1ull << 30)) return false;  // (PHM005's 1 M entries: 700 MB of slabs, written and read once)
   l->total = 256 + l->cursor_bytes + l->tuple_bytes + l->slab_bytes;
@@ -422,17 +432,21 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
 }
 
 // ---- the instantiations (scan_bhm_shapes.h: the list; this file holds <4-byte columns, no filter> and pass B) ------------------
-HDK_BHM_DEFINE_KERNELS(4, false)
+HDK_BHM_DEFINE_KERNELS(4, false, HDK_BHM_SHAPE_FN_NULLS)
 
 struct BhmStaticShape {
   int nk, ns;
   uint32_t code[kBhmMaxDer];
-  const void* (*aggregate)(int tw);  // pass B of the two-pass form (the keys are folded into the tuple: NK, W, the filter do not matter)
+  const void* (*aggregate)(int tw, bool nulls);  // pass B of the two-pass form (the keys are folded into the tuple: NK, W, the filter do not matter)
 };
 #define HDK_BHM_SHAPE_ROW(NK, NS, D0, D1, D2, D3)                                                                            \
-  {NK, NS, {D0, D1, D2, D3}, [](int tw) -> const void* {                                                                     \
-     return tw == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS, 2>)                     \
-                    : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3>, NS, 4>);                    \
+  {NK, NS, {D0, D1, D2, D3}, [](int tw, bool nulls) -> const void* {                                                         \
+     if (nulls) {                                                                                                            \
+       return tw == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3, true>, NS, 2>)             \
+                      : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3, true>, NS, 4>);            \
+     }                                                                                                                       \
+     return tw == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3, false>, NS, 2>)              \
+                    : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmStatic<D0, D1, D2, D3, false>, NS, 4>);             \
    }},
 static const BhmStaticShape kBhmShapes[] = {HDK_BHM_SHAPES(HDK_BHM_SHAPE_ROW)};
 #undef HDK_BHM_SHAPE_ROW
@@ -449,6 +463,13 @@ static const void* bhm_scatter_kernel(const BhmArgs& a, const BhmGeom& g) {
       [&] { return BhmKernels<8, false>::scatter(g.nk, g.ns); }, [&] { return BhmKernels<8, true>::scatter(g.nk, g.ns); });
 }
 
+template <int W>
+static const void* bhm_sample_kernel_w(int nk) {
+  return nk == 1 ? reinterpret_cast<const void*>(hdk_bhm_part_sample<1, W>)
+                 : (nk == 2 ? reinterpret_cast<const void*>(hdk_bhm_part_sample<2, W>) : reinterpret_cast<const void*>(hdk_bhm_part_sample<3, W>));
+}
+static const void* bhm_sample_kernel(const BhmGeom& g) { return g.width == 8 ? bhm_sample_kernel_w<8>(g.nk) : bhm_sample_kernel_w<4>(g.nk); }
+
 static uint32_t bhm_code_of(const BhmArgs& a, int i) {
   if (i >= a.nder) return kBhmNone;
   const BhmDer& d = a.der[i];
@@ -456,19 +477,25 @@ static uint32_t bhm_code_of(const BhmArgs& a, int i) {
   return bhm_code(d.src, d.packed >= 0, d.has_mx != 0, d.has_mn != 0, d.mul != 1 ? 2 : (d.add != 0 ? 1 : 0));
 }
 
-// compile-time shape when there is one (no NULLs to look for, every field inside 32 bits), else the run-time form
+// compile-time shape when there is one (every field inside 32 bits; with NULLs announced: the unfiltered quarters' twins), else the
+// run-time form
 static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_static) {
   *is_static = false;
-  if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
+  if (a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
+    const bool nulls = a.any_nullable != 0;
     for (int si = 0; si < kBhmNumShapes; ++si) {
       const BhmStaticShape& sh = kBhmShapes[si];
       bool same = sh.nk == g.nk && sh.ns == g.ns;
       for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
       if (same) {
-        *is_static = true;
-        return bhm_by_quarter(
-            a, g, [&] { return BhmKernels<4, false>::fixed(si, g.block); }, [&] { return BhmKernels<4, true>::fixed(si, g.block); },
-            [&] { return BhmKernels<8, false>::fixed(si, g.block); }, [&] { return BhmKernels<8, true>::fixed(si, g.block); });
+        const void* k = bhm_by_quarter(
+            a, g, [&] { return BhmKernels<4, false>::fixed(si, g.block, nulls); }, [&] { return BhmKernels<4, true>::fixed(si, g.block, nulls); },
+            [&] { return BhmKernels<8, false>::fixed(si, g.block, nulls); }, [&] { return BhmKernels<8, true>::fixed(si, g.block, nulls); });
+        if (k) {
+          *is_static = true;
+          return k;
+        }
+        break;
       }
     }
   }
@@ -484,11 +511,11 @@ static const void* bhm_aggregate_dynamic(int ns) {
                             : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 3, TW>));
 }
 static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g, int tw) {
-  if (!a.any_nullable && a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
+  if (a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
     for (const BhmStaticShape& sh : kBhmShapes) {
       bool same = sh.ns == g.ns;  // (any NK: pass B sees entries, not keys)
       for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
-      if (same) return sh.aggregate(tw);
+      if (same) return sh.aggregate(tw, a.any_nullable != 0);
     }
   }
   return tw == 2 ? bhm_aggregate_dynamic<2>(g.ns) : bhm_aggregate_dynamic<4>(g.ns);
@@ -502,7 +529,7 @@ const char* bhm_kernel_name(const hdk_hip_plan* p, const hdk_hip_kernel_options*
     BhmPartLayout l;
     if (match_bhm_part(p, ko, &pg, &g, &l)) {
       return g.perfect ? "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_finalize"
-                       : "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_bhm_fold";
+                       : "hdk_bhm_scatter,hdk_bhm_aggregate,hdk_bhm_reduce_slabs,hdk_bhm_fold";  // (behind hdk_bhm_part_sample, _layout)
     }
     return nullptr;
   }
@@ -541,6 +568,11 @@ static int32_t launch_bhm_folds(const hdk_hip_plan* plan, const hdk_hip_plan* d_
     }
     HDK_HIP_CHECK(hipGetLastError());
   }
+  if (hdk_sw(SW_BHM_FLAG_IS_ERROR)) {  // (tests: "this input must stay on the fast path" -- the flag becomes an error code)
+    hipLaunchKernelGGL(hdk_bhm_flag_is_error<0>, dim3(1), dim3(1), 0, s, a.flag, kp.error_code);
+    HDK_HIP_CHECK(hipGetLastError());
+    return HDK_HIP_OK;
+  }
   // armed: runs only when the flag says the statistics did not hold (the folds skipped then)
   return launch_scan_global_armed(plan, d_plan, kp, ko, props, s, a.flag);
 }
@@ -561,6 +593,7 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   a.kp = kp;
   a.flag = reinterpret_cast<uint32_t*>(base);
   pg.fill = reinterpret_cast<uint32_t*>(base + 256);
+  pg.layout = pg.fill + static_cast<size_t>(pg.nbins) * kPbXcds * kPbCursorStride;  // (zeroed with the cursors)
   pg.tuples = reinterpret_cast<uint32_t*>(base + 256 + l.cursor_bytes);
   a.slabs = reinterpret_cast<int64_t*>(base + 256 + l.cursor_bytes + l.tuple_bytes);
   const void* sk = bhm_scatter_kernel(a, g);
@@ -568,6 +601,12 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatter_lds)));
   const unsigned g1 = scatter_grid(sk, kBhmPartBlock, scatter_lds, props, 1024 / kBhmPartBlock);
   void* kargs[] = {&pg};
+  // the sample of the keys, the sub-slabs made from it
+  // (few blocks: every block ends with one global add per bin -- 3 900 blocks met on the 196 counters for 180 us)
+  const uint64_t sampled_tiles = ko->total_rows / (256ull * (16 / g.width)) / pg.sample_stride + 1;
+  const unsigned g0 = static_cast<unsigned>(std::min<uint64_t>((sampled_tiles + 3) / 4, static_cast<uint64_t>(props->num_cu)));
+  HDK_HIP_CHECK(hipLaunchKernel(bhm_sample_kernel(g), dim3(g0), dim3(256), kargs, 0, s));
+  HDK_HIP_CHECK(hipLaunchKernel(reinterpret_cast<const void*>(hdk_bhm_part_layout<0>), dim3(1), dim3(kPbMaxBins), kargs, 0, s));
   HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kBhmPartBlock), kargs, scatter_lds, s));
   const void* ak = bhm_aggregate_kernel(a, g, static_cast<int>(pg.tw));
   if (a.lds_bytes > (48u << 10)) {

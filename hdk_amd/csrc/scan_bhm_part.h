@@ -32,6 +32,14 @@ constexpr int bhm_part_vr(int w) { return w == 8 ? 8 : 16; }
 constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kBhmPartBlock) * bhm_part_vr(w) * 5 + 16; }  // uint32 staging | uint8 bin of every slot
 constexpr int kBhmAggBlock = 256;
 
+// words of BhmPartArgs::layout
+constexpr uint32_t kBlHist = 0;       // [kPbMaxBins] sampled rows per bin
+constexpr uint32_t kBlSampled = 256;  // sampled rows
+constexpr uint32_t kBlCap = 512;      // [kPbMaxBins] tuples of a sub-slab of the bin (a multiple of 8)
+constexpr uint32_t kBlOff = 768;      // [kPbMaxBins] where it starts inside an XCD's region
+constexpr uint32_t kBlRegion = 1024;  // tuples of one XCD's region
+constexpr uint32_t kBlWords = 1032;
+
 struct BhmPartArgs {
   BhmArgs b;               // columns, statistics, argument descriptors; the LDS geometry of pass B (entries = 2^w)
   uint32_t w;              // bits of a tuple's entry inside its bin
@@ -40,10 +48,149 @@ struct BhmPartArgs {
   uint32_t tw;             // bytes of a tuple: 2 when entry and codes fit 16 bits (BH005 / PHS005: 9 + 4), else 4
   uint32_t cshift[kBhmMaxSrc];  // position of argument column s's code in the tuple
   uint32_t cmask[kBhmMaxSrc];
-  uint64_t cap;            // tuples of a (bin, XCD) sub-slab (a multiple of 8: sub-slabs start 16-byte aligned)
-  uint32_t* tuples;        // [kPbXcds][nbins][cap] tuples of `tw` bytes (+ one batch of slack behind the last)
+  uint64_t cap_limit;      // most tuples a (bin, XCD) sub-slab may hold (pass B's packed fields: rows in 24 bits, sums in 40)
+  uint64_t region_max;     // tuples of one XCD's region the allocation has room for
+  uint64_t total_rows;     // the launch's row bound
+  uint32_t* tuples;        // [kPbXcds] regions of `region` tuples of `tw` bytes (+ one batch of slack behind the last): sub-slab
+                           // (x, bin) starts at layout[kBlOff + bin] of region x and holds layout[kBlCap + bin] tuples
   uint32_t* fill;          // [kPbXcds][nbins] x kPbCursorStride
+  uint32_t* layout;        // kBl* words: what the sample saw and the sub-slabs made from it (hdk_bhm_part_sample / _layout)
+  uint32_t sample_stride;  // every sample_stride-th tile of 16-byte steps is looked at
+  uint32_t pad2_;
 };
+
+// ---- the sub-slabs are sized from a SAMPLE of the keys ----------------------------------------------------------------------------
+// Sub-slabs of one size for every bin (twice the even share) made any uneven bin a fallback: 2 % of NULL keys -- one entry, one
+// bin -- sent MSPHS003 from 1.3 ms to 1 270 ms per 256 M rows through the armed global-atomics launch.  Now every
+// sample_stride-th tile's keys are binned first (a few per cent of one column's bytes), and a bin's sub-slabs hold twice what
+// the sample promises (+ 4 096).  What the sample did not see still overflows into the flag and the fallback.
+template <int NK, int W>
+HDK_DEV uint32_t bhm_part_sample_bin(const BhmPartArgs& g, const uint32_t (&kr)[NK][4], int i, bool nulls) {
+  const BhmArgs& a = g.b;
+  uint32_t idx = 0;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const BhmKey& key = a.key[kk];
+    bool wide;
+    const int32_t kv = bhm_narrow<W>(kr[kk], i, wide);
+    uint32_t d = min(static_cast<uint32_t>(kv) - static_cast<uint32_t>(key.min), key.n - 1u);
+    if (nulls && key.nullable != 0 && kv == key.null32) {
+      d = key.null_d;
+    }
+    idx += NK == 1 ? d : __umul24(d, key.stride);
+  }
+  return min(idx >> g.w, g.nbins - 1u);
+}
+
+template <int NK, int W>
+__global__ __launch_bounds__(256) void hdk_bhm_part_sample(BhmPartArgs g) {
+  constexpr int R = 16 / W;
+  constexpr int64_t kTile = 256 * R;
+  const BhmArgs& a = g.b;
+  __shared__ uint32_t s_hist[kPbMaxBins];
+  const int tid = threadIdx.x;
+  s_hist[tid] = 0;
+  __syncthreads();
+  const uint64_t nfrag = *a.kp.num_fragments;
+  const uint32_t ntab = *a.kp.num_tables;
+  const bool nulls = a.any_nullable != 0;
+  const int64_t stride = g.sample_stride;
+  uint32_t seen = 0;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * stride;
+  int64_t frag_tile_begin = 0;
+  for (uint64_t f = 0; f < nfrag; ++f) {
+    const int64_t ntiles = a.kp.num_rows[f * ntab] / kTile;  // (full tiles only)
+    const int8_t* const* cols = a.kp.col_buffers[f];
+    // four sampled tiles at a time: their loads go out together (a tile at a time the kernel was a chain of load -> LDS adds)
+    while (tile < frag_tile_begin + ntiles) {
+      uint32_t kr[4][NK][4];
+      bool have[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t t = tile + j * static_cast<int64_t>(gridDim.x) * stride;
+        have[j] = t < frag_tile_begin + ntiles;
+        if (have[j]) {
+          const int64_t r = (t - frag_tile_begin) * kTile + static_cast<int64_t>(tid) * R;
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            load_bytes<16, false>((gcol_t)cols[a.key[kk].buf_idx] + r * W, kr[j][kk]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (have[j]) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            atomicAdd(&s_hist[bhm_part_sample_bin<NK, W>(g, kr[j], i, nulls)], 1u);
+          }
+          seen += R;
+          tile += static_cast<int64_t>(gridDim.x) * stride;
+        }
+      }
+    }
+    frag_tile_begin += ntiles;
+  }
+  __syncthreads();
+  if (s_hist[tid]) {
+    atomicAdd(g.layout + kBlHist + tid, s_hist[tid]);
+  }
+  if (seen) {
+    atomicAdd(g.layout + kBlSampled, seen);
+  }
+}
+
+// one block: the bins' sub-slab sizes and starts from the sample
+template <int DUMMY = 0>
+__global__ __launch_bounds__(kPbMaxBins) void hdk_bhm_part_layout(BhmPartArgs g) {
+  __shared__ uint64_t s_scan[kPbMaxBins];
+  __shared__ uint32_t s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_bad = 0;
+  }
+  __syncthreads();
+  const uint32_t sampled = g.layout[kBlSampled];
+  const uint64_t even = g.total_rows / g.nbins;
+  uint64_t est = 0;
+  if (static_cast<uint32_t>(tid) < g.nbins) {
+    // (too small a sample -- short fragments -- says nothing: the even share then)
+    est = sampled >= 64u * g.nbins ? static_cast<uint64_t>(static_cast<double>(g.layout[kBlHist + tid]) * static_cast<double>(g.total_rows) /
+                                                           static_cast<double>(sampled))
+                                   : even;
+  }
+  uint64_t cap = static_cast<uint32_t>(tid) < g.nbins ? ((est / kPbXcds) * 2 + 4096 + 7) & ~7ull : 0;
+  if (cap > g.cap_limit) {
+    s_bad = 1;  // a bin beyond what one pass-B block's packed fields hold (a very hot key): the fallback
+    cap = g.cap_limit & ~7ull;
+  }
+  s_scan[tid] = cap;
+  __syncthreads();
+  for (int d = 1; d < kPbMaxBins; d <<= 1) {
+    const uint64_t v = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  uint64_t region = s_scan[kPbMaxBins - 1];
+  uint64_t off = s_scan[tid] - cap;
+  if (region > g.region_max) {  // (a sample that promises more rows than the launch's bound by a quarter: not with honest inputs)
+    s_bad = 1;
+    cap = (g.region_max / g.nbins) & ~7ull;
+    off = static_cast<uint64_t>(tid) * cap;
+    region = static_cast<uint64_t>(g.nbins) * cap;
+  }
+  g.layout[kBlCap + tid] = static_cast<uint32_t>(tid) < g.nbins ? static_cast<uint32_t>(cap) : 0u;
+  g.layout[kBlOff + tid] = static_cast<uint32_t>(off);
+  __syncthreads();
+  if (tid == 0) {
+    g.layout[kBlRegion] = static_cast<uint32_t>(region);
+    g.layout[kBlRegion + 1] = static_cast<uint32_t>(region >> 32);
+    if (s_bad) {
+      atomicOr(g.b.flag, 1u);
+    }
+  }
+}
 
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------
 // R = 16 / W consecutive rows of one lane (one 16-byte step of every streamed column) -> their tuples and bins.  FULL: the
@@ -173,8 +320,14 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
   for (int i = tid; i <= kPbMaxBins; i += kBhmPartBlock) {
     s_cnt[i] = 0;
   }
-  // this block's tuples go to its XCD's part of the slab: [xcd][bin][cap] -- positions inside it fit 32 bits
-  uint8_t* const xcd_tuples = reinterpret_cast<uint8_t*>(g.tuples) + static_cast<size_t>(xcd) * g.nbins * g.cap * g.tw;
+  // this block's tuples go to its XCD's region of the slab -- positions inside it fit 32 bits
+  const uint64_t region = (static_cast<uint64_t>(g.layout[kBlRegion + 1]) << 32) | g.layout[kBlRegion];
+  uint8_t* const xcd_tuples = reinterpret_cast<uint8_t*>(g.tuples) + static_cast<size_t>(xcd) * region * g.tw;
+  uint32_t my_cap = 0, my_off = 0;  // of the bin this thread claims for
+  if (tid < kPbMaxBins) {
+    my_cap = g.layout[kBlCap + tid];
+    my_off = g.layout[kBlOff + tid];
+  }
   __syncthreads();
   const uint64_t nfrag = *a.kp.num_fragments;
   const uint32_t ntab = *a.kp.num_tables;
@@ -351,11 +504,11 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
         // a claim that does not fit its sub-slab (a hot key) raises the flag -- the launch is redone by the armed fallback -- and
         // is clamped to the sub-slab's end: its tuples spill over the next sub-slab's first ones (or the slack behind the last)
         uint32_t base = claim_base;
-        if (claim_n && static_cast<uint64_t>(claim_base) + claim_n > g.cap) {
+        if (claim_n && static_cast<uint64_t>(claim_base) + claim_n > my_cap) {
           stale = 1;
-          base = static_cast<uint32_t>(min(static_cast<uint64_t>(claim_base), g.cap));
+          base = min(claim_base, my_cap);
         }
-        s_delta[tid] = static_cast<uint32_t>(static_cast<uint64_t>(tid) * g.cap) + base - s_x[tid];
+        s_delta[tid] = my_off + base - s_x[tid];
         s_cnt[tid] = 0;
       }
       if (tid == 0) {
@@ -414,8 +567,9 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   uint8_t* rp = lds8 + static_cast<size_t>(tid & (a.rep - 1)) * a.rep_bytes;
   const uint32_t bin = blockIdx.x / kPbXcds, x = blockIdx.x % kPbXcds;
   const size_t sub = static_cast<size_t>(x) * g.nbins + bin;  // ([xcd][bin][cap])
-  const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(g.fill[sub * kPbCursorStride]), g.cap));
-  const uint8_t* t = reinterpret_cast<const uint8_t*>(g.tuples) + sub * g.cap * TW;
+  const uint32_t n = min(g.fill[sub * kPbCursorStride], g.layout[kBlCap + bin]);
+  const uint64_t region = (static_cast<uint64_t>(g.layout[kBlRegion + 1]) << 32) | g.layout[kBlRegion];
+  const uint8_t* t = reinterpret_cast<const uint8_t*>(g.tuples) + (static_cast<size_t>(x) * region + g.layout[kBlOff + bin]) * TW;
   const uint32_t wmask = (1u << g.w) - 1u;
   const uint32_t dummy = a.entries;  // (= 2^w: the entry behind the bin's table)
   const bool nulls = C::nulls(a);

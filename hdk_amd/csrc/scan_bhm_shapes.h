@@ -53,19 +53,26 @@ constexpr uint32_t kN = kBhmNone;
 // scan_bhm_w8.hip <8, false>, scan_bhm_w8q.hip <8, true>.  shape_index: the row of HDK_BHM_SHAPES.
 template <int W, bool Q>
 struct BhmKernels {
-  static const void* fixed(int shape_index, int block);     // BhmStatic
-  static const void* dynamic(int nk, int ns, int block);    // BhmDynamic
-  static const void* scatter(int nk, int ns);               // pass A of the two-pass form
+  static const void* fixed(int shape_index, int block, bool nulls);  // BhmStatic (nullptr: no such instantiation)
+  static const void* dynamic(int nk, int ns, int block);             // BhmDynamic
+  static const void* scatter(int nk, int ns);                        // pass A of the two-pass form
 };
-#define HDK_BHM_SHAPE_FN(NK, NS, D0, D1, D2, D3) [](int b) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3>, NK, NS, kW, kQ>(b); },
-#define HDK_BHM_DEFINE_KERNELS(W_, Q_)                                                                                         \
+// (the NULL-carrying twins of the compile-time shapes exist for the unfiltered quarters: NULLS_TOO)
+#define HDK_BHM_SHAPE_FN(NK, NS, D0, D1, D2, D3) [](int b) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3, false>, NK, NS, kW, kQ>(b); },
+#define HDK_BHM_SHAPE_FN_NULLS(NK, NS, D0, D1, D2, D3) [](int b) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3, true>, NK, NS, kW, kQ>(b); },
+#define HDK_BHM_SHAPE_FN_NONE(NK, NS, D0, D1, D2, D3) nullptr,
+#define HDK_BHM_DEFINE_KERNELS(W_, Q_, NULLS_FN)                                                                               \
   template <>                                                                                                                  \
-  const void* BhmKernels<W_, Q_>::fixed(int shape_index, int block) {                                                          \
+  const void* BhmKernels<W_, Q_>::fixed(int shape_index, int block, bool nulls) {                                              \
     using Fn = const void* (*)(int);                                                                                           \
     constexpr int kW = W_;                                                                                                     \
     constexpr bool kQ = Q_;                                                                                                    \
     static const Fn kTable[] = {HDK_BHM_SHAPES(HDK_BHM_SHAPE_FN)};                                                             \
-    return kTable[shape_index](block);                                                                                         \
+    static const Fn kNulls[] = {HDK_BHM_SHAPES(NULLS_FN)};                                                                     \
+    const Fn fn = nulls ? kNulls[shape_index] : kTable[shape_index];                                                           \
+    (void)kW;                                                                                                                  \
+    (void)kQ;                                                                                                                  \
+    return fn ? fn(block) : nullptr;                                                                                           \
   }                                                                                                                            \
   template <>                                                                                                                  \
   const void* BhmKernels<W_, Q_>::dynamic(int nk, int ns, int block) {                                                         \
@@ -75,16 +82,16 @@ struct BhmKernels {
   const void* BhmKernels<W_, Q_>::scatter(int nk, int ns) {                                                                    \
     return nk == 1 ? bhm_scatter_nk<1, W_, Q_>(ns) : (nk == 2 ? bhm_scatter_nk<2, W_, Q_>(ns) : bhm_scatter_nk<3, W_, Q_>(ns)); \
   }
-template <> const void* BhmKernels<4, false>::fixed(int, int);
+template <> const void* BhmKernels<4, false>::fixed(int, int, bool);
 template <> const void* BhmKernels<4, false>::dynamic(int, int, int);
 template <> const void* BhmKernels<4, false>::scatter(int, int);
-template <> const void* BhmKernels<4, true>::fixed(int, int);
+template <> const void* BhmKernels<4, true>::fixed(int, int, bool);
 template <> const void* BhmKernels<4, true>::dynamic(int, int, int);
 template <> const void* BhmKernels<4, true>::scatter(int, int);
-template <> const void* BhmKernels<8, false>::fixed(int, int);
+template <> const void* BhmKernels<8, false>::fixed(int, int, bool);
 template <> const void* BhmKernels<8, false>::dynamic(int, int, int);
 template <> const void* BhmKernels<8, false>::scatter(int, int);
-template <> const void* BhmKernels<8, true>::fixed(int, int);
+template <> const void* BhmKernels<8, true>::fixed(int, int, bool);
 template <> const void* BhmKernels<8, true>::dynamic(int, int, int);
 template <> const void* BhmKernels<8, true>::scatter(int, int);
 

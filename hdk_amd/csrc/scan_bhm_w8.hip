@@ -5,6 +5,6 @@
 
 namespace hdk {
 
-HDK_BHM_DEFINE_KERNELS(8, false)
+HDK_BHM_DEFINE_KERNELS(8, false, HDK_BHM_SHAPE_FN_NULLS)
 
 }  // namespace hdk

@@ -13,8 +13,10 @@ namespace hdk {
   X(BH_PARTITIONS_ALWAYS)           \
   X(BHM_BLOCKS_PER_CU)              \
   X(BHM_DYNAMIC)                    \
+  X(BHM_FLAG_IS_ERROR)              \
   X(BHM_PART_MIN_BINS)              \
   X(BHM_PART_REPLICAS)              \
+  X(BHM_PART_SAMPLE_STRIDE)         \
   X(BHM_WIDE_TUPLES)                \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \

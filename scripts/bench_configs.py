@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--null-frac", type=float, default=0.0, help="NULLs in every column of the synthetic suite's table (nga*, msbs*, msphs*, phm*)")
     ap.add_argument("--flags", type=int, default=0, help="extra HDK_HIP_LAUNCH_* flags")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -129,7 +130,7 @@ def main():
                     if hasattr(x, attr) and getattr(x, attr) is not None and not isinstance(getattr(x, attr), (int, float, str)):
                         stack.append(getattr(x, attr))
     if want2:
-        st.import_numpy("syn2", SQ.syn_table(rng, n, sorted(cols2)), fragment_size=frag)
+        st.import_numpy("syn2", SQ.syn_table(rng, n, sorted(cols2), null_frac=args.null_frac), fragment_size=frag)
     ex = Executor(st, 0)
     ex.fuse_join_tables = not args.no_fuse
 
