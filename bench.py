@@ -972,7 +972,7 @@ def main():
     del w
     extra = args.extra
     if extra == "auto":
-        extra = "c3,c3g,c3gm,c3m,bh1,bh3,bh4,bh5,nga2,msbs1,msphs1,phm2,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
+        extra = "c3,c3g,c3gm,c3m,bh1,bh3,bh4,bh5,nga2,msbs1,msphs1,msphs1w,msphs1f,phm2,c5,c5s,q1,q2,q3,q4" if (comm.world == 1 and args.config == "c2" and not args.rows) else ""
     if extra == "none":
         extra = ""
     configs = []

@@ -126,6 +126,9 @@ struct BhmArgs {
                            // in-band NULL is mapped to INT32_MIN: key / src `null32` say INT32_MIN then)
   int64_t key_null_word;   // key word of the NULL key's entry
   // plain filters `column cmp literal` / AND-OR-NOT programs over them (plain_quals.h): the kernels' Q instantiations
+  // pass B of the two-pass form works on the tuples' CODES (value - min + 1): the sum of a plain column's codes is turned into
+  // the sum of its values when the table is decoded (+= non-NULL rows x psum_k)
+  int32_t psum_k[kBhmMaxDer];
   int32_t nquals;
   int32_t qvec;            // every filter column is an integer column of the streamed width: loaded 16 bytes a lane with the tile
   ProjFastQual q[kMaxPlainQuals];
@@ -280,7 +283,7 @@ HDK_DEV uint32_t bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[N
   return badm;
 }
 
-template <class C, int NS, int NR, bool Q = false>
+template <class C, int NS, int NR, bool Q = false, bool CODED = false>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]);
 
 // NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s; okm: rows that take part (a ragged tile's
@@ -303,8 +306,12 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
   bhm_update<C, NS, NR, Q>(a, rp, a.entries, e, x, live);
 }
 
-// the LDS updates of NR rows whose entries are known (e[j]; `dummy` for rows that do not take part)
-template <class C, int NS, int NR, bool Q>
+// the LDS updates of NR rows whose entries are known (e[j]; `dummy` for rows that do not take part).
+// CODED (pass B of the two-pass form): x holds the tuples' codes (value - min + 1, inside the statistics by construction) -- a
+// plain column's MAX field code IS that code, its MIN code one subtraction away (der.mn.bias = span + 2 there), no masks, no
+// sign; `column op literal` arguments get their value from the code (der.add shifted by the host).  Pass B was bound by vector
+// instructions (28 a row, SQ_ACTIVE_INST_VALU 78 % of the cycles), not by LDS atomics.
+template <class C, int NS, int NR, bool Q, bool CODED>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]) {
   const bool nulls = C::nulls(a);
   constexpr bool skips = C::kSkips || Q;  // rows that take no part exist
@@ -337,6 +344,7 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
         const int st = C::step(a, i);
         v[j] = st == 0 ? raw : (st == 1 ? raw + der.add : __mul24(raw, der.mul) + der.add);
       }
+      const bool plain_code = CODED && C::step(a, i) == 0;
       if (C::packed(a, i)) {
         unsigned long long* pk = reinterpret_cast<unsigned long long*>(rp) + static_cast<uint32_t>(der.packed) * a.e1;
 #pragma unroll
@@ -345,17 +353,22 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
           // dummy entry would serialise -- 30 % of the rows dropped: 5.2 ms per 1 B rows with the adds, X without)
           const uint32_t ej = nulls ? (lv[j] ? e[j] : dummy) : e[j];
           if (!skips || ej != dummy) {
-            atomicAdd(pk + ej, (1ull << kBhmSumBits) + static_cast<unsigned long long>(static_cast<long long>(v[j])));
+            atomicAdd(pk + ej, (1ull << kBhmSumBits) + (plain_code ? static_cast<unsigned long long>(static_cast<uint32_t>(v[j]))
+                                                                   : static_cast<unsigned long long>(static_cast<long long>(v[j]))));
           }
         }
       }
       if (C::mx(a, i)) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          const uint32_t code = static_cast<uint32_t>(v[j] - der.mx.bias);
+          const uint32_t code = plain_code ? static_cast<uint32_t>(v[j]) : static_cast<uint32_t>(v[j] - der.mx.bias);
           const uint32_t c = nulls ? (lv[j] ? code : 0u) : code;
-          cand_lo[j] |= (c & der.mx.mask_lo) << der.mx.shift;
-          if (mmb == 8) cand_hi[j] |= (c & der.mx.mask_hi) << der.mx.shift;
+          if (plain_code && mmb != 8) {
+            cand_lo[j] |= c << der.mx.shift;
+          } else {
+            cand_lo[j] |= (c & der.mx.mask_lo) << der.mx.shift;
+            if (mmb == 8) cand_hi[j] |= (c & der.mx.mask_hi) << der.mx.shift;
+          }
         }
       }
       if (C::mn(a, i)) {
@@ -363,8 +376,12 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
         for (int j = 0; j < NR; ++j) {
           const uint32_t code = static_cast<uint32_t>(der.mn.bias - v[j]);
           const uint32_t c = nulls ? (lv[j] ? code : 0u) : code;
-          cand_lo[j] |= (c & der.mn.mask_lo) << der.mn.shift;
-          if (mmb == 8) cand_hi[j] |= (c & der.mn.mask_hi) << der.mn.shift;
+          if (plain_code && mmb != 8) {
+            cand_lo[j] |= c << der.mn.shift;
+          } else {
+            cand_lo[j] |= (c & der.mn.mask_lo) << der.mn.shift;
+            if (mmb == 8) cand_hi[j] |= (c & der.mn.mask_hi) << der.mn.shift;
+          }
         }
       }
     }
@@ -467,6 +484,10 @@ HDK_DEV void bhm_slab_entry(const BhmArgs& a, const uint8_t* lds8, uint32_t ei, 
     if (a.rows_packed < 0) {
       rows += reinterpret_cast<const uint32_t*>(rp + a.off_rows)[ei];
     }
+  }
+#pragma unroll
+  for (int pi = 0; pi < kBhmMaxDer; ++pi) {
+    psum[pi] += pcnt[pi] * a.psum_k[pi];  // (0 except in pass B of the two-pass form)
   }
   for (int w = 0; w < a.wpe; ++w) {
     const BhmSlabWord sw = a.sw[w];

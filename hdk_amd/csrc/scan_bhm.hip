@@ -599,7 +599,7 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   const void* sk = bhm_scatter_kernel(a, g);
   const size_t scatter_lds = bhm_scatter_lds(g.width);
   HDK_HIP_CHECK(hipFuncSetAttribute(sk, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatter_lds)));
-  const unsigned g1 = scatter_grid(sk, kBhmPartBlock, scatter_lds, props, 1024 / kBhmPartBlock);
+  const unsigned g1 = scatter_grid(sk, kBhmPartBlock, scatter_lds, props, kBhmPartWaves * 256 / kBhmPartBlock);
   void* kargs[] = {&pg};
   // the sample of the keys, the sub-slabs made from it
   // (few blocks: every block ends with one global add per bin -- 3 900 blocks met on the 196 counters for 180 us)
@@ -609,10 +609,24 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   HDK_HIP_CHECK(hipLaunchKernel(reinterpret_cast<const void*>(hdk_bhm_part_layout<0>), dim3(1), dim3(kPbMaxBins), kargs, 0, s));
   HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kBhmPartBlock), kargs, scatter_lds, s));
   const void* ak = bhm_aggregate_kernel(a, g, static_cast<int>(pg.tw));
+  // pass B reads CODES (value - min + 1) out of the tuples: its own copy of the descriptors, shifted to them (bhm_update<CODED>)
+  BhmPartArgs pgb = pg;
+  for (int d = 0; d < pgb.b.nder; ++d) {
+    BhmDer& der = pgb.b.der[d];
+    const BhmSrc& src = pgb.b.src[der.src];
+    if (der.mul == 1 && der.add == 0) {
+      der.mx.bias = 0;                                         // (MAX code = the tuple's code)
+      der.mn.bias = static_cast<int32_t>(src.raw_span) + 2;    // (MIN code = span + 2 - code)
+      if (der.packed >= 0) pgb.b.psum_k[der.packed] = src.raw_min - 1;  // (sum of values = sum of codes + rows x (min - 1))
+    } else {
+      der.add = static_cast<int32_t>(der.add + (static_cast<int64_t>(src.raw_min) - 1) * der.mul);  // (value = (code + min - 1) x mul + add)
+    }
+  }
+  void* kargs_b[] = {&pgb};
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
   }
-  HDK_HIP_CHECK(hipLaunchKernel(ak, dim3(pg.nbins * kPbXcds), dim3(kBhmAggBlock), kargs, a.lds_bytes, s));
+  HDK_HIP_CHECK(hipLaunchKernel(ak, dim3(pg.nbins * kPbXcds), dim3(kBhmAggBlock), kargs_b, a.lds_bytes, s));
   // the eight slabs -> one (a thread per word, coalesced), then the fold with a thread per entry: folding the eight directly
   // took 110 - 135 us for 100 K entries (88 strided words per thread)
   BhmReduceArgs r;

@@ -28,8 +28,15 @@ namespace hdk {
 #endif
 constexpr int kBhmPartBlock = HDK_BHM_PART_BLOCK;  // pass A's block (A/B builds: -DHDK_BHM_PART_BLOCK=256)
 // rows per lane and batch of pass A: 16 over 4-byte columns (8 192 rows a batch), 8 over 8-byte ones (their loads take twice the registers)
-constexpr int bhm_part_vr(int w) { return w == 8 ? 8 : 16; }
-constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kBhmPartBlock) * bhm_part_vr(w) * 5 + 16; }  // uint32 staging | uint8 bin of every slot
+#ifndef HDK_BHM_PART_VR
+#define HDK_BHM_PART_VR 16
+#endif
+#ifndef HDK_BHM_PART_WAVES
+#define HDK_BHM_PART_WAVES 4  // waves per SIMD the register budget is held to (A/B builds: -DHDK_BHM_PART_VR=8 -DHDK_BHM_PART_WAVES=6)
+#endif
+constexpr int kBhmPartWaves = HDK_BHM_PART_WAVES;
+constexpr int bhm_part_vr(int w) { return w == 8 ? 8 : HDK_BHM_PART_VR; }
+constexpr size_t bhm_scatter_lds(int w) { return static_cast<size_t>(kBhmPartBlock) * bhm_part_vr(w) * 8; }  // {tuple, place} of every row of a batch
 constexpr int kBhmAggBlock = 256;
 
 // words of BhmPartArgs::layout
@@ -298,7 +305,7 @@ HDK_DEV void bhm_part_rows(const BhmPartArgs& g, const int8_t* const* cols, cons
 }
 
 template <int NK, int NS, int W = 4, bool Q = false>
-__global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void hdk_bhm_scatter(BhmPartArgs g) {
+__global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(kBhmPartWaves, kBhmPartWaves))) void hdk_bhm_scatter(BhmPartArgs g) {
   constexpr int VR = bhm_part_vr(W);
   constexpr int kBhmPartTile = kBhmPartBlock * VR;
   constexpr int R = 16 / W, U = VR / R;
@@ -309,12 +316,9 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
   // loops carry no `if (live)` (the compiler kept 16 lane masks in scalar registers and spilled them: 258 v_readlane /
   // v_writelane and 111 branches in a kernel that is bound by instruction issue)
   __shared__ uint32_t s_cnt[kPbMaxBins + 1];
-  __shared__ uint32_t s_x[kPbMaxBins + 1];
-  __shared__ uint32_t s_delta[kPbMaxBins];
+  __shared__ uint2 s_pair[kPbMaxBins + 1];  // {start of the bin's run in the staging area, place of the run's first tuple}
   __shared__ int32_t s_watch;
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn32[];
-  uint32_t* s_stage = s_dyn32;
-  uint8_t* s_binof = reinterpret_cast<uint8_t*>(s_dyn32 + kBhmPartTile);
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn32[];  // the staging area: {tuple, place} per row of the batch
   const int tid = threadIdx.x;
   const uint32_t xcd = static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (kPbXcds - 1);
   for (int i = tid; i <= kPbMaxBins; i += kBhmPartBlock) {
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
       }
       const int64_t row0 = (tile - frag_tile_begin) * kBhmPartTile;
       const bool full = row0 + kBhmPartTile <= nrows;
-      uint32_t tup[VR], bin4[VR];  // bin4: byte offset of the row's bin in s_cnt / s_x (the dead bin: 4 * kPbMaxBins)
+      uint32_t tup[VR], bin4[VR];  // bin4: byte offset of the row's bin in s_cnt (the dead bin: 4 * kPbMaxBins)
       // (issuing the NEXT tile's loads here, before the batch's LDS work, measured worse: 2.43 -> 2.49 ms per 1 B rows for BH005,
       // 1.31 -> 1.47 ms per 256 M for MSBS002 -- the second register set spills)
       uint32_t kr[U][NK][4], xr[U][NS][4], qr[Q ? U : 1][kMaxPlainQuals][4];
@@ -445,7 +449,10 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
       }
 #undef HDK_BHM_PART_ROWS
 #undef HDK_BHM_PART_LOAD
-      // the batch: LDS histogram by bin, one cursor claim per bin and XCD, staging ordered by bin, copy-out in runs
+      // the batch: LDS histogram by bin, one cursor claim per bin and XCD, staging ordered by bin, copy-out in runs.
+      // LDS operations per row: the histogram's add, ONE 8-byte read of its bin's {start of the run in the staging area, place of
+      // the run's first tuple behind the cursor}, ONE 8-byte staging write {tuple, place}, one 8-byte read at copy-out -- four,
+      // where separate arrays (run starts, bin of every slot, staging words, deltas) took seven
       uint32_t rank[VR];
 #pragma unroll
       for (int r = 0; r < VR; ++r) {
@@ -453,81 +460,74 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(4
         rank[r] = (!Q || bin4[r] != 4u * kPbMaxBins) ? atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(s_cnt) + bin4[r]), 1u) : 0u;
       }
       __syncthreads();
-      // one cursor claim per bin: issued here, its answer is looked at after the staging writes
-      uint32_t claim_n = 0, claim_base = 0;
       if (tid < kPbMaxBins) {
-        claim_n = s_cnt[tid];
-        if (claim_n) {
-          claim_base = atomicAdd(g.fill + (static_cast<size_t>(xcd) * g.nbins + tid) * kPbCursorStride, claim_n);
+        // a thread per bin: the claim behind the bin's cursor, and -- every wave for itself, no barrier -- the exclusive scan of
+        // the counts (its own 64 bins by shuffles, the bins of the waves before it summed from LDS)
+        const uint32_t n = s_cnt[tid];
+        uint32_t base = 0;
+        if (n) {
+          base = atomicAdd(g.fill + (static_cast<size_t>(xcd) * g.nbins + tid) * kPbCursorStride, n);
         }
-      }
-      if (tid < kWave) {  // exclusive scan of the live bins' counts; the dead run starts where they end
-        uint32_t carry = 0;
-        for (int c0 = 0; c0 < kPbMaxBins; c0 += kWave) {
-          const uint32_t n = s_cnt[c0 + tid];
-          uint32_t incl = n;
+        const int lane = tid & (kWave - 1), wv = tid / kWave;
+        uint32_t incl = n;
 #pragma unroll
-          for (int dd = 1; dd < kWave; dd <<= 1) {
-            const uint32_t v = __shfl_up(incl, dd, kWave);
-            if (tid >= dd) {
-              incl += v;
-            }
+        for (int dd = 1; dd < kWave; dd <<= 1) {
+          const uint32_t v = __shfl_up(incl, dd, kWave);
+          if (lane >= dd) {
+            incl += v;
           }
-          s_x[c0 + tid] = carry + incl - n;
-          carry += __shfl(incl, kWave - 1, kWave);
         }
-        if (tid == 0) {
-          s_x[kPbMaxBins] = carry;
+        uint32_t before = 0;
+        for (int c = 0; c < wv; ++c) {  // (wave-uniform trip count)
+          uint32_t v = s_cnt[c * kWave + lane];
+#pragma unroll
+          for (int dd = kWave / 2; dd >= 1; dd >>= 1) {
+            v += __shfl_xor(v, dd, kWave);
+          }
+          before += v;
+        }
+        const uint32_t x = before + incl - n;
+        // a claim that does not fit its sub-slab (a hot key) raises the flag -- the launch is redone by the armed fallback -- and
+        // is clamped to the sub-slab's end: its tuples spill over the next sub-slab's first ones (or the slack behind the last)
+        if (n && static_cast<uint64_t>(base) + n > my_cap) {
+          stale = 1;
+          base = min(base, my_cap);
+        }
+        s_pair[tid] = make_uint2(x, my_off + base);
+        if (tid == kPbMaxBins - 1) {
+          s_pair[kPbMaxBins] = make_uint2(x + n, 0u);  // the dead run starts where the live ones end
         }
       }
       __syncthreads();
-      if (narrow) {  // (a uniform branch around the loops, not inside them)
+      uint2* const stage = reinterpret_cast<uint2*>(s_dyn32);
 #pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          if (!Q || bin4[r] != 4u * kPbMaxBins) {
-            const uint32_t si = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_x) + bin4[r]) + rank[r];
-            s_binof[si] = static_cast<uint8_t>(bin4[r] >> 2);  // (the dead run's are never read)
-            reinterpret_cast<uint16_t*>(s_stage)[si] = static_cast<uint16_t>(tup[r]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < VR; ++r) {
-          if (!Q || bin4[r] != 4u * kPbMaxBins) {
-            const uint32_t si = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_x) + bin4[r]) + rank[r];
-            s_binof[si] = static_cast<uint8_t>(bin4[r] >> 2);
-            s_stage[si] = tup[r];
-          }
+      for (int r = 0; r < VR; ++r) {
+        if (!Q || bin4[r] != 4u * kPbMaxBins) {
+          const uint2 pr = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(s_pair) + 2u * bin4[r]);
+          stage[pr.x + rank[r]] = make_uint2(tup[r], pr.y + rank[r]);  // (the dead run's are never read)
         }
       }
       if (tid < kPbMaxBins) {
-        // a claim that does not fit its sub-slab (a hot key) raises the flag -- the launch is redone by the armed fallback -- and
-        // is clamped to the sub-slab's end: its tuples spill over the next sub-slab's first ones (or the slack behind the last)
-        uint32_t base = claim_base;
-        if (claim_n && static_cast<uint64_t>(claim_base) + claim_n > my_cap) {
-          stale = 1;
-          base = min(claim_base, my_cap);
-        }
-        s_delta[tid] = my_off + base - s_x[tid];
         s_cnt[tid] = 0;
       }
       if (tid == 0) {
         s_cnt[kPbMaxBins] = 0;
       }
       __syncthreads();
-      const uint32_t total = s_x[kPbMaxBins];
-      if (narrow) {
+      const uint32_t total = s_pair[kPbMaxBins].x;
+      if (narrow) {  // (a uniform branch around the loops, not inside them)
         for (uint32_t i = tid; i < total; i += kBhmPartBlock) {
-          const uint32_t at = s_delta[s_binof[i]] + i;
-          reinterpret_cast<uint16_t*>(xcd_tuples)[at] = reinterpret_cast<const uint16_t*>(s_stage)[i];
+          const uint2 v = stage[i];
+          reinterpret_cast<uint16_t*>(xcd_tuples)[v.y] = static_cast<uint16_t>(v.x);
         }
       } else {
         for (uint32_t i = tid; i < total; i += kBhmPartBlock) {
-          const uint32_t at = s_delta[s_binof[i]] + i;
-          reinterpret_cast<uint32_t*>(xcd_tuples)[at] = s_stage[i];
+          const uint2 v = stage[i];
+          reinterpret_cast<uint32_t*>(xcd_tuples)[v.y] = v.x;
         }
       }
-      __syncthreads();
+      // (no barrier here: the next batch touches only the counters -- zeroed before the last barrier -- until ITS first barrier,
+      // which a wave reaches after its copy-out; waves that are done start on the next tile's loads)
     }
     frag_tile_begin += ntiles;
   }
@@ -578,6 +578,29 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   constexpr int R = 4;          // rows of one bhm_update
   constexpr uint32_t kStep = kBhmAggBlock * TPV * U;
   typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
+  // FULL: every tuple of the step exists (no per-tuple bound)
+#define HDK_BHM_AGG_ROWS(FULL_)                                                                                  \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
+    const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * TPV;                            \
+    const uint32_t wd[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};                                                \
+    _Pragma("unroll") for (int h = 0; h < TPV / R; ++h) {                                                       \
+      uint32_t e[R];                                                                                            \
+      int32_t xv[NS][R];                                                                                        \
+      bool lv[NS][R];                                                                                           \
+      _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                           \
+        const int jj = h * R + j;                                                                               \
+        const uint32_t tup = TW == 2 ? (wd[jj / 2] >> (16 * (jj & 1))) & 0xFFFFu : wd[jj % 4];                  \
+        const bool in = FULL_ || (i + jj < n);                                                                  \
+        e[j] = in ? tup & wmask : dummy;                                                                        \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                        \
+          const uint32_t code = (tup >> g.cshift[s]) & g.cmask[s];                                              \
+          xv[s][j] = static_cast<int32_t>(code);                                                                \
+          lv[s][j] = nulls ? (in & (code != 0)) : true;                                                         \
+        }                                                                                                       \
+      }                                                                                                         \
+      bhm_update<C, NS, R, false, true>(a, rp, dummy, e, xv, lv);                                               \
+    }                                                                                                           \
+  }
   for (uint32_t base = 0; base < n; base += kStep) {
     const bool full = base + kStep <= n;
     u32x4_t tv[U];
@@ -604,32 +627,13 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
         tv[u].w = wd[3];
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = base + (static_cast<uint32_t>(u) * kBhmAggBlock + tid) * TPV;
-      const uint32_t wd[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
-#pragma unroll
-      for (int h = 0; h < TPV / R; ++h) {
-        uint32_t e[R];
-        int32_t xv[NS][R];
-        bool lv[NS][R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const int jj = h * R + j;
-          const uint32_t tup = TW == 2 ? (wd[jj / 2] >> (16 * (jj & 1))) & 0xFFFFu : wd[jj % 4];
-          const bool in = full | (i + jj < n);
-          e[j] = in ? tup & wmask : dummy;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const uint32_t code = (tup >> g.cshift[s]) & g.cmask[s];
-            xv[s][j] = static_cast<int32_t>(code) + (a.src[s].raw_min - 1);
-            lv[s][j] = nulls ? (in & (code != 0)) : true;
-          }
-        }
-        bhm_update<C, NS, R>(a, rp, dummy, e, xv, lv);
-      }
+    if (full) {
+      HDK_BHM_AGG_ROWS(true)
+    } else {
+      HDK_BHM_AGG_ROWS(false)
     }
   }
+#undef HDK_BHM_AGG_ROWS
   __syncthreads();
   // the block's part of slab x of the whole dense table
   const uint32_t e0 = bin << g.w;

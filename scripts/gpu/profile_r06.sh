@@ -19,7 +19,7 @@ run_pmc() {  # name, tag, counters, bench args...
 run_stats bench_default --no-live-traffic
 run_stats bench_no_e2e --no-end-to-end --no-live-traffic
 Q="--steps 5 --warmup 2 --no-cpu-baseline --no-oracle-sample --no-multi-gpu-emulation --no-end-to-end --no-live-traffic --extra none"
-for c in $([ -n "$SKIP_PMC" ] || echo ${CONFIGS:-c2 c3 c3g c3gm c3m bh1 bh3 bh4 bh5 nga2 msbs1 msphs1 phm2 c5 c5s q1 q2 q3 q4}); do
+for c in $([ -n "$SKIP_PMC" ] || echo ${CONFIGS:-c2 c3 c3g c3gm c3m bh1 bh3 bh4 bh5 nga2 msbs1 msphs1 msphs1w msphs1f phm2 c5 c5s q1 q2 q3 q4}); do
   run_pmc $c fetch "FETCH_SIZE" --config $c $Q
   run_pmc $c write "WRITE_SIZE" --config $c $Q
 done
