@@ -283,7 +283,7 @@ HDK_DEV uint32_t bhm_src_live(const BhmArgs& a, bool nulls, const int32_t (&x)[N
   return badm;
 }
 
-template <class C, int NS, int NR, bool Q = false, bool CODED = false>
+template <class C, int NS, int NR, bool Q = false>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]);
 
 // NR rows of one lane.  k[kk][j]: key column kk of row j; x[s][j]: argument column s; okm: rows that take part (a ragged tile's
@@ -303,15 +303,27 @@ HDK_DEV void bhm_rows(const BhmArgs& a, uint8_t* rp, const int32_t (&k)[NK][NR],
       e[j] = ((okm & ~badm) >> j) & 1u ? e[j] : a.entries;
     }
   }
-  bhm_update<C, NS, NR, Q>(a, rp, a.entries, e, x, live);
+  int32_t code[NS][NR];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      code[s][j] = x[s][j] - a.src[s].raw_min + 1;
+    }
+  }
+  bhm_update<C, NS, NR, Q>(a, rp, a.entries, e, code, live);
 }
 
 // the LDS updates of NR rows whose entries are known (e[j]; `dummy` for rows that do not take part).
-// CODED (pass B of the two-pass form): x holds the tuples' codes (value - min + 1, inside the statistics by construction) -- a
-// plain column's MAX field code IS that code, its MIN code one subtraction away (der.mn.bias = span + 2 there), no masks, no
-// sign; `column op literal` arguments get their value from the code (der.add shifted by the host).  Pass B was bound by vector
-// instructions (28 a row, SQ_ACTIVE_INST_VALU 78 % of the cycles), not by LDS atomics.
-template <class C, int NS, int NR, bool Q, bool CODED>
+// x holds CODES: column value - (its minimum - 1), so 1 .. span + 1 inside the statistics (the one-pass kernel subtracts once per
+// column and row, bhm_rows; pass B of the two-pass form finds them in its tuples).  The host hands the kernels descriptors
+// shifted to codes (bhm_shift_to_codes, scan_bhm.hip): for `column` and `column +- literal` arguments the MAX field code IS the
+// code, the MIN code one subtraction away (der.mn.bias = span + 2), the packed word adds the code itself (the decode adds non-NULL
+// rows x (smallest value - 1) to the sum, BhmArgs::psum_k) -- no bias subtraction, no masks, no sign extension; `column x
+// literal` arguments get their value from the code (der.add shifted).  A code outside the statistics may spill into the next
+// field: the flag is up then and the table is thrown away.  Both kernels were bound by vector instructions, not by LDS atomics
+// (pass B: 28 a row, SQ_ACTIVE_INST_VALU 78 % of the cycles; MSPHS001 in one pass: 45 a row, 67 %).
+template <class C, int NS, int NR, bool Q>
 HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uint32_t (&e)[NR], const int32_t (&x)[NS][NR], const bool (&live)[NS][NR]) {
   const bool nulls = C::nulls(a);
   constexpr bool skips = C::kSkips || Q;  // rows that take no part exist
@@ -342,9 +354,9 @@ HDK_DEV void bhm_update(const BhmArgs& a, uint8_t* rp, uint32_t dummy, const uin
           lv[j] = live[NS > 2 ? 2 : 0][j];
         }
         const int st = C::step(a, i);
-        v[j] = st == 0 ? raw : (st == 1 ? raw + der.add : __mul24(raw, der.mul) + der.add);
+        v[j] = st <= 1 ? raw : __mul24(raw, der.mul) + der.add;  // (the code; column x literal: the value)
       }
-      const bool plain_code = CODED && C::step(a, i) == 0;
+      const bool plain_code = C::step(a, i) <= 1;  // column, column +- literal: the same code
       if (C::packed(a, i)) {
         unsigned long long* pk = reinterpret_cast<unsigned long long*>(rp) + static_cast<uint32_t>(der.packed) * a.e1;
 #pragma unroll

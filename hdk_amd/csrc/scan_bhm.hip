@@ -470,6 +470,21 @@ static const void* bhm_sample_kernel_w(int nk) {
 }
 static const void* bhm_sample_kernel(const BhmGeom& g) { return g.width == 8 ? bhm_sample_kernel_w<8>(g.nk) : bhm_sample_kernel_w<4>(g.nk); }
 
+// the argument descriptors as bhm_update wants them: over codes (column value - (minimum - 1)) instead of values
+static void bhm_shift_to_codes(BhmArgs* a) {
+  for (int d = 0; d < a->nder; ++d) {
+    BhmDer& der = a->der[d];
+    const BhmSrc& src = a->src[der.src];
+    if (der.mul == 1) {  // column, column +- literal: code of the value = code of the column
+      der.mx.bias = 0;                                       // (MAX code = the code)
+      der.mn.bias = static_cast<int32_t>(src.raw_span) + 2;  // (MIN code = span + 2 - code)
+      if (der.packed >= 0) a->psum_k[der.packed] = src.raw_min + der.add - 1;  // (sum of values = sum of codes + rows x (smallest value - 1))
+    } else {
+      der.add = static_cast<int32_t>(der.add + (static_cast<int64_t>(src.raw_min) - 1) * der.mul);  // (value = (code + min - 1) x mul + add)
+    }
+  }
+}
+
 static uint32_t bhm_code_of(const BhmArgs& a, int i) {
   if (i >= a.nder) return kBhmNone;
   const BhmDer& d = a.der[i];
@@ -609,19 +624,10 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   HDK_HIP_CHECK(hipLaunchKernel(reinterpret_cast<const void*>(hdk_bhm_part_layout<0>), dim3(1), dim3(kPbMaxBins), kargs, 0, s));
   HDK_HIP_CHECK(hipLaunchKernel(sk, dim3(g1), dim3(kBhmPartBlock), kargs, scatter_lds, s));
   const void* ak = bhm_aggregate_kernel(a, g, static_cast<int>(pg.tw));
-  // pass B reads CODES (value - min + 1) out of the tuples: its own copy of the descriptors, shifted to them (bhm_update<CODED>)
+  // pass B reads CODES (value - min + 1) out of the tuples: its own copy of the descriptors, shifted to them (pass A codes the
+  // columns by their statistics and needs those as they are)
   BhmPartArgs pgb = pg;
-  for (int d = 0; d < pgb.b.nder; ++d) {
-    BhmDer& der = pgb.b.der[d];
-    const BhmSrc& src = pgb.b.src[der.src];
-    if (der.mul == 1 && der.add == 0) {
-      der.mx.bias = 0;                                         // (MAX code = the tuple's code)
-      der.mn.bias = static_cast<int32_t>(src.raw_span) + 2;    // (MIN code = span + 2 - code)
-      if (der.packed >= 0) pgb.b.psum_k[der.packed] = src.raw_min - 1;  // (sum of values = sum of codes + rows x (min - 1))
-    } else {
-      der.add = static_cast<int32_t>(der.add + (static_cast<int64_t>(src.raw_min) - 1) * der.mul);  // (value = (code + min - 1) x mul + add)
-    }
-  }
+  bhm_shift_to_codes(&pgb.b);
   void* kargs_b[] = {&pgb};
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
@@ -689,6 +695,7 @@ int32_t launch_bhm(const hdk_hip_plan* plan, const hdk_hip_plan* d_plan, const K
   a.kp = kp;
   a.flag = static_cast<uint32_t*>(scratch.p);
   a.slabs = reinterpret_cast<int64_t*>(static_cast<int8_t*>(scratch.p) + 256);
+  bhm_shift_to_codes(&a);  // (after the kernel was chosen by the arguments' forms)
   void* kargs[] = {&a};
   HDK_HIP_CHECK(hipLaunchKernel(k, dim3(grid), dim3(g.block), kargs, a.lds_bytes, s));
   const int64_t* fold_slabs = a.slabs;

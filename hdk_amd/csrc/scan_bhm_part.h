@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
           lv[s][j] = nulls ? (in & (code != 0)) : true;                                                         \
         }                                                                                                       \
       }                                                                                                         \
-      bhm_update<C, NS, R, false, true>(a, rp, dummy, e, xv, lv);                                               \
+      bhm_update<C, NS, R, false>(a, rp, dummy, e, xv, lv);                                               \
     }                                                                                                           \
   }
   for (uint32_t base = 0; base < n; base += kStep) {
