@@ -222,10 +222,13 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   a->col_width = width;
   g->width = width;
   a->qvec = a->nquals > 0;
+  bool lean = a->nquals > 0 && a->q[0].nprog == 0;
   for (int qi = 0; qi < a->nquals; ++qi) {
     const ProjFastCol& c = a->q[qi].col;
     a->qvec = a->qvec && c.kind == HDK_COL_INT && c.width == width;
+    lean = lean && a->q[qi].fp == 0 && a->q[qi].col_fp == 0;
   }
+  if (a->qvec && lean) a->qvec = 2;
   // (one key, one plain argument is scan_bh_packed.h's own shape: its one-pass kernels are asked first, launch_bh_packed; what
   // they cannot hold -- 24 bytes an entry, 4 096 entries -- may still fit here at 12: BH004 / PHS004's 10 000 groups in ONE pass)
   for (int k = 0; k < a->nkeys; ++k) a->any_nullable |= a->key[k].nullable;

@@ -236,7 +236,13 @@ HDK_DEV void bhm_part_rows(const BhmPartArgs& g, const int8_t* const* cols, cons
     ok[i] = FULL || first_row + i < nrows;
   }
   if (Q) {  // plain filters: rows that fail are not scattered
-    if (qvec) {
+    if (qvec && a.qvec == 2) {
+      const uint32_t lean = bhm_quals_lean<R, W>(a, qr);
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        ok[i] = ok[i] && ((lean >> i) & 1u) != 0;
+      }
+    } else if (qvec) {
       plain_quals_pass_with<R, true>(
           a.q, a.nquals,
           [&](int qi, const ProjFastQual&, const bool (&)[R], int64_t (&v)[R]) {
