@@ -413,9 +413,13 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   // the sub-slabs are sized on the device from a sample of the keys (hdk_bhm_part_sample / _layout): twice what the sample
   // promises a bin.  The allocation has room for a quarter more rows than the launch's bound says there are.
   const int64_t by_sum = ((1ll << 39) - 1) / amax;
-  pg->cap_limit = static_cast<uint64_t>(std::min<int64_t>(by_sum, 1ll << 23));
-  const uint64_t even_cap = ((ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds)) * 2 + 4096 + 7) & ~7ull;
-  if (even_cap > pg->cap_limit) return false;
+  // one LDS table of pass B takes a GENERATION of tuples (rows in 24 bits, sums in 40); a sub-slab with more is flushed in between
+  uint64_t generation = static_cast<uint64_t>(std::min<int64_t>(by_sum, 1ll << 23)) & ~4095ull;
+  if (const char* e = hdk_sw(SW_BHM_PART_GENERATION)) generation = static_cast<uint64_t>(std::max(1, atoi(e))) * 4096;  // (tests)
+  if (generation < 4096) return false;
+  pg->generation = static_cast<uint32_t>(generation);
+  for (int w = 0; w < a->wpe; ++w) pg->wop[w] = g->wop[w];
+  pg->cap_limit = 0xFFFFFFF0ull;
   pg->total_rows = ko->total_rows;
   pg->region_max = ((ko->total_rows / kPbXcds) * 5 / 2 + static_cast<uint64_t>(pg->nbins) * 4104 + 7) & ~7ull;
   if (pg->region_max > 0xFFFFFFF0ull) return false;

@@ -55,7 +55,7 @@ struct BhmPartArgs {
   uint32_t tw;             // bytes of a tuple: 2 when entry and codes fit 16 bits (BH005 / PHS005: 9 + 4), else 4
   uint32_t cshift[kBhmMaxSrc];  // position of argument column s's code in the tuple
   uint32_t cmask[kBhmMaxSrc];
-  uint64_t cap_limit;      // most tuples a (bin, XCD) sub-slab may hold (pass B's packed fields: rows in 24 bits, sums in 40)
+  uint64_t cap_limit;      // most tuples a (bin, XCD) sub-slab may hold (its size is a 32-bit word of the layout)
   uint64_t region_max;     // tuples of one XCD's region the allocation has room for
   uint64_t total_rows;     // the launch's row bound
   uint32_t* tuples;        // [kPbXcds] regions of `region` tuples of `tw` bytes (+ one batch of slack behind the last): sub-slab
@@ -63,7 +63,9 @@ struct BhmPartArgs {
   uint32_t* fill;          // [kPbXcds][nbins] x kPbCursorStride
   uint32_t* layout;        // kBl* words: what the sample saw and the sub-slabs made from it (hdk_bhm_part_sample / _layout)
   uint32_t sample_stride;  // every sample_stride-th tile of 16-byte steps is looked at
-  uint32_t pad2_;
+  uint32_t generation;     // tuples one LDS table of pass B may take (its packed fields: rows in 24 bits, sums in 40): a block
+                           // with more flushes its table into the slab and starts the next generation (a multiple of 4 096)
+  int32_t wop[kMaxWordsPerEntry];  // how a slab word of a later generation joins the earlier ones (agg_common.h's word_combine)
 };
 
 // ---- the sub-slabs are sized from a SAMPLE of the keys ----------------------------------------------------------------------------
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kPbMaxBins) void hdk_bhm_part_layout(BhmPartArgs g)
   }
   uint64_t cap = static_cast<uint32_t>(tid) < g.nbins ? ((est / kPbXcds) * 2 + 4096 + 7) & ~7ull : 0;
   if (cap > g.cap_limit) {
-    s_bad = 1;  // a bin beyond what one pass-B block's packed fields hold (a very hot key): the fallback
+    s_bad = 1;  // (a sub-slab's size must fit 32 bits)
     cap = g.cap_limit & ~7ull;
   }
   s_scan[tid] = cap;
@@ -607,7 +609,39 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
       bhm_update<C, NS, R, false>(a, rp, dummy, e, xv, lv);                                               \
     }                                                                                                           \
   }
+  // the block's part of slab x of the whole dense table: written when the tuples are through -- and before that whenever the
+  // table has taken a generation's worth of them (a hot key: one bin with a large share of the rows), joined word by word
+  const uint32_t e0 = bin << g.w;
+  int64_t* slab = a.slabs + static_cast<size_t>(x) * g.total_entries * a.wpe;
+  bool flushed = false;
+  auto flush = [&]() {
+    for (uint32_t ei = tid; ei < a.entries && e0 + ei < g.total_entries; ei += kBhmAggBlock) {
+      int64_t* out = slab + static_cast<size_t>(e0 + ei) * a.wpe;
+      if (!flushed) {
+        bhm_slab_entry(a, lds8, ei, out);
+      } else {
+        int64_t w[kMaxWordsPerEntry];
+        bhm_slab_entry(a, lds8, ei, w);
+        for (int k = 0; k < a.wpe; ++k) {
+          out[k] = word_combine(g.wop[k], out[k], w[k]);
+        }
+      }
+    }
+  };
+  uint32_t next_flush = g.generation;
   for (uint32_t base = 0; base < n; base += kStep) {
+    if (base >= next_flush) {  // (block-uniform)
+      __syncthreads();
+      flush();
+      flushed = true;
+      __syncthreads();
+      uint4* z = reinterpret_cast<uint4*>(lds8);
+      for (uint32_t i = tid; i < a.lds_bytes / 16; i += kBhmAggBlock) {
+        z[i] = make_uint4(0, 0, 0, 0);
+      }
+      __syncthreads();
+      next_flush += g.generation;
+    }
     const bool full = base + kStep <= n;
     u32x4_t tv[U];
 #pragma unroll
@@ -641,12 +675,7 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   }
 #undef HDK_BHM_AGG_ROWS
   __syncthreads();
-  // the block's part of slab x of the whole dense table
-  const uint32_t e0 = bin << g.w;
-  int64_t* slab = a.slabs + static_cast<size_t>(x) * g.total_entries * a.wpe;
-  for (uint32_t ei = tid; ei < a.entries && e0 + ei < g.total_entries; ei += kBhmAggBlock) {
-    bhm_slab_entry(a, lds8, ei, slab + static_cast<size_t>(e0 + ei) * a.wpe);
-  }
+  flush();
 }
 
 }  // namespace hdk

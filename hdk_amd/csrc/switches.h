@@ -14,6 +14,7 @@ namespace hdk {
   X(BHM_BLOCKS_PER_CU)              \
   X(BHM_DYNAMIC)                    \
   X(BHM_FLAG_IS_ERROR)              \
+  X(BHM_PART_GENERATION)            \
   X(BHM_PART_MIN_BINS)              \
   X(BHM_PART_REPLICAS)              \
   X(BHM_PART_SAMPLE_STRIDE)         \

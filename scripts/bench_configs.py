@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--dim-rows", type=int, default=10_000_000)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--hot-frac", type=float, default=0.0, help="this share of the rows gets ONE key in x10k / x100k (msbs2-3, msphs2-3, phm3-5)")
     ap.add_argument("--null-frac", type=float, default=0.0, help="NULLs in every column of the synthetic suite's table (nga*, msbs*, msphs*, phm*)")
     ap.add_argument("--flags", type=int, default=0, help="extra HDK_HIP_LAUNCH_* flags")
     args = ap.parse_args()
@@ -130,7 +131,12 @@ def main():
                     if hasattr(x, attr) and getattr(x, attr) is not None and not isinstance(getattr(x, attr), (int, float, str)):
                         stack.append(getattr(x, attr))
     if want2:
-        st.import_numpy("syn2", SQ.syn_table(rng, n, sorted(cols2), null_frac=args.null_frac), fragment_size=frag)
+        t2 = SQ.syn_table(rng, n, sorted(cols2), null_frac=args.null_frac)
+        if args.hot_frac > 0:  # one hot key in the big key columns
+            for c in ("x10k", "x100k"):
+                if c in t2:
+                    t2[c][rng.random(n) < args.hot_frac] = 4242
+        st.import_numpy("syn2", t2, fragment_size=frag)
     ex = Executor(st, 0)
     ex.fuse_join_tables = not args.no_fuse
 

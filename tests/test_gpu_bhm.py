@@ -186,9 +186,30 @@ def test_two_pass_form_for_tables_beyond_lds(oracle, gpu_executor_factory, monke
             _run(oracle, gpu_executor_factory, st, dataclasses.replace(q, targets=q.targets[:3]), kernel=PART)
 
 
+def test_two_pass_form_hot_key_stays_on_chip_in_generations(oracle, gpu_executor_factory, monkeypatch):
+    """70 % of the rows in ONE group: the sample gives that bin sub-slabs of its size, and pass B -- whose packed fields hold 2^23
+    rows of a table -- flushes its LDS table into the slab generation by generation (here: every 4 096 tuples, so that every
+    block does it many times and every word kind is joined: counts, sums, MIN, MAX, NULL counts).  No fallback (the hook)."""
+    monkeypatch.setenv("HDK_HIP_BH_PARTITIONS_ALWAYS", "1")
+    monkeypatch.setenv("HDK_HIP_BHM_FLAG_IS_ERROR", "1")
+    monkeypatch.setenv("HDK_HIP_BHM_PART_GENERATION", "1")
+    rng = np.random.default_rng(34)
+    n = 1_000_000
+    cols = syn_table(rng, n, ("x10", "y10", "z10", "x100", "x10k", "x100k"), null_frac=0.02)
+    cols["x10k"][rng.random(n) < 0.7] = 4242
+    cols["x100k"][rng.random(n) < 0.5] = 77_777
+    st = ArrowStorage()
+    st.import_numpy("syn", cols, fragment_size=333_334)
+    y = ColRef("y10")
+    five = QueryUnit("syn", groupby=[Cast(ColRef("x100k"), FP64)], targets=[KeyRef(0, "k")] + [Agg(kd, y, kd) for kd in ("count", "sum", "max", "min", "avg")])
+    for q in (msphs(2), msbs(2, key_type=FP64), msphs(3), five, phm(4)):
+        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+
+
 def test_two_pass_form_falls_back_on_a_hot_key_and_on_stale_statistics(oracle, gpu_executor_factory, monkeypatch):
-    """70 % of the rows in one group overflow that bin's sub-slabs (sized for twice the even share); an argument outside its
-    statistics: either way the flag is raised, the folds skip and the armed global-atomics kernel gives the oracle's result."""
+    """70 % of the rows in one group (the sample sees it: no overflow any more -- the result must be the oracle's either way); an
+    argument outside its statistics: the flag is raised, the folds skip and the armed global-atomics kernel gives the oracle's
+    result."""
     monkeypatch.setenv("HDK_HIP_BH_PARTITIONS_ALWAYS", "1")
     rng = np.random.default_rng(32)
     n = 900_000
