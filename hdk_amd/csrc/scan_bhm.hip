@@ -420,6 +420,11 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
   pg->generation = static_cast<uint32_t>(generation);
   for (int w = 0; w < a->wpe; ++w) pg->wop[w] = g->wop[w];
   pg->cap_limit = 0xFFFFFFF0ull;
+  // pass B cuts a sub-slab of more than four times the average into parts of twice the average (at least 64 K tuples)
+  pg->parts = 64;
+  const uint64_t avg = ko->total_rows / (static_cast<uint64_t>(pg->nbins) * kPbXcds) + 1;
+  pg->part_tuples = static_cast<uint32_t>(std::min<uint64_t>((std::max<uint64_t>(2 * avg, 65536) + 4095) & ~4095ull, 1u << 30));
+  if (const char* e = hdk_sw(SW_BHM_PART_TUPLES)) pg->part_tuples = static_cast<uint32_t>(std::max(1, atoi(e))) * 4096u;  // (tests)
   pg->total_rows = ko->total_rows;
   pg->region_max = ((ko->total_rows / kPbXcds) * 5 / 2 + static_cast<uint64_t>(pg->nbins) * 4104 + 7) & ~7ull;
   if (pg->region_max > 0xFFFFFFF0ull) return false;
@@ -639,7 +644,18 @@ static int32_t launch_bhm_part(const hdk_hip_plan* plan, const hdk_hip_plan* d_p
   if (a.lds_bytes > (48u << 10)) {
     HDK_HIP_CHECK(hipFuncSetAttribute(ak, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
   }
-  HDK_HIP_CHECK(hipLaunchKernel(ak, dim3(pg.nbins * kPbXcds), dim3(kBhmAggBlock), kargs_b, a.lds_bytes, s));
+  {
+    BhmSlabInitArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.slabs = a.slabs;
+    ia.words = static_cast<uint64_t>(kPbXcds) * pg.total_entries * static_cast<uint32_t>(a.wpe);
+    ia.wpe = a.wpe;
+    for (int w = 0; w < a.wpe; ++w) ia.wop[w] = g.wop[w];
+    const unsigned gi = static_cast<unsigned>(std::min<uint64_t>((ia.words + 255) / 256, static_cast<uint64_t>(props->num_cu) * 8));
+    hipLaunchKernelGGL(hdk_bhm_slab_init<0>, dim3(gi), dim3(256), 0, s, ia);
+    HDK_HIP_CHECK(hipGetLastError());
+  }
+  HDK_HIP_CHECK(hipLaunchKernel(ak, dim3(pg.nbins * kPbXcds, pg.parts), dim3(kBhmAggBlock), kargs_b, a.lds_bytes, s));
   // the eight slabs -> one (a thread per word, coalesced), then the fold with a thread per entry: folding the eight directly
   // took 110 - 135 us for 100 K entries (88 strided words per thread)
   BhmReduceArgs r;

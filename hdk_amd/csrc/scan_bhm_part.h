@@ -63,6 +63,8 @@ struct BhmPartArgs {
   uint32_t* fill;          // [kPbXcds][nbins] x kPbCursorStride
   uint32_t* layout;        // kBl* words: what the sample saw and the sub-slabs made from it (hdk_bhm_part_sample / _layout)
   uint32_t sample_stride;  // every sample_stride-th tile of 16-byte steps is looked at
+  uint32_t parts;          // pass B: blocks a (bin, XCD) sub-slab may be cut into (grid.y) ...
+  uint32_t part_tuples;    // ... when it holds more than this many tuples per part (a multiple of 4 096): a hot key's bin
   uint32_t generation;     // tuples one LDS table of pass B may take (its packed fields: rows in 24 bits, sums in 40): a block
                            // with more flushes its table into the slab and starts the next generation (a multiple of 4 096)
   int32_t wop[kMaxWordsPerEntry];  // how a slab word of a later generation joins the earlier ones (agg_common.h's word_combine)
@@ -555,6 +557,20 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(k
   }
 }
 
+// the slabs hold every word's identity before pass B (parts of a hot sub-slab join their tables with atomics)
+struct BhmSlabInitArgs {
+  int64_t* slabs;
+  uint64_t words;
+  int32_t wpe;
+  int32_t wop[kMaxWordsPerEntry];
+};
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void hdk_bhm_slab_init(BhmSlabInitArgs a) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < a.words; i += static_cast<uint64_t>(gridDim.x) * 256) {
+    a.slabs[i] = word_identity(a.wop[i % static_cast<uint32_t>(a.wpe)]);
+  }
+}
+
 // ---- pass B: one block per (bin, XCD sub-slab) -----------------------------------------------------------------------------------
 template <class C, int NS, int TW = 4>
 __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g) {
@@ -563,6 +579,24 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   const int tid = threadIdx.x;
   if (*a.flag) {
     return;  // (pass A already knows the launch is to be redone)
+  }
+  const uint32_t bin = blockIdx.x / kPbXcds, x = blockIdx.x % kPbXcds;
+  const size_t sub = static_cast<size_t>(x) * g.nbins + bin;  // ([xcd][bin][cap])
+  const uint32_t n_sub = min(g.fill[sub * kPbCursorStride], g.layout[kBlCap + bin]);
+  // A sub-slab far above the average (a hot key, a NULL key: one LDS address for a large share of the rows -- 64 lanes of a wave
+  // serialise on it) is cut into parts, one block each, which JOIN their tables into the slab with global atomics (the slab
+  // holds the words' identities then: hdk_bhm_slab_init); every other sub-slab is block 0's alone and plainly written.  One
+  // block per sub-slab took 27.5 ms per 256 M rows with half the rows in one key, 7.8 ms with 10 % NULL keys.
+  const uint32_t nparts = n_sub > 2 * static_cast<uint64_t>(g.part_tuples) ? min(g.parts, (n_sub + g.part_tuples - 1) / g.part_tuples) : 1u;
+  if (blockIdx.y >= max(nparts, 1u)) {
+    return;
+  }
+  const bool shared = nparts > 1;
+  uint32_t part_begin = 0, n = n_sub;
+  if (shared) {
+    const uint32_t chunk = (((n_sub + nparts - 1) / nparts) + 4095u) & ~4095u;
+    part_begin = min(blockIdx.y * chunk, n_sub);
+    n = min(part_begin + chunk, n_sub) - part_begin;
   }
   {
     uint4* z = reinterpret_cast<uint4*>(lds8);
@@ -573,11 +607,8 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   }
   __syncthreads();
   uint8_t* rp = lds8 + static_cast<size_t>(tid & (a.rep - 1)) * a.rep_bytes;
-  const uint32_t bin = blockIdx.x / kPbXcds, x = blockIdx.x % kPbXcds;
-  const size_t sub = static_cast<size_t>(x) * g.nbins + bin;  // ([xcd][bin][cap])
-  const uint32_t n = min(g.fill[sub * kPbCursorStride], g.layout[kBlCap + bin]);
   const uint64_t region = (static_cast<uint64_t>(g.layout[kBlRegion + 1]) << 32) | g.layout[kBlRegion];
-  const uint8_t* t = reinterpret_cast<const uint8_t*>(g.tuples) + (static_cast<size_t>(x) * region + g.layout[kBlOff + bin]) * TW;
+  const uint8_t* t = reinterpret_cast<const uint8_t*>(g.tuples) + (static_cast<size_t>(x) * region + g.layout[kBlOff + bin] + part_begin) * TW;
   const uint32_t wmask = (1u << g.w) - 1u;
   const uint32_t dummy = a.entries;  // (= 2^w: the entry behind the bin's table)
   const bool nulls = C::nulls(a);
@@ -617,7 +648,23 @@ __global__ __launch_bounds__(kBhmAggBlock) void hdk_bhm_aggregate(BhmPartArgs g)
   auto flush = [&]() {
     for (uint32_t ei = tid; ei < a.entries && e0 + ei < g.total_entries; ei += kBhmAggBlock) {
       int64_t* out = slab + static_cast<size_t>(e0 + ei) * a.wpe;
-      if (!flushed) {
+      if (shared) {
+        int64_t w[kMaxWordsPerEntry];
+        bhm_slab_entry(a, lds8, ei, w);
+        for (int k = 0; k < a.wpe; ++k) {
+          const int32_t op = g.wop[k];
+          if (w[k] == word_identity(op)) {
+            continue;  // (most entries of a hot bin's other keys in most parts: nothing to add)
+          }
+          if (op == WOP_MIN_I64) {
+            atomicMin(reinterpret_cast<long long*>(out + k), static_cast<long long>(w[k]));
+          } else if (op == WOP_MAX_I64) {
+            atomicMax(reinterpret_cast<long long*>(out + k), static_cast<long long>(w[k]));
+          } else {
+            atomicAdd(reinterpret_cast<unsigned long long*>(out + k), static_cast<unsigned long long>(w[k]));
+          }
+        }
+      } else if (!flushed) {
         bhm_slab_entry(a, lds8, ei, out);
       } else {
         int64_t w[kMaxWordsPerEntry];

@@ -18,6 +18,7 @@ namespace hdk {
   X(BHM_PART_MIN_BINS)              \
   X(BHM_PART_REPLICAS)              \
   X(BHM_PART_SAMPLE_STRIDE)         \
+  X(BHM_PART_TUPLES)                \
   X(BHM_WIDE_TUPLES)                \
   X(BUILD_PARTITION_MIN_ROWS)       \
   X(BUILD_TWO_LEVELS)               \

@@ -133,7 +133,7 @@ def main():
     if want2:
         t2 = SQ.syn_table(rng, n, sorted(cols2), null_frac=args.null_frac)
         if args.hot_frac > 0:  # one hot key in the big key columns
-            for c in ("x10k", "x100k"):
+            for c in ("x1k", "x10k", "x100k"):
                 if c in t2:
                     t2[c][rng.random(n) < args.hot_frac] = 4242
         st.import_numpy("syn2", t2, fragment_size=frag)

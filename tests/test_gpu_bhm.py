@@ -204,6 +204,14 @@ def test_two_pass_form_hot_key_stays_on_chip_in_generations(oracle, gpu_executor
     five = QueryUnit("syn", groupby=[Cast(ColRef("x100k"), FP64)], targets=[KeyRef(0, "k")] + [Agg(kd, y, kd) for kd in ("count", "sum", "max", "min", "avg")])
     for q in (msphs(2), msbs(2, key_type=FP64), msphs(3), five, phm(4)):
         _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+    # ... and the hot bin's sub-slabs cut into parts whose blocks join their tables in the slab with atomics (here: any sub-slab
+    # beyond 8 192 tuples; generations of 4 096 inside the parts, and without)
+    monkeypatch.setenv("HDK_HIP_BHM_PART_TUPLES", "1")
+    for q in (msphs(2), msbs(2, key_type=FP64), five, phm(4)):
+        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
+    monkeypatch.delenv("HDK_HIP_BHM_PART_GENERATION")
+    for q in (msphs(3), five):
+        _run(oracle, gpu_executor_factory, st, q, kernel=PART)
 
 
 def test_two_pass_form_falls_back_on_a_hot_key_and_on_stale_statistics(oracle, gpu_executor_factory, monkeypatch):
