@@ -30,6 +30,8 @@
 // than the packed fields were sized for) raise a flag instead of an exact per-row path: the folds then skip, and the
 // global-atomics kernel armed behind them redoes the launch -- never a wrong result from stale metadata, only a slower one.
 #pragma once
+#include <cstddef>
+
 #include "watch.h"
 #include "agg_common.h"
 #include "plain_quals.h"
@@ -231,24 +233,27 @@ HDK_DEV int32_t bhm_narrow(const uint32_t* regs, int i, bool& wide) {
   return isnull ? INT32_MIN : lo;
 }
 
-// A plain conjunction of `integer column cmp integer literal` over columns that rode in with the tile (BhmArgs::qvec == 2): the
-// leaves unrolled, their descriptors at constant offsets, one compare and one NULL test per row and leaf.  plain_quals.h's
+// `integer column cmp integer literal` leaves -- a plain conjunction or an AND / OR / NOT program over them -- on columns that
+// rode in with the tile (BhmArgs::qvec == 2): the leaves unrolled, their descriptors at constant offsets, one compare and one NULL test per row and leaf.  plain_quals.h's
 // general evaluator (any column type, programs, a run-time loop over the leaves with their 64-byte descriptors re-read for
 // every 16-byte step, and -- with the columns in registers -- three extracts and two selects per row to pick a leaf's column)
 // made MSPHS001 WHERE x10 < 8 run at 4.1 ms per 1 B rows, twice the unfiltered time.  Returns the rows that pass.
 template <int R, int W>
 HDK_DEV uint32_t bhm_quals_lean(const BhmArgs& a, const uint32_t (&qr)[kMaxPlainQuals][4]) {
-  uint32_t okm = (1u << R) - 1u;
+  uint32_t lt[kMaxPlainQuals], ln[kMaxPlainQuals];  // leaf qi: bit i = TRUE / NULL for row i
 #pragma unroll
   for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+    lt[qi] = 0;
+    ln[qi] = 0;
     if (qi < a.nquals) {  // (wave-uniform)
       const int64_t rhs = a.q[qi].rhs, nullv = a.q[qi].null_val;
       const bool nullable = a.q[qi].nullable != 0;
-      uint32_t m = 0;
+      uint32_t t = 0, n = 0;
 #define HDK_BHM_QROWS(OP)                                                                  \
   _Pragma("unroll") for (int i = 0; i < R; ++i) {                                         \
     const int64_t v = extract_elem<W>(qr[qi], i);                                         \
-    m |= ((v OP rhs) && !(nullable && v == nullv)) ? 1u << i : 0u;                        \
+    t |= (v OP rhs) ? 1u << i : 0u;                                                       \
+    n |= (nullable && v == nullv) ? 1u << i : 0u;                                         \
   }
       switch (a.q[qi].cmp) {
         case HDK_CMP_EQ: HDK_BHM_QROWS(==) break;
@@ -259,10 +264,51 @@ HDK_DEV uint32_t bhm_quals_lean(const BhmArgs& a, const uint32_t (&qr)[kMaxPlain
         default: HDK_BHM_QROWS(>=) break;
       }
 #undef HDK_BHM_QROWS
-      okm &= m;
+      lt[qi] = t & ~n;  // (a NULL operand: the comparison is NULL, not TRUE)
+      ln[qi] = n;
     }
   }
-  return okm;
+  const uint32_t all = (1u << R) - 1u;
+  const int nprog = a.q[0].nprog;
+  if (nprog == 0) {  // the plain conjunction
+    uint32_t okm = all;
+#pragma unroll
+    for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+      okm &= qi < a.nquals ? lt[qi] : all;
+    }
+    return okm;
+  }
+  // the filter's postfix AND / OR / NOT program over the leaves' masks (plain_quals.h's three-valued combiner: a = top, b, c)
+  // (the twelve program bytes as three kernel-argument words read once: a byte load per step is a scalar-memory round trip in
+  // every 16-byte step of every wave -- MSPHS001 under a four-step OR / NOT program ran at 5.2 ms per 1 B rows with them)
+  static_assert(kMaxPlainProg == 12 && offsetof(ProjFastQual, prog) % 4 == 0, "three aligned words");
+  const uint32_t* pw = reinterpret_cast<const uint32_t*>(a.q[0].prog);
+  const uint32_t p0 = pw[0], p1 = pw[1], p2 = pw[2];
+  uint32_t at = 0, an = 0, bt = 0, bn = 0, ct = 0, cn = 0;
+  for (int i = 0; i < nprog; ++i) {
+    const uint32_t op = ((i < 4 ? p0 : (i < 8 ? p1 : p2)) >> (8 * (i & 3))) & 0xFFu;
+    if (op < HDK_F_AND) {
+      ct = bt; cn = bn;
+      bt = at; bn = an;
+      at = op == 0 ? lt[0] : (op == 1 ? lt[1] : lt[2]);
+      an = op == 0 ? ln[0] : (op == 1 ? ln[1] : ln[2]);
+    } else if (op == HDK_F_NOT) {
+      at = ~(at | an);  // NULL stays NULL, TRUE <-> FALSE
+    } else {
+      uint32_t rt, rn;
+      if (op == HDK_F_AND) {
+        const uint32_t fa = ~(at | an), fb = ~(bt | bn);  // FALSE operands
+        rt = at & bt;
+        rn = ~(rt | fa | fb);
+      } else {
+        rt = at | bt;
+        rn = ~rt & (an | bn);
+      }
+      at = rt; an = rn;
+      bt = ct; bn = cn;
+    }
+  }
+  return at & all;
 }
 
 // the dense entry of NR rows from their key columns (dummy = the entry behind the table for a key outside the statistics);

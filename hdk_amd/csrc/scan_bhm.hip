@@ -222,7 +222,7 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
   a->col_width = width;
   g->width = width;
   a->qvec = a->nquals > 0;
-  bool lean = a->nquals > 0 && a->q[0].nprog == 0;
+  bool lean = a->nquals > 0;  // (programs too: bhm_quals_lean carries the three-valued combiner)
   for (int qi = 0; qi < a->nquals; ++qi) {
     const ProjFastCol& c = a->q[qi].col;
     a->qvec = a->qvec && c.kind == HDK_COL_INT && c.width == width;

@@ -74,3 +74,13 @@ def filtered(q, column, op, literal):
     import dataclasses
     from hdk_amd.ir import Cmp, Lit
     return dataclasses.replace(q, quals=list(q.quals) + [Cmp(ColRef(column), op, Lit(literal))])
+
+
+def filtered_or(q, first, second):
+    """`q` WHERE first OR NOT (second negated): two (column, op, literal) leaves under an OR / NOT program"""
+    import dataclasses
+    from hdk_amd.ir import Cmp, Lit, Not, Or
+    neg = {"<": ">=", "<=": ">", ">": "<=", ">=": "<", "=": "<>", "<>": "="}
+    c1 = Cmp(ColRef(first[0]), first[1], Lit(first[2]))
+    c2 = Not(Cmp(ColRef(second[0]), neg[second[1]], Lit(second[2])))
+    return dataclasses.replace(q, quals=list(q.quals) + [Or(c1, c2)])

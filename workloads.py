@@ -68,6 +68,7 @@ CONFIGS = {
                                 "two-column perfect hash"),
     "msphs1w": (1_000_000_000, 24, "MSPHS001 over BIGINT columns (an Arrow table of int64): the same kernel, narrowing in registers"),
     "msphs1f": (1_000_000_000, 12, "MSPHS001 WHERE x10 < 8 (about 70 % of the rows pass; the filter column is one of the arguments)"),
+    "msphs1o": (1_000_000_000, 12, "MSPHS001 WHERE x10 < 4 OR NOT (x100 <= 60) (an AND / OR / NOT program; 58 % of the rows pass)"),
     "c5": (1_000_000_000, 16, "C5: SELECT key, SUM(val) GROUP BY key; int64, 100 M uniform keys (open addressing)"),
     "c5s": (125_000_000, 16, "C5 per-GPU shard of 8: 125 M rows drawn from the 100 M-key domain"),
     "q1": (1_000_000_000, 4, "taxi Q1: SELECT cab_type, COUNT(*) GROUP BY cab_type"),
@@ -86,6 +87,7 @@ SYN_SUITE = {
     "phm2": lambda SQ: SQ.phm(2),
     "msphs1w": lambda SQ: SQ.msphs(1),
     "msphs1f": lambda SQ: SQ.filtered(SQ.msphs(1), "x10", "<", 8),
+    "msphs1o": lambda SQ: SQ.filtered_or(SQ.msphs(1), ("x10", "<", 4), ("x100", ">", 60)),
 }
 SYN_WIDE = ("msphs1w",)  # 8-byte columns
 
@@ -102,7 +104,13 @@ def _expr_columns(e, out):
 
 def _query_columns(q):
     out = set()
-    for e in list(q.groupby) + [t.arg for t in q.targets if getattr(t, "arg", None) is not None] + [c.lhs for c in q.quals]:
+    def leaves(c):
+        from hdk_amd.ir import Cmp
+        if isinstance(c, Cmp):
+            return [c.lhs]
+        return [x for attr in ("lhs", "rhs", "arg", "left", "right", "operand", "a", "b") if hasattr(c, attr) and getattr(c, attr) is not None
+                for x in leaves(getattr(c, attr))]
+    for e in list(q.groupby) + [t.arg for t in q.targets if getattr(t, "arg", None) is not None] + [x for c in q.quals for x in leaves(c)]:
         _expr_columns(e, out)
     return out
 
@@ -382,10 +390,19 @@ class Workload:
                 stride *= d
             if gid is None:
                 gid = torch.zeros(self.frag_rows[f], dtype=torch.int64, device=self.dev)
-            keep = None  # the suite's filters: a conjunction of `column cmp literal` over columns without NULLs
+            keep = None  # the suite's filters: `column cmp literal` leaves under AND / OR / NOT, over columns without NULLs
+
+            def cond(c):
+                from hdk_amd.ir import And, Cmp, Not, Or
+                if isinstance(c, Cmp):
+                    a, b = self._syn_eval(c.lhs, f), int(c.rhs.value)
+                    return {"<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b, "=": a == b, "<>": a != b}[c.op]
+                kids = [cond(getattr(c, attr)) for attr in vars(c) if getattr(c, attr) is not None]
+                if isinstance(c, Not):
+                    return ~kids[0]
+                return kids[0] & kids[1] if isinstance(c, And) else kids[0] | kids[1]
             for c in q.quals:
-                a, b = self._syn_eval(c.lhs, f), int(c.rhs.value)
-                m = {"<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b, "=": a == b, "<>": a != b}[c.op]
+                m = cond(c)
                 keep = m if keep is None else keep & m
             if keep is not None:
                 gid = gid[keep]
