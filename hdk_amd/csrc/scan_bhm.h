@@ -135,7 +135,12 @@ struct BhmArgs {
   int32_t qvec;            // every filter column is an integer column of the streamed width: loaded 16 bytes a lane with the tile
                            // (2: and the filter is a plain conjunction of integer comparisons -- bhm_quals_lean)
   ProjFastQual q[kMaxPlainQuals];
+  // qvec == 2: where leaf qi's column comes from -- key column kk (kk), argument column s (kBhmMaxKeys + s): already in the
+  // tile's registers; kBhmQualOwnLoad: its own 16-byte load
+  int32_t qsrc[kMaxPlainQuals];
+  int32_t pad4_;
 };
+constexpr int32_t kBhmQualOwnLoad = 255;
 
 // ---- the shape of a plan's arguments, as compile-time constants or read from the descriptors ------------------------------
 // code of argument i: bits 0-1 the column, bit 2 a packed word, bit 3 a MAX field, bit 4 a MIN field, bits 5-6 the step
@@ -238,8 +243,8 @@ HDK_DEV int32_t bhm_narrow(const uint32_t* regs, int i, bool& wide) {
 // general evaluator (any column type, programs, a run-time loop over the leaves with their 64-byte descriptors re-read for
 // every 16-byte step, and -- with the columns in registers -- three extracts and two selects per row to pick a leaf's column)
 // made MSPHS001 WHERE x10 < 8 run at 4.1 ms per 1 B rows, twice the unfiltered time.  Returns the rows that pass.
-template <int R, int W>
-HDK_DEV uint32_t bhm_quals_lean(const BhmArgs& a, const uint32_t (&qr)[kMaxPlainQuals][4]) {
+template <int R, int W, int NK, int NS>
+HDK_DEV uint32_t bhm_quals_lean(const BhmArgs& a, const uint32_t (&kr)[NK][4], const uint32_t (&xr)[NS][4], const uint32_t (&qr)[kMaxPlainQuals][4]) {
   uint32_t lt[kMaxPlainQuals], ln[kMaxPlainQuals];  // leaf qi: bit i = TRUE / NULL for row i
 #pragma unroll
   for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
@@ -248,10 +253,36 @@ HDK_DEV uint32_t bhm_quals_lean(const BhmArgs& a, const uint32_t (&qr)[kMaxPlain
     if (qi < a.nquals) {  // (wave-uniform)
       const int64_t rhs = a.q[qi].rhs, nullv = a.q[qi].null_val;
       const bool nullable = a.q[qi].nullable != 0;
+      // the leaf's column: one the tile streams anyway (a key, an argument: wave-uniform branches over the register sets), or
+      // its own load
+      int64_t val[R];
+      const int32_t from = a.qsrc[qi];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        val[i] = extract_elem<W>(qr[qi], i);
+      }
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        if (from == kk) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            val[i] = extract_elem<W>(kr[kk], i);
+          }
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        if (from == kBhmMaxKeys + s2) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            val[i] = extract_elem<W>(xr[s2], i);
+          }
+        }
+      }
       uint32_t t = 0, n = 0;
 #define HDK_BHM_QROWS(OP)                                                                  \
   _Pragma("unroll") for (int i = 0; i < R; ++i) {                                         \
-    const int64_t v = extract_elem<W>(qr[qi], i);                                         \
+    const int64_t v = val[i];                                                             \
     t |= (v OP rhs) ? 1u << i : 0u;                                                       \
     n |= (nullable && v == nullv) ? 1u << i : 0u;                                         \
   }
@@ -673,7 +704,7 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
           // the batch has landed, their latency stood alone -- 5.2 ms per 1 B rows for MSPHS001 WHERE x10 < 8, X this way
 #pragma unroll
           for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
-            if (Q && qvec && qi < a.nquals) {
+            if (Q && qvec && qi < a.nquals && (a.qvec != 2 || a.qsrc[qi] == kBhmQualOwnLoad)) {
               load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);
             }
           }
@@ -706,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void hdk_scan_agg_bhm(BhmArgs a) {
               ok[i] = true;
             }
             if (a.qvec == 2) {
-              const uint32_t lean = bhm_quals_lean<R, W>(a, qr[Q ? u : 0]);
+              const uint32_t lean = bhm_quals_lean<R, W, NK, NS>(a, kr[u], xr[u], qr[Q ? u : 0]);
 #pragma unroll
               for (int i = 0; i < R; ++i) {
                 ok[i] = ((lean >> i) & 1u) != 0;

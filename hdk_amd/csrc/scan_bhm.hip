@@ -229,6 +229,16 @@ static bool match_bhm_shape(const hdk_hip_plan* p, const hdk_hip_kernel_options*
     lean = lean && a->q[qi].fp == 0 && a->q[qi].col_fp == 0;
   }
   if (a->qvec && lean) a->qvec = 2;
+  for (int qi = 0; qi < kMaxPlainQuals; ++qi) {
+    a->qsrc[qi] = kBhmQualOwnLoad;
+    if (qi >= a->nquals) continue;
+    for (int k = 0; k < a->nkeys; ++k) {
+      if (a->key[k].buf_idx == a->q[qi].col.buf_idx) a->qsrc[qi] = k;
+    }
+    for (int s = 0; s < a->nsrc; ++s) {
+      if (a->src[s].buf_idx == a->q[qi].col.buf_idx) a->qsrc[qi] = kBhmMaxKeys + s;
+    }
+  }
   // (one key, one plain argument is scan_bh_packed.h's own shape: its one-pass kernels are asked first, launch_bh_packed; what
   // they cannot hold -- 24 bytes an entry, 4 096 entries -- may still fit here at 12: BH004 / PHS004's 10 000 groups in ONE pass)
   for (int k = 0; k < a->nkeys; ++k) a->any_nullable |= a->key[k].nullable;

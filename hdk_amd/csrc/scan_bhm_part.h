@@ -241,7 +241,7 @@ HDK_DEV void bhm_part_rows(const BhmPartArgs& g, const int8_t* const* cols, cons
   }
   if (Q) {  // plain filters: rows that fail are not scattered
     if (qvec && a.qvec == 2) {
-      const uint32_t lean = bhm_quals_lean<R, W>(a, qr);
+      const uint32_t lean = bhm_quals_lean<R, W, NK, NS>(a, kr, xr, qr);
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         ok[i] = ok[i] && ((lean >> i) & 1u) != 0;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBhmPartBlock) __attribute__((amdgpu_waves_per_eu(k
       load_bytes<16, true>(xcol[s] + r * W, xr[u][s]);                                               \
     }                                                                                                \
     _Pragma("unroll") for (int qi = 0; qi < kMaxPlainQuals; ++qi) {                                  \
-      if (Q && a.qvec != 0 && qi < a.nquals) {                                                       \
+      if (Q && a.qvec != 0 && qi < a.nquals && (a.qvec != 2 || a.qsrc[qi] == kBhmQualOwnLoad)) {     \
         load_bytes<16, true>((gcol_t)cols[a.q[qi].col.buf_idx] + r * W, qr[Q ? u : 0][qi]);          \
       }                                                                                              \
     }                                                                                                \
