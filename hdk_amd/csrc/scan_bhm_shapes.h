@@ -45,6 +45,9 @@ constexpr uint32_t kN = kBhmNone;
   /* sums (counts, averages) of two columns: MultiStep/MSBS006-007, MSPHM's SUM(x10), SUM(y10) by one key and by two          */  \
   X(1, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN)                                          \
   X(2, 2, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), kN, kN)                                          \
+  /* ... and of three columns (three measures by one key, by two)                                                            */  \
+  X(1, 3, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), bhm_code(2, true, false, false, 0), kN)          \
+  X(2, 3, bhm_code(0, true, false, false, 0), bhm_code(1, true, false, false, 0), bhm_code(2, true, false, false, 0), kN)          \
   /* sum of one column by two keys; sum of `column + literal` by one                                                          */  \
   X(2, 1, bhm_code(0, true, false, false, 0), kN, kN, kN)                                                                          \
   X(1, 1, bhm_code(0, true, false, false, 1), kN, kN, kN)

@@ -117,6 +117,10 @@ def main():
     SYN2.update({f"msphs{i}": (SQ.msphs(i, "syn2"), 12) for i in ("2k", "4k", "6k")})
     SYN2.update({f"msbs{i}": (SQ.msbs(i, "syn2"), 12) for i in ("2k", "4k", "6k")})
     SYN2.update({f"phm{i}": (SQ.phm(i, "syn2"), 12) for i in range(1, 7)})
+    # three measures by one key / by two keys (not in the reference's suite: the shape next to MSBS006-007)
+    _s3 = [Agg("sum", ColRef(c), "s" + c) for c in ("x10", "y10", "z10")]
+    SYN2["sum3"] = (QueryUnit("syn2", groupby=[ColRef("x1k")], targets=[KeyRef(0, "k"), Agg("count", None, "n")] + _s3), 16)
+    SYN2["sum3k2"] = (QueryUnit("syn2", groupby=[ColRef("x100"), ColRef("y100")], targets=[KeyRef(0, "k0"), KeyRef(1, "k1")] + _s3), 20)
     want2 = [k for k in SYN2 if k in only]
     cols2 = set()
     for k in want2:
