@@ -138,7 +138,7 @@ struct BhmArgs {
   // qvec == 2: where leaf qi's column comes from -- key column kk (kk), argument column s (kBhmMaxKeys + s): already in the
   // tile's registers; kBhmQualOwnLoad: its own 16-byte load
   int32_t qsrc[kMaxPlainQuals];
-  int32_t pad4_;
+  uint32_t plain_flags;    // BhmPlain: bits 3 i .. 3 i + 2 = argument i has a packed word / a MAX field / a MIN field
 };
 constexpr int32_t kBhmQualOwnLoad = 255;
 
@@ -162,6 +162,21 @@ struct BhmStatic {
   HDK_DEV static int step(const BhmArgs&, int i) { return static_cast<int>((code(i) >> 5) & 3u); }
   HDK_DEV static bool nulls(const BhmArgs&) { return NULLS; }
   HDK_DEV static int mm_bytes(const BhmArgs&) { return ((D0 | (D1 == kBhmNone ? 0 : D1) | (D2 == kBhmNone ? 0 : D2) | (D3 == kBhmNone ? 0 : D3)) & 24u) ? 4 : 0; }
+};
+// Between the two: AGGREGATES OF PLAIN COLUMNS -- argument i is column i as it is (no literal step), which of count-and-sum /
+// MAX / MIN it feeds is read at run time (BhmArgs::plain_flags, three bits an argument).  Every mix of count / sum / avg / min /
+// max over up to NS columns without the run-time form's scalar-register spills (its descriptors are a dozen words here).
+template <int NS_>
+struct BhmPlain {
+  static constexpr bool kSkips = true;
+  HDK_DEV static bool used(const BhmArgs&, int i) { return i < NS_; }
+  HDK_DEV static int src(const BhmArgs&, int i) { return i; }
+  HDK_DEV static bool packed(const BhmArgs& a, int i) { return ((a.plain_flags >> (3 * i)) & 1u) != 0; }
+  HDK_DEV static bool mx(const BhmArgs& a, int i) { return ((a.plain_flags >> (3 * i)) & 2u) != 0; }
+  HDK_DEV static bool mn(const BhmArgs& a, int i) { return ((a.plain_flags >> (3 * i)) & 4u) != 0; }
+  HDK_DEV static int step(const BhmArgs&, int) { return 0; }
+  HDK_DEV static bool nulls(const BhmArgs& a) { return a.any_nullable != 0; }
+  HDK_DEV static int mm_bytes(const BhmArgs& a) { return a.mm_bytes; }
 };
 struct BhmDynamic {
   static constexpr bool kSkips = true;

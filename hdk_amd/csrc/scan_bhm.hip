@@ -454,7 +454,7 @@ static bool match_bhm_part(const hdk_hip_plan* p, const hdk_hip_kernel_options* 
 }
 
 // ---- the instantiations (scan_bhm_shapes.h: the list; this file holds <4-byte columns, no filter> and pass B) ------------------
-HDK_BHM_DEFINE_KERNELS(4, false, HDK_BHM_SHAPE_FN_NULLS)
+HDK_BHM_DEFINE_KERNELS(4, false, HDK_BHM_SHAPE_FN_NULLS, HDK_BHM_PLAIN_BODY_YES)
 
 struct BhmStaticShape {
   int nk, ns;
@@ -493,7 +493,9 @@ static const void* bhm_sample_kernel_w(int nk) {
 static const void* bhm_sample_kernel(const BhmGeom& g) { return g.width == 8 ? bhm_sample_kernel_w<8>(g.nk) : bhm_sample_kernel_w<4>(g.nk); }
 
 // the argument descriptors as bhm_update wants them: over codes (column value - (minimum - 1)) instead of values
+static uint32_t bhm_plain_flags(const BhmArgs& a);
 static void bhm_shift_to_codes(BhmArgs* a) {
+  a->plain_flags = bhm_plain_flags(*a);
   for (int d = 0; d < a->nder; ++d) {
     BhmDer& der = a->der[d];
     const BhmSrc& src = a->src[der.src];
@@ -512,6 +514,18 @@ static uint32_t bhm_code_of(const BhmArgs& a, int i) {
   const BhmDer& d = a.der[i];
   if (d.mul != 1 && d.add != 0) return 0xFE;  // (column * literal + literal: never produced by the matcher)
   return bhm_code(d.src, d.packed >= 0, d.has_mx != 0, d.has_mn != 0, d.mul != 1 ? 2 : (d.add != 0 ? 1 : 0));
+}
+
+// argument i is column i as it is, for every argument: the flags BhmPlain reads (0: not that family)
+static uint32_t bhm_plain_flags(const BhmArgs& a) {
+  if (a.nder != a.nsrc) return 0;
+  uint32_t f = 0;
+  for (int i = 0; i < a.nder; ++i) {
+    const BhmDer& d = a.der[i];
+    if (d.src != i || d.mul != 1 || d.add != 0) return 0;
+    f |= ((d.packed >= 0 ? 1u : 0u) | (d.has_mx ? 2u : 0u) | (d.has_mn ? 4u : 0u)) << (3 * i);
+  }
+  return f;
 }
 
 // compile-time shape when there is one (every field inside 32 bits; with NULLs announced: the unfiltered quarters' twins), else the
@@ -536,6 +550,12 @@ static const void* bhm_kernel(const BhmArgs& a, const BhmGeom& g, bool* is_stati
       }
     }
   }
+  if (bhm_plain_flags(a) && !hdk_sw(SW_BHM_DYNAMIC)) {  // aggregates of plain columns (BhmPlain; the unfiltered quarters)
+    const void* k = bhm_by_quarter(
+        a, g, [&] { return BhmKernels<4, false>::plain(g.nk, g.ns, g.block); }, [&] { return BhmKernels<4, true>::plain(g.nk, g.ns, g.block); },
+        [&] { return BhmKernels<8, false>::plain(g.nk, g.ns, g.block); }, [&] { return BhmKernels<8, true>::plain(g.nk, g.ns, g.block); });
+    if (k) return k;
+  }
   return bhm_by_quarter(
       a, g, [&] { return BhmKernels<4, false>::dynamic(g.nk, g.ns, g.block); }, [&] { return BhmKernels<4, true>::dynamic(g.nk, g.ns, g.block); },
       [&] { return BhmKernels<8, false>::dynamic(g.nk, g.ns, g.block); }, [&] { return BhmKernels<8, true>::dynamic(g.nk, g.ns, g.block); });
@@ -547,6 +567,12 @@ static const void* bhm_aggregate_dynamic(int ns) {
                  : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 2, TW>)
                             : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmDynamic, 3, TW>));
 }
+template <int TW>
+static const void* bhm_aggregate_plain(int ns) {
+  return ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmPlain<1>, 1, TW>)
+                 : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmPlain<2>, 2, TW>)
+                            : reinterpret_cast<const void*>(hdk_bhm_aggregate<BhmPlain<3>, 3, TW>));
+}
 static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g, int tw) {
   if (a.mm_bytes != 8 && !hdk_sw(SW_BHM_DYNAMIC)) {
     for (const BhmStaticShape& sh : kBhmShapes) {
@@ -554,6 +580,9 @@ static const void* bhm_aggregate_kernel(const BhmArgs& a, const BhmGeom& g, int 
       for (int i = 0; same && i < kBhmMaxDer; ++i) same = sh.code[i] == bhm_code_of(a, i);
       if (same) return sh.aggregate(tw, a.any_nullable != 0);
     }
+  }
+  if (bhm_plain_flags(a) && !hdk_sw(SW_BHM_DYNAMIC)) {
+    return tw == 2 ? bhm_aggregate_plain<2>(g.ns) : bhm_aggregate_plain<4>(g.ns);
   }
   return tw == 2 ? bhm_aggregate_dynamic<2>(g.ns) : bhm_aggregate_dynamic<4>(g.ns);
 }

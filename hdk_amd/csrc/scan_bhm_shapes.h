@@ -26,6 +26,11 @@ static const void* bhm_dynamic_nk(int ns, int block) {
                  : (ns == 2 ? bhm_kernel_of<BhmDynamic, NK, 2, W, Q>(block) : bhm_kernel_of<BhmDynamic, NK, 3, W, Q>(block));
 }
 template <int NK, int W, bool Q>
+static const void* bhm_plain_nk(int ns, int block) {
+  return ns == 1 ? bhm_kernel_of<BhmPlain<1>, NK, 1, W, Q>(block)
+                 : (ns == 2 ? bhm_kernel_of<BhmPlain<2>, NK, 2, W, Q>(block) : bhm_kernel_of<BhmPlain<3>, NK, 3, W, Q>(block));
+}
+template <int NK, int W, bool Q>
 static const void* bhm_scatter_nk(int ns) {
   return ns == 1 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 1, W, Q>)
                  : (ns == 2 ? reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 2, W, Q>) : reinterpret_cast<const void*>(hdk_bhm_scatter<NK, 3, W, Q>));
@@ -58,13 +63,25 @@ template <int W, bool Q>
 struct BhmKernels {
   static const void* fixed(int shape_index, int block, bool nulls);  // BhmStatic (nullptr: no such instantiation)
   static const void* dynamic(int nk, int ns, int block);             // BhmDynamic
+  static const void* plain(int nk, int ns, int block);               // BhmPlain (nullptr: the filtered quarters have none)
   static const void* scatter(int nk, int ns);                        // pass A of the two-pass form
 };
 // (the NULL-carrying twins of the compile-time shapes exist for the unfiltered quarters: NULLS_TOO)
 #define HDK_BHM_SHAPE_FN(NK, NS, D0, D1, D2, D3) [](int b) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3, false>, NK, NS, kW, kQ>(b); },
 #define HDK_BHM_SHAPE_FN_NULLS(NK, NS, D0, D1, D2, D3) [](int b) -> const void* { return bhm_kernel_of<BhmStatic<D0, D1, D2, D3, true>, NK, NS, kW, kQ>(b); },
 #define HDK_BHM_SHAPE_FN_NONE(NK, NS, D0, D1, D2, D3) nullptr,
-#define HDK_BHM_DEFINE_KERNELS(W_, Q_, NULLS_FN)                                                                               \
+#define HDK_BHM_PLAIN_BODY_YES(W_, Q_) \
+  return nk == 1 ? bhm_plain_nk<1, W_, Q_>(ns, block) : (nk == 2 ? bhm_plain_nk<2, W_, Q_>(ns, block) : bhm_plain_nk<3, W_, Q_>(ns, block));
+#define HDK_BHM_PLAIN_BODY_NO(W_, Q_) \
+  (void)nk;                           \
+  (void)ns;                           \
+  (void)block;                        \
+  return nullptr;
+#define HDK_BHM_DEFINE_KERNELS(W_, Q_, NULLS_FN, PLAIN_BODY)                                                                   \
+  template <>                                                                                                                  \
+  const void* BhmKernels<W_, Q_>::plain(int nk, int ns, int block) {                                                           \
+    PLAIN_BODY(W_, Q_)                                                                                                         \
+  }                                                                                                                            \
   template <>                                                                                                                  \
   const void* BhmKernels<W_, Q_>::fixed(int shape_index, int block, bool nulls) {                                              \
     using Fn = const void* (*)(int);                                                                                           \
@@ -87,15 +104,19 @@ struct BhmKernels {
   }
 template <> const void* BhmKernels<4, false>::fixed(int, int, bool);
 template <> const void* BhmKernels<4, false>::dynamic(int, int, int);
+template <> const void* BhmKernels<4, false>::plain(int, int, int);
 template <> const void* BhmKernels<4, false>::scatter(int, int);
 template <> const void* BhmKernels<4, true>::fixed(int, int, bool);
 template <> const void* BhmKernels<4, true>::dynamic(int, int, int);
+template <> const void* BhmKernels<4, true>::plain(int, int, int);
 template <> const void* BhmKernels<4, true>::scatter(int, int);
 template <> const void* BhmKernels<8, false>::fixed(int, int, bool);
 template <> const void* BhmKernels<8, false>::dynamic(int, int, int);
+template <> const void* BhmKernels<8, false>::plain(int, int, int);
 template <> const void* BhmKernels<8, false>::scatter(int, int);
 template <> const void* BhmKernels<8, true>::fixed(int, int, bool);
 template <> const void* BhmKernels<8, true>::dynamic(int, int, int);
+template <> const void* BhmKernels<8, true>::plain(int, int, int);
 template <> const void* BhmKernels<8, true>::scatter(int, int);
 
 }  // namespace hdk

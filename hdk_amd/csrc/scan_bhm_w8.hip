@@ -5,6 +5,6 @@
 
 namespace hdk {
 
-HDK_BHM_DEFINE_KERNELS(8, false, HDK_BHM_SHAPE_FN_NULLS)
+HDK_BHM_DEFINE_KERNELS(8, false, HDK_BHM_SHAPE_FN_NULLS, HDK_BHM_PLAIN_BODY_YES)
 
 }  // namespace hdk

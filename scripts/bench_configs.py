@@ -121,6 +121,10 @@ def main():
     _s3 = [Agg("sum", ColRef(c), "s" + c) for c in ("x10", "y10", "z10")]
     SYN2["sum3"] = (QueryUnit("syn2", groupby=[ColRef("x1k")], targets=[KeyRef(0, "k"), Agg("count", None, "n")] + _s3), 16)
     SYN2["sum3k2"] = (QueryUnit("syn2", groupby=[ColRef("x100"), ColRef("y100")], targets=[KeyRef(0, "k0"), KeyRef(1, "k1")] + _s3), 20)
+    # a mix no compile-time shape covers: the "aggregates of plain columns" policy (BhmPlain) against the run-time form
+    SYN2["mix3"] = (QueryUnit("syn2", groupby=[ColRef("x1k")], targets=[KeyRef(0, "k"), Agg("count", None, "n"), Agg("sum", ColRef("x10"), "s"),
+                                                                        Agg("max", ColRef("y10"), "mx"), Agg("min", ColRef("z10"), "mn"),
+                                                                        Agg("avg", ColRef("z10"), "av")]), 16)
     want2 = [k for k in SYN2 if k in only]
     cols2 = set()
     for k in want2:
