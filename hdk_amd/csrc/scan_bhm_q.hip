@@ -5,6 +5,6 @@
 
 namespace hdk {
 
-HDK_BHM_DEFINE_KERNELS(4, true, HDK_BHM_SHAPE_FN_NONE, HDK_BHM_PLAIN_BODY_NO)
+HDK_BHM_DEFINE_KERNELS(4, true, HDK_BHM_SHAPE_FN_NONE, HDK_BHM_PLAIN_BODY_YES)
 
 }  // namespace hdk

@@ -125,11 +125,12 @@ def main():
     SYN2["mix3"] = (QueryUnit("syn2", groupby=[ColRef("x1k")], targets=[KeyRef(0, "k"), Agg("count", None, "n"), Agg("sum", ColRef("x10"), "s"),
                                                                         Agg("max", ColRef("y10"), "mx"), Agg("min", ColRef("z10"), "mn"),
                                                                         Agg("avg", ColRef("z10"), "av")]), 16)
+    SYN2["mix3f"] = (QueryUnit("syn2", quals=[Cmp(ColRef("x100"), "<", Lit(71))], groupby=SYN2["mix3"][0].groupby, targets=SYN2["mix3"][0].targets), 20)
     want2 = [k for k in SYN2 if k in only]
     cols2 = set()
     for k in want2:
         q2 = SYN2[k][0]
-        for e in list(q2.groupby) + [t.arg for t in q2.targets if getattr(t, "arg", None) is not None]:
+        for e in list(q2.groupby) + [t.arg for t in q2.targets if getattr(t, "arg", None) is not None] + [c.lhs for c in q2.quals if hasattr(c, "lhs")]:
             stack = [e]
             while stack:
                 x = stack.pop()
